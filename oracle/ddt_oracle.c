@@ -1,0 +1,407 @@
+/*
+ * ddt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code; see ddt_oracle.h).
+ *
+ * *** PARITY UNPINNED ***: the reference (FPGA RTL) has no tests/golden vectors and cannot be run
+ * here.  This file restates the RTL's scoring semantics; each function cites the lines it follows.
+ * All paths below are relative to /root/reference/rtl/DTEngine/.
+ */
+#include "ddt_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* =============================================================================================
+ * 1. The reference's fp32 adder: FloPoCo FPAdder_8_23 (common/FPAdder_2cycles_latency.v:210-387)
+ *    modelled at bit level on the 34-bit FloPoCo word.
+ * ============================================================================================= */
+
+#define EXC(w)  ((uint32_t)(((w) >> 32) & 3u))
+#define SGN(w)  ((uint32_t)(((w) >> 31) & 1u))
+#define EXPF(w) ((uint32_t)(((w) >> 23) & 0xFFu))
+#define FRAC(w) ((uint32_t)((w) & 0x7FFFFFu))
+
+/* Wrapper used at every adder input that comes from a raw 32-bit word: exception field = {0, |bits}
+ * (core/FPAddersReduceTree.sv:94-95, core/FPAggregator.v:124, ResultsCombiner.sv:295-296). */
+uint64_t orc_fp34_wrap(uint32_t bits) { return ((uint64_t)(bits != 0u) << 32) | bits; }
+
+/* Exception 00 forces the 32-bit output to +0 (FPAddersReduceTree.sv:141, FPAggregator.v:107-112). */
+uint32_t orc_fp34_unwrap(uint64_t w) { return EXC(w) == 0u ? 0u : (uint32_t)w; }
+
+uint64_t orc_fp34_add(uint64_t X, uint64_t Y) {
+  /* exponent difference and swap (FPAdder...v:296-303): order by {exc, exp, frac} */
+  const uint64_t keyX = ((uint64_t)EXC(X) << 31) | (X & 0x7FFFFFFFu);
+  const uint64_t keyY = ((uint64_t)EXC(Y) << 31) | (Y & 0x7FFFFFFFu);
+  const int swap = keyX < keyY;
+  const uint64_t nX = swap ? Y : X, nY = swap ? X : Y;
+  const uint32_t expX = EXPF(nX), excX = EXC(nX), excY = EXC(nY);
+  const uint32_t sX = SGN(nX), sY = SGN(nY);
+  const uint32_t effSub = sX ^ sY; /* :308 */
+
+  /* exception of the result from the operands' exceptions (:313-320) */
+  uint32_t excRt;
+  const uint32_t ee = (excX << 2) | excY;
+  if (ee == 0x0) excRt = 0;                                   /* zero + zero                 */
+  else if (ee == 0x5 || ee == 0x4 || ee == 0x1) excRt = 1;    /* normal/zero mixes           */
+  else if (ee == 0xA) excRt = (sX == sY) ? 2u : 3u;           /* inf+inf: same sign inf, else NaN */
+  else if (ee == 0x8 || ee == 0x2 || ee == 0x9 || ee == 0x6) excRt = 2; /* inf with zero/normal */
+  else excRt = 3;                                             /* anything with NaN           */
+  /* sign: (+0)+(-0) in either order gives +0, otherwise sign of the larger operand (:322) */
+  const uint32_t signR = (ee == 0x0 && sX != sY) ? 0u : sX;
+
+  /* alignment (:324-330): 9-bit exponent difference of the swapped operands */
+  const uint32_t expDiff = (expX - EXPF(nY)) & 0x1FFu;
+  const int shiftedOut = expDiff >= 25u;
+  const uint32_t shiftVal = shiftedOut ? 26u : (expDiff & 31u);
+  const uint32_t fracY = (excY == 0u) ? 0u : (0x800000u | FRAC(nY)); /* :311 */
+  const uint64_t shifted = (((uint64_t)fracY) << 26) >> shiftVal;    /* 50-bit RightShifter (:31-59) */
+
+  /* far-path add with sticky (:333-344) */
+  const uint32_t sticky = (shifted & 0xFFFFFFu) != 0u;
+  uint32_t fracYfar = (uint32_t)((shifted >> 24) & 0x3FFFFFFu);      /* 27 bits with a leading 0 */
+  if (effSub) fracYfar = (~fracYfar) & 0x7FFFFFFu;
+  const uint32_t fracXfar = (1u << 25) | (FRAC(nX) << 2);            /* {01, frac, 00} */
+  const uint32_t cin = effSub & (sticky ^ 1u);
+  const uint32_t fracAdd = (fracXfar + fracYfar + cin) & 0x7FFFFFFu;
+  uint32_t I = (fracAdd << 1) | sticky;                              /* fracGRS, 28 bits */
+  const uint32_t extExpInc = expX + 1u;                              /* 10 bits */
+
+  /* leading-zero count + normalise (LZCShifter_28_to_28_counting_32, :126-171) */
+  const uint32_t M28 = 0xFFFFFFFu;
+  uint32_t c4 = ((I >> 12) & 0xFFFFu) == 0u; if (c4) I = (I << 16) & M28;
+  uint32_t c3 = ((I >> 20) & 0xFFu) == 0u;   if (c3) I = (I << 8) & M28;
+  uint32_t c2 = ((I >> 24) & 0xFu) == 0u;    if (c2) I = (I << 4) & M28;
+  uint32_t c1 = ((I >> 26) & 0x3u) == 0u;    if (c1) I = (I << 2) & M28;
+  uint32_t c0 = ((I >> 27) & 0x1u) == 0u;    if (c0) I = (I << 1) & M28;
+  const uint32_t nZeros = (c4 << 4) | (c3 << 3) | (c2 << 2) | (c1 << 1) | c0;
+  const uint32_t updatedExp = (extExpInc - nZeros) & 0x3FFu;         /* :348 */
+  const int eqdiffsign = nZeros == 31u;                              /* :349 */
+
+  /* round to nearest even (:350-366) */
+  const uint64_t expFrac = ((uint64_t)updatedExp << 24) | ((I >> 3) & 0xFFFFFFu);
+  const uint32_t stk = (I & 3u) != 0u, rnd = (I >> 2) & 1u, grd = (I >> 3) & 1u, lsb = (I >> 4) & 1u;
+  const uint32_t addToRound = !(lsb == 0u && grd == 1u && rnd == 0u && stk == 0u);
+  const uint64_t rounded = (expFrac + addToRound) & 0x3FFFFFFFFull;
+  const uint32_t upExc = (uint32_t)((rounded >> 32) & 3u);
+  const uint32_t fracR = (uint32_t)((rounded >> 1) & 0x7FFFFFu);
+  const uint32_t expR = (uint32_t)((rounded >> 24) & 0xFFu);
+
+  /* exponent overflow/underflow folded into the exception field (:372-385) */
+  uint32_t excRt2;
+  if (excRt == 0u) excRt2 = 0;                                  /* 0000,0100,1000,1100 */
+  else if (excRt == 1u) excRt2 = (upExc == 0u) ? 1u : (upExc == 1u) ? 2u : 0u; /* ok / overflow->inf / underflow->zero */
+  else if (excRt == 2u) excRt2 = (upExc <= 1u) ? 2u : 3u;       /* 0010,0110 -> inf, else NaN */
+  else excRt2 = 3;
+  const uint32_t excR = (eqdiffsign && effSub) ? 0u : excRt2;   /* exact cancellation -> zero */
+  return ((uint64_t)excR << 32) | ((uint64_t)signR << 31) | ((uint64_t)expR << 23) | fracR;
+}
+
+uint32_t orc_fpadd_bits(uint32_t a, uint32_t b) {
+  return orc_fp34_unwrap(orc_fp34_add(orc_fp34_wrap(a), orc_fp34_wrap(b)));
+}
+
+void orc_fpadd_bits_batch(const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+  for (size_t i = 0; i < n; ++i) out[i] = orc_fpadd_bits(a[i], b[i]);
+}
+
+/* =============================================================================================
+ * 2. Wire format (A2: little-endian word packing, core/PipelinedMUX.sv:65)
+ * ============================================================================================= */
+
+uint32_t orc_weights_lines_per_tree(uint32_t D) { return (uint32_t)((((1ull << (D + 1)) - 1) + 3) / 4); }
+uint32_t orc_findex_lines_per_tree(uint32_t D) { return (uint32_t)((((1ull << D) - 1) + 7) / 8); }
+uint32_t orc_tuple_lines(uint32_t F) { return (F + 3) / 4; }
+
+void orc_pack_model(uint32_t T, uint32_t D, const uint32_t* thr_bits, const uint16_t* fidx,
+                    const uint8_t* miss_right, const uint32_t* leaf_bits, uint32_t* wlines,
+                    uint16_t* flines) {
+  const uint32_t nint = (1u << D) - 1u, nleaf = 1u << D;
+  const uint32_t wstride = orc_weights_lines_per_tree(D) * 4u, fstride = orc_findex_lines_per_tree(D) * 8u;
+  memset(wlines, 0, (size_t)T * wstride * sizeof(uint32_t));
+  memset(flines, 0, (size_t)T * fstride * sizeof(uint16_t));
+  for (uint32_t i = 0; i < T; ++i) {
+    uint32_t* w = wlines + (size_t)i * wstride;
+    uint16_t* f = flines + (size_t)i * fstride;
+    for (uint32_t n = 0; n < nint; ++n) {
+      w[n] = thr_bits[(size_t)i * nint + n];
+      /* entry layout DTPU.sv:628,637,659: [10:0] feature index, [13] missing-goes-right */
+      f[n] = (uint16_t)((fidx[(size_t)i * nint + n] & 0x7FFu) | ((miss_right[(size_t)i * nint + n] & 1u) << 13));
+    }
+    for (uint32_t l = 0; l < nleaf; ++l) w[nint + l] = leaf_bits[(size_t)i * nleaf + l];
+  }
+}
+
+/* =============================================================================================
+ * 3. Traversal (core/DTPU.sv:579-760)
+ * ============================================================================================= */
+
+static inline int orc_is_nan_bits(uint32_t b) { return (b & 0x7FFFFFFFu) > 0x7F800000u; }
+
+static inline int orc_less(uint32_t f, uint32_t w, uint32_t cmp_mode) {
+  if (cmp_mode == 0u) {
+    /* DTPU.sv:655: {~f[31],f} < {~w[31],w} as 33-bit unsigned == signed int32 compare of raw bits */
+    return (int32_t)f < (int32_t)w;
+  }
+  /* cmp_mode 1 (this repo's extension): IEEE-754 binary32 '<' (false if either is NaN, -0 == +0) */
+  if (orc_is_nan_bits(f) || orc_is_nan_bits(w)) return 0;
+  float a, b;
+  memcpy(&a, &f, 4);
+  memcpy(&b, &w, 4);
+  return a < b;
+}
+
+uint32_t orc_traverse(const orc_params* p, const uint32_t* weights_lines, const uint16_t* findex_lines,
+                      const uint32_t* tuple, uint32_t tree) {
+  /* stride = lines/tree (the published RTL's off-by-one stride quirk is NOT replicated) */
+  const uint32_t* w = weights_lines + (size_t)tree * p->weights_lines_per_tree * 4u;
+  const uint16_t* fi = findex_lines + (size_t)tree * p->findex_lines_per_tree * 8u;
+  uint32_t n = 0; /* root, DTPU.sv:582 */
+  for (uint32_t lvl = 0; lvl < p->num_levels; ++lvl) { /* level counter 0..LastLevelIndex, :588,663 */
+    const uint16_t e = fi[n];
+    const uint32_t j = e & 0x7FFu;                      /* :628 */
+    const uint32_t miss_right = (e >> 13) & 1u;         /* :659 (bit 13)  */
+    const uint32_t f = tuple[j], thr = w[n];
+    uint32_t right;
+    if (f == p->missing_bits) right = miss_right;       /* :653,667 bit-equality with MissingFeatureValue */
+    else right = !orc_less(f, thr, p->cmp_mode);        /* :655-657 */
+    n = 2u * n + 1u + right;                            /* :594-596,710-712 */
+  }
+  return w[n];                                          /* leaf read through port B, :731-732 */
+}
+
+void orc_leaves(const orc_params* p, const uint32_t* weights_lines, const uint16_t* findex_lines,
+                const uint32_t* tuple, uint32_t* leaves) {
+  for (uint32_t i = 0; i < p->num_trees; ++i) leaves[i] = orc_traverse(p, weights_lines, findex_lines, tuple, i);
+}
+
+/* =============================================================================================
+ * 4. Reference-order reduction (one device)
+ *    tree i (local stream order) -> PU i%8 (Core.sv:352-357), group g=i/8 -> cluster g%C, slot g/C
+ *    (Core.sv:291-304, RLS.v:41-52).  Per cluster: for slot t: s_t = 8-way pairwise tree over PUs
+ *    (FPAddersReduceTree.sv:94-141), acc <- s_t + acc (FPAggregator.v:95-131).  Then the cluster
+ *    results are accumulated sequentially c = 0..C-1 by the same module (Core.sv:486-541).
+ * ============================================================================================= */
+
+static inline float f_from(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
+static inline uint32_t b_from(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
+
+static uint32_t reduce_flopoco(const uint32_t* leaves, uint32_t T, uint32_t C) {
+  const uint32_t groups = (T + 7u) / 8u;
+  const uint32_t slots = (groups + C - 1u) / C; /* trees per PU (CSR205[43:36]); extra slots are EMPTY */
+  uint64_t acc[8];
+  for (uint32_t c = 0; c < C; ++c) acc[c] = 0; /* prev_aggreg_value reset, FPAggregator.v:83 */
+  for (uint32_t t = 0; t < slots; ++t) {
+    for (uint32_t c = 0; c < C; ++c) {
+      const uint32_t g = t * C + c;
+      uint64_t l[8];
+      for (uint32_t pu = 0; pu < 8; ++pu) {
+        const uint32_t i = g * 8u + pu;
+        l[pu] = orc_fp34_wrap(i < T ? leaves[i] : 0u); /* EMPTY slot outputs 0, DTPU.sv:760 */
+      }
+      const uint64_t a0 = orc_fp34_add(l[0], l[1]), a1 = orc_fp34_add(l[2], l[3]);
+      const uint64_t a2 = orc_fp34_add(l[4], l[5]), a3 = orc_fp34_add(l[6], l[7]);
+      const uint64_t b0 = orc_fp34_add(a0, a1), b1 = orc_fp34_add(a2, a3);
+      const uint32_t s = orc_fp34_unwrap(orc_fp34_add(b0, b1)); /* tree_out, :141 */
+      acc[c] = orc_fp34_add(orc_fp34_wrap(s), acc[c]);           /* X = new, Y = running, FPAggregator.v:124-131 */
+    }
+  }
+  uint64_t tot = 0;
+  for (uint32_t c = 0; c < C; ++c) tot = orc_fp34_add(orc_fp34_wrap(orc_fp34_unwrap(acc[c])), tot);
+  return orc_fp34_unwrap(tot);
+}
+
+static uint32_t reduce_native(const uint32_t* leaves, uint32_t T, uint32_t C) {
+  const uint32_t groups = (T + 7u) / 8u;
+  const uint32_t slots = (groups + C - 1u) / C;
+  volatile float acc[8]; /* volatile: forbid re-association / contraction by the host compiler */
+  for (uint32_t c = 0; c < C; ++c) acc[c] = 0.0f;
+  for (uint32_t t = 0; t < slots; ++t) {
+    for (uint32_t c = 0; c < C; ++c) {
+      const uint32_t g = t * C + c;
+      float l[8];
+      for (uint32_t pu = 0; pu < 8; ++pu) {
+        const uint32_t i = g * 8u + pu;
+        l[pu] = i < T ? f_from(leaves[i]) : 0.0f;
+      }
+      volatile float a0 = l[0] + l[1], a1 = l[2] + l[3], a2 = l[4] + l[5], a3 = l[6] + l[7];
+      volatile float b0 = a0 + a1, b1 = a2 + a3;
+      volatile float s = b0 + b1;
+      acc[c] = s + acc[c];
+    }
+  }
+  volatile float tot = 0.0f;
+  for (uint32_t c = 0; c < C; ++c) tot = acc[c] + tot;
+  return b_from(tot);
+}
+
+uint32_t orc_reduce_device(const uint32_t* leaves, uint32_t num_trees, uint32_t C, int flopoco) {
+  return flopoco ? reduce_flopoco(leaves, num_trees, C) : reduce_native(leaves, num_trees, C);
+}
+
+/* =============================================================================================
+ * 5. Batch scoring
+ * ============================================================================================= */
+
+int orc_hw_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static int check_params(const orc_params* p, size_t n_wlines, size_t n_flines) {
+  if (!p || p->num_trees == 0 || p->num_levels == 0 || p->num_levels > 16 || p->num_features == 0 ||
+      p->num_features > 2048)
+    return -1;
+  if (p->clusters_per_tuple != 1 && p->clusters_per_tuple != 2 && p->clusters_per_tuple != 4 &&
+      p->clusters_per_tuple != 8)
+    return -1;
+  if (p->weights_lines_per_tree < orc_weights_lines_per_tree(p->num_levels)) return -2;
+  if (p->findex_lines_per_tree < orc_findex_lines_per_tree(p->num_levels)) return -2;
+  if (n_wlines < (size_t)p->num_trees * p->weights_lines_per_tree) return -3;
+  if (n_flines < (size_t)p->num_trees * p->findex_lines_per_tree) return -3;
+  return 0;
+}
+
+static uint32_t shard_sum(const uint32_t* leaves, uint32_t n, uint32_t C, int sum_mode) {
+  if (sum_mode == ORC_SUM_REF_FLOPOCO) return reduce_flopoco(leaves, n, C);
+  if (sum_mode == ORC_SUM_REF_NATIVE) return reduce_native(leaves, n, C);
+  double a = 0.0; /* ORC_SUM_F64_SEQ */
+  for (uint32_t i = 0; i < n; ++i) a += (double)f_from(leaves[i]);
+  return b_from((float)a);
+}
+
+int orc_score_shard(const orc_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines,
+                    const void* tl, size_t n_tuples, uint32_t tree_begin, uint32_t tree_end, float* out,
+                    int sum_mode, int nthreads) {
+  int rc = check_params(p, n_wlines, n_flines);
+  if (rc) return rc;
+  if (tree_begin > tree_end || tree_end > p->num_trees) return -4;
+  const uint32_t* w = (const uint32_t*)wl;
+  const uint16_t* f = (const uint16_t*)fl;
+  const uint32_t* t = (const uint32_t*)tl;
+  const uint32_t tw = orc_tuple_lines(p->num_features) * 4u, nloc = tree_end - tree_begin;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    uint32_t* leaves = (uint32_t*)malloc(sizeof(uint32_t) * (nloc ? nloc : 1));
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (long long r = 0; r < (long long)n_tuples; ++r) {
+      const uint32_t* x = t + (size_t)r * tw;
+      for (uint32_t i = 0; i < nloc; ++i) leaves[i] = orc_traverse(p, w, f, x, tree_begin + i);
+      out[r] = f_from(shard_sum(leaves, nloc, p->clusters_per_tuple, sum_mode));
+    }
+    free(leaves);
+  }
+  (void)nthreads;
+  return 0;
+}
+
+int orc_score(const orc_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines,
+              const void* tl, size_t n_tuples, float* out, double* gold, int sum_mode, int n_devices,
+              int nthreads) {
+  int rc = check_params(p, n_wlines, n_flines);
+  if (rc) return rc;
+  if (n_devices < 1 || (uint32_t)n_devices > p->num_trees) return -5;
+  const uint32_t* w = (const uint32_t*)wl;
+  const uint16_t* f = (const uint16_t*)fl;
+  const uint32_t* t = (const uint32_t*)tl;
+  const uint32_t T = p->num_trees, tw = orc_tuple_lines(p->num_features) * 4u;
+  const uint32_t per_dev = (T + (uint32_t)n_devices - 1u) / (uint32_t)n_devices; /* PCIeReceiver.sv:241-264 */
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    uint32_t* leaves = (uint32_t*)malloc(sizeof(uint32_t) * T);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (long long r = 0; r < (long long)n_tuples; ++r) {
+      const uint32_t* x = t + (size_t)r * tw;
+      for (uint32_t i = 0; i < T; ++i) leaves[i] = orc_traverse(p, w, f, x, i);
+      /* chain reduce host -> dev1 -> ...: each hop adds local + upstream (ResultsCombiner.sv:292-311) */
+      uint32_t run = 0;
+      for (int d = 0; d < n_devices; ++d) {
+        const uint32_t b = (uint32_t)d * per_dev, e = (b + per_dev < T) ? b + per_dev : T;
+        const uint32_t part = (b < e) ? shard_sum(leaves + b, e - b, p->clusters_per_tuple, sum_mode) : 0u;
+        if (d == 0) run = part;
+        else if (sum_mode == ORC_SUM_REF_FLOPOCO) run = orc_fpadd_bits(part, run);
+        else { volatile float s = f_from(part) + f_from(run); run = b_from(s); }
+      }
+      out[r] = f_from(run);
+      if (gold) {
+        double a = 0.0;
+        for (uint32_t i = 0; i < T; ++i) a += (double)f_from(leaves[i]);
+        gold[r] = a;
+      }
+    }
+    free(leaves);
+  }
+  (void)nthreads;
+  return 0;
+}
+
+/* =============================================================================================
+ * 6. Deterministic synthetic inputs
+ * ============================================================================================= */
+
+#define SEED_X 0x0DD7000000000001ull
+#define SEED_M 0x0DD7000000000002ull
+
+uint64_t orc_splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static inline float unit24(uint64_t h) { return (float)(h >> 40) * (1.0f / 16777216.0f); }
+
+void orc_gen_tuples(uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits, uint32_t* out) {
+  const uint32_t tw = orc_tuple_lines(F) * 4u;
+  for (size_t r = 0; r < n; ++r) {
+    uint32_t* x = out + r * tw;
+    for (uint32_t j = 0; j < tw; ++j) x[j] = 0u;
+    for (uint32_t j = 0; j < F; ++j) {
+      const uint64_t h = orc_splitmix64(SEED_X + (row0 + r) * (uint64_t)F + j);
+      float v = unit24(h);
+      if (dist == 1) {
+        v = v * 2.0f - 1.0f;
+        if (((h >> 8) & 0xFFFFu) % 20u == 0u) { x[j] = missing_bits; continue; }
+      }
+      x[j] = b_from(v);
+    }
+  }
+}
+
+void orc_gen_model(uint32_t T, uint32_t D, uint32_t F, int dist, uint32_t* wlines, uint16_t* flines) {
+  const uint32_t nint = (1u << D) - 1u, ntot = (1u << (D + 1)) - 1u;
+  const uint32_t wstride = orc_weights_lines_per_tree(D) * 4u, fstride = orc_findex_lines_per_tree(D) * 8u;
+  memset(wlines, 0, (size_t)T * wstride * sizeof(uint32_t));
+  memset(flines, 0, (size_t)T * fstride * sizeof(uint16_t));
+  for (uint32_t i = 0; i < T; ++i) {
+    for (uint32_t n = 0; n < ntot; ++n) {
+      const uint64_t g = (uint64_t)i * (1ull << (D + 1)) + n;
+      const float u = unit24(orc_splitmix64(SEED_M + 3ull * g + 1ull));
+      if (n < nint) {
+        const uint32_t fidx = (uint32_t)(orc_splitmix64(SEED_M + 3ull * g) % F);
+        const uint32_t mr = (uint32_t)(orc_splitmix64(SEED_M + 3ull * g + 2ull) & 1ull);
+        const float thr = dist == 1 ? u * 2.0f - 1.0f : u;
+        wlines[(size_t)i * wstride + n] = b_from(thr);
+        flines[(size_t)i * fstride + n] = (uint16_t)(fidx | (mr << 13));
+      } else {
+        volatile float c = u - 0.5f;
+        volatile float v = c * 0.2f;
+        wlines[(size_t)i * wstride + n] = b_from(v);
+      }
+    }
+  }
+}

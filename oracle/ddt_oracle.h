@@ -1,0 +1,113 @@
+/*
+ * ddt_oracle.h -- CPU ORACLE for the tree-ensemble scoring hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it, and only as the checker /
+ * the reported CPU baseline.  The product (libddt.so) never links, loads or calls this code.
+ *
+ * What it is: a plain-C restatement of the scoring semantics of the FPGA reference
+ * (fpgasystems/Distributed-DecisionTrees, RTL under rtl/DTEngine/).  Every function cites the
+ * reference file:line it follows.  The reference is hardware only (no host software, no CPU
+ * scorer, no tests, no golden vectors) and cannot be simulated in this environment (no Verilog
+ * simulator, vendor IP missing), so:
+ *
+ *      *** PARITY UNPINNED ***  -- there is nothing in the reference to pin this oracle against.
+ *
+ * Mitigations (tests/test_oracle_*.py): hand-computed known-answer tests for every rule, a
+ * bit-level model of the reference's FloPoCo fp32 adder cross-checked against IEEE-754 hardware
+ * adds on normal operands, and an independent cross-check of the traversal against scikit-learn.
+ */
+#ifndef DDT_ORACLE_H
+#define DDT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Run parameters == the reference's CSR 204/205 fields (rtl/DTEngine/EngineCSR.sv:218-233). */
+typedef struct orc_params {
+  uint32_t num_trees;              /* real trees in the stream (slots beyond are EMPTY, DTPU.sv:544,760) */
+  uint32_t num_levels;             /* D = compare levels per tree, CSR205[35:32]                     */
+  uint32_t num_features;           /* F; tuple lines = ceil(F/4), CSR204[63:48]                      */
+  uint32_t missing_bits;           /* CSR205[31:0] (DTPU.sv:445,653)                                 */
+  uint32_t weights_lines_per_tree; /* CSR204[31:16]; >= ceil((2^(D+1)-1)/4)                          */
+  uint32_t findex_lines_per_tree;  /* CSR204[47:32]; >= ceil((2^D-1)/8)                              */
+  uint32_t cmp_mode;               /* 0 = reference int32-bit-pattern compare (DTPU.sv:655), 1 = IEEE '<' */
+  uint32_t clusters_per_tuple;     /* C in {1,2,4,8}, CSR205[47:44] (Core.sv:305-316,486-541)        */
+} orc_params;
+
+/* Summation modes for orc_score(). */
+enum {
+  ORC_SUM_REF_FLOPOCO = 0, /* reference order, bit-level FloPoCo adder model (normative)            */
+  ORC_SUM_REF_NATIVE  = 1, /* reference order, host IEEE fp32 adds (== mode 0 on normal values)     */
+  ORC_SUM_F64_SEQ     = 2, /* fp64 sequential over trees in stream order, rounded once to fp32      */
+};
+
+/* ---- fp32 adder of the reference ------------------------------------------------------------ */
+/* 34-bit FloPoCo word: [33:32] exception (00 zero, 01 normal, 10 inf, 11 NaN), [31] sign,
+ * [30:23] exponent, [22:0] fraction.  common/FPAdder_2cycles_latency.v:210-387. */
+uint64_t orc_fp34_wrap(uint32_t bits);            /* {1'b0, |bits, bits}: FPAddersReduceTree.sv:94-95 */
+uint32_t orc_fp34_unwrap(uint64_t w);             /* exc==00 ? 0 : w[31:0]: FPAddersReduceTree.sv:141 */
+uint64_t orc_fp34_add(uint64_t x, uint64_t y);    /* FPAdder_8_23_uid2_l2                            */
+uint32_t orc_fpadd_bits(uint32_t a, uint32_t b);  /* unwrap(add(wrap(a), wrap(b)))                   */
+void orc_fpadd_bits_batch(const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n);
+
+/* ---- traversal ------------------------------------------------------------------------------- */
+/* One (tuple, tree) walk.  tuple = F_pad fp32 words (F padded to a multiple of 4, A2 packing).
+ * Returns the raw bits of the selected leaf.  DTPU.sv:579-760. */
+uint32_t orc_traverse(const orc_params* p, const uint32_t* weights_lines, const uint16_t* findex_lines,
+                      const uint32_t* tuple, uint32_t tree);
+
+/* Leaf bits of every tree for one tuple (leaves[num_trees]). */
+void orc_leaves(const orc_params* p, const uint32_t* weights_lines, const uint16_t* findex_lines,
+                const uint32_t* tuple, uint32_t* leaves);
+
+/* Reference-order reduction of per-tree leaf bits for ONE device (DTPUCluster.sv:188-201,
+ * FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131, Core.sv:486-541).  flopoco!=0 uses the
+ * bit-level adder model, else host IEEE adds. */
+uint32_t orc_reduce_device(const uint32_t* leaves, uint32_t num_trees, uint32_t clusters_per_tuple,
+                           int flopoco);
+
+/* Score n tuples.  tuple_lines: n * ceil(F/4) lines of 16 B (row-major fp32, zero padded).
+ * n_devices >= 1 models the tree-sharded multi-FPGA mode: trees are split into contiguous shards of
+ * ceil(T/n_devices) trees (PCIeReceiver.sv:241-264), each device reduces its shard in reference order,
+ * and the partials are chain-added host -> dev1 -> ... (ResultsCombiner.sv:292-311,359-369).
+ * out[n] receives fp32 scores; gold[n] (optional, may be NULL) receives the exact-ish fp64 sum.
+ * nthreads <= 0 -> all hardware threads (OpenMP).  Returns 0, or <0 on bad parameters. */
+int orc_score(const orc_params* p, const void* weights_lines, size_t n_wlines,
+              const void* findex_lines, size_t n_flines, const void* tuple_lines, size_t n_tuples,
+              float* out, double* gold, int sum_mode, int n_devices, int nthreads);
+
+/* Partial (per-shard) scores: trees [tree_begin, tree_end) only, reduced as one device. */
+int orc_score_shard(const orc_params* p, const void* weights_lines, size_t n_wlines,
+                    const void* findex_lines, size_t n_flines, const void* tuple_lines, size_t n_tuples,
+                    uint32_t tree_begin, uint32_t tree_end, float* out, int sum_mode, int nthreads);
+
+/* ---- wire-format helpers (A2 packing, PipelinedMUX.sv:65) ------------------------------------ */
+uint32_t orc_weights_lines_per_tree(uint32_t num_levels); /* ceil((2^(D+1)-1)/4) */
+uint32_t orc_findex_lines_per_tree(uint32_t num_levels);  /* ceil((2^D-1)/8)     */
+uint32_t orc_tuple_lines(uint32_t num_features);          /* ceil(F/4)           */
+
+/* Build the two model streams from plain arrays.  thr/fidx/miss_right: [T][2^D-1] heap order,
+ * leaves: [T][2^D].  wlines: T*wlpt*4 words, flines: T*flpt*8 u16, both zero padded. */
+void orc_pack_model(uint32_t T, uint32_t D, const uint32_t* thr_bits, const uint16_t* fidx,
+                    const uint8_t* miss_right, const uint32_t* leaf_bits, uint32_t* wlines,
+                    uint16_t* flines);
+
+/* ---- deterministic synthetic inputs --------------------------------- */
+uint64_t orc_splitmix64(uint64_t x);
+/* rows [row0, row0+n) of the benchmark tuple matrix, as tuple lines (ceil(F/4)*4 words per row).
+ * dist 0: uniform [0,1) no missing (benchmark); dist 1: uniform [-1,1) with ~5% missing_bits. */
+void orc_gen_tuples(uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits, uint32_t* out);
+/* synthetic model streams; dist as above (dist 1: thresholds in [-1,1)). */
+void orc_gen_model(uint32_t T, uint32_t D, uint32_t F, int dist, uint32_t* wlines, uint16_t* flines);
+
+int orc_hw_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

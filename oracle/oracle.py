@@ -1,0 +1,207 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU ORACLE (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module, and only
+as the checker / the reported CPU baseline.  PARITY UNPINNED: the reference (FPGA RTL) ships no tests
+or golden vectors and cannot be simulated here; see oracle/ddt_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+SUM_REF_FLOPOCO, SUM_REF_NATIVE, SUM_F64_SEQ = 0, 1, 2
+
+
+class Params(C.Structure):
+    """Mirror of orc_params (== the reference's CSR 204/205 fields, EngineCSR.sv:218-233)."""
+
+    _fields_ = [
+        ("num_trees", C.c_uint32),
+        ("num_levels", C.c_uint32),
+        ("num_features", C.c_uint32),
+        ("missing_bits", C.c_uint32),
+        ("weights_lines_per_tree", C.c_uint32),
+        ("findex_lines_per_tree", C.c_uint32),
+        ("cmp_mode", C.c_uint32),
+        ("clusters_per_tuple", C.c_uint32),
+    ]
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("ddt_oracle.c", "ddt_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        u32, u64, vp, sz = C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t
+        PP = C.POINTER(Params)
+        L.orc_fp34_wrap.restype, L.orc_fp34_wrap.argtypes = u64, [u32]
+        L.orc_fp34_unwrap.restype, L.orc_fp34_unwrap.argtypes = u32, [u64]
+        L.orc_fp34_add.restype, L.orc_fp34_add.argtypes = u64, [u64, u64]
+        L.orc_fpadd_bits.restype, L.orc_fpadd_bits.argtypes = u32, [u32, u32]
+        L.orc_fpadd_bits_batch.restype, L.orc_fpadd_bits_batch.argtypes = None, [vp, vp, vp, sz]
+        L.orc_traverse.restype, L.orc_traverse.argtypes = u32, [PP, vp, vp, vp, u32]
+        L.orc_leaves.restype, L.orc_leaves.argtypes = None, [PP, vp, vp, vp, vp]
+        L.orc_reduce_device.restype, L.orc_reduce_device.argtypes = u32, [vp, u32, u32, C.c_int]
+        L.orc_score.restype = C.c_int
+        L.orc_score.argtypes = [PP, vp, sz, vp, sz, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int]
+        L.orc_score_shard.restype = C.c_int
+        L.orc_score_shard.argtypes = [PP, vp, sz, vp, sz, vp, sz, u32, u32, vp, C.c_int, C.c_int]
+        for n in ("orc_weights_lines_per_tree", "orc_findex_lines_per_tree", "orc_tuple_lines"):
+            getattr(L, n).restype, getattr(L, n).argtypes = u32, [u32]
+        L.orc_pack_model.restype, L.orc_pack_model.argtypes = None, [u32, u32, vp, vp, vp, vp, vp, vp]
+        L.orc_splitmix64.restype, L.orc_splitmix64.argtypes = u64, [u64]
+        L.orc_gen_tuples.restype, L.orc_gen_tuples.argtypes = None, [u64, sz, u32, C.c_int, u32, vp]
+        L.orc_gen_model.restype, L.orc_gen_model.argtypes = None, [u32, u32, u32, C.c_int, vp, vp]
+        L.orc_hw_threads.restype, L.orc_hw_threads.argtypes = C.c_int, []
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def wlpt(D: int) -> int:
+    return ((1 << (D + 1)) - 1 + 3) // 4
+
+
+def flpt(D: int) -> int:
+    return ((1 << D) - 1 + 7) // 8
+
+
+def tuple_lines(F: int) -> int:
+    return (F + 3) // 4
+
+
+def default_clusters(T: int) -> int:
+    """Smallest C in {1,2,4,8} whose 8*16*C tree slots hold T trees (16 trees/PU, DTPU.sv:74)."""
+    for c in (1, 2, 4, 8):
+        if T <= 128 * c:
+            return c
+    return 8
+
+
+def make_params(T, D, F, missing_bits=0x7FC00000, cmp_mode=0, clusters=None) -> Params:
+    return Params(T, D, F, missing_bits, wlpt(D), flpt(D), cmp_mode,
+                  default_clusters(T) if clusters is None else clusters)
+
+
+class Model:
+    """A model in the reference wire format: weights lines (u32) + feature-index lines (u16)."""
+
+    def __init__(self, params: Params, wlines: np.ndarray, flines: np.ndarray):
+        self.params = params
+        self.wlines = np.ascontiguousarray(wlines, dtype=np.uint32).reshape(-1)
+        self.flines = np.ascontiguousarray(flines, dtype=np.uint16).reshape(-1)
+
+    @property
+    def n_wlines(self) -> int:
+        return self.wlines.size // 4
+
+    @property
+    def n_flines(self) -> int:
+        return self.flines.size // 8
+
+
+def pack_model(thr: np.ndarray, fidx: np.ndarray, miss_right: np.ndarray, leaves: np.ndarray,
+               F: int, **kw) -> Model:
+    """thr [T, 2^D-1] fp32 (or uint32 bit patterns), fidx [T, 2^D-1], miss_right [T, 2^D-1], leaves [T, 2^D]."""
+    T, nint = fidx.shape
+    D = int(np.log2(nint + 1))
+    assert (1 << D) - 1 == nint and leaves.shape == (T, 1 << D)
+    tb = np.ascontiguousarray(thr).view(np.uint32) if thr.dtype == np.float32 else np.ascontiguousarray(thr, np.uint32)
+    lb = np.ascontiguousarray(leaves).view(np.uint32) if leaves.dtype == np.float32 else np.ascontiguousarray(leaves, np.uint32)
+    fi = np.ascontiguousarray(fidx, np.uint16)
+    mr = np.ascontiguousarray(miss_right, np.uint8)
+    w = np.zeros(T * wlpt(D) * 4, np.uint32)
+    f = np.zeros(T * flpt(D) * 8, np.uint16)
+    lib().orc_pack_model(T, D, _p(tb), _p(fi), _p(mr), _p(lb), _p(w), _p(f))
+    return Model(make_params(T, D, F, **kw), w, f)
+
+
+def gen_model(T: int, D: int, F: int, dist: int = 0, **kw) -> Model:
+    w = np.zeros(T * wlpt(D) * 4, np.uint32)
+    f = np.zeros(T * flpt(D) * 8, np.uint16)
+    lib().orc_gen_model(T, D, F, dist, _p(w), _p(f))
+    return Model(make_params(T, D, F, **kw), w, f)
+
+
+def gen_tuples(row0: int, n: int, F: int, dist: int = 0, missing_bits: int = 0x7FC00000) -> np.ndarray:
+    """-> uint32 [n, ceil(F/4)*4] tuple lines (fp32 bit patterns)."""
+    out = np.zeros((n, tuple_lines(F) * 4), np.uint32)
+    lib().orc_gen_tuples(row0, n, F, dist, missing_bits, _p(out))
+    return out
+
+
+def tuples_from_float(x: np.ndarray) -> np.ndarray:
+    """fp32 [n, F] -> uint32 tuple lines [n, ceil(F/4)*4] (zero padded)."""
+    n, F = x.shape
+    out = np.zeros((n, tuple_lines(F) * 4), np.uint32)
+    out[:, :F] = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return out
+
+
+def score(m: Model, tuples: np.ndarray, sum_mode: int = SUM_REF_FLOPOCO, n_devices: int = 1,
+          nthreads: int = 0, want_gold: bool = False):
+    t = np.ascontiguousarray(tuples, np.uint32)
+    n = t.shape[0]
+    out = np.zeros(n, np.float32)
+    gold = np.zeros(n, np.float64) if want_gold else None
+    rc = lib().orc_score(C.byref(m.params), _p(m.wlines), m.n_wlines, _p(m.flines), m.n_flines, _p(t), n,
+                         _p(out), _p(gold) if want_gold else None, sum_mode, n_devices, nthreads)
+    if rc:
+        raise ValueError(f"orc_score rc={rc}")
+    return (out, gold) if want_gold else out
+
+
+def score_shard(m: Model, tuples: np.ndarray, tree_begin: int, tree_end: int,
+                sum_mode: int = SUM_REF_FLOPOCO, nthreads: int = 0) -> np.ndarray:
+    t = np.ascontiguousarray(tuples, np.uint32)
+    out = np.zeros(t.shape[0], np.float32)
+    rc = lib().orc_score_shard(C.byref(m.params), _p(m.wlines), m.n_wlines, _p(m.flines), m.n_flines, _p(t),
+                               t.shape[0], tree_begin, tree_end, _p(out), sum_mode, nthreads)
+    if rc:
+        raise ValueError(f"orc_score_shard rc={rc}")
+    return out
+
+
+def leaves(m: Model, tuple_row: np.ndarray) -> np.ndarray:
+    t = np.ascontiguousarray(tuple_row, np.uint32)
+    out = np.zeros(m.params.num_trees, np.uint32)
+    lib().orc_leaves(C.byref(m.params), _p(m.wlines), _p(m.flines), _p(t), _p(out))
+    return out
+
+
+def fpadd_bits(a: int, b: int) -> int:
+    return lib().orc_fpadd_bits(a & 0xFFFFFFFF, b & 0xFFFFFFFF)
+
+
+def fpadd_bits_batch(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, np.uint32)
+    b = np.ascontiguousarray(b, np.uint32)
+    out = np.zeros_like(a)
+    lib().orc_fpadd_bits_batch(_p(a), _p(b), _p(out), a.size)
+    return out
+
+
+def hw_threads() -> int:
+    return lib().orc_hw_threads()

@@ -1,0 +1,85 @@
+"""The oracle's bit-level model of the reference's FloPoCo fp32 adder
+(rtl/DTEngine/common/FPAdder_2cycles_latency.v:210-387) versus IEEE-754 hardware adds.
+
+Claim under test: for normal operands whose sum is normal or exactly zero the FloPoCo adder
+IS IEEE-754 binary32 round-to-nearest-even addition; it differs only for subnormals, Inf, NaN and -0.
+"""
+import numpy as np
+
+from oracle import oracle as O
+
+
+def _rand_normals(rng, n):
+    e = rng.integers(1, 255, n, dtype=np.uint32)
+    m = rng.integers(0, 1 << 23, n, dtype=np.uint32)
+    s = rng.integers(0, 2, n, dtype=np.uint32)
+    return (s << 31) | (e << 23) | m
+
+
+def _ieee(a, b):
+    with np.errstate(over="ignore", invalid="ignore"):
+        return (a.view(np.float32) + b.view(np.float32)).view(np.uint32)
+
+
+def _normal_or_zero(r):
+    e = (r >> 23) & 0xFF
+    return ((e > 0) & (e < 255)) | (r == 0)
+
+
+def test_random_normals_match_ieee():
+    rng = np.random.default_rng(0)
+    n = 400_000
+    a, b = _rand_normals(rng, n), _rand_normals(rng, n)
+    # half of the pairs: close exponents (alignment, cancellation, rounding ties all get exercised)
+    k = n // 2
+    eb = ((a[:k] >> 23) & 0xFF).astype(np.int64) + rng.integers(-3, 4, k)
+    b[:k] = (b[:k] & 0x807FFFFF) | (np.clip(eb, 1, 254).astype(np.uint32) << 23)
+    got, ref = O.fpadd_bits_batch(a, b), _ieee(a, b)
+    ok = _normal_or_zero(ref)
+    assert ok.sum() > 0.95 * n
+    assert np.array_equal(got[ok], ref[ok])
+
+
+def test_leaf_scale_values_match_ieee():
+    # the magnitudes the scorer actually adds: |v| <= 0.1 leaves and their partial sums
+    rng = np.random.default_rng(1)
+    a = ((rng.random(300_000) - 0.5) * 0.2).astype(np.float32).view(np.uint32)
+    b = ((rng.random(300_000) - 0.5) * 20.0).astype(np.float32).view(np.uint32)
+    assert np.array_equal(O.fpadd_bits_batch(a, b), _ieee(a, b))
+    assert np.array_equal(O.fpadd_bits_batch(a, a[::-1].copy()), _ieee(a, a[::-1].copy()))
+
+
+def test_rounding_ties_and_cancellation():
+    one, ulp = np.float32(1.0), np.float32(2.0 ** -23)
+    f = lambda x: int(np.array(x, np.float32).view(np.uint32))
+    half = np.float32(2.0 ** -24)
+    assert O.fpadd_bits(f(one), f(half)) == f(one)                          # tie -> even (down)
+    assert O.fpadd_bits(f(one + ulp), f(half)) == f(one + 2 * ulp)          # tie -> even (up)
+    assert O.fpadd_bits(f(one), f(half * np.float32(1.5))) == f(one + ulp)  # above tie -> up
+    assert O.fpadd_bits(f(0.1), f(-0.1)) == 0                               # exact cancellation -> +0
+    assert O.fpadd_bits(f(-0.1), f(0.1)) == 0
+    assert O.fpadd_bits(f(3.0), 0) == f(3.0) and O.fpadd_bits(0, f(-3.0)) == f(-3.0)
+    assert O.fpadd_bits(0, 0) == 0
+    assert O.fpadd_bits(f(1.0), f(2.0 ** -60)) == f(1.0)                    # shifted out entirely
+
+
+def test_documented_divergences_from_ieee():
+    # -0.0 has non-zero bits, so the wrapper tags it "normal" (exc = {0,|bits}); it survives +0
+    assert O.fpadd_bits(0x80000000, 0) == 0x80000000        # IEEE would give +0
+    # FloPoCo has no subnormals: a result below 2^-126 flushes to zero
+    tiny = int(np.array(2.0 ** -126, np.float32).view(np.uint32))
+    tiny15 = int(np.array(1.5 * 2.0 ** -126, np.float32).view(np.uint32))
+    assert O.fpadd_bits(tiny15, tiny | 0x80000000) == 0     # IEEE: 0.5 * 2^-126 (subnormal)
+    # FloPoCo uses exponent field 255 as an ordinary exponent: FLT_MAX + FLT_MAX is a "normal" number whose
+    # 32-bit image looks like an IEEE NaN; only exponent 256 raises the inf exception
+    big = 0x7F7FFFFF
+    w = O.lib().orc_fp34_add(O.lib().orc_fp34_wrap(big), O.lib().orc_fp34_wrap(big))
+    assert (w >> 32) & 3 == 1 and (w & 0xFFFFFFFF) == 0x7FFFFFFF
+    w2 = O.lib().orc_fp34_add(w, w)
+    assert (w2 >> 32) & 3 == 2
+
+
+def test_commutative():
+    rng = np.random.default_rng(2)
+    a, b = _rand_normals(rng, 100_000), _rand_normals(rng, 100_000)
+    assert np.array_equal(O.fpadd_bits_batch(a, b), O.fpadd_bits_batch(b, a))
