@@ -1,0 +1,562 @@
+// ddt_engine.cpp -- host side of libddt.so: model stream parsing/validation, device image packing,
+// kernel variant selection, the pinned double-buffered tuple feeder, and the C-ABI of include/ddt.h.
+//
+// Reference interfaces restated here (the reference has no host software; these are its hardware
+// contracts): CSR map rtl/DTEngine/EngineCSR.sv:190-305; stream order and framing
+// rtl/DTEngine/PCIeReceiver.sv:136-139,230-312; line packing rtl/DTEngine/core/PipelinedMUX.sv:65;
+// model store rtl/DTEngine/core/DTPU.sv:282-354; result packing rtl/DTEngine/ResultsCombiner.sv:136-160.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "ddt_internal.h"
+
+using namespace ddt;
+
+namespace {
+
+constexpr uint32_t kMaxLdsBytes = 160u * 1024u;  // MI355X: 160 KiB LDS per CU / workgroup
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// The model as parsed from the reference wire format (this engine's shard only).
+struct HostModel {
+  ddt_params p{};
+  uint32_t tree_begin = 0, tree_end = 0;  // global ids
+  uint32_t nint = 0, nleaf = 0;
+  std::vector<uint32_t> thr;    // [T_local][nint]   raw fp32 bit patterns (heap order, 0-based)
+  std::vector<uint16_t> fidx;   // [T_local][nint]
+  std::vector<uint8_t> mright;  // [T_local][nint]
+  std::vector<uint32_t> leaf;   // [T_local][nleaf]
+  uint32_t trees() const { return tree_end - tree_begin; }
+};
+
+}  // namespace
+
+struct ddt_engine {
+  int device = -1;
+  hipDeviceProp_t prop{};
+  bool loaded = false;
+  HostModel m;
+  int forced_variant = -1;
+  int variant_id = 0;
+  // device image for the active variant
+  void* d_img = nullptr;
+  size_t img_bytes = 0;
+  uint32_t img_trees = 0, img_chunks = 0;
+  // feeder
+  size_t feeder_rows = 1u << 18;
+  hipStream_t fs[2] = {nullptr, nullptr};
+  hipEvent_t fe[2] = {nullptr, nullptr};
+  void* pin_in[2] = {nullptr, nullptr};
+  void* pin_out[2] = {nullptr, nullptr};
+  void* dev_in[2] = {nullptr, nullptr};
+  void* dev_out[2] = {nullptr, nullptr};
+  size_t feeder_cap_rows = 0, feeder_cap_words = 0;
+  ddt_stats st{};
+  char err[256] = {0};
+};
+
+namespace {
+
+int fail(ddt_engine* e, int code, const char* fmt, ...) {
+  if (e) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(e->err, sizeof(e->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                          \
+  do {                                                                                            \
+    hipError_t _r = (call);                                                                       \
+    if (_r != hipSuccess) return fail((e), DDT_EHIP, "%s -> %s", #call, hipGetErrorString(_r));   \
+  } while (0)
+
+uint32_t wlines_min(uint32_t D) { return (uint32_t)((((1ull << (D + 1)) - 1) + 3) / 4); }
+uint32_t flines_min(uint32_t D) { return (uint32_t)((((1ull << D) - 1) + 7) / 8); }
+
+int validate(ddt_engine* e, const ddt_params* p, size_t n_wlines, size_t n_flines) {
+  if (!p) return fail(e, DDT_EINVAL, "params is NULL");
+  if (p->num_trees == 0) return fail(e, DDT_EINVAL, "num_trees == 0");
+  if (p->num_levels < 1 || p->num_levels > 16) return fail(e, DDT_EINVAL, "num_levels %u not in 1..16 (CSR205 is 4 bits)", p->num_levels);
+  if (p->num_features < 1 || p->num_features > 2048) return fail(e, DDT_EINVAL, "num_features %u not in 1..2048 (DTPU.sv:72)", p->num_features);
+  if (p->cmp_mode > 1) return fail(e, DDT_EINVAL, "cmp_mode %u", p->cmp_mode);
+  if (p->sum_mode > 1) return fail(e, DDT_EINVAL, "sum_mode %u", p->sum_mode);
+  const uint32_t c = p->clusters_per_tuple;
+  if (c != 1 && c != 2 && c != 4 && c != 8) return fail(e, DDT_EINVAL, "clusters_per_tuple %u not in {1,2,4,8}", c);
+  if (p->reserved[0] | p->reserved[1] | p->reserved[2]) return fail(e, DDT_EINVAL, "reserved fields must be 0");
+  if (p->weights_lines_per_tree < wlines_min(p->num_levels))
+    return fail(e, DDT_EINVAL, "weights_lines_per_tree %u < %u", p->weights_lines_per_tree, wlines_min(p->num_levels));
+  if (p->findex_lines_per_tree < flines_min(p->num_levels))
+    return fail(e, DDT_EINVAL, "findex_lines_per_tree %u < %u", p->findex_lines_per_tree, flines_min(p->num_levels));
+  if (n_wlines < (size_t)p->num_trees * p->weights_lines_per_tree) return fail(e, DDT_EINVAL, "weights stream too short");
+  if (n_flines < (size_t)p->num_trees * p->findex_lines_per_tree) return fail(e, DDT_EINVAL, "feature-index stream too short");
+  return DDT_OK;
+}
+
+// Parse the shard [b, e) of the two streams (A2 packing: word k of a line = bits [32k+31:32k]).
+int parse_model(ddt_engine* eng, const ddt_params* p, const uint32_t* w, const uint16_t* f, uint32_t b, uint32_t e,
+                HostModel* out) {
+  HostModel m;
+  m.p = *p;
+  m.tree_begin = b;
+  m.tree_end = e;
+  const uint32_t D = p->num_levels;
+  m.nint = (1u << D) - 1u;
+  m.nleaf = 1u << D;
+  const uint32_t T = e - b;
+  try {
+    m.thr.resize((size_t)T * m.nint);
+    m.fidx.resize((size_t)T * m.nint);
+    m.mright.resize((size_t)T * m.nint);
+    m.leaf.resize((size_t)T * m.nleaf);
+  } catch (const std::bad_alloc&) {
+    return fail(eng, DDT_ENOMEM, "host model allocation failed");
+  }
+  for (uint32_t i = 0; i < T; ++i) {
+    const uint32_t* wt = w + (size_t)(b + i) * p->weights_lines_per_tree * 4u;
+    const uint16_t* ft = f + (size_t)(b + i) * p->findex_lines_per_tree * 8u;
+    for (uint32_t n = 0; n < m.nint; ++n) {
+      const uint16_t en = ft[n];
+      const uint32_t j = en & 0x7FFu;  // DTPU.sv:628
+      if (j >= p->num_features)
+        return fail(eng, DDT_EINVAL, "tree %u node %u: feature index %u >= num_features %u", b + i, n, j, p->num_features);
+      if (en & (1u << 14))  // "next node is leaf" has no well-defined result in the published RTL
+        return fail(eng, DDT_EUNSUPPORTED, "tree %u node %u: early-leaf flag (bit 14) is not supported; pad the tree to a perfect one", b + i, n);
+      m.thr[(size_t)i * m.nint + n] = wt[n];
+      m.fidx[(size_t)i * m.nint + n] = (uint16_t)j;
+      m.mright[(size_t)i * m.nint + n] = (uint8_t)((en >> 13) & 1u);  // DTPU.sv:659
+    }
+    for (uint32_t l = 0; l < m.nleaf; ++l) m.leaf[(size_t)i * m.nleaf + l] = wt[m.nint + l];
+  }
+  *out = std::move(m);
+  return DDT_OK;
+}
+
+uint32_t thr_key(const HostModel& m, uint32_t bits) {
+  if (m.p.cmp_mode == 0) return bits;
+  if ((bits & 0x7FFFFFFFu) > 0x7F800000u) return 0x80000000u;  // x < NaN is never true -> always right
+  return ieee_key(bits);
+}
+
+uint32_t tuple_words(const ddt_params& p) { return (p.num_features + 3u) / 4u * 4u; }
+
+bool variant_fits(const Variant& v, const HostModel& m) {
+  if (v.levels == 0) return true;
+  if ((uint32_t)v.levels != m.p.num_levels) return false;
+  return v.lds_bytes(tuple_words(m.p)) <= kMaxLdsBytes;
+}
+
+int auto_variant(const HostModel& m) {
+  // preference order per depth; first that fits wins (tuned from profiles/)
+  static const char* pref[] = {"d8_t512_r2_c4_u4_dma", "d8_t512_r1_c4_u4_dma", "d8_t256_r1_c4_u4_dma",
+                               "d6_t256_r1_c16_u4_dma", "d4_t256_r1_c64_u8_dma"};
+  for (const char* name : pref)
+    for (int i = 0; i < num_variants(); ++i)
+      if (!strcmp(variant(i).name, name) && variant_fits(variant(i), m)) return i;
+  for (int i = 1; i < num_variants(); ++i)
+    if (variant_fits(variant(i), m)) return i;
+  return 0;
+}
+
+void free_image(ddt_engine* e) {
+  if (e->d_img) (void)hipFree(e->d_img);
+  e->d_img = nullptr;
+  e->img_bytes = 0;
+}
+
+// Build the device image for variant `vid` and upload it.
+int build_image(ddt_engine* e, int vid) {
+  const Variant& v = variant(vid);
+  const HostModel& m = e->m;
+  const uint32_t D = m.p.num_levels, T = m.trees();
+  const uint32_t tree_bytes = 12u << D;
+  const uint32_t granule = (v.levels == 0) ? 8u : (uint32_t)((v.chunk_trees > 8) ? v.chunk_trees : 8);
+  const uint32_t Tpad = (T + granule - 1u) / granule * granule;  // EMPTY trees: every leaf +0 (DTPU.sv:544,760)
+  const size_t bytes = (size_t)Tpad * tree_bytes;
+  std::vector<uint32_t> img;
+  try {
+    img.assign(bytes / 4, 0u);
+  } catch (const std::bad_alloc&) {
+    return fail(e, DDT_ENOMEM, "image allocation (%zu bytes) failed", bytes);
+  }
+  const uint32_t row = v.tile() * 4u, feat_off = (v.levels == 0) ? 0u : v.feat_off();
+  for (uint32_t i = 0; i < Tpad; ++i) {
+    uint32_t* t = img.data() + (size_t)i * (tree_bytes / 4);
+    if (i >= T) {  // EMPTY tree: any walk ends in a +0 leaf; node words must still gather in range
+      for (uint32_t mm = 1; mm <= m.nint; ++mm) t[2 * mm + 1] = (v.levels == 0) ? 0u : feat_off;
+      continue;
+    }
+    for (uint32_t n = 0; n < m.nint; ++n) {
+      const uint32_t mm = n + 1;  // 1-based heap record
+      const uint32_t j = m.fidx[(size_t)i * m.nint + n];
+      const uint32_t word = (v.levels == 0) ? j : (feat_off + j * row);
+      t[2 * mm + 0] = thr_key(m, m.thr[(size_t)i * m.nint + n]);
+      t[2 * mm + 1] = word | (m.mright[(size_t)i * m.nint + n] ? kFlagMissRight : 0u);
+    }
+    uint32_t* lv = t + (8u << D) / 4;
+    for (uint32_t l = 0; l < m.nleaf; ++l) lv[l] = m.leaf[(size_t)i * m.nleaf + l];
+  }
+  free_image(e);
+  HIP_TRY(e, hipMalloc(&e->d_img, bytes));
+  HIP_TRY(e, hipMemcpy(e->d_img, img.data(), bytes, hipMemcpyHostToDevice));
+  e->img_bytes = bytes;
+  e->img_trees = Tpad;
+  e->img_chunks = (v.levels == 0) ? Tpad : Tpad / (uint32_t)v.chunk_trees;
+  e->variant_id = vid;
+  return DDT_OK;
+}
+
+int select_and_build(ddt_engine* e) {
+  int vid = e->forced_variant;
+  if (vid >= 0) {
+    if (vid >= num_variants()) return fail(e, DDT_EINVAL, "variant %d out of range", vid);
+    if (!variant_fits(variant(vid), e->m))
+      return fail(e, DDT_EUNSUPPORTED, "variant %s does not fit this model (D=%u, F=%u)", variant(vid).name,
+                  e->m.p.num_levels, e->m.p.num_features);
+  } else {
+    vid = auto_variant(e->m);
+  }
+  return build_image(e, vid);
+}
+
+void fill_args(const ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, ScoreArgs* a) {
+  const HostModel& m = e->m;
+  a->img = reinterpret_cast<const uint4*>(e->d_img);
+  a->tuples = reinterpret_cast<const uint32_t*>(d_tuples);
+  a->out = d_scores;
+  a->n = n;
+  a->tuple_words = tuple_words(m.p);
+  a->n_trees = e->img_trees;
+  a->n_chunks = e->img_chunks;
+  a->levels = m.p.num_levels;
+  a->clusters = m.p.clusters_per_tuple;
+  a->miss_raw = m.p.missing_bits;
+  a->miss_key = m.p.cmp_mode ? kMissSentinelIeee : m.p.missing_bits;
+  a->ieee = m.p.cmp_mode;
+  a->sum_mode = m.p.sum_mode;
+}
+
+void feeder_free(ddt_engine* e) {
+  for (int b = 0; b < 2; ++b) {
+    if (e->pin_in[b]) (void)hipHostFree(e->pin_in[b]);
+    if (e->pin_out[b]) (void)hipHostFree(e->pin_out[b]);
+    if (e->dev_in[b]) (void)hipFree(e->dev_in[b]);
+    if (e->dev_out[b]) (void)hipFree(e->dev_out[b]);
+    e->pin_in[b] = e->pin_out[b] = e->dev_in[b] = e->dev_out[b] = nullptr;
+  }
+  e->feeder_cap_rows = e->feeder_cap_words = 0;
+}
+
+int feeder_reserve(ddt_engine* e, size_t rows, size_t words) {
+  if (e->feeder_cap_rows >= rows && e->feeder_cap_words >= words) return DDT_OK;
+  feeder_free(e);
+  for (int b = 0; b < 2; ++b) {
+    if (!e->fs[b]) HIP_TRY(e, hipStreamCreateWithFlags(&e->fs[b], hipStreamNonBlocking));
+    if (!e->fe[b]) HIP_TRY(e, hipEventCreateWithFlags(&e->fe[b], hipEventDisableTiming));
+    HIP_TRY(e, hipHostMalloc(&e->pin_in[b], rows * words * 4, hipHostMallocDefault));
+    HIP_TRY(e, hipHostMalloc(&e->pin_out[b], rows * 4, hipHostMallocDefault));
+    HIP_TRY(e, hipMalloc(&e->dev_in[b], rows * words * 4));
+    HIP_TRY(e, hipMalloc(&e->dev_out[b], rows * 4));
+  }
+  e->feeder_cap_rows = rows;
+  e->feeder_cap_words = words;
+  return DDT_OK;
+}
+
+int launch_score(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
+  ScoreArgs a;
+  fill_args(e, d_tuples, n, d_scores, &a);
+  const Variant& v = variant(e->variant_id);
+  hipError_t r = v.launch(a, v, s);
+  if (r != hipSuccess) return fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
+  e->st.kernel_launches++;
+  return DDT_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C-ABI
+// =====================================================================================================
+extern "C" {
+
+int ddt_create(ddt_engine** out, int device_id) {
+  if (!out) return DDT_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return DDT_ENODEVICE;  // never a CPU fallback
+  if (device_id < 0 || device_id >= count) return DDT_EINVAL;
+  std::unique_ptr<ddt_engine> e(new (std::nothrow) ddt_engine());
+  if (!e) return DDT_ENOMEM;
+  e->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess) return DDT_EHIP;
+  if (hipGetDeviceProperties(&e->prop, device_id) != hipSuccess) return DDT_EHIP;
+  if (strncmp(e->prop.gcnArchName, "gfx950", 6) != 0) return DDT_ENODEVICE;  // kernels are built for gfx950 only
+  *out = e.release();
+  return DDT_OK;
+}
+
+void ddt_destroy(ddt_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  feeder_free(e);
+  for (int b = 0; b < 2; ++b) {
+    if (e->fs[b]) (void)hipStreamDestroy(e->fs[b]);
+    if (e->fe[b]) (void)hipEventDestroy(e->fe[b]);
+  }
+  free_image(e);
+  delete e;
+}
+
+int ddt_load_model_shard(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wlines, const void* fl,
+                         size_t n_flines, uint32_t shard_index, uint32_t shard_count) {
+  if (!e) return DDT_EINVAL;
+  if (!wl || !fl) return fail(e, DDT_EINVAL, "NULL model stream");
+  int rc = validate(e, p, n_wlines, n_flines);
+  if (rc) return rc;
+  if (shard_count == 0 || shard_index >= shard_count || shard_count > p->num_trees)
+    return fail(e, DDT_EINVAL, "shard %u of %u (trees %u)", shard_index, shard_count, p->num_trees);
+  const double t0 = now_ms();
+  HIP_TRY(e, hipSetDevice(e->device));
+  // contiguous shards of ceil(T/G) trees, device order = stream order (PCIeReceiver.sv:241-264)
+  const uint32_t per = (p->num_trees + shard_count - 1u) / shard_count;
+  const uint32_t b = shard_index * per < p->num_trees ? shard_index * per : p->num_trees;
+  const uint32_t en = (b + per < p->num_trees) ? b + per : p->num_trees;
+  if (b >= en) return fail(e, DDT_EINVAL, "shard %u of %u is empty", shard_index, shard_count);
+  HostModel m;
+  rc = parse_model(e, p, reinterpret_cast<const uint32_t*>(wl), reinterpret_cast<const uint16_t*>(fl), b, en, &m);
+  if (rc) return rc;
+  e->m = std::move(m);
+  e->loaded = false;
+  rc = select_and_build(e);
+  if (rc) return rc;
+  e->loaded = true;
+  e->st.model_lines_in += (uint64_t)(en - b) * (p->weights_lines_per_tree + p->findex_lines_per_tree);
+  e->st.prog_ms += now_ms() - t0;
+  return DDT_OK;
+}
+
+int ddt_load_model(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wlines, const void* fl,
+                   size_t n_flines) {
+  return ddt_load_model_shard(e, p, wl, n_wlines, fl, n_flines, 0, 1);
+}
+
+int ddt_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, void* stream) {
+  if (!e) return DDT_EINVAL;
+  if (!e->loaded) return fail(e, DDT_ESTATE, "no model loaded");
+  if (n == 0) return DDT_OK;
+  if (!d_tuples || !d_scores) return fail(e, DDT_EINVAL, "NULL device buffer");
+  int rc = launch_score(e, d_tuples, n, d_scores, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  e->st.score_calls++;
+  e->st.tuples_in += n;
+  e->st.tuples_out += n;
+  e->st.tuple_lines_in += (uint64_t)n * (tuple_words(e->m.p) / 4);
+  e->st.result_lines_out += (n + 3) / 4;
+  return DDT_OK;
+}
+
+int ddt_score(ddt_engine* e, const void* tuple_lines, size_t n, float* scores_out) {
+  if (!e) return DDT_EINVAL;
+  if (!e->loaded) return fail(e, DDT_ESTATE, "no model loaded");
+  if (n == 0) return DDT_OK;
+  if (!tuple_lines || !scores_out) return fail(e, DDT_EINVAL, "NULL host buffer");
+  const double t0 = now_ms();
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t W = tuple_words(e->m.p);
+  const size_t rows = e->feeder_rows < n ? e->feeder_rows : n;
+  int rc = feeder_reserve(e, rows, W);
+  if (rc) return rc;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(tuple_lines);
+  // pinned double buffer: while chunk i computes on stream i&1, chunk i+1 is copied in on the other
+  size_t pending_off[2] = {0, 0}, pending_n[2] = {0, 0};
+  for (size_t off = 0, i = 0; off < n; off += rows, ++i) {
+    const int b = (int)(i & 1);
+    const size_t cn = (n - off < rows) ? n - off : rows;
+    if (pending_n[b]) {  // drain the previous use of this buffer
+      HIP_TRY(e, hipEventSynchronize(e->fe[b]));
+      memcpy(scores_out + pending_off[b], e->pin_out[b], pending_n[b] * 4);
+      pending_n[b] = 0;
+    }
+    memcpy(e->pin_in[b], src + off * W, cn * W * 4);
+    HIP_TRY(e, hipMemcpyAsync(e->dev_in[b], e->pin_in[b], cn * W * 4, hipMemcpyHostToDevice, e->fs[b]));
+    rc = launch_score(e, e->dev_in[b], cn, reinterpret_cast<float*>(e->dev_out[b]), e->fs[b]);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->pin_out[b], e->dev_out[b], cn * 4, hipMemcpyDeviceToHost, e->fs[b]));
+    HIP_TRY(e, hipEventRecord(e->fe[b], e->fs[b]));
+    pending_off[b] = off;
+    pending_n[b] = cn;
+  }
+  for (int b = 0; b < 2; ++b)
+    if (pending_n[b]) {
+      HIP_TRY(e, hipEventSynchronize(e->fe[b]));
+      memcpy(scores_out + pending_off[b], e->pin_out[b], pending_n[b] * 4);
+    }
+  e->st.score_calls++;
+  e->st.tuples_in += n;
+  e->st.tuples_out += n;
+  e->st.tuple_lines_in += (uint64_t)n * (W / 4);
+  e->st.result_lines_out += (n + 3) / 4;
+  e->st.exec_ms += now_ms() - t0;
+  return DDT_OK;
+}
+
+int ddt_chain_sum_device(ddt_engine* e, const float* d_parts, uint32_t n_parts, size_t n, float* d_out, void* stream) {
+  if (!e) return DDT_EINVAL;
+  if (n_parts == 0 || (!d_parts && n) || (!d_out && n)) return fail(e, DDT_EINVAL, "bad chain-sum arguments");
+  hipError_t r = launch_chain_sum(d_parts, n_parts, n, d_out, reinterpret_cast<hipStream_t>(stream));
+  if (r != hipSuccess) return fail(e, DDT_EHIP, "chain_sum -> %s", hipGetErrorString(r));
+  return DDT_OK;
+}
+
+int ddt_get_info(const ddt_engine* e, ddt_info* out) {
+  if (!e || !out) return DDT_EINVAL;
+  memset(out, 0, sizeof(*out));
+  out->abi_version = DDT_ABI_VERSION;
+  out->device_id = e->device;
+  snprintf(out->device_name, sizeof(out->device_name), "%s (%s)", e->prop.name, e->prop.gcnArchName);
+  if (!e->loaded) return DDT_OK;
+  const Variant& v = variant(e->variant_id);
+  const HostModel& m = e->m;
+  out->tree_begin = m.tree_begin;
+  out->tree_end = m.tree_end;
+  out->num_levels = m.p.num_levels;
+  out->num_features = m.p.num_features;
+  out->tuple_words = tuple_words(m.p);
+  out->variant = (uint32_t)e->variant_id;
+  out->tile_tuples = v.tile();
+  out->block_threads = (uint32_t)v.threads;
+  out->lds_bytes = v.levels ? v.lds_bytes(out->tuple_words) : generic_lds_bytes(m.p.num_levels, out->tuple_words, nullptr, nullptr);
+  out->model_bytes_unpadded = (uint64_t)m.trees() * (4ull * ((2ull << m.p.num_levels) - 1) + 2ull * ((1ull << m.p.num_levels) - 1));
+  out->image_bytes = e->img_bytes;
+  snprintf(out->variant_name, sizeof(out->variant_name), "%s", v.name);
+  return DDT_OK;
+}
+
+int ddt_get_stats(const ddt_engine* e, ddt_stats* out) {
+  if (!e || !out) return DDT_EINVAL;
+  *out = e->st;
+  return DDT_OK;
+}
+
+const char* ddt_strerror(int code) {
+  switch (code) {
+    case DDT_OK: return "ok";
+    case DDT_EINVAL: return "invalid argument";
+    case DDT_ENOMEM: return "out of memory";
+    case DDT_EHIP: return "HIP runtime error";
+    case DDT_ESTATE: return "bad call order (no model loaded?)";
+    case DDT_EUNSUPPORTED: return "not supported";
+    case DDT_ENODEVICE: return "no usable gfx950 device (this library has no CPU fallback)";
+    default: return "unknown error";
+  }
+}
+
+const char* ddt_last_error(const ddt_engine* e) { return e ? e->err : ""; }
+
+int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
+  if (!e || !key) return DDT_EINVAL;
+  if (!strcmp(key, "variant")) {
+    if (value >= num_variants()) return fail(e, DDT_EINVAL, "variant %lld out of range", (long long)value);
+    e->forced_variant = value < 0 ? -1 : (int)value;
+    if (e->loaded) {
+      HIP_TRY(e, hipSetDevice(e->device));
+      HIP_TRY(e, hipDeviceSynchronize());
+      e->loaded = false;
+      int rc = select_and_build(e);
+      if (rc) return rc;
+      e->loaded = true;
+    }
+    return DDT_OK;
+  }
+  if (!strcmp(key, "feeder_rows")) {
+    if (value < 1) return fail(e, DDT_EINVAL, "feeder_rows must be >= 1");
+    e->feeder_rows = (size_t)value;
+    return DDT_OK;
+  }
+  return fail(e, DDT_EINVAL, "unknown option '%s'", key);
+}
+
+int ddt_num_variants(void) { return num_variants(); }
+
+int ddt_variant_name(int v, char* buf, size_t buflen) {
+  if (v < 0 || v >= num_variants() || !buf || !buflen) return DDT_EINVAL;
+  snprintf(buf, buflen, "%s", variant(v).name);
+  return DDT_OK;
+}
+
+// ---- synthetic inputs --------------------------------------------------------------
+static inline float unit24(uint64_t h) { return (float)(h >> 40) * (1.0f / 16777216.0f); }
+static inline uint32_t fbits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
+
+int ddt_synth_model(uint32_t T, uint32_t D, uint32_t F, int dist, void* wlines, void* flines) {
+  if (!wlines || !flines || T == 0 || D < 1 || D > 16 || F < 1 || F > 2048) return DDT_EINVAL;
+  uint32_t* w = reinterpret_cast<uint32_t*>(wlines);
+  uint16_t* f = reinterpret_cast<uint16_t*>(flines);
+  const uint32_t nint = (1u << D) - 1u, ntot = (2u << D) - 1u;
+  const size_t ws = (size_t)wlines_min(D) * 4u, fs = (size_t)flines_min(D) * 8u;
+  memset(w, 0, (size_t)T * ws * 4);
+  memset(f, 0, (size_t)T * fs * 2);
+  for (uint32_t i = 0; i < T; ++i)
+    for (uint32_t n = 0; n < ntot; ++n) {
+      const uint64_t g = (uint64_t)i * (2ull << D) + n;
+      const float u = unit24(splitmix64(kSeedM + 3ull * g + 1ull));
+      if (n < nint) {
+        const uint32_t j = (uint32_t)(splitmix64(kSeedM + 3ull * g) % F);
+        const uint32_t mr = (uint32_t)(splitmix64(kSeedM + 3ull * g + 2ull) & 1ull);
+        w[(size_t)i * ws + n] = fbits(dist == 1 ? u * 2.0f - 1.0f : u);
+        f[(size_t)i * fs + n] = (uint16_t)(j | (mr << 13));
+      } else {
+        volatile float c = u - 0.5f;
+        volatile float v = c * 0.2f;
+        w[(size_t)i * ws + n] = fbits(v);
+      }
+    }
+  return DDT_OK;
+}
+
+int ddt_synth_tuples_host(void* out_, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits) {
+  if (!out_ || F < 1 || F > 2048) return DDT_EINVAL;
+  uint32_t* out = reinterpret_cast<uint32_t*>(out_);
+  const uint32_t W = (F + 3u) / 4u * 4u;
+  for (size_t r = 0; r < n; ++r)
+    for (uint32_t j = 0; j < W; ++j) {
+      uint32_t bits = 0;
+      if (j < F) {
+        const uint64_t h = splitmix64(kSeedX + (row0 + r) * (uint64_t)F + j);
+        float v = unit24(h);
+        if (dist == 1) {
+          v = v * 2.0f - 1.0f;
+          bits = (((h >> 8) & 0xFFFFull) % 20ull == 0ull) ? missing_bits : fbits(v);
+        } else {
+          bits = fbits(v);
+        }
+      }
+      out[r * W + j] = bits;
+    }
+  return DDT_OK;
+}
+
+int ddt_synth_tuples_device(ddt_engine* e, void* d_out, uint64_t row0, size_t n, uint32_t F, int dist,
+                            uint32_t missing_bits, void* stream) {
+  if (!e) return DDT_EINVAL;
+  if (!d_out || F < 1 || F > 2048) return fail(e, DDT_EINVAL, "bad synth arguments");
+  hipError_t r = launch_synth_tuples(reinterpret_cast<uint32_t*>(d_out), row0, n, F, dist, missing_bits,
+                                     reinterpret_cast<hipStream_t>(stream));
+  if (r != hipSuccess) return fail(e, DDT_EHIP, "synth_tuples -> %s", hipGetErrorString(r));
+  return DDT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// ddt_internal.h -- shared between the host engine (ddt_engine.cpp) and the HIP kernels (ddt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ddt.h"
+
+namespace ddt {
+
+// ---------------------------------------------------------------------------------------------------
+// Packed tree image ("LDS image").  One tree occupies TREE_BYTES = 12 * 2^D bytes:
+//   [0, 8*2^D)        node records, 1-BASED heap (record 0 is padding): {u32 thr_key, u32 w2}
+//                     w2 = feature word (variant specific, see pack_image) | miss_right << 31
+//   [8*2^D, 12*2^D)   2^D fp32 leaves, left to right
+// Heap walk in byte units: m8 = 8 (root); m8 <- 2*m8 + 8*right; leaf byte = 8*2^D + (m8/2 - 4*2^D).
+// Reference semantics: rtl/DTEngine/core/DTPU.sv:579-760 (0-based n' = 2n+1+right is the same walk).
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kFlagMissRight = 0x80000000u;
+constexpr uint32_t kMissSentinelIeee = 0x7FFFFFFEu;  // key-space missing marker for cmp_mode 1
+
+struct ScoreArgs {
+  const uint4* img;        // packed image, n_chunks * chunk_bytes (tile kernels) or trees * tree_bytes (generic)
+  const uint32_t* tuples;  // device, row-major tuple lines: tuple_words u32 per tuple
+  float* out;              // device, one fp32 per tuple
+  uint64_t n;              // tuples
+  uint32_t tuple_words;    // 4*ceil(F/4)
+  uint32_t n_trees;        // trees in the image (padded to the variant's granule with EMPTY trees)
+  uint32_t n_chunks;       // tile kernels: image chunks
+  uint32_t levels;         // D
+  uint32_t clusters;       // C (reference summation order)
+  uint32_t miss_raw;       // params.missing_bits (tested on raw tuple bits while staging)
+  uint32_t miss_key;       // what a missing feature looks like inside LDS (== miss_raw for cmp_mode 0)
+  uint32_t ieee;           // 1: stage features through the IEEE order-preserving key transform
+  uint32_t sum_mode;       // 0 reference-order fp32, 1 fp64 sequential
+};
+
+struct Variant {
+  const char* name;
+  int levels;         // compile-time D, 0 = generic (runtime D)
+  int threads;        // block size
+  int tuples_per_lane;
+  int chunk_trees;    // trees per LDS chunk (tile kernels)
+  int ilp_trees;      // trees walked concurrently per lane
+  int stage;          // 0: model chunks staged through registers, 1: global->LDS DMA
+  // LDS geometry (tile kernels): model double buffer first, feature tile after it
+  uint32_t tile() const { return (uint32_t)threads * (uint32_t)tuples_per_lane; }
+  uint32_t tree_bytes() const { return 12u << levels; }
+  uint32_t chunk_bytes() const { return tree_bytes() * (uint32_t)chunk_trees; }
+  uint32_t feat_off() const {  // multiple of tile*4 so that (row offset | lane offset) is an OR
+    uint32_t row = tile() * 4u, need = 2u * chunk_bytes();
+    return (need + row - 1u) / row * row;
+  }
+  uint32_t lds_bytes(uint32_t tuple_words) const { return feat_off() + tuple_words * tile() * 4u + 64u; }  // +64: per-wave flags
+  hipError_t (*launch)(const ScoreArgs&, const Variant&, hipStream_t);
+};
+
+int num_variants();
+const Variant& variant(int i);
+
+// generic kernel geometry (runtime D; see ddt_kernels.hip)
+constexpr int kGenericThreads = 256;
+hipError_t launch_generic(const ScoreArgs& a, const Variant& v, hipStream_t s);
+uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds);
+
+hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s);
+hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits,
+                               hipStream_t s);
+
+// host-side splitmix64 / synthetic definitions; shared by host generator and kernels
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+constexpr uint64_t kSeedX = 0x0DD7000000000001ull;
+constexpr uint64_t kSeedM = 0x0DD7000000000002ull;
+
+// IEEE order-preserving key (cmp_mode 1): signed-int compare of keys == IEEE '<' on the floats;
+// every NaN -> INT_MAX (never "less"), -0 -> +0.
+__host__ __device__ inline uint32_t ieee_key(uint32_t b) {
+  if ((b & 0x7FFFFFFFu) > 0x7F800000u) return 0x7FFFFFFFu;
+  if (b == 0x80000000u) return 0u;
+  return (b & 0x80000000u) ? (b ^ 0x7FFFFFFFu) : b;
+}
+
+}  // namespace ddt

@@ -1,0 +1,551 @@
+// ddt_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4).  No MFMA: the path is
+// compare + gather; the binding resource is the LDS pipe (2 DS ops per node visit).
+//
+// Hot path replaced: the DTPU traversal loop + leaf reduce of the reference
+//   rtl/DTEngine/core/DTPU.sv:579-760       read node -> gather feature -> compare -> next node -> leaf
+//   rtl/DTEngine/core/FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131, Core.sv:486-541   leaf sum
+//
+// Mapping (score_tile_kernel): one lane = one tuple (R tuples per lane), a block owns a TILE of tuples
+// whose features sit in LDS feature-major ([feature][tuple]: bank == lane, so the per-lane feature
+// gather is conflict-free for any feature index).  The ensemble streams through LDS in chunks of CT
+// trees (double buffered; global->LDS DMA or register staged); every lane walks U trees at a time
+// (ILP) with the whole level loop unrolled, node offsets folded into DS immediates.
+#include <hip/hip_runtime.h>
+
+#include "ddt_internal.h"
+
+namespace ddt {
+
+// ---------------------------------------------------------------------------------------------------
+// LDS access by ABSOLUTE byte address.  The kernels declare no static __shared__ object, so the dynamic
+// LDS segment starts at address 0 (checked at build time: group_segment_fixed_size == 0) and a DS
+// address is just the byte offset.  Going through the `extern __shared__` symbol instead makes hipcc
+// add the (link-time) symbol address to every DS address -- one wasted VALU op per node visit.
+// ---------------------------------------------------------------------------------------------------
+#define DDT_LDS(T) __attribute__((address_space(3))) T
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_u2(uint32_t a) {
+  const u32x2 v = *reinterpret_cast<const DDT_LDS(u32x2)*>(a);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *reinterpret_cast<const DDT_LDS(uint32_t)*>(a); }
+__device__ __forceinline__ float lds_f32(uint32_t a) { return *reinterpret_cast<const DDT_LDS(float)*>(a); }
+__device__ __forceinline__ void lds_st_u32(uint32_t a, uint32_t v) { *reinterpret_cast<DDT_LDS(uint32_t)*>(a) = v; }
+__device__ __forceinline__ void lds_st_u4(uint32_t a, uint4 v) {
+  u32x4 t = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<DDT_LDS(u32x4)*>(a) = t;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reference-order fp32 accumulation state (per lane, per tuple)
+//   tree i -> PU i%8; group g=i/8 -> cluster g%C; per cluster acc <- s_g + acc in slot order; final
+//   sequential add over clusters.  SURVEY.md 8(a) A4/A11/A12.
+// ---------------------------------------------------------------------------------------------------
+// The C cluster accumulators live in registers a[0..C-1] and are ROTATED after every group so that the
+// current cluster is always a[0]: every index below is a compile-time constant.  (A `switch (cluster)`
+// over acc[k] gets merged by hipcc into one dynamically indexed access, which lands in scratch.)
+template <int R>
+struct RefAcc {
+  float a[R][8];
+  float half[R];
+  uint32_t pos;  // wave-uniform: groups pushed so far, mod C
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      half[r] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[r][k] = 0.f;
+    }
+    pos = 0;
+  }
+  __device__ __forceinline__ void rotate(uint32_t C) {  // a[k] <- a[k+1], a[C-1] <- a[0]
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float t = a[r][0];
+      if (C == 8u) {
+        a[r][0] = a[r][1]; a[r][1] = a[r][2]; a[r][2] = a[r][3]; a[r][3] = a[r][4];
+        a[r][4] = a[r][5]; a[r][5] = a[r][6]; a[r][6] = a[r][7]; a[r][7] = t;
+      } else if (C == 4u) {
+        a[r][0] = a[r][1]; a[r][1] = a[r][2]; a[r][2] = a[r][3]; a[r][3] = t;
+      } else if (C == 2u) {
+        a[r][0] = a[r][1]; a[r][1] = t;
+      }
+    }
+  }
+  // s[r] = 8-way pairwise sum of one PU group: acc <- s + acc on the group's cluster (FPAggregator.v:124-131)
+  __device__ __forceinline__ void push_group(const float (&s)[R], uint32_t C) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r][0] = s[r] + a[r][0];
+    rotate(C);
+    pos = (pos + 1u == C) ? 0u : pos + 1u;
+  }
+  // finish the current turn of the ring so that a[k] is cluster k again
+  __device__ __forceinline__ void align(uint32_t C) {
+    while (pos != 0u) {
+      rotate(C);
+      pos = (pos + 1u == C) ? 0u : pos + 1u;
+    }
+  }
+  // sequential add over clusters c = 0..C-1 (Core.sv:486-541); call align() first
+  __device__ __forceinline__ float total(int r, uint32_t C) const {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if ((uint32_t)k < C) t = a[r][k] + t;
+    return t;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// walk U trees x R tuples through D levels; returns the selected leaves
+// ---------------------------------------------------------------------------------------------------
+template <int D, int U, int R, int TREE_BYTES, bool SLOW>
+__device__ __forceinline__ void walk_trees(const int base /*compile-time*/,
+                                           const uint32_t (&lane_off)[R], const uint32_t miss_key,
+                                           float (&leaf)[R][U]) {
+  uint32_t m8[R][U];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int u = 0; u < U; ++u) m8[r][u] = 8u;  // root of the 1-based heap, in bytes
+
+#pragma unroll
+  for (int lvl = 0; lvl < D; ++lvl) {
+    uint2 nd[R][U];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        nd[r][u] = lds_u2(m8[r][u] + (uint32_t)(base + u * TREE_BYTES));  // ds_read_b64, tree offset = immediate
+    uint32_t f[R][U];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        f[r][u] = lds_u32((nd[r][u].y & 0x7FFFFFFFu) | lane_off[r]);  // ds_read_b32, conflict-free gather
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        bool right = (int32_t)f[r][u] >= (int32_t)nd[r][u].x;  // !(feature < threshold), DTPU.sv:655-657
+        if (SLOW) right = (f[r][u] == miss_key) ? ((nd[r][u].y >> 31) != 0u) : right;  // DTPU.sv:653,667
+        m8[r][u] = (m8[r][u] << 1) + (right ? 8u : 0u);
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      leaf[r][u] = lds_f32((m8[r][u] >> 1) + (uint32_t)(base + u * TREE_BYTES + (4 << D)));
+}
+
+// one LDS chunk (CT trees) for all R tuples of the lane
+template <int D, int U, int R, int CT, int BUF_OFF, int PHASE0, bool SLOW, int SUM>
+__device__ __forceinline__ void compute_chunk(const uint32_t (&lane_off)[R],
+                                              const uint32_t miss_key, const uint32_t C, RefAcc<R>& ra,
+                                              double (&dacc)[R]) {
+  constexpr int TREE_BYTES = 12 << D;
+  static_assert(CT % U == 0 && (U == 4 || U == 8), "sub-group geometry");
+#pragma unroll
+  for (int sg = 0; sg < CT / U; ++sg) {
+    float lf[R][U];
+    walk_trees<D, U, R, TREE_BYTES, SLOW>(BUF_OFF + sg * U * TREE_BYTES, lane_off, miss_key, lf);
+    if (SUM == 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) dacc[r] += (double)lf[r][u];  // stream order, fp64
+    } else if (U == 8) {
+      float s[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        s[r] = ((lf[r][0] + lf[r][1]) + (lf[r][2] + lf[r][3])) + ((lf[r][4 % U] + lf[r][5 % U]) + (lf[r][6 % U] + lf[r][7 % U]));
+      ra.push_group(s, C);
+    } else {  // U == 4: two sub-groups make one PU group
+      const int phase = (PHASE0 + sg) & 1;  // compile-time after unrolling
+      float p[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) p[r] = (lf[r][0] + lf[r][1]) + (lf[r][2] + lf[r][3]);
+      if (phase == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) ra.half[r] = p[r];
+      } else {
+        float s[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] = ra.half[r] + p[r];
+        ra.push_group(s, C);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// model chunk staging
+// ---------------------------------------------------------------------------------------------------
+template <int THREADS, int CHUNK_BYTES>
+struct StageRegs {
+  static constexpr int UNITS = CHUNK_BYTES / 16;
+  static constexpr int PER = (UNITS + THREADS - 1) / THREADS;
+  uint4 v[PER];
+  __device__ __forceinline__ void load(const uint4* __restrict__ img, uint32_t k, int tid) {
+    const uint4* src = img + (size_t)k * UNITS;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int unit = tid + i * THREADS;
+      if (unit < UNITS) v[i] = src[unit];
+    }
+  }
+  __device__ __forceinline__ void commit(int buf_off, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int unit = tid + i * THREADS;
+      if (unit < UNITS) lds_st_u4((uint32_t)(buf_off + unit * 16), v[i]);
+    }
+  }
+};
+
+// global -> LDS DMA (global_load_lds_dwordx4): LDS destination = M0 (wave-uniform base) + lane*16.
+// Issued through inline asm on purpose: with the builtin, hipcc (ROCm 7.2) cannot prove that the DMA's
+// LDS write does not alias the ds_reads of the *other* buffer and puts `s_waitcnt vmcnt(0)` in front of
+// the first ds_read of the compute phase, which serialises the prefetch with the compute.  The asm form
+// is invisible to that pass; the kernel waits for it itself (vmcnt(0) right before the chunk barrier).
+template <int THREADS, int CHUNK_BYTES>
+__device__ __forceinline__ void dma_chunk(const uint4* __restrict__ img, uint32_t k, int buf_off, int tid) {
+  constexpr int UNITS = CHUNK_BYTES / 16;
+  static_assert(UNITS % 64 == 0, "whole waves per DMA");
+  constexpr int PER = (UNITS + THREADS - 1) / THREADS;
+  const uint4* src = img + (size_t)k * UNITS;
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if (wave_base + i * THREADS < UNITS) {  // wave-uniform
+      const uint4* g = src + (tid + i * THREADS);
+      const uint32_t lds_addr = (uint32_t)(buf_off + (wave_base + i * THREADS) * 16);  // dynamic LDS starts at 0
+      asm volatile(
+          "s_mov_b32 m0, %0\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off"
+          :
+          : "s"(lds_addr), "v"(g)
+          : "memory");  // m0 is a reserved register for hipcc: it re-materialises m0 before its own uses
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the tile kernel
+// ---------------------------------------------------------------------------------------------------
+template <int D, int THREADS, int R, int CT, int U, int STAGE>
+__global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) {
+  constexpr int TILE = THREADS * R;
+  constexpr int TREE_BYTES = 12 << D;
+  constexpr int CHUNK_BYTES = TREE_BYTES * CT;
+  constexpr int ROW = TILE * 4;
+  constexpr int FEAT_OFF = (2 * CHUNK_BYTES + ROW - 1) / ROW * ROW;
+  static_assert((ROW & (ROW - 1)) == 0, "tile must be a power of two (row|lane OR trick)");
+  static_assert(CT == 4 || CT % 8 == 0, "chunk = half a PU group or whole groups");
+  static_assert(CT != 4 || U == 4, "CT=4 needs U=4");
+  // dynamic LDS only (launch-time size); addressed absolutely through lds_*()
+
+  const int tid = threadIdx.x;
+  const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+  const uint32_t n_chunks = a.n_chunks;
+
+  StageRegs<THREADS, CHUNK_BYTES> sr;
+  if (STAGE == 1) dma_chunk<THREADS, CHUNK_BYTES>(a.img, 0, 0, tid);
+  else sr.load(a.img, 0, tid);
+
+  // ---- stage the tuple tile, transposed to [feature][tuple]; detect missing values on the way ----
+  const uint32_t W = a.tuple_words;
+  uint32_t lane_off[R];
+  uint32_t miss_any = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t col = (uint32_t)(r * THREADS + tid);
+    lane_off[r] = col * 4u;
+    const uint64_t row = tile0 + col;
+    const bool valid = row < a.n;
+    const uint4* src = reinterpret_cast<const uint4*>(a.tuples + row * W);
+#pragma unroll 4
+    for (uint32_t q = 0; q < W / 4; ++q) {
+      uint4 v = valid ? src[q] : make_uint4(0u, 0u, 0u, 0u);
+      const uint32_t mx = v.x == a.miss_raw, my = v.y == a.miss_raw, mz = v.z == a.miss_raw, mw = v.w == a.miss_raw;
+      miss_any |= (mx | my | mz | mw) & (valid ? 1u : 0u);
+      if (a.ieee) {  // wave-uniform
+        v.x = mx ? kMissSentinelIeee : ieee_key(v.x);
+        v.y = my ? kMissSentinelIeee : ieee_key(v.y);
+        v.z = mz ? kMissSentinelIeee : ieee_key(v.z);
+        v.w = mw ? kMissSentinelIeee : ieee_key(v.w);
+      }
+      const uint32_t fa = (uint32_t)FEAT_OFF + (4u * q) * (uint32_t)ROW + col * 4u;
+      lds_st_u32(fa + 0 * ROW, v.x);
+      lds_st_u32(fa + 1 * ROW, v.y);
+      lds_st_u32(fa + 2 * ROW, v.z);
+      lds_st_u32(fa + 3 * ROW, v.w);
+    }
+  }
+  if (STAGE == 0) sr.commit(0, tid);
+  // block-wide OR of miss_any through one dynamic-LDS word per wave (no static __shared__: a static
+  // object would move the dynamic base off 0 and cost an extra address add per DS access)
+  const uint32_t flags = (uint32_t)FEAT_OFF + W * (uint32_t)ROW;
+  const unsigned long long wave_any = __ballot(miss_any != 0u);
+  if ((tid & 63) == 0) lds_st_u32(flags + (uint32_t)(tid >> 6) * 4u, wave_any != 0ull ? 1u : 0u);
+  __syncthreads();
+  uint32_t any = 0;
+#pragma unroll
+  for (int w = 0; w < THREADS / 64; ++w) any |= lds_u32(flags + (uint32_t)w * 4u);
+  const bool slow = __builtin_amdgcn_readfirstlane(any) != 0u;
+
+  RefAcc<R> ra;
+  ra.init();
+  double dacc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) dacc[r] = 0.0;
+  const uint32_t C = a.clusters, miss_key = a.miss_key;
+  const int SUM1 = (int)a.sum_mode;
+
+  // chunk k lives in buffer k&1; the loop is unrolled by two so buffer offsets are immediates
+#define DDT_COMPUTE(BUF, PH)                                                                                   \
+  do {                                                                                                         \
+    if (SUM1 == 0) {                                                                                           \
+      if (!slow) compute_chunk<D, U, R, CT, (BUF) * CHUNK_BYTES, PH, false, 0>(lane_off, miss_key, C, ra, dacc); \
+      else compute_chunk<D, U, R, CT, (BUF) * CHUNK_BYTES, PH, true, 0>(lane_off, miss_key, C, ra, dacc);        \
+    } else {                                                                                                   \
+      if (!slow) compute_chunk<D, U, R, CT, (BUF) * CHUNK_BYTES, PH, false, 1>(lane_off, miss_key, C, ra, dacc); \
+      else compute_chunk<D, U, R, CT, (BUF) * CHUNK_BYTES, PH, true, 1>(lane_off, miss_key, C, ra, dacc);        \
+    }                                                                                                          \
+  } while (0)
+
+  constexpr int PH1 = (CT == 4) ? 1 : 0;  // CT=4: odd chunks are the second half of a PU group
+  for (uint32_t k = 0; k < n_chunks; k += 2) {
+    if (STAGE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // chunk k is in buffer 0 for everyone; everyone is done with buffer 1
+    const bool more1 = k + 1 < n_chunks;
+    if (more1) {
+      if (STAGE == 1) dma_chunk<THREADS, CHUNK_BYTES>(a.img, k + 1, CHUNK_BYTES, tid);
+      else sr.load(a.img, k + 1, tid);
+    }
+    DDT_COMPUTE(0, 0);
+    if (!more1) break;
+    if (STAGE == 0) sr.commit(CHUNK_BYTES, tid);
+    if (STAGE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool more2 = k + 2 < n_chunks;
+    if (more2) {
+      if (STAGE == 1) dma_chunk<THREADS, CHUNK_BYTES>(a.img, k + 2, 0, tid);
+      else sr.load(a.img, k + 2, tid);
+    }
+    DDT_COMPUTE(1, PH1);
+    if (STAGE == 0 && more2) sr.commit(0, tid);
+  }
+#undef DDT_COMPUTE
+
+  ra.align(C);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint64_t row = tile0 + (uint64_t)(r * THREADS + tid);
+    if (row < a.n) a.out[row] = (SUM1 == 0) ? ra.total(r, C) : (float)dacc[r];
+  }
+}
+
+template <int D, int THREADS, int R, int CT, int U, int STAGE>
+static hipError_t launch_tile(const ScoreArgs& a, const Variant& v, hipStream_t s) {
+  auto kern = score_tile_kernel<D, THREADS, R, CT, U, STAGE>;
+  const uint32_t lds = v.lds_bytes(a.tuple_words);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const uint64_t tile = (uint64_t)THREADS * R;
+  const uint64_t blocks = (a.n + tile - 1) / tile;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(THREADS), lds, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// generic kernel: any D (1..16), any F (1..2048).  Lane = tuple, 256 tuples per block, one tree at a
+// time.  Features in LDS when the tile fits, else gathered from global memory; tree in LDS when it
+// fits (12*2^D bytes), else nodes are read from global memory (L2).  Correctness path for shapes the
+// specialised tile kernels do not cover; same image format with w2 = feature index | miss_right<<31.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kGenericLdsBudget = 150u * 1024u;
+
+uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds) {
+  const uint64_t feat = (uint64_t)tuple_words * kGenericThreads * 4u;
+  const uint64_t tree = 12ull << levels;
+  bool f = feat <= 96u * 1024u;
+  bool t = tree + (f ? feat : 0) <= kGenericLdsBudget;
+  if (feat_in_lds) *feat_in_lds = f;
+  if (tree_in_lds) *tree_in_lds = t;
+  return (uint32_t)((f ? feat : 0) + (t ? tree : 0));
+}
+
+template <bool FEAT_LDS, bool TREE_LDS>
+__global__ __launch_bounds__(kGenericThreads) void score_generic_kernel(const ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TILE = kGenericThreads;
+  const int tid = threadIdx.x;
+  const uint32_t W = a.tuple_words, D = a.levels;
+  const uint64_t row = (uint64_t)blockIdx.x * TILE + tid;
+  const bool valid = row < a.n;
+  const uint32_t* xrow = a.tuples + (valid ? row : 0) * W;
+  uint32_t* feat = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t tree_bytes = 12u << D;
+  unsigned char* tree_lds = smem + (FEAT_LDS ? W * TILE * 4u : 0u);
+
+  if (FEAT_LDS) {
+    for (uint32_t j = 0; j < W; ++j) {
+      uint32_t v = valid ? xrow[j] : 0u;
+      if (a.ieee) v = (v == a.miss_raw) ? kMissSentinelIeee : ieee_key(v);
+      feat[j * TILE + tid] = v;
+    }
+  }
+  RefAcc<1> ra;
+  ra.init();
+  double dacc = 0.0;
+  float grp[8];
+  for (uint32_t t8 = 0; t8 < a.n_trees; t8 += 8u) {
+#pragma unroll
+   for (uint32_t tu = 0; tu < 8u; ++tu) {
+    const uint32_t t = t8 + tu;
+    const unsigned char* timg = reinterpret_cast<const unsigned char*>(a.img) + (size_t)t * tree_bytes;
+    if (TREE_LDS) {
+      __syncthreads();  // previous tree fully consumed (also publishes feat on the first pass)
+      for (uint32_t off = tid * 16u; off < tree_bytes; off += TILE * 16u)
+        *reinterpret_cast<uint4*>(tree_lds + off) = *reinterpret_cast<const uint4*>(timg + off);
+      __syncthreads();
+    }
+    const unsigned char* tb = TREE_LDS ? tree_lds : timg;
+    uint32_t m = 1;
+    for (uint32_t lvl = 0; lvl < D; ++lvl) {
+      const uint2 nd = *reinterpret_cast<const uint2*>(tb + (size_t)m * 8u);
+      const uint32_t j = nd.y & 0x7FFFFFFFu;
+      uint32_t f;
+      if (FEAT_LDS) f = feat[j * TILE + tid];
+      else {
+        f = xrow[j];
+        if (a.ieee) f = (f == a.miss_raw) ? kMissSentinelIeee : ieee_key(f);
+      }
+      bool right = (int32_t)f >= (int32_t)nd.x;
+      right = (f == a.miss_key) ? ((nd.y >> 31) != 0u) : right;
+      m = 2u * m + (right ? 1u : 0u);
+    }
+    const float leaf = *reinterpret_cast<const float*>(tb + (8u << D) + (size_t)(m - (1u << D)) * 4u);
+    if (a.sum_mode == 1) dacc += (double)leaf;
+    grp[tu] = leaf;
+   }
+   if (a.sum_mode != 1) {
+     const float s[1] = {((grp[0] + grp[1]) + (grp[2] + grp[3])) + ((grp[4] + grp[5]) + (grp[6] + grp[7]))};
+     ra.push_group(s, a.clusters);
+   }
+  }
+  ra.align(a.clusters);
+  if (valid) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, a.clusters);
+}
+
+hipError_t launch_generic(const ScoreArgs& a, const Variant&, hipStream_t s) {
+  bool fl, tl;
+  const uint32_t lds = generic_lds_bytes(a.levels, a.tuple_words, &fl, &tl);
+  const uint64_t blocks = (a.n + kGenericThreads - 1) / kGenericThreads;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+#define DDT_GEN(FL, TL)                                                                                              \
+  do {                                                                                                               \
+    auto kern = score_generic_kernel<FL, TL>;                                                                        \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                                                   \
+    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(kGenericThreads), lds, s, a);                              \
+  } while (0)
+  if (fl && tl) DDT_GEN(true, true);
+  else if (fl) DDT_GEN(true, false);
+  else if (tl) DDT_GEN(false, true);
+  else DDT_GEN(false, false);
+#undef DDT_GEN
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// chain sum of partial score vectors: out = (((p0 + p1) + p2) + ...)  (ResultsCombiner.sv:292-311)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chain_sum_kernel(const float* __restrict__ parts, uint32_t n_parts, size_t n,
+                                                        float* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float run = parts[i];
+    for (uint32_t p = 1; p < n_parts; ++p) run = parts[(size_t)p * n + i] + run;  // local + upstream
+    out[i] = run;
+  }
+}
+
+hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048 * 8) blocks = 2048 * 8;
+  hipLaunchKernelGGL(chain_sum_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, parts, n_parts, n, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// synthetic tuple generator: x[r][j] = unit(splitmix64(SEED_X + r*F + j))
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void synth_tuples_kernel(uint32_t* __restrict__ out, uint64_t row0, size_t n, uint32_t F,
+                                                           uint32_t W, int dist, uint32_t missing_bits) {
+  const size_t total = n * (size_t)W;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t r = i / W;
+    const uint32_t j = (uint32_t)(i - r * W);
+    uint32_t bits = 0u;
+    if (j < F) {
+      const uint64_t h = splitmix64(kSeedX + (row0 + r) * (uint64_t)F + j);
+      float v = (float)(h >> 40) * (1.0f / 16777216.0f);
+      if (dist == 1) {
+        v = v * 2.0f - 1.0f;
+        bits = (((h >> 8) & 0xFFFFull) % 20ull == 0ull) ? missing_bits : __float_as_uint(v);
+      } else {
+        bits = __float_as_uint(v);
+      }
+    }
+    out[i] = bits;
+  }
+}
+
+hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits,
+                               hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const uint32_t W = (F + 3u) / 4u * 4u;
+  hipLaunchKernelGGL(synth_tuples_kernel, dim3(256 * 16), dim3(256), 0, s, out, row0, n, F, W, dist, missing_bits);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// variant table
+// ---------------------------------------------------------------------------------------------------
+#define DDT_V(NAME, D, TH, R, CT, U, ST) \
+  Variant { NAME, D, TH, R, CT, U, ST, &launch_tile<D, TH, R, CT, U, ST> }
+
+static const Variant g_variants[] = {
+    Variant{"generic", 0, kGenericThreads, 1, 1, 1, 0, &launch_generic},
+    // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB
+    DDT_V("d8_t1024_r1_c4_u4_dma", 8, 1024, 1, 4, 4, 1),
+    DDT_V("d8_t1024_r1_c4_u4_reg", 8, 1024, 1, 4, 4, 0),
+    DDT_V("d8_t512_r2_c4_u4_dma", 8, 512, 2, 4, 4, 1),
+    DDT_V("d8_t512_r1_c4_u4_dma", 8, 512, 1, 4, 4, 1),
+    DDT_V("d8_t512_r1_c8_u8_dma", 8, 512, 1, 8, 8, 1),
+    DDT_V("d8_t256_r1_c4_u4_dma", 8, 256, 1, 4, 4, 1),
+    DDT_V("d8_t256_r1_c8_u8_dma", 8, 256, 1, 8, 8, 1),
+    DDT_V("d8_t256_r2_c4_u4_dma", 8, 256, 2, 4, 4, 1),
+    DDT_V("d8_t256_r1_c8_u4_reg", 8, 256, 1, 8, 4, 0),
+    // depth 6 (BASELINE config 2): tree = 768 B
+    DDT_V("d6_t256_r1_c16_u4_dma", 6, 256, 1, 16, 4, 1),
+    DDT_V("d6_t512_r1_c16_u8_dma", 6, 512, 1, 16, 8, 1),
+    DDT_V("d6_t1024_r1_c16_u4_dma", 6, 1024, 1, 16, 4, 1),
+    // depth 4 (BASELINE config 1): tree = 192 B
+    DDT_V("d4_t256_r1_c64_u8_dma", 4, 256, 1, 64, 8, 1),
+};
+
+int num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
+const Variant& variant(int i) { return g_variants[i]; }
+
+}  // namespace ddt

@@ -1,0 +1,8 @@
+"""ddt -- host-side Python mirror of libddt.so (MI355X-native decision-tree-ensemble scoring).
+
+The product is the HIP library behind the C-ABI in include/ddt.h; this package is plumbing (ctypes +
+torch device memory / streams / torch.distributed)."""
+from ._lib import Info, Params, Stats, build, lib  # noqa: F401
+from .engine import (DDTError, Engine, default_clusters, findex_lines_per_tree, make_params,  # noqa: F401
+                     synth_model, synth_tuples_host, tuple_words, variant_names, weights_lines_per_tree)
+from .sharded import ShardedScorer, chain_sum, shard_bounds  # noqa: F401

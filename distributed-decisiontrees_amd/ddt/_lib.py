@@ -1,0 +1,97 @@
+"""Loader for lib/libddt.so (the C-ABI of include/ddt.h).  Fails loudly when the library is missing:
+there is no Python/CPU fallback for the scoring path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libddt.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+# every symbol include/ddt.h declares (tests check the built library exports exactly these)
+SYMBOLS = [
+    "ddt_create", "ddt_destroy", "ddt_load_model", "ddt_load_model_shard", "ddt_score", "ddt_score_device",
+    "ddt_chain_sum_device", "ddt_get_info", "ddt_get_stats", "ddt_strerror", "ddt_last_error", "ddt_set_option",
+    "ddt_num_variants", "ddt_variant_name", "ddt_synth_model", "ddt_synth_tuples_host", "ddt_synth_tuples_device",
+]
+
+
+class Params(C.Structure):
+    """ddt_params (include/ddt.h) == the reference's CSR 204/205 fields (EngineCSR.sv:218-233)."""
+
+    _fields_ = [
+        ("num_trees", C.c_uint32), ("num_levels", C.c_uint32), ("num_features", C.c_uint32),
+        ("missing_bits", C.c_uint32), ("weights_lines_per_tree", C.c_uint32),
+        ("findex_lines_per_tree", C.c_uint32), ("cmp_mode", C.c_uint32), ("clusters_per_tuple", C.c_uint32),
+        ("sum_mode", C.c_uint32), ("reserved", C.c_uint32 * 3),
+    ]
+
+
+class Info(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("device_id", C.c_int32), ("tree_begin", C.c_uint32), ("tree_end", C.c_uint32),
+        ("num_levels", C.c_uint32), ("num_features", C.c_uint32), ("tuple_words", C.c_uint32),
+        ("variant", C.c_uint32), ("tile_tuples", C.c_uint32), ("block_threads", C.c_uint32),
+        ("lds_bytes", C.c_uint32), ("model_bytes_unpadded", C.c_uint64), ("image_bytes", C.c_uint64),
+        ("variant_name", C.c_char * 64), ("device_name", C.c_char * 64),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("tuples_in", C.c_uint64), ("tuples_out", C.c_uint64), ("tuple_lines_in", C.c_uint64),
+        ("result_lines_out", C.c_uint64), ("model_lines_in", C.c_uint64), ("score_calls", C.c_uint64),
+        ("kernel_launches", C.c_uint64), ("prog_ms", C.c_double), ("exec_ms", C.c_double),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s"]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
+            "The scoring path has no fallback.")
+    # torch bundles its own HIP runtime (same soname); import it first so that libddt.so binds to the
+    # runtime that owns torch's device allocations and streams.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the pure C-ABI use
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32, u64, i32, i64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_int64
+    PP = C.POINTER(Params)
+    L.ddt_create.restype, L.ddt_create.argtypes = i32, [C.POINTER(vp), i32]
+    L.ddt_destroy.restype, L.ddt_destroy.argtypes = None, [vp]
+    L.ddt_load_model.restype, L.ddt_load_model.argtypes = i32, [vp, PP, vp, sz, vp, sz]
+    L.ddt_load_model_shard.restype, L.ddt_load_model_shard.argtypes = i32, [vp, PP, vp, sz, vp, sz, u32, u32]
+    L.ddt_score.restype, L.ddt_score.argtypes = i32, [vp, vp, sz, vp]
+    L.ddt_score_device.restype, L.ddt_score_device.argtypes = i32, [vp, vp, sz, vp, vp]
+    L.ddt_chain_sum_device.restype, L.ddt_chain_sum_device.argtypes = i32, [vp, vp, u32, sz, vp, vp]
+    L.ddt_get_info.restype, L.ddt_get_info.argtypes = i32, [vp, C.POINTER(Info)]
+    L.ddt_get_stats.restype, L.ddt_get_stats.argtypes = i32, [vp, C.POINTER(Stats)]
+    L.ddt_strerror.restype, L.ddt_strerror.argtypes = C.c_char_p, [i32]
+    L.ddt_last_error.restype, L.ddt_last_error.argtypes = C.c_char_p, [vp]
+    L.ddt_set_option.restype, L.ddt_set_option.argtypes = i32, [vp, C.c_char_p, i64]
+    L.ddt_num_variants.restype, L.ddt_num_variants.argtypes = i32, []
+    L.ddt_variant_name.restype, L.ddt_variant_name.argtypes = i32, [i32, C.c_char_p, sz]
+    L.ddt_synth_model.restype, L.ddt_synth_model.argtypes = i32, [u32, u32, u32, i32, vp, vp]
+    L.ddt_synth_tuples_host.restype, L.ddt_synth_tuples_host.argtypes = i32, [vp, u64, sz, u32, i32, u32]
+    L.ddt_synth_tuples_device.restype, L.ddt_synth_tuples_device.argtypes = i32, [vp, vp, u64, sz, u32, i32, u32, vp]
+    _lib = L
+    return L

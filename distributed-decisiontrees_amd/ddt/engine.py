@@ -1,0 +1,185 @@
+"""Host-side mirror of the engine interface above the C-ABI (include/ddt.h).
+
+The reference has no host software; what a host program must do is fixed by its hardware contract:
+write the run parameters (CSR 201-207, rtl/DTEngine/EngineCSR.sv:190-248), stream the model
+(weights lines then feature-index lines, rtl/DTEngine/PCIeReceiver.sv:136-139,230-275), stream tuples,
+read back result lines (rtl/DTEngine/ResultsCombiner.sv:136-160).  `Engine` is that sequence as an
+object: Engine(device) -> load_model(params, weights_lines, findex_lines) -> score(tuple_lines).
+PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Info, Params, Stats
+
+MISSING_DEFAULT = 0x7FC00000
+
+
+class DDTError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        msg = _lib.lib().ddt_strerror(code).decode()
+        super().__init__(f"ddt error {code} ({msg}){': ' + detail if detail else ''}")
+
+
+def weights_lines_per_tree(D: int) -> int:
+    return ((1 << (D + 1)) - 1 + 3) // 4
+
+
+def findex_lines_per_tree(D: int) -> int:
+    return ((1 << D) - 1 + 7) // 8
+
+
+def tuple_words(F: int) -> int:
+    return (F + 3) // 4 * 4
+
+
+def default_clusters(T: int) -> int:
+    """Smallest C in {1,2,4,8} whose 8 PUs x 16 trees x C slots hold T trees (DTPU.sv:74, Core.sv:291-316)."""
+    for c in (1, 2, 4, 8):
+        if T <= 128 * c:
+            return c
+    return 8
+
+
+def make_params(T: int, D: int, F: int, missing_bits: int = MISSING_DEFAULT, cmp_mode: int = 0,
+                clusters: int | None = None, sum_mode: int = 0) -> Params:
+    p = Params()
+    p.num_trees, p.num_levels, p.num_features, p.missing_bits = T, D, F, missing_bits
+    p.weights_lines_per_tree, p.findex_lines_per_tree = weights_lines_per_tree(D), findex_lines_per_tree(D)
+    p.cmp_mode, p.sum_mode = cmp_mode, sum_mode
+    p.clusters_per_tuple = default_clusters(T) if clusters is None else clusters
+    return p
+
+
+def synth_model(T: int, D: int, F: int, dist: int = 0):
+    """Deterministic synthetic model of SURVEY.md 8(d) in the reference wire format -> (wlines u32, flines u16)."""
+    w = np.zeros(T * weights_lines_per_tree(D) * 4, np.uint32)
+    f = np.zeros(T * findex_lines_per_tree(D) * 8, np.uint16)
+    rc = _lib.lib().ddt_synth_model(T, D, F, dist, w.ctypes.data, f.ctypes.data)
+    if rc:
+        raise DDTError(rc)
+    return w, f
+
+
+def synth_tuples_host(row0: int, n: int, F: int, dist: int = 0, missing_bits: int = MISSING_DEFAULT) -> np.ndarray:
+    out = np.zeros((n, tuple_words(F)), np.uint32)
+    rc = _lib.lib().ddt_synth_tuples_host(out.ctypes.data, row0, n, F, dist, missing_bits)
+    if rc:
+        raise DDTError(rc)
+    return out
+
+
+class Engine:
+    """One engine == one GPU (the analogue of one FPGA running DTInference)."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.ddt_create(C.byref(h), device)
+        if rc:
+            raise DDTError(rc, "ddt_create")
+        self._h = h
+        self.device = device
+        self.params = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ddt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            raise DDTError(rc, self._L.ddt_last_error(self._h).decode())
+
+    # ---- model ------------------------------------------------------------------------------------
+    def load_model(self, params: Params, wlines: np.ndarray, flines: np.ndarray, shard_index: int = 0,
+                   shard_count: int = 1):
+        w = np.ascontiguousarray(wlines).view(np.uint32).reshape(-1)
+        f = np.ascontiguousarray(flines).view(np.uint16).reshape(-1)
+        self._check(self._L.ddt_load_model_shard(self._h, C.byref(params), w.ctypes.data, w.size // 4,
+                                                 f.ctypes.data, f.size // 8, shard_index, shard_count))
+        self.params = params
+        return self
+
+    def set_option(self, key: str, value: int):
+        self._check(self._L.ddt_set_option(self._h, key.encode(), int(value)))
+
+    # ---- scoring ----------------------------------------------------------------------------------
+    def score(self, tuple_lines: np.ndarray) -> np.ndarray:
+        """Host buffers through the pinned double-buffered feeder (the PCIe tuple stream)."""
+        t = np.ascontiguousarray(tuple_lines).view(np.uint32)
+        W = tuple_words(self.params.num_features)
+        t = t.reshape(-1, W)
+        out = np.empty(t.shape[0], np.float32)
+        self._check(self._L.ddt_score(self._h, t.ctypes.data, t.shape[0], out.ctypes.data))
+        return out
+
+    def score_device(self, d_tuples, out=None, stream=None):
+        """torch CUDA tensor of tuple lines ([n, W] int32/uint32/float32) -> torch float32 [n], asynchronous."""
+        import torch
+
+        W = tuple_words(self.params.num_features)
+        assert d_tuples.is_cuda and d_tuples.is_contiguous() and d_tuples.element_size() == 4
+        n = d_tuples.numel() // W
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=d_tuples.device)
+        assert out.is_cuda and out.is_contiguous() and out.dtype == torch.float32 and out.numel() >= n
+        s = torch.cuda.current_stream(d_tuples.device) if stream is None else stream
+        self._check(self._L.ddt_score_device(self._h, d_tuples.data_ptr(), n, out.data_ptr(), s.cuda_stream))
+        return out
+
+    def chain_sum_device(self, parts, out=None, stream=None):
+        """parts: torch float32 [G, n] -> out[n] = (((p0+p1)+p2)+...) in the reference's chain order."""
+        import torch
+
+        assert parts.is_cuda and parts.is_contiguous() and parts.dtype == torch.float32 and parts.dim() == 2
+        G, n = parts.shape
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=parts.device)
+        s = torch.cuda.current_stream(parts.device) if stream is None else stream
+        self._check(self._L.ddt_chain_sum_device(self._h, parts.data_ptr(), G, n, out.data_ptr(), s.cuda_stream))
+        return out
+
+    def synth_tuples_device(self, row0: int, n: int, F: int, dist: int = 0, missing_bits: int = MISSING_DEFAULT,
+                            out=None, stream=None):
+        import torch
+
+        W = tuple_words(F)
+        if out is None:
+            out = torch.empty((n, W), dtype=torch.int32, device=f"cuda:{self.device}")
+        s = torch.cuda.current_stream(out.device) if stream is None else stream
+        self._check(self._L.ddt_synth_tuples_device(self._h, out.data_ptr(), row0, n, F, dist, missing_bits,
+                                                    s.cuda_stream))
+        return out
+
+    # ---- introspection ----------------------------------------------------------------------------
+    def info(self) -> Info:
+        i = Info()
+        self._check(self._L.ddt_get_info(self._h, C.byref(i)))
+        return i
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self._check(self._L.ddt_get_stats(self._h, C.byref(s)))
+        return s
+
+
+def variant_names():
+    L = _lib.lib()
+    out = []
+    for v in range(L.ddt_num_variants()):
+        b = C.create_string_buffer(64)
+        L.ddt_variant_name(v, b, 64)
+        out.append(b.value.decode())
+    return out

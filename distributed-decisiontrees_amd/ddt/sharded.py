@@ -1,0 +1,104 @@
+"""Tree-sharded multi-GPU scoring: one process per GPU, torch.distributed ("nccl" == RCCL over xGMI).
+
+Reference mode reproduced (rtl/DTEngine/DTInference.sv:28-37, mode "trees partitioned, tuples broadcast,
+results aggregated"): rank g holds the contiguous tree shard g of ceil(T/G) trees
+(PCIeReceiver.sv:241-264), every rank scores ALL tuples against its shard, and the per-tuple partial
+scores are summed across ranks -- the reference does that with a chain of fp32 adders, host -> dev1 ->
+... (ResultsCombiner.sv:292-311,359-369).  Two combine modes:
+
+  "allreduce"  one RCCL all-reduce (sum) per chunk of partial scores -- the collective BASELINE.json
+               names.  The ring's summation order is RCCL's, so results match the reference chain order
+               to fp32 rounding (|err| <= ~G ulp), not bit for bit.
+  "chain"      deterministic: all-to-all (each rank receives every rank's slice of its 1/G segment),
+               fixed-order chain add p0+p1+...+p(G-1) on the owner, all-gather.  Same bytes on the wire
+               as a ring all-reduce, point-to-point over the fully connected xGMI mesh, and bit-exact
+               with the reference's chain order.
+
+Chunks are pipelined: chunk k's collective runs on RCCL's stream while chunk k+1 is being scored.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+
+def shard_bounds(T: int, G: int):
+    """Contiguous shards of ceil(T/G) trees in stream order (PCIeReceiver.sv:241-264)."""
+    per = (T + G - 1) // G
+    return [(min(g * per, T), min((g + 1) * per, T)) for g in range(G)]
+
+
+def chain_sum(parts):
+    """parts [G, n] (torch, any device) -> (((p0 + p1) + p2) + ...), fp32, the reference's hop order."""
+    run = parts[0].clone()
+    for g in range(1, parts.shape[0]):
+        run = parts[g] + run  # local + upstream, ResultsCombiner.sv:292-311
+    return run
+
+
+class ShardedScorer:
+    """Combine per-rank partial scores into full scores on every rank.
+
+    partial_fn(tuples, out) must write this rank's partial scores for `tuples` into `out` (asynchronously
+    on the current stream for CUDA tensors).  chain_fn(parts[G, n]) -> [n] is the ordered chain add
+    (defaults to the torch implementation above; the GPU path passes Engine.chain_sum_device).
+    """
+
+    def __init__(self, partial_fn: Callable, tuple_words: int, group=None, mode: str = "allreduce",
+                 chunk_rows: int = 1 << 23, chain_fn: Optional[Callable] = None):
+        import torch.distributed as dist
+
+        assert mode in ("allreduce", "chain")
+        self.partial_fn, self.W, self.group, self.mode = partial_fn, tuple_words, group, mode
+        self.chunk_rows = int(chunk_rows)
+        self.chain_fn = chain_fn or chain_sum
+        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    @classmethod
+    def from_engine(cls, engine, **kw):
+        from .engine import tuple_words
+
+        def partial(tuples, out):
+            engine.score_device(tuples, out=out)
+
+        def chain(parts):
+            return engine.chain_sum_device(parts.contiguous())
+
+        return cls(partial, tuple_words(engine.params.num_features), chain_fn=chain, **kw)
+
+    def score(self, tuples, out=None):
+        """tuples: [n, W] 4-byte tensor (replicated on every rank) -> fp32 [n] full scores on every rank."""
+        import torch
+        import torch.distributed as dist
+
+        n = tuples.numel() // self.W
+        tuples = tuples.reshape(n, self.W)
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=tuples.device)
+        if self.G == 1:
+            self.partial_fn(tuples, out)
+            return out
+        works, keep = [], []
+        G = self.G
+        for lo in range(0, n, self.chunk_rows):
+            hi = min(n, lo + self.chunk_rows)
+            if self.mode == "allreduce":
+                o = out[lo:hi]
+                self.partial_fn(tuples[lo:hi], o)
+                works.append(dist.all_reduce(o, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                m = hi - lo
+                seg = (m + G - 1) // G  # segment owned by each rank (last one zero padded)
+                part = torch.zeros(G * seg, dtype=torch.float32, device=tuples.device)
+                self.partial_fn(tuples[lo:hi], part[:m])
+                recv = torch.empty(G * seg, dtype=torch.float32, device=tuples.device)
+                dist.all_to_all_single(recv, part, group=self.group)  # recv[g*seg:(g+1)*seg] = rank g's slice of my segment
+                mine = self.chain_fn(recv.view(G, seg))
+                full = torch.empty(G * seg, dtype=torch.float32, device=tuples.device)
+                works.append(dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group, async_op=True))
+                keep.append((lo, hi, full, part, recv, mine))
+        for w in works:
+            w.wait()
+        for (lo, hi, full, *_rest) in keep:
+            out[lo:hi] = full[: hi - lo]
+        return out

@@ -1,0 +1,138 @@
+/*
+ * ddt.h -- C-ABI of libddt.so: MI355X-native decision-tree-ensemble scoring engine.
+ *
+ * The reference (fpgasystems/Distributed-DecisionTrees) is FPGA RTL with NO host software: the only
+ * host-visible contract it defines is (1) the soft-register (CSR) parameter map,
+ * rtl/DTEngine/EngineCSR.sv:190-305, and (2) the 128-bit-line stream formats for weights, feature
+ * indexes, tuples and results, rtl/DTEngine/PCIeReceiver.sv:136-149 / ResultsCombiner.sv:136-203 with
+ * the little-endian word packing of rtl/DTEngine/core/PipelinedMUX.sv:65.  This header is that contract
+ * restated as a C-ABI: every entry point names the reference interface it replaces.  The function
+ * names are this repository's (there is no reference software API to copy).
+ *
+ * One engine == one GPU (the analogue of one FPGA running DTInference, rtl/DTEngine/DTInference.sv:46-75).
+ * Like the reference (one job between `start` and `process_done`, Core.sv:167-187) an engine is NOT
+ * re-entrant: one in-flight ddt_score* per engine; independent engines are independent.
+ * Ownership: the caller owns every buffer; the model is copied at load; tuple/score pointers are not
+ * retained after a synchronous call returns (after stream completion for the *_device calls).
+ *
+ * There is NO CPU fallback in this library: without a usable HIP device ddt_create() fails.
+ */
+#ifndef DDT_H
+#define DDT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDT_ABI_VERSION 1
+
+/* Return codes.  The reference has no error signalling beyond status counters (EngineCSR.sv:113-126);
+ * every check below is an addition of this library. */
+enum {
+  DDT_OK = 0,
+  DDT_EINVAL = -1,       /* bad argument / parameter out of range                          */
+  DDT_ENOMEM = -2,       /* host or device allocation failed                               */
+  DDT_EHIP = -3,         /* a HIP runtime call failed (see ddt_last_error)                 */
+  DDT_ESTATE = -4,       /* call order: no model loaded, etc.                              */
+  DDT_EUNSUPPORTED = -5, /* valid in the reference format but not supported by this build  */
+  DDT_ENODEVICE = -6     /* no usable gfx950 device: the engine never falls back to CPU    */
+};
+
+/* Run parameters: one-to-one with the reference's CSR 204/205 fields (EngineCSR.sv:218-233).       */
+typedef struct ddt_params {
+  uint32_t num_trees;              /* trees in the model stream; slots beyond are EMPTY = +0 (DTPU.sv:544,760) */
+  uint32_t num_levels;             /* D, compare levels per tree, CSR205[35:32]; 1..16                 */
+  uint32_t num_features;           /* F; tuple lines = ceil(F/4) = CSR204[63:48]; 1..2048 (DTPU.sv:72)  */
+  uint32_t missing_bits;           /* CSR205[31:0]: bit pattern that means "feature missing" (DTPU.sv:653) */
+  uint32_t weights_lines_per_tree; /* CSR204[31:16]; >= ceil((2^(D+1)-1)/4)                            */
+  uint32_t findex_lines_per_tree;  /* CSR204[47:32]; >= ceil((2^D-1)/8)                                */
+  uint32_t cmp_mode;               /* 0 = reference compare: signed-int32 on raw fp32 bits (DTPU.sv:655);
+                                      1 = IEEE-754 '<' (extension)                                      */
+  uint32_t clusters_per_tuple;     /* C in {1,2,4,8}, CSR205[47:44]: fixes the fp32 summation order
+                                      (Core.sv:291-316,486-541)                                         */
+  uint32_t sum_mode;               /* 0 = reference adder order in fp32 (bit-exact with the RTL's adder
+                                      network on normal values); 1 = fp64 accumulate in stream order,
+                                      rounded once to fp32 (extension)                                  */
+  uint32_t reserved[3];            /* must be 0 */
+} ddt_params;
+
+typedef struct ddt_engine ddt_engine;
+
+/* What the engine decided at load time; also the inputs of the roofline arithmetic. */
+typedef struct ddt_info {
+  uint32_t abi_version;
+  int32_t  device_id;
+  uint32_t tree_begin, tree_end;     /* shard held by this engine (global tree ids)                 */
+  uint32_t num_levels, num_features, tuple_words; /* tuple_words = 4*ceil(F/4)                      */
+  uint32_t variant;                  /* kernel variant id in use                                    */
+  uint32_t tile_tuples, block_threads, lds_bytes;
+  uint64_t model_bytes_unpadded;     /* T_local*(4*(2^(D+1)-1) + 2*(2^D-1)): algorithmic model bytes */
+  uint64_t image_bytes;              /* packed device image actually read per tile pass             */
+  char     variant_name[64];
+  char     device_name[64];
+} ddt_info;
+
+/* Observability counters, the analogue of CSR 220-226 / appStatus (EngineCSR.sv:113-126,
+ * DTInference.sv:314-374). */
+typedef struct ddt_stats {
+  uint64_t tuples_in, tuples_out;    /* DTInference.sv:367-372                                      */
+  uint64_t tuple_lines_in, result_lines_out, model_lines_in;
+  uint64_t score_calls, kernel_launches;
+  double   prog_ms, exec_ms;         /* progCycles / execCycles equivalents (host wall, ms)          */
+} ddt_stats;
+
+/* -- lifecycle (replaces: CSR 200 start / reset, EngineCSR.sv:191-193, Core.sv:167-187) -------------- */
+int  ddt_create(ddt_engine** out, int device_id);
+void ddt_destroy(ddt_engine* e);
+
+/* -- model load (replaces: the weights + feature-index PCIe streams, PCIeReceiver.sv:136-139,230-275,
+ *    DTPU.sv:282-354, and CSR 202-205).  Both streams are in the reference wire format, host memory. -- */
+int ddt_load_model(ddt_engine* e, const ddt_params* p, const void* weights_lines, size_t n_wlines,
+                   const void* findex_lines, size_t n_flines);
+/* Tree-sharded multi-device mode: keep only shard `shard_index` of `shard_count` contiguous shards of
+ * ceil(T/shard_count) trees -- the per-device split of CSR 203 / PCIeReceiver.sv:241-264.            */
+int ddt_load_model_shard(ddt_engine* e, const ddt_params* p, const void* weights_lines, size_t n_wlines,
+                         const void* findex_lines, size_t n_flines, uint32_t shard_index,
+                         uint32_t shard_count);
+
+/* -- scoring (replaces: the tuple PCIe stream in / result stream out, PCIeReceiver.sv:276-312,
+ *    ResultsCombiner.sv:136-160,193; N need not be a multiple of 4 here, unlike A14) ------------------ */
+/* Host buffers: tuple_lines = n_tuples * ceil(F/4) lines of 16 B; scores_out = n_tuples fp32.
+ * Streams the batch through a pinned, double-buffered hipMemcpyAsync feeder (the PCIe feeder).      */
+int ddt_score(ddt_engine* e, const void* tuple_lines, size_t n_tuples, float* scores_out);
+/* Device buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = the null stream).              */
+int ddt_score_device(ddt_engine* e, const void* d_tuple_lines, size_t n_tuples, float* d_scores,
+                     void* hip_stream);
+
+/* -- multi-device combine (replaces: ResultsCombiner.sv:292-311,359-369 chain add) -------------------
+ * d_parts = n_parts arrays of n fp32 partial scores laid out [part][n]; out[i] = (((p0+p1)+p2)+...),
+ * i.e. the reference's host -> dev1 -> ... chain order.  Used by the deterministic multi-GPU path.   */
+int ddt_chain_sum_device(ddt_engine* e, const float* d_parts, uint32_t n_parts, size_t n, float* d_out,
+                         void* hip_stream);
+
+/* -- introspection ----------------------------------------------------------------------------------- */
+int ddt_get_info(const ddt_engine* e, ddt_info* out);
+int ddt_get_stats(const ddt_engine* e, ddt_stats* out);
+const char* ddt_strerror(int code);
+const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure on this engine */
+/* Tuning knobs: "variant" (kernel variant id, -1 = auto), "feeder_rows" (rows per feeder chunk). */
+int ddt_set_option(ddt_engine* e, const char* key, int64_t value);
+int ddt_num_variants(void);
+int ddt_variant_name(int variant, char* buf, size_t buflen);
+
+/* -- deterministic synthetic inputs of SURVEY.md 8(d) (bench/test support; device generator so that
+ *    the timed region starts with inputs resident in HBM) -------------------------------------------- */
+int ddt_synth_model(uint32_t num_trees, uint32_t num_levels, uint32_t num_features, int dist,
+                    void* weights_lines, void* findex_lines);
+int ddt_synth_tuples_host(void* tuple_lines, uint64_t row0, size_t n, uint32_t num_features, int dist,
+                          uint32_t missing_bits);
+int ddt_synth_tuples_device(ddt_engine* e, void* d_tuple_lines, uint64_t row0, size_t n,
+                            uint32_t num_features, int dist, uint32_t missing_bits, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDT_H */

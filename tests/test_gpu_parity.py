@@ -1,0 +1,244 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (include/ddt.h via ddt.Engine), against the
+CPU oracle on identical seeded inputs.  Bar: BIT-EXACT fp32 scores (the kernel reproduces the reference's
+adder order) for sum_mode 0, bit-exact for the fp64-accumulate mode too, and the
+north-star tolerance (1e-6 relative to max(|gold|, sum|leaf|)) against the fp64 gold sum.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import ddt
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = ddt.Engine(0)
+    yield e
+    e.close()
+
+
+def _params(m, sum_mode=0):
+    p = m.params
+    return ddt.make_params(p.num_trees, p.num_levels, p.num_features, p.missing_bits, p.cmp_mode,
+                           p.clusters_per_tuple, sum_mode)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _gpu_score(eng, m, x, sum_mode=0, variant=-1, shard=(0, 1)):
+    import torch
+
+    eng.set_option("variant", variant)
+    eng.load_model(_params(m, sum_mode), m.wlines, m.flines, *shard)
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    out = eng.score_device(d)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _fitting_variants(eng, m):
+    """ids of every compiled kernel variant that accepts this model (always includes 0 = generic)."""
+    ids = []
+    for v, _name in enumerate(ddt.variant_names()):
+        try:
+            eng.set_option("variant", v)
+            eng.load_model(_params(m), m.wlines, m.flines)
+            ids.append(v)
+        except ddt.DDTError as ex:
+            assert ex.code == -5  # DDT_EUNSUPPORTED: wrong depth / tile does not fit LDS
+    eng.set_option("variant", -1)
+    return ids
+
+
+# BASELINE.json configs (rows reduced to what the oracle scores in seconds), plus edge shapes
+SHAPES = [
+    # T, D, F, rows, dist
+    (8, 4, 16, 1000, 0),      # config 1 exactly
+    (100, 6, 28, 6001, 0),    # config 2 shape
+    (100, 6, 28, 3000, 1),    #   with negatives + missing values (slow path inside the kernel)
+    (1000, 8, 32, 2500, 0),   # config 3 shape (single GPU holds all 1000 trees)
+    (1000, 8, 32, 1100, 1),
+    (37, 8, 32, 1029, 1),     # tree count not a multiple of 8: EMPTY slots
+    (9, 8, 20, 515, 1),       # F not a multiple of 4
+    (64, 6, 64, 700, 1),
+    (16, 4, 8, 300, 1),
+]
+
+
+@pytest.mark.parametrize("T,D,F,rows,dist", SHAPES)
+def test_bit_exact_vs_oracle_all_variants(eng, T, D, F, rows, dist):
+    m = O.gen_model(T, D, F, dist=dist)
+    x = O.gen_tuples(3, rows, F, dist=dist, missing_bits=m.params.missing_bits)
+    want = O.score(m, x, sum_mode=O.SUM_REF_FLOPOCO)
+    want64 = O.score(m, x, sum_mode=O.SUM_F64_SEQ)
+    _, gold = O.score(m, x, want_gold=True)
+    vids = _fitting_variants(eng, m)
+    assert 0 in vids and (len(vids) > 1 or D not in (4, 6, 8))
+    names = ddt.variant_names()
+    for v in vids:
+        got = _gpu_score(eng, m, x, 0, v)
+        assert np.array_equal(_bits(got), _bits(want)), f"variant {names[v]} differs from the reference-order sum"
+        got64 = _gpu_score(eng, m, x, 1, v)
+        assert np.array_equal(_bits(got64), _bits(want64)), f"variant {names[v]} fp64 mode"
+    # north-star tolerance against the fp64 gold
+    leaves = np.stack([O.leaves(m, x[r]).view(np.float32) for r in range(0, rows, max(1, rows // 50))])
+    sabs = np.abs(leaves.astype(np.float64)).sum(axis=1)
+    g = gold[:: max(1, rows // 50)]
+    assert np.all(np.abs(got[:: max(1, rows // 50)].astype(np.float64) - g) <= 1e-6 * np.maximum(np.abs(g), sabs))
+
+
+@pytest.mark.parametrize("cmp_mode", [0, 1])
+@pytest.mark.parametrize("clusters", [1, 2, 4, 8])
+def test_compare_modes_and_cluster_orders(eng, cmp_mode, clusters):
+    T, D, F, rows = 53, 8, 32, 777
+    m = O.gen_model(T, D, F, dist=1, cmp_mode=cmp_mode, clusters=clusters)
+    x = O.gen_tuples(9, rows, F, dist=1)
+    x[5, 3] = 0x80000000   # -0.0
+    x[6, 4] = 0x7FC00001   # a NaN that is not the missing pattern
+    x[7, 5] = 0xFF800000   # -inf
+    want = O.score(m, x)
+    for v in _fitting_variants(eng, m):
+        assert np.array_equal(_bits(_gpu_score(eng, m, x, 0, v)), _bits(want)), (cmp_mode, clusters, v)
+
+
+@pytest.mark.parametrize("D,F", [(1, 4), (2, 5), (3, 7), (5, 33), (7, 12), (9, 64), (10, 100), (12, 16), (13, 8), (4, 2048), (8, 200)])
+def test_generic_kernel_covers_odd_shapes(eng, D, F):
+    T = 11 if D < 12 else 3
+    m = O.gen_model(T, D, F, dist=1)
+    x = O.gen_tuples(1, 401, F, dist=1)
+    want = O.score(m, x)
+    got = _gpu_score(eng, m, x)
+    assert eng.info().variant_name.decode() == "generic"
+    assert np.array_equal(_bits(got), _bits(want))
+
+
+def test_missing_reset_value_and_all_missing(eng):
+    # CSR205 reset value 0 => 0.0 is the missing pattern (EngineCSR.sv:167); a tuple of all-missing features
+    m = O.gen_model(40, 6, 28, dist=0, missing_bits=0)
+    x = O.gen_tuples(0, 600, 28, dist=0)
+    x[::7, :28] = 0
+    assert np.array_equal(_bits(_gpu_score(eng, m, x)), _bits(O.score(m, x)))
+
+
+def test_edge_sizes_and_feeder_path(eng):
+    m = O.gen_model(100, 6, 28, dist=1)
+    eng.set_option("variant", -1)
+    eng.load_model(_params(m), m.wlines, m.flines)
+    tile = eng.info().tile_tuples
+    for n in (1, 3, tile - 1, tile, tile + 1, 4 * tile + 5):
+        x = O.gen_tuples(77, n, 28, dist=1)
+        assert np.array_equal(_bits(eng.score(x)), _bits(O.score(m, x))), n
+    assert eng.score(np.zeros((0, 28), np.uint32)).size == 0
+    # pinned double-buffered feeder with many small chunks == one device call
+    x = O.gen_tuples(5, 10_000, 28, dist=1)
+    eng.set_option("feeder_rows", 777)
+    a = eng.score(x)
+    eng.set_option("feeder_rows", 1 << 18)
+    b = eng.score(x)
+    assert np.array_equal(_bits(a), _bits(b)) and np.array_equal(_bits(a), _bits(O.score(m, x)))
+    st = eng.stats()
+    assert st.tuples_in == st.tuples_out and st.tuples_in >= 20_000 and st.kernel_launches >= 14
+
+
+def test_error_behaviour(eng):
+    w, f = ddt.synth_model(8, 4, 16)
+    e2 = ddt.Engine(0)
+    with pytest.raises(ddt.DDTError) as ei:
+        e2.score(np.zeros((4, 16), np.uint32))  # no model
+    assert ei.value.code == -4
+    bad = ddt.make_params(8, 4, 16, clusters=3)
+    with pytest.raises(ddt.DDTError):
+        e2.load_model(bad, w, f)
+    with pytest.raises(ddt.DDTError):
+        e2.load_model(ddt.make_params(9, 4, 16), w, f)  # stream too short
+    f2 = f.copy()
+    f2[0] = 17  # feature index >= F
+    with pytest.raises(ddt.DDTError):
+        e2.load_model(ddt.make_params(8, 4, 16), w, f2)
+    e2.close()
+
+
+def test_golden_fixtures(eng):
+    gdir = os.path.join(ROOT, "tests", "golden")
+    for fn in sorted(os.listdir(gdir)):
+        if not fn.endswith(".npz"):
+            continue
+        g = np.load(os.path.join(gdir, fn))
+        T, D, F, miss, wl, fl, cmp_mode, C = [int(v) for v in g["params"]]
+        for sum_mode, key in ((0, "score_ref_bits"), (1, "score_f64_bits")):
+            p = ddt.make_params(T, D, F, miss, cmp_mode, C, sum_mode)
+            eng.set_option("variant", -1)
+            eng.load_model(p, g["wlines"], g["flines"])
+            assert np.array_equal(_bits(eng.score(g["tuples"])), g[key]), (fn, key)
+
+
+def test_virtual_ranks_tree_sharded_chain(eng):
+    """Tree-sharded mode on one GPU: G engines each hold one shard; chain-add of their partials is
+    bit-exact with the oracle's multi-device model and with a real single-engine run to fp32 rounding."""
+    import torch
+
+    T, D, F, rows = 1000, 8, 32, 3000
+    m = O.gen_model(T, D, F)
+    x = O.gen_tuples(0, rows, F)
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    for G in (2, 4, 8):
+        parts = torch.empty((G, rows), dtype=torch.float32, device="cuda")
+        engines = []
+        for g in range(G):
+            e = ddt.Engine(0)
+            e.load_model(_params(m), m.wlines, m.flines, g, G)
+            i = e.info()
+            assert (i.tree_begin, i.tree_end) == ddt.shard_bounds(T, G)[g]
+            e.score_device(d, out=parts[g])
+            engines.append(e)
+        got = engines[0].chain_sum_device(parts)
+        torch.cuda.synchronize()
+        assert np.array_equal(_bits(got.cpu().numpy()), _bits(O.score(m, x, n_devices=G))), G
+        for g, e in enumerate(engines):
+            b, en = ddt.shard_bounds(T, G)[g]
+            assert np.array_equal(_bits(parts[g].cpu().numpy()), _bits(O.score_shard(m, x, b, en)))
+            e.close()
+
+
+def test_device_generator_matches_oracle(eng):
+    import torch
+
+    for F, dist in ((32, 0), (28, 1), (5, 1)):
+        d = eng.synth_tuples_device(1 << 33, 4099, F, dist)
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), O.gen_tuples(1 << 33, 4099, F, dist=dist))
+
+
+@pytest.mark.parametrize("T,D,F,N", [(100, 6, 28, 10_000_000), (1000, 8, 32, 4_000_000)])
+def test_full_size_properties(eng, T, D, F, N):
+    """BASELINE-size batches (config 2 at its full 10 M rows; config 3's per-step batch): properties that do
+    not need the oracle to score everything -- determinism, chunk invariance, and exact parity on a
+    strided sample of rows that the oracle re-scores."""
+    import torch
+
+    w, f = ddt.synth_model(T, D, F)
+    p = ddt.make_params(T, D, F)
+    eng.set_option("variant", -1)
+    eng.load_model(p, w, f)
+    d = eng.synth_tuples_device(0, N, F)
+    a = eng.score_device(d)
+    b = eng.score_device(d)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))                      # idempotent / deterministic
+    half = N // 2 + 13
+    c = torch.cat([eng.score_device(d[:half]), eng.score_device(d[half:].contiguous())])
+    assert torch.equal(a.view(torch.int32), c.view(torch.int32))                      # batch-split invariant
+    idx = torch.arange(0, N, 9973, device="cuda")
+    xs = d[idx].cpu().numpy().view(np.uint32)
+    m = O.Model(O.make_params(T, D, F), w, f)
+    assert np.array_equal(_bits(a[idx].cpu().numpy()), _bits(O.score(m, xs)))        # parity on the sample
+    assert np.array_equal(xs, np.concatenate([O.gen_tuples(int(i), 1, F) for i in idx.cpu().numpy()[:50]] +
+                                             [xs[50:]]))                              # inputs are the seeded ones
+    assert torch.isfinite(a).all()
