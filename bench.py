@@ -152,7 +152,7 @@ def main():
         t1 = time.perf_counter()
         ref = O.score(m, xs, sum_mode=O.SUM_REF_NATIVE)
         rate = probe / max(1e-9, time.perf_counter() - t1)
-        rows = int(max(probe, min(N, 2_000_000, rate * args.cpu_seconds)))
+        rows = int(max(probe, min(N, 16_000_000, rate * args.cpu_seconds)))
         xs = tuples[:rows].cpu().numpy().view(np.uint32)
         t1 = time.perf_counter()
         ref = O.score(m, xs, sum_mode=O.SUM_REF_NATIVE if args.sum_mode == 0 else O.SUM_F64_SEQ)

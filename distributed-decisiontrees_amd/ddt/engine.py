@@ -119,6 +119,8 @@ class Engine:
     def score(self, tuple_lines: np.ndarray) -> np.ndarray:
         """Host buffers through the pinned double-buffered feeder (the PCIe tuple stream)."""
         t = np.ascontiguousarray(tuple_lines).view(np.uint32)
+        if self.params is None:  # let the library report DDT_ESTATE
+            self._check(self._L.ddt_score(self._h, t.ctypes.data, 1, t.ctypes.data))
         W = tuple_words(self.params.num_features)
         t = t.reshape(-1, W)
         out = np.empty(t.shape[0], np.float32)
