@@ -152,21 +152,40 @@ uint32_t thr_key(const HostModel& m, uint32_t bits) {
 
 uint32_t tuple_words(const ddt_params& p) { return (p.num_features + 3u) / 4u * 4u; }
 
+uint32_t padded_trees(const Variant& v, uint32_t T) {
+  const uint32_t granule = (v.kind == kKindTile && v.chunk_trees > 8) ? (uint32_t)v.chunk_trees : 8u;
+  return (T + granule - 1u) / granule * granule;  // whole PU groups of 8 (and whole chunks)
+}
+
+constexpr uint32_t kStreamLdsBudget = 40u * 1024u;  // keeps >= 4 resident blocks per CU for HBM latency hiding
+
 bool variant_fits(const Variant& v, const HostModel& m) {
-  if (v.levels == 0) return true;
+  if (v.kind == kKindGeneric) return true;
   if ((uint32_t)v.levels != m.p.num_levels) return false;
-  return v.lds_bytes(tuple_words(m.p)) <= kMaxLdsBytes;
+  const uint32_t W = tuple_words(m.p);
+  if (v.kind == kKindStream)
+    return W <= 4u * (uint32_t)v.opt && v.lds_bytes_stream(padded_trees(v, m.trees()), W) <= kStreamLdsBudget;
+  return v.lds_bytes(W) <= kMaxLdsBytes;
+}
+
+int find_variant(const char* name) {
+  for (int i = 0; i < num_variants(); ++i)
+    if (!strcmp(variant(i).name, name)) return i;
+  return -1;
 }
 
 int auto_variant(const HostModel& m) {
-  // preference order per depth; first that fits wins (tuned from profiles/)
-  static const char* pref[] = {"d8_t1024_r1_c4_u4_dma", "d8_t512_r1_c8_u8_dma", "d8_t256_r1_c4_u4_dma",
-                               "d6_t1024_r1_c16_u4_dma", "d6_t256_r1_c16_u4_dma"};
-  for (const char* name : pref)
-    for (int i = 0; i < num_variants(); ++i)
-      if (!strcmp(variant(i).name, name) && variant_fits(variant(i), m)) return i;
-  // everything else (odd depths, wide tuples, and the tiny depth-4 shape, which is HBM-streaming bound
-  // and measured faster on the generic kernel): generic
+  // Preference order, first that fits wins; tuned from the sweeps under profiles/ (see DESIGN.md):
+  // small ensembles that fit LDS whole -> streaming kernel (HBM-bound regime); otherwise the tile kernel with
+  // the most waves per CU the feature tile allows; anything else -> generic.
+  static const char* pref[] = {"stream_d4_u4_l4", "stream_d4_u4_l8", "stream_d6_u4_l4", "stream_d6_u4_l8", "stream_d8_u4_l8",
+                               "d8_t1024_r1_c4_u4_dma_f", "d8_t512_r1_c8_u8_dma_f", "d8_t256_r1_c4_u4_dma",
+                               "d6_t1024_r1_c16_u4_dma", "d6_t512_r1_c16_u8_dma", "d6_t256_r1_c16_u4_dma",
+                               "d4_t256_r1_c64_u8_dma"};
+  for (const char* name : pref) {
+    const int i = find_variant(name);
+    if (i >= 0 && variant_fits(variant(i), m)) return i;
+  }
   return 0;
 }
 
@@ -176,14 +195,13 @@ void free_image(ddt_engine* e) {
   e->img_bytes = 0;
 }
 
-// Build the device image for variant `vid` and upload it.
+// Build the device image for variant `vid` and upload it (layouts: ddt_internal.h).
 int build_image(ddt_engine* e, int vid) {
   const Variant& v = variant(vid);
   const HostModel& m = e->m;
   const uint32_t D = m.p.num_levels, T = m.trees();
   const uint32_t tree_bytes = 12u << D;
-  const uint32_t granule = (v.levels == 0) ? 8u : (uint32_t)((v.chunk_trees > 8) ? v.chunk_trees : 8);
-  const uint32_t Tpad = (T + granule - 1u) / granule * granule;  // EMPTY trees: every leaf +0 (DTPU.sv:544,760)
+  const uint32_t Tpad = padded_trees(v, T);  // EMPTY trees: every leaf +0 (DTPU.sv:544,760)
   const size_t bytes = (size_t)Tpad * tree_bytes;
   std::vector<uint32_t> img;
   try {
@@ -191,29 +209,43 @@ int build_image(ddt_engine* e, int vid) {
   } catch (const std::bad_alloc&) {
     return fail(e, DDT_ENOMEM, "image allocation (%zu bytes) failed", bytes);
   }
-  const uint32_t row = v.tile() * 4u, feat_off = (v.levels == 0) ? 0u : v.feat_off();
+  // feature word of feature j: generic = j itself; tile/stream = absolute LDS byte address of row j
+  const uint32_t row = v.row_bytes();
+  const uint32_t feat_off = v.kind == kKindTile ? v.feat_off() : v.kind == kKindStream ? v.feat_off_stream(Tpad) : 0u;
+  auto feature_word = [&](uint32_t j) { return v.kind == kKindGeneric ? j : feat_off + j * row; };
+  const bool fused = v.kind == kKindTile && (v.opt & 1);
+  const uint32_t first_last = 1u << (D - 1);  // 1-based index of the first last-level node
   for (uint32_t i = 0; i < Tpad; ++i) {
     uint32_t* t = img.data() + (size_t)i * (tree_bytes / 4);
-    if (i >= T) {  // EMPTY tree: any walk ends in a +0 leaf; node words must still gather in range
-      for (uint32_t mm = 1; mm <= m.nint; ++mm) t[2 * mm + 1] = (v.levels == 0) ? 0u : feat_off;
-      continue;
-    }
+    const bool empty = i >= T;  // EMPTY tree: all-zero thresholds and leaves; node words must still gather in range
     for (uint32_t n = 0; n < m.nint; ++n) {
       const uint32_t mm = n + 1;  // 1-based heap record
-      const uint32_t j = m.fidx[(size_t)i * m.nint + n];
-      const uint32_t word = (v.levels == 0) ? j : (feat_off + j * row);
-      t[2 * mm + 0] = thr_key(m, m.thr[(size_t)i * m.nint + n]);
-      t[2 * mm + 1] = word | (m.mright[(size_t)i * m.nint + n] ? kFlagMissRight : 0u);
+      const uint32_t j = empty ? 0u : m.fidx[(size_t)i * m.nint + n];
+      const uint32_t word = feature_word(j) | ((!empty && m.mright[(size_t)i * m.nint + n]) ? kFlagMissRight : 0u);
+      const uint32_t key = empty ? 0u : thr_key(m, m.thr[(size_t)i * m.nint + n]);
+      if (fused && mm >= first_last) {  // layout 1: {thr, w2, leafL, leafR} at 4*2^D + 16*(m - 2^(D-1))
+        const uint32_t r = mm - first_last;
+        uint32_t* rec = t + (4u << D) / 4 + 4 * r;
+        rec[0] = key;
+        rec[1] = word;
+        rec[2] = empty ? 0u : m.leaf[(size_t)i * m.nleaf + 2 * r];
+        rec[3] = empty ? 0u : m.leaf[(size_t)i * m.nleaf + 2 * r + 1];
+      } else {
+        t[2 * mm + 0] = key;
+        t[2 * mm + 1] = word;
+      }
     }
-    uint32_t* lv = t + (8u << D) / 4;
-    for (uint32_t l = 0; l < m.nleaf; ++l) lv[l] = m.leaf[(size_t)i * m.nleaf + l];
+    if (!fused && !empty) {
+      uint32_t* lv = t + (8u << D) / 4;
+      for (uint32_t l = 0; l < m.nleaf; ++l) lv[l] = m.leaf[(size_t)i * m.nleaf + l];
+    }
   }
   free_image(e);
   HIP_TRY(e, hipMalloc(&e->d_img, bytes));
   HIP_TRY(e, hipMemcpy(e->d_img, img.data(), bytes, hipMemcpyHostToDevice));
   e->img_bytes = bytes;
   e->img_trees = Tpad;
-  e->img_chunks = (v.levels == 0) ? Tpad : Tpad / (uint32_t)v.chunk_trees;
+  e->img_chunks = v.kind == kKindTile ? Tpad / (uint32_t)v.chunk_trees : Tpad;
   e->variant_id = vid;
   return DDT_OK;
 }
@@ -438,7 +470,9 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   out->variant = (uint32_t)e->variant_id;
   out->tile_tuples = v.tile();
   out->block_threads = (uint32_t)v.threads;
-  out->lds_bytes = v.levels ? v.lds_bytes(out->tuple_words) : generic_lds_bytes(m.p.num_levels, out->tuple_words, nullptr, nullptr);
+  out->lds_bytes = v.kind == kKindTile     ? v.lds_bytes(out->tuple_words)
+                   : v.kind == kKindStream ? v.lds_bytes_stream(e->img_trees, out->tuple_words)
+                                           : generic_lds_bytes(m.p.num_levels, out->tuple_words, nullptr, nullptr);
   out->model_bytes_unpadded = (uint64_t)m.trees() * (4ull * ((2ull << m.p.num_levels) - 1) + 2ull * ((1ull << m.p.num_levels) - 1));
   out->image_bytes = e->img_bytes;
   snprintf(out->variant_name, sizeof(out->variant_name), "%s", v.name);

@@ -11,18 +11,22 @@
 namespace ddt {
 
 // ---------------------------------------------------------------------------------------------------
-// Packed tree image ("LDS image").  One tree occupies TREE_BYTES = 12 * 2^D bytes:
-//   [0, 8*2^D)        node records, 1-BASED heap (record 0 is padding): {u32 thr_key, u32 w2}
-//                     w2 = feature word (variant specific, see pack_image) | miss_right << 31
-//   [8*2^D, 12*2^D)   2^D fp32 leaves, left to right
-// Heap walk in byte units: m8 = 8 (root); m8 <- 2*m8 + 8*right; leaf byte = 8*2^D + (m8/2 - 4*2^D).
+// Packed tree image ("LDS image").  One tree occupies TREE_BYTES = 12 * 2^D bytes.
+//   layout 0 (classic):
+//     [0, 8*2^D)        node records, 1-BASED heap (record 0 is padding): {u32 thr_key, u32 w2}
+//                       w2 = feature word (kernel specific, see build_image) | miss_right << 31
+//     [8*2^D, 12*2^D)   2^D fp32 leaves, left to right
+//   layout 1 (last level fused with its leaves, Variant::opt bit 0):
+//     [0, 4*2^D)        records of levels 0..D-2 (1-based heap, record 0 padding)
+//     [4*2^D, 12*2^D)   2^(D-1) records of 16 bytes {thr_key, w2, leaf_left, leaf_right} for level D-1
+// Heap walk in byte units: m8 = 8 (root); m8 <- 2*m8 + 8*right.
 // Reference semantics: rtl/DTEngine/core/DTPU.sv:579-760 (0-based n' = 2n+1+right is the same walk).
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kFlagMissRight = 0x80000000u;
 constexpr uint32_t kMissSentinelIeee = 0x7FFFFFFEu;  // key-space missing marker for cmp_mode 1
 
 struct ScoreArgs {
-  const uint4* img;        // packed image, n_chunks * chunk_bytes (tile kernels) or trees * tree_bytes (generic)
+  const uint4* img;        // packed image: n_trees * tree_bytes
   const uint32_t* tuples;  // device, row-major tuple lines: tuple_words u32 per tuple
   float* out;              // device, one fp32 per tuple
   uint64_t n;              // tuples
@@ -37,24 +41,41 @@ struct ScoreArgs {
   uint32_t sum_mode;       // 0 reference-order fp32, 1 fp64 sequential
 };
 
+enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2 };
+
 struct Variant {
   const char* name;
+  int kind;
   int levels;         // compile-time D, 0 = generic (runtime D)
   int threads;        // block size
   int tuples_per_lane;
-  int chunk_trees;    // trees per LDS chunk (tile kernels)
+  int chunk_trees;    // trees per LDS chunk (tile kernels); padding granule otherwise
   int ilp_trees;      // trees walked concurrently per lane
-  int stage;          // 0: model chunks staged through registers, 1: global->LDS DMA
-  // LDS geometry (tile kernels): model double buffer first, feature tile after it
+  int stage;          // tile: 0 = model chunks staged through registers, 1 = global->LDS DMA
+  int opt;            // tile: bit 0 = last level fused with its leaves (image layout 1); stream: max lines per tuple
+  hipError_t (*launch)(const ScoreArgs&, const Variant&, hipStream_t);
+
   uint32_t tile() const { return (uint32_t)threads * (uint32_t)tuples_per_lane; }
+  uint32_t row_bytes() const { return tile() * 4u; }
   uint32_t tree_bytes() const { return 12u << levels; }
   uint32_t chunk_bytes() const { return tree_bytes() * (uint32_t)chunk_trees; }
-  uint32_t feat_off() const {  // multiple of tile*4 so that (row offset | lane offset) is an OR
-    uint32_t row = tile() * 4u, need = 2u * chunk_bytes();
+  // ---- tile kernels: LDS = [model_base, +2 chunks) double buffer, then the feature tile ----
+  // layout 1 addresses the last level as 2*m8 + (tree base - 4*2^D): the model buffers start 4*2^D bytes
+  // into LDS so that this DS immediate is never negative
+  uint32_t model_base() const { return (opt & 1) ? (4u << levels) : 0u; }
+  uint32_t feat_off() const {  // multiple of the row size so that (row offset | lane offset) is an OR
+    const uint32_t row = row_bytes(), need = model_base() + 2u * chunk_bytes();
     return (need + row - 1u) / row * row;
   }
-  uint32_t lds_bytes(uint32_t tuple_words) const { return feat_off() + tuple_words * tile() * 4u + 64u; }  // +64: per-wave flags
-  hipError_t (*launch)(const ScoreArgs&, const Variant&, hipStream_t);
+  uint32_t lds_bytes(uint32_t tuple_words) const { return feat_off() + tuple_words * row_bytes() + 64u; }  // +64: per-wave flags
+  // ---- stream kernels: LDS = [0, image) resident model, then the feature tile ----
+  uint32_t feat_off_stream(uint32_t n_trees_padded) const {
+    const uint32_t row = row_bytes(), need = n_trees_padded * tree_bytes();
+    return (need + row - 1u) / row * row;
+  }
+  uint32_t lds_bytes_stream(uint32_t n_trees_padded, uint32_t tuple_words) const {
+    return feat_off_stream(n_trees_padded) + tuple_words * row_bytes() + 64u;
+  }
 };
 
 int num_variants();
@@ -64,12 +85,13 @@ const Variant& variant(int i);
 constexpr int kGenericThreads = 256;
 hipError_t launch_generic(const ScoreArgs& a, const Variant& v, hipStream_t s);
 uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds);
+uint32_t stream_blocks_per_cu(uint32_t lds_bytes);
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s);
 hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits,
                                hipStream_t s);
 
-// host-side splitmix64 / synthetic definitions; shared by host generator and kernels
+// splitmix64 / synthetic definitions; shared by host generator and kernels
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
   uint64_t z = x + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

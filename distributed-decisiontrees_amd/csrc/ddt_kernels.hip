@@ -1,15 +1,19 @@
 // ddt_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4).  No MFMA: the path is
-// compare + gather; the binding resource is the LDS pipe (2 DS ops per node visit).
+// compare + gather.  Measured binding resources on the headline shape (profiles/):
+// the LDS pipe (2 DS ops per node visit, ~68 % busy) together with VALU issue (~4.6 ops per visit,
+// ~60 % of SIMD issue), at the 16 waves/CU that the 128 KiB feature tile allows.
 //
 // Hot path replaced: the DTPU traversal loop + leaf reduce of the reference
 //   rtl/DTEngine/core/DTPU.sv:579-760       read node -> gather feature -> compare -> next node -> leaf
 //   rtl/DTEngine/core/FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131, Core.sv:486-541   leaf sum
 //
-// Mapping (score_tile_kernel): one lane = one tuple (R tuples per lane), a block owns a TILE of tuples
-// whose features sit in LDS feature-major ([feature][tuple]: bank == lane, so the per-lane feature
-// gather is conflict-free for any feature index).  The ensemble streams through LDS in chunks of CT
-// trees (double buffered; global->LDS DMA or register staged); every lane walks U trees at a time
-// (ILP) with the whole level loop unrolled, node offsets folded into DS immediates.
+// Three kernels, one mapping (lane = tuple, features of a tile of tuples in LDS feature-major so that
+// bank == lane and the per-lane feature gather is conflict-free for any feature index):
+//   score_tile_kernel    big ensembles: the model streams through LDS in double-buffered chunks (global->LDS
+//                        DMA), U trees walked concurrently per lane, level loop fully unrolled.
+//   score_stream_kernel  small ensembles (whole model resident in LDS): persistent blocks, coalesced tuple
+//                        loads prefetched one tile ahead -- the HBM-bound regime.
+//   score_generic_kernel any depth / any feature count (correctness path).
 #include <hip/hip_runtime.h>
 
 #include "ddt_internal.h"
@@ -18,9 +22,9 @@ namespace ddt {
 
 // ---------------------------------------------------------------------------------------------------
 // LDS access by ABSOLUTE byte address.  The kernels declare no static __shared__ object, so the dynamic
-// LDS segment starts at address 0 (checked at build time: group_segment_fixed_size == 0) and a DS
-// address is just the byte offset.  Going through the `extern __shared__` symbol instead makes hipcc
-// add the (link-time) symbol address to every DS address -- one wasted VALU op per node visit.
+// LDS segment starts at address 0 (tests check group_segment_fixed_size == 0) and a DS address is just
+// the byte offset.  Going through the `extern __shared__` symbol instead makes hipcc add the (link-time)
+// symbol address to every DS address -- one wasted VALU op per node visit.
 // ---------------------------------------------------------------------------------------------------
 #define DDT_LDS(T) __attribute__((address_space(3))) T
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -28,6 +32,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint2 lds_u2(uint32_t a) {
   const u32x2 v = *reinterpret_cast<const DDT_LDS(u32x2)*>(a);
   return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint4 lds_u4(uint32_t a) {
+  const u32x4 v = *reinterpret_cast<const DDT_LDS(u32x4)*>(a);
+  return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *reinterpret_cast<const DDT_LDS(uint32_t)*>(a); }
 __device__ __forceinline__ float lds_f32(uint32_t a) { return *reinterpret_cast<const DDT_LDS(float)*>(a); }
@@ -41,10 +49,10 @@ __device__ __forceinline__ void lds_st_u4(uint32_t a, uint4 v) {
 // reference-order fp32 accumulation state (per lane, per tuple)
 //   tree i -> PU i%8; group g=i/8 -> cluster g%C; per cluster acc <- s_g + acc in slot order; final
 //   sequential add over clusters.  SURVEY.md 8(a) A4/A11/A12.
-// ---------------------------------------------------------------------------------------------------
 // The C cluster accumulators live in registers a[0..C-1] and are ROTATED after every group so that the
 // current cluster is always a[0]: every index below is a compile-time constant.  (A `switch (cluster)`
 // over acc[k] gets merged by hipcc into one dynamically indexed access, which lands in scratch.)
+// ---------------------------------------------------------------------------------------------------
 template <int R>
 struct RefAcc {
   float a[R][8];
@@ -97,13 +105,57 @@ struct RefAcc {
   }
 };
 
+// fold the leaves of one sub-group of U trees (stream order) into the accumulators
+template <int U, int R, int SUM>
+__device__ __forceinline__ void fold_leaves(const float (&lf)[R][U], const int phase /*U==4: 0 first half, 1 second*/,
+                                            const uint32_t C, RefAcc<R>& ra, double (&dacc)[R]) {
+  static_assert(U == 4 || U == 8, "sub-group = half a PU group or a whole one");
+  if (SUM == 1) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) dacc[r] += (double)lf[r][u];  // stream order, fp64
+  } else if (U == 8) {
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)  // FPAddersReduceTree.sv:94-141: ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7))
+      s[r] = ((lf[r][0] + lf[r][1]) + (lf[r][2] + lf[r][3])) + ((lf[r][4 % U] + lf[r][5 % U]) + (lf[r][6 % U] + lf[r][7 % U]));
+    ra.push_group(s, C);
+  } else {
+    float p[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) p[r] = (lf[r][0] + lf[r][1]) + (lf[r][2] + lf[r][3]);
+    if (phase == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) ra.half[r] = p[r];
+    } else {
+      float s[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[r] = ra.half[r] + p[r];
+      ra.push_group(s, C);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
-// walk U trees x R tuples through D levels; returns the selected leaves
+// walk U trees x R tuples through D levels; returns the selected leaves.
+//   `base` = LDS byte address of the first tree (compile-time in the tile kernel => DS immediates; a
+//   wave-uniform runtime value in the stream kernel), trees TREE_BYTES apart.
+//   FUSED (image layout 1): levels 0..D-2 are 8-byte records of the 1-based heap at byte 8*m; the last
+//   level is 16-byte records {thr, w2, leafL, leafR} at 4*2^D + 16*(m - 2^(D-1)), so the leaf comes
+//   with its parent (one LDS round trip and one DS op less per tree).
 // ---------------------------------------------------------------------------------------------------
-template <int D, int U, int R, int TREE_BYTES, bool SLOW>
-__device__ __forceinline__ void walk_trees(const int base /*compile-time*/,
-                                           const uint32_t (&lane_off)[R], const uint32_t miss_key,
+template <bool SLOW>
+__device__ __forceinline__ bool go_right(uint32_t f, uint32_t thr, uint32_t w2, uint32_t miss_key) {
+  bool right = (int32_t)f >= (int32_t)thr;                         // !(feature < threshold), DTPU.sv:655-657
+  if (SLOW) right = (f == miss_key) ? ((w2 >> 31) != 0u) : right;  // DTPU.sv:653,667
+  return right;
+}
+
+template <int D, int U, int R, int TREE_BYTES, bool SLOW, bool FUSED>
+__device__ __forceinline__ void walk_trees(const uint32_t base, const uint32_t (&lane_off)[R], const uint32_t miss_key,
                                            float (&leaf)[R][U]) {
+  constexpr int LAST = FUSED ? D - 1 : D;  // levels walked over 8-byte records
   uint32_t m8[R][U];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -111,77 +163,50 @@ __device__ __forceinline__ void walk_trees(const int base /*compile-time*/,
     for (int u = 0; u < U; ++u) m8[r][u] = 8u;  // root of the 1-based heap, in bytes
 
 #pragma unroll
-  for (int lvl = 0; lvl < D; ++lvl) {
+  for (int lvl = 0; lvl < LAST; ++lvl) {
     uint2 nd[R][U];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        nd[r][u] = lds_u2(m8[r][u] + (uint32_t)(base + u * TREE_BYTES));  // ds_read_b64, tree offset = immediate
+      for (int u = 0; u < U; ++u) nd[r][u] = lds_u2(m8[r][u] + (base + (uint32_t)(u * TREE_BYTES)));  // ds_read_b64
     uint32_t f[R][U];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        f[r][u] = lds_u32((nd[r][u].y & 0x7FFFFFFFu) | lane_off[r]);  // ds_read_b32, conflict-free gather
+      for (int u = 0; u < U; ++u) f[r][u] = lds_u32((nd[r][u].y & 0x7FFFFFFFu) | lane_off[r]);  // ds_read_b32, conflict-free
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        bool right = (int32_t)f[r][u] >= (int32_t)nd[r][u].x;  // !(feature < threshold), DTPU.sv:655-657
-        if (SLOW) right = (f[r][u] == miss_key) ? ((nd[r][u].y >> 31) != 0u) : right;  // DTPU.sv:653,667
-        m8[r][u] = (m8[r][u] << 1) + (right ? 8u : 0u);
-      }
+      for (int u = 0; u < U; ++u)
+        m8[r][u] = (m8[r][u] << 1) + (go_right<SLOW>(f[r][u], nd[r][u].x, nd[r][u].y, miss_key) ? 8u : 0u);
   }
+  if (FUSED) {
+    uint4 rec[R][U];
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      leaf[r][u] = lds_f32((m8[r][u] >> 1) + (uint32_t)(base + u * TREE_BYTES + (4 << D)));
-}
-
-// one LDS chunk (CT trees) for all R tuples of the lane
-template <int D, int U, int R, int CT, int BUF_OFF, int PHASE0, bool SLOW, int SUM>
-__device__ __forceinline__ void compute_chunk(const uint32_t (&lane_off)[R],
-                                              const uint32_t miss_key, const uint32_t C, RefAcc<R>& ra,
-                                              double (&dacc)[R]) {
-  constexpr int TREE_BYTES = 12 << D;
-  static_assert(CT % U == 0 && (U == 4 || U == 8), "sub-group geometry");
+      for (int u = 0; u < U; ++u)  // ds_read_b128; offset = tree base - 4*2^D >= 0 because of Variant::model_base()
+        rec[r][u] = lds_u4((m8[r][u] << 1) + (base + (uint32_t)(u * TREE_BYTES + (4 << D) - (8 << D))));
+    uint32_t f[R][U];
 #pragma unroll
-  for (int sg = 0; sg < CT / U; ++sg) {
-    float lf[R][U];
-    walk_trees<D, U, R, TREE_BYTES, SLOW>(BUF_OFF + sg * U * TREE_BYTES, lane_off, miss_key, lf);
-    if (SUM == 1) {
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int u = 0; u < U; ++u) f[r][u] = lds_u32((rec[r][u].y & 0x7FFFFFFFu) | lane_off[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int u = 0; u < U; ++u)
+        leaf[r][u] = __uint_as_float(go_right<SLOW>(f[r][u], rec[r][u].x, rec[r][u].y, miss_key) ? rec[r][u].w : rec[r][u].z);
+  } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dacc[r] += (double)lf[r][u];  // stream order, fp64
-    } else if (U == 8) {
-      float s[R];
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-        s[r] = ((lf[r][0] + lf[r][1]) + (lf[r][2] + lf[r][3])) + ((lf[r][4 % U] + lf[r][5 % U]) + (lf[r][6 % U] + lf[r][7 % U]));
-      ra.push_group(s, C);
-    } else {  // U == 4: two sub-groups make one PU group
-      const int phase = (PHASE0 + sg) & 1;  // compile-time after unrolling
-      float p[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) p[r] = (lf[r][0] + lf[r][1]) + (lf[r][2] + lf[r][3]);
-      if (phase == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) ra.half[r] = p[r];
-      } else {
-        float s[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) s[r] = ra.half[r] + p[r];
-        ra.push_group(s, C);
-      }
-    }
+      for (int u = 0; u < U; ++u) leaf[r][u] = lds_f32((m8[r][u] >> 1) + (base + (uint32_t)(u * TREE_BYTES + (4 << D))));
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// model chunk staging
+// model chunk staging (tile kernel)
 // ---------------------------------------------------------------------------------------------------
 template <int THREADS, int CHUNK_BYTES>
 struct StageRegs {
@@ -233,16 +258,52 @@ __device__ __forceinline__ void dma_chunk(const uint4* __restrict__ img, uint32_
   }
 }
 
+// raw / IEEE-key transform of one staged feature word + missing detection
+__device__ __forceinline__ uint32_t stage_word(uint32_t v, const ScoreArgs& a, uint32_t& miss_any, bool valid) {
+  const uint32_t m = (v == a.miss_raw) ? 1u : 0u;
+  miss_any |= m & (valid ? 1u : 0u);
+  if (a.ieee) v = m ? kMissSentinelIeee : ieee_key(v);  // wave-uniform branch
+  return v;
+}
+
+// block-wide OR through one dynamic-LDS word per wave (no static __shared__, see lds_* above); contains the
+// barrier that publishes the staged tile
+template <int THREADS>
+__device__ __forceinline__ bool block_any(uint32_t flag, uint32_t flags_addr, int tid) {
+  const unsigned long long wave_any = __ballot(flag != 0u);
+  if ((tid & 63) == 0) lds_st_u32(flags_addr + (uint32_t)(tid >> 6) * 4u, wave_any != 0ull ? 1u : 0u);
+  __syncthreads();
+  uint32_t any = 0;
+#pragma unroll
+  for (int w = 0; w < THREADS / 64; ++w) any |= lds_u32(flags_addr + (uint32_t)w * 4u);
+  return __builtin_amdgcn_readfirstlane(any) != 0u;
+}
+
 // ---------------------------------------------------------------------------------------------------
-// the tile kernel
+// the tile kernel (model streamed through LDS)
 // ---------------------------------------------------------------------------------------------------
-template <int D, int THREADS, int R, int CT, int U, int STAGE>
+template <int D, int U, int R, int CT, int BUF_OFF, int PHASE0, bool SLOW, int SUM, bool FUSED>
+__device__ __forceinline__ void compute_chunk(const uint32_t (&lane_off)[R], const uint32_t miss_key, const uint32_t C,
+                                              RefAcc<R>& ra, double (&dacc)[R]) {
+  constexpr int TREE_BYTES = 12 << D;
+  static_assert(CT % U == 0, "sub-group geometry");
+#pragma unroll
+  for (int sg = 0; sg < CT / U; ++sg) {
+    float lf[R][U];
+    walk_trees<D, U, R, TREE_BYTES, SLOW, FUSED>((uint32_t)(BUF_OFF + sg * U * TREE_BYTES), lane_off, miss_key, lf);
+    fold_leaves<U, R, SUM>(lf, (PHASE0 + sg) & 1, C, ra, dacc);
+  }
+}
+
+template <int D, int THREADS, int R, int CT, int U, int STAGE, int OPT>
 __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) {
   constexpr int TILE = THREADS * R;
   constexpr int TREE_BYTES = 12 << D;
   constexpr int CHUNK_BYTES = TREE_BYTES * CT;
   constexpr int ROW = TILE * 4;
-  constexpr int FEAT_OFF = (2 * CHUNK_BYTES + ROW - 1) / ROW * ROW;
+  constexpr bool FUSED = (OPT & 1) != 0;
+  constexpr int MB = FUSED ? (4 << D) : 0;  // model buffers start here (Variant::model_base)
+  constexpr int FEAT_OFF = (MB + 2 * CHUNK_BYTES + ROW - 1) / ROW * ROW;
   static_assert((ROW & (ROW - 1)) == 0, "tile must be a power of two (row|lane OR trick)");
   static_assert(CT == 4 || CT % 8 == 0, "chunk = half a PU group or whole groups");
   static_assert(CT != 4 || U == 4, "CT=4 needs U=4");
@@ -253,7 +314,7 @@ __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) 
   const uint32_t n_chunks = a.n_chunks;
 
   StageRegs<THREADS, CHUNK_BYTES> sr;
-  if (STAGE == 1) dma_chunk<THREADS, CHUNK_BYTES>(a.img, 0, 0, tid);
+  if (STAGE == 1) dma_chunk<THREADS, CHUNK_BYTES>(a.img, 0, MB, tid);
   else sr.load(a.img, 0, tid);
 
   // ---- stage the tuple tile, transposed to [feature][tuple]; detect missing values on the way ----
@@ -270,32 +331,15 @@ __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) 
 #pragma unroll 4
     for (uint32_t q = 0; q < W / 4; ++q) {
       uint4 v = valid ? src[q] : make_uint4(0u, 0u, 0u, 0u);
-      const uint32_t mx = v.x == a.miss_raw, my = v.y == a.miss_raw, mz = v.z == a.miss_raw, mw = v.w == a.miss_raw;
-      miss_any |= (mx | my | mz | mw) & (valid ? 1u : 0u);
-      if (a.ieee) {  // wave-uniform
-        v.x = mx ? kMissSentinelIeee : ieee_key(v.x);
-        v.y = my ? kMissSentinelIeee : ieee_key(v.y);
-        v.z = mz ? kMissSentinelIeee : ieee_key(v.z);
-        v.w = mw ? kMissSentinelIeee : ieee_key(v.w);
-      }
       const uint32_t fa = (uint32_t)FEAT_OFF + (4u * q) * (uint32_t)ROW + col * 4u;
-      lds_st_u32(fa + 0 * ROW, v.x);
-      lds_st_u32(fa + 1 * ROW, v.y);
-      lds_st_u32(fa + 2 * ROW, v.z);
-      lds_st_u32(fa + 3 * ROW, v.w);
+      lds_st_u32(fa + 0 * ROW, stage_word(v.x, a, miss_any, valid));
+      lds_st_u32(fa + 1 * ROW, stage_word(v.y, a, miss_any, valid));
+      lds_st_u32(fa + 2 * ROW, stage_word(v.z, a, miss_any, valid));
+      lds_st_u32(fa + 3 * ROW, stage_word(v.w, a, miss_any, valid));
     }
   }
-  if (STAGE == 0) sr.commit(0, tid);
-  // block-wide OR of miss_any through one dynamic-LDS word per wave (no static __shared__: a static
-  // object would move the dynamic base off 0 and cost an extra address add per DS access)
-  const uint32_t flags = (uint32_t)FEAT_OFF + W * (uint32_t)ROW;
-  const unsigned long long wave_any = __ballot(miss_any != 0u);
-  if ((tid & 63) == 0) lds_st_u32(flags + (uint32_t)(tid >> 6) * 4u, wave_any != 0ull ? 1u : 0u);
-  __syncthreads();
-  uint32_t any = 0;
-#pragma unroll
-  for (int w = 0; w < THREADS / 64; ++w) any |= lds_u32(flags + (uint32_t)w * 4u);
-  const bool slow = __builtin_amdgcn_readfirstlane(any) != 0u;
+  if (STAGE == 0) sr.commit(MB, tid);
+  const bool slow = block_any<THREADS>(miss_any, (uint32_t)FEAT_OFF + W * (uint32_t)ROW, tid);
 
   RefAcc<R> ra;
   ra.init();
@@ -306,15 +350,15 @@ __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) 
   const int SUM1 = (int)a.sum_mode;
 
   // chunk k lives in buffer k&1; the loop is unrolled by two so buffer offsets are immediates
-#define DDT_COMPUTE(BUF, PH)                                                                                   \
-  do {                                                                                                         \
-    if (SUM1 == 0) {                                                                                           \
-      if (!slow) compute_chunk<D, U, R, CT, (BUF) * CHUNK_BYTES, PH, false, 0>(lane_off, miss_key, C, ra, dacc); \
-      else compute_chunk<D, U, R, CT, (BUF) * CHUNK_BYTES, PH, true, 0>(lane_off, miss_key, C, ra, dacc);        \
-    } else {                                                                                                   \
-      if (!slow) compute_chunk<D, U, R, CT, (BUF) * CHUNK_BYTES, PH, false, 1>(lane_off, miss_key, C, ra, dacc); \
-      else compute_chunk<D, U, R, CT, (BUF) * CHUNK_BYTES, PH, true, 1>(lane_off, miss_key, C, ra, dacc);        \
-    }                                                                                                          \
+#define DDT_COMPUTE(BUF, PH)                                                                                          \
+  do {                                                                                                                \
+    if (SUM1 == 0) {                                                                                                  \
+      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 0, FUSED>(lane_off, miss_key, C, ra, dacc); \
+      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 0, FUSED>(lane_off, miss_key, C, ra, dacc);        \
+    } else {                                                                                                          \
+      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 1, FUSED>(lane_off, miss_key, C, ra, dacc); \
+      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 1, FUSED>(lane_off, miss_key, C, ra, dacc);        \
+    }                                                                                                                 \
   } while (0)
 
   constexpr int PH1 = (CT == 4) ? 1 : 0;  // CT=4: odd chunks are the second half of a PU group
@@ -323,21 +367,21 @@ __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) 
     __syncthreads();  // chunk k is in buffer 0 for everyone; everyone is done with buffer 1
     const bool more1 = k + 1 < n_chunks;
     if (more1) {
-      if (STAGE == 1) dma_chunk<THREADS, CHUNK_BYTES>(a.img, k + 1, CHUNK_BYTES, tid);
+      if (STAGE == 1) dma_chunk<THREADS, CHUNK_BYTES>(a.img, k + 1, MB + CHUNK_BYTES, tid);
       else sr.load(a.img, k + 1, tid);
     }
     DDT_COMPUTE(0, 0);
     if (!more1) break;
-    if (STAGE == 0) sr.commit(CHUNK_BYTES, tid);
+    if (STAGE == 0) sr.commit(MB + CHUNK_BYTES, tid);
     if (STAGE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool more2 = k + 2 < n_chunks;
     if (more2) {
-      if (STAGE == 1) dma_chunk<THREADS, CHUNK_BYTES>(a.img, k + 2, 0, tid);
+      if (STAGE == 1) dma_chunk<THREADS, CHUNK_BYTES>(a.img, k + 2, MB, tid);
       else sr.load(a.img, k + 2, tid);
     }
     DDT_COMPUTE(1, PH1);
-    if (STAGE == 0 && more2) sr.commit(0, tid);
+    if (STAGE == 0 && more2) sr.commit(MB, tid);
   }
 #undef DDT_COMPUTE
 
@@ -349,9 +393,9 @@ __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) 
   }
 }
 
-template <int D, int THREADS, int R, int CT, int U, int STAGE>
+template <int D, int THREADS, int R, int CT, int U, int STAGE, int OPT>
 static hipError_t launch_tile(const ScoreArgs& a, const Variant& v, hipStream_t s) {
-  auto kern = score_tile_kernel<D, THREADS, R, CT, U, STAGE>;
+  auto kern = score_tile_kernel<D, THREADS, R, CT, U, STAGE, OPT>;
   const uint32_t lds = v.lds_bytes(a.tuple_words);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -364,10 +408,111 @@ static hipError_t launch_tile(const ScoreArgs& a, const Variant& v, hipStream_t 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// the stream kernel: small ensembles whose whole image fits in LDS next to one tile of tuples -- the
+// HBM-bound regime (e.g. BASELINE config 1: 8 trees x depth 4 = 32 node visits per 68 compulsory bytes).
+// Persistent blocks (grid = CUs x blocks/CU) walk the tiles with a grid stride.  Tuples are read with
+// fully coalesced 16-byte loads (thread t takes float4 #t of the tile's contiguous byte range), one tile
+// AHEAD of the compute, and written transposed into LDS.  The transposed write is LPT-way bank conflicted
+// (LPT = lines per tuple); that costs ~LPT LDS cycles per tuple, negligible against the HBM time here and
+// the price of perfectly coalesced reads.  Model image: classic layout at LDS [0, img_bytes).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kStreamThreads = 256;
+constexpr int kStreamMaxLpt = 8;   // tuples up to 32 words
+constexpr uint32_t kStreamRow = kStreamThreads * 4u;
+
+template <int D, int U, int MAXLPT>
+__global__ __launch_bounds__(kStreamThreads) void score_stream_kernel(const ScoreArgs a) {
+  constexpr int THREADS = kStreamThreads, TILE = kStreamThreads;
+  constexpr int TREE_BYTES = 12 << D;
+  const int tid = threadIdx.x;
+  const uint32_t W = a.tuple_words, LPT = W / 4u;
+  const uint32_t img_bytes = a.n_trees * (uint32_t)TREE_BYTES;
+  const uint32_t feat_off = (img_bytes + kStreamRow - 1u) / kStreamRow * kStreamRow;  // == host's Variant::feat_off
+  const uint32_t flags = feat_off + W * kStreamRow;
+  const uint64_t n_tiles = (a.n + TILE - 1) / TILE;
+  const uint32_t C = a.clusters, miss_key = a.miss_key;
+
+  // resident model
+  for (uint32_t off = (uint32_t)tid * 16u; off < img_bytes; off += THREADS * 16u)
+    lds_st_u4(off, a.img[off / 16u]);
+
+  // element e (0..TILE*LPT) of a tile = float4 #e of its byte range: tuple e / LPT, line e % LPT
+  uint4 pre[MAXLPT];
+  auto prefetch = [&](uint64_t tile) {
+    const uint4* src = reinterpret_cast<const uint4*>(a.tuples + tile * TILE * W);
+    const uint64_t avail = (a.n - tile * TILE < (uint64_t)TILE ? a.n - tile * TILE : (uint64_t)TILE) * LPT;
+#pragma unroll
+    for (int i = 0; i < MAXLPT; ++i) {
+      const uint32_t e = (uint32_t)tid + (uint32_t)i * THREADS;
+      pre[i] = ((uint32_t)i < LPT && e < avail) ? src[e] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+
+  uint64_t tile = blockIdx.x;
+  if (tile < n_tiles) prefetch(tile);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile fully consumed (first pass: model image written)
+    uint32_t miss_any = 0;
+#pragma unroll
+    for (int i = 0; i < MAXLPT; ++i) {
+      if ((uint32_t)i < LPT) {
+        const uint32_t e = (uint32_t)tid + (uint32_t)i * THREADS;
+        const uint32_t t = e / LPT, q = e - t * LPT;
+        const bool valid = tile * TILE + t < a.n;
+        const uint32_t fa = feat_off + (4u * q) * kStreamRow + t * 4u;
+        lds_st_u32(fa + 0 * kStreamRow, stage_word(pre[i].x, a, miss_any, valid));
+        lds_st_u32(fa + 1 * kStreamRow, stage_word(pre[i].y, a, miss_any, valid));
+        lds_st_u32(fa + 2 * kStreamRow, stage_word(pre[i].z, a, miss_any, valid));
+        lds_st_u32(fa + 3 * kStreamRow, stage_word(pre[i].w, a, miss_any, valid));
+      }
+    }
+    const bool slow = block_any<THREADS>(miss_any, flags, tid);
+    if (tile + gridDim.x < n_tiles) prefetch(tile + gridDim.x);  // next tile's HBM reads fly during the walk
+
+    RefAcc<1> ra;
+    ra.init();
+    double dacc[1] = {0.0};
+    const uint32_t lane_off[1] = {(uint32_t)tid * 4u};
+    for (uint32_t t0 = 0; t0 < a.n_trees; t0 += (uint32_t)U) {  // U = 8: one PU group per iteration, U = 4: half
+      float lf[1][U];
+      const uint32_t base = t0 * (uint32_t)TREE_BYTES;
+      const int phase = (int)((t0 / (uint32_t)U) & 1u);
+      if (!slow) walk_trees<D, U, 1, TREE_BYTES, false, false>(base, lane_off, miss_key, lf);
+      else walk_trees<D, U, 1, TREE_BYTES, true, false>(base, lane_off, miss_key, lf);
+      if (a.sum_mode == 0) fold_leaves<U, 1, 0>(lf, phase, C, ra, dacc);
+      else fold_leaves<U, 1, 1>(lf, phase, C, ra, dacc);
+    }
+    ra.align(C);
+    const uint64_t row = tile * TILE + (uint64_t)tid;
+    if (row < a.n) a.out[row] = (a.sum_mode == 0) ? ra.total(0, C) : (float)dacc[0];
+  }
+}
+
+uint32_t stream_blocks_per_cu(uint32_t lds_bytes) {
+  uint32_t b = (160u * 1024u) / (lds_bytes ? lds_bytes : 1u);
+  return b < 1u ? 1u : (b > 8u ? 8u : b);
+}
+
+template <int D, int U, int MAXLPT>
+static hipError_t launch_stream(const ScoreArgs& a, const Variant& v, hipStream_t s) {
+  if (a.tuple_words > 4u * MAXLPT) return hipErrorInvalidValue;
+  auto kern = score_stream_kernel<D, U, MAXLPT>;
+  const uint32_t lds = v.lds_bytes_stream(a.n_trees, a.tuple_words);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const uint64_t tiles = (a.n + kStreamThreads - 1) / kStreamThreads;
+  if (tiles == 0) return hipSuccess;
+  uint64_t grid = 256ull * stream_blocks_per_cu(lds);  // persistent: CUs x resident blocks per CU
+  if (grid > tiles) grid = tiles;
+  hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(kStreamThreads), lds, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // generic kernel: any D (1..16), any F (1..2048).  Lane = tuple, 256 tuples per block, one tree at a
 // time.  Features in LDS when the tile fits, else gathered from global memory; tree in LDS when it
 // fits (12*2^D bytes), else nodes are read from global memory (L2).  Correctness path for shapes the
-// specialised tile kernels do not cover; same image format with w2 = feature index | miss_right<<31.
+// specialised kernels do not cover; same image format with w2 = feature index | miss_right<<31.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kGenericLdsBudget = 150u * 1024u;
 
@@ -383,22 +528,20 @@ uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_
 
 template <bool FEAT_LDS, bool TREE_LDS>
 __global__ __launch_bounds__(kGenericThreads) void score_generic_kernel(const ScoreArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int TILE = kGenericThreads;
-  const int tid = threadIdx.x;
+  constexpr uint32_t TILE = kGenericThreads;
+  const uint32_t tid = threadIdx.x;
   const uint32_t W = a.tuple_words, D = a.levels;
   const uint64_t row = (uint64_t)blockIdx.x * TILE + tid;
   const bool valid = row < a.n;
   const uint32_t* xrow = a.tuples + (valid ? row : 0) * W;
-  uint32_t* feat = reinterpret_cast<uint32_t*>(smem);
   const uint32_t tree_bytes = 12u << D;
-  unsigned char* tree_lds = smem + (FEAT_LDS ? W * TILE * 4u : 0u);
+  const uint32_t tree_lds = FEAT_LDS ? W * TILE * 4u : 0u;  // LDS: [features][one tree]
 
   if (FEAT_LDS) {
     for (uint32_t j = 0; j < W; ++j) {
       uint32_t v = valid ? xrow[j] : 0u;
       if (a.ieee) v = (v == a.miss_raw) ? kMissSentinelIeee : ieee_key(v);
-      feat[j * TILE + tid] = v;
+      lds_st_u32((j * TILE + tid) * 4u, v);
     }
   }
   RefAcc<1> ra;
@@ -407,38 +550,36 @@ __global__ __launch_bounds__(kGenericThreads) void score_generic_kernel(const Sc
   float grp[8];
   for (uint32_t t8 = 0; t8 < a.n_trees; t8 += 8u) {
 #pragma unroll
-   for (uint32_t tu = 0; tu < 8u; ++tu) {
-    const uint32_t t = t8 + tu;
-    const unsigned char* timg = reinterpret_cast<const unsigned char*>(a.img) + (size_t)t * tree_bytes;
-    if (TREE_LDS) {
-      __syncthreads();  // previous tree fully consumed (also publishes feat on the first pass)
-      for (uint32_t off = tid * 16u; off < tree_bytes; off += TILE * 16u)
-        *reinterpret_cast<uint4*>(tree_lds + off) = *reinterpret_cast<const uint4*>(timg + off);
-      __syncthreads();
-    }
-    const unsigned char* tb = TREE_LDS ? tree_lds : timg;
-    uint32_t m = 1;
-    for (uint32_t lvl = 0; lvl < D; ++lvl) {
-      const uint2 nd = *reinterpret_cast<const uint2*>(tb + (size_t)m * 8u);
-      const uint32_t j = nd.y & 0x7FFFFFFFu;
-      uint32_t f;
-      if (FEAT_LDS) f = feat[j * TILE + tid];
-      else {
-        f = xrow[j];
-        if (a.ieee) f = (f == a.miss_raw) ? kMissSentinelIeee : ieee_key(f);
+    for (uint32_t tu = 0; tu < 8u; ++tu) {
+      const uint32_t t = t8 + tu;
+      const unsigned char* timg = reinterpret_cast<const unsigned char*>(a.img) + (size_t)t * tree_bytes;
+      if (TREE_LDS) {
+        __syncthreads();  // previous tree fully consumed
+        for (uint32_t off = tid * 16u; off < tree_bytes; off += TILE * 16u)
+          lds_st_u4(tree_lds + off, *reinterpret_cast<const uint4*>(timg + off));
+        __syncthreads();
       }
-      bool right = (int32_t)f >= (int32_t)nd.x;
-      right = (f == a.miss_key) ? ((nd.y >> 31) != 0u) : right;
-      m = 2u * m + (right ? 1u : 0u);
+      uint32_t m = 1;
+      for (uint32_t lvl = 0; lvl < D; ++lvl) {
+        const uint2 nd = TREE_LDS ? lds_u2(tree_lds + m * 8u) : *reinterpret_cast<const uint2*>(timg + (size_t)m * 8u);
+        const uint32_t j = nd.y & 0x7FFFFFFFu;
+        uint32_t f;
+        if (FEAT_LDS) f = lds_u32((j * TILE + tid) * 4u);
+        else {
+          f = xrow[j];
+          if (a.ieee) f = (f == a.miss_raw) ? kMissSentinelIeee : ieee_key(f);
+        }
+        m = 2u * m + (go_right<true>(f, nd.x, nd.y, a.miss_key) ? 1u : 0u);
+      }
+      const uint32_t lo = (8u << D) + (m - (1u << D)) * 4u;
+      const float leaf = TREE_LDS ? lds_f32(tree_lds + lo) : *reinterpret_cast<const float*>(timg + lo);
+      if (a.sum_mode == 1) dacc += (double)leaf;
+      grp[tu] = leaf;
     }
-    const float leaf = *reinterpret_cast<const float*>(tb + (8u << D) + (size_t)(m - (1u << D)) * 4u);
-    if (a.sum_mode == 1) dacc += (double)leaf;
-    grp[tu] = leaf;
-   }
-   if (a.sum_mode != 1) {
-     const float s[1] = {((grp[0] + grp[1]) + (grp[2] + grp[3])) + ((grp[4] + grp[5]) + (grp[6] + grp[7]))};
-     ra.push_group(s, a.clusters);
-   }
+    if (a.sum_mode != 1) {
+      const float s[1] = {((grp[0] + grp[1]) + (grp[2] + grp[3])) + ((grp[4] + grp[5]) + (grp[6] + grp[7]))};
+      ra.push_group(s, a.clusters);
+    }
   }
   ra.align(a.clusters);
   if (valid) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, a.clusters);
@@ -522,27 +663,36 @@ hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t 
 // ---------------------------------------------------------------------------------------------------
 // variant table
 // ---------------------------------------------------------------------------------------------------
-#define DDT_V(NAME, D, TH, R, CT, U, ST) \
-  Variant { NAME, D, TH, R, CT, U, ST, &launch_tile<D, TH, R, CT, U, ST> }
+#define DDT_V(NAME, D, TH, R, CT, U, ST, OPT) \
+  Variant { NAME, kKindTile, D, TH, R, CT, U, ST, OPT, &launch_tile<D, TH, R, CT, U, ST, OPT> }
+#define DDT_S(NAME, D, U, MAXLPT) \
+  Variant { NAME, kKindStream, D, kStreamThreads, 1, 8, U, 0, MAXLPT, &launch_stream<D, U, MAXLPT> }
 
 static const Variant g_variants[] = {
-    Variant{"generic", 0, kGenericThreads, 1, 1, 1, 0, &launch_generic},
-    // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB
-    DDT_V("d8_t1024_r1_c4_u4_dma", 8, 1024, 1, 4, 4, 1),
-    DDT_V("d8_t1024_r1_c4_u4_reg", 8, 1024, 1, 4, 4, 0),
-    DDT_V("d8_t512_r2_c4_u4_dma", 8, 512, 2, 4, 4, 1),
-    DDT_V("d8_t512_r1_c4_u4_dma", 8, 512, 1, 4, 4, 1),
-    DDT_V("d8_t512_r1_c8_u8_dma", 8, 512, 1, 8, 8, 1),
-    DDT_V("d8_t256_r1_c4_u4_dma", 8, 256, 1, 4, 4, 1),
-    DDT_V("d8_t256_r1_c8_u8_dma", 8, 256, 1, 8, 8, 1),
-    DDT_V("d8_t256_r2_c4_u4_dma", 8, 256, 2, 4, 4, 1),
-    DDT_V("d8_t256_r1_c8_u4_reg", 8, 256, 1, 8, 4, 0),
+    Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_generic},
+    // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB.  suffix _f = last level fused with its leaves
+    DDT_V("d8_t1024_r1_c4_u4_dma_f", 8, 1024, 1, 4, 4, 1, 1),
+    DDT_V("d8_t1024_r1_c4_u4_dma", 8, 1024, 1, 4, 4, 1, 0),
+    DDT_V("d8_t1024_r1_c4_u4_reg", 8, 1024, 1, 4, 4, 0, 0),
+    DDT_V("d8_t512_r2_c4_u4_dma", 8, 512, 2, 4, 4, 1, 0),
+    DDT_V("d8_t512_r1_c8_u8_dma", 8, 512, 1, 8, 8, 1, 0),
+    DDT_V("d8_t512_r1_c8_u8_dma_f", 8, 512, 1, 8, 8, 1, 1),
+    DDT_V("d8_t256_r1_c4_u4_dma", 8, 256, 1, 4, 4, 1, 0),
     // depth 6 (BASELINE config 2): tree = 768 B
-    DDT_V("d6_t256_r1_c16_u4_dma", 6, 256, 1, 16, 4, 1),
-    DDT_V("d6_t512_r1_c16_u8_dma", 6, 512, 1, 16, 8, 1),
-    DDT_V("d6_t1024_r1_c16_u4_dma", 6, 1024, 1, 16, 4, 1),
-    // depth 4 (BASELINE config 1): tree = 192 B
-    DDT_V("d4_t256_r1_c64_u8_dma", 4, 256, 1, 64, 8, 1),
+    DDT_V("d6_t1024_r1_c16_u4_dma", 6, 1024, 1, 16, 4, 1, 0),
+    DDT_V("d6_t1024_r1_c16_u8_dma", 6, 1024, 1, 16, 8, 1, 0),
+    DDT_V("d6_t512_r1_c16_u8_dma", 6, 512, 1, 16, 8, 1, 0),
+    DDT_V("d6_t256_r1_c16_u4_dma", 6, 256, 1, 16, 4, 1, 0),
+    // depth 4: tree = 192 B
+    DDT_V("d4_t256_r1_c64_u8_dma", 4, 256, 1, 64, 8, 1, 0),
+    // resident-model streaming kernels (small ensembles, HBM-bound; BASELINE config 1 is depth 4)
+    DDT_S("stream_d4_u4_l4", 4, 4, 4),
+    DDT_S("stream_d4_u8_l4", 4, 8, 4),
+    DDT_S("stream_d4_u4_l8", 4, 4, 8),
+    DDT_S("stream_d4_u8_l8", 4, 8, 8),
+    DDT_S("stream_d6_u4_l4", 6, 4, 4),
+    DDT_S("stream_d6_u4_l8", 6, 4, 8),
+    DDT_S("stream_d8_u4_l8", 8, 4, 8),
 };
 
 int num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
