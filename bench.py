@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--chunk-rows", type=int, default=12_500_000, help="rows per pipelined collective (N>1)")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant id (-1 = engine's choice)")
     ap.add_argument("--sum-mode", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) is the product path; gloo lets N ranks share one GPU for a functional test")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -63,9 +65,13 @@ def main():
         sys.exit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the scoring path has no CPU fallback)")
+    local = local % torch.cuda.device_count() if args.backend == "gloo" else local
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     T, D, F, N = args.trees, args.levels, args.features, args.rows
     W = ddt.tuple_words(F)
@@ -173,7 +179,8 @@ def main():
             "config": {"workload": f"{T} trees x depth {D} x {F} fp32 features, {N} tuples/step, "
                                    + ("single engine" if world == 1 else f"tree-sharded {world}x + RCCL {args.combine}"),
                        "trees": T, "levels": D, "features": F, "rows": N, "parallelism": f"tree-shard{world}",
-                       "combine": args.combine if world > 1 else None, "kernel": info.variant_name.decode(),
+                       "combine": args.combine if world > 1 else None,
+                       "collective_backend": (args.backend if world > 1 else None), "kernel": info.variant_name.decode(),
                        "sum_mode": "reference-order fp32" if args.sum_mode == 0 else "fp64 accumulate",
                        "device": info.device_name.decode()},
         }

@@ -53,6 +53,9 @@ class ShardedScorer:
         self.chain_fn = chain_fn or chain_sum
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # gloo has no device collectives: device tensors are staged through host memory (functional test mode
+        # for boxes with one GPU; the production path is backend "nccl" == RCCL over xGMI)
+        self.gloo = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     @classmethod
     def from_engine(cls, engine, **kw):
@@ -85,7 +88,23 @@ class ShardedScorer:
             if self.mode == "allreduce":
                 o = out[lo:hi]
                 self.partial_fn(tuples[lo:hi], o)
-                works.append(dist.all_reduce(o, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.gloo and o.is_cuda:
+                    h = o.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                    o.copy_(h)
+                else:
+                    works.append(dist.all_reduce(o, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            elif self.gloo and tuples.is_cuda:
+                m = hi - lo
+                seg = (m + G - 1) // G
+                part = torch.zeros(G * seg, dtype=torch.float32, device=tuples.device)
+                self.partial_fn(tuples[lo:hi], part[:m])
+                recv = torch.empty(G * seg, dtype=torch.float32)
+                dist.all_to_all_single(recv, part.cpu(), group=self.group)
+                mine = self.chain_fn(recv.to(tuples.device).view(G, seg))
+                full = torch.empty(G * seg, dtype=torch.float32)
+                dist.all_gather_into_tensor(full, mine.cpu().contiguous(), group=self.group)
+                out[lo:hi] = full[:m].to(tuples.device)
             else:
                 m = hi - lo
                 seg = (m + G - 1) // G  # segment owned by each rank (last one zero padded)

@@ -242,3 +242,50 @@ def test_full_size_properties(eng, T, D, F, N):
     assert np.array_equal(xs, np.concatenate([O.gen_tuples(int(i), 1, F) for i in idx.cpu().numpy()[:50]] +
                                              [xs[50:]]))                              # inputs are the seeded ones
     assert torch.isfinite(a).all()
+
+
+def _two_rank_worker(rank, world, port, mode, ret):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        T, D, F, n = 1000, 8, 32, 5003
+        w, f = ddt.synth_model(T, D, F)
+        e = ddt.Engine(0)
+        e.load_model(ddt.make_params(T, D, F), w, f, rank, world)
+        d = e.synth_tuples_device(0, n, F)
+        sc = ddt.ShardedScorer.from_engine(e, mode=mode, chunk_rows=2048)
+        got = sc.score(d)
+        torch.cuda.synchronize()
+        m = O.Model(O.make_params(T, D, F), w, f)
+        want = O.score(m, d.cpu().numpy().view(np.uint32), n_devices=world)
+        ret[rank] = bool(np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)))
+        e.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "chain"])
+def test_two_ranks_tree_sharded_on_one_gpu(mode):
+    """One process per rank (here both on cuda:0, gloo as the collective backend because RCCL refuses two ranks
+    on one device): the whole N>1 host path -- shard load, chunked partial scoring, combine -- against the
+    oracle's 2-device model.  With 2 ranks a sum of two fp32 partials is order independent => bit-exact."""
+    import socket
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, mode, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert ret.get(0) and ret.get(1), dict(ret)
