@@ -20,23 +20,26 @@ using namespace ddt;
 
 namespace {
 
-constexpr uint32_t kMaxLdsBytes = 160u * 1024u;  // MI355X: 160 KiB LDS per CU / workgroup
+constexpr uint32_t kMaxLdsBytes = 160u * 1024u;     // MI355X: 160 KiB LDS per CU / workgroup
+constexpr uint32_t kStreamLdsBudget = 40u * 1024u;  // stream kernels: keep >= 4 resident blocks per CU
 
 double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-// The model as parsed from the reference wire format (this engine's shard only).
-struct HostModel {
-  ddt_params p{};
-  uint32_t tree_begin = 0, tree_end = 0;  // global ids
-  uint32_t nint = 0, nleaf = 0;
-  std::vector<uint32_t> thr;    // [T_local][nint]   raw fp32 bit patterns (heap order, 0-based)
-  std::vector<uint16_t> fidx;   // [T_local][nint]
-  std::vector<uint8_t> mright;  // [T_local][nint]
-  std::vector<uint32_t> leaf;   // [T_local][nleaf]
-  uint32_t trees() const { return tree_end - tree_begin; }
+// One ensemble as parsed from the reference wire format: the trees this engine holds of one class
+// (single-output models have exactly one ensemble), plus its device image for the active variant.
+struct Ensemble {
+  std::vector<uint32_t> ids;    // global tree ids in stream order
+  std::vector<uint32_t> thr;    // [T][nint]   raw fp32 bit patterns (heap order, 0-based)
+  std::vector<uint16_t> fidx;   // [T][nint]
+  std::vector<uint8_t> mright;  // [T][nint]
+  std::vector<uint32_t> leaf;   // [T][nleaf]
+  void* d_img = nullptr;
+  size_t img_bytes = 0;
+  uint32_t img_trees = 0, img_chunks = 0;
+  uint32_t trees() const { return (uint32_t)ids.size(); }
 };
 
 }  // namespace
@@ -45,13 +48,12 @@ struct ddt_engine {
   int device = -1;
   hipDeviceProp_t prop{};
   bool loaded = false;
-  HostModel m;
+  ddt_params p{};
+  uint32_t nint = 0, nleaf = 0;
+  uint32_t num_classes = 1;
+  std::vector<Ensemble> ens;  // one per class
   int forced_variant = -1;
   int variant_id = 0;
-  // device image for the active variant
-  void* d_img = nullptr;
-  size_t img_bytes = 0;
-  uint32_t img_trees = 0, img_chunks = 0;
   // feeder
   size_t feeder_rows = 1u << 18;
   hipStream_t fs[2] = {nullptr, nullptr};
@@ -60,7 +62,10 @@ struct ddt_engine {
   void* pin_out[2] = {nullptr, nullptr};
   void* dev_in[2] = {nullptr, nullptr};
   void* dev_out[2] = {nullptr, nullptr};
-  size_t feeder_cap_rows = 0, feeder_cap_words = 0;
+  size_t feeder_cap_rows = 0, feeder_cap_words = 0, feeder_cap_outs = 0;
+  // classify workspace (grow-only)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
   ddt_stats st{};
   char err[256] = {0};
 };
@@ -85,6 +90,7 @@ int fail(ddt_engine* e, int code, const char* fmt, ...) {
 
 uint32_t wlines_min(uint32_t D) { return (uint32_t)((((1ull << (D + 1)) - 1) + 3) / 4); }
 uint32_t flines_min(uint32_t D) { return (uint32_t)((((1ull << D) - 1) + 7) / 8); }
+uint32_t tuple_words(const ddt_params& p) { return (p.num_features + 3u) / 4u * 4u; }
 
 int validate(ddt_engine* e, const ddt_params* p, size_t n_wlines, size_t n_flines) {
   if (!p) return fail(e, DDT_EINVAL, "params is NULL");
@@ -105,66 +111,64 @@ int validate(ddt_engine* e, const ddt_params* p, size_t n_wlines, size_t n_fline
   return DDT_OK;
 }
 
-// Parse the shard [b, e) of the two streams (A2 packing: word k of a line = bits [32k+31:32k]).
-int parse_model(ddt_engine* eng, const ddt_params* p, const uint32_t* w, const uint16_t* f, uint32_t b, uint32_t e,
-                HostModel* out) {
-  HostModel m;
-  m.p = *p;
-  m.tree_begin = b;
-  m.tree_end = e;
-  const uint32_t D = p->num_levels;
-  m.nint = (1u << D) - 1u;
-  m.nleaf = 1u << D;
-  const uint32_t T = e - b;
+// Parse the trees `ids` out of the two streams (A2 packing: word k of a line = bits [32k+31:32k]).
+int parse_trees(ddt_engine* eng, const ddt_params* p, const uint32_t* w, const uint16_t* f, std::vector<uint32_t> ids,
+                Ensemble* out) {
+  Ensemble m;
+  const uint32_t D = p->num_levels, nint = (1u << D) - 1u, nleaf = 1u << D;
+  const uint32_t T = (uint32_t)ids.size();
   try {
-    m.thr.resize((size_t)T * m.nint);
-    m.fidx.resize((size_t)T * m.nint);
-    m.mright.resize((size_t)T * m.nint);
-    m.leaf.resize((size_t)T * m.nleaf);
+    m.thr.resize((size_t)T * nint);
+    m.fidx.resize((size_t)T * nint);
+    m.mright.resize((size_t)T * nint);
+    m.leaf.resize((size_t)T * nleaf);
   } catch (const std::bad_alloc&) {
     return fail(eng, DDT_ENOMEM, "host model allocation failed");
   }
   for (uint32_t i = 0; i < T; ++i) {
-    const uint32_t* wt = w + (size_t)(b + i) * p->weights_lines_per_tree * 4u;
-    const uint16_t* ft = f + (size_t)(b + i) * p->findex_lines_per_tree * 8u;
-    for (uint32_t n = 0; n < m.nint; ++n) {
+    const uint32_t* wt = w + (size_t)ids[i] * p->weights_lines_per_tree * 4u;
+    const uint16_t* ft = f + (size_t)ids[i] * p->findex_lines_per_tree * 8u;
+    for (uint32_t n = 0; n < nint; ++n) {
       const uint16_t en = ft[n];
       const uint32_t j = en & 0x7FFu;  // DTPU.sv:628
       if (j >= p->num_features)
-        return fail(eng, DDT_EINVAL, "tree %u node %u: feature index %u >= num_features %u", b + i, n, j, p->num_features);
+        return fail(eng, DDT_EINVAL, "tree %u node %u: feature index %u >= num_features %u", ids[i], n, j, p->num_features);
       if (en & (1u << 14))  // "next node is leaf" has no well-defined result in the published RTL
-        return fail(eng, DDT_EUNSUPPORTED, "tree %u node %u: early-leaf flag (bit 14) is not supported; pad the tree to a perfect one", b + i, n);
-      m.thr[(size_t)i * m.nint + n] = wt[n];
-      m.fidx[(size_t)i * m.nint + n] = (uint16_t)j;
-      m.mright[(size_t)i * m.nint + n] = (uint8_t)((en >> 13) & 1u);  // DTPU.sv:659
+        return fail(eng, DDT_EUNSUPPORTED, "tree %u node %u: early-leaf flag (bit 14) is not supported; pad the tree to a perfect one", ids[i], n);
+      m.thr[(size_t)i * nint + n] = wt[n];
+      m.fidx[(size_t)i * nint + n] = (uint16_t)j;
+      m.mright[(size_t)i * nint + n] = (uint8_t)((en >> 13) & 1u);  // DTPU.sv:659
     }
-    for (uint32_t l = 0; l < m.nleaf; ++l) m.leaf[(size_t)i * m.nleaf + l] = wt[m.nint + l];
+    for (uint32_t l = 0; l < nleaf; ++l) m.leaf[(size_t)i * nleaf + l] = wt[nint + l];
   }
+  m.ids = std::move(ids);
   *out = std::move(m);
   return DDT_OK;
 }
 
-uint32_t thr_key(const HostModel& m, uint32_t bits) {
-  if (m.p.cmp_mode == 0) return bits;
+uint32_t thr_key(const ddt_params& p, uint32_t bits) {
+  if (p.cmp_mode == 0) return bits;
   if ((bits & 0x7FFFFFFFu) > 0x7F800000u) return 0x80000000u;  // x < NaN is never true -> always right
   return ieee_key(bits);
 }
-
-uint32_t tuple_words(const ddt_params& p) { return (p.num_features + 3u) / 4u * 4u; }
 
 uint32_t padded_trees(const Variant& v, uint32_t T) {
   const uint32_t granule = (v.kind == kKindTile && v.chunk_trees > 8) ? (uint32_t)v.chunk_trees : 8u;
   return (T + granule - 1u) / granule * granule;  // whole PU groups of 8 (and whole chunks)
 }
 
-constexpr uint32_t kStreamLdsBudget = 40u * 1024u;  // keeps >= 4 resident blocks per CU for HBM latency hiding
+uint32_t max_trees(const ddt_engine* e) {
+  uint32_t t = 0;
+  for (const Ensemble& m : e->ens) t = m.trees() > t ? m.trees() : t;
+  return t;
+}
 
-bool variant_fits(const Variant& v, const HostModel& m) {
+bool variant_fits(const Variant& v, const ddt_engine* e) {
   if (v.kind == kKindGeneric) return true;
-  if ((uint32_t)v.levels != m.p.num_levels) return false;
-  const uint32_t W = tuple_words(m.p);
+  if ((uint32_t)v.levels != e->p.num_levels) return false;
+  const uint32_t W = tuple_words(e->p);
   if (v.kind == kKindStream)
-    return W <= 4u * (uint32_t)v.opt && v.lds_bytes_stream(padded_trees(v, m.trees()), W) <= kStreamLdsBudget;
+    return W <= 4u * (uint32_t)v.opt && v.lds_bytes_stream(padded_trees(v, max_trees(e)), W) <= kStreamLdsBudget;
   return v.lds_bytes(W) <= kMaxLdsBytes;
 }
 
@@ -174,7 +178,7 @@ int find_variant(const char* name) {
   return -1;
 }
 
-int auto_variant(const HostModel& m) {
+int auto_variant(const ddt_engine* e) {
   // Preference order, first that fits wins; tuned from the sweeps under profiles/ (see DESIGN.md):
   // small ensembles that fit LDS whole -> streaming kernel (HBM-bound regime); otherwise the tile kernel with
   // the most waves per CU the feature tile allows; anything else -> generic.
@@ -184,22 +188,22 @@ int auto_variant(const HostModel& m) {
                                "d4_t256_r1_c64_u8_dma"};
   for (const char* name : pref) {
     const int i = find_variant(name);
-    if (i >= 0 && variant_fits(variant(i), m)) return i;
+    if (i >= 0 && variant_fits(variant(i), e)) return i;
   }
   return 0;
 }
 
-void free_image(ddt_engine* e) {
-  if (e->d_img) (void)hipFree(e->d_img);
-  e->d_img = nullptr;
-  e->img_bytes = 0;
+void free_images(ddt_engine* e) {
+  for (Ensemble& m : e->ens) {
+    if (m.d_img) (void)hipFree(m.d_img);
+    m.d_img = nullptr;
+    m.img_bytes = 0;
+  }
 }
 
-// Build the device image for variant `vid` and upload it (layouts: ddt_internal.h).
-int build_image(ddt_engine* e, int vid) {
-  const Variant& v = variant(vid);
-  const HostModel& m = e->m;
-  const uint32_t D = m.p.num_levels, T = m.trees();
+// Build the device image of one ensemble for variant `v` and upload it (layouts: ddt_internal.h).
+int build_image(ddt_engine* e, const Variant& v, Ensemble& m) {
+  const uint32_t D = e->p.num_levels, T = m.trees(), nint = e->nint, nleaf = e->nleaf;
   const uint32_t tree_bytes = 12u << D;
   const uint32_t Tpad = padded_trees(v, T);  // EMPTY trees: every leaf +0 (DTPU.sv:544,760)
   const size_t bytes = (size_t)Tpad * tree_bytes;
@@ -217,19 +221,19 @@ int build_image(ddt_engine* e, int vid) {
   const uint32_t first_last = 1u << (D - 1);  // 1-based index of the first last-level node
   for (uint32_t i = 0; i < Tpad; ++i) {
     uint32_t* t = img.data() + (size_t)i * (tree_bytes / 4);
-    const bool empty = i >= T;  // EMPTY tree: all-zero thresholds and leaves; node words must still gather in range
-    for (uint32_t n = 0; n < m.nint; ++n) {
+    const bool empty = i >= T;  // EMPTY tree: zero thresholds and leaves; node words must still gather in range
+    for (uint32_t n = 0; n < nint; ++n) {
       const uint32_t mm = n + 1;  // 1-based heap record
-      const uint32_t j = empty ? 0u : m.fidx[(size_t)i * m.nint + n];
-      const uint32_t word = feature_word(j) | ((!empty && m.mright[(size_t)i * m.nint + n]) ? kFlagMissRight : 0u);
-      const uint32_t key = empty ? 0u : thr_key(m, m.thr[(size_t)i * m.nint + n]);
+      const uint32_t j = empty ? 0u : m.fidx[(size_t)i * nint + n];
+      const uint32_t word = feature_word(j) | ((!empty && m.mright[(size_t)i * nint + n]) ? kFlagMissRight : 0u);
+      const uint32_t key = empty ? 0u : thr_key(e->p, m.thr[(size_t)i * nint + n]);
       if (fused && mm >= first_last) {  // layout 1: {thr, w2, leafL, leafR} at 4*2^D + 16*(m - 2^(D-1))
         const uint32_t r = mm - first_last;
         uint32_t* rec = t + (4u << D) / 4 + 4 * r;
         rec[0] = key;
         rec[1] = word;
-        rec[2] = empty ? 0u : m.leaf[(size_t)i * m.nleaf + 2 * r];
-        rec[3] = empty ? 0u : m.leaf[(size_t)i * m.nleaf + 2 * r + 1];
+        rec[2] = empty ? 0u : m.leaf[(size_t)i * nleaf + 2 * r];
+        rec[3] = empty ? 0u : m.leaf[(size_t)i * nleaf + 2 * r + 1];
       } else {
         t[2 * mm + 0] = key;
         t[2 * mm + 1] = word;
@@ -237,16 +241,16 @@ int build_image(ddt_engine* e, int vid) {
     }
     if (!fused && !empty) {
       uint32_t* lv = t + (8u << D) / 4;
-      for (uint32_t l = 0; l < m.nleaf; ++l) lv[l] = m.leaf[(size_t)i * m.nleaf + l];
+      for (uint32_t l = 0; l < nleaf; ++l) lv[l] = m.leaf[(size_t)i * nleaf + l];
     }
   }
-  free_image(e);
-  HIP_TRY(e, hipMalloc(&e->d_img, bytes));
-  HIP_TRY(e, hipMemcpy(e->d_img, img.data(), bytes, hipMemcpyHostToDevice));
-  e->img_bytes = bytes;
-  e->img_trees = Tpad;
-  e->img_chunks = v.kind == kKindTile ? Tpad / (uint32_t)v.chunk_trees : Tpad;
-  e->variant_id = vid;
+  if (m.d_img) (void)hipFree(m.d_img);
+  m.d_img = nullptr;
+  HIP_TRY(e, hipMalloc(&m.d_img, bytes));
+  HIP_TRY(e, hipMemcpy(m.d_img, img.data(), bytes, hipMemcpyHostToDevice));
+  m.img_bytes = bytes;
+  m.img_trees = Tpad;
+  m.img_chunks = v.kind == kKindTile ? Tpad / (uint32_t)v.chunk_trees : Tpad;
   return DDT_OK;
 }
 
@@ -254,30 +258,34 @@ int select_and_build(ddt_engine* e) {
   int vid = e->forced_variant;
   if (vid >= 0) {
     if (vid >= num_variants()) return fail(e, DDT_EINVAL, "variant %d out of range", vid);
-    if (!variant_fits(variant(vid), e->m))
+    if (!variant_fits(variant(vid), e))
       return fail(e, DDT_EUNSUPPORTED, "variant %s does not fit this model (D=%u, F=%u)", variant(vid).name,
-                  e->m.p.num_levels, e->m.p.num_features);
+                  e->p.num_levels, e->p.num_features);
   } else {
-    vid = auto_variant(e->m);
+    vid = auto_variant(e);
   }
-  return build_image(e, vid);
+  for (Ensemble& m : e->ens) {
+    int rc = build_image(e, variant(vid), m);
+    if (rc) return rc;
+  }
+  e->variant_id = vid;
+  return DDT_OK;
 }
 
-void fill_args(const ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, ScoreArgs* a) {
-  const HostModel& m = e->m;
-  a->img = reinterpret_cast<const uint4*>(e->d_img);
+void fill_args(const ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t n, float* d_scores, ScoreArgs* a) {
+  a->img = reinterpret_cast<const uint4*>(m.d_img);
   a->tuples = reinterpret_cast<const uint32_t*>(d_tuples);
   a->out = d_scores;
   a->n = n;
-  a->tuple_words = tuple_words(m.p);
-  a->n_trees = e->img_trees;
-  a->n_chunks = e->img_chunks;
-  a->levels = m.p.num_levels;
-  a->clusters = m.p.clusters_per_tuple;
-  a->miss_raw = m.p.missing_bits;
-  a->miss_key = m.p.cmp_mode ? kMissSentinelIeee : m.p.missing_bits;
-  a->ieee = m.p.cmp_mode;
-  a->sum_mode = m.p.sum_mode;
+  a->tuple_words = tuple_words(e->p);
+  a->n_trees = m.img_trees;
+  a->n_chunks = m.img_chunks;
+  a->levels = e->p.num_levels;
+  a->clusters = e->p.clusters_per_tuple;
+  a->miss_raw = e->p.missing_bits;
+  a->miss_key = e->p.cmp_mode ? kMissSentinelIeee : e->p.missing_bits;
+  a->ieee = e->p.cmp_mode;
+  a->sum_mode = e->p.sum_mode;
 }
 
 void feeder_free(ddt_engine* e) {
@@ -288,32 +296,105 @@ void feeder_free(ddt_engine* e) {
     if (e->dev_out[b]) (void)hipFree(e->dev_out[b]);
     e->pin_in[b] = e->pin_out[b] = e->dev_in[b] = e->dev_out[b] = nullptr;
   }
-  e->feeder_cap_rows = e->feeder_cap_words = 0;
+  e->feeder_cap_rows = e->feeder_cap_words = e->feeder_cap_outs = 0;
 }
 
-int feeder_reserve(ddt_engine* e, size_t rows, size_t words) {
-  if (e->feeder_cap_rows >= rows && e->feeder_cap_words >= words) return DDT_OK;
+// `outs` = 4-byte output words per row (1 for scores; K + 1 for classify: K class scores + label)
+int feeder_reserve(ddt_engine* e, size_t rows, size_t words, size_t outs) {
+  if (e->feeder_cap_rows >= rows && e->feeder_cap_words >= words && e->feeder_cap_outs >= outs) return DDT_OK;
   feeder_free(e);
   for (int b = 0; b < 2; ++b) {
     if (!e->fs[b]) HIP_TRY(e, hipStreamCreateWithFlags(&e->fs[b], hipStreamNonBlocking));
     if (!e->fe[b]) HIP_TRY(e, hipEventCreateWithFlags(&e->fe[b], hipEventDisableTiming));
     HIP_TRY(e, hipHostMalloc(&e->pin_in[b], rows * words * 4, hipHostMallocDefault));
-    HIP_TRY(e, hipHostMalloc(&e->pin_out[b], rows * 4, hipHostMallocDefault));
+    HIP_TRY(e, hipHostMalloc(&e->pin_out[b], rows * outs * 4, hipHostMallocDefault));
     HIP_TRY(e, hipMalloc(&e->dev_in[b], rows * words * 4));
-    HIP_TRY(e, hipMalloc(&e->dev_out[b], rows * 4));
+    HIP_TRY(e, hipMalloc(&e->dev_out[b], rows * outs * 4));
   }
   e->feeder_cap_rows = rows;
   e->feeder_cap_words = words;
+  e->feeder_cap_outs = outs;
   return DDT_OK;
 }
 
-int launch_score(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
+int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
   ScoreArgs a;
-  fill_args(e, d_tuples, n, d_scores, &a);
+  fill_args(e, m, d_tuples, n, d_scores, &a);
   const Variant& v = variant(e->variant_id);
   hipError_t r = v.launch(a, v, s);
   if (r != hipSuccess) return fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
   e->st.kernel_launches++;
+  return DDT_OK;
+}
+
+// class scores [K][n] into d_class_scores, then argmax into d_labels (if non-NULL)
+int launch_classify(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s) {
+  for (uint32_t k = 0; k < e->num_classes; ++k) {
+    int rc = launch_score(e, e->ens[k], d_tuples, n, d_class_scores + (size_t)k * n, s);
+    if (rc) return rc;
+  }
+  if (d_labels) {
+    hipError_t r = launch_argmax(d_class_scores, e->num_classes, n, d_labels, s);
+    if (r != hipSuccess) return fail(e, DDT_EHIP, "argmax -> %s", hipGetErrorString(r));
+  }
+  return DDT_OK;
+}
+
+void count_job(ddt_engine* e, size_t n) {
+  e->st.score_calls++;
+  e->st.tuples_in += n;
+  e->st.tuples_out += n;
+  e->st.tuple_lines_in += (uint64_t)n * (tuple_words(e->p) / 4);
+  e->st.result_lines_out += (n + 3) / 4;
+}
+
+// contiguous shard g of `G` of a tree-id list: ceil(|list|/G) trees each (PCIeReceiver.sv:241-264)
+std::vector<uint32_t> shard_of(const std::vector<uint32_t>& ids, uint32_t g, uint32_t G) {
+  const size_t per = (ids.size() + G - 1) / G;
+  const size_t b = (size_t)g * per < ids.size() ? (size_t)g * per : ids.size();
+  const size_t en = b + per < ids.size() ? b + per : ids.size();
+  return std::vector<uint32_t>(ids.begin() + b, ids.begin() + en);
+}
+
+int load_common(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines,
+                uint32_t num_classes, int interleaved, uint32_t shard_index, uint32_t shard_count) {
+  if (!e) return DDT_EINVAL;
+  if (!wl || !fl) return fail(e, DDT_EINVAL, "NULL model stream");
+  int rc = validate(e, p, n_wlines, n_flines);
+  if (rc) return rc;
+  if (num_classes == 0 || num_classes > p->num_trees) return fail(e, DDT_EINVAL, "num_classes %u (trees %u)", num_classes, p->num_trees);
+  if (!interleaved && p->num_trees % num_classes) return fail(e, DDT_EINVAL, "class-major layout needs num_trees %% num_classes == 0");
+  const uint32_t per_class = (p->num_trees + num_classes - 1) / num_classes;
+  if (shard_count == 0 || shard_index >= shard_count || shard_count > per_class)
+    return fail(e, DDT_EINVAL, "shard %u of %u (trees per class %u)", shard_index, shard_count, per_class);
+  const double t0 = now_ms();
+  HIP_TRY(e, hipSetDevice(e->device));
+  std::vector<Ensemble> ens(num_classes);
+  uint64_t lines = 0;
+  for (uint32_t k = 0; k < num_classes; ++k) {
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < p->num_trees; ++i) {
+      const uint32_t cls = interleaved ? i % num_classes : i / (p->num_trees / num_classes);
+      if (cls == k) ids.push_back(i);
+    }
+    std::vector<uint32_t> mine = shard_of(ids, shard_index, shard_count);
+    if (mine.empty()) return fail(e, DDT_EINVAL, "shard %u of %u of class %u is empty", shard_index, shard_count, k);
+    lines += (uint64_t)mine.size() * (p->weights_lines_per_tree + p->findex_lines_per_tree);
+    rc = parse_trees(e, p, reinterpret_cast<const uint32_t*>(wl), reinterpret_cast<const uint16_t*>(fl), std::move(mine), &ens[k]);
+    if (rc) return rc;
+  }
+  free_images(e);
+  e->loaded = false;
+  e->p = *p;
+  e->nint = (1u << p->num_levels) - 1u;
+  e->nleaf = 1u << p->num_levels;
+  e->num_classes = num_classes;
+  e->ens = std::move(ens);
+  rc = select_and_build(e);
+  if (rc) return rc;
+  e->loaded = true;
+  e->st.model_lines_in += lines;
+  e->st.prog_ms += now_ms() - t0;
   return DDT_OK;
 }
 
@@ -348,101 +429,125 @@ void ddt_destroy(ddt_engine* e) {
     if (e->fs[b]) (void)hipStreamDestroy(e->fs[b]);
     if (e->fe[b]) (void)hipEventDestroy(e->fe[b]);
   }
-  free_image(e);
+  if (e->ws) (void)hipFree(e->ws);
+  free_images(e);
   delete e;
 }
 
 int ddt_load_model_shard(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wlines, const void* fl,
                          size_t n_flines, uint32_t shard_index, uint32_t shard_count) {
-  if (!e) return DDT_EINVAL;
-  if (!wl || !fl) return fail(e, DDT_EINVAL, "NULL model stream");
-  int rc = validate(e, p, n_wlines, n_flines);
-  if (rc) return rc;
-  if (shard_count == 0 || shard_index >= shard_count || shard_count > p->num_trees)
-    return fail(e, DDT_EINVAL, "shard %u of %u (trees %u)", shard_index, shard_count, p->num_trees);
-  const double t0 = now_ms();
-  HIP_TRY(e, hipSetDevice(e->device));
-  // contiguous shards of ceil(T/G) trees, device order = stream order (PCIeReceiver.sv:241-264)
-  const uint32_t per = (p->num_trees + shard_count - 1u) / shard_count;
-  const uint32_t b = shard_index * per < p->num_trees ? shard_index * per : p->num_trees;
-  const uint32_t en = (b + per < p->num_trees) ? b + per : p->num_trees;
-  if (b >= en) return fail(e, DDT_EINVAL, "shard %u of %u is empty", shard_index, shard_count);
-  HostModel m;
-  rc = parse_model(e, p, reinterpret_cast<const uint32_t*>(wl), reinterpret_cast<const uint16_t*>(fl), b, en, &m);
-  if (rc) return rc;
-  e->m = std::move(m);
-  e->loaded = false;
-  rc = select_and_build(e);
-  if (rc) return rc;
-  e->loaded = true;
-  e->st.model_lines_in += (uint64_t)(en - b) * (p->weights_lines_per_tree + p->findex_lines_per_tree);
-  e->st.prog_ms += now_ms() - t0;
-  return DDT_OK;
+  return load_common(e, p, wl, n_wlines, fl, n_flines, 1, 0, shard_index, shard_count);
 }
 
 int ddt_load_model(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wlines, const void* fl,
                    size_t n_flines) {
-  return ddt_load_model_shard(e, p, wl, n_wlines, fl, n_flines, 0, 1);
+  return load_common(e, p, wl, n_wlines, fl, n_flines, 1, 0, 0, 1);
+}
+
+int ddt_load_model_multiclass(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wlines, const void* fl,
+                              size_t n_flines, uint32_t num_classes, int interleaved, uint32_t shard_index,
+                              uint32_t shard_count) {
+  return load_common(e, p, wl, n_wlines, fl, n_flines, num_classes, interleaved, shard_index, shard_count);
 }
 
 int ddt_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, void* stream) {
   if (!e) return DDT_EINVAL;
   if (!e->loaded) return fail(e, DDT_ESTATE, "no model loaded");
+  if (e->num_classes != 1) return fail(e, DDT_ESTATE, "multi-class model loaded: use ddt_classify*");
   if (n == 0) return DDT_OK;
   if (!d_tuples || !d_scores) return fail(e, DDT_EINVAL, "NULL device buffer");
-  int rc = launch_score(e, d_tuples, n, d_scores, reinterpret_cast<hipStream_t>(stream));
+  int rc = launch_score(e, e->ens[0], d_tuples, n, d_scores, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
-  e->st.score_calls++;
-  e->st.tuples_in += n;
-  e->st.tuples_out += n;
-  e->st.tuple_lines_in += (uint64_t)n * (tuple_words(e->m.p) / 4);
-  e->st.result_lines_out += (n + 3) / 4;
+  count_job(e, n);
+  return DDT_OK;
+}
+
+int ddt_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels,
+                        void* stream) {
+  if (!e) return DDT_EINVAL;
+  if (!e->loaded) return fail(e, DDT_ESTATE, "no model loaded");
+  if (n == 0) return DDT_OK;
+  if (!d_tuples || !d_class_scores) return fail(e, DDT_EINVAL, "NULL device buffer");
+  int rc = launch_classify(e, d_tuples, n, d_class_scores, d_labels, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  count_job(e, n);
+  return DDT_OK;
+}
+
+int ddt_argmax_device(ddt_engine* e, const float* d_class_scores, uint32_t K, size_t n, int32_t* d_labels, void* stream) {
+  if (!e) return DDT_EINVAL;
+  if (K == 0 || (n && (!d_class_scores || !d_labels))) return fail(e, DDT_EINVAL, "bad argmax arguments");
+  hipError_t r = launch_argmax(d_class_scores, K, n, d_labels, reinterpret_cast<hipStream_t>(stream));
+  if (r != hipSuccess) return fail(e, DDT_EHIP, "argmax -> %s", hipGetErrorString(r));
+  return DDT_OK;
+}
+
+// Shared host-buffer path: pinned double buffer; while chunk i computes on stream i&1, chunk i+1 is copied in on
+// the other.  classify: per chunk the device output is [K][cn] class scores followed by cn int32 labels.
+static int score_host(ddt_engine* e, const void* tuple_lines, size_t n, float* scores_out, int32_t* labels_out,
+                      float* class_scores_out) {
+  const bool classify = labels_out != nullptr;
+  const uint32_t K = classify ? e->num_classes : 1u;
+  const double t0 = now_ms();
+  HIP_TRY(e, hipSetDevice(e->device));
+  const size_t W = tuple_words(e->p);
+  const size_t rows = e->feeder_rows < n ? e->feeder_rows : n;
+  const size_t outs = classify ? K + 1 : 1;
+  int rc = feeder_reserve(e, rows, W, outs);
+  if (rc) return rc;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(tuple_lines);
+  size_t pending_off[2] = {0, 0}, pending_n[2] = {0, 0};
+  auto drain = [&](int b) -> int {
+    HIP_TRY(e, hipEventSynchronize(e->fe[b]));
+    const size_t cn = pending_n[b], off = pending_off[b];
+    const float* po = reinterpret_cast<const float*>(e->pin_out[b]);
+    if (!classify) {
+      memcpy(scores_out + off, po, cn * 4);
+    } else {
+      if (class_scores_out)
+        for (uint32_t k = 0; k < K; ++k) memcpy(class_scores_out + (size_t)k * n + off, po + (size_t)k * cn, cn * 4);
+      memcpy(labels_out + off, po + (size_t)K * cn, cn * 4);
+    }
+    pending_n[b] = 0;
+    return DDT_OK;
+  };
+  for (size_t off = 0, i = 0; off < n; off += rows, ++i) {
+    const int b = (int)(i & 1);
+    const size_t cn = (n - off < rows) ? n - off : rows;
+    if (pending_n[b] && (rc = drain(b))) return rc;
+    memcpy(e->pin_in[b], src + off * W, cn * W * 4);
+    HIP_TRY(e, hipMemcpyAsync(e->dev_in[b], e->pin_in[b], cn * W * 4, hipMemcpyHostToDevice, e->fs[b]));
+    float* dout = reinterpret_cast<float*>(e->dev_out[b]);
+    if (!classify) rc = launch_score(e, e->ens[0], e->dev_in[b], cn, dout, e->fs[b]);
+    else rc = launch_classify(e, e->dev_in[b], cn, dout, reinterpret_cast<int32_t*>(dout + (size_t)K * cn), e->fs[b]);
+    if (rc) return rc;
+    HIP_TRY(e, hipMemcpyAsync(e->pin_out[b], e->dev_out[b], cn * outs * 4, hipMemcpyDeviceToHost, e->fs[b]));
+    HIP_TRY(e, hipEventRecord(e->fe[b], e->fs[b]));
+    pending_off[b] = off;
+    pending_n[b] = cn;
+  }
+  for (int b = 0; b < 2; ++b)
+    if (pending_n[b] && (rc = drain(b))) return rc;
+  count_job(e, n);
+  e->st.exec_ms += now_ms() - t0;
   return DDT_OK;
 }
 
 int ddt_score(ddt_engine* e, const void* tuple_lines, size_t n, float* scores_out) {
   if (!e) return DDT_EINVAL;
   if (!e->loaded) return fail(e, DDT_ESTATE, "no model loaded");
+  if (e->num_classes != 1) return fail(e, DDT_ESTATE, "multi-class model loaded: use ddt_classify*");
   if (n == 0) return DDT_OK;
   if (!tuple_lines || !scores_out) return fail(e, DDT_EINVAL, "NULL host buffer");
-  const double t0 = now_ms();
-  HIP_TRY(e, hipSetDevice(e->device));
-  const size_t W = tuple_words(e->m.p);
-  const size_t rows = e->feeder_rows < n ? e->feeder_rows : n;
-  int rc = feeder_reserve(e, rows, W);
-  if (rc) return rc;
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(tuple_lines);
-  // pinned double buffer: while chunk i computes on stream i&1, chunk i+1 is copied in on the other
-  size_t pending_off[2] = {0, 0}, pending_n[2] = {0, 0};
-  for (size_t off = 0, i = 0; off < n; off += rows, ++i) {
-    const int b = (int)(i & 1);
-    const size_t cn = (n - off < rows) ? n - off : rows;
-    if (pending_n[b]) {  // drain the previous use of this buffer
-      HIP_TRY(e, hipEventSynchronize(e->fe[b]));
-      memcpy(scores_out + pending_off[b], e->pin_out[b], pending_n[b] * 4);
-      pending_n[b] = 0;
-    }
-    memcpy(e->pin_in[b], src + off * W, cn * W * 4);
-    HIP_TRY(e, hipMemcpyAsync(e->dev_in[b], e->pin_in[b], cn * W * 4, hipMemcpyHostToDevice, e->fs[b]));
-    rc = launch_score(e, e->dev_in[b], cn, reinterpret_cast<float*>(e->dev_out[b]), e->fs[b]);
-    if (rc) return rc;
-    HIP_TRY(e, hipMemcpyAsync(e->pin_out[b], e->dev_out[b], cn * 4, hipMemcpyDeviceToHost, e->fs[b]));
-    HIP_TRY(e, hipEventRecord(e->fe[b], e->fs[b]));
-    pending_off[b] = off;
-    pending_n[b] = cn;
-  }
-  for (int b = 0; b < 2; ++b)
-    if (pending_n[b]) {
-      HIP_TRY(e, hipEventSynchronize(e->fe[b]));
-      memcpy(scores_out + pending_off[b], e->pin_out[b], pending_n[b] * 4);
-    }
-  e->st.score_calls++;
-  e->st.tuples_in += n;
-  e->st.tuples_out += n;
-  e->st.tuple_lines_in += (uint64_t)n * (W / 4);
-  e->st.result_lines_out += (n + 3) / 4;
-  e->st.exec_ms += now_ms() - t0;
-  return DDT_OK;
+  return score_host(e, tuple_lines, n, scores_out, nullptr, nullptr);
+}
+
+int ddt_classify(ddt_engine* e, const void* tuple_lines, size_t n, int32_t* labels, float* class_scores) {
+  if (!e) return DDT_EINVAL;
+  if (!e->loaded) return fail(e, DDT_ESTATE, "no model loaded");
+  if (n == 0) return DDT_OK;
+  if (!tuple_lines || !labels) return fail(e, DDT_EINVAL, "NULL host buffer");
+  return score_host(e, tuple_lines, n, nullptr, labels, class_scores);
 }
 
 int ddt_chain_sum_device(ddt_engine* e, const float* d_parts, uint32_t n_parts, size_t n, float* d_out, void* stream) {
@@ -461,20 +566,28 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   snprintf(out->device_name, sizeof(out->device_name), "%s (%s)", e->prop.name, e->prop.gcnArchName);
   if (!e->loaded) return DDT_OK;
   const Variant& v = variant(e->variant_id);
-  const HostModel& m = e->m;
-  out->tree_begin = m.tree_begin;
-  out->tree_end = m.tree_end;
-  out->num_levels = m.p.num_levels;
-  out->num_features = m.p.num_features;
-  out->tuple_words = tuple_words(m.p);
+  const Ensemble& m0 = e->ens[0];
+  uint32_t trees = 0;
+  uint64_t img = 0;
+  for (const Ensemble& m : e->ens) {
+    trees += m.trees();
+    img += m.img_bytes;
+  }
+  out->tree_begin = m0.ids.front();
+  out->tree_end = e->ens.back().ids.back() + 1;
+  out->num_levels = e->p.num_levels;
+  out->num_features = e->p.num_features;
+  out->tuple_words = tuple_words(e->p);
   out->variant = (uint32_t)e->variant_id;
   out->tile_tuples = v.tile();
   out->block_threads = (uint32_t)v.threads;
   out->lds_bytes = v.kind == kKindTile     ? v.lds_bytes(out->tuple_words)
-                   : v.kind == kKindStream ? v.lds_bytes_stream(e->img_trees, out->tuple_words)
-                                           : generic_lds_bytes(m.p.num_levels, out->tuple_words, nullptr, nullptr);
-  out->model_bytes_unpadded = (uint64_t)m.trees() * (4ull * ((2ull << m.p.num_levels) - 1) + 2ull * ((1ull << m.p.num_levels) - 1));
-  out->image_bytes = e->img_bytes;
+                   : v.kind == kKindStream ? v.lds_bytes_stream(m0.img_trees, out->tuple_words)
+                                           : generic_lds_bytes(e->p.num_levels, out->tuple_words, nullptr, nullptr);
+  out->model_bytes_unpadded = (uint64_t)trees * (4ull * ((2ull << e->p.num_levels) - 1) + 2ull * ((1ull << e->p.num_levels) - 1));
+  out->image_bytes = img;
+  out->num_classes = e->num_classes;
+  out->local_trees = trees;
   snprintf(out->variant_name, sizeof(out->variant_name), "%s", v.name);
   return DDT_OK;
 }

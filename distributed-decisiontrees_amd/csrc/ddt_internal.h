@@ -88,6 +88,7 @@ uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_
 uint32_t stream_blocks_per_cu(uint32_t lds_bytes);
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s);
+hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s);
 hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits,
                                hipStream_t s);
 

@@ -417,7 +417,6 @@ static hipError_t launch_tile(const ScoreArgs& a, const Variant& v, hipStream_t 
 // the price of perfectly coalesced reads.  Model image: classic layout at LDS [0, img_bytes).
 // ---------------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 256;
-constexpr int kStreamMaxLpt = 8;   // tuples up to 32 words
 constexpr uint32_t kStreamRow = kStreamThreads * 4u;
 
 template <int D, int U, int MAXLPT>
@@ -624,6 +623,36 @@ hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, floa
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048 * 8) blocks = 2048 * 8;
   hipLaunchKernelGGL(chain_sum_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, parts, n_parts, n, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// argmax over K per-class score vectors laid out [K][n]; lowest class index wins ties; a NaN score never
+// wins against a number (BASELINE config 5: one-vs-all, per-class sums then argmax -- an extension, the
+// reference has no classes)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ scores, uint32_t K, size_t n,
+                                                     int32_t* __restrict__ labels) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float best = scores[i];
+    int32_t arg = 0;
+    for (uint32_t k = 1; k < K; ++k) {
+      const float s = scores[(size_t)k * n + i];
+      if (s > best || (best != best && s == s)) {
+        best = s;
+        arg = (int32_t)k;
+      }
+    }
+    labels[i] = arg;
+  }
+}
+
+hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048 * 8) blocks = 2048 * 8;
+  hipLaunchKernelGGL(argmax_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, scores, K, n, labels);
   return hipGetLastError();
 }
 

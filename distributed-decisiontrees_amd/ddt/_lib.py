@@ -13,7 +13,8 @@ CSRC = os.path.join(_PKG, "csrc")
 # every symbol include/ddt.h declares (tests check the built library exports exactly these)
 SYMBOLS = [
     "ddt_create", "ddt_destroy", "ddt_load_model", "ddt_load_model_shard", "ddt_score", "ddt_score_device",
-    "ddt_chain_sum_device", "ddt_get_info", "ddt_get_stats", "ddt_strerror", "ddt_last_error", "ddt_set_option",
+    "ddt_chain_sum_device", "ddt_load_model_multiclass", "ddt_classify_device", "ddt_classify", "ddt_argmax_device",
+    "ddt_get_info", "ddt_get_stats", "ddt_strerror", "ddt_last_error", "ddt_set_option",
     "ddt_num_variants", "ddt_variant_name", "ddt_synth_model", "ddt_synth_tuples_host", "ddt_synth_tuples_device",
 ]
 
@@ -34,7 +35,8 @@ class Info(C.Structure):
         ("abi_version", C.c_uint32), ("device_id", C.c_int32), ("tree_begin", C.c_uint32), ("tree_end", C.c_uint32),
         ("num_levels", C.c_uint32), ("num_features", C.c_uint32), ("tuple_words", C.c_uint32),
         ("variant", C.c_uint32), ("tile_tuples", C.c_uint32), ("block_threads", C.c_uint32),
-        ("lds_bytes", C.c_uint32), ("model_bytes_unpadded", C.c_uint64), ("image_bytes", C.c_uint64),
+        ("lds_bytes", C.c_uint32), ("num_classes", C.c_uint32), ("local_trees", C.c_uint32),
+        ("model_bytes_unpadded", C.c_uint64), ("image_bytes", C.c_uint64),
         ("variant_name", C.c_char * 64), ("device_name", C.c_char * 64),
     ]
 
@@ -83,6 +85,11 @@ def lib():
     L.ddt_score.restype, L.ddt_score.argtypes = i32, [vp, vp, sz, vp]
     L.ddt_score_device.restype, L.ddt_score_device.argtypes = i32, [vp, vp, sz, vp, vp]
     L.ddt_chain_sum_device.restype, L.ddt_chain_sum_device.argtypes = i32, [vp, vp, u32, sz, vp, vp]
+    L.ddt_load_model_multiclass.restype = i32
+    L.ddt_load_model_multiclass.argtypes = [vp, PP, vp, sz, vp, sz, u32, i32, u32, u32]
+    L.ddt_classify_device.restype, L.ddt_classify_device.argtypes = i32, [vp, vp, sz, vp, vp, vp]
+    L.ddt_classify.restype, L.ddt_classify.argtypes = i32, [vp, vp, sz, vp, vp]
+    L.ddt_argmax_device.restype, L.ddt_argmax_device.argtypes = i32, [vp, vp, u32, sz, vp, vp]
     L.ddt_get_info.restype, L.ddt_get_info.argtypes = i32, [vp, C.POINTER(Info)]
     L.ddt_get_stats.restype, L.ddt_get_stats.argtypes = i32, [vp, C.POINTER(Stats)]
     L.ddt_strerror.restype, L.ddt_strerror.argtypes = C.c_char_p, [i32]

@@ -112,6 +112,53 @@ class Engine:
         self.params = params
         return self
 
+    def load_model_multiclass(self, params: Params, wlines: np.ndarray, flines: np.ndarray, num_classes: int,
+                              interleaved: bool = True, shard_index: int = 0, shard_count: int = 1):
+        """One-vs-all ensemble of `num_classes` classes (BASELINE config 5; an extension of the reference)."""
+        w = np.ascontiguousarray(wlines).view(np.uint32).reshape(-1)
+        f = np.ascontiguousarray(flines).view(np.uint16).reshape(-1)
+        self._check(self._L.ddt_load_model_multiclass(self._h, C.byref(params), w.ctypes.data, w.size // 4,
+                                                      f.ctypes.data, f.size // 8, num_classes, int(interleaved),
+                                                      shard_index, shard_count))
+        self.params = params
+        self.num_classes = num_classes
+        return self
+
+    def classify(self, tuple_lines: np.ndarray, want_scores: bool = False):
+        """Host buffers -> int32 labels [n] (and fp32 class scores [K, n])."""
+        t = np.ascontiguousarray(tuple_lines).view(np.uint32).reshape(-1, tuple_words(self.params.num_features))
+        n = t.shape[0]
+        labels = np.empty(n, np.int32)
+        cs = np.empty((self.num_classes, n), np.float32) if want_scores else None
+        self._check(self._L.ddt_classify(self._h, t.ctypes.data, n, labels.ctypes.data,
+                                         cs.ctypes.data if want_scores else None))
+        return (labels, cs) if want_scores else labels
+
+    def classify_device(self, d_tuples, class_scores=None, labels=None, want_labels: bool = True, stream=None):
+        """torch CUDA tuple lines -> (labels int32 [n] or None, class scores fp32 [K, n]); asynchronous."""
+        import torch
+
+        W = tuple_words(self.params.num_features)
+        n = d_tuples.numel() // W
+        if class_scores is None:
+            class_scores = torch.empty((self.num_classes, n), dtype=torch.float32, device=d_tuples.device)
+        if labels is None and want_labels:
+            labels = torch.empty(n, dtype=torch.int32, device=d_tuples.device)
+        s = torch.cuda.current_stream(d_tuples.device) if stream is None else stream
+        self._check(self._L.ddt_classify_device(self._h, d_tuples.data_ptr(), n, class_scores.data_ptr(),
+                                                labels.data_ptr() if labels is not None else None, s.cuda_stream))
+        return labels, class_scores
+
+    def argmax_device(self, class_scores, labels=None, stream=None):
+        import torch
+
+        K, n = class_scores.shape
+        if labels is None:
+            labels = torch.empty(n, dtype=torch.int32, device=class_scores.device)
+        s = torch.cuda.current_stream(class_scores.device) if stream is None else stream
+        self._check(self._L.ddt_argmax_device(self._h, class_scores.data_ptr(), K, n, labels.data_ptr(), s.cuda_stream))
+        return labels
+
     def set_option(self, key: str, value: int):
         self._check(self._L.ddt_set_option(self._h, key.encode(), int(value)))
 

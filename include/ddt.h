@@ -69,6 +69,7 @@ typedef struct ddt_info {
   uint32_t num_levels, num_features, tuple_words; /* tuple_words = 4*ceil(F/4)                      */
   uint32_t variant;                  /* kernel variant id in use                                    */
   uint32_t tile_tuples, block_threads, lds_bytes;
+  uint32_t num_classes, local_trees; /* classes (1 = plain ensemble); trees held by this engine      */
   uint64_t model_bytes_unpadded;     /* T_local*(4*(2^(D+1)-1) + 2*(2^D-1)): algorithmic model bytes */
   uint64_t image_bytes;              /* packed device image actually read per tile pass             */
   char     variant_name[64];
@@ -112,6 +113,26 @@ int ddt_score_device(ddt_engine* e, const void* d_tuple_lines, size_t n_tuples, 
  * i.e. the reference's host -> dev1 -> ... chain order.  Used by the deterministic multi-GPU path.   */
 int ddt_chain_sum_device(ddt_engine* e, const float* d_parts, uint32_t n_parts, size_t n, float* d_out,
                          void* hip_stream);
+
+/* -- multi-class one-vs-all (BASELINE config 5; an EXTENSION: the reference scores one fp32 sum per tuple and
+ *    has no classes).  The model stream holds num_trees trees of num_classes classes; tree i belongs to class
+ *    i % num_classes when `interleaved` != 0 (XGBoost multi:softprob order), else to class
+ *    i / (num_trees / num_classes) (class-major; num_trees must then be a multiple of num_classes).  Every class
+ *    is scored as an independent ensemble in the reference's adder order (ddt_params.clusters_per_tuple applies
+ *    per class) and the label is argmax over classes, lowest index on ties.  With shard_count > 1 each class is
+ *    tree-sharded like ddt_load_model_shard and the per-class partial sums must be combined across devices
+ *    before the argmax (ddt_argmax_device).                                                                 -- */
+int ddt_load_model_multiclass(ddt_engine* e, const ddt_params* p, const void* weights_lines, size_t n_wlines,
+                              const void* findex_lines, size_t n_flines, uint32_t num_classes, int interleaved,
+                              uint32_t shard_index, uint32_t shard_count);
+/* d_class_scores: [num_classes][n] fp32 (this shard's partial sums per class), d_labels (may be NULL when
+ * shard_count > 1): int32 argmax.  Asynchronous on hip_stream.                                               */
+int ddt_classify_device(ddt_engine* e, const void* d_tuple_lines, size_t n_tuples, float* d_class_scores,
+                        int32_t* d_labels, void* hip_stream);
+/* host buffers; class_scores may be NULL */
+int ddt_classify(ddt_engine* e, const void* tuple_lines, size_t n_tuples, int32_t* labels, float* class_scores);
+int ddt_argmax_device(ddt_engine* e, const float* d_class_scores, uint32_t num_classes, size_t n, int32_t* d_labels,
+                      void* hip_stream);
 
 /* -- introspection ----------------------------------------------------------------------------------- */
 int ddt_get_info(const ddt_engine* e, ddt_info* out);

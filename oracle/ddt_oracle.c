@@ -349,6 +349,58 @@ int orc_score(const orc_params* p, const void* wl, size_t n_wlines, const void* 
   return 0;
 }
 
+/* Multi-class one-vs-all (BASELINE config 5; NOT in the reference, which has no classes): class k owns the
+ * trees {i : i % K == k} (interleaved) or [k*T/K, (k+1)*T/K) (class-major); each class is an independent
+ * ensemble reduced in reference order (optionally tree-sharded over n_devices with chain add); label =
+ * argmax over classes, lowest index on ties.  class_scores (may be NULL): [K][n]. */
+int orc_classify(const orc_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines,
+                 const void* tl, size_t n_tuples, uint32_t K, int interleaved, int sum_mode, int n_devices,
+                 int32_t* labels, float* class_scores) {
+  int rc = check_params(p, n_wlines, n_flines);
+  if (rc) return rc;
+  if (K == 0 || K > p->num_trees || (!interleaved && p->num_trees % K) || n_devices < 1) return -6;
+  const uint32_t* w = (const uint32_t*)wl;
+  const uint16_t* f = (const uint16_t*)fl;
+  const uint32_t* t = (const uint32_t*)tl;
+  const uint32_t T = p->num_trees, tw = orc_tuple_lines(p->num_features) * 4u;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    uint32_t* leaves = (uint32_t*)malloc(sizeof(uint32_t) * T);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (long long r = 0; r < (long long)n_tuples; ++r) {
+      const uint32_t* x = t + (size_t)r * tw;
+      float best = 0.f;
+      int32_t arg = 0;
+      for (uint32_t k = 0; k < K; ++k) {
+        uint32_t nk = 0;
+        for (uint32_t i = 0; i < T; ++i) {
+          const uint32_t cls = interleaved ? i % K : i / (T / K);
+          if (cls == k) leaves[nk++] = orc_traverse(p, w, f, x, i);
+        }
+        const uint32_t per_dev = (nk + (uint32_t)n_devices - 1u) / (uint32_t)n_devices;
+        uint32_t run = 0;
+        for (int d = 0; d < n_devices; ++d) {
+          const uint32_t b = (uint32_t)d * per_dev, e = (b + per_dev < nk) ? b + per_dev : nk;
+          const uint32_t part = (b < e) ? shard_sum(leaves + b, e - b, p->clusters_per_tuple, sum_mode) : 0u;
+          if (d == 0) run = part;
+          else if (sum_mode == ORC_SUM_REF_FLOPOCO) run = orc_fpadd_bits(part, run);
+          else { volatile float s = f_from(part) + f_from(run); run = b_from(s); }
+        }
+        const float sc = f_from(run);
+        if (class_scores) class_scores[(size_t)k * n_tuples + (size_t)r] = sc;
+        if (k == 0 || sc > best || (best != best && sc == sc)) { best = sc; arg = (int32_t)k; }
+      }
+      labels[r] = arg;
+    }
+    free(leaves);
+  }
+  return 0;
+}
+
 /* =============================================================================================
  * 6. Deterministic synthetic inputs
  * ============================================================================================= */

@@ -86,6 +86,12 @@ int orc_score_shard(const orc_params* p, const void* weights_lines, size_t n_wli
                     const void* findex_lines, size_t n_flines, const void* tuple_lines, size_t n_tuples,
                     uint32_t tree_begin, uint32_t tree_end, float* out, int sum_mode, int nthreads);
 
+/* Multi-class one-vs-all with argmax (BASELINE config 5; an extension, the reference has no classes):
+ * see ddt_oracle.c.  labels[n]; class_scores[K][n] may be NULL. */
+int orc_classify(const orc_params* p, const void* weights_lines, size_t n_wlines, const void* findex_lines,
+                 size_t n_flines, const void* tuple_lines, size_t n_tuples, uint32_t num_classes, int interleaved,
+                 int sum_mode, int n_devices, int32_t* labels, float* class_scores);
+
 /* ---- wire-format helpers (A2 packing, PipelinedMUX.sv:65) ------------------------------------ */
 uint32_t orc_weights_lines_per_tree(uint32_t num_levels); /* ceil((2^(D+1)-1)/4) */
 uint32_t orc_findex_lines_per_tree(uint32_t num_levels);  /* ceil((2^D-1)/8)     */

@@ -65,6 +65,8 @@ def lib():
         L.orc_score.argtypes = [PP, vp, sz, vp, sz, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int]
         L.orc_score_shard.restype = C.c_int
         L.orc_score_shard.argtypes = [PP, vp, sz, vp, sz, vp, sz, u32, u32, vp, C.c_int, C.c_int]
+        L.orc_classify.restype = C.c_int
+        L.orc_classify.argtypes = [PP, vp, sz, vp, sz, vp, sz, u32, C.c_int, C.c_int, C.c_int, vp, vp]
         for n in ("orc_weights_lines_per_tree", "orc_findex_lines_per_tree", "orc_tuple_lines"):
             getattr(L, n).restype, getattr(L, n).argtypes = u32, [u32]
         L.orc_pack_model.restype, L.orc_pack_model.argtypes = None, [u32, u32, vp, vp, vp, vp, vp, vp]
@@ -182,6 +184,20 @@ def score_shard(m: Model, tuples: np.ndarray, tree_begin: int, tree_end: int,
     if rc:
         raise ValueError(f"orc_score_shard rc={rc}")
     return out
+
+
+def classify(m: Model, tuples: np.ndarray, num_classes: int, interleaved: bool = True,
+             sum_mode: int = SUM_REF_FLOPOCO, n_devices: int = 1):
+    """-> (labels int32 [n], class_scores fp32 [K, n])"""
+    t = np.ascontiguousarray(tuples, np.uint32)
+    n = t.shape[0]
+    labels = np.zeros(n, np.int32)
+    cs = np.zeros((num_classes, n), np.float32)
+    rc = lib().orc_classify(C.byref(m.params), _p(m.wlines), m.n_wlines, _p(m.flines), m.n_flines, _p(t), n,
+                            num_classes, int(interleaved), sum_mode, n_devices, _p(labels), _p(cs))
+    if rc:
+        raise ValueError(f"orc_classify rc={rc}")
+    return labels, cs
 
 
 def leaves(m: Model, tuple_row: np.ndarray) -> np.ndarray:

@@ -1,0 +1,80 @@
+"""BASELINE config 5: 10-class one-vs-all, 100 trees/class, depth 8, per-class sums then argmax.
+An EXTENSION (the reference has one fp32 sum per tuple and no classes): the oracle defines it as K independent
+reference-order ensembles + argmax (lowest index on ties); labels must match bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import ddt
+from tests import refimpl as R
+
+
+def test_oracle_classify_equals_per_class_scoring():
+    T, D, F, K, n = 40, 5, 12, 4, 300
+    m = O.gen_model(T, D, F, dist=1, clusters=2)
+    x = O.gen_tuples(0, n, F, dist=1)
+    thr, fidx, mr, leaf = R.unpack_model(m.wlines, m.flines, T, D, O.wlpt(D), O.flpt(D))
+    lb = R.traverse_all(thr, fidx, mr, leaf, x, m.params.missing_bits)
+    for inter in (True, False):
+        labels, cs = O.classify(m, x, K, interleaved=inter)
+        for k in range(K):
+            ids = [i for i in range(T) if (i % K if inter else i // (T // K)) == k]
+            want = R.score_reference_order(lb[:, ids], 2)
+            assert np.array_equal(cs[k].view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(labels, np.argmax(cs, axis=0).astype(np.int32))  # numpy argmax: first max wins
+    l2, cs2 = O.classify(m, x, K, n_devices=2)
+    assert np.allclose(cs2, O.classify(m, x, K)[1], rtol=0, atol=1e-6)
+
+
+def test_argmax_tie_goes_to_lowest_class():
+    # two identical classes => every tuple ties => label 0
+    thr = np.full((2, 1), 0.5, np.float32)
+    m = O.pack_model(thr, np.zeros((2, 1), np.int64), np.zeros((2, 1), np.uint8),
+                     np.array([[1.0, 2.0], [1.0, 2.0]], np.float32), 4)
+    x = O.tuples_from_float(np.array([[0.1, 0, 0, 0], [0.9, 0, 0, 0]], np.float32))
+    labels, cs = O.classify(m, x, 2)
+    assert list(labels) == [0, 0] and np.array_equal(cs[0], cs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,F,K,n,inter", [(1000, 8, 32, 10, 1500, True), (1000, 8, 32, 10, 700, False),
+                                              (60, 6, 28, 3, 2000, True), (24, 4, 16, 2, 999, True),
+                                              (35, 7, 20, 5, 600, True)])
+def test_gpu_classify_matches_oracle(T, D, F, K, n, inter):
+    import torch
+
+    dist = 1 if D != 8 else 0
+    w, f = ddt.synth_model(T, D, F, dist)
+    C = ddt.default_clusters((T + K - 1) // K)
+    m = O.Model(O.make_params(T, D, F, clusters=C), w, f)
+    x = O.gen_tuples(2, n, F, dist=dist)
+    want_l, want_cs = O.classify(m, x, K, interleaved=inter)
+    e = ddt.Engine(0)
+    e.load_model_multiclass(ddt.make_params(T, D, F, clusters=C), w, f, K, inter)
+    assert e.info().num_classes == K and e.info().local_trees == T
+    labels, cs = e.classify(x, want_scores=True)                                   # host feeder path
+    assert np.array_equal(cs.view(np.uint32), want_cs.view(np.uint32))
+    assert np.array_equal(labels, want_l)
+    dl, dcs = e.classify_device(torch.from_numpy(x.view(np.int32)).cuda())          # device path
+    torch.cuda.synchronize()
+    assert np.array_equal(dl.cpu().numpy(), want_l) and np.array_equal(dcs.cpu().numpy().view(np.uint32), want_cs.view(np.uint32))
+    with pytest.raises(ddt.DDTError):
+        e.score(x)  # a multi-class engine refuses the single-score call
+    # tree-sharded x2: per-class partials from two engines, chain add per class, argmax == oracle's 2-device model
+    if T // K >= 2:
+        want2_l, want2_cs = O.classify(m, x, K, interleaved=inter, n_devices=2)
+        parts = []
+        d = torch.from_numpy(x.view(np.int32)).cuda()
+        for g in range(2):
+            eg = ddt.Engine(0)
+            eg.load_model_multiclass(ddt.make_params(T, D, F, clusters=C), w, f, K, inter, g, 2)
+            parts.append(eg.classify_device(d, want_labels=False)[1])
+            torch.cuda.synchronize()
+            eg.close()
+        stacked = torch.stack(parts).reshape(2, K * n).contiguous()
+        comb = e.chain_sum_device(stacked).reshape(K, n)
+        lab = e.argmax_device(comb.contiguous())
+        torch.cuda.synchronize()
+        assert np.array_equal(comb.cpu().numpy().view(np.uint32), want2_cs.view(np.uint32))
+        assert np.array_equal(lab.cpu().numpy(), want2_l)
+    e.close()
