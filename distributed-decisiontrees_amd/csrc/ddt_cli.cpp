@@ -1,0 +1,219 @@
+// ddt_cli -- stand-in for the reference's (unpublished) host program.
+//
+// It consumes exactly what a host would hand the FPGA engine: the soft-register block (CSR 200..211,
+// rtl/DTEngine/EngineCSR.sv:190-305) and the three inbound line streams in the reference wire format
+// (rtl/DTEngine/PCIeReceiver.sv:136-139: all weights lines, then all feature-index lines, then tuple lines;
+// word packing rtl/DTEngine/core/PipelinedMUX.sv:65), and writes the outbound result-line stream
+// (rtl/DTEngine/ResultsCombiner.sv:136-160: four fp32 scores per 128-bit line, tuple order).
+//
+//   ddt_cli gen   --trees T --levels D --features F --rows N [--dist 0|1] [--devices G] --prefix DIR/name
+//        writes name.csr (text: "<addr> <hex64>" per register), name.weights, name.findex, name.tuples
+//   ddt_cli score --csr f.csr --weights f.weights --findex f.findex --tuples f.tuples --out f.results
+//                 [--device 0] [--shard i --of n] [--cmp-mode 0|1] [--sum-mode 0|1] [--variant v]
+//   ddt_cli info
+//
+// All scoring goes through the C-ABI of include/ddt.h; there is no CPU fallback.
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ddt.h"
+
+namespace {
+
+std::map<std::string, std::string> parse(int argc, char** argv, int first) {
+  std::map<std::string, std::string> o;
+  for (int i = first; i + 1 < argc; i += 2) {
+    if (strncmp(argv[i], "--", 2)) {
+      fprintf(stderr, "bad option %s\n", argv[i]);
+      exit(2);
+    }
+    o[argv[i] + 2] = argv[i + 1];
+  }
+  return o;
+}
+
+uint64_t num(const std::map<std::string, std::string>& o, const char* k, uint64_t dflt, bool required = false) {
+  auto it = o.find(k);
+  if (it == o.end()) {
+    if (required) {
+      fprintf(stderr, "missing --%s\n", k);
+      exit(2);
+    }
+    return dflt;
+  }
+  return strtoull(it->second.c_str(), nullptr, 0);
+}
+
+std::string str(const std::map<std::string, std::string>& o, const char* k) {
+  auto it = o.find(k);
+  if (it == o.end()) {
+    fprintf(stderr, "missing --%s\n", k);
+    exit(2);
+  }
+  return it->second;
+}
+
+bool read_file(const std::string& path, std::vector<unsigned char>* out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out->resize((size_t)n);
+  const bool ok = n == 0 || fread(out->data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  return ok;
+}
+
+bool write_file(const std::string& path, const void* p, size_t n) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  const bool ok = n == 0 || fwrite(p, 1, n, f) == n;
+  fclose(f);
+  return ok;
+}
+
+bool read_csr(const std::string& path, uint64_t csr[DDT_CSR_COUNT]) {
+  FILE* f = fopen(path.c_str(), "r");
+  if (!f) return false;
+  memset(csr, 0, sizeof(uint64_t) * DDT_CSR_COUNT);
+  char line[256];
+  while (fgets(line, sizeof(line), f)) {
+    if (line[0] == '#' || line[0] == '\n') continue;
+    unsigned addr;
+    unsigned long long val;
+    if (sscanf(line, "%u %llx", &addr, &val) == 2 && addr >= DDT_CSR_FIRST && addr < DDT_CSR_FIRST + DDT_CSR_COUNT)
+      csr[addr - DDT_CSR_FIRST] = val;
+  }
+  fclose(f);
+  return true;
+}
+
+int die(int rc, ddt_engine* e, const char* what) {
+  fprintf(stderr, "ddt_cli: %s: %s%s%s\n", what, ddt_strerror(rc), e ? ": " : "", e ? ddt_last_error(e) : "");
+  if (e) ddt_destroy(e);
+  return 1;
+}
+
+int cmd_gen(const std::map<std::string, std::string>& o) {
+  const uint32_t T = (uint32_t)num(o, "trees", 0, true), D = (uint32_t)num(o, "levels", 0, true);
+  const uint32_t F = (uint32_t)num(o, "features", 0, true), G = (uint32_t)num(o, "devices", 1);
+  const uint64_t N = num(o, "rows", 0, true);
+  const int dist = (int)num(o, "dist", 0);
+  const std::string prefix = str(o, "prefix");
+  ddt_params p;
+  memset(&p, 0, sizeof(p));
+  p.num_trees = T;
+  p.num_levels = D;
+  p.num_features = F;
+  p.missing_bits = 0x7FC00000u;
+  p.weights_lines_per_tree = (uint32_t)((((1ull << (D + 1)) - 1) + 3) / 4);
+  p.findex_lines_per_tree = (uint32_t)((((1ull << D) - 1) + 7) / 8);
+  const uint32_t per_dev = (T + G - 1) / G;
+  p.clusters_per_tuple = per_dev <= 128 ? 1 : per_dev <= 256 ? 2 : per_dev <= 512 ? 4 : 8;
+  uint64_t csr[DDT_CSR_COUNT];
+  int rc = ddt_csr_encode(&p, N, G, csr);
+  if (rc) return die(rc, nullptr, "csr encode");
+  std::vector<uint32_t> w((size_t)T * p.weights_lines_per_tree * 4);
+  std::vector<uint16_t> f((size_t)T * p.findex_lines_per_tree * 8);
+  rc = ddt_synth_model(T, D, F, dist, w.data(), f.data());
+  if (rc) return die(rc, nullptr, "synth model");
+  const size_t W = (F + 3) / 4 * 4;
+  std::vector<uint32_t> x((size_t)N * W);
+  rc = ddt_synth_tuples_host(x.data(), 0, N, F, dist, p.missing_bits);
+  if (rc) return die(rc, nullptr, "synth tuples");
+  FILE* c = fopen((prefix + ".csr").c_str(), "w");
+  if (!c) return die(DDT_EINVAL, nullptr, "open csr file");
+  fprintf(c, "# soft registers as the host writes them (EngineCSR.sv:190-305); CSR 200 (start) last on the wire\n");
+  for (int k = 1; k < DDT_CSR_COUNT; ++k) fprintf(c, "%d %016" PRIx64 "\n", DDT_CSR_FIRST + k, csr[k]);
+  fprintf(c, "%d %016" PRIx64 "\n", DDT_CSR_FIRST, csr[0]);
+  fclose(c);
+  if (!write_file(prefix + ".weights", w.data(), w.size() * 4) || !write_file(prefix + ".findex", f.data(), f.size() * 2) ||
+      !write_file(prefix + ".tuples", x.data(), x.size() * 4))
+    return die(DDT_EINVAL, nullptr, "write stream files");
+  printf("wrote %s.{csr,weights,findex,tuples}: %u trees x depth %u x %u features, %" PRIu64 " tuples, %u device(s)\n",
+         prefix.c_str(), T, D, F, N, G);
+  return 0;
+}
+
+int cmd_score(const std::map<std::string, std::string>& o) {
+  uint64_t csr[DDT_CSR_COUNT];
+  if (!read_csr(str(o, "csr"), csr)) return die(DDT_EINVAL, nullptr, "read csr file");
+  ddt_params p;
+  uint64_t n_csr = 0;
+  uint32_t devices = 1;
+  int rc = ddt_csr_decode(csr, &p, &n_csr, &devices);
+  if (rc) return die(rc, nullptr, "csr decode");
+  p.cmp_mode = (uint32_t)num(o, "cmp-mode", 0);
+  p.sum_mode = (uint32_t)num(o, "sum-mode", 0);
+  std::vector<unsigned char> w, f, x;
+  if (!read_file(str(o, "weights"), &w) || !read_file(str(o, "findex"), &f) || !read_file(str(o, "tuples"), &x))
+    return die(DDT_EINVAL, nullptr, "read stream files");
+  const size_t tuple_bytes = (size_t)p.num_features * 4;  // decode returns F = 4 * tuple lines
+  const uint64_t n = x.size() / tuple_bytes;              // the tuple stream is authoritative (CSR207 counts whole lines)
+  if (x.size() % tuple_bytes) return die(DDT_EINVAL, nullptr, "tuple stream is not a whole number of tuples");
+  if ((n + 3) / 4 != (n_csr + 3) / 4)
+    fprintf(stderr, "ddt_cli: note: CSR207 announces %" PRIu64 " result lines, the tuple stream holds %" PRIu64 " tuples\n", n_csr / 4, n);
+  ddt_engine* e = nullptr;
+  rc = ddt_create(&e, (int)num(o, "device", 0));
+  if (rc) return die(rc, nullptr, "ddt_create");
+  if (o.count("variant")) ddt_set_option(e, "variant", (int64_t)num(o, "variant", 0));
+  const uint32_t of = (uint32_t)num(o, "of", 1), shard = (uint32_t)num(o, "shard", 0);
+  rc = ddt_load_model_shard(e, &p, w.data(), w.size() / 16, f.data(), f.size() / 16, shard, of);
+  if (rc) return die(rc, e, "load model");
+  std::vector<float> scores((size_t)((n + 3) / 4 * 4), 0.0f);  // whole result lines, zero padded
+  rc = ddt_score(e, x.data(), n, scores.data());
+  if (rc) return die(rc, e, "score");
+  if (!write_file(str(o, "out"), scores.data(), scores.size() * 4)) return die(DDT_EINVAL, e, "write results");
+  ddt_info info;
+  ddt_stats st;
+  ddt_get_info(e, &info);
+  ddt_get_stats(e, &st);
+  printf("scored %" PRIu64 " tuples with trees [%u, %u) of %u on %s, kernel %s, %.3f ms (%.2f Mtuples/s incl. PCIe), %" PRIu64
+         " result lines\n",
+         n, info.tree_begin, info.tree_end, p.num_trees, info.device_name, info.variant_name, st.exec_ms,
+         st.exec_ms > 0 ? (double)n / st.exec_ms / 1e3 : 0.0, st.result_lines_out);
+  ddt_destroy(e);
+  return 0;
+}
+
+int cmd_info() {
+  ddt_engine* e = nullptr;
+  const int rc = ddt_create(&e, 0);
+  printf("libddt ABI %d, %d kernel variants\n", DDT_ABI_VERSION, ddt_num_variants());
+  for (int v = 0; v < ddt_num_variants(); ++v) {
+    char name[64];
+    ddt_variant_name(v, name, sizeof(name));
+    printf("  variant %2d  %s\n", v, name);
+  }
+  if (rc) {
+    printf("device: none usable (%s)\n", ddt_strerror(rc));
+    return 0;
+  }
+  ddt_info info;
+  ddt_get_info(e, &info);
+  printf("device 0: %s\n", info.device_name);
+  ddt_destroy(e);
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    fprintf(stderr, "usage: ddt_cli gen|score|info [--option value ...]   (see the header of ddt_cli.cpp)\n");
+    return 2;
+  }
+  const std::string cmd = argv[1];
+  const auto o = parse(argc, argv, 2);
+  if (cmd == "gen") return cmd_gen(o);
+  if (cmd == "score") return cmd_score(o);
+  if (cmd == "info") return cmd_info();
+  fprintf(stderr, "unknown command %s\n", cmd.c_str());
+  return 2;
+}

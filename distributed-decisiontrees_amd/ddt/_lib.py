@@ -14,7 +14,7 @@ CSRC = os.path.join(_PKG, "csrc")
 SYMBOLS = [
     "ddt_create", "ddt_destroy", "ddt_load_model", "ddt_load_model_shard", "ddt_score", "ddt_score_device",
     "ddt_chain_sum_device", "ddt_load_model_multiclass", "ddt_classify_device", "ddt_classify", "ddt_argmax_device",
-    "ddt_get_info", "ddt_get_stats", "ddt_strerror", "ddt_last_error", "ddt_set_option",
+    "ddt_csr_encode", "ddt_csr_decode", "ddt_get_info", "ddt_get_stats", "ddt_strerror", "ddt_last_error", "ddt_set_option",
     "ddt_num_variants", "ddt_variant_name", "ddt_synth_model", "ddt_synth_tuples_host", "ddt_synth_tuples_device",
 ]
 
@@ -90,6 +90,9 @@ def lib():
     L.ddt_classify_device.restype, L.ddt_classify_device.argtypes = i32, [vp, vp, sz, vp, vp, vp]
     L.ddt_classify.restype, L.ddt_classify.argtypes = i32, [vp, vp, sz, vp, vp]
     L.ddt_argmax_device.restype, L.ddt_argmax_device.argtypes = i32, [vp, vp, u32, sz, vp, vp]
+    L.ddt_csr_encode.restype, L.ddt_csr_encode.argtypes = i32, [PP, u64, u32, C.POINTER(u64 * 12)]
+    L.ddt_csr_decode.restype = i32
+    L.ddt_csr_decode.argtypes = [C.POINTER(u64 * 12), PP, C.POINTER(u64), C.POINTER(u32)]
     L.ddt_get_info.restype, L.ddt_get_info.argtypes = i32, [vp, C.POINTER(Info)]
     L.ddt_get_stats.restype, L.ddt_get_stats.argtypes = i32, [vp, C.POINTER(Stats)]
     L.ddt_strerror.restype, L.ddt_strerror.argtypes = C.c_char_p, [i32]

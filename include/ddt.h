@@ -144,6 +144,17 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value);
 int ddt_num_variants(void);
 int ddt_variant_name(int variant, char* buf, size_t buflen);
 
+/* -- soft-register (CSR) block codec: the reference's run parameters as the host writes them, CSR 200..211
+ *    (EngineCSR.sv:190-305).  csr[k] is the 64-bit value written to register 200+k.  encode() fills the fields
+ *    this engine consumes plus sane values for the FPGA-only ones (mode flags, packet sizes); decode() recovers
+ *    ddt_params, the tuple count (4 * CSR207[31:0], the reference counts whole result lines) and the device
+ *    count (CSR203[39:32]).  num_features comes back as 4 * tuple lines (the wire format does not carry F);
+ *    cmp_mode / sum_mode are not in the CSR map and decode to 0 (the RTL's behaviour).                      -- */
+#define DDT_CSR_FIRST 200
+#define DDT_CSR_COUNT 12
+int ddt_csr_encode(const ddt_params* p, uint64_t n_tuples, uint32_t num_devices, uint64_t csr[DDT_CSR_COUNT]);
+int ddt_csr_decode(const uint64_t csr[DDT_CSR_COUNT], ddt_params* p, uint64_t* n_tuples, uint32_t* num_devices);
+
 /* -- deterministic synthetic inputs of SURVEY.md 8(d) (bench/test support; device generator so that
  *    the timed region starts with inputs resident in HBM) -------------------------------------------- */
 int ddt_synth_model(uint32_t num_trees, uint32_t num_levels, uint32_t num_features, int dist,

@@ -1,0 +1,91 @@
+"""the soft-register (CSR) codec and the ddt_cli host program that consumes the reference's
+register block + line-stream files."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import ddt
+
+
+def _encode(p, n, devices=1):
+    csr = (C.c_uint64 * 12)()
+    rc = ddt.lib().ddt_csr_encode(C.byref(p), n, devices, C.byref(csr))
+    return rc, csr
+
+
+def test_csr_fields_sit_where_the_rtl_reads_them():
+    # BASELINE config 3 on one device: field positions of rtl/DTEngine/EngineCSR.sv:190-248
+    p = ddt.make_params(1000, 8, 32)
+    rc, csr = _encode(p, 100_000_000)
+    assert rc == 0
+    assert csr[0] & 1                                                       # 200: start
+    assert csr[2] & 0xFFFFFFFF == 1000 * (128 + 32) and csr[2] >> 32 == 1000 * 128   # 202: total / weights lines
+    assert (csr[4] >> 16) & 0xFFFF == 128 and (csr[4] >> 32) & 0xFFFF == 32 and csr[4] >> 48 == 8   # 204
+    assert csr[4] & 0xFF == 0x01 and (csr[4] >> 8) & 0xFF == 0xFF           # C = 8: one replica, all clusters per tuple
+    assert csr[5] & 0xFFFFFFFF == 0x7FC00000 and (csr[5] >> 32) & 0xF == 8  # 205: missing, levels
+    assert (csr[5] >> 36) & 0xFF == 16 and (csr[5] >> 44) & 0xF == 8        #      16 trees per PU, 8 clusters per tuple
+    assert csr[7] & 0xFFFFFFFF == 25_000_000                                # 207: N / 4 result lines
+    assert (csr[3] >> 32) & 0xFF == 1
+
+
+@pytest.mark.parametrize("T,D,F,n,dev", [(8, 4, 16, 1000, 1), (100, 6, 28, 10_000_001, 1), (1000, 8, 32, 4096, 8),
+                                         (3, 16, 2048, 7, 1), (512, 12, 64, 12, 1)])
+def test_csr_roundtrip(T, D, F, n, dev):
+    p = ddt.make_params(T, D, F, missing_bits=0x12345678, clusters=ddt.default_clusters((T + dev - 1) // dev))
+    rc, csr = _encode(p, n, dev)
+    if D == 12 and T == 512:
+        assert rc == 0
+    assert rc == 0
+    q, n2, d2 = ddt.Params(), C.c_uint64(), C.c_uint32()
+    assert ddt.lib().ddt_csr_decode(C.byref(csr), C.byref(q), C.byref(n2), C.byref(d2)) == 0
+    assert (q.num_trees, q.num_levels, q.missing_bits) == (T, D, 0x12345678)
+    assert q.num_features == ddt.tuple_words(F) and q.clusters_per_tuple == p.clusters_per_tuple
+    assert (q.weights_lines_per_tree, q.findex_lines_per_tree) == (p.weights_lines_per_tree, p.findex_lines_per_tree)
+    assert n2.value == (n + 3) // 4 * 4 and d2.value == dev
+
+
+def test_csr_rejects_inconsistent_blocks():
+    p = ddt.make_params(8, 4, 16)
+    _, csr = _encode(p, 100)
+    q = ddt.Params()
+    bad = (C.c_uint64 * 12)(*csr)
+    bad[2] += 1  # total lines no longer T * (wl + fl)
+    assert ddt.lib().ddt_csr_decode(C.byref(bad), C.byref(q), None, None) == -1
+    bad = (C.c_uint64 * 12)(*csr)
+    bad[5] = (bad[5] & ~(0xF << 44)) | (3 << 44)  # 3 clusters per tuple
+    assert ddt.lib().ddt_csr_decode(C.byref(bad), C.byref(q), None, None) == -1
+    # 250 trees x 512 lines per device do not fit the RTL's 16-bit per-device line counter (EngineCSR.sv:213)
+    assert ddt.lib().ddt_csr_encode(C.byref(ddt.make_params(1000, 10, 32)), 8, 4, C.byref(csr)) == -5
+
+
+def test_cli_gen_writes_wire_format_files(tmp_path):
+    assert os.path.exists(ddt.CLI_PATH), "ddt_cli not built"
+    pre = str(tmp_path / "m")
+    subprocess.check_call([ddt.CLI_PATH, "gen", "--trees", "100", "--levels", "6", "--features", "28", "--rows", "515",
+                           "--dist", "1", "--prefix", pre])
+    m = O.gen_model(100, 6, 28, dist=1)
+    assert np.array_equal(np.fromfile(pre + ".weights", np.uint32), m.wlines)
+    assert np.array_equal(np.fromfile(pre + ".findex", np.uint16), m.flines)
+    assert np.array_equal(np.fromfile(pre + ".tuples", np.uint32).reshape(515, 28), O.gen_tuples(0, 515, 28, dist=1))
+    regs = dict((int(a), int(v, 16)) for a, v in (l.split() for l in open(pre + ".csr") if l[0] != "#"))
+    assert regs[202] & 0xFFFFFFFF == 100 * (32 + 8) and regs[207] == (515 + 3) // 4 and list(regs)[-1] == 200
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,D,F,n,dist", [(8, 4, 16, 1000, 0), (1000, 8, 32, 3001, 0), (100, 6, 28, 2222, 1)])
+def test_cli_score_matches_oracle(tmp_path, T, D, F, n, dist):
+    pre = str(tmp_path / "m")
+    subprocess.check_call([ddt.CLI_PATH, "gen", "--trees", str(T), "--levels", str(D), "--features", str(F),
+                           "--rows", str(n), "--dist", str(dist), "--prefix", pre])
+    out = subprocess.check_output([ddt.CLI_PATH, "score", "--csr", pre + ".csr", "--weights", pre + ".weights",
+                                   "--findex", pre + ".findex", "--tuples", pre + ".tuples", "--out", pre + ".results"]).decode()
+    assert f"scored {n} tuples" in out
+    res = np.fromfile(pre + ".results", np.float32)
+    assert res.size == (n + 3) // 4 * 4 and not res[n:].any()  # whole 128-bit result lines (ResultsCombiner.sv:136-160)
+    m = O.gen_model(T, D, F, dist=dist)
+    want = O.score(m, O.gen_tuples(0, n, F, dist=dist))
+    assert np.array_equal(res[:n].view(np.uint32), want.view(np.uint32))

@@ -1,0 +1,136 @@
+"""the model importer (ddt/importer.py).  CPU tests score the imported streams with the oracle,
+the GPU test with the engine; both must reproduce scikit-learn's own predictions."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import ddt
+from ddt import importer as I
+
+sk = pytest.importorskip("sklearn")
+from sklearn import ensemble, tree  # noqa: E402
+
+
+def _omodel(im, clusters=None):
+    p = O.make_params(im.num_trees, im.num_levels, im.num_features, im.missing_bits, im.cmp_mode, clusters)
+    return O.Model(p, im.wlines, im.flines)
+
+
+def _data(n=1200, F=9, seed=0):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, F)).astype(np.float32)  # negatives on purpose: needs the IEEE comparator
+    y = (np.sin(2 * X[:, 0]) + X[:, 1] * X[:, 2] - 0.5 * X[:, 3] + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    return X, y
+
+
+def test_le_to_lt_threshold_is_exact():
+    rng = np.random.default_rng(1)
+    t = np.concatenate([rng.standard_normal(2000), rng.standard_normal(2000).astype(np.float32).astype(np.float64), [0.0, -0.0, 1e-40, -1e-40]])
+    thr = I.le_to_lt_threshold(t)
+    for probe in (t.astype(np.float32), np.nextafter(t.astype(np.float32), np.float32(np.inf)), np.nextafter(t.astype(np.float32), np.float32(-np.inf))):
+        assert np.array_equal(probe.astype(np.float64) <= t, probe < thr)
+
+
+@pytest.mark.parametrize("maker", [
+    lambda: tree.DecisionTreeRegressor(max_depth=6, random_state=0),
+    lambda: ensemble.RandomForestRegressor(n_estimators=25, max_depth=7, random_state=0),
+    lambda: ensemble.ExtraTreesRegressor(n_estimators=10, max_depth=5, random_state=0),
+    lambda: ensemble.GradientBoostingRegressor(n_estimators=40, max_depth=3, random_state=0),
+])
+def test_sklearn_regressors_through_oracle(maker):
+    X, y = _data()
+    mdl = maker().fit(X, y)
+    im = I.from_sklearn(mdl)
+    Xt = _data(500, seed=5)[0]
+    got = O.score(_omodel(im), O.tuples_from_float(Xt), sum_mode=O.SUM_F64_SEQ) + np.float32(im.base_score[0])
+    assert np.allclose(got, mdl.predict(Xt), rtol=2e-5, atol=2e-5)
+    # per-tree exactness: every imported tree picks the leaf sklearn picks
+    if hasattr(mdl, "estimators_") and not isinstance(mdl, ensemble.GradientBoostingRegressor):
+        lv = O.leaves(_omodel(im), O.tuples_from_float(Xt)[7]).view(np.float32) * len(mdl.estimators_)
+        want = np.array([e.predict(Xt[7:8])[0] for e in mdl.estimators_])
+        assert np.allclose(lv, want, rtol=1e-6, atol=1e-7)
+
+
+def test_sklearn_missing_values_follow_default_direction():
+    X, y = _data(1500, 6, 3)
+    Xm = X.copy()
+    Xm[np.random.default_rng(2).random(X.shape) < 0.1] = np.nan
+    mdl = tree.DecisionTreeRegressor(max_depth=6, random_state=0).fit(Xm, y)
+    im = I.from_sklearn(mdl)
+    Xt = _data(400, 6, 9)[0]
+    Xt[np.random.default_rng(4).random(Xt.shape) < 0.15] = np.nan
+    tl = O.tuples_from_float(Xt)
+    assert (tl[:, :6] == 0x7FC00000).sum() > 100  # np.nan is the canonical quiet NaN the engine treats as missing
+    got = O.score(_omodel(im), tl, sum_mode=O.SUM_F64_SEQ)
+    assert np.allclose(got, mdl.predict(Xt), rtol=1e-6, atol=1e-6)
+
+
+def test_sklearn_classifiers_through_oracle():
+    X, y = _data(2000, 8, 7)
+    lab = np.digitize(y, np.quantile(y, [0.25, 0.5, 0.75]))  # 4 classes
+    Xt = _data(600, 8, 8)[0]
+    gbc = ensemble.GradientBoostingClassifier(n_estimators=15, max_depth=3, random_state=0).fit(X, lab)
+    im = I.from_sklearn(gbc)
+    assert im.num_classes == 4 and im.num_trees == 60
+    _, cs = O.classify(_omodel(im), O.tuples_from_float(Xt), 4, sum_mode=O.SUM_F64_SEQ)
+    raw = cs.T.astype(np.float64) + im.base_score[None, :]
+    assert np.allclose(raw, gbc.decision_function(Xt), rtol=1e-4, atol=1e-4)
+    assert np.mean(np.argmax(raw, axis=1) == gbc.predict(Xt)) > 0.995
+    rfc = ensemble.RandomForestClassifier(n_estimators=12, max_depth=6, random_state=0).fit(X, lab)
+    im = I.from_sklearn(rfc)
+    labels, cs = O.classify(_omodel(im), O.tuples_from_float(Xt), 4, sum_mode=O.SUM_F64_SEQ)
+    assert np.allclose(cs.T, rfc.predict_proba(Xt), atol=1e-5)
+    assert np.mean(labels == rfc.predict(Xt)) > 0.99
+
+
+def _xgb_eval(tr, x):
+    n = 0
+    while tr["left_children"][n] >= 0:
+        f, c = tr["split_indices"][n], np.float32(tr["split_conditions"][n])
+        v = x[f]
+        go_left = bool(tr["default_left"][n]) if np.isnan(v) else bool(v < c)
+        n = tr["left_children"][n] if go_left else tr["right_children"][n]
+    return tr["split_conditions"][n]
+
+
+def test_xgboost_json_dump():
+    t0 = {"left_children": [1, 3, -1, -1, -1], "right_children": [2, 4, -1, -1, -1], "split_indices": [0, 1, 0, 0, 0],
+          "split_conditions": [0.5, -0.25, 0.3, -0.1, 0.2], "default_left": [1, 0, 0, 0, 0]}
+    t1 = {"left_children": [1, -1, -1], "right_children": [2, -1, -1], "split_indices": [2, 0, 0],
+          "split_conditions": [0.0, 1.5, -1.5], "default_left": [0, 0, 0]}
+    j = {"learner": {"learner_model_param": {"num_feature": "3", "num_class": "0", "base_score": "0.5"},
+                     "gradient_booster": {"name": "gbtree", "model": {"trees": [t0, t1], "tree_info": [0, 0]}}}}
+    im = I.from_xgboost_json(j)
+    assert (im.num_trees, im.num_levels, im.num_features) == (2, 2, 3)
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((300, 3)).astype(np.float32)
+    X[rng.random(X.shape) < 0.2] = np.nan
+    X[0] = [0.5, -0.25, 0.0]  # exactly on the thresholds: '<' sends them right
+    got = O.score(_omodel(im), O.tuples_from_float(X), sum_mode=O.SUM_F64_SEQ)
+    want = np.array([_xgb_eval(t0, x) + _xgb_eval(t1, x) for x in X], np.float32)
+    assert np.allclose(got, want, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_imported_models_on_gpu():
+    X, y = _data(3000, 12, 11)
+    Xt = _data(5000, 12, 12)[0]
+    tl = O.tuples_from_float(Xt)
+    e = ddt.Engine(0)
+    rf = ensemble.RandomForestRegressor(n_estimators=64, max_depth=8, random_state=0).fit(X, y)
+    im = I.from_sklearn(rf)
+    for sum_mode in (0, 1):
+        e.load_model(im.params(sum_mode=sum_mode), im.wlines, im.flines)
+        got = e.score(tl)
+        assert np.allclose(got, rf.predict(Xt), rtol=2e-5, atol=2e-5)
+        om = _omodel(im, im.params().clusters_per_tuple)
+        assert np.array_equal(got.view(np.uint32), O.score(om, tl, sum_mode=O.SUM_REF_FLOPOCO if sum_mode == 0 else O.SUM_F64_SEQ).view(np.uint32))
+    lab = np.digitize(y, np.quantile(y, [0.33, 0.66]))
+    gbc = ensemble.GradientBoostingClassifier(n_estimators=20, max_depth=4, random_state=0).fit(X, lab)
+    im = I.from_sklearn(gbc)
+    e.load_model_multiclass(im.params(sum_mode=1), im.wlines, im.flines, im.num_classes, True)
+    labels, cs = e.classify(tl, want_scores=True)
+    raw = cs.T.astype(np.float64) + im.base_score[None, :]
+    assert np.allclose(raw, gbc.decision_function(Xt), rtol=1e-4, atol=1e-4)
+    assert np.mean(np.argmax(raw, axis=1) == gbc.predict(Xt)) > 0.995
+    e.close()
