@@ -1,0 +1,83 @@
+"""Analytic performance model.
+
+Part 1 restates the reference's offline sizing / throughput model (`profiler/profiler.cpp:51-118`,
+`profiler/profiler_performance_model.cpp:50-110`): engine throughput = f * Ncu * Npe / (depth * Ntrees)
+tuples/s, a system is capped by the PCIe tuple rate and (for more than one FPGA) the network tuple rate.
+Part 2 re-parameterises the same idea for MI355X with the constants measured in profiles/: the per-GPU rate is
+min(LDS-pipe node-visit ceiling x achieved efficiency, HBM rate), tree-sharding divides the visits per GPU and
+adds an all-reduce of 4 bytes per tuple that overlaps with scoring.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+# ---- part 1: the reference's model, verbatim semantics ----------------------------------------------------
+@dataclass
+class FpgaPlatform:
+    freq_mhz: int = 150            # profiler.cpp:35
+    n_cu: int = 4                  # :36  (the published RTL instantiates 8 clusters, DTEngine_Types.sv:26)
+    n_pe: int = 8                  # :37
+    max_nodes_per_pe: int = 8192   # :38
+    pcie_gbps: float = 2.2         # :40
+    network_gbps: float = 3.0      # :41
+    tuple_bytes: int = 128         # :34
+
+
+def engine_throughput(p: FpgaPlatform, depth: int, n_trees: int) -> float:
+    """profiler.cpp:97-102 -- tuples/s of one FPGA."""
+    return float(p.freq_mhz * 1e6 * p.n_cu * p.n_pe) / float(depth * n_trees)
+
+
+def sizing(p: FpgaPlatform, n_trees: int, depth: int) -> dict:
+    """profiler.cpp:51-86 -- min/max useful FPGA count and the modelled throughput at each."""
+    cap = p.n_cu * p.n_pe * p.max_nodes_per_pe
+    want = n_trees * (2 ** depth)
+    te = engine_throughput(p, depth, n_trees)
+    out = {"max_trees_size_in_fpga": cap, "user_desired_tree_size": want, "engine_tuples_per_s": te}
+    if want <= cap:
+        out.update(max_fpgas=1, max_throughput=te)
+    else:
+        out["max_fpgas"] = int(p.pcie_gbps * 1e9 / (te * p.tuple_bytes))  # C truncation of the double
+        out["min_fpgas"] = int(want / cap)
+        out["min_throughput"] = out["min_fpgas"] * te
+        out["max_throughput"] = out["max_fpgas"] * te
+    return out
+
+
+def system_throughput(p: FpgaPlatform, n_fpgas: int, depth_incl_leaf_level: int, n_trees: int) -> float:
+    """profiler_performance_model.cpp:70-75,101-110 -- note it counts depth-1 compare levels."""
+    te = n_fpgas * engine_throughput(p, depth_incl_leaf_level - 1, n_trees)
+    t_mem = p.pcie_gbps * 1e9 / p.tuple_bytes
+    t_net = p.network_gbps * 1e9 / p.tuple_bytes
+    return min(te, t_mem, t_net) if n_fpgas > 1 else min(te, t_mem)
+
+
+# ---- part 2: MI355X ----------------------------------------------------------------------------------------
+@dataclass
+class Mi355x:
+    cus: int = 256
+    clock_hz: float = 2.4e9
+    hbm_bytes_per_s: float = 8.0e12        # spec peak; ~6.3e12 achievable (MI355X_MICROARCH.md)
+    ds_ops_per_visit: float = 2.10         # measured, profiles/r01_pmc_d8_t1024_v1.md
+    lds_cycles_per_ds_op: float = 2.48     # measured incl. bank conflicts
+    lds_efficiency: float = 0.70           # achieved / LDS-pipe ceiling at 16 waves per CU (measured)
+    hbm_efficiency: float = 0.60           # streaming kernel, measured on config 1
+    allreduce_alg_bytes_per_s: float = 87e9  # ring over xGMI: ~153 GB/s link x 8/14
+
+
+def lds_visit_ceiling(g: Mi355x) -> float:
+    """node visits per second if the LDS pipe were 100 % busy"""
+    return g.cus * g.clock_hz * 64.0 / (g.ds_ops_per_visit * g.lds_cycles_per_ds_op)
+
+
+def predict(g: Mi355x, n_trees: int, depth: int, n_features: int, n_gpus: int = 1, rows: float = 1e8) -> dict:
+    """Predicted whole-job Mtuples/s for the tree-sharded mode (trees / n_gpus per GPU, all tuples on every GPU)."""
+    visits = (n_trees / n_gpus) * depth
+    t_lds = rows * visits / (lds_visit_ceiling(g) * g.lds_efficiency)
+    t_hbm = rows * (4 * n_features + 4) / (g.hbm_bytes_per_s * g.hbm_efficiency)
+    t_score = max(t_lds, t_hbm)
+    t_comm = 0.0 if n_gpus == 1 else rows * 4 / g.allreduce_alg_bytes_per_s
+    t = max(t_score, t_comm) + (0.0 if n_gpus == 1 else min(t_score, t_comm) / 8.0)  # 8 pipelined chunks: one is exposed
+    return {"seconds": t, "mtuples_per_s": rows / t / 1e6, "bound": "lds" if t_lds >= t_hbm else "hbm",
+            "t_score": t_score, "t_comm": t_comm}

@@ -1,0 +1,47 @@
+"""the port of the reference's analytic profiler, checked against the outputs of the
+reference programs themselves (tests/golden/profiler*_ref.txt, produced by oracle/_ref -- the only
+reference code that compiles), and the MI355X re-parameterisation against this repo's measurements."""
+import os
+import re
+
+from ddt import perf_model as P
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_profiler_cpp_known_answers():
+    txt = open(os.path.join(G, "profiler_ref.txt")).read()
+    val = lambda k: float(re.search(re.escape(k) + r"\s*=\s*([0-9.e+]+)", txt).group(1))
+    s = P.sizing(P.FpgaPlatform(), 512, 12)
+    assert s["max_trees_size_in_fpga"] == val("max_trees_size_in_fpga")
+    assert s["user_desired_tree_size"] == val("user_desired_tree_size")
+    assert s["engine_tuples_per_s"] == val("ret_val")
+    assert s["min_fpgas"] == val("Minimum no.of.fpgas_needed") and s["max_fpgas"] == val("Maximum no.of.fpgas_needed")
+    thr = [float(v) for v in re.findall(r"Corresponding Throughput = ([0-9.e+]+)", txt)]
+    assert abs(s["min_throughput"] - thr[0]) <= 1e-6 * thr[0] and abs(s["max_throughput"] - thr[1]) <= 1e-6 * thr[1]
+
+
+def test_profiler_performance_model_sweep():
+    rows = [l.split() for l in open(os.path.join(G, "profiler_performance_model_ref.txt")) if re.match(r"^\d+\s", l)]
+    assert len(rows) == 40
+    for n, d, t in rows:
+        got = P.system_throughput(P.FpgaPlatform(), int(n), int(d), 512)
+        assert abs(got - float(t)) <= 6e-6 * float(t), (n, d, t, got)  # the reference prints 6 significant digits
+
+
+def test_reference_model_on_baseline_configs():
+    # 1000 trees, depth 8 -> 0.6 Mtuples/s per FPGA with the model's 32 PEs, 1.2 M with the RTL's 64
+    assert abs(P.engine_throughput(P.FpgaPlatform(), 8, 1000) - 0.6e6) < 1
+    assert abs(P.engine_throughput(P.FpgaPlatform(n_cu=8), 8, 1000) - 1.2e6) < 1
+
+
+def test_mi355x_model_matches_measurements_within_20_percent():
+    g = P.Mi355x()
+    measured = {  # profiles/r01_*: Mtuples/s on one MI355X
+        (1000, 8, 32): 664.7, (100, 6, 28): 7222.0, (8, 4, 16): 70253.6}
+    for (T, D, F), m in measured.items():
+        p = P.predict(g, T, D, F)["mtuples_per_s"]
+        assert 0.8 < p / m < 1.25, (T, D, F, p, m)
+    assert P.predict(g, 8, 4, 16)["bound"] == "hbm" and P.predict(g, 1000, 8, 32)["bound"] == "lds"
+    s8 = P.predict(g, 1000, 8, 32, 8)["mtuples_per_s"] / P.predict(g, 1000, 8, 32, 1)["mtuples_per_s"]
+    assert 6.0 < s8 <= 8.0  # the >= 6x aggregate target of the north star is plausible with overlapped all-reduce
