@@ -176,6 +176,40 @@ void orc_leaves(const orc_params* p, const uint32_t* weights_lines, const uint16
   for (uint32_t i = 0; i < p->num_trees; ++i) leaves[i] = orc_traverse(p, weights_lines, findex_lines, tuple, i);
 }
 
+/* Same walk as orc_traverse for trees [first, first+cnt), eight trees in lock-step per level so that a CPU core
+ * has eight independent load chains in flight (the batch scorers below use it: it is what makes the CPU baseline
+ * a fair one).  tests/test_oracle_kat.py checks it against orc_traverse tree by tree. */
+static void traverse_range(const orc_params* p, const uint32_t* wl, const uint16_t* fl, const uint32_t* x,
+                           uint32_t first, uint32_t cnt, uint32_t* leaves) {
+  const size_t ws = (size_t)p->weights_lines_per_tree * 4u, fs = (size_t)p->findex_lines_per_tree * 8u;
+  const uint32_t D = p->num_levels, miss = p->missing_bits, mode = p->cmp_mode;
+  uint32_t i = 0;
+  for (; i + 8 <= cnt; i += 8) {
+    const uint32_t* w[8];
+    const uint16_t* f[8];
+    uint32_t n[8];
+    for (int u = 0; u < 8; ++u) {
+      w[u] = wl + (size_t)(first + i + u) * ws;
+      f[u] = fl + (size_t)(first + i + u) * fs;
+      n[u] = 0;
+    }
+    for (uint32_t lvl = 0; lvl < D; ++lvl)
+      for (int u = 0; u < 8; ++u) {
+        const uint16_t e = f[u][n[u]];
+        const uint32_t v = x[e & 0x7FFu], thr = w[u][n[u]];
+        const uint32_t right = (v == miss) ? ((e >> 13) & 1u) : (uint32_t)!orc_less(v, thr, mode);
+        n[u] = 2u * n[u] + 1u + right;
+      }
+    for (int u = 0; u < 8; ++u) leaves[i + u] = w[u][n[u]];
+  }
+  for (; i < cnt; ++i) leaves[i] = orc_traverse(p, wl, fl, x, first + i);
+}
+
+void orc_leaves_fast(const orc_params* p, const uint32_t* weights_lines, const uint16_t* findex_lines,
+                     const uint32_t* tuple, uint32_t* leaves) {
+  traverse_range(p, weights_lines, findex_lines, tuple, 0, p->num_trees, leaves);
+}
+
 /* =============================================================================================
  * 4. Reference-order reduction (one device)
  *    tree i (local stream order) -> PU i%8 (Core.sv:352-357), group g=i/8 -> cluster g%C, slot g/C
@@ -295,7 +329,7 @@ int orc_score_shard(const orc_params* p, const void* wl, size_t n_wlines, const 
 #endif
     for (long long r = 0; r < (long long)n_tuples; ++r) {
       const uint32_t* x = t + (size_t)r * tw;
-      for (uint32_t i = 0; i < nloc; ++i) leaves[i] = orc_traverse(p, w, f, x, tree_begin + i);
+      traverse_range(p, w, f, x, tree_begin, nloc, leaves);
       out[r] = f_from(shard_sum(leaves, nloc, p->clusters_per_tuple, sum_mode));
     }
     free(leaves);
@@ -326,7 +360,7 @@ int orc_score(const orc_params* p, const void* wl, size_t n_wlines, const void* 
 #endif
     for (long long r = 0; r < (long long)n_tuples; ++r) {
       const uint32_t* x = t + (size_t)r * tw;
-      for (uint32_t i = 0; i < T; ++i) leaves[i] = orc_traverse(p, w, f, x, i);
+      traverse_range(p, w, f, x, 0, T, leaves);
       /* chain reduce host -> dev1 -> ...: each hop adds local + upstream (ResultsCombiner.sv:292-311) */
       uint32_t run = 0;
       for (int d = 0; d < n_devices; ++d) {

@@ -65,6 +65,10 @@ uint32_t orc_traverse(const orc_params* p, const uint32_t* weights_lines, const 
 void orc_leaves(const orc_params* p, const uint32_t* weights_lines, const uint16_t* findex_lines,
                 const uint32_t* tuple, uint32_t* leaves);
 
+/* same result as orc_leaves, eight trees walked in lock-step (the batch scorers' inner loop) */
+void orc_leaves_fast(const orc_params* p, const uint32_t* weights_lines, const uint16_t* findex_lines,
+                     const uint32_t* tuple, uint32_t* leaves);
+
 /* Reference-order reduction of per-tree leaf bits for ONE device (DTPUCluster.sv:188-201,
  * FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131, Core.sv:486-541).  flopoco!=0 uses the
  * bit-level adder model, else host IEEE adds. */

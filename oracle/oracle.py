@@ -60,6 +60,7 @@ def lib():
         L.orc_fpadd_bits_batch.restype, L.orc_fpadd_bits_batch.argtypes = None, [vp, vp, vp, sz]
         L.orc_traverse.restype, L.orc_traverse.argtypes = u32, [PP, vp, vp, vp, u32]
         L.orc_leaves.restype, L.orc_leaves.argtypes = None, [PP, vp, vp, vp, vp]
+        L.orc_leaves_fast.restype, L.orc_leaves_fast.argtypes = None, [PP, vp, vp, vp, vp]
         L.orc_reduce_device.restype, L.orc_reduce_device.argtypes = u32, [vp, u32, u32, C.c_int]
         L.orc_score.restype = C.c_int
         L.orc_score.argtypes = [PP, vp, sz, vp, sz, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int]
@@ -204,6 +205,13 @@ def leaves(m: Model, tuple_row: np.ndarray) -> np.ndarray:
     t = np.ascontiguousarray(tuple_row, np.uint32)
     out = np.zeros(m.params.num_trees, np.uint32)
     lib().orc_leaves(C.byref(m.params), _p(m.wlines), _p(m.flines), _p(t), _p(out))
+    return out
+
+
+def leaves_fast(m: Model, tuple_row: np.ndarray) -> np.ndarray:
+    t = np.ascontiguousarray(tuple_row, np.uint32)
+    out = np.zeros(m.params.num_trees, np.uint32)
+    lib().orc_leaves_fast(C.byref(m.params), _p(m.wlines), _p(m.flines), _p(t), _p(out))
     return out
 
 

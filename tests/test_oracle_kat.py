@@ -169,6 +169,7 @@ def test_oracle_equals_independent_numpy_restatement(T, D, Fe, dist):
         lb = R.traverse_all(thr, fidx, mr, leaf, x, m.params.missing_bits, cmp_mode)
         for r in (0, 1, n - 1):
             assert np.array_equal(O.leaves(m, x[r]), lb[r])
+            assert np.array_equal(O.leaves_fast(m, x[r]), lb[r])  # the 8-wide walk the batch scorers use
         want = R.score_reference_order(lb, m.params.clusters_per_tuple)
         for mode in (O.SUM_REF_FLOPOCO, O.SUM_REF_NATIVE):
             got, gold = O.score(m, x, sum_mode=mode, want_gold=True)
