@@ -7,6 +7,7 @@
 // model store rtl/DTEngine/core/DTPU.sv:282-354; result packing rtl/DTEngine/ResultsCombiner.sv:136-160.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -39,7 +40,18 @@ struct Ensemble {
   void* d_img = nullptr;
   size_t img_bytes = 0;
   uint32_t img_trees = 0, img_chunks = 0;
+  // rank-quantised path only: image with miss_right flags, per-feature threshold tables
+  void* d_img_slow = nullptr;
+  void* d_tables = nullptr;
+  void* d_tabK = nullptr;
+  uint32_t Kpad = 0;
   uint32_t trees() const { return (uint32_t)ids.size(); }
+};
+
+// sorted distinct threshold keys per feature of one ensemble (q16 path)
+struct RankTables {
+  std::vector<std::vector<uint32_t>> keys;  // [W], ascending as signed int32
+  uint32_t max_len = 0;
 };
 
 }  // namespace
@@ -66,6 +78,16 @@ struct ddt_engine {
   // classify workspace (grow-only)
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  // rank-quantised path workspace (grow-only): transposed tuples, ranks, per-tile flags
+  // slot 0: ddt_score_device / ddt_classify_device (stream ordered); slots 1, 2: the feeder's two streams
+  void* q_xT[3] = {nullptr, nullptr, nullptr};
+  void* q_q[3] = {nullptr, nullptr, nullptr};
+  void* q_flags[3] = {nullptr, nullptr, nullptr};
+  uint64_t q_rows[3] = {0, 0, 0};  // capacity in rows (multiple of 1024)
+  int q_slot = 0;
+  // optional per-call kernel timing (option "kernel_timing"): start / before scoring kernel / end
+  bool kernel_timing = false, timing_pending = false;
+  hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
   ddt_stats st{};
   char err[256] = {0};
 };
@@ -153,7 +175,8 @@ uint32_t thr_key(const ddt_params& p, uint32_t bits) {
 }
 
 uint32_t padded_trees(const Variant& v, uint32_t T) {
-  const uint32_t granule = (v.kind == kKindTile && v.chunk_trees > 8) ? (uint32_t)v.chunk_trees : 8u;
+  const bool chunked = v.kind == kKindTile || v.kind == kKindQ16;
+  const uint32_t granule = (chunked && v.chunk_trees > 8) ? (uint32_t)v.chunk_trees : 8u;
   return (T + granule - 1u) / granule * granule;  // whole PU groups of 8 (and whole chunks)
 }
 
@@ -163,10 +186,34 @@ uint32_t max_trees(const ddt_engine* e) {
   return t;
 }
 
+// q16: sorted distinct threshold keys (comparator domain) per feature, over the trees of one ensemble
+RankTables rank_tables(const ddt_engine* e, const Ensemble& m) {
+  RankTables rt;
+  const uint32_t W = tuple_words(e->p), nint = e->nint;
+  rt.keys.resize(W);
+  for (uint32_t i = 0; i < m.trees(); ++i)
+    for (uint32_t n = 0; n < nint; ++n)
+      rt.keys[m.fidx[(size_t)i * nint + n]].push_back(thr_key(e->p, m.thr[(size_t)i * nint + n]));
+  for (auto& k : rt.keys) {
+    std::sort(k.begin(), k.end(), [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; });
+    k.erase(std::unique(k.begin(), k.end()), k.end());
+    if (k.size() > rt.max_len) rt.max_len = (uint32_t)k.size();
+  }
+  return rt;
+}
+
+constexpr uint32_t kQ16MaxTable = 32767;  // ranks must stay below 0xFFFF and a table (x4 B) must fit LDS in the rank kernel
+
 bool variant_fits(const Variant& v, const ddt_engine* e) {
   if (v.kind == kKindGeneric) return true;
   if ((uint32_t)v.levels != e->p.num_levels) return false;
   const uint32_t W = tuple_words(e->p);
+  if (v.kind == kKindQ16) {
+    if (W > 32u || v.lds_bytes_q16(W) > kMaxLdsBytes / 2u) return false;  // two blocks per CU or it is not worth it
+    for (const Ensemble& m : e->ens)
+      if (rank_tables(e, m).max_len > kQ16MaxTable) return false;
+    return true;
+  }
   if (v.kind == kKindStream)
     return W <= 4u * (uint32_t)v.opt && v.lds_bytes_stream(padded_trees(v, max_trees(e)), W) <= kStreamLdsBudget;
   return v.lds_bytes(W) <= kMaxLdsBytes;
@@ -186,6 +233,16 @@ int auto_variant(const ddt_engine* e) {
                                "d8_t1024_r1_c4_u4_dma_f", "d8_t512_r1_c8_u8_dma_f", "d8_t256_r1_c4_u4_dma",
                                "d6_t1024_r1_c16_u4_dma", "d6_t512_r1_c16_u8_dma", "d6_t256_r1_c16_u4_dma",
                                "d4_t256_r1_c64_u8_dma"};
+  // Rank-quantised path: its scoring kernel is ~1.3x faster (32 waves/CU) but it pays a fixed transpose + rank
+  // pre-pass per tuple (measured 1.22 ms per 8 M tuples vs 9.4 ms of scoring per 1000 depth-8 trees): worth it
+  // from ~450 trees per engine upwards (profiles/r01_q16_*).
+  if (max_trees(e) >= 448u) {
+    static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4"};
+    for (const char* name : qpref) {
+      const int i = find_variant(name);
+      if (i >= 0 && variant_fits(variant(i), e)) return i;
+    }
+  }
   for (const char* name : pref) {
     const int i = find_variant(name);
     if (i >= 0 && variant_fits(variant(i), e)) return i;
@@ -195,9 +252,21 @@ int auto_variant(const ddt_engine* e) {
 
 void free_images(ddt_engine* e) {
   for (Ensemble& m : e->ens) {
-    if (m.d_img) (void)hipFree(m.d_img);
-    m.d_img = nullptr;
+    for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK}) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
     m.img_bytes = 0;
+  }
+}
+
+void free_q16_workspace(ddt_engine* e) {
+  for (int k = 0; k < 3; ++k) {
+    for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k]}) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    e->q_rows[k] = 0;
   }
 }
 
@@ -254,6 +323,80 @@ int build_image(ddt_engine* e, const Variant& v, Ensemble& m) {
   return DDT_OK;
 }
 
+// q16 images: per tree 2^D records {R (lo16) | row offset (hi16)} in a 1-based heap, then 2^D fp32 leaves.
+// R = 1 + index of the node's threshold in its feature's table; the slow image carries miss_right in bit 16.
+int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m) {
+  const uint32_t D = e->p.num_levels, T = m.trees(), nint = e->nint, nleaf = e->nleaf, W = tuple_words(e->p);
+  const uint32_t tree_words = (8u << D) / 4u, Tpad = padded_trees(v, T);
+  const RankTables rt = rank_tables(e, m);
+  uint32_t Kpad = 2;
+  while (Kpad <= rt.max_len) Kpad <<= 1;  // power of two > max_len: the search reads indices < Kpad - 1
+  std::vector<uint32_t> fast, slow, tab, tabK;
+  try {
+    fast.assign((size_t)Tpad * tree_words, 0u);
+    tab.assign((size_t)W * Kpad, 0x7FFFFFFFu);
+    tabK.assign(W, 0u);
+  } catch (const std::bad_alloc&) {
+    return fail(e, DDT_ENOMEM, "q16 image allocation failed");
+  }
+  for (uint32_t j = 0; j < W; ++j) {
+    tabK[j] = (uint32_t)rt.keys[j].size();
+    std::copy(rt.keys[j].begin(), rt.keys[j].end(), tab.begin() + (size_t)j * Kpad);
+  }
+  const uint32_t row = v.tile() * 2u;  // bytes per feature row of the u16 tile
+  for (uint32_t i = 0; i < T; ++i) {
+    uint32_t* t = fast.data() + (size_t)i * tree_words;
+    for (uint32_t n = 0; n < nint; ++n) {
+      const uint32_t j = m.fidx[(size_t)i * nint + n], key = thr_key(e->p, m.thr[(size_t)i * nint + n]);
+      const auto& k = rt.keys[j];
+      const uint32_t idx = (uint32_t)(std::lower_bound(k.begin(), k.end(), key, [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; }) - k.begin());
+      t[n + 1] = (idx + 1u) | ((j * row) << 16);
+    }
+    for (uint32_t l = 0; l < nleaf; ++l) t[(1u << D) + l] = m.leaf[(size_t)i * nleaf + l];
+  }
+  slow = fast;
+  for (uint32_t i = 0; i < T; ++i)
+    for (uint32_t n = 0; n < nint; ++n)
+      if (m.mright[(size_t)i * nint + n]) slow[(size_t)i * tree_words + n + 1] |= 1u << 16;
+  for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  const size_t bytes = fast.size() * 4;
+  HIP_TRY(e, hipMalloc(&m.d_img, bytes));
+  HIP_TRY(e, hipMalloc(&m.d_img_slow, bytes));
+  HIP_TRY(e, hipMalloc(&m.d_tables, tab.size() * 4));
+  HIP_TRY(e, hipMalloc(&m.d_tabK, tabK.size() * 4));
+  HIP_TRY(e, hipMemcpy(m.d_img, fast.data(), bytes, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(m.d_img_slow, slow.data(), bytes, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(m.d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(m.d_tabK, tabK.data(), tabK.size() * 4, hipMemcpyHostToDevice));
+  m.img_bytes = bytes;
+  m.img_trees = Tpad;
+  m.img_chunks = Tpad / (uint32_t)v.chunk_trees;
+  m.Kpad = Kpad;
+  return DDT_OK;
+}
+
+// grow-only workspace of the q16 pre-pass (synchronous allocation on first use / growth)
+int ensure_q16_workspace(ddt_engine* e, size_t n) {
+  const uint64_t rows = (n + 1023) / 1024 * 1024;
+  const int k = e->q_slot;
+  if (rows <= e->q_rows[k]) return DDT_OK;
+  HIP_TRY(e, hipDeviceSynchronize());
+  for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k]}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  e->q_rows[k] = 0;
+  const uint32_t W = tuple_words(e->p);
+  HIP_TRY(e, hipMalloc(&e->q_xT[k], rows * W * 4));
+  HIP_TRY(e, hipMalloc(&e->q_q[k], rows * W * 2));
+  HIP_TRY(e, hipMalloc(&e->q_flags[k], rows / 1024 * 4));
+  e->q_rows[k] = rows;
+  return DDT_OK;
+}
+
 int select_and_build(ddt_engine* e) {
   int vid = e->forced_variant;
   if (vid >= 0) {
@@ -265,7 +408,7 @@ int select_and_build(ddt_engine* e) {
     vid = auto_variant(e);
   }
   for (Ensemble& m : e->ens) {
-    int rc = build_image(e, variant(vid), m);
+    int rc = variant(vid).kind == kKindQ16 ? build_image_q16(e, variant(vid), m) : build_image(e, variant(vid), m);
     if (rc) return rc;
   }
   e->variant_id = vid;
@@ -286,6 +429,8 @@ void fill_args(const ddt_engine* e, const Ensemble& m, const void* d_tuples, siz
   a->miss_key = e->p.cmp_mode ? kMissSentinelIeee : e->p.missing_bits;
   a->ieee = e->p.cmp_mode;
   a->sum_mode = e->p.sum_mode;
+  a->aux = nullptr;
+  a->ev_mid = nullptr;
 }
 
 void feeder_free(ddt_engine* e) {
@@ -317,12 +462,40 @@ int feeder_reserve(ddt_engine* e, size_t rows, size_t words, size_t outs) {
   return DDT_OK;
 }
 
+int ensure_q16_workspace(ddt_engine* e, size_t n);
+
 int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
   ScoreArgs a;
   fill_args(e, m, d_tuples, n, d_scores, &a);
   const Variant& v = variant(e->variant_id);
+  Q16Aux qa;
+  if (v.kind == kKindQ16) {
+    int rc = ensure_q16_workspace(e, n);
+    if (rc) return rc;
+    qa.xT = reinterpret_cast<uint32_t*>(e->q_xT[e->q_slot]);
+    qa.q = reinterpret_cast<uint16_t*>(e->q_q[e->q_slot]);
+    qa.tile_flags = reinterpret_cast<uint32_t*>(e->q_flags[e->q_slot]);
+    qa.tables = reinterpret_cast<const uint32_t*>(m.d_tables);
+    qa.tabK = reinterpret_cast<const uint32_t*>(m.d_tabK);
+    qa.Kpad = m.Kpad;
+    qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
+    qa.n_pad = (n + 1023) / 1024 * 1024;
+    a.aux = &qa;
+  }
+  const bool timing = e->kernel_timing && e->q_slot == 0;
+  if (timing) {
+    for (hipEvent_t& ev : e->tev)
+      if (!ev) HIP_TRY(e, hipEventCreate(&ev));
+    HIP_TRY(e, hipEventRecord(e->tev[0], s));
+    if (v.kind == kKindQ16) a.ev_mid = e->tev[1];
+    else HIP_TRY(e, hipEventRecord(e->tev[1], s));
+  }
   hipError_t r = v.launch(a, v, s);
   if (r != hipSuccess) return fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
+  if (timing) {
+    HIP_TRY(e, hipEventRecord(e->tev[2], s));
+    e->timing_pending = true;
+  }
   e->st.kernel_launches++;
   return DDT_OK;
 }
@@ -384,6 +557,7 @@ int load_common(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wli
     if (rc) return rc;
   }
   free_images(e);
+  free_q16_workspace(e);  // sized for the previous model's tuple width
   e->loaded = false;
   e->p = *p;
   e->nint = (1u << p->num_levels) - 1u;
@@ -430,7 +604,10 @@ void ddt_destroy(ddt_engine* e) {
     if (e->fe[b]) (void)hipEventDestroy(e->fe[b]);
   }
   if (e->ws) (void)hipFree(e->ws);
+  for (hipEvent_t ev : e->tev)
+    if (ev) (void)hipEventDestroy(ev);
   free_images(e);
+  free_q16_workspace(e);
   delete e;
 }
 
@@ -518,8 +695,10 @@ static int score_host(ddt_engine* e, const void* tuple_lines, size_t n, float* s
     memcpy(e->pin_in[b], src + off * W, cn * W * 4);
     HIP_TRY(e, hipMemcpyAsync(e->dev_in[b], e->pin_in[b], cn * W * 4, hipMemcpyHostToDevice, e->fs[b]));
     float* dout = reinterpret_cast<float*>(e->dev_out[b]);
+    e->q_slot = 1 + b;  // the two feeder streams run concurrently: separate q16 workspaces
     if (!classify) rc = launch_score(e, e->ens[0], e->dev_in[b], cn, dout, e->fs[b]);
     else rc = launch_classify(e, e->dev_in[b], cn, dout, reinterpret_cast<int32_t*>(dout + (size_t)K * cn), e->fs[b]);
+    e->q_slot = 0;
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(e->pin_out[b], e->dev_out[b], cn * outs * 4, hipMemcpyDeviceToHost, e->fs[b]));
     HIP_TRY(e, hipEventRecord(e->fe[b], e->fs[b]));
@@ -583,6 +762,7 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   out->block_threads = (uint32_t)v.threads;
   out->lds_bytes = v.kind == kKindTile     ? v.lds_bytes(out->tuple_words)
                    : v.kind == kKindStream ? v.lds_bytes_stream(m0.img_trees, out->tuple_words)
+                   : v.kind == kKindQ16    ? v.lds_bytes_q16(out->tuple_words)
                                            : generic_lds_bytes(e->p.num_levels, out->tuple_words, nullptr, nullptr);
   out->model_bytes_unpadded = (uint64_t)trees * (4ull * ((2ull << e->p.num_levels) - 1) + 2ull * ((1ull << e->p.num_levels) - 1));
   out->image_bytes = img;
@@ -592,8 +772,18 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   return DDT_OK;
 }
 
-int ddt_get_stats(const ddt_engine* e, ddt_stats* out) {
-  if (!e || !out) return DDT_EINVAL;
+int ddt_get_stats(const ddt_engine* e_, ddt_stats* out) {
+  if (!e_ || !out) return DDT_EINVAL;
+  ddt_engine* e = const_cast<ddt_engine*>(e_);  // resolving pending event times is a logically-const refresh
+  if (e->timing_pending) {
+    float pre = 0.f, sc = 0.f;
+    if (hipEventSynchronize(e->tev[2]) == hipSuccess && hipEventElapsedTime(&pre, e->tev[0], e->tev[1]) == hipSuccess &&
+        hipEventElapsedTime(&sc, e->tev[1], e->tev[2]) == hipSuccess) {
+      e->st.last_prepass_ms = pre;
+      e->st.last_score_ms = sc;
+    }
+    e->timing_pending = false;
+  }
   *out = e->st;
   return DDT_OK;
 }
@@ -626,6 +816,10 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
       if (rc) return rc;
       e->loaded = true;
     }
+    return DDT_OK;
+  }
+  if (!strcmp(key, "kernel_timing")) {
+    e->kernel_timing = value != 0;
     return DDT_OK;
   }
   if (!strcmp(key, "feeder_rows")) {

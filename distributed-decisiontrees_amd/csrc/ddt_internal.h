@@ -39,9 +39,22 @@ struct ScoreArgs {
   uint32_t miss_key;       // what a missing feature looks like inside LDS (== miss_raw for cmp_mode 0)
   uint32_t ieee;           // 1: stage features through the IEEE order-preserving key transform
   uint32_t sum_mode;       // 0 reference-order fp32, 1 fp64 sequential
+  const void* aux;         // kind-specific extras (Q16Aux for the rank-quantised path), else NULL
+  hipEvent_t ev_mid;       // optional ("kernel_timing"): recorded right before the scoring kernel proper
 };
 
-enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2 };
+struct Q16Aux {               // device pointers of the rank-quantised path (ScoreArgs::aux)
+  uint32_t* xT;               // workspace [W][n_pad]: transposed tuples
+  uint16_t* q;                // workspace [tiles][W][1024]: feature ranks
+  uint32_t* tile_flags;       // workspace [tiles]: 1 = the tile holds a missing value
+  const uint32_t* tables;     // [W][Kpad] sorted distinct threshold keys per feature, padded with INT_MAX
+  const uint32_t* tabK;       // [W] real table lengths
+  uint32_t Kpad;              // power of two > max table length
+  const uint4* img_slow;      // image with the miss_right flags (used by tiles that contain a missing value)
+  uint64_t n_pad;             // rows rounded up to whole tiles of 1024
+};
+
+enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2, kKindQ16 = 3 };
 
 struct Variant {
   const char* name;
@@ -76,6 +89,10 @@ struct Variant {
   uint32_t lds_bytes_stream(uint32_t n_trees_padded, uint32_t tuple_words) const {
     return feat_off_stream(n_trees_padded) + tuple_words * row_bytes() + 64u;
   }
+  // ---- q16 kernels: 4-byte node records + fp32 leaves = 8*2^D bytes per tree; u16 feature tile ----
+  uint32_t tree_bytes_q16() const { return 8u << levels; }
+  uint32_t feat_off_q16() const { return 2u * tree_bytes_q16() * (uint32_t)chunk_trees; }
+  uint32_t lds_bytes_q16(uint32_t tuple_words) const { return feat_off_q16() + tuple_words * tile() * 2u; }
 };
 
 int num_variants();

@@ -508,6 +508,216 @@ static hipError_t launch_stream(const ScoreArgs& a, const Variant& v, hipStream_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The rank-quantised path ("q16").  A node test only needs the ORDER of x[fidx] relative to the node's
+// threshold, so a feature can be replaced EXACTLY by its rank among the sorted distinct thresholds the model
+// uses on that feature:  r(x) = #{t_k <= x},  node rank R = k + 1  =>  !(x < t_k)  <=>  r(x) >= R.
+// Ranks fit 16 bits (the engine falls back to the fp32 kernels otherwise), which halves the feature tile
+// (64 KiB per 1024 tuples) and the node records (4 bytes {R, row offset}): two 1024-thread blocks fit a CU,
+// 32 waves instead of 16 -- the occupancy the fp32 tile cannot reach (measured +30 % node-visits/s).
+// Three launches per batch:
+//   transpose_kernel  tuples [n][W] fp32  ->  xT [W][n_pad]                           (HBM streaming)
+//   rank_kernel       per feature: threshold table in LDS, branch-free binary search  ->  q [tile][W][1024] u16,
+//                     missing -> 0xFFFF and tile_flags[tile] = 1
+//   score_q16_kernel  the walk over u16 ranks; the tile arrives by global->LDS DMA, no transpose needed
+// ---------------------------------------------------------------------------------------------------
+constexpr int kQTile = 1024;        // tuples per q tile == threads per scoring block
+constexpr uint32_t kQMissing = 0xFFFFu;
+
+__global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restrict__ tuples, uint32_t W, uint64_t n,
+                                                        uint64_t n_pad, uint32_t* __restrict__ xT) {
+  // 256 rows per block through LDS [256][W+1] (odd stride: conflict-free column reads)
+  const uint32_t tid = threadIdx.x, S = W + 1u;
+  const uint64_t row0 = (uint64_t)blockIdx.x * 256u;
+  const uint32_t rows = (uint32_t)((n - row0) < 256u ? (n - row0) : 256u);
+  const uint4* src = reinterpret_cast<const uint4*>(tuples + row0 * W);
+  const uint32_t LPT = W / 4u;  // 16-byte lines per tuple (<= 8 on this path)
+  uint4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // all loads first (coalesced, independent), then the LDS scatter
+    const uint32_t e = tid + (uint32_t)i * 256u;
+    v[i] = ((uint32_t)i < LPT && e / LPT < rows) ? src[e] : make_uint4(0u, 0u, 0u, 0u);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if ((uint32_t)i < LPT) {
+      const uint32_t e = tid + (uint32_t)i * 256u, r = e / LPT, c = (e - r * LPT) * 4u;
+      lds_st_u32((r * S + c + 0u) * 4u, v[i].x);
+      lds_st_u32((r * S + c + 1u) * 4u, v[i].y);
+      lds_st_u32((r * S + c + 2u) * 4u, v[i].z);
+      lds_st_u32((r * S + c + 3u) * 4u, v[i].w);
+    }
+  }
+  __syncthreads();
+  for (uint32_t c = 0; c < W; ++c) xT[(uint64_t)c * n_pad + row0 + tid] = lds_u32((tid * S + c) * 4u);
+}
+
+constexpr uint32_t kRankThreads = 1024;  // two blocks per CU share the LDS with their tables: 32 waves x 4 searches each
+__global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __restrict__ xT, uint64_t n, uint64_t n_pad,
+                                                   const uint32_t* __restrict__ tables, uint32_t Kpad,
+                                                   const uint32_t* __restrict__ tabK, uint32_t miss_raw, uint32_t ieee,
+                                                   uint32_t W, uint16_t* __restrict__ q, uint32_t* __restrict__ tile_flags) {
+  const uint32_t j = blockIdx.y, tid = threadIdx.x;
+  // The probes of a power-of-two binary search are all = step-1 (mod step): with a linear table every probe of
+  // the first log2(Kpad)-5 steps lands in ONE bank (measured: 23.6 conflict cycles per DS op, LDS pipe 97 % busy).
+  // Entry i is therefore stored at i + i/32: one padding word per 32 entries rotates the bank per segment.
+  for (uint32_t i = tid; i < Kpad; i += kRankThreads) lds_st_u32((i + (i >> 5)) * 4u, tables[(size_t)j * Kpad + i]);
+  __syncthreads();
+  const uint32_t K = tabK[j];
+  constexpr int ILP = 4;  // independent searches per lane: the 13-15 dependent LDS reads of one search are latency bound
+  const uint64_t stride = (uint64_t)gridDim.x * kRankThreads * ILP;
+  for (uint64_t row0 = (uint64_t)blockIdx.x * kRankThreads * ILP + tid; row0 < n_pad; row0 += stride) {
+    uint32_t raw[ILP], pos[ILP];
+    int32_t x[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) {
+      const uint64_t row = row0 + (uint64_t)i * kRankThreads;
+      raw[i] = row < n_pad ? xT[(uint64_t)j * n_pad + row] : 0u;
+      x[i] = (int32_t)(ieee ? ieee_key(raw[i]) : raw[i]);
+      pos[i] = 0;
+    }
+    for (uint32_t step = Kpad >> 1; step >= 1u; step >>= 1) {  // table padded with INT_MAX up to Kpad
+#pragma unroll
+      for (int i = 0; i < ILP; ++i) {
+        const uint32_t probe = pos[i] + step - 1u;
+        if ((int32_t)lds_u32((probe + (probe >> 5)) * 4u) <= x[i]) pos[i] += step;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) {
+      const uint64_t row = row0 + (uint64_t)i * kRankThreads;
+      if (row >= n_pad) continue;
+      uint32_t r = pos[i] < K ? pos[i] : K;
+      if (raw[i] == miss_raw && row < n) {  // bit equality with the missing pattern (DTPU.sv:653), before any transform
+        r = kQMissing;
+        atomicOr(&tile_flags[row / kQTile], 1u);
+      }
+      // within a feature row, tuple t sits in dword (t % 512), half (t / 512): the 64 lanes of a wave then read 64
+      // DIFFERENT dwords (two lanes sharing one dword at different byte addresses would 2-way bank-conflict)
+      const uint32_t t = (uint32_t)(row % kQTile);
+      q[((row / kQTile) * W + j) * (uint64_t)kQTile + (2u * (t & 511u) + (t >> 9))] = (uint16_t)r;
+    }
+  }
+}
+
+// walk over 4-byte records {R (lo16), feature row byte offset (hi16, bit 16 = miss_right in the slow image)};
+// m4 = 4 * (1-based heap index); leaves start at byte 4*2^D of the tree, so leaf address = tree + m4.
+template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW>
+__device__ __forceinline__ void walk_trees_q16(const uint32_t base, const uint32_t lane2, float (&leaf)[U]) {
+  uint32_t m4[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) m4[u] = 4u;
+#pragma unroll
+  for (int lvl = 0; lvl < D; ++lvl) {
+    uint32_t nd[U], f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) nd[u] = lds_u32(m4[u] + (base + (uint32_t)(u * TREE_BYTES)));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t off = SLOW ? ((nd[u] >> 16) & 0xFFFEu) : (nd[u] >> 16);
+      // ds_read_u16 with FEAT_OFF as the DS immediate; conflict-free (bank = lane/2, two lanes share a dword)
+      f[u] = *reinterpret_cast<const DDT_LDS(uint16_t)*>((off | lane2) + (uint32_t)FEAT_OFF);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bool right = f[u] >= (nd[u] & 0xFFFFu);
+      if (SLOW) right = (f[u] == kQMissing) ? ((nd[u] >> 16) & 1u) != 0u : right;
+      m4[u] = (m4[u] << 1) + (right ? 4u : 0u);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) leaf[u] = lds_f32(m4[u] + (base + (uint32_t)(u * TREE_BYTES)));
+}
+
+template <int D, int CT, int U>
+__global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, const Q16Aux x) {
+  constexpr int THREADS = kQTile;
+  constexpr int TREE_BYTES = 8 << D;
+  constexpr int CHUNK_BYTES = TREE_BYTES * CT;
+  constexpr int FEAT_OFF = 2 * CHUNK_BYTES;
+  constexpr int ROW = kQTile * 2;
+  static_assert(CT % U == 0 && (U == 4 || U == 8) && (CT == 4 || CT % 8 == 0), "geometry");
+  static_assert(FEAT_OFF % ROW == 0, "row|lane OR trick");
+  const int tid = threadIdx.x;
+  const uint64_t tile = blockIdx.x, tile0 = tile * kQTile;
+  const uint32_t W = a.tuple_words, n_chunks = a.n_chunks;
+  const bool slow = x.tile_flags[tile] != 0u;  // block-uniform
+  const uint4* img = slow ? x.img_slow : a.img;
+
+  dma_chunk<THREADS, CHUNK_BYTES>(img, 0, 0, tid);
+  {  // the whole feature tile is one contiguous block of W*2048 bytes: DMA it in
+    const uint4* src = reinterpret_cast<const uint4*>(x.q + tile * (uint64_t)W * kQTile);
+    const uint32_t units = W * (ROW / 16);
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    for (uint32_t u0 = 0; u0 < units; u0 += THREADS) {
+      const uint32_t lds_addr = (uint32_t)FEAT_OFF + (u0 + (uint32_t)wave_base) * 16u;
+      const uint4* g = src + (u0 + (uint32_t)tid);
+      if (u0 + (uint32_t)wave_base < units)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
+    }
+  }
+  RefAcc<1> ra;
+  ra.init();
+  double dacc[1] = {0.0};
+  const uint32_t C = a.clusters, lane2 = (((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1);  // see rank_kernel
+  const int SUM1 = (int)a.sum_mode;
+
+#define DDT_QCOMPUTE(BUF, PH)                                                                          \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int sg = 0; sg < CT / U; ++sg) {                                            \
+      float lf[1][U];                                                                                  \
+      if (!slow) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0]); \
+      else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0]);        \
+      if (SUM1 == 0) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc);                           \
+      else fold_leaves<U, 1, 1>(lf, ((PH) + sg) & 1, C, ra, dacc);                                     \
+    }                                                                                                  \
+  } while (0)
+
+  constexpr int PH1 = (CT == 4) ? 1 : 0;
+  for (uint32_t k = 0; k < n_chunks; k += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool more1 = k + 1 < n_chunks;
+    if (more1) dma_chunk<THREADS, CHUNK_BYTES>(img, k + 1, CHUNK_BYTES, tid);
+    DDT_QCOMPUTE(0, 0);
+    if (!more1) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k + 2 < n_chunks) dma_chunk<THREADS, CHUNK_BYTES>(img, k + 2, 0, tid);
+    DDT_QCOMPUTE(1, PH1);
+  }
+#undef DDT_QCOMPUTE
+  ra.align(C);
+  const uint64_t row = tile0 + (uint64_t)tid;
+  if (row < a.n) a.out[row] = (SUM1 == 0) ? ra.total(0, C) : (float)dacc[0];
+}
+
+template <int D, int CT, int U>
+static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s) {
+  const Q16Aux& x = *reinterpret_cast<const Q16Aux*>(a.aux);
+  const uint64_t tiles = (a.n + kQTile - 1) / kQTile;
+  if (tiles == 0) return hipSuccess;
+  if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  const uint32_t W = a.tuple_words;
+  auto kern = score_q16_kernel<D, CT, U>;
+  const uint32_t lds = v.lds_bytes_q16(W);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const uint32_t rank_lds = (x.Kpad + (x.Kpad >> 5) + 1u) * 4u;  // skewed table, see rank_kernel
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(x.tile_flags, 0, tiles * 4, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
+  uint32_t bx = (uint32_t)((x.n_pad + kRankThreads * 4 - 1) / (kRankThreads * 4));  // kRankThreads x 4 rows each per pass
+  if (bx > 512u) bx = 512u;  // grid-stride over rows; blockIdx.y = feature (the table is loaded once per block)
+  hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabK, a.miss_raw,
+                     a.ieee, W, x.q, x.tile_flags);
+  if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
+  hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kQTile), lds, s, a, x);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // generic kernel: any D (1..16), any F (1..2048).  Lane = tuple, 256 tuples per block, one tree at a
 // time.  Features in LDS when the tile fits, else gathered from global memory; tree in LDS when it
 // fits (12*2^D bytes), else nodes are read from global memory (L2).  Correctness path for shapes the
@@ -697,8 +907,15 @@ hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t 
 #define DDT_S(NAME, D, U, MAXLPT) \
   Variant { NAME, kKindStream, D, kStreamThreads, 1, 8, U, 0, MAXLPT, &launch_stream<D, U, MAXLPT> }
 
+#define DDT_Q(NAME, D, CT, U) \
+  Variant { NAME, kKindQ16, D, kQTile, 1, CT, U, 1, 0, &launch_q16<D, CT, U> }
+
 static const Variant g_variants[] = {
     Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_generic},
+    // rank-quantised u16 path: 2 blocks x 1024 threads per CU
+    DDT_Q("q16_d8_c4_u4", 8, 4, 4),
+    DDT_Q("q16_d6_c16_u4", 6, 16, 4),
+    DDT_Q("q16_d4_c64_u8", 4, 64, 8),
     // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB.  suffix _f = last level fused with its leaves
     DDT_V("d8_t1024_r1_c4_u4_dma_f", 8, 1024, 1, 4, 4, 1, 1),
     DDT_V("d8_t1024_r1_c4_u4_dma", 8, 1024, 1, 4, 4, 1, 0),

@@ -46,6 +46,7 @@ class Stats(C.Structure):
         ("tuples_in", C.c_uint64), ("tuples_out", C.c_uint64), ("tuple_lines_in", C.c_uint64),
         ("result_lines_out", C.c_uint64), ("model_lines_in", C.c_uint64), ("score_calls", C.c_uint64),
         ("kernel_launches", C.c_uint64), ("prog_ms", C.c_double), ("exec_ms", C.c_double),
+        ("last_prepass_ms", C.c_double), ("last_score_ms", C.c_double),
     ]
 
 
