@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--levels", type=int, default=8)
     ap.add_argument("--features", type=int, default=32)
     ap.add_argument("--combine", default="allreduce", choices=["allreduce", "chain"])
+    ap.add_argument("--shard", default="trees", choices=["trees", "rows"],
+                    help="N>1: 'trees' = the headline mode (ensemble sharded tree-wise, partial scores all-reduced); "
+                         "'rows' = the reference's other mode (replicated ensemble, tuples partitioned, scores all-gathered)")
     ap.add_argument("--chunk-rows", type=int, default=12_500_000, help="rows per pipelined collective (N>1)")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant id (-1 = engine's choice)")
     ap.add_argument("--sum-mode", type=int, default=0)
@@ -79,12 +82,16 @@ def main():
     eng.set_option("variant", args.variant)
     w, f = ddt.synth_model(T, D, F, 0)
     params = ddt.make_params(T, D, F, sum_mode=args.sum_mode)
-    eng.load_model(params, w, f, rank, world)
+    rows_mode = world > 1 and args.shard == "rows"
+    eng.load_model(params, w, f, 0 if rows_mode else rank, 1 if rows_mode else world)
     info = eng.info()
 
     tuples = eng.synth_tuples_device(0, N, F, 0)          # resident in HBM before the timed region
     out = torch.empty(N, dtype=torch.float32, device=tuples.device)
-    scorer = ddt.ShardedScorer.from_engine(eng, mode=args.combine, chunk_rows=args.chunk_rows) if world > 1 else None
+    scorer = None
+    if world > 1:
+        scorer = (ddt.RowShardedScorer(eng) if rows_mode else
+                  ddt.ShardedScorer.from_engine(eng, mode=args.combine, chunk_rows=args.chunk_rows))
 
     # per-launch HIP-event times of the pass, taken by the library on the launch stream ("kernel_timing"):
     # pre-pass kernels (rank-quantised path only) and the scoring kernel proper
@@ -179,8 +186,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{T} trees x depth {D} x {F} fp32 features, {N} tuples/step, "
-                                   + ("single engine" if world == 1 else f"tree-sharded {world}x + RCCL {args.combine}"),
-                       "trees": T, "levels": D, "features": F, "rows": N, "parallelism": f"tree-shard{world}",
+                                   + ("single engine" if world == 1 else
+                                      f"row-sharded {world}x (replicas) + RCCL all-gather" if rows_mode else
+                                      f"tree-sharded {world}x + RCCL {args.combine}"),
+                       "trees": T, "levels": D, "features": F, "rows": N, "parallelism": f"row-shard{world}" if rows_mode else f"tree-shard{world}",
                        "combine": args.combine if world > 1 else None,
                        "collective_backend": (args.backend if world > 1 else None), "kernel": info.variant_name.decode(),
                        "sum_mode": "reference-order fp32" if args.sum_mode == 0 else "fp64 accumulate",

@@ -328,14 +328,20 @@ __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) 
     const uint64_t row = tile0 + col;
     const bool valid = row < a.n;
     const uint4* src = reinterpret_cast<const uint4*>(a.tuples + row * W);
-#pragma unroll 4
-    for (uint32_t q = 0; q < W / 4; ++q) {
-      uint4 v = valid ? src[q] : make_uint4(0u, 0u, 0u, 0u);
-      const uint32_t fa = (uint32_t)FEAT_OFF + (4u * q) * (uint32_t)ROW + col * 4u;
-      lds_st_u32(fa + 0 * ROW, stage_word(v.x, a, miss_any, valid));
-      lds_st_u32(fa + 1 * ROW, stage_word(v.y, a, miss_any, valid));
-      lds_st_u32(fa + 2 * ROW, stage_word(v.z, a, miss_any, valid));
-      lds_st_u32(fa + 3 * ROW, stage_word(v.w, a, miss_any, valid));
+    for (uint32_t q0 = 0; q0 < W / 4; q0 += 8) {  // 8 independent 16-byte loads in flight, then the LDS scatter:
+      uint4 v[8];                                 // one HBM round trip per 32 features instead of one per 16
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (valid && q0 + i < W / 4) ? src[q0 + i] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (q0 + i < W / 4) {
+          const uint32_t fa = (uint32_t)FEAT_OFF + (4u * (q0 + i)) * (uint32_t)ROW + col * 4u;
+          lds_st_u32(fa + 0 * ROW, stage_word(v[i].x, a, miss_any, valid));
+          lds_st_u32(fa + 1 * ROW, stage_word(v[i].y, a, miss_any, valid));
+          lds_st_u32(fa + 2 * ROW, stage_word(v[i].z, a, miss_any, valid));
+          lds_st_u32(fa + 3 * ROW, stage_word(v[i].w, a, miss_any, valid));
+        }
+      }
     }
   }
   if (STAGE == 0) sr.commit(MB, tid);

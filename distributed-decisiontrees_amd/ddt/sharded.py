@@ -27,6 +27,49 @@ def shard_bounds(T: int, G: int):
     return [(min(g * per, T), min((g + 1) * per, T)) for g in range(G)]
 
 
+class RowShardedScorer:
+    """The reference's OTHER multi-device mode (rtl/DTEngine/DTInference.sv:28-37, PCIeReceiver.sv:289-312): every
+    device holds the whole ensemble, the tuples are partitioned, results are interleaved -- "replicas only", no
+    arithmetic crosses devices.  Rank r scores rows [r*ceil(n/G), ...) and an all-gather gives every rank the full
+    score vector (skip it with gather=False to leave the scores sharded).  Each engine must hold ALL trees."""
+
+    def __init__(self, engine, group=None, gather: bool = True):
+        import torch.distributed as dist
+
+        self.engine, self.group, self.gather = engine, group, gather
+        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.gloo = dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+    def score(self, tuples, out=None):
+        import torch
+        import torch.distributed as dist
+
+        from .engine import tuple_words
+
+        W = tuple_words(self.engine.params.num_features)
+        n = tuples.numel() // W
+        tuples = tuples.reshape(n, W)
+        per = (n + self.G - 1) // self.G
+        lo, hi = min(self.rank * per, n), min((self.rank + 1) * per, n)
+        full = torch.zeros(self.G * per, dtype=torch.float32, device=tuples.device)
+        mine = full[self.rank * per: self.rank * per + per]
+        if hi > lo:
+            self.engine.score_device(tuples[lo:hi], out=mine[: hi - lo])
+        if self.G > 1 and self.gather:
+            if self.gloo and full.is_cuda:
+                h = torch.empty(self.G * per, dtype=torch.float32)
+                dist.all_gather_into_tensor(h, mine.cpu().contiguous(), group=self.group)
+                full.copy_(h)
+            else:
+                dist.all_gather_into_tensor(full, mine.clone(), group=self.group)
+        res = full[:n]
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+
 def chain_sum(parts):
     """parts [G, n] (torch, any device) -> (((p0 + p1) + p2) + ...), fp32, the reference's hop order."""
     run = parts[0].clone()
