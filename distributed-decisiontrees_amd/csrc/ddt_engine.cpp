@@ -176,7 +176,8 @@ uint32_t thr_key(const ddt_params& p, uint32_t bits) {
 
 uint32_t padded_trees(const Variant& v, uint32_t T) {
   const bool chunked = v.kind == kKindTile || v.kind == kKindQ16;
-  const uint32_t granule = (chunked && v.chunk_trees > 8) ? (uint32_t)v.chunk_trees : 8u;
+  uint32_t granule = (chunked && v.chunk_trees > 8) ? (uint32_t)v.chunk_trees : 8u;
+  if (v.kind == kKindTile && (v.opt & 2) && granule < 2u * (uint32_t)v.chunk_trees) granule = 2u * (uint32_t)v.chunk_trees;  // even chunk count
   return (T + granule - 1u) / granule * granule;  // whole PU groups of 8 (and whole chunks)
 }
 
@@ -216,6 +217,7 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
   }
   if (v.kind == kKindStream)
     return W <= 4u * (uint32_t)v.opt && v.lds_bytes_stream(padded_trees(v, max_trees(e)), W) <= kStreamLdsBudget;
+  if ((v.opt & 2) && W > 32u) return false;  // persistent form prefetches at most 8 lines per tuple
   return v.lds_bytes(W) <= kMaxLdsBytes;
 }
 

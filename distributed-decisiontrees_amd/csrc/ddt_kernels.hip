@@ -279,6 +279,34 @@ __device__ __forceinline__ bool block_any(uint32_t flag, uint32_t flags_addr, in
   return __builtin_amdgcn_readfirstlane(any) != 0u;
 }
 
+// 4x4 transpose inside a lane quad: in: lane t holds v[j] = element (row j, column t); out: v[i] = (row t, column i).
+// Two butterfly stages (partner lane t^1, then t^2) through DPP quad_perm moves; no LDS traffic.
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t dpp_xor2(uint32_t x) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true); }
+__device__ __forceinline__ void quad_transpose(u32x4 (&v)[4], uint32_t t) {
+  const bool odd = (t & 1u) != 0u, hi = (t & 2u) != 0u;
+#pragma unroll
+  for (int p = 0; p < 4; p += 2) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t x = v[p][c], y = v[p + 1][c];
+      const uint32_t px = dpp_xor1(x), py = dpp_xor1(y);  // cross-lane reads with every lane active, THEN select
+      v[p][c] = odd ? py : x;
+      v[p + 1][c] = odd ? y : px;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t x = v[p][c], z = v[p + 2][c];
+      const uint32_t px = dpp_xor2(x), pz = dpp_xor2(z);
+      v[p][c] = hi ? pz : x;
+      v[p + 2][c] = hi ? z : px;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the tile kernel (model streamed through LDS)
 // ---------------------------------------------------------------------------------------------------
@@ -327,19 +355,38 @@ __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) 
     lane_off[r] = col * 4u;
     const uint64_t row = tile0 + col;
     const bool valid = row < a.n;
-    const uint4* src = reinterpret_cast<const uint4*>(a.tuples + row * W);
-    for (uint32_t q0 = 0; q0 < W / 4; q0 += 8) {  // 8 independent 16-byte loads in flight, then the LDS scatter:
-      uint4 v[8];                                 // one HBM round trip per 32 features instead of one per 16
+    // Quad-coalesced loads: the four lanes of a quad read 64 contiguous bytes (lines 4g..4g+3) of ONE row per
+    // instruction, rows quad_base+0..3 over four instructions, and a 4x4 transpose inside the quad (DPP) hands
+    // every lane the four lines of its own row.  One-row-per-lane loads touch 64 cache lines per instruction
+    // (8192 L1 accesses per 1024x32 tile, ~7.8 us per tile exposed: profiles/r01_tile_overhead.md); this is 16.
+    const uint32_t t4 = (uint32_t)tid & 3u;
+    const uint64_t quad_row = tile0 + (uint64_t)(col & ~3u);
+    const uint32_t lpt = W / 4u;
+    for (uint32_t g0 = 0; g0 < lpt; g0 += 8) {  // two groups of four lines = 8 independent 16-byte loads in flight
+      u32x4 v[2][4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (valid && q0 + i < W / 4) ? src[q0 + i] : make_uint4(0u, 0u, 0u, 0u);
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t line = g0 + 4u * h + t4;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (q0 + i < W / 4) {
-          const uint32_t fa = (uint32_t)FEAT_OFF + (4u * (q0 + i)) * (uint32_t)ROW + col * 4u;
-          lds_st_u32(fa + 0 * ROW, stage_word(v[i].x, a, miss_any, valid));
-          lds_st_u32(fa + 1 * ROW, stage_word(v[i].y, a, miss_any, valid));
-          lds_st_u32(fa + 2 * ROW, stage_word(v[i].z, a, miss_any, valid));
-          lds_st_u32(fa + 3 * ROW, stage_word(v[i].w, a, miss_any, valid));
+        for (int j = 0; j < 4; ++j) {
+          const uint64_t rj = quad_row + (uint64_t)j;
+          v[h][j] = (rj < a.n && line < lpt) ? *reinterpret_cast<const u32x4*>(a.tuples + rj * W + 4u * line)
+                                             : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        quad_transpose(v[h], t4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t line = g0 + 4u * h + (uint32_t)i;
+          if (line < lpt) {
+            const uint32_t fa = (uint32_t)FEAT_OFF + (4u * line) * (uint32_t)ROW + col * 4u;
+            lds_st_u32(fa + 0 * ROW, stage_word(v[h][i].x, a, miss_any, valid));
+            lds_st_u32(fa + 1 * ROW, stage_word(v[h][i].y, a, miss_any, valid));
+            lds_st_u32(fa + 2 * ROW, stage_word(v[h][i].z, a, miss_any, valid));
+            lds_st_u32(fa + 3 * ROW, stage_word(v[h][i].w, a, miss_any, valid));
+          }
         }
       }
     }
@@ -410,6 +457,153 @@ static hipError_t launch_tile(const ScoreArgs& a, const Variant& v, hipStream_t 
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(THREADS), lds, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// persistent form of the tile kernel (Variant::opt bit 1, suffix _p): one block per CU walks the tiles with a
+// grid stride; the model chunks stream through the two LDS buffers as ONE continuous ring across tiles (the
+// chunk count is even, so chunk 0 of the next tile always lands in buffer 0), and the next tile's tuples are
+// loaded into registers while the current tile is being scored.  What the plain form pays per tile is pure
+// latency (profiles/r01_tile_overhead.md): with one block per CU all 16 waves sit in the tuple-load phase
+// together, then wait for the first model chunk.  VMEM issue order per tile and the waits that go with it:
+//   stage `pre` (already transposed) -> LDS | DMA(1) | PF x8 (next tile) | compute(0)
+//   B(k=0): vmcnt(8)  -> DMA(1) landed, the prefetch may still fly       | DMA(2) | compute(1)
+//   k >= 2: vmcnt(0) at both barriers; the last B issues DMA(0) of the NEXT tile
+//   tile end: transpose `pre` (hipcc waits for the prefetch there) | store the scores
+// The prefetch loads are ordinary loads, always exactly 8 per wave (clamped addresses, no predication), so
+// the counted wait is exact; the DMA is invisible to hipcc, so hipcc's own waits can only over-wait.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPrefetchLines = 8;  // W <= 32 words
+
+// lane t of a quad takes line 4h+t of rows quad_row+0..3 (see the staging comment in score_tile_kernel);
+// rows past the end and lines past the tuple re-read the last valid one (never staged / never stored)
+__device__ __forceinline__ void prefetch_tile(u32x4 (&pre)[2][4], const uint32_t* tuples, uint64_t quad_row, uint64_t n,
+                                              uint32_t W, uint32_t lpt, uint32_t t4) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t line = 4u * h + t4 < lpt ? 4u * h + t4 : lpt - 1u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t rj = quad_row + (uint64_t)j < n ? quad_row + (uint64_t)j : n - 1u;
+      pre[h][j] = *reinterpret_cast<const u32x4*>(tuples + rj * W + 4u * line);
+    }
+  }
+}
+
+template <int D, int THREADS, int CT, int U, int OPT>
+__global__ __launch_bounds__(THREADS) void score_tile_persist_kernel(const ScoreArgs a) {
+  constexpr int R = 1;
+  constexpr int TILE = THREADS;
+  constexpr int TREE_BYTES = 12 << D;
+  constexpr int CHUNK_BYTES = TREE_BYTES * CT;
+  constexpr int ROW = TILE * 4;
+  constexpr bool FUSED = (OPT & 1) != 0;
+  constexpr int MB = FUSED ? (4 << D) : 0;
+  constexpr int FEAT_OFF = (MB + 2 * CHUNK_BYTES + ROW - 1) / ROW * ROW;
+  static_assert((ROW & (ROW - 1)) == 0, "tile must be a power of two");
+  static_assert(CT == 4 || CT % 8 == 0, "chunk = half a PU group or whole groups");
+  static_assert(CT != 4 || U == 4, "CT=4 needs U=4");
+
+  const int tid = threadIdx.x;
+  const uint32_t n_chunks = a.n_chunks, W = a.tuple_words, lpt = W / 4u;  // n_chunks is even (launch_tile_persist)
+  const uint64_t n_tiles = (a.n + TILE - 1) / TILE;
+  const uint32_t lane_off[R] = {(uint32_t)tid * 4u};
+  const uint32_t C = a.clusters, miss_key = a.miss_key;
+  const int SUM1 = (int)a.sum_mode;
+  const uint32_t t4 = (uint32_t)tid & 3u;
+  const uint32_t quad_col = (uint32_t)tid & ~3u;
+
+  u32x4 pre[2][4];
+  uint64_t tile = blockIdx.x;
+  prefetch_tile(pre, a.tuples, tile * TILE + quad_col, a.n, W, lpt, t4);
+  dma_chunk<THREADS, CHUNK_BYTES>(a.img, 0, MB, tid);
+  quad_transpose(pre[0], t4);
+  quad_transpose(pre[1], t4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile only: this wave's share of chunk 0
+
+  for (;;) {
+    const uint64_t row = tile * TILE + (uint64_t)tid;
+    const bool valid = row < a.n;
+    const uint64_t next = tile + gridDim.x;
+    const bool has_next = next < n_tiles;
+
+    __syncthreads();  // every wave is done with the previous tile (feature tile, buffer 1) and chunk 0 is in buffer 0
+    uint32_t miss_any = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t line = 4u * h + (uint32_t)i;
+        if (line < lpt) {
+          const uint32_t fa = (uint32_t)FEAT_OFF + (4u * line) * (uint32_t)ROW + (uint32_t)tid * 4u;
+          lds_st_u32(fa + 0 * ROW, stage_word(pre[h][i].x, a, miss_any, valid));
+          lds_st_u32(fa + 1 * ROW, stage_word(pre[h][i].y, a, miss_any, valid));
+          lds_st_u32(fa + 2 * ROW, stage_word(pre[h][i].z, a, miss_any, valid));
+          lds_st_u32(fa + 3 * ROW, stage_word(pre[h][i].w, a, miss_any, valid));
+        }
+      }
+    }
+    const bool slow = block_any<THREADS>(miss_any, (uint32_t)FEAT_OFF + W * (uint32_t)ROW, tid);  // barrier inside
+
+    dma_chunk<THREADS, CHUNK_BYTES>(a.img, 1, MB + CHUNK_BYTES, tid);
+    // next tile's tuples -> registers (the last tile re-reads itself: keeps the VMEM count uniform)
+    prefetch_tile(pre, a.tuples, (has_next ? next : tile) * TILE + quad_col, a.n, W, lpt, t4);
+
+    RefAcc<R> ra;
+    ra.init();
+    double dacc[R] = {0.0};
+
+#define DDT_COMPUTE(BUF, PH)                                                                                          \
+  do {                                                                                                                \
+    if (SUM1 == 0) {                                                                                                  \
+      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 0, FUSED>(lane_off, miss_key, C, ra, dacc); \
+      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 0, FUSED>(lane_off, miss_key, C, ra, dacc);        \
+    } else {                                                                                                          \
+      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 1, FUSED>(lane_off, miss_key, C, ra, dacc); \
+      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 1, FUSED>(lane_off, miss_key, C, ra, dacc);        \
+    }                                                                                                                 \
+  } while (0)
+
+    constexpr int PH1 = (CT == 4) ? 1 : 0;
+    for (uint32_t k = 0; k < n_chunks; k += 2) {
+      if (k != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // chunk k is in buffer 0 for everyone; everyone is done with buffer 1
+        dma_chunk<THREADS, CHUNK_BYTES>(a.img, k + 1, MB + CHUNK_BYTES, tid);
+      }
+      DDT_COMPUTE(0, 0);
+      if (k == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // chunk k+1 is in buffer 1; everyone is done with buffer 0
+      dma_chunk<THREADS, CHUNK_BYTES>(a.img, k + 2 < n_chunks ? k + 2 : 0u, MB, tid);  // wraps to the next tile's chunk 0
+      DDT_COMPUTE(1, PH1);
+    }
+#undef DDT_COMPUTE
+
+    ra.align(C);
+    quad_transpose(pre[0], t4);  // hipcc's wait for the prefetch sits here, before the store goes out
+    quad_transpose(pre[1], t4);
+    if (valid) a.out[row] = (SUM1 == 0) ? ra.total(0, C) : (float)dacc[0];
+    if (!has_next) break;
+    tile = next;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wrapped DMA of the last tile must not outlive the wave
+}
+
+template <int D, int THREADS, int R, int CT, int U, int STAGE, int OPT>
+static hipError_t launch_tile_persist(const ScoreArgs& a, const Variant& v, hipStream_t s) {
+  static_assert(R == 1 && STAGE == 1, "persistent form: one tuple per lane, DMA staging");
+  if (a.tuple_words > 4u * kPrefetchLines || (a.n_chunks & 1u) || a.n == 0) return a.n == 0 ? hipSuccess : hipErrorInvalidValue;
+  auto kern = score_tile_persist_kernel<D, THREADS, CT, U, OPT>;
+  const uint32_t lds = v.lds_bytes(a.tuple_words);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const uint64_t tiles = (a.n + THREADS - 1) / THREADS;
+  if (tiles == 0) return hipSuccess;
+  uint64_t grid = 256ull * (lds <= 80u * 1024u ? 2u : 1u);  // resident blocks: CUs x blocks per CU
+  if (grid > tiles) grid = tiles;
+  hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(THREADS), lds, s, a);
   return hipGetLastError();
 }
 
@@ -678,6 +872,9 @@ __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, co
     }                                                                                                  \
   } while (0)
 
+  // (tried: levels 0-1 from SGPRs via hidden s_load_dwordx4 of the next chunk's top records -- 15 DS ops per tree
+  // instead of 17 -- measured 4 % SLOWER, 134.0 vs 128.7 ms per 100 M x 1000 trees: the outstanding scalar loads
+  // inflate lgkmcnt, so every LDS wait of the wave stalls until they return.  profiles/r01_experiments.md)
   constexpr int PH1 = (CT == 4) ? 1 : 0;
   for (uint32_t k = 0; k < n_chunks; k += 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -910,6 +1107,8 @@ hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t 
 // ---------------------------------------------------------------------------------------------------
 #define DDT_V(NAME, D, TH, R, CT, U, ST, OPT) \
   Variant { NAME, kKindTile, D, TH, R, CT, U, ST, OPT, &launch_tile<D, TH, R, CT, U, ST, OPT> }
+#define DDT_VP(NAME, D, TH, R, CT, U, ST, OPT) \
+  Variant { NAME, kKindTile, D, TH, R, CT, U, ST, OPT, &launch_tile_persist<D, TH, R, CT, U, ST, OPT> }
 #define DDT_S(NAME, D, U, MAXLPT) \
   Variant { NAME, kKindStream, D, kStreamThreads, 1, 8, U, 0, MAXLPT, &launch_stream<D, U, MAXLPT> }
 
@@ -923,6 +1122,7 @@ static const Variant g_variants[] = {
     DDT_Q("q16_d6_c16_u4", 6, 16, 4),
     DDT_Q("q16_d4_c64_u8", 4, 64, 8),
     // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB.  suffix _f = last level fused with its leaves
+    DDT_VP("d8_t1024_r1_c4_u4_dma_fp", 8, 1024, 1, 4, 4, 1, 3),  // _p = persistent blocks + register prefetch
     DDT_V("d8_t1024_r1_c4_u4_dma_f", 8, 1024, 1, 4, 4, 1, 1),
     DDT_V("d8_t1024_r1_c4_u4_dma", 8, 1024, 1, 4, 4, 1, 0),
     DDT_V("d8_t1024_r1_c4_u4_reg", 8, 1024, 1, 4, 4, 0, 0),

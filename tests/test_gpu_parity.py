@@ -289,3 +289,25 @@ def test_two_ranks_tree_sharded_on_one_gpu(mode):
         p.join(300)
         assert p.exitcode == 0
     assert ret.get(0) and ret.get(1), dict(ret)
+
+
+@pytest.mark.parametrize("T,D,F,dist", [(12, 8, 32, 0), (7, 8, 32, 1), (3, 8, 20, 1), (125, 8, 28, 1), (1, 8, 4, 0)])
+def test_persistent_tile_kernels_walk_many_tiles(eng, T, D, F, dist):
+    """The _p variants keep one block per CU alive and prefetch the next tile's tuples into registers: give
+    every block several tiles (rows > 2 x 256 CUs x 1024) plus a ragged tail, with missing values in some tiles
+    only when dist=1, and compare EVERY row with the oracle."""
+    rows = 2 * 256 * 1024 + 256 * 1024 // 3 + 77
+    m = O.gen_model(T, D, F, dist=dist)
+    x = O.gen_tuples(11, rows, F, dist=0, missing_bits=m.params.missing_bits)
+    if dist:
+        x[5000:9000] = O.gen_tuples(12, 4000, F, dist=1, missing_bits=m.params.missing_bits)
+        x[-3000:] = O.gen_tuples(13, 3000, F, dist=1, missing_bits=m.params.missing_bits)
+    want = O.score(m, x)
+    names = ddt.variant_names()
+    vids = [v for v in _fitting_variants(eng, m) if names[v].endswith("p")]
+    assert vids, "no persistent variant accepted this shape"
+    for v in vids:
+        got = _gpu_score(eng, m, x, 0, v)
+        bad = np.flatnonzero(_bits(got) != _bits(want))
+        assert bad.size == 0, f"{names[v]}: {bad.size} rows differ, first {bad[:5]}"
+    eng.set_option("variant", -1)
