@@ -43,7 +43,8 @@ struct Ensemble {
   // rank-quantised path only: image with miss_right flags, per-feature threshold tables
   void* d_img_slow = nullptr;
   void* d_tables = nullptr;
-  void* d_tabK = nullptr;
+  void* d_tabK = nullptr;   // q16: per-feature search parameters (Q16Aux::tabP)
+  void* d_tabS = nullptr;   // q16: bucket starts (Q16Aux::tabS)
   uint32_t Kpad = 0;
   uint32_t trees() const { return (uint32_t)ids.size(); }
 };
@@ -235,10 +236,10 @@ int auto_variant(const ddt_engine* e) {
                                "d8_t1024_r1_c4_u4_dma_f", "d8_t512_r1_c8_u8_dma_f", "d8_t256_r1_c4_u4_dma",
                                "d6_t1024_r1_c16_u4_dma", "d6_t512_r1_c16_u8_dma", "d6_t256_r1_c16_u4_dma",
                                "d4_t256_r1_c64_u8_dma"};
-  // Rank-quantised path: its scoring kernel is ~1.3x faster (32 waves/CU) but it pays a fixed transpose + rank
-  // pre-pass per tuple (measured 1.22 ms per 8 M tuples vs 9.4 ms of scoring per 1000 depth-8 trees): worth it
-  // from ~450 trees per engine upwards (profiles/r01_q16_*).
-  if (max_trees(e) >= 448u) {
+  // Rank-quantised path: its scoring kernel is ~1.3x faster per tree (32 waves/CU) but it pays a fixed transpose +
+  // rank pre-pass per tuple.  Measured per 100 M tuples (profiles/r01_*): q16 = 10.9 ms + 0.113 ms/tree, fp32 tile =
+  // 3.2 ms + 0.147 ms/tree => break-even near 200 trees per engine; 250 trees (4-way shard of 1000) goes to q16.
+  if (max_trees(e) >= 224u) {
     static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
@@ -254,7 +255,7 @@ int auto_variant(const ddt_engine* e) {
 
 void free_images(ddt_engine* e) {
   for (Ensemble& m : e->ens) {
-    for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK}) {
+    for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
@@ -334,16 +335,45 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m) {
   uint32_t Kpad = 2;
   while (Kpad <= rt.max_len) Kpad <<= 1;  // power of two > max_len: the search reads indices < Kpad - 1
   std::vector<uint32_t> fast, slow, tab, tabK;
+  std::vector<uint16_t> tabS;
   try {
     fast.assign((size_t)Tpad * tree_words, 0u);
     tab.assign((size_t)W * Kpad, 0x7FFFFFFFu);
-    tabK.assign(W, 0u);
+    tabK.assign((size_t)W * 8u, 0u);
+    tabS.assign((size_t)W * kQ16RankBuckets, 0u);
   } catch (const std::bad_alloc&) {
     return fail(e, DDT_ENOMEM, "q16 image allocation failed");
   }
   for (uint32_t j = 0; j < W; ++j) {
-    tabK[j] = (uint32_t)rt.keys[j].size();
-    std::copy(rt.keys[j].begin(), rt.keys[j].end(), tab.begin() + (size_t)j * Kpad);
+    const std::vector<uint32_t>& k = rt.keys[j];
+    const uint32_t K = (uint32_t)k.size();
+    std::copy(k.begin(), k.end(), tab.begin() + (size_t)j * Kpad);
+    // first level of the rank search (rank_kernel): slice the key range into kQ16RankBuckets equal pieces
+    uint32_t* P = tabK.data() + (size_t)j * 8u;
+    uint16_t* S = tabS.data() + (size_t)j * kQ16RankBuckets;
+    P[0] = K;
+    P[1] = P[2] = 0x7FFFFFFFu;  // unused feature: every x is "below lo" -> bucket 0 -> rank 0
+    P[3] = 0u;
+    P[4] = 1u;
+    if (K) {
+      const uint32_t lo = k.front(), hi = k.back(), span = hi - lo;  // int32 order: hi >= lo, the difference fits 32 bits
+      uint32_t shift = 0;
+      while ((span >> shift) >= kQ16RankBuckets) ++shift;
+      std::vector<uint32_t> cnt(kQ16RankBuckets, 0u);
+      for (uint32_t key : k) ++cnt[(key - lo) >> shift];
+      uint32_t run = 0, max_len = 0;
+      for (uint32_t b = 0; b < kQ16RankBuckets; ++b) {
+        S[b] = (uint16_t)run;  // run <= K <= 32767
+        run += cnt[b];
+        max_len = cnt[b] > max_len ? cnt[b] : max_len;
+      }
+      uint32_t pow2 = 1;
+      while (pow2 <= max_len) pow2 <<= 1;  // strictly more than the fullest slice
+      P[1] = lo;
+      P[2] = hi;
+      P[3] = shift;
+      P[4] = pow2;
+    }
   }
   const uint32_t row = v.tile() * 2u;  // bytes per feature row of the u16 tile
   for (uint32_t i = 0; i < T; ++i) {
@@ -360,7 +390,7 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m) {
   for (uint32_t i = 0; i < T; ++i)
     for (uint32_t n = 0; n < nint; ++n)
       if (m.mright[(size_t)i * nint + n]) slow[(size_t)i * tree_words + n + 1] |= 1u << 16;
-  for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK}) {
+  for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -369,10 +399,12 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m) {
   HIP_TRY(e, hipMalloc(&m.d_img_slow, bytes));
   HIP_TRY(e, hipMalloc(&m.d_tables, tab.size() * 4));
   HIP_TRY(e, hipMalloc(&m.d_tabK, tabK.size() * 4));
+  HIP_TRY(e, hipMalloc(&m.d_tabS, tabS.size() * 2));
   HIP_TRY(e, hipMemcpy(m.d_img, fast.data(), bytes, hipMemcpyHostToDevice));
   HIP_TRY(e, hipMemcpy(m.d_img_slow, slow.data(), bytes, hipMemcpyHostToDevice));
   HIP_TRY(e, hipMemcpy(m.d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(e, hipMemcpy(m.d_tabK, tabK.data(), tabK.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(m.d_tabS, tabS.data(), tabS.size() * 2, hipMemcpyHostToDevice));
   m.img_bytes = bytes;
   m.img_trees = Tpad;
   m.img_chunks = Tpad / (uint32_t)v.chunk_trees;
@@ -478,7 +510,8 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     qa.q = reinterpret_cast<uint16_t*>(e->q_q[e->q_slot]);
     qa.tile_flags = reinterpret_cast<uint32_t*>(e->q_flags[e->q_slot]);
     qa.tables = reinterpret_cast<const uint32_t*>(m.d_tables);
-    qa.tabK = reinterpret_cast<const uint32_t*>(m.d_tabK);
+    qa.tabP = reinterpret_cast<const uint32_t*>(m.d_tabK);
+    qa.tabS = reinterpret_cast<const uint16_t*>(m.d_tabS);
     qa.Kpad = m.Kpad;
     qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
     qa.n_pad = (n + 1023) / 1024 * 1024;

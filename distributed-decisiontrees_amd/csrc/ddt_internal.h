@@ -43,12 +43,15 @@ struct ScoreArgs {
   hipEvent_t ev_mid;       // optional ("kernel_timing"): recorded right before the scoring kernel proper
 };
 
+constexpr uint32_t kQ16RankBuckets = 4096;
+
 struct Q16Aux {               // device pointers of the rank-quantised path (ScoreArgs::aux)
   uint32_t* xT;               // workspace [W][n_pad]: transposed tuples
   uint16_t* q;                // workspace [tiles][W][1024]: feature ranks
   uint32_t* tile_flags;       // workspace [tiles]: 1 = the tile holds a missing value
   const uint32_t* tables;     // [W][Kpad] sorted distinct threshold keys per feature, padded with INT_MAX
-  const uint32_t* tabK;       // [W] real table lengths
+  const uint32_t* tabP;       // [W][8] per feature: K (real table length), lo, hi (first / last key), shift, P, 0, 0, 0
+  const uint16_t* tabS;       // [W][kQ16RankBuckets] bucket starts: number of keys in the slices below (rank_kernel)
   uint32_t Kpad;              // power of two > max table length
   const uint4* img_slow;      // image with the miss_right flags (used by tiles that contain a missing value)
   uint64_t n_pad;             // rows rounded up to whole tiles of 1024

@@ -722,6 +722,7 @@ static hipError_t launch_stream(const ScoreArgs& a, const Variant& v, hipStream_
 // ---------------------------------------------------------------------------------------------------
 constexpr int kQTile = 1024;        // tuples per q tile == threads per scoring block
 constexpr uint32_t kQMissing = 0xFFFFu;
+constexpr uint32_t kRankBuckets = kQ16RankBuckets;  // slices of a feature's key range (first level of the rank search)
 
 __global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restrict__ tuples, uint32_t W, uint64_t n,
                                                         uint64_t n_pad, uint32_t* __restrict__ xT) {
@@ -752,49 +753,77 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restri
 }
 
 constexpr uint32_t kRankThreads = 1024;  // two blocks per CU share the LDS with their tables: 32 waves x 4 searches each
+// Search = one bucket lookup + a short binary search.  The key range [lo, hi] of the feature's table is cut into
+// kRankBuckets equal slices of 2^shift codes; starts[b] = number of keys in slices < b, and no slice holds P or more
+// keys (P = power of two, per feature, from the host: ddt_engine.cpp build_image_q16), so log2(P) probes from
+// starts[b] finish the count -- keys past the slice are > x by construction, no end test.  1000 trees x 255
+// nodes over 32 features (~8 k keys per table): 1 + 5 LDS reads instead of 13.  Degenerate key distributions
+// only make P larger, up to the plain binary search over the whole table.
 __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __restrict__ xT, uint64_t n, uint64_t n_pad,
                                                    const uint32_t* __restrict__ tables, uint32_t Kpad,
-                                                   const uint32_t* __restrict__ tabK, uint32_t miss_raw, uint32_t ieee,
+                                                   const uint32_t* __restrict__ tabP, const uint16_t* __restrict__ tabS,
+                                                   uint32_t miss_raw, uint32_t ieee,
                                                    uint32_t W, uint16_t* __restrict__ q, uint32_t* __restrict__ tile_flags) {
   const uint32_t j = blockIdx.y, tid = threadIdx.x;
   // The probes of a power-of-two binary search are all = step-1 (mod step): with a linear table every probe of
-  // the first log2(Kpad)-5 steps lands in ONE bank (measured: 23.6 conflict cycles per DS op, LDS pipe 97 % busy).
+  // the first steps lands in ONE bank (measured: 23.6 conflict cycles per DS op, LDS pipe 97 % busy).
   // Entry i is therefore stored at i + i/32: one padding word per 32 entries rotates the bank per segment.
   for (uint32_t i = tid; i < Kpad; i += kRankThreads) lds_st_u32((i + (i >> 5)) * 4u, tables[(size_t)j * Kpad + i]);
+  const uint32_t starts_off = (Kpad + (Kpad >> 5) + 1u) * 4u;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(tabS + (size_t)j * kRankBuckets);
+    for (uint32_t i = tid; i < kRankBuckets / 2u; i += kRankThreads) lds_st_u32(starts_off + i * 4u, src[i]);
+  }
   __syncthreads();
-  const uint32_t K = tabK[j];
-  constexpr int ILP = 4;  // independent searches per lane: the 13-15 dependent LDS reads of one search are latency bound
-  const uint64_t stride = (uint64_t)gridDim.x * kRankThreads * ILP;
-  for (uint64_t row0 = (uint64_t)blockIdx.x * kRankThreads * ILP + tid; row0 < n_pad; row0 += stride) {
+  const uint32_t K = tabP[j * 8u + 0u], lo = tabP[j * 8u + 1u], hi = tabP[j * 8u + 2u], shift = tabP[j * 8u + 3u];
+  const uint32_t P = tabP[j * 8u + 4u];
+  // Lane (tid & 511) of half-block (tid >> 9) owns tuples t and t+512 of a tile -- the two halves of one dword of
+  // the q tile (see the layout note below) -- in two tiles per pass: 4 independent searches per lane (the
+  // dependent LDS reads of one search are latency bound) and full 4-byte, fully coalesced stores of the ranks.
+  constexpr int ILP = 4;
+  const uint32_t t = tid & 511u, sub = tid >> 9;
+  const uint64_t tiles = n_pad / kQTile;
+  uint32_t* __restrict__ q32 = reinterpret_cast<uint32_t*>(q);
+  for (uint64_t tile0 = (uint64_t)blockIdx.x * 4u + sub; tile0 < tiles; tile0 += (uint64_t)gridDim.x * 4u) {
     uint32_t raw[ILP], pos[ILP];
     int32_t x[ILP];
 #pragma unroll
-    for (int i = 0; i < ILP; ++i) {
-      const uint64_t row = row0 + (uint64_t)i * kRankThreads;
-      raw[i] = row < n_pad ? xT[(uint64_t)j * n_pad + row] : 0u;
+    for (int i = 0; i < ILP; ++i) {  // i = 2 * (tile within the pass) + half
+      const uint64_t tile = tile0 + 2u * (uint32_t)(i >> 1);
+      const uint64_t row = tile * kQTile + t + 512u * (uint32_t)(i & 1);
+      raw[i] = tile < tiles ? xT[(uint64_t)j * n_pad + row] : 0u;
       x[i] = (int32_t)(ieee ? ieee_key(raw[i]) : raw[i]);
-      pos[i] = 0;
+      uint32_t b = ((uint32_t)x[i] - lo) >> shift;  // wraps to a huge value below lo: selected away next
+      b = b < kRankBuckets - 1u ? b : kRankBuckets - 1u;
+      b = x[i] < (int32_t)lo ? 0u : b;
+      pos[i] = *reinterpret_cast<const DDT_LDS(uint16_t)*>(starts_off + b * 2u);
     }
-    for (uint32_t step = Kpad >> 1; step >= 1u; step >>= 1) {  // table padded with INT_MAX up to Kpad
+    for (uint32_t step = P >> 1; step >= 1u; step >>= 1) {
 #pragma unroll
       for (int i = 0; i < ILP; ++i) {
-        const uint32_t probe = pos[i] + step - 1u;
+        uint32_t probe = pos[i] + step - 1u;
+        probe = probe < Kpad - 1u ? probe : Kpad - 1u;  // entry Kpad-1 is always the INT_MAX pad
         if ((int32_t)lds_u32((probe + (probe >> 5)) * 4u) <= x[i]) pos[i] += step;
       }
     }
+    uint32_t r[ILP];
 #pragma unroll
     for (int i = 0; i < ILP; ++i) {
-      const uint64_t row = row0 + (uint64_t)i * kRankThreads;
-      if (row >= n_pad) continue;
-      uint32_t r = pos[i] < K ? pos[i] : K;
-      if (raw[i] == miss_raw && row < n) {  // bit equality with the missing pattern (DTPU.sv:653), before any transform
-        r = kQMissing;
-        atomicOr(&tile_flags[row / kQTile], 1u);
+      const uint64_t tile = tile0 + 2u * (uint32_t)(i >> 1);
+      const uint64_t row = tile * kQTile + t + 512u * (uint32_t)(i & 1);
+      r[i] = x[i] > (int32_t)hi ? K : (pos[i] < K ? pos[i] : K);
+      if (raw[i] == miss_raw && tile < tiles && row < n) {  // bit equality with the missing pattern (DTPU.sv:653), before any transform
+        r[i] = kQMissing;
+        atomicOr(&tile_flags[tile], 1u);
       }
-      // within a feature row, tuple t sits in dword (t % 512), half (t / 512): the 64 lanes of a wave then read 64
-      // DIFFERENT dwords (two lanes sharing one dword at different byte addresses would 2-way bank-conflict)
-      const uint32_t t = (uint32_t)(row % kQTile);
-      q[((row / kQTile) * W + j) * (uint64_t)kQTile + (2u * (t & 511u) + (t >> 9))] = (uint16_t)r;
+    }
+    // within a feature row of the q tile, tuple t sits in dword (t % 512), half (t / 512): the 64 lanes of a scoring
+    // wave then read 64 DIFFERENT dwords (two lanes sharing one dword at different byte addresses would 2-way
+    // bank-conflict); here it makes one lane the owner of a whole dword
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+      const uint64_t tile = tile0 + 2u * (uint32_t)p2;
+      if (tile < tiles) q32[(tile * W + j) * (uint64_t)(kQTile / 2) + t] = r[2 * p2] | (r[2 * p2 + 1] << 16);
     }
   }
 }
@@ -872,9 +901,10 @@ __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, co
     }                                                                                                  \
   } while (0)
 
-  // (tried: levels 0-1 from SGPRs via hidden s_load_dwordx4 of the next chunk's top records -- 15 DS ops per tree
-  // instead of 17 -- measured 4 % SLOWER, 134.0 vs 128.7 ms per 100 M x 1000 trees: the outstanding scalar loads
-  // inflate lgkmcnt, so every LDS wait of the wave stalls until they return.  profiles/r01_experiments.md)
+  // (tried twice, both slower, both removed -- numbers in profiles/r01_tile_overhead.md: levels 0-1 from SGPRs via
+  // hidden s_load_dwordx4 of the next chunk's top records, and levels 0-1 tested against ranks kept in 16 VGPRs with
+  // a wave-uniform register index; 15 DS ops per tree instead of 17 either way, but the extra wait points cost more
+  // than the LDS cycles they save.)
   constexpr int PH1 = (CT == 4) ? 1 : 0;
   for (uint32_t k = 0; k < n_chunks; k += 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -905,15 +935,15 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
   const uint32_t lds = v.lds_bytes_q16(W);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  const uint32_t rank_lds = (x.Kpad + (x.Kpad >> 5) + 1u) * 4u;  // skewed table, see rank_kernel
+  const uint32_t rank_lds = (x.Kpad + (x.Kpad >> 5) + 1u) * 4u + kRankBuckets * 2u;  // skewed table + bucket starts, see rank_kernel
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(x.tile_flags, 0, tiles * 4, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
-  uint32_t bx = (uint32_t)((x.n_pad + kRankThreads * 4 - 1) / (kRankThreads * 4));  // kRankThreads x 4 rows each per pass
+  uint32_t bx = (uint32_t)((x.n_pad / kQTile + 3) / 4);  // 4 tiles (kRankThreads x 4 rows) per block and pass
   if (bx > 512u) bx = 512u;  // grid-stride over rows; blockIdx.y = feature (the table is loaded once per block)
-  hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabK, a.miss_raw,
+  hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabP, x.tabS, a.miss_raw,
                      a.ieee, W, x.q, x.tile_flags);
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kQTile), lds, s, a, x);

@@ -85,3 +85,41 @@ def test_kernel_timing_counters():
     assert st.last_score_ms > 0.2 and st.last_prepass_ms < 0.05    # fp32 kernel: no pre-pass
     torch.cuda.synchronize()
     e.close()
+
+
+@pytest.mark.parametrize("cmp_mode", [0, 1])
+@pytest.mark.parametrize("shape", ["cluster+outliers", "two_keys", "one_key", "full_range"])
+def test_rank_search_on_degenerate_threshold_distributions(cmp_mode, shape):
+    """The rank pre-pass looks a value up in equal slices of the feature's key range, then finishes with a short
+    binary search; clustered thresholds with far outliers put almost every key in one slice (the search then
+    degenerates to the plain one), one or two distinct keys exercise the zero-width and tiny ranges, and
+    full_range spans negative to positive bit patterns (uint32 difference > 2^31)."""
+    T, D, F, n = 64, 8, 8, 5000
+    m = O.gen_model(T, D, F, dist=1, cmp_mode=cmp_mode)
+    rng = np.random.default_rng(7)
+    w = m.wlines.copy().reshape(T, -1)
+    nint = 255
+    if shape == "cluster+outliers":
+        thr = (np.float32(0.25) + rng.integers(0, 3000, (T, nint)).astype(np.float32) * np.float32(2 ** -22)).astype(np.float32)
+        thr[0, 0], thr[1, 0], thr[2, 0] = np.float32(-3.0e38), np.float32(3.0e38), np.float32(1e-30)
+    elif shape == "two_keys":
+        thr = np.where(rng.random((T, nint)) < 0.5, np.float32(0.5), np.float32(-0.5)).astype(np.float32)
+    elif shape == "one_key":
+        thr = np.full((T, nint), np.float32(0.125), np.float32)
+    else:
+        thr = rng.integers(0, 2 ** 32, (T, nint), dtype=np.uint64).astype(np.uint32).view(np.float32)
+        thr = np.where(np.isnan(thr), np.float32(1.0), thr).astype(np.float32)
+    w[:, :nint] = thr.view(np.uint32)
+    m = O.Model(m.params, w.reshape(m.wlines.shape), m.flines)
+    x = O.gen_tuples(5, n, F, dist=1, missing_bits=m.params.missing_bits)
+    flat = thr.view(np.uint32).reshape(-1)
+    pick = flat[rng.integers(0, flat.size, (n, F))].astype(np.int64) + rng.integers(-2, 3, (n, F))
+    mask = rng.random((n, F)) < 0.7
+    x[:, :F] = np.where(mask, (pick & 0xFFFFFFFF).astype(np.uint32), x[:, :F])
+    e = ddt.Engine(0)
+    e.set_option("variant", _variant("q16_d8_c4_u4"))
+    e.load_model(_params(m), m.wlines, m.flines)
+    assert e.info().variant_name.decode() == "q16_d8_c4_u4"
+    got = e.score(x)
+    assert np.array_equal(got.view(np.uint32), O.score(m, x).view(np.uint32))
+    e.close()
