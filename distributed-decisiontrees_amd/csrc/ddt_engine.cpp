@@ -188,20 +188,29 @@ uint32_t max_trees(const ddt_engine* e) {
   return t;
 }
 
-// q16: sorted distinct threshold keys (comparator domain) per feature, over the trees of one ensemble
-RankTables rank_tables(const ddt_engine* e, const Ensemble& m) {
+// q16: sorted distinct threshold keys (comparator domain) per feature, over the trees of EVERY ensemble of the
+// engine: the classes of a multi-class model share one set of tables, so one transpose + rank pre-pass per batch
+// serves all K scoring launches (launch_classify)
+RankTables rank_tables(const ddt_engine* e) {
   RankTables rt;
   const uint32_t W = tuple_words(e->p), nint = e->nint;
   rt.keys.resize(W);
-  for (uint32_t i = 0; i < m.trees(); ++i)
-    for (uint32_t n = 0; n < nint; ++n)
-      rt.keys[m.fidx[(size_t)i * nint + n]].push_back(thr_key(e->p, m.thr[(size_t)i * nint + n]));
+  for (const Ensemble& m : e->ens)
+    for (uint32_t i = 0; i < m.trees(); ++i)
+      for (uint32_t n = 0; n < nint; ++n)
+        rt.keys[m.fidx[(size_t)i * nint + n]].push_back(thr_key(e->p, m.thr[(size_t)i * nint + n]));
   for (auto& k : rt.keys) {
     std::sort(k.begin(), k.end(), [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; });
     k.erase(std::unique(k.begin(), k.end()), k.end());
     if (k.size() > rt.max_len) rt.max_len = (uint32_t)k.size();
   }
   return rt;
+}
+
+uint32_t total_trees(const ddt_engine* e) {
+  uint32_t t = 0;
+  for (const Ensemble& m : e->ens) t += m.trees();
+  return t;
 }
 
 constexpr uint32_t kQ16MaxTable = 32767;  // ranks must stay below 0xFFFF and a table (x4 B) must fit LDS in the rank kernel
@@ -212,9 +221,7 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
   const uint32_t W = tuple_words(e->p);
   if (v.kind == kKindQ16) {
     if (W > 32u || v.lds_bytes_q16(W) > kMaxLdsBytes / 2u) return false;  // two blocks per CU or it is not worth it
-    for (const Ensemble& m : e->ens)
-      if (rank_tables(e, m).max_len > kQ16MaxTable) return false;
-    return true;
+    return rank_tables(e).max_len <= kQ16MaxTable;
   }
   if (v.kind == kKindStream)
     return W <= 4u * (uint32_t)v.opt && v.lds_bytes_stream(padded_trees(v, max_trees(e)), W) <= kStreamLdsBudget;
@@ -239,7 +246,7 @@ int auto_variant(const ddt_engine* e) {
   // Rank-quantised path: its scoring kernel is ~1.3x faster per tree (32 waves/CU) but it pays a fixed transpose +
   // rank pre-pass per tuple.  Measured per 100 M tuples (profiles/r01_*): q16 = 10.9 ms + 0.113 ms/tree, fp32 tile =
   // 3.2 ms + 0.147 ms/tree => break-even near 200 trees per engine; 250 trees (4-way shard of 1000) goes to q16.
-  if (max_trees(e) >= 224u) {
+  if (total_trees(e) >= 224u) {  // the pre-pass is shared by the classes of a multi-class model
     static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
@@ -328,10 +335,9 @@ int build_image(ddt_engine* e, const Variant& v, Ensemble& m) {
 
 // q16 images: per tree 2^D records {R (lo16) | row offset (hi16)} in a 1-based heap, then 2^D fp32 leaves.
 // R = 1 + index of the node's threshold in its feature's table; the slow image carries miss_right in bit 16.
-int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m) {
+int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTables& rt, bool upload_tables) {
   const uint32_t D = e->p.num_levels, T = m.trees(), nint = e->nint, nleaf = e->nleaf, W = tuple_words(e->p);
   const uint32_t tree_words = (8u << D) / 4u, Tpad = padded_trees(v, T);
-  const RankTables rt = rank_tables(e, m);
   uint32_t Kpad = 2;
   while (Kpad <= rt.max_len) Kpad <<= 1;  // power of two > max_len: the search reads indices < Kpad - 1
   std::vector<uint32_t> fast, slow, tab, tabK;
@@ -397,14 +403,18 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m) {
   const size_t bytes = fast.size() * 4;
   HIP_TRY(e, hipMalloc(&m.d_img, bytes));
   HIP_TRY(e, hipMalloc(&m.d_img_slow, bytes));
-  HIP_TRY(e, hipMalloc(&m.d_tables, tab.size() * 4));
-  HIP_TRY(e, hipMalloc(&m.d_tabK, tabK.size() * 4));
-  HIP_TRY(e, hipMalloc(&m.d_tabS, tabS.size() * 2));
+  if (upload_tables) {
+    HIP_TRY(e, hipMalloc(&m.d_tables, tab.size() * 4));
+    HIP_TRY(e, hipMalloc(&m.d_tabK, tabK.size() * 4));
+    HIP_TRY(e, hipMalloc(&m.d_tabS, tabS.size() * 2));
+  }
   HIP_TRY(e, hipMemcpy(m.d_img, fast.data(), bytes, hipMemcpyHostToDevice));
   HIP_TRY(e, hipMemcpy(m.d_img_slow, slow.data(), bytes, hipMemcpyHostToDevice));
-  HIP_TRY(e, hipMemcpy(m.d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
-  HIP_TRY(e, hipMemcpy(m.d_tabK, tabK.data(), tabK.size() * 4, hipMemcpyHostToDevice));
-  HIP_TRY(e, hipMemcpy(m.d_tabS, tabS.data(), tabS.size() * 2, hipMemcpyHostToDevice));
+  if (upload_tables) {
+    HIP_TRY(e, hipMemcpy(m.d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(m.d_tabK, tabK.data(), tabK.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(m.d_tabS, tabS.data(), tabS.size() * 2, hipMemcpyHostToDevice));
+  }
   m.img_bytes = bytes;
   m.img_trees = Tpad;
   m.img_chunks = Tpad / (uint32_t)v.chunk_trees;
@@ -441,8 +451,11 @@ int select_and_build(ddt_engine* e) {
   } else {
     vid = auto_variant(e);
   }
+  RankTables rt;
+  if (variant(vid).kind == kKindQ16) rt = rank_tables(e);
   for (Ensemble& m : e->ens) {
-    int rc = variant(vid).kind == kKindQ16 ? build_image_q16(e, variant(vid), m) : build_image(e, variant(vid), m);
+    int rc = variant(vid).kind == kKindQ16 ? build_image_q16(e, variant(vid), m, rt, &m == &e->ens[0])  // tables live in ens[0]
+                                          : build_image(e, variant(vid), m);
     if (rc) return rc;
   }
   e->variant_id = vid;
@@ -498,7 +511,8 @@ int feeder_reserve(ddt_engine* e, size_t rows, size_t words, size_t outs) {
 
 int ensure_q16_workspace(ddt_engine* e, size_t n);
 
-int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
+int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t n, float* d_scores, hipStream_t s,
+                 bool reuse_prepass = false) {
   ScoreArgs a;
   fill_args(e, m, d_tuples, n, d_scores, &a);
   const Variant& v = variant(e->variant_id);
@@ -509,10 +523,12 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     qa.xT = reinterpret_cast<uint32_t*>(e->q_xT[e->q_slot]);
     qa.q = reinterpret_cast<uint16_t*>(e->q_q[e->q_slot]);
     qa.tile_flags = reinterpret_cast<uint32_t*>(e->q_flags[e->q_slot]);
-    qa.tables = reinterpret_cast<const uint32_t*>(m.d_tables);
-    qa.tabP = reinterpret_cast<const uint32_t*>(m.d_tabK);
-    qa.tabS = reinterpret_cast<const uint16_t*>(m.d_tabS);
-    qa.Kpad = m.Kpad;
+    const Ensemble& tm = e->ens[0];  // the rank tables are shared by all classes and owned by the first ensemble
+    qa.tables = reinterpret_cast<const uint32_t*>(tm.d_tables);
+    qa.tabP = reinterpret_cast<const uint32_t*>(tm.d_tabK);
+    qa.tabS = reinterpret_cast<const uint16_t*>(tm.d_tabS);
+    qa.Kpad = tm.Kpad;
+    qa.skip_prepass = reuse_prepass ? 1u : 0u;
     qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
     qa.n_pad = (n + 1023) / 1024 * 1024;
     a.aux = &qa;
@@ -538,7 +554,8 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
 // class scores [K][n] into d_class_scores, then argmax into d_labels (if non-NULL)
 int launch_classify(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s) {
   for (uint32_t k = 0; k < e->num_classes; ++k) {
-    int rc = launch_score(e, e->ens[k], d_tuples, n, d_class_scores + (size_t)k * n, s);
+    // rank-quantised path: the q tiles of this batch are computed by the first class's launch and reused
+    int rc = launch_score(e, e->ens[k], d_tuples, n, d_class_scores + (size_t)k * n, s, k > 0);
     if (rc) return rc;
   }
   if (d_labels) {

@@ -55,6 +55,7 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   uint32_t Kpad;              // power of two > max table length
   const uint4* img_slow;      // image with the miss_right flags (used by tiles that contain a missing value)
   uint64_t n_pad;             // rows rounded up to whole tiles of 1024
+  uint32_t skip_prepass;      // 1 = q / tile_flags already hold this batch (2nd..Kth class of a multi-class model)
 };
 
 enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2, kKindQ16 = 3 };

@@ -729,7 +729,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restri
   // 256 rows per block through LDS [256][W+1] (odd stride: conflict-free column reads)
   const uint32_t tid = threadIdx.x, S = W + 1u;
   const uint64_t row0 = (uint64_t)blockIdx.x * 256u;
-  const uint32_t rows = (uint32_t)((n - row0) < 256u ? (n - row0) : 256u);
+  const uint32_t rows = row0 >= n ? 0u : (uint32_t)((n - row0) < 256u ? (n - row0) : 256u);  // blocks past n only write the zero padding
   const uint4* src = reinterpret_cast<const uint4*>(tuples + row0 * W);
   const uint32_t LPT = W / 4u;  // 16-byte lines per tuple (<= 8 on this path)
   uint4 v[8];
@@ -938,13 +938,15 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
   const uint32_t rank_lds = (x.Kpad + (x.Kpad >> 5) + 1u) * 4u + kRankBuckets * 2u;  // skewed table + bucket starts, see rank_kernel
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(x.tile_flags, 0, tiles * 4, s);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
-  uint32_t bx = (uint32_t)((x.n_pad / kQTile + 3) / 4);  // 4 tiles (kRankThreads x 4 rows) per block and pass
-  if (bx > 512u) bx = 512u;  // grid-stride over rows; blockIdx.y = feature (the table is loaded once per block)
-  hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabP, x.tabS, a.miss_raw,
-                     a.ieee, W, x.q, x.tile_flags);
+  if (!x.skip_prepass) {
+    e = hipMemsetAsync(x.tile_flags, 0, tiles * 4, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
+    uint32_t bx = (uint32_t)((x.n_pad / kQTile + 3) / 4);  // 4 tiles (kRankThreads x 4 rows) per block and pass
+    if (bx > 512u) bx = 512u;  // grid-stride over tiles; blockIdx.y = feature (the table is loaded once per block)
+    hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabP, x.tabS, a.miss_raw,
+                       a.ieee, W, x.q, x.tile_flags);
+  }
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kQTile), lds, s, a, x);
   return hipGetLastError();

@@ -78,3 +78,27 @@ def test_gpu_classify_matches_oracle(T, D, F, K, n, inter):
         assert np.array_equal(comb.cpu().numpy().view(np.uint32), want2_cs.view(np.uint32))
         assert np.array_equal(lab.cpu().numpy(), want2_l)
     e.close()
+
+
+@pytest.mark.gpu
+def test_classes_share_one_rank_prepass():
+    """Multi-class models big enough for the rank-quantised path build ONE set of rank tables over all classes and
+    run the transpose + rank pre-pass once per batch; missing values and negatives (slow image) included."""
+    import torch
+
+    T, D, F, K, n = 400, 8, 32, 4, 3000
+    w, f = ddt.synth_model(T, D, F, 1)
+    C = ddt.default_clusters(T // K)
+    m = O.Model(O.make_params(T, D, F, clusters=C), w, f)
+    x = O.gen_tuples(4, n, F, dist=1)
+    want_l, want_cs = O.classify(m, x, K, interleaved=True)
+    e = ddt.Engine(0)
+    e.load_model_multiclass(ddt.make_params(T, D, F, clusters=C), w, f, K, True)
+    assert e.info().variant_name.decode().startswith("q16")     # 100 trees per class, 400 in total
+    dl, dcs = e.classify_device(torch.from_numpy(x.view(np.int32)).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(dcs.cpu().numpy().view(np.uint32), want_cs.view(np.uint32))
+    assert np.array_equal(dl.cpu().numpy(), want_l)
+    labels, cs = e.classify(x, want_scores=True)                 # host feeder: two workspaces in flight
+    assert np.array_equal(cs.view(np.uint32), want_cs.view(np.uint32)) and np.array_equal(labels, want_l)
+    e.close()

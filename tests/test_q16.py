@@ -123,3 +123,19 @@ def test_rank_search_on_degenerate_threshold_distributions(cmp_mode, shape):
     got = e.score(x)
     assert np.array_equal(got.view(np.uint32), O.score(m, x).view(np.uint32))
     e.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 700, 1025, 1500, 2049])
+def test_short_batches_do_not_read_past_the_tuples(n):
+    """Batches that end well inside a 1024-tuple tile: the pre-pass pads q to whole tiles but must not read the
+    tuple buffer past row n (the host path hands it an exactly sized device allocation)."""
+    T, D, F = 300, 8, 32
+    m = O.gen_model(T, D, F, dist=1)
+    x = O.gen_tuples(21, n, F, dist=1)
+    e = ddt.Engine(0)
+    e.load_model(_params(m), m.wlines, m.flines)
+    assert e.info().variant_name.decode() == "q16_d8_c4_u4"
+    e.set_option("feeder_rows", 1 << 20)
+    got = e.score(x)
+    assert np.array_equal(got.view(np.uint32), O.score(m, x).view(np.uint32))
+    e.close()

@@ -1,0 +1,4 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "Extension modules" > gpurun_out/s18_tests.log
+tail -4 gpurun_out/s18_tests.log
