@@ -993,32 +993,67 @@ __global__ __launch_bounds__(kGenericThreads) void score_generic_kernel(const Sc
   double dacc = 0.0;
   float grp[8];
   for (uint32_t t8 = 0; t8 < a.n_trees; t8 += 8u) {
+    if (!TREE_LDS) {
+      // deep trees (nodes in L2 / HBM): the 8 trees of a PU group advance level by level together, so a lane has
+      // 8 independent node loads in flight instead of one dependent chain (config 4: 0.34 -> see profiles/)
+      const unsigned char* base = reinterpret_cast<const unsigned char*>(a.img) + (size_t)t8 * tree_bytes;
+      uint32_t m[8];
 #pragma unroll
-    for (uint32_t tu = 0; tu < 8u; ++tu) {
-      const uint32_t t = t8 + tu;
-      const unsigned char* timg = reinterpret_cast<const unsigned char*>(a.img) + (size_t)t * tree_bytes;
-      if (TREE_LDS) {
-        __syncthreads();  // previous tree fully consumed
-        for (uint32_t off = tid * 16u; off < tree_bytes; off += TILE * 16u)
-          lds_st_u4(tree_lds + off, *reinterpret_cast<const uint4*>(timg + off));
-        __syncthreads();
-      }
-      uint32_t m = 1;
+      for (uint32_t tu = 0; tu < 8u; ++tu) m[tu] = 1u;
       for (uint32_t lvl = 0; lvl < D; ++lvl) {
-        const uint2 nd = TREE_LDS ? lds_u2(tree_lds + m * 8u) : *reinterpret_cast<const uint2*>(timg + (size_t)m * 8u);
-        const uint32_t j = nd.y & 0x7FFFFFFFu;
-        uint32_t f;
-        if (FEAT_LDS) f = lds_u32((j * TILE + tid) * 4u);
-        else {
-          f = xrow[j];
-          if (a.ieee) f = (f == a.miss_raw) ? kMissSentinelIeee : ieee_key(f);
+        uint2 nd[8];
+#pragma unroll
+        for (uint32_t tu = 0; tu < 8u; ++tu)
+          nd[tu] = *reinterpret_cast<const uint2*>(base + (size_t)tu * tree_bytes + (size_t)m[tu] * 8u);
+#pragma unroll
+        for (uint32_t tu = 0; tu < 8u; ++tu) {
+          const uint32_t j = nd[tu].y & 0x7FFFFFFFu;
+          uint32_t f;
+          if (FEAT_LDS) f = lds_u32((j * TILE + tid) * 4u);
+          else {
+            f = xrow[j];
+            if (a.ieee) f = (f == a.miss_raw) ? kMissSentinelIeee : ieee_key(f);
+          }
+          m[tu] = 2u * m[tu] + (go_right<true>(f, nd[tu].x, nd[tu].y, a.miss_key) ? 1u : 0u);
         }
-        m = 2u * m + (go_right<true>(f, nd.x, nd.y, a.miss_key) ? 1u : 0u);
       }
-      const uint32_t lo = (8u << D) + (m - (1u << D)) * 4u;
-      const float leaf = TREE_LDS ? lds_f32(tree_lds + lo) : *reinterpret_cast<const float*>(timg + lo);
-      if (a.sum_mode == 1) dacc += (double)leaf;
-      grp[tu] = leaf;
+#pragma unroll
+      for (uint32_t tu = 0; tu < 8u; ++tu) {
+        const uint32_t lo = (8u << D) + (m[tu] - (1u << D)) * 4u;
+        grp[tu] = *reinterpret_cast<const float*>(base + (size_t)tu * tree_bytes + lo);
+      }
+      if (a.sum_mode == 1) {
+#pragma unroll
+        for (uint32_t tu = 0; tu < 8u; ++tu) dacc += (double)grp[tu];
+      }
+    } else {
+#pragma unroll
+      for (uint32_t tu = 0; tu < 8u; ++tu) {
+        const uint32_t t = t8 + tu;
+        const unsigned char* timg = reinterpret_cast<const unsigned char*>(a.img) + (size_t)t * tree_bytes;
+        if (TREE_LDS) {
+          __syncthreads();  // previous tree fully consumed
+          for (uint32_t off = tid * 16u; off < tree_bytes; off += TILE * 16u)
+            lds_st_u4(tree_lds + off, *reinterpret_cast<const uint4*>(timg + off));
+          __syncthreads();
+        }
+        uint32_t m = 1;
+        for (uint32_t lvl = 0; lvl < D; ++lvl) {
+          const uint2 nd = TREE_LDS ? lds_u2(tree_lds + m * 8u) : *reinterpret_cast<const uint2*>(timg + (size_t)m * 8u);
+          const uint32_t j = nd.y & 0x7FFFFFFFu;
+          uint32_t f;
+          if (FEAT_LDS) f = lds_u32((j * TILE + tid) * 4u);
+          else {
+            f = xrow[j];
+            if (a.ieee) f = (f == a.miss_raw) ? kMissSentinelIeee : ieee_key(f);
+          }
+          m = 2u * m + (go_right<true>(f, nd.x, nd.y, a.miss_key) ? 1u : 0u);
+        }
+        const uint32_t lo = (8u << D) + (m - (1u << D)) * 4u;
+        const float leaf = TREE_LDS ? lds_f32(tree_lds + lo) : *reinterpret_cast<const float*>(timg + lo);
+        if (a.sum_mode == 1) dacc += (double)leaf;
+        grp[tu] = leaf;
+      }
     }
     if (a.sum_mode != 1) {
       const float s[1] = {((grp[0] + grp[1]) + (grp[2] + grp[3])) + ((grp[4] + grp[5]) + (grp[6] + grp[7]))};
