@@ -45,6 +45,8 @@ struct Ensemble {
   void* d_tables = nullptr;
   void* d_tabK = nullptr;   // q16: per-feature search parameters (Q16Aux::tabP)
   void* d_tabS = nullptr;   // q16: bucket starts (Q16Aux::tabS)
+  void* d_fused = nullptr;  // q16, small tables: LDS image of the fused pre-pass (Q16Aux::fused_img)
+  uint32_t fused_bytes = 0, fused_par_off = 0, fused_P = 0;
   uint32_t Kpad = 0;
   uint32_t trees() const { return (uint32_t)ids.size(); }
 };
@@ -86,6 +88,7 @@ struct ddt_engine {
   void* q_flags[3] = {nullptr, nullptr, nullptr};
   uint64_t q_rows[3] = {0, 0, 0};  // capacity in rows (multiple of 1024)
   int q_slot = 0;
+  int q16_fused_prepass = 1;  // option "q16_fused_prepass": 0 forces the transpose + rank kernels (A/B, tests)
   // optional per-call kernel timing (option "kernel_timing"): start / before scoring kernel / end
   bool kernel_timing = false, timing_pending = false;
   hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
@@ -207,12 +210,68 @@ RankTables rank_tables(const ddt_engine* e) {
   return rt;
 }
 
+// Fused pre-pass (fused_rank_kernel) when every table fits LDS together: exact LDS image = per feature a skewed
+// table of K + P keys (INT_MAX pads), then all bucket starts, then 8 parameter words per feature
+// {K, lo, shift, table byte offset, starts byte offset, 0, 0, 0}.  Returns false (image left empty) when it does
+// not fit; `fimg` may be NULL to only ask the question.
+bool build_fused_image(const RankTables& rt, uint32_t W, std::vector<uint32_t>* fimg, uint32_t* par_off, uint32_t* P_out) {
+  std::vector<uint32_t> tab_off(W), cnt, lo(W, 0x7FFFFFFFu), shift(W, 0u);
+  std::vector<std::vector<uint16_t>> starts(W, std::vector<uint16_t>(kQ16FusedBuckets, 0));
+  uint32_t P = 1;
+  for (uint32_t j = 0; j < W; ++j) {
+    const std::vector<uint32_t>& k = rt.keys[j];
+    if (k.empty()) continue;
+    lo[j] = k.front();
+    const uint32_t span = k.back() - k.front();  // int32 order: the difference fits 32 bits
+    while ((span >> shift[j]) >= kQ16FusedBuckets) ++shift[j];
+    cnt.assign(kQ16FusedBuckets, 0u);
+    for (uint32_t key : k) ++cnt[(key - lo[j]) >> shift[j]];
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < kQ16FusedBuckets; ++b) {
+      starts[j][b] = (uint16_t)run;
+      run += cnt[b];
+      while (P <= cnt[b]) P <<= 1;  // strictly more than the fullest bucket
+    }
+  }
+  size_t words = 0;
+  for (uint32_t j = 0; j < W; ++j) {
+    const uint32_t len = (uint32_t)rt.keys[j].size() + P;  // the search reads indices < K + P
+    tab_off[j] = (uint32_t)words * 4u;
+    words += len + (len >> 5) + 1u;
+  }
+  words = (words + 3u) & ~(size_t)3u;
+  const size_t starts_word0 = words;
+  words += (size_t)W * kQ16FusedBuckets / 2u;
+  const uint32_t poff = (uint32_t)words * 4u;
+  words += (size_t)W * 8u;
+  if (words * 4u > kMaxLdsBytes) return false;
+  if (par_off) *par_off = poff;
+  if (P_out) *P_out = P;
+  if (!fimg) return true;
+  fimg->assign(words, 0x7FFFFFFFu);
+  for (uint32_t j = 0; j < W; ++j) {
+    const std::vector<uint32_t>& k = rt.keys[j];
+    for (uint32_t i = 0; i < k.size(); ++i) (*fimg)[tab_off[j] / 4u + i + (i >> 5)] = k[i];
+    uint16_t* S = reinterpret_cast<uint16_t*>(fimg->data() + starts_word0) + (size_t)j * kQ16FusedBuckets;
+    std::copy(starts[j].begin(), starts[j].end(), S);
+    uint32_t* Pp = fimg->data() + poff / 4u + (size_t)j * 8u;
+    Pp[0] = (uint32_t)k.size();
+    Pp[1] = lo[j];
+    Pp[2] = shift[j];
+    Pp[3] = tab_off[j];
+    Pp[4] = (uint32_t)(starts_word0 * 4u) + j * kQ16FusedBuckets * 2u;
+    Pp[5] = Pp[6] = Pp[7] = 0u;
+  }
+  return true;
+}
+
 uint32_t total_trees(const ddt_engine* e) {
   uint32_t t = 0;
   for (const Ensemble& m : e->ens) t += m.trees();
   return t;
 }
 
+constexpr uint32_t kQ16MinTreesFused = 112;  // measured break-even with the fused pre-pass ~90 trees (profiles/r01_fused_prepass.md)
 constexpr uint32_t kQ16MaxTable = 32767;  // ranks must stay below 0xFFFF and a table (x4 B) must fit LDS in the rank kernel
 
 bool variant_fits(const Variant& v, const ddt_engine* e) {
@@ -246,7 +305,13 @@ int auto_variant(const ddt_engine* e) {
   // Rank-quantised path: its scoring kernel is ~1.3x faster per tree (32 waves/CU) but it pays a fixed transpose +
   // rank pre-pass per tuple.  Measured per 100 M tuples (profiles/r01_*): q16 = 10.9 ms + 0.113 ms/tree, fp32 tile =
   // 3.2 ms + 0.147 ms/tree => break-even near 200 trees per engine; 250 trees (4-way shard of 1000) goes to q16.
-  if (total_trees(e) >= 224u) {  // the pre-pass is shared by the classes of a multi-class model
+  // With small tables (they all fit LDS together, e.g. a 125-tree shard) the pre-pass is one fused kernel and the
+  // break-even drops accordingly (kQ16MinTreesFused).
+  uint32_t q16_min = 224u;
+  if (e->q16_fused_prepass && tuple_words(e->p) <= 32u && total_trees(e) >= kQ16MinTreesFused && total_trees(e) < 224u &&
+      build_fused_image(rank_tables(e), tuple_words(e->p), nullptr, nullptr, nullptr))
+    q16_min = kQ16MinTreesFused;
+  if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
     static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
@@ -262,7 +327,7 @@ int auto_variant(const ddt_engine* e) {
 
 void free_images(ddt_engine* e) {
   for (Ensemble& m : e->ens) {
-    for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS}) {
+    for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_fused}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
@@ -381,6 +446,9 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
       P[4] = pow2;
     }
   }
+  std::vector<uint32_t> fimg;
+  uint32_t fused_par_off = 0, fused_P = 1;
+  if (upload_tables) (void)build_fused_image(rt, W, &fimg, &fused_par_off, &fused_P);
   const uint32_t row = v.tile() * 2u;  // bytes per feature row of the u16 tile
   for (uint32_t i = 0; i < T; ++i) {
     uint32_t* t = fast.data() + (size_t)i * tree_words;
@@ -396,7 +464,7 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
   for (uint32_t i = 0; i < T; ++i)
     for (uint32_t n = 0; n < nint; ++n)
       if (m.mright[(size_t)i * nint + n]) slow[(size_t)i * tree_words + n + 1] |= 1u << 16;
-  for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS}) {
+  for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_fused}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -414,6 +482,14 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
     HIP_TRY(e, hipMemcpy(m.d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(m.d_tabK, tabK.data(), tabK.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(m.d_tabS, tabS.data(), tabS.size() * 2, hipMemcpyHostToDevice));
+    m.fused_bytes = 0;
+    if (!fimg.empty()) {
+      HIP_TRY(e, hipMalloc(&m.d_fused, fimg.size() * 4));
+      HIP_TRY(e, hipMemcpy(m.d_fused, fimg.data(), fimg.size() * 4, hipMemcpyHostToDevice));
+      m.fused_bytes = (uint32_t)(fimg.size() * 4);
+      m.fused_par_off = fused_par_off;
+      m.fused_P = fused_P;
+    }
   }
   m.img_bytes = bytes;
   m.img_trees = Tpad;
@@ -436,7 +512,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint32_t W = tuple_words(e->p);
   HIP_TRY(e, hipMalloc(&e->q_xT[k], rows * W * 4));
   HIP_TRY(e, hipMalloc(&e->q_q[k], rows * W * 2));
-  HIP_TRY(e, hipMalloc(&e->q_flags[k], rows / 1024 * 4));
+  HIP_TRY(e, hipMalloc(&e->q_flags[k], (rows / 1024 + 4) * 4));  // + the fused pre-pass's 8-byte work counter
   e->q_rows[k] = rows;
   return DDT_OK;
 }
@@ -529,6 +605,10 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     qa.tabS = reinterpret_cast<const uint16_t*>(tm.d_tabS);
     qa.Kpad = tm.Kpad;
     qa.skip_prepass = reuse_prepass ? 1u : 0u;
+    qa.fused_img = reinterpret_cast<const uint4*>(tm.d_fused);
+    qa.fused_bytes = e->q16_fused_prepass ? tm.fused_bytes : 0u;
+    qa.fused_par_off = tm.fused_par_off;
+    qa.fused_P = tm.fused_P;
     qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
     qa.n_pad = (n + 1023) / 1024 * 1024;
     a.aux = &qa;
@@ -872,6 +952,10 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   }
   if (!strcmp(key, "kernel_timing")) {
     e->kernel_timing = value != 0;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "q16_fused_prepass")) {  // 0: always transpose + rank kernels (A/B and tests); default 1
+    e->q16_fused_prepass = value != 0;
     return DDT_OK;
   }
   if (!strcmp(key, "feeder_rows")) {

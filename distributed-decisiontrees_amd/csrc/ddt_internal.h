@@ -44,6 +44,7 @@ struct ScoreArgs {
 };
 
 constexpr uint32_t kQ16RankBuckets = 4096;
+constexpr uint32_t kQ16FusedBuckets = 256;   // per feature, fused pre-pass (all tables resident in LDS)
 
 struct Q16Aux {               // device pointers of the rank-quantised path (ScoreArgs::aux)
   uint32_t* xT;               // workspace [W][n_pad]: transposed tuples
@@ -56,6 +57,10 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   const uint4* img_slow;      // image with the miss_right flags (used by tiles that contain a missing value)
   uint64_t n_pad;             // rows rounded up to whole tiles of 1024
   uint32_t skip_prepass;      // 1 = q / tile_flags already hold this batch (2nd..Kth class of a multi-class model)
+  const uint4* fused_img;     // small tables only: exact LDS image of fused_rank_kernel (tables, bucket starts, parameters)
+  uint32_t fused_bytes;       // its size (0 = use transpose_kernel + rank_kernel)
+  uint32_t fused_par_off;     // byte offset of the per-feature parameter block inside the image
+  uint32_t fused_P;           // power of two > the fullest bucket of any feature
 };
 
 enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2, kKindQ16 = 3 };

@@ -828,6 +828,126 @@ __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused pre-pass for SMALL tables (all W tables + their bucket starts fit one CU's LDS, e.g. a 125-tree shard:
+// ~1000 keys per feature): one kernel reads the tuples row-wise and writes the rank tiles, no transposed fp32
+// intermediate -- HBM traffic 4F + 2F bytes per tuple instead of 4F + 4F + 4F + 2F.  The host packs the exact
+// LDS image (ddt_engine.cpp build_image_q16): per feature a skewed key table with >= P INT_MAX pads, 256 bucket
+// starts (u16) and 8 parameter words {K, lo, shift, table byte offset, starts byte offset, 0, 0, 0}.
+// A lane owns tuples t and t+512 of a tile (the two halves of one dword of the rank tile): quad-coalesced
+// loads + DPP transpose as in score_tile_kernel, then per feature two searches and one 4-byte store.
+// Work unit = 64 lane pairs (128 tuples) of one tile, handed out to WAVES through a global atomic counter: no
+// barrier after the image load, the 16 waves of the block drift apart and cover each other's load latency, and
+// blocks that start late (CUs busy with another stream's kernels, e.g. RCCL) simply take fewer units.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kFusedThreads = 1024;  // two tiles per block and pass; 16 waves x 8 independent searches hide the LDS latency
+constexpr uint32_t kFusedBuckets = kQ16FusedBuckets;
+
+__global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
+                                                                   const uint4* __restrict__ lds_img, uint32_t img_bytes, uint32_t par_off,
+                                                                   uint32_t P, uint32_t miss_raw, uint32_t ieee,
+                                                                   uint32_t* __restrict__ q32, uint32_t* __restrict__ tile_flags,
+                                                                   unsigned long long* __restrict__ work_counter) {
+  const uint32_t tid = threadIdx.x, t4 = tid & 3u, lpt = W / 4u;
+  for (uint32_t off = tid * 16u; off < img_bytes; off += kFusedThreads * 16u) lds_st_u4(off, lds_img[off / 16u]);
+  __syncthreads();
+  const uint64_t tiles = n_pad / kQTile;
+
+  // one half-unit = lines 4g..4g+3 (16 features) of rows lt and lt+512: 8 x 16-byte loads per lane
+  auto load_half = [&](u32x4 (&v)[2][4], uint64_t tile, uint32_t lt, uint32_t g) {
+    const uint32_t line = 4u * g + t4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint64_t quad_row = tile * kQTile + 512u * (uint32_t)h + (lt & ~3u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint64_t rj = quad_row + (uint64_t)j;
+        v[h][j] = (rj < n && line < lpt) ? *reinterpret_cast<const u32x4*>(tuples + rj * W + 4u * line) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  // rank the 16 features of a half-tile; returns "this lane saw a missing value"
+  auto rank_half = [&](u32x4 (&v)[2][4], uint64_t tile, uint32_t lt, uint32_t g) -> bool {
+    bool any_missing = false;
+    quad_transpose(v[0], t4);  // v[h][i] = line 4g+i of row (tile*1024 + lt + 512h)
+    quad_transpose(v[1], t4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t line = 4u * g + (uint32_t)i;
+      if (line >= lpt) continue;
+      // the four features of this line x two rows: 8 searches advance together
+      uint32_t K[4], tab[4], raw[4][2], pos[4][2];
+      int32_t x[4][2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t j = 4u * line + (uint32_t)c;
+        const uint4 par = lds_u4(par_off + j * 32u);  // same address in every lane: {K, lo, shift, table_off}
+        const uint32_t st = lds_u32(par_off + j * 32u + 16u);
+        K[c] = par.x;
+        tab[c] = par.w;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          raw[c][h] = v[h][i][c];
+          x[c][h] = (int32_t)(ieee ? ieee_key(raw[c][h]) : raw[c][h]);
+          uint32_t bk = ((uint32_t)x[c][h] - par.y) >> par.z;  // wraps to a huge value below lo: selected away next
+          bk = bk < kFusedBuckets - 1u ? bk : kFusedBuckets - 1u;
+          bk = x[c][h] < (int32_t)par.y ? 0u : bk;
+          pos[c][h] = *reinterpret_cast<const DDT_LDS(uint16_t)*>(st + bk * 2u);
+        }
+      }
+      for (uint32_t step = P >> 1; step >= 1u; step >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t probe = pos[c][h] + step - 1u;  // < K + P: inside the padded table
+            if ((int32_t)lds_u32(tab[c] + (probe + (probe >> 5)) * 4u) <= x[c][h]) pos[c][h] += step;
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint32_t r[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          r[h] = pos[c][h] < K[c] ? pos[c][h] : K[c];
+          if (raw[c][h] == miss_raw && tile * kQTile + lt + 512u * (uint32_t)h < n) {  // DTPU.sv:653, before any transform
+            r[h] = kQMissing;
+            any_missing = true;
+          }
+        }
+        q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + lt] = r[0] | (r[1] << 16);
+      }
+    }
+    return any_missing;
+  };
+
+  // (a software pipeline over half-tiles -- next half's loads in flight while this one is ranked -- measured
+  // slower, 21.45 vs 20.58 ms end to end at 125 trees: at 128 VGPRs it spills; 16 waves hide the latency well enough)
+  // a wave takes 4 units (half a tile) per grab: one grab per unit made 781 k same-address atomics per 100 M rows
+  // the bottleneck (measured 9.3 instead of 5.4 ms)
+  const unsigned long long units = (unsigned long long)tiles * 8u;
+  for (;;) {
+    unsigned long long u0 = 0;
+    if ((tid & 63u) == 0u) u0 = atomicAdd(work_counter, 4ull);
+    u0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u0 >> 32)) << 32) |
+         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u0);
+    if (u0 >= units) break;
+    const uint64_t tile = u0 >> 3;
+    bool miss = false;
+    for (uint32_t k = 0; k < 4u; ++k) {
+      const uint32_t lt = ((((uint32_t)u0 & 7u) + k) << 6) | (tid & 63u);
+#pragma unroll
+      for (uint32_t g = 0; g < 2u; ++g) {
+        u32x4 v[2][4];
+        load_half(v, tile, lt, g);
+        miss |= rank_half(v, tile, lt, g);
+      }
+    }
+    if (miss) atomicOr(&tile_flags[tile], 1u);
+  }
+}
+
 // walk over 4-byte records {R (lo16), feature row byte offset (hi16, bit 16 = miss_right in the slow image)};
 // m4 = 4 * (1-based heap index); leaves start at byte 4*2^D of the tree, so leaf address = tree + m4.
 template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW>
@@ -939,13 +1059,23 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds);
   if (e != hipSuccess) return e;
   if (!x.skip_prepass) {
-    e = hipMemsetAsync(x.tile_flags, 0, tiles * 4, s);
+    // tile flags + (8-byte aligned, right behind them) the work counter of the fused pre-pass
+    unsigned long long* counter = reinterpret_cast<unsigned long long*>(x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u));
+    e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u) * 4, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
-    uint32_t bx = (uint32_t)((x.n_pad / kQTile + 3) / 4);  // 4 tiles (kRankThreads x 4 rows) per block and pass
-    if (bx > 512u) bx = 512u;  // grid-stride over tiles; blockIdx.y = feature (the table is loaded once per block)
-    hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabP, x.tabS, a.miss_raw,
-                       a.ieee, W, x.q, x.tile_flags);
+    if (x.fused_bytes) {  // small tables: one fused kernel, all tables resident in LDS
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.fused_bytes);
+      if (e != hipSuccess) return e;
+      const uint32_t grid = (tiles + 1u) / 2u < 256u ? (uint32_t)((tiles + 1u) / 2u) : 256u;  // at most one block per CU
+      hipLaunchKernelGGL(fused_rank_kernel, dim3(grid), dim3(kFusedThreads), x.fused_bytes, s, a.tuples, a.n, x.n_pad, W, x.fused_img,
+                         x.fused_bytes, x.fused_par_off, x.fused_P, a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
+    } else {
+      hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
+      uint32_t bx = (uint32_t)((x.n_pad / kQTile + 3) / 4);  // 4 tiles (kRankThreads x 4 rows) per block and pass
+      if (bx > 512u) bx = 512u;  // grid-stride over tiles; blockIdx.y = feature (the table is loaded once per block)
+      hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabP, x.tabS, a.miss_raw,
+                         a.ieee, W, x.q, x.tile_flags);
+    }
   }
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kQTile), lds, s, a, x);

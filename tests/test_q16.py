@@ -51,7 +51,13 @@ def test_auto_selection_and_fallbacks():
     w, f = ddt.synth_model(1000, 8, 32)
     e.load_model(ddt.make_params(1000, 8, 32), w, f)
     assert e.info().variant_name.decode() == "q16_d8_c4_u4"        # many trees: the pre-pass pays off
-    e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)          # 125 trees per engine (8-way shard): fp32 tile kernel
+    e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)          # 125 trees per engine (8-way shard): all rank tables
+    assert e.info().variant_name.decode() == "q16_d8_c4_u4"        # fit LDS together -> fused pre-pass -> q16 still pays
+    e.set_option("q16_fused_prepass", 0)                            # without it the fixed pre-pass cost is too high
+    e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)
+    assert e.info().variant_name.decode() == "d8_t1024_r1_c4_u4_dma_f"
+    e.set_option("q16_fused_prepass", 1)
+    e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 16)         # 63 trees: below the break-even either way
     assert e.info().variant_name.decode() == "d8_t1024_r1_c4_u4_dma_f"
     # too many distinct thresholds on one feature for 16-bit ranks: 2000 trees x 255 nodes on 4 features
     w, f = ddt.synth_model(2000, 8, 4)
@@ -138,4 +144,22 @@ def test_short_batches_do_not_read_past_the_tuples(n):
     e.set_option("feeder_rows", 1 << 20)
     got = e.score(x)
     assert np.array_equal(got.view(np.uint32), O.score(m, x).view(np.uint32))
+    e.close()
+
+
+@pytest.mark.parametrize("cmp_mode", [0, 1])
+def test_fused_and_two_kernel_prepass_agree(cmp_mode):
+    """Small tables: the fused pre-pass (all tables in LDS) and the transpose + rank kernels must give identical
+    scores, missing values and negatives included; ragged batch (last tile partly filled)."""
+    T, D, F, n = 100, 8, 28, 5 * 1024 + 333
+    m = O.gen_model(T, D, F, dist=1, cmp_mode=cmp_mode)
+    x = O.gen_tuples(31, n, F, dist=1)
+    want = O.score(m, x)
+    e = ddt.Engine(0)
+    e.set_option("variant", _variant("q16_d8_c4_u4"))
+    for fused in (1, 0):
+        e.set_option("q16_fused_prepass", fused)
+        e.load_model(_params(m), m.wlines, m.flines)
+        got = e.score(x)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"fused={fused}"
     e.close()

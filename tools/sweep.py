@@ -23,8 +23,12 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="", help="substring filter on variant names")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep.json"))
+    ap.add_argument("--opt", default="", help="engine options, comma separated key=value (e.g. q16_fused_prepass=0)")
     a = ap.parse_args()
     eng = ddt.Engine(0)
+    for kv in filter(None, a.opt.split(",")):
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     names = ddt.variant_names()
     res = []
     for shp in a.shapes.split(","):
