@@ -46,7 +46,7 @@ struct Ensemble {
   void* d_tabK = nullptr;   // q16: per-feature search parameters (Q16Aux::tabP)
   void* d_tabS = nullptr;   // q16: bucket starts (Q16Aux::tabS)
   void* d_fused = nullptr;  // q16, small tables: LDS image of the fused pre-pass (Q16Aux::fused_img)
-  uint32_t fused_bytes = 0, fused_par_off = 0, fused_P = 0;
+  FusedPlan fused;          // geometry of that image (groups of features, one launch per group)
   uint32_t Kpad = 0;
   uint32_t trees() const { return (uint32_t)ids.size(); }
 };
@@ -210,16 +210,18 @@ RankTables rank_tables(const ddt_engine* e) {
   return rt;
 }
 
-// Fused pre-pass (fused_rank_kernel) when every table fits LDS together: exact LDS image = per feature a skewed
-// table of K + P keys (INT_MAX pads), then all bucket starts, then 8 parameter words per feature
-// {K, lo, shift, table byte offset, starts byte offset, 0, 0, 0}.  Returns false (image left empty) when it does
-// not fit; `fimg` may be NULL to only ask the question.
-bool build_fused_image(const RankTables& rt, uint32_t W, std::vector<uint32_t>* fimg, uint32_t* par_off, uint32_t* P_out) {
-  std::vector<uint32_t> tab_off(W), cnt, lo(W, 0x7FFFFFFFu), shift(W, 0u);
-  std::vector<std::vector<uint16_t>> starts(W, std::vector<uint16_t>(kQ16FusedBuckets, 0));
+// Fused pre-pass (fused_rank_kernel): the features are cut into G = 1 or 2 groups of 8 / 4 tuple lines
+// (32 / 16 features) such that the tables of ONE group fit a CU's LDS; one launch per group.  Exact LDS image
+// of a group = per feature a skewed table of K + P keys (INT_MAX pads), then the bucket starts, then 8 parameter
+// words per feature {K, lo, shift, table byte offset, starts byte offset, 0, 0, 0}; the images are concatenated.
+// Returns false when even G = 2 does not fit (plan.groups = 0); `fimg` may be NULL to only ask the question.
+bool build_fused_group(const RankTables& rt, uint32_t f0, uint32_t f1, std::vector<uint32_t>* img, uint32_t* par_off, uint32_t* P_out) {
+  const uint32_t nf = f1 - f0;
+  std::vector<uint32_t> tab_off(nf), cnt, lo(nf, 0x7FFFFFFFu), shift(nf, 0u);
+  std::vector<std::vector<uint16_t>> starts(nf, std::vector<uint16_t>(kQ16FusedBuckets, 0));
   uint32_t P = 1;
-  for (uint32_t j = 0; j < W; ++j) {
-    const std::vector<uint32_t>& k = rt.keys[j];
+  for (uint32_t j = 0; j < nf; ++j) {
+    const std::vector<uint32_t>& k = rt.keys[f0 + j];
     if (k.empty()) continue;
     lo[j] = k.front();
     const uint32_t span = k.back() - k.front();  // int32 order: the difference fits 32 bits
@@ -234,27 +236,27 @@ bool build_fused_image(const RankTables& rt, uint32_t W, std::vector<uint32_t>* 
     }
   }
   size_t words = 0;
-  for (uint32_t j = 0; j < W; ++j) {
-    const uint32_t len = (uint32_t)rt.keys[j].size() + P;  // the search reads indices < K + P
+  for (uint32_t j = 0; j < nf; ++j) {
+    const uint32_t len = (uint32_t)rt.keys[f0 + j].size() + P;  // the search reads indices < K + P
     tab_off[j] = (uint32_t)words * 4u;
     words += len + (len >> 5) + 1u;
   }
   words = (words + 3u) & ~(size_t)3u;
   const size_t starts_word0 = words;
-  words += (size_t)W * kQ16FusedBuckets / 2u;
+  words += (size_t)nf * kQ16FusedBuckets / 2u;
   const uint32_t poff = (uint32_t)words * 4u;
-  words += (size_t)W * 8u;
+  words += (size_t)nf * 8u;
   if (words * 4u > kMaxLdsBytes) return false;
-  if (par_off) *par_off = poff;
-  if (P_out) *P_out = P;
-  if (!fimg) return true;
-  fimg->assign(words, 0x7FFFFFFFu);
-  for (uint32_t j = 0; j < W; ++j) {
-    const std::vector<uint32_t>& k = rt.keys[j];
-    for (uint32_t i = 0; i < k.size(); ++i) (*fimg)[tab_off[j] / 4u + i + (i >> 5)] = k[i];
-    uint16_t* S = reinterpret_cast<uint16_t*>(fimg->data() + starts_word0) + (size_t)j * kQ16FusedBuckets;
+  *par_off = poff;
+  *P_out = P;
+  if (!img) return true;
+  img->assign(words, 0x7FFFFFFFu);
+  for (uint32_t j = 0; j < nf; ++j) {
+    const std::vector<uint32_t>& k = rt.keys[f0 + j];
+    for (uint32_t i = 0; i < k.size(); ++i) (*img)[tab_off[j] / 4u + i + (i >> 5)] = k[i];
+    uint16_t* S = reinterpret_cast<uint16_t*>(img->data() + starts_word0) + (size_t)j * kQ16FusedBuckets;
     std::copy(starts[j].begin(), starts[j].end(), S);
-    uint32_t* Pp = fimg->data() + poff / 4u + (size_t)j * 8u;
+    uint32_t* Pp = img->data() + poff / 4u + (size_t)j * 8u;
     Pp[0] = (uint32_t)k.size();
     Pp[1] = lo[j];
     Pp[2] = shift[j];
@@ -263,6 +265,45 @@ bool build_fused_image(const RankTables& rt, uint32_t W, std::vector<uint32_t>* 
     Pp[5] = Pp[6] = Pp[7] = 0u;
   }
   return true;
+}
+
+bool build_fused_image(const RankTables& rt, uint32_t W, std::vector<uint32_t>* fimg, FusedPlan* plan) {
+  plan->groups = 0;
+  for (uint32_t G = 1; G <= 2u; G <<= 1) {  // G = 4 (each launch re-reads the half rows) measured slower than transpose + rank: 69.4 vs 67.4 ms at 500 trees
+    const uint32_t lines = 8u / G;  // tuple lines (4 features each) per group
+    std::vector<std::vector<uint32_t>> imgs(G);
+    FusedPlan pl{};
+    bool ok = true;
+    uint32_t used = 0;
+    for (uint32_t g = 0; g < G && ok; ++g) {
+      const uint32_t f0 = g * lines * 4u < W ? g * lines * 4u : W, f1 = (g + 1u) * lines * 4u < W ? (g + 1u) * lines * 4u : W;
+      if (f0 == f1) continue;  // narrow tuples: trailing groups are empty
+      ok = build_fused_group(rt, f0, f1, fimg ? &imgs[used] : nullptr, &pl.par_off[used], &pl.P[used]);
+      pl.line_lo[used] = g * lines;
+      pl.line_hi[used] = (g + 1u) * lines;
+      ++used;
+    }
+    if (!ok) continue;
+    size_t off = 0;
+    if (fimg) fimg->clear();
+    for (uint32_t g = 0; g < used; ++g) {
+      if (fimg) {
+        pl.img_off[g] = (uint32_t)off;
+        pl.bytes[g] = (uint32_t)(imgs[g].size() * 4u);
+        fimg->insert(fimg->end(), imgs[g].begin(), imgs[g].end());
+        off += imgs[g].size() * 4u;
+      }
+    }
+    pl.groups = used;
+    *plan = pl;
+    return true;
+  }
+  return false;
+}
+
+uint32_t fused_plan_groups(const ddt_engine* e) {
+  FusedPlan pl;
+  return build_fused_image(rank_tables(e), tuple_words(e->p), nullptr, &pl) ? pl.groups : 0u;
 }
 
 uint32_t total_trees(const ddt_engine* e) {
@@ -309,7 +350,7 @@ int auto_variant(const ddt_engine* e) {
   // break-even drops accordingly (kQ16MinTreesFused).
   uint32_t q16_min = 224u;
   if (e->q16_fused_prepass && tuple_words(e->p) <= 32u && total_trees(e) >= kQ16MinTreesFused && total_trees(e) < 224u &&
-      build_fused_image(rank_tables(e), tuple_words(e->p), nullptr, nullptr, nullptr))
+      fused_plan_groups(e) >= 1u)
     q16_min = kQ16MinTreesFused;
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
     static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4"};
@@ -447,8 +488,8 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
     }
   }
   std::vector<uint32_t> fimg;
-  uint32_t fused_par_off = 0, fused_P = 1;
-  if (upload_tables) (void)build_fused_image(rt, W, &fimg, &fused_par_off, &fused_P);
+  FusedPlan fplan{};
+  if (upload_tables) (void)build_fused_image(rt, W, &fimg, &fplan);
   const uint32_t row = v.tile() * 2u;  // bytes per feature row of the u16 tile
   for (uint32_t i = 0; i < T; ++i) {
     uint32_t* t = fast.data() + (size_t)i * tree_words;
@@ -482,13 +523,11 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
     HIP_TRY(e, hipMemcpy(m.d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(m.d_tabK, tabK.data(), tabK.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(m.d_tabS, tabS.data(), tabS.size() * 2, hipMemcpyHostToDevice));
-    m.fused_bytes = 0;
-    if (!fimg.empty()) {
+    m.fused = FusedPlan{};
+    if (fplan.groups && !fimg.empty()) {
       HIP_TRY(e, hipMalloc(&m.d_fused, fimg.size() * 4));
       HIP_TRY(e, hipMemcpy(m.d_fused, fimg.data(), fimg.size() * 4, hipMemcpyHostToDevice));
-      m.fused_bytes = (uint32_t)(fimg.size() * 4);
-      m.fused_par_off = fused_par_off;
-      m.fused_P = fused_P;
+      m.fused = fplan;
     }
   }
   m.img_bytes = bytes;
@@ -512,7 +551,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint32_t W = tuple_words(e->p);
   HIP_TRY(e, hipMalloc(&e->q_xT[k], rows * W * 4));
   HIP_TRY(e, hipMalloc(&e->q_q[k], rows * W * 2));
-  HIP_TRY(e, hipMalloc(&e->q_flags[k], (rows / 1024 + 4) * 4));  // + the fused pre-pass's 8-byte work counter
+  HIP_TRY(e, hipMalloc(&e->q_flags[k], (rows / 1024 + 10) * 4));  // + the fused pre-pass's 8-byte work counters (<= 4)
   e->q_rows[k] = rows;
   return DDT_OK;
 }
@@ -606,9 +645,8 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     qa.Kpad = tm.Kpad;
     qa.skip_prepass = reuse_prepass ? 1u : 0u;
     qa.fused_img = reinterpret_cast<const uint4*>(tm.d_fused);
-    qa.fused_bytes = e->q16_fused_prepass ? tm.fused_bytes : 0u;
-    qa.fused_par_off = tm.fused_par_off;
-    qa.fused_P = tm.fused_P;
+    qa.fused = tm.fused;
+    if (!e->q16_fused_prepass) qa.fused.groups = 0;
     qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
     qa.n_pad = (n + 1023) / 1024 * 1024;
     a.aux = &qa;

@@ -46,6 +46,14 @@ struct ScoreArgs {
 constexpr uint32_t kQ16RankBuckets = 4096;
 constexpr uint32_t kQ16FusedBuckets = 256;   // per feature, fused pre-pass (all tables resident in LDS)
 
+// fused rank pre-pass: the features are processed in `groups` launches of fused_rank_kernel, group g covering tuple
+// lines [line_lo, line_hi) with its tables resident in LDS (image = bytes[g] at byte offset img_off[g])
+struct FusedPlan {
+  uint32_t groups = 0;
+  uint32_t img_off[4] = {0, 0, 0, 0}, bytes[4] = {0, 0, 0, 0}, par_off[4] = {0, 0, 0, 0}, P[4] = {1, 1, 1, 1};
+  uint32_t line_lo[4] = {0, 0, 0, 0}, line_hi[4] = {0, 0, 0, 0};
+};
+
 struct Q16Aux {               // device pointers of the rank-quantised path (ScoreArgs::aux)
   uint32_t* xT;               // workspace [W][n_pad]: transposed tuples
   uint16_t* q;                // workspace [tiles][W][1024]: feature ranks
@@ -57,10 +65,8 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   const uint4* img_slow;      // image with the miss_right flags (used by tiles that contain a missing value)
   uint64_t n_pad;             // rows rounded up to whole tiles of 1024
   uint32_t skip_prepass;      // 1 = q / tile_flags already hold this batch (2nd..Kth class of a multi-class model)
-  const uint4* fused_img;     // small tables only: exact LDS image of fused_rank_kernel (tables, bucket starts, parameters)
-  uint32_t fused_bytes;       // its size (0 = use transpose_kernel + rank_kernel)
-  uint32_t fused_par_off;     // byte offset of the per-feature parameter block inside the image
-  uint32_t fused_P;           // power of two > the fullest bucket of any feature
+  const uint4* fused_img;     // fused pre-pass: concatenated LDS images of fused_rank_kernel, one per feature group
+  FusedPlan fused;            // groups == 0: use transpose_kernel + rank_kernel
 };
 
 enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2, kKindQ16 = 3 };

@@ -845,7 +845,7 @@ constexpr uint32_t kFusedBuckets = kQ16FusedBuckets;
 
 __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
                                                                    const uint4* __restrict__ lds_img, uint32_t img_bytes, uint32_t par_off,
-                                                                   uint32_t P, uint32_t miss_raw, uint32_t ieee,
+                                                                   uint32_t P, uint32_t line_lo, uint32_t line_hi, uint32_t miss_raw, uint32_t ieee,
                                                                    uint32_t* __restrict__ q32, uint32_t* __restrict__ tile_flags,
                                                                    unsigned long long* __restrict__ work_counter) {
   const uint32_t tid = threadIdx.x, t4 = tid & 3u, lpt = W / 4u;
@@ -874,13 +874,13 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t line = 4u * g + (uint32_t)i;
-      if (line >= lpt) continue;
+      if (line >= lpt || line < line_lo || line >= line_hi) continue;  // this launch's feature group only
       // the four features of this line x two rows: 8 searches advance together
       uint32_t K[4], tab[4], raw[4][2], pos[4][2];
       int32_t x[4][2];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const uint32_t j = 4u * line + (uint32_t)c;
+        const uint32_t j = 4u * (line - line_lo) + (uint32_t)c;  // feature index inside the group
         const uint4 par = lds_u4(par_off + j * 32u);  // same address in every lane: {K, lo, shift, table_off}
         const uint32_t st = lds_u32(par_off + j * 32u + 16u);
         K[c] = par.x;
@@ -939,6 +939,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
       const uint32_t lt = ((((uint32_t)u0 & 7u) + k) << 6) | (tid & 63u);
 #pragma unroll
       for (uint32_t g = 0; g < 2u; ++g) {
+        if (4u * g >= line_hi || 4u * g + 4u <= line_lo) continue;  // half-row without lines of this group (wave-uniform)
         u32x4 v[2][4];
         load_half(v, tile, lt, g);
         miss |= rank_half(v, tile, lt, g);
@@ -1059,16 +1060,19 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds);
   if (e != hipSuccess) return e;
   if (!x.skip_prepass) {
-    // tile flags + (8-byte aligned, right behind them) the work counter of the fused pre-pass
+    // tile flags + (8-byte aligned, right behind them) one work counter per launch of the fused pre-pass
     unsigned long long* counter = reinterpret_cast<unsigned long long*>(x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u));
-    e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u) * 4, s);
+    e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 8u) * 4, s);
     if (e != hipSuccess) return e;
-    if (x.fused_bytes) {  // small tables: one fused kernel, all tables resident in LDS
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.fused_bytes);
-      if (e != hipSuccess) return e;
+    if (x.fused.groups) {  // the tables of a feature group fit LDS: fused kernel(s), no transposed intermediate
       const uint32_t grid = (tiles + 1u) / 2u < 256u ? (uint32_t)((tiles + 1u) / 2u) : 256u;  // at most one block per CU
-      hipLaunchKernelGGL(fused_rank_kernel, dim3(grid), dim3(kFusedThreads), x.fused_bytes, s, a.tuples, a.n, x.n_pad, W, x.fused_img,
-                         x.fused_bytes, x.fused_par_off, x.fused_P, a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
+      for (uint32_t g = 0; g < x.fused.groups; ++g) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.fused.bytes[g]);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fused_rank_kernel, dim3(grid), dim3(kFusedThreads), x.fused.bytes[g], s, a.tuples, a.n, x.n_pad, W,
+                           x.fused_img + x.fused.img_off[g] / 16u, x.fused.bytes[g], x.fused.par_off[g], x.fused.P[g], x.fused.line_lo[g],
+                           x.fused.line_hi[g], a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter + g);
+      }
     } else {
       hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
       uint32_t bx = (uint32_t)((x.n_pad / kQTile + 3) / 4);  // 4 tiles (kRankThreads x 4 rows) per block and pass
