@@ -592,6 +592,7 @@ void fill_args(const ddt_engine* e, const Ensemble& m, const void* d_tuples, siz
   a->ieee = e->p.cmp_mode;
   a->sum_mode = e->p.sum_mode;
   a->aux = nullptr;
+  a->top_levels = 0;
   a->ev_mid = nullptr;
 }
 
@@ -933,7 +934,7 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   out->lds_bytes = v.kind == kKindTile     ? v.lds_bytes(out->tuple_words)
                    : v.kind == kKindStream ? v.lds_bytes_stream(m0.img_trees, out->tuple_words)
                    : v.kind == kKindQ16    ? v.lds_bytes_q16(out->tuple_words)
-                                           : generic_lds_bytes(e->p.num_levels, out->tuple_words, nullptr, nullptr);
+                                           : generic_lds_bytes(e->p.num_levels, out->tuple_words, nullptr, nullptr, nullptr);
   out->model_bytes_unpadded = (uint64_t)trees * (4ull * ((2ull << e->p.num_levels) - 1) + 2ull * ((1ull << e->p.num_levels) - 1));
   out->image_bytes = img;
   out->num_classes = e->num_classes;

@@ -40,6 +40,7 @@ struct ScoreArgs {
   uint32_t ieee;           // 1: stage features through the IEEE order-preserving key transform
   uint32_t sum_mode;       // 0 reference-order fp32, 1 fp64 sequential
   const void* aux;         // kind-specific extras (Q16Aux for the rank-quantised path), else NULL
+  uint32_t top_levels;     // generic kernel, deep trees: levels of each tree staged in LDS (set by launch_generic)
   hipEvent_t ev_mid;       // optional ("kernel_timing"): recorded right before the scoring kernel proper
 };
 
@@ -116,7 +117,7 @@ const Variant& variant(int i);
 // generic kernel geometry (runtime D; see ddt_kernels.hip)
 constexpr int kGenericThreads = 256;
 hipError_t launch_generic(const ScoreArgs& a, const Variant& v, hipStream_t s);
-uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds);
+uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds, uint32_t* top_levels);
 uint32_t stream_blocks_per_cu(uint32_t lds_bytes);
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s);

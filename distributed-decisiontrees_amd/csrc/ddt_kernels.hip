@@ -1094,14 +1094,27 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kGenericLdsBudget = 150u * 1024u;
 
-uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds) {
+uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds, uint32_t* top_levels) {
   const uint64_t feat = (uint64_t)tuple_words * kGenericThreads * 4u;
   const uint64_t tree = 12ull << levels;
   bool f = feat <= 96u * 1024u;
-  bool t = tree + (f ? feat : 0) <= kGenericLdsBudget;
+  // whole tree in LDS only while it is small: from depth 9 on, re-staging 12*2^D bytes per tree and block costs more
+  // than gathering the lower levels (measured 64 x d12: 3.5 ms vs the staged-top form below)
+  bool t = levels <= 8u && tree + (f ? feat : 0) <= kGenericLdsBudget;
+  // deep trees (config 4): the top levels of the 8 trees of a PU group are staged in LDS, only the lower levels are
+  // gathered from L2/HBM.  As many levels as keep two blocks per CU (80 KiB each), at least 6 if the block fits at all.
+  uint32_t top = 0;
+  if (!t) {
+    const uint64_t base = f ? feat : 0;
+    for (uint32_t d = 1; d < levels && d <= 10u; ++d) {
+      const uint64_t need = base + 8ull * (8ull << d);
+      if (need <= 80u * 1024u || (d <= 6u && need <= kGenericLdsBudget)) top = d;
+    }
+  }
   if (feat_in_lds) *feat_in_lds = f;
   if (tree_in_lds) *tree_in_lds = t;
-  return (uint32_t)((f ? feat : 0) + (t ? tree : 0));
+  if (top_levels) *top_levels = top;
+  return (uint32_t)((f ? feat : 0) + (t ? tree : 0) + (top ? 8ull * (8ull << top) : 0));
 }
 
 template <bool FEAT_LDS, bool TREE_LDS>
@@ -1128,17 +1141,31 @@ __global__ __launch_bounds__(kGenericThreads) void score_generic_kernel(const Sc
   float grp[8];
   for (uint32_t t8 = 0; t8 < a.n_trees; t8 += 8u) {
     if (!TREE_LDS) {
-      // deep trees (nodes in L2 / HBM): the 8 trees of a PU group advance level by level together, so a lane has
-      // 8 independent node loads in flight instead of one dependent chain (config 4: 0.34 -> see profiles/)
+      // deep trees: the top levels of the group's 8 trees are staged in LDS, the lower ones gathered from L2 / HBM;
+      // the 8 trees advance level by level together, so a lane has 8 independent node reads in flight
       const unsigned char* base = reinterpret_cast<const unsigned char*>(a.img) + (size_t)t8 * tree_bytes;
+      const uint32_t DT = a.top_levels, top_bytes = 8u << DT;  // per tree: heap records 0 .. 2^DT - 1
+      if (DT) {
+        __syncthreads();  // previous group's top levels fully consumed
+        for (uint32_t off = tid * 16u; off < 8u * top_bytes; off += TILE * 16u) {
+          const uint32_t tu = off / top_bytes, o = off - tu * top_bytes;
+          lds_st_u4(tree_lds + off, *reinterpret_cast<const uint4*>(base + (size_t)tu * tree_bytes + o));
+        }
+        __syncthreads();
+      }
       uint32_t m[8];
 #pragma unroll
       for (uint32_t tu = 0; tu < 8u; ++tu) m[tu] = 1u;
       for (uint32_t lvl = 0; lvl < D; ++lvl) {
         uint2 nd[8];
+        if (lvl < DT) {  // wave-uniform
 #pragma unroll
-        for (uint32_t tu = 0; tu < 8u; ++tu)
-          nd[tu] = *reinterpret_cast<const uint2*>(base + (size_t)tu * tree_bytes + (size_t)m[tu] * 8u);
+          for (uint32_t tu = 0; tu < 8u; ++tu) nd[tu] = lds_u2(tree_lds + tu * top_bytes + m[tu] * 8u);
+        } else {
+#pragma unroll
+          for (uint32_t tu = 0; tu < 8u; ++tu)
+            nd[tu] = *reinterpret_cast<const uint2*>(base + (size_t)tu * tree_bytes + (size_t)m[tu] * 8u);
+        }
 #pragma unroll
         for (uint32_t tu = 0; tu < 8u; ++tu) {
           const uint32_t j = nd[tu].y & 0x7FFFFFFFu;
@@ -1198,9 +1225,10 @@ __global__ __launch_bounds__(kGenericThreads) void score_generic_kernel(const Sc
   if (valid) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, a.clusters);
 }
 
-hipError_t launch_generic(const ScoreArgs& a, const Variant&, hipStream_t s) {
+hipError_t launch_generic(const ScoreArgs& a_in, const Variant&, hipStream_t s) {
   bool fl, tl;
-  const uint32_t lds = generic_lds_bytes(a.levels, a.tuple_words, &fl, &tl);
+  ScoreArgs a = a_in;
+  const uint32_t lds = generic_lds_bytes(a.levels, a.tuple_words, &fl, &tl, &a.top_levels);
   const uint64_t blocks = (a.n + kGenericThreads - 1) / kGenericThreads;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;

@@ -108,7 +108,7 @@ def test_compare_modes_and_cluster_orders(eng, cmp_mode, clusters):
         assert np.array_equal(_bits(_gpu_score(eng, m, x, 0, v)), _bits(want)), (cmp_mode, clusters, v)
 
 
-@pytest.mark.parametrize("D,F", [(1, 4), (2, 5), (3, 7), (5, 33), (7, 12), (9, 64), (10, 100), (12, 16), (13, 8), (16, 64), (4, 2048), (8, 200)])
+@pytest.mark.parametrize("D,F", [(1, 4), (2, 5), (3, 7), (5, 33), (7, 12), (9, 64), (10, 100), (12, 16), (13, 8), (16, 64), (14, 200), (15, 24), (4, 2048), (8, 200)])
 def test_generic_kernel_covers_odd_shapes(eng, D, F):
     T = 11 if D < 12 else 3
     m = O.gen_model(T, D, F, dist=1)
