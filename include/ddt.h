@@ -142,7 +142,8 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out);
 int ddt_get_stats(const ddt_engine* e, ddt_stats* out);
 const char* ddt_strerror(int code);
 const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure on this engine */
-/* Tuning knobs: "variant" (kernel variant id, -1 = auto), "feeder_rows" (rows per feeder chunk), "kernel_timing"
+/* Tuning knobs: "variant" (kernel variant id, -1 = auto), "feeder_rows" (rows per feeder chunk), "feeder_threads"
+ * (host threads of the staging copy, default 8), "kernel_timing"
  * (see ddt_stats), "q16_fused_prepass" (1 = default; 0 = always use the two-kernel rank pre-pass). */
 int ddt_set_option(ddt_engine* e, const char* key, int64_t value);
 int ddt_num_variants(void);

@@ -15,11 +15,13 @@ e = ddt.Engine(0)
 w, f = ddt.synth_model(T, D, F)
 e.load_model(ddt.make_params(T, D, F), w, f)
 x = ddt.synth_tuples_host(0, N, F)
-for rows in (1 << 16, 1 << 18, 1 << 20, 1 << 22):
-    e.set_option("feeder_rows", rows)
-    e.score(x[: rows * 2])
-    t0 = time.perf_counter()
-    out = e.score(x)
-    dt = time.perf_counter() - t0
-    print(f"feeder_rows {rows:>8}: {N / dt / 1e6:8.1f} Mtuples/s  ({N * 132 / dt / 1e9:6.2f} GB/s over PCIe both ways, {dt * 1e3:.1f} ms for {N} tuples)", flush=True)
+for threads in (1, 4, 8, 16):
+    e.set_option("feeder_threads", threads)
+    for rows in (1 << 18, 1 << 20, 1 << 22):
+        e.set_option("feeder_rows", rows)
+        e.score(x[: rows * 2])
+        t0 = time.perf_counter()
+        out = e.score(x)
+        dt = time.perf_counter() - t0
+        print(f"feeder_threads {threads:>2} feeder_rows {rows:>8}: {N / dt / 1e6:8.1f} Mtuples/s  ({N * 132 / dt / 1e9:6.2f} GB/s over PCIe both ways, {dt * 1e3:.1f} ms for {N} tuples)", flush=True)
 e.close()
