@@ -72,7 +72,7 @@ struct ddt_engine {
   int forced_variant = -1;
   int variant_id = 0;
   // feeder
-  size_t feeder_rows = 1u << 18;
+  size_t feeder_rows = 1u << 20;
   int feeder_threads = 8;   // host threads that copy a chunk into the pinned staging buffer (one thread: ~26 GB/s < PCIe)
   hipStream_t fs[2] = {nullptr, nullptr};
   hipEvent_t fe[2] = {nullptr, nullptr};
