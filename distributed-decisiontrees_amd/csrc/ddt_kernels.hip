@@ -858,10 +858,12 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
     const uint32_t line = 4u * g + t4;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint64_t quad_row = tile * kQTile + 512u * (uint32_t)h + (lt & ~3u);
+      // load j: the 16 quads of the wave read 16 CONSECUTIVE rows (16j + quad) -- a linear 2 KiB span per instruction;
+      // after the transposes lane (quad q, t) therefore owns row 16t + q of its 64-row slice (`own` below)
+      const uint64_t slice_row = tile * kQTile + 512u * (uint32_t)h + (lt & ~63u) + ((lt >> 2) & 15u);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint64_t rj = quad_row + (uint64_t)j;
+        const uint64_t rj = slice_row + 16u * (uint32_t)j;
         v[h][j] = (rj < n && line < lpt) ? *reinterpret_cast<const u32x4*>(tuples + rj * W + 4u * line) : u32x4{0u, 0u, 0u, 0u};
       }
     }
@@ -869,7 +871,8 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
   // rank the 16 features of a half-tile; returns "this lane saw a missing value"
   auto rank_half = [&](u32x4 (&v)[2][4], uint64_t tile, uint32_t lt, uint32_t g) -> bool {
     bool any_missing = false;
-    quad_transpose(v[0], t4);  // v[h][i] = line 4g+i of row (tile*1024 + lt + 512h)
+    const uint32_t own = (lt & ~63u) + 16u * t4 + ((lt >> 2) & 15u);  // a permutation of the wave's 64 tuples
+    quad_transpose(v[0], t4);  // v[h][i] = line 4g+i of row (tile*1024 + own + 512h)
     quad_transpose(v[1], t4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -911,12 +914,12 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           r[h] = pos[c][h] < K[c] ? pos[c][h] : K[c];
-          if (raw[c][h] == miss_raw && tile * kQTile + lt + 512u * (uint32_t)h < n) {  // DTPU.sv:653, before any transform
+          if (raw[c][h] == miss_raw && tile * kQTile + own + 512u * (uint32_t)h < n) {  // DTPU.sv:653, before any transform
             r[h] = kQMissing;
             any_missing = true;
           }
         }
-        q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + lt] = r[0] | (r[1] << 16);
+        q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + own] = r[0] | (r[1] << 16);
       }
     }
     return any_missing;
