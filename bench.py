@@ -72,7 +72,10 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            except TypeError:  # older torch: no device_id keyword
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group("gloo")
 
