@@ -356,7 +356,7 @@ int auto_variant(const ddt_engine* e) {
       fused_plan_groups(e) >= 1u)
     q16_min = kQ16MinTreesFused;
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
-    static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4"};
+    static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4", "q16_d4_c64_u8"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
       if (i >= 0 && variant_fits(variant(i), e)) return i;
