@@ -1,19 +1,26 @@
 // ddt_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4).  No MFMA: the path is
-// compare + gather.  Measured binding resources on the headline shape (profiles/):
-// the LDS pipe (2 DS ops per node visit, ~68 % busy) together with VALU issue (~4.6 ops per visit,
-// ~60 % of SIMD issue), at the 16 waves/CU that the 128 KiB feature tile allows.
+// compare + gather.  Measured binding resources on the headline shape (profiles/): the CU's
+// LDS pipe (2 DS ops per node visit) together with VALU issue (4 ops per visit); on the rank-quantised path
+// both sit at 82-90 % of their issue ceilings.
 //
 // Hot path replaced: the DTPU traversal loop + leaf reduce of the reference
 //   rtl/DTEngine/core/DTPU.sv:579-760       read node -> gather feature -> compare -> next node -> leaf
 //   rtl/DTEngine/core/FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131, Core.sv:486-541   leaf sum
 //
-// Three kernels, one mapping (lane = tuple, features of a tile of tuples in LDS feature-major so that
-// bank == lane and the per-lane feature gather is conflict-free for any feature index):
-//   score_tile_kernel    big ensembles: the model streams through LDS in double-buffered chunks (global->LDS
-//                        DMA), U trees walked concurrently per lane, level loop fully unrolled.
-//   score_stream_kernel  small ensembles (whole model resident in LDS): persistent blocks, coalesced tuple
-//                        loads prefetched one tile ahead -- the HBM-bound regime.
-//   score_generic_kernel any depth / any feature count (correctness path).
+// One mapping everywhere (lane = tuple, the features of a tile of tuples in LDS feature-major so that the
+// per-lane feature gather is conflict-free for any feature index); the kernels, in file order:
+//   score_tile_kernel          fp32 features; the model streams through LDS in double-buffered chunks (global->LDS
+//                              DMA), U trees walked concurrently per lane, level loop fully unrolled.
+//   score_tile_persist_kernel  the same walk with one persistent block per CU, a continuous chunk ring across
+//                              tiles and the next tile's tuples prefetched into registers (opt-in _p variants).
+//   score_stream_kernel        small ensembles (whole model resident in LDS): persistent blocks, coalesced tuple
+//                              loads prefetched one tile ahead -- the HBM-bound regime.
+//   transpose_kernel, rank_kernel, fused_rank_kernel, score_q16_kernel
+//                              the rank-quantised path: features replaced exactly by u16 ranks among the model's
+//                              thresholds (two pre-pass flavours), 4-byte node records, 32 waves per CU -- the
+//                              default for big ensembles.
+//   score_generic_kernel       any depth / any feature count; deep trees: top levels staged in LDS, rest gathered.
+//   chain_sum_kernel, argmax_kernel, synth_tuples_kernel   multi-device combine, class labels, bench inputs.
 #include <hip/hip_runtime.h>
 
 #include "ddt_internal.h"
