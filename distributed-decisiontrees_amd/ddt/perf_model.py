@@ -81,3 +81,40 @@ def predict(g: Mi355x, n_trees: int, depth: int, n_features: int, n_gpus: int = 
     t = max(t_score, t_comm) + (0.0 if n_gpus == 1 else min(t_score, t_comm) / 8.0)  # 8 pipelined chunks: one is exposed
     return {"seconds": t, "mtuples_per_s": rows / t / 1e6, "bound": "lds" if t_lds >= t_hbm else "hbm",
             "t_score": t_score, "t_comm": t_comm}
+
+
+# ---- part 3: the engine's own cost model (what ddt_engine.cpp's auto_variant encodes), per GPU ----------------
+@dataclass
+class PathCosts:
+    """Measured on one MI355X, milliseconds per 100 M tuples of 32 fp32 features, depth-8 trees
+    (profiles/r01_final_bench.md, r01_fused_prepass.md, r01_sweep_shard_regime.json, r01_tile_overhead.md)."""
+    q16_ms_per_tree: float = 0.113        # score_q16_kernel: 7.08 T node visits/s
+    fp32_ms_per_tree: float = 0.147       # score_tile_kernel: 5.4 T node visits/s
+    q16_fixed: float = 0.8                # per-tile fixed cost of the q16 scoring kernel
+    fp32_fixed: float = 3.2               # per-tile fixed cost of the fp32 tile kernel (tuple load phase)
+    prepass_two_kernel: float = 10.6      # transpose_kernel + rank_kernel
+    prepass_fused_1: float = 4.8          # fused_rank_kernel, all tables in LDS (<= ~32 k keys)
+    prepass_fused_2: float = 5.6          # two feature groups (<= ~64 k keys)
+    keys_per_group: int = 32_000          # distinct thresholds whose tables (+ pads, bucket starts) fit 160 KiB of LDS
+
+
+def engine_ms(trees: int, depth: int = 8, rows: float = 1e8, c: PathCosts = PathCosts()) -> dict:
+    """Predicted time of one scoring call on one GPU and the path the engine picks (thresholds of auto_variant)."""
+    scale = rows / 1e8 * depth / 8.0
+    keys = trees * (2 ** depth - 1)  # upper bound: every node a distinct threshold
+    pre = c.prepass_fused_1 if keys <= c.keys_per_group else c.prepass_fused_2 if keys <= 2 * c.keys_per_group else c.prepass_two_kernel
+    q16 = pre * rows / 1e8 + (c.q16_fixed + c.q16_ms_per_tree * trees) * scale
+    fp32 = (c.fp32_fixed + c.fp32_ms_per_tree * trees) * scale
+    q16_min = 112 if keys <= 2 * c.keys_per_group else 224
+    path = "q16" if trees >= q16_min else "fp32"
+    return {"path": path, "ms": q16 if path == "q16" else fp32, "q16_ms": q16, "fp32_ms": fp32}
+
+
+def tree_sharded_ms(trees: int, n_gpus: int, depth: int = 8, rows: float = 1e8, g: Mi355x = Mi355x(), chunks: int = 8) -> dict:
+    """Whole-job time of the tree-sharded mode: per-rank scoring of ceil(T/G) trees + the exposed part of the
+    chunk-pipelined all-reduce (the last chunk)."""
+    per = -(-trees // n_gpus)
+    e = engine_ms(per, depth, rows)
+    comm = 0.0 if n_gpus == 1 else rows * 4 / g.allreduce_alg_bytes_per_s * 1e3 / chunks
+    ms = e["ms"] + comm
+    return {"ms": ms, "mtuples_per_s": rows / ms / 1e3, "path": e["path"], "score_ms": e["ms"], "exposed_comm_ms": comm}
