@@ -544,18 +544,21 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
 int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint64_t rows = (n + 1023) / 1024 * 1024;
   const int k = e->q_slot;
-  if (rows <= e->q_rows[k]) return DDT_OK;
+  // the transposed fp32 intermediate is only needed by the two-kernel pre-pass
+  const bool need_xT = !(e->q16_fused_prepass && !e->ens.empty() && e->ens[0].fused.groups);
+  if (rows <= e->q_rows[k] && (!need_xT || e->q_xT[k])) return DDT_OK;
   HIP_TRY(e, hipDeviceSynchronize());
   for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k]}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
+  const uint64_t cap = rows > e->q_rows[k] ? rows : e->q_rows[k];
   e->q_rows[k] = 0;
   const uint32_t W = tuple_words(e->p);
-  HIP_TRY(e, hipMalloc(&e->q_xT[k], rows * W * 4));
-  HIP_TRY(e, hipMalloc(&e->q_q[k], rows * W * 2));
-  HIP_TRY(e, hipMalloc(&e->q_flags[k], (rows / 1024 + 10) * 4));  // + the fused pre-pass's 8-byte work counters (<= 4)
-  e->q_rows[k] = rows;
+  if (need_xT) HIP_TRY(e, hipMalloc(&e->q_xT[k], cap * W * 4));
+  HIP_TRY(e, hipMalloc(&e->q_q[k], cap * W * 2));
+  HIP_TRY(e, hipMalloc(&e->q_flags[k], (cap / 1024 + 10) * 4));  // + the fused pre-pass's 8-byte work counters (<= 4)
+  e->q_rows[k] = cap;
   return DDT_OK;
 }
 
