@@ -244,6 +244,44 @@ def test_full_size_properties(eng, T, D, F, N):
     assert torch.isfinite(a).all()
 
 
+def test_config3_full_batch_and_eight_way_chain(eng):
+    """BASELINE config 3 at its full size (1000 trees x depth 8 x 32 features, 100 M tuples resident in HBM):
+    determinism, batch-split invariance, bit-exact parity on a strided sample, and the 8-way tree-sharded job as
+    "virtual ranks" -- eight shard engines' partial scores chain-added in the reference's hop order -- against the
+    oracle's 8-device model (bit-exact on the sample) and against the single-engine scores (<= 1e-6 relative)."""
+    import torch
+
+    T, D, F, N, G = 1000, 8, 32, 100_000_000, 8
+    w, f = ddt.synth_model(T, D, F)
+    p = ddt.make_params(T, D, F)
+    eng.set_option("variant", -1)
+    eng.load_model(p, w, f)
+    d = eng.synth_tuples_device(0, N, F)
+    a = eng.score_device(d)
+    b = eng.score_device(d)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    del b
+    cut = 37_000_001
+    c = torch.cat([eng.score_device(d[:cut]), eng.score_device(d[cut:])])
+    assert torch.equal(a.view(torch.int32), c.view(torch.int32))
+    del c
+    idx = torch.arange(0, N, 9973, device="cuda")
+    xs = d[idx].cpu().numpy().view(np.uint32)
+    m = O.Model(O.make_params(T, D, F), w, f)
+    assert np.array_equal(_bits(a[idx].cpu().numpy()), _bits(O.score(m, xs)))
+    parts = torch.empty((G, N), dtype=torch.float32, device="cuda")
+    for g in range(G):
+        eng.load_model(p, w, f, g, G)
+        eng.score_device(d, out=parts[g])
+    total = eng.chain_sum_device(parts)
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(total[idx].cpu().numpy()), _bits(O.score(m, xs, n_devices=G)))
+    # north-star tolerance for regrouped fp32 sums: 1e-6 relative to max(|score|, sum |leaf|); sum |leaf| <= 1000 x 0.1
+    assert (total - a).abs().max().item() <= 1e-6 * 100.0
+    eng.load_model(p, w, f)
+
+
 def _two_rank_worker(rank, world, port, mode, ret):
     import torch
     import torch.distributed as dist
