@@ -102,3 +102,35 @@ def test_classes_share_one_rank_prepass():
     labels, cs = e.classify(x, want_scores=True)                 # host feeder: two workspaces in flight
     assert np.array_equal(cs.view(np.uint32), want_cs.view(np.uint32)) and np.array_equal(labels, want_l)
     e.close()
+
+
+@pytest.mark.gpu
+def test_config5_full_batch_properties():
+    """BASELINE config 5 at 10 M rows: deterministic, batch-split invariant, labels and per-class sums bit-exact on a
+    strided sample that the oracle re-scores."""
+    import torch
+
+    T, D, F, K, N = 1000, 8, 32, 10, 10_000_000
+    w, f = ddt.synth_model(T, D, F)
+    C = ddt.default_clusters(T // K)
+    e = ddt.Engine(0)
+    e.load_model_multiclass(ddt.make_params(T, D, F, clusters=C), w, f, K, True)
+    d = e.synth_tuples_device(0, N, F)
+    l1, s1 = e.classify_device(d)
+    l2, s2 = e.classify_device(d)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2) and torch.equal(s1.view(torch.int32), s2.view(torch.int32))
+    cut = 3_333_337
+    la, sa = e.classify_device(d[:cut])
+    lb, sb = e.classify_device(d[cut:])
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([la, lb]), l1)
+    assert torch.equal(torch.cat([sa, sb], dim=1).view(torch.int32), s1.view(torch.int32))
+    idx = torch.arange(0, N, 4999, device="cuda")
+    xs = d[idx].cpu().numpy().view(np.uint32)
+    m = O.Model(O.make_params(T, D, F, clusters=C), w, f)
+    want_l, want_cs = O.classify(m, xs, K, interleaved=True)
+    assert np.array_equal(l1[idx].cpu().numpy(), want_l)
+    assert np.array_equal(s1[:, idx].cpu().numpy().view(np.uint32), want_cs.view(np.uint32))
+    assert len(np.unique(want_l)) == K      # every class wins somewhere: the argmax is not degenerate
+    e.close()
