@@ -282,6 +282,30 @@ def test_config3_full_batch_and_eight_way_chain(eng):
     eng.load_model(p, w, f)
 
 
+def test_config4_shape_full_forest(eng):
+    """BASELINE config 4's shape -- 512 perfect depth-16 trees, 64 features (403 MB of nodes; deep, divergent walks;
+    top levels staged in LDS, lower levels gathered from L2/HBM) -- on 1 M rows: determinism and bit-exact parity on a
+    strided sample."""
+    import torch
+
+    T, D, F, N = 512, 16, 64, 1_000_000
+    w, f = ddt.synth_model(T, D, F)
+    eng.set_option("variant", -1)
+    eng.load_model(ddt.make_params(T, D, F), w, f)
+    assert eng.info().variant_name.decode() == "generic"
+    d = eng.synth_tuples_device(0, N, F)
+    a = eng.score_device(d)
+    b = eng.score_device(d)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    idx = torch.arange(0, N, 997, device="cuda")
+    xs = d[idx].cpu().numpy().view(np.uint32)
+    m = O.Model(O.make_params(T, D, F), w, f)
+    assert np.array_equal(_bits(a[idx].cpu().numpy()), _bits(O.score(m, xs)))
+    w2, f2 = ddt.synth_model(40, 6, 28)  # leave a small model behind for the tests that follow
+    eng.load_model(ddt.make_params(40, 6, 28), w2, f2)
+
+
 def _two_rank_worker(rank, world, port, mode, ret):
     import torch
     import torch.distributed as dist
