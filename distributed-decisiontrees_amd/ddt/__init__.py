@@ -5,7 +5,7 @@ torch device memory / streams / torch.distributed)."""
 from ._lib import Info, Params, Stats, build, lib  # noqa: F401
 from .engine import (DDTError, Engine, default_clusters, findex_lines_per_tree, make_params,  # noqa: F401
                      synth_model, synth_tuples_host, tuple_words, variant_names, weights_lines_per_tree)
-from .sharded import RowShardedScorer, ShardedScorer, chain_sum, shard_bounds  # noqa: F401
+from .sharded import RowShardedScorer, ShardedClassifier, ShardedScorer, chain_sum, shard_bounds  # noqa: F401
 from . import importer  # noqa: F401
 
 CLI_PATH = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__file__)), "bin", "ddt_cli")

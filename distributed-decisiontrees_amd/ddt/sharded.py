@@ -164,3 +164,84 @@ class ShardedScorer:
         for (lo, hi, full, *_rest) in keep:
             out[lo:hi] = full[: hi - lo]
         return out
+
+
+class ShardedClassifier:
+    """BASELINE config 5 across GPUs: every rank holds shard g of EVERY class (ddt_load_model_multiclass with
+    shard_index / shard_count), scores all tuples, the per-class partial sums [K, n] are combined across ranks exactly
+    like the scalar scores of ShardedScorer (an all-reduce, or the deterministic chain), and the argmax runs on the
+    combined sums.  partial_fn(tuples, out[K, m]) writes this rank's partial class scores; argmax_fn([K, n]) -> int32 [n].
+    """
+
+    def __init__(self, partial_fn: Callable, tuple_words: int, num_classes: int, argmax_fn: Callable, group=None,
+                 mode: str = "allreduce", chunk_rows: int = 1 << 22, chain_fn: Optional[Callable] = None):
+        import torch.distributed as dist
+
+        assert mode in ("allreduce", "chain")
+        self.partial_fn, self.W, self.K, self.argmax_fn = partial_fn, tuple_words, int(num_classes), argmax_fn
+        self.group, self.mode, self.chunk_rows = group, mode, int(chunk_rows)
+        self.chain_fn = chain_fn or chain_sum
+        self.G = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.gloo = dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+    @classmethod
+    def from_engine(cls, engine, **kw):
+        from .engine import tuple_words
+
+        def partial(tuples, out):
+            engine.classify_device(tuples, class_scores=out, want_labels=False)
+
+        def chain(parts):
+            return engine.chain_sum_device(parts.contiguous())
+
+        return cls(partial, tuple_words(engine.params.num_features), engine.num_classes, engine.argmax_device,
+                   chain_fn=chain, **kw)
+
+    def _combine(self, pc):
+        """pc: contiguous [K, m] partial sums of this rank -> (combined [K, m] tensor, async work or None)."""
+        import torch
+        import torch.distributed as dist
+
+        G = self.G
+        if G == 1:
+            return pc, None
+        stage = self.gloo and pc.is_cuda  # gloo has no device collectives: stage through host memory (functional mode)
+        if self.mode == "allreduce":
+            if stage:
+                h = pc.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                pc.copy_(h)
+                return pc, None
+            return pc, dist.all_reduce(pc, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        flat = pc.reshape(-1)
+        m = flat.numel()
+        seg = (m + G - 1) // G
+        dev = torch.device("cpu") if stage else pc.device
+        part = torch.zeros(G * seg, dtype=torch.float32, device=dev)
+        part[:m] = flat.to(dev)
+        recv = torch.empty(G * seg, dtype=torch.float32, device=dev)
+        dist.all_to_all_single(recv, part, group=self.group)
+        mine = self.chain_fn(recv.to(pc.device).view(G, seg)).to(dev).contiguous()
+        full = torch.empty(G * seg, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(full, mine, group=self.group)
+        return full[:m].to(pc.device).view(pc.shape), None
+
+    def classify(self, tuples):
+        """tuples [n, W] (replicated on every rank) -> (labels int32 [n], class scores fp32 [K, n]) on every rank."""
+        import torch
+
+        n = tuples.numel() // self.W
+        tuples = tuples.reshape(n, self.W)
+        scores = torch.empty((self.K, n), dtype=torch.float32, device=tuples.device)
+        pending = []
+        for lo in range(0, n, self.chunk_rows):
+            hi = min(n, lo + self.chunk_rows)
+            pc = torch.empty((self.K, hi - lo), dtype=torch.float32, device=tuples.device)
+            self.partial_fn(tuples[lo:hi], pc)
+            pending.append((lo, hi) + self._combine(pc))
+        for lo, hi, comb, work in pending:
+            if work is not None:
+                work.wait()
+            scores[:, lo:hi] = comb
+        return self.argmax_fn(scores), scores

@@ -134,3 +134,55 @@ def test_config5_full_batch_properties():
     assert np.array_equal(s1[:, idx].cpu().numpy().view(np.uint32), want_cs.view(np.uint32))
     assert len(np.unique(want_l)) == K      # every class wins somewhere: the argmax is not degenerate
     e.close()
+
+
+def _sharded_cls_worker(rank, world, port, mode, ret):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        T, D, F, K, n = 1000, 8, 32, 10, 6007
+        w, f = ddt.synth_model(T, D, F)
+        C = ddt.default_clusters(T // K)
+        e = ddt.Engine(0)
+        e.load_model_multiclass(ddt.make_params(T, D, F, clusters=C), w, f, K, True, rank, world)
+        d = e.synth_tuples_device(0, n, F)
+        sc = ddt.ShardedClassifier.from_engine(e, mode=mode, chunk_rows=2500)
+        labels, scores = sc.classify(d)
+        torch.cuda.synchronize()
+        m = O.Model(O.make_params(T, D, F, clusters=C), w, f)
+        want_l, want_cs = O.classify(m, d.cpu().numpy().view(np.uint32), K, interleaved=True, n_devices=world)
+        ret[rank] = bool(np.array_equal(scores.cpu().numpy().view(np.uint32), want_cs.view(np.uint32))
+                         and np.array_equal(labels.cpu().numpy(), want_l))
+        e.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["allreduce", "chain"])
+def test_sharded_classifier_two_ranks_on_one_gpu(mode):
+    """config 5 tree-sharded over 2 ranks (gloo, both on GPU 0): per-class partial sums combined, then argmax --
+    bit-exact with the oracle's 2-device model (a two-term fp32 add is order independent)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_sharded_cls_worker, args=(r, 2, port, mode, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert ret.get(0) and ret.get(1), dict(ret)

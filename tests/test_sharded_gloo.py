@@ -66,3 +66,48 @@ def test_chain_sum_is_the_reference_hop_order():
     parts = torch.tensor([[1.0], [2.0 ** -24], [2.0 ** -24], [2.0 ** -24]], dtype=torch.float32)
     # ((1 + e) + e) + e = 1 (each add ties to even); any pairwise order would give 1 + 2^-23
     assert ddt.chain_sum(parts)[0].item() == 1.0
+
+
+def _cls_worker(rank, world, port, mode, chunk_rows, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        T, D, F, K, n = 96, 5, 12, 4, 777
+        m = O.gen_model(T, D, F, dist=1, clusters=2)
+        x = O.gen_tuples(8, n, F, dist=1)
+        per = T // K  # class-major layout: class k = trees [k*per, (k+1)*per); this rank holds shard `rank` of each class
+
+        def partial(tuples, out):
+            t = tuples.numpy().view(np.uint32)
+            for k in range(K):
+                b, e = ddt.shard_bounds(per, world)[rank]
+                out[k].copy_(torch.from_numpy(O.score_shard(m, t, k * per + b, k * per + e)))
+
+        def argmax(scores):
+            return torch.from_numpy(np.argmax(scores.numpy(), axis=0).astype(np.int32))  # first maximum wins
+
+        sc = ddt.ShardedClassifier(partial, ddt.tuple_words(F), K, argmax, mode=mode, chunk_rows=chunk_rows)
+        labels, scores = sc.classify(torch.from_numpy(x.view(np.int32)))
+        want_l, want_cs = O.classify(m, x, K, interleaved=False, n_devices=world)
+        if mode == "chain" or world == 2:
+            ok = np.array_equal(scores.numpy().view(np.uint32), want_cs.view(np.uint32)) and np.array_equal(labels.numpy(), want_l)
+        else:
+            ok = np.allclose(scores.numpy(), want_cs, rtol=1e-6, atol=1e-6)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode,chunk", [(2, "allreduce", 300), (2, "chain", 300), (4, "chain", 1 << 20), (4, "allreduce", 200)])
+def test_sharded_classifier_gloo(world, mode, chunk):
+    """config 5 across ranks: per-class partial sums combined (all-reduce / deterministic chain), then argmax."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_cls_worker, args=(r, world, port, mode, chunk, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
