@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--sum-mode", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI) is the product path; gloo lets N ranks share one GPU for a functional test")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N=1 only: run the multi-GPU chunk pipeline and the collectives in a one-rank group (overhead / sanity run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -70,7 +72,12 @@ def main():
         sys.exit("bench.py needs a GPU (the scoring path has no CPU fallback)")
     local = local % torch.cuda.device_count() if args.backend == "gloo" else local
     torch.cuda.set_device(local)
-    if world > 1:
+    if world == 1 and args.force_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or args.force_collectives:
         if args.backend == "nccl":
             try:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -92,18 +99,19 @@ def main():
     tuples = eng.synth_tuples_device(0, N, F, 0)          # resident in HBM before the timed region
     out = torch.empty(N, dtype=torch.float32, device=tuples.device)
     scorer = None
-    if world > 1:
+    if world > 1 or args.force_collectives:
         scorer = (ddt.RowShardedScorer(eng) if rows_mode else
-                  ddt.ShardedScorer.from_engine(eng, mode=args.combine, chunk_rows=args.chunk_rows))
+                  ddt.ShardedScorer.from_engine(eng, mode=args.combine, chunk_rows=args.chunk_rows,
+                                                force_collectives=args.force_collectives))
 
     # per-launch HIP-event times of the pass, taken by the library on the launch stream ("kernel_timing"):
     # pre-pass kernels (rank-quantised path only) and the scoring kernel proper
     kernel_ms = []
-    if world == 1:
+    if scorer is None:
         eng.set_option("kernel_timing", 1)
 
     def step(record: bool):
-        if world == 1:
+        if scorer is None:
             eng.score_device(tuples, out=out)
             if record:
                 st = eng.stats()  # waits for this launch's end event
@@ -113,7 +121,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or args.force_collectives:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -206,7 +214,7 @@ def main():
         if parity:
             line["parity"] = parity
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         dist.destroy_process_group()
     eng.close()
 

@@ -87,11 +87,12 @@ class ShardedScorer:
     """
 
     def __init__(self, partial_fn: Callable, tuple_words: int, group=None, mode: str = "allreduce",
-                 chunk_rows: int = 1 << 23, chain_fn: Optional[Callable] = None):
+                 chunk_rows: int = 1 << 23, chain_fn: Optional[Callable] = None, force_collectives: bool = False):
         import torch.distributed as dist
 
         assert mode in ("allreduce", "chain")
         self.partial_fn, self.W, self.group, self.mode = partial_fn, tuple_words, group, mode
+        self.force = bool(force_collectives)  # run the chunk pipeline + collectives even in a one-rank group (sanity / overhead runs)
         self.chunk_rows = int(chunk_rows)
         self.chain_fn = chain_fn or chain_sum
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -121,7 +122,7 @@ class ShardedScorer:
         tuples = tuples.reshape(n, self.W)
         if out is None:
             out = torch.empty(n, dtype=torch.float32, device=tuples.device)
-        if self.G == 1:
+        if self.G == 1 and not self.force:
             self.partial_fn(tuples, out)
             return out
         works, keep = [], []
