@@ -791,14 +791,26 @@ __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __re
   const uint32_t t = tid & 511u, sub = tid >> 9;
   const uint64_t tiles = n_pad / kQTile;
   uint32_t* __restrict__ q32 = reinterpret_cast<uint32_t*>(q);
-  for (uint64_t tile0 = (uint64_t)blockIdx.x * 4u + sub; tile0 < tiles; tile0 += (uint64_t)gridDim.x * 4u) {
-    uint32_t raw[ILP], pos[ILP];
-    int32_t x[ILP];
+  // the column values of the NEXT pass are loaded while this pass searches (a pass is otherwise a serial chain:
+  // HBM read -> 6 dependent LDS reads -> store)
+  const uint64_t pass_stride = (uint64_t)gridDim.x * 4u;
+  auto load_pass = [&](uint32_t (&dst)[ILP], uint64_t tile0) {
 #pragma unroll
     for (int i = 0; i < ILP; ++i) {  // i = 2 * (tile within the pass) + half
       const uint64_t tile = tile0 + 2u * (uint32_t)(i >> 1);
-      const uint64_t row = tile * kQTile + t + 512u * (uint32_t)(i & 1);
-      raw[i] = tile < tiles ? xT[(uint64_t)j * n_pad + row] : 0u;
+      dst[i] = tile < tiles ? xT[(uint64_t)j * n_pad + tile * kQTile + t + 512u * (uint32_t)(i & 1)] : 0u;
+    }
+  };
+  uint32_t raw_next[ILP];
+  load_pass(raw_next, (uint64_t)blockIdx.x * 4u + sub);
+  for (uint64_t tile0 = (uint64_t)blockIdx.x * 4u + sub; tile0 < tiles; tile0 += pass_stride) {
+    uint32_t raw[ILP], pos[ILP];
+    int32_t x[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) raw[i] = raw_next[i];
+    load_pass(raw_next, tile0 + pass_stride);
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) {
       x[i] = (int32_t)(ieee ? ieee_key(raw[i]) : raw[i]);
       uint32_t b = ((uint32_t)x[i] - lo) >> shift;  // wraps to a huge value below lo: selected away next
       b = b < kRankBuckets - 1u ? b : kRankBuckets - 1u;
