@@ -92,7 +92,7 @@ class PathCosts:
     fp32_ms_per_tree: float = 0.147       # score_tile_kernel: 5.4 T node visits/s
     q16_fixed: float = 0.8                # per-tile fixed cost of the q16 scoring kernel
     fp32_fixed: float = 3.2               # per-tile fixed cost of the fp32 tile kernel (tuple load phase)
-    prepass_two_kernel: float = 10.6      # transpose_kernel + rank_kernel
+    prepass_two_kernel: float = 9.8       # transpose_kernel + rank_kernel
     prepass_fused_1: float = 4.8          # fused_rank_kernel, all tables in LDS (<= ~32 k keys)
     prepass_fused_2: float = 5.6          # two feature groups (<= ~64 k keys)
     keys_per_group: int = 32_000          # distinct thresholds whose tables (+ pads, bucket starts) fit 160 KiB of LDS
