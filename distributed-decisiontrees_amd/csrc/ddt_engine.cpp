@@ -343,9 +343,12 @@ int auto_variant(const ddt_engine* e) {
   // small ensembles that fit LDS whole -> streaming kernel (HBM-bound regime); otherwise the tile kernel with
   // the most waves per CU the feature tile allows; anything else -> generic.
   static const char* pref[] = {"stream_d4_u4_l4", "stream_d4_u4_l8", "stream_d6_u4_l4", "stream_d6_u4_l8", "stream_d8_u4_l8",
+                               "stream_d7_u4_l8", "stream_d5_u4_l8", "stream_d3_u4_l8",
                                "d8_t1024_r1_c4_u4_dma_f", "d8_t512_r1_c8_u8_dma_f", "d8_t256_r1_c4_u4_dma",
                                "d6_t1024_r1_c16_u4_dma", "d6_t512_r1_c16_u8_dma", "d6_t256_r1_c16_u4_dma",
-                               "d4_t256_r1_c64_u8_dma"};
+                               "d4_t256_r1_c64_u8_dma",
+                               "d7_t1024_r1_c8_u4_dma", "d7_t256_r1_c8_u4_dma", "d5_t1024_r1_c32_u4_dma", "d5_t256_r1_c32_u4_dma",
+                               "d3_t1024_r1_c128_u8_dma", "d3_t256_r1_c128_u8_dma"};
   // Rank-quantised path: its scoring kernel is ~1.3x faster per tree (32 waves/CU) but it pays a fixed transpose +
   // rank pre-pass per tuple.  Measured per 100 M tuples (profiles/r01_*): q16 = 10.9 ms + 0.113 ms/tree, fp32 tile =
   // 3.2 ms + 0.147 ms/tree => break-even near 200 trees per engine; 250 trees (4-way shard of 1000) goes to q16.
@@ -356,7 +359,7 @@ int auto_variant(const ddt_engine* e) {
       fused_plan_groups(e) >= 1u)
     q16_min = kQ16MinTreesFused;
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
-    static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4", "q16_d4_c64_u8"};
+    static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4", "q16_d5_c32_u4", "q16_d3_c128_u8"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
       if (i >= 0 && variant_fits(variant(i), e)) return i;

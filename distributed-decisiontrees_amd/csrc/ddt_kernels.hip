@@ -1372,6 +1372,10 @@ static const Variant g_variants[] = {
     DDT_Q("q16_d8_c4_u4", 8, 4, 4),
     DDT_Q("q16_d6_c16_u4", 6, 16, 4),
     DDT_Q("q16_d4_c64_u8", 4, 64, 8),
+    // odd depths (XGBoost / scikit-learn defaults 3, 5, 7): same 8 KiB chunks
+    DDT_Q("q16_d7_c8_u4", 7, 8, 4),
+    DDT_Q("q16_d5_c32_u4", 5, 32, 4),
+    DDT_Q("q16_d3_c128_u8", 3, 128, 8),
     // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB.  suffix _f = last level fused with its leaves
     DDT_VP("d8_t1024_r1_c4_u4_dma_fp", 8, 1024, 1, 4, 4, 1, 3),  // _p = persistent blocks + register prefetch
     DDT_V("d8_t1024_r1_c4_u4_dma_f", 8, 1024, 1, 4, 4, 1, 1),
@@ -1388,6 +1392,13 @@ static const Variant g_variants[] = {
     DDT_V("d6_t256_r1_c16_u4_dma", 6, 256, 1, 16, 4, 1, 0),
     // depth 4: tree = 192 B
     DDT_V("d4_t256_r1_c64_u8_dma", 4, 256, 1, 64, 8, 1, 0),
+    // depths 7, 5, 3: 12 KiB chunks like the depth-8 kernel
+    DDT_V("d7_t1024_r1_c8_u4_dma", 7, 1024, 1, 8, 4, 1, 0),
+    DDT_V("d7_t256_r1_c8_u4_dma", 7, 256, 1, 8, 4, 1, 0),
+    DDT_V("d5_t1024_r1_c32_u4_dma", 5, 1024, 1, 32, 4, 1, 0),
+    DDT_V("d5_t256_r1_c32_u4_dma", 5, 256, 1, 32, 4, 1, 0),
+    DDT_V("d3_t1024_r1_c128_u8_dma", 3, 1024, 1, 128, 8, 1, 0),
+    DDT_V("d3_t256_r1_c128_u8_dma", 3, 256, 1, 128, 8, 1, 0),
     // resident-model streaming kernels (small ensembles, HBM-bound; BASELINE config 1 is depth 4)
     DDT_S("stream_d4_u4_l4", 4, 4, 4),
     DDT_S("stream_d4_u8_l4", 4, 8, 4),
@@ -1396,6 +1407,9 @@ static const Variant g_variants[] = {
     DDT_S("stream_d6_u4_l4", 6, 4, 4),
     DDT_S("stream_d6_u4_l8", 6, 4, 8),
     DDT_S("stream_d8_u4_l8", 8, 4, 8),
+    DDT_S("stream_d7_u4_l8", 7, 4, 8),
+    DDT_S("stream_d5_u4_l8", 5, 4, 8),
+    DDT_S("stream_d3_u4_l8", 3, 4, 8),
 };
 
 int num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }

@@ -69,6 +69,11 @@ SHAPES = [
     (9, 8, 20, 515, 1),       # F not a multiple of 4
     (64, 6, 64, 700, 1),
     (16, 4, 8, 300, 1),
+    (90, 7, 20, 3001, 1),     # odd depths have their own tile / stream / rank-quantised variants too
+    (70, 5, 33, 2000, 1),
+    (300, 5, 16, 1500, 0),
+    (200, 3, 12, 2500, 1),
+    (600, 7, 32, 1200, 0),
 ]
 
 
@@ -80,7 +85,7 @@ def test_bit_exact_vs_oracle_all_variants(eng, T, D, F, rows, dist):
     want64 = O.score(m, x, sum_mode=O.SUM_F64_SEQ)
     _, gold = O.score(m, x, want_gold=True)
     vids = _fitting_variants(eng, m)
-    assert 0 in vids and (len(vids) > 1 or D not in (4, 6, 8))
+    assert 0 in vids and (len(vids) > 1 or D not in (3, 4, 5, 6, 7, 8))
     names = ddt.variant_names()
     for v in vids:
         got = _gpu_score(eng, m, x, 0, v)
@@ -114,9 +119,10 @@ def test_generic_kernel_covers_odd_shapes(eng, D, F):
     m = O.gen_model(T, D, F, dist=1)
     x = O.gen_tuples(1, 401, F, dist=1)
     want = O.score(m, x)
-    got = _gpu_score(eng, m, x)
+    got = _gpu_score(eng, m, x, variant=0)  # force the generic kernel: depths 3-8 have specialised variants as well
     assert eng.info().variant_name.decode() == "generic"
     assert np.array_equal(_bits(got), _bits(want))
+    eng.set_option("variant", -1)
 
 
 def test_missing_reset_value_and_all_missing(eng):
