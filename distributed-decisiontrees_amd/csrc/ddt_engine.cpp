@@ -348,7 +348,7 @@ int auto_variant(const ddt_engine* e) {
                                "d6_t1024_r1_c16_u4_dma", "d6_t512_r1_c16_u8_dma", "d6_t256_r1_c16_u4_dma",
                                "d4_t256_r1_c64_u8_dma",
                                "d7_t1024_r1_c8_u4_dma", "d7_t256_r1_c8_u4_dma", "d5_t1024_r1_c32_u4_dma", "d5_t256_r1_c32_u4_dma",
-                               "d3_t1024_r1_c128_u8_dma", "d3_t256_r1_c128_u8_dma"};
+                               "d3_t256_r1_c128_u8_dma"};
   // Rank-quantised path: its scoring kernel is ~1.3x faster per tree (32 waves/CU) but it pays a fixed transpose +
   // rank pre-pass per tuple.  Measured per 100 M tuples (profiles/r01_*): q16 = 10.9 ms + 0.113 ms/tree, fp32 tile =
   // 3.2 ms + 0.147 ms/tree => break-even near 200 trees per engine; 250 trees (4-way shard of 1000) goes to q16.

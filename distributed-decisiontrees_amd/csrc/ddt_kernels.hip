@@ -1397,7 +1397,6 @@ static const Variant g_variants[] = {
     DDT_V("d7_t256_r1_c8_u4_dma", 7, 256, 1, 8, 4, 1, 0),
     DDT_V("d5_t1024_r1_c32_u4_dma", 5, 1024, 1, 32, 4, 1, 0),
     DDT_V("d5_t256_r1_c32_u4_dma", 5, 256, 1, 32, 4, 1, 0),
-    DDT_V("d3_t1024_r1_c128_u8_dma", 3, 1024, 1, 128, 8, 1, 0),
     DDT_V("d3_t256_r1_c128_u8_dma", 3, 256, 1, 128, 8, 1, 0),
     // resident-model streaming kernels (small ensembles, HBM-bound; BASELINE config 1 is depth 4)
     DDT_S("stream_d4_u4_l4", 4, 4, 4),
