@@ -736,6 +736,7 @@ int load_common(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wli
     rc = parse_trees(e, p, reinterpret_cast<const uint32_t*>(wl), reinterpret_cast<const uint16_t*>(fl), std::move(mine), &ens[k]);
     if (rc) return rc;
   }
+  HIP_TRY(e, hipDeviceSynchronize());  // asynchronous scoring of the previous model may still be in flight
   free_images(e);
   free_q16_workspace(e);  // sized for the previous model's tuple width
   e->loaded = false;
@@ -778,6 +779,7 @@ int ddt_create(ddt_engine** out, int device_id) {
 void ddt_destroy(ddt_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();  // asynchronous ddt_*_device work may still read the images / workspaces
   feeder_free(e);
   for (int b = 0; b < 2; ++b) {
     if (e->fs[b]) (void)hipStreamDestroy(e->fs[b]);

@@ -29,6 +29,10 @@ extern "C" {
 
 #define DDT_ABI_VERSION 1
 
+/* Threading: an engine is not thread-safe -- calls on ONE engine must not overlap; different engines (also on the
+ * same device) are independent.  ddt_*_device calls are asynchronous on the given stream; ddt_destroy and
+ * ddt_load_model* wait for the device before freeing or replacing what such work may still read. */
+
 /* Return codes.  The reference has no error signalling beyond status counters (EngineCSR.sv:113-126);
  * every check below is an addition of this library. */
 enum {
