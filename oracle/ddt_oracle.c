@@ -1,8 +1,10 @@
 /*
  * ddt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code; see ddt_oracle.h).
  *
- * *** PARITY UNPINNED ***: the reference (FPGA RTL) has no tests/golden vectors and cannot be run
- * here.  This file restates the RTL's scoring semantics; each function cites the lines it follows.
+ * PARITY: the fp32 adder and the compare rule are pinned against vectors evaluated from the reference's
+ * own RTL source (tests/golden/make_adder_golden.py); *** everything else is UNPINNED *** -- the
+ * reference (FPGA RTL) has no tests/golden vectors and cannot be run here (see ddt_oracle.h).
+ * This file restates the RTL's scoring semantics; each function cites the lines it follows.
  * All paths below are relative to /root/reference/rtl/DTEngine/.
  */
 #include "ddt_oracle.h"
@@ -152,6 +154,14 @@ static inline int orc_less(uint32_t f, uint32_t w, uint32_t cmp_mode) {
   return a < b;
 }
 
+/* The comparison stage, DTPU.sv:653-667: incrementNodeOffset = isFeatureMissing ? isMissingRight : ~isFeatureSmaller.
+ * tests/test_oracle_adder.py checks it against vectors produced by evaluating those RTL assigns themselves
+ * (tests/golden/make_adder_golden.py). */
+uint32_t orc_go_right(uint32_t f, uint32_t w, uint32_t missing_bits, uint32_t miss_right, uint32_t cmp_mode) {
+  if (f == missing_bits) return miss_right & 1u;      /* :653,667 bit-equality with MissingFeatureValue */
+  return (uint32_t)!orc_less(f, w, cmp_mode);         /* :655-657 */
+}
+
 uint32_t orc_traverse(const orc_params* p, const uint32_t* weights_lines, const uint16_t* findex_lines,
                       const uint32_t* tuple, uint32_t tree) {
   /* stride = lines/tree (the published RTL's off-by-one stride quirk is NOT replicated) */
@@ -163,9 +173,7 @@ uint32_t orc_traverse(const orc_params* p, const uint32_t* weights_lines, const 
     const uint32_t j = e & 0x7FFu;                      /* :628 */
     const uint32_t miss_right = (e >> 13) & 1u;         /* :659 (bit 13)  */
     const uint32_t f = tuple[j], thr = w[n];
-    uint32_t right;
-    if (f == p->missing_bits) right = miss_right;       /* :653,667 bit-equality with MissingFeatureValue */
-    else right = !orc_less(f, thr, p->cmp_mode);        /* :655-657 */
+    const uint32_t right = orc_go_right(f, thr, p->missing_bits, miss_right, p->cmp_mode);
     n = 2u * n + 1u + right;                            /* :594-596,710-712 */
   }
   return w[n];                                          /* leaf read through port B, :731-732 */
@@ -197,7 +205,7 @@ static void traverse_range(const orc_params* p, const uint32_t* wl, const uint16
       for (int u = 0; u < 8; ++u) {
         const uint16_t e = f[u][n[u]];
         const uint32_t v = x[e & 0x7FFu], thr = w[u][n[u]];
-        const uint32_t right = (v == miss) ? ((e >> 13) & 1u) : (uint32_t)!orc_less(v, thr, mode);
+        const uint32_t right = orc_go_right(v, thr, miss, (e >> 13) & 1u, mode);
         n[u] = 2u * n[u] + 1u + right;
       }
     for (int u = 0; u < 8; ++u) leaves[i + u] = w[u][n[u]];

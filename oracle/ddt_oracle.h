@@ -9,13 +9,19 @@
  * (fpgasystems/Distributed-DecisionTrees, RTL under rtl/DTEngine/).  Every function cites the
  * reference file:line it follows.  The reference is hardware only (no host software, no CPU
  * scorer, no tests, no golden vectors) and cannot be simulated in this environment (no Verilog
- * simulator, vendor IP missing), so:
+ * simulator, vendor IP missing).  What could be pinned against the reference ITSELF is pinned:
  *
- *      *** PARITY UNPINNED ***  -- there is nothing in the reference to pin this oracle against.
+ *   PINNED    the fp32 adder (orc_fp34_add) and the go-left / go-right rule (orc_go_right): golden vectors
+ *             produced by evaluating the reference's own RTL source text -- common/FPAdder_2cycles_latency.v
+ *             and the comparison-stage assigns of core/DTPU.sv:653-667 -- with the Verilog-subset evaluator of
+ *             tests/golden/make_adder_golden.py (17,884 + 21,072 vectors, tests/test_oracle_adder.py).
  *
- * Mitigations (tests/test_oracle_*.py): hand-computed known-answer tests for every rule, a
- * bit-level model of the reference's FloPoCo fp32 adder cross-checked against IEEE-754 hardware
- * adds on normal operands, and an independent cross-check of the traversal against scikit-learn.
+ *      *** PARITY UNPINNED for everything else *** -- the traversal loop, the stream formats, the order
+ *      in which leaves reach the adders (reduce tree, slot and cluster accumulation, multi-device chain)
+ *      are restated from sequential SystemVerilog that nothing here can execute.
+ *
+ * Mitigations for the unpinned part (tests/test_oracle_*.py): hand-computed known-answer tests for every
+ * rule, an independent numpy restatement, and a cross-check of the traversal against scikit-learn.
  */
 #ifndef DDT_ORACLE_H
 #define DDT_ORACLE_H
@@ -53,6 +59,8 @@ uint64_t orc_fp34_wrap(uint32_t bits);            /* {1'b0, |bits, bits}: FPAdde
 uint32_t orc_fp34_unwrap(uint64_t w);             /* exc==00 ? 0 : w[31:0]: FPAddersReduceTree.sv:141 */
 uint64_t orc_fp34_add(uint64_t x, uint64_t y);    /* FPAdder_8_23_uid2_l2                            */
 uint32_t orc_fpadd_bits(uint32_t a, uint32_t b);  /* unwrap(add(wrap(a), wrap(b)))                   */
+uint32_t orc_go_right(uint32_t f_bits, uint32_t w_bits, uint32_t missing_bits, uint32_t miss_right,
+                      uint32_t cmp_mode);         /* comparison stage, DTPU.sv:653-667                */
 void orc_fpadd_bits_batch(const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n);
 
 /* ---- traversal ------------------------------------------------------------------------------- */

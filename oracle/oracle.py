@@ -1,8 +1,9 @@
 """ctypes binding of oracle/liboracle.so -- the CPU ORACLE (test infrastructure, NOT product code).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module, and only
-as the checker / the reported CPU baseline.  PARITY UNPINNED: the reference (FPGA RTL) ships no tests
-or golden vectors and cannot be simulated here; see oracle/ddt_oracle.h.
+as the checker / the reported CPU baseline.  Parity: adder and compare rule pinned against vectors evaluated
+from the reference's RTL source, everything else UNPINNED (the reference ships no tests or golden vectors and
+cannot be simulated here); see oracle/ddt_oracle.h.
 """
 from __future__ import annotations
 
@@ -57,6 +58,7 @@ def lib():
         L.orc_fp34_unwrap.restype, L.orc_fp34_unwrap.argtypes = u32, [u64]
         L.orc_fp34_add.restype, L.orc_fp34_add.argtypes = u64, [u64, u64]
         L.orc_fpadd_bits.restype, L.orc_fpadd_bits.argtypes = u32, [u32, u32]
+        L.orc_go_right.restype, L.orc_go_right.argtypes = u32, [u32, u32, u32, u32, u32]
         L.orc_fpadd_bits_batch.restype, L.orc_fpadd_bits_batch.argtypes = None, [vp, vp, vp, sz]
         L.orc_traverse.restype, L.orc_traverse.argtypes = u32, [PP, vp, vp, vp, u32]
         L.orc_leaves.restype, L.orc_leaves.argtypes = None, [PP, vp, vp, vp, vp]

@@ -1,0 +1,427 @@
+#!/usr/bin/env python3
+"""Golden vectors for the oracle's fp32 adder model, produced from the REFERENCE'S OWN RTL SOURCE.
+
+The reference sums leaves with a FloPoCo-generated adder, rtl/DTEngine/common/FPAdder_2cycles_latency.v (module
+FPAdder_8_23_uid2_l2: 34-bit operands {exc[1:0], sign, exp[7:0], frac[22:0]}).  No HDL simulator exists in this
+image, so this script is a small evaluator for exactly the Verilog subset that file uses (vhd2vl output: wire/reg
+declarations, continuous assigns, posedge-clk pipeline registers, two `always @(*) case` tables, named-port module
+instances).  Pipeline registers are treated as wires: with constant inputs the registered design settles to the
+combinational function, which is what a 2-cycle-latency adder computes for every operand pair.
+
+The same evaluator runs the four continuous assigns of the reference's comparison stage
+(rtl/DTEngine/core/DTPU.sv:653-667: isFeatureMissing, isFeatureSmaller, isRightChild, incrementNodeOffset) on
+feature / threshold / missing-pattern / flag inputs: golden vectors for the go-left / go-right rule.
+
+Run HERE (needs /root/reference); writes tests/golden/fpadder_rtl_vectors.npz and compare_rtl_vectors.npz, which
+travel with the repo:
+    python tests/golden/make_adder_golden.py
+tests/test_oracle_adder.py then checks oracle/ddt_oracle.c (orc_fp34_add, orc_go_right) against every vector.
+"""
+import os
+import re
+import sys
+
+import numpy as np
+
+SRC = "/root/reference/rtl/DTEngine/common/FPAdder_2cycles_latency.v"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fpadder_rtl_vectors.npz")
+TOP = "FPAdder_8_23_uid2_l2"
+
+
+# ---------------------------------------------------------------------------------------------- lexer / parser
+TOK = re.compile(r"\s*(?:(\d+)\s*'\s*([bBhHdD])\s*([0-9a-fA-F_]+)|(\d+)|([A-Za-z_][A-Za-z_0-9]*)|"
+                 r"(<=|>=|==|!=|&&|\|\||<<|>>|[-+~!&|^?:(){}\[\],<>]))")
+
+
+def tokenize(text):
+    out, pos, text = [], 0, text.strip()
+    while pos < len(text):
+        m = TOK.match(text, pos)
+        if not m:
+            raise SyntaxError(f"cannot tokenize at: {text[pos:pos + 40]!r}")
+        if m.group(1):
+            base = {"b": 2, "h": 16, "d": 10}[m.group(2).lower()]
+            out.append(("lit", int(m.group(3).replace("_", ""), base), int(m.group(1))))
+        elif m.group(4):
+            out.append(("lit", int(m.group(4)), 32))
+        elif m.group(5):
+            out.append(("id", m.group(5)))
+        else:
+            out.append(("op", m.group(6)))
+        pos = m.end()
+    return out
+
+
+class Parser:
+    """Precedence climbing; AST nodes are tuples."""
+
+    def __init__(self, toks):
+        self.t, self.i = toks, 0
+
+    def peek(self):
+        return self.t[self.i] if self.i < len(self.t) else ("eof",)
+
+    def take(self, op=None):
+        tok = self.peek()
+        if op is not None and tok != ("op", op):
+            raise SyntaxError(f"expected {op}, got {tok}")
+        self.i += 1
+        return tok
+
+    def parse(self):
+        e = self.ternary()
+        if self.peek()[0] != "eof":
+            raise SyntaxError(f"trailing tokens {self.t[self.i:]}")
+        return e
+
+    def ternary(self):
+        c = self.binary(0)
+        if self.peek() == ("op", "?"):
+            self.take()
+            a = self.ternary()
+            self.take(":")
+            b = self.ternary()
+            return ("?", c, a, b)
+        return c
+
+    LEVELS = [["||"], ["&&"], ["|"], ["^"], ["&"], ["==", "!="], ["<", "<=", ">", ">="], ["<<", ">>"], ["+", "-"]]
+
+    def binary(self, lvl):
+        if lvl == len(self.LEVELS):
+            return self.unary()
+        left = self.binary(lvl + 1)
+        while self.peek()[0] == "op" and self.peek()[1] in self.LEVELS[lvl]:
+            op = self.take()[1]
+            left = ("bin", op, left, self.binary(lvl + 1))
+        return left
+
+    def unary(self):
+        tok = self.peek()
+        if tok[0] == "op" and tok[1] in ("~", "!", "-"):
+            self.take()
+            return ("un", tok[1], self.unary())
+        return self.primary()
+
+    def primary(self):
+        tok = self.take()
+        if tok[0] == "lit":
+            return tok
+        if tok[0] == "id":
+            if self.peek() == ("op", "["):
+                self.take()
+                hi = self.ternary()
+                lo = hi
+                if self.peek() == ("op", ":"):
+                    self.take()
+                    lo = self.ternary()
+                self.take("]")
+                return ("sel", tok[1], hi, lo)
+            return tok
+        if tok == ("op", "("):
+            e = self.ternary()
+            self.take(")")
+            return e
+        if tok == ("op", "{"):
+            parts = [self.ternary()]
+            while self.peek() == ("op", ","):
+                self.take()
+                parts.append(self.ternary())
+            self.take("}")
+            return ("cat", parts)
+        raise SyntaxError(f"unexpected {tok}")
+
+
+def parse_expr(text):
+    return Parser(tokenize(text)).parse()
+
+
+def const(text):
+    """Integer value of a constant expression such as `8 + 23 + 2`."""
+    return Evaluator(None, {}).ev(parse_expr(text))[0]
+
+
+# ---------------------------------------------------------------------------------------------- module model
+class Module:
+    def __init__(self, name, body):
+        self.name = name
+        self.width, self.inputs, self.outputs = {}, [], []
+        self.assign, self.cases, self.insts = {}, {}, []
+        header, body = body.split(";", 1)
+        # declarations
+        for kind, rng, names in re.findall(r"\b(input|output|wire|reg)\s*(\[[^\]]+\])?\s*([^;]+);", body):
+            w = 1
+            if rng:
+                hi, lo = rng[1:-1].split(":")
+                w = const(hi) - const(lo) + 1
+            for n in [x.strip() for x in names.split(",") if x.strip()]:
+                if kind in ("wire", "reg") and n in self.width and not rng:
+                    continue
+                self.width[n] = w
+                if kind == "input":
+                    self.inputs.append(n)
+                if kind == "output":
+                    self.outputs.append(n)
+        # always blocks: clocked -> the registers become wires; combinational case -> table
+        def clocked(m):
+            for lhs, rhs in re.findall(r"([A-Za-z_0-9]+)\s*<=\s*([^;]+);", m.group(0)):
+                self.assign[lhs] = parse_expr(rhs)
+            return ""
+
+        body = re.sub(r"always\s*@\s*\(\s*posedge[^)]*\)\s*begin.*?\n\s*end\s*\n\s*end", clocked, body, flags=re.S)
+
+        def comb(m):
+            sel = parse_expr(m.group(1))
+            arms, default, target = [], None, None
+            for labels, lhs, rhs in re.findall(r"([^:;]+):\s*([A-Za-z_0-9]+)\s*<=\s*([^;]+);", m.group(2)):
+                target = lhs
+                if labels.strip() == "default":
+                    default = parse_expr(rhs)
+                else:
+                    arms.append(([parse_expr(x) for x in labels.split(",")], parse_expr(rhs)))
+            self.cases[target] = (sel, arms, default)
+            return ""
+
+        body = re.sub(r"always\s*@\s*\(\s*\*\s*\)\s*begin\s*case\s*\((.*?)\)\s*\n(.*?)endcase\s*end", comb, body, flags=re.S)
+        # continuous assigns
+        for lhs, rhs in re.findall(r"\bassign\s+([A-Za-z_0-9]+)\s*=\s*([^;]+);", body):
+            self.assign[lhs] = parse_expr(rhs)
+        body = re.sub(r"\bassign\s+[^;]+;", "", body)
+        # instances: TYPE name( .port(sig), ... );
+        for typ, inst, conns in re.findall(r"\b([A-Za-z_][A-Za-z_0-9]*)\s+([A-Za-z_][A-Za-z_0-9]*)\s*\(\s*(\.[^;]+)\)\s*;", body):
+            ports = {p: parse_expr(e) for p, e in re.findall(r"\.([A-Za-z_0-9]+)\s*\(([^()]*(?:\([^()]*\))?[^()]*)\)", conns)}
+            self.insts.append((typ, inst, ports))
+
+
+def load_modules(path):
+    text = re.sub(r"//[^\n]*", "", open(path).read())
+    mods = {}
+    for name, body in re.findall(r"\bmodule\s+([A-Za-z_0-9]+)\s*\((.*?)\bendmodule", text, flags=re.S):
+        mods[name] = Module(name, body)
+    return mods
+
+
+class Evaluator:
+    """Evaluates one instance of a module for given input values; values are (int, width-or-None)."""
+
+    def __init__(self, mods, inputs, mod=None):
+        self.mods, self.mod, self.val = mods, mod, dict(inputs)
+        self.inst_out = {}
+
+    @staticmethod
+    def mask(v, w):
+        return v & ((1 << w) - 1)
+
+    def get(self, name):
+        if name in self.val:
+            return self.val[name]
+        m = self.mod
+        w = m.width[name]
+        if name in m.assign:
+            v = self.ev(m.assign[name])[0]
+        elif name in m.cases:
+            sel, arms, default = m.cases[name]
+            s = self.ev(sel)[0]
+            v = None
+            for labels, rhs in arms:
+                if any(self.ev(x)[0] == s for x in labels):
+                    v = self.ev(rhs)[0]
+                    break
+            if v is None:
+                v = self.ev(default)[0]
+        else:
+            v = None
+            for typ, inst, ports in m.insts:
+                sub = self.mods[typ]
+                for p, e in ports.items():
+                    if p in sub.outputs and e == ("id", name):
+                        if inst not in self.inst_out:
+                            ins = {q: (self.mask(self.ev(x)[0], sub.width[q]), sub.width[q])
+                                   for q, x in ports.items() if q in sub.inputs and q not in ("clk", "rst", "stall", "seq_stall")}
+                            self.inst_out[inst] = Evaluator(self.mods, ins, sub)
+                        v = self.inst_out[inst].get(p)[0]
+            if v is None:
+                raise KeyError(f"{m.name}.{name} is never driven")
+        self.val[name] = (self.mask(v, w), w)
+        return self.val[name]
+
+    def ev(self, e):
+        k = e[0]
+        if k == "lit":
+            return e[1], e[2]
+        if k == "id":
+            return self.get(e[1])
+        if k == "sel":
+            v, _ = self.get(e[1])
+            hi, lo = self.ev(e[2])[0], self.ev(e[3])[0]
+            return (v >> lo) & ((1 << (hi - lo + 1)) - 1), hi - lo + 1
+        if k == "cat":
+            v, w = 0, 0
+            for p in e[1]:
+                pv, pw = self.ev(p)
+                assert pw is not None, "concatenation of an unsized expression"
+                v, w = (v << pw) | self.mask(pv, pw), w + pw
+            return v, w
+        if k == "?":
+            c = self.ev(e[1])[0]
+            a, b = self.ev(e[2]), self.ev(e[3])
+            w = None if a[1] is None or b[1] is None else max(a[1], b[1])
+            return (a[0] if c else b[0]), w
+        if k == "un":
+            v, w = self.ev(e[2])
+            if e[1] == "~":
+                return (~v if w is None else self.mask(~v, w)), w
+            if e[1] == "!":
+                return int(v == 0), 1
+            return -v, None
+        if k == "bin":
+            op = e[1]
+            (a, wa), (b, wb) = self.ev(e[2]), self.ev(e[3])
+            w = None if wa is None or wb is None else max(wa, wb)
+            if op in ("==", "!=", "<", "<=", ">", ">=", "&&", "||"):
+                r = {"==": a == b, "!=": a != b, "<": a < b, "<=": a <= b, ">": a > b, ">=": a >= b,
+                     "&&": bool(a) and bool(b), "||": bool(a) or bool(b)}[op]
+                return int(r), 1
+            if op in ("&", "|", "^"):
+                return {"&": a & b, "|": a | b, "^": a ^ b}[op], w
+            if op == "+":
+                return a + b, None   # unbounded: masked to the width of the assignment target (context-determined)
+            if op == "-":
+                return a - b, None
+            if op == "<<":
+                return a << b, None
+            if op == ">>":
+                return a >> b, wa
+        raise NotImplementedError(e)
+
+
+def rtl_add(mods, X, Y):
+    ev = Evaluator(mods, {"X": (X, 34), "Y": (Y, 34)}, mods[TOP])
+    return ev.get("R")[0]
+
+
+# ---------------------------------------------------------------------------------------------- vectors
+def wrap(bits):
+    """FPAddersReduceTree.sv:94-95: exc = {1'b0, |bits}."""
+    return ((1 if bits else 0) << 32) | bits
+
+
+def vectors():
+    rng = np.random.default_rng(20260921)
+    xs, ys = [], []
+
+    def add(a, b):
+        xs.append(int(a))
+        ys.append(int(b))
+
+    # (a) what the engine feeds the adder: wrapped fp32 bit patterns, mixed magnitudes and signs
+    f = (rng.standard_normal(6000) * 10.0 ** rng.uniform(-6, 6, 6000)).astype(np.float32).view(np.uint32)
+    g = (rng.standard_normal(6000) * 10.0 ** rng.uniform(-6, 6, 6000)).astype(np.float32).view(np.uint32)
+    for a, b in zip(f, g):
+        add(wrap(int(a)), wrap(int(b)))
+    # leaves-like values: |v| <= 0.1 and partial sums up to a few units
+    f = ((rng.random(4000) - 0.5) * 0.2).astype(np.float32).view(np.uint32)
+    g = ((rng.random(4000) - 0.5) * 8.0).astype(np.float32).view(np.uint32)
+    for a, b in zip(f, g):
+        add(wrap(int(a)), wrap(int(b)))
+    # (b) adversarial: same / adjacent exponents with opposite signs (cancellation, LZC up to 27), ties to even,
+    #     alignment distances around the 24/25/26 boundary, carries into the exponent, exponent 254 -> overflow
+    for _ in range(5000):
+        e = int(rng.integers(1, 255))
+        d = int(rng.choice([0, 0, 1, 1, 2, 3, 22, 23, 24, 25, 26, 27, 30]))
+        e2 = max(1, e - d)
+        fa = int(rng.integers(0, 1 << 23))
+        fb = int(rng.choice([fa, fa ^ 1, fa + 1 & 0x7FFFFF, int(rng.integers(0, 1 << 23)), 0, 0x7FFFFF, 0x400000]))
+        sa, sb = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        add(wrap((sa << 31) | (e << 23) | fa), wrap((sb << 31) | (e2 << 23) | fb))
+    for fa in (0, 1, 2, 3, 0x7FFFFE, 0x7FFFFF, 0x400000, 0x3FFFFF):   # round-to-nearest-even corner patterns
+        for fb in (0, 1, 0x400000, 0x7FFFFF, 0x600000, 0x200000, 0x000001, 0x000003):
+            for d in (0, 1, 2, 23, 24, 25):
+                for s in (0, 1):
+                    add(wrap((100 << 23) | fa), wrap((s << 31) | ((100 - d) << 23) | fb))
+    # zeros, -0, sub-normal bit patterns (treated as normals by the wrapper), exponent 255 patterns
+    special = [0x00000000, 0x80000000, 0x00000001, 0x807FFFFF, 0x00800000, 0x7F7FFFFF, 0xFF7FFFFF, 0x7F800000,
+               0xFF800000, 0x7FC00000, 0x7FFFFFFF, 0x3F800000, 0xBF800000, 0x33800000]
+    for a in special:
+        for b in special:
+            add(wrap(a), wrap(b))
+    # (c) every exception-code combination the 34-bit format allows (00 zero, 01 normal, 10 inf, 11 NaN)
+    for ea in range(4):
+        for eb in range(4):
+            for _ in range(120):
+                pa, pb = int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32))
+                add((ea << 32) | pa, (eb << 32) | pb)
+    return np.array(xs, np.uint64), np.array(ys, np.uint64)
+
+
+# ---------------------------------------------------------------------------------------------- comparison stage
+DTPU = "/root/reference/rtl/DTEngine/core/DTPU.sv"
+OUT_CMP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "compare_rtl_vectors.npz")
+CMP_NAMES = ("isFeatureMissing", "isFeatureSmaller", "isRightChild", "isMissingRight", "incrementNodeOffset")
+
+
+def compare_stage_module():
+    """A Module holding exactly the comparison-stage assigns, text taken verbatim from DTPU.sv."""
+    text = re.sub(r"//[^\n]*", "", open(DTPU).read())
+    m = Module.__new__(Module)
+    m.name, m.inputs, m.outputs, m.assign, m.cases, m.insts = "DTPU_compare", [], [], {}, {}, []
+    m.width = {n: 1 for n in CMP_NAMES}
+    for lhs, rhs in re.findall(r"\bassign\s+(" + "|".join(CMP_NAMES) + r")\s*=\s*([^;]+);", text):
+        m.assign[lhs] = parse_expr(rhs)
+    assert set(m.assign) == set(CMP_NAMES), sorted(m.assign)
+    return m
+
+
+def rtl_go_right(mod, f, w, missing, flags):
+    ev = Evaluator({}, {"features_rd_data": (f, 32), "weight_data_d2": (w, 32), "MissingFeatureValue": (missing, 32),
+                        "feature_index_data_d2": (flags, 3), "DATA_PRECISION": (32, 32)}, mod)
+    return ev.get("incrementNodeOffset")[0]
+
+
+def compare_vectors():
+    rng = np.random.default_rng(7)
+    rows = []
+    interesting = [0x00000000, 0x80000000, 0x00000001, 0x80000001, 0x3F800000, 0xBF800000, 0x7F800000, 0xFF800000,
+                   0x7FC00000, 0xFFC00000, 0x7FFFFFFF, 0xFFFFFFFF, 0x7F7FFFFF, 0xFF7FFFFF, 0x00800000, 0x807FFFFF]
+    for f in interesting:
+        for w in interesting:
+            for miss in (0x7FC00000, 0x00000000, f):
+                for flags in (0, 1, 2, 5):
+                    rows.append((f, w, miss, flags))
+    for _ in range(12000):
+        w = int(rng.integers(0, 1 << 32))
+        f = int(rng.choice([w, (w + 1) & 0xFFFFFFFF, (w - 1) & 0xFFFFFFFF, w ^ 0x80000000, int(rng.integers(0, 1 << 32))]))
+        miss = int(rng.choice([0x7FC00000, 0, f, int(rng.integers(0, 1 << 32))]))
+        rows.append((f, w, miss, int(rng.integers(0, 8))))
+    a = (rng.standard_normal(6000) * 10.0 ** rng.uniform(-3, 3, 6000)).astype(np.float32).view(np.uint32)
+    b = (rng.standard_normal(6000) * 10.0 ** rng.uniform(-3, 3, 6000)).astype(np.float32).view(np.uint32)
+    for f, w in zip(a, b):
+        rows.append((int(f), int(w), 0x7FC00000, int(rng.integers(0, 2))))
+    return np.array(rows, np.uint32)
+
+
+def main():
+    if not os.path.exists(SRC):
+        sys.exit(f"{SRC} not found: run this in the build container (the reference is not on the GPU box)")
+    mods = load_modules(SRC)
+    assert set(mods) >= {TOP, "FPAdder_8_23_uid2_RightShifter_l2", "IntAdder_27_f110_uid6_l2",
+                         "LZCShifter_28_to_28_counting_32_uid16_l2", "IntAdder_34_f110_uid18_l2"}, sorted(mods)
+    X, Y = vectors()
+    R = np.array([rtl_add(mods, int(x), int(y)) for x, y in zip(X, Y)], np.uint64)
+    # self-check of the evaluator on facts that follow from IEEE-754 for normal operands and results
+    one, two = wrap(0x3F800000), wrap(0x40000000)
+    assert rtl_add(mods, one, one) == two and rtl_add(mods, one, wrap(0xBF800000)) >> 32 == 0
+    np.savez_compressed(OUT, X=X, Y=Y, R=R, source=np.array([SRC]))
+    print(f"wrote {OUT}: {len(X)} vectors")
+    cm = compare_stage_module()
+    V = compare_vectors()
+    right = np.array([rtl_go_right(cm, int(f), int(w), int(ms), int(fl)) for f, w, ms, fl in V], np.uint8)
+    # evaluator self-check: for non-negative, non-missing operands the rule is the IEEE "not (f < w)"
+    for f, w, ms, fl, r in zip(V[:, 0], V[:, 1], V[:, 2], V[:, 3], right):
+        if f != ms and f < 0x7F800000 and w < 0x7F800000:
+            assert r == (not (np.uint32(f).view(np.float32) < np.uint32(w).view(np.float32)))
+    np.savez_compressed(OUT_CMP, f=V[:, 0], w=V[:, 1], missing=V[:, 2], flags=V[:, 3], right=right, source=np.array([DTPU]))
+    print(f"wrote {OUT_CMP}: {len(V)} vectors")
+
+
+if __name__ == "__main__":
+    main()
