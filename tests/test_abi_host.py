@@ -107,7 +107,7 @@ def test_shard_bounds_match_oracle_split():
 
 def test_golden_fixtures_still_match_the_oracle():
     gdir = os.path.join(ROOT, "tests", "golden")
-    files = sorted(f for f in os.listdir(gdir) if f.endswith(".npz"))
+    files = sorted(f for f in os.listdir(gdir) if f.endswith(".npz") and not f.endswith("_rtl_vectors.npz"))
     assert len(files) >= 4
     for fn in files:
         g = np.load(os.path.join(gdir, fn))

@@ -174,7 +174,7 @@ def test_error_behaviour(eng):
 def test_golden_fixtures(eng):
     gdir = os.path.join(ROOT, "tests", "golden")
     for fn in sorted(os.listdir(gdir)):
-        if not fn.endswith(".npz"):
+        if not fn.endswith(".npz") or fn.endswith("_rtl_vectors.npz"):
             continue
         g = np.load(os.path.join(gdir, fn))
         T, D, F, miss, wl, fl, cmp_mode, C = [int(v) for v in g["params"]]
