@@ -229,6 +229,18 @@ void orc_leaves_fast(const orc_params* p, const uint32_t* weights_lines, const u
 static inline float f_from(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline uint32_t b_from(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
 
+/* The 8-way adder tree of one PU group, FPAddersReduceTree.sv:88-141: inputs wrapped with exc = {0, |x}, three
+ * levels of FPAdder_8_23 on the 34-bit values, tree_out forced to +0 when the result's exception code is 00.
+ * tests/test_oracle_adder.py checks it against vectors from the elaborated RTL (tests/golden/make_adder_golden.py). */
+uint32_t orc_tree8(const uint32_t* leaf_bits) {
+  uint64_t l[8];
+  for (uint32_t pu = 0; pu < 8; ++pu) l[pu] = orc_fp34_wrap(leaf_bits[pu]);
+  const uint64_t a0 = orc_fp34_add(l[0], l[1]), a1 = orc_fp34_add(l[2], l[3]);
+  const uint64_t a2 = orc_fp34_add(l[4], l[5]), a3 = orc_fp34_add(l[6], l[7]);
+  const uint64_t b0 = orc_fp34_add(a0, a1), b1 = orc_fp34_add(a2, a3);
+  return orc_fp34_unwrap(orc_fp34_add(b0, b1)); /* tree_out, :141 */
+}
+
 static uint32_t reduce_flopoco(const uint32_t* leaves, uint32_t T, uint32_t C) {
   const uint32_t groups = (T + 7u) / 8u;
   const uint32_t slots = (groups + C - 1u) / C; /* trees per PU (CSR205[43:36]); extra slots are EMPTY */
@@ -237,15 +249,12 @@ static uint32_t reduce_flopoco(const uint32_t* leaves, uint32_t T, uint32_t C) {
   for (uint32_t t = 0; t < slots; ++t) {
     for (uint32_t c = 0; c < C; ++c) {
       const uint32_t g = t * C + c;
-      uint64_t l[8];
+      uint32_t l[8];
       for (uint32_t pu = 0; pu < 8; ++pu) {
         const uint32_t i = g * 8u + pu;
-        l[pu] = orc_fp34_wrap(i < T ? leaves[i] : 0u); /* EMPTY slot outputs 0, DTPU.sv:760 */
+        l[pu] = i < T ? leaves[i] : 0u; /* EMPTY slot outputs 0, DTPU.sv:760 */
       }
-      const uint64_t a0 = orc_fp34_add(l[0], l[1]), a1 = orc_fp34_add(l[2], l[3]);
-      const uint64_t a2 = orc_fp34_add(l[4], l[5]), a3 = orc_fp34_add(l[6], l[7]);
-      const uint64_t b0 = orc_fp34_add(a0, a1), b1 = orc_fp34_add(a2, a3);
-      const uint32_t s = orc_fp34_unwrap(orc_fp34_add(b0, b1)); /* tree_out, :141 */
+      const uint32_t s = orc_tree8(l);
       acc[c] = orc_fp34_add(orc_fp34_wrap(s), acc[c]);           /* X = new, Y = running, FPAggregator.v:124-131 */
     }
   }

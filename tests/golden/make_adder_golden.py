@@ -12,8 +12,12 @@ The same evaluator runs the four continuous assigns of the reference's compariso
 (rtl/DTEngine/core/DTPU.sv:653-667: isFeatureMissing, isFeatureSmaller, isRightChild, incrementNodeOffset) on
 feature / threshold / missing-pattern / flag inputs: golden vectors for the go-left / go-right rule.
 
-Run HERE (needs /root/reference); writes tests/golden/fpadder_rtl_vectors.npz and compare_rtl_vectors.npz, which
-travel with the repo:
+And it elaborates the generate loops of the 8-way adder tree (rtl/DTEngine/core/FPAddersReduceTree.sv:88-141: wrap
+exc = {0, |x}, seven FPAdder instances in three levels, tree_out forced to +0 on exception 00): golden vectors
+for the ORDER in which the eight leaves of a PU group are added.
+
+Run HERE (needs /root/reference); writes tests/golden/fpadder_rtl_vectors.npz, compare_rtl_vectors.npz and
+reduce_tree_rtl_vectors.npz, which travel with the repo:
     python tests/golden/make_adder_golden.py
 tests/test_oracle_adder.py then checks oracle/ddt_oracle.c (orc_fp34_add, orc_go_right) against every vector.
 """
@@ -30,7 +34,7 @@ TOP = "FPAdder_8_23_uid2_l2"
 
 # ---------------------------------------------------------------------------------------------- lexer / parser
 TOK = re.compile(r"\s*(?:(\d+)\s*'\s*([bBhHdD])\s*([0-9a-fA-F_]+)|(\d+)|([A-Za-z_][A-Za-z_0-9]*)|"
-                 r"(<=|>=|==|!=|&&|\|\||<<|>>|[-+~!&|^?:(){}\[\],<>]))")
+                 r"(<=|>=|==|!=|&&|\|\||<<|>>|[-+~!&|^?:(){}\[\],<>%]))")
 
 
 def tokenize(text):
@@ -84,7 +88,7 @@ class Parser:
             return ("?", c, a, b)
         return c
 
-    LEVELS = [["||"], ["&&"], ["|"], ["^"], ["&"], ["==", "!="], ["<", "<=", ">", ">="], ["<<", ">>"], ["+", "-"]]
+    LEVELS = [["||"], ["&&"], ["|"], ["^"], ["&"], ["==", "!="], ["<", "<=", ">", ">="], ["<<", ">>"], ["+", "-"], ["%"]]
 
     def binary(self, lvl):
         if lvl == len(self.LEVELS):
@@ -100,6 +104,9 @@ class Parser:
         if tok[0] == "op" and tok[1] in ("~", "!", "-"):
             self.take()
             return ("un", tok[1], self.unary())
+        if tok == ("op", "|"):   # reduction OR in prefix position
+            self.take()
+            return ("un", "r|", self.unary())
         return self.primary()
 
     def primary(self):
@@ -272,6 +279,8 @@ class Evaluator:
                 return (~v if w is None else self.mask(~v, w)), w
             if e[1] == "!":
                 return int(v == 0), 1
+            if e[1] == "r|":
+                return int(v != 0), 1
             return -v, None
         if k == "bin":
             op = e[1]
@@ -291,6 +300,8 @@ class Evaluator:
                 return a << b, None
             if op == ">>":
                 return a >> b, wa
+            if op == "%":
+                return a % b, None
         raise NotImplementedError(e)
 
 
@@ -399,6 +410,129 @@ def compare_vectors():
     return np.array(rows, np.uint32)
 
 
+# ---------------------------------------------------------------------------------------------- 8-way reduce tree
+TREE = "/root/reference/rtl/DTEngine/core/FPAddersReduceTree.sv"
+OUT_TREE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reduce_tree_rtl_vectors.npz")
+
+
+def _match(text, start, open_re, close_re):
+    """Index just past the token that closes the construct opened before `start` (nesting aware)."""
+    depth, pos = 1, start
+    tok = re.compile(f"({open_re})|({close_re})")
+    while depth:
+        m = tok.search(text, pos)
+        if not m:
+            raise SyntaxError("unbalanced construct")
+        depth += 1 if m.group(1) else -1
+        pos = m.end()
+    return pos
+
+
+def _expand_generate(text, consts):
+    """Unroll `for (v = a; v < b; v = v + 1) begin:name ... end` (nested) -> flat statement text."""
+    out, pos = [], 0
+    head = re.compile(r"\bfor\s*\(\s*(\w+)\s*=\s*([^;]+);\s*\w+\s*<\s*([^;]+);[^)]*\)\s*begin\s*:\s*\w+")
+    while True:
+        m = head.search(text, pos)
+        if not m:
+            out.append(text[pos:])
+            break
+        out.append(text[pos:m.start()])
+        end = _match(text, m.end(), r"\bbegin\b", r"\bend\b")
+        body = text[m.end():end - len("end")]
+        var, lo, hi = m.group(1), m.group(2), m.group(3)
+        ev = Evaluator(None, {k: (v, 32) for k, v in consts.items()})
+        for val in range(ev.ev(parse_expr(lo))[0], ev.ev(parse_expr(hi))[0]):
+            inner = re.sub(rf"\b{var}\b", f"({val})", body)
+            out.append(_expand_generate(inner, consts))
+        pos = end
+    return "".join(out)
+
+
+def _flatten_arrays(text, dims, consts):
+    """tree_data[e0][e1][e2] -> tree_data__v0__v1__v2 (indices are elaboration-time constants)."""
+    ev = Evaluator(None, {k: (v, 32) for k, v in consts.items()})
+    out, pos = [], 0
+    pat = re.compile(r"\b(" + "|".join(dims) + r")\s*\[")
+    while True:
+        m = pat.search(text, pos)
+        if not m:
+            out.append(text[pos:])
+            break
+        out.append(text[pos:m.start()])
+        name, p, idx = m.group(1), m.end() - 1, []
+        for _ in range(dims[name]):
+            assert text[p] == "[", text[p:p + 30]
+            q = _match(text, p + 1, r"\[", r"\]")
+            idx.append(ev.ev(parse_expr(text[p + 1:q - 1]))[0])
+            p = q
+            while p < len(text) and text[p].isspace():
+                p += 1
+        out.append(name + "".join(f"__{i}" for i in idx))
+        pos = p
+    return "".join(out)
+
+
+def reduce_tree_module():
+    """The adder tree of FPAddersReduceTree.sv (generate blocks treeLevel1 / treeLevels + the tree_out assign), elaborated
+    for the parameter defaults in the file (NUM_FP_POINTS = 8)."""
+    text = re.sub(r"/\*.*?\*/", "", open(TREE).read(), flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    consts = {k: int(v) for k, v in re.findall(r"parameter\s+(\w+)\s*=\s*(\d+)", text)}
+    lp = re.search(r"localparam\s+(NUM_TREE_LEVELS)\s*=\s*([^;]+);", text)
+    consts[lp.group(1)] = Evaluator(None, {k: (v, 32) for k, v in consts.items()}).ev(parse_expr(lp.group(2)))[0]
+    assert consts["NUM_FP_POINTS"] == 8 and consts["NUM_TREE_LEVELS"] == 3, consts
+    flat = ""
+    for g in re.findall(r"\bgenerate\b(.*?)\bendgenerate\b", text, flags=re.S):
+        if "FPAdder_8_23_uid2_l2" in g:
+            flat += _expand_generate(re.sub(r"\bgenvar\s+\w+\s*;", "", g), consts)
+    flat += re.search(r"\bassign\s+tree_out\s*=[^;]+;", text).group(0)
+    flat = _flatten_arrays(flat, {"tree_data": 3, "fp_in_vector": 1}, consts)
+    for k, v in consts.items():
+        flat = re.sub(rf"\b{k}\b", str(v), flat)
+    m = Module.__new__(Module)
+    m.name, m.inputs, m.outputs, m.assign, m.cases, m.insts = "FPAddersReduceTree_tree", [], [], {}, {}, []
+    m.width = {"tree_out": 32}
+    for n in set(re.findall(r"\btree_data__\d+__\d+__\d+\b", flat)):
+        m.width[n] = 34
+    for lhs, rhs in re.findall(r"\bassign\s+(\w+)\s*=\s*([^;]+);", flat):
+        m.assign[lhs] = parse_expr(rhs)
+    for k, (typ, inst, conns) in enumerate(re.findall(r"\b(FPAdder_8_23_uid2_l2)\s+(\w+)\s*\(\s*(\.[^;]+)\)\s*;", flat)):
+        ports = {p: parse_expr(e) for p, e in re.findall(r"\.(\w+)\s*\(([^()]*(?:\([^()]*\))?[^()]*)\)", conns)}
+        m.insts.append((typ, f"{inst}_{k}", ports))
+    assert len(m.insts) == 7, len(m.insts)   # 4 + 2 + 1 adders
+    return m
+
+
+def rtl_tree8(mods, tree_mod, leaves):
+    ev = Evaluator(mods, {f"fp_in_vector__{i}": (int(v), 32) for i, v in enumerate(leaves)}, tree_mod)
+    return ev.get("tree_out")[0]
+
+
+def tree_vectors():
+    rng = np.random.default_rng(11)
+    rows = []
+    for _ in range(1500):   # leaves as the models produce them: |v| <= 0.1, mixed sign
+        rows.append(((rng.random(8) - 0.5) * 0.2).astype(np.float32).view(np.uint32))
+    for _ in range(1000):   # wide dynamic range + cancellation inside pairs
+        v = (rng.standard_normal(8) * 10.0 ** rng.uniform(-8, 8, 8)).astype(np.float32)
+        k = int(rng.integers(0, 4))
+        v[2 * k + 1] = -v[2 * k] * np.float32(rng.choice([1.0, 1.0, 1.0000001, 0.5]))
+        rows.append(v.view(np.uint32))
+    for _ in range(500):    # EMPTY slots (+0), -0, and a few special patterns mixed in
+        v = ((rng.random(8) - 0.5) * 4.0).astype(np.float32).view(np.uint32)
+        for i in range(8):
+            r = rng.random()
+            if r < 0.35:
+                v[i] = 0
+            elif r < 0.45:
+                v[i] = 0x80000000
+            elif r < 0.50:
+                v[i] = int(rng.choice([0x00000001, 0x7F7FFFFF, 0xFF7FFFFF, 0x7F800000, 0x7FC00000, 0x00800000]))
+        rows.append(v)
+    return np.array(rows, np.uint32)
+
+
 def main():
     if not os.path.exists(SRC):
         sys.exit(f"{SRC} not found: run this in the build container (the reference is not on the GPU box)")
@@ -421,6 +555,16 @@ def main():
             assert r == (not (np.uint32(f).view(np.float32) < np.uint32(w).view(np.float32)))
     np.savez_compressed(OUT_CMP, f=V[:, 0], w=V[:, 1], missing=V[:, 2], flags=V[:, 3], right=right, source=np.array([DTPU]))
     print(f"wrote {OUT_CMP}: {len(V)} vectors")
+    tm = reduce_tree_module()
+    Lv = tree_vectors()
+    out = np.array([rtl_tree8(mods, tm, row) for row in Lv], np.uint32)
+    # evaluator self-check: on leaf-like values the tree is ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)) in IEEE fp32
+    for row, o in zip(Lv[:1500], out[:1500]):
+        l = row.view(np.float32)
+        want = np.float32(np.float32(np.float32(l[0] + l[1]) + np.float32(l[2] + l[3])) + np.float32(np.float32(l[4] + l[5]) + np.float32(l[6] + l[7])))
+        assert want == 0 or int(want.view(np.uint32)) == int(o), (row, hex(int(o)))
+    np.savez_compressed(OUT_TREE, leaves=Lv, out=out, source=np.array([TREE]))
+    print(f"wrote {OUT_TREE}: {len(Lv)} vectors")
 
 
 if __name__ == "__main__":
