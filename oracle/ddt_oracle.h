@@ -11,16 +11,18 @@
  * scorer, no tests, no golden vectors) and cannot be simulated in this environment (no Verilog
  * simulator, vendor IP missing).  What could be pinned against the reference ITSELF is pinned:
  *
- *   PINNED    the fp32 adder (orc_fp34_add), the go-left / go-right rule (orc_go_right) and the 8-way adder
- *             tree of a PU group (orc_tree8): golden vectors produced by evaluating the reference's own RTL
- *             source text -- common/FPAdder_2cycles_latency.v, the comparison-stage assigns of
- *             core/DTPU.sv:653-667 and the elaborated generate loops of core/FPAddersReduceTree.sv:88-141 --
- *             with the Verilog-subset evaluator of tests/golden/make_adder_golden.py (17,884 + 21,072 + 3,000
- *             vectors, tests/test_oracle_adder.py).
+ *   PINNED    the fp32 adder (orc_fp34_add), the go-left / go-right rule (orc_go_right), the 8-way adder
+ *             tree of a PU group (orc_tree8) and the datapath of the sequential accumulator (orc_aggregate):
+ *             golden vectors produced by evaluating the reference's own RTL source text --
+ *             common/FPAdder_2cycles_latency.v, the comparison-stage assigns of core/DTPU.sv:653-667, the
+ *             elaborated generate loops of core/FPAddersReduceTree.sv:88-141, the wrap / adder wiring /
+ *             next-state / output rules of core/FPAggregator.v -- with the Verilog-subset evaluator of
+ *             tests/golden/make_adder_golden.py (17,884 + 21,072 + 3,000 vectors + 700 sequences,
+ *             tests/test_oracle_adder.py).
  *
  *      *** PARITY UNPINNED for everything else *** -- the traversal loop, the stream formats, the
- *      tree -> PU / cluster schedule and the sequential accumulation (slots, clusters, multi-device chain)
- *      are restated from sequential SystemVerilog that nothing here can execute.
+ *      tree -> PU / cluster schedule, the control of the accumulator (FIFO, latency counter) and the
+ *      multi-device chain are restated from sequential SystemVerilog that nothing here can execute.
  *
  * Mitigations for the unpinned part (tests/test_oracle_*.py): hand-computed known-answer tests for every
  * rule, an independent numpy restatement, and a cross-check of the traversal against scikit-learn.
@@ -62,6 +64,7 @@ uint32_t orc_fp34_unwrap(uint64_t w);             /* exc==00 ? 0 : w[31:0]: FPAd
 uint64_t orc_fp34_add(uint64_t x, uint64_t y);    /* FPAdder_8_23_uid2_l2                            */
 uint32_t orc_fpadd_bits(uint32_t a, uint32_t b);  /* unwrap(add(wrap(a), wrap(b)))                   */
 uint32_t orc_tree8(const uint32_t* leaf_bits);        /* 8-way adder tree, FPAddersReduceTree.sv:88-141 */
+uint32_t orc_aggregate(const uint32_t* x_bits, uint32_t n); /* sequential accumulator, FPAggregator.v:79-131 */
 uint32_t orc_go_right(uint32_t f_bits, uint32_t w_bits, uint32_t missing_bits, uint32_t miss_right,
                       uint32_t cmp_mode);         /* comparison stage, DTPU.sv:653-667                */
 void orc_fpadd_bits_batch(const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n);

@@ -60,6 +60,7 @@ def lib():
         L.orc_fpadd_bits.restype, L.orc_fpadd_bits.argtypes = u32, [u32, u32]
         L.orc_go_right.restype, L.orc_go_right.argtypes = u32, [u32, u32, u32, u32, u32]
         L.orc_tree8.restype, L.orc_tree8.argtypes = u32, [vp]
+        L.orc_aggregate.restype, L.orc_aggregate.argtypes = u32, [vp, u32]
         L.orc_fpadd_bits_batch.restype, L.orc_fpadd_bits_batch.argtypes = None, [vp, vp, vp, sz]
         L.orc_traverse.restype, L.orc_traverse.argtypes = u32, [PP, vp, vp, vp, u32]
         L.orc_leaves.restype, L.orc_leaves.argtypes = None, [PP, vp, vp, vp, vp]
