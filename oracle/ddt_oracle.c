@@ -2,7 +2,7 @@
  * ddt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code; see ddt_oracle.h).
  *
  * PARITY: the fp32 adder and the compare rule are pinned against vectors evaluated from the reference's
- * own RTL source (tests/golden/make_adder_golden.py); *** everything else is UNPINNED *** -- the
+ * own RTL source (tests/golden/make_rtl_golden.py); *** everything else is UNPINNED *** -- the
  * reference (FPGA RTL) has no tests/golden vectors and cannot be run here (see ddt_oracle.h).
  * This file restates the RTL's scoring semantics; each function cites the lines it follows.
  * All paths below are relative to /root/reference/rtl/DTEngine/.
@@ -156,7 +156,7 @@ static inline int orc_less(uint32_t f, uint32_t w, uint32_t cmp_mode) {
 
 /* The comparison stage, DTPU.sv:653-667: incrementNodeOffset = isFeatureMissing ? isMissingRight : ~isFeatureSmaller.
  * tests/test_oracle_adder.py checks it against vectors produced by evaluating those RTL assigns themselves
- * (tests/golden/make_adder_golden.py). */
+ * (tests/golden/make_rtl_golden.py). */
 uint32_t orc_go_right(uint32_t f, uint32_t w, uint32_t missing_bits, uint32_t miss_right, uint32_t cmp_mode) {
   if (f == missing_bits) return miss_right & 1u;      /* :653,667 bit-equality with MissingFeatureValue */
   return (uint32_t)!orc_less(f, w, cmp_mode);         /* :655-657 */
@@ -231,7 +231,7 @@ static inline uint32_t b_from(float f) { uint32_t b; memcpy(&b, &f, 4); return b
 
 /* The 8-way adder tree of one PU group, FPAddersReduceTree.sv:88-141: inputs wrapped with exc = {0, |x}, three
  * levels of FPAdder_8_23 on the 34-bit values, tree_out forced to +0 when the result's exception code is 00.
- * tests/test_oracle_adder.py checks it against vectors from the elaborated RTL (tests/golden/make_adder_golden.py). */
+ * tests/test_oracle_adder.py checks it against vectors from the elaborated RTL (tests/golden/make_rtl_golden.py). */
 uint32_t orc_tree8(const uint32_t* leaf_bits) {
   uint64_t l[8];
   for (uint32_t pu = 0; pu < 8; ++pu) l[pu] = orc_fp34_wrap(leaf_bits[pu]);
@@ -244,7 +244,7 @@ uint32_t orc_tree8(const uint32_t* leaf_bits) {
 /* The sequential accumulator, FPAggregator.v:79-131: running 34-bit value reset to 0, per input
  * running <- FPAdder(X = {0, |x, x}, Y = running), output after the last input forced to +0 on exception 00.
  * The same module accumulates the tree slots of a cluster and then the clusters (Core.sv:486-541).
- * tests/test_oracle_adder.py checks it against the datapath of the RTL (tests/golden/make_adder_golden.py). */
+ * tests/test_oracle_adder.py checks it against the datapath of the RTL (tests/golden/make_rtl_golden.py). */
 uint32_t orc_aggregate(const uint32_t* x_bits, uint32_t n) {
   uint64_t acc = 0; /* prev_aggreg_value reset, FPAggregator.v:83 */
   for (uint32_t i = 0; i < n; ++i) acc = orc_fp34_add(orc_fp34_wrap(x_bits[i]), acc); /* X = new, Y = running, :124-131 */

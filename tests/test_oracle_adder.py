@@ -85,7 +85,7 @@ def test_commutative():
     assert np.array_equal(O.fpadd_bits_batch(a, b), O.fpadd_bits_batch(b, a))
 
 
-# ---- pinned against the reference's own RTL source (evaluated by tests/golden/make_adder_golden.py) -------------
+# ---- pinned against the reference's own RTL source (evaluated by tests/golden/make_rtl_golden.py) -------------
 import os as _os
 
 _G = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
@@ -93,7 +93,7 @@ _G = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
 
 def test_adder_model_matches_the_reference_rtl_vectors():
     """17,884 operand pairs run through rtl/DTEngine/common/FPAdder_2cycles_latency.v (FPAdder_8_23_uid2_l2) by the
-    Verilog-subset evaluator of tests/golden/make_adder_golden.py: wrapped fp32 pairs, cancellation / tie / alignment
+    Verilog-subset evaluator of tests/golden/make_rtl_golden.py: wrapped fp32 pairs, cancellation / tie / alignment
     corner cases, zeros, -0, sub-normal and exponent-255 patterns, and all 16 exception-code combinations."""
     d = np.load(_os.path.join(_G, "fpadder_rtl_vectors.npz"))
     L = O.lib()
