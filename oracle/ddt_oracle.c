@@ -1,9 +1,10 @@
 /*
  * ddt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code; see ddt_oracle.h).
  *
- * PARITY: the fp32 adder and the compare rule are pinned against vectors evaluated from the reference's
- * own RTL source (tests/golden/make_rtl_golden.py); *** everything else is UNPINNED *** -- the
- * reference (FPGA RTL) has no tests/golden vectors and cannot be run here (see ddt_oracle.h).
+ * PARITY: adder, compare rule, group tree, accumulator datapath, chain hop and the traversal datapath are
+ * pinned against vectors evaluated from the reference's own RTL source (tests/golden/make_rtl_golden.py);
+ * *** everything else is UNPINNED *** -- the reference (FPGA RTL) has no tests/golden vectors and its
+ * sequential control cannot be run here (see ddt_oracle.h).
  * This file restates the RTL's scoring semantics; each function cites the lines it follows.
  * All paths below are relative to /root/reference/rtl/DTEngine/.
  */

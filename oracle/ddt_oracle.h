@@ -11,20 +11,20 @@
  * scorer, no tests, no golden vectors) and cannot be simulated in this environment (no Verilog
  * simulator, vendor IP missing).  What could be pinned against the reference ITSELF is pinned:
  *
- *   PINNED    the fp32 adder (orc_fp34_add), the go-left / go-right rule (orc_go_right), the 8-way adder
- *             tree of a PU group (orc_tree8) and the datapath of the sequential accumulator (orc_aggregate):
- *             golden vectors produced by evaluating the reference's own RTL source text --
- *             common/FPAdder_2cycles_latency.v, the comparison-stage assigns of core/DTPU.sv:653-667, the
- *             elaborated generate loops of core/FPAddersReduceTree.sv:88-141, the wrap / adder wiring /
- *             next-state / output rules of core/FPAggregator.v -- with the Verilog-subset evaluator of
- *             tests/golden/make_rtl_golden.py (17,884 + 21,072 + 3,000 vectors + 700 sequences,
- *             tests/test_oracle_adder.py).  The multi-device hop (ResultsCombiner.sv:292-311) is pinned the
- *             same way wherever its adder's exception code is not 00; on 00 the RTL forwards a non-zero garbage
- *             pattern (exact cancellation of two devices' partial sums), which is NOT replicated: +0 here.
+ *   PINNED    against golden vectors produced by EVALUATING THE REFERENCE'S OWN RTL SOURCE TEXT with the
+ *             Verilog-subset evaluator of tests/golden/make_rtl_golden.py (tests/test_oracle_adder.py):
+ *               orc_fp34_add   common/FPAdder_2cycles_latency.v, whole module                      17,884 vectors
+ *               orc_go_right   comparison-stage assigns, core/DTPU.sv:653-667                       21,072 vectors
+ *               orc_tree8      elaborated generate loops of core/FPAddersReduceTree.sv:88-141        3,000 vectors
+ *               orc_aggregate  datapath of core/FPAggregator.v (wrap, adder wiring, next state, output)  700 sequences
+ *               chain hop      elaborated adders of ResultsCombiner.sv:292-311 (where exception != 00; on 00 the
+ *                              RTL forwards a non-zero garbage pattern -- a defect, NOT replicated: +0 here)
+ *               orc_traverse   datapath of core/DTPU.sv: all assigns, the wiring of its delay pipelines, the
+ *                              clocked update of the recirculating instruction; memories as flat arrays   960 walks
  *
- *      *** PARITY UNPINNED for everything else *** -- the traversal loop, the stream formats, the
- *      tree -> PU / cluster schedule, the control of the accumulator (FIFO, latency counter) and the
- *      multi-device chain are restated from sequential SystemVerilog that nothing here can execute.
+ *      *** PARITY UNPINNED for everything else *** -- how the model / tuple streams are written into the
+ *      memories (programming side), the tree -> PU / cluster schedule, all valid / ready / FIFO control,
+ *      the multi-device plumbing: sequential SystemVerilog that nothing here can execute.
  *
  * Mitigations for the unpinned part (tests/test_oracle_*.py): hand-computed known-answer tests for every
  * rule, an independent numpy restatement, and a cross-check of the traversal against scikit-learn.
