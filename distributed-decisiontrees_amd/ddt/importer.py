@@ -163,6 +163,25 @@ def from_sklearn(model, num_levels: int | None = None) -> ImportedModel:
 
         trees = [_sk_tree(e.tree_, 0, prob(k)) for e in ests for k in range(K)]  # interleaved: tree i -> class i % K
         return _pack(trees, [1.0 / n] * len(trees), F, num_classes=K, num_levels=num_levels)
+    if name in ("HistGradientBoostingRegressor", "HistGradientBoostingClassifier"):
+        # model._predictors[iteration][k].nodes: structured array {value, feature_idx, num_threshold, missing_go_to_left,
+        # left, right, is_leaf, ...}; a sample goes left iff x <= num_threshold (missing: missing_go_to_left); the
+        # learning rate is already folded into the leaf values; raw score = baseline + sum of the leaves.
+        K = len(model._predictors[0])
+        trees = []
+        for it in model._predictors:
+            for k in range(K):
+                nd = it[k].nodes
+                if "is_categorical" in nd.dtype.names and np.any(nd["is_categorical"][~nd["is_leaf"].astype(bool)]):
+                    raise TypeError("categorical splits (bitsets) have no counterpart in the reference's threshold format")
+                leafmask = nd["is_leaf"].astype(bool)
+                left = np.where(leafmask, -1, nd["left"].astype(np.int64))
+                right = np.where(leafmask, -1, nd["right"].astype(np.int64))
+                thr = np.where(leafmask, 0.0, nd["num_threshold"].astype(np.float64))
+                mr = np.where(leafmask, 0, 1 - nd["missing_go_to_left"].astype(np.uint8)).astype(np.uint8)
+                trees.append(_Tree(left, right, np.where(leafmask, 0, nd["feature_idx"]), le_to_lt_threshold(thr), nd["value"], mr))
+        base = np.ravel(model._baseline_prediction).astype(np.float64)
+        return _pack(trees, [1.0] * len(trees), F, num_classes=K, base=base, num_levels=num_levels)
     raise TypeError(f"unsupported scikit-learn model {name}")
 
 

@@ -83,6 +83,35 @@ def test_sklearn_classifiers_through_oracle():
     assert np.mean(labels == rfc.predict(Xt)) > 0.99
 
 
+def test_sklearn_hist_gradient_boosting_through_oracle():
+    """HistGradientBoosting (binned training, real-valued thresholds at predict time, native missing-value support):
+    raw predictions of regressor, binary and multi-class classifier reproduced through the reference format."""
+    X, y = _data(3000, 10, 11)
+    Xm = X.copy()
+    Xm[np.random.default_rng(3).random(X.shape) < 0.05] = np.nan
+    Xt = _data(700, 10, 12)[0]
+    Xt[np.random.default_rng(5).random(Xt.shape) < 0.08] = np.nan
+    tl = O.tuples_from_float(Xt)
+    reg = ensemble.HistGradientBoostingRegressor(max_iter=30, max_depth=6, random_state=0).fit(Xm, y)
+    im = I.from_sklearn(reg)
+    assert im.num_classes == 1 and im.num_trees == 30 and im.num_levels <= 6
+    got = O.score(_omodel(im), tl, sum_mode=O.SUM_F64_SEQ).astype(np.float64) + im.base_score[0]
+    assert np.allclose(got, reg.predict(Xt), rtol=2e-5, atol=2e-5)
+    lab = np.digitize(y, np.quantile(y, [1 / 3, 2 / 3]))  # 3 classes
+    clf = ensemble.HistGradientBoostingClassifier(max_iter=12, max_depth=5, random_state=0).fit(Xm, lab)
+    im = I.from_sklearn(clf)
+    assert im.num_classes == 3 and im.num_trees == 36
+    labels, cs = O.classify(_omodel(im), tl, 3, sum_mode=O.SUM_F64_SEQ)
+    raw = cs.T.astype(np.float64) + im.base_score[None, :]
+    assert np.allclose(raw, clf.decision_function(Xt), rtol=1e-4, atol=1e-4)
+    assert np.mean(np.argmax(raw, axis=1) == clf.predict(Xt)) > 0.995
+    binc = ensemble.HistGradientBoostingClassifier(max_iter=10, max_depth=4, random_state=0).fit(Xm, (y > np.median(y)).astype(int))
+    im = I.from_sklearn(binc)
+    assert im.num_classes == 1
+    got = O.score(_omodel(im), tl, sum_mode=O.SUM_F64_SEQ).astype(np.float64) + im.base_score[0]
+    assert np.allclose(got, binc.decision_function(Xt), rtol=1e-4, atol=1e-4)
+
+
 def _xgb_eval(tr, x):
     n = 0
     while tr["left_children"][n] >= 0:
