@@ -323,7 +323,8 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
   if ((uint32_t)v.levels != e->p.num_levels) return false;
   const uint32_t W = tuple_words(e->p);
   if (v.kind == kKindQ16) {
-    if (W > 32u || v.lds_bytes_q16(W) > kMaxLdsBytes / 2u) return false;  // two blocks per CU or it is not worth it
+    // depth <= 8: two blocks per CU or it is not worth it; deeper trees have no other specialised kernel: one block
+    if (W > 32u || v.lds_bytes_q16(W) > (v.levels <= 8 ? kMaxLdsBytes / 2u : kMaxLdsBytes)) return false;
     return rank_tables(e).max_len <= kQ16MaxTable;
   }
   if (v.kind == kKindStream)
@@ -359,7 +360,8 @@ int auto_variant(const ddt_engine* e) {
       fused_plan_groups(e) >= 1u)
     q16_min = kQ16MinTreesFused;
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
-    static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4", "q16_d5_c32_u4", "q16_d3_c128_u8"};
+    static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4", "q16_d5_c32_u4", "q16_d3_c128_u8",
+                                  "q16_d9_c4_u4", "q16_d10_c4_u4"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
       if (i >= 0 && variant_fits(variant(i), e)) return i;

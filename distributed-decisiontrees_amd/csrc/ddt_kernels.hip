@@ -1376,6 +1376,9 @@ static const Variant g_variants[] = {
     DDT_Q("q16_d7_c8_u4", 7, 8, 4),
     DDT_Q("q16_d5_c32_u4", 5, 32, 4),
     DDT_Q("q16_d3_c128_u8", 3, 128, 8),
+    // deeper trees: 16 / 32 KiB chunks, one 1024-thread block per CU (the tile + two chunks no longer fit twice)
+    DDT_Q("q16_d9_c4_u4", 9, 4, 4),
+    DDT_Q("q16_d10_c4_u4", 10, 4, 4),
     // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB.  suffix _f = last level fused with its leaves
     DDT_VP("d8_t1024_r1_c4_u4_dma_fp", 8, 1024, 1, 4, 4, 1, 3),  // _p = persistent blocks + register prefetch
     DDT_V("d8_t1024_r1_c4_u4_dma_f", 8, 1024, 1, 4, 4, 1, 1),

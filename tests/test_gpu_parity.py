@@ -74,6 +74,8 @@ SHAPES = [
     (300, 5, 16, 1500, 0),
     (200, 3, 12, 2500, 1),
     (600, 7, 32, 1200, 0),
+    (260, 9, 24, 1500, 1),    # depths 9 and 10: rank-quantised variants with one block per CU
+    (230, 10, 32, 1100, 1),
 ]
 
 
@@ -85,7 +87,7 @@ def test_bit_exact_vs_oracle_all_variants(eng, T, D, F, rows, dist):
     want64 = O.score(m, x, sum_mode=O.SUM_F64_SEQ)
     _, gold = O.score(m, x, want_gold=True)
     vids = _fitting_variants(eng, m)
-    assert 0 in vids and (len(vids) > 1 or D not in (3, 4, 5, 6, 7, 8))
+    assert 0 in vids and (len(vids) > 1 or D not in (3, 4, 5, 6, 7, 8, 9, 10))
     names = ddt.variant_names()
     for v in vids:
         got = _gpu_score(eng, m, x, 0, v)
