@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 def _cases():
     rng = np.random.default_rng(20260921)
     out = []
-    for i in range(36):
-        D = int(rng.choice([4, 6, 8, 8, 8, 5, 7, 3]))
-        T = int(rng.integers(1, 330))
-        F = int(rng.integers(1, 41)) if D in (4, 6, 8) else int(rng.integers(1, 80))
+    for i in range(44):
+        D = int(rng.choice([4, 6, 8, 8, 8, 5, 7, 3, 9, 10]))
+        T = int(rng.integers(1, 330)) if D <= 8 else int(rng.integers(1, 130))
+        F = int(rng.integers(1, 41)) if D in (4, 6, 8, 9, 10) else int(rng.integers(1, 80))
         n = int(rng.integers(1, 7000))
         out.append((i, T, D, F, n, int(rng.integers(0, 2)), int(rng.choice([1, 2, 4, 8])), int(rng.integers(0, 2))))
     return out
