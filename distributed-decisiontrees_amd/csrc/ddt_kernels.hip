@@ -1387,6 +1387,7 @@ static const Variant g_variants[] = {
     DDT_V("d8_t512_r2_c4_u4_dma", 8, 512, 2, 4, 4, 1, 0),
     DDT_V("d8_t512_r1_c8_u8_dma", 8, 512, 1, 8, 8, 1, 0),
     DDT_V("d8_t512_r1_c8_u8_dma_f", 8, 512, 1, 8, 8, 1, 1),
+    DDT_V("d8_t512_r1_c4_u4_dma_f", 8, 512, 1, 4, 4, 1, 1),  // 33..64 words per tuple: 128 KiB tile + 2 x 12 KiB chunks
     DDT_V("d8_t256_r1_c4_u4_dma", 8, 256, 1, 4, 4, 1, 0),
     // depth 6 (BASELINE config 2): tree = 768 B
     DDT_V("d6_t1024_r1_c16_u4_dma", 6, 1024, 1, 16, 4, 1, 0),

@@ -74,6 +74,7 @@ SHAPES = [
     (300, 5, 16, 1500, 0),
     (200, 3, 12, 2500, 1),
     (600, 7, 32, 1200, 0),
+    (120, 8, 64, 1500, 1),    # 64 features: the 512-tuple tile variants
     (260, 9, 24, 1500, 1),    # depths 9 and 10: rank-quantised variants with one block per CU
     (230, 10, 32, 1100, 1),
 ]
