@@ -345,8 +345,8 @@ int auto_variant(const ddt_engine* e) {
   // the most waves per CU the feature tile allows; anything else -> generic.
   static const char* pref[] = {"stream_d4_u4_l4", "stream_d4_u4_l8", "stream_d6_u4_l4", "stream_d6_u4_l8", "stream_d8_u4_l8",
                                "stream_d7_u4_l8", "stream_d5_u4_l8", "stream_d3_u4_l8",
-                               "d8_t1024_r1_c4_u4_dma_f", "d8_t512_r1_c8_u8_dma_f", "d8_t512_r1_c4_u4_dma_f", "d8_t256_r1_c4_u4_dma",
-                               "d6_t1024_r1_c16_u4_dma", "d6_t512_r1_c16_u8_dma", "d6_t256_r1_c16_u4_dma",
+                               "d8_t1024_r1_c4_u4_dma_f", "d8_t512_r1_c8_u8_dma_f", "d8_t512_r1_c4_u4_dma_f", "d8_t256_r1_c4_u4_dma", "d8_t128_r1_c8_u8_dma", "d8_t64_r1_c8_u8_dma",
+                               "d6_t1024_r1_c16_u4_dma", "d6_t512_r1_c16_u8_dma", "d6_t256_r1_c16_u4_dma", "d6_t128_r1_c16_u8_dma", "d6_t64_r1_c16_u8_dma",
                                "d4_t256_r1_c64_u8_dma",
                                "d7_t1024_r1_c8_u4_dma", "d7_t256_r1_c8_u4_dma", "d5_t1024_r1_c32_u4_dma", "d5_t256_r1_c32_u4_dma",
                                "d3_t256_r1_c128_u8_dma"};

@@ -1389,11 +1389,15 @@ static const Variant g_variants[] = {
     DDT_V("d8_t512_r1_c8_u8_dma_f", 8, 512, 1, 8, 8, 1, 1),
     DDT_V("d8_t512_r1_c4_u4_dma_f", 8, 512, 1, 4, 4, 1, 1),  // 33..64 words per tuple: 128 KiB tile + 2 x 12 KiB chunks
     DDT_V("d8_t256_r1_c4_u4_dma", 8, 256, 1, 4, 4, 1, 0),
+    DDT_V("d8_t128_r1_c8_u8_dma", 8, 128, 1, 8, 8, 1, 0),     // very wide tuples (up to ~220 words): 128-tuple tile, 8 chains per lane
+    DDT_V("d8_t64_r1_c8_u8_dma", 8, 64, 1, 8, 8, 1, 0),       // up to ~440 words: one wave per CU, still 10x the generic kernel's global gathers
     // depth 6 (BASELINE config 2): tree = 768 B
     DDT_V("d6_t1024_r1_c16_u4_dma", 6, 1024, 1, 16, 4, 1, 0),
     DDT_V("d6_t1024_r1_c16_u8_dma", 6, 1024, 1, 16, 8, 1, 0),
     DDT_V("d6_t512_r1_c16_u8_dma", 6, 512, 1, 16, 8, 1, 0),
     DDT_V("d6_t256_r1_c16_u4_dma", 6, 256, 1, 16, 4, 1, 0),
+    DDT_V("d6_t128_r1_c16_u8_dma", 6, 128, 1, 16, 8, 1, 0),
+    DDT_V("d6_t64_r1_c16_u8_dma", 6, 64, 1, 16, 8, 1, 0),
     // depth 4: tree = 192 B
     DDT_V("d4_t256_r1_c64_u8_dma", 4, 256, 1, 64, 8, 1, 0),
     // depths 7, 5, 3: 12 KiB chunks like the depth-8 kernel

@@ -75,6 +75,9 @@ SHAPES = [
     (200, 3, 12, 2500, 1),
     (600, 7, 32, 1200, 0),
     (120, 8, 64, 1500, 1),    # 64 features: the 512-tuple tile variants
+    (90, 8, 200, 700, 1),     # 200 features: 128-tuple tiles
+    (90, 6, 150, 700, 1),
+    (60, 8, 400, 300, 1),     # 400 features: 64-tuple tiles
     (260, 9, 24, 1500, 1),    # depths 9 and 10: rank-quantised variants with one block per CU
     (230, 10, 32, 1100, 1),
 ]
