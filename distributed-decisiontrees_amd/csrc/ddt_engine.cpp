@@ -347,9 +347,10 @@ int auto_variant(const ddt_engine* e) {
                                "stream_d7_u4_l8", "stream_d5_u4_l8", "stream_d3_u4_l8",
                                "d8_t1024_r1_c4_u4_dma_f", "d8_t512_r1_c8_u8_dma_f", "d8_t512_r1_c4_u4_dma_f", "d8_t256_r1_c4_u4_dma", "d8_t128_r1_c8_u8_dma", "d8_t64_r1_c8_u8_dma",
                                "d6_t1024_r1_c16_u4_dma", "d6_t512_r1_c16_u8_dma", "d6_t256_r1_c16_u4_dma", "d6_t128_r1_c16_u8_dma", "d6_t64_r1_c16_u8_dma",
-                               "d4_t256_r1_c64_u8_dma",
-                               "d7_t1024_r1_c8_u4_dma", "d7_t256_r1_c8_u4_dma", "d5_t1024_r1_c32_u4_dma", "d5_t256_r1_c32_u4_dma",
-                               "d3_t256_r1_c128_u8_dma"};
+                               "d4_t256_r1_c64_u8_dma", "d4_t128_r1_c64_u8_dma",
+                               "d7_t1024_r1_c8_u4_dma", "d7_t256_r1_c8_u4_dma", "d7_t128_r1_c8_u8_dma",
+                               "d5_t1024_r1_c32_u4_dma", "d5_t256_r1_c32_u4_dma", "d5_t128_r1_c32_u8_dma",
+                               "d3_t256_r1_c128_u8_dma", "d3_t128_r1_c128_u8_dma"};
   // Rank-quantised path: its scoring kernel is ~1.3x faster per tree (32 waves/CU) but it pays a fixed transpose +
   // rank pre-pass per tuple.  Measured per 100 M tuples (profiles/r01_*): q16 = 10.9 ms + 0.113 ms/tree, fp32 tile =
   // 3.2 ms + 0.147 ms/tree => break-even near 200 trees per engine; 250 trees (4-way shard of 1000) goes to q16.

@@ -1400,12 +1400,16 @@ static const Variant g_variants[] = {
     DDT_V("d6_t64_r1_c16_u8_dma", 6, 64, 1, 16, 8, 1, 0),
     // depth 4: tree = 192 B
     DDT_V("d4_t256_r1_c64_u8_dma", 4, 256, 1, 64, 8, 1, 0),
+    DDT_V("d4_t128_r1_c64_u8_dma", 4, 128, 1, 64, 8, 1, 0),
     // depths 7, 5, 3: 12 KiB chunks like the depth-8 kernel
     DDT_V("d7_t1024_r1_c8_u4_dma", 7, 1024, 1, 8, 4, 1, 0),
     DDT_V("d7_t256_r1_c8_u4_dma", 7, 256, 1, 8, 4, 1, 0),
+    DDT_V("d7_t128_r1_c8_u8_dma", 7, 128, 1, 8, 8, 1, 0),
     DDT_V("d5_t1024_r1_c32_u4_dma", 5, 1024, 1, 32, 4, 1, 0),
     DDT_V("d5_t256_r1_c32_u4_dma", 5, 256, 1, 32, 4, 1, 0),
+    DDT_V("d5_t128_r1_c32_u8_dma", 5, 128, 1, 32, 8, 1, 0),
     DDT_V("d3_t256_r1_c128_u8_dma", 3, 256, 1, 128, 8, 1, 0),
+    DDT_V("d3_t128_r1_c128_u8_dma", 3, 128, 1, 128, 8, 1, 0),
     // resident-model streaming kernels (small ensembles, HBM-bound; BASELINE config 1 is depth 4)
     DDT_S("stream_d4_u4_l4", 4, 4, 4),
     DDT_S("stream_d4_u8_l4", 4, 8, 4),

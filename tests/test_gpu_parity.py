@@ -78,6 +78,9 @@ SHAPES = [
     (90, 8, 200, 700, 1),     # 200 features: 128-tuple tiles
     (90, 6, 150, 700, 1),
     (60, 8, 400, 300, 1),     # 400 features: 64-tuple tiles
+    (70, 5, 180, 500, 1),
+    (70, 7, 160, 500, 0),
+    (40, 4, 200, 400, 1),
     (260, 9, 24, 1500, 1),    # depths 9 and 10: rank-quantised variants with one block per CU
     (230, 10, 32, 1100, 1),
 ]
