@@ -17,105 +17,11 @@
 #include <thread>
 #include <vector>
 
-#include "ddt_internal.h"
+#include "ddt_engine_priv.h"
 
 using namespace ddt;
 
-namespace {
-
-constexpr uint32_t kMaxLdsBytes = 160u * 1024u;     // MI355X: 160 KiB LDS per CU / workgroup
-constexpr uint32_t kStreamLdsBudget = 40u * 1024u;  // stream kernels: keep >= 4 resident blocks per CU
-
-double now_ms() {
-  using namespace std::chrono;
-  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
-// One ensemble as parsed from the reference wire format: the trees this engine holds of one class
-// (single-output models have exactly one ensemble), plus its device image for the active variant.
-struct Ensemble {
-  std::vector<uint32_t> ids;    // global tree ids in stream order
-  std::vector<uint32_t> thr;    // [T][nint]   raw fp32 bit patterns (heap order, 0-based)
-  std::vector<uint16_t> fidx;   // [T][nint]
-  std::vector<uint8_t> mright;  // [T][nint]
-  std::vector<uint32_t> leaf;   // [T][nleaf]
-  void* d_img = nullptr;
-  size_t img_bytes = 0;
-  uint32_t img_trees = 0, img_chunks = 0;
-  // rank-quantised path only: image with miss_right flags, per-feature threshold tables
-  void* d_img_slow = nullptr;
-  void* d_tables = nullptr;
-  void* d_tabK = nullptr;   // q16: per-feature search parameters (Q16Aux::tabP)
-  void* d_tabS = nullptr;   // q16: bucket starts (Q16Aux::tabS)
-  void* d_fused = nullptr;  // q16, small tables: LDS image of the fused pre-pass (Q16Aux::fused_img)
-  FusedPlan fused;          // geometry of that image (groups of features, one launch per group)
-  uint32_t Kpad = 0;
-  uint32_t trees() const { return (uint32_t)ids.size(); }
-};
-
-// sorted distinct threshold keys per feature of one ensemble (q16 path)
-struct RankTables {
-  std::vector<std::vector<uint32_t>> keys;  // [W], ascending as signed int32
-  uint32_t max_len = 0;
-};
-
-}  // namespace
-
-struct ddt_engine {
-  int device = -1;
-  hipDeviceProp_t prop{};
-  bool loaded = false;
-  ddt_params p{};
-  uint32_t nint = 0, nleaf = 0;
-  uint32_t num_classes = 1;
-  std::vector<Ensemble> ens;  // one per class
-  int forced_variant = -1;
-  int variant_id = 0;
-  // feeder
-  size_t feeder_rows = 1u << 20;
-  int feeder_threads = 8;   // host threads that copy a chunk into the pinned staging buffer (one thread: ~26 GB/s < PCIe)
-  hipStream_t fs[2] = {nullptr, nullptr};
-  hipEvent_t fe[2] = {nullptr, nullptr};
-  void* pin_in[2] = {nullptr, nullptr};
-  void* pin_out[2] = {nullptr, nullptr};
-  void* dev_in[2] = {nullptr, nullptr};
-  void* dev_out[2] = {nullptr, nullptr};
-  size_t feeder_cap_rows = 0, feeder_cap_words = 0, feeder_cap_outs = 0;
-  // classify workspace (grow-only)
-  void* ws = nullptr;
-  size_t ws_bytes = 0;
-  // rank-quantised path workspace (grow-only): transposed tuples, ranks, per-tile flags
-  // slot 0: ddt_score_device / ddt_classify_device (stream ordered); slots 1, 2: the feeder's two streams
-  void* q_xT[3] = {nullptr, nullptr, nullptr};
-  void* q_q[3] = {nullptr, nullptr, nullptr};
-  void* q_flags[3] = {nullptr, nullptr, nullptr};
-  uint64_t q_rows[3] = {0, 0, 0};  // capacity in rows (multiple of 1024)
-  int q_slot = 0;
-  int q16_fused_prepass = 1;  // option "q16_fused_prepass": 0 forces the transpose + rank kernels (A/B, tests)
-  // optional per-call kernel timing (option "kernel_timing"): start / before scoring kernel / end
-  bool kernel_timing = false, timing_pending = false;
-  hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
-  ddt_stats st{};
-  char err[256] = {0};
-};
-
-namespace {
-
-int fail(ddt_engine* e, int code, const char* fmt, ...) {
-  if (e) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(e->err, sizeof(e->err), fmt, ap);
-    va_end(ap);
-  }
-  return code;
-}
-
-#define HIP_TRY(e, call)                                                                          \
-  do {                                                                                            \
-    hipError_t _r = (call);                                                                       \
-    if (_r != hipSuccess) return fail((e), DDT_EHIP, "%s -> %s", #call, hipGetErrorString(_r));   \
-  } while (0)
+namespace ddt {
 
 uint32_t wlines_min(uint32_t D) { return (uint32_t)((((1ull << (D + 1)) - 1) + 3) / 4); }
 uint32_t flines_min(uint32_t D) { return (uint32_t)((((1ull << D) - 1) + 7) / 8); }
@@ -168,11 +74,27 @@ int parse_trees(ddt_engine* eng, const ddt_params* p, const uint32_t* w, const u
       m.fidx[(size_t)i * nint + n] = (uint16_t)j;
       m.mright[(size_t)i * nint + n] = (uint8_t)((en >> 13) & 1u);  // DTPU.sv:659
     }
-    for (uint32_t l = 0; l < nleaf; ++l) m.leaf[(size_t)i * nleaf + l] = wt[nint + l];
+    for (uint32_t l = 0; l < nleaf; ++l) {
+      const uint32_t lb = wt[nint + l];
+      // The GPU adds are IEEE-754; the reference's FloPoCo adder treats sub-normal / Inf / NaN inputs as normals and
+      // keeps -0 (FPAdder_2cycles_latency.v:313-320,376-385 behind the {0, |bits} wrapper of FPAddersReduceTree.sv:94-95):
+      // outside normal values and +0 "bit-exact with the reference" cannot be promised in the reference-order sum
+      if (p->sum_mode == 0 && eng && eng->leaf_domain_check && leaf_outside_exact_domain(lb))
+        return fail(eng, DDT_EUNSUPPORTED,
+                    "tree %u leaf %u = 0x%08X: -0 / sub-normal / Inf / NaN leaves are outside the domain where IEEE adds equal the "
+                    "reference adder (flush them to +0 when exporting, use sum_mode 1, or set option leaf_domain_check = 0)",
+                    ids[i], l, lb);
+      m.leaf[(size_t)i * nleaf + l] = lb;
+    }
   }
   m.ids = std::move(ids);
   *out = std::move(m);
   return DDT_OK;
+}
+
+bool leaf_outside_exact_domain(uint32_t bits) {
+  const uint32_t ex = (bits >> 23) & 0xFFu;
+  return bits != 0u && (ex == 0u || ex == 0xFFu);  // -0, sub-normals, Inf, NaN
 }
 
 uint32_t thr_key(const ddt_params& p, uint32_t bits) {
@@ -185,6 +107,7 @@ uint32_t padded_trees(const Variant& v, uint32_t T) {
   const bool chunked = v.kind == kKindTile || v.kind == kKindQ16;
   uint32_t granule = (chunked && v.chunk_trees > 8) ? (uint32_t)v.chunk_trees : 8u;
   if (v.kind == kKindTile && (v.opt & 2) && granule < 2u * (uint32_t)v.chunk_trees) granule = 2u * (uint32_t)v.chunk_trees;  // even chunk count
+  if (T == 0) T = 1;  // an empty shard (T < shard_count * ceil(T / shard_count)) is one group of EMPTY slots: scores +0
   return (T + granule - 1u) / granule * granule;  // whole PU groups of 8 (and whole chunks)
 }
 
@@ -319,6 +242,7 @@ constexpr uint32_t kQ16MinTreesFused = 112;  // measured break-even with the fus
 constexpr uint32_t kQ16MaxTable = 32767;  // ranks must stay below 0xFFFF and a table (x4 B) must fit LDS in the rank kernel
 
 bool variant_fits(const Variant& v, const ddt_engine* e) {
+  if (v.kind == kKindSparse) return false;  // sparse forests pick their kernel in ddt_sparse_host.cpp
   if (v.kind == kKindGeneric) return true;
   if ((uint32_t)v.levels != e->p.num_levels) return false;
   const uint32_t W = tuple_words(e->p);
@@ -696,6 +620,30 @@ int launch_classify(ddt_engine* e, const void* d_tuples, size_t n, float* d_clas
   return DDT_OK;
 }
 
+int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
+  if (!e->sparse) return launch_score(e, e->ens[0], d_tuples, n, d_scores, s);
+  const bool timing = e->kernel_timing && e->q_slot == 0;
+  if (timing) {
+    for (hipEvent_t& ev : e->tev)
+      if (!ev) HIP_TRY(e, hipEventCreate(&ev));
+    HIP_TRY(e, hipEventRecord(e->tev[0], s));
+    HIP_TRY(e, hipEventRecord(e->tev[1], s));  // no pre-pass on this path
+  }
+  int rc = sparse_launch(e, d_tuples, n, d_scores, s);
+  if (rc) return rc;
+  if (timing) {
+    HIP_TRY(e, hipEventRecord(e->tev[2], s));
+    e->timing_pending = true;
+  }
+  e->st.kernel_launches++;
+  return DDT_OK;
+}
+
+int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s) {
+  if (e->sparse) return fail(e, DDT_EUNSUPPORTED, "sparse models hold one class");
+  return launch_classify(e, d_tuples, n, d_class_scores, d_labels, s);
+}
+
 void count_job(ddt_engine* e, size_t n) {
   e->st.score_calls++;
   e->st.tuples_in += n;
@@ -724,7 +672,8 @@ int load_common(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wli
   if (shard_count == 0 || shard_index >= shard_count || shard_count > per_class)
     return fail(e, DDT_EINVAL, "shard %u of %u (trees per class %u)", shard_index, shard_count, per_class);
   const double t0 = now_ms();
-  HIP_TRY(e, hipSetDevice(e->device));
+  DeviceGuard dg(e->device);
+  if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
   std::vector<Ensemble> ens(num_classes);
   uint64_t lines = 0;
   for (uint32_t k = 0; k < num_classes; ++k) {
@@ -734,7 +683,9 @@ int load_common(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wli
       if (cls == k) ids.push_back(i);
     }
     std::vector<uint32_t> mine = shard_of(ids, shard_index, shard_count);
-    if (mine.empty()) return fail(e, DDT_EINVAL, "shard %u of %u of class %u is empty", shard_index, shard_count, k);
+    // an EMPTY shard is legal: ceil(T/G) trees per device leaves the trailing devices without trees when
+    // (G-1)*ceil(T/G) >= T (e.g. T = 9, G = 4); such a device holds only EMPTY slots (DTPU.sv:544,760) and returns +0,
+    // so every rank of a sharded job behaves the same and nobody is left waiting in a collective
     lines += (uint64_t)mine.size() * (p->weights_lines_per_tree + p->findex_lines_per_tree);
     rc = parse_trees(e, p, reinterpret_cast<const uint32_t*>(wl), reinterpret_cast<const uint16_t*>(fl), std::move(mine), &ens[k]);
     if (rc) return rc;
@@ -742,6 +693,8 @@ int load_common(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wli
   HIP_TRY(e, hipDeviceSynchronize());  // asynchronous scoring of the previous model may still be in flight
   free_images(e);
   free_q16_workspace(e);  // sized for the previous model's tuple width
+  sparse_free(e);
+  e->sparse = false;
   e->loaded = false;
   e->p = *p;
   e->nint = (1u << p->num_levels) - 1u;
@@ -772,7 +725,8 @@ int ddt_create(ddt_engine** out, int device_id) {
   std::unique_ptr<ddt_engine> e(new (std::nothrow) ddt_engine());
   if (!e) return DDT_ENOMEM;
   e->device = device_id;
-  if (hipSetDevice(device_id) != hipSuccess) return DDT_EHIP;
+  DeviceGuard dg(device_id);
+  if (!dg.ok) return DDT_EHIP;
   if (hipGetDeviceProperties(&e->prop, device_id) != hipSuccess) return DDT_EHIP;
   if (strncmp(e->prop.gcnArchName, "gfx950", 6) != 0) return DDT_ENODEVICE;  // kernels are built for gfx950 only
   *out = e.release();
@@ -781,7 +735,7 @@ int ddt_create(ddt_engine** out, int device_id) {
 
 void ddt_destroy(ddt_engine* e) {
   if (!e) return;
-  (void)hipSetDevice(e->device);
+  DeviceGuard dg(e->device);
   (void)hipDeviceSynchronize();  // asynchronous ddt_*_device work may still read the images / workspaces
   feeder_free(e);
   for (int b = 0; b < 2; ++b) {
@@ -793,6 +747,7 @@ void ddt_destroy(ddt_engine* e) {
     if (ev) (void)hipEventDestroy(ev);
   free_images(e);
   free_q16_workspace(e);
+  sparse_free(e);
   delete e;
 }
 
@@ -818,7 +773,9 @@ int ddt_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_sco
   if (e->num_classes != 1) return fail(e, DDT_ESTATE, "multi-class model loaded: use ddt_classify*");
   if (n == 0) return DDT_OK;
   if (!d_tuples || !d_scores) return fail(e, DDT_EINVAL, "NULL device buffer");
-  int rc = launch_score(e, e->ens[0], d_tuples, n, d_scores, reinterpret_cast<hipStream_t>(stream));
+  DeviceGuard dg(e->device);
+  if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
+  int rc = engine_score_device(e, d_tuples, n, d_scores, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
   count_job(e, n);
   return DDT_OK;
@@ -830,7 +787,9 @@ int ddt_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_
   if (!e->loaded) return fail(e, DDT_ESTATE, "no model loaded");
   if (n == 0) return DDT_OK;
   if (!d_tuples || !d_class_scores) return fail(e, DDT_EINVAL, "NULL device buffer");
-  int rc = launch_classify(e, d_tuples, n, d_class_scores, d_labels, reinterpret_cast<hipStream_t>(stream));
+  DeviceGuard dg(e->device);
+  if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
+  int rc = engine_classify_device(e, d_tuples, n, d_class_scores, d_labels, reinterpret_cast<hipStream_t>(stream));
   if (rc) return rc;
   count_job(e, n);
   return DDT_OK;
@@ -839,6 +798,8 @@ int ddt_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_
 int ddt_argmax_device(ddt_engine* e, const float* d_class_scores, uint32_t K, size_t n, int32_t* d_labels, void* stream) {
   if (!e) return DDT_EINVAL;
   if (K == 0 || (n && (!d_class_scores || !d_labels))) return fail(e, DDT_EINVAL, "bad argmax arguments");
+  DeviceGuard dg(e->device);
+  if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
   hipError_t r = launch_argmax(d_class_scores, K, n, d_labels, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(e, DDT_EHIP, "argmax -> %s", hipGetErrorString(r));
   return DDT_OK;
@@ -874,7 +835,8 @@ static int score_host(ddt_engine* e, const void* tuple_lines, size_t n, float* s
   const bool classify = labels_out != nullptr;
   const uint32_t K = classify ? e->num_classes : 1u;
   const double t0 = now_ms();
-  HIP_TRY(e, hipSetDevice(e->device));
+  DeviceGuard dg(e->device);
+  if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
   const size_t W = tuple_words(e->p);
   const size_t rows = e->feeder_rows < n ? e->feeder_rows : n;
   const size_t outs = classify ? K + 1 : 1;
@@ -904,8 +866,8 @@ static int score_host(ddt_engine* e, const void* tuple_lines, size_t n, float* s
     HIP_TRY(e, hipMemcpyAsync(e->dev_in[b], e->pin_in[b], cn * W * 4, hipMemcpyHostToDevice, e->fs[b]));
     float* dout = reinterpret_cast<float*>(e->dev_out[b]);
     e->q_slot = 1 + b;  // the two feeder streams run concurrently: separate q16 workspaces
-    if (!classify) rc = launch_score(e, e->ens[0], e->dev_in[b], cn, dout, e->fs[b]);
-    else rc = launch_classify(e, e->dev_in[b], cn, dout, reinterpret_cast<int32_t*>(dout + (size_t)K * cn), e->fs[b]);
+    if (!classify) rc = engine_score_device(e, e->dev_in[b], cn, dout, e->fs[b]);
+    else rc = engine_classify_device(e, e->dev_in[b], cn, dout, reinterpret_cast<int32_t*>(dout + (size_t)K * cn), e->fs[b]);
     e->q_slot = 0;
     if (rc) return rc;
     HIP_TRY(e, hipMemcpyAsync(e->pin_out[b], e->dev_out[b], cn * outs * 4, hipMemcpyDeviceToHost, e->fs[b]));
@@ -934,12 +896,15 @@ int ddt_classify(ddt_engine* e, const void* tuple_lines, size_t n, int32_t* labe
   if (!e->loaded) return fail(e, DDT_ESTATE, "no model loaded");
   if (n == 0) return DDT_OK;
   if (!tuple_lines || !labels) return fail(e, DDT_EINVAL, "NULL host buffer");
+  if (e->sparse) return fail(e, DDT_EUNSUPPORTED, "sparse models hold one class");
   return score_host(e, tuple_lines, n, nullptr, labels, class_scores);
 }
 
 int ddt_chain_sum_device(ddt_engine* e, const float* d_parts, uint32_t n_parts, size_t n, float* d_out, void* stream) {
   if (!e) return DDT_EINVAL;
   if (n_parts == 0 || (!d_parts && n) || (!d_out && n)) return fail(e, DDT_EINVAL, "bad chain-sum arguments");
+  DeviceGuard dg(e->device);
+  if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
   hipError_t r = launch_chain_sum(d_parts, n_parts, n, d_out, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(e, DDT_EHIP, "chain_sum -> %s", hipGetErrorString(r));
   return DDT_OK;
@@ -953,6 +918,24 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   snprintf(out->device_name, sizeof(out->device_name), "%s (%s)", e->prop.name, e->prop.gcnArchName);
   if (!e->loaded) return DDT_OK;
   const Variant& v = variant(e->variant_id);
+  if (e->sparse) {
+    const SparseForest& sp = e->sp;
+    out->tree_begin = sp.ids.empty() ? 0u : sp.ids.front();
+    out->tree_end = sp.ids.empty() ? 0u : sp.ids.back() + 1;
+    out->num_levels = sp.max_depth;
+    out->num_features = e->p.num_features;
+    out->tuple_words = tuple_words(e->p);
+    out->variant = (uint32_t)e->variant_id;
+    out->tile_tuples = v.tile();
+    out->block_threads = (uint32_t)v.threads;
+    out->lds_bytes = v.lds_bytes_sparse(out->tuple_words);
+    out->model_bytes_unpadded = (uint64_t)sp.lines.size() * 4ull;  // 16 bytes per internal node: the stream itself
+    out->image_bytes = sp.top_bytes + sp.deep_bytes;
+    out->num_classes = 1;
+    out->local_trees = sp.trees();
+    snprintf(out->variant_name, sizeof(out->variant_name), "%s", v.name);
+    return DDT_OK;
+  }
   const Ensemble& m0 = e->ens[0];
   uint32_t trees = 0;
   uint64_t img = 0;
@@ -960,8 +943,8 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
     trees += m.trees();
     img += m.img_bytes;
   }
-  out->tree_begin = m0.ids.front();
-  out->tree_end = e->ens.back().ids.back() + 1;
+  out->tree_begin = m0.ids.empty() ? 0u : m0.ids.front();
+  out->tree_end = e->ens.back().ids.empty() ? out->tree_begin : e->ens.back().ids.back() + 1;
   out->num_levels = e->p.num_levels;
   out->num_features = e->p.num_features;
   out->tuple_words = tuple_words(e->p);
@@ -1016,14 +999,37 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   if (!strcmp(key, "variant")) {
     if (value >= num_variants()) return fail(e, DDT_EINVAL, "variant %lld out of range", (long long)value);
     e->forced_variant = value < 0 ? -1 : (int)value;
-    if (e->loaded) {
-      HIP_TRY(e, hipSetDevice(e->device));
+    if (e->loaded && !e->sparse) {
+      DeviceGuard dg(e->device);
+      if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
       HIP_TRY(e, hipDeviceSynchronize());
       e->loaded = false;
       int rc = select_and_build(e);
       if (rc) return rc;
       e->loaded = true;
     }
+    return DDT_OK;
+  }
+  if (!strcmp(key, "sparse_top_levels") || !strcmp(key, "sparse_deep_order")) {
+    // sparse forests: K = levels staged in LDS (-1 = as many as fit), order of the deep records (0 level order,
+    // 1 depth-first per sub-tree); a loaded sparse model is re-packed
+    const bool top = key[7] == 't';
+    if (top && value >= 0 && (value < kSparseMinTop || value > kSparseMaxTop)) return fail(e, DDT_EINVAL, "sparse_top_levels must be -1 or %d..%d", kSparseMinTop, kSparseMaxTop);
+    if (!top && (value < 0 || value > 1)) return fail(e, DDT_EINVAL, "sparse_deep_order must be 0 or 1");
+    (top ? e->sparse_top_levels : e->sparse_deep_order) = (int)value;
+    if (e->loaded && e->sparse) {
+      DeviceGuard dg(e->device);
+      if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
+      HIP_TRY(e, hipDeviceSynchronize());
+      e->loaded = false;
+      int rc = sparse_rebuild(e);
+      if (rc) return rc;
+      e->loaded = true;
+    }
+    return DDT_OK;
+  }
+  if (!strcmp(key, "leaf_domain_check")) {  // 1 (default): refuse -0 / sub-normal / Inf / NaN leaves in the reference-order sum
+    e->leaf_domain_check = value != 0;
     return DDT_OK;
   }
   if (!strcmp(key, "kernel_timing")) {
@@ -1085,6 +1091,53 @@ int ddt_synth_model(uint32_t T, uint32_t D, uint32_t F, int dist, void* wlines, 
   return DDT_OK;
 }
 
+int64_t ddt_synth_sparse_model(uint32_t T, uint32_t max_depth, uint32_t F, uint32_t full_levels, uint32_t split_permille, int dist,
+                               void* node_lines, size_t cap_lines, uint64_t* first) {
+  if (T == 0 || max_depth < 1 || max_depth > 64 || F < 1 || F > 2048 || split_permille > 1000) return DDT_EINVAL;
+  // breadth-first growth; the n-th internal node of tree i (BFS order) draws from hash base g = i << 24 | n:
+  // feature h(8g) % F, threshold unit(h(8g+1)), missing direction h(8g+2) & 1, child `side` internal iff its depth is
+  // < max_depth and (< full_levels or (h(8g+4+side) >> 20) % 1000 < split_permille), else a leaf (unit(h(8g+6+side)) - 0.5) * 0.2
+  constexpr uint32_t kCap = 4u << 20;  // internal nodes per tree
+  uint32_t* lines = reinterpret_cast<uint32_t*>(node_lines);
+  std::vector<uint8_t> depth;
+  size_t total = 0;
+  for (uint32_t i = 0; i < T; ++i) {
+    if (first) first[i] = total;
+    depth.assign(1, 0);
+    for (uint32_t n = 0; n < depth.size(); ++n) {
+      const uint64_t g = ((uint64_t)i << 24) | n;
+      const uint32_t d = depth[n];
+      uint32_t en = (uint32_t)(splitmix64(kSeedS + 8ull * g) % F) | ((uint32_t)(splitmix64(kSeedS + 8ull * g + 2ull) & 1ull) << 13);
+      const float u = unit24(splitmix64(kSeedS + 8ull * g + 1ull));
+      uint32_t child[2];
+      for (uint32_t side = 0; side < 2; ++side) {
+        const uint64_t hs = splitmix64(kSeedS + 8ull * g + 4ull + side);
+        const bool internal = d + 1u < max_depth && depth.size() < kCap &&
+                              (d + 1u < full_levels || (uint32_t)((hs >> 20) % 1000ull) < split_permille);
+        if (internal) {
+          child[side] = (uint32_t)depth.size();
+          depth.push_back((uint8_t)(d + 1u));
+        } else {
+          volatile float c = unit24(splitmix64(kSeedS + 8ull * g + 6ull + side)) - 0.5f;
+          volatile float v = c * 0.2f;
+          child[side] = fbits(v);
+          en |= 1u << (14 + side);
+        }
+      }
+      if (lines && total + n < cap_lines) {
+        uint32_t* r = lines + (total + n) * 4u;
+        r[0] = fbits(dist == 1 ? u * 2.0f - 1.0f : u);
+        r[1] = en;
+        r[2] = child[0];
+        r[3] = child[1];
+      }
+    }
+    total += depth.size();
+  }
+  if (first) first[T] = total;
+  return (int64_t)total;
+}
+
 int ddt_synth_tuples_host(void* out_, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits) {
   if (!out_ || F < 1 || F > 2048) return DDT_EINVAL;
   uint32_t* out = reinterpret_cast<uint32_t*>(out_);
@@ -1111,6 +1164,8 @@ int ddt_synth_tuples_device(ddt_engine* e, void* d_out, uint64_t row0, size_t n,
                             uint32_t missing_bits, void* stream) {
   if (!e) return DDT_EINVAL;
   if (!d_out || F < 1 || F > 2048) return fail(e, DDT_EINVAL, "bad synth arguments");
+  DeviceGuard dg(e->device);
+  if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
   hipError_t r = launch_synth_tuples(reinterpret_cast<uint32_t*>(d_out), row0, n, F, dist, missing_bits,
                                      reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(e, DDT_EHIP, "synth_tuples -> %s", hipGetErrorString(r));

@@ -1,0 +1,163 @@
+// ddt_engine_priv.h -- the engine object and the host-side helpers shared by the translation units of libddt.so
+// (ddt_engine.cpp: perfect-tree models, feeder, C-ABI; ddt_sparse_host.cpp: sparse forests; ddt_comm.cpp: RCCL).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ddt_internal.h"
+
+namespace ddt {
+
+constexpr uint32_t kMaxLdsBytes = 160u * 1024u;     // MI355X: 160 KiB LDS per CU / workgroup
+constexpr uint32_t kStreamLdsBudget = 40u * 1024u;  // stream kernels: keep >= 4 resident blocks per CU
+
+inline double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// One ensemble as parsed from the reference wire format: the trees this engine holds of one class
+// (single-output models have exactly one ensemble), plus its device image for the active variant.
+struct Ensemble {
+  std::vector<uint32_t> ids;    // global tree ids in stream order
+  std::vector<uint32_t> thr;    // [T][nint]   raw fp32 bit patterns (heap order, 0-based)
+  std::vector<uint16_t> fidx;   // [T][nint]
+  std::vector<uint8_t> mright;  // [T][nint]
+  std::vector<uint32_t> leaf;   // [T][nleaf]
+  void* d_img = nullptr;
+  size_t img_bytes = 0;
+  uint32_t img_trees = 0, img_chunks = 0;
+  // rank-quantised path only: image with miss_right flags, per-feature threshold tables
+  void* d_img_slow = nullptr;
+  void* d_tables = nullptr;
+  void* d_tabK = nullptr;   // q16: per-feature search parameters (Q16Aux::tabP)
+  void* d_tabS = nullptr;   // q16: bucket starts (Q16Aux::tabS)
+  void* d_fused = nullptr;  // q16, small tables: LDS image of the fused pre-pass (Q16Aux::fused_img)
+  FusedPlan fused;          // geometry of that image (groups of features, one launch per group)
+  uint32_t Kpad = 0;
+  uint32_t trees() const { return (uint32_t)ids.size(); }
+};
+
+// sorted distinct threshold keys per feature of one ensemble (q16 path)
+struct RankTables {
+  std::vector<std::vector<uint32_t>> keys;  // [W], ascending as signed int32
+  uint32_t max_len = 0;
+};
+
+// A sparse (explicit-children) forest as loaded: this engine's shard, node lines re-based per tree (include/ddt.h
+// ddt_load_model_sparse); device images: ddt_internal.h "Sparse forests".
+struct SparseForest {
+  std::vector<uint32_t> ids;      // global tree ids held by this engine, stream order
+  std::vector<uint64_t> first;    // [trees + 1] line index of each tree's root inside `lines`
+  std::vector<uint32_t> lines;    // 4 words per internal node
+  uint32_t max_depth = 0;         // deepest leaf (levels of compares on the longest path)
+  void* d_top = nullptr;          // [groups][8][12 * 2^K] top images
+  void* d_deep = nullptr;         // deep records
+  size_t top_bytes = 0, deep_bytes = 0;
+  uint32_t groups = 0;
+  uint32_t trees() const { return (uint32_t)ids.size(); }
+};
+
+}  // namespace ddt
+
+struct ddt_engine {
+  using Ensemble = ddt::Ensemble;
+  using FusedPlan = ddt::FusedPlan;
+  int device = -1;
+  hipDeviceProp_t prop{};
+  bool loaded = false;
+  ddt_params p{};
+  uint32_t nint = 0, nleaf = 0;
+  uint32_t num_classes = 1;
+  std::vector<Ensemble> ens;  // one per class
+  int forced_variant = -1;
+  int variant_id = 0;
+  // feeder
+  size_t feeder_rows = 1u << 20;
+  int feeder_threads = 8;   // host threads that copy a chunk into the pinned staging buffer (one thread: ~26 GB/s < PCIe)
+  hipStream_t fs[2] = {nullptr, nullptr};
+  hipEvent_t fe[2] = {nullptr, nullptr};
+  void* pin_in[2] = {nullptr, nullptr};
+  void* pin_out[2] = {nullptr, nullptr};
+  void* dev_in[2] = {nullptr, nullptr};
+  void* dev_out[2] = {nullptr, nullptr};
+  size_t feeder_cap_rows = 0, feeder_cap_words = 0, feeder_cap_outs = 0;
+  // classify workspace (grow-only)
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  // rank-quantised path workspace (grow-only): transposed tuples, ranks, per-tile flags
+  // slot 0: ddt_score_device / ddt_classify_device (stream ordered); slots 1, 2: the feeder's two streams
+  void* q_xT[3] = {nullptr, nullptr, nullptr};
+  void* q_q[3] = {nullptr, nullptr, nullptr};
+  void* q_flags[3] = {nullptr, nullptr, nullptr};
+  uint64_t q_rows[3] = {0, 0, 0};  // capacity in rows (multiple of 1024)
+  int q_slot = 0;
+  int q16_fused_prepass = 1;  // option "q16_fused_prepass": 0 forces the transpose + rank kernels (A/B, tests)
+  // optional per-call kernel timing (option "kernel_timing"): start / before scoring kernel / end
+  bool kernel_timing = false, timing_pending = false;
+  hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
+  // sparse forests (ddt_load_model_sparse)
+  bool sparse = false;
+  ddt::SparseForest sp;
+  int sparse_top_levels = -1;   // option "sparse_top_levels": K, -1 = the most the LDS takes
+  int sparse_deep_order = 1;    // option "sparse_deep_order": 0 = level order, 1 = depth-first per sub-tree
+  int leaf_domain_check = 1;    // option "leaf_domain_check": reject leaves outside the exact domain of the reference adder
+  ddt_stats st{};
+  char err[256] = {0};
+};
+
+namespace ddt {
+
+inline int fail(ddt_engine* e, int code, const char* fmt, ...) {
+  if (e) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(e->err, sizeof(e->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                          \
+  do {                                                                                            \
+    hipError_t _r = (call);                                                                       \
+    if (_r != hipSuccess) return fail((e), DDT_EHIP, "%s -> %s", #call, hipGetErrorString(_r));   \
+  } while (0)
+
+// RAII: make the engine's device current for the duration of a C-ABI call and restore the caller's device (several
+// engines on different GPUs may live in one process; kernel launches and allocations follow the CURRENT device)
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    else prev = -1;  // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// helpers defined in ddt_engine.cpp
+uint32_t tuple_words(const ddt_params& p);
+uint32_t thr_key(const ddt_params& p, uint32_t bits);
+std::vector<uint32_t> shard_of(const std::vector<uint32_t>& ids, uint32_t g, uint32_t G);
+void free_images(ddt_engine* e);
+void free_q16_workspace(ddt_engine* e);
+int find_variant(const char* name);
+bool leaf_outside_exact_domain(uint32_t bits);
+// one scoring pass of the loaded model (perfect or sparse) over device-resident tuples, asynchronous on `s`
+int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s);
+int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s);
+// ddt_sparse_host.cpp
+void sparse_free(ddt_engine* e);
+int sparse_launch(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s);
+int sparse_rebuild(ddt_engine* e);
+
+}  // namespace ddt

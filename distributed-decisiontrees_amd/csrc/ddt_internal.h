@@ -70,7 +70,25 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   FusedPlan fused;            // groups == 0: use transpose_kernel + rank_kernel
 };
 
-enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2, kKindQ16 = 3 };
+// ---------------------------------------------------------------------------------------------------
+// Sparse (explicit-children) forests -- include/ddt.h ddt_load_model_sparse, kernel in ddt_sparse.hip.
+//   top image   per PU group of 8 trees, per tree 12 * 2^K bytes: the first K levels as a PERFECT heap (early leaves
+//               padded with dummy nodes): [0, 4*2^K) 8-byte records {thr_key, w} of levels 0..K-2 (1-based heap, record 0
+//               padding), [4*2^K, 12*2^K) 2^(K-1) 16-byte records {thr_key, w, left, right} of level K-1
+//   deep array  one 16-byte record {thr_key, w, left, right} per internal node at depth >= K, whole engine
+//   w           = absolute LDS byte address of the feature row | kFlagMissRight | kSpLeftLeaf | kSpRightLeaf
+//   left/right  = index into the deep array, or the leaf's fp32 bits when the matching flag is set
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kSpLeftLeaf = 0x40000000u, kSpRightLeaf = 0x20000000u, kSpAddrMask = 0x1FFFFFFFu;
+constexpr int kSparseThreads = 256;      // tuples per tile == threads per block
+constexpr int kSparseMinTop = 6, kSparseMaxTop = 10;
+
+struct SparseAux {           // ScoreArgs::aux of the sparse kernels
+  const uint4* deep;         // deep records (at least one, record 0 is a valid dummy)
+  uint32_t n_groups;         // PU groups of 8 trees in the top image
+};
+
+enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2, kKindQ16 = 3, kKindSparse = 4 };
 
 struct Variant {
   const char* name;
@@ -109,6 +127,13 @@ struct Variant {
   uint32_t tree_bytes_q16() const { return 8u << levels; }
   uint32_t feat_off_q16() const { return 2u * tree_bytes_q16() * (uint32_t)chunk_trees; }
   uint32_t lds_bytes_q16(uint32_t tuple_words) const { return feat_off_q16() + tuple_words * tile() * 2u; }
+  // ---- sparse kernels (levels = K, the top levels staged in LDS): LDS = [top image of one PU group][feature tile] ----
+  uint32_t top_bytes_sparse() const { return 12u << levels; }
+  uint32_t feat_off_sparse() const {
+    const uint32_t row = row_bytes(), need = 8u * top_bytes_sparse();
+    return (need + row - 1u) / row * row;
+  }
+  uint32_t lds_bytes_sparse(uint32_t tuple_words) const { return feat_off_sparse() + tuple_words * row_bytes() + 64u; }
 };
 
 int num_variants();
@@ -119,6 +144,8 @@ constexpr int kGenericThreads = 256;
 hipError_t launch_generic(const ScoreArgs& a, const Variant& v, hipStream_t s);
 uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds, uint32_t* top_levels);
 uint32_t stream_blocks_per_cu(uint32_t lds_bytes);
+
+hipError_t launch_sparse(const ScoreArgs& a, const Variant& v, hipStream_t s);  // ddt_sparse.hip
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s);
 hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s);
@@ -134,6 +161,7 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
 }
 constexpr uint64_t kSeedX = 0x0DD7000000000001ull;
 constexpr uint64_t kSeedM = 0x0DD7000000000002ull;
+constexpr uint64_t kSeedS = 0x0DD7000000000003ull;  // synthetic sparse forests (ddt_synth_sparse_model)
 
 // IEEE order-preserving key (cmp_mode 1): signed-int compare of keys == IEEE '<' on the floats;
 // every NaN -> INT_MAX (never "less"), -0 -> +0.

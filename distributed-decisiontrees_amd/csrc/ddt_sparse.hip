@@ -1,0 +1,176 @@
+// ddt_sparse.hip -- scoring kernel for SPARSE (explicit-children) forests: BASELINE config 4, deep random forests.
+//
+// What it replaces: nothing that works in the reference -- its engine only takes perfect trees that fit a PU's BRAM
+// (rtl/DTEngine/core/DTPU.sv:20-28); the hook for bigger trees is the disabled hybrid path (entry bit 14 "next node
+// is a leaf", DTPU.sv:637,661,675,712-715; PartialTrees, Core.sv:380 bit 8, DTPU.sv:736-745).  The per-node work is
+// the reference's: read node -> gather feature -> compare / missing rule -> next node (DTPU.sv:579-720), leaf sums in
+// the reference's adder order (FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131, Core.sv:486-541).
+//
+// Mapping: lane = tuple, 256 tuples per block with their features feature-major in LDS (the per-lane gather x[fidx]
+// is then bank-conflict free for any fidx), the 8 trees of a PU group walked in lock-step (8 independent dependent-
+// load chains per lane).  A tree is walked in two phases:
+//   top    the first K levels, stored as a perfect heap and staged in LDS by global->LDS DMA (one image per group,
+//          single buffer: the DMA of group g+1 is issued right after the last LDS read of group g and overlaps the
+//          deep phase of group g)
+//   deep   16-byte records {thr, w, left, right} gathered from L2 / HBM: child pointers or leaf values are IN the
+//          parent's record, so a visit is ONE 16-byte load and the leaf needs no extra access.  Lanes that reached a
+//          leaf idle until the wave's deepest lane is done (__ballot early exit, per tree and per wave).
+// No MFMA: compare + gather.  Bound by the vector-memory gather rate of the deep phase.
+#include <hip/hip_runtime.h>
+
+#include "ddt_device.h"
+#include "ddt_internal.h"
+
+namespace ddt {
+
+// one visit on a 16-byte record: returns the child word; `leaf` = that child is a leaf value
+__device__ __forceinline__ uint32_t visit16(const uint4 r, const uint32_t lane_off, const uint32_t miss_key, bool& leaf) {
+  const uint32_t f = lds_u32((r.y & kSpAddrMask) | lane_off);
+  const bool right = go_right<true>(f, r.x, r.y, miss_key);
+  leaf = (r.y & (right ? kSpRightLeaf : kSpLeftLeaf)) != 0u;
+  return right ? r.w : r.z;
+}
+
+template <int K>
+__global__ __launch_bounds__(kSparseThreads) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
+  constexpr int THREADS = kSparseThreads;
+  constexpr int TOPB = 12 << K;          // bytes of one tree's top image
+  constexpr int GROUPB = 8 * TOPB;       // one PU group
+  constexpr int ROW = THREADS * 4;
+  constexpr int FEAT_OFF = (GROUPB + ROW - 1) / ROW * ROW;
+  static_assert((GROUPB / 16) % 64 == 0, "whole waves per DMA");
+  const int tid = threadIdx.x;
+  const uint64_t tile0 = (uint64_t)blockIdx.x * THREADS;
+  const uint32_t W = a.tuple_words, lpt = W / 4u;
+
+  dma_chunk<THREADS, GROUPB>(a.img, 0, 0, tid);  // top image of group 0
+
+  // ---- stage the tuple tile feature-major (quad-coalesced loads + in-quad DPP transpose, see score_tile_kernel) ----
+  {
+    const uint32_t col = (uint32_t)tid, t4 = col & 3u;
+    const bool valid = tile0 + col < a.n;
+    const uint64_t quad_row = tile0 + (uint64_t)(col & ~3u);
+    uint32_t miss_any = 0;  // unused: this kernel always applies the per-node missing rule
+    for (uint32_t g0 = 0; g0 < lpt; g0 += 8) {
+      u32x4 v[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t line = g0 + 4u * h + t4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint64_t rj = quad_row + (uint64_t)j;
+          v[h][j] = (rj < a.n && line < lpt) ? *reinterpret_cast<const u32x4*>(a.tuples + rj * W + 4u * line) : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        quad_transpose(v[h], t4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t line = g0 + 4u * h + (uint32_t)i;
+          if (line < lpt) {
+            const uint32_t fa = (uint32_t)FEAT_OFF + (4u * line) * (uint32_t)ROW + col * 4u;
+            lds_st_u32(fa + 0 * ROW, stage_word(v[h][i].x, a, miss_any, valid));
+            lds_st_u32(fa + 1 * ROW, stage_word(v[h][i].y, a, miss_any, valid));
+            lds_st_u32(fa + 2 * ROW, stage_word(v[h][i].z, a, miss_any, valid));
+            lds_st_u32(fa + 3 * ROW, stage_word(v[h][i].w, a, miss_any, valid));
+          }
+        }
+      }
+    }
+  }
+
+  RefAcc<1> ra;
+  ra.init();
+  double dacc = 0.0;
+  const uint32_t lane_off = (uint32_t)tid * 4u, miss_key = a.miss_key, C = a.clusters;
+  const uint4* __restrict__ deep = x.deep;
+
+  for (uint32_t g = 0; g < x.n_groups; ++g) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // top image g (and, first pass, the feature tile) is in LDS for everyone
+
+    // ---- top phase: levels 0..K-2 over 8-byte heap records, level K-1 over 16-byte records ----
+    uint32_t m8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m8[u] = 8u;
+#pragma unroll
+    for (int lvl = 0; lvl < K - 1; ++lvl) {
+      uint2 nd[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nd[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
+      uint32_t f[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f[u] = lds_u32((nd[u].y & kSpAddrMask) | lane_off);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m8[u] = (m8[u] << 1) + (go_right<true>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
+    }
+    uint4 r[8];  // m8 = 8 * heap index in [2^(K-1), 2^K): record at 4*2^K + 16*(m - 2^(K-1)) = 2*m8 - 4*2^K
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = lds_u4((m8[u] << 1) - (uint32_t)(4 << K) + (uint32_t)(u * TOPB));
+    __syncthreads();  // every wave holds its level K-1 records: the top image buffer is free
+    if (g + 1 < x.n_groups) dma_chunk<THREADS, GROUPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
+
+    // ---- deep phase ----
+    uint32_t act = 0xFFu;  // per lane: trees still walking
+    float leafv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) leafv[u] = 0.f;
+    for (;;) {
+      uint32_t idx[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        bool leaf;
+        const uint32_t nxt = visit16(r[u], lane_off, miss_key, leaf);
+        const bool on = (act >> u) & 1u;
+        if (on && leaf) {
+          leafv[u] = __uint_as_float(nxt);
+          act &= ~(1u << u);
+        }
+        idx[u] = (on && !leaf) ? nxt : 0u;  // finished lanes re-read record 0 (one shared line): branch-free loads
+      }
+      if (__ballot(act != 0u) == 0ull) break;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (__ballot((act >> u) & 1u) != 0ull) r[u] = deep[idx[u]];  // wave-uniform skip of finished trees
+    }
+
+    if (a.sum_mode == 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dacc += (double)leafv[u];
+    } else {
+      const float s[1] = {((leafv[0] + leafv[1]) + (leafv[2] + leafv[3])) + ((leafv[4] + leafv[5]) + (leafv[6] + leafv[7]))};
+      ra.push_group(s, C);
+    }
+  }
+  ra.align(C);
+  const uint64_t row = tile0 + (uint64_t)tid;
+  if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C);
+}
+
+template <int K>
+static hipError_t launch_sparse_k(const ScoreArgs& a, const SparseAux& x, uint32_t lds, hipStream_t s) {
+  auto kern = score_sparse_kernel<K>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const uint64_t blocks = (a.n + kSparseThreads - 1) / kSparseThreads;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(kSparseThreads), lds, s, a, x);
+  return hipGetLastError();
+}
+
+hipError_t launch_sparse(const ScoreArgs& a, const Variant& v, hipStream_t s) {
+  const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
+  const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
+  switch (v.levels) {
+    case 6: return launch_sparse_k<6>(a, x, lds, s);
+    case 7: return launch_sparse_k<7>(a, x, lds, s);
+    case 8: return launch_sparse_k<8>(a, x, lds, s);
+    case 9: return launch_sparse_k<9>(a, x, lds, s);
+    case 10: return launch_sparse_k<10>(a, x, lds, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace ddt

@@ -1,0 +1,309 @@
+// ddt_sparse_host.cpp -- host side of the SPARSE (explicit-children) forest path: stream validation, tree sharding,
+// packing of the device images (top-K heap per PU group + deep records) and the launch.  Format: include/ddt.h
+// (ddt_load_model_sparse); device layout: ddt_internal.h "Sparse forests"; kernel: ddt_sparse.hip.
+//
+// Reference anchors: the perfect-tree engine this extends is rtl/DTEngine/core/DTPU.sv:579-760; its capacity limit and
+// the (disabled) hook for trees that exceed it are DTPU.sv:20-28,736-745 and Core.sv:380 bit 8; entry bit layout
+// DTPU.sv:628,637,659-661; contiguous per-device tree shards PCIeReceiver.sv:241-264; EMPTY slots DTPU.sv:544,760.
+#include <algorithm>
+
+#include "ddt_engine_priv.h"
+
+namespace ddt {
+
+namespace {
+
+struct Cursor {  // a position while expanding the top heap: an internal node of the tree, or a leaf value
+  bool leaf;
+  uint32_t v;    // node index / leaf bits
+};
+
+// pick K (levels of every tree staged in LDS): the most the LDS takes next to the feature tile, no more than the
+// deepest tree needs, or the user's choice (option "sparse_top_levels")
+int pick_variant(ddt_engine* e, uint32_t max_depth) {
+  const uint32_t W = tuple_words(e->p);
+  int best = -1;
+  for (int K = kSparseMinTop; K <= kSparseMaxTop; ++K) {
+    char name[32];
+    snprintf(name, sizeof(name), "sparse_k%d", K);
+    const int vid = find_variant(name);
+    if (vid < 0) continue;
+    if (variant(vid).lds_bytes_sparse(W) > kMaxLdsBytes) break;
+    if (e->sparse_top_levels >= 0) {
+      if (K == e->sparse_top_levels) return vid;
+      continue;
+    }
+    best = vid;
+    if ((uint32_t)K >= max_depth) break;  // nothing left for the deep phase beyond this
+  }
+  return e->sparse_top_levels >= 0 ? -1 : best;
+}
+
+}  // namespace
+
+void sparse_free(ddt_engine* e) {
+  for (void** p : {&e->sp.d_top, &e->sp.d_deep}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  e->sp.top_bytes = e->sp.deep_bytes = 0;
+  e->sp.groups = 0;
+}
+
+// Pack the device images of e->sp for the chosen K and upload them.
+int sparse_rebuild(ddt_engine* e) {
+  SparseForest& sp = e->sp;
+  const int vid = pick_variant(e, sp.max_depth);
+  if (vid < 0)
+    return fail(e, DDT_EUNSUPPORTED, "no sparse kernel fits: %u tuple words need more than %u bytes of LDS (or sparse_top_levels %d does not fit)",
+                tuple_words(e->p), kMaxLdsBytes, e->sparse_top_levels);
+  const Variant& v = variant(vid);
+  const uint32_t K = (uint32_t)v.levels, T = sp.trees();
+  const uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
+  const uint32_t top_words = (12u << K) / 4u;       // per tree
+  const uint32_t feat_off = v.feat_off_sparse(), row = v.row_bytes();
+  auto feat_word = [&](uint32_t j) { return feat_off + j * row; };
+
+  std::vector<uint32_t> top, deep;
+  try {
+    top.assign((size_t)groups * 8u * top_words, 0u);
+  } catch (const std::bad_alloc&) {
+    return fail(e, DDT_ENOMEM, "sparse top image allocation failed");
+  }
+  // dummy record: both children are the leaf +0 (EMPTY slots and the padding under early leaves use it with their value)
+  auto put8 = [&](uint32_t* t, uint32_t m, uint32_t key, uint32_t w) {
+    t[2u * m + 0u] = key;
+    t[2u * m + 1u] = w;
+  };
+  auto put16 = [&](uint32_t* rec, uint32_t key, uint32_t w, uint32_t l, uint32_t r) {
+    rec[0] = key;
+    rec[1] = w;
+    rec[2] = l;
+    rec[3] = r;
+  };
+  deep.assign(4u, 0u);  // record 0: a valid dummy (finished lanes keep re-reading it)
+  put16(deep.data(), 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
+
+  std::vector<Cursor> cur, nxt;
+  std::vector<std::pair<uint32_t, uint32_t*>> pending;  // (tree node at depth K, slot of the parent's child word to patch)
+  std::vector<uint32_t> order, stack;
+  for (uint32_t i = 0; i < groups * 8u; ++i) {
+    uint32_t* t = top.data() + (size_t)i * top_words;
+    uint32_t* last = t + (4u << K) / 4u;  // 16-byte records of level K-1
+    if (i >= T) {  // EMPTY slot: contributes exactly +0 (DTPU.sv:544,760)
+      for (uint32_t m = 1; m < (1u << (K - 1)); ++m) put8(t, m, 0u, feat_word(0));
+      for (uint32_t r = 0; r < (1u << (K - 1)); ++r) put16(last + 4u * r, 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
+      continue;
+    }
+    const uint32_t* L = sp.lines.data() + sp.first[i] * 4u;
+    auto child = [&](uint32_t n, uint32_t side) { return Cursor{((L[4u * n + 1u] >> (14u + side)) & 1u) != 0u, L[4u * n + 2u + side]}; };
+    auto node_w = [&](uint32_t n) { return feat_word(L[4u * n + 1u] & 0x7FFu) | (((L[4u * n + 1u] >> 13) & 1u) ? kFlagMissRight : 0u); };
+    // ---- top heap, level by level ----
+    cur.assign(1, Cursor{false, 0u});
+    for (uint32_t lvl = 0; lvl + 1u < K; ++lvl) {
+      nxt.clear();
+      for (uint32_t k = 0; k < cur.size(); ++k) {
+        const uint32_t m = (1u << lvl) + k;
+        if (cur[k].leaf) {  // padding under an early leaf: any direction ends on the same value
+          put8(t, m, 0u, feat_word(0));
+          nxt.push_back(cur[k]);
+          nxt.push_back(cur[k]);
+        } else {
+          const uint32_t n = cur[k].v;
+          put8(t, m, thr_key(e->p, L[4u * n]), node_w(n));
+          nxt.push_back(child(n, 0));
+          nxt.push_back(child(n, 1));
+        }
+      }
+      cur.swap(nxt);
+    }
+    // ---- level K-1: 16-byte records whose children are leaves or deep records ----
+    pending.clear();
+    for (uint32_t k = 0; k < cur.size(); ++k) {
+      uint32_t* rec = last + 4u * k;
+      if (cur[k].leaf) {
+        put16(rec, 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, cur[k].v, cur[k].v);
+        continue;
+      }
+      const uint32_t n = cur[k].v;
+      uint32_t w = node_w(n);
+      for (uint32_t side = 0; side < 2; ++side) {
+        const Cursor c = child(n, side);
+        if (c.leaf) {
+          w |= side ? kSpRightLeaf : kSpLeftLeaf;
+          rec[2u + side] = c.v;
+        } else {
+          pending.push_back({c.v, rec + 2u + side});
+        }
+      }
+      rec[0] = thr_key(e->p, L[4u * n]);
+      rec[1] = w;
+    }
+    // ---- deep records of this tree: the sub-trees hanging below level K-1 ----
+    // order 0: all of them level by level (breadth-first over the whole remainder of the tree);
+    // order 1: one sub-tree after the other, each in depth-first pre-order (a parent's left child is the next
+    //          record: half of the steps of a walk stay inside the cache line they are in)
+    order.clear();
+    if (e->sparse_deep_order == 0) {
+      for (auto& pe : pending) order.push_back(pe.first);
+      for (size_t q = 0; q < order.size(); ++q)
+        for (uint32_t side = 0; side < 2; ++side) {
+          const Cursor c = child(order[q], side);
+          if (!c.leaf) order.push_back(c.v);
+        }
+    } else {
+      for (auto& pe : pending) {
+        stack.assign(1, pe.first);
+        while (!stack.empty()) {
+          const uint32_t n = stack.back();
+          stack.pop_back();
+          order.push_back(n);
+          const Cursor r = child(n, 1), l = child(n, 0);
+          if (!r.leaf) stack.push_back(r.v);
+          if (!l.leaf) stack.push_back(l.v);  // popped first: pre-order, left before right
+        }
+      }
+    }
+    const size_t base = deep.size() / 4u;
+    if (base + order.size() > 0xFFFFFFFFull) return fail(e, DDT_EUNSUPPORTED, "more than 2^32 deep records");
+    // node -> deep index: the tree's node indices are dense, use a scratch map sized by the tree
+    const uint64_t cnt = sp.first[i + 1] - sp.first[i];
+    std::vector<uint32_t> where(cnt, 0u);
+    for (size_t q = 0; q < order.size(); ++q) where[order[q]] = (uint32_t)(base + q);
+    deep.resize(deep.size() + order.size() * 4u);
+    for (size_t q = 0; q < order.size(); ++q) {
+      const uint32_t n = order[q];
+      uint32_t* rec = deep.data() + (base + q) * 4u;
+      uint32_t w = node_w(n);
+      for (uint32_t side = 0; side < 2; ++side) {
+        const Cursor c = child(n, side);
+        if (c.leaf) w |= side ? kSpRightLeaf : kSpLeftLeaf;
+        rec[2u + side] = c.leaf ? c.v : where[c.v];
+      }
+      rec[0] = thr_key(e->p, L[4u * n]);
+      rec[1] = w;
+    }
+    for (auto& pe : pending) *pe.second = where[pe.first];
+  }
+
+  sparse_free(e);
+  HIP_TRY(e, hipMalloc(&sp.d_top, top.size() * 4u));
+  HIP_TRY(e, hipMalloc(&sp.d_deep, deep.size() * 4u));
+  HIP_TRY(e, hipMemcpy(sp.d_top, top.data(), top.size() * 4u, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(sp.d_deep, deep.data(), deep.size() * 4u, hipMemcpyHostToDevice));
+  sp.top_bytes = top.size() * 4u;
+  sp.deep_bytes = deep.size() * 4u;
+  sp.groups = groups;
+  e->variant_id = vid;
+  return DDT_OK;
+}
+
+int sparse_launch(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
+  const SparseForest& sp = e->sp;
+  const Variant& v = variant(e->variant_id);
+  ScoreArgs a{};
+  a.img = reinterpret_cast<const uint4*>(sp.d_top);
+  a.tuples = reinterpret_cast<const uint32_t*>(d_tuples);
+  a.out = d_scores;
+  a.n = n;
+  a.tuple_words = tuple_words(e->p);
+  a.n_trees = sp.groups * 8u;
+  a.n_chunks = sp.groups;
+  a.levels = (uint32_t)v.levels;
+  a.clusters = e->p.clusters_per_tuple;
+  a.miss_raw = e->p.missing_bits;
+  a.miss_key = e->p.cmp_mode ? kMissSentinelIeee : e->p.missing_bits;
+  a.ieee = e->p.cmp_mode;
+  a.sum_mode = e->p.sum_mode;
+  SparseAux x;
+  x.deep = reinterpret_cast<const uint4*>(sp.d_deep);
+  x.n_groups = sp.groups;
+  a.aux = &x;
+  hipError_t r = v.launch(a, v, s);
+  if (r != hipSuccess) return fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
+  return DDT_OK;
+}
+
+}  // namespace ddt
+
+using namespace ddt;
+
+extern "C" int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const void* node_lines, size_t n_lines,
+                                     const uint64_t* first, uint32_t shard_index, uint32_t shard_count) {
+  if (!e) return DDT_EINVAL;
+  if (!p || !node_lines || !first) return fail(e, DDT_EINVAL, "NULL argument");
+  if (p->num_trees == 0) return fail(e, DDT_EINVAL, "num_trees == 0");
+  if (p->num_levels < 1 || p->num_levels > 64) return fail(e, DDT_EINVAL, "num_levels %u not in 1..64 (depth bound of a sparse model)", p->num_levels);
+  if (p->num_features < 1 || p->num_features > 2048) return fail(e, DDT_EINVAL, "num_features %u not in 1..2048 (DTPU.sv:72)", p->num_features);
+  if (p->cmp_mode > 1 || p->sum_mode > 1) return fail(e, DDT_EINVAL, "cmp_mode %u / sum_mode %u", p->cmp_mode, p->sum_mode);
+  const uint32_t c = p->clusters_per_tuple;
+  if (c != 1 && c != 2 && c != 4 && c != 8) return fail(e, DDT_EINVAL, "clusters_per_tuple %u not in {1,2,4,8}", c);
+  if (p->reserved[0] | p->reserved[1] | p->reserved[2]) return fail(e, DDT_EINVAL, "reserved fields must be 0");
+  if (shard_count == 0 || shard_index >= shard_count || shard_count > p->num_trees)
+    return fail(e, DDT_EINVAL, "shard %u of %u (trees %u)", shard_index, shard_count, p->num_trees);
+  if (first[0] != 0 || first[p->num_trees] > n_lines) return fail(e, DDT_EINVAL, "tree_first_line does not start at 0 / exceeds the stream");
+  const double t0 = now_ms();
+  const uint32_t* lines = reinterpret_cast<const uint32_t*>(node_lines);
+
+  std::vector<uint32_t> all(p->num_trees);
+  for (uint32_t i = 0; i < p->num_trees; ++i) all[i] = i;
+  SparseForest sp;
+  sp.ids = shard_of(all, shard_index, shard_count);  // contiguous shards of ceil(T/G) trees; trailing shards may be empty
+  sp.first.assign(1, 0u);
+  std::vector<uint8_t> depth;
+  for (uint32_t id : sp.ids) {
+    if (first[id + 1] <= first[id]) return fail(e, DDT_EINVAL, "tree %u has no lines", id);
+    const uint64_t cnt = first[id + 1] - first[id];
+    if (cnt > 0xFFFFFFFFull) return fail(e, DDT_EUNSUPPORTED, "tree %u has more than 2^32 nodes", id);
+    const uint32_t* t = lines + first[id] * 4u;
+    depth.assign(cnt, 0);
+    for (uint64_t n = 0; n < cnt; ++n) {
+      const uint32_t en = t[4u * n + 1u];
+      if (en >> 16) return fail(e, DDT_EINVAL, "tree %u node %llu: word 1 bits [31:16] must be 0", id, (unsigned long long)n);
+      if ((en & 0x7FFu) >= p->num_features)
+        return fail(e, DDT_EINVAL, "tree %u node %llu: feature index %u >= num_features %u", id, (unsigned long long)n, en & 0x7FFu, p->num_features);
+      if ((uint32_t)depth[n] + 1u > p->num_levels) return fail(e, DDT_EINVAL, "tree %u is deeper than num_levels %u", id, p->num_levels);
+      if ((uint32_t)depth[n] + 1u > sp.max_depth) sp.max_depth = (uint32_t)depth[n] + 1u;
+      for (uint32_t side = 0; side < 2; ++side) {
+        const uint32_t cw = t[4u * n + 2u + side];
+        if ((en >> (14u + side)) & 1u) {
+          if (p->sum_mode == 0 && e->leaf_domain_check && leaf_outside_exact_domain(cw))
+            return fail(e, DDT_EUNSUPPORTED,
+                        "tree %u node %llu: leaf 0x%08X is -0 / sub-normal / Inf / NaN, outside the domain where IEEE adds equal the reference "
+                        "adder (flush to +0 when exporting, use sum_mode 1, or set option leaf_domain_check = 0)", id, (unsigned long long)n, cw);
+          continue;
+        }
+        if (cw <= n || cw >= cnt)  // children after their parent: every walk terminates
+          return fail(e, DDT_EINVAL, "tree %u node %llu: child index %u out of order / range (%llu nodes)", id, (unsigned long long)n, cw,
+                      (unsigned long long)cnt);
+        depth[cw] = (uint8_t)(depth[n] + 1u);
+      }
+    }
+    try {
+      sp.lines.insert(sp.lines.end(), t, t + cnt * 4u);
+    } catch (const std::bad_alloc&) {
+      return fail(e, DDT_ENOMEM, "host model allocation failed");
+    }
+    sp.first.push_back(sp.first.back() + cnt);
+  }
+
+  DeviceGuard dg(e->device);
+  if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
+  HIP_TRY(e, hipDeviceSynchronize());  // asynchronous scoring of the previous model may still be in flight
+  free_images(e);
+  free_q16_workspace(e);
+  sparse_free(e);
+  e->ens.clear();
+  e->loaded = false;
+  e->p = *p;
+  e->nint = e->nleaf = 0;
+  e->num_classes = 1;
+  e->sp = std::move(sp);
+  e->sparse = true;
+  int rc = sparse_rebuild(e);
+  if (rc) return rc;
+  e->loaded = true;
+  e->st.model_lines_in += e->sp.lines.size() / 4u;
+  e->st.prog_ms += now_ms() - t0;
+  return DDT_OK;
+}

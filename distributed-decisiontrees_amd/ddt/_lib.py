@@ -16,6 +16,7 @@ SYMBOLS = [
     "ddt_chain_sum_device", "ddt_load_model_multiclass", "ddt_classify_device", "ddt_classify", "ddt_argmax_device",
     "ddt_csr_encode", "ddt_csr_decode", "ddt_get_info", "ddt_get_stats", "ddt_strerror", "ddt_last_error", "ddt_set_option",
     "ddt_num_variants", "ddt_variant_name", "ddt_synth_model", "ddt_synth_tuples_host", "ddt_synth_tuples_device",
+    "ddt_load_model_sparse", "ddt_synth_sparse_model", "ddt_csr_encode_ex", "ddt_csr_decode_ex",
 ]
 
 
@@ -101,6 +102,13 @@ def lib():
     L.ddt_set_option.restype, L.ddt_set_option.argtypes = i32, [vp, C.c_char_p, i64]
     L.ddt_num_variants.restype, L.ddt_num_variants.argtypes = i32, []
     L.ddt_variant_name.restype, L.ddt_variant_name.argtypes = i32, [i32, C.c_char_p, sz]
+    L.ddt_load_model_sparse.restype, L.ddt_load_model_sparse.argtypes = i32, [vp, PP, vp, sz, vp, u32, u32]
+    L.ddt_synth_sparse_model.restype = C.c_int64
+    L.ddt_synth_sparse_model.argtypes = [u32, u32, u32, u32, u32, i32, vp, sz, vp]
+    L.ddt_csr_encode_ex.restype, L.ddt_csr_encode_ex.argtypes = i32, [PP, u64, u32, u32, u32, C.POINTER(u64 * 12)]
+    L.ddt_csr_decode_ex.restype = i32
+    L.ddt_csr_decode_ex.argtypes = [C.POINTER(u64 * 12), PP, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32),
+                                    C.POINTER(u32), C.POINTER(C.c_uint8 * 20)]
     L.ddt_synth_model.restype, L.ddt_synth_model.argtypes = i32, [u32, u32, u32, i32, vp, vp]
     L.ddt_synth_tuples_host.restype, L.ddt_synth_tuples_host.argtypes = i32, [vp, u64, sz, u32, i32, u32]
     L.ddt_synth_tuples_device.restype, L.ddt_synth_tuples_device.argtypes = i32, [vp, vp, u64, sz, u32, i32, u32, vp]

@@ -66,6 +66,29 @@ def synth_model(T: int, D: int, F: int, dist: int = 0):
     return w, f
 
 
+def make_sparse_params(T: int, max_depth: int, F: int, missing_bits: int = MISSING_DEFAULT, cmp_mode: int = 0,
+                       clusters: int | None = None, sum_mode: int = 0) -> Params:
+    """Parameters of a SPARSE (explicit-children) model: num_levels is the depth bound, no lines-per-tree fields."""
+    p = Params()
+    p.num_trees, p.num_levels, p.num_features, p.missing_bits = T, max_depth, F, missing_bits
+    p.cmp_mode, p.sum_mode = cmp_mode, sum_mode
+    p.clusters_per_tuple = default_clusters(T) if clusters is None else clusters
+    return p
+
+
+def synth_sparse_model(T: int, max_depth: int, F: int, full_levels: int, split_permille: int, dist: int = 0):
+    """Deterministic random-forest-like sparse model (include/ddt.h ddt_synth_sparse_model)
+    -> (node_lines uint32 [n, 4], tree_first_line uint64 [T + 1])."""
+    L = _lib.lib()
+    first = np.zeros(T + 1, np.uint64)
+    n = L.ddt_synth_sparse_model(T, max_depth, F, full_levels, split_permille, dist, None, 0, first.ctypes.data)
+    if n < 0:
+        raise DDTError(int(n))
+    lines = np.zeros((n, 4), np.uint32)
+    L.ddt_synth_sparse_model(T, max_depth, F, full_levels, split_permille, dist, lines.ctypes.data, n, first.ctypes.data)
+    return lines, first
+
+
 def synth_tuples_host(row0: int, n: int, F: int, dist: int = 0, missing_bits: int = MISSING_DEFAULT) -> np.ndarray:
     out = np.zeros((n, tuple_words(F)), np.uint32)
     rc = _lib.lib().ddt_synth_tuples_host(out.ctypes.data, row0, n, F, dist, missing_bits)
@@ -86,6 +109,7 @@ class Engine:
         self._h = h
         self.device = device
         self.params = None
+        self.num_classes = 1
 
     def close(self):
         if getattr(self, "_h", None):
@@ -110,6 +134,20 @@ class Engine:
         self._check(self._L.ddt_load_model_shard(self._h, C.byref(params), w.ctypes.data, w.size // 4,
                                                  f.ctypes.data, f.size // 8, shard_index, shard_count))
         self.params = params
+        self.num_classes = 1
+        return self
+
+    def load_model_sparse(self, params: Params, node_lines: np.ndarray, tree_first_line: np.ndarray,
+                          shard_index: int = 0, shard_count: int = 1):
+        """Sparse (explicit-children) forest: one 128-bit line per internal node (include/ddt.h ddt_load_model_sparse)."""
+        nl = np.ascontiguousarray(node_lines).view(np.uint32).reshape(-1, 4)
+        first = np.ascontiguousarray(tree_first_line, dtype=np.uint64).reshape(-1)
+        if first.size != params.num_trees + 1:
+            raise ValueError("tree_first_line must hold num_trees + 1 entries")
+        self._check(self._L.ddt_load_model_sparse(self._h, C.byref(params), nl.ctypes.data, nl.shape[0],
+                                                  first.ctypes.data, shard_index, shard_count))
+        self.params = params
+        self.num_classes = 1
         return self
 
     def load_model_multiclass(self, params: Params, wlines: np.ndarray, flines: np.ndarray, num_classes: int,

@@ -19,6 +19,12 @@ Rules applied:
                    callers must present NaNs in that canonical form).
   comparator       real models have negative features, where the reference's raw-bit signed-int comparator
                    (DTPU.sv:655) is inverted; imported models therefore set cmp_mode = 1 (IEEE '<').
+  leaf values      rounded to fp32; results that are -0 or sub-normal are flushed to +0: the reference's adder treats
+                   sub-normal inputs as normals and keeps -0 (FPAdder_2cycles_latency.v:313-320,376-385), so such leaves
+                   have no exact meaning in its sum and the engine refuses them (option leaf_domain_check).
+  sparse=True      instead of padding to a perfect heap (2^(D+1) words per tree -- hopeless for a depth-16 random
+                   forest), emit the SPARSE stream of include/ddt.h (ddt_load_model_sparse): one 128-bit line per internal
+                   node {threshold, feature entry | leaf flags, left, right} in breadth-first order.
 """
 from __future__ import annotations
 
@@ -27,7 +33,8 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .engine import MISSING_DEFAULT, findex_lines_per_tree, make_params, weights_lines_per_tree
+from .engine import (MISSING_DEFAULT, findex_lines_per_tree, make_params, make_sparse_params,
+                     weights_lines_per_tree)
 
 MAX_LEVELS = 16  # CSR205 num_levels is 4 bits (EngineCSR.sv:230)
 
@@ -45,10 +52,34 @@ class ImportedModel:
     base_score: np.ndarray = field(default_factory=lambda: np.zeros(1, np.float64))  # per class, added by the caller
     missing_bits: int = MISSING_DEFAULT
     cmp_mode: int = 1
+    node_lines: np.ndarray | None = None       # sparse=True: uint32 [n_lines, 4]; wlines / flines are then empty
+    tree_first_line: np.ndarray | None = None  # sparse=True: uint64 [num_trees + 1]
+
+    @property
+    def sparse(self) -> bool:
+        return self.node_lines is not None
 
     def params(self, sum_mode: int = 0, clusters: int | None = None):
+        if self.sparse:
+            return make_sparse_params(self.num_trees, self.num_levels, self.num_features, self.missing_bits,
+                                      self.cmp_mode, clusters, sum_mode)
         return make_params(self.num_trees, self.num_levels, self.num_features, self.missing_bits, self.cmp_mode,
                            clusters, sum_mode)
+
+    def load_into(self, engine, shard_index: int = 0, shard_count: int = 1, **kw):
+        """Load this model into a ddt.Engine (single-output models; multi-class: Engine.load_model_multiclass)."""
+        if self.sparse:
+            return engine.load_model_sparse(self.params(**kw), self.node_lines, self.tree_first_line, shard_index, shard_count)
+        return engine.load_model(self.params(**kw), self.wlines, self.flines, shard_index, shard_count)
+
+
+def leaf_f32(v) -> np.float32:
+    """fp32 leaf value; -0 and sub-normal results are flushed to +0 (see the module docstring)."""
+    with np.errstate(over="ignore", under="ignore"):
+        f = np.float32(v)
+    if f == 0 or abs(f) < np.finfo(np.float32).tiny:
+        return np.float32(0.0)
+    return f
 
 
 def le_to_lt_threshold(t64) -> np.ndarray:
@@ -91,7 +122,7 @@ class _Tree:
             if k == D:
                 if not is_leaf:
                     raise ValueError("tree deeper than num_levels")
-                leaf[h - nint] = np.float32((frozen if n < 0 else float(self.value[n])) * scale)
+                leaf[h - nint] = leaf_f32((frozen if n < 0 else float(self.value[n])) * scale)
             elif is_leaf:  # pad: dummy node, both children repeat the leaf value
                 v = frozen if n < 0 else float(self.value[n])
                 stack.append((-1, 2 * h + 1, k + 1, v))
@@ -103,7 +134,52 @@ class _Tree:
         return thr, fidx, mr, leaf
 
 
-def _pack(trees, scales, num_features, num_classes=1, base=None, num_levels=None) -> ImportedModel:
+    def to_sparse(self, scale: float = 1.0) -> np.ndarray:
+        """-> uint32 [n_internal, 4] node lines in breadth-first order (children after their parent)."""
+        if self.left[0] < 0:  # a single leaf: one line, both children the value
+            v = leaf_f32(float(self.value[0]) * scale).view(np.uint32)
+            return np.array([[0, 0xC000, v, v]], np.uint32)
+        order, pos = [0], {0: 0}
+        for n in order:  # breadth-first over internal nodes
+            for c in (int(self.left[n]), int(self.right[n])):
+                if self.left[c] >= 0:
+                    pos[c] = len(order)
+                    order.append(c)
+        lines = np.zeros((len(order), 4), np.uint32)
+        for k, n in enumerate(order):
+            e = int(self.feature[n]) | (int(self.miss_right[n]) << 13)
+            lines[k, 0] = np.float32(self.thr_lt[n]).view(np.uint32)
+            for side, c in enumerate((int(self.left[n]), int(self.right[n]))):
+                if self.left[c] < 0:
+                    e |= 1 << (14 + side)
+                    lines[k, 2 + side] = leaf_f32(float(self.value[c]) * scale).view(np.uint32)
+                else:
+                    lines[k, 2 + side] = pos[c]
+            lines[k, 1] = e
+        return lines
+
+
+def _pack_sparse(trees, scales, num_features, num_classes=1, base=None, num_levels=None) -> ImportedModel:
+    D = max(1, max(t.depth() for t in trees))
+    if num_levels is not None:
+        if num_levels < D:
+            raise ValueError("tree deeper than num_levels")
+        D = num_levels
+    if D > 64:
+        raise ValueError(f"tree depth {D} exceeds the sparse format's 64 levels")
+    per = [t.to_sparse(s) for t, s in zip(trees, scales)]
+    if any((ln[:, 1] & 0x7FF).max(initial=0) >= num_features for ln in per):
+        raise ValueError("feature index out of range")
+    first = np.zeros(len(per) + 1, np.uint64)
+    first[1:] = np.cumsum([ln.shape[0] for ln in per])
+    return ImportedModel(np.zeros(0, np.uint32), np.zeros(0, np.uint16), len(trees), D, num_features, num_classes,
+                         np.zeros(num_classes) if base is None else np.asarray(base, np.float64).reshape(-1),
+                         node_lines=np.concatenate(per, axis=0), tree_first_line=first)
+
+
+def _pack(trees, scales, num_features, num_classes=1, base=None, num_levels=None, sparse=False) -> ImportedModel:
+    if sparse:
+        return _pack_sparse(trees, scales, num_features, num_classes, base, num_levels)
     D = max(1, max(t.depth() for t in trees)) if num_levels is None else num_levels
     if D > MAX_LEVELS:
         raise ValueError(f"tree depth {D} exceeds the format's {MAX_LEVELS} levels")
@@ -135,25 +211,25 @@ def _sk_tree(tree_, out_index=0, value_transform=None) -> _Tree:
     return _Tree(t.children_left, t.children_right, np.where(leafmask, 0, t.feature), le_to_lt_threshold(thr), val, mr)
 
 
-def from_sklearn(model, num_levels: int | None = None) -> ImportedModel:
+def from_sklearn(model, num_levels: int | None = None, sparse: bool = False) -> ImportedModel:
     """score(x) + base_score == model.predict(x) (regressors) / decision_function (boosted classifiers);
     RandomForest/ExtraTrees/DecisionTree classifiers: class score = mean class probability, label = argmax."""
     name = type(model).__name__
     F = int(model.n_features_in_)
     if name in ("DecisionTreeRegressor", "ExtraTreeRegressor"):
-        return _pack([_sk_tree(model.tree_)], [1.0], F, num_levels=num_levels)
+        return _pack([_sk_tree(model.tree_)], [1.0], F, num_levels=num_levels, sparse=sparse)
     if name in ("RandomForestRegressor", "ExtraTreesRegressor"):
         n = len(model.estimators_)
-        return _pack([_sk_tree(e.tree_) for e in model.estimators_], [1.0 / n] * n, F, num_levels=num_levels)
+        return _pack([_sk_tree(e.tree_) for e in model.estimators_], [1.0 / n] * n, F, num_levels=num_levels, sparse=sparse)
     if name == "GradientBoostingRegressor":
         trees = [_sk_tree(e.tree_) for e in model.estimators_[:, 0]]
         base = float(np.ravel(model.init_.predict(np.zeros((1, F))))[0]) if model.init_ != "zero" else 0.0
-        return _pack(trees, [float(model.learning_rate)] * len(trees), F, base=[base], num_levels=num_levels)
+        return _pack(trees, [float(model.learning_rate)] * len(trees), F, base=[base], num_levels=num_levels, sparse=sparse)
     if name == "GradientBoostingClassifier":
         K = model.estimators_.shape[1]  # 1 for binary (log-odds of class 1), n_classes otherwise
         trees = [_sk_tree(model.estimators_[s, k].tree_) for s in range(model.estimators_.shape[0]) for k in range(K)]
         raw0 = np.ravel(model._raw_predict_init(np.zeros((1, F))))
-        return _pack(trees, [float(model.learning_rate)] * len(trees), F, num_classes=K, base=raw0, num_levels=num_levels)
+        return _pack(trees, [float(model.learning_rate)] * len(trees), F, num_classes=K, base=raw0, num_levels=num_levels, sparse=sparse)
     if name in ("RandomForestClassifier", "ExtraTreesClassifier", "DecisionTreeClassifier", "ExtraTreeClassifier"):
         ests = [model] if name.startswith(("DecisionTree", "ExtraTreeC")) else list(model.estimators_)
         K, n = int(model.n_classes_), len(ests)
@@ -162,7 +238,7 @@ def from_sklearn(model, num_levels: int | None = None) -> ImportedModel:
             return lambda v: v[:, k] / np.maximum(v.sum(axis=1), 1e-300)
 
         trees = [_sk_tree(e.tree_, 0, prob(k)) for e in ests for k in range(K)]  # interleaved: tree i -> class i % K
-        return _pack(trees, [1.0 / n] * len(trees), F, num_classes=K, num_levels=num_levels)
+        return _pack(trees, [1.0 / n] * len(trees), F, num_classes=K, num_levels=num_levels, sparse=sparse)
     if name in ("HistGradientBoostingRegressor", "HistGradientBoostingClassifier"):
         # model._predictors[iteration][k].nodes: structured array {value, feature_idx, num_threshold, missing_go_to_left,
         # left, right, is_leaf, ...}; a sample goes left iff x <= num_threshold (missing: missing_go_to_left); the
@@ -181,14 +257,58 @@ def from_sklearn(model, num_levels: int | None = None) -> ImportedModel:
                 mr = np.where(leafmask, 0, 1 - nd["missing_go_to_left"].astype(np.uint8)).astype(np.uint8)
                 trees.append(_Tree(left, right, np.where(leafmask, 0, nd["feature_idx"]), le_to_lt_threshold(thr), nd["value"], mr))
         base = np.ravel(model._baseline_prediction).astype(np.float64)
-        return _pack(trees, [1.0] * len(trees), F, num_classes=K, base=base, num_levels=num_levels)
+        return _pack(trees, [1.0] * len(trees), F, num_classes=K, base=base, num_levels=num_levels, sparse=sparse)
     raise TypeError(f"unsupported scikit-learn model {name}")
 
 
 # ---- XGBoost JSON ---------------------------------------------------------------------------------------
-def from_xgboost_json(path_or_dict, num_levels: int | None = None) -> ImportedModel:
+# objective -> how learner_model_param.base_score (stored in the OUTPUT space) becomes the additive margin offset
+_XGB_LINK = {
+    "reg:squarederror": "identity", "reg:squaredlogerror": "identity", "reg:absoluteerror": "identity",
+    "reg:pseudohubererror": "identity", "reg:quantileerror": "identity", "binary:logitraw": "identity",
+    "binary:hinge": "identity", "rank:pairwise": "identity", "rank:ndcg": "identity", "rank:map": "identity",
+    "multi:softmax": "identity", "multi:softprob": "identity",
+    "binary:logistic": "logit", "reg:logistic": "logit",
+    "count:poisson": "log", "reg:gamma": "log", "reg:tweedie": "log", "survival:cox": "log",
+}
+
+
+def _xgb_base_scores(lmp, objective: str, K: int) -> np.ndarray:
+    """Margin-space offset(s).  base_score comes as "0.5", as a bracketed string "[5E-1]" / "[1E0,2E0]" (XGBoost >= 2,
+    which also estimates it from the data) or as a list."""
+    raw = lmp.get("base_score", "0.5")
+    if isinstance(raw, (list, tuple)):
+        vals = [float(v) for v in raw]
+    else:
+        txt = str(raw).strip()
+        vals = [float(v) for v in txt.strip("[]").split(",") if v.strip()] if txt.startswith("[") else [float(txt)]
+    if not vals:
+        vals = [0.5]
+    link = _XGB_LINK.get(objective)
+    if link is None:
+        raise TypeError(f"unsupported XGBoost objective {objective!r}: the link of base_score is not known")
+    v = np.asarray(vals, np.float64)
+    if link == "logit":
+        if np.any((v <= 0) | (v >= 1)):
+            raise ValueError("base_score of a logistic objective must lie in (0, 1)")
+        v = np.log(v / (1.0 - v))
+    elif link == "log":
+        if np.any(v <= 0):
+            raise ValueError("base_score of a log-link objective must be positive")
+        v = np.log(v)
+    if v.size == 1:
+        v = np.repeat(v, K)
+    if v.size != K:
+        raise ValueError(f"{v.size} base scores for {K} classes")
+    return v
+
+
+def from_xgboost_json(path_or_dict, num_levels: int | None = None, sparse: bool = False) -> ImportedModel:
     """XGBoost `save_model("*.json")` (gbtree).  XGBoost goes left iff x < split_condition -- the reference's rule;
-    `default_left` -> miss_right = 0.  score + base_score == margin; multi-class: tree_info gives the class."""
+    `default_left` -> miss_right = 0.  score + base_score == margin, base_score being the model's
+    learner_model_param.base_score mapped through the objective's link (logit for binary:logistic / reg:logistic, log
+    for poisson / gamma / tweedie, identity otherwise; unknown objectives are refused); multi-class: tree_info gives
+    the class."""
     j = path_or_dict if isinstance(path_or_dict, dict) else json.load(open(path_or_dict))
     learner = j["learner"]
     gb = learner["gradient_booster"]
@@ -198,7 +318,8 @@ def from_xgboost_json(path_or_dict, num_levels: int | None = None) -> ImportedMo
     lmp = learner["learner_model_param"]
     F = int(lmp["num_feature"])
     K = max(1, int(lmp.get("num_class", "0")))
-    base = float(lmp.get("base_score", "0.5")) if not isinstance(lmp.get("base_score"), list) else float(lmp["base_score"][0])
+    objective = learner.get("objective", {}).get("name", "reg:squarederror")
+    base = _xgb_base_scores(lmp, objective, K)
     info = [int(v) for v in model.get("tree_info", [0] * len(model["trees"]))]
     trees = []
     for t in model["trees"]:
@@ -212,4 +333,4 @@ def from_xgboost_json(path_or_dict, num_levels: int | None = None) -> ImportedMo
     if K > 1:  # our class rule is interleaved i % K; XGBoost's tree_info normally is exactly that
         if any(c != i % K for i, c in enumerate(info)):
             raise ValueError("tree_info is not round-robin over classes")
-    return _pack(trees, [1.0] * len(trees), F, num_classes=K, base=[base] * K, num_levels=num_levels)
+    return _pack(trees, [1.0] * len(trees), F, num_classes=K, base=base, num_levels=num_levels, sparse=sparse)

@@ -141,6 +141,24 @@ int ddt_classify(ddt_engine* e, const void* tuple_lines, size_t n_tuples, int32_
 int ddt_argmax_device(ddt_engine* e, const float* d_class_scores, uint32_t num_classes, size_t n, int32_t* d_labels,
                       void* hip_stream);
 
+/* -- sparse (explicit-children) model stream (BASELINE config 4: deep random forests; an EXTENSION -- the reference
+ *    only takes perfect trees of <= 16 levels whose 2^(D+1)-1 words fit a PU's BRAM, DTPU.sv:20-28; its own hook for
+ *    bigger trees is the disabled hybrid path: entry bit 14 "next node is a leaf", DTPU.sv:637,661,675,712-715, and
+ *    the PartialTrees control bit, Core.sv:380 bit 8, DTPU.sv:736-745 -- ill-defined in the published RTL, SURVEY
+ *    A10b).  One 128-bit line per INTERNAL node, A2 packing (PipelinedMUX.sv:65):
+ *      word 0        threshold bits
+ *      word 1[15:0]  feature-index entry in the reference's bit layout (DTPU.sv:628,637,659-661): [10:0] feature,
+ *                    [13] missing goes right, [14] the LEFT child is a leaf, [15] the RIGHT child is a leaf
+ *                    (bit 14 keeps its RTL meaning "the next node is a leaf"); word 1[31:16] must be 0
+ *      word 2, 3     left / right child: node index relative to the tree's first line, or the leaf's fp32 bits
+ *    Children must have larger indices than their parent (BFS, DFS pre-order, ...).  tree_first_line[num_trees + 1]
+ *    delimits the trees; a tree that is a single leaf is one line with both leaf flags set and the value twice.
+ *    ddt_params: num_levels = upper bound of the depth (1..64), weights/findex lines per tree ignored.  Compare rule,
+ *    missing rule, EMPTY slots, summation order and tree sharding are exactly those of the perfect format; the model
+ *    is then scored with ddt_score / ddt_score_device.  (One class only.)                                        -- */
+int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const void* node_lines, size_t n_lines,
+                          const uint64_t* tree_first_line, uint32_t shard_index, uint32_t shard_count);
+
 /* -- introspection ----------------------------------------------------------------------------------- */
 int ddt_get_info(const ddt_engine* e, ddt_info* out);
 int ddt_get_stats(const ddt_engine* e, ddt_stats* out);
@@ -163,11 +181,29 @@ int ddt_variant_name(int variant, char* buf, size_t buflen);
 #define DDT_CSR_COUNT 12
 int ddt_csr_encode(const ddt_params* p, uint64_t n_tuples, uint32_t num_devices, uint64_t csr[DDT_CSR_COUNT]);
 int ddt_csr_decode(const uint64_t csr[DDT_CSR_COUNT], ddt_params* p, uint64_t* n_tuples, uint32_t* num_devices);
+/* Per-device blocks of a multi-device job (EngineCSR.sv:194-205 mode flags, :235-243 next-hop addresses, :250-296
+ * device list at a byte stride).  shard_mode: the reference's two modes (DTInference.sv:28-37) -- DDT_SHARD_TREES =
+ * ensemble spread over the devices, tuples broadcast, partial results aggregated (broadcast_data + aggreg_enabled);
+ * DDT_SHARD_ROWS = every device holds the whole ensemble, tuples dealt in batches of 4, results forwarded
+ * (broadcast_trees).  device_index 0 is the host node, the last one sets last_node.  ddt_csr_encode() is
+ * (DDT_SHARD_TREES, device 0).  decode_ex also returns the mode, the raw CSR201[7:0] flags and the 20 device ids
+ * sliced the way the RTL slices them (any of the three may be NULL). */
+enum { DDT_SHARD_TREES = 0, DDT_SHARD_ROWS = 1 };
+int ddt_csr_encode_ex(const ddt_params* p, uint64_t n_tuples, uint32_t num_devices, uint32_t shard_mode,
+                      uint32_t device_index, uint64_t csr[DDT_CSR_COUNT]);
+int ddt_csr_decode_ex(const uint64_t csr[DDT_CSR_COUNT], ddt_params* p, uint64_t* n_tuples, uint32_t* num_devices,
+                      uint32_t* shard_mode, uint32_t* mode_flags, uint8_t device_ids[20]);
 
 /* -- deterministic synthetic inputs of SURVEY.md 8(d) (bench/test support; device generator so that
  *    the timed region starts with inputs resident in HBM) -------------------------------------------- */
 int ddt_synth_model(uint32_t num_trees, uint32_t num_levels, uint32_t num_features, int dist,
                     void* weights_lines, void* findex_lines);
+/* synthetic random-forest-like SPARSE model (deterministic): nodes above `full_levels` are all internal, below a
+ * child is internal with probability split_permille / 1000 until max_depth.  Returns the number of node lines
+ * (negative DDT_E* on bad arguments); call with node_lines == NULL to size the buffers first. */
+int64_t ddt_synth_sparse_model(uint32_t num_trees, uint32_t max_depth, uint32_t num_features, uint32_t full_levels,
+                               uint32_t split_permille, int dist, void* node_lines, size_t cap_lines,
+                               uint64_t* tree_first_line);
 int ddt_synth_tuples_host(void* tuple_lines, uint64_t row0, size_t n, uint32_t num_features, int dist,
                           uint32_t missing_bits);
 int ddt_synth_tuples_device(ddt_engine* e, void* d_tuple_lines, uint64_t row0, size_t n,

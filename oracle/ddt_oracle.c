@@ -518,3 +518,193 @@ void orc_gen_model(uint32_t T, uint32_t D, uint32_t F, int dist, uint32_t* wline
     }
   }
 }
+
+/* =============================================================================================
+ * 7. Sparse (explicit-children) model stream -- this repository's extension, see ddt_oracle.h.
+ *    Compare rule = orc_go_right (DTPU.sv:653-667); entry bits [10:0], [13] as in DTPU.sv:628,659; bit 14 keeps the
+ *    RTL's meaning "the next node is a leaf" (DTPU.sv:661) for the left branch, bit 15 says it for the right one.
+ * ============================================================================================= */
+
+int orc_sparse_check(const orc_params* p, const uint32_t* lines, size_t n_lines, const uint64_t* first) {
+  if (!p || !lines || !first || p->num_trees == 0 || p->num_levels == 0 || p->num_levels > 64 || p->num_features == 0 ||
+      p->num_features > 2048)
+    return -1;
+  if (first[0] != 0 || first[p->num_trees] > n_lines) return -2;
+  for (uint32_t i = 0; i < p->num_trees; ++i) {
+    if (first[i + 1] <= first[i]) return -2; /* every tree has at least one line */
+    const uint64_t cnt = first[i + 1] - first[i];
+    const uint32_t* t = lines + first[i] * 4u;
+    uint8_t* depth = (uint8_t*)calloc(cnt, 1);
+    for (uint64_t n = 0; n < cnt; ++n) {
+      const uint32_t e = t[4 * n + 1];
+      if ((e & 0x7FFu) >= p->num_features || (e >> 16)) { free(depth); return -3; }
+      if ((uint32_t)depth[n] + 1u > p->num_levels) { free(depth); return -5; }
+      for (int side = 0; side < 2; ++side) {
+        if ((e >> (14 + side)) & 1u) continue;
+        const uint32_t c = t[4 * n + 2 + side];
+        if (c <= n || c >= cnt) { free(depth); return -4; } /* children after their parent: the walk terminates */
+        depth[c] = (uint8_t)(depth[n] + 1u);
+      }
+    }
+    free(depth);
+  }
+  return 0;
+}
+
+uint32_t orc_traverse_sparse(const orc_params* p, const uint32_t* lines, const uint64_t* first, const uint32_t* x,
+                             uint32_t tree) {
+  const uint32_t* t = lines + first[tree] * 4u;
+  uint32_t n = 0;
+  for (;;) {
+    const uint32_t* r = t + 4u * n;
+    const uint32_t e = r[1];
+    const uint32_t right = orc_go_right(x[e & 0x7FFu], r[0], p->missing_bits, (e >> 13) & 1u, p->cmp_mode);
+    const uint32_t child = r[2u + right];
+    if ((e >> (14u + right)) & 1u) return child; /* leaf value bits */
+    n = child;
+  }
+}
+
+int orc_score_sparse(const orc_params* p, const void* nl, size_t n_lines, const uint64_t* first, const void* tl,
+                     size_t n_tuples, float* out, double* gold, int sum_mode, int n_devices, int nthreads) {
+  int rc = orc_sparse_check(p, (const uint32_t*)nl, n_lines, first);
+  if (rc) return rc;
+  const uint32_t C = p->clusters_per_tuple;
+  if (C != 1 && C != 2 && C != 4 && C != 8) return -1;
+  if (n_devices < 1 || (uint32_t)n_devices > p->num_trees) return -5;
+  const uint32_t* lines = (const uint32_t*)nl;
+  const uint32_t* t = (const uint32_t*)tl;
+  const uint32_t T = p->num_trees, tw = orc_tuple_lines(p->num_features) * 4u;
+  const uint32_t per_dev = (T + (uint32_t)n_devices - 1u) / (uint32_t)n_devices;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    uint32_t* leaves = (uint32_t*)malloc(sizeof(uint32_t) * T);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (long long r = 0; r < (long long)n_tuples; ++r) {
+      const uint32_t* x = t + (size_t)r * tw;
+      for (uint32_t i = 0; i < T; ++i) leaves[i] = orc_traverse_sparse(p, lines, first, x, i);
+      uint32_t run = 0;
+      for (int d = 0; d < n_devices; ++d) { /* same device model as orc_score */
+        const uint32_t b = (uint32_t)d * per_dev, e = (b + per_dev < T) ? b + per_dev : T;
+        const uint32_t part = (b < e) ? shard_sum(leaves + b, e - b, C, sum_mode) : 0u;
+        if (d == 0) run = part;
+        else if (sum_mode == ORC_SUM_REF_FLOPOCO) run = orc_fpadd_bits(part, run);
+        else { volatile float s = f_from(part) + f_from(run); run = b_from(s); }
+      }
+      out[r] = f_from(run);
+      if (gold) {
+        double a = 0.0;
+        for (uint32_t i = 0; i < T; ++i) a += (double)f_from(leaves[i]);
+        gold[r] = a;
+      }
+    }
+    free(leaves);
+  }
+  (void)nthreads;
+  return 0;
+}
+
+void orc_sparse_from_perfect(const orc_params* p, const uint32_t* wl, const uint16_t* fl, uint32_t* lines, uint64_t* first) {
+  const uint32_t D = p->num_levels, nint = (1u << D) - 1u;
+  const size_t ws = (size_t)p->weights_lines_per_tree * 4u, fs = (size_t)p->findex_lines_per_tree * 8u;
+  for (uint32_t i = 0; i < p->num_trees; ++i) {
+    first[i] = (uint64_t)i * nint;
+    const uint32_t* w = wl + (size_t)i * ws;
+    const uint16_t* f = fl + (size_t)i * fs;
+    uint32_t* t = lines + (size_t)i * nint * 4u;
+    for (uint32_t n = 0; n < nint; ++n) {
+      const int last = 2u * n + 1u >= nint; /* children are leaves */
+      t[4 * n + 0] = w[n];
+      t[4 * n + 1] = (uint32_t)(f[n] & 0x27FFu) | (last ? 0xC000u : 0u);
+      t[4 * n + 2] = last ? w[2u * n + 1u] : 2u * n + 1u;
+      t[4 * n + 3] = last ? w[2u * n + 2u] : 2u * n + 2u;
+    }
+  }
+  first[p->num_trees] = (uint64_t)p->num_trees * nint;
+}
+
+static int sparse_fill(const uint32_t* t, uint32_t D, uint32_t n, int is_leaf, uint32_t leaf_bits, uint32_t h,
+                       uint32_t lvl, uint32_t* w, uint16_t* f) {
+  const uint32_t nint = (1u << D) - 1u;
+  if (lvl == D) {
+    if (!is_leaf) return -1; /* deeper than D */
+    w[h] = leaf_bits;
+    return 0;
+  }
+  if (is_leaf) { /* dummy node: threshold 0, feature 0; both sub-trees repeat the value */
+    w[h] = 0u;
+    f[h] = 0u;
+    int rc = sparse_fill(t, D, 0, 1, leaf_bits, 2u * h + 1u, lvl + 1u, w, f);
+    return rc ? rc : sparse_fill(t, D, 0, 1, leaf_bits, 2u * h + 2u, lvl + 1u, w, f);
+  }
+  (void)nint;
+  const uint32_t* r = t + 4u * n;
+  w[h] = r[0];
+  f[h] = (uint16_t)(r[1] & 0x27FFu);
+  int rc = sparse_fill(t, D, r[2], (r[1] >> 14) & 1u, r[2], 2u * h + 1u, lvl + 1u, w, f);
+  return rc ? rc : sparse_fill(t, D, r[3], (r[1] >> 15) & 1u, r[3], 2u * h + 2u, lvl + 1u, w, f);
+}
+
+int orc_sparse_to_perfect(const orc_params* p, const uint32_t* lines, const uint64_t* first, uint32_t* wl, uint16_t* fl) {
+  const uint32_t D = p->num_levels;
+  if (D == 0 || D > 16) return -1;
+  const size_t ws = (size_t)orc_weights_lines_per_tree(D) * 4u, fs = (size_t)orc_findex_lines_per_tree(D) * 8u;
+  memset(wl, 0, (size_t)p->num_trees * ws * 4u);
+  memset(fl, 0, (size_t)p->num_trees * fs * 2u);
+  for (uint32_t i = 0; i < p->num_trees; ++i) {
+    int rc = sparse_fill(lines + first[i] * 4u, D, 0, 0, 0u, 0u, 0u, wl + (size_t)i * ws, fl + (size_t)i * fs);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+#define SEED_S 0x0DD7000000000003ull
+
+size_t orc_gen_sparse_model(uint32_t T, uint32_t max_depth, uint32_t F, uint32_t full_levels, uint32_t split_permille,
+                            int dist, uint32_t* lines, size_t cap, uint64_t* first) {
+  /* BFS growth; the n-th internal node of tree i in BFS order has hash base g = i << 24 | n */
+  size_t total = 0;
+  const uint32_t qcap = 4u * 1024u * 1024u; /* internal nodes per tree (hash base keeps 24 bits for n) */
+  uint32_t* depth_q = (uint32_t*)malloc(sizeof(uint32_t) * qcap);
+  for (uint32_t i = 0; i < T; ++i) {
+    if (first) first[i] = total;
+    uint32_t cnt = 1; /* internal nodes allocated so far (node 0 = root, depth 0) */
+    depth_q[0] = 0;
+    for (uint32_t n = 0; n < cnt; ++n) {
+      const uint64_t g = ((uint64_t)i << 24) | n;
+      const uint32_t d = depth_q[n];
+      uint32_t e = (uint32_t)(orc_splitmix64(SEED_S + 8ull * g) % F) | ((uint32_t)(orc_splitmix64(SEED_S + 8ull * g + 2ull) & 1ull) << 13);
+      const float u = unit24(orc_splitmix64(SEED_S + 8ull * g + 1ull));
+      uint32_t child[2];
+      for (uint32_t side = 0; side < 2; ++side) {
+        const uint64_t hs = orc_splitmix64(SEED_S + 8ull * g + 4ull + side);
+        const int internal = d + 1u < max_depth && cnt < qcap && (d + 1u < full_levels || (uint32_t)((hs >> 20) % 1000ull) < split_permille);
+        if (internal) {
+          depth_q[cnt] = d + 1u;
+          child[side] = cnt++;
+        } else {
+          volatile float c = unit24(orc_splitmix64(SEED_S + 8ull * g + 6ull + side)) - 0.5f;
+          volatile float v = c * 0.2f;
+          child[side] = b_from(v);
+          e |= 1u << (14 + side);
+        }
+      }
+      if (lines && total + n < cap) {
+        uint32_t* r = lines + (total + n) * 4u;
+        r[0] = b_from(dist == 1 ? u * 2.0f - 1.0f : u);
+        r[1] = e;
+        r[2] = child[0];
+        r[3] = child[1];
+      }
+    }
+    total += cnt;
+  }
+  if (first) first[T] = total;
+  free(depth_q);
+  return total;
+}

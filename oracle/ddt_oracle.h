@@ -112,6 +112,41 @@ int orc_classify(const orc_params* p, const void* weights_lines, size_t n_wlines
                  size_t n_flines, const void* tuple_lines, size_t n_tuples, uint32_t num_classes, int interleaved,
                  int sum_mode, int n_devices, int32_t* labels, float* class_scores);
 
+/* ---- sparse (explicit-children) model stream ----------------------------------------------------
+ * An EXTENSION of this repository for trees that do not fit the reference's perfect-heap format (BASELINE
+ * config 4: depth-16 random forests need 2^17 words per tree when padded).  The reference's own hook for such
+ * trees is its disabled hybrid path: entry bit 14 "next node is a leaf" (core/DTPU.sv:637,661,675,712-715) and
+ * the PartialTrees control bit (Core.sv:380 bit 8, DTPU.sv:20-28,736-745) -- ill-defined in the published RTL
+ * (SURVEY A10b), so the format below is defined HERE and its oracle is pinned to the perfect-tree oracle through
+ * orc_sparse_to_perfect (pad) + orc_traverse (tests/test_sparse.py): same compare rule (orc_go_right), same
+ * reduction.  One 128-bit line per INTERNAL node (A2 packing, PipelinedMUX.sv:65):
+ *   word 0        threshold bits
+ *   word 1[15:0]  feature-index entry, reference bit layout (DTPU.sv:628,637,659-661): [10:0] feature,
+ *                 [13] missing goes right, [14] the LEFT child is a leaf, [15] the RIGHT child is a leaf
+ *   word 2, 3     left / right child: node index relative to the tree's first line, or the leaf's fp32 bits
+ * Children have larger indices than their parent (BFS, DFS pre-order, ...).  tree_first_line[T+1] delimits the
+ * trees; a tree that is a single leaf is one line with both leaf flags set and the value twice.
+ * orc_params.num_levels = upper bound of the depth (1..64); the lines-per-tree fields are ignored. */
+int orc_sparse_check(const orc_params* p, const uint32_t* node_lines, size_t n_lines, const uint64_t* tree_first_line);
+uint32_t orc_traverse_sparse(const orc_params* p, const uint32_t* node_lines, const uint64_t* tree_first_line,
+                             const uint32_t* tuple, uint32_t tree);
+/* same reduction / multi-device model as orc_score */
+int orc_score_sparse(const orc_params* p, const void* node_lines, size_t n_lines, const uint64_t* tree_first_line,
+                     const void* tuple_lines, size_t n_tuples, float* out, double* gold, int sum_mode, int n_devices,
+                     int nthreads);
+/* perfect stream -> sparse stream (one line per internal node, heap order); node_lines: T*(2^D-1) lines */
+void orc_sparse_from_perfect(const orc_params* p, const uint32_t* wlines, const uint16_t* flines, uint32_t* node_lines,
+                             uint64_t* tree_first_line);
+/* pad_to_perfect: a leaf above depth D = p->num_levels becomes a dummy sub-tree repeating its value.
+ * wlines / flines sized by orc_*_lines_per_tree(D); returns <0 if a tree is deeper than D */
+int orc_sparse_to_perfect(const orc_params* p, const uint32_t* node_lines, const uint64_t* tree_first_line,
+                          uint32_t* wlines, uint16_t* flines);
+/* synthetic random-forest-like sparse model (deterministic): every node above `full_levels` is internal, below it a
+ * child is internal with probability split_permille/1000 until max_depth.  Returns the number of lines (also when
+ * node_lines == NULL or cap is too small: call twice). */
+size_t orc_gen_sparse_model(uint32_t T, uint32_t max_depth, uint32_t F, uint32_t full_levels, uint32_t split_permille,
+                            int dist, uint32_t* node_lines, size_t cap_lines, uint64_t* tree_first_line);
+
 /* ---- wire-format helpers (A2 packing, PipelinedMUX.sv:65) ------------------------------------ */
 uint32_t orc_weights_lines_per_tree(uint32_t num_levels); /* ceil((2^(D+1)-1)/4) */
 uint32_t orc_findex_lines_per_tree(uint32_t num_levels);  /* ceil((2^D-1)/8)     */

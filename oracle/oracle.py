@@ -79,6 +79,14 @@ def lib():
         L.orc_gen_tuples.restype, L.orc_gen_tuples.argtypes = None, [u64, sz, u32, C.c_int, u32, vp]
         L.orc_gen_model.restype, L.orc_gen_model.argtypes = None, [u32, u32, u32, C.c_int, vp, vp]
         L.orc_hw_threads.restype, L.orc_hw_threads.argtypes = C.c_int, []
+        L.orc_sparse_check.restype, L.orc_sparse_check.argtypes = C.c_int, [PP, vp, sz, vp]
+        L.orc_traverse_sparse.restype, L.orc_traverse_sparse.argtypes = u32, [PP, vp, vp, vp, u32]
+        L.orc_score_sparse.restype = C.c_int
+        L.orc_score_sparse.argtypes = [PP, vp, sz, vp, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int]
+        L.orc_sparse_from_perfect.restype, L.orc_sparse_from_perfect.argtypes = None, [PP, vp, vp, vp, vp]
+        L.orc_sparse_to_perfect.restype, L.orc_sparse_to_perfect.argtypes = C.c_int, [PP, vp, vp, vp, vp]
+        L.orc_gen_sparse_model.restype = sz
+        L.orc_gen_sparse_model.argtypes = [u32, u32, u32, u32, u32, C.c_int, vp, sz, vp]
         _lib = L
     return _lib
 
@@ -233,3 +241,73 @@ def fpadd_bits_batch(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 
 def hw_threads() -> int:
     return lib().orc_hw_threads()
+
+
+# ---- sparse (explicit-children) model stream: this repository's extension, see ddt_oracle.h ----------------------
+class SparseModel:
+    """node_lines uint32 [n_lines, 4] (one 128-bit line per internal node), tree_first_line uint64 [T + 1]."""
+
+    def __init__(self, params: Params, node_lines: np.ndarray, tree_first_line: np.ndarray):
+        self.params = params
+        self.node_lines = np.ascontiguousarray(node_lines, dtype=np.uint32).reshape(-1, 4)
+        self.first = np.ascontiguousarray(tree_first_line, dtype=np.uint64).reshape(-1)
+        assert self.first.size == params.num_trees + 1
+
+    @property
+    def n_lines(self) -> int:
+        return self.node_lines.shape[0]
+
+    def check(self) -> int:
+        return lib().orc_sparse_check(C.byref(self.params), _p(self.node_lines), self.n_lines, _p(self.first))
+
+
+def make_sparse_params(T, max_depth, F, missing_bits=0x7FC00000, cmp_mode=0, clusters=None) -> Params:
+    return Params(T, max_depth, F, missing_bits, 0, 0, cmp_mode, default_clusters(T) if clusters is None else clusters)
+
+
+def gen_sparse_model(T: int, max_depth: int, F: int, full_levels: int, split_permille: int, dist: int = 0, **kw) -> SparseModel:
+    first = np.zeros(T + 1, np.uint64)
+    n = lib().orc_gen_sparse_model(T, max_depth, F, full_levels, split_permille, dist, None, 0, _p(first))
+    lines = np.zeros((n, 4), np.uint32)
+    lib().orc_gen_sparse_model(T, max_depth, F, full_levels, split_permille, dist, _p(lines), n, _p(first))
+    return SparseModel(make_sparse_params(T, max_depth, F, **kw), lines, first)
+
+
+def sparse_from_perfect(m: Model) -> SparseModel:
+    T, D = m.params.num_trees, m.params.num_levels
+    lines = np.zeros((T * ((1 << D) - 1), 4), np.uint32)
+    first = np.zeros(T + 1, np.uint64)
+    lib().orc_sparse_from_perfect(C.byref(m.params), _p(m.wlines), _p(m.flines), _p(lines), _p(first))
+    q = m.params
+    return SparseModel(Params(T, D, q.num_features, q.missing_bits, 0, 0, q.cmp_mode, q.clusters_per_tuple), lines, first)
+
+
+def sparse_to_perfect(s: SparseModel, D: int | None = None) -> Model:
+    """pad_to_perfect"""
+    q = s.params
+    D = q.num_levels if D is None else D
+    pp = Params(q.num_trees, D, q.num_features, q.missing_bits, wlpt(D), flpt(D), q.cmp_mode, q.clusters_per_tuple)
+    w = np.zeros(q.num_trees * wlpt(D) * 4, np.uint32)
+    f = np.zeros(q.num_trees * flpt(D) * 8, np.uint16)
+    rc = lib().orc_sparse_to_perfect(C.byref(pp), _p(s.node_lines), _p(s.first), _p(w), _p(f))
+    if rc:
+        raise ValueError(f"orc_sparse_to_perfect rc={rc}")
+    return Model(pp, w, f)
+
+
+def score_sparse(s: SparseModel, tuples: np.ndarray, sum_mode: int = SUM_REF_FLOPOCO, n_devices: int = 1,
+                 nthreads: int = 0, want_gold: bool = False):
+    t = np.ascontiguousarray(tuples, np.uint32)
+    n = t.shape[0]
+    out = np.zeros(n, np.float32)
+    gold = np.zeros(n, np.float64) if want_gold else None
+    rc = lib().orc_score_sparse(C.byref(s.params), _p(s.node_lines), s.n_lines, _p(s.first), _p(t), n, _p(out),
+                                _p(gold) if want_gold else None, sum_mode, n_devices, nthreads)
+    if rc:
+        raise ValueError(f"orc_score_sparse rc={rc}")
+    return (out, gold) if want_gold else out
+
+
+def traverse_sparse(s: SparseModel, tuple_row: np.ndarray, tree: int) -> int:
+    t = np.ascontiguousarray(tuple_row, np.uint32)
+    return lib().orc_traverse_sparse(C.byref(s.params), _p(s.node_lines), _p(s.first), _p(t), tree)

@@ -48,6 +48,74 @@ def test_csr_roundtrip(T, D, F, n, dev):
     assert n2.value == (n + 3) // 4 * 4 and d2.value == dev
 
 
+def _rtl_device_list(csr):
+    """devices_list[] exactly as rtl/DTEngine/EngineCSR.sv:250-296 slices registers 208-210 (5 bits at a byte stride;
+    register 210 holds ids 16..19 only)."""
+    out = []
+    for i in range(20):
+        reg = csr[8 + i // 8]
+        lo = 8 * (i % 8)
+        out.append((reg >> lo) & 0x1F)
+    return out
+
+
+@pytest.mark.parametrize("devices", [1, 2, 8, 9, 20])
+def test_csr_device_list_sits_where_the_rtl_slices_it(devices):
+    p = ddt.make_params(40, 4, 16)
+    rc, csr = _encode(p, 4096, devices)
+    assert rc == 0
+    lst = _rtl_device_list(csr)
+    assert lst[:devices] == list(range(devices)) and not any(lst[devices:])
+    assert csr[10] >> 32 == 0  # CSR 210: ids 16..19 only
+    assert (csr[3] >> 32) & 0xFF == devices
+    # the library's own decoder slices the same way
+    ids = (C.c_uint8 * 20)()
+    q, mode, flags = ddt.Params(), C.c_uint32(), C.c_uint32()
+    assert ddt.lib().ddt_csr_decode_ex(C.byref(csr), C.byref(q), None, None, C.byref(mode), C.byref(flags), C.byref(ids)) == 0
+    assert list(ids) == lst and mode.value == 0
+
+
+def test_csr_mode_flags_per_device_for_both_sharding_modes():
+    """CSR 201 (EngineCSR.sv:194-205): [0] data_distributed [1] host_node [2] broadcast_data [3] broadcast_trees
+    [4] aggreg_enabled [5] multiple_nodes [6] pcie_receiver_enabled [7] last_node; the two modes of DTInference.sv:28-37."""
+    L = ddt.lib()
+    p = ddt.make_params(64, 6, 28)
+    n = 1000
+
+    def enc(mode, dev, G):
+        csr = (C.c_uint64 * 12)()
+        assert L.ddt_csr_encode_ex(C.byref(p), n, G, mode, dev, C.byref(csr)) == 0
+        return csr
+
+    HOST, BDATA, BTREES, AGG, MULTI, PCIE, LAST = 1 << 1, 1 << 2, 1 << 3, 1 << 4, 1 << 5, 1 << 6, 1 << 7
+    # tree-sharded, 4 devices: tuples broadcast + partial results aggregated on every device
+    for d in range(4):
+        f = enc(0, d, 4)[1] & 0xFF
+        assert f & (BDATA | AGG | MULTI) == BDATA | AGG | MULTI and not f & BTREES
+        assert bool(f & HOST) == (d == 0) and bool(f & PCIE) == (d == 0) and bool(f & LAST) == (d == 3)
+    # row-sharded: trees broadcast, tuples dealt in batches of 4 (= 4 * tuple lines), no aggregation
+    for d in range(4):
+        csr = enc(1, d, 4)
+        f = csr[1] & 0xFF
+        assert f & (BTREES | MULTI) == BTREES | MULTI and not f & (BDATA | AGG)
+        assert bool(f & HOST) == (d == 0) and bool(f & LAST) == (d == 3)
+        assert csr[1] >> 32 == 4 * 7  # 28 features = 7 lines per tuple, 4 tuples per batch (DTInference.sv:35-36)
+        assert (csr[5] >> 36) & 0xFF == 8  # every device holds all 64 trees: 8 groups / 1 cluster
+        mode = C.c_uint32()
+        q = ddt.Params()
+        assert L.ddt_csr_decode_ex(C.byref(csr), C.byref(q), None, None, C.byref(mode), None, None) == 0 and mode.value == 1
+    # result lines each device announces (CSR 207): the host sees all, the others their round-robin share
+    lines = [enc(1, d, 4)[7] for d in range(4)]
+    assert lines[0] == 250 and sum(lines[1:]) + (250 // 4 + (1 if 0 < 250 % 4 else 0)) == 250
+    # one device: host and last at once, nothing broadcast
+    f = enc(0, 0, 1)[1] & 0xFF
+    assert f == HOST | PCIE | LAST
+    # next-hop addresses close the ring (CSR 206 [7:0] broadcast, [15:8] results)
+    assert [enc(0, d, 3)[6] & 0xFF for d in range(3)] == [1, 2, 0]
+    assert L.ddt_csr_encode_ex(C.byref(p), n, 4, 2, 0, C.byref((C.c_uint64 * 12)())) == -1   # unknown mode
+    assert L.ddt_csr_encode_ex(C.byref(p), n, 4, 0, 4, C.byref((C.c_uint64 * 12)())) == -1   # device index out of range
+
+
 def test_csr_rejects_inconsistent_blocks():
     p = ddt.make_params(8, 4, 16)
     _, csr = _encode(p, 100)
