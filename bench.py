@@ -3,19 +3,27 @@
 
   python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (BASELINE.json `metric` / configs[2]): 1000 trees, depth 8, 32 fp32 features, 100 M synthetic
-tuples (SURVEY.md 8(d) generator, resident in HBM before the timed region).  One "step" = one pass of the
-hot path over the whole batch.  N=1: one engine holds all 1000 trees.  N>1: the ensemble is sharded
-tree-wise (rank g holds trees [g*T/N, (g+1)*T/N)), every rank scores all tuples against its shard and the
-per-tuple fp32 partial scores are combined with an RCCL all-reduce over xGMI, chunk-pipelined with the
-scoring (total work fixed => "strong" scaling).  `value` = tuples scored by the whole job / wall time.
+Default workload (BASELINE.json `metric` / configs[2]): 1000 trees, depth 8, 32 fp32 features, 100 M synthetic
+tuples (SURVEY.md 8(d) generator, resident in HBM before the timed region).  One "step" = one pass of the hot path
+over the whole batch.  N=1: one engine holds all 1000 trees.  N>1: the ensemble is sharded tree-wise (rank g holds
+trees [g*ceil(T/N), ...)), every rank scores all tuples against its shard and the per-tuple fp32 partial scores are
+combined over RCCL -- issued from C++ behind the C-ABI (ddt_comm_* / ddt_score_sharded_device, csrc/ddt_comm.cpp),
+chunk-pipelined with the scoring (total work fixed => "strong" scaling).  `value` = tuples scored by the whole job /
+wall time (max over ranks).
+
+  --config 4   BASELINE configs[3]: a random-forest-like SPARSE model (512 trees, depth <= 16, 64 features; synthetic
+               growth of include/ddt.h ddt_synth_sparse_model, ~10^4 internal nodes per tree), 10 M tuples per step,
+               scored by the explicit-children kernel (csrc/ddt_sparse.hip).
 
 Extra objects on the JSON line:
-  roofline     algorithmic HBM bytes (4F+4 per tuple + model once) / mean kernel time measured
-               with HIP events on the launch stream, against the 8 TB/s HBM3E peak.  NOTE: this shape is
-               LDS-gather bound (8000 dependent node visits per 132 compulsory bytes); visits/s is reported too.
-  cpu_baseline the CPU oracle (a port of the reference RTL semantics; the reference has no CPU scorer) timed
-               on a bounded prefix of the same batch on this box's host cores (rank 0, N=1 only).
+  roofline     algorithmic HBM bytes (4F+4 per tuple + model once) / mean kernel time measured with HIP
+               events on the launch stream, against the 8 TB/s HBM3E peak.  NOTE: these shapes are not HBM bound
+               (config 3: 8000 dependent node visits per 132 compulsory bytes -> LDS gather pipe; config 4: vector-memory
+               gathers); node visits/s and the pipe ceilings, derived from the device properties, are reported too.
+  cpu_baseline the CPU oracle (a port of the reference RTL semantics; the reference has no CPU scorer) timed on a
+               bounded prefix of the same batch on this box's host cores (rank 0, N=1 only).
+  streamed     N=1: the same model fed from HOST memory through the pinned double-buffered hipMemcpyAsync feeder
+               (PCIe-inclusive rate on a bounded sample; never `value`).
 """
 import argparse
 import json
@@ -35,22 +43,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=100_000_000, help="tuples per step (BASELINE: 100 M)")
-    ap.add_argument("--trees", type=int, default=1000)
-    ap.add_argument("--levels", type=int, default=8)
-    ap.add_argument("--features", type=int, default=32)
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4], help="BASELINE.json config: 3 = headline (default), 4 = sparse random forest")
+    ap.add_argument("--rows", type=int, default=0, help="tuples per step (default: 100 M for config 3, 10 M for config 4)")
+    ap.add_argument("--trees", type=int, default=0)
+    ap.add_argument("--levels", type=int, default=0)
+    ap.add_argument("--features", type=int, default=0)
+    ap.add_argument("--full-levels", type=int, default=10, help="config 4: levels grown completely")
+    ap.add_argument("--permille", type=int, default=700, help="config 4: split probability below the full levels, in 1/1000")
     ap.add_argument("--combine", default="allreduce", choices=["allreduce", "chain"])
     ap.add_argument("--shard", default="trees", choices=["trees", "rows"],
                     help="N>1: 'trees' = the headline mode (ensemble sharded tree-wise, partial scores all-reduced); "
                          "'rows' = the reference's other mode (replicated ensemble, tuples partitioned, scores all-gathered)")
     ap.add_argument("--chunk-rows", type=int, default=12_500_000, help="rows per pipelined collective (N>1)")
+    ap.add_argument("--collectives", default="cabi", choices=["cabi", "torch"],
+                    help="cabi = RCCL called from C++ behind the C-ABI (the product path); torch = the same pipeline "
+                         "driven from Python through torch.distributed (needed for --backend gloo)")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant id (-1 = engine's choice)")
     ap.add_argument("--sum-mode", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL over xGMI) is the product path; gloo lets N ranks share one GPU for a functional test")
+                    help="process-group backend used for the barrier / timing reduction (and for --collectives torch); "
+                         "gloo lets N ranks share one GPU for a functional test")
     ap.add_argument("--force-collectives", action="store_true",
                     help="N=1 only: run the multi-GPU chunk pipeline and the collectives in a one-rank group (overhead / sanity run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streamed", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
 
@@ -59,6 +75,12 @@ def main():
     import torch.distributed as dist
 
     import ddt
+
+    sparse = args.config == 4
+    T = args.trees or (512 if sparse else 1000)
+    D = args.levels or (16 if sparse else 8)
+    F = args.features or (64 if sparse else 32)
+    N = args.rows or (10_000_000 if sparse else 100_000_000)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -70,14 +92,17 @@ def main():
         sys.exit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the scoring path has no CPU fallback)")
+    if args.backend == "gloo" and args.collectives == "cabi" and world > 1:
+        args.collectives = "torch"  # several ranks on one GPU cannot form an RCCL communicator
     local = local % torch.cuda.device_count() if args.backend == "gloo" else local
     torch.cuda.set_device(local)
+    multi = world > 1 or args.force_collectives
     if world == 1 and args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    if world > 1 or args.force_collectives:
+    if multi:
         if args.backend == "nccl":
             try:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -86,20 +111,33 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    T, D, F, N = args.trees, args.levels, args.features, args.rows
     W = ddt.tuple_words(F)
     eng = ddt.Engine(local)
     eng.set_option("variant", args.variant)
-    w, f = ddt.synth_model(T, D, F, 0)
-    params = ddt.make_params(T, D, F, sum_mode=args.sum_mode)
     rows_mode = world > 1 and args.shard == "rows"
-    eng.load_model(params, w, f, 0 if rows_mode else rank, 1 if rows_mode else world)
+    shard = (0, 1) if rows_mode else (rank, world)
+    if sparse:
+        lines, first = ddt.synth_sparse_model(T, D, F, args.full_levels, args.permille, 0)
+        params = ddt.make_sparse_params(T, D, F, sum_mode=args.sum_mode)
+        eng.load_model_sparse(params, lines, first, *shard)
+    else:
+        w, f = ddt.synth_model(T, D, F, 0)
+        params = ddt.make_params(T, D, F, sum_mode=args.sum_mode)
+        eng.load_model(params, w, f, *shard)
     info = eng.info()
 
     tuples = eng.synth_tuples_device(0, N, F, 0)          # resident in HBM before the timed region
     out = torch.empty(N, dtype=torch.float32, device=tuples.device)
-    scorer = None
-    if world > 1 or args.force_collectives:
+    comm = scorer = None
+    combine = ddt.COMBINE_CHAIN if args.combine == "chain" else ddt.COMBINE_ALLREDUCE
+    if multi and args.collectives == "cabi":
+        # the communicator id travels over the launcher's channel (torch.distributed's store); everything after that
+        # -- ncclCommInitRank, the chunk pipeline, every collective -- happens in C++ behind the C-ABI
+        box = [ddt.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = ddt.Comm(eng, rank, world, box[0])
+        comm.set_option("chunk_rows", args.chunk_rows)
+    elif multi:
         scorer = (ddt.RowShardedScorer(eng) if rows_mode else
                   ddt.ShardedScorer.from_engine(eng, mode=args.combine, chunk_rows=args.chunk_rows,
                                                 force_collectives=args.force_collectives))
@@ -107,21 +145,26 @@ def main():
     # per-launch HIP-event times of the pass, taken by the library on the launch stream ("kernel_timing"):
     # pre-pass kernels (rank-quantised path only) and the scoring kernel proper
     kernel_ms = []
-    if scorer is None:
+    if not multi:
         eng.set_option("kernel_timing", 1)
 
     def step(record: bool):
-        if scorer is None:
+        if comm is not None:
+            if rows_mode:
+                comm.score_rowsharded(tuples, out=out)
+            else:
+                comm.score_sharded(tuples, out=out, combine=combine)
+        elif scorer is not None:
+            scorer.score(tuples, out=out)
+        else:
             eng.score_device(tuples, out=out)
             if record:
                 st = eng.stats()  # waits for this launch's end event
                 kernel_ms.append((st.last_prepass_ms, st.last_score_ms))
-        else:
-            scorer.score(tuples, out=out)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1 or args.force_collectives:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -143,67 +186,111 @@ def main():
     # ---- roofline of the dominant kernel (the per-shard scoring kernel) ----------------------------
     alg_bytes_per_launch = N * (4 * F + 4) + int(info.model_bytes_unpadded)  # tuples in, scores out, model once
     roofline = None
-    if world == 1 and kernel_ms:
+    if not multi and kernel_ms:
         pre_ms = sum(a for a, _ in kernel_ms) / len(kernel_ms)
         k_ms = sum(b for _, b in kernel_ms) / len(kernel_ms)  # the dominant (scoring) kernel
         ach = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # HBM bytes per launch from rocprofv3 --pmc, if collected
-        if os.path.exists(pmc):
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic_cfg4.json" if sparse else "pmc_traffic.json")
+        if os.path.exists(pmc):  # HBM bytes per launch of this kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of THIS command, collected in its own run
             try:
                 pj = json.load(open(pmc))
                 if pj.get("rows") == N and pj.get("trees") == T:
                     traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_source = f"profiles/{os.path.basename(pmc)}: rocprofv3 --pmc of this command (separate run, gfx950 FETCH_SIZE x2 correction applied); not measured in this run"
             except Exception:
                 traffic = None
-        t_local = info.tree_end - info.tree_begin
+        clock_hz = info.clock_khz * 1e3
         roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": info.variant_name.decode(), "kernel_ms": round(k_ms, 4),
                     "prepass_ms": round(pre_ms, 4),  # transpose + rank kernels of the rank-quantised path (0 otherwise)
                     "alg_bytes_per_launch": alg_bytes_per_launch,
-                    "binding_resource": "LDS gather pipe (2 DS ops per node visit) + VALU issue, not HBM",
-                    "node_visits_per_s": round(N * t_local * D / (k_ms * 1e-3), 1),
-                    "lds_ceiling_visits_per_s": 256 * 2.4e9 * 64 / 4}
+                    "device": {"cus": info.num_cus, "clock_mhz": round(clock_hz / 1e6, 1), "lds_bytes_per_cu": info.lds_bytes_per_cu}}
+        if sparse:
+            # leaf depth of the model = node visits per tuple and tree: measured on a sample with the oracle below
+            roofline["binding_resource"] = ("vector-memory gathers of the deep phase: one 16-byte load per lane and visit "
+                                            "(the VMEM address pipe takes about one lane per cycle and CU), not HBM")
+            roofline["vmem_ceiling_gathers_per_s"] = info.num_cus * clock_hz
+        else:
+            t_local = info.tree_end - info.tree_begin
+            roofline["binding_resource"] = "LDS gather pipe (2 DS ops per node visit) + VALU issue, not HBM"
+            roofline["node_visits_per_s"] = round(N * t_local * D / (k_ms * 1e-3), 1)
+            # 2 conflict-free DS wave-instructions per 64 visits at 2 LDS cycles each (MI355X_MICROARCH.md, LDS table)
+            roofline["lds_ceiling_visits_per_s"] = info.num_cus * clock_hz * 64 / 4
 
     # ---- CPU baseline (oracle = port of the reference RTL semantics), rank 0 / N=1 only ---------------
-    cpu = None
-    parity = None
+    cpu = parity = streamed = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as O
 
-        m = O.Model(O.make_params(T, D, F), w, f)
-        O.score(m, tuples[: min(N, 4096)].cpu().numpy().view(np.uint32), sum_mode=O.SUM_REF_NATIVE)  # thread-pool warm-up
+        if sparse:
+            m = O.SparseModel(O.make_sparse_params(T, D, F), lines, first)
+
+            def cpu_score(xs):
+                return O.score_sparse(m, xs, sum_mode=O.SUM_REF_NATIVE if args.sum_mode == 0 else O.SUM_F64_SEQ)
+            what = "oracle/ddt_oracle.c orc_score_sparse"
+        else:
+            m = O.Model(O.make_params(T, D, F), w, f)
+
+            def cpu_score(xs):
+                return O.score_fast(m, xs, sum_mode=O.SUM_REF_NATIVE if args.sum_mode == 0 else O.SUM_F64_SEQ)
+            what = "oracle/ddt_oracle.c orc_score_fast: cache-blocked 8-byte nodes, 8 walks in flight per thread"
+        cpu_score(tuples[: min(N, 4096)].cpu().numpy().view(np.uint32))  # thread-pool warm-up
         probe = min(N, 262_144)
         xs = tuples[:probe].cpu().numpy().view(np.uint32)
         t1 = time.perf_counter()
-        ref = O.score(m, xs, sum_mode=O.SUM_REF_NATIVE)
+        cpu_score(xs)
         rate = probe / max(1e-9, time.perf_counter() - t1)
-        rows = int(max(probe, min(N, 16_000_000, rate * args.cpu_seconds)))
+        rows = int(max(probe, min(N, 64_000_000, rate * args.cpu_seconds)))
         xs = tuples[:rows].cpu().numpy().view(np.uint32)
         t1 = time.perf_counter()
-        ref = O.score(m, xs, sum_mode=O.SUM_REF_NATIVE if args.sum_mode == 0 else O.SUM_F64_SEQ)
+        ref = cpu_score(xs)
         cdt = time.perf_counter() - t1
         cpu = {"value": round(rows / cdt / 1e6, 4), "unit": "Mtuples/s", "cores": O.hw_threads(), "kind": "port",
-               "sample": f"first {rows} rows of the same synthetic batch, all {T} trees, OpenMP over rows, "
-                         f"{cdt:.1f} s (oracle/ddt_oracle.c: CPU restatement of the reference RTL semantics)"}
+               "sample": f"first {rows} rows of the same synthetic batch, all {T} trees, OpenMP over row blocks, "
+                         f"{cdt:.1f} s ({what}; a CPU restatement of the reference RTL semantics, the reference has no CPU scorer)"}
         got = out[:rows].cpu().numpy()
         parity = {"rows_checked": rows, "bit_exact": bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32)))}
+        if sparse and roofline is not None:
+            depth = O.sparse_mean_depth(m, xs[:2048])  # node visits per (tuple, tree) on a sample
+            k_s = roofline["kernel_ms"] * 1e-3
+            roofline["model"] = {"internal_nodes": int(lines.shape[0]), "nodes_per_tree": round(lines.shape[0] / T, 1),
+                                 "mean_visits_per_tuple_and_tree": round(depth, 3)}
+            roofline["node_visits_per_s"] = round(N * T * depth / k_s, 1)
+            roofline["deep_gathers_per_s"] = round(N * T * max(0.0, depth - int(info.variant_name.decode().split("_k")[1].split("_")[0])) / k_s, 1)
+
+    # ---- PCIe-inclusive "streamed" mode (SURVEY 8(d) timing protocol): host buffers through the pinned feeder ----
+    if world == 1 and rank == 0 and not args.no_streamed and not multi:
+        srows = min(N, 16_000_000)
+        host = tuples[:srows].cpu().numpy().view(np.uint32)  # pageable host memory, as a caller would hold it
+        eng.score(host[: min(srows, 1 << 20)])                # feeder buffers allocated
+        t1 = time.perf_counter()
+        hs = eng.score(host)
+        sdt = time.perf_counter() - t1
+        streamed = {"value": round(srows / sdt / 1e6, 2), "unit": "Mtuples/s", "rows": srows,
+                    "link_GBs": round(srows * (4 * W + 4) / sdt / 1e9, 2),
+                    "note": "host tuples -> pinned double buffer -> hipMemcpyAsync H2D -> kernels -> D2H, PCIe-inclusive; never `value`",
+                    "bit_exact_vs_resident": bool(np.array_equal(hs.view(np.uint32), out[:srows].cpu().numpy().view(np.uint32)))}
 
     if rank == 0:
+        par = "single engine" if world == 1 else (
+            f"row-sharded {world}x (replicas) + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-gather" if rows_mode else
+            f"tree-sharded {world}x + {'RCCL' if args.backend == 'nccl' else 'gloo (functional test)'} {args.combine}")
+        shape = (f"{T} sparse trees (depth <= {D}, {lines.shape[0]} internal nodes) x {F} fp32 features" if sparse
+                 else f"{T} trees x depth {D} x {F} fp32 features")
         line = {
-            "metric": "Mtuples/s scored, 1000 trees depth-8 / 32 feat" if (T, D, F) == (1000, 8, 32)
-            else f"Mtuples/s scored, {T} trees depth-{D} / {F} feat",
+            "metric": "Mtuples/s scored, 1000 trees depth-8 / 32 feat" if (T, D, F, sparse) == (1000, 8, 32, False)
+            else f"Mtuples/s scored, {T} trees depth-{D} / {F} feat" + (" (sparse random forest, BASELINE config 4)" if sparse else ""),
             "value": round(mtuples, 3), "unit": "Mtuples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{T} trees x depth {D} x {F} fp32 features, {N} tuples/step, "
-                                   + ("single engine" if world == 1 else
-                                      f"row-sharded {world}x (replicas) + RCCL all-gather" if rows_mode else
-                                      f"tree-sharded {world}x + RCCL {args.combine}"),
-                       "trees": T, "levels": D, "features": F, "rows": N, "parallelism": f"row-shard{world}" if rows_mode else f"tree-shard{world}",
-                       "combine": args.combine if world > 1 else None,
-                       "collective_backend": (args.backend if world > 1 else None), "kernel": info.variant_name.decode(),
+            "config": {"workload": f"{shape}, {N} tuples/step, {par}",
+                       "trees": T, "levels": D, "features": F, "rows": N,
+                       "parallelism": f"row-shard{world}" if rows_mode else f"tree-shard{world}",
+                       "combine": args.combine if multi else None,
+                       "collectives": (("C-ABI ddt_comm (csrc/ddt_comm.cpp)" if comm is not None else "torch.distributed") if multi else None),
+                       "collective_backend": (args.backend if multi else None), "kernel": info.variant_name.decode(),
                        "sum_mode": "reference-order fp32" if args.sum_mode == 0 else "fp64 accumulate",
                        "device": info.device_name.decode()},
         }
@@ -213,8 +300,12 @@ def main():
             line["cpu_baseline"] = cpu
         if parity:
             line["parity"] = parity
+        if streamed:
+            line["streamed"] = streamed
         print(json.dumps(line), flush=True)
-    if world > 1 or args.force_collectives:
+    if comm is not None:
+        comm.close()
+    if multi:
         dist.destroy_process_group()
     eng.close()
 

@@ -10,6 +10,8 @@
 //        writes name.csr (text: "<addr> <hex64>" per register), name.weights, name.findex, name.tuples
 //   ddt_cli score --csr f.csr --weights f.weights --findex f.findex --tuples f.tuples --out f.results
 //                 [--device 0] [--shard i --of n] [--cmp-mode 0|1] [--sum-mode 0|1] [--variant v]
+//                 [--devices G [--combine allreduce|chain]]   the whole multi-GPU job in this process: tree shard g on
+//                                                             device g, partial scores combined over RCCL (ddt_group_*)
 //   ddt_cli info
 //
 // All scoring goes through the C-ABI of include/ddt.h; there is no CPU fallback.
@@ -159,6 +161,31 @@ int cmd_score(const std::map<std::string, std::string>& o) {
   if (x.size() % tuple_bytes) return die(DDT_EINVAL, nullptr, "tuple stream is not a whole number of tuples");
   if ((n + 3) / 4 != (n_csr + 3) / 4)
     fprintf(stderr, "ddt_cli: note: CSR207 announces %" PRIu64 " result lines, the tuple stream holds %" PRIu64 " tuples\n", n_csr / 4, n);
+  std::vector<float> scores((size_t)((n + 3) / 4 * 4), 0.0f);  // whole result lines, zero padded
+  if (o.count("devices")) {  // the tree-sharded multi-GPU job of the CSR block's mode, all devices driven from this process
+    const int G = (int)num(o, "devices", 1);
+    const std::string cmb = o.count("combine") ? o.at("combine") : "allreduce";
+    if (G < 1 || (cmb != "allreduce" && cmb != "chain")) return die(DDT_EINVAL, nullptr, "--devices / --combine");
+    ddt_group* g = nullptr;
+    rc = ddt_group_create(&g, G, nullptr);  // devices 0 .. G-1
+    if (rc) return die(rc, nullptr, "ddt_group_create");
+    if (o.count("variant"))
+      for (int i = 0; i < G; ++i) ddt_set_option(ddt_group_engine(g, i), "variant", (int64_t)num(o, "variant", 0));
+    rc = ddt_group_load_model(g, &p, w.data(), w.size() / 16, f.data(), f.size() / 16);
+    if (!rc) rc = ddt_group_score(g, x.data(), n, scores.data(), cmb == "chain" ? DDT_COMBINE_CHAIN : DDT_COMBINE_ALLREDUCE);
+    if (rc) {
+      fprintf(stderr, "ddt_cli: multi-GPU job failed: %s (%s)\n", ddt_strerror(rc), ddt_group_last_error(g));
+      ddt_group_destroy(g);
+      return 1;
+    }
+    if (!write_file(str(o, "out"), scores.data(), scores.size() * 4)) return die(DDT_EINVAL, nullptr, "write results");
+    ddt_info info;
+    ddt_get_info(ddt_group_engine(g, 0), &info);
+    printf("scored %" PRIu64 " tuples on %d device(s), %u trees sharded tree-wise (device 0: [%u, %u), kernel %s), combine %s over RCCL\n",
+           n, G, p.num_trees, info.tree_begin, info.tree_end, info.variant_name, cmb.c_str());
+    ddt_group_destroy(g);
+    return 0;
+  }
   ddt_engine* e = nullptr;
   rc = ddt_create(&e, (int)num(o, "device", 0));
   if (rc) return die(rc, nullptr, "ddt_create");
@@ -166,7 +193,6 @@ int cmd_score(const std::map<std::string, std::string>& o) {
   const uint32_t of = (uint32_t)num(o, "of", 1), shard = (uint32_t)num(o, "shard", 0);
   rc = ddt_load_model_shard(e, &p, w.data(), w.size() / 16, f.data(), f.size() / 16, shard, of);
   if (rc) return die(rc, e, "load model");
-  std::vector<float> scores((size_t)((n + 3) / 4 * 4), 0.0f);  // whole result lines, zero padded
   rc = ddt_score(e, x.data(), n, scores.data());
   if (rc) return die(rc, e, "score");
   if (!write_file(str(o, "out"), scores.data(), scores.size() * 4)) return die(DDT_EINVAL, e, "write results");

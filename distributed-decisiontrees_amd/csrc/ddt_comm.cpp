@@ -1,0 +1,515 @@
+// ddt_comm.cpp -- multi-GPU jobs behind the C-ABI: RCCL (librccl, the ROCm NCCL) over xGMI.
+//
+// Replaces the reference's inter-FPGA networks:
+//   tuple broadcast            rtl/DTEngine/InputDistributor.sv:199-204 (ring re-broadcast of tuple lines)
+//   partial-result aggregation rtl/DTEngine/ResultsCombiner.sv:292-311 (four fp32 adders: local line + upstream line),
+//                              :359-369,426-430 (forwarding along host -> dev1 -> ... and back to the host's PCIe)
+//   per-device tree shards     rtl/DTEngine/PCIeReceiver.sv:241-264 (CSR 203), tuple batches :289-312 (row mode)
+// MI355X mapping: one communicator rank per GPU; the tree-sharded job runs a chunk pipeline on two HIP streams -- the
+// caller's stream scores chunk k+1 while the comm's own stream combines chunk k -- with either one ncclAllReduce per
+// chunk (the collective BASELINE.json names) or the deterministic chain: grouped ncclSend/ncclRecv all-to-all of 1/G
+// slices, fixed-order add on the owner, ncclAllGather.  xGMI is point-to-point (fully connected mesh), so the
+// all-to-all form puts one slice on every link at once.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <memory>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "ddt_engine_priv.h"
+
+using namespace ddt;
+
+struct ddt_comm {
+  ddt_engine* e = nullptr;
+  int rank = 0, n = 1;
+  ncclComm_t comm = nullptr;
+  hipStream_t cs = nullptr;                       // the comm's own stream: collectives + chain adds
+  hipEvent_t ev_scored[2] = {nullptr, nullptr};   // caller's stream: chunk scored into slot b
+  hipEvent_t ev_free[2] = {nullptr, nullptr};     // comm stream: slot b consumed
+  hipEvent_t ev_done = nullptr;
+  size_t chunk_rows = 12'500'000;
+  // chain / classify workspaces, two slots (grow-only): part = this rank's partial values (G*seg floats, zero padded),
+  // recv = every rank's slice of my segment [G][seg], full = combined values of all segments
+  float* part[2] = {nullptr, nullptr};
+  float* recv[2] = {nullptr, nullptr};
+  float* full[2] = {nullptr, nullptr};
+  size_t cap = 0;  // floats per buffer
+  bool slot_used[2] = {false, false};
+  char err[256] = {0};
+};
+
+namespace {
+
+int cfail(ddt_comm* c, int code, const char* fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define CHIP(c, call)                                                                             \
+  do {                                                                                            \
+    hipError_t _r = (call);                                                                       \
+    if (_r != hipSuccess) return cfail((c), DDT_EHIP, "%s -> %s", #call, hipGetErrorString(_r));  \
+  } while (0)
+#define CNCCL(c, call)                                                                            \
+  do {                                                                                            \
+    ncclResult_t _r = (call);                                                                     \
+    if (_r != ncclSuccess) return cfail((c), DDT_EHIP, "%s -> %s", #call, ncclGetErrorString(_r)); \
+  } while (0)
+
+int comm_init_common(ddt_comm* c) {
+  CHIP(c, hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking));
+  for (int b = 0; b < 2; ++b) {
+    CHIP(c, hipEventCreateWithFlags(&c->ev_scored[b], hipEventDisableTiming));
+    CHIP(c, hipEventCreateWithFlags(&c->ev_free[b], hipEventDisableTiming));
+  }
+  CHIP(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  return DDT_OK;
+}
+
+// workspaces for `floats` values per chunk (rounded up to whole segments by the callers)
+int comm_reserve(ddt_comm* c, size_t floats) {
+  if (floats <= c->cap) return DDT_OK;
+  CHIP(c, hipDeviceSynchronize());
+  for (int b = 0; b < 2; ++b)
+    for (float** p : {&c->part[b], &c->recv[b], &c->full[b]}) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+  c->cap = 0;
+  for (int b = 0; b < 2; ++b)
+    for (float** p : {&c->part[b], &c->recv[b], &c->full[b]}) CHIP(c, hipMalloc(reinterpret_cast<void**>(p), floats * sizeof(float)));
+  c->cap = floats;
+  c->slot_used[0] = c->slot_used[1] = false;
+  return DDT_OK;
+}
+
+// Combine `count` partial values sitting in part[b][0, count) (tail up to G*seg already zero) into full[b][0, count),
+// on the comm stream.  seg = ceil(count / G).
+int chain_combine(ddt_comm* c, int b, size_t count) {
+  const size_t G = (size_t)c->n, seg = (count + G - 1) / G;
+  // all-to-all: my slice r goes to rank r; I receive every rank's slice of MY segment
+  CNCCL(c, ncclGroupStart());
+  for (int r = 0; r < c->n; ++r) {
+    CNCCL(c, ncclSend(c->part[b] + (size_t)r * seg, seg, ncclFloat, r, c->comm, c->cs));
+    CNCCL(c, ncclRecv(c->recv[b] + (size_t)r * seg, seg, ncclFloat, r, c->comm, c->cs));
+  }
+  CNCCL(c, ncclGroupEnd());
+  // p0 + p1 + ... in rank order: the reference's hop order (ResultsCombiner.sv:292-311: local + upstream)
+  hipError_t r = launch_chain_sum(c->recv[b], (uint32_t)c->n, seg, c->full[b] + (size_t)c->rank * seg, c->cs);
+  if (r != hipSuccess) return cfail(c, DDT_EHIP, "chain_sum -> %s", hipGetErrorString(r));
+  CNCCL(c, ncclAllGather(c->full[b] + (size_t)c->rank * seg, c->full[b], seg, ncclFloat, c->comm, c->cs));
+  return DDT_OK;
+}
+
+int check_call(ddt_comm* c, const void* d_tuples, const void* d_out, size_t n) {
+  if (!c) return DDT_EINVAL;
+  if (!c->e || !c->e->loaded) return cfail(c, DDT_ESTATE, "no model loaded on the engine of this communicator");
+  if (n && (!d_tuples || !d_out)) return cfail(c, DDT_EINVAL, "NULL device buffer");
+  return DDT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ddt_comm_get_unique_id(void* id_out) {
+  if (!id_out) return DDT_EINVAL;
+  static_assert(sizeof(ncclUniqueId) == DDT_COMM_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return DDT_EHIP;
+  memcpy(id_out, &id, sizeof(id));
+  return DDT_OK;
+}
+
+int ddt_comm_create(ddt_comm** out, ddt_engine* e, int rank, int n_ranks, const void* unique_id) {
+  if (!out) return DDT_EINVAL;
+  *out = nullptr;
+  if (!e || !unique_id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return DDT_EINVAL;
+  std::unique_ptr<ddt_comm> c(new (std::nothrow) ddt_comm());
+  if (!c) return DDT_ENOMEM;
+  c->e = e;
+  c->rank = rank;
+  c->n = n_ranks;
+  DeviceGuard dg(e->device);
+  if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  ncclResult_t r = ncclCommInitRank(&c->comm, n_ranks, id, rank);
+  if (r != ncclSuccess) return fail(e, DDT_EHIP, "ncclCommInitRank(rank %d of %d) -> %s", rank, n_ranks, ncclGetErrorString(r));
+  int rc = comm_init_common(c.get());
+  if (rc) {
+    fail(e, rc, "%s", c->err);
+    (void)ncclCommDestroy(c->comm);
+    return rc;
+  }
+  *out = c.release();
+  return DDT_OK;
+}
+
+void ddt_comm_destroy(ddt_comm* c) {
+  if (!c) return;
+  DeviceGuard dg(c->e ? c->e->device : 0);
+  if (c->cs) (void)hipStreamSynchronize(c->cs);
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  for (int b = 0; b < 2; ++b) {
+    for (float** p : {&c->part[b], &c->recv[b], &c->full[b]})
+      if (*p) (void)hipFree(*p);
+    if (c->ev_scored[b]) (void)hipEventDestroy(c->ev_scored[b]);
+    if (c->ev_free[b]) (void)hipEventDestroy(c->ev_free[b]);
+  }
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->cs) (void)hipStreamDestroy(c->cs);
+  delete c;
+}
+
+const char* ddt_comm_last_error(const ddt_comm* c) {
+  if (!c) return "";
+  return c->err[0] ? c->err : (c->e ? c->e->err : "");
+}
+
+int ddt_comm_set_option(ddt_comm* c, const char* key, int64_t value) {
+  if (!c || !key) return DDT_EINVAL;
+  if (!strcmp(key, "chunk_rows")) {
+    if (value < 1) return cfail(c, DDT_EINVAL, "chunk_rows must be >= 1");
+    c->chunk_rows = (size_t)value;
+    return DDT_OK;
+  }
+  return cfail(c, DDT_EINVAL, "unknown option '%s'", key);
+}
+
+// Shared chunk pipeline.  K = values per row (1 = scores, num_classes = class sums); `dst` = [K][n] result.
+static int sharded_pipeline(ddt_comm* c, const void* d_tuples, size_t n, float* dst, uint32_t K, int combine, hipStream_t s) {
+  ddt_engine* e = c->e;
+  const size_t W = tuple_words(e->p), G = (size_t)c->n;
+  const bool chain = combine == DDT_COMBINE_CHAIN;
+  const bool staged = chain || K > 1;  // all-reduce of plain scores runs in place in the caller's buffer
+  const size_t rows = std::min(c->chunk_rows, n);
+  c->err[0] = 0;
+  if (staged) {
+    const size_t seg = (rows * K + G - 1) / G;
+    int rc = comm_reserve(c, seg * G);
+    if (rc) return rc;
+  }
+  const uint32_t* tup = reinterpret_cast<const uint32_t*>(d_tuples);
+  size_t k = 0;
+  for (size_t lo = 0; lo < n; lo += rows, ++k) {
+    const int b = (int)(k & 1);
+    const size_t m = std::min(rows, n - lo), count = m * K, seg = (count + G - 1) / G;
+    int rc;
+    if (!staged) {
+      rc = engine_score_device(e, tup + lo * W, m, dst + lo, s);
+      if (rc) return cfail(c, rc, "%s", e->err);
+      CHIP(c, hipEventRecord(c->ev_scored[b], s));
+      CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));
+      CNCCL(c, ncclAllReduce(dst + lo, dst + lo, m, ncclFloat, ncclSum, c->comm, c->cs));
+      continue;
+    }
+    if (c->slot_used[b]) CHIP(c, hipStreamWaitEvent(s, c->ev_free[b], 0));  // slot b still feeds chunk k-2's collective
+    if (seg * G > count) CHIP(c, hipMemsetAsync(c->part[b] + count, 0, (seg * G - count) * sizeof(float), s));
+    rc = K == 1 ? engine_score_device(e, tup + lo * W, m, c->part[b], s)
+                : engine_classify_device(e, tup + lo * W, m, c->part[b], nullptr, s);
+    if (rc) return cfail(c, rc, "%s", e->err);
+    CHIP(c, hipEventRecord(c->ev_scored[b], s));
+    CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));
+    const float* res;
+    if (chain) {
+      rc = chain_combine(c, b, count);
+      if (rc) return rc;
+      res = c->full[b];
+    } else {
+      CNCCL(c, ncclAllReduce(c->part[b], c->part[b], count, ncclFloat, ncclSum, c->comm, c->cs));
+      res = c->part[b];
+    }
+    // [K][m] chunk block -> rows [lo, lo+m) of the [K][n] result
+    CHIP(c, hipMemcpy2DAsync(dst + lo, n * sizeof(float), res, m * sizeof(float), m * sizeof(float), K, hipMemcpyDeviceToDevice, c->cs));
+    CHIP(c, hipEventRecord(c->ev_free[b], c->cs));
+    c->slot_used[b] = true;
+  }
+  CHIP(c, hipEventRecord(c->ev_done, c->cs));
+  CHIP(c, hipStreamWaitEvent(s, c->ev_done, 0));  // results are ready in stream order on the caller's stream
+  return DDT_OK;
+}
+
+int ddt_score_sharded_device(ddt_comm* c, const void* d_tuples, size_t n, float* d_scores, int combine, void* stream) {
+  int rc = check_call(c, d_tuples, d_scores, n);
+  if (rc) return rc;
+  if (c->e->num_classes != 1) return cfail(c, DDT_ESTATE, "multi-class model loaded: use ddt_classify_sharded_device");
+  if (combine != DDT_COMBINE_ALLREDUCE && combine != DDT_COMBINE_CHAIN) return cfail(c, DDT_EINVAL, "combine %d", combine);
+  if (n == 0) return DDT_OK;
+  DeviceGuard dg(c->e->device);
+  if (!dg.ok) return cfail(c, DDT_EHIP, "hipSetDevice(%d) failed", c->e->device);
+  rc = sharded_pipeline(c, d_tuples, n, d_scores, 1, combine, reinterpret_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  c->e->st.score_calls++;
+  c->e->st.tuples_in += n;
+  c->e->st.tuples_out += n;
+  c->e->st.tuple_lines_in += (uint64_t)n * (tuple_words(c->e->p) / 4);
+  c->e->st.result_lines_out += (n + 3) / 4;
+  return DDT_OK;
+}
+
+int ddt_classify_sharded_device(ddt_comm* c, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, int combine,
+                                void* stream) {
+  int rc = check_call(c, d_tuples, d_class_scores, n);
+  if (rc) return rc;
+  if (combine != DDT_COMBINE_ALLREDUCE && combine != DDT_COMBINE_CHAIN) return cfail(c, DDT_EINVAL, "combine %d", combine);
+  if (n == 0) return DDT_OK;
+  DeviceGuard dg(c->e->device);
+  if (!dg.ok) return cfail(c, DDT_EHIP, "hipSetDevice(%d) failed", c->e->device);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const uint32_t K = c->e->num_classes;
+  // K == 1 would take the in-place all-reduce path of the scalar scores: same result layout ([1][n])
+  rc = sharded_pipeline(c, d_tuples, n, d_class_scores, K, combine, s);
+  if (rc) return rc;
+  if (d_labels) {
+    hipError_t r = launch_argmax(d_class_scores, K, n, d_labels, s);
+    if (r != hipSuccess) return cfail(c, DDT_EHIP, "argmax -> %s", hipGetErrorString(r));
+  }
+  c->e->st.score_calls++;
+  c->e->st.tuples_in += n;
+  c->e->st.tuples_out += n;
+  return DDT_OK;
+}
+
+int ddt_score_rowsharded_device(ddt_comm* c, const void* d_tuples, size_t n, float* d_scores, void* stream) {
+  int rc = check_call(c, d_tuples, d_scores, n);
+  if (rc) return rc;
+  if (c->e->num_classes != 1) return cfail(c, DDT_ESTATE, "multi-class model loaded");
+  if (n == 0) return DDT_OK;
+  DeviceGuard dg(c->e->device);
+  if (!dg.ok) return cfail(c, DDT_EHIP, "hipSetDevice(%d) failed", c->e->device);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  ddt_engine* e = c->e;
+  const size_t W = tuple_words(e->p), G = (size_t)c->n, per = (n + G - 1) / G;
+  const size_t lo = std::min((size_t)c->rank * per, n), hi = std::min(lo + per, n);
+  c->err[0] = 0;
+  const bool exact = per * G == n;  // the gather can land in the caller's buffer directly
+  float* full = d_scores;
+  if (!exact) {
+    rc = comm_reserve(c, per * G);
+    if (rc) return rc;
+    full = c->full[0];
+    if (c->slot_used[0]) CHIP(c, hipStreamWaitEvent(s, c->ev_free[0], 0));
+  }
+  float* mine = full + (size_t)c->rank * per;
+  if (hi - lo < per) CHIP(c, hipMemsetAsync(mine + (hi - lo), 0, (per - (hi - lo)) * sizeof(float), s));
+  if (hi > lo) {
+    rc = engine_score_device(e, reinterpret_cast<const uint32_t*>(d_tuples) + lo * W, hi - lo, mine, s);
+    if (rc) return cfail(c, rc, "%s", e->err);
+  }
+  CHIP(c, hipEventRecord(c->ev_scored[0], s));
+  CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[0], 0));
+  CNCCL(c, ncclAllGather(mine, full, per, ncclFloat, c->comm, c->cs));  // results interleaved, not summed (ResultsCombiner.sv:371-391)
+  if (!exact) {
+    CHIP(c, hipMemcpyAsync(d_scores, full, n * sizeof(float), hipMemcpyDeviceToDevice, c->cs));
+    CHIP(c, hipEventRecord(c->ev_free[0], c->cs));
+    c->slot_used[0] = true;
+  }
+  CHIP(c, hipEventRecord(c->ev_done, c->cs));
+  CHIP(c, hipStreamWaitEvent(s, c->ev_done, 0));
+  e->st.score_calls++;
+  e->st.tuples_in += hi - lo;
+  e->st.tuples_out += n;
+  return DDT_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// single-process multi-GPU group
+// =====================================================================================================
+struct ddt_group {
+  int n = 0;
+  std::vector<int> devices;
+  std::vector<ddt_engine*> eng;
+  std::vector<ddt_comm*> comm;
+  std::vector<hipStream_t> stream;
+  std::vector<void*> d_tuples;
+  std::vector<float*> d_scores;
+  size_t cap_rows = 0, cap_words = 0;
+  size_t group_rows = 8u << 20;  // rows per super-chunk held on the devices at once
+  char err[320] = {0};
+};
+
+namespace {
+
+int gfail(ddt_group* g, int code, const char* fmt, ...) {
+  if (g) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g->err, sizeof(g->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+// run fn(i) for every device on its own thread; first failing code wins
+template <class F>
+int for_each_device(ddt_group* g, F fn) {
+  std::vector<int> rc((size_t)g->n, DDT_OK);
+  std::vector<std::thread> th;
+  for (int i = 1; i < g->n; ++i) th.emplace_back([&, i] { rc[(size_t)i] = fn(i); });
+  rc[0] = fn(0);
+  for (std::thread& t : th) t.join();
+  for (int i = 0; i < g->n; ++i)
+    if (rc[(size_t)i]) return rc[(size_t)i];
+  return DDT_OK;
+}
+
+void group_free_buffers(ddt_group* g) {
+  for (int i = 0; i < g->n; ++i) {
+    (void)hipSetDevice(g->devices[(size_t)i]);
+    if (g->d_tuples[(size_t)i]) (void)hipFree(g->d_tuples[(size_t)i]);
+    if (g->d_scores[(size_t)i]) (void)hipFree(g->d_scores[(size_t)i]);
+    g->d_tuples[(size_t)i] = nullptr;
+    g->d_scores[(size_t)i] = nullptr;
+  }
+  g->cap_rows = g->cap_words = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ddt_group_create(ddt_group** out, int n_devices, const int* device_ids) {
+  if (!out) return DDT_EINVAL;
+  *out = nullptr;
+  if (n_devices < 1 || n_devices > 64) return DDT_EINVAL;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  std::unique_ptr<ddt_group> g(new (std::nothrow) ddt_group());
+  if (!g) return DDT_ENOMEM;
+  g->n = n_devices;
+  for (int i = 0; i < n_devices; ++i) g->devices.push_back(device_ids ? device_ids[i] : i);
+  g->eng.assign((size_t)n_devices, nullptr);
+  g->comm.assign((size_t)n_devices, nullptr);
+  g->stream.assign((size_t)n_devices, nullptr);
+  g->d_tuples.assign((size_t)n_devices, nullptr);
+  g->d_scores.assign((size_t)n_devices, nullptr);
+  int rc = DDT_OK;
+  for (int i = 0; i < n_devices && !rc; ++i) rc = ddt_create(&g->eng[(size_t)i], g->devices[(size_t)i]);
+  std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
+  if (!rc && ncclCommInitAll(comms.data(), n_devices, g->devices.data()) != ncclSuccess) rc = DDT_EHIP;
+  for (int i = 0; i < n_devices && !rc; ++i) {
+    std::unique_ptr<ddt_comm> c(new (std::nothrow) ddt_comm());
+    if (!c) {
+      rc = DDT_ENOMEM;
+      break;
+    }
+    c->e = g->eng[(size_t)i];
+    c->rank = i;
+    c->n = n_devices;
+    c->comm = comms[(size_t)i];
+    comms[(size_t)i] = nullptr;
+    if (hipSetDevice(g->devices[(size_t)i]) != hipSuccess) rc = DDT_EHIP;
+    if (!rc) rc = comm_init_common(c.get());
+    if (!rc && hipStreamCreateWithFlags(&g->stream[(size_t)i], hipStreamNonBlocking) != hipSuccess) rc = DDT_EHIP;
+    g->comm[(size_t)i] = c.release();
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (rc) {
+    for (ncclComm_t c : comms)
+      if (c) (void)ncclCommDestroy(c);
+    ddt_group_destroy(g.release());
+    return rc;
+  }
+  *out = g.release();
+  return DDT_OK;
+}
+
+void ddt_group_destroy(ddt_group* g) {
+  if (!g) return;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  group_free_buffers(g);
+  for (int i = 0; i < g->n; ++i) {
+    (void)hipSetDevice(g->devices[(size_t)i]);
+    if (g->stream[(size_t)i]) {
+      (void)hipStreamSynchronize(g->stream[(size_t)i]);
+      (void)hipStreamDestroy(g->stream[(size_t)i]);
+    }
+    if (g->comm[(size_t)i]) ddt_comm_destroy(g->comm[(size_t)i]);
+    if (g->eng[(size_t)i]) ddt_destroy(g->eng[(size_t)i]);
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  delete g;
+}
+
+const char* ddt_group_last_error(const ddt_group* g) { return g ? g->err : ""; }
+
+ddt_engine* ddt_group_engine(ddt_group* g, int index) { return (g && index >= 0 && index < g->n) ? g->eng[(size_t)index] : nullptr; }
+
+int ddt_group_load_model(ddt_group* g, const ddt_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines) {
+  if (!g) return DDT_EINVAL;
+  int rc = for_each_device(g, [&](int i) { return ddt_load_model_shard(g->eng[(size_t)i], p, wl, n_wlines, fl, n_flines, (uint32_t)i, (uint32_t)g->n); });
+  if (rc)
+    for (int i = 0; i < g->n; ++i)
+      if (g->eng[(size_t)i]->err[0]) return gfail(g, rc, "device %d: %s", g->devices[(size_t)i], g->eng[(size_t)i]->err);
+  return rc;
+}
+
+int ddt_group_load_model_sparse(ddt_group* g, const ddt_params* p, const void* node_lines, size_t n_lines, const uint64_t* first) {
+  if (!g) return DDT_EINVAL;
+  int rc = for_each_device(g, [&](int i) { return ddt_load_model_sparse(g->eng[(size_t)i], p, node_lines, n_lines, first, (uint32_t)i, (uint32_t)g->n); });
+  if (rc)
+    for (int i = 0; i < g->n; ++i)
+      if (g->eng[(size_t)i]->err[0]) return gfail(g, rc, "device %d: %s", g->devices[(size_t)i], g->eng[(size_t)i]->err);
+  return rc;
+}
+
+int ddt_group_score(ddt_group* g, const void* tuple_lines, size_t n, float* scores_out, int combine) {
+  if (!g) return DDT_EINVAL;
+  if (n == 0) return DDT_OK;
+  if (!tuple_lines || !scores_out) return gfail(g, DDT_EINVAL, "NULL host buffer");
+  if (!g->eng[0]->loaded) return gfail(g, DDT_ESTATE, "no model loaded");
+  const size_t W = tuple_words(g->eng[0]->p);
+  const size_t rows = std::min(g->group_rows, n);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  if (rows > g->cap_rows || W > g->cap_words) {
+    group_free_buffers(g);
+    for (int i = 0; i < g->n; ++i) {
+      if (hipSetDevice(g->devices[(size_t)i]) != hipSuccess || hipMalloc(&g->d_tuples[(size_t)i], rows * W * 4) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&g->d_scores[(size_t)i]), rows * sizeof(float)) != hipSuccess) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return gfail(g, DDT_ENOMEM, "device %d: tuple / score buffers for %zu rows", g->devices[(size_t)i], rows);
+      }
+    }
+    g->cap_rows = rows;
+    g->cap_words = W;
+  }
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(tuple_lines);
+  int rc = DDT_OK;
+  for (size_t off = 0; off < n && !rc; off += rows) {
+    const size_t m = std::min(rows, n - off);
+    // every device: its own copy of the tuples (the reference broadcasts them along the ring), the sharded job, and
+    // -- device 0 only -- the combined scores back to the host
+    rc = for_each_device(g, [&](int i) -> int {
+      const size_t k = (size_t)i;
+      if (hipSetDevice(g->devices[k]) != hipSuccess) return DDT_EHIP;
+      if (hipMemcpyAsync(g->d_tuples[k], src + off * W, m * W * 4, hipMemcpyHostToDevice, g->stream[k]) != hipSuccess) return DDT_EHIP;
+      int r = ddt_score_sharded_device(g->comm[k], g->d_tuples[k], m, g->d_scores[k], combine, g->stream[k]);
+      if (r) return r;
+      if (i == 0 && hipMemcpyAsync(scores_out + off, g->d_scores[k], m * sizeof(float), hipMemcpyDeviceToHost, g->stream[k]) != hipSuccess) return DDT_EHIP;
+      return hipStreamSynchronize(g->stream[k]) == hipSuccess ? DDT_OK : DDT_EHIP;
+    });
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (rc)
+    for (int i = 0; i < g->n; ++i) {
+      const char* msg = ddt_comm_last_error(g->comm[(size_t)i]);
+      if (msg && msg[0]) return gfail(g, rc, "device %d: %s", g->devices[(size_t)i], msg);
+    }
+  return rc;
+}
+
+}  // extern "C"

@@ -530,6 +530,7 @@ void fill_args(const ddt_engine* e, const Ensemble& m, const void* d_tuples, siz
   a->aux = nullptr;
   a->top_levels = 0;
   a->ev_mid = nullptr;
+  a->num_cus = e->prop.multiProcessorCount > 0 ? (uint32_t)e->prop.multiProcessorCount : 256u;
 }
 
 void feeder_free(ddt_engine* e) {
@@ -916,6 +917,9 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   out->abi_version = DDT_ABI_VERSION;
   out->device_id = e->device;
   snprintf(out->device_name, sizeof(out->device_name), "%s (%s)", e->prop.name, e->prop.gcnArchName);
+  out->num_cus = (uint32_t)e->prop.multiProcessorCount;
+  out->clock_khz = (uint32_t)e->prop.clockRate;
+  out->lds_bytes_per_cu = (uint32_t)e->prop.maxSharedMemoryPerMultiProcessor;
   if (!e->loaded) return DDT_OK;
   const Variant& v = variant(e->variant_id);
   if (e->sparse) {
@@ -999,6 +1003,16 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   if (!strcmp(key, "variant")) {
     if (value >= num_variants()) return fail(e, DDT_EINVAL, "variant %lld out of range", (long long)value);
     e->forced_variant = value < 0 ? -1 : (int)value;
+    if (e->loaded && e->sparse) {  // re-pack for the forced sparse kernel (or back to the automatic choice)
+      DeviceGuard dg(e->device);
+      if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
+      HIP_TRY(e, hipDeviceSynchronize());
+      e->loaded = false;
+      int rc = sparse_rebuild(e);
+      if (rc) return rc;
+      e->loaded = true;
+      return DDT_OK;
+    }
     if (e->loaded && !e->sparse) {
       DeviceGuard dg(e->device);
       if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);

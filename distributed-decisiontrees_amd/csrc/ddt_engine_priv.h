@@ -105,7 +105,7 @@ struct ddt_engine {
   bool sparse = false;
   ddt::SparseForest sp;
   int sparse_top_levels = -1;   // option "sparse_top_levels": K, -1 = the most the LDS takes
-  int sparse_deep_order = 1;    // option "sparse_deep_order": 0 = level order, 1 = depth-first per sub-tree
+  int sparse_deep_order = 0;    // option "sparse_deep_order": 0 = level order (default: measured faster), 1 = depth-first per sub-tree
   int leaf_domain_check = 1;    // option "leaf_domain_check": reject leaves outside the exact domain of the reference adder
   ddt_stats st{};
   char err[256] = {0};

@@ -42,6 +42,7 @@ struct ScoreArgs {
   const void* aux;         // kind-specific extras (Q16Aux for the rank-quantised path), else NULL
   uint32_t top_levels;     // generic kernel, deep trees: levels of each tree staged in LDS (set by launch_generic)
   hipEvent_t ev_mid;       // optional ("kernel_timing"): recorded right before the scoring kernel proper
+  uint32_t num_cus;        // hipDeviceProp_t::multiProcessorCount: sizes the persistent grids
 };
 
 constexpr uint32_t kQ16RankBuckets = 4096;
@@ -80,7 +81,6 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
 //   left/right  = index into the deep array, or the leaf's fp32 bits when the matching flag is set
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kSpLeftLeaf = 0x40000000u, kSpRightLeaf = 0x20000000u, kSpAddrMask = 0x1FFFFFFFu;
-constexpr int kSparseThreads = 256;      // tuples per tile == threads per block
 constexpr int kSparseMinTop = 6, kSparseMaxTop = 10;
 
 struct SparseAux {           // ScoreArgs::aux of the sparse kernels
@@ -129,8 +129,8 @@ struct Variant {
   uint32_t lds_bytes_q16(uint32_t tuple_words) const { return feat_off_q16() + tuple_words * tile() * 2u; }
   // ---- sparse kernels (levels = K, the top levels staged in LDS): LDS = [top image of one PU group][feature tile] ----
   uint32_t top_bytes_sparse() const { return 12u << levels; }
-  uint32_t feat_off_sparse() const {
-    const uint32_t row = row_bytes(), need = 8u * top_bytes_sparse();
+  uint32_t feat_off_sparse() const {  // chunk_trees = trees walked in lock-step = top images resident per pass
+    const uint32_t row = row_bytes(), need = (uint32_t)chunk_trees * top_bytes_sparse();
     return (need + row - 1u) / row * row;
   }
   uint32_t lds_bytes_sparse(uint32_t tuple_words) const { return feat_off_sparse() + tuple_words * row_bytes() + 64u; }
@@ -145,7 +145,8 @@ hipError_t launch_generic(const ScoreArgs& a, const Variant& v, hipStream_t s);
 uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds, uint32_t* top_levels);
 uint32_t stream_blocks_per_cu(uint32_t lds_bytes);
 
-hipError_t launch_sparse(const ScoreArgs& a, const Variant& v, hipStream_t s);  // ddt_sparse.hip
+int num_sparse_variants();                 // ddt_sparse.hip: appended to the variant table after the perfect-tree kernels
+const Variant& sparse_variant(int i);
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s);
 hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s);

@@ -322,7 +322,7 @@ static hipError_t launch_tile_persist(const ScoreArgs& a, const Variant& v, hipS
   if (e != hipSuccess) return e;
   const uint64_t tiles = (a.n + THREADS - 1) / THREADS;
   if (tiles == 0) return hipSuccess;
-  uint64_t grid = 256ull * (lds <= 80u * 1024u ? 2u : 1u);  // resident blocks: CUs x blocks per CU
+  uint64_t grid = (uint64_t)a.num_cus * (lds <= 80u * 1024u ? 2u : 1u);  // resident blocks: CUs x blocks per CU
   if (grid > tiles) grid = tiles;
   hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(THREADS), lds, s, a);
   return hipGetLastError();
@@ -422,7 +422,7 @@ static hipError_t launch_stream(const ScoreArgs& a, const Variant& v, hipStream_
   if (e != hipSuccess) return e;
   const uint64_t tiles = (a.n + kStreamThreads - 1) / kStreamThreads;
   if (tiles == 0) return hipSuccess;
-  uint64_t grid = 256ull * stream_blocks_per_cu(lds);  // persistent: CUs x resident blocks per CU
+  uint64_t grid = (uint64_t)a.num_cus * stream_blocks_per_cu(lds);  // persistent: CUs x resident blocks per CU
   if (grid > tiles) grid = tiles;
   hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(kStreamThreads), lds, s, a);
   return hipGetLastError();
@@ -801,7 +801,7 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
     e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 8u) * 4, s);
     if (e != hipSuccess) return e;
     if (x.fused.groups) {  // the tables of a feature group fit LDS: fused kernel(s), no transposed intermediate
-      const uint32_t grid = (tiles + 1u) / 2u < 256u ? (uint32_t)((tiles + 1u) / 2u) : 256u;  // at most one block per CU
+      const uint32_t grid = (tiles + 1u) / 2u < a.num_cus ? (uint32_t)((tiles + 1u) / 2u) : a.num_cus;  // at most one block per CU
       for (uint32_t g = 0; g < x.fused.groups; ++g) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.fused.bytes[g]);
         if (e != hipSuccess) return e;
@@ -1082,13 +1082,6 @@ hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t 
 
 static const Variant g_variants[] = {
     Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_generic},
-    // sparse (explicit-children) forests, `levels` = K top levels staged in LDS (ddt_sparse.hip); never auto-selected for
-    // perfect-tree models
-    Variant{"sparse_k6", kKindSparse, 6, kSparseThreads, 1, 8, 8, 1, 0, &launch_sparse},
-    Variant{"sparse_k7", kKindSparse, 7, kSparseThreads, 1, 8, 8, 1, 0, &launch_sparse},
-    Variant{"sparse_k8", kKindSparse, 8, kSparseThreads, 1, 8, 8, 1, 0, &launch_sparse},
-    Variant{"sparse_k9", kKindSparse, 9, kSparseThreads, 1, 8, 8, 1, 0, &launch_sparse},
-    Variant{"sparse_k10", kKindSparse, 10, kSparseThreads, 1, 8, 8, 1, 0, &launch_sparse},
     // rank-quantised u16 path: 2 blocks x 1024 threads per CU
     DDT_Q("q16_d8_c4_u4", 8, 4, 4),
     DDT_Q("q16_d6_c16_u4", 6, 16, 4),
@@ -1144,7 +1137,9 @@ static const Variant g_variants[] = {
     DDT_S("stream_d3_u4_l8", 3, 4, 8),
 };
 
-int num_variants() { return (int)(sizeof(g_variants) / sizeof(g_variants[0])); }
-const Variant& variant(int i) { return g_variants[i]; }
+// ids: the perfect-tree kernels above, then the sparse-forest kernels of ddt_sparse.hip
+static constexpr int kDenseVariants = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
+int num_variants() { return kDenseVariants + num_sparse_variants(); }
+const Variant& variant(int i) { return i < kDenseVariants ? g_variants[i] : sparse_variant(i - kDenseVariants); }
 
 }  // namespace ddt

@@ -31,19 +31,20 @@ __device__ __forceinline__ uint32_t visit16(const uint4 r, const uint32_t lane_o
   return right ? r.w : r.z;
 }
 
-template <int K>
-__global__ __launch_bounds__(kSparseThreads) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
-  constexpr int THREADS = kSparseThreads;
+template <int K, int U, int THREADS>
+__global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 12 << K;          // bytes of one tree's top image
   constexpr int GROUPB = 8 * TOPB;       // one PU group
+  constexpr int STEPB = (U / 8) * GROUPB;  // groups walked in lock-step per pass: U trees, U independent load chains per lane
   constexpr int ROW = THREADS * 4;
-  constexpr int FEAT_OFF = (GROUPB + ROW - 1) / ROW * ROW;
-  static_assert((GROUPB / 16) % 64 == 0, "whole waves per DMA");
+  constexpr int FEAT_OFF = (STEPB + ROW - 1) / ROW * ROW;
+  static_assert(U == 8 || U == 16, "one or two PU groups per pass");
+  static_assert((STEPB / 16) % 64 == 0, "whole waves per DMA");
   const int tid = threadIdx.x;
   const uint64_t tile0 = (uint64_t)blockIdx.x * THREADS;
   const uint32_t W = a.tuple_words, lpt = W / 4u;
 
-  dma_chunk<THREADS, GROUPB>(a.img, 0, 0, tid);  // top image of group 0
+  dma_chunk<THREADS, STEPB>(a.img, 0, 0, tid);  // top images of the first pass
 
   // ---- stage the tuple tile feature-major (quad-coalesced loads + in-quad DPP transpose, see score_tile_kernel) ----
   {
@@ -85,62 +86,66 @@ __global__ __launch_bounds__(kSparseThreads) void score_sparse_kernel(const Scor
   double dacc = 0.0;
   const uint32_t lane_off = (uint32_t)tid * 4u, miss_key = a.miss_key, C = a.clusters;
   const uint4* __restrict__ deep = x.deep;
+  const uint32_t n_steps = x.n_groups / (uint32_t)(U / 8);  // the host pads the image to whole passes
 
-  for (uint32_t g = 0; g < x.n_groups; ++g) {
+  for (uint32_t g = 0; g < n_steps; ++g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // top image g (and, first pass, the feature tile) is in LDS for everyone
+    __syncthreads();  // the top images of this pass (and, first pass, the feature tile) are in LDS for everyone
 
     // ---- top phase: levels 0..K-2 over 8-byte heap records, level K-1 over 16-byte records ----
-    uint32_t m8[8];
+    uint32_t m8[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) m8[u] = 8u;
+    for (int u = 0; u < U; ++u) m8[u] = 8u;
 #pragma unroll
     for (int lvl = 0; lvl < K - 1; ++lvl) {
-      uint2 nd[8];
+      uint2 nd[U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) nd[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
-      uint32_t f[8];
+      for (int u = 0; u < U; ++u) nd[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
+      uint32_t f[U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) f[u] = lds_u32((nd[u].y & kSpAddrMask) | lane_off);
+      for (int u = 0; u < U; ++u) f[u] = lds_u32((nd[u].y & kSpAddrMask) | lane_off);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) m8[u] = (m8[u] << 1) + (go_right<true>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
+      for (int u = 0; u < U; ++u) m8[u] = (m8[u] << 1) + (go_right<true>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
     }
-    uint4 r[8];  // m8 = 8 * heap index in [2^(K-1), 2^K): record at 4*2^K + 16*(m - 2^(K-1)) = 2*m8 - 4*2^K
+    uint4 r[U];  // m8 = 8 * heap index in [2^(K-1), 2^K): record at 4*2^K + 16*(m - 2^(K-1)) = 2*m8 - 4*2^K
 #pragma unroll
-    for (int u = 0; u < 8; ++u) r[u] = lds_u4((m8[u] << 1) - (uint32_t)(4 << K) + (uint32_t)(u * TOPB));
+    for (int u = 0; u < U; ++u) r[u] = lds_u4((m8[u] << 1) - (uint32_t)(4 << K) + (uint32_t)(u * TOPB));
     __syncthreads();  // every wave holds its level K-1 records: the top image buffer is free
-    if (g + 1 < x.n_groups) dma_chunk<THREADS, GROUPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
+    if (g + 1 < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
 
-    // ---- deep phase ----
-    uint32_t act = 0xFFu;  // per lane: trees still walking
-    float leafv[8];
+    // ---- deep phase: one 16-byte gather per visit; lanes whose tree has reached its leaf are masked off (the
+    //      vector-memory pipe takes one lane address per cycle: an idle lane must not cost one) ----
+    uint32_t act = (1u << U) - 1u;  // per lane: trees still walking
+    float leafv[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) leafv[u] = 0.f;
+    for (int u = 0; u < U; ++u) leafv[u] = 0.f;
     for (;;) {
-      uint32_t idx[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < U; ++u) {
         bool leaf;
         const uint32_t nxt = visit16(r[u], lane_off, miss_key, leaf);
-        const bool on = (act >> u) & 1u;
-        if (on && leaf) {
-          leafv[u] = __uint_as_float(nxt);
-          act &= ~(1u << u);
+        if ((act >> u) & 1u) {
+          if (leaf) {
+            leafv[u] = __uint_as_float(nxt);
+            act &= ~(1u << u);
+          } else {
+            r[u] = deep[nxt];
+          }
         }
-        idx[u] = (on && !leaf) ? nxt : 0u;  // finished lanes re-read record 0 (one shared line): branch-free loads
       }
       if (__ballot(act != 0u) == 0ull) break;
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (__ballot((act >> u) & 1u) != 0ull) r[u] = deep[idx[u]];  // wave-uniform skip of finished trees
     }
 
-    if (a.sum_mode == 1) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) dacc += (double)leafv[u];
-    } else {
-      const float s[1] = {((leafv[0] + leafv[1]) + (leafv[2] + leafv[3])) + ((leafv[4] + leafv[5]) + (leafv[6] + leafv[7]))};
-      ra.push_group(s, C);
+    for (int h = 0; h < U / 8; ++h) {
+      if (a.sum_mode == 1) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dacc += (double)leafv[8 * h + u];
+      } else {
+        const float s[1] = {((leafv[8 * h + 0] + leafv[8 * h + 1]) + (leafv[8 * h + 2] + leafv[8 * h + 3])) +
+                            ((leafv[8 * h + 4] + leafv[8 * h + 5]) + (leafv[8 * h + 6] + leafv[8 * h + 7]))};
+        ra.push_group(s, C);
+      }
     }
   }
   ra.align(C);
@@ -148,29 +153,33 @@ __global__ __launch_bounds__(kSparseThreads) void score_sparse_kernel(const Scor
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C);
 }
 
-template <int K>
-static hipError_t launch_sparse_k(const ScoreArgs& a, const SparseAux& x, uint32_t lds, hipStream_t s) {
-  auto kern = score_sparse_kernel<K>;
+template <int K, int U, int THREADS>
+static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
+  const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
+  const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
+  auto kern = score_sparse_kernel<K, U, THREADS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  const uint64_t blocks = (a.n + kSparseThreads - 1) / kSparseThreads;
+  const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(kSparseThreads), lds, s, a, x);
+  hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(THREADS), lds, s, a, x);
   return hipGetLastError();
 }
 
-hipError_t launch_sparse(const ScoreArgs& a, const Variant& v, hipStream_t s) {
-  const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
-  const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  switch (v.levels) {
-    case 6: return launch_sparse_k<6>(a, x, lds, s);
-    case 7: return launch_sparse_k<7>(a, x, lds, s);
-    case 8: return launch_sparse_k<8>(a, x, lds, s);
-    case 9: return launch_sparse_k<9>(a, x, lds, s);
-    case 10: return launch_sparse_k<10>(a, x, lds, s);
-    default: return hipErrorInvalidValue;
-  }
-}
+#define DDT_SP(K, U, T) \
+  Variant { "sparse_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 0, &launch_sparse_v<K, U, T> }
+
+// `levels` = K (top levels staged in LDS), `chunk_trees` = trees walked in lock-step, `threads` = tuples per tile
+static const Variant g_sparse_variants[] = {
+    DDT_SP(6, 8, 256), DDT_SP(7, 8, 256), DDT_SP(8, 8, 256), DDT_SP(9, 8, 256), DDT_SP(10, 8, 256),
+    DDT_SP(6, 16, 256), DDT_SP(7, 16, 256), DDT_SP(8, 16, 256),
+    DDT_SP(6, 8, 128), DDT_SP(7, 8, 128), DDT_SP(8, 8, 128), DDT_SP(9, 8, 128), DDT_SP(10, 8, 128),
+    DDT_SP(6, 16, 128), DDT_SP(7, 16, 128), DDT_SP(8, 16, 128), DDT_SP(9, 16, 128),
+    DDT_SP(8, 8, 64), DDT_SP(9, 8, 64), DDT_SP(10, 8, 64),
+};
+
+int num_sparse_variants() { return (int)(sizeof(g_sparse_variants) / sizeof(g_sparse_variants[0])); }
+const Variant& sparse_variant(int i) { return g_sparse_variants[i]; }
 
 }  // namespace ddt

@@ -18,25 +18,37 @@ struct Cursor {  // a position while expanding the top heap: an internal node of
   uint32_t v;    // node index / leaf bits
 };
 
-// pick K (levels of every tree staged in LDS): the most the LDS takes next to the feature tile, no more than the
-// deepest tree needs, or the user's choice (option "sparse_top_levels")
+// Kernel choice for a sparse forest.  A forced id (option "variant") wins when it is a sparse kernel that fits; option
+// "sparse_top_levels" fixes K and takes the widest tile that fits; otherwise the preference list below -- measured on
+// BASELINE config 4 (512 trees x depth 16 x 64 features, profiles/r02_sparse_sweep*.json): the deep phase is bound by the
+// vector-memory pipe's lane-address rate, and hiding its latency needs >= 8 waves per CU, so a smaller K that lets two
+// 256-tuple blocks share a CU beats a larger K with one.
 int pick_variant(ddt_engine* e, uint32_t max_depth) {
   const uint32_t W = tuple_words(e->p);
-  int best = -1;
-  for (int K = kSparseMinTop; K <= kSparseMaxTop; ++K) {
-    char name[32];
-    snprintf(name, sizeof(name), "sparse_k%d", K);
-    const int vid = find_variant(name);
-    if (vid < 0) continue;
-    if (variant(vid).lds_bytes_sparse(W) > kMaxLdsBytes) break;
-    if (e->sparse_top_levels >= 0) {
-      if (K == e->sparse_top_levels) return vid;
-      continue;
+  auto fits = [&](int vid, uint32_t budget) { return vid >= 0 && variant(vid).kind == kKindSparse && variant(vid).lds_bytes_sparse(W) <= budget; };
+  if (e->forced_variant >= 0) return fits(e->forced_variant, kMaxLdsBytes) ? e->forced_variant : -1;
+  char name[40];
+  if (e->sparse_top_levels >= 0) {
+    for (int T : {256, 128, 64}) {
+      snprintf(name, sizeof(name), "sparse_k%d_u8_t%d", e->sparse_top_levels, T);
+      const int vid = find_variant(name);
+      if (fits(vid, kMaxLdsBytes)) return vid;
     }
-    best = vid;
-    if ((uint32_t)K >= max_depth) break;  // nothing left for the deep phase beyond this
+    return -1;
   }
-  return e->sparse_top_levels >= 0 ? -1 : best;
+  // deepest K worth staging: nothing is left for the deep phase beyond the deepest tree
+  const int kcap = (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, kSparseMinTop), kSparseMaxTop);
+  static const struct { int K, U, T; uint32_t budget; } pref[] = {
+      {7, 8, 256, kMaxLdsBytes / 2}, {6, 8, 256, kMaxLdsBytes / 2},   // two 256-tuple blocks per CU
+      {8, 8, 128, kMaxLdsBytes / 2}, {7, 8, 128, kMaxLdsBytes / 2}, {6, 8, 128, kMaxLdsBytes / 2},
+      {9, 8, 256, kMaxLdsBytes},     {8, 8, 256, kMaxLdsBytes},     {7, 8, 256, kMaxLdsBytes}, {6, 8, 256, kMaxLdsBytes},
+      {8, 8, 128, kMaxLdsBytes},     {6, 8, 128, kMaxLdsBytes},     {8, 8, 64, kMaxLdsBytes}};
+  for (const auto& c : pref) {
+    snprintf(name, sizeof(name), "sparse_k%d_u%d_t%d", std::min(c.K, std::max(kcap, c.T == 64 ? 8 : kSparseMinTop)), c.U, c.T);
+    const int vid = find_variant(name);
+    if (fits(vid, c.budget)) return vid;
+  }
+  return -1;
 }
 
 }  // namespace
@@ -55,11 +67,13 @@ int sparse_rebuild(ddt_engine* e) {
   SparseForest& sp = e->sp;
   const int vid = pick_variant(e, sp.max_depth);
   if (vid < 0)
-    return fail(e, DDT_EUNSUPPORTED, "no sparse kernel fits: %u tuple words need more than %u bytes of LDS (or sparse_top_levels %d does not fit)",
-                tuple_words(e->p), kMaxLdsBytes, e->sparse_top_levels);
+    return fail(e, DDT_EUNSUPPORTED, "no sparse kernel fits: %u tuple words need more than %u bytes of LDS (or the forced variant %d / "
+                "sparse_top_levels %d is not a sparse kernel that fits)", tuple_words(e->p), kMaxLdsBytes, e->forced_variant, e->sparse_top_levels);
   const Variant& v = variant(vid);
   const uint32_t K = (uint32_t)v.levels, T = sp.trees();
-  const uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
+  const uint32_t per_pass = (uint32_t)v.chunk_trees / 8u;  // PU groups walked in lock-step
+  uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
+  groups = (groups + per_pass - 1u) / per_pass * per_pass;  // whole passes: the padding groups are EMPTY slots too (+0)
   const uint32_t top_words = (12u << K) / 4u;       // per tree
   const uint32_t feat_off = v.feat_off_sparse(), row = v.row_bytes();
   auto feat_word = [&](uint32_t j) { return feat_off + j * row; };
@@ -215,6 +229,7 @@ int sparse_launch(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores
   a.miss_key = e->p.cmp_mode ? kMissSentinelIeee : e->p.missing_bits;
   a.ieee = e->p.cmp_mode;
   a.sum_mode = e->p.sum_mode;
+  a.num_cus = e->prop.multiProcessorCount > 0 ? (uint32_t)e->prop.multiProcessorCount : 256u;
   SparseAux x;
   x.deep = reinterpret_cast<const uint4*>(sp.d_deep);
   x.n_groups = sp.groups;

@@ -17,6 +17,10 @@ SYMBOLS = [
     "ddt_csr_encode", "ddt_csr_decode", "ddt_get_info", "ddt_get_stats", "ddt_strerror", "ddt_last_error", "ddt_set_option",
     "ddt_num_variants", "ddt_variant_name", "ddt_synth_model", "ddt_synth_tuples_host", "ddt_synth_tuples_device",
     "ddt_load_model_sparse", "ddt_synth_sparse_model", "ddt_csr_encode_ex", "ddt_csr_decode_ex",
+    "ddt_comm_get_unique_id", "ddt_comm_create", "ddt_comm_destroy", "ddt_comm_last_error", "ddt_comm_set_option",
+    "ddt_score_sharded_device", "ddt_score_rowsharded_device", "ddt_classify_sharded_device",
+    "ddt_group_create", "ddt_group_destroy", "ddt_group_last_error", "ddt_group_engine", "ddt_group_load_model",
+    "ddt_group_load_model_sparse", "ddt_group_score",
 ]
 
 
@@ -39,6 +43,7 @@ class Info(C.Structure):
         ("lds_bytes", C.c_uint32), ("num_classes", C.c_uint32), ("local_trees", C.c_uint32),
         ("model_bytes_unpadded", C.c_uint64), ("image_bytes", C.c_uint64),
         ("variant_name", C.c_char * 64), ("device_name", C.c_char * 64),
+        ("num_cus", C.c_uint32), ("clock_khz", C.c_uint32), ("lds_bytes_per_cu", C.c_uint32), ("reserved_", C.c_uint32),
     ]
 
 
@@ -109,6 +114,22 @@ def lib():
     L.ddt_csr_decode_ex.restype = i32
     L.ddt_csr_decode_ex.argtypes = [C.POINTER(u64 * 12), PP, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32),
                                     C.POINTER(u32), C.POINTER(C.c_uint8 * 20)]
+    # multi-GPU jobs (RCCL behind the C-ABI)
+    L.ddt_comm_get_unique_id.restype, L.ddt_comm_get_unique_id.argtypes = i32, [vp]
+    L.ddt_comm_create.restype, L.ddt_comm_create.argtypes = i32, [C.POINTER(vp), vp, i32, i32, vp]
+    L.ddt_comm_destroy.restype, L.ddt_comm_destroy.argtypes = None, [vp]
+    L.ddt_comm_last_error.restype, L.ddt_comm_last_error.argtypes = C.c_char_p, [vp]
+    L.ddt_comm_set_option.restype, L.ddt_comm_set_option.argtypes = i32, [vp, C.c_char_p, i64]
+    L.ddt_score_sharded_device.restype, L.ddt_score_sharded_device.argtypes = i32, [vp, vp, sz, vp, i32, vp]
+    L.ddt_score_rowsharded_device.restype, L.ddt_score_rowsharded_device.argtypes = i32, [vp, vp, sz, vp, vp]
+    L.ddt_classify_sharded_device.restype, L.ddt_classify_sharded_device.argtypes = i32, [vp, vp, sz, vp, vp, i32, vp]
+    L.ddt_group_create.restype, L.ddt_group_create.argtypes = i32, [C.POINTER(vp), i32, C.POINTER(i32)]
+    L.ddt_group_destroy.restype, L.ddt_group_destroy.argtypes = None, [vp]
+    L.ddt_group_last_error.restype, L.ddt_group_last_error.argtypes = C.c_char_p, [vp]
+    L.ddt_group_engine.restype, L.ddt_group_engine.argtypes = vp, [vp, i32]
+    L.ddt_group_load_model.restype, L.ddt_group_load_model.argtypes = i32, [vp, PP, vp, sz, vp, sz]
+    L.ddt_group_load_model_sparse.restype, L.ddt_group_load_model_sparse.argtypes = i32, [vp, PP, vp, sz, vp]
+    L.ddt_group_score.restype, L.ddt_group_score.argtypes = i32, [vp, vp, sz, vp, i32]
     L.ddt_synth_model.restype, L.ddt_synth_model.argtypes = i32, [u32, u32, u32, i32, vp, vp]
     L.ddt_synth_tuples_host.restype, L.ddt_synth_tuples_host.argtypes = i32, [vp, u64, sz, u32, i32, u32]
     L.ddt_synth_tuples_device.restype, L.ddt_synth_tuples_device.argtypes = i32, [vp, vp, u64, sz, u32, i32, u32, vp]

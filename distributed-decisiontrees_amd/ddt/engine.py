@@ -270,3 +270,135 @@ def variant_names():
         L.ddt_variant_name(v, b, 64)
         out.append(b.value.decode())
     return out
+
+
+COMBINE_ALLREDUCE, COMBINE_CHAIN = 0, 1
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the C-ABI: rank 0 makes it, the launcher hands it to every rank."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = _lib.lib().ddt_comm_get_unique_id(buf)
+    if rc:
+        raise DDTError(rc, "ddt_comm_get_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """One rank of a multi-GPU job: an RCCL communicator bound to an Engine (include/ddt.h ddt_comm_*).  The sharded
+    calls are collective: every rank calls them with the same arguments."""
+
+    def __init__(self, engine: Engine, rank: int, n_ranks: int, unique_id: bytes):
+        self._L, self.engine, self.rank, self.n_ranks = _lib.lib(), engine, rank, n_ranks
+        assert len(unique_id) == COMM_ID_BYTES
+        h = C.c_void_p()
+        rc = self._L.ddt_comm_create(C.byref(h), engine._h, rank, n_ranks, unique_id)
+        if rc:
+            raise DDTError(rc, self._L.ddt_last_error(engine._h).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ddt_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            raise DDTError(rc, self._L.ddt_comm_last_error(self._h).decode())
+
+    def set_option(self, key: str, value: int):
+        self._check(self._L.ddt_comm_set_option(self._h, key.encode(), int(value)))
+
+    def _args(self, d_tuples, stream):
+        import torch
+
+        W = tuple_words(self.engine.params.num_features)
+        assert d_tuples.is_cuda and d_tuples.is_contiguous() and d_tuples.element_size() == 4
+        s = torch.cuda.current_stream(d_tuples.device) if stream is None else stream
+        return d_tuples.numel() // W, s
+
+    def score_sharded(self, d_tuples, out=None, combine: int = COMBINE_ALLREDUCE, stream=None):
+        """Tree-sharded job: tuples replicated on every rank -> full fp32 scores on every rank (asynchronous)."""
+        import torch
+
+        n, s = self._args(d_tuples, stream)
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=d_tuples.device)
+        self._check(self._L.ddt_score_sharded_device(self._h, d_tuples.data_ptr(), n, out.data_ptr(), combine, s.cuda_stream))
+        return out
+
+    def score_rowsharded(self, d_tuples, out=None, stream=None):
+        """Row-sharded job ("replicas only"): every rank holds the whole ensemble and scores its slice of the rows."""
+        import torch
+
+        n, s = self._args(d_tuples, stream)
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=d_tuples.device)
+        self._check(self._L.ddt_score_rowsharded_device(self._h, d_tuples.data_ptr(), n, out.data_ptr(), s.cuda_stream))
+        return out
+
+    def classify_sharded(self, d_tuples, combine: int = COMBINE_ALLREDUCE, want_labels: bool = True, stream=None):
+        """-> (labels int32 [n] or None, combined class scores fp32 [K, n])"""
+        import torch
+
+        n, s = self._args(d_tuples, stream)
+        cs = torch.empty((self.engine.num_classes, n), dtype=torch.float32, device=d_tuples.device)
+        labels = torch.empty(n, dtype=torch.int32, device=d_tuples.device) if want_labels else None
+        self._check(self._L.ddt_classify_sharded_device(self._h, d_tuples.data_ptr(), n, cs.data_ptr(),
+                                                        labels.data_ptr() if want_labels else None, combine, s.cuda_stream))
+        return labels, cs
+
+
+class Group:
+    """Single-process multi-GPU job (include/ddt.h ddt_group_*): n engines + one RCCL communicator over them."""
+
+    def __init__(self, device_ids):
+        self._L = _lib.lib()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = self._L.ddt_group_create(C.byref(h), len(device_ids), ids)
+        if rc:
+            raise DDTError(rc, "ddt_group_create")
+        self._h, self.n, self.params = h, len(device_ids), None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ddt_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            raise DDTError(rc, self._L.ddt_group_last_error(self._h).decode())
+
+    def load_model(self, params: Params, wlines: np.ndarray, flines: np.ndarray):
+        w = np.ascontiguousarray(wlines).view(np.uint32).reshape(-1)
+        f = np.ascontiguousarray(flines).view(np.uint16).reshape(-1)
+        self._check(self._L.ddt_group_load_model(self._h, C.byref(params), w.ctypes.data, w.size // 4, f.ctypes.data, f.size // 8))
+        self.params = params
+        return self
+
+    def load_model_sparse(self, params: Params, node_lines: np.ndarray, tree_first_line: np.ndarray):
+        nl = np.ascontiguousarray(node_lines).view(np.uint32).reshape(-1, 4)
+        first = np.ascontiguousarray(tree_first_line, dtype=np.uint64).reshape(-1)
+        self._check(self._L.ddt_group_load_model_sparse(self._h, C.byref(params), nl.ctypes.data, nl.shape[0], first.ctypes.data))
+        self.params = params
+        return self
+
+    def score(self, tuple_lines: np.ndarray, combine: int = COMBINE_ALLREDUCE) -> np.ndarray:
+        t = np.ascontiguousarray(tuple_lines).view(np.uint32).reshape(-1, tuple_words(self.params.num_features))
+        out = np.empty(t.shape[0], np.float32)
+        self._check(self._L.ddt_group_score(self._h, t.ctypes.data, t.shape[0], out.ctypes.data, combine))
+        return out

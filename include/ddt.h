@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDT_ABI_VERSION 1
+#define DDT_ABI_VERSION 2
 
 /* Threading: an engine is not thread-safe -- calls on ONE engine must not overlap; different engines (also on the
  * same device) are independent.  ddt_*_device calls are asynchronous on the given stream; ddt_destroy and
@@ -78,6 +78,8 @@ typedef struct ddt_info {
   uint64_t image_bytes;              /* packed device image actually read per tile pass             */
   char     variant_name[64];
   char     device_name[64];
+  uint32_t num_cus, clock_khz;       /* hipDeviceProp_t: multiProcessorCount, clockRate (inputs of the LDS / VMEM ceilings) */
+  uint32_t lds_bytes_per_cu, reserved_;
 } ddt_info;
 
 /* Observability counters, the analogue of CSR 220-226 / appStatus (EngineCSR.sv:113-126,
@@ -158,6 +160,61 @@ int ddt_argmax_device(ddt_engine* e, const float* d_class_scores, uint32_t num_c
  *    is then scored with ddt_score / ddt_score_device.  (One class only.)                                        -- */
 int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const void* node_lines, size_t n_lines,
                           const uint64_t* tree_first_line, uint32_t shard_index, uint32_t shard_count);
+
+/* -- multi-GPU jobs: RCCL over xGMI behind the C-ABI ---------------------------------------------------------------
+ *    Replaces the inter-FPGA networks of the reference: the ring broadcast of tuple lines (InputDistributor.sv:199-204)
+ *    and the partial-result network (ResultsCombiner.sv:292-311 chain adders, :359-369,426-430 forwarding).  Both of
+ *    the reference's modes (DTInference.sv:28-37):
+ *      tree-sharded  rank g holds shard g of ceil(T/G) contiguous trees (ddt_load_model_shard / _sparse / _multiclass
+ *                    with shard_index = rank, shard_count = n_ranks), every rank scores ALL tuples, the per-tuple
+ *                    partial scores are combined across ranks, chunk-pipelined (chunk k's collective runs on the
+ *                    comm's own stream while chunk k+1 is being scored):
+ *                      DDT_COMBINE_ALLREDUCE  one ncclAllReduce(ncclFloat, ncclSum) per chunk; the ring's summation
+ *                                             order is RCCL's: equal to the reference's chain order to fp32 rounding;
+ *                      DDT_COMBINE_CHAIN      deterministic: all-to-all (grouped ncclSend / ncclRecv of 1/G slices),
+ *                                             fixed-order add p0 + p1 + ... on the owner (ResultsCombiner.sv:292-311's
+ *                                             host -> dev1 -> ... order), ncclAllGather: bit-exact with the chain.
+ *      row-sharded   every rank holds the whole ensemble and scores rows [r*ceil(n/G), ...); ncclAllGather returns the
+ *                    full score vector to every rank ("replicas only": no arithmetic crosses devices).
+ *    One ddt_comm per (process or thread) x device; the calls are collective: every rank calls them with the same
+ *    arguments (tuples replicated on every rank for the tree-sharded calls).  They are asynchronous on `hip_stream`
+ *    like ddt_score_device; workspace buffers are (re)allocated synchronously when a call needs more than before.
+ *    Multi-process (one process per GPU): rank 0 calls ddt_comm_get_unique_id and hands the 128 bytes to every rank
+ *    (any launcher-side channel: a file, MPI, torch.distributed's store), then every rank calls ddt_comm_create.
+ *    Single process driving several GPUs: ddt_group_* below (ncclCommInitAll + one worker thread per device).      -- */
+typedef struct ddt_comm ddt_comm;
+#define DDT_COMM_ID_BYTES 128
+enum { DDT_COMBINE_ALLREDUCE = 0, DDT_COMBINE_CHAIN = 1 };
+int  ddt_comm_get_unique_id(void* id_out /* DDT_COMM_ID_BYTES */);
+int  ddt_comm_create(ddt_comm** out, ddt_engine* e, int rank, int n_ranks, const void* unique_id);
+void ddt_comm_destroy(ddt_comm* c);
+const char* ddt_comm_last_error(const ddt_comm* c);
+/* "chunk_rows": rows per pipelined collective (default 12,500,000) */
+int  ddt_comm_set_option(ddt_comm* c, const char* key, int64_t value);
+int  ddt_score_sharded_device(ddt_comm* c, const void* d_tuple_lines, size_t n_tuples, float* d_scores, int combine,
+                              void* hip_stream);
+int  ddt_score_rowsharded_device(ddt_comm* c, const void* d_tuple_lines, size_t n_tuples, float* d_scores,
+                                 void* hip_stream);
+/* multi-class (ddt_load_model_multiclass with shard_index = rank): per-class partial sums [K][n] combined like the
+ * scalar scores, then the argmax over the combined sums (d_labels may be NULL) */
+int  ddt_classify_sharded_device(ddt_comm* c, const void* d_tuple_lines, size_t n_tuples, float* d_class_scores,
+                                 int32_t* d_labels, int combine, void* hip_stream);
+
+/* Single-process multi-GPU job: n engines + one RCCL communicator over them (ncclCommInitAll), one worker thread per
+ * device.  ddt_group_load_model* gives device g tree shard g; ddt_group_score takes HOST buffers, replicates the
+ * tuples on every device (one H2D copy per device, the analogue of the reference's tuple broadcast), runs the
+ * tree-sharded job and returns the combined scores from device 0.  ddt_group_engine(g, i) exposes engine i
+ * (options, stats). */
+typedef struct ddt_group ddt_group;
+int  ddt_group_create(ddt_group** out, int n_devices, const int* device_ids);
+void ddt_group_destroy(ddt_group* g);
+const char* ddt_group_last_error(const ddt_group* g);
+ddt_engine* ddt_group_engine(ddt_group* g, int index);
+int  ddt_group_load_model(ddt_group* g, const ddt_params* p, const void* weights_lines, size_t n_wlines,
+                          const void* findex_lines, size_t n_flines);
+int  ddt_group_load_model_sparse(ddt_group* g, const ddt_params* p, const void* node_lines, size_t n_lines,
+                                 const uint64_t* tree_first_line);
+int  ddt_group_score(ddt_group* g, const void* tuple_lines, size_t n_tuples, float* scores_out, int combine);
 
 /* -- introspection ----------------------------------------------------------------------------------- */
 int ddt_get_info(const ddt_engine* e, ddt_info* out);

@@ -520,6 +520,76 @@ void orc_gen_model(uint32_t T, uint32_t D, uint32_t F, int dist, uint32_t* wline
 }
 
 /* =============================================================================================
+ * 8. The CPU baseline form of the scorer (bench.py cpu_baseline): same results as orc_score(ORC_SUM_REF_NATIVE / F64)
+ *    for cmp_mode 0, organised for a cache hierarchy instead of for readability: nodes re-packed to 8-byte
+ *    {threshold, feature | miss_right << 31} records, rows processed in blocks so that a group of 8 trees (16 KB at
+ *    depth 8) is walked for a whole block of rows out of L1 before the next group is touched, 8 independent walks in
+ *    flight per thread, branch-free direction select.  tests/test_oracle_kat.py holds it to orc_score bit for bit.
+ * ============================================================================================= */
+typedef struct { uint32_t thr, fi; } fast_node;
+
+int orc_score_fast(const orc_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines, const void* tl,
+                   size_t n_tuples, float* out, int sum_mode, int nthreads) {
+  int rc = check_params(p, n_wlines, n_flines);
+  if (rc) return rc;
+  if (p->cmp_mode != 0 || sum_mode == ORC_SUM_REF_FLOPOCO)  /* the general scorer covers those */
+    return orc_score(p, wl, n_wlines, fl, n_flines, tl, n_tuples, out, NULL, sum_mode, 1, nthreads);
+  const uint32_t T = p->num_trees, D = p->num_levels, nint = (1u << D) - 1u, nleaf = 1u << D;
+  const uint32_t Tp = (T + 7u) & ~7u, tw = orc_tuple_lines(p->num_features) * 4u, miss = p->missing_bits;
+  const size_t ws = (size_t)p->weights_lines_per_tree * 4u, fs = (size_t)p->findex_lines_per_tree * 8u;
+  fast_node* nodes = (fast_node*)calloc((size_t)Tp * nint, sizeof(fast_node)); /* EMPTY trees: leaves +0 */
+  uint32_t* leaf = (uint32_t*)calloc((size_t)Tp * nleaf, sizeof(uint32_t));
+  if (!nodes || !leaf) { free(nodes); free(leaf); return -7; }
+  for (uint32_t i = 0; i < T; ++i) {
+    const uint32_t* w = (const uint32_t*)wl + (size_t)i * ws;
+    const uint16_t* f = (const uint16_t*)fl + (size_t)i * fs;
+    for (uint32_t n = 0; n < nint; ++n) {
+      nodes[(size_t)i * nint + n].thr = w[n];
+      nodes[(size_t)i * nint + n].fi = (uint32_t)(f[n] & 0x7FFu) | ((uint32_t)((f[n] >> 13) & 1u) << 31);
+    }
+    memcpy(leaf + (size_t)i * nleaf, w + nint, (size_t)nleaf * 4u);
+  }
+  const uint32_t* t = (const uint32_t*)tl;
+  enum { RB = 64 };
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    uint32_t* lv = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)RB * Tp);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (long long b0 = 0; b0 < (long long)n_tuples; b0 += RB) {
+      const uint32_t rows = (uint32_t)((long long)n_tuples - b0 < RB ? (long long)n_tuples - b0 : RB);
+      for (uint32_t t0 = 0; t0 < Tp; t0 += 8u) {
+        const fast_node* nd = nodes + (size_t)t0 * nint;
+        const uint32_t* lf = leaf + (size_t)t0 * nleaf;
+        for (uint32_t r = 0; r < rows; ++r) {
+          const uint32_t* x = t + ((size_t)b0 + r) * tw;
+          uint32_t n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (uint32_t lvl = 0; lvl < D; ++lvl)
+            for (int u = 0; u < 8; ++u) {
+              const fast_node q = nd[(size_t)u * nint + n[u]];
+              const uint32_t f = x[q.fi & 0x7FFu];
+              const uint32_t ge = (uint32_t)!((int32_t)f < (int32_t)q.thr);   /* DTPU.sv:655-657 */
+              const uint32_t right = f == miss ? q.fi >> 31 : ge;             /* DTPU.sv:653,667 */
+              n[u] = 2u * n[u] + 1u + right;
+            }
+          for (int u = 0; u < 8; ++u) lv[(size_t)r * Tp + t0 + (uint32_t)u] = lf[(size_t)u * nleaf + (n[u] - nint)];
+        }
+      }
+      for (uint32_t r = 0; r < rows; ++r) out[(size_t)b0 + r] = f_from(shard_sum(lv + (size_t)r * Tp, T, p->clusters_per_tuple, sum_mode));
+    }
+    free(lv);
+  }
+  free(nodes);
+  free(leaf);
+  (void)nthreads;
+  return 0;
+}
+
+/* =============================================================================================
  * 7. Sparse (explicit-children) model stream -- this repository's extension, see ddt_oracle.h.
  *    Compare rule = orc_go_right (DTPU.sv:653-667); entry bits [10:0], [13] as in DTPU.sv:628,659; bit 14 keeps the
  *    RTL's meaning "the next node is a leaf" (DTPU.sv:661) for the left branch, bit 15 says it for the right one.
@@ -563,6 +633,27 @@ uint32_t orc_traverse_sparse(const orc_params* p, const uint32_t* lines, const u
     if ((e >> (14u + right)) & 1u) return child; /* leaf value bits */
     n = child;
   }
+}
+
+/* mean number of node visits per (tuple, tree): the leaf depth actually walked (bench.py / tools: node-visit rates) */
+double orc_sparse_mean_depth(const orc_params* p, const uint32_t* lines, const uint64_t* first, const uint32_t* tuples, size_t n) {
+  const uint32_t tw = orc_tuple_lines(p->num_features) * 4u;
+  double visits = 0.0;
+  for (size_t r = 0; r < n; ++r) {
+    const uint32_t* x = tuples + r * tw;
+    for (uint32_t i = 0; i < p->num_trees; ++i) {
+      const uint32_t* t = lines + first[i] * 4u;
+      uint32_t node = 0;
+      for (;;) {
+        const uint32_t* q = t + 4u * node;
+        const uint32_t right = orc_go_right(x[q[1] & 0x7FFu], q[0], p->missing_bits, (q[1] >> 13) & 1u, p->cmp_mode);
+        visits += 1.0;
+        if ((q[1] >> (14u + right)) & 1u) break;
+        node = q[2u + right];
+      }
+    }
+  }
+  return n ? visits / ((double)n * p->num_trees) : 0.0;
 }
 
 int orc_score_sparse(const orc_params* p, const void* nl, size_t n_lines, const uint64_t* first, const void* tl,

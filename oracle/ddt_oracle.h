@@ -101,6 +101,11 @@ int orc_score(const orc_params* p, const void* weights_lines, size_t n_wlines,
               const void* findex_lines, size_t n_flines, const void* tuple_lines, size_t n_tuples,
               float* out, double* gold, int sum_mode, int n_devices, int nthreads);
 
+/* The CPU-baseline form of orc_score (single device, ORC_SUM_REF_NATIVE or ORC_SUM_F64_SEQ, cmp_mode 0): identical
+ * results, cache-blocked and branch-free (see ddt_oracle.c section 8); other modes fall through to orc_score. */
+int orc_score_fast(const orc_params* p, const void* weights_lines, size_t n_wlines, const void* findex_lines,
+                   size_t n_flines, const void* tuple_lines, size_t n_tuples, float* out, int sum_mode, int nthreads);
+
 /* Partial (per-shard) scores: trees [tree_begin, tree_end) only, reduced as one device. */
 int orc_score_shard(const orc_params* p, const void* weights_lines, size_t n_wlines,
                     const void* findex_lines, size_t n_flines, const void* tuple_lines, size_t n_tuples,
@@ -130,6 +135,8 @@ int orc_classify(const orc_params* p, const void* weights_lines, size_t n_wlines
 int orc_sparse_check(const orc_params* p, const uint32_t* node_lines, size_t n_lines, const uint64_t* tree_first_line);
 uint32_t orc_traverse_sparse(const orc_params* p, const uint32_t* node_lines, const uint64_t* tree_first_line,
                              const uint32_t* tuple, uint32_t tree);
+double orc_sparse_mean_depth(const orc_params* p, const uint32_t* node_lines, const uint64_t* tree_first_line,
+                             const uint32_t* tuples, size_t n_tuples);
 /* same reduction / multi-device model as orc_score */
 int orc_score_sparse(const orc_params* p, const void* node_lines, size_t n_lines, const uint64_t* tree_first_line,
                      const void* tuple_lines, size_t n_tuples, float* out, double* gold, int sum_mode, int n_devices,

@@ -68,6 +68,8 @@ def lib():
         L.orc_reduce_device.restype, L.orc_reduce_device.argtypes = u32, [vp, u32, u32, C.c_int]
         L.orc_score.restype = C.c_int
         L.orc_score.argtypes = [PP, vp, sz, vp, sz, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int]
+        L.orc_score_fast.restype = C.c_int
+        L.orc_score_fast.argtypes = [PP, vp, sz, vp, sz, vp, sz, vp, C.c_int, C.c_int]
         L.orc_score_shard.restype = C.c_int
         L.orc_score_shard.argtypes = [PP, vp, sz, vp, sz, vp, sz, u32, u32, vp, C.c_int, C.c_int]
         L.orc_classify.restype = C.c_int
@@ -81,6 +83,7 @@ def lib():
         L.orc_hw_threads.restype, L.orc_hw_threads.argtypes = C.c_int, []
         L.orc_sparse_check.restype, L.orc_sparse_check.argtypes = C.c_int, [PP, vp, sz, vp]
         L.orc_traverse_sparse.restype, L.orc_traverse_sparse.argtypes = u32, [PP, vp, vp, vp, u32]
+        L.orc_sparse_mean_depth.restype, L.orc_sparse_mean_depth.argtypes = C.c_double, [PP, vp, vp, vp, sz]
         L.orc_score_sparse.restype = C.c_int
         L.orc_score_sparse.argtypes = [PP, vp, sz, vp, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int]
         L.orc_sparse_from_perfect.restype, L.orc_sparse_from_perfect.argtypes = None, [PP, vp, vp, vp, vp]
@@ -186,6 +189,17 @@ def score(m: Model, tuples: np.ndarray, sum_mode: int = SUM_REF_FLOPOCO, n_devic
     if rc:
         raise ValueError(f"orc_score rc={rc}")
     return (out, gold) if want_gold else out
+
+
+def score_fast(m: Model, tuples: np.ndarray, sum_mode: int = SUM_REF_NATIVE, nthreads: int = 0) -> np.ndarray:
+    """The CPU-baseline form of score(): identical bits, cache-blocked (oracle/ddt_oracle.c section 8)."""
+    t = np.ascontiguousarray(tuples, np.uint32)
+    out = np.zeros(t.shape[0], np.float32)
+    rc = lib().orc_score_fast(C.byref(m.params), _p(m.wlines), m.n_wlines, _p(m.flines), m.n_flines, _p(t), t.shape[0],
+                              _p(out), sum_mode, nthreads)
+    if rc:
+        raise ValueError(f"orc_score_fast rc={rc}")
+    return out
 
 
 def score_shard(m: Model, tuples: np.ndarray, tree_begin: int, tree_end: int,
@@ -311,3 +325,9 @@ def score_sparse(s: SparseModel, tuples: np.ndarray, sum_mode: int = SUM_REF_FLO
 def traverse_sparse(s: SparseModel, tuple_row: np.ndarray, tree: int) -> int:
     t = np.ascontiguousarray(tuple_row, np.uint32)
     return lib().orc_traverse_sparse(C.byref(s.params), _p(s.node_lines), _p(s.first), _p(t), tree)
+
+
+def sparse_mean_depth(s: SparseModel, tuples: np.ndarray) -> float:
+    """mean node visits per (tuple, tree) on these tuples"""
+    t = np.ascontiguousarray(tuples, np.uint32)
+    return float(lib().orc_sparse_mean_depth(C.byref(s.params), _p(s.node_lines), _p(s.first), _p(t), t.shape[0]))

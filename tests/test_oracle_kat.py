@@ -247,3 +247,16 @@ def test_generators_match_python_integer_model():
         g = i * (1 << (D + 1)) + n
         u = F32((_sm64(SM + 3 * g + 1) >> 40) / 16777216.0)
         assert leaf[i, n - 63] == bits(F32(F32(u - F32(0.5)) * F32(0.2)))
+
+
+def test_cpu_baseline_scorer_equals_the_plain_oracle():
+    """orc_score_fast (bench.py's cpu_baseline: cache-blocked, branch-free, 8-byte nodes) == orc_score bit for bit."""
+    for (T, D, F, rows, dist) in [(1000, 8, 32, 3000, 0), (37, 6, 28, 2049, 1), (9, 3, 5, 130, 1), (100, 6, 28, 63, 1)]:
+        m = O.gen_model(T, D, F, dist)
+        x = O.gen_tuples(11, rows, F, dist)
+        for mode in (O.SUM_REF_NATIVE, O.SUM_F64_SEQ):
+            a, b = O.score(m, x, sum_mode=mode), O.score_fast(m, x, sum_mode=mode)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (T, D, F, mode)
+    m = O.gen_model(20, 5, 12, 1, cmp_mode=1)  # modes it does not specialise fall through to the plain scorer
+    x = O.gen_tuples(0, 500, 12, 1)
+    assert np.array_equal(O.score(m, x, sum_mode=O.SUM_REF_NATIVE).view(np.uint32), O.score_fast(m, x).view(np.uint32))

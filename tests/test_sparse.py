@@ -131,7 +131,7 @@ def eng():
     e.close()
 
 
-def _gpu_sparse(eng, s, x, sum_mode=0, shard=(0, 1), top=-1, order=1):
+def _gpu_sparse(eng, s, x, sum_mode=0, shard=(0, 1), top=-1, order=0):
     import torch
 
     q = s.params
