@@ -70,6 +70,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
 
+    # stdout discipline: the driver wants ONE JSON line.  Native libraries (RCCL prints a version banner through C stdio)
+    # must not add lines to it: everything but the final print goes to stderr.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -302,12 +308,18 @@ def main():
             line["parity"] = parity
         if streamed:
             line["streamed"] = streamed
-        print(json.dumps(line), flush=True)
     if comm is not None:
         comm.close()
     if multi:
         dist.destroy_process_group()
     eng.close()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)  # C stdio buffers of native libraries -> stderr, before stdout comes back
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -384,6 +384,14 @@ int ddt_group_create(ddt_group** out, int n_devices, const int* device_ids) {
   if (!out) return DDT_EINVAL;
   *out = nullptr;
   if (n_devices < 1 || n_devices > 64) return DDT_EINVAL;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return DDT_ENODEVICE;
+  for (int i = 0; i < n_devices; ++i) {
+    const int d = device_ids ? device_ids[i] : i;
+    if (d < 0 || d >= count) return DDT_EINVAL;  // before anything is created
+    for (int j = 0; j < i; ++j)
+      if ((device_ids ? device_ids[j] : j) == d) return DDT_EINVAL;  // one communicator rank per device
+  }
   int prev = -1;
   (void)hipGetDevice(&prev);
   std::unique_ptr<ddt_group> g(new (std::nothrow) ddt_group());

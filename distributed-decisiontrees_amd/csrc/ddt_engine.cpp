@@ -597,6 +597,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     if (v.kind == kKindQ16) a.ev_mid = e->tev[1];
     else HIP_TRY(e, hipEventRecord(e->tev[1], s));
   }
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   hipError_t r = v.launch(a, v, s);
   if (r != hipSuccess) return fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
   if (timing) {

@@ -998,6 +998,7 @@ __global__ __launch_bounds__(256) void chain_sum_kernel(const float* __restrict_
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s) {
   if (n == 0) return hipSuccess;
+  (void)hipGetLastError();  // do not inherit a stale error
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048 * 8) blocks = 2048 * 8;
   hipLaunchKernelGGL(chain_sum_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, parts, n_parts, n, out);
@@ -1028,6 +1029,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ s
 
 hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s) {
   if (n == 0) return hipSuccess;
+  (void)hipGetLastError();  // do not inherit a stale error
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048 * 8) blocks = 2048 * 8;
   hipLaunchKernelGGL(argmax_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, scores, K, n, labels);
@@ -1062,6 +1064,7 @@ __global__ __launch_bounds__(256) void synth_tuples_kernel(uint32_t* __restrict_
 hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits,
                                hipStream_t s) {
   if (n == 0) return hipSuccess;
+  (void)hipGetLastError();  // do not inherit a stale error
   const uint32_t W = (F + 3u) / 4u * 4u;
   hipLaunchKernelGGL(synth_tuples_kernel, dim3(256 * 16), dim3(256), 0, s, out, row0, n, F, W, dist, missing_bits);
   return hipGetLastError();

@@ -120,20 +120,22 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
 #pragma unroll
     for (int u = 0; u < U; ++u) leafv[u] = 0.f;
     for (;;) {
+      // phase A: one visit per tree on the records in registers (no memory access besides the LDS feature gather)
+      uint32_t nxt[U], go = 0u;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         bool leaf;
-        const uint32_t nxt = visit16(r[u], lane_off, miss_key, leaf);
-        if ((act >> u) & 1u) {
-          if (leaf) {
-            leafv[u] = __uint_as_float(nxt);
-            act &= ~(1u << u);
-          } else {
-            r[u] = deep[nxt];
-          }
-        }
+        nxt[u] = visit16(r[u], lane_off, miss_key, leaf);
+        const bool on = ((act >> u) & 1u) != 0u;
+        if (on && leaf) leafv[u] = __uint_as_float(nxt[u]);
+        if (on && leaf) act &= ~(1u << u);
+        if (on && !leaf) go |= 1u << u;
       }
       if (__ballot(act != 0u) == 0ull) break;
+      // phase B: all gathers of this round back to back, each under its own lane mask; nothing waits in between
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if ((go >> u) & 1u) r[u] = deep[nxt[u]];
     }
 
 #pragma unroll

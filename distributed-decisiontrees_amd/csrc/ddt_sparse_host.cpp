@@ -234,6 +234,7 @@ int sparse_launch(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores
   x.deep = reinterpret_cast<const uint4*>(sp.d_deep);
   x.n_groups = sp.groups;
   a.aux = &x;
+  (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   hipError_t r = v.launch(a, v, s);
   if (r != hipSuccess) return fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
   return DDT_OK;
