@@ -179,6 +179,8 @@ static const Variant g_sparse_variants[] = {
     DDT_SP(6, 8, 128), DDT_SP(7, 8, 128), DDT_SP(8, 8, 128), DDT_SP(9, 8, 128), DDT_SP(10, 8, 128),
     DDT_SP(6, 16, 128), DDT_SP(7, 16, 128), DDT_SP(8, 16, 128), DDT_SP(9, 16, 128),
     DDT_SP(8, 8, 64), DDT_SP(9, 8, 64), DDT_SP(10, 8, 64),
+    // 512-tuple tiles: one block of 8 waves per CU shares ONE set of top images (two 256-tuple blocks hold two)
+    DDT_SP(6, 8, 512), DDT_SP(7, 8, 512), DDT_SP(8, 8, 512), DDT_SP(9, 8, 512),
 };
 
 int num_sparse_variants() { return (int)(sizeof(g_sparse_variants) / sizeof(g_sparse_variants[0])); }

@@ -38,17 +38,27 @@ int pick_variant(ddt_engine* e, uint32_t max_depth) {
   }
   // deepest K worth staging: nothing is left for the deep phase beyond the deepest tree
   const int kcap = (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, kSparseMinTop), kSparseMaxTop);
-  static const struct { int K, U, T; uint32_t budget; } pref[] = {
-      {7, 8, 256, kMaxLdsBytes / 2}, {6, 8, 256, kMaxLdsBytes / 2},   // two 256-tuple blocks per CU
-      {8, 8, 128, kMaxLdsBytes / 2}, {7, 8, 128, kMaxLdsBytes / 2}, {6, 8, 128, kMaxLdsBytes / 2},
-      {9, 8, 256, kMaxLdsBytes},     {8, 8, 256, kMaxLdsBytes},     {7, 8, 256, kMaxLdsBytes}, {6, 8, 256, kMaxLdsBytes},
-      {8, 8, 128, kMaxLdsBytes},     {6, 8, 128, kMaxLdsBytes},     {8, 8, 64, kMaxLdsBytes}};
-  for (const auto& c : pref) {
-    snprintf(name, sizeof(name), "sparse_k%d_u%d_t%d", std::min(c.K, std::max(kcap, c.T == 64 ? 8 : kSparseMinTop)), c.U, c.T);
-    const int vid = find_variant(name);
-    if (fits(vid, c.budget)) return vid;
+  // Geometries that keep >= 8 waves on a CU (then fewer, for very wide tuples), each with the largest K whose top
+  // images fit next to the feature tile; the largest K wins, ties go to the earlier geometry.
+  static const struct { int T; uint32_t blocks; } geo[] = {{256, 2}, {512, 1}, {128, 4}, {256, 1}, {128, 2}, {128, 1}, {64, 2}, {64, 1}};
+  int best = -1, best_k = -1;
+  uint32_t best_waves = 0;
+  for (const auto& g : geo) {
+    const uint32_t waves = (uint32_t)g.T / 64u * g.blocks;
+    if (best >= 0 && waves < best_waves) break;  // only fall to fewer waves when nothing fitted with more
+    for (int K = kcap; K >= kSparseMinTop; --K) {
+      snprintf(name, sizeof(name), "sparse_k%d_u8_t%d", K, g.T);
+      const int vid = find_variant(name);
+      if (!fits(vid, kMaxLdsBytes / g.blocks)) continue;
+      if (K > best_k) {
+        best = vid;
+        best_k = K;
+        best_waves = waves;
+      }
+      break;
+    }
   }
-  return -1;
+  return best;
 }
 
 }  // namespace
