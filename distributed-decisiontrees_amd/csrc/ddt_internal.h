@@ -77,10 +77,12 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
 //               padded with dummy nodes): [0, 4*2^K) 8-byte records {thr_key, w} of levels 0..K-2 (1-based heap, record 0
 //               padding), [4*2^K, 12*2^K) 2^(K-1) 16-byte records {thr_key, w, left, right} of level K-1
 //   deep array  one 16-byte record {thr_key, w, left, right} per internal node at depth >= K, whole engine
-//   w           = absolute LDS byte address of the feature row | kFlagMissRight | kSpLeftLeaf | kSpRightLeaf
-//   left/right  = index into the deep array, or the leaf's fp32 bits when the matching flag is set
+//   w           = absolute LDS byte address of the feature row | kSpLeftLeaf | kSpRightLeaf | kSpMissRight: the two
+//                 leaf flags sit in bits 31 / 30 so that each is ONE sign test (of w, of w << 1)
+//   left/right  = index into the deep array (< 2^28: the kernel addresses it with a 32-bit byte offset), or the leaf's
+//                 fp32 bits when the matching flag is set
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kSpLeftLeaf = 0x40000000u, kSpRightLeaf = 0x20000000u, kSpAddrMask = 0x1FFFFFFFu;
+constexpr uint32_t kSpLeftLeaf = 0x80000000u, kSpRightLeaf = 0x40000000u, kSpMissRight = 0x20000000u, kSpAddrMask = 0x1FFFFFFFu;
 constexpr int kSparseMinTop = 6, kSparseMaxTop = 10;
 
 struct SparseAux {           // ScoreArgs::aux of the sparse kernels

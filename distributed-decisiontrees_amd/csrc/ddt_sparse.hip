@@ -23,12 +23,95 @@
 
 namespace ddt {
 
-// one visit on a 16-byte record: returns the child word; `leaf` = that child is a leaf value
-__device__ __forceinline__ uint32_t visit16(const uint4 r, const uint32_t lane_off, const uint32_t miss_key, bool& leaf) {
-  const uint32_t f = lds_u32((r.y & kSpAddrMask) | lane_off);
-  const bool right = go_right<true>(f, r.x, r.y, miss_key);
-  leaf = (r.y & (right ? kSpRightLeaf : kSpLeftLeaf)) != 0u;
-  return right ? r.w : r.z;
+// Compare rule on a sparse record (thr, w): DTPU.sv:653-667, the missing direction in kSpMissRight.  Written with
+// logical operators on purpose: hipcc keeps such lane predicates as SGPR masks (s_and / s_or), whereas a ternary
+// between two predicates is lowered to 0/1 VGPRs and four extra VALU instructions per visit.
+template <bool SLOW>
+__device__ __forceinline__ bool sp_right(uint32_t f, uint32_t thr, uint32_t w, uint32_t miss_key) {
+  const bool ge = (int32_t)f >= (int32_t)thr;
+  if (!SLOW) return ge;
+  const bool miss = f == miss_key, mr = (int32_t)(w << 2) < 0;  // kSpMissRight = bit 29
+  return (miss && mr) || (!miss && ge);
+}
+
+// The walk of all PU groups for one tile.  SLOW = the tile holds a missing value: apply the per-node missing rule
+// (block-uniform choice, like the perfect-tree kernels).
+template <int K, int U, int THREADS, bool SLOW>
+__device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
+  constexpr int TOPB = 12 << K;
+  constexpr int STEPB = (U / 8) * 8 * TOPB;
+  const uint32_t lane_off = (uint32_t)tid * 4u, miss_key = a.miss_key, C = a.clusters;
+  const uint4* __restrict__ deep = x.deep;
+  const uint32_t n_steps = x.n_groups / (uint32_t)(U / 8);  // the host pads the image to whole passes
+  for (uint32_t g = 0; g < n_steps; ++g) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the top images of this pass (and, first pass, the feature tile) are in LDS for everyone
+
+    // ---- top phase: levels 0..K-2 over 8-byte heap records, level K-1 over 16-byte records ----
+    uint32_t m8[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) m8[u] = 8u;
+#pragma unroll
+    for (int lvl = 0; lvl < K - 1; ++lvl) {
+      uint2 nd[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) nd[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
+      uint32_t f[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) f[u] = lds_u32((nd[u].y & kSpAddrMask) | lane_off);
+#pragma unroll
+      for (int u = 0; u < U; ++u) m8[u] = (m8[u] << 1) + (sp_right<SLOW>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
+    }
+    uint4 r[U];  // m8 = 8 * heap index in [2^(K-1), 2^K): record at 4*2^K + 16*(m - 2^(K-1)) = 2*m8 - 4*2^K
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = lds_u4((m8[u] << 1) - (uint32_t)(4 << K) + (uint32_t)(u * TOPB));
+    __syncthreads();  // every wave holds its level K-1 records: the top image buffer is free
+    if (g + 1 < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
+
+    // ---- deep phase: one 16-byte gather per visit; lanes whose tree has reached its leaf are masked off (the
+    //      vector-memory pipe takes one lane address per cycle: an idle lane must not cost one) ----
+    bool act[U];  // per lane: tree still walking (kept as lane masks in SGPRs, not as bits of a VGPR)
+    float leafv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      act[u] = true;
+      leafv[u] = 0.f;
+    }
+    for (;;) {
+      // phase A: one visit per tree on the records in registers (no memory access besides the LDS feature gather)
+      uint32_t nxt[U];
+      bool any = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t f = lds_u32((r[u].y & kSpAddrMask) | lane_off);
+        const bool right = sp_right<SLOW>(f, r[u].x, r[u].y, miss_key);
+        const uint32_t lw = right ? (r[u].y << 1) : r[u].y;  // kSpRightLeaf (bit 30) or kSpLeftLeaf (bit 31) into the sign bit
+        const bool leaf = (int32_t)lw < 0;
+        nxt[u] = right ? r[u].w : r[u].z;
+        if (act[u] && leaf) leafv[u] = __uint_as_float(nxt[u]);
+        act[u] = act[u] && !leaf;
+        any = any || act[u];
+      }
+      if (__ballot(any) == 0ull) break;
+      // phase B: all gathers of this round back to back, each under its own lane mask; nothing waits in between.
+      // 32-bit byte offset from a uniform base (the host keeps the deep array below 2^28 records)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (act[u]) r[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(deep) + (nxt[u] << 4));
+    }
+
+#pragma unroll
+    for (int h = 0; h < U / 8; ++h) {
+      if (a.sum_mode == 1) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dacc += (double)leafv[8 * h + u];
+      } else {
+        const float s[1] = {((leafv[8 * h + 0] + leafv[8 * h + 1]) + (leafv[8 * h + 2] + leafv[8 * h + 3])) +
+                            ((leafv[8 * h + 4] + leafv[8 * h + 5]) + (leafv[8 * h + 6] + leafv[8 * h + 7]))};
+        ra.push_group(s, C);
+      }
+    }
+  }
 }
 
 template <int K, int U, int THREADS>
@@ -47,11 +130,11 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   dma_chunk<THREADS, STEPB>(a.img, 0, 0, tid);  // top images of the first pass
 
   // ---- stage the tuple tile feature-major (quad-coalesced loads + in-quad DPP transpose, see score_tile_kernel) ----
+  uint32_t miss_any = 0;
   {
     const uint32_t col = (uint32_t)tid, t4 = col & 3u;
     const bool valid = tile0 + col < a.n;
     const uint64_t quad_row = tile0 + (uint64_t)(col & ~3u);
-    uint32_t miss_any = 0;  // unused: this kernel always applies the per-node missing rule
     for (uint32_t g0 = 0; g0 < lpt; g0 += 8) {
       u32x4 v[2][4];
 #pragma unroll
@@ -81,75 +164,14 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
     }
   }
 
+  // the barrier inside publishes the staged tile; tiles without a missing value skip the missing rule altogether
+  const bool slow = block_any<THREADS>(miss_any, (uint32_t)FEAT_OFF + W * (uint32_t)ROW, tid);
   RefAcc<1> ra;
   ra.init();
   double dacc = 0.0;
-  const uint32_t lane_off = (uint32_t)tid * 4u, miss_key = a.miss_key, C = a.clusters;
-  const uint4* __restrict__ deep = x.deep;
-  const uint32_t n_steps = x.n_groups / (uint32_t)(U / 8);  // the host pads the image to whole passes
-
-  for (uint32_t g = 0; g < n_steps; ++g) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // the top images of this pass (and, first pass, the feature tile) are in LDS for everyone
-
-    // ---- top phase: levels 0..K-2 over 8-byte heap records, level K-1 over 16-byte records ----
-    uint32_t m8[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) m8[u] = 8u;
-#pragma unroll
-    for (int lvl = 0; lvl < K - 1; ++lvl) {
-      uint2 nd[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) nd[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
-      uint32_t f[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) f[u] = lds_u32((nd[u].y & kSpAddrMask) | lane_off);
-#pragma unroll
-      for (int u = 0; u < U; ++u) m8[u] = (m8[u] << 1) + (go_right<true>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
-    }
-    uint4 r[U];  // m8 = 8 * heap index in [2^(K-1), 2^K): record at 4*2^K + 16*(m - 2^(K-1)) = 2*m8 - 4*2^K
-#pragma unroll
-    for (int u = 0; u < U; ++u) r[u] = lds_u4((m8[u] << 1) - (uint32_t)(4 << K) + (uint32_t)(u * TOPB));
-    __syncthreads();  // every wave holds its level K-1 records: the top image buffer is free
-    if (g + 1 < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
-
-    // ---- deep phase: one 16-byte gather per visit; lanes whose tree has reached its leaf are masked off (the
-    //      vector-memory pipe takes one lane address per cycle: an idle lane must not cost one) ----
-    uint32_t act = (1u << U) - 1u;  // per lane: trees still walking
-    float leafv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) leafv[u] = 0.f;
-    for (;;) {
-      // phase A: one visit per tree on the records in registers (no memory access besides the LDS feature gather)
-      uint32_t nxt[U], go = 0u;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        bool leaf;
-        nxt[u] = visit16(r[u], lane_off, miss_key, leaf);
-        const bool on = ((act >> u) & 1u) != 0u;
-        if (on && leaf) leafv[u] = __uint_as_float(nxt[u]);
-        if (on && leaf) act &= ~(1u << u);
-        if (on && !leaf) go |= 1u << u;
-      }
-      if (__ballot(act != 0u) == 0ull) break;
-      // phase B: all gathers of this round back to back, each under its own lane mask; nothing waits in between
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if ((go >> u) & 1u) r[u] = deep[nxt[u]];
-    }
-
-#pragma unroll
-    for (int h = 0; h < U / 8; ++h) {
-      if (a.sum_mode == 1) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) dacc += (double)leafv[8 * h + u];
-      } else {
-        const float s[1] = {((leafv[8 * h + 0] + leafv[8 * h + 1]) + (leafv[8 * h + 2] + leafv[8 * h + 3])) +
-                            ((leafv[8 * h + 4] + leafv[8 * h + 5]) + (leafv[8 * h + 6] + leafv[8 * h + 7]))};
-        ra.push_group(s, C);
-      }
-    }
-  }
+  const uint32_t C = a.clusters;
+  if (!slow) sparse_walk<K, U, THREADS, false>(a, x, tid, ra, dacc);
+  else sparse_walk<K, U, THREADS, true>(a, x, tid, ra, dacc);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C);

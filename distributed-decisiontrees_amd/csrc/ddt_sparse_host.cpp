@@ -121,7 +121,7 @@ int sparse_rebuild(ddt_engine* e) {
     }
     const uint32_t* L = sp.lines.data() + sp.first[i] * 4u;
     auto child = [&](uint32_t n, uint32_t side) { return Cursor{((L[4u * n + 1u] >> (14u + side)) & 1u) != 0u, L[4u * n + 2u + side]}; };
-    auto node_w = [&](uint32_t n) { return feat_word(L[4u * n + 1u] & 0x7FFu) | (((L[4u * n + 1u] >> 13) & 1u) ? kFlagMissRight : 0u); };
+    auto node_w = [&](uint32_t n) { return feat_word(L[4u * n + 1u] & 0x7FFu) | (((L[4u * n + 1u] >> 13) & 1u) ? kSpMissRight : 0u); };
     // ---- top heap, level by level ----
     cur.assign(1, Cursor{false, 0u});
     for (uint32_t lvl = 0; lvl + 1u < K; ++lvl) {
@@ -189,7 +189,7 @@ int sparse_rebuild(ddt_engine* e) {
       }
     }
     const size_t base = deep.size() / 4u;
-    if (base + order.size() > 0xFFFFFFFFull) return fail(e, DDT_EUNSUPPORTED, "more than 2^32 deep records");
+    if (base + order.size() >= (1ull << 28)) return fail(e, DDT_EUNSUPPORTED, "more than 2^28 deep records (4 GiB of 16-byte records)");
     // node -> deep index: the tree's node indices are dense, use a scratch map sized by the tree
     const uint64_t cnt = sp.first[i + 1] - sp.first[i];
     std::vector<uint32_t> where(cnt, 0u);
