@@ -1047,6 +1047,16 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     e->leaf_domain_check = value != 0;
     return DDT_OK;
   }
+  if (!strcmp(key, "reserve_rows")) {
+    // pre-size the rank-quantised path's workspace (ranks, per-tile flags, transposed tuples) for calls of up to `value`
+    // rows, so that the asynchronous ddt_*_device calls never have to synchronise and allocate on first use / growth
+    if (value < 0) return fail(e, DDT_EINVAL, "reserve_rows must be >= 0");
+    if (!e->loaded) return fail(e, DDT_ESTATE, "reserve_rows: load a model first (the workspace depends on its tuple width)");
+    if (e->sparse || variant(e->variant_id).kind != kKindQ16 || value == 0) return DDT_OK;  // nothing to reserve on the other paths
+    DeviceGuard dg(e->device);
+    if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
+    return ensure_q16_workspace(e, (size_t)value);
+  }
   if (!strcmp(key, "kernel_timing")) {
     e->kernel_timing = value != 0;
     return DDT_OK;

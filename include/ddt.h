@@ -221,9 +221,13 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out);
 int ddt_get_stats(const ddt_engine* e, ddt_stats* out);
 const char* ddt_strerror(int code);
 const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure on this engine */
-/* Tuning knobs: "variant" (kernel variant id, -1 = auto), "feeder_rows" (rows per feeder chunk), "feeder_threads"
- * (host threads of the staging copy, default 8), "kernel_timing"
- * (see ddt_stats), "q16_fused_prepass" (1 = default; 0 = always use the two-kernel rank pre-pass). */
+/* Tuning knobs: "variant" (kernel variant id, -1 = auto; a loaded model is re-packed), "feeder_rows" (rows per feeder
+ * chunk), "feeder_threads" (host threads of the staging copy, default 8), "kernel_timing" (see ddt_stats),
+ * "q16_fused_prepass" (1 = default; 0 = always use the two-kernel rank pre-pass), "reserve_rows" (pre-size the
+ * workspace of the rank-quantised path for calls of up to that many rows: the *_device calls then never allocate),
+ * "leaf_domain_check" (1 = default: refuse -0 / sub-normal / Inf / NaN leaves in the reference-order sum, where the
+ * GPU's IEEE adds and the reference's adder differ), "sparse_top_levels" (-1 = auto, or 6..10 levels of a sparse
+ * forest staged in LDS), "sparse_deep_order" (0 = level order, default; 1 = depth-first per sub-tree). */
 int ddt_set_option(ddt_engine* e, const char* key, int64_t value);
 int ddt_num_variants(void);
 int ddt_variant_name(int variant, char* buf, size_t buflen);

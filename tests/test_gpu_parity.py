@@ -388,3 +388,66 @@ def test_persistent_tile_kernels_walk_many_tiles(eng, T, D, F, dist):
         bad = np.flatnonzero(_bits(got) != _bits(want))
         assert bad.size == 0, f"{names[v]}: {bad.size} rows differ, first {bad[:5]}"
     eng.set_option("variant", -1)
+
+
+def test_leaves_outside_the_exact_domain_are_refused_unless_asked(eng):
+    """The GPU adds are IEEE-754; the reference's FloPoCo adder treats sub-normal / Inf / NaN inputs as normals and keeps
+    -0 (FPAdder_2cycles_latency.v:313-320,376-385).  Such leaves are refused in the reference-order sum (the caller flushes
+    them, as ddt.importer does), accepted on request and in the fp64-accumulate mode -- where the result is then the
+    IEEE one, shown here against the oracle's IEEE-adds mode."""
+    import torch
+
+    T, D, F = 16, 4, 8
+    m = O.gen_model(T, D, F, 0)
+    nint = (1 << D) - 1
+    for bad in (0x80000000, 0x00000001, 0x807FFFFF, 0x7F800000, 0x7FC00000):  # -0, sub-normals, +Inf, NaN
+        w = m.wlines.copy()
+        w[3 * O.wlpt(D) * 4 + nint + 5] = bad  # one leaf of tree 3
+        with pytest.raises(ddt.DDTError) as ex:
+            eng.load_model(ddt.make_params(T, D, F), w, m.flines)
+        assert ex.value.code == -5 and "leaf" in str(ex.value)
+        eng.load_model(ddt.make_params(T, D, F, sum_mode=1), w, m.flines)  # fp64 accumulate: no bit-exactness claim
+    # on request: IEEE semantics, equal to the oracle's reference-order sum with host IEEE adds
+    w = m.wlines.copy()
+    w[3 * O.wlpt(D) * 4 + nint + 5] = 0x80000000
+    w[5 * O.wlpt(D) * 4 + nint + 2] = 0x00000123
+    eng.set_option("leaf_domain_check", 0)
+    try:
+        eng.load_model(ddt.make_params(T, D, F), w, m.flines)
+        x = O.gen_tuples(0, 2000, F, 0)
+        got = eng.score_device(torch.from_numpy(x.view(np.int32)).cuda()).cpu().numpy()
+        want = O.score(O.Model(m.params, w, m.flines), x, sum_mode=O.SUM_REF_NATIVE)
+        assert np.array_equal(_bits(got), _bits(want))
+    finally:
+        eng.set_option("leaf_domain_check", 1)
+
+
+def test_empty_tree_shards_score_zero_on_every_rank(eng):
+    """ceil(T/G) trees per device leaves trailing devices without trees (T = 9, G = 4 -> 3, 3, 3, 0): such an engine holds
+    only EMPTY slots (DTPU.sv:544,760) and returns +0 instead of failing on one rank while the others wait in a collective."""
+    import torch
+
+    T, D, F, G = 9, 6, 12, 4
+    m = O.gen_model(T, D, F, 1)
+    x = O.gen_tuples(0, 1500, F, 1)
+    parts = np.stack([_gpu_score(eng, m, x, shard=(g, G)) for g in range(G)])
+    assert not parts[3].any() and eng.info().local_trees == 0
+    got = eng.chain_sum_device(torch.from_numpy(parts).cuda()).cpu().numpy()
+    assert np.array_equal(_bits(got), _bits(O.score(m, x, n_devices=G)))
+    with pytest.raises(ddt.DDTError):
+        eng.load_model(_params(m), m.wlines, m.flines, 0, T + 1)  # more shards than trees: refused on every rank alike
+
+
+def test_engine_bookkeeping_num_classes_and_reserve_rows(eng):
+    import torch
+
+    m = O.gen_model(300, 8, 32, 0)
+    eng.load_model_multiclass(ddt.make_params(300, 8, 32, clusters=1), m.wlines, m.flines, 3, True)
+    assert eng.num_classes == 3
+    eng.load_model(_params(m), m.wlines, m.flines)
+    assert eng.num_classes == 1  # a plain load after a multi-class one resets it
+    assert eng.info().variant_name.decode().startswith("q16")
+    eng.set_option("reserve_rows", 50_000)  # the rank-quantised path's workspace exists before the first asynchronous call
+    x = O.gen_tuples(0, 40_000, 32, 0)
+    got = eng.score_device(torch.from_numpy(x.view(np.int32)).cuda()).cpu().numpy()
+    assert np.array_equal(_bits(got), _bits(O.score_fast(m, x)))

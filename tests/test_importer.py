@@ -163,3 +163,42 @@ def test_imported_models_on_gpu():
     assert np.allclose(raw, gbc.decision_function(Xt), rtol=1e-4, atol=1e-4)
     assert np.mean(np.argmax(raw, axis=1) == gbc.predict(Xt)) > 0.995
     e.close()
+
+
+def _xgb_json(objective, base_score, K=0):
+    """A hand-written XGBoost model dump: one stump per class, `x0 < 0.5 ? -1 : +1`."""
+    tree = {"left_children": [1, -1, -1], "right_children": [2, -1, -1], "split_conditions": [0.5, -1.0, 1.0],
+            "split_indices": [0, 0, 0], "default_left": [1, 0, 0]}
+    n = max(1, K)
+    return {"learner": {"objective": {"name": objective},
+                        "learner_model_param": {"num_feature": "3", "num_class": str(K), "base_score": base_score},
+                        "gradient_booster": {"name": "gbtree", "model": {"trees": [tree] * n, "tree_info": list(range(n))}}}}
+
+
+def test_xgboost_base_score_goes_through_the_objectives_link():
+    """learner_model_param.base_score lives in OUTPUT space: logit for the logistic objectives, log for poisson /
+    gamma / tweedie, identity otherwise; XGBoost >= 2 writes it as a bracketed string."""
+    im = ddt.importer.from_xgboost_json(_xgb_json("binary:logistic", "[3E-1]"))
+    assert np.allclose(im.base_score, [np.log(0.3 / 0.7)])
+    im = ddt.importer.from_xgboost_json(_xgb_json("binary:logistic", "0.5"))
+    assert np.allclose(im.base_score, [0.0])
+    im = ddt.importer.from_xgboost_json(_xgb_json("count:poisson", "2.5E0"))
+    assert np.allclose(im.base_score, [np.log(2.5)])
+    im = ddt.importer.from_xgboost_json(_xgb_json("reg:squarederror", "[1.25E0]"))
+    assert np.allclose(im.base_score, [1.25])
+    im = ddt.importer.from_xgboost_json(_xgb_json("multi:softprob", "[1E-1,2E-1,3E-1]", K=3))
+    assert np.allclose(im.base_score, [0.1, 0.2, 0.3]) and im.num_classes == 3
+    im = ddt.importer.from_xgboost_json(_xgb_json("multi:softprob", "5E-1", K=3))
+    assert np.allclose(im.base_score, [0.5] * 3)
+    with pytest.raises(TypeError):
+        ddt.importer.from_xgboost_json(_xgb_json("rank:some_new_objective", "0.5"))
+    with pytest.raises(ValueError):
+        ddt.importer.from_xgboost_json(_xgb_json("binary:logistic", "1.5"))
+    # margin = tree sum + base: the oracle on the imported streams
+    im = ddt.importer.from_xgboost_json(_xgb_json("binary:logistic", "[3E-1]"))
+    m = O.Model(O.make_params(1, im.num_levels, 3, cmp_mode=1), im.wlines, im.flines)
+    x = O.tuples_from_float(np.array([[0.2, 0, 0], [0.7, 0, 0]], np.float32))
+    assert np.allclose(O.score(m, x) + im.base_score[0], [-1 + np.log(0.3 / 0.7), 1 + np.log(0.3 / 0.7)])
+    sp = ddt.importer.from_xgboost_json(_xgb_json("binary:logistic", "[3E-1]"), sparse=True)
+    s = O.SparseModel(O.make_sparse_params(1, sp.num_levels, 3, cmp_mode=1), sp.node_lines, sp.tree_first_line)
+    assert np.array_equal(O.score_sparse(s, x), O.score(m, x))
