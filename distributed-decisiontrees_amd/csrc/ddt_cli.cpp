@@ -12,6 +12,11 @@
 //                 [--device 0] [--shard i --of n] [--cmp-mode 0|1] [--sum-mode 0|1] [--variant v]
 //                 [--devices G [--combine allreduce|chain]]   the whole multi-GPU job in this process: tree shard g on
 //                                                             device g, partial scores combined over RCCL (ddt_group_*)
+//   ddt_cli gen-sparse   --trees T --max-depth D --features F --rows N [--full-levels L] [--permille P] [--dist 0|1] --prefix DIR/name
+//        a random-forest-like SPARSE model (include/ddt.h ddt_load_model_sparse): name.nodes (one 128-bit line per
+//        internal node), name.first (u64 line index of every tree's root, T + 1 entries), name.tuples
+//   ddt_cli score-sparse --nodes f.nodes --first f.first --tuples f.tuples --features F --max-depth D --out f.results
+//                        [--device 0] [--shard i --of n] [--cmp-mode 0|1] [--sum-mode 0|1] [--clusters C] [--missing 0x7FC00000]
 //   ddt_cli info
 //
 // All scoring goes through the C-ABI of include/ddt.h; there is no CPU fallback.
@@ -208,6 +213,69 @@ int cmd_score(const std::map<std::string, std::string>& o) {
   return 0;
 }
 
+int cmd_gen_sparse(const std::map<std::string, std::string>& o) {
+  const uint32_t T = (uint32_t)num(o, "trees", 0, true), D = (uint32_t)num(o, "max-depth", 0, true);
+  const uint32_t F = (uint32_t)num(o, "features", 0, true);
+  const uint32_t full = (uint32_t)num(o, "full-levels", D < 10 ? D / 2 : 10), pm = (uint32_t)num(o, "permille", 700);
+  const uint64_t N = num(o, "rows", 0, true);
+  const int dist = (int)num(o, "dist", 0);
+  const std::string prefix = str(o, "prefix");
+  std::vector<uint64_t> first((size_t)T + 1);
+  const int64_t n_lines = ddt_synth_sparse_model(T, D, F, full, pm, dist, nullptr, 0, first.data());
+  if (n_lines < 0) return die((int)n_lines, nullptr, "synth sparse model");
+  std::vector<uint32_t> nodes((size_t)n_lines * 4);
+  ddt_synth_sparse_model(T, D, F, full, pm, dist, nodes.data(), (size_t)n_lines, first.data());
+  const size_t W = (F + 3) / 4 * 4;
+  std::vector<uint32_t> x((size_t)N * W);
+  int rc = ddt_synth_tuples_host(x.data(), 0, N, F, dist, 0x7FC00000u);
+  if (rc) return die(rc, nullptr, "synth tuples");
+  if (!write_file(prefix + ".nodes", nodes.data(), nodes.size() * 4) || !write_file(prefix + ".first", first.data(), first.size() * 8) ||
+      !write_file(prefix + ".tuples", x.data(), x.size() * 4))
+    return die(DDT_EINVAL, nullptr, "write stream files");
+  printf("wrote %s.{nodes,first,tuples}: %u sparse trees (depth <= %u, %" PRId64 " internal nodes) x %u features, %" PRIu64 " tuples\n",
+         prefix.c_str(), T, D, n_lines, F, N);
+  return 0;
+}
+
+int cmd_score_sparse(const std::map<std::string, std::string>& o) {
+  std::vector<unsigned char> nodes, first, x;
+  if (!read_file(str(o, "nodes"), &nodes) || !read_file(str(o, "first"), &first) || !read_file(str(o, "tuples"), &x))
+    return die(DDT_EINVAL, nullptr, "read stream files");
+  if (first.size() < 16 || first.size() % 8 || nodes.size() % 16) return die(DDT_EINVAL, nullptr, "malformed .first / .nodes file");
+  ddt_params p;
+  memset(&p, 0, sizeof(p));
+  p.num_trees = (uint32_t)(first.size() / 8 - 1);
+  p.num_levels = (uint32_t)num(o, "max-depth", 0, true);
+  p.num_features = (uint32_t)num(o, "features", 0, true);
+  p.missing_bits = (uint32_t)num(o, "missing", 0x7FC00000u);
+  p.cmp_mode = (uint32_t)num(o, "cmp-mode", 0);
+  p.sum_mode = (uint32_t)num(o, "sum-mode", 0);
+  const uint32_t of = (uint32_t)num(o, "of", 1), shard = (uint32_t)num(o, "shard", 0);
+  const uint32_t per_dev = (p.num_trees + of - 1) / of;
+  p.clusters_per_tuple = (uint32_t)num(o, "clusters", per_dev <= 128 ? 1 : per_dev <= 256 ? 2 : per_dev <= 512 ? 4 : 8);
+  const size_t tuple_bytes = (size_t)(p.num_features + 3) / 4 * 16;
+  if (x.size() % tuple_bytes) return die(DDT_EINVAL, nullptr, "tuple stream is not a whole number of tuples");
+  const uint64_t n = x.size() / tuple_bytes;
+  ddt_engine* e = nullptr;
+  int rc = ddt_create(&e, (int)num(o, "device", 0));
+  if (rc) return die(rc, nullptr, "ddt_create");
+  rc = ddt_load_model_sparse(e, &p, nodes.data(), nodes.size() / 16, reinterpret_cast<const uint64_t*>(first.data()), shard, of);
+  if (rc) return die(rc, e, "load sparse model");
+  std::vector<float> scores((size_t)((n + 3) / 4 * 4), 0.0f);  // whole result lines, zero padded
+  rc = ddt_score(e, x.data(), n, scores.data());
+  if (rc) return die(rc, e, "score");
+  if (!write_file(str(o, "out"), scores.data(), scores.size() * 4)) return die(DDT_EINVAL, e, "write results");
+  ddt_info info;
+  ddt_stats st;
+  ddt_get_info(e, &info);
+  ddt_get_stats(e, &st);
+  printf("scored %" PRIu64 " tuples with sparse trees [%u, %u) of %u on %s, kernel %s, %.3f ms (%.2f Mtuples/s incl. PCIe)\n", n,
+         info.tree_begin, info.tree_end, p.num_trees, info.device_name, info.variant_name, st.exec_ms,
+         st.exec_ms > 0 ? (double)n / st.exec_ms / 1e3 : 0.0);
+  ddt_destroy(e);
+  return 0;
+}
+
 int cmd_info() {
   ddt_engine* e = nullptr;
   const int rc = ddt_create(&e, 0);
@@ -232,13 +300,15 @@ int cmd_info() {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    fprintf(stderr, "usage: ddt_cli gen|score|info [--option value ...]   (see the header of ddt_cli.cpp)\n");
+    fprintf(stderr, "usage: ddt_cli gen|score|gen-sparse|score-sparse|info [--option value ...]   (see the header of ddt_cli.cpp)\n");
     return 2;
   }
   const std::string cmd = argv[1];
   const auto o = parse(argc, argv, 2);
   if (cmd == "gen") return cmd_gen(o);
   if (cmd == "score") return cmd_score(o);
+  if (cmd == "gen-sparse") return cmd_gen_sparse(o);
+  if (cmd == "score-sparse") return cmd_score_sparse(o);
   if (cmd == "info") return cmd_info();
   fprintf(stderr, "unknown command %s\n", cmd.c_str());
   return 2;

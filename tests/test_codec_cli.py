@@ -157,3 +157,21 @@ def test_cli_score_matches_oracle(tmp_path, T, D, F, n, dist):
     m = O.gen_model(T, D, F, dist=dist)
     want = O.score(m, O.gen_tuples(0, n, F, dist=dist))
     assert np.array_equal(res[:n].view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cli_scores_a_sparse_forest(tmp_path):
+    """gen-sparse / score-sparse: the explicit-children stream as files, scored by the C++ host alone."""
+    pre = str(tmp_path / "rf")
+    T, D, F, n = 24, 13, 20, 2051
+    subprocess.check_call([ddt.CLI_PATH, "gen-sparse", "--trees", str(T), "--max-depth", str(D), "--features", str(F), "--rows", str(n),
+                           "--full-levels", "4", "--permille", "650", "--dist", "1", "--prefix", pre])
+    s = O.gen_sparse_model(T, D, F, 4, 650, 1)
+    assert np.array_equal(np.fromfile(pre + ".nodes", np.uint32).reshape(-1, 4), s.node_lines)
+    assert np.array_equal(np.fromfile(pre + ".first", np.uint64), s.first)
+    out = subprocess.check_output([ddt.CLI_PATH, "score-sparse", "--nodes", pre + ".nodes", "--first", pre + ".first", "--tuples", pre + ".tuples",
+                                   "--features", str(F), "--max-depth", str(D), "--out", pre + ".results"]).decode()
+    assert f"scored {n} tuples with sparse trees [0, {T})" in out and "sparse_k" in out
+    res = np.fromfile(pre + ".results", np.float32)
+    want = O.score_sparse(s, O.gen_tuples(0, n, F, dist=1))
+    assert res.size == (n + 3) // 4 * 4 and np.array_equal(res[:n].view(np.uint32), want.view(np.uint32))
