@@ -1,8 +1,9 @@
 /*
  * ddt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code; see ddt_oracle.h).
  *
- * PARITY: adder, compare rule, group tree, accumulator datapath, chain hop and the traversal datapath are
- * pinned against vectors evaluated from the reference's own RTL source (tests/golden/make_rtl_golden.py);
+ * PARITY: adder, compare rule, group tree, accumulator datapath, chain hop, the traversal datapath and the tree ->
+ * cluster / PU schedule are pinned against vectors evaluated from the reference's own RTL source
+ * (tests/golden/make_rtl_golden.py, tests/golden/make_schedule_golden.py);
  * *** everything else is UNPINNED *** -- the reference (FPGA RTL) has no tests/golden vectors and its
  * sequential control cannot be run here (see ddt_oracle.h).
  * This file restates the RTL's scoring semantics; each function cites the lines it follows.

@@ -21,10 +21,17 @@
  *                              RTL forwards a non-zero garbage pattern -- a defect, NOT replicated: +0 here)
  *               orc_traverse   datapath of core/DTPU.sv: all assigns, the wiring of its delay pipelines, the
  *                              clocked update of the recirculating instruction; memories as flat arrays   960 walks
+ *               orc_reduce_device  the tree -> PU / cluster / slot schedule and the order clusters are accumulated in:
+ *                              Core.sv:167-245,291-372,503-541 and core/RLS.v:36-62 EXECUTED cycle by cycle by the
+ *                              procedural-Verilog interpreter of tests/golden/make_schedule_golden.py (one documented
+ *                              repair: the unreachable IDLE -> PROG_MODE edge), 16 (C, T) cases; tests/test_oracle_schedule.py
+ *                              rebuilds the summation from those placements and holds orc_reduce_device to it
  *
  *      *** PARITY UNPINNED for everything else *** -- how the model / tuple streams are written into the
- *      memories (programming side), the tree -> PU / cluster schedule, all valid / ready / FIFO control,
- *      the multi-device plumbing: sequential SystemVerilog that nothing here can execute.
+ *      PU memories (programming side of DTPU.sv), all valid / ready / FIFO control, the multi-device plumbing:
+ *      sequential SystemVerilog that nothing here can execute as a whole.  The SPARSE format (section further
+ *      down) is this repository's extension: it has no RTL to be pinned to and is anchored to the perfect-tree
+ *      oracle through pad_to_perfect instead.
  *
  * Mitigations for the unpinned part (tests/test_oracle_*.py): hand-computed known-answer tests for every
  * rule, an independent numpy restatement, and a cross-check of the traversal against scikit-learn.

@@ -1,13 +1,25 @@
 #!/bin/bash
-# round evidence: GPU tests, bench line, rocprofv3 kernel-trace stats and HBM-traffic PMC passes of the SAME bench command
-mkdir -p gpurun_out && cd "$GRAFT_REPO_ROOT"
+# Round evidence on the GPU box (through gpurun): GPU tests, the bench lines (config 3 = headline, config 4 = sparse
+# forest), rocprofv3 kernel-trace stats and HBM-traffic PMC passes of the SAME bench commands, smoke().
+# Usage: tools/gpu_evidence.sh <tag>    -> gpurun_out/<tag>/...
+set -u
+tag=${1:-ev}
+cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out
-rm -rf $OUT/ev_stats $OUT/ev_fetch $OUT/ev_write
-( timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "Extension modules" ) > $OUT/ev_tests.log; tail -2 $OUT/ev_tests.log
-( timeout 900 python bench.py ) > $OUT/ev_bench.log 2>&1; tail -1 $OUT/ev_bench.log | cut -c1-400
-B="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/ev_stats -o bench -- $B ) > $OUT/ev_stats.log 2>&1; echo "stats rc=$?"
-( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/ev_fetch -o pmc -- $B ) > $OUT/ev_fetch.log 2>&1; echo "fetch rc=$?"
-( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/ev_write -o pmc -- $B ) > $OUT/ev_write.log 2>&1; echo "write rc=$?"
-ls -la $OUT/ev_stats $OUT/ev_fetch $OUT/ev_write 2>/dev/null | head -20
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$tag
+rm -rf "$OUT"; mkdir -p "$OUT"
+( timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -v "Extension modules" ) > $OUT/gpu_tests.log; grep -n "passed\|failed" $OUT/gpu_tests.log | tail -2
+( timeout 300 python __graft_entry__.py smoke ) > $OUT/smoke.log 2>&1; grep "smoke ok" $OUT/smoke.log
+( timeout 900 python bench.py ) > $OUT/bench_cfg3.log 2> $OUT/bench_cfg3.err; tail -1 $OUT/bench_cfg3.log | cut -c1-300
+( timeout 900 python bench.py --config 4 ) > $OUT/bench_cfg4.log 2> $OUT/bench_cfg4.err; tail -1 $OUT/bench_cfg4.log | cut -c1-300
+for cfg in 3 4; do
+  B="python $GRAFT_REPO_ROOT/bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-streamed"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats_cfg$cfg -o bench -- $B ) > $OUT/stats_cfg$cfg.log 2>&1; echo "cfg$cfg stats rc=$?"
+  ( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_cfg$cfg -o pmc -- $B ) > $OUT/fetch_cfg$cfg.log 2>&1; echo "cfg$cfg fetch rc=$?"
+  ( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/write_cfg$cfg -o pmc -- $B ) > $OUT/write_cfg$cfg.log 2>&1; echo "cfg$cfg write rc=$?"
+done
+( timeout 600 python bench.py --steps 3 --warmup 1 --force-collectives --no-cpu-baseline --no-streamed ) > $OUT/bench_force_allreduce.log 2>/dev/null
+( timeout 600 python bench.py --steps 3 --warmup 1 --force-collectives --combine chain --no-cpu-baseline --no-streamed ) > $OUT/bench_force_chain.log 2>/dev/null
+( timeout 600 python bench.py --steps 3 --warmup 1 --trees 125 --force-collectives --no-cpu-baseline --no-streamed ) > $OUT/bench_force_t125.log 2>/dev/null
+( timeout 600 python bench.py --steps 3 --warmup 1 --trees 125 --no-cpu-baseline --no-streamed ) > $OUT/bench_t125.log 2>/dev/null
+tail -qn1 $OUT/bench_force_*.log $OUT/bench_t125.log | cut -c1-160
