@@ -730,6 +730,107 @@ int orc_score_sparse(const orc_params* p, const void* nl, size_t n_lines, const 
   return 0;
 }
 
+/* The CPU-baseline form of orc_score_sparse (bench.py --config 4 cpu_baseline; single device, ORC_SUM_REF_NATIVE or
+ * ORC_SUM_F64_SEQ): identical results, organised for caches.  A deep forest is ~100 MB, so walking all trees for one
+ * row at a time misses the cache on nearly every visit; here a block of rows (their tuples stay in L2) is taken through
+ * ONE tree at a time (the tree, ~200 KB, stays in L2), eight rows in flight per thread, and the eight leaves of a PU
+ * group are folded into the per-row cluster accumulators as soon as the group is complete.
+ * tests/test_sparse.py holds it to orc_score_sparse bit for bit. */
+int orc_score_sparse_fast(const orc_params* p, const void* nl, size_t n_lines, const uint64_t* first, const void* tl,
+                          size_t n_tuples, float* out, int sum_mode, int nthreads) {
+  if (sum_mode == ORC_SUM_REF_FLOPOCO) return orc_score_sparse(p, nl, n_lines, first, tl, n_tuples, out, NULL, sum_mode, 1, nthreads);
+  int rc = orc_sparse_check(p, (const uint32_t*)nl, n_lines, first);
+  if (rc) return rc;
+  const uint32_t C = p->clusters_per_tuple;
+  if (C != 1 && C != 2 && C != 4 && C != 8) return -1;
+  const uint32_t* lines = (const uint32_t*)nl;
+  const uint32_t* t = (const uint32_t*)tl;
+  const uint32_t T = p->num_trees, tw = orc_tuple_lines(p->num_features) * 4u, miss = p->missing_bits, mode = p->cmp_mode;
+  enum { RB = 1024 };
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    float* acc = (float*)malloc(sizeof(float) * (size_t)RB * 8u);
+    double* dacc = (double*)malloc(sizeof(double) * (size_t)RB);
+    float* grp = (float*)malloc(sizeof(float) * (size_t)RB * 8u); /* leaves of the current PU group, [row][tree in group] */
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (long long b0 = 0; b0 < (long long)n_tuples; b0 += RB) {
+      const uint32_t rows = (uint32_t)((long long)n_tuples - b0 < RB ? (long long)n_tuples - b0 : RB);
+      for (uint32_t i = 0; i < rows * 8u; ++i) acc[i] = 0.0f;
+      for (uint32_t r = 0; r < rows; ++r) dacc[r] = 0.0;
+      for (uint32_t t0 = 0; t0 < T; t0 += 8u) {
+        const uint32_t c = (t0 / 8u) % C;
+        for (uint32_t u = 0; u < 8u; ++u) {
+          if (t0 + u >= T) { /* EMPTY slot: +0 (DTPU.sv:544,760) */
+            for (uint32_t r = 0; r < rows; ++r) grp[(size_t)r * 8u + u] = 0.0f;
+            continue;
+          }
+          const uint32_t* tr = lines + first[t0 + u] * 4u;
+          uint32_t r = 0;
+          for (; r + 8u <= rows; r += 8u) { /* eight rows in flight through this tree */
+            uint32_t node[8], done = 0;
+            for (int k = 0; k < 8; ++k) node[k] = 0;
+            while (done != 0xFFu)
+              for (int k = 0; k < 8; ++k) {
+                if ((done >> k) & 1u) continue;
+                const uint32_t* q = tr + 4u * node[k];
+                const uint32_t* x = t + ((size_t)b0 + r + (uint32_t)k) * tw;
+                const uint32_t right = orc_go_right(x[q[1] & 0x7FFu], q[0], miss, (q[1] >> 13) & 1u, mode);
+                const uint32_t child = q[2u + right];
+                if ((q[1] >> (14u + right)) & 1u) {
+                  grp[((size_t)r + (uint32_t)k) * 8u + u] = f_from(child);
+                  done |= 1u << k;
+                } else {
+                  node[k] = child;
+                }
+              }
+          }
+          for (; r < rows; ++r) {
+            const uint32_t* x = t + ((size_t)b0 + r) * tw;
+            uint32_t node = 0;
+            for (;;) {
+              const uint32_t* q = tr + 4u * node;
+              const uint32_t right = orc_go_right(x[q[1] & 0x7FFu], q[0], miss, (q[1] >> 13) & 1u, mode);
+              if ((q[1] >> (14u + right)) & 1u) { grp[(size_t)r * 8u + u] = f_from(q[2u + right]); break; }
+              node = q[2u + right];
+            }
+          }
+        }
+        for (uint32_t r = 0; r < rows; ++r) {
+          const float* l = grp + (size_t)r * 8u;
+          if (sum_mode == ORC_SUM_F64_SEQ) {
+            for (uint32_t u = 0; u < 8u && t0 + u < T; ++u) dacc[r] += (double)l[u];
+          } else {
+            volatile float a0 = l[0] + l[1], a1 = l[2] + l[3], a2 = l[4] + l[5], a3 = l[6] + l[7];
+            volatile float h0 = a0 + a1, h1 = a2 + a3;
+            volatile float s = h0 + h1;
+            volatile float na = s + acc[(size_t)r * 8u + c];
+            acc[(size_t)r * 8u + c] = na;
+          }
+        }
+      }
+      for (uint32_t r = 0; r < rows; ++r) {
+        if (sum_mode == ORC_SUM_F64_SEQ) {
+          out[(size_t)b0 + r] = (float)dacc[r];
+        } else {
+          volatile float tot = 0.0f;
+          for (uint32_t k = 0; k < C; ++k) tot = acc[(size_t)r * 8u + k] + tot;
+          out[(size_t)b0 + r] = tot;
+        }
+      }
+    }
+    free(acc);
+    free(dacc);
+    free(grp);
+  }
+  (void)nthreads;
+  return 0;
+}
+
 void orc_sparse_from_perfect(const orc_params* p, const uint32_t* wl, const uint16_t* fl, uint32_t* lines, uint64_t* first) {
   const uint32_t D = p->num_levels, nint = (1u << D) - 1u;
   const size_t ws = (size_t)p->weights_lines_per_tree * 4u, fs = (size_t)p->findex_lines_per_tree * 8u;

@@ -148,6 +148,9 @@ double orc_sparse_mean_depth(const orc_params* p, const uint32_t* node_lines, co
 int orc_score_sparse(const orc_params* p, const void* node_lines, size_t n_lines, const uint64_t* tree_first_line,
                      const void* tuple_lines, size_t n_tuples, float* out, double* gold, int sum_mode, int n_devices,
                      int nthreads);
+/* cache-blocked form of orc_score_sparse for the CPU baseline (single device; see ddt_oracle.c) */
+int orc_score_sparse_fast(const orc_params* p, const void* node_lines, size_t n_lines, const uint64_t* tree_first_line,
+                          const void* tuple_lines, size_t n_tuples, float* out, int sum_mode, int nthreads);
 /* perfect stream -> sparse stream (one line per internal node, heap order); node_lines: T*(2^D-1) lines */
 void orc_sparse_from_perfect(const orc_params* p, const uint32_t* wlines, const uint16_t* flines, uint32_t* node_lines,
                              uint64_t* tree_first_line);

@@ -86,6 +86,8 @@ def lib():
         L.orc_sparse_mean_depth.restype, L.orc_sparse_mean_depth.argtypes = C.c_double, [PP, vp, vp, vp, sz]
         L.orc_score_sparse.restype = C.c_int
         L.orc_score_sparse.argtypes = [PP, vp, sz, vp, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int]
+        L.orc_score_sparse_fast.restype = C.c_int
+        L.orc_score_sparse_fast.argtypes = [PP, vp, sz, vp, vp, sz, vp, C.c_int, C.c_int]
         L.orc_sparse_from_perfect.restype, L.orc_sparse_from_perfect.argtypes = None, [PP, vp, vp, vp, vp]
         L.orc_sparse_to_perfect.restype, L.orc_sparse_to_perfect.argtypes = C.c_int, [PP, vp, vp, vp, vp]
         L.orc_gen_sparse_model.restype = sz
@@ -320,6 +322,17 @@ def score_sparse(s: SparseModel, tuples: np.ndarray, sum_mode: int = SUM_REF_FLO
     if rc:
         raise ValueError(f"orc_score_sparse rc={rc}")
     return (out, gold) if want_gold else out
+
+
+def score_sparse_fast(s: SparseModel, tuples: np.ndarray, sum_mode: int = SUM_REF_NATIVE, nthreads: int = 0) -> np.ndarray:
+    """The CPU-baseline form of score_sparse(): identical bits, one tree at a time over a block of rows."""
+    t = np.ascontiguousarray(tuples, np.uint32)
+    out = np.zeros(t.shape[0], np.float32)
+    rc = lib().orc_score_sparse_fast(C.byref(s.params), _p(s.node_lines), s.n_lines, _p(s.first), _p(t), t.shape[0], _p(out),
+                                     sum_mode, nthreads)
+    if rc:
+        raise ValueError(f"orc_score_sparse_fast rc={rc}")
+    return out
 
 
 def traverse_sparse(s: SparseModel, tuple_row: np.ndarray, tree: int) -> int:

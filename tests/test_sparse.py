@@ -58,6 +58,16 @@ def test_sparse_oracle_equals_padded_perfect_oracle(shape, cmp_mode):
     assert np.array_equal(_bits(a), _bits(b))
 
 
+@pytest.mark.parametrize("shape", SHAPES)
+def test_cpu_baseline_form_of_the_sparse_oracle_is_identical(shape):
+    """orc_score_sparse_fast (bench.py --config 4 cpu_baseline: one tree at a time over a block of rows) == orc_score_sparse."""
+    T, D, F, full, pm, dist, rows = shape
+    s = O.gen_sparse_model(T, D, F, full, pm, dist)
+    x = O.gen_tuples(7, rows + 1030, F, dist)  # more than one row block, ragged tail
+    for mode in (O.SUM_REF_NATIVE, O.SUM_F64_SEQ, O.SUM_REF_FLOPOCO):
+        assert np.array_equal(_bits(O.score_sparse(s, x, sum_mode=mode)), _bits(O.score_sparse_fast(s, x, sum_mode=mode))), (shape, mode)
+
+
 def test_perfect_to_sparse_roundtrip():
     m = O.gen_model(37, 6, 28, 1)
     s = O.sparse_from_perfect(m)
