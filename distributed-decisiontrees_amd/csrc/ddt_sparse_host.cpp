@@ -81,7 +81,7 @@ int sparse_rebuild(ddt_engine* e) {
                 "sparse_top_levels %d is not a sparse kernel that fits)", tuple_words(e->p), kMaxLdsBytes, e->forced_variant, e->sparse_top_levels);
   const Variant& v = variant(vid);
   const uint32_t K = (uint32_t)v.levels, T = sp.trees();
-  const uint32_t per_pass = (uint32_t)v.chunk_trees / 8u;  // PU groups walked in lock-step
+  const uint32_t per_pass = std::max(1u, (uint32_t)v.chunk_trees / 8u);  // PU groups walked in lock-step (half groups: 1)
   uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
   groups = (groups + per_pass - 1u) / per_pass * per_pass;  // whole passes: the padding groups are EMPTY slots too (+0)
   const uint32_t top_words = (12u << K) / 4u;       // per tree

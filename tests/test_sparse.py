@@ -180,6 +180,35 @@ def test_gpu_sparse_bit_exact_all_top_levels_and_orders(eng, shape):
 
 
 @pytest.mark.gpu
+def test_gpu_every_sparse_kernel_variant(eng):
+    """every compiled (K, trees in lock-step, tile) geometry of the sparse kernel, forced by id, against the oracle"""
+    import torch
+
+    for (T, D, F, full, pm, dist, rows) in [(20, 13, 24, 4, 650, 1, 1100), (12, 16, 64, 7, 700, 0, 700)]:
+        s = O.gen_sparse_model(T, D, F, full, pm, dist)
+        x = O.gen_tuples(0, rows, F, dist)
+        want = O.score_sparse(s, x)
+        d = torch.from_numpy(x.view(np.int32)).cuda()
+        ran = 0
+        for vid, name in enumerate(ddt.variant_names()):
+            if not name.startswith("sparse_"):
+                continue
+            try:
+                eng.set_option("variant", vid)
+                eng.load_model_sparse(ddt.make_sparse_params(T, D, F), s.node_lines, s.first)
+            except ddt.DDTError as ex:
+                assert ex.code == -5, name  # its top images do not fit the LDS next to this feature tile
+                continue
+            assert eng.info().variant_name.decode() == name
+            got = eng.score_device(d)
+            torch.cuda.synchronize()
+            assert np.array_equal(_bits(got.cpu().numpy()), _bits(want)), (name, T, D, F)
+            ran += 1
+        eng.set_option("variant", -1)
+        assert ran >= 10
+
+
+@pytest.mark.gpu
 def test_gpu_sparse_tree_shards_and_chain(eng):
     import torch
 
