@@ -1096,13 +1096,11 @@ static const Variant g_variants[] = {
     // deeper trees: 16 / 32 KiB chunks, one 1024-thread block per CU (the tile + two chunks no longer fit twice)
     DDT_Q("q16_d9_c4_u4", 9, 4, 4),
     DDT_Q("q16_d10_c4_u4", 10, 4, 4),
-    // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB.  suffix _f = last level fused with its leaves
+    // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB.  suffix _f = last level fused with its leaves.  Experiment variants
+    // that no choice uses any more were removed in round 2 (register-staged chunks, R = 2, the unfused forms, 8-chain
+    // stream kernels; their measurements stay in profiles/r01_sweep_*.json)
     DDT_VP("d8_t1024_r1_c4_u4_dma_fp", 8, 1024, 1, 4, 4, 1, 3),  // _p = persistent blocks + register prefetch
     DDT_V("d8_t1024_r1_c4_u4_dma_f", 8, 1024, 1, 4, 4, 1, 1),
-    DDT_V("d8_t1024_r1_c4_u4_dma", 8, 1024, 1, 4, 4, 1, 0),
-    DDT_V("d8_t1024_r1_c4_u4_reg", 8, 1024, 1, 4, 4, 0, 0),
-    DDT_V("d8_t512_r2_c4_u4_dma", 8, 512, 2, 4, 4, 1, 0),
-    DDT_V("d8_t512_r1_c8_u8_dma", 8, 512, 1, 8, 8, 1, 0),
     DDT_V("d8_t512_r1_c8_u8_dma_f", 8, 512, 1, 8, 8, 1, 1),
     DDT_V("d8_t512_r1_c4_u4_dma_f", 8, 512, 1, 4, 4, 1, 1),  // 33..64 words per tuple: 128 KiB tile + 2 x 12 KiB chunks
     DDT_V("d8_t256_r1_c4_u4_dma", 8, 256, 1, 4, 4, 1, 0),
@@ -1110,7 +1108,6 @@ static const Variant g_variants[] = {
     DDT_V("d8_t64_r1_c8_u8_dma", 8, 64, 1, 8, 8, 1, 0),       // up to ~440 words: one wave per CU, still 10x the generic kernel's global gathers
     // depth 6 (BASELINE config 2): tree = 768 B
     DDT_V("d6_t1024_r1_c16_u4_dma", 6, 1024, 1, 16, 4, 1, 0),
-    DDT_V("d6_t1024_r1_c16_u8_dma", 6, 1024, 1, 16, 8, 1, 0),
     DDT_V("d6_t512_r1_c16_u8_dma", 6, 512, 1, 16, 8, 1, 0),
     DDT_V("d6_t256_r1_c16_u4_dma", 6, 256, 1, 16, 4, 1, 0),
     DDT_V("d6_t128_r1_c16_u8_dma", 6, 128, 1, 16, 8, 1, 0),
@@ -1129,9 +1126,7 @@ static const Variant g_variants[] = {
     DDT_V("d3_t128_r1_c128_u8_dma", 3, 128, 1, 128, 8, 1, 0),
     // resident-model streaming kernels (small ensembles, HBM-bound; BASELINE config 1 is depth 4)
     DDT_S("stream_d4_u4_l4", 4, 4, 4),
-    DDT_S("stream_d4_u8_l4", 4, 8, 4),
     DDT_S("stream_d4_u4_l8", 4, 4, 8),
-    DDT_S("stream_d4_u8_l8", 4, 8, 8),
     DDT_S("stream_d6_u4_l4", 6, 4, 4),
     DDT_S("stream_d6_u4_l8", 6, 4, 8),
     DDT_S("stream_d8_u4_l8", 8, 4, 8),

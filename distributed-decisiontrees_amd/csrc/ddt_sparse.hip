@@ -39,11 +39,10 @@ __device__ __forceinline__ bool sp_right(uint32_t f, uint32_t thr, uint32_t w, u
 template <int K, int U, int THREADS, bool SLOW>
 __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
   constexpr int TOPB = 12 << K;
-  constexpr int STEPB = U * TOPB;  // U trees per pass: half a PU group (U = 4), one, or two
+  constexpr int STEPB = U * TOPB;  // U trees per pass: one PU group (or two)
   const uint32_t lane_off = (uint32_t)tid * 4u, miss_key = a.miss_key, C = a.clusters;
   const uint4* __restrict__ deep = x.deep;
   const uint32_t n_steps = x.n_groups * 8u / (uint32_t)U;  // the host pads the image to whole passes
-  float half = 0.f;  // U = 4: the pairwise sum of the first four trees of the group, waiting for the other four
   for (uint32_t g = 0; g < n_steps; ++g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the top images of this pass (and, first pass, the feature tile) are in LDS for everyone
@@ -105,30 +104,15 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
       }
     }
 
-    if (U == 4) {  // FPAddersReduceTree.sv:94-141 over two passes: ((l0+l1)+(l2+l3)) + ((l4+l5)+(l6+l7))
+#pragma unroll
+    for (int h = 0; h < U / 8; ++h) {
       if (a.sum_mode == 1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dacc += (double)leafv[u];
-      } else {
-        const float p4 = (leafv[0] + leafv[1]) + (leafv[2] + leafv[3]);
-        if ((g & 1u) == 0u) {
-          half = p4;
-        } else {
-          const float s[1] = {half + p4};
-          ra.push_group(s, C);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int h = 0; h < U / 8; ++h) {
-        if (a.sum_mode == 1) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) dacc += (double)leafv[(8 * h + u) % U];
-        } else {
-          const float s[1] = {((leafv[(8 * h + 0) % U] + leafv[(8 * h + 1) % U]) + (leafv[(8 * h + 2) % U] + leafv[(8 * h + 3) % U])) +
-                              ((leafv[(8 * h + 4) % U] + leafv[(8 * h + 5) % U]) + (leafv[(8 * h + 6) % U] + leafv[(8 * h + 7) % U]))};
-          ra.push_group(s, C);
-        }
+        for (int u = 0; u < 8; ++u) dacc += (double)leafv[8 * h + u];
+      } else {  // FPAddersReduceTree.sv:94-141, then the slot accumulate of this group's cluster
+        const float s[1] = {((leafv[8 * h + 0] + leafv[8 * h + 1]) + (leafv[8 * h + 2] + leafv[8 * h + 3])) +
+                            ((leafv[8 * h + 4] + leafv[8 * h + 5]) + (leafv[8 * h + 6] + leafv[8 * h + 7]))};
+        ra.push_group(s, C);
       }
     }
   }
@@ -141,7 +125,7 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   constexpr int STEPB = U * TOPB;  // top images resident per pass: U trees walked in lock-step = U independent load chains per lane
   constexpr int ROW = THREADS * 4;
   constexpr int FEAT_OFF = (STEPB + ROW - 1) / ROW * ROW;
-  static_assert(U == 4 || U == 8 || U == 16, "half a PU group, one, or two per pass");
+  static_assert(U == 8 || U == 16, "one or two PU groups per pass");
   static_assert((STEPB / 16) % 64 == 0, "whole waves per DMA");
   const int tid = threadIdx.x;
   const uint64_t tile0 = (uint64_t)blockIdx.x * THREADS;
@@ -216,15 +200,14 @@ static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStrea
 
 // `levels` = K (top levels staged in LDS), `chunk_trees` = trees walked in lock-step, `threads` = tuples per tile
 static const Variant g_sparse_variants[] = {
+    // measured and NOT instantiated (profiles/r02_sparse_sweep_*.log): 16 trees in lock-step (u16: no gain over u8), half a
+    // PU group per pass (u4: K + 1 at the same occupancy, but 4 loads in flight per lane: 159 vs 196 Mtuples/s)
     DDT_SP(6, 8, 256), DDT_SP(7, 8, 256), DDT_SP(8, 8, 256), DDT_SP(9, 8, 256), DDT_SP(10, 8, 256),
-    DDT_SP(6, 16, 256), DDT_SP(7, 16, 256), DDT_SP(8, 16, 256),
-    DDT_SP(6, 8, 128), DDT_SP(7, 8, 128), DDT_SP(8, 8, 128), DDT_SP(9, 8, 128), DDT_SP(10, 8, 128),
-    DDT_SP(6, 16, 128), DDT_SP(7, 16, 128), DDT_SP(8, 16, 128), DDT_SP(9, 16, 128),
-    DDT_SP(8, 8, 64), DDT_SP(9, 8, 64), DDT_SP(10, 8, 64),
     // 512-tuple tiles: one block of 8 waves per CU shares ONE set of top images (two 256-tuple blocks hold two)
     DDT_SP(6, 8, 512), DDT_SP(7, 8, 512), DDT_SP(8, 8, 512), DDT_SP(9, 8, 512),
-    // half a PU group per pass: half the top-image bytes per pass buys one more level at the same occupancy
-    DDT_SP(9, 4, 512), DDT_SP(9, 4, 256), DDT_SP(10, 4, 256), DDT_SP(8, 4, 256),
+    // narrower tiles for wide tuples (the feature tile is 4 * W bytes per tuple)
+    DDT_SP(6, 8, 128), DDT_SP(7, 8, 128), DDT_SP(8, 8, 128), DDT_SP(9, 8, 128), DDT_SP(10, 8, 128),
+    DDT_SP(8, 8, 64), DDT_SP(9, 8, 64), DDT_SP(10, 8, 64),
 };
 
 int num_sparse_variants() { return (int)(sizeof(g_sparse_variants) / sizeof(g_sparse_variants[0])); }

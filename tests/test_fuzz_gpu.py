@@ -50,3 +50,40 @@ def test_random_shape_bit_exact(seed, T, D, F, n, cmp_mode, clusters, sum_mode):
             assert np.array_equal(got2.view(np.uint32), want.view(np.uint32)), names[forced]
     finally:
         e.close()
+
+
+def _sparse_cases():
+    rng = np.random.default_rng(20260922)
+    out = []
+    for i in range(24):
+        D = int(rng.integers(1, 21))                     # depth bound; deeper than 16 is fine in the sparse format
+        T = int(rng.integers(1, 70))
+        F = int(rng.integers(1, 100))
+        full = int(rng.integers(0, min(D, 7) + 1))
+        pm = int(rng.integers(300, 900))
+        n = int(rng.integers(1, 3000))
+        out.append((i, T, D, F, full, pm, n, int(rng.integers(0, 2)), int(rng.choice([1, 2, 4, 8])), int(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("seed,T,D,F,full,pm,n,cmp_mode,clusters,sum_mode", _sparse_cases())
+def test_random_sparse_forest_bit_exact(seed, T, D, F, full, pm, n, cmp_mode, clusters, sum_mode):
+    """Seeded random SPARSE forests (ragged depths 1..20, tree counts that are not multiples of 8, 1..99 features, both
+    compare modes, all cluster counts, missing values) through the engine's own kernel choice and the host feeder."""
+    s = O.gen_sparse_model(T, D, F, full, pm, 1, cmp_mode=cmp_mode, clusters=clusters)
+    x = O.gen_tuples(2000 + seed, n, F, dist=1)
+    want = O.score_sparse(s, x, sum_mode=O.SUM_REF_FLOPOCO if sum_mode == 0 else O.SUM_F64_SEQ)
+    q = s.params
+    p = ddt.make_sparse_params(q.num_trees, q.num_levels, q.num_features, q.missing_bits, q.cmp_mode, q.clusters_per_tuple, sum_mode)
+    e = ddt.Engine(0)
+    try:
+        e.load_model_sparse(p, s.node_lines, s.first)
+        got = e.score(x)
+        bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+        assert bad.size == 0, f"{e.info().variant_name.decode()}: {bad.size} rows differ, first {bad[:5]}"
+        e.set_option("sparse_deep_order", 1)
+        e.set_option("sparse_top_levels", 6)
+        e.load_model_sparse(p, s.node_lines, s.first, 0, 1)
+        assert np.array_equal(e.score(x).view(np.uint32), want.view(np.uint32))
+    finally:
+        e.close()
