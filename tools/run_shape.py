@@ -25,9 +25,13 @@ def main():
     ap.add_argument("--full-levels", type=int, default=10)
     ap.add_argument("--permille", type=int, default=700)
     ap.add_argument("--variant", default="", help="kernel variant name")
+    ap.add_argument("--opt", default="", help="engine options, comma separated key=value")
     a = ap.parse_args()
     T, D, F, N = a.trees, a.levels, a.features, a.rows
     eng = ddt.Engine(0)
+    for kv in filter(None, a.opt.split(",")):
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     if a.variant:
         eng.set_option("variant", ddt.variant_names().index(a.variant))
     if a.sparse:
@@ -41,6 +45,12 @@ def main():
     out = torch.empty(N, dtype=torch.float32, device="cuda")
     eng.score_device(d, out=out)
     torch.cuda.synchronize()
+    if not a.sparse and N >= 4096:  # parity on a prefix, so that an experiment cannot be fast and wrong
+        import numpy as np
+        from oracle import oracle as O
+        m = O.Model(O.make_params(T, D, F), w, f)
+        xs = d[:4096].cpu().numpy().view(np.uint32)
+        assert np.array_equal(out[:4096].cpu().numpy().view(np.uint32), O.score(m, xs).view(np.uint32)), "parity"
     ts = []
     for _ in range(a.reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
