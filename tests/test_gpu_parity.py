@@ -292,6 +292,14 @@ def test_config3_full_batch_and_eight_way_chain(eng):
     total = eng.chain_sum_device(parts)
     torch.cuda.synchronize()
     assert np.array_equal(_bits(total[idx].cpu().numpy()), _bits(O.score(m, xs, n_devices=G)))
+    # ... and on two contiguous 256 K-row stretches (the start and an unaligned interior one) with the fast form of the
+    # oracle's 8-device model: per-device reference-order sums (host IEEE adds == the FloPoCo model on these normal
+    # values), chain-added host -> dev1 -> ...
+    for lo in (0, 61_234_567):
+        xs2 = d[lo: lo + 262_144].cpu().numpy().view(np.uint32)
+        want = O.score(m, xs2, sum_mode=O.SUM_REF_NATIVE, n_devices=G)
+        assert np.array_equal(_bits(total[lo: lo + 262_144].cpu().numpy()), _bits(want)), lo
+        assert np.array_equal(_bits(a[lo: lo + 262_144].cpu().numpy()), _bits(O.score_fast(m, xs2))), lo
     # north-star tolerance for regrouped fp32 sums: 1e-6 relative to max(|score|, sum |leaf|); sum |leaf| <= 1000 x 0.1
     assert (total - a).abs().max().item() <= 1e-6 * 100.0
     eng.load_model(p, w, f)
