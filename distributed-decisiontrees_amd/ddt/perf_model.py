@@ -118,3 +118,26 @@ def tree_sharded_ms(trees: int, n_gpus: int, depth: int = 8, rows: float = 1e8, 
     comm = 0.0 if n_gpus == 1 else rows * 4 / g.allreduce_alg_bytes_per_s * 1e3 / chunks
     ms = e["ms"] + comm
     return {"ms": ms, "mtuples_per_s": rows / ms / 1e3, "path": e["path"], "score_ms": e["ms"], "exposed_comm_ms": comm}
+
+
+# ---- part 4: sparse forests (config 4): the vector-memory lane-address ceiling ---------------------------------
+@dataclass
+class SparseCosts:
+    """Measured on one MI355X (profiles/r02_pmc_sparse_k8_t512.md, r02_sparse_sweep_final.json): the deep phase gathers one
+    16-byte record per lane and visit; the vector-memory path takes about ONE lane address per cycle and CU."""
+    lane_addresses_per_cycle_per_cu: float = 1.0
+    efficiency_k8: float = 0.72          # 0.44 T gathers/s reached at K = 8 against CUs x clock = 0.61 T/s
+    lds_visit_rate: float = 7.0e12       # top-phase visits run at the LDS rate of the dense kernels; a minor term
+
+
+def predict_sparse(trees: int, mean_visits_per_tree: float, top_levels: int = 8, rows: float = 1e7, g: Mi355x = Mi355x(),
+                   c: SparseCosts = SparseCosts()) -> dict:
+    """Predicted Mtuples/s of score_sparse_kernel: `mean_visits_per_tree` node visits per tuple and tree (the leaf depth
+    actually walked), the first `top_levels` of them out of LDS, the rest as gathers at the lane-address ceiling."""
+    deep = max(0.0, mean_visits_per_tree - top_levels)
+    ceiling = g.cus * g.clock_hz * c.lane_addresses_per_cycle_per_cu
+    t_deep = rows * trees * deep / (ceiling * c.efficiency_k8)
+    t_top = rows * trees * min(mean_visits_per_tree, top_levels) / c.lds_visit_rate
+    t = t_deep + t_top
+    return {"seconds": t, "mtuples_per_s": rows / t / 1e6, "gather_ceiling_per_s": ceiling, "deep_visits_per_tree": deep,
+            "ceiling_mtuples_per_s": (ceiling / (trees * deep) / 1e6) if deep else float("inf")}

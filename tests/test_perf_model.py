@@ -58,3 +58,11 @@ def test_engine_cost_model_matches_the_measured_shard_regime():
     assert abs(P.engine_ms(125)["fp32_ms"] - 21.4) < 1.5                     # what the 8-way shard cost before the fused pre-pass
     s = {n: P.tree_sharded_ms(1000, n)["mtuples_per_s"] for n in (1, 2, 4, 8)}
     assert 780 < s[1] < 840 and 5.5 < s[8] / s[1] < 6.6                      # north star: >= 6x aggregate at 8 GPUs is within reach
+
+
+def test_sparse_forest_model_matches_the_config4_measurement():
+    """profiles/r02_bench_cfg4.log: 512 sparse trees, 12.06 visits per tuple and tree, K = 8 -> 213.7 Mtuples/s measured."""
+    r = P.predict_sparse(512, 12.059, top_levels=8)
+    assert abs(r["mtuples_per_s"] - 213.7) / 213.7 < 0.2
+    assert 280 < r["ceiling_mtuples_per_s"] < 310  # the lane-address ceiling of this model at K = 8
+    assert P.predict_sparse(512, 12.059, top_levels=9)["ceiling_mtuples_per_s"] > r["ceiling_mtuples_per_s"]
