@@ -43,8 +43,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=3, choices=[3, 4], help="BASELINE.json config: 3 = headline (default), 4 = sparse random forest")
-    ap.add_argument("--rows", type=int, default=0, help="tuples per step (default: 100 M for config 3, 10 M for config 4)")
+    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5],
+                    help="BASELINE.json config: 3 = headline (default); 1 = 8 trees x d4 x 16 features (HBM-bound shape, 200 M rows "
+                         "instead of the 1 K rows of the CPU plumbing case); 2 = 100 x d6 x 28, 10 M rows; 4 = sparse random forest; "
+                         "5 = 10-class one-vs-all, 100 trees/class, d8, 32 features, 10 M rows (value = tuples classified)")
+    ap.add_argument("--rows", type=int, default=0, help="tuples per step (default: the config's)")
     ap.add_argument("--trees", type=int, default=0)
     ap.add_argument("--levels", type=int, default=0)
     ap.add_argument("--features", type=int, default=0)
@@ -83,10 +86,10 @@ def main():
     import ddt
 
     sparse = args.config == 4
-    T = args.trees or (512 if sparse else 1000)
-    D = args.levels or (16 if sparse else 8)
-    F = args.features or (64 if sparse else 32)
-    N = args.rows or (10_000_000 if sparse else 100_000_000)
+    classes = 10 if args.config == 5 else 1
+    shape = {1: (8, 4, 16, 200_000_000), 2: (100, 6, 28, 10_000_000), 3: (1000, 8, 32, 100_000_000),
+             4: (512, 16, 64, 10_000_000), 5: (1000, 8, 32, 10_000_000)}[args.config]
+    T, D, F, N = (args.trees or shape[0], args.levels or shape[1], args.features or shape[2], args.rows or shape[3])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +129,10 @@ def main():
         lines, first = ddt.synth_sparse_model(T, D, F, args.full_levels, args.permille, 0)
         params = ddt.make_sparse_params(T, D, F, sum_mode=args.sum_mode)
         eng.load_model_sparse(params, lines, first, *shard)
+    elif classes > 1:
+        w, f = ddt.synth_model(T, D, F, 0)
+        params = ddt.make_params(T, D, F, clusters=ddt.default_clusters(T // classes), sum_mode=args.sum_mode)
+        eng.load_model_multiclass(params, w, f, classes, True, *shard)  # tree i belongs to class i % 10 (XGBoost multi:softprob order)
     else:
         w, f = ddt.synth_model(T, D, F, 0)
         params = ddt.make_params(T, D, F, sum_mode=args.sum_mode)
@@ -134,6 +141,12 @@ def main():
 
     tuples = eng.synth_tuples_device(0, N, F, 0)          # resident in HBM before the timed region
     out = torch.empty(N, dtype=torch.float32, device=tuples.device)
+    labels = cls_scores = None
+    if classes > 1:
+        labels = torch.empty(N, dtype=torch.int32, device=tuples.device)
+        cls_scores = torch.empty((classes, N), dtype=torch.float32, device=tuples.device)
+        if rows_mode or args.collectives != "cabi":
+            sys.exit("config 5 across GPUs: tree-sharded through the C-ABI collectives only")
     comm = scorer = None
     combine = ddt.COMBINE_CHAIN if args.combine == "chain" else ddt.COMBINE_ALLREDUCE
     if multi and args.collectives == "cabi":
@@ -155,7 +168,12 @@ def main():
         eng.set_option("kernel_timing", 1)
 
     def step(record: bool):
-        if comm is not None:
+        if classes > 1:
+            if comm is not None:
+                comm.classify_sharded(tuples, combine=combine, class_scores=cls_scores, labels=labels)
+            else:
+                eng.classify_device(tuples, class_scores=cls_scores, labels=labels)
+        elif comm is not None:
             if rows_mode:
                 comm.score_rowsharded(tuples, out=out)
             else:
@@ -164,6 +182,7 @@ def main():
             scorer.score(tuples, out=out)
         else:
             eng.score_device(tuples, out=out)
+        if comm is None and scorer is None:
             if record:
                 st = eng.stats()  # waits for this launch's end event
                 kernel_ms.append((st.last_prepass_ms, st.last_score_ms))
@@ -190,11 +209,14 @@ def main():
     mtuples = N / (dt / max(1, args.steps)) / 1e6
 
     # ---- roofline of the dominant kernel (the per-shard scoring kernel) ----------------------------
-    alg_bytes_per_launch = N * (4 * F + 4) + int(info.model_bytes_unpadded)  # tuples in, scores out, model once
+    # tuples in, scores out, model once; config 5 writes the K per-class sums and the label (argmax not fused)
+    alg_bytes_per_launch = N * (4 * F + 4 * (classes + 1 if classes > 1 else 1)) + int(info.model_bytes_unpadded)
     roofline = None
     if not multi and kernel_ms:
         pre_ms = sum(a for a, _ in kernel_ms) / len(kernel_ms)
         k_ms = sum(b for _, b in kernel_ms) / len(kernel_ms)  # the dominant (scoring) kernel
+        if classes > 1:  # the library times the LAST class's launch: the K launches are alike, the pre-pass ran once with the first
+            k_ms, pre_ms = ms_per_step, 0.0
         ach = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic_cfg4.json" if sparse else "pmc_traffic.json")
@@ -236,6 +258,12 @@ def main():
             def cpu_score(xs):
                 return O.score_sparse_fast(m, xs, sum_mode=O.SUM_REF_NATIVE if args.sum_mode == 0 else O.SUM_F64_SEQ)
             what = "oracle/ddt_oracle.c orc_score_sparse_fast: one tree at a time over a 1024-row block, 8 rows in flight per thread"
+        elif classes > 1:
+            m = O.Model(O.make_params(T, D, F, clusters=ddt.default_clusters(T // classes)), w, f)
+
+            def cpu_score(xs):
+                return O.classify(m, xs, classes, True, sum_mode=O.SUM_REF_NATIVE if args.sum_mode == 0 else O.SUM_F64_SEQ)[0]
+            what = "oracle/ddt_oracle.c orc_classify: per-class reference-order sums, argmax"
         else:
             m = O.Model(O.make_params(T, D, F), w, f)
 
@@ -256,8 +284,9 @@ def main():
         cpu = {"value": round(rows / cdt / 1e6, 4), "unit": "Mtuples/s", "cores": O.hw_threads(), "kind": "port",
                "sample": f"first {rows} rows of the same synthetic batch, all {T} trees, OpenMP over row blocks, "
                          f"{cdt:.1f} s ({what}; a CPU restatement of the reference RTL semantics, the reference has no CPU scorer)"}
-        got = out[:rows].cpu().numpy()
-        parity = {"rows_checked": rows, "bit_exact": bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32)))}
+        got = (labels if classes > 1 else out)[:rows].cpu().numpy()
+        parity = {"rows_checked": rows, "bit_exact": bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32))),
+                  "what": "int32 class labels" if classes > 1 else "fp32 scores"}
         if sparse and roofline is not None:
             depth = O.sparse_mean_depth(m, xs[:2048])  # node visits per (tuple, tree) on a sample
             k_s = roofline["kernel_ms"] * 1e-3
@@ -267,7 +296,7 @@ def main():
             roofline["deep_gathers_per_s"] = round(N * T * max(0.0, depth - int(info.variant_name.decode().split("_k")[1].split("_")[0])) / k_s, 1)
 
     # ---- PCIe-inclusive "streamed" mode (SURVEY 8(d) timing protocol): host buffers through the pinned feeder ----
-    if world == 1 and rank == 0 and not args.no_streamed and not multi:
+    if world == 1 and rank == 0 and not args.no_streamed and not multi and classes == 1:
         srows = min(N, 16_000_000)
         host = tuples[:srows].cpu().numpy().view(np.uint32)  # pageable host memory, as a caller would hold it
         eng.score(host[: min(srows, 1 << 20)])                # feeder buffers allocated
@@ -284,10 +313,12 @@ def main():
             f"row-sharded {world}x (replicas) + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-gather" if rows_mode else
             f"tree-sharded {world}x + {'RCCL' if args.backend == 'nccl' else 'gloo (functional test)'} {args.combine}")
         shape = (f"{T} sparse trees (depth <= {D}, {lines.shape[0]} internal nodes) x {F} fp32 features" if sparse
+                 else f"{classes}-class one-vs-all, {T // classes} trees/class x depth {D} x {F} fp32 features, argmax labels" if classes > 1
                  else f"{T} trees x depth {D} x {F} fp32 features")
         line = {
-            "metric": "Mtuples/s scored, 1000 trees depth-8 / 32 feat" if (T, D, F, sparse) == (1000, 8, 32, False)
-            else f"Mtuples/s scored, {T} trees depth-{D} / {F} feat" + (" (sparse random forest, BASELINE config 4)" if sparse else ""),
+            "metric": "Mtuples/s scored, 1000 trees depth-8 / 32 feat" if (T, D, F, sparse, classes) == (1000, 8, 32, False, 1)
+            else f"Mtuples/s {'classified' if classes > 1 else 'scored'}, {T} trees depth-{D} / {F} feat"
+                 + (" (sparse random forest, BASELINE config 4)" if sparse else f" (BASELINE config {args.config})" if args.config != 3 else ""),
             "value": round(mtuples, 3), "unit": "Mtuples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -344,13 +344,16 @@ class Comm:
         self._check(self._L.ddt_score_rowsharded_device(self._h, d_tuples.data_ptr(), n, out.data_ptr(), s.cuda_stream))
         return out
 
-    def classify_sharded(self, d_tuples, combine: int = COMBINE_ALLREDUCE, want_labels: bool = True, stream=None):
+    def classify_sharded(self, d_tuples, combine: int = COMBINE_ALLREDUCE, want_labels: bool = True, stream=None,
+                         class_scores=None, labels=None):
         """-> (labels int32 [n] or None, combined class scores fp32 [K, n])"""
         import torch
 
         n, s = self._args(d_tuples, stream)
-        cs = torch.empty((self.engine.num_classes, n), dtype=torch.float32, device=d_tuples.device)
-        labels = torch.empty(n, dtype=torch.int32, device=d_tuples.device) if want_labels else None
+        cs = class_scores if class_scores is not None else torch.empty((self.engine.num_classes, n), dtype=torch.float32, device=d_tuples.device)
+        if labels is None and want_labels:
+            labels = torch.empty(n, dtype=torch.int32, device=d_tuples.device)
+        want_labels = labels is not None
         self._check(self._L.ddt_classify_sharded_device(self._h, d_tuples.data_ptr(), n, cs.data_ptr(),
                                                         labels.data_ptr() if want_labels else None, combine, s.cuda_stream))
         return labels, cs
