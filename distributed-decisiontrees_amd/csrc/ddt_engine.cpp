@@ -631,7 +631,7 @@ int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_
     HIP_TRY(e, hipEventRecord(e->tev[0], s));
     HIP_TRY(e, hipEventRecord(e->tev[1], s));  // no pre-pass on this path
   }
-  int rc = sparse_launch(e, d_tuples, n, d_scores, s);
+  int rc = sparse_launch(e, 0, d_tuples, n, d_scores, s);
   if (rc) return rc;
   if (timing) {
     HIP_TRY(e, hipEventRecord(e->tev[2], s));
@@ -642,7 +642,18 @@ int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_
 }
 
 int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s) {
-  if (e->sparse) return fail(e, DDT_EUNSUPPORTED, "sparse models hold one class");
+  if (e->sparse) {  // one sparse forest per class, then the argmax over the per-class sums
+    for (uint32_t k = 0; k < e->num_classes; ++k) {
+      int rc = sparse_launch(e, k, d_tuples, n, d_class_scores + (size_t)k * n, s);
+      if (rc) return rc;
+      e->st.kernel_launches++;
+    }
+    if (d_labels) {
+      hipError_t r = launch_argmax(d_class_scores, e->num_classes, n, d_labels, s);
+      if (r != hipSuccess) return fail(e, DDT_EHIP, "argmax -> %s", hipGetErrorString(r));
+    }
+    return DDT_OK;
+  }
   return launch_classify(e, d_tuples, n, d_class_scores, d_labels, s);
 }
 
@@ -696,6 +707,7 @@ int load_common(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wli
   free_images(e);
   free_q16_workspace(e);  // sized for the previous model's tuple width
   sparse_free(e);
+  e->sps.clear();
   e->sparse = false;
   e->loaded = false;
   e->p = *p;
@@ -898,7 +910,6 @@ int ddt_classify(ddt_engine* e, const void* tuple_lines, size_t n, int32_t* labe
   if (!e->loaded) return fail(e, DDT_ESTATE, "no model loaded");
   if (n == 0) return DDT_OK;
   if (!tuple_lines || !labels) return fail(e, DDT_EINVAL, "NULL host buffer");
-  if (e->sparse) return fail(e, DDT_EUNSUPPORTED, "sparse models hold one class");
   return score_host(e, tuple_lines, n, nullptr, labels, class_scores);
 }
 
@@ -924,20 +935,29 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   if (!e->loaded) return DDT_OK;
   const Variant& v = variant(e->variant_id);
   if (e->sparse) {
-    const SparseForest& sp = e->sp;
-    out->tree_begin = sp.ids.empty() ? 0u : sp.ids.front();
-    out->tree_end = sp.ids.empty() ? 0u : sp.ids.back() + 1;
-    out->num_levels = sp.max_depth;
+    uint32_t trees = 0, depth = 0;
+    uint64_t lines = 0, img = 0;
+    for (const SparseForest& sp : e->sps) {
+      trees += sp.trees();
+      depth = sp.max_depth > depth ? sp.max_depth : depth;
+      lines += sp.lines.size() / 4u;
+      img += sp.top_bytes + sp.deep_bytes;
+    }
+    const SparseForest& s0 = e->sps.front();
+    const SparseForest& s1 = e->sps.back();
+    out->tree_begin = s0.ids.empty() ? 0u : s0.ids.front();
+    out->tree_end = s1.ids.empty() ? out->tree_begin : s1.ids.back() + 1;
+    out->num_levels = depth;
     out->num_features = e->p.num_features;
     out->tuple_words = tuple_words(e->p);
     out->variant = (uint32_t)e->variant_id;
     out->tile_tuples = v.tile();
     out->block_threads = (uint32_t)v.threads;
     out->lds_bytes = v.lds_bytes_sparse(out->tuple_words);
-    out->model_bytes_unpadded = (uint64_t)sp.lines.size() * 4ull;  // 16 bytes per internal node: the stream itself
-    out->image_bytes = sp.top_bytes + sp.deep_bytes;
-    out->num_classes = 1;
-    out->local_trees = sp.trees();
+    out->model_bytes_unpadded = lines * 16ull;  // 16 bytes per internal node: the stream itself
+    out->image_bytes = img;
+    out->num_classes = e->num_classes;
+    out->local_trees = trees;
     snprintf(out->variant_name, sizeof(out->variant_name), "%s", v.name);
     return DDT_OK;
   }

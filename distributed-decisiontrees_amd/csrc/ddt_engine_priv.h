@@ -103,7 +103,7 @@ struct ddt_engine {
   hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
   // sparse forests (ddt_load_model_sparse)
   bool sparse = false;
-  ddt::SparseForest sp;
+  std::vector<ddt::SparseForest> sps;  // one per class (single-output models: exactly one)
   int sparse_top_levels = -1;   // option "sparse_top_levels": K, -1 = the most the LDS takes
   int sparse_deep_order = 0;    // option "sparse_deep_order": 0 = level order (default: measured faster), 1 = depth-first per sub-tree
   int leaf_domain_check = 1;    // option "leaf_domain_check": reject leaves outside the exact domain of the reference adder
@@ -157,7 +157,7 @@ int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_
 int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s);
 // ddt_sparse_host.cpp
 void sparse_free(ddt_engine* e);
-int sparse_launch(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s);
+int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, float* d_scores, hipStream_t s);
 int sparse_rebuild(ddt_engine* e);
 
 }  // namespace ddt

@@ -64,22 +64,37 @@ int pick_variant(ddt_engine* e, uint32_t max_depth) {
 }  // namespace
 
 void sparse_free(ddt_engine* e) {
-  for (void** p : {&e->sp.d_top, &e->sp.d_deep}) {
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
+  for (SparseForest& sp : e->sps) {
+    for (void** p : {&sp.d_top, &sp.d_deep}) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    sp.top_bytes = sp.deep_bytes = 0;
+    sp.groups = 0;
   }
-  e->sp.top_bytes = e->sp.deep_bytes = 0;
-  e->sp.groups = 0;
 }
 
-// Pack the device images of e->sp for the chosen K and upload them.
+static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp);
+
+// Choose the kernel for the loaded forest(s) and pack the device images of every class for it.
 int sparse_rebuild(ddt_engine* e) {
-  SparseForest& sp = e->sp;
-  const int vid = pick_variant(e, sp.max_depth);
+  uint32_t max_depth = 0;
+  for (const SparseForest& sp : e->sps) max_depth = sp.max_depth > max_depth ? sp.max_depth : max_depth;
+  const int vid = pick_variant(e, max_depth);
   if (vid < 0)
     return fail(e, DDT_EUNSUPPORTED, "no sparse kernel fits: %u tuple words need more than %u bytes of LDS (or the forced variant %d / "
                 "sparse_top_levels %d is not a sparse kernel that fits)", tuple_words(e->p), kMaxLdsBytes, e->forced_variant, e->sparse_top_levels);
-  const Variant& v = variant(vid);
+  sparse_free(e);
+  for (SparseForest& sp : e->sps) {
+    int rc = sparse_pack(e, variant(vid), sp);
+    if (rc) return rc;
+  }
+  e->variant_id = vid;
+  return DDT_OK;
+}
+
+// Pack the device images of one forest for kernel `v` and upload them.
+static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp) {
   const uint32_t K = (uint32_t)v.levels, T = sp.trees();
   const uint32_t per_pass = std::max(1u, (uint32_t)v.chunk_trees / 8u);  // PU groups walked in lock-step (half groups: 1)
   uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
@@ -210,7 +225,6 @@ int sparse_rebuild(ddt_engine* e) {
     for (auto& pe : pending) *pe.second = where[pe.first];
   }
 
-  sparse_free(e);
   HIP_TRY(e, hipMalloc(&sp.d_top, top.size() * 4u));
   HIP_TRY(e, hipMalloc(&sp.d_deep, deep.size() * 4u));
   HIP_TRY(e, hipMemcpy(sp.d_top, top.data(), top.size() * 4u, hipMemcpyHostToDevice));
@@ -218,12 +232,11 @@ int sparse_rebuild(ddt_engine* e) {
   sp.top_bytes = top.size() * 4u;
   sp.deep_bytes = deep.size() * 4u;
   sp.groups = groups;
-  e->variant_id = vid;
   return DDT_OK;
 }
 
-int sparse_launch(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
-  const SparseForest& sp = e->sp;
+int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
+  const SparseForest& sp = e->sps[cls];
   const Variant& v = variant(e->variant_id);
   ScoreArgs a{};
   a.img = reinterpret_cast<const uint4*>(sp.d_top);
@@ -254,30 +267,14 @@ int sparse_launch(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores
 
 using namespace ddt;
 
-extern "C" int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const void* node_lines, size_t n_lines,
-                                     const uint64_t* first, uint32_t shard_index, uint32_t shard_count) {
-  if (!e) return DDT_EINVAL;
-  if (!p || !node_lines || !first) return fail(e, DDT_EINVAL, "NULL argument");
-  if (p->num_trees == 0) return fail(e, DDT_EINVAL, "num_trees == 0");
-  if (p->num_levels < 1 || p->num_levels > 64) return fail(e, DDT_EINVAL, "num_levels %u not in 1..64 (depth bound of a sparse model)", p->num_levels);
-  if (p->num_features < 1 || p->num_features > 2048) return fail(e, DDT_EINVAL, "num_features %u not in 1..2048 (DTPU.sv:72)", p->num_features);
-  if (p->cmp_mode > 1 || p->sum_mode > 1) return fail(e, DDT_EINVAL, "cmp_mode %u / sum_mode %u", p->cmp_mode, p->sum_mode);
-  const uint32_t c = p->clusters_per_tuple;
-  if (c != 1 && c != 2 && c != 4 && c != 8) return fail(e, DDT_EINVAL, "clusters_per_tuple %u not in {1,2,4,8}", c);
-  if (p->reserved[0] | p->reserved[1] | p->reserved[2]) return fail(e, DDT_EINVAL, "reserved fields must be 0");
-  if (shard_count == 0 || shard_index >= shard_count || shard_count > p->num_trees)
-    return fail(e, DDT_EINVAL, "shard %u of %u (trees %u)", shard_index, shard_count, p->num_trees);
-  if (first[0] != 0 || first[p->num_trees] > n_lines) return fail(e, DDT_EINVAL, "tree_first_line does not start at 0 / exceeds the stream");
-  const double t0 = now_ms();
-  const uint32_t* lines = reinterpret_cast<const uint32_t*>(node_lines);
+namespace {
 
-  std::vector<uint32_t> all(p->num_trees);
-  for (uint32_t i = 0; i < p->num_trees; ++i) all[i] = i;
+// validate the trees `ids` of the stream and copy them (re-based) into `out`
+int take_trees(ddt_engine* e, const ddt_params* p, const uint32_t* lines, const uint64_t* first, std::vector<uint32_t> ids, SparseForest* out) {
   SparseForest sp;
-  sp.ids = shard_of(all, shard_index, shard_count);  // contiguous shards of ceil(T/G) trees; trailing shards may be empty
   sp.first.assign(1, 0u);
   std::vector<uint8_t> depth;
-  for (uint32_t id : sp.ids) {
+  for (uint32_t id : ids) {
     if (first[id + 1] <= first[id]) return fail(e, DDT_EINVAL, "tree %u has no lines", id);
     const uint64_t cnt = first[id + 1] - first[id];
     if (cnt > 0xFFFFFFFFull) return fail(e, DDT_EUNSUPPORTED, "tree %u has more than 2^32 nodes", id);
@@ -312,6 +309,47 @@ extern "C" int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const v
     }
     sp.first.push_back(sp.first.back() + cnt);
   }
+  sp.ids = std::move(ids);
+  *out = std::move(sp);
+  return DDT_OK;
+}
+
+}  // namespace
+
+extern "C" int ddt_load_model_sparse_multiclass(ddt_engine* e, const ddt_params* p, const void* node_lines, size_t n_lines,
+                                                const uint64_t* first, uint32_t num_classes, int interleaved, uint32_t shard_index,
+                                                uint32_t shard_count) {
+  if (!e) return DDT_EINVAL;
+  if (!p || !node_lines || !first) return fail(e, DDT_EINVAL, "NULL argument");
+  if (p->num_trees == 0) return fail(e, DDT_EINVAL, "num_trees == 0");
+  if (p->num_levels < 1 || p->num_levels > 64) return fail(e, DDT_EINVAL, "num_levels %u not in 1..64 (depth bound of a sparse model)", p->num_levels);
+  if (p->num_features < 1 || p->num_features > 2048) return fail(e, DDT_EINVAL, "num_features %u not in 1..2048 (DTPU.sv:72)", p->num_features);
+  if (p->cmp_mode > 1 || p->sum_mode > 1) return fail(e, DDT_EINVAL, "cmp_mode %u / sum_mode %u", p->cmp_mode, p->sum_mode);
+  const uint32_t c = p->clusters_per_tuple;
+  if (c != 1 && c != 2 && c != 4 && c != 8) return fail(e, DDT_EINVAL, "clusters_per_tuple %u not in {1,2,4,8}", c);
+  if (p->reserved[0] | p->reserved[1] | p->reserved[2]) return fail(e, DDT_EINVAL, "reserved fields must be 0");
+  if (num_classes == 0 || num_classes > p->num_trees) return fail(e, DDT_EINVAL, "num_classes %u (trees %u)", num_classes, p->num_trees);
+  if (!interleaved && p->num_trees % num_classes) return fail(e, DDT_EINVAL, "class-major layout needs num_trees %% num_classes == 0");
+  const uint32_t per_class = (p->num_trees + num_classes - 1) / num_classes;
+  if (shard_count == 0 || shard_index >= shard_count || shard_count > per_class)
+    return fail(e, DDT_EINVAL, "shard %u of %u (trees per class %u)", shard_index, shard_count, per_class);
+  if (first[0] != 0 || first[p->num_trees] > n_lines) return fail(e, DDT_EINVAL, "tree_first_line does not start at 0 / exceeds the stream");
+  const double t0 = now_ms();
+  const uint32_t* lines = reinterpret_cast<const uint32_t*>(node_lines);
+
+  std::vector<SparseForest> sps(num_classes);
+  uint64_t model_lines = 0;
+  for (uint32_t k = 0; k < num_classes; ++k) {
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < p->num_trees; ++i) {
+      const uint32_t cls = interleaved ? i % num_classes : i / (p->num_trees / num_classes);
+      if (cls == k) ids.push_back(i);
+    }
+    // contiguous shards of ceil(T_class / G) trees (PCIeReceiver.sv:241-264); trailing shards may be empty: EMPTY slots, +0
+    int rc = take_trees(e, p, lines, first, shard_of(ids, shard_index, shard_count), &sps[k]);
+    if (rc) return rc;
+    model_lines += sps[k].lines.size() / 4u;
+  }
 
   DeviceGuard dg(e->device);
   if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
@@ -323,13 +361,18 @@ extern "C" int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const v
   e->loaded = false;
   e->p = *p;
   e->nint = e->nleaf = 0;
-  e->num_classes = 1;
-  e->sp = std::move(sp);
+  e->num_classes = num_classes;
+  e->sps = std::move(sps);
   e->sparse = true;
   int rc = sparse_rebuild(e);
   if (rc) return rc;
   e->loaded = true;
-  e->st.model_lines_in += e->sp.lines.size() / 4u;
+  e->st.model_lines_in += model_lines;
   e->st.prog_ms += now_ms() - t0;
   return DDT_OK;
+}
+
+extern "C" int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const void* node_lines, size_t n_lines,
+                                     const uint64_t* first, uint32_t shard_index, uint32_t shard_count) {
+  return ddt_load_model_sparse_multiclass(e, p, node_lines, n_lines, first, 1, 0, shard_index, shard_count);
 }

@@ -16,7 +16,7 @@ SYMBOLS = [
     "ddt_chain_sum_device", "ddt_load_model_multiclass", "ddt_classify_device", "ddt_classify", "ddt_argmax_device",
     "ddt_csr_encode", "ddt_csr_decode", "ddt_get_info", "ddt_get_stats", "ddt_strerror", "ddt_last_error", "ddt_set_option",
     "ddt_num_variants", "ddt_variant_name", "ddt_synth_model", "ddt_synth_tuples_host", "ddt_synth_tuples_device",
-    "ddt_load_model_sparse", "ddt_synth_sparse_model", "ddt_csr_encode_ex", "ddt_csr_decode_ex",
+    "ddt_load_model_sparse", "ddt_load_model_sparse_multiclass", "ddt_synth_sparse_model", "ddt_csr_encode_ex", "ddt_csr_decode_ex",
     "ddt_comm_get_unique_id", "ddt_comm_create", "ddt_comm_destroy", "ddt_comm_last_error", "ddt_comm_set_option",
     "ddt_score_sharded_device", "ddt_score_rowsharded_device", "ddt_classify_sharded_device",
     "ddt_group_create", "ddt_group_destroy", "ddt_group_last_error", "ddt_group_engine", "ddt_group_load_model",
@@ -108,6 +108,8 @@ def lib():
     L.ddt_num_variants.restype, L.ddt_num_variants.argtypes = i32, []
     L.ddt_variant_name.restype, L.ddt_variant_name.argtypes = i32, [i32, C.c_char_p, sz]
     L.ddt_load_model_sparse.restype, L.ddt_load_model_sparse.argtypes = i32, [vp, PP, vp, sz, vp, u32, u32]
+    L.ddt_load_model_sparse_multiclass.restype = i32
+    L.ddt_load_model_sparse_multiclass.argtypes = [vp, PP, vp, sz, vp, u32, i32, u32, u32]
     L.ddt_synth_sparse_model.restype = C.c_int64
     L.ddt_synth_sparse_model.argtypes = [u32, u32, u32, u32, u32, i32, vp, sz, vp]
     L.ddt_csr_encode_ex.restype, L.ddt_csr_encode_ex.argtypes = i32, [PP, u64, u32, u32, u32, C.POINTER(u64 * 12)]

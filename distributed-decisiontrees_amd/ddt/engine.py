@@ -138,16 +138,17 @@ class Engine:
         return self
 
     def load_model_sparse(self, params: Params, node_lines: np.ndarray, tree_first_line: np.ndarray,
-                          shard_index: int = 0, shard_count: int = 1):
-        """Sparse (explicit-children) forest: one 128-bit line per internal node (include/ddt.h ddt_load_model_sparse)."""
+                          shard_index: int = 0, shard_count: int = 1, num_classes: int = 1, interleaved: bool = True):
+        """Sparse (explicit-children) forest: one 128-bit line per internal node (include/ddt.h ddt_load_model_sparse);
+        num_classes > 1: one-vs-all classes in the stream (ddt_load_model_sparse_multiclass), scored with classify*()."""
         nl = np.ascontiguousarray(node_lines).view(np.uint32).reshape(-1, 4)
         first = np.ascontiguousarray(tree_first_line, dtype=np.uint64).reshape(-1)
         if first.size != params.num_trees + 1:
             raise ValueError("tree_first_line must hold num_trees + 1 entries")
-        self._check(self._L.ddt_load_model_sparse(self._h, C.byref(params), nl.ctypes.data, nl.shape[0],
-                                                  first.ctypes.data, shard_index, shard_count))
+        self._check(self._L.ddt_load_model_sparse_multiclass(self._h, C.byref(params), nl.ctypes.data, nl.shape[0], first.ctypes.data,
+                                                             num_classes, int(interleaved), shard_index, shard_count))
         self.params = params
-        self.num_classes = 1
+        self.num_classes = num_classes
         return self
 
     def load_model_multiclass(self, params: Params, wlines: np.ndarray, flines: np.ndarray, num_classes: int,

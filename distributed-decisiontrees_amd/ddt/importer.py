@@ -67,9 +67,15 @@ class ImportedModel:
                            clusters, sum_mode)
 
     def load_into(self, engine, shard_index: int = 0, shard_count: int = 1, **kw):
-        """Load this model into a ddt.Engine (single-output models; multi-class: Engine.load_model_multiclass)."""
+        """Load this model into a ddt.Engine; models with classes are scored with Engine.classify*()."""
+        if self.num_classes > 1 and "clusters" not in kw:  # every class is its own ensemble of num_trees / num_classes trees
+            from .engine import default_clusters
+            kw["clusters"] = default_clusters(-(-self.num_trees // self.num_classes))
         if self.sparse:
-            return engine.load_model_sparse(self.params(**kw), self.node_lines, self.tree_first_line, shard_index, shard_count)
+            return engine.load_model_sparse(self.params(**kw), self.node_lines, self.tree_first_line, shard_index, shard_count,
+                                            self.num_classes, True)
+        if self.num_classes > 1:
+            return engine.load_model_multiclass(self.params(**kw), self.wlines, self.flines, self.num_classes, True, shard_index, shard_count)
         return engine.load_model(self.params(**kw), self.wlines, self.flines, shard_index, shard_count)
 
 

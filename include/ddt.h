@@ -157,9 +157,14 @@ int ddt_argmax_device(ddt_engine* e, const float* d_class_scores, uint32_t num_c
  *    delimits the trees; a tree that is a single leaf is one line with both leaf flags set and the value twice.
  *    ddt_params: num_levels = upper bound of the depth (1..64), weights/findex lines per tree ignored.  Compare rule,
  *    missing rule, EMPTY slots, summation order and tree sharding are exactly those of the perfect format; the model
- *    is then scored with ddt_score / ddt_score_device.  (One class only.)                                        -- */
+ *    is then scored with ddt_score / ddt_score_device.                                                           -- */
 int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const void* node_lines, size_t n_lines,
                           const uint64_t* tree_first_line, uint32_t shard_index, uint32_t shard_count);
+/* one-vs-all classes in a sparse stream (random-forest classifiers): class membership, sharding and argmax as in
+ * ddt_load_model_multiclass; score with ddt_classify* / ddt_classify_sharded_device */
+int ddt_load_model_sparse_multiclass(ddt_engine* e, const ddt_params* p, const void* node_lines, size_t n_lines,
+                                     const uint64_t* tree_first_line, uint32_t num_classes, int interleaved,
+                                     uint32_t shard_index, uint32_t shard_count);
 
 /* -- multi-GPU jobs: RCCL over xGMI behind the C-ABI ---------------------------------------------------------------
  *    Replaces the inter-FPGA networks of the reference: the ring broadcast of tuple lines (InputDistributor.sv:199-204)

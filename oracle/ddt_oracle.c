@@ -831,6 +831,56 @@ int orc_score_sparse_fast(const orc_params* p, const void* nl, size_t n_lines, c
   return 0;
 }
 
+/* one-vs-all classes over a sparse stream: the sparse counterpart of orc_classify (same class rule, same per-class
+ * device model, same argmax: lowest index wins ties, a NaN never beats a number) */
+int orc_classify_sparse(const orc_params* p, const void* nl, size_t n_lines, const uint64_t* first, const void* tl, size_t n_tuples,
+                        uint32_t K, int interleaved, int sum_mode, int n_devices, int32_t* labels, float* class_scores) {
+  int rc = orc_sparse_check(p, (const uint32_t*)nl, n_lines, first);
+  if (rc) return rc;
+  const uint32_t C = p->clusters_per_tuple;
+  if (C != 1 && C != 2 && C != 4 && C != 8) return -1;
+  if (K == 0 || K > p->num_trees || (!interleaved && p->num_trees % K) || n_devices < 1) return -6;
+  const uint32_t* lines = (const uint32_t*)nl;
+  const uint32_t* t = (const uint32_t*)tl;
+  const uint32_t T = p->num_trees, tw = orc_tuple_lines(p->num_features) * 4u;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    uint32_t* leaves = (uint32_t*)malloc(sizeof(uint32_t) * T);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (long long r = 0; r < (long long)n_tuples; ++r) {
+      const uint32_t* x = t + (size_t)r * tw;
+      float best = 0.f;
+      int32_t arg = 0;
+      for (uint32_t k = 0; k < K; ++k) {
+        uint32_t nk = 0;
+        for (uint32_t i = 0; i < T; ++i) {
+          const uint32_t cls = interleaved ? i % K : i / (T / K);
+          if (cls == k) leaves[nk++] = orc_traverse_sparse(p, lines, first, x, i);
+        }
+        const uint32_t per_dev = (nk + (uint32_t)n_devices - 1u) / (uint32_t)n_devices;
+        uint32_t run = 0;
+        for (int d = 0; d < n_devices; ++d) {
+          const uint32_t b = (uint32_t)d * per_dev, e = (b + per_dev < nk) ? b + per_dev : nk;
+          const uint32_t part = (b < e) ? shard_sum(leaves + b, e - b, C, sum_mode) : 0u;
+          if (d == 0) run = part;
+          else if (sum_mode == ORC_SUM_REF_FLOPOCO) run = orc_fpadd_bits(part, run);
+          else { volatile float s = f_from(part) + f_from(run); run = b_from(s); }
+        }
+        const float sc = f_from(run);
+        if (class_scores) class_scores[(size_t)k * n_tuples + (size_t)r] = sc;
+        if (k == 0 || sc > best || (best != best && sc == sc)) { best = sc; arg = (int32_t)k; }
+      }
+      labels[r] = arg;
+    }
+    free(leaves);
+  }
+  return 0;
+}
+
 void orc_sparse_from_perfect(const orc_params* p, const uint32_t* wl, const uint16_t* fl, uint32_t* lines, uint64_t* first) {
   const uint32_t D = p->num_levels, nint = (1u << D) - 1u;
   const size_t ws = (size_t)p->weights_lines_per_tree * 4u, fs = (size_t)p->findex_lines_per_tree * 8u;

@@ -148,6 +148,10 @@ double orc_sparse_mean_depth(const orc_params* p, const uint32_t* node_lines, co
 int orc_score_sparse(const orc_params* p, const void* node_lines, size_t n_lines, const uint64_t* tree_first_line,
                      const void* tuple_lines, size_t n_tuples, float* out, double* gold, int sum_mode, int n_devices,
                      int nthreads);
+/* one-vs-all classes over a sparse stream (see orc_classify); labels[n], class_scores[K][n] may be NULL */
+int orc_classify_sparse(const orc_params* p, const void* node_lines, size_t n_lines, const uint64_t* tree_first_line,
+                        const void* tuple_lines, size_t n_tuples, uint32_t num_classes, int interleaved, int sum_mode,
+                        int n_devices, int32_t* labels, float* class_scores);
 /* cache-blocked form of orc_score_sparse for the CPU baseline (single device; see ddt_oracle.c) */
 int orc_score_sparse_fast(const orc_params* p, const void* node_lines, size_t n_lines, const uint64_t* tree_first_line,
                           const void* tuple_lines, size_t n_tuples, float* out, int sum_mode, int nthreads);

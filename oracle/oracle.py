@@ -86,6 +86,8 @@ def lib():
         L.orc_sparse_mean_depth.restype, L.orc_sparse_mean_depth.argtypes = C.c_double, [PP, vp, vp, vp, sz]
         L.orc_score_sparse.restype = C.c_int
         L.orc_score_sparse.argtypes = [PP, vp, sz, vp, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int]
+        L.orc_classify_sparse.restype = C.c_int
+        L.orc_classify_sparse.argtypes = [PP, vp, sz, vp, vp, sz, u32, C.c_int, C.c_int, C.c_int, vp, vp]
         L.orc_score_sparse_fast.restype = C.c_int
         L.orc_score_sparse_fast.argtypes = [PP, vp, sz, vp, vp, sz, vp, C.c_int, C.c_int]
         L.orc_sparse_from_perfect.restype, L.orc_sparse_from_perfect.argtypes = None, [PP, vp, vp, vp, vp]
@@ -333,6 +335,20 @@ def score_sparse_fast(s: SparseModel, tuples: np.ndarray, sum_mode: int = SUM_RE
     if rc:
         raise ValueError(f"orc_score_sparse_fast rc={rc}")
     return out
+
+
+def classify_sparse(s: SparseModel, tuples: np.ndarray, num_classes: int, interleaved: bool = True,
+                    sum_mode: int = SUM_REF_FLOPOCO, n_devices: int = 1):
+    """-> (labels int32 [n], class_scores fp32 [K, n])"""
+    t = np.ascontiguousarray(tuples, np.uint32)
+    n = t.shape[0]
+    labels = np.zeros(n, np.int32)
+    cs = np.zeros((num_classes, n), np.float32)
+    rc = lib().orc_classify_sparse(C.byref(s.params), _p(s.node_lines), s.n_lines, _p(s.first), _p(t), n, num_classes,
+                                   int(interleaved), sum_mode, n_devices, _p(labels), _p(cs))
+    if rc:
+        raise ValueError(f"orc_classify_sparse rc={rc}")
+    return labels, cs
 
 
 def traverse_sparse(s: SparseModel, tuple_row: np.ndarray, tree: int) -> int:

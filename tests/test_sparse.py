@@ -68,6 +68,18 @@ def test_cpu_baseline_form_of_the_sparse_oracle_is_identical(shape):
         assert np.array_equal(_bits(O.score_sparse(s, x, sum_mode=mode)), _bits(O.score_sparse_fast(s, x, sum_mode=mode))), (shape, mode)
 
 
+def test_sparse_classes_oracle_equals_padded_perfect_oracle():
+    """orc_classify_sparse == pad_to_perfect + orc_classify (labels and per-class sums), both class layouts, sharded too"""
+    for (T, D, F, K, inter) in [(30, 10, 12, 3, True), (24, 7, 9, 4, False), (21, 12, 20, 7, True)]:
+        s = O.gen_sparse_model(T, D, F, 3, 650, 1, clusters=1)
+        x = O.gen_tuples(5, 600, F, 1)
+        m = O.sparse_to_perfect(s)
+        for nd in (1, 2):
+            la, ca = O.classify_sparse(s, x, K, inter, n_devices=nd)
+            lb, cb = O.classify(m, x, K, inter, n_devices=nd)
+            assert np.array_equal(la, lb) and np.array_equal(_bits(ca), _bits(cb)), (T, K, inter, nd)
+
+
 def test_perfect_to_sparse_roundtrip():
     m = O.gen_model(37, 6, 28, 1)
     s = O.sparse_from_perfect(m)
@@ -234,6 +246,65 @@ def test_gpu_sparse_single_leaf_trees_and_clusters(eng):
         s = O.SparseModel(O.make_sparse_params(2, 2, 4, clusters=C_), lines, first)
         assert s.check() == 0
         assert np.array_equal(_bits(_gpu_sparse(eng, s, x)), _bits(O.score_sparse(s, x)))
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_classes(eng):
+    """one-vs-all classes in a sparse stream: per-class sums bit-exact, labels exact; class shards + chain add; host path"""
+    import torch
+
+    for (T, D, F, K, inter) in [(30, 10, 12, 3, True), (24, 7, 9, 4, False), (70, 13, 33, 10, True)]:
+        s = O.gen_sparse_model(T, D, F, 3, 650, 1, clusters=1)
+        x = O.gen_tuples(5, 1500, F, 1)
+        want_l, want_s = O.classify_sparse(s, x, K, inter)
+        p = ddt.make_sparse_params(T, D, F, clusters=1)
+        eng.load_model_sparse(p, s.node_lines, s.first, 0, 1, K, inter)
+        d = torch.from_numpy(x.view(np.int32)).cuda()
+        gl, gs = eng.classify_device(d)
+        torch.cuda.synchronize()
+        assert np.array_equal(gl.cpu().numpy(), want_l) and np.array_equal(_bits(gs.cpu().numpy()), _bits(want_s)), (T, K, inter)
+        hl, hs = eng.classify(x, want_scores=True)
+        assert np.array_equal(hl, want_l) and np.array_equal(_bits(hs), _bits(want_s))
+        with pytest.raises(ddt.DDTError):
+            eng.score_device(d)  # the scalar call refuses a model with classes
+        # two class shards, chain-added per class, then the argmax
+        parts = []
+        for g in range(2):
+            eng.load_model_sparse(p, s.node_lines, s.first, g, 2, K, inter)
+            parts.append(eng.classify_device(d, want_labels=False)[1])
+        comb = torch.stack([eng.chain_sum_device(torch.stack([parts[0][k], parts[1][k]])) for k in range(K)])
+        lab = eng.argmax_device(comb.contiguous())
+        wl2, ws2 = O.classify_sparse(s, x, K, inter, n_devices=2)
+        assert np.array_equal(lab.cpu().numpy(), wl2) and np.array_equal(_bits(comb.cpu().numpy()), _bits(ws2))
+
+
+@pytest.mark.gpu
+def test_gpu_real_random_forest_classifier_sparse(eng):
+    """a scikit-learn RandomForestClassifier (deep, ragged trees) imported as a sparse one-vs-all model: class scores bit-exact
+    with the oracle, labels equal to scikit-learn's predict wherever its winning margin is not a rounding tie"""
+    import torch
+    from sklearn.ensemble import RandomForestClassifier
+
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(6000, 20)).astype(np.float32)
+    y = (np.digitize(X[:, 0] + 0.5 * X[:, 1] * X[:, 2], [-0.8, 0.0, 0.8])).astype(np.int64)  # 4 classes
+    rf = RandomForestClassifier(n_estimators=40, max_depth=14, random_state=1, n_jobs=-1).fit(X, y)
+    im = ddt.importer.from_sklearn(rf, sparse=True)
+    assert im.sparse and im.num_classes == 4 and im.num_trees == 160
+    Xt = rng.normal(size=(3000, 20)).astype(np.float32)
+    xs = O.tuples_from_float(Xt)
+    im.load_into(eng)
+    assert eng.num_classes == 4
+    gl, gs = eng.classify_device(torch.from_numpy(xs.view(np.int32)).cuda())
+    torch.cuda.synchronize()
+    s = O.SparseModel(O.make_sparse_params(160, im.num_levels, 20, cmp_mode=1, clusters=1), im.node_lines, im.tree_first_line)
+    want_l, want_s = O.classify_sparse(s, xs, 4)
+    assert np.array_equal(gl.cpu().numpy(), want_l) and np.array_equal(_bits(gs.cpu().numpy()), _bits(want_s))
+    proba = rf.predict_proba(Xt)
+    assert np.max(np.abs(gs.cpu().numpy().T.astype(np.float64) - proba)) <= 1e-5
+    top2 = np.sort(proba, axis=1)
+    clear = top2[:, -1] - top2[:, -2] > 1e-5
+    assert clear.mean() > 0.9 and np.array_equal(gl.cpu().numpy()[clear], rf.predict(Xt)[clear])
 
 
 @pytest.mark.gpu
