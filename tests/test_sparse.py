@@ -342,11 +342,11 @@ def test_gpu_real_random_forest_512_depth16_64_features(eng):
     without padding, scored bit-exact against the sparse oracle and within 1e-5 of scikit-learn's own prediction."""
     import torch
 
-    rf, X = _rf(512, 16, F=64, n=20000, seed=4)
+    rf, X = _rf(512, 16, F=64, n=8000, seed=4)
     im = ddt.importer.from_sklearn(rf, sparse=True)
     assert im.num_levels == 16 and im.num_trees == 512
     n_nodes = im.node_lines.shape[0]
-    assert n_nodes < 512 * 20000  # nowhere near the 2^16 internal nodes per tree of the padded form
+    assert n_nodes < 512 * 8000  # nowhere near the 2^16 internal nodes per tree of the padded form
     rng = np.random.default_rng(9)
     Xt = rng.normal(size=(6000, 64)).astype(np.float32)
     Xt[rng.random(Xt.shape) < 0.01] = np.nan  # missing values (canonical quiet NaN) exercise the per-node default direction

@@ -6,7 +6,7 @@ tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p "$out"
 if [ "${1:-}" != "--no-tests" ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q > "$out/gpu_tests.log" 2>&1
+  timeout 1200 python -m pytest tests -m gpu -x -q --durations=8 > "$out/gpu_tests.log" 2>&1
   echo "gpu tests rc=$?" | tee -a "$out/gpu_tests.log"
   tail -5 "$out/gpu_tests.log"
 else
