@@ -35,6 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "distributed-decisiontrees_amd"))
 sys.path.insert(0, ROOT)
 
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL / tensor sharing fail with the legacy mode); the launcher
+# normally exports it already -- set before the HIP runtime is loaded, never overriding an explicit choice
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
