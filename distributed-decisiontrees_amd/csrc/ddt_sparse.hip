@@ -121,7 +121,6 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
 template <int K, int U, int THREADS>
 __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 12 << K;          // bytes of one tree's top image
-  constexpr int GROUPB = 8 * TOPB;       // one PU group
   constexpr int STEPB = U * TOPB;  // top images resident per pass: U trees walked in lock-step = U independent load chains per lane
   constexpr int ROW = THREADS * 4;
   constexpr int FEAT_OFF = (STEPB + ROW - 1) / ROW * ROW;
