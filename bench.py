@@ -286,7 +286,8 @@ def main():
         ref = cpu_score(xs)
         cdt = time.perf_counter() - t1
         cpu = {"value": round(rows / cdt / 1e6, 4), "unit": "Mtuples/s", "cores": O.hw_threads(), "kind": "port",
-               "sample": f"first {rows} rows of the same synthetic batch, all {T} trees, OpenMP over row blocks, "
+               "sample": f"first {rows} rows of the same synthetic batch, all {T} trees, OpenMP over row blocks on {O.hw_threads()} threads "
+                         f"(= the CPUs this process may use: affinity mask and cgroup quota, of {os.cpu_count()} logical CPUs on the box), "
                          f"{cdt:.1f} s ({what}; a CPU restatement of the reference RTL semantics, the reference has no CPU scorer)"}
         got = (labels if classes > 1 else out)[:rows].cpu().numpy()
         parity = {"rows_checked": rows, "bit_exact": bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32))),

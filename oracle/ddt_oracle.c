@@ -9,8 +9,11 @@
  * This file restates the RTL's scoring semantics; each function cites the lines it follows.
  * All paths below are relative to /root/reference/rtl/DTEngine/.
  */
+#define _GNU_SOURCE
 #include "ddt_oracle.h"
 
+#include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -306,12 +309,31 @@ uint32_t orc_reduce_device(const uint32_t* leaves, uint32_t num_trees, uint32_t 
  * 5. Batch scoring
  * ============================================================================================= */
 
+/* Threads the batch scorers use by default = CPUs this process may actually run on: the OpenMP default, capped by the
+ * scheduler affinity mask and by the cgroup CPU quota (a container with `cpu.max = 1600000 100000` gets 16 CPUs' worth of
+ * time however many logical CPUs the box shows; running 128 threads under that quota is slower than running 16). */
 int orc_hw_threads(void) {
+  int n = 1;
 #ifdef _OPENMP
-  return omp_get_max_threads();
-#else
-  return 1;
+  n = omp_get_max_threads();
 #endif
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const int a = CPU_COUNT(&set);
+    if (a > 0 && a < n) n = a;
+  }
+  FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f) {
+    long long quota = -1, period = 0;
+    char first[32] = {0};
+    if (fscanf(f, "%31s %lld", first, &period) == 2 && strcmp(first, "max") != 0) quota = atoll(first);
+    fclose(f);
+    if (quota > 0 && period > 0) {
+      const int q = (int)((quota + period - 1) / period);
+      if (q > 0 && q < n) n = q;
+    }
+  }
+  return n > 0 ? n : 1;
 }
 
 static int check_params(const orc_params* p, size_t n_wlines, size_t n_flines) {
@@ -347,7 +369,7 @@ int orc_score_shard(const orc_params* p, const void* wl, size_t n_wlines, const 
   const uint32_t* t = (const uint32_t*)tl;
   const uint32_t tw = orc_tuple_lines(p->num_features) * 4u, nloc = tree_end - tree_begin;
 #ifdef _OPENMP
-  if (nthreads <= 0) nthreads = omp_get_max_threads();
+  if (nthreads <= 0) nthreads = orc_hw_threads();
 #pragma omp parallel num_threads(nthreads)
 #endif
   {
@@ -378,7 +400,7 @@ int orc_score(const orc_params* p, const void* wl, size_t n_wlines, const void* 
   const uint32_t T = p->num_trees, tw = orc_tuple_lines(p->num_features) * 4u;
   const uint32_t per_dev = (T + (uint32_t)n_devices - 1u) / (uint32_t)n_devices; /* PCIeReceiver.sv:241-264 */
 #ifdef _OPENMP
-  if (nthreads <= 0) nthreads = omp_get_max_threads();
+  if (nthreads <= 0) nthreads = orc_hw_threads();
 #pragma omp parallel num_threads(nthreads)
 #endif
   {
@@ -426,7 +448,7 @@ int orc_classify(const orc_params* p, const void* wl, size_t n_wlines, const voi
   const uint32_t* t = (const uint32_t*)tl;
   const uint32_t T = p->num_trees, tw = orc_tuple_lines(p->num_features) * 4u;
 #ifdef _OPENMP
-#pragma omp parallel
+#pragma omp parallel num_threads(orc_hw_threads())
 #endif
   {
     uint32_t* leaves = (uint32_t*)malloc(sizeof(uint32_t) * T);
@@ -556,7 +578,7 @@ int orc_score_fast(const orc_params* p, const void* wl, size_t n_wlines, const v
   enum { RB = 256 }; /* rows per block: 32 KB of tuples at 32 features; a PU group (8 trees, 16 KB at depth 8) is walked
                         for the whole block out of L1 / L2 before the next group is touched */
 #ifdef _OPENMP
-  if (nthreads <= 0) nthreads = omp_get_max_threads();
+  if (nthreads <= 0) nthreads = orc_hw_threads();
 #pragma omp parallel num_threads(nthreads)
 #endif
   {
@@ -698,7 +720,7 @@ int orc_score_sparse(const orc_params* p, const void* nl, size_t n_lines, const 
   const uint32_t T = p->num_trees, tw = orc_tuple_lines(p->num_features) * 4u;
   const uint32_t per_dev = (T + (uint32_t)n_devices - 1u) / (uint32_t)n_devices;
 #ifdef _OPENMP
-  if (nthreads <= 0) nthreads = omp_get_max_threads();
+  if (nthreads <= 0) nthreads = orc_hw_threads();
 #pragma omp parallel num_threads(nthreads)
 #endif
   {
@@ -748,7 +770,7 @@ int orc_score_sparse_fast(const orc_params* p, const void* nl, size_t n_lines, c
   const uint32_t T = p->num_trees, tw = orc_tuple_lines(p->num_features) * 4u, miss = p->missing_bits, mode = p->cmp_mode;
   enum { RB = 1024 };
 #ifdef _OPENMP
-  if (nthreads <= 0) nthreads = omp_get_max_threads();
+  if (nthreads <= 0) nthreads = orc_hw_threads();
 #pragma omp parallel num_threads(nthreads)
 #endif
   {
@@ -844,7 +866,7 @@ int orc_classify_sparse(const orc_params* p, const void* nl, size_t n_lines, con
   const uint32_t* t = (const uint32_t*)tl;
   const uint32_t T = p->num_trees, tw = orc_tuple_lines(p->num_features) * 4u;
 #ifdef _OPENMP
-#pragma omp parallel
+#pragma omp parallel num_threads(orc_hw_threads())
 #endif
   {
     uint32_t* leaves = (uint32_t*)malloc(sizeof(uint32_t) * T);
