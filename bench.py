@@ -246,7 +246,10 @@ def main():
             roofline["vmem_ceiling_gathers_per_s"] = info.num_cus * clock_hz
         else:
             t_local = info.tree_end - info.tree_begin
-            roofline["binding_resource"] = "LDS gather pipe (2 DS ops per node visit) + VALU issue, not HBM"
+            if ach / HBM_PEAK_GBS > 0.3:
+                roofline["binding_resource"] = "HBM: the tuple stream (each tuple read once, each score written once)"
+            else:
+                roofline["binding_resource"] = "LDS gather pipe (2 DS ops per node visit) + VALU issue, not HBM"
             roofline["node_visits_per_s"] = round(N * t_local * D / (k_ms * 1e-3), 1)
             # 2 conflict-free DS wave-instructions per 64 visits at 2 LDS cycles each (MI355X_MICROARCH.md, LDS table)
             roofline["lds_ceiling_visits_per_s"] = info.num_cus * clock_hz * 64 / 4
