@@ -141,21 +141,21 @@ RankTables rank_tables(const ddt_engine* e) {
 // of a group = per feature a skewed table of K + P keys (INT_MAX pads), then the bucket starts, then 8 parameter
 // words per feature {K, lo, shift, table byte offset, starts byte offset, 0, 0, 0}; the images are concatenated.
 // Returns false when even G = 2 does not fit (plan.groups = 0); `fimg` may be NULL to only ask the question.
-bool build_fused_group(const RankTables& rt, uint32_t f0, uint32_t f1, std::vector<uint32_t>* img, uint32_t* par_off, uint32_t* P_out) {
+bool build_fused_group(const RankTables& rt, uint32_t f0, uint32_t f1, uint32_t nb, std::vector<uint32_t>* img, uint32_t* par_off, uint32_t* P_out) {
   const uint32_t nf = f1 - f0;
   std::vector<uint32_t> tab_off(nf), cnt, lo(nf, 0x7FFFFFFFu), shift(nf, 0u);
-  std::vector<std::vector<uint16_t>> starts(nf, std::vector<uint16_t>(kQ16FusedBuckets, 0));
+  std::vector<std::vector<uint16_t>> starts(nf, std::vector<uint16_t>(nb, 0));
   uint32_t P = 1;
   for (uint32_t j = 0; j < nf; ++j) {
     const std::vector<uint32_t>& k = rt.keys[f0 + j];
     if (k.empty()) continue;
     lo[j] = k.front();
     const uint32_t span = k.back() - k.front();  // int32 order: the difference fits 32 bits
-    while ((span >> shift[j]) >= kQ16FusedBuckets) ++shift[j];
-    cnt.assign(kQ16FusedBuckets, 0u);
+    while ((span >> shift[j]) >= nb) ++shift[j];
+    cnt.assign(nb, 0u);
     for (uint32_t key : k) ++cnt[(key - lo[j]) >> shift[j]];
     uint32_t run = 0;
-    for (uint32_t b = 0; b < kQ16FusedBuckets; ++b) {
+    for (uint32_t b = 0; b < nb; ++b) {
       starts[j][b] = (uint16_t)run;
       run += cnt[b];
       while (P <= cnt[b]) P <<= 1;  // strictly more than the fullest bucket
@@ -169,7 +169,7 @@ bool build_fused_group(const RankTables& rt, uint32_t f0, uint32_t f1, std::vect
   }
   words = (words + 3u) & ~(size_t)3u;
   const size_t starts_word0 = words;
-  words += (size_t)nf * kQ16FusedBuckets / 2u;
+  words += (size_t)nf * nb / 2u;
   const uint32_t poff = (uint32_t)words * 4u;
   words += (size_t)nf * 8u;
   if (words * 4u > kMaxLdsBytes) return false;
@@ -180,14 +180,14 @@ bool build_fused_group(const RankTables& rt, uint32_t f0, uint32_t f1, std::vect
   for (uint32_t j = 0; j < nf; ++j) {
     const std::vector<uint32_t>& k = rt.keys[f0 + j];
     for (uint32_t i = 0; i < k.size(); ++i) (*img)[tab_off[j] / 4u + i + (i >> 5)] = k[i];
-    uint16_t* S = reinterpret_cast<uint16_t*>(img->data() + starts_word0) + (size_t)j * kQ16FusedBuckets;
+    uint16_t* S = reinterpret_cast<uint16_t*>(img->data() + starts_word0) + (size_t)j * nb;
     std::copy(starts[j].begin(), starts[j].end(), S);
     uint32_t* Pp = img->data() + poff / 4u + (size_t)j * 8u;
     Pp[0] = (uint32_t)k.size();
     Pp[1] = lo[j];
     Pp[2] = shift[j];
     Pp[3] = tab_off[j];
-    Pp[4] = (uint32_t)(starts_word0 * 4u) + j * kQ16FusedBuckets * 2u;
+    Pp[4] = (uint32_t)(starts_word0 * 4u) + j * nb * 2u;
     Pp[5] = Pp[6] = Pp[7] = 0u;
   }
   return true;
@@ -204,7 +204,7 @@ bool build_fused_image(const RankTables& rt, uint32_t W, std::vector<uint32_t>* 
     for (uint32_t g = 0; g < G && ok; ++g) {
       const uint32_t f0 = g * lines * 4u < W ? g * lines * 4u : W, f1 = (g + 1u) * lines * 4u < W ? (g + 1u) * lines * 4u : W;
       if (f0 == f1) continue;  // narrow tuples: trailing groups are empty
-      ok = build_fused_group(rt, f0, f1, fimg ? &imgs[used] : nullptr, &pl.par_off[used], &pl.P[used]);
+      ok = build_fused_group(rt, f0, f1, kQ16FusedBuckets, fimg ? &imgs[used] : nullptr, &pl.par_off[used], &pl.P[used]);
       pl.line_lo[used] = g * lines;
       pl.line_hi[used] = (g + 1u) * lines;
       ++used;
@@ -223,6 +223,44 @@ bool build_fused_image(const RankTables& rt, uint32_t W, std::vector<uint32_t>* 
     pl.groups = used;
     *plan = pl;
     return true;
+  }
+  return false;
+}
+
+// Grouped pre-pass (grouped_rank_kernel, ddt_internal.h GroupedPlan): tables too big to sit in LDS together.  G = 4 or 8
+// groups of 2 / 1 tuple lines, as many bucket starts per feature as still fit (more buckets = fewer probes); the image
+// of a group has the fused layout.  Returns false when not even one line's tables fit (then: transpose + rank kernels).
+bool build_grouped_image(const RankTables& rt, uint32_t W, std::vector<uint32_t>* gimg, GroupedPlan* plan) {
+  plan->groups = 0;
+  for (uint32_t G = 4; G <= kQ16GroupedMaxGroups; G <<= 1) {
+    const uint32_t lines = 8u / G;
+    for (uint32_t nb = 4096; nb >= 256u; nb >>= 1) {
+      GroupedPlan pl{};
+      std::vector<std::vector<uint32_t>> imgs(G);
+      bool ok = true;
+      uint32_t used = 0;
+      for (uint32_t g = 0; g < G && ok; ++g) {
+        const uint32_t f0 = g * lines * 4u < W ? g * lines * 4u : W, f1 = (g + 1u) * lines * 4u < W ? (g + 1u) * lines * 4u : W;
+        if (f0 == f1) continue;  // narrow tuples: trailing groups are empty
+        ok = build_fused_group(rt, f0, f1, nb, gimg ? &imgs[used] : nullptr, &pl.par_off[used], &pl.P[used]);
+        pl.line_lo[used] = g * lines;
+        ++used;
+      }
+      if (!ok || used == 0) continue;
+      if (gimg) {
+        gimg->clear();
+        for (uint32_t g = 0; g < used; ++g) {
+          pl.img_off[g] = (uint32_t)(gimg->size() * 4u);
+          pl.bytes[g] = (uint32_t)(imgs[g].size() * 4u);
+          gimg->insert(gimg->end(), imgs[g].begin(), imgs[g].end());
+        }
+      }
+      pl.groups = used;
+      pl.lines = lines;
+      pl.nb = nb;
+      *plan = pl;
+      return true;
+    }
   }
   return false;
 }
@@ -301,7 +339,7 @@ int auto_variant(const ddt_engine* e) {
 
 void free_images(ddt_engine* e) {
   for (Ensemble& m : e->ens) {
-    for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_fused}) {
+    for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_fused, &m.d_grouped}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
@@ -422,7 +460,12 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
   }
   std::vector<uint32_t> fimg;
   FusedPlan fplan{};
-  if (upload_tables) (void)build_fused_image(rt, W, &fimg, &fplan);
+  std::vector<uint32_t> gimg;
+  GroupedPlan gplan{};
+  if (upload_tables) {
+    (void)build_fused_image(rt, W, &fimg, &fplan);
+    if (!fplan.groups && W <= 32u) (void)build_grouped_image(rt, W, &gimg, &gplan);
+  }
   const uint32_t row = v.tile() * 2u;  // bytes per feature row of the u16 tile
   for (uint32_t i = 0; i < T; ++i) {
     uint32_t* t = fast.data() + (size_t)i * tree_words;
@@ -438,7 +481,7 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
   for (uint32_t i = 0; i < T; ++i)
     for (uint32_t n = 0; n < nint; ++n)
       if (m.mright[(size_t)i * nint + n]) slow[(size_t)i * tree_words + n + 1] |= 1u << 16;
-  for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_fused}) {
+  for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_fused, &m.d_grouped}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -462,6 +505,12 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
       HIP_TRY(e, hipMemcpy(m.d_fused, fimg.data(), fimg.size() * 4, hipMemcpyHostToDevice));
       m.fused = fplan;
     }
+    m.grouped = GroupedPlan{};
+    if (gplan.groups && !gimg.empty()) {
+      HIP_TRY(e, hipMalloc(&m.d_grouped, gimg.size() * 4));
+      HIP_TRY(e, hipMemcpy(m.d_grouped, gimg.data(), gimg.size() * 4, hipMemcpyHostToDevice));
+      m.grouped = gplan;
+    }
   }
   m.img_bytes = bytes;
   m.img_trees = Tpad;
@@ -475,7 +524,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint64_t rows = (n + 1023) / 1024 * 1024;
   const int k = e->q_slot;
   // the transposed fp32 intermediate is only needed by the two-kernel pre-pass
-  const bool need_xT = !(e->q16_fused_prepass && !e->ens.empty() && e->ens[0].fused.groups);
+  const bool need_xT = !(!e->ens.empty() && ((e->q16_fused_prepass && e->ens[0].fused.groups) || (e->q16_grouped_prepass && e->ens[0].grouped.groups)));
   if (rows <= e->q_rows[k] && (!need_xT || e->q_xT[k])) return DDT_OK;
   HIP_TRY(e, hipDeviceSynchronize());
   for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k]}) {
@@ -487,7 +536,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint32_t W = tuple_words(e->p);
   if (need_xT) HIP_TRY(e, hipMalloc(&e->q_xT[k], cap * W * 4));
   HIP_TRY(e, hipMalloc(&e->q_q[k], cap * W * 2));
-  HIP_TRY(e, hipMalloc(&e->q_flags[k], (cap / 1024 + 10) * 4));  // + the fused pre-pass's 8-byte work counters (<= 4)
+  HIP_TRY(e, hipMalloc(&e->q_flags[k], (cap / 1024 + 2 + 2 * kQ16GroupedCounters) * 4));  // + the 8-byte work counters of the fused / grouped pre-pass
   e->q_rows[k] = cap;
   return DDT_OK;
 }
@@ -585,6 +634,9 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     qa.fused_img = reinterpret_cast<const uint4*>(tm.d_fused);
     qa.fused = tm.fused;
     if (!e->q16_fused_prepass) qa.fused.groups = 0;
+    qa.grouped_img = reinterpret_cast<const uint4*>(tm.d_grouped);
+    qa.grouped = tm.grouped;
+    if (!e->q16_grouped_prepass) qa.grouped.groups = 0;
     qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
     qa.n_pad = (n + 1023) / 1024 * 1024;
     a.aux = &qa;
@@ -1079,6 +1131,10 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   }
   if (!strcmp(key, "kernel_timing")) {
     e->kernel_timing = value != 0;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "q16_grouped_prepass")) {  // 0: big tables go through the transpose + rank kernels (A/B and tests); default 1
+    e->q16_grouped_prepass = value != 0;
     return DDT_OK;
   }
   if (!strcmp(key, "q16_fused_prepass")) {  // 0: always transpose + rank kernels (A/B and tests); default 1

@@ -39,6 +39,8 @@ struct Ensemble {
   void* d_tabS = nullptr;   // q16: bucket starts (Q16Aux::tabS)
   void* d_fused = nullptr;  // q16, small tables: LDS image of the fused pre-pass (Q16Aux::fused_img)
   FusedPlan fused;          // geometry of that image (groups of features, one launch per group)
+  void* d_grouped = nullptr;  // q16, big tables: LDS images of the grouped pre-pass (Q16Aux::grouped_img)
+  GroupedPlan grouped;
   uint32_t Kpad = 0;
   uint32_t trees() const { return (uint32_t)ids.size(); }
 };
@@ -97,6 +99,7 @@ struct ddt_engine {
   void* q_flags[3] = {nullptr, nullptr, nullptr};
   uint64_t q_rows[3] = {0, 0, 0};  // capacity in rows (multiple of 1024)
   int q_slot = 0;
+  int q16_grouped_prepass = 1;  // option "q16_grouped_prepass": 0 sends big tables through the transpose + rank kernels
   int q16_fused_prepass = 1;  // option "q16_fused_prepass": 0 forces the transpose + rank kernels (A/B, tests)
   // optional per-call kernel timing (option "kernel_timing"): start / before scoring kernel / end
   bool kernel_timing = false, timing_pending = false;

@@ -56,6 +56,18 @@ struct FusedPlan {
   uint32_t line_lo[4] = {0, 0, 0, 0}, line_hi[4] = {0, 0, 0, 0};
 };
 
+// grouped rank pre-pass (big tables, e.g. 1000 trees: ~8 k keys per feature): ONE launch in which the blocks are split over
+// `groups` feature groups of `lines` tuple lines (4 features each) -- a block keeps the tables of its group resident in LDS
+// (image = bytes[g] at byte offset img_off[g] of Q16Aux::grouped_img) -- and over `parts` row partitions (= XCDs: the blocks
+// of all groups that work on the same rows share one L2, so a tuple row leaves HBM once although every group reads it)
+constexpr uint32_t kQ16GroupedMaxGroups = 8;
+struct GroupedPlan {
+  uint32_t groups = 0, lines = 0, nb = 0;  // nb = bucket starts per feature (power of two)
+  uint32_t img_off[kQ16GroupedMaxGroups] = {}, bytes[kQ16GroupedMaxGroups] = {}, par_off[kQ16GroupedMaxGroups] = {}, P[kQ16GroupedMaxGroups] = {};
+  uint32_t line_lo[kQ16GroupedMaxGroups] = {};
+};
+constexpr uint32_t kQ16GroupedCounters = 64;  // 8-byte work counters behind the tile flags: one per (group, part)
+
 struct Q16Aux {               // device pointers of the rank-quantised path (ScoreArgs::aux)
   uint32_t* xT;               // workspace [W][n_pad]: transposed tuples
   uint16_t* q;                // workspace [tiles][W][1024]: feature ranks
@@ -68,7 +80,9 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   uint64_t n_pad;             // rows rounded up to whole tiles of 1024
   uint32_t skip_prepass;      // 1 = q / tile_flags already hold this batch (2nd..Kth class of a multi-class model)
   const uint4* fused_img;     // fused pre-pass: concatenated LDS images of fused_rank_kernel, one per feature group
-  FusedPlan fused;            // groups == 0: use transpose_kernel + rank_kernel
+  FusedPlan fused;            // groups == 0: use grouped_rank_kernel, else transpose_kernel + rank_kernel
+  const uint4* grouped_img;   // grouped pre-pass: concatenated LDS images, one per feature group
+  GroupedPlan grouped;        // groups == 0: use transpose_kernel + rank_kernel
 };
 
 // ---------------------------------------------------------------------------------------------------

@@ -573,6 +573,57 @@ __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __re
 // barrier after the image load, the 16 waves of the block drift apart and cover each other's load latency, and
 // blocks that start late (CUs busy with another stream's kernels, e.g. RCCL) simply take fewer units.
 // ---------------------------------------------------------------------------------------------------
+// One tuple line (4 features) of two rows against the tables resident in LDS: 8 searches advance together (the
+// dependent LDS reads of one search are latency bound).  `par` = LDS byte address of the line's first parameter
+// block {K, lo, shift, table byte offset, starts byte offset, 0, 0, 0}; nb = bucket starts per feature (power of two).
+// Returns r(row0) | r(row1) << 16 per feature; in0 / in1 = the row exists (a missing value only counts there).
+__device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P, const uint32_t nb, const uint32_t ieee, const uint32_t miss_raw,
+                                           const bool in0, const bool in1, const u32x4& v0, const u32x4& v1, bool& any_missing) {
+  uint32_t K[4], tab[4], raw[4][2], pos[4][2];
+  int32_t x[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint4 pr = lds_u4(par + (uint32_t)c * 32u);  // same address in every lane: {K, lo, shift, table_off}
+    const uint32_t st = lds_u32(par + (uint32_t)c * 32u + 16u);
+    K[c] = pr.x;
+    tab[c] = pr.w;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      raw[c][h] = h ? v1[c] : v0[c];
+      x[c][h] = (int32_t)(ieee ? ieee_key(raw[c][h]) : raw[c][h]);
+      uint32_t bk = ((uint32_t)x[c][h] - pr.y) >> pr.z;  // wraps to a huge value below lo: selected away next
+      bk = bk < nb - 1u ? bk : nb - 1u;
+      bk = x[c][h] < (int32_t)pr.y ? 0u : bk;
+      pos[c][h] = *reinterpret_cast<const DDT_LDS(uint16_t)*>(st + bk * 2u);
+    }
+  }
+  for (uint32_t step = P >> 1; step >= 1u; step >>= 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t probe = pos[c][h] + step - 1u;  // < K + P: inside the padded table
+        if ((int32_t)lds_u32(tab[c] + (probe + (probe >> 5)) * 4u) <= x[c][h]) pos[c][h] += step;
+      }
+    }
+  }
+  u32x4 out;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    uint32_t r[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      r[h] = pos[c][h] < K[c] ? pos[c][h] : K[c];
+      if (raw[c][h] == miss_raw && (h ? in1 : in0)) {  // DTPU.sv:653, bit equality before any transform
+        r[h] = kQMissing;
+        any_missing = true;
+      }
+    }
+    out[c] = r[0] | (r[1] << 16);
+  }
+  return out;
+}
+
 constexpr int kFusedThreads = 1024;  // two tiles per block and pass; 16 waves x 8 independent searches hide the LDS latency
 constexpr uint32_t kFusedBuckets = kQ16FusedBuckets;
 
@@ -611,49 +662,10 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
     for (int i = 0; i < 4; ++i) {
       const uint32_t line = 4u * g + (uint32_t)i;
       if (line >= lpt || line < line_lo || line >= line_hi) continue;  // this launch's feature group only
-      // the four features of this line x two rows: 8 searches advance together
-      uint32_t K[4], tab[4], raw[4][2], pos[4][2];
-      int32_t x[4][2];
+      const u32x4 r = rank_line(par_off + 4u * (line - line_lo) * 32u, P, kFusedBuckets, ieee, miss_raw, tile * kQTile + own < n,
+                                tile * kQTile + own + 512u < n, v[0][i], v[1][i], any_missing);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint32_t j = 4u * (line - line_lo) + (uint32_t)c;  // feature index inside the group
-        const uint4 par = lds_u4(par_off + j * 32u);  // same address in every lane: {K, lo, shift, table_off}
-        const uint32_t st = lds_u32(par_off + j * 32u + 16u);
-        K[c] = par.x;
-        tab[c] = par.w;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          raw[c][h] = v[h][i][c];
-          x[c][h] = (int32_t)(ieee ? ieee_key(raw[c][h]) : raw[c][h]);
-          uint32_t bk = ((uint32_t)x[c][h] - par.y) >> par.z;  // wraps to a huge value below lo: selected away next
-          bk = bk < kFusedBuckets - 1u ? bk : kFusedBuckets - 1u;
-          bk = x[c][h] < (int32_t)par.y ? 0u : bk;
-          pos[c][h] = *reinterpret_cast<const DDT_LDS(uint16_t)*>(st + bk * 2u);
-        }
-      }
-      for (uint32_t step = P >> 1; step >= 1u; step >>= 1) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const uint32_t probe = pos[c][h] + step - 1u;  // < K + P: inside the padded table
-            if ((int32_t)lds_u32(tab[c] + (probe + (probe >> 5)) * 4u) <= x[c][h]) pos[c][h] += step;
-          }
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        uint32_t r[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          r[h] = pos[c][h] < K[c] ? pos[c][h] : K[c];
-          if (raw[c][h] == miss_raw && tile * kQTile + own + 512u * (uint32_t)h < n) {  // DTPU.sv:653, before any transform
-            r[h] = kQMissing;
-            any_missing = true;
-          }
-        }
-        q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + own] = r[0] | (r[1] << 16);
-      }
+      for (int c = 0; c < 4; ++c) q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + own] = r[c];
     }
     return any_missing;
   };
@@ -679,6 +691,83 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
         u32x4 v[2][4];
         load_half(v, tile, lt, g);
         miss |= rank_half(v, tile, lt, g);
+      }
+    }
+    if (miss) atomicOr(&tile_flags[tile], 1u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Grouped pre-pass for BIG tables (1000 trees x 255 nodes over 32 features: ~8 k keys = 33 KiB per feature, 1 MiB in all):
+// no transposed fp32 intermediate either.  The features are cut into G = 4 or 8 groups of L = 2 or 1 tuple lines whose
+// tables fit one CU's LDS; ONE launch, block b works for group (b / parts) % G on the row partition b % parts
+// (workgroups go to the XCDs round-robin, so parts = 8 puts the blocks of all G groups that read the same rows behind the
+// same L2: a row is fetched from HBM once and the other G - 1 reads hit that L2 / the Infinity Cache).  HBM traffic
+// 4F + 2F bytes per tuple instead of 4F + 4F + 4F + 2F, and no [W][n] fp32 workspace.  A lane owns rows t and t+512 of
+// a tile and reads ITS line(s) of them directly (16-byte loads at a 128-byte stride; the neighbours in the row belong
+// to other groups), ranks 4 features x 2 rows in lock-step (rank_line) and stores one fully coalesced dword per feature.
+// Work = half tiles, handed to waves through one atomic counter per (group, part); the loads of the next 64 lane
+// pairs are in flight while the current ones are ranked.
+// ---------------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
+                                                                     const uint4* __restrict__ img_base, const GroupedPlan pl, uint32_t parts,
+                                                                     uint32_t miss_raw, uint32_t ieee, uint32_t* __restrict__ q32,
+                                                                     uint32_t* __restrict__ tile_flags, unsigned long long* __restrict__ counters) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, lpt = W / 4u;
+  const uint32_t part = blockIdx.x % parts, g = (blockIdx.x / parts) % pl.groups;
+  const uint64_t tiles = n_pad / kQTile;
+  const uint64_t tiles_part = tiles > part ? (tiles - part + parts - 1u) / parts : 0u;
+  if (tiles_part == 0u) return;
+  const uint32_t img_bytes = pl.bytes[g], par_off = pl.par_off[g], P = pl.P[g], line_lo = pl.line_lo[g], nb = pl.nb;
+  const uint4* __restrict__ img = img_base + pl.img_off[g] / 16u;
+  for (uint32_t off = tid * 16u; off < img_bytes; off += kFusedThreads * 16u) lds_st_u4(off, img[off / 16u]);
+  __syncthreads();
+  unsigned long long* __restrict__ counter = counters + g * parts + part;
+  const unsigned long long units = (unsigned long long)tiles_part * 8u;
+
+  auto load_unit = [&](u32x4 (&v)[L][2], uint64_t tile, uint32_t lt) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint64_t row = tile * kQTile + lt + 512u * (uint32_t)h;
+        const uint32_t line = line_lo + (uint32_t)l;
+        v[l][h] = (row < n && line < lpt) ? *reinterpret_cast<const u32x4*>(tuples + row * W + 4u * line) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+
+  for (;;) {
+    unsigned long long u0 = 0;
+    if (lane == 0u) u0 = atomicAdd(counter, 4ull);
+    u0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u0 >> 32)) << 32) |
+         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u0);
+    if (u0 >= units) break;
+    const uint64_t tile = (u0 >> 3) * parts + part;
+    const uint32_t lt0 = (((uint32_t)u0 & 7u) << 6) | lane;  // the 4 units of this grab: lt0, lt0 + 64, .. + 192 (< 512)
+    bool miss = false;
+    u32x4 cur[L][2], nxt[L][2];
+    load_unit(cur, tile, lt0);
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      const uint32_t lt = lt0 + 64u * k;
+      if (k + 1u < 4u) load_unit(nxt, tile, lt + 64u);
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        const uint32_t line = line_lo + (uint32_t)l;
+        if (line >= lpt) continue;  // narrow tuples: the last group may be short (wave-uniform)
+        const u32x4 r = rank_line(par_off + 4u * (uint32_t)l * 32u, P, nb, ieee, miss_raw, tile * kQTile + lt < n, tile * kQTile + lt + 512u < n,
+                                  cur[l][0], cur[l][1], miss);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + lt] = r[c];
+      }
+      if (k + 1u < 4u) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+          cur[l][0] = nxt[l][0];
+          cur[l][1] = nxt[l][1];
+        }
       }
     }
     if (miss) atomicOr(&tile_flags[tile], 1u);
@@ -796,9 +885,9 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds);
   if (e != hipSuccess) return e;
   if (!x.skip_prepass) {
-    // tile flags + (8-byte aligned, right behind them) one work counter per launch of the fused pre-pass
+    // tile flags + (8-byte aligned, right behind them) the work counters of the fused / grouped pre-pass
     unsigned long long* counter = reinterpret_cast<unsigned long long*>(x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u));
-    e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 8u) * 4, s);
+    e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters) * 4, s);
     if (e != hipSuccess) return e;
     if (x.fused.groups) {  // the tables of a feature group fit LDS: fused kernel(s), no transposed intermediate
       const uint32_t grid = (tiles + 1u) / 2u < a.num_cus ? (uint32_t)((tiles + 1u) / 2u) : a.num_cus;  // at most one block per CU
@@ -809,6 +898,22 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
                            x.fused_img + x.fused.img_off[g] / 16u, x.fused.bytes[g], x.fused.par_off[g], x.fused.P[g], x.fused.line_lo[g],
                            x.fused.line_hi[g], a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter + g);
       }
+    } else if (x.grouped.groups) {  // big tables: one launch, blocks split over feature groups x row partitions (XCDs)
+      const GroupedPlan& gp = x.grouped;
+      uint32_t lds = 0;
+      for (uint32_t g = 0; g < gp.groups; ++g) lds = gp.bytes[g] > lds ? gp.bytes[g] : lds;
+      // one block per CU (the image takes most of the LDS); 8 row partitions when every (group, partition) gets a block
+      const uint32_t parts = (a.num_cus >= 8u * gp.groups && tiles >= 8u) ? 8u : 1u;
+      uint32_t per_pair = a.num_cus / (parts * gp.groups);
+      if (per_pair < 1u) per_pair = 1u;
+      const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
+      if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
+      const uint32_t grid = parts * gp.groups * per_pair;
+      auto gk = gp.lines == 1u ? grouped_rank_kernel<1> : grouped_rank_kernel<2>;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(gk, dim3(grid), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.grouped_img, gp, parts, a.miss_raw, a.ieee,
+                         reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
     } else {
       hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
       uint32_t bx = (uint32_t)((x.n_pad / kQTile + 3) / 4);  // 4 tiles (kRankThreads x 4 rows) per block and pass

@@ -164,3 +164,24 @@ def test_fused_and_two_kernel_prepass_agree(cmp_mode):
         got = e.score(x)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"fused={fused}"
     e.close()
+
+
+@pytest.mark.parametrize("T,F", [(1000, 32), (400, 32), (700, 20), (900, 12), (320, 7)])
+def test_grouped_and_two_kernel_prepass_agree(T, F):
+    """Big tables (they do not fit one CU's LDS together): the grouped pre-pass (one launch, blocks split over feature
+    groups x row partitions, no transposed fp32 intermediate) and the transpose + rank kernels must give identical
+    scores -- missing values and negatives included, narrow tuples (short last group), batches of fewer than 8 tiles (one
+    row partition) and of more (8 partitions), ragged tails."""
+    D = 8
+    m = O.gen_model(T, D, F, dist=1)
+    e = ddt.Engine(0)
+    e.set_option("variant", _variant("q16_d8_c4_u4"))
+    for n in (1, 1500, 11 * 1024 + 77):
+        x = O.gen_tuples(41 + n, n, F, dist=1, missing_bits=m.params.missing_bits)
+        want = O.score(m, x)
+        for grouped in (1, 0):
+            e.set_option("q16_grouped_prepass", grouped)
+            e.load_model(_params(m), m.wlines, m.flines)
+            got = e.score(x)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"grouped={grouped} n={n}"
+    e.close()
