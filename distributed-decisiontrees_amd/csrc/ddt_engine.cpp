@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -136,138 +137,209 @@ RankTables rank_tables(const ddt_engine* e) {
   return rt;
 }
 
-// Fused pre-pass (fused_rank_kernel): the features are cut into G = 1 or 2 groups of 8 / 4 tuple lines
-// (32 / 16 features) such that the tables of ONE group fit a CU's LDS; one launch per group.  Exact LDS image
-// of a group = per feature a skewed table of K + P keys (INT_MAX pads), then the bucket starts, then 8 parameter
-// words per feature {K, lo, shift, table byte offset, starts byte offset, 0, 0, 0}; the images are concatenated.
-// Returns false when even G = 2 does not fit (plan.groups = 0); `fimg` may be NULL to only ask the question.
-bool build_fused_group(const RankTables& rt, uint32_t f0, uint32_t f1, uint32_t nb, std::vector<uint32_t>* img, uint32_t* par_off, uint32_t* P_out) {
-  const uint32_t nf = f1 - f0;
-  std::vector<uint32_t> tab_off(nf), cnt, lo(nf, 0x7FFFFFFFu), shift(nf, 0u);
-  std::vector<std::vector<uint16_t>> starts(nf, std::vector<uint16_t>(nb, 0));
-  uint32_t P = 1;
-  for (uint32_t j = 0; j < nf; ++j) {
-    const std::vector<uint32_t>& k = rt.keys[f0 + j];
-    if (k.empty()) continue;
-    lo[j] = k.front();
-    const uint32_t span = k.back() - k.front();  // int32 order: the difference fits 32 bits
-    while ((span >> shift[j]) >= nb) ++shift[j];
-    cnt.assign(nb, 0u);
-    for (uint32_t key : k) ++cnt[(key - lo[j]) >> shift[j]];
-    uint32_t run = 0;
-    for (uint32_t b = 0; b < nb; ++b) {
-      starts[j][b] = (uint16_t)run;
-      run += cnt[b];
-      while (P <= cnt[b]) P <<= 1;  // strictly more than the fullest bucket
-    }
+// LDS-resident rank pre-pass (fused_rank_kernel / grouped_rank_kernel, ddt_internal.h PrepassPlan).  The features are
+// cut into G = 1, 2, 4 or 8 groups of 8 / 4 / 2 / 1 tuple lines whose tables fit one CU's LDS.  Exact LDS image of a group:
+//   per feature  a skewed table of K + P keys (INT_MAX pads; entry i at word i + i/32)
+//   then         the bucket starts of all its features (u16: number of keys in the buckets below)
+//   then         per feature a segment table, kQ16Segments words {first bucket | log2(bucket width) << 16}
+//   then         per feature 8 parameter words {K, lo, span, table byte offset, starts byte offset, segment table byte
+//                offset, segment shift, 0}
+// Bucket index of a key: d = min(key - lo, span); segment = d >> segment shift (<= 32 equal slices of the key range);
+// bucket = first[segment] + ((d & segment mask) >> log2 width[segment]).  The bucket WIDTH is per segment: dense slices
+// of the key range get narrow buckets, sparse ones wide buckets (thresholds uniform in VALUE are exponentially dense in
+// IEEE key space -- with one global width half of them shared 1/13 of the buckets).  Widths are chosen greedily under
+// the LDS budget: keep halving the width of the segment that holds the fullest bucket; P = power of two above the
+// fullest bucket, so log2(P) probes from starts[bucket] finish the count.
+struct SegFeature {
+  uint32_t K = 0, lo = 0x7FFFFFFFu, span = 0, seg_shift = 0, nseg = 1;
+  uint32_t sh[kQ16Segments] = {};  // log2(bucket width) per segment
+};
+
+uint32_t seg_buckets(const SegFeature& f, uint32_t s) { return 1u << (f.seg_shift - f.sh[s]); }
+
+// fullest bucket of one segment (its keys, sorted) at bucket width 2^sh
+uint32_t seg_fullest(const std::vector<uint32_t>& keys, const SegFeature& f, uint32_t sh) {
+  uint32_t best = 0, run = 0, prev = 0xFFFFFFFFu;
+  const uint32_t mask = (1u << f.seg_shift) - 1u;  // seg_shift <= 27
+  for (uint32_t key : keys) {
+    const uint32_t b = ((key - f.lo) & mask) >> sh;
+    run = b == prev ? run + 1u : 1u;
+    prev = b;
+    best = run > best ? run : best;
   }
-  size_t words = 0;
-  for (uint32_t j = 0; j < nf; ++j) {
-    const uint32_t len = (uint32_t)rt.keys[f0 + j].size() + P;  // the search reads indices < K + P
-    tab_off[j] = (uint32_t)words * 4u;
-    words += len + (len >> 5) + 1u;
-  }
-  words = (words + 3u) & ~(size_t)3u;
-  const size_t starts_word0 = words;
-  words += (size_t)nf * nb / 2u;
-  const uint32_t poff = (uint32_t)words * 4u;
-  words += (size_t)nf * 8u;
-  if (words * 4u > kMaxLdsBytes) return false;
-  *par_off = poff;
-  *P_out = P;
-  if (!img) return true;
-  img->assign(words, 0x7FFFFFFFu);
-  for (uint32_t j = 0; j < nf; ++j) {
-    const std::vector<uint32_t>& k = rt.keys[f0 + j];
-    for (uint32_t i = 0; i < k.size(); ++i) (*img)[tab_off[j] / 4u + i + (i >> 5)] = k[i];
-    uint16_t* S = reinterpret_cast<uint16_t*>(img->data() + starts_word0) + (size_t)j * nb;
-    std::copy(starts[j].begin(), starts[j].end(), S);
-    uint32_t* Pp = img->data() + poff / 4u + (size_t)j * 8u;
-    Pp[0] = (uint32_t)k.size();
-    Pp[1] = lo[j];
-    Pp[2] = shift[j];
-    Pp[3] = tab_off[j];
-    Pp[4] = (uint32_t)(starts_word0 * 4u) + j * nb * 2u;
-    Pp[5] = Pp[6] = Pp[7] = 0u;
-  }
-  return true;
+  return best;
 }
 
-bool build_fused_image(const RankTables& rt, uint32_t W, std::vector<uint32_t>* fimg, FusedPlan* plan) {
+// one group (features [f0, f1)): returns false when it cannot fit kMaxLdsBytes; img may be NULL to only ask
+bool build_prepass_group(const RankTables& rt, uint32_t f0, uint32_t f1, std::vector<uint32_t>* img, uint32_t* par_off, uint32_t* P_out) {
+  const uint32_t nf = f1 - f0;
+  std::vector<SegFeature> F(nf);
+  std::vector<std::vector<std::vector<uint32_t>>> seg_keys(nf);  // keys of each (feature, segment)
+  for (uint32_t j = 0; j < nf; ++j) {
+    const std::vector<uint32_t>& k = rt.keys[f0 + j];
+    SegFeature& f = F[j];
+    f.K = (uint32_t)k.size();
+    if (!k.empty()) {
+      f.lo = k.front();
+      f.span = k.back() - k.front();  // int32 order: the difference fits 32 bits
+      while ((f.span >> f.seg_shift) >= kQ16Segments) ++f.seg_shift;
+      f.nseg = (f.span >> f.seg_shift) + 1u;
+    }
+    seg_keys[j].resize(f.nseg);
+    for (uint32_t key : k) seg_keys[j][(key - f.lo) >> f.seg_shift].push_back(key);
+  }
+  struct Item {
+    uint32_t full, j, s;
+  };
+  auto less_full = [](const Item& a, const Item& b) { return a.full < b.full; };
+  for (uint32_t P = 2; P <= 65536u; P <<= 1) {
+    // LDS left for the bucket starts once the tables carry P pads
+    size_t words = 0;
+    for (uint32_t j = 0; j < nf; ++j) {
+      const uint32_t len = F[j].K + P;
+      words += len + (len >> 5) + 1u;
+    }
+    words = (words + 3u) & ~(size_t)3u;
+    const size_t fixed = words * 4u + (size_t)nf * (kQ16Segments + 8u) * 4u + 32u;
+    if (fixed >= kMaxLdsBytes) return false;  // more pads only make it worse
+    const size_t budget = (kMaxLdsBytes - fixed) / 2u;  // u16 entries for the whole group
+    // one bucket per segment to start with, then keep halving the bucket width of the segment with the fullest bucket
+    size_t used = 0;
+    std::vector<Item> heap;
+    std::vector<size_t> feat_buckets(nf, 0);
+    for (uint32_t j = 0; j < nf; ++j)
+      for (uint32_t s = 0; s < F[j].nseg; ++s) {
+        F[j].sh[s] = F[j].seg_shift;
+        ++used;
+        ++feat_buckets[j];
+        heap.push_back({(uint32_t)seg_keys[j][s].size(), j, s});
+      }
+    if (used > budget) continue;
+    std::make_heap(heap.begin(), heap.end(), less_full);
+    bool ok = false;
+    for (;;) {
+      std::pop_heap(heap.begin(), heap.end(), less_full);
+      Item it = heap.back();
+      if (it.full < P) {  // the fullest bucket of the whole group holds fewer than P keys
+        ok = true;
+        break;
+      }
+      SegFeature& f = F[it.j];
+      const size_t cost = seg_buckets(f, it.s);  // halving the width adds as many buckets as the segment has
+      if (f.sh[it.s] == 0u || used + cost > budget || feat_buckets[it.j] + cost > 32768u) break;  // cannot thin the fullest bucket
+      --f.sh[it.s];
+      used += cost;
+      feat_buckets[it.j] += cost;
+      it.full = seg_fullest(seg_keys[it.j][it.s], f, f.sh[it.s]);
+      heap.back() = it;
+      std::push_heap(heap.begin(), heap.end(), less_full);
+    }
+    if (!ok) continue;
+    // layout
+    std::vector<uint32_t> tab_off(nf), starts_off(nf), seg_off(nf);
+    words = 0;
+    for (uint32_t j = 0; j < nf; ++j) {
+      const uint32_t len = F[j].K + P;
+      tab_off[j] = (uint32_t)words * 4u;
+      words += len + (len >> 5) + 1u;
+    }
+    words = (words + 3u) & ~(size_t)3u;
+    size_t half = words * 2u;  // in u16 units
+    for (uint32_t j = 0; j < nf; ++j) {
+      starts_off[j] = (uint32_t)half * 2u;
+      half += feat_buckets[j];
+    }
+    words = ((half + 1u) / 2u + 3u) & ~(size_t)3u;
+    for (uint32_t j = 0; j < nf; ++j) {
+      seg_off[j] = (uint32_t)words * 4u;
+      words += kQ16Segments;
+    }
+    const uint32_t poff = (uint32_t)words * 4u;
+    words += (size_t)nf * 8u;
+    if (words * 4u > kMaxLdsBytes) continue;  // alignment padding pushed it over: next P has fewer buckets
+    *par_off = poff;
+    *P_out = P;
+    if (!img) return true;
+    img->assign(words, 0x7FFFFFFFu);
+    for (uint32_t j = 0; j < nf; ++j) {
+      const std::vector<uint32_t>& k = rt.keys[f0 + j];
+      const SegFeature& f = F[j];
+      for (uint32_t i = 0; i < k.size(); ++i) (*img)[tab_off[j] / 4u + i + (i >> 5)] = k[i];
+      uint16_t* S = reinterpret_cast<uint16_t*>(img->data()) + starts_off[j] / 2u;
+      uint32_t* seg = img->data() + seg_off[j] / 4u;
+      uint32_t first = 0, run = 0;
+      const uint32_t mask = (1u << f.seg_shift) - 1u;
+      for (uint32_t s = 0; s < kQ16Segments; ++s) {
+        if (s >= f.nseg) {
+          seg[s] = 0u;
+          continue;
+        }
+        seg[s] = first | (f.sh[s] << 16);
+        const uint32_t nb = seg_buckets(f, s);
+        std::vector<uint32_t> cnt(nb, 0u);
+        for (uint32_t key : seg_keys[j][s]) ++cnt[((key - f.lo) & mask) >> f.sh[s]];
+        for (uint32_t b = 0; b < nb; ++b) {
+          S[first + b] = (uint16_t)run;  // run <= K <= 32767
+          run += cnt[b];
+        }
+        first += nb;
+      }
+      uint32_t* Pp = img->data() + poff / 4u + (size_t)j * 8u;
+      Pp[0] = f.K;
+      Pp[1] = f.lo;
+      Pp[2] = f.span;
+      Pp[3] = tab_off[j];
+      Pp[4] = starts_off[j];
+      Pp[5] = seg_off[j];
+      Pp[6] = f.seg_shift;
+      Pp[7] = 0u;
+    }
+    return true;
+  }
+  return false;
+}
+
+// groups_wanted: 0 = every G in turn (first that fits), else exactly that G.  allow_one / allow_many: engine options.
+bool build_prepass_image(const RankTables& rt, uint32_t W, uint32_t groups_wanted, bool allow_one, bool allow_many, std::vector<uint32_t>* pimg,
+                         PrepassPlan* plan) {
   plan->groups = 0;
-  for (uint32_t G = 1; G <= 2u; G <<= 1) {  // G = 4 (each launch re-reads the half rows) measured slower than transpose + rank: 69.4 vs 67.4 ms at 500 trees
+  if (W > 32u) return false;
+  for (uint32_t G = 1; G <= kQ16MaxGroups; G <<= 1) {
+    if (groups_wanted && G != groups_wanted) continue;
+    if (G == 1u ? !allow_one : !allow_many) continue;
     const uint32_t lines = 8u / G;  // tuple lines (4 features each) per group
+    PrepassPlan pl{};
     std::vector<std::vector<uint32_t>> imgs(G);
-    FusedPlan pl{};
     bool ok = true;
     uint32_t used = 0;
     for (uint32_t g = 0; g < G && ok; ++g) {
       const uint32_t f0 = g * lines * 4u < W ? g * lines * 4u : W, f1 = (g + 1u) * lines * 4u < W ? (g + 1u) * lines * 4u : W;
       if (f0 == f1) continue;  // narrow tuples: trailing groups are empty
-      ok = build_fused_group(rt, f0, f1, kQ16FusedBuckets, fimg ? &imgs[used] : nullptr, &pl.par_off[used], &pl.P[used]);
+      ok = build_prepass_group(rt, f0, f1, pimg ? &imgs[used] : nullptr, &pl.par_off[used], &pl.P[used]);
       pl.line_lo[used] = g * lines;
-      pl.line_hi[used] = (g + 1u) * lines;
       ++used;
     }
-    if (!ok) continue;
-    size_t off = 0;
-    if (fimg) fimg->clear();
-    for (uint32_t g = 0; g < used; ++g) {
-      if (fimg) {
-        pl.img_off[g] = (uint32_t)off;
+    if (!ok || used == 0) continue;
+    if (pimg) {
+      pimg->clear();
+      for (uint32_t g = 0; g < used; ++g) {
+        pl.img_off[g] = (uint32_t)(pimg->size() * 4u);
         pl.bytes[g] = (uint32_t)(imgs[g].size() * 4u);
-        fimg->insert(fimg->end(), imgs[g].begin(), imgs[g].end());
-        off += imgs[g].size() * 4u;
+        pimg->insert(pimg->end(), imgs[g].begin(), imgs[g].end());
       }
     }
     pl.groups = used;
+    pl.lines = lines;
     *plan = pl;
     return true;
   }
   return false;
 }
 
-// Grouped pre-pass (grouped_rank_kernel, ddt_internal.h GroupedPlan): tables too big to sit in LDS together.  G = 4 or 8
-// groups of 2 / 1 tuple lines, as many bucket starts per feature as still fit (more buckets = fewer probes); the image
-// of a group has the fused layout.  Returns false when not even one line's tables fit (then: transpose + rank kernels).
-bool build_grouped_image(const RankTables& rt, uint32_t W, std::vector<uint32_t>* gimg, GroupedPlan* plan) {
-  plan->groups = 0;
-  for (uint32_t G = 4; G <= kQ16GroupedMaxGroups; G <<= 1) {
-    const uint32_t lines = 8u / G;
-    for (uint32_t nb = 4096; nb >= 256u; nb >>= 1) {
-      GroupedPlan pl{};
-      std::vector<std::vector<uint32_t>> imgs(G);
-      bool ok = true;
-      uint32_t used = 0;
-      for (uint32_t g = 0; g < G && ok; ++g) {
-        const uint32_t f0 = g * lines * 4u < W ? g * lines * 4u : W, f1 = (g + 1u) * lines * 4u < W ? (g + 1u) * lines * 4u : W;
-        if (f0 == f1) continue;  // narrow tuples: trailing groups are empty
-        ok = build_fused_group(rt, f0, f1, nb, gimg ? &imgs[used] : nullptr, &pl.par_off[used], &pl.P[used]);
-        pl.line_lo[used] = g * lines;
-        ++used;
-      }
-      if (!ok || used == 0) continue;
-      if (gimg) {
-        gimg->clear();
-        for (uint32_t g = 0; g < used; ++g) {
-          pl.img_off[g] = (uint32_t)(gimg->size() * 4u);
-          pl.bytes[g] = (uint32_t)(imgs[g].size() * 4u);
-          gimg->insert(gimg->end(), imgs[g].begin(), imgs[g].end());
-        }
-      }
-      pl.groups = used;
-      pl.lines = lines;
-      pl.nb = nb;
-      *plan = pl;
-      return true;
-    }
-  }
-  return false;
-}
-
-uint32_t fused_plan_groups(const ddt_engine* e) {
-  FusedPlan pl;
-  return build_fused_image(rank_tables(e), tuple_words(e->p), nullptr, &pl) ? pl.groups : 0u;
+bool prepass_plan_exists(const ddt_engine* e) {
+  PrepassPlan pl;
+  return build_prepass_image(rank_tables(e), tuple_words(e->p), (uint32_t)e->q16_prepass_groups, e->q16_fused_prepass != 0, e->q16_grouped_prepass != 0,
+                             nullptr, &pl);
 }
 
 uint32_t total_trees(const ddt_engine* e) {
@@ -319,8 +391,7 @@ int auto_variant(const ddt_engine* e) {
   // With small tables (they all fit LDS together, e.g. a 125-tree shard) the pre-pass is one fused kernel and the
   // break-even drops accordingly (kQ16MinTreesFused).
   uint32_t q16_min = 224u;
-  if (e->q16_fused_prepass && tuple_words(e->p) <= 32u && total_trees(e) >= kQ16MinTreesFused && total_trees(e) < 224u &&
-      fused_plan_groups(e) >= 1u)
+  if (tuple_words(e->p) <= 32u && total_trees(e) >= kQ16MinTreesFused && total_trees(e) < 224u && prepass_plan_exists(e))
     q16_min = kQ16MinTreesFused;
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
     static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4", "q16_d5_c32_u4", "q16_d3_c128_u8",
@@ -339,7 +410,7 @@ int auto_variant(const ddt_engine* e) {
 
 void free_images(ddt_engine* e) {
   for (Ensemble& m : e->ens) {
-    for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_fused, &m.d_grouped}) {
+    for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_prepass}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
@@ -458,13 +529,14 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
       P[4] = pow2;
     }
   }
-  std::vector<uint32_t> fimg;
-  FusedPlan fplan{};
-  std::vector<uint32_t> gimg;
-  GroupedPlan gplan{};
-  if (upload_tables) {
-    (void)build_fused_image(rt, W, &fimg, &fplan);
-    if (!fplan.groups && W <= 32u) (void)build_grouped_image(rt, W, &gimg, &gplan);
+  std::vector<uint32_t> pimg;
+  PrepassPlan pplan{};
+  if (upload_tables)
+    (void)build_prepass_image(rt, W, (uint32_t)e->q16_prepass_groups, e->q16_fused_prepass != 0, e->q16_grouped_prepass != 0, &pimg, &pplan);
+  if (upload_tables && getenv("DDT_DEBUG_PREPASS")) {
+    fprintf(stderr, "[ddt] rank pre-pass: %u feature group(s) of %u line(s), longest table %u keys;", pplan.groups, pplan.lines, rt.max_len);
+    for (uint32_t g = 0; g < pplan.groups; ++g) fprintf(stderr, " [P=%u, %u B]", pplan.P[g], pplan.bytes[g]);
+    fprintf(stderr, "\n");
   }
   const uint32_t row = v.tile() * 2u;  // bytes per feature row of the u16 tile
   for (uint32_t i = 0; i < T; ++i) {
@@ -481,7 +553,7 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
   for (uint32_t i = 0; i < T; ++i)
     for (uint32_t n = 0; n < nint; ++n)
       if (m.mright[(size_t)i * nint + n]) slow[(size_t)i * tree_words + n + 1] |= 1u << 16;
-  for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_fused, &m.d_grouped}) {
+  for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_prepass}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -499,17 +571,11 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
     HIP_TRY(e, hipMemcpy(m.d_tables, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(m.d_tabK, tabK.data(), tabK.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(m.d_tabS, tabS.data(), tabS.size() * 2, hipMemcpyHostToDevice));
-    m.fused = FusedPlan{};
-    if (fplan.groups && !fimg.empty()) {
-      HIP_TRY(e, hipMalloc(&m.d_fused, fimg.size() * 4));
-      HIP_TRY(e, hipMemcpy(m.d_fused, fimg.data(), fimg.size() * 4, hipMemcpyHostToDevice));
-      m.fused = fplan;
-    }
-    m.grouped = GroupedPlan{};
-    if (gplan.groups && !gimg.empty()) {
-      HIP_TRY(e, hipMalloc(&m.d_grouped, gimg.size() * 4));
-      HIP_TRY(e, hipMemcpy(m.d_grouped, gimg.data(), gimg.size() * 4, hipMemcpyHostToDevice));
-      m.grouped = gplan;
+    m.prepass = PrepassPlan{};
+    if (pplan.groups && !pimg.empty()) {
+      HIP_TRY(e, hipMalloc(&m.d_prepass, pimg.size() * 4));
+      HIP_TRY(e, hipMemcpy(m.d_prepass, pimg.data(), pimg.size() * 4, hipMemcpyHostToDevice));
+      m.prepass = pplan;
     }
   }
   m.img_bytes = bytes;
@@ -524,7 +590,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint64_t rows = (n + 1023) / 1024 * 1024;
   const int k = e->q_slot;
   // the transposed fp32 intermediate is only needed by the two-kernel pre-pass
-  const bool need_xT = !(!e->ens.empty() && ((e->q16_fused_prepass && e->ens[0].fused.groups) || (e->q16_grouped_prepass && e->ens[0].grouped.groups)));
+  const bool need_xT = e->ens.empty() || e->ens[0].prepass.groups == 0;
   if (rows <= e->q_rows[k] && (!need_xT || e->q_xT[k])) return DDT_OK;
   HIP_TRY(e, hipDeviceSynchronize());
   for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k]}) {
@@ -631,12 +697,8 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     qa.tabS = reinterpret_cast<const uint16_t*>(tm.d_tabS);
     qa.Kpad = tm.Kpad;
     qa.skip_prepass = reuse_prepass ? 1u : 0u;
-    qa.fused_img = reinterpret_cast<const uint4*>(tm.d_fused);
-    qa.fused = tm.fused;
-    if (!e->q16_fused_prepass) qa.fused.groups = 0;
-    qa.grouped_img = reinterpret_cast<const uint4*>(tm.d_grouped);
-    qa.grouped = tm.grouped;
-    if (!e->q16_grouped_prepass) qa.grouped.groups = 0;
+    qa.prepass_img = reinterpret_cast<const uint4*>(tm.d_prepass);
+    qa.prepass = tm.prepass;
     qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
     qa.n_pad = (n + 1023) / 1024 * 1024;
     a.aux = &qa;
@@ -986,6 +1048,7 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   out->lds_bytes_per_cu = (uint32_t)e->prop.maxSharedMemoryPerMultiProcessor;
   if (!e->loaded) return DDT_OK;
   const Variant& v = variant(e->variant_id);
+  if (!e->sparse && v.kind == kKindQ16 && !e->ens.empty()) out->prepass_groups = e->ens[0].prepass.groups;
   if (e->sparse) {
     uint32_t trees = 0, depth = 0;
     uint64_t lines = 0, img = 0;
@@ -1133,11 +1196,17 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     e->kernel_timing = value != 0;
     return DDT_OK;
   }
-  if (!strcmp(key, "q16_grouped_prepass")) {  // 0: big tables go through the transpose + rank kernels (A/B and tests); default 1
+  if (!strcmp(key, "q16_grouped_prepass")) {  // 0: no pre-pass split over feature groups (G > 1); with q16_fused_prepass 0 too: transpose + rank kernels
     e->q16_grouped_prepass = value != 0;
     return DDT_OK;
   }
-  if (!strcmp(key, "q16_fused_prepass")) {  // 0: always transpose + rank kernels (A/B and tests); default 1
+  if (!strcmp(key, "q16_prepass_groups")) {  // 0 (default): the smallest number of feature groups that fits; 1, 2, 4, 8: exactly that (A/B)
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(e, DDT_EINVAL, "q16_prepass_groups must be 0, 1, 2, 4 or 8");
+    e->q16_prepass_groups = (int)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "q16_fused_prepass")) {  // 0: never the single-group form (all tables resident together); both 0: transpose + rank kernels.
+                                            // These three take effect at the next model load (A/B and tests); defaults 1, 1, 0
     e->q16_fused_prepass = value != 0;
     return DDT_OK;
   }

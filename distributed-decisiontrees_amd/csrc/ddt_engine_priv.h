@@ -37,10 +37,8 @@ struct Ensemble {
   void* d_tables = nullptr;
   void* d_tabK = nullptr;   // q16: per-feature search parameters (Q16Aux::tabP)
   void* d_tabS = nullptr;   // q16: bucket starts (Q16Aux::tabS)
-  void* d_fused = nullptr;  // q16, small tables: LDS image of the fused pre-pass (Q16Aux::fused_img)
-  FusedPlan fused;          // geometry of that image (groups of features, one launch per group)
-  void* d_grouped = nullptr;  // q16, big tables: LDS images of the grouped pre-pass (Q16Aux::grouped_img)
-  GroupedPlan grouped;
+  void* d_prepass = nullptr;  // q16: LDS images of the LDS-resident rank pre-pass (Q16Aux::prepass_img), one per feature group
+  PrepassPlan prepass;        // geometry of those images; groups == 0: transpose + rank kernels
   uint32_t Kpad = 0;
   uint32_t trees() const { return (uint32_t)ids.size(); }
 };
@@ -69,7 +67,7 @@ struct SparseForest {
 
 struct ddt_engine {
   using Ensemble = ddt::Ensemble;
-  using FusedPlan = ddt::FusedPlan;
+  using PrepassPlan = ddt::PrepassPlan;
   int device = -1;
   hipDeviceProp_t prop{};
   bool loaded = false;
@@ -99,7 +97,8 @@ struct ddt_engine {
   void* q_flags[3] = {nullptr, nullptr, nullptr};
   uint64_t q_rows[3] = {0, 0, 0};  // capacity in rows (multiple of 1024)
   int q_slot = 0;
-  int q16_grouped_prepass = 1;  // option "q16_grouped_prepass": 0 sends big tables through the transpose + rank kernels
+  int q16_grouped_prepass = 1;  // option "q16_grouped_prepass": 0 = never split the pre-pass over feature groups
+  int q16_prepass_groups = 0;   // option "q16_prepass_groups": force the number of feature groups (A/B), 0 = automatic
   int q16_fused_prepass = 1;  // option "q16_fused_prepass": 0 forces the transpose + rank kernels (A/B, tests)
   // optional per-call kernel timing (option "kernel_timing"): start / before scoring kernel / end
   bool kernel_timing = false, timing_pending = false;

@@ -46,25 +46,17 @@ struct ScoreArgs {
 };
 
 constexpr uint32_t kQ16RankBuckets = 4096;
-constexpr uint32_t kQ16FusedBuckets = 256;   // per feature, fused pre-pass (all tables resident in LDS)
-
-// fused rank pre-pass: the features are processed in `groups` launches of fused_rank_kernel, group g covering tuple
-// lines [line_lo, line_hi) with its tables resident in LDS (image = bytes[g] at byte offset img_off[g])
-struct FusedPlan {
-  uint32_t groups = 0;
-  uint32_t img_off[4] = {0, 0, 0, 0}, bytes[4] = {0, 0, 0, 0}, par_off[4] = {0, 0, 0, 0}, P[4] = {1, 1, 1, 1};
-  uint32_t line_lo[4] = {0, 0, 0, 0}, line_hi[4] = {0, 0, 0, 0};
-};
-
-// grouped rank pre-pass (big tables, e.g. 1000 trees: ~8 k keys per feature): ONE launch in which the blocks are split over
-// `groups` feature groups of `lines` tuple lines (4 features each) -- a block keeps the tables of its group resident in LDS
-// (image = bytes[g] at byte offset img_off[g] of Q16Aux::grouped_img) -- and over `parts` row partitions (= XCDs: the blocks
-// of all groups that work on the same rows share one L2, so a tuple row leaves HBM once although every group reads it)
-constexpr uint32_t kQ16GroupedMaxGroups = 8;
-struct GroupedPlan {
-  uint32_t groups = 0, lines = 0, nb = 0;  // nb = bucket starts per feature (power of two)
-  uint32_t img_off[kQ16GroupedMaxGroups] = {}, bytes[kQ16GroupedMaxGroups] = {}, par_off[kQ16GroupedMaxGroups] = {}, P[kQ16GroupedMaxGroups] = {};
-  uint32_t line_lo[kQ16GroupedMaxGroups] = {};
+// LDS-resident rank pre-pass (no transposed fp32 intermediate): the features are cut into `groups` groups of `lines`
+// tuple lines (4 features each); a block keeps the tables of ONE group resident in LDS (image = bytes[g] at byte offset
+// img_off[g] of Q16Aux::prepass_img; layout: ddt_engine.cpp build_prepass_group).  groups == 1: fused_rank_kernel (all
+// tables fit together, e.g. a 125-tree shard).  groups > 1: grouped_rank_kernel, ONE launch whose blocks are split over
+// the groups and over `parts` row partitions (= XCDs: the blocks of all groups that work on the same rows share one L2,
+// so a tuple row leaves HBM once although every group reads it).
+constexpr uint32_t kQ16MaxGroups = 8, kQ16Segments = 32;
+struct PrepassPlan {
+  uint32_t groups = 0, lines = 0;
+  uint32_t img_off[kQ16MaxGroups] = {}, bytes[kQ16MaxGroups] = {}, par_off[kQ16MaxGroups] = {}, P[kQ16MaxGroups] = {};
+  uint32_t line_lo[kQ16MaxGroups] = {};
 };
 constexpr uint32_t kQ16GroupedCounters = 64;  // 8-byte work counters behind the tile flags: one per (group, part)
 
@@ -79,10 +71,8 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   const uint4* img_slow;      // image with the miss_right flags (used by tiles that contain a missing value)
   uint64_t n_pad;             // rows rounded up to whole tiles of 1024
   uint32_t skip_prepass;      // 1 = q / tile_flags already hold this batch (2nd..Kth class of a multi-class model)
-  const uint4* fused_img;     // fused pre-pass: concatenated LDS images of fused_rank_kernel, one per feature group
-  FusedPlan fused;            // groups == 0: use grouped_rank_kernel, else transpose_kernel + rank_kernel
-  const uint4* grouped_img;   // grouped pre-pass: concatenated LDS images, one per feature group
-  GroupedPlan grouped;        // groups == 0: use transpose_kernel + rank_kernel
+  const uint4* prepass_img;   // LDS-resident pre-pass: concatenated LDS images, one per feature group
+  PrepassPlan prepass;        // groups == 0: use transpose_kernel + rank_kernel
 };
 
 // ---------------------------------------------------------------------------------------------------

@@ -575,26 +575,32 @@ __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __re
 // ---------------------------------------------------------------------------------------------------
 // One tuple line (4 features) of two rows against the tables resident in LDS: 8 searches advance together (the
 // dependent LDS reads of one search are latency bound).  `par` = LDS byte address of the line's first parameter
-// block {K, lo, shift, table byte offset, starts byte offset, 0, 0, 0}; nb = bucket starts per feature (power of two).
+// block {K, lo, span, table byte offset | starts byte offset, segment table byte offset, segment shift, 0} (layout and
+// the segmented bucket index: ddt_engine.cpp build_prepass_group).  Search = segment lookup (a 32-entry table: few distinct
+// addresses per wave) + bucket start + log2(P) probes; keys past the bucket are > x by construction, no end test.
 // Returns r(row0) | r(row1) << 16 per feature; in0 / in1 = the row exists (a missing value only counts there).
-__device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P, const uint32_t nb, const uint32_t ieee, const uint32_t miss_raw,
-                                           const bool in0, const bool in1, const u32x4& v0, const u32x4& v1, bool& any_missing) {
-  uint32_t K[4], tab[4], raw[4][2], pos[4][2];
+__device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P, const uint32_t ieee, const uint32_t miss_raw, const bool in0,
+                                           const bool in1, const u32x4& v0, const u32x4& v1, bool& any_missing) {
+  uint32_t K[4], tab[4], pos[4][2], missing = 0u;
   int32_t x[4][2];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const uint4 pr = lds_u4(par + (uint32_t)c * 32u);  // same address in every lane: {K, lo, shift, table_off}
-    const uint32_t st = lds_u32(par + (uint32_t)c * 32u + 16u);
-    K[c] = pr.x;
-    tab[c] = pr.w;
+    const uint4 pa = lds_u4(par + (uint32_t)c * 32u);        // same address in every lane: {K, lo, span, table_off}
+    const uint4 pb = lds_u4(par + (uint32_t)c * 32u + 16u);  // {starts_off, seg_off, seg_shift, 0}
+    K[c] = pa.x;
+    tab[c] = pa.w;
+    const uint32_t seg_mask = (1u << pb.z) - 1u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      raw[c][h] = h ? v1[c] : v0[c];
-      x[c][h] = (int32_t)(ieee ? ieee_key(raw[c][h]) : raw[c][h]);
-      uint32_t bk = ((uint32_t)x[c][h] - pr.y) >> pr.z;  // wraps to a huge value below lo: selected away next
-      bk = bk < nb - 1u ? bk : nb - 1u;
-      bk = x[c][h] < (int32_t)pr.y ? 0u : bk;
-      pos[c][h] = *reinterpret_cast<const DDT_LDS(uint16_t)*>(st + bk * 2u);
+      const uint32_t raw = h ? v1[c] : v0[c];
+      if (raw == miss_raw && (h ? in1 : in0)) missing |= 1u << (2 * c + h);  // DTPU.sv:653, bit equality before any transform
+      x[c][h] = (int32_t)(ieee ? ieee_key(raw) : raw);
+      uint32_t d = (uint32_t)x[c][h] - pa.y;
+      d = x[c][h] < (int32_t)pa.y ? 0u : d;  // below the table: bucket 0, nothing there is <= x
+      d = d < pa.z ? d : pa.z;               // above it: the last bucket, everything from there on is <= x
+      const uint32_t sg = lds_u32(pb.y + (d >> pb.z) * 4u);  // first bucket | log2(bucket width) << 16
+      const uint32_t bk = (sg & 0xFFFFu) + ((d & seg_mask) >> (sg >> 16));
+      pos[c][h] = *reinterpret_cast<const DDT_LDS(uint16_t)*>(pb.x + bk * 2u);
     }
   }
   for (uint32_t step = P >> 1; step >= 1u; step >>= 1) {
@@ -607,6 +613,7 @@ __device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P,
       }
     }
   }
+  any_missing = any_missing || missing != 0u;
   u32x4 out;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -614,10 +621,7 @@ __device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P,
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       r[h] = pos[c][h] < K[c] ? pos[c][h] : K[c];
-      if (raw[c][h] == miss_raw && (h ? in1 : in0)) {  // DTPU.sv:653, bit equality before any transform
-        r[h] = kQMissing;
-        any_missing = true;
-      }
+      r[h] = (missing >> (2 * c + h)) & 1u ? kQMissing : r[h];
     }
     out[c] = r[0] | (r[1] << 16);
   }
@@ -625,7 +629,6 @@ __device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P,
 }
 
 constexpr int kFusedThreads = 1024;  // two tiles per block and pass; 16 waves x 8 independent searches hide the LDS latency
-constexpr uint32_t kFusedBuckets = kQ16FusedBuckets;
 
 __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
                                                                    const uint4* __restrict__ lds_img, uint32_t img_bytes, uint32_t par_off,
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
     for (int i = 0; i < 4; ++i) {
       const uint32_t line = 4u * g + (uint32_t)i;
       if (line >= lpt || line < line_lo || line >= line_hi) continue;  // this launch's feature group only
-      const u32x4 r = rank_line(par_off + 4u * (line - line_lo) * 32u, P, kFusedBuckets, ieee, miss_raw, tile * kQTile + own < n,
+      const u32x4 r = rank_line(par_off + 4u * (line - line_lo) * 32u, P, ieee, miss_raw, tile * kQTile + own < n,
                                 tile * kQTile + own + 512u < n, v[0][i], v[1][i], any_missing);
 #pragma unroll
       for (int c = 0; c < 4; ++c) q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + own] = r[c];
@@ -707,11 +710,13 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
 // a tile and reads ITS line(s) of them directly (16-byte loads at a 128-byte stride; the neighbours in the row belong
 // to other groups), ranks 4 features x 2 rows in lock-step (rank_line) and stores one fully coalesced dword per feature.
 // Work = half tiles, handed to waves through one atomic counter per (group, part); the loads of the next 64 lane
-// pairs are in flight while the current ones are ranked.
+// pairs are in flight while the current ones are ranked.  (Deeper prefetch -- whole-tile grabs with 8 x 16-byte loads per
+// lane in flight -- measured SLOWER, 7.3 vs 5.7 ms at 1000 trees: every 16-byte load pulls a whole line into the L2 the
+// groups share, and the footprint in flight then exceeds it.)
 // ---------------------------------------------------------------------------------------------------
 template <int L>
 __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
-                                                                     const uint4* __restrict__ img_base, const GroupedPlan pl, uint32_t parts,
+                                                                     const uint4* __restrict__ img_base, const PrepassPlan pl, uint32_t parts,
                                                                      uint32_t miss_raw, uint32_t ieee, uint32_t* __restrict__ q32,
                                                                      uint32_t* __restrict__ tile_flags, unsigned long long* __restrict__ counters) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, lpt = W / 4u;
@@ -719,7 +724,7 @@ __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint3
   const uint64_t tiles = n_pad / kQTile;
   const uint64_t tiles_part = tiles > part ? (tiles - part + parts - 1u) / parts : 0u;
   if (tiles_part == 0u) return;
-  const uint32_t img_bytes = pl.bytes[g], par_off = pl.par_off[g], P = pl.P[g], line_lo = pl.line_lo[g], nb = pl.nb;
+  const uint32_t img_bytes = pl.bytes[g], par_off = pl.par_off[g], P = pl.P[g], line_lo = pl.line_lo[g];
   const uint4* __restrict__ img = img_base + pl.img_off[g] / 16u;
   for (uint32_t off = tid * 16u; off < img_bytes; off += kFusedThreads * 16u) lds_st_u4(off, img[off / 16u]);
   __syncthreads();
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint3
       for (int l = 0; l < L; ++l) {
         const uint32_t line = line_lo + (uint32_t)l;
         if (line >= lpt) continue;  // narrow tuples: the last group may be short (wave-uniform)
-        const u32x4 r = rank_line(par_off + 4u * (uint32_t)l * 32u, P, nb, ieee, miss_raw, tile * kQTile + lt < n, tile * kQTile + lt + 512u < n,
+        const u32x4 r = rank_line(par_off + 4u * (uint32_t)l * 32u, P, ieee, miss_raw, tile * kQTile + lt < n, tile * kQTile + lt + 512u < n,
                                   cur[l][0], cur[l][1], miss);
 #pragma unroll
         for (int c = 0; c < 4; ++c) q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + lt] = r[c];
@@ -889,30 +894,27 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
     unsigned long long* counter = reinterpret_cast<unsigned long long*>(x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u));
     e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters) * 4, s);
     if (e != hipSuccess) return e;
-    if (x.fused.groups) {  // the tables of a feature group fit LDS: fused kernel(s), no transposed intermediate
+    const PrepassPlan& pp = x.prepass;
+    if (pp.groups == 1u) {  // all tables fit one CU's LDS together: fused kernel, no transposed intermediate
       const uint32_t grid = (tiles + 1u) / 2u < a.num_cus ? (uint32_t)((tiles + 1u) / 2u) : a.num_cus;  // at most one block per CU
-      for (uint32_t g = 0; g < x.fused.groups; ++g) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x.fused.bytes[g]);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fused_rank_kernel, dim3(grid), dim3(kFusedThreads), x.fused.bytes[g], s, a.tuples, a.n, x.n_pad, W,
-                           x.fused_img + x.fused.img_off[g] / 16u, x.fused.bytes[g], x.fused.par_off[g], x.fused.P[g], x.fused.line_lo[g],
-                           x.fused.line_hi[g], a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter + g);
-      }
-    } else if (x.grouped.groups) {  // big tables: one launch, blocks split over feature groups x row partitions (XCDs)
-      const GroupedPlan& gp = x.grouped;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.bytes[0]);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(fused_rank_kernel, dim3(grid), dim3(kFusedThreads), pp.bytes[0], s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp.bytes[0],
+                         pp.par_off[0], pp.P[0], 0u, 8u, a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
+    } else if (pp.groups) {  // one launch, blocks split over feature groups x row partitions (XCDs)
       uint32_t lds = 0;
-      for (uint32_t g = 0; g < gp.groups; ++g) lds = gp.bytes[g] > lds ? gp.bytes[g] : lds;
+      for (uint32_t g = 0; g < pp.groups; ++g) lds = pp.bytes[g] > lds ? pp.bytes[g] : lds;
       // one block per CU (the image takes most of the LDS); 8 row partitions when every (group, partition) gets a block
-      const uint32_t parts = (a.num_cus >= 8u * gp.groups && tiles >= 8u) ? 8u : 1u;
-      uint32_t per_pair = a.num_cus / (parts * gp.groups);
+      const uint32_t parts = (a.num_cus >= 8u * pp.groups && tiles >= 8u) ? 8u : 1u;
+      uint32_t per_pair = a.num_cus / (parts * pp.groups);
       if (per_pair < 1u) per_pair = 1u;
       const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
       if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
-      const uint32_t grid = parts * gp.groups * per_pair;
-      auto gk = gp.lines == 1u ? grouped_rank_kernel<1> : grouped_rank_kernel<2>;
+      const uint32_t grid = parts * pp.groups * per_pair;
+      auto gk = pp.lines == 1u ? grouped_rank_kernel<1> : pp.lines == 2u ? grouped_rank_kernel<2> : grouped_rank_kernel<4>;
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(gk, dim3(grid), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.grouped_img, gp, parts, a.miss_raw, a.ieee,
+      hipLaunchKernelGGL(gk, dim3(grid), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp, parts, a.miss_raw, a.ieee,
                          reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
     } else {
       hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);

@@ -43,7 +43,7 @@ class Info(C.Structure):
         ("lds_bytes", C.c_uint32), ("num_classes", C.c_uint32), ("local_trees", C.c_uint32),
         ("model_bytes_unpadded", C.c_uint64), ("image_bytes", C.c_uint64),
         ("variant_name", C.c_char * 64), ("device_name", C.c_char * 64),
-        ("num_cus", C.c_uint32), ("clock_khz", C.c_uint32), ("lds_bytes_per_cu", C.c_uint32), ("reserved_", C.c_uint32),
+        ("num_cus", C.c_uint32), ("clock_khz", C.c_uint32), ("lds_bytes_per_cu", C.c_uint32), ("prepass_groups", C.c_uint32),
     ]
 
 

@@ -79,7 +79,10 @@ typedef struct ddt_info {
   char     variant_name[64];
   char     device_name[64];
   uint32_t num_cus, clock_khz;       /* hipDeviceProp_t: multiProcessorCount, clockRate (inputs of the LDS / VMEM ceilings) */
-  uint32_t lds_bytes_per_cu, reserved_;
+  uint32_t lds_bytes_per_cu;
+  uint32_t prepass_groups;           /* rank-quantised path: feature groups of the LDS-resident rank pre-pass (1 = all tables
+                                        resident together, 2/4/8 = one launch split over groups), 0 = transpose + rank kernels
+                                        or not the rank-quantised path                                                  */
 } ddt_info;
 
 /* Observability counters, the analogue of CSR 220-226 / appStatus (EngineCSR.sv:113-126,

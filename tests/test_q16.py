@@ -12,6 +12,13 @@ import ddt
 pytestmark = pytest.mark.gpu
 
 
+def _prepass(e, groups):
+    """groups = -1: transpose + rank kernels; 0: automatic; 1 / 2 / 4 / 8: that many feature groups (takes effect at the next load)."""
+    e.set_option("q16_fused_prepass", 0 if groups < 0 else 1)
+    e.set_option("q16_grouped_prepass", 0 if groups < 0 else 1)
+    e.set_option("q16_prepass_groups", max(groups, 0))
+
+
 def _variant(name):
     return ddt.variant_names().index(name)
 
@@ -53,10 +60,10 @@ def test_auto_selection_and_fallbacks():
     assert e.info().variant_name.decode() == "q16_d8_c4_u4"        # many trees: the pre-pass pays off
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)          # 125 trees per engine (8-way shard): all rank tables
     assert e.info().variant_name.decode() == "q16_d8_c4_u4"        # fit LDS together -> fused pre-pass -> q16 still pays
-    e.set_option("q16_fused_prepass", 0)                            # without it the fixed pre-pass cost is too high
+    _prepass(e, -1)                                                 # with the transpose + rank kernels the fixed pre-pass cost is too high
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)
     assert e.info().variant_name.decode() == "d8_t1024_r1_c4_u4_dma_f"
-    e.set_option("q16_fused_prepass", 1)
+    _prepass(e, 0)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 16)         # 63 trees: below the break-even either way
     assert e.info().variant_name.decode() == "d8_t1024_r1_c4_u4_dma_f"
     # too many distinct thresholds on one feature for 16-bit ranks: 2000 trees x 255 nodes on 4 features
@@ -124,10 +131,13 @@ def test_rank_search_on_degenerate_threshold_distributions(cmp_mode, shape):
     x[:, :F] = np.where(mask, (pick & 0xFFFFFFFF).astype(np.uint32), x[:, :F])
     e = ddt.Engine(0)
     e.set_option("variant", _variant("q16_d8_c4_u4"))
-    e.load_model(_params(m), m.wlines, m.flines)
-    assert e.info().variant_name.decode() == "q16_d8_c4_u4"
-    got = e.score(x)
-    assert np.array_equal(got.view(np.uint32), O.score(m, x).view(np.uint32))
+    want = O.score(m, x)
+    for groups in (0, 2, 8, -1):  # the LDS-resident pre-pass (segmented bucket index) in 1 / 2 / 8 feature groups; transpose + rank kernels
+        _prepass(e, groups)
+        e.load_model(_params(m), m.wlines, m.flines)
+        assert e.info().variant_name.decode() == "q16_d8_c4_u4"
+        got = e.score(x)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), groups
     e.close()
 
 
@@ -158,11 +168,11 @@ def test_fused_and_two_kernel_prepass_agree(cmp_mode):
     want = O.score(m, x)
     e = ddt.Engine(0)
     e.set_option("variant", _variant("q16_d8_c4_u4"))
-    for fused in (1, 0):
-        e.set_option("q16_fused_prepass", fused)
+    for groups in (1, 2, 4, 8, -1):
+        _prepass(e, groups)
         e.load_model(_params(m), m.wlines, m.flines)
         got = e.score(x)
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"fused={fused}"
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"groups={groups}"
     e.close()
 
 
@@ -179,9 +189,9 @@ def test_grouped_and_two_kernel_prepass_agree(T, F):
     for n in (1, 1500, 11 * 1024 + 77):
         x = O.gen_tuples(41 + n, n, F, dist=1, missing_bits=m.params.missing_bits)
         want = O.score(m, x)
-        for grouped in (1, 0):
-            e.set_option("q16_grouped_prepass", grouped)
+        for groups in (0, 4, 8, -1):
+            _prepass(e, groups)
             e.load_model(_params(m), m.wlines, m.flines)
             got = e.score(x)
-            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"grouped={grouped} n={n}"
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"groups={groups} n={n}"
     e.close()

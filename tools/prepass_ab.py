@@ -20,10 +20,10 @@ from oracle import oracle as O  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=100_000_000)
-    ap.add_argument("--trees", default="1000,500,250")
+    ap.add_argument("--trees", default="1000,500,250,125")
     ap.add_argument("--features", type=int, default=32)
     ap.add_argument("--reps", type=int, default=4)
-    ap.add_argument("--opts", default="q16_grouped_prepass=1;q16_grouped_prepass=0")
+    ap.add_argument("--opts", default="q16_prepass_groups=0;q16_prepass_groups=1;q16_prepass_groups=2;q16_prepass_groups=4;q16_prepass_groups=8;q16_fused_prepass=0,q16_grouped_prepass=0")
     a = ap.parse_args()
     D, F, N = 8, a.features, a.rows
     eng = ddt.Engine(0)
@@ -36,7 +36,7 @@ def main():
         xs = d[:4096].cpu().numpy().view(np.uint32)
         want = O.score(m, xs)
         for opts in a.opts.split(";"):
-            for kv in filter(None, opts.split(",")):
+            for kv in ["q16_fused_prepass=1", "q16_grouped_prepass=1", "q16_prepass_groups=0"] + list(filter(None, opts.split(","))):
                 k, v = kv.split("=")
                 eng.set_option(k, int(v))
             eng.load_model(ddt.make_params(T, D, F), w, f)
@@ -54,7 +54,7 @@ def main():
                 st = eng.stats()
                 t = (e0.elapsed_time(e1), st.last_prepass_ms, st.last_score_ms)
                 best = t if best is None or t[0] < best[0] else best
-            print(f"T={T:5d} {opts:28s} {eng.info().variant_name.decode():14s} ok={ok and tail_ok}  total {best[0]:8.3f} ms  prepass {best[1]:7.3f} ms  "
+            print(f"T={T:5d} {opts:28s} {eng.info().variant_name.decode():14s} G={eng.info().prepass_groups} ok={ok and tail_ok}  total {best[0]:8.3f} ms  prepass {best[1]:7.3f} ms  "
                   f"score {best[2]:8.3f} ms  {N / best[0] / 1e3:8.1f} Mtuples/s", flush=True)
 
 
