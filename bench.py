@@ -236,7 +236,8 @@ def main():
         roofline = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": info.variant_name.decode(), "kernel_ms": round(k_ms, 4),
-                    "prepass_ms": round(pre_ms, 4),  # transpose + rank kernels of the rank-quantised path (0 otherwise)
+                    "prepass_ms": round(pre_ms, 4),  # rank pre-pass of the rank-quantised path (0 otherwise)
+                    "prepass_groups": info.prepass_groups,  # feature groups of the LDS-resident pre-pass (0: transpose + rank kernels / n.a.)
                     "alg_bytes_per_launch": alg_bytes_per_launch,
                     "device": {"cus": info.num_cus, "clock_mhz": round(clock_hz / 1e6, 1), "lds_bytes_per_cu": info.lds_bytes_per_cu}}
         if sparse:

@@ -299,41 +299,59 @@ bool build_prepass_group(const RankTables& rt, uint32_t f0, uint32_t f1, std::ve
   return false;
 }
 
-// groups_wanted: 0 = every G in turn (first that fits), else exactly that G.  allow_one / allow_many: engine options.
+// one candidate: G groups; pimg may be NULL to only plan
+bool build_prepass_groups(const RankTables& rt, uint32_t W, uint32_t G, std::vector<uint32_t>* pimg, PrepassPlan* plan) {
+  const uint32_t lines = 8u / G;  // tuple lines (4 features each) per group
+  PrepassPlan pl{};
+  std::vector<std::vector<uint32_t>> imgs(G);
+  uint32_t used = 0;
+  for (uint32_t g = 0; g < G; ++g) {
+    const uint32_t f0 = g * lines * 4u < W ? g * lines * 4u : W, f1 = (g + 1u) * lines * 4u < W ? (g + 1u) * lines * 4u : W;
+    if (f0 == f1) continue;  // narrow tuples: trailing groups are empty
+    if (!build_prepass_group(rt, f0, f1, pimg ? &imgs[used] : nullptr, &pl.par_off[used], &pl.P[used])) return false;
+    pl.line_lo[used] = g * lines;
+    ++used;
+  }
+  if (used == 0) return false;
+  if (pimg) {
+    pimg->clear();
+    for (uint32_t g = 0; g < used; ++g) {
+      pl.img_off[g] = (uint32_t)(pimg->size() * 4u);
+      pl.bytes[g] = (uint32_t)(imgs[g].size() * 4u);
+      pimg->insert(pimg->end(), imgs[g].begin(), imgs[g].end());
+    }
+  }
+  pl.groups = used;
+  pl.lines = lines;
+  *plan = pl;
+  return true;
+}
+
+// groups_wanted: 0 = the cheapest G that fits, else exactly that G.  allow_one / allow_many: engine options.
+// Cost of a candidate, ms per 100 M tuples of 32 features on one MI355X (fitted to profiles/r02_prepass_ab_grid.log): a floor set by how
+// the rows are read (G <= 2: whole 64-byte sectors per block; G = 4: half; G = 8: a quarter of every sector pulled
+// through the L1) + the probes (log2 P dependent LDS reads with ~3.5-way bank conflicts), which hide less behind the
+// loads the more of the time is load-bound.
 bool build_prepass_image(const RankTables& rt, uint32_t W, uint32_t groups_wanted, bool allow_one, bool allow_many, std::vector<uint32_t>* pimg,
                          PrepassPlan* plan) {
   plan->groups = 0;
   if (W > 32u) return false;
-  for (uint32_t G = 1; G <= kQ16MaxGroups; G <<= 1) {
+  static const float base[4] = {3.28f, 3.14f, 3.72f, 4.62f}, per_probe[4] = {0.35f, 0.35f, 0.275f, 0.275f};
+  uint32_t best_G = 0;
+  float best = 0.f;
+  for (uint32_t G = 1, i = 0; G <= kQ16MaxGroups; G <<= 1, ++i) {
     if (groups_wanted && G != groups_wanted) continue;
     if (G == 1u ? !allow_one : !allow_many) continue;
-    const uint32_t lines = 8u / G;  // tuple lines (4 features each) per group
     PrepassPlan pl{};
-    std::vector<std::vector<uint32_t>> imgs(G);
-    bool ok = true;
-    uint32_t used = 0;
-    for (uint32_t g = 0; g < G && ok; ++g) {
-      const uint32_t f0 = g * lines * 4u < W ? g * lines * 4u : W, f1 = (g + 1u) * lines * 4u < W ? (g + 1u) * lines * 4u : W;
-      if (f0 == f1) continue;  // narrow tuples: trailing groups are empty
-      ok = build_prepass_group(rt, f0, f1, pimg ? &imgs[used] : nullptr, &pl.par_off[used], &pl.P[used]);
-      pl.line_lo[used] = g * lines;
-      ++used;
-    }
-    if (!ok || used == 0) continue;
-    if (pimg) {
-      pimg->clear();
-      for (uint32_t g = 0; g < used; ++g) {
-        pl.img_off[g] = (uint32_t)(pimg->size() * 4u);
-        pl.bytes[g] = (uint32_t)(imgs[g].size() * 4u);
-        pimg->insert(pimg->end(), imgs[g].begin(), imgs[g].end());
-      }
-    }
-    pl.groups = used;
-    pl.lines = lines;
-    *plan = pl;
-    return true;
+    if (!build_prepass_groups(rt, W, G, nullptr, &pl)) continue;
+    uint32_t P = 1, probes = 0;
+    for (uint32_t g = 0; g < pl.groups; ++g) P = pl.P[g] > P ? pl.P[g] : P;
+    while ((2u << probes) <= P) ++probes;  // log2 P
+    const float cost = base[i] + per_probe[i] * (float)probes;
+    if (!best_G || cost < best) best_G = G, best = cost;
   }
-  return false;
+  if (!best_G) return false;
+  return build_prepass_groups(rt, W, best_G, pimg, plan);
 }
 
 bool prepass_plan_exists(const ddt_engine* e) {

@@ -631,14 +631,22 @@ __device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P,
 constexpr int kFusedThreads = 1024;  // two tiles per block and pass; 16 waves x 8 independent searches hide the LDS latency
 
 __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
-                                                                   const uint4* __restrict__ lds_img, uint32_t img_bytes, uint32_t par_off,
-                                                                   uint32_t P, uint32_t line_lo, uint32_t line_hi, uint32_t miss_raw, uint32_t ieee,
-                                                                   uint32_t* __restrict__ q32, uint32_t* __restrict__ tile_flags,
-                                                                   unsigned long long* __restrict__ work_counter) {
+                                                                   const uint4* __restrict__ img_base, const PrepassPlan pl, uint32_t parts,
+                                                                   uint32_t miss_raw, uint32_t ieee, uint32_t* __restrict__ q32,
+                                                                   uint32_t* __restrict__ tile_flags, unsigned long long* __restrict__ counters) {
   const uint32_t tid = threadIdx.x, t4 = tid & 3u, lpt = W / 4u;
+  // one group (all tables resident): every block the same image, parts = 1.  Two groups of 4 lines: block b works for
+  // group (b / parts) % 2 on row partition b % parts (see grouped_rank_kernel for why the partitions follow the XCDs)
+  const uint32_t part = blockIdx.x % parts, g_own = (blockIdx.x / parts) % pl.groups;
+  const uint64_t tiles_all = n_pad / kQTile;
+  const uint64_t tiles = tiles_all > part ? (tiles_all - part + parts - 1u) / parts : 0u;  // of this partition
+  if (tiles == 0u) return;
+  const uint32_t img_bytes = pl.bytes[g_own], par_off = pl.par_off[g_own], P = pl.P[g_own];
+  const uint32_t line_lo = pl.line_lo[g_own], line_hi = line_lo + pl.lines;
+  const uint4* __restrict__ lds_img = img_base + pl.img_off[g_own] / 16u;
+  unsigned long long* __restrict__ work_counter = counters + g_own * parts + part;
   for (uint32_t off = tid * 16u; off < img_bytes; off += kFusedThreads * 16u) lds_st_u4(off, lds_img[off / 16u]);
   __syncthreads();
-  const uint64_t tiles = n_pad / kQTile;
 
   // one half-unit = lines 4g..4g+3 (16 features) of rows lt and lt+512: 8 x 16-byte loads per lane
   auto load_half = [&](u32x4 (&v)[2][4], uint64_t tile, uint32_t lt, uint32_t g) {
@@ -684,7 +692,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
     u0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u0 >> 32)) << 32) |
          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u0);
     if (u0 >= units) break;
-    const uint64_t tile = u0 >> 3;
+    const uint64_t tile = (u0 >> 3) * parts + part;
     bool miss = false;
     for (uint32_t k = 0; k < 4u; ++k) {
       const uint32_t lt = ((((uint32_t)u0 & 7u) + k) << 6) | (tid & 63u);
@@ -731,14 +739,33 @@ __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint3
   unsigned long long* __restrict__ counter = counters + g * parts + part;
   const unsigned long long units = (unsigned long long)tiles_part * 8u;
 
+  // L = 1: a lane reads its own two rows' line (16 bytes of every 128-byte row: the rest belongs to the other groups).
+  // L = 2: the two lanes of a pair read the 32 contiguous bytes of ONE row (lane parity = line), 32 consecutive rows per
+  // instruction, then swap halves (DPP): lane (pair p, parity t) ends up with both lines of row 32t + p of the wave's
+  // 64-row slice (`own`).  Half of every 64-byte sector pulled through the L1 is used instead of a quarter.
+  const uint32_t t2 = lane & 1u;
   auto load_unit = [&](u32x4 (&v)[L][2], uint64_t tile, uint32_t lt) {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const uint64_t row = tile * kQTile + lt + 512u * (uint32_t)h;
-        const uint32_t line = line_lo + (uint32_t)l;
+        const uint64_t row = tile * kQTile + 512u * (uint32_t)h + (L == 2 ? (lt & ~63u) + 32u * (uint32_t)l + ((lt >> 1) & 31u) : lt);
+        const uint32_t line = line_lo + (L == 2 ? t2 : (uint32_t)l);
         v[l][h] = (row < n && line < lpt) ? *reinterpret_cast<const u32x4*>(tuples + row * W + 4u * line) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  auto pair_swap = [&](u32x4 (&v)[L][2]) {  // L == 2: v[l][h] = line (line_lo + l) of the lane's own row
+    if (L == 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t x = v[0][h][c], y = v[L - 1][h][c];
+          const uint32_t px = dpp_xor1(x), py = dpp_xor1(y);  // cross-lane reads with every lane active, THEN select
+          v[0][h][c] = t2 ? py : x;
+          v[L - 1][h][c] = t2 ? y : px;
+        }
       }
     }
   };
@@ -758,14 +785,16 @@ __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint3
     for (uint32_t k = 0; k < 4u; ++k) {
       const uint32_t lt = lt0 + 64u * k;
       if (k + 1u < 4u) load_unit(nxt, tile, lt + 64u);
+      pair_swap(cur);
+      const uint32_t own = L == 2 ? (lt & ~63u) + 32u * t2 + ((lt >> 1) & 31u) : lt;  // a permutation of the wave's 64 tuples
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         const uint32_t line = line_lo + (uint32_t)l;
         if (line >= lpt) continue;  // narrow tuples: the last group may be short (wave-uniform)
-        const u32x4 r = rank_line(par_off + 4u * (uint32_t)l * 32u, P, ieee, miss_raw, tile * kQTile + lt < n, tile * kQTile + lt + 512u < n,
+        const u32x4 r = rank_line(par_off + 4u * (uint32_t)l * 32u, P, ieee, miss_raw, tile * kQTile + own < n, tile * kQTile + own + 512u < n,
                                   cur[l][0], cur[l][1], miss);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + lt] = r[c];
+        for (int c = 0; c < 4; ++c) q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + own] = r[c];
       }
       if (k + 1u < 4u) {
 #pragma unroll
@@ -895,12 +924,20 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
     e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters) * 4, s);
     if (e != hipSuccess) return e;
     const PrepassPlan& pp = x.prepass;
-    if (pp.groups == 1u) {  // all tables fit one CU's LDS together: fused kernel, no transposed intermediate
-      const uint32_t grid = (tiles + 1u) / 2u < a.num_cus ? (uint32_t)((tiles + 1u) / 2u) : a.num_cus;  // at most one block per CU
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.bytes[0]);
+    if (pp.groups && pp.lines >= 4u) {
+      // 1 group (all tables fit one CU's LDS together) or 2 groups of 4 lines: quad-coalesced loads, every 64-byte sector a block
+      // pulls is used whole (fused_rank_kernel); at most one block per CU
+      uint32_t lds = 0;
+      for (uint32_t g = 0; g < pp.groups; ++g) lds = pp.bytes[g] > lds ? pp.bytes[g] : lds;
+      const uint32_t parts = (pp.groups > 1u && a.num_cus >= 8u * pp.groups && tiles >= 8u) ? 8u : 1u;
+      uint32_t per_pair = a.num_cus / (parts * pp.groups);
+      if (per_pair < 1u) per_pair = 1u;
+      const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
+      if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(fused_rank_kernel, dim3(grid), dim3(kFusedThreads), pp.bytes[0], s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp.bytes[0],
-                         pp.par_off[0], pp.P[0], 0u, 8u, a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
+      hipLaunchKernelGGL(fused_rank_kernel, dim3(parts * pp.groups * per_pair), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp,
+                         parts, a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
     } else if (pp.groups) {  // one launch, blocks split over feature groups x row partitions (XCDs)
       uint32_t lds = 0;
       for (uint32_t g = 0; g < pp.groups; ++g) lds = pp.bytes[g] > lds ? pp.bytes[g] : lds;
@@ -911,7 +948,7 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
       const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
       if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
       const uint32_t grid = parts * pp.groups * per_pair;
-      auto gk = pp.lines == 1u ? grouped_rank_kernel<1> : pp.lines == 2u ? grouped_rank_kernel<2> : grouped_rank_kernel<4>;
+      auto gk = pp.lines == 1u ? grouped_rank_kernel<1> : grouped_rank_kernel<2>;
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(gk, dim3(grid), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp, parts, a.miss_raw, a.ieee,

@@ -87,27 +87,46 @@ def predict(g: Mi355x, n_trees: int, depth: int, n_features: int, n_gpus: int = 
 @dataclass
 class PathCosts:
     """Measured on one MI355X, milliseconds per 100 M tuples of 32 fp32 features, depth-8 trees
-    (profiles/r01_final_bench.md, r01_fused_prepass.md, r01_sweep_shard_regime.json, r01_tile_overhead.md)."""
+    (profiles/r01_final_bench.md, r01_sweep_shard_regime.json, r01_tile_overhead.md; pre-pass: profiles/r02_prepass_ab.log)."""
     q16_ms_per_tree: float = 0.113        # score_q16_kernel: 7.08 T node visits/s
     fp32_ms_per_tree: float = 0.147       # score_tile_kernel: 5.4 T node visits/s
     q16_fixed: float = 0.8                # per-tile fixed cost of the q16 scoring kernel
     fp32_fixed: float = 3.2               # per-tile fixed cost of the fp32 tile kernel (tuple load phase)
-    prepass_two_kernel: float = 9.8       # transpose_kernel + rank_kernel
-    prepass_fused_1: float = 4.8          # fused_rank_kernel, all tables in LDS (<= ~32 k keys)
-    prepass_fused_2: float = 5.6          # two feature groups (<= ~64 k keys)
+    prepass_two_kernel: float = 9.8       # transpose_kernel + rank_kernel (tables too big for 8 feature groups, or > 32 tuple words)
+    # LDS-resident pre-pass in 1 / 2 / 4 / 8 feature groups (fused / grouped_rank_kernel): floor + ms per probe (log2 P probes)
+    prepass_base: tuple = (3.28, 3.14, 3.72, 4.62)
+    prepass_per_probe: tuple = (0.35, 0.35, 0.275, 0.275)
     keys_per_group: int = 32_000          # distinct thresholds whose tables (+ pads, bucket starts) fit 160 KiB of LDS
+
+
+def prepass_ms(keys: int, c: "PathCosts") -> float:
+    """The engine's choice (ddt_engine.cpp build_prepass_image): cheapest feasible number of feature groups.  Bucket
+    budget -> probes: the LDS left after the tables holds ~2 bytes per bucket; P = power of two above the fullest bucket,
+    about 4x the mean occupancy for thresholds uniform in value."""
+    best = c.prepass_two_kernel
+    for i, g in enumerate((1, 2, 4, 8)):
+        per_group = keys / g
+        left = 160 * 1024 - per_group * 4.3
+        if left <= 4096:
+            continue
+        occupancy = per_group / (left / 2.0)
+        probes = 1
+        while (1 << probes) <= 4.0 * max(occupancy, 0.25) + 1.0:
+            probes += 1
+        best = min(best, c.prepass_base[i] + c.prepass_per_probe[i] * probes)
+    return best
 
 
 def engine_ms(trees: int, depth: int = 8, rows: float = 1e8, c: PathCosts = PathCosts()) -> dict:
     """Predicted time of one scoring call on one GPU and the path the engine picks (thresholds of auto_variant)."""
     scale = rows / 1e8 * depth / 8.0
     keys = trees * (2 ** depth - 1)  # upper bound: every node a distinct threshold
-    pre = c.prepass_fused_1 if keys <= c.keys_per_group else c.prepass_fused_2 if keys <= 2 * c.keys_per_group else c.prepass_two_kernel
+    pre = prepass_ms(keys, c)
     q16 = pre * rows / 1e8 + (c.q16_fixed + c.q16_ms_per_tree * trees) * scale
     fp32 = (c.fp32_fixed + c.fp32_ms_per_tree * trees) * scale
-    q16_min = 112 if keys <= 2 * c.keys_per_group else 224
+    q16_min = 112 if keys <= 8 * c.keys_per_group else 224
     path = "q16" if trees >= q16_min else "fp32"
-    return {"path": path, "ms": q16 if path == "q16" else fp32, "q16_ms": q16, "fp32_ms": fp32}
+    return {"path": path, "ms": q16 if path == "q16" else fp32, "q16_ms": q16, "fp32_ms": fp32, "prepass_ms": pre}
 
 
 def tree_sharded_ms(trees: int, n_gpus: int, depth: int = 8, rows: float = 1e8, g: Mi355x = Mi355x(), chunks: int = 8) -> dict:

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Regenerate profiles/pmc_traffic.json (config 3) and profiles/pmc_traffic_cfg4.json from the FETCH_SIZE / WRITE_SIZE passes of
+tools/gpu_evidence.sh:  python tools/update_pmc_traffic.py gpurun_out/<tag>.  bench.py reads `hbm_bytes_per_launch` of these files
+into roofline.traffic (labelled `traffic_source`: measured by rocprofv3 on the same command, in separate runs)."""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pmc(path, like):
+    out = {}
+    for db in glob.glob(path + "/**/*.db", recursive=True):
+        cur = sqlite3.connect(db).cursor()
+        q = "select counter_name, sum(value), count(*) from counters_collection where kernel_name like ? group by counter_name"
+        for cn, v, n in cur.execute(q, (f"%{like}%",)):
+            out[cn] = v / n
+    return out
+
+
+def kib(d, key):
+    return int(d[key] * 1024) if key in d else None
+
+
+def main():
+    ev = sys.argv[1].rstrip("/")
+    cmd = "python bench.py --config {} --steps 3 --warmup 1 --no-cpu-baseline --no-streamed"
+    # ---- config 3: rank-quantised path -----------------------------------------------------------------------------
+    f, w = pmc(ev + "/fetch_cfg3", "score_q16"), pmc(ev + "/write_cfg3", "score_q16")
+    fr, wr = kib(f, "FETCH_SIZE"), kib(w, "WRITE_SIZE")
+    pre = {}
+    for name, like in (("grouped_rank", "grouped_rank_kernel"), ("fused_rank", "fused_rank_kernel"), ("rank", "ddt::rank_kernel"),
+                       ("transpose", "transpose_kernel")):
+        f2, w2 = pmc(ev + "/fetch_cfg3", like), pmc(ev + "/write_cfg3", like)
+        if f2 or w2:
+            pre[name] = {"FETCH_SIZE": kib(f2, "FETCH_SIZE"), "WRITE_SIZE": kib(w2, "WRITE_SIZE")}
+    step = 2 * fr + wr + sum(2 * v["FETCH_SIZE"] + v["WRITE_SIZE"] for v in pre.values())
+    j = {"rows": 100000000, "trees": 1000, "kernel": "score_q16_kernel<8,4,4>",
+         "fetch_bytes_raw_per_launch": fr, "fetch_bytes_x2_corrected_per_launch": 2 * fr, "write_bytes_per_launch": wr,
+         "hbm_bytes_per_launch": 2 * fr + wr,
+         "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), averaged over the launches of the scoring kernel; FETCH_SIZE "
+                 "doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950 (the q tiles arrive by 16 B/lane global->LDS DMA). "
+                 "The scoring kernel reads the u16 rank tiles (6.4 GB) + the model image's L2 misses and writes 0.4 GB of scores; the fp32 tuples "
+                 "(12.8 GB) are read once, by the rank pre-pass (`prepass`: raw counter bytes per launch of its kernel(s)).",
+         "prepass": pre, "step_hbm_bytes_x2_corrected": step, "round": 2,
+         "source": f"{ev} (tools/gpu_evidence.sh): `{cmd.format(3)}`"}
+    json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    print("config 3: scoring kernel", j["hbm_bytes_per_launch"], "B/launch; whole step", step, "B;", pre)
+    # ---- config 4: sparse forest -----------------------------------------------------------------------------------
+    p4 = os.path.join(ROOT, "profiles", "pmc_traffic_cfg4.json")
+    c4 = json.load(open(p4))
+    f, w = pmc(ev + "/fetch_cfg4", "score_sparse"), pmc(ev + "/write_cfg4", "score_sparse")
+    if f and w:
+        fr4, wr4 = kib(f, "FETCH_SIZE"), kib(w, "WRITE_SIZE")
+        c4.update({"fetch_bytes_raw_per_launch": fr4, "write_bytes_per_launch": wr4,
+                   "hbm_bytes_per_launch": fr4 + c4["tuple_stream_bytes"] // 2 + wr4, "source": f"{ev}: `{cmd.format(4)}`"})
+        json.dump(c4, open(p4, "w"), indent=1)
+        print("config 4:", c4["hbm_bytes_per_launch"], "B/launch")
+
+
+if __name__ == "__main__":
+    main()
