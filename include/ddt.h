@@ -231,7 +231,10 @@ const char* ddt_strerror(int code);
 const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure on this engine */
 /* Tuning knobs: "variant" (kernel variant id, -1 = auto; a loaded model is re-packed), "feeder_rows" (rows per feeder
  * chunk), "feeder_threads" (host threads of the staging copy, default 8), "kernel_timing" (see ddt_stats),
- * "q16_fused_prepass" (1 = default; 0 = always use the two-kernel rank pre-pass), "reserve_rows" (pre-size the
+ * "q16_fused_prepass" / "q16_grouped_prepass" (1 = default; 0 = never rank with all tables resident together / never
+ * split the rank pre-pass over feature groups; both 0 = the transpose + rank kernels) and "q16_prepass_groups" (0 =
+ * cheapest, default; 1, 2, 4, 8 = exactly that many feature groups): A/B switches, effective at the next model load;
+ * "reserve_rows" (pre-size the
  * workspace of the rank-quantised path for calls of up to that many rows: the *_device calls then never allocate),
  * "leaf_domain_check" (1 = default: refuse -0 / sub-normal / Inf / NaN leaves in the reference-order sum, where the
  * GPU's IEEE adds and the reference's adder differ), "sparse_top_levels" (-1 = auto, or 6..10 levels of a sparse
