@@ -334,8 +334,9 @@ struct ddt_group {
   std::vector<ddt_comm*> comm;
   std::vector<hipStream_t> stream;
   std::vector<void*> d_tuples;
-  std::vector<float*> d_scores;
-  size_t cap_rows = 0, cap_words = 0;
+  std::vector<float*> d_scores;  // [cap_classes][cap_rows]: scalar scores, or the per-class sums of a multi-class model
+  std::vector<int32_t*> d_labels;
+  size_t cap_rows = 0, cap_words = 0, cap_classes = 0;
   size_t group_rows = 8u << 20;  // rows per super-chunk held on the devices at once
   char err[320] = {0};
 };
@@ -370,10 +371,12 @@ void group_free_buffers(ddt_group* g) {
     (void)hipSetDevice(g->devices[(size_t)i]);
     if (g->d_tuples[(size_t)i]) (void)hipFree(g->d_tuples[(size_t)i]);
     if (g->d_scores[(size_t)i]) (void)hipFree(g->d_scores[(size_t)i]);
+    if (g->d_labels[(size_t)i]) (void)hipFree(g->d_labels[(size_t)i]);
     g->d_tuples[(size_t)i] = nullptr;
     g->d_scores[(size_t)i] = nullptr;
+    g->d_labels[(size_t)i] = nullptr;
   }
-  g->cap_rows = g->cap_words = 0;
+  g->cap_rows = g->cap_words = g->cap_classes = 0;
 }
 
 }  // namespace
@@ -403,6 +406,7 @@ int ddt_group_create(ddt_group** out, int n_devices, const int* device_ids) {
   g->stream.assign((size_t)n_devices, nullptr);
   g->d_tuples.assign((size_t)n_devices, nullptr);
   g->d_scores.assign((size_t)n_devices, nullptr);
+  g->d_labels.assign((size_t)n_devices, nullptr);
   int rc = DDT_OK;
   for (int i = 0; i < n_devices && !rc; ++i) rc = ddt_create(&g->eng[(size_t)i], g->devices[(size_t)i]);
   std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
@@ -474,41 +478,70 @@ int ddt_group_load_model_sparse(ddt_group* g, const ddt_params* p, const void* n
   return rc;
 }
 
-int ddt_group_score(ddt_group* g, const void* tuple_lines, size_t n, float* scores_out, int combine) {
+int ddt_group_load_model_multiclass(ddt_group* g, const ddt_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines,
+                                    uint32_t num_classes, int interleaved) {
   if (!g) return DDT_EINVAL;
-  if (n == 0) return DDT_OK;
-  if (!tuple_lines || !scores_out) return gfail(g, DDT_EINVAL, "NULL host buffer");
+  int rc = for_each_device(g, [&](int i) {
+    return ddt_load_model_multiclass(g->eng[(size_t)i], p, wl, n_wlines, fl, n_flines, num_classes, interleaved, (uint32_t)i, (uint32_t)g->n);
+  });
+  if (rc)
+    for (int i = 0; i < g->n; ++i)
+      if (g->eng[(size_t)i]->err[0]) return gfail(g, rc, "device %d: %s", g->devices[(size_t)i], g->eng[(size_t)i]->err);
+  return rc;
+}
+
+}  // extern "C"
+
+namespace {
+
+// host tuples -> every device -> the sharded job -> device 0's results back to the host, in super-chunks of group_rows.
+// classes == 1: scores_out [n].  classes > 1: labels_out [n] and (optional) class_scores_out [classes][n].
+int group_run(ddt_group* g, const void* tuple_lines, size_t n, float* scores_out, int32_t* labels_out, float* class_scores_out, int combine) {
   if (!g->eng[0]->loaded) return gfail(g, DDT_ESTATE, "no model loaded");
+  const size_t K = g->eng[0]->num_classes;
+  const bool classify = labels_out != nullptr || class_scores_out != nullptr;
+  if (classify != (K > 1)) return gfail(g, DDT_ESTATE, K > 1 ? "multi-class model loaded: use ddt_group_classify" : "scalar model loaded: use ddt_group_score");
   const size_t W = tuple_words(g->eng[0]->p);
   const size_t rows = std::min(g->group_rows, n);
   int prev = -1;
   (void)hipGetDevice(&prev);
-  if (rows > g->cap_rows || W > g->cap_words) {
+  if (rows > g->cap_rows || W > g->cap_words || K > g->cap_classes) {
     group_free_buffers(g);
     for (int i = 0; i < g->n; ++i) {
       if (hipSetDevice(g->devices[(size_t)i]) != hipSuccess || hipMalloc(&g->d_tuples[(size_t)i], rows * W * 4) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&g->d_scores[(size_t)i]), rows * sizeof(float)) != hipSuccess) {
+          hipMalloc(reinterpret_cast<void**>(&g->d_scores[(size_t)i]), K * rows * sizeof(float)) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&g->d_labels[(size_t)i]), rows * sizeof(int32_t)) != hipSuccess) {
         if (prev >= 0) (void)hipSetDevice(prev);
         return gfail(g, DDT_ENOMEM, "device %d: tuple / score buffers for %zu rows", g->devices[(size_t)i], rows);
       }
     }
     g->cap_rows = rows;
     g->cap_words = W;
+    g->cap_classes = K;
   }
   const uint32_t* src = reinterpret_cast<const uint32_t*>(tuple_lines);
   int rc = DDT_OK;
   for (size_t off = 0; off < n && !rc; off += rows) {
     const size_t m = std::min(rows, n - off);
     // every device: its own copy of the tuples (the reference broadcasts them along the ring), the sharded job, and
-    // -- device 0 only -- the combined scores back to the host
+    // -- device 0 only -- the combined results back to the host
     rc = for_each_device(g, [&](int i) -> int {
       const size_t k = (size_t)i;
+      hipStream_t s = g->stream[k];
       if (hipSetDevice(g->devices[k]) != hipSuccess) return DDT_EHIP;
-      if (hipMemcpyAsync(g->d_tuples[k], src + off * W, m * W * 4, hipMemcpyHostToDevice, g->stream[k]) != hipSuccess) return DDT_EHIP;
-      int r = ddt_score_sharded_device(g->comm[k], g->d_tuples[k], m, g->d_scores[k], combine, g->stream[k]);
+      if (hipMemcpyAsync(g->d_tuples[k], src + off * W, m * W * 4, hipMemcpyHostToDevice, s) != hipSuccess) return DDT_EHIP;
+      int r = classify ? ddt_classify_sharded_device(g->comm[k], g->d_tuples[k], m, g->d_scores[k], g->d_labels[k], combine, s)
+                       : ddt_score_sharded_device(g->comm[k], g->d_tuples[k], m, g->d_scores[k], combine, s);
       if (r) return r;
-      if (i == 0 && hipMemcpyAsync(scores_out + off, g->d_scores[k], m * sizeof(float), hipMemcpyDeviceToHost, g->stream[k]) != hipSuccess) return DDT_EHIP;
-      return hipStreamSynchronize(g->stream[k]) == hipSuccess ? DDT_OK : DDT_EHIP;
+      if (i == 0) {
+        bool ok = true;
+        if (!classify) ok = hipMemcpyAsync(scores_out + off, g->d_scores[k], m * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (classify && labels_out) ok = hipMemcpyAsync(labels_out + off, g->d_labels[k], m * sizeof(int32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
+        for (size_t c = 0; classify && class_scores_out && ok && c < K; ++c)  // device layout [K][m] of this super-chunk -> host [K][n]
+          ok = hipMemcpyAsync(class_scores_out + c * n + off, g->d_scores[k] + c * m, m * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess;
+        if (!ok) return DDT_EHIP;
+      }
+      return hipStreamSynchronize(s) == hipSuccess ? DDT_OK : DDT_EHIP;
     });
   }
   if (prev >= 0) (void)hipSetDevice(prev);
@@ -518,6 +551,24 @@ int ddt_group_score(ddt_group* g, const void* tuple_lines, size_t n, float* scor
       if (msg && msg[0]) return gfail(g, rc, "device %d: %s", g->devices[(size_t)i], msg);
     }
   return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ddt_group_score(ddt_group* g, const void* tuple_lines, size_t n, float* scores_out, int combine) {
+  if (!g) return DDT_EINVAL;
+  if (n == 0) return DDT_OK;
+  if (!tuple_lines || !scores_out) return gfail(g, DDT_EINVAL, "NULL host buffer");
+  return group_run(g, tuple_lines, n, scores_out, nullptr, nullptr, combine);
+}
+
+int ddt_group_classify(ddt_group* g, const void* tuple_lines, size_t n, int32_t* labels_out, float* class_scores_out, int combine) {
+  if (!g) return DDT_EINVAL;
+  if (n == 0) return DDT_OK;
+  if (!tuple_lines || !labels_out) return gfail(g, DDT_EINVAL, "NULL host buffer");
+  return group_run(g, tuple_lines, n, nullptr, labels_out, class_scores_out, combine);
 }
 
 }  // extern "C"

@@ -366,7 +366,8 @@ uint32_t total_trees(const ddt_engine* e) {
   return t;
 }
 
-constexpr uint32_t kQ16MinTreesFused = 112;  // measured break-even with the fused pre-pass ~90 trees (profiles/r01_fused_prepass.md)
+constexpr uint32_t kQ16MinTreeLevels = 640;  // trees x levels from which the rank-quantised path wins with the LDS-resident pre-pass
+                                             // (profiles/r02_sweep_q16_small.json: 60 x d8 +4 %, 80 x d8 +5 %, 100 x d6 +1 %, 112 x d8 +7 %, 200 x d6 +9 %)
 constexpr uint32_t kQ16MaxTable = 32767;  // ranks must stay below 0xFFFF and a table (x4 B) must fit LDS in the rank kernel
 
 bool variant_fits(const Variant& v, const ddt_engine* e) {
@@ -407,10 +408,10 @@ int auto_variant(const ddt_engine* e) {
   // rank pre-pass per tuple.  Measured per 100 M tuples (profiles/r01_*): q16 = 10.9 ms + 0.113 ms/tree, fp32 tile =
   // 3.2 ms + 0.147 ms/tree => break-even near 200 trees per engine; 250 trees (4-way shard of 1000) goes to q16.
   // With small tables (they all fit LDS together, e.g. a 125-tree shard) the pre-pass is one fused kernel and the
-  // break-even drops accordingly (kQ16MinTreesFused).
+  // break-even drops accordingly (kQ16MinTreeLevels).
   uint32_t q16_min = 224u;
-  if (tuple_words(e->p) <= 32u && total_trees(e) >= kQ16MinTreesFused && total_trees(e) < 224u && prepass_plan_exists(e))
-    q16_min = kQ16MinTreesFused;
+  if (tuple_words(e->p) <= 32u && total_trees(e) * e->p.num_levels >= kQ16MinTreeLevels && total_trees(e) < 224u && prepass_plan_exists(e))
+    q16_min = total_trees(e);
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
     static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4", "q16_d5_c32_u4", "q16_d3_c128_u8",
                                   "q16_d9_c4_u4", "q16_d10_c4_u4"};

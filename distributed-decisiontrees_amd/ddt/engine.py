@@ -401,8 +401,24 @@ class Group:
         self.params = params
         return self
 
+    def load_model_multiclass(self, params: Params, wlines: np.ndarray, flines: np.ndarray, num_classes: int, interleaved: bool = True):
+        w = np.ascontiguousarray(wlines).view(np.uint32).reshape(-1)
+        f = np.ascontiguousarray(flines).view(np.uint16).reshape(-1)
+        self._check(self._L.ddt_group_load_model_multiclass(self._h, C.byref(params), w.ctypes.data, w.size // 4, f.ctypes.data, f.size // 8,
+                                                             num_classes, 1 if interleaved else 0))
+        self.params, self.num_classes = params, num_classes
+        return self
+
     def score(self, tuple_lines: np.ndarray, combine: int = COMBINE_ALLREDUCE) -> np.ndarray:
         t = np.ascontiguousarray(tuple_lines).view(np.uint32).reshape(-1, tuple_words(self.params.num_features))
         out = np.empty(t.shape[0], np.float32)
         self._check(self._L.ddt_group_score(self._h, t.ctypes.data, t.shape[0], out.ctypes.data, combine))
         return out
+
+    def classify(self, tuple_lines: np.ndarray, combine: int = COMBINE_ALLREDUCE, want_scores: bool = True):
+        """labels [n] int32 and (optionally) the combined per-class sums [num_classes][n]."""
+        t = np.ascontiguousarray(tuple_lines).view(np.uint32).reshape(-1, tuple_words(self.params.num_features))
+        labels = np.empty(t.shape[0], np.int32)
+        cs = np.empty((self.num_classes, t.shape[0]), np.float32) if want_scores else None
+        self._check(self._L.ddt_group_classify(self._h, t.ctypes.data, t.shape[0], labels.ctypes.data, cs.ctypes.data if want_scores else None, combine))
+        return labels, cs

@@ -124,8 +124,8 @@ def engine_ms(trees: int, depth: int = 8, rows: float = 1e8, c: PathCosts = Path
     pre = prepass_ms(keys, c)
     q16 = pre * rows / 1e8 + (c.q16_fixed + c.q16_ms_per_tree * trees) * scale
     fp32 = (c.fp32_fixed + c.fp32_ms_per_tree * trees) * scale
-    q16_min = 112 if keys <= 8 * c.keys_per_group else 224
-    path = "q16" if trees >= q16_min else "fp32"
+    q16_ok = trees >= 224 or (keys <= 8 * c.keys_per_group and trees * depth >= 640)  # ddt_engine.cpp kQ16MinTreeLevels
+    path = "q16" if q16_ok else "fp32"
     return {"path": path, "ms": q16 if path == "q16" else fp32, "q16_ms": q16, "fp32_ms": fp32, "prepass_ms": pre}
 
 

@@ -223,6 +223,12 @@ int  ddt_group_load_model(ddt_group* g, const ddt_params* p, const void* weights
 int  ddt_group_load_model_sparse(ddt_group* g, const ddt_params* p, const void* node_lines, size_t n_lines,
                                  const uint64_t* tree_first_line);
 int  ddt_group_score(ddt_group* g, const void* tuple_lines, size_t n_tuples, float* scores_out, int combine);
+/* multi-class models (config 5): class k's trees sharded tree-wise like the scalar ensemble; labels_out [n] int32 argmax of
+ * the combined per-class sums, class_scores_out (may be NULL) [num_classes][n] */
+int  ddt_group_load_model_multiclass(ddt_group* g, const ddt_params* p, const void* weights_lines, size_t n_wlines,
+                                     const void* findex_lines, size_t n_flines, uint32_t num_classes, int interleaved);
+int  ddt_group_classify(ddt_group* g, const void* tuple_lines, size_t n_tuples, int32_t* labels_out, float* class_scores_out,
+                        int combine);
 
 /* -- introspection ----------------------------------------------------------------------------------- */
 int ddt_get_info(const ddt_engine* e, ddt_info* out);

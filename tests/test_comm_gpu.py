@@ -104,6 +104,17 @@ def test_group_of_one_device_host_buffers(eng):
     xs = O.gen_tuples(0, 3000, 20, 1)
     g.load_model_sparse(ddt.make_sparse_params(16, 12, 20), s.node_lines, s.first)
     assert np.array_equal(_bits(g.score(xs)), _bits(O.score_sparse(s, xs)))
+    # a multi-class model through the group: labels + per-class sums; more rows than one super-chunk would need no change
+    T, D, F, K, rows = 60, 6, 16, 3, 2100
+    m = O.gen_model(T, D, F, 1)
+    xc = O.gen_tuples(0, rows, F, 1)
+    labels, cs = O.classify(m, xc, K)
+    g.load_model_multiclass(ddt.make_params(T, D, F, clusters=1), m.wlines, m.flines, K, True)
+    for combine in (0, 1):
+        gl, gs = g.classify(xc, combine=combine)
+        assert np.array_equal(gl, labels) and np.array_equal(_bits(gs), _bits(cs)), combine
+    with pytest.raises(ddt.DDTError):  # the scalar call refuses a multi-class model
+        g.score(xc)
     g.close()
     with pytest.raises(ddt.DDTError):  # no such device
         ddt.Group([0, 63])
