@@ -87,3 +87,69 @@ def test_random_sparse_forest_bit_exact(seed, T, D, F, full, pm, n, cmp_mode, cl
         assert np.array_equal(e.score(x).view(np.uint32), want.view(np.uint32))
     finally:
         e.close()
+
+
+def _dist_cases():
+    rng = np.random.default_rng(20260923)
+    return [(i, int(rng.integers(80, 420)), int(rng.integers(1, 33)), int(rng.integers(1, 5000)), int(rng.integers(0, 2))) for i in range(14)]
+
+
+@pytest.mark.parametrize("seed,T,F,n,cmp_mode", _dist_cases())
+def test_rank_prepass_on_mixed_threshold_distributions(seed, T, F, n, cmp_mode):
+    """The LDS-resident rank pre-pass (segmented bucket index) on models whose thresholds follow a DIFFERENT distribution per
+    feature -- uniform, exponential over 30 octaves, small integers, one constant, negative, +-huge, two tight clusters --
+    with tuples drawn around the thresholds (many exactly on one), missing values, both compare modes; every number of
+    feature groups that fits, and the transpose + rank kernels."""
+    rng = np.random.default_rng(777 + seed)
+    D, nint = 8, 255
+    m = O.gen_model(T, D, F, dist=1, cmp_mode=cmp_mode)
+    w = m.wlines.copy().reshape(T, -1)
+    fidx = rng.integers(0, F, (T, nint))
+    kinds = rng.integers(0, 7, F)
+    thr = np.empty((T, nint), np.float32)
+    for j in range(F):
+        sel = fidx == j
+        k = int(sel.sum())
+        if k == 0:
+            continue
+        kind = kinds[j]
+        if kind == 0:
+            v = rng.random(k)
+        elif kind == 1:
+            v = np.exp2(rng.uniform(-20, 10, k))
+        elif kind == 2:
+            v = rng.integers(-5, 40, k).astype(np.float64)
+        elif kind == 3:
+            v = np.full(k, 0.75)
+        elif kind == 4:
+            v = -np.exp2(rng.uniform(-3, 3, k))
+        elif kind == 5:
+            v = rng.choice([-3.0e38, 3.0e38, 1e-30, -1e-30, 0.0, 1.0], k)
+        else:
+            v = np.where(rng.random(k) < 0.5, 0.25 + rng.integers(0, 4000, k) * 2.0 ** -24, 1000.0 + rng.integers(0, 4000, k) * 2.0 ** -12)
+        thr[sel] = v.astype(np.float32)
+    w[:, :nint] = thr.view(np.uint32)
+    # feature-index lines: one u16 entry per node, keep the flag bits of the generated model, replace the index
+    fl = m.flines.copy().reshape(T, -1)
+    fl[:, :nint] = (fl[:, :nint] & 0xF800) | fidx.astype(fl.dtype)
+    m = O.Model(m.params, w.reshape(m.wlines.shape), fl.reshape(m.flines.shape))
+    x = O.gen_tuples(9000 + seed, n, F, dist=1, missing_bits=m.params.missing_bits)
+    pick = thr.reshape(-1)[rng.integers(0, thr.size, (n, F))].view(np.uint32).astype(np.int64) + rng.integers(-1, 2, (n, F))
+    keep = rng.random((n, F)) < 0.6
+    x[:, :F] = np.where(keep, (pick & 0xFFFFFFFF).astype(np.uint32), x[:, :F])
+    want = O.score(m, x)
+    p = m.params
+    params = ddt.make_params(p.num_trees, p.num_levels, p.num_features, p.missing_bits, p.cmp_mode, p.clusters_per_tuple, 0)
+    e = ddt.Engine(0)
+    try:
+        e.set_option("variant", ddt.variant_names().index("q16_d8_c4_u4"))
+        for groups in (0, 1, 2, 4, 8, -1):
+            e.set_option("q16_fused_prepass", 0 if groups < 0 else 1)
+            e.set_option("q16_grouped_prepass", 0 if groups < 0 else 1)
+            e.set_option("q16_prepass_groups", max(groups, 0))
+            e.load_model(params, m.wlines, m.flines)
+            got = e.score(x)
+            bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+            assert bad.size == 0, f"groups={groups} (plan {e.info().prepass_groups}): {bad.size} rows differ, first {bad[:5]}"
+    finally:
+        e.close()
