@@ -1254,6 +1254,38 @@ int ddt_variant_name(int v, char* buf, size_t buflen) {
 static inline float unit24(uint64_t h) { return (float)(h >> 40) * (1.0f / 16777216.0f); }
 static inline uint32_t fbits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
 
+int64_t ddt_debug_prepass_image(const uint32_t* keys, const uint32_t* counts, uint32_t n_words, uint32_t groups, uint32_t* image_out,
+                                size_t image_cap_words, uint32_t plan_out[42]) {
+  if (!keys || !counts || !plan_out || n_words == 0 || n_words > 32u || (n_words & 3u)) return DDT_EINVAL;
+  if (groups != 0 && groups != 1 && groups != 2 && groups != 4 && groups != 8) return DDT_EINVAL;
+  RankTables rt;
+  rt.keys.resize(n_words);
+  size_t off = 0;
+  for (uint32_t w = 0; w < n_words; ++w) {
+    if (counts[w] > kQ16MaxTable) return DDT_EUNSUPPORTED;
+    rt.keys[w].assign(keys + off, keys + off + counts[w]);
+    for (uint32_t i = 1; i < counts[w]; ++i)
+      if (!((int32_t)rt.keys[w][i - 1] < (int32_t)rt.keys[w][i])) return DDT_EINVAL;  // sorted, distinct
+    off += counts[w];
+    rt.max_len = counts[w] > rt.max_len ? counts[w] : rt.max_len;
+  }
+  std::vector<uint32_t> img;
+  PrepassPlan pl{};
+  memset(plan_out, 0, 42 * sizeof(uint32_t));
+  if (!build_prepass_image(rt, n_words, groups, true, true, &img, &pl)) return 0;
+  plan_out[0] = pl.groups;
+  plan_out[1] = pl.lines;
+  for (uint32_t g = 0; g < pl.groups; ++g) {
+    uint32_t* o = plan_out + 2 + 5 * g;
+    o[0] = pl.img_off[g], o[1] = pl.bytes[g], o[2] = pl.par_off[g], o[3] = pl.P[g], o[4] = pl.line_lo[g];
+  }
+  if (image_out) {
+    if (image_cap_words < img.size()) return DDT_EINVAL;
+    memcpy(image_out, img.data(), img.size() * 4);
+  }
+  return (int64_t)img.size();
+}
+
 int ddt_synth_model(uint32_t T, uint32_t D, uint32_t F, int dist, void* wlines, void* flines) {
   if (!wlines || !flines || T == 0 || D < 1 || D > 16 || F < 1 || F > 2048) return DDT_EINVAL;
   uint32_t* w = reinterpret_cast<uint32_t*>(wlines);

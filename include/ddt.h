@@ -287,6 +287,17 @@ int ddt_synth_tuples_host(void* tuple_lines, uint64_t row0, size_t n, uint32_t n
 int ddt_synth_tuples_device(ddt_engine* e, void* d_tuple_lines, uint64_t row0, size_t n,
                             uint32_t num_features, int dist, uint32_t missing_bits, void* hip_stream);
 
+/* -- host-only test hook (needs no GPU): the LDS images of the rank pre-pass of the rank-quantised path -------------
+ *    keys = the sorted (signed int32 order) distinct threshold keys of every feature, concatenated; counts[w] per tuple
+ *    word w (n_words = 4 * ceil(F / 4) <= 32).  groups: 0 = the engine's choice, else 1 / 2 / 4 / 8 feature groups.
+ *    plan_out[0] = groups built (0: tables too big, the engine would fall back to its transposed pre-pass), [1] = tuple
+ *    lines per group, then per group g {image byte offset, image bytes, parameter-block byte offset, P, first line} at
+ *    plan_out[2 + 5 g].  image_out (may be NULL to size it) receives the concatenated images; returns the number of
+ *    32-bit words they take (negative DDT_E* on bad arguments).  Layout: DESIGN.md section 3; tests/test_prepass_host.py
+ *    replays the kernel's search on it against a plain sorted-table count. */
+int64_t ddt_debug_prepass_image(const uint32_t* keys, const uint32_t* counts, uint32_t n_words, uint32_t groups,
+                                uint32_t* image_out, size_t image_cap_words, uint32_t plan_out[42]);
+
 #ifdef __cplusplus
 }
 #endif
