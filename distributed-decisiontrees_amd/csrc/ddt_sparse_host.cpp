@@ -6,6 +6,9 @@
 // the (disabled) hook for trees that exceed it are DTPU.sv:20-28,736-745 and Core.sv:380 bit 8; entry bit layout
 // DTPU.sv:628,637,659-661; contiguous per-device tree shards PCIeReceiver.sv:241-264; EMPTY slots DTPU.sv:544,760.
 #include <algorithm>
+#include <cstring>
+#include <memory>
+#include <new>
 
 #include "ddt_engine_priv.h"
 
@@ -75,6 +78,8 @@ void sparse_free(ddt_engine* e) {
 }
 
 static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp);
+static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest& sp, std::vector<uint32_t>& top, std::vector<uint32_t>& deep,
+                            uint32_t* groups_out);
 
 // Choose the kernel for the loaded forest(s) and pack the device images of every class for it.
 int sparse_rebuild(ddt_engine* e) {
@@ -94,7 +99,9 @@ int sparse_rebuild(ddt_engine* e) {
 }
 
 // Pack the device images of one forest for kernel `v` and upload them.
-static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp) {
+// the host half of the packing (no HIP call: also behind the test hook ddt_debug_sparse_image)
+static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest& sp, std::vector<uint32_t>& top, std::vector<uint32_t>& deep,
+                            uint32_t* groups_out) {
   const uint32_t K = (uint32_t)v.levels, T = sp.trees();
   const uint32_t per_pass = std::max(1u, (uint32_t)v.chunk_trees / 8u);  // PU groups walked in lock-step (half groups: 1)
   uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
@@ -103,7 +110,6 @@ static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp) {
   const uint32_t feat_off = v.feat_off_sparse(), row = v.row_bytes();
   auto feat_word = [&](uint32_t j) { return feat_off + j * row; };
 
-  std::vector<uint32_t> top, deep;
   try {
     top.assign((size_t)groups * 8u * top_words, 0u);
   } catch (const std::bad_alloc&) {
@@ -224,7 +230,15 @@ static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp) {
     }
     for (auto& pe : pending) *pe.second = where[pe.first];
   }
+  *groups_out = groups;
+  return DDT_OK;
+}
 
+static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp) {
+  std::vector<uint32_t> top, deep;
+  uint32_t groups = 0;
+  int rc = sparse_pack_host(e, v, sp, top, deep, &groups);
+  if (rc) return rc;
   HIP_TRY(e, hipMalloc(&sp.d_top, top.size() * 4u));
   HIP_TRY(e, hipMalloc(&sp.d_deep, deep.size() * 4u));
   HIP_TRY(e, hipMemcpy(sp.d_top, top.data(), top.size() * 4u, hipMemcpyHostToDevice));
@@ -375,4 +389,43 @@ extern "C" int ddt_load_model_sparse_multiclass(ddt_engine* e, const ddt_params*
 extern "C" int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const void* node_lines, size_t n_lines,
                                      const uint64_t* first, uint32_t shard_index, uint32_t shard_count) {
   return ddt_load_model_sparse_multiclass(e, p, node_lines, n_lines, first, 1, 0, shard_index, shard_count);
+}
+
+// Host-only test hook (include/ddt.h): validate + pack a sparse forest for kernel variant `variant_id` without touching a GPU.
+extern "C" int ddt_debug_sparse_image(const ddt_params* p, const void* node_lines, size_t n_lines, const uint64_t* first, int variant_id,
+                                      int deep_order, uint32_t* top_out, size_t top_cap_words, uint32_t* deep_out, size_t deep_cap_words,
+                                      uint64_t info_out[6]) {
+  if (!p || !node_lines || !first || !info_out) return DDT_EINVAL;
+  if (variant_id < 0 || variant_id >= num_variants() || variant(variant_id).kind != kKindSparse) return DDT_EINVAL;
+  if (p->num_trees == 0 || p->num_levels < 1 || p->num_levels > 64 || p->num_features < 1 || p->num_features > 2048) return DDT_EINVAL;
+  if (first[0] != 0 || first[p->num_trees] > n_lines) return DDT_EINVAL;
+  std::unique_ptr<ddt_engine> e(new (std::nothrow) ddt_engine());  // never created on a device: only p, the options and err are used
+  if (!e) return DDT_ENOMEM;
+  e->p = *p;
+  e->sparse_deep_order = deep_order ? 1 : 0;
+  std::vector<uint32_t> ids(p->num_trees);
+  for (uint32_t i = 0; i < p->num_trees; ++i) ids[i] = i;
+  SparseForest sp;
+  int rc = take_trees(e.get(), p, reinterpret_cast<const uint32_t*>(node_lines), first, std::move(ids), &sp);
+  if (rc) return rc;
+  const Variant& v = variant(variant_id);
+  std::vector<uint32_t> top, deep;
+  uint32_t groups = 0;
+  rc = sparse_pack_host(e.get(), v, sp, top, deep, &groups);
+  if (rc) return rc;
+  info_out[0] = top.size();
+  info_out[1] = deep.size();
+  info_out[2] = groups;
+  info_out[3] = (uint64_t)v.levels;
+  info_out[4] = v.feat_off_sparse();
+  info_out[5] = v.row_bytes();
+  if (top_out) {
+    if (top_cap_words < top.size()) return DDT_EINVAL;
+    memcpy(top_out, top.data(), top.size() * 4u);
+  }
+  if (deep_out) {
+    if (deep_cap_words < deep.size()) return DDT_EINVAL;
+    memcpy(deep_out, deep.data(), deep.size() * 4u);
+  }
+  return DDT_OK;
 }

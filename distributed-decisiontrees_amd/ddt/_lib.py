@@ -20,7 +20,7 @@ SYMBOLS = [
     "ddt_comm_get_unique_id", "ddt_comm_create", "ddt_comm_destroy", "ddt_comm_last_error", "ddt_comm_set_option",
     "ddt_score_sharded_device", "ddt_score_rowsharded_device", "ddt_classify_sharded_device",
     "ddt_group_create", "ddt_group_destroy", "ddt_group_last_error", "ddt_group_engine", "ddt_group_load_model",
-    "ddt_group_load_model_sparse", "ddt_group_score", "ddt_group_load_model_multiclass", "ddt_group_classify", "ddt_debug_prepass_image",
+    "ddt_group_load_model_sparse", "ddt_group_score", "ddt_group_load_model_multiclass", "ddt_group_classify", "ddt_debug_prepass_image", "ddt_debug_sparse_image",
 ]
 
 
@@ -135,6 +135,7 @@ def lib():
     L.ddt_group_load_model_multiclass.restype, L.ddt_group_load_model_multiclass.argtypes = i32, [vp, PP, vp, sz, vp, sz, u32, i32]
     L.ddt_group_classify.restype, L.ddt_group_classify.argtypes = i32, [vp, vp, sz, vp, vp, i32]
     L.ddt_debug_prepass_image.restype, L.ddt_debug_prepass_image.argtypes = C.c_int64, [vp, vp, u32, u32, vp, sz, vp]
+    L.ddt_debug_sparse_image.restype, L.ddt_debug_sparse_image.argtypes = i32, [PP, vp, sz, vp, i32, i32, vp, sz, vp, sz, vp]
     L.ddt_synth_model.restype, L.ddt_synth_model.argtypes = i32, [u32, u32, u32, i32, vp, vp]
     L.ddt_synth_tuples_host.restype, L.ddt_synth_tuples_host.argtypes = i32, [vp, u64, sz, u32, i32, u32]
     L.ddt_synth_tuples_device.restype, L.ddt_synth_tuples_device.argtypes = i32, [vp, vp, u64, sz, u32, i32, u32, vp]

@@ -297,6 +297,13 @@ int ddt_synth_tuples_device(ddt_engine* e, void* d_tuple_lines, uint64_t row0, s
  *    replays the kernel's search on it against a plain sorted-table count. */
 int64_t ddt_debug_prepass_image(const uint32_t* keys, const uint32_t* counts, uint32_t n_words, uint32_t groups,
                                 uint32_t* image_out, size_t image_cap_words, uint32_t plan_out[42]);
+/*    the device images of a sparse forest as sparse kernel variant `variant_id` wants them: the whole
+ *    stream is validated like ddt_load_model_sparse does, then packed -- top heap images per PU group and the deep record
+ *    array.  info_out = {top words, deep words, PU groups, top levels K, LDS byte offset of feature row 0, bytes per
+ *    feature row}; top_out / deep_out may be NULL to size them.  tests/test_sparse_host.py walks the images in numpy. */
+int ddt_debug_sparse_image(const ddt_params* p, const void* node_lines, size_t n_lines, const uint64_t* tree_first_line,
+                           int variant_id, int deep_order, uint32_t* top_out, size_t top_cap_words, uint32_t* deep_out,
+                           size_t deep_cap_words, uint64_t info_out[6]);
 
 #ifdef __cplusplus
 }

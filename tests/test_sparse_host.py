@@ -1,0 +1,106 @@
+"""Host logic of the sparse (explicit-children) path, no GPU needed: the device images `ddt_sparse_host.cpp sparse_pack_host`
+builds (top-K perfect heap images per PU group with dummy nodes under early leaves, level K-1 records, the deep record
+array in level or depth-first order) come back through the test hook `ddt_debug_sparse_image` and
+are walked in numpy the way `score_sparse_kernel` walks them; every (tuple, tree) must end on the leaf the oracle's walk of
+the wire format ends on, EMPTY slots on +0."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import ddt
+from ddt import _lib
+
+LEFT_LEAF, RIGHT_LEAF, MISS_RIGHT, ADDR = 0x80000000, 0x40000000, 0x20000000, 0x1FFFFFFF
+
+
+def _images(s, variant, order):
+    L = _lib.lib()
+    nl = np.ascontiguousarray(s.node_lines).view(np.uint32).reshape(-1, 4)
+    first = np.ascontiguousarray(s.first, dtype=np.uint64)
+    q = s.params
+    p = ddt.make_sparse_params(q.num_trees, q.num_levels, q.num_features, q.missing_bits, q.cmp_mode, q.clusters_per_tuple, 0)
+    info = np.zeros(6, np.uint64)
+    rc = L.ddt_debug_sparse_image(C.byref(p), nl.ctypes.data, nl.shape[0], first.ctypes.data, variant, order, None, 0, None, 0, info.ctypes.data)
+    assert rc == 0, rc
+    top, deep = np.zeros(int(info[0]), np.uint32), np.zeros(int(info[1]), np.uint32)
+    rc = L.ddt_debug_sparse_image(C.byref(p), nl.ctypes.data, nl.shape[0], first.ctypes.data, variant, order, top.ctypes.data, top.size,
+                                  deep.ctypes.data, deep.size, info.ctypes.data)
+    assert rc == 0, rc
+    return top, deep.reshape(-1, 4), [int(v) for v in info]
+
+
+def _walk(top, deep, info, slot, x, miss_bits):
+    """score_sparse_kernel's walk of one tree slot for one tuple (cmp_mode 0: signed compare of the raw bits)"""
+    _, _, _, K, feat_off, row = info
+    t = top[slot * (12 << K) // 4: (slot + 1) * (12 << K) // 4]
+
+    def right(key, w):
+        f = int(x[((w & ADDR) - feat_off) // row])
+        if f == miss_bits:
+            return (w & MISS_RIGHT) != 0
+        return np.int32(np.uint32(f).view(np.int32)) >= np.uint32(key).view(np.int32)
+
+    m = 1
+    for _ in range(K - 1):
+        m = 2 * m + int(right(int(t[2 * m]), int(t[2 * m + 1])))
+    rec = t[(4 << K) // 4 + 4 * (m - (1 << (K - 1))):][:4]
+    for _ in range(80):
+        key, w, lo, hi = (int(v) for v in rec)
+        r = bool(right(key, w))
+        nxt = hi if r else lo
+        if w & (RIGHT_LEAF if r else LEFT_LEAF):
+            return nxt
+        assert 0 < nxt < deep.shape[0]
+        rec = deep[nxt]
+    raise AssertionError("walk does not terminate")
+
+
+def _sparse_variants():
+    return [(i, n) for i, n in enumerate(ddt.variant_names()) if n.startswith("sparse_")]
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("shape", [(19, 14, 12, 3, 600), (8, 3, 5, 1, 500), (11, 20, 30, 0, 850), (1, 1, 3, 0, 0)])
+def test_packed_images_walk_to_the_oracles_leaves(shape, order):
+    T, depth, F, full, pm = shape
+    s = O.gen_sparse_model(T, depth, F, full, pm, 1)
+    x = O.gen_tuples(3, 60, F, dist=1, missing_bits=s.params.missing_bits)
+    x[::7, 0] = s.params.missing_bits  # missing values on the feature most roots test
+    seen_k = set()
+    for vid, name in _sparse_variants():
+        K = int(name.split("_")[1][1:])
+        if K in seen_k:  # one variant per K: the packing depends on K and on the tile geometry only through the feature-row addresses
+            continue
+        seen_k.add(K)
+        top, deep, info = _images(s, vid, order)
+        assert info[3] == K and info[2] * 8 >= T and top.size == info[2] * 8 * (12 << K) // 4
+        for r in range(x.shape[0]):
+            for i in range(info[2] * 8):
+                got = _walk(top, deep, info, i, x[r], int(s.params.missing_bits))
+                want = O.traverse_sparse(s, x[r], i) if i < T else 0
+                assert got == want, (name, order, r, i, hex(got), hex(want))
+    assert len(seen_k) >= 4
+
+
+def test_hook_rejects_what_the_loader_rejects():
+    s = O.gen_sparse_model(4, 6, 5, 2, 600, 1)
+    vid = _sparse_variants()[0][0]
+    L = _lib.lib()
+    nl = np.ascontiguousarray(s.node_lines).view(np.uint32).reshape(-1, 4).copy()
+    first = np.ascontiguousarray(s.first, dtype=np.uint64)
+    p = ddt.make_sparse_params(4, 6, 5)
+    info = np.zeros(6, np.uint64)
+    call = lambda lines, par=p, v=vid: L.ddt_debug_sparse_image(C.byref(par), lines.ctypes.data, lines.shape[0], first.ctypes.data, v, 0, None, 0, None, 0,
+                                                                 info.ctypes.data)
+    assert call(nl) == 0
+    bad = nl.copy()
+    bad[0, 1] = (int(bad[0, 1]) & 0xFFFFF800) | 9  # feature index >= num_features
+    assert call(bad) < 0
+    bad = nl.copy()
+    internal = np.flatnonzero((bad[:, 1] >> 14) & 1 == 0)  # a node whose left child is internal
+    bad[internal[0], 2] = internal[0]  # child index not after its parent
+    assert call(bad) < 0
+    assert call(nl, ddt.make_sparse_params(4, 3, 5)) < 0   # deeper than num_levels
+    assert call(nl, p, 0) < 0                              # not a sparse kernel variant
