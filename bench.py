@@ -168,7 +168,7 @@ def main():
     # per-launch HIP-event times of the pass, taken by the library on the launch stream ("kernel_timing"):
     # pre-pass kernels (rank-quantised path only) and the scoring kernel proper
     kernel_ms = []
-    if not multi:
+    if not multi and classes == 1:  # (the per-launch events would pin the classes of config 5 to one stream)
         eng.set_option("kernel_timing", 1)
 
     def step(record: bool):

@@ -743,10 +743,27 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
 
 // class scores [K][n] into d_class_scores, then argmax into d_labels (if non-NULL)
 int launch_classify(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s) {
+  // Two streams: class 0 (with the shared pre-pass) on the caller's stream, then odd classes on the engine's own stream and
+  // even ones on the caller's.  Each class is one launch of n / tile blocks; its last wave of blocks leaves most CUs idle
+  // for one block time (5 % of a 100-tree launch over 10 M tuples) -- with a second launch in flight those CUs have work.
+  const bool two = e->class_streams && e->num_classes > 2 && !e->kernel_timing;
+  if (two && !e->class_stream) {
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->class_stream, hipStreamNonBlocking));
+    for (hipEvent_t& ev : e->class_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
   for (uint32_t k = 0; k < e->num_classes; ++k) {
     // rank-quantised path: the q tiles of this batch are computed by the first class's launch and reused
-    int rc = launch_score(e, e->ens[k], d_tuples, n, d_class_scores + (size_t)k * n, s, k > 0);
+    hipStream_t sk = (two && (k & 1u)) ? e->class_stream : s;
+    int rc = launch_score(e, e->ens[k], d_tuples, n, d_class_scores + (size_t)k * n, sk, k > 0);
     if (rc) return rc;
+    if (two && k == 0) {  // everything the other stream needs (tuples written by the caller's stream, the pre-pass) is behind this point
+      HIP_TRY(e, hipEventRecord(e->class_ev[0], s));
+      HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));
+    }
+  }
+  if (two) {
+    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));
+    HIP_TRY(e, hipStreamWaitEvent(s, e->class_ev[1], 0));
   }
   if (d_labels) {
     hipError_t r = launch_argmax(d_class_scores, e->num_classes, n, d_labels, s);
@@ -892,6 +909,9 @@ void ddt_destroy(ddt_engine* e) {
   if (e->ws) (void)hipFree(e->ws);
   for (hipEvent_t ev : e->tev)
     if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->class_ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->class_stream) (void)hipStreamDestroy(e->class_stream);
   free_images(e);
   free_q16_workspace(e);
   sparse_free(e);
@@ -1210,6 +1230,10 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     DeviceGuard dg(e->device);
     if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
     return ensure_q16_workspace(e, (size_t)value);
+  }
+  if (!strcmp(key, "class_streams")) {  // 1 (default): the classes of a multi-class model alternate between two streams; 0: one stream
+    e->class_streams = value != 0;
+    return DDT_OK;
   }
   if (!strcmp(key, "kernel_timing")) {
     e->kernel_timing = value != 0;

@@ -103,6 +103,11 @@ struct ddt_engine {
   // optional per-call kernel timing (option "kernel_timing"): start / before scoring kernel / end
   bool kernel_timing = false, timing_pending = false;
   hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
+  // multi-class models: the classes' scoring launches alternate between the caller's stream and this one, so that the tail of
+  // one launch (the last, partly filled wave of blocks) overlaps the next class's launch (option "class_streams", default 1)
+  hipStream_t class_stream = nullptr;
+  hipEvent_t class_ev[2] = {nullptr, nullptr};
+  int class_streams = 1;
   // sparse forests (ddt_load_model_sparse)
   bool sparse = false;
   std::vector<ddt::SparseForest> sps;  // one per class (single-output models: exactly one)
