@@ -792,11 +792,24 @@ int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_
 }
 
 int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s) {
-  if (e->sparse) {  // one sparse forest per class, then the argmax over the per-class sums
+  if (e->sparse) {  // one sparse forest per class (two streams, see launch_classify), then the argmax over the per-class sums
+    const bool two = e->class_streams && e->num_classes > 2 && !e->kernel_timing;
+    if (two && !e->class_stream) {
+      HIP_TRY(e, hipStreamCreateWithFlags(&e->class_stream, hipStreamNonBlocking));
+      for (hipEvent_t& ev : e->class_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    if (two) {  // the other stream starts behind whatever the caller's stream has queued (the tuples may come from there)
+      HIP_TRY(e, hipEventRecord(e->class_ev[0], s));
+      HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));
+    }
     for (uint32_t k = 0; k < e->num_classes; ++k) {
-      int rc = sparse_launch(e, k, d_tuples, n, d_class_scores + (size_t)k * n, s);
+      int rc = sparse_launch(e, k, d_tuples, n, d_class_scores + (size_t)k * n, (two && (k & 1u)) ? e->class_stream : s);
       if (rc) return rc;
       e->st.kernel_launches++;
+    }
+    if (two) {
+      HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));
+      HIP_TRY(e, hipStreamWaitEvent(s, e->class_ev[1], 0));
     }
     if (d_labels) {
       hipError_t r = launch_argmax(d_class_scores, e->num_classes, n, d_labels, s);
