@@ -241,6 +241,8 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * split the rank pre-pass over feature groups; both 0 = the transpose + rank kernels) and "q16_prepass_groups" (0 =
  * cheapest, default; 1, 2, 4, 8 = exactly that many feature groups): A/B switches, effective at the next model load;
  * (environment DDT_DEBUG_PREPASS=1 prints the chosen plan -- groups, P, image bytes -- to stderr at load);
+ * "class_streams" (1 = default: the per-class scoring launches of a multi-class model alternate between the caller's stream and
+ * one stream of the engine, joined before the argmax / before the call's work is visible on the caller's stream; 0 = one stream);
  * "reserve_rows" (pre-size the
  * workspace of the rank-quantised path for calls of up to that many rows: the *_device calls then never allocate),
  * "leaf_domain_check" (1 = default: refuse -0 / sub-normal / Inf / NaN leaves in the reference-order sum, where the
