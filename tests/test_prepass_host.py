@@ -137,3 +137,33 @@ def test_fullest_bucket_stays_below_p_and_degenerate_tables():
     counts = np.array([40000, 0, 0, 0], np.uint32)
     keys = np.arange(40000, dtype=np.uint32)
     assert L.ddt_debug_prepass_image(keys.ctypes.data, counts.ctypes.data, 4, 0, None, 0, np.zeros(42, np.uint32).ctypes.data) < 0  # > 16-bit ranks
+
+
+def _tables_of_model(T, D, F, shard=None):
+    """sorted distinct threshold bits per tuple word of the synthetic benchmark model (cmp_mode 0: signed-int order of the bits)"""
+    import ddt
+    w, f = ddt.synth_model(T, D, F)
+    nint = (1 << D) - 1
+    wt = np.ascontiguousarray(w).view(np.uint32).reshape(T, -1)[:, :nint]
+    ft = np.ascontiguousarray(f).view(np.uint16).reshape(T, -1)[:, :nint] & 0x7FF
+    if shard is not None:
+        per = -(-T // shard[1])
+        wt, ft = wt[shard[0] * per:(shard[0] + 1) * per], ft[shard[0] * per:(shard[0] + 1) * per]
+    W = 4 * ((F + 3) // 4)
+    return [np.unique(wt[ft == j].view(np.int32)) for j in range(W)]
+
+
+def test_plan_of_the_headline_model_and_its_shards():
+    """What the engine picks for BASELINE config 3 and its tree shards (profiles/r02_prepass_ab_grid.log): 1000 trees
+    -> 8 feature groups (one tuple line each), 500 -> 4, 250 -> 4 or 2, the 125-tree shard of an 8-GPU job -> 2 groups with P = 8."""
+    expect = {None: (8, 16), (0, 2): (4, 16), (1, 4): (None, None), (3, 8): (2, 8)}
+    for shard, (groups, P) in expect.items():
+        plan, img = _build(_tables_of_model(1000, 8, 32, shard), 0)
+        assert plan is not None
+        G, lines = int(plan[0]), int(plan[1])
+        Ps = [int(plan[2 + 5 * g + 3]) for g in range(G)]
+        if groups is None:
+            assert G in (2, 4) and max(Ps) <= 16
+        else:
+            assert (G, max(Ps)) == (groups, P), (shard, G, Ps)
+        assert G * lines == 8 and all(int(plan[2 + 5 * g + 1]) <= LDS_BYTES for g in range(G))
