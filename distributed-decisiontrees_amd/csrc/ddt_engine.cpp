@@ -413,7 +413,7 @@ int auto_variant(const ddt_engine* e) {
   if (tuple_words(e->p) <= 32u && total_trees(e) * e->p.num_levels >= kQ16MinTreeLevels && total_trees(e) < 224u && prepass_plan_exists(e))
     q16_min = total_trees(e);
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
-    static const char* qpref[] = {"q16_d8_c4_u4", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4", "q16_d5_c32_u4", "q16_d3_c128_u8",
+    static const char* qpref[] = {"q16_d8_c8_u4_gl", "q16_d8_c4_u4", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4", "q16_d5_c32_u4", "q16_d3_c128_u8",
                                   "q16_d9_c4_u4", "q16_d10_c4_u4"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
@@ -558,20 +558,27 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
     fprintf(stderr, "\n");
   }
   const uint32_t row = v.tile() * 2u;  // bytes per feature row of the u16 tile
+  // word offsets of tree i's records and leaves: tree by tree (records, then leaves), or -- "_gl" variants -- per chunk the
+  // records of its CT trees followed by the leaves of its CT trees (only the first half of a chunk is staged in LDS)
+  const uint32_t CT = (uint32_t)v.chunk_trees, half = 1u << D;
+  const bool gl = (v.opt & 1) != 0;
+  auto rec_off = [&](uint32_t i) { return gl ? (size_t)(i / CT) * CT * tree_words + (size_t)(i % CT) * half : (size_t)i * tree_words; };
+  auto leaf_off = [&](uint32_t i) { return gl ? (size_t)(i / CT) * CT * tree_words + (size_t)CT * half + (size_t)(i % CT) * half : (size_t)i * tree_words + half; };
   for (uint32_t i = 0; i < T; ++i) {
-    uint32_t* t = fast.data() + (size_t)i * tree_words;
+    uint32_t* t = fast.data() + rec_off(i);
     for (uint32_t n = 0; n < nint; ++n) {
       const uint32_t j = m.fidx[(size_t)i * nint + n], key = thr_key(e->p, m.thr[(size_t)i * nint + n]);
       const auto& k = rt.keys[j];
       const uint32_t idx = (uint32_t)(std::lower_bound(k.begin(), k.end(), key, [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; }) - k.begin());
       t[n + 1] = (idx + 1u) | ((j * row) << 16);
     }
-    for (uint32_t l = 0; l < nleaf; ++l) t[(1u << D) + l] = m.leaf[(size_t)i * nleaf + l];
+    uint32_t* lf = fast.data() + leaf_off(i);
+    for (uint32_t l = 0; l < nleaf; ++l) lf[l] = m.leaf[(size_t)i * nleaf + l];
   }
   slow = fast;
   for (uint32_t i = 0; i < T; ++i)
     for (uint32_t n = 0; n < nint; ++n)
-      if (m.mright[(size_t)i * nint + n]) slow[(size_t)i * tree_words + n + 1] |= 1u << 16;
+      if (m.mright[(size_t)i * nint + n]) slow[rec_off(i) + n + 1] |= 1u << 16;
   for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_prepass}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;

@@ -130,8 +130,12 @@ struct Variant {
     return feat_off_stream(n_trees_padded) + tuple_words * row_bytes() + 64u;
   }
   // ---- q16 kernels: 4-byte node records + fp32 leaves = 8*2^D bytes per tree; u16 feature tile ----
+  // opt bit 0 ("_gl"): only the node records are staged in LDS (4*2^D bytes per tree); the leaves stay in global memory and
+  // are gathered through the vector-memory path.  The image keeps 8*2^D bytes per tree either way: per chunk the records
+  // of its trees, then (opt 1) the leaves of its trees / (opt 0) records and leaves tree by tree.
   uint32_t tree_bytes_q16() const { return 8u << levels; }
-  uint32_t feat_off_q16() const { return 2u * tree_bytes_q16() * (uint32_t)chunk_trees; }
+  uint32_t lds_tree_bytes_q16() const { return (opt & 1) ? (4u << levels) : (8u << levels); }
+  uint32_t feat_off_q16() const { return 2u * lds_tree_bytes_q16() * (uint32_t)chunk_trees; }
   uint32_t lds_bytes_q16(uint32_t tuple_words) const { return feat_off_q16() + tuple_words * tile() * 2u; }
   // ---- sparse kernels (levels = K, the top levels staged in LDS): LDS = [top image of one PU group][feature tile] ----
   uint32_t top_bytes_sparse() const { return 12u << levels; }

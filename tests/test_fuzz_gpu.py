@@ -142,7 +142,7 @@ def test_rank_prepass_on_mixed_threshold_distributions(seed, T, F, n, cmp_mode):
     params = ddt.make_params(p.num_trees, p.num_levels, p.num_features, p.missing_bits, p.cmp_mode, p.clusters_per_tuple, 0)
     e = ddt.Engine(0)
     try:
-        e.set_option("variant", ddt.variant_names().index("q16_d8_c4_u4"))
+        e.set_option("variant", ddt.variant_names().index("q16_d8_c8_u4_gl"))
         for groups in (0, 1, 2, 4, 8, -1):
             e.set_option("q16_fused_prepass", 0 if groups < 0 else 1)
             e.set_option("q16_grouped_prepass", 0 if groups < 0 else 1)

@@ -28,8 +28,9 @@ def _params(m, sum_mode=0):
     return ddt.make_params(p.num_trees, p.num_levels, p.num_features, p.missing_bits, p.cmp_mode, p.clusters_per_tuple, sum_mode)
 
 
+@pytest.mark.parametrize("kernel", ["q16_d8_c8_u4_gl", "q16_d8_c4_u4"])  # leaves gathered from global memory / leaves staged in LDS
 @pytest.mark.parametrize("cmp_mode", [0, 1])
-def test_values_on_and_next_to_thresholds(cmp_mode):
+def test_values_on_and_next_to_thresholds(cmp_mode, kernel):
     T, D, F, n = 200, 8, 32, 4096
     m = O.gen_model(T, D, F, dist=1, cmp_mode=cmp_mode)
     rng = np.random.default_rng(0)
@@ -42,11 +43,11 @@ def test_values_on_and_next_to_thresholds(cmp_mode):
     x[:, :F] = np.where(mask, near, x[:, :F])
     x[0, :F] = [0x80000000, 0x00000000, 0x7F800000, 0xFF800000, 0x7FC00001, 0x7FFFFFFF, 0x80000001, 0x00000001] * 4
     e = ddt.Engine(0)
-    e.set_option("variant", _variant("q16_d8_c4_u4"))
+    e.set_option("variant", _variant(kernel))
     want = O.score(m, x)
     for sum_mode in (0, 1):
         e.load_model(_params(m, sum_mode), m.wlines, m.flines)
-        assert e.info().variant_name.decode() == "q16_d8_c4_u4"
+        assert e.info().variant_name.decode() == kernel
         got = e.score(x)
         ref = want if sum_mode == 0 else O.score(m, x, sum_mode=O.SUM_F64_SEQ)
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
@@ -57,15 +58,15 @@ def test_auto_selection_and_fallbacks():
     e = ddt.Engine(0)
     w, f = ddt.synth_model(1000, 8, 32)
     e.load_model(ddt.make_params(1000, 8, 32), w, f)
-    assert e.info().variant_name.decode() == "q16_d8_c4_u4"        # many trees: the pre-pass pays off
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl"        # many trees: the pre-pass pays off
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)          # 125 trees per engine (8-way shard): all rank tables
-    assert e.info().variant_name.decode() == "q16_d8_c4_u4"        # fit LDS together -> fused pre-pass -> q16 still pays
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl"        # fit LDS together -> fused pre-pass -> q16 still pays
     _prepass(e, -1)                                                 # with the transpose + rank kernels the fixed pre-pass cost is too high
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)
     assert e.info().variant_name.decode() == "d8_t1024_r1_c4_u4_dma_f"
     _prepass(e, 0)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 12)         # 84 trees x 8 levels >= 640: q16 with the LDS-resident pre-pass
-    assert e.info().variant_name.decode() == "q16_d8_c4_u4" and e.info().prepass_groups in (1, 2, 4, 8)
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl" and e.info().prepass_groups in (1, 2, 4, 8)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 16)         # 63 trees: below the break-even either way
     assert e.info().prepass_groups == 0
     with pytest.raises(ddt.DDTError):
@@ -73,7 +74,7 @@ def test_auto_selection_and_fallbacks():
     assert e.info().variant_name.decode() == "d8_t1024_r1_c4_u4_dma_f"
     # too many distinct thresholds on one feature for 16-bit ranks: 2000 trees x 255 nodes on 4 features
     w, f = ddt.synth_model(2000, 8, 4)
-    e.set_option("variant", _variant("q16_d8_c4_u4"))
+    e.set_option("variant", _variant("q16_d8_c8_u4_gl"))
     with pytest.raises(ddt.DDTError) as ei:
         e.load_model(ddt.make_params(2000, 8, 4), w, f)
     assert ei.value.code == -5
@@ -135,12 +136,12 @@ def test_rank_search_on_degenerate_threshold_distributions(cmp_mode, shape):
     mask = rng.random((n, F)) < 0.7
     x[:, :F] = np.where(mask, (pick & 0xFFFFFFFF).astype(np.uint32), x[:, :F])
     e = ddt.Engine(0)
-    e.set_option("variant", _variant("q16_d8_c4_u4"))
+    e.set_option("variant", _variant("q16_d8_c8_u4_gl"))
     want = O.score(m, x)
     for groups in (0, 2, 8, -1):  # the LDS-resident pre-pass (segmented bucket index) in 1 / 2 / 8 feature groups; transpose + rank kernels
         _prepass(e, groups)
         e.load_model(_params(m), m.wlines, m.flines)
-        assert e.info().variant_name.decode() == "q16_d8_c4_u4"
+        assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl"
         got = e.score(x)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), groups
     e.close()
@@ -155,7 +156,7 @@ def test_short_batches_do_not_read_past_the_tuples(n, T):
     m = O.gen_model(T, D, F, dist=1)
     x = O.gen_tuples(21, n, F, dist=1)
     e = ddt.Engine(0)
-    e.set_option("variant", _variant("q16_d8_c4_u4"))
+    e.set_option("variant", _variant("q16_d8_c8_u4_gl"))
     e.load_model(_params(m), m.wlines, m.flines)
     e.set_option("feeder_rows", 1 << 20)
     got = e.score(x)
@@ -172,7 +173,7 @@ def test_fused_and_two_kernel_prepass_agree(cmp_mode):
     x = O.gen_tuples(31, n, F, dist=1)
     want = O.score(m, x)
     e = ddt.Engine(0)
-    e.set_option("variant", _variant("q16_d8_c4_u4"))
+    e.set_option("variant", _variant("q16_d8_c8_u4_gl"))
     for groups in (1, 2, 4, 8, -1):
         _prepass(e, groups)
         e.load_model(_params(m), m.wlines, m.flines)
@@ -190,7 +191,7 @@ def test_grouped_and_two_kernel_prepass_agree(T, F):
     D = 8
     m = O.gen_model(T, D, F, dist=1)
     e = ddt.Engine(0)
-    e.set_option("variant", _variant("q16_d8_c4_u4"))
+    e.set_option("variant", _variant("q16_d8_c8_u4_gl"))
     for n in (1, 1500, 11 * 1024 + 77):
         x = O.gen_tuples(41 + n, n, F, dist=1, missing_bits=m.params.missing_bits)
         want = O.score(m, x)
