@@ -88,7 +88,7 @@ def predict(g: Mi355x, n_trees: int, depth: int, n_features: int, n_gpus: int = 
 class PathCosts:
     """Measured on one MI355X, milliseconds per 100 M tuples of 32 fp32 features, depth-8 trees
     (profiles/r01_final_bench.md, r01_sweep_shard_regime.json, r01_tile_overhead.md; pre-pass: profiles/r02_prepass_ab.log)."""
-    q16_ms_per_tree: float = 0.113        # score_q16_kernel: 7.08 T node visits/s
+    q16_ms_per_tree: float = 0.1065       # score_q16_kernel (leaves gathered from global memory, 8-tree chunks): 7.46 T node visits/s
     fp32_ms_per_tree: float = 0.147       # score_tile_kernel: 5.4 T node visits/s
     q16_fixed: float = 0.8                # per-tile fixed cost of the q16 scoring kernel
     fp32_fixed: float = 3.2               # per-tile fixed cost of the fp32 tile kernel (tuple load phase)

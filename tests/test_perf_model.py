@@ -49,7 +49,7 @@ def test_mi355x_model_matches_measurements_within_20_percent():
 
 def test_engine_cost_model_matches_the_measured_shard_regime():
     # per-rank scoring time of the headline job's shards, measured on one MI355X (profiles/r01_*), ms per 100 M tuples
-    measured = {1000: 119.4, 500: 61.8, 250: 33.6, 125: 19.1}  # profiles/r02_prepass_ab_grid.log
+    measured = {1000: 113.0, 125: 18.5}  # profiles/r02_bench_cfg3.log, r02_bench_t125.log (q16_d8_c8_u4_gl)
     for trees, ms in measured.items():
         e = P.engine_ms(trees)
         assert e["path"] == "q16"
@@ -57,7 +57,7 @@ def test_engine_cost_model_matches_the_measured_shard_regime():
     assert P.engine_ms(100, depth=6)["path"] == "fp32"                       # config 2 stays on the fp32 tile kernel
     assert abs(P.engine_ms(125)["fp32_ms"] - 21.4) < 1.5                     # what the 8-way shard cost before the fused pre-pass
     s = {n: P.tree_sharded_ms(1000, n)["mtuples_per_s"] for n in (1, 2, 4, 8)}
-    assert 800 < s[1] < 870 and 5.5 < s[8] / s[1] < 6.6                      # north star: >= 6x aggregate at 8 GPUs is within reach
+    assert 850 < s[1] < 920 and 5.5 < s[8] / s[1] < 6.6                      # north star: >= 6x aggregate at 8 GPUs is within reach
 
 
 def test_sparse_forest_model_matches_the_config4_measurement():
