@@ -1,11 +1,12 @@
 /*
  * ddt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code; see ddt_oracle.h).
  *
- * PARITY: adder, compare rule, group tree, accumulator datapath, chain hop, the traversal datapath and the tree ->
- * cluster / PU schedule are pinned against vectors evaluated from the reference's own RTL source
- * (tests/golden/make_rtl_golden.py, tests/golden/make_schedule_golden.py);
+ * PARITY: adder, compare rule, group tree, accumulator datapath, chain hop, the traversal datapath, the tree ->
+ * cluster / PU schedule and the programming side (how the streams land in the PU memories, per-tree offsets, EMPTY
+ * slots) are pinned against vectors evaluated / executed from the reference's own RTL source
+ * (tests/golden/make_rtl_golden.py, make_schedule_golden.py, make_program_golden.py);
  * *** everything else is UNPINNED *** -- the reference (FPGA RTL) has no tests/golden vectors and its
- * sequential control cannot be run here (see ddt_oracle.h).
+ * handshake / FIFO control cannot be run here (see ddt_oracle.h).
  * This file restates the RTL's scoring semantics; each function cites the lines it follows.
  * All paths below are relative to /root/reference/rtl/DTEngine/.
  */

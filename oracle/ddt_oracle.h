@@ -27,8 +27,17 @@
  *                              repair: the unreachable IDLE -> PROG_MODE edge), 16 (C, T) cases; tests/test_oracle_schedule.py
  *                              rebuilds the summation from those placements and holds orc_reduce_device to it
  *
- *      *** PARITY UNPINNED for everything else *** -- how the model / tuple streams are written into the
- *      PU memories (programming side of DTPU.sv), all valid / ready / FIFO control, the multi-device plumbing:
+ *               orc_leaves / orc_traverse's reading of the WIRE FORMAT (word n of a tree's weights lines = node n, leaves
+ *                              behind the 2^D-1 internal nodes, u16 entry n, feature j of a tuple, stride = lines per tree,
+ *                              little-endian lines, EMPTY slots = +0): ONE DTPU programmed and driven line by line --
+ *                              core/DTPU.sv:304-354,379-399,429-447,459-460,512-567 executed by the interpreter, memory
+ *                              wrappers core/Mem1in2out.v / dualport_mem.v, core/PipelinedMUX.sv elaborated from its
+ *                              generate blocks, control word from Core.sv:380 -- tests/golden/make_program_golden.py,
+ *                              222 walks over 10 PU programs; tests/test_oracle_program.py (also holds the PRODUCT's CSR
+ *                              codec to the executed EngineCSR.sv:146-308)
+ *
+ *      *** PARITY UNPINNED for everything else *** -- valid / ready handshakes, FIFO depths and back-pressure, the
+ *      time-stamp alignment of the PUs, the PCIe stream splitter, the multi-device plumbing:
  *      sequential SystemVerilog that nothing here can execute as a whole.  The SPARSE format (section further
  *      down) is this repository's extension: it has no RTL to be pinned to and is anchored to the perfect-tree
  *      oracle through pad_to_perfect instead.

@@ -1,9 +1,9 @@
 """ctypes binding of oracle/liboracle.so -- the CPU ORACLE (test infrastructure, NOT product code).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module, and only
-as the checker / the reported CPU baseline.  Parity: arithmetic, compare rule and traversal datapath pinned against
-vectors evaluated from the reference's RTL source, everything else UNPINNED (the reference ships no tests or golden
-vectors and its control logic cannot be simulated here); see oracle/ddt_oracle.h.
+as the checker / the reported CPU baseline.  Parity: arithmetic, compare rule, traversal datapath, schedule and the
+programming side pinned against vectors evaluated / executed from the reference's RTL source, the handshake / FIFO control
+UNPINNED (the reference ships no tests or golden vectors and cannot be simulated as a whole here); see oracle/ddt_oracle.h.
 """
 from __future__ import annotations
 
