@@ -837,9 +837,8 @@ void count_job(ddt_engine* e, size_t n) {
 
 // contiguous shard g of `G` of a tree-id list: ceil(|list|/G) trees each (PCIeReceiver.sv:241-264)
 std::vector<uint32_t> shard_of(const std::vector<uint32_t>& ids, uint32_t g, uint32_t G) {
-  const size_t per = (ids.size() + G - 1) / G;
-  const size_t b = (size_t)g * per < ids.size() ? (size_t)g * per : ids.size();
-  const size_t en = b + per < ids.size() ? b + per : ids.size();
+  uint32_t b = 0, en = 0;
+  (void)ddt_shard_range((uint32_t)ids.size(), g, G, &b, &en);  // g < G checked by the callers
   return std::vector<uint32_t>(ids.begin() + b, ids.begin() + en);
 }
 
@@ -1284,6 +1283,15 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     return DDT_OK;
   }
   return fail(e, DDT_EINVAL, "unknown option '%s'", key);
+}
+
+int ddt_shard_range(uint32_t num_trees, uint32_t shard_index, uint32_t shard_count, uint32_t* tree_begin, uint32_t* tree_end) {
+  if (!tree_begin || !tree_end || shard_count == 0 || shard_index >= shard_count) return DDT_EINVAL;
+  const uint64_t per = ((uint64_t)num_trees + shard_count - 1) / shard_count;
+  const uint64_t b = (uint64_t)shard_index * per < num_trees ? (uint64_t)shard_index * per : num_trees;
+  *tree_begin = (uint32_t)b;
+  *tree_end = (uint32_t)(b + per < num_trees ? b + per : num_trees);
+  return DDT_OK;
 }
 
 int ddt_num_variants(void) { return num_variants(); }

@@ -110,6 +110,13 @@ int ddt_load_model(ddt_engine* e, const ddt_params* p, const void* weights_lines
 int ddt_load_model_shard(ddt_engine* e, const ddt_params* p, const void* weights_lines, size_t n_wlines,
                          const void* findex_lines, size_t n_flines, uint32_t shard_index,
                          uint32_t shard_count);
+/* The split itself (host-only, needs no engine): shard `shard_index` of a list of `num_trees` trees is the contiguous
+ * range [*tree_begin, *tree_end) of ceil(num_trees/shard_count) trees; trailing shards may be empty (begin == end).  It is
+ * what the host node's stream router does with the model stream (PCIeReceiver.sv:241-264: `numcls_local_weights` lines per
+ * device in list order; tests/test_oracle_receiver.py holds it to that block EXECUTED from the reference's source).  For a
+ * multi-class model the list is the trees of ONE class.                                                              */
+int ddt_shard_range(uint32_t num_trees, uint32_t shard_index, uint32_t shard_count, uint32_t* tree_begin,
+                    uint32_t* tree_end);
 
 /* -- scoring (replaces: the tuple PCIe stream in / result stream out, PCIeReceiver.sv:276-312,
  *    ResultsCombiner.sv:136-160,193; N need not be a multiple of 4 here, unlike A14) ------------------ */
