@@ -447,13 +447,13 @@ void free_q16_workspace(ddt_engine* e) {
   }
 }
 
-// Build the device image of one ensemble for variant `v` and upload it (layouts: ddt_internal.h).
-int build_image(ddt_engine* e, const Variant& v, Ensemble& m) {
+// Device image of one ensemble for variant `v` (layouts: ddt_internal.h).  Host half -- no HIP call, also behind the test hook
+// ddt_debug_model_image: the packed image for a tile / stream / generic variant; build_image uploads it.
+int pack_image(ddt_engine* e, const Variant& v, const Ensemble& m, std::vector<uint32_t>& img, uint32_t* Tpad_out) {
   const uint32_t D = e->p.num_levels, T = m.trees(), nint = e->nint, nleaf = e->nleaf;
   const uint32_t tree_bytes = 12u << D;
   const uint32_t Tpad = padded_trees(v, T);  // EMPTY trees: every leaf +0 (DTPU.sv:544,760)
   const size_t bytes = (size_t)Tpad * tree_bytes;
-  std::vector<uint32_t> img;
   try {
     img.assign(bytes / 4, 0u);
   } catch (const std::bad_alloc&) {
@@ -490,6 +490,16 @@ int build_image(ddt_engine* e, const Variant& v, Ensemble& m) {
       for (uint32_t l = 0; l < nleaf; ++l) lv[l] = m.leaf[(size_t)i * nleaf + l];
     }
   }
+  *Tpad_out = Tpad;
+  return DDT_OK;
+}
+
+int build_image(ddt_engine* e, const Variant& v, Ensemble& m) {
+  std::vector<uint32_t> img;
+  uint32_t Tpad = 0;
+  const int rc = pack_image(e, v, m, img, &Tpad);
+  if (rc) return rc;
+  const size_t bytes = img.size() * 4u;
   if (m.d_img) (void)hipFree(m.d_img);
   m.d_img = nullptr;
   HIP_TRY(e, hipMalloc(&m.d_img, bytes));
@@ -502,13 +512,22 @@ int build_image(ddt_engine* e, const Variant& v, Ensemble& m) {
 
 // q16 images: per tree 2^D records {R (lo16) | row offset (hi16)} in a 1-based heap, then 2^D fp32 leaves.
 // R = 1 + index of the node's threshold in its feature's table; the slow image carries miss_right in bit 16.
-int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTables& rt, bool upload_tables) {
+struct Q16HostImage {
+  std::vector<uint32_t> fast, slow, tab, tabK, pimg;
+  std::vector<uint16_t> tabS;
+  PrepassPlan pplan{};
+  uint32_t Tpad = 0, Kpad = 0;
+};
+
+// host half of build_image_q16 (no HIP call; also behind the test hook ddt_debug_model_image)
+int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const RankTables& rt, bool upload_tables, Q16HostImage& h) {
   const uint32_t D = e->p.num_levels, T = m.trees(), nint = e->nint, nleaf = e->nleaf, W = tuple_words(e->p);
   const uint32_t tree_words = (8u << D) / 4u, Tpad = padded_trees(v, T);
   uint32_t Kpad = 2;
   while (Kpad <= rt.max_len) Kpad <<= 1;  // power of two > max_len: the search reads indices < Kpad - 1
-  std::vector<uint32_t> fast, slow, tab, tabK;
-  std::vector<uint16_t> tabS;
+  std::vector<uint32_t>&fast = h.fast, &slow = h.slow, &tab = h.tab, &tabK = h.tabK, &pimg = h.pimg;
+  std::vector<uint16_t>& tabS = h.tabS;
+  PrepassPlan& pplan = h.pplan;
   try {
     fast.assign((size_t)Tpad * tree_words, 0u);
     tab.assign((size_t)W * Kpad, 0x7FFFFFFFu);
@@ -548,8 +567,7 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
       P[4] = pow2;
     }
   }
-  std::vector<uint32_t> pimg;
-  PrepassPlan pplan{};
+  pplan = PrepassPlan{};
   if (upload_tables)
     (void)build_prepass_image(rt, W, (uint32_t)e->q16_prepass_groups, e->q16_fused_prepass != 0, e->q16_grouped_prepass != 0, &pimg, &pplan);
   if (upload_tables && getenv("DDT_DEBUG_PREPASS")) {
@@ -579,6 +597,19 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
   for (uint32_t i = 0; i < T; ++i)
     for (uint32_t n = 0; n < nint; ++n)
       if (m.mright[(size_t)i * nint + n]) slow[rec_off(i) + n + 1] |= 1u << 16;
+  h.Tpad = Tpad;
+  h.Kpad = Kpad;
+  return DDT_OK;
+}
+
+int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTables& rt, bool upload_tables) {
+  Q16HostImage h;
+  const int rc = pack_image_q16(e, v, m, rt, upload_tables, h);
+  if (rc) return rc;
+  const std::vector<uint32_t>&fast = h.fast, &slow = h.slow, &tab = h.tab, &tabK = h.tabK, &pimg = h.pimg;
+  const std::vector<uint16_t>& tabS = h.tabS;
+  const PrepassPlan& pplan = h.pplan;
+  const uint32_t Tpad = h.Tpad, Kpad = h.Kpad;
   for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_prepass}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
@@ -1336,6 +1367,67 @@ int64_t ddt_debug_prepass_image(const uint32_t* keys, const uint32_t* counts, ui
     memcpy(image_out, img.data(), img.size() * 4);
   }
   return (int64_t)img.size();
+}
+
+// Host-only test hook (include/ddt.h): parse + pack a perfect-tree model for kernel variant `variant_id` (-1: the engine's
+// choice) exactly as ddt_load_model would, without touching a GPU.
+int ddt_debug_model_image(const ddt_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines, int variant_id,
+                          uint32_t* img_out, uint32_t* img_slow_out, size_t img_cap_words, uint32_t* tables_out, size_t tables_cap_words,
+                          uint64_t info_out[12]) {
+  if (!p || !wl || !fl || !info_out) return DDT_EINVAL;
+  std::unique_ptr<ddt_engine> e(new (std::nothrow) ddt_engine());  // never created on a device: p, options, ens and err are used
+  if (!e) return DDT_ENOMEM;
+  int rc = validate(e.get(), p, n_wlines, n_flines);
+  if (rc) return rc;
+  e->p = *p;
+  e->nint = (1u << p->num_levels) - 1u;
+  e->nleaf = 1u << p->num_levels;
+  std::vector<uint32_t> ids(p->num_trees);
+  for (uint32_t i = 0; i < p->num_trees; ++i) ids[i] = i;
+  e->ens.resize(1);
+  rc = parse_trees(e.get(), p, reinterpret_cast<const uint32_t*>(wl), reinterpret_cast<const uint16_t*>(fl), std::move(ids), &e->ens[0]);
+  if (rc) return rc;
+  const int vid = variant_id < 0 ? auto_variant(e.get()) : variant_id;
+  if (vid >= num_variants() || !variant_fits(variant(vid), e.get())) return DDT_EUNSUPPORTED;
+  const Variant& v = variant(vid);
+  const uint32_t W = tuple_words(e->p);
+  std::vector<uint32_t> img;
+  Q16HostImage h;
+  uint32_t Tpad = 0;
+  if (v.kind == kKindQ16) {
+    rc = pack_image_q16(e.get(), v, e->ens[0], rank_tables(e.get()), true, h);
+    Tpad = h.Tpad;
+  } else {
+    rc = pack_image(e.get(), v, e->ens[0], img, &Tpad);
+  }
+  if (rc) return rc;
+  const std::vector<uint32_t>& out = v.kind == kKindQ16 ? h.fast : img;
+  memset(info_out, 0, 12 * sizeof(uint64_t));
+  info_out[0] = out.size();
+  info_out[1] = Tpad;
+  info_out[2] = (uint64_t)v.kind;
+  info_out[3] = (uint64_t)v.opt;
+  info_out[4] = (uint64_t)v.chunk_trees;
+  info_out[5] = v.tile();
+  info_out[6] = v.kind == kKindTile ? v.feat_off() : v.kind == kKindStream ? v.feat_off_stream(Tpad) : v.kind == kKindQ16 ? v.feat_off_q16() : 0u;
+  info_out[7] = v.kind == kKindQ16 ? v.tile() * 2u : v.kind == kKindGeneric ? 0u : v.row_bytes();
+  info_out[8] = h.Kpad;
+  info_out[9] = W;
+  info_out[10] = (uint64_t)vid;
+  info_out[11] = h.tab.size();
+  if (img_out) {
+    if (img_cap_words < out.size()) return DDT_EINVAL;
+    memcpy(img_out, out.data(), out.size() * 4u);
+  }
+  if (img_slow_out && v.kind == kKindQ16) {
+    if (img_cap_words < h.slow.size()) return DDT_EINVAL;
+    memcpy(img_slow_out, h.slow.data(), h.slow.size() * 4u);
+  }
+  if (tables_out && v.kind == kKindQ16) {
+    if (tables_cap_words < h.tab.size()) return DDT_EINVAL;
+    memcpy(tables_out, h.tab.data(), h.tab.size() * 4u);
+  }
+  return DDT_OK;
 }
 
 int ddt_synth_model(uint32_t T, uint32_t D, uint32_t F, int dist, void* wlines, void* flines) {

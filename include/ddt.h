@@ -307,6 +307,17 @@ int ddt_synth_tuples_device(ddt_engine* e, void* d_tuple_lines, uint64_t row0, s
  *    replays the kernel's search on it against a plain sorted-table count. */
 int64_t ddt_debug_prepass_image(const uint32_t* keys, const uint32_t* counts, uint32_t n_words, uint32_t groups,
                                 uint32_t* image_out, size_t image_cap_words, uint32_t plan_out[42]);
+/*    the device image of a PERFECT-tree model as kernel variant `variant_id` wants it (-1 = the variant the engine would pick
+ *    for this model: its id comes back in info_out[10]); the streams are validated and parsed like ddt_load_model does, then
+ *    packed (csrc/ddt_internal.h).  info_out = {image words, trees incl. EMPTY padding, variant kind
+ *    (0 generic, 1 tile, 2 stream, 3 rank-quantised), variant opt bits, trees per chunk, tuples per tile, LDS byte address of
+ *    feature row 0, bytes per feature row, Kpad (rank-quantised: entries per table), tuple words, variant id, table words}.
+ *    Rank-quantised variants also return the image used by tiles that hold a missing value (img_slow_out) and the per-feature
+ *    sorted threshold tables [tuple words][Kpad] (tables_out).  All outputs may be NULL to size them first.
+ *    tests/test_image_host.py walks the images in numpy the way the kernels do, against the oracle.                       */
+int ddt_debug_model_image(const ddt_params* p, const void* weights_lines, size_t n_wlines, const void* findex_lines,
+                          size_t n_flines, int variant_id, uint32_t* img_out, uint32_t* img_slow_out, size_t img_cap_words,
+                          uint32_t* tables_out, size_t tables_cap_words, uint64_t info_out[12]);
 /*    the device images of a sparse forest as sparse kernel variant `variant_id` wants them: the whole
  *    stream is validated like ddt_load_model_sparse does, then packed -- top heap images per PU group and the deep record
  *    array.  info_out = {top words, deep words, PU groups, top levels K, LDS byte offset of feature row 0, bytes per
