@@ -20,6 +20,7 @@ land in the PU memories, and which base offsets the per-tree instructions carry 
       core/Mem1in2out.v, core/dualport_mem.v   line address / word offset split around the vendor RAMs (the RAM IP itself
                                is absent from the reference: modelled as an array of lines at the address its wrapper passes)
       core/PipelinedMUX.sv     the word select, ELABORATED from its generate blocks for the instance parameters
+      ResultsCombiner.sv:131-160,193  scores -> 128-bit result lines (four to a line, word k = score 4L + k)
       core/DTPU.sv:579-760     the walk itself (datapath evaluator of make_rtl_golden.py), every memory read going
                                through the wrappers above -- no address or word order is asserted by this script
 
@@ -611,6 +612,7 @@ def program_vectors(consts):
     out["full_pu_local_num_trees"] = np.array([f["pu"].sig["local_num_trees"]], np.int64)
     out["full_pu_all_zero"] = np.array([int((f["out"] == 0).all())], np.int64)
     out["instr_fields"] = np.array([consts_pu["TREE_OFFSET_BITS"], consts_pu["TUPLE_OFFSET_BITS"]], np.uint64)
+    out["result_scores"], out["result_lines"] = result_line_vectors(consts)
     np.savez_compressed(OUT_PROG, **out)
     print(f"wrote {OUT_PROG}: idle_tfi_advance={out['idle_tfi_advance'][0]} idle_read_hits_prog_addr={out['idle_read_hits_prog_addr'][0]}")
 
@@ -718,6 +720,54 @@ def csr_vectors(consts):
     np.savez_compressed(OUT_CSR, **out)
     print(f"wrote {OUT_CSR}: {len(rows)} codec blocks + {len(rand)} random blocks, {len(regs_all[0])} registers; "
           f"Core stride ports wired to {wiring['tree_weights_numcls']} / {wiring['tree_feature_index_numcls']}")
+
+
+# ------------------------------------------------------------------------------------------ part 3: result lines (A14)
+def result_line_vectors(consts):
+    """ResultsCombiner.sv:131-160: local scores are collected four to a 128-bit line, word k of the line = score 4L + k; the
+    line enters the result FIFO as {w3, w2, w1, w0} (:193).  Executed with the FIFO never full."""
+    text = subst(_strip(open(f"{REF}/ResultsCombiner.sv").read()), consts)
+    m = re.search(r"\.din\s*\(\s*\{local_core_result_line\[3\], local_core_result_line\[2\], local_core_result_line\[1\], local_core_result_line\[0\]\}\s*\)", text)
+    assert m, "the result FIFO no longer takes {line[3], line[2], line[1], line[0]}"
+    text = re.sub(r"for\s*\(i = 0; i < 4; i=i\+1\)\s*begin\s*local_core_result_line\[\s*i\s*\]\s*<=\s*32'b0;\s*end", "", text)
+    # the run-time word select on the left-hand side, spelled out per word
+    text, n = re.subn(r"local_core_result_line\[\s*curr_word\s*\]\s*<=\s*local_core_result;",
+                      " ".join(f"if (curr_word == {k}) local_core_result_line__{k} <= local_core_result;" for k in range(4)), text)
+    assert n == 1
+    block = None
+    for sens, ast, _pos in always_blocks(text):
+        if "curr_word" in assigned_names(ast, set()):
+            block = ast
+    assert block is not None
+    fill = expr(re.search(r"\bassign\s+fill_local_core_result_line\s*=\s*([^;]+);", text).group(1))
+    width = {"rst_n": 1, "local_core_result_valid": 1, "local_core_result": 32, "aggreg_core_result_full": 1, "curr_word": 2,
+             "local_core_result_line_filled": 1, "fill_local_core_result_line": 1}
+    width.update({f"local_core_result_line__{k}": 32 for k in range(4)})
+    mod = Module.__new__(Module)
+    mod.name, mod.inputs, mod.outputs, mod.cases, mod.insts, mod.width, mod.assign = "rc", [], [], {}, [], width, {"fill_local_core_result_line": fill}
+    sim = LazySim(width, mod)
+    s = sim.sig
+    s.pop("fill_local_core_result_line")
+
+    lines = []
+
+    def clock(**inp):
+        s.update(inp)
+        if s.get("local_core_result_line_filled"):                                    # the result FIFO's write enable, this cycle
+            lines.append(sum(s[f"local_core_result_line__{w}"] << (32 * w) for w in range(4)))   # din = {w3, w2, w1, w0}
+        env, nxt = dict(s), {}
+        sim.run(block, env, nxt, False)
+        s.update(nxt)
+
+    rng = np.random.default_rng(9)
+    scores = rng.integers(1, 1 << 32, 23, dtype=np.uint64).astype(np.uint32)
+    clock(rst_n=0, local_core_result_valid=0, local_core_result=0, aggreg_core_result_full=0)
+    for k, sc in enumerate(scores):
+        clock(rst_n=1, local_core_result_valid=1, local_core_result=int(sc), aggreg_core_result_full=0)
+        if k % 3 == 2:
+            clock(local_core_result_valid=0, local_core_result=0xDEADBEEF)            # a gap in the score stream
+    clock(local_core_result_valid=0)
+    return scores, np.array([[(ln >> (32 * w)) & 0xFFFFFFFF for w in range(4)] for ln in lines], np.uint32)
 
 
 if __name__ == "__main__":

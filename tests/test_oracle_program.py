@@ -108,6 +108,15 @@ def test_recorded_defects_of_the_published_rtl(prog):
     assert got[0, 0] == want[0, 0] and not np.array_equal(got, want)
 
 
+def test_scores_fill_result_lines_four_to_a_line_in_tuple_order(prog):
+    """ResultsCombiner.sv:131-160,193 executed: word k of result line L is score 4L + k -- the fp32 array in tuple order that
+    ddt_score returns (and ddt_cli writes, padded to whole lines) read as little-endian 128-bit lines; an unfinished line is not
+    emitted (the reference needs N % 4 == 0, the library does not)."""
+    scores, lines = prog["result_scores"], prog["result_lines"]
+    assert lines.shape == (len(scores) // 4, 4)
+    assert np.array_equal(lines.reshape(-1), scores[:lines.size])
+
+
 # ---------------------------------------------------------------------------------------------------- the CSR chain
 COLS = ("T", "D", "F", "C", "missing", "wl", "fl", "n", "devices", "mode", "index")
 
