@@ -32,6 +32,8 @@ struct ddt_comm {
   hipEvent_t ev_free[2] = {nullptr, nullptr};     // comm stream: slot b consumed
   hipEvent_t ev_done = nullptr;
   size_t chunk_rows = 12'500'000;
+  int taper_tail = -1;               // option "taper_tail": 1 = split the last chunk (1/2, 1/4, 1/4), 0 = never, -1 = when n > 1
+  size_t taper_min_rows = 1u << 20;  // option "taper_min_rows": pieces are not made smaller than this
   // chain / classify workspaces, two slots (grow-only): part = this rank's partial values (G*seg floats, zero padded),
   // recv = every rank's slice of my segment [G][seg], full = combined values of all segments
   float* part[2] = {nullptr, nullptr};
@@ -117,6 +119,26 @@ int check_call(ddt_comm* c, const void* d_tuples, const void* d_out, size_t n) {
   return DDT_OK;
 }
 
+// Chunk lengths of a sharded call: `rows` each; with `taper` the final stretch (<= rows) is cut into halves down to
+// max(rows / 4, min_rows), whole 1024-tuple tiles, so that the collective left exposed behind the last scoring launch is about a
+// quarter of a chunk.  Every rank computes the same list from the same arguments.
+std::vector<size_t> chunk_schedule(size_t n, size_t rows, bool taper, size_t min_rows) {
+  std::vector<size_t> out;
+  rows = rows ? rows : 1;
+  const size_t floor_rows = std::max(rows / 4, std::max<size_t>(min_rows, 1));
+  for (size_t left = n; left;) {
+    size_t m = std::min(rows, left);
+    if (taper && left <= rows && left > floor_rows) {
+      size_t half = left / 2;
+      if (half >= 1024) half = (half + 1023) / 1024 * 1024;  // whole tiles of the scoring kernels
+      if (half && half < left) m = half;
+    }
+    out.push_back(m);
+    left -= m;
+  }
+  return out;
+}
+
 }  // namespace
 
 extern "C" {
@@ -183,7 +205,27 @@ int ddt_comm_set_option(ddt_comm* c, const char* key, int64_t value) {
     c->chunk_rows = (size_t)value;
     return DDT_OK;
   }
+  if (!strcmp(key, "taper_tail")) {
+    if (value < -1 || value > 1) return cfail(c, DDT_EINVAL, "taper_tail must be -1 (automatic), 0 or 1");
+    c->taper_tail = (int)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "taper_min_rows")) {
+    if (value < 1) return cfail(c, DDT_EINVAL, "taper_min_rows must be >= 1");
+    c->taper_min_rows = (size_t)value;
+    return DDT_OK;
+  }
   return cfail(c, DDT_EINVAL, "unknown option '%s'", key);
+}
+
+int64_t ddt_comm_chunk_schedule(size_t n, size_t chunk_rows, int taper, size_t taper_min_rows, size_t* lens_out, size_t cap) {
+  if (chunk_rows == 0) return DDT_EINVAL;
+  const std::vector<size_t> v = chunk_schedule(n, chunk_rows, taper != 0, taper_min_rows);
+  if (lens_out) {
+    if (cap < v.size()) return DDT_EINVAL;
+    std::copy(v.begin(), v.end(), lens_out);
+  }
+  return (int64_t)v.size();
 }
 
 // Shared chunk pipeline.  K = values per row (1 = scores, num_classes = class sums); `dst` = [K][n] result.
@@ -200,10 +242,12 @@ static int sharded_pipeline(ddt_comm* c, const void* d_tuples, size_t n, float* 
     if (rc) return rc;
   }
   const uint32_t* tup = reinterpret_cast<const uint32_t*>(d_tuples);
-  size_t k = 0;
-  for (size_t lo = 0; lo < n; lo += rows, ++k) {
+  const bool taper = c->taper_tail < 0 ? c->n > 1 : c->taper_tail != 0;
+  const std::vector<size_t> sched = chunk_schedule(n, rows, taper, c->taper_min_rows);  // every piece <= rows: fits the workspaces
+  size_t lo = 0;
+  for (size_t k = 0; k < sched.size(); lo += sched[k], ++k) {
     const int b = (int)(k & 1);
-    const size_t m = std::min(rows, n - lo), count = m * K, seg = (count + G - 1) / G;
+    const size_t m = sched[k], count = m * K, seg = (count + G - 1) / G;
     int rc;
     if (!staged) {
       rc = engine_score_device(e, tup + lo * W, m, dst + lo, s);

@@ -129,12 +129,13 @@ def engine_ms(trees: int, depth: int = 8, rows: float = 1e8, c: PathCosts = Path
     return {"path": path, "ms": q16 if path == "q16" else fp32, "q16_ms": q16, "fp32_ms": fp32, "prepass_ms": pre}
 
 
-def tree_sharded_ms(trees: int, n_gpus: int, depth: int = 8, rows: float = 1e8, g: Mi355x = Mi355x(), chunks: int = 8) -> dict:
+def tree_sharded_ms(trees: int, n_gpus: int, depth: int = 8, rows: float = 1e8, g: Mi355x = Mi355x(), chunks: int = 8,
+                    taper: bool = True) -> dict:
     """Whole-job time of the tree-sharded mode: per-rank scoring of ceil(T/G) trees + the exposed part of the
-    chunk-pipelined all-reduce (the last chunk)."""
+    chunk-pipelined all-reduce (the last piece: a chunk, or a quarter of one with the tapered tail of csrc/ddt_comm.cpp)."""
     per = -(-trees // n_gpus)
     e = engine_ms(per, depth, rows)
-    comm = 0.0 if n_gpus == 1 else rows * 4 / g.allreduce_alg_bytes_per_s * 1e3 / chunks
+    comm = 0.0 if n_gpus == 1 else rows * 4 / g.allreduce_alg_bytes_per_s * 1e3 / chunks / (4.0 if taper else 1.0)
     ms = e["ms"] + comm
     return {"ms": ms, "mtuples_per_s": rows / ms / 1e3, "path": e["path"], "score_ms": e["ms"], "exposed_comm_ms": comm}
 

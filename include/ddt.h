@@ -204,8 +204,14 @@ int  ddt_comm_get_unique_id(void* id_out /* DDT_COMM_ID_BYTES */);
 int  ddt_comm_create(ddt_comm** out, ddt_engine* e, int rank, int n_ranks, const void* unique_id);
 void ddt_comm_destroy(ddt_comm* c);
 const char* ddt_comm_last_error(const ddt_comm* c);
-/* "chunk_rows": rows per pipelined collective (default 12,500,000) */
+/* "chunk_rows": rows per pipelined collective (default 12,500,000); "taper_tail": 1 = the last chunk is cut into 1/2, 1/4, 1/4
+ * (whole 1024-tuple tiles, pieces of at least "taper_min_rows" = 2^20 rows) so that the collective left exposed behind the last
+ * scoring launch is a quarter of the size, 0 = never, -1 (default) = when the communicator has more than one rank */
 int  ddt_comm_set_option(ddt_comm* c, const char* key, int64_t value);
+/* the chunk lengths a sharded call of n_tuples rows uses (host-only; every rank derives the same list): returns their number,
+ * lens_out (may be NULL to count) receives them */
+int64_t ddt_comm_chunk_schedule(size_t n_tuples, size_t chunk_rows, int taper, size_t taper_min_rows, size_t* lens_out,
+                                size_t cap);
 int  ddt_score_sharded_device(ddt_comm* c, const void* d_tuple_lines, size_t n_tuples, float* d_scores, int combine,
                               void* hip_stream);
 int  ddt_score_rowsharded_device(ddt_comm* c, const void* d_tuple_lines, size_t n_tuples, float* d_scores,

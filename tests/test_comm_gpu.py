@@ -56,6 +56,44 @@ def test_one_rank_sharded_job_equals_plain_call(eng, comm, T, D, F, rows, dist):
     comm.set_option("chunk_rows", 12_500_000)
 
 
+def test_one_rank_tapered_tail_equals_plain_call(eng, comm):
+    """The last chunk cut into 1/2, 1/4, 1/4 (what a communicator with real peers does by default): same scores, same labels."""
+    import torch
+
+    T, D, F, rows = 300, 8, 32, 9000
+    m = O.gen_model(T, D, F, 1)
+    x = O.gen_tuples(0, rows, F, 1)
+    want = O.score(m, x)
+    eng.load_model(ddt.make_params(T, D, F), m.wlines, m.flines, 0, 1)
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    comm.set_option("taper_tail", 1)
+    comm.set_option("taper_min_rows", 64)
+    try:
+        for chunk in (12_500_000, 4096, 2000, 1024):  # the whole call is the tail; two chunks + tail; ragged; many chunks
+            comm.set_option("chunk_rows", chunk)
+            for combine in (ddt.COMBINE_ALLREDUCE, ddt.COMBINE_CHAIN):
+                outs = [comm.score_sharded(d, combine=combine) for _ in range(2)]  # back to back: slots reused
+                torch.cuda.synchronize()
+                for got in outs:
+                    assert np.array_equal(_bits(got.cpu().numpy()), _bits(want)), (chunk, combine)
+        K = 3
+        mc = O.gen_model(90, 6, 16, 1)
+        xc = O.gen_tuples(0, 5000, 16, 1)
+        labels, cs = O.classify(mc, xc, K)
+        eng.load_model_multiclass(ddt.make_params(90, 6, 16, clusters=1), mc.wlines, mc.flines, K, True, 0, 1)
+        dc = torch.from_numpy(xc.view(np.int32)).cuda()
+        for chunk in (12_500_000, 1500):
+            comm.set_option("chunk_rows", chunk)
+            for combine in (0, 1):
+                gl, gs = comm.classify_sharded(dc, combine=combine)
+                torch.cuda.synchronize()
+                assert np.array_equal(gl.cpu().numpy(), labels) and np.array_equal(_bits(gs.cpu().numpy()), _bits(cs)), (chunk, combine)
+    finally:
+        comm.set_option("taper_tail", -1)
+        comm.set_option("taper_min_rows", 1 << 20)
+        comm.set_option("chunk_rows", 12_500_000)
+
+
 def test_one_rank_sharded_sparse_and_back_to_back_calls(eng, comm):
     import torch
 
