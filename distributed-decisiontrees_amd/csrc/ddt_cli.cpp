@@ -12,6 +12,10 @@
 //                 [--device 0] [--shard i --of n] [--cmp-mode 0|1] [--sum-mode 0|1] [--variant v]
 //                 [--devices G [--combine allreduce|chain]]   the whole multi-GPU job in this process: tree shard g on
 //                                                             device g, partial scores combined over RCCL (ddt_group_*)
+//                 [--ranks N --rank r --id-file PATH [--combine allreduce|chain] [--device d]]   one process per GPU: this
+//                                                             process is rank r (tree shard r, device r unless --device), the RCCL
+//                                                             id is published by rank 0 through PATH (fresh per job); every
+//                                                             rank gets all scores, --out is optional (ddt_comm_*)
 //   ddt_cli gen-sparse   --trees T --max-depth D --features F --rows N [--full-levels L] [--permille P] [--dist 0|1] --prefix DIR/name
 //        a random-forest-like SPARSE model (include/ddt.h ddt_load_model_sparse): name.nodes (one 128-bit line per
 //        internal node), name.first (u64 line index of every tree's root, T + 1 entries), name.tuples
@@ -24,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <string>
 #include <vector>
@@ -99,6 +104,27 @@ bool read_csr(const std::string& path, uint64_t csr[DDT_CSR_COUNT]) {
   }
   fclose(f);
   return true;
+}
+
+// The communicator id of a one-process-per-GPU job travels through a file: rank 0 makes it (ddt_comm_get_unique_id) and
+// publishes it with an atomic rename, the other ranks wait for the file (any launcher-side channel would do: include/ddt.h).
+bool exchange_id(const std::string& path, int rank, int timeout_s, unsigned char id[DDT_COMM_ID_BYTES]) {
+  if (rank == 0) {
+    if (ddt_comm_get_unique_id(id) != DDT_OK) return false;
+    const std::string tmp = path + ".tmp";
+    if (!write_file(tmp, id, DDT_COMM_ID_BYTES)) return false;
+    return rename(tmp.c_str(), path.c_str()) == 0;
+  }
+  for (int waited_ms = 0; waited_ms <= timeout_s * 1000; waited_ms += 50) {
+    std::vector<unsigned char> buf;
+    if (read_file(path, &buf) && buf.size() == DDT_COMM_ID_BYTES) {
+      memcpy(id, buf.data(), DDT_COMM_ID_BYTES);
+      return true;
+    }
+    struct timespec ts = {0, 50 * 1000 * 1000};
+    nanosleep(&ts, nullptr);
+  }
+  return false;
 }
 
 int die(int rc, ddt_engine* e, const char* what) {
@@ -189,6 +215,38 @@ int cmd_score(const std::map<std::string, std::string>& o) {
     printf("scored %" PRIu64 " tuples on %d device(s), %u trees sharded tree-wise (device 0: [%u, %u), kernel %s), combine %s over RCCL\n",
            n, G, p.num_trees, info.tree_begin, info.tree_end, info.variant_name, cmb.c_str());
     ddt_group_destroy(g);
+    return 0;
+  }
+  if (o.count("ranks")) {  // one process per GPU: this process is rank `--rank` of `--ranks`, the id travels through a file
+    const int R = (int)num(o, "ranks", 1), r = (int)num(o, "rank", 0, true);
+    const std::string cmb = o.count("combine") ? o.at("combine") : "allreduce";
+    if (R < 1 || r < 0 || r >= R || (cmb != "allreduce" && cmb != "chain")) return die(DDT_EINVAL, nullptr, "--ranks / --rank / --combine");
+    const std::string id_file = str(o, "id-file");
+    ddt_engine* e = nullptr;
+    rc = ddt_create(&e, (int)num(o, "device", (uint64_t)r));  // default: rank r drives device r
+    if (rc) return die(rc, nullptr, "ddt_create");
+    if (o.count("variant")) ddt_set_option(e, "variant", (int64_t)num(o, "variant", 0));
+    rc = ddt_load_model_shard(e, &p, w.data(), w.size() / 16, f.data(), f.size() / 16, (uint32_t)r, (uint32_t)R);
+    if (rc) return die(rc, e, "load model shard");
+    unsigned char id[DDT_COMM_ID_BYTES];
+    if (!exchange_id(id_file, r, (int)num(o, "id-timeout", 120), id)) return die(DDT_ESTATE, e, "communicator id exchange (--id-file)");
+    ddt_comm* c = nullptr;
+    rc = ddt_comm_create(&c, e, r, R, id);
+    if (rc) return die(rc, e, "ddt_comm_create");
+    rc = ddt_comm_score(c, x.data(), n, scores.data(), cmb == "chain" ? DDT_COMBINE_CHAIN : DDT_COMBINE_ALLREDUCE);
+    if (rc) {
+      fprintf(stderr, "ddt_cli: rank %d: sharded job failed: %s (%s)\n", r, ddt_strerror(rc), ddt_comm_last_error(c));
+      ddt_comm_destroy(c);
+      ddt_destroy(e);
+      return 1;
+    }
+    if (o.count("out") && !write_file(o.at("out"), scores.data(), scores.size() * 4)) return die(DDT_EINVAL, e, "write results");
+    ddt_info info;
+    ddt_get_info(e, &info);
+    printf("rank %d of %d: scored %" PRIu64 " tuples, trees [%u, %u) of %u on %s, kernel %s, combine %s over RCCL\n", r, R, n, info.tree_begin,
+           info.tree_end, p.num_trees, info.device_name, info.variant_name, cmb.c_str());
+    ddt_comm_destroy(c);
+    ddt_destroy(e);
     return 0;
   }
   ddt_engine* e = nullptr;

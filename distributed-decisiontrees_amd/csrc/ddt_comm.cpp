@@ -41,6 +41,12 @@ struct ddt_comm {
   float* full[2] = {nullptr, nullptr};
   size_t cap = 0;  // floats per buffer
   bool slot_used[2] = {false, false};
+  // host-buffer form (ddt_comm_score): this rank's staging buffers and stream, grow-only
+  hipStream_t hs = nullptr;
+  void* h_tuples = nullptr;
+  float* h_scores = nullptr;
+  size_t h_rows = 0, h_words = 0;
+  size_t host_rows = 8u << 20;  // option "host_rows": rows per super-chunk held on the device at once
   char err[256] = {0};
 };
 
@@ -190,6 +196,12 @@ void ddt_comm_destroy(ddt_comm* c) {
   }
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->cs) (void)hipStreamDestroy(c->cs);
+  if (c->hs) {
+    (void)hipStreamSynchronize(c->hs);
+    (void)hipStreamDestroy(c->hs);
+  }
+  if (c->h_tuples) (void)hipFree(c->h_tuples);
+  if (c->h_scores) (void)hipFree(c->h_scores);
   delete c;
 }
 
@@ -203,6 +215,11 @@ int ddt_comm_set_option(ddt_comm* c, const char* key, int64_t value) {
   if (!strcmp(key, "chunk_rows")) {
     if (value < 1) return cfail(c, DDT_EINVAL, "chunk_rows must be >= 1");
     c->chunk_rows = (size_t)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "host_rows")) {
+    if (value < 1) return cfail(c, DDT_EINVAL, "host_rows must be >= 1");
+    c->host_rows = (size_t)value;
     return DDT_OK;
   }
   if (!strcmp(key, "taper_tail")) {
@@ -298,6 +315,44 @@ int ddt_score_sharded_device(ddt_comm* c, const void* d_tuples, size_t n, float*
   c->e->st.tuples_out += n;
   c->e->st.tuple_lines_in += (uint64_t)n * (tuple_words(c->e->p) / 4);
   c->e->st.result_lines_out += (n + 3) / 4;
+  return DDT_OK;
+}
+
+// Host-buffer form for one process per GPU (the per-rank counterpart of ddt_group_score): tuples from host memory to this
+// rank's device in super-chunks of `host_rows`, the sharded job, the combined scores back to the host.  Collective: every
+// rank calls it with the same tuples; every rank receives the scores.
+int ddt_comm_score(ddt_comm* c, const void* tuple_lines, size_t n, float* scores_out, int combine) {
+  if (!c) return DDT_EINVAL;
+  if (!c->e || !c->e->loaded) return cfail(c, DDT_ESTATE, "no model loaded on the engine of this communicator");
+  if (c->e->num_classes != 1) return cfail(c, DDT_ESTATE, "multi-class model loaded");
+  if (combine != DDT_COMBINE_ALLREDUCE && combine != DDT_COMBINE_CHAIN) return cfail(c, DDT_EINVAL, "combine %d", combine);
+  if (n == 0) return DDT_OK;
+  if (!tuple_lines || !scores_out) return cfail(c, DDT_EINVAL, "NULL host buffer");
+  DeviceGuard dg(c->e->device);
+  if (!dg.ok) return cfail(c, DDT_EHIP, "hipSetDevice(%d) failed", c->e->device);
+  const size_t W = tuple_words(c->e->p), rows = std::min(c->host_rows, n);
+  if (!c->hs) CHIP(c, hipStreamCreateWithFlags(&c->hs, hipStreamNonBlocking));
+  if (rows > c->h_rows || W > c->h_words) {
+    CHIP(c, hipStreamSynchronize(c->hs));
+    if (c->h_tuples) (void)hipFree(c->h_tuples);
+    if (c->h_scores) (void)hipFree(c->h_scores);
+    c->h_tuples = nullptr;
+    c->h_scores = nullptr;
+    c->h_rows = c->h_words = 0;
+    CHIP(c, hipMalloc(&c->h_tuples, rows * W * 4));
+    CHIP(c, hipMalloc(reinterpret_cast<void**>(&c->h_scores), rows * sizeof(float)));
+    c->h_rows = rows;
+    c->h_words = W;
+  }
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(tuple_lines);
+  for (size_t off = 0; off < n; off += rows) {
+    const size_t m = std::min(rows, n - off);
+    CHIP(c, hipMemcpyAsync(c->h_tuples, src + off * W, m * W * 4, hipMemcpyHostToDevice, c->hs));
+    const int rc = ddt_score_sharded_device(c, c->h_tuples, m, c->h_scores, combine, c->hs);
+    if (rc) return rc;
+    CHIP(c, hipMemcpyAsync(scores_out + off, c->h_scores, m * sizeof(float), hipMemcpyDeviceToHost, c->hs));
+    CHIP(c, hipStreamSynchronize(c->hs));
+  }
   return DDT_OK;
 }
 

@@ -216,6 +216,10 @@ int  ddt_score_sharded_device(ddt_comm* c, const void* d_tuple_lines, size_t n_t
                               void* hip_stream);
 int  ddt_score_rowsharded_device(ddt_comm* c, const void* d_tuple_lines, size_t n_tuples, float* d_scores,
                                  void* hip_stream);
+/* host buffers (the per-rank counterpart of ddt_group_score; `ddt_cli score --ranks N --rank r` is built on it): the tuples
+ * go to this rank's device in super-chunks ("host_rows" option, default 2^23 rows), through ddt_score_sharded_device, and the
+ * combined scores come back to every rank.  Collective and synchronous. */
+int  ddt_comm_score(ddt_comm* c, const void* tuple_lines, size_t n_tuples, float* scores_out, int combine);
 /* multi-class (ddt_load_model_multiclass with shard_index = rank): per-class partial sums [K][n] combined like the
  * scalar scores, then the argmax over the combined sums (d_labels may be NULL) */
 int  ddt_classify_sharded_device(ddt_comm* c, const void* d_tuple_lines, size_t n_tuples, float* d_class_scores,

@@ -175,3 +175,16 @@ def test_cli_scores_a_sparse_forest(tmp_path):
     res = np.fromfile(pre + ".results", np.float32)
     want = O.score_sparse(s, O.gen_tuples(0, n, F, dist=1))
     assert res.size == (n + 3) // 4 * 4 and np.array_equal(res[:n].view(np.uint32), want.view(np.uint32))
+
+
+def test_cli_rejects_a_bad_rank_before_touching_a_device(tmp_path):
+    """--ranks / --rank (one process per GPU, ddt_comm_*) are checked before ddt_create: no GPU needed for the refusal."""
+    pre = str(tmp_path / "m")
+    subprocess.check_call([ddt.CLI_PATH, "gen", "--trees", "16", "--levels", "4", "--features", "16", "--rows", "8", "--prefix", pre])
+    base = [ddt.CLI_PATH, "score", "--csr", pre + ".csr", "--weights", pre + ".weights", "--findex", pre + ".findex", "--tuples", pre + ".tuples"]
+    for extra in (["--ranks", "2", "--rank", "2", "--id-file", pre + ".id"], ["--ranks", "0", "--rank", "0", "--id-file", pre + ".id"],
+                  ["--ranks", "2", "--rank", "0", "--id-file", pre + ".id", "--combine", "tree"]):
+        r = subprocess.run(base + extra, capture_output=True)
+        assert r.returncode == 1 and b"--ranks / --rank / --combine" in r.stderr
+    r = subprocess.run(base + ["--ranks", "2"], capture_output=True)          # --rank is required
+    assert r.returncode == 2 and b"missing --rank" in r.stderr
