@@ -62,6 +62,9 @@ def main():
                     help="N>1: 'trees' = the headline mode (ensemble sharded tree-wise, partial scores all-reduced); "
                          "'rows' = the reference's other mode (replicated ensemble, tuples partitioned, scores all-gathered)")
     ap.add_argument("--chunk-rows", type=int, default=12_500_000, help="rows per pipelined collective (N>1)")
+    ap.add_argument("--taper", type=int, default=-1, choices=[-1, 0, 1],
+                    help="N>1 / --force-collectives: cut the last chunk into 1/2, 1/4, 1/4 so that the exposed collective is a quarter "
+                         "chunk (-1 = the library's default: on when the communicator has more than one rank)")
     ap.add_argument("--collectives", default="cabi", choices=["cabi", "torch"],
                     help="cabi = RCCL called from C++ behind the C-ABI (the product path); torch = the same pipeline "
                          "driven from Python through torch.distributed (needed for --backend gloo)")
@@ -160,6 +163,7 @@ def main():
         dist.broadcast_object_list(box, src=0)
         comm = ddt.Comm(eng, rank, world, box[0])
         comm.set_option("chunk_rows", args.chunk_rows)
+        comm.set_option("taper_tail", args.taper)
     elif multi:
         scorer = (ddt.RowShardedScorer(eng) if rows_mode else
                   ddt.ShardedScorer.from_engine(eng, mode=args.combine, chunk_rows=args.chunk_rows,
@@ -335,6 +339,7 @@ def main():
                        "trees": T, "levels": D, "features": F, "rows": N,
                        "parallelism": f"row-shard{world}" if rows_mode else f"tree-shard{world}",
                        "combine": args.combine if multi else None,
+                       "tapered_tail": ((args.taper == 1 or (args.taper < 0 and world > 1)) if comm is not None else None),
                        "collectives": (("C-ABI ddt_comm (csrc/ddt_comm.cpp)" if comm is not None else "torch.distributed") if multi else None),
                        "collective_backend": (args.backend if multi else None), "kernel": info.variant_name.decode(),
                        "sum_mode": "reference-order fp32" if args.sum_mode == 0 else "fp64 accumulate",

@@ -22,4 +22,7 @@ done
 ( timeout 600 python bench.py --steps 3 --warmup 1 --force-collectives --combine chain --no-cpu-baseline --no-streamed ) > $OUT/bench_force_chain.log 2>/dev/null
 ( timeout 600 python bench.py --steps 3 --warmup 1 --trees 125 --force-collectives --no-cpu-baseline --no-streamed ) > $OUT/bench_force_t125.log 2>/dev/null
 ( timeout 600 python bench.py --steps 3 --warmup 1 --trees 125 --no-cpu-baseline --no-streamed ) > $OUT/bench_t125.log 2>/dev/null
+# the tapered tail of the multi-GPU pipeline in a one-rank communicator: what the two extra launches cost before any peer exists
+( timeout 600 python bench.py --steps 3 --warmup 1 --trees 125 --force-collectives --taper 1 --no-cpu-baseline --no-streamed ) > $OUT/bench_force_t125_taper.log 2>/dev/null
+( timeout 600 python bench.py --steps 3 --warmup 1 --force-collectives --taper 1 --no-cpu-baseline --no-streamed ) > $OUT/bench_force_allreduce_taper.log 2>/dev/null
 tail -qn1 $OUT/bench_force_*.log $OUT/bench_t125.log | cut -c1-160
