@@ -1,0 +1,607 @@
+// mock_runtime.cpp -- TEST INFRASTRUCTURE: a deferred-execution model of the HIP streams / events and RCCL collectives that
+// csrc/ddt_comm.cpp uses, plus a stand-in engine, so that the REAL multi-GPU pipeline code (chunk schedule, workspace slots,
+// event protocol, all-to-all segment arithmetic, [K][n] layouts, row partitions, the single-process group) runs with
+// G = 2 .. 8 ranks on a machine without GPUs (tests/test_comm_mock.py builds this file together with csrc/ddt_comm.cpp).
+//
+// Model: every stream is a FIFO of operations that are NOT executed when enqueued.  A scheduler executes one runnable
+// operation at a time -- runnable = at the head of its stream and every event it waits for has been recorded -- choosing
+// among the candidates by a policy: lowest stream id first, highest first, or seeded random.  Only what HIP guarantees is
+// honoured (stream order, hipStreamWaitEvent on the record that was enqueued last, blocking synchronisation calls), so a
+// missing dependency in the pipeline gives a wrong result under some schedule.  A collective executes when all ranks'
+// copies are runnable (that is RCCL's rendezvous).  "Device memory" is host memory; kernels are host functions.
+//
+// Stand-in engine: a rank's partial score of tuple `row` (word 0 of the tuple line) for class k is the integer-valued
+// float f(shard, k, row) below -- sums over ranks are exact in any order, so every result is checked bit for bit.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <random>
+#include <set>
+#include <vector>
+
+#include "ddt_engine_priv.h"
+
+namespace {
+
+std::mutex M;
+std::condition_variable CV;
+
+struct Coll;
+struct Op {
+  std::function<void()> run;
+  std::vector<uint64_t> deps;
+  uint64_t record = 0;
+  Coll* coll = nullptr;
+};
+}  // namespace
+
+struct MockStream {
+  int dev = 0, id = 0;
+  std::deque<Op*> q;
+  uint64_t enq = 0, done = 0;
+};
+struct MockEvent {
+  uint64_t serial = 0;  // last record enqueued on this event (0 = never recorded: a wait is a no-op, as in HIP)
+};
+
+namespace {
+struct Group;
+}
+struct MockComm {
+  Group* g = nullptr;
+  int rank = 0;
+  uint64_t next_seq = 0;
+};
+
+namespace {
+
+struct P2P {
+  bool send;
+  int peer;
+  const void* sbuf;
+  void* rbuf;
+  size_t count;
+};
+struct CollArg {
+  int type = -1;  // 0 all-reduce, 1 all-gather, 2 grouped send / recv
+  const void* send = nullptr;
+  void* recv = nullptr;
+  size_t count = 0;
+  std::vector<P2P> p2p;
+  Op* op = nullptr;
+  MockStream* st = nullptr;
+};
+struct Coll {
+  Group* g;
+  uint64_t seq;
+  int arrived = 0;
+  std::vector<CollArg> arg;
+};
+struct Group {
+  int n = 0, joined = 0;
+  std::vector<MockComm*> comm;
+  std::map<uint64_t, Coll*> pending;
+};
+
+std::set<uint64_t> g_done;
+uint64_t g_serial = 1, g_executed = 0;
+std::vector<MockStream*> g_streams;
+std::map<int, MockStream*> g_null;
+std::map<std::string, Group*> g_groups;  // by unique id
+int g_policy = 0, g_devices = 8, g_errors = 0, g_next_stream = 1;
+uint64_t g_next_id = 1;
+std::mt19937_64 g_rng(1);
+thread_local int t_dev = 0;
+thread_local bool t_in_group = false;
+thread_local std::vector<P2P> t_p2p;
+thread_local MockComm* t_group_comm = nullptr;
+thread_local MockStream* t_group_stream = nullptr;
+
+MockStream* resolve(hipStream_t s) {  // M held
+  if (s) return s;
+  MockStream*& d = g_null[t_dev];
+  if (!d) {
+    d = new MockStream();
+    d->dev = t_dev;
+    d->id = 0;
+    g_streams.push_back(d);
+  }
+  return d;
+}
+
+bool deps_done(const Op* op) {
+  for (uint64_t d : op->deps)
+    if (!g_done.count(d)) return false;
+  return true;
+}
+
+bool coll_ready(const Coll* c) {
+  if (c->arrived != c->g->n) return false;
+  for (const CollArg& a : c->arg)
+    if (a.st->q.empty() || a.st->q.front() != a.op || !deps_done(a.op)) return false;
+  return true;
+}
+
+void run_coll(Coll* c) {
+  const int n = c->g->n;
+  const CollArg& a0 = c->arg[0];
+  for (const CollArg& a : c->arg)
+    if (a.type != a0.type || (a.type != 2 && a.count != a0.count)) {
+      fprintf(stderr, "[mock] collective %llu: ranks disagree (type %d/%d, count %zu/%zu)\n", (unsigned long long)c->seq, a.type, a0.type, a.count,
+              a0.count);
+      ++g_errors;
+      return;
+    }
+  if (a0.type == 0) {  // sum in rank order (the partials are integer-valued: any order gives the same bits)
+    std::vector<float> acc(a0.count, 0.0f);
+    for (int r = 0; r < n; ++r) {
+      const float* s = reinterpret_cast<const float*>(c->arg[(size_t)r].send);
+      for (size_t i = 0; i < a0.count; ++i) {
+        volatile float v = acc[i] + s[i];
+        acc[i] = v;
+      }
+    }
+    for (int r = 0; r < n; ++r) memcpy(c->arg[(size_t)r].recv, acc.data(), a0.count * sizeof(float));
+  } else if (a0.type == 1) {
+    std::vector<float> all((size_t)n * a0.count);
+    for (int r = 0; r < n; ++r) memcpy(all.data() + (size_t)r * a0.count, c->arg[(size_t)r].send, a0.count * sizeof(float));
+    for (int r = 0; r < n; ++r) memcpy(c->arg[(size_t)r].recv, all.data(), all.size() * sizeof(float));
+  } else {  // grouped send / recv: the k-th send of rank r to peer d pairs with the k-th recv of rank d from peer r
+    std::vector<std::vector<float>> staged;  // read everything first: buffers may alias
+    std::vector<std::pair<void*, size_t>> dst;
+    for (int r = 0; r < n; ++r) {
+      std::map<int, int> nth;
+      for (const P2P& p : c->arg[(size_t)r].p2p) {
+        if (!p.send) continue;
+        const int k = nth[p.peer]++;
+        int seen = 0;
+        const P2P* match = nullptr;
+        for (const P2P& q : c->arg[(size_t)p.peer].p2p)
+          if (!q.send && q.peer == r && seen++ == k) {
+            match = &q;
+            break;
+          }
+        if (!match || match->count != p.count) {
+          fprintf(stderr, "[mock] send %d -> %d (%zu floats) has no matching recv\n", r, p.peer, p.count);
+          ++g_errors;
+          continue;
+        }
+        staged.emplace_back(reinterpret_cast<const float*>(p.sbuf), reinterpret_cast<const float*>(p.sbuf) + p.count);
+        dst.emplace_back(match->rbuf, p.count);
+      }
+    }
+    size_t recvs = 0;
+    for (int r = 0; r < n; ++r)
+      for (const P2P& p : c->arg[(size_t)r].p2p) recvs += p.send ? 0 : 1;
+    if (recvs != dst.size()) {
+      fprintf(stderr, "[mock] %zu recvs for %zu sends\n", recvs, dst.size());
+      ++g_errors;
+    }
+    for (size_t i = 0; i < dst.size(); ++i) memcpy(dst[i].first, staged[i].data(), dst[i].second * sizeof(float));
+  }
+}
+
+void finish(MockStream* st, Op* op) {
+  st->q.pop_front();
+  ++st->done;
+  if (op->record) g_done.insert(op->record);
+  delete op;
+  ++g_executed;
+}
+
+// one scheduling step; returns false when nothing is runnable.  M held.
+bool step() {
+  std::vector<MockStream*> cand;
+  for (MockStream* st : g_streams) {
+    if (st->q.empty()) continue;
+    Op* op = st->q.front();
+    if (op->coll ? coll_ready(op->coll) : deps_done(op)) cand.push_back(st);
+  }
+  if (cand.empty()) return false;
+  MockStream* st = cand[0];
+  if (g_policy == 1) {
+    for (MockStream* c : cand)
+      if (c->id > st->id) st = c;
+  } else if (g_policy == 2) {
+    st = cand[g_rng() % cand.size()];
+  } else {
+    for (MockStream* c : cand)
+      if (c->id < st->id) st = c;
+  }
+  Op* op = st->q.front();
+  if (op->coll) {
+    Coll* c = op->coll;
+    run_coll(c);
+    c->g->pending.erase(c->seq);
+    for (CollArg& a : c->arg) finish(a.st, a.op);
+    delete c;
+  } else {
+    if (op->run) op->run();
+    finish(st, op);
+  }
+  return true;
+}
+
+template <class Pred>
+hipError_t drive(std::unique_lock<std::mutex>& lk, Pred pred) {
+  while (!pred()) {
+    if (step()) {
+      CV.notify_all();
+      continue;
+    }
+    if (CV.wait_for(lk, std::chrono::seconds(20)) == std::cv_status::timeout && !pred()) {
+      fprintf(stderr, "[mock] no progress for 20 s: a rank is waiting for work that nobody will enqueue\n");
+      ++g_errors;
+      return hipErrorInvalidValue;
+    }
+  }
+  return hipSuccess;
+}
+
+void enqueue(hipStream_t s, Op* op) {
+  std::lock_guard<std::mutex> lk(M);
+  MockStream* st = resolve(s);
+  st->q.push_back(op);
+  ++st->enq;
+  CV.notify_all();
+}
+
+ncclResult_t enqueue_coll(MockComm* c, hipStream_t s, CollArg a) {
+  std::lock_guard<std::mutex> lk(M);
+  MockStream* st = resolve(s);
+  Group* g = c->g;
+  const uint64_t seq = c->next_seq++;
+  Coll*& k = g->pending[seq];
+  if (!k) {
+    k = new Coll{g, seq, 0, std::vector<CollArg>((size_t)g->n)};
+  }
+  Op* op = new Op();
+  op->coll = k;
+  a.op = op;
+  a.st = st;
+  k->arg[(size_t)c->rank] = a;
+  ++k->arrived;
+  st->q.push_back(op);
+  ++st->enq;
+  CV.notify_all();
+  return ncclSuccess;
+}
+
+// the stand-in engine's arithmetic
+inline float partial(uint32_t shard, uint32_t cls, uint32_t row) { return (float)((int)((row * 7u + shard * 13u + cls * 101u) % 1000u) - 500); }
+struct MockModel {
+  uint32_t shard = 0, count = 1, classes = 1;
+};
+std::map<ddt_engine*, MockModel> g_models;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------ HIP
+extern "C" {
+
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "mock hip error"; }
+hipError_t hipGetDeviceCount(int* n) {
+  *n = g_devices;
+  return hipSuccess;
+}
+hipError_t hipGetDevice(int* d) {
+  *d = t_dev;
+  return hipSuccess;
+}
+hipError_t hipSetDevice(int d) {
+  if (d < 0 || d >= g_devices) return hipErrorInvalidDevice;
+  t_dev = d;
+  return hipSuccess;
+}
+hipError_t hipMalloc(void** p, size_t bytes) {
+  *p = malloc(bytes ? bytes : 1);
+  if (*p) memset(*p, 0xA5, bytes);  // never zero: stale reads show
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipFree(void* p) {
+  (void)hipDeviceSynchronize();  // hipFree waits for the device
+  free(p);
+  return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+  std::lock_guard<std::mutex> lk(M);
+  MockStream* st = new MockStream();
+  st->dev = t_dev;
+  st->id = g_next_stream++;
+  g_streams.push_back(st);
+  *s = st;
+  return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s) {
+  std::unique_lock<std::mutex> lk(M);
+  MockStream* st = resolve(s);
+  const uint64_t target = st->enq;
+  return drive(lk, [&] { return st->done >= target; });
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+  if (!s) return hipErrorInvalidValue;
+  (void)hipStreamSynchronize(s);
+  std::lock_guard<std::mutex> lk(M);
+  for (size_t i = 0; i < g_streams.size(); ++i)
+    if (g_streams[i] == s) g_streams.erase(g_streams.begin() + (long)i);
+  delete s;
+  return hipSuccess;
+}
+hipError_t hipDeviceSynchronize(void) {
+  std::unique_lock<std::mutex> lk(M);
+  std::vector<std::pair<MockStream*, uint64_t>> targets;
+  for (MockStream* st : g_streams)
+    if (st->dev == t_dev) targets.emplace_back(st, st->enq);
+  return drive(lk, [&] {
+    for (auto& t : targets)
+      if (t.first->done < t.second) return false;
+    return true;
+  });
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) {
+  *e = new MockEvent();
+  return hipSuccess;
+}
+hipError_t hipEventDestroy(hipEvent_t e) {
+  delete e;
+  return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  Op* op = new Op();
+  {
+    std::lock_guard<std::mutex> lk(M);
+    op->record = g_serial++;
+    e->serial = op->record;
+  }
+  enqueue(s, op);
+  return hipSuccess;
+}
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+  Op* op = new Op();
+  {
+    std::lock_guard<std::mutex> lk(M);
+    if (e->serial) op->deps.push_back(e->serial);  // the record enqueued last, as HIP defines it
+  }
+  enqueue(s, op);
+  return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t s) {
+  Op* op = new Op();
+  op->run = [=] { memset(p, value, bytes); };
+  enqueue(s, op);
+  return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t s) {
+  Op* op = new Op();
+  op->run = [=] { memmove(dst, src, bytes); };
+  enqueue(s, op);
+  return hipSuccess;
+}
+hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t s) {
+  Op* op = new Op();
+  op->run = [=] {
+    for (size_t r = 0; r < height; ++r) memmove(reinterpret_cast<char*>(dst) + r * dpitch, reinterpret_cast<const char*>(src) + r * spitch, width);
+  };
+  enqueue(s, op);
+  return hipSuccess;
+}
+
+// ----------------------------------------------------------------------------------------------------------------- RCCL
+const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "success" : "mock nccl error"; }
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+  std::lock_guard<std::mutex> lk(M);
+  memset(id, 0, sizeof(*id));
+  snprintf(id->internal, sizeof(id->internal), "mock-id-%llu", (unsigned long long)g_next_id++);
+  return ncclSuccess;
+}
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int n, ncclUniqueId id, int rank) {
+  std::unique_lock<std::mutex> lk(M);
+  Group*& g = g_groups[std::string(id.internal)];
+  if (!g) {
+    g = new Group();
+    g->n = n;
+    g->comm.assign((size_t)n, nullptr);
+  }
+  if (g->n != n || rank < 0 || rank >= n || g->comm[(size_t)rank]) return ncclInvalidArgument;
+  MockComm* c = new MockComm();
+  c->g = g;
+  c->rank = rank;
+  g->comm[(size_t)rank] = c;
+  ++g->joined;
+  CV.notify_all();
+  Group* gg = g;
+  while (gg->joined < gg->n)  // ncclCommInitRank returns when every rank has joined
+    if (CV.wait_for(lk, std::chrono::seconds(20)) == std::cv_status::timeout) return ncclInternalError;
+  *comm = c;
+  return ncclSuccess;
+}
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int n, const int*) {
+  std::lock_guard<std::mutex> lk(M);
+  Group* g = new Group();
+  g->n = g->joined = n;
+  for (int r = 0; r < n; ++r) {
+    MockComm* c = new MockComm();
+    c->g = g;
+    c->rank = r;
+    g->comm.push_back(c);
+    comms[r] = c;
+  }
+  return ncclSuccess;
+}
+ncclResult_t ncclCommDestroy(ncclComm_t comm) {
+  delete comm;  // the group object is left to the process (tests are short lived)
+  return ncclSuccess;
+}
+ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t, ncclRedOp_t, ncclComm_t comm, hipStream_t s) {
+  CollArg a;
+  a.type = 0, a.send = send, a.recv = recv, a.count = count;
+  return enqueue_coll(comm, s, a);
+}
+ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclDataType_t, ncclComm_t comm, hipStream_t s) {
+  CollArg a;
+  a.type = 1, a.send = send, a.recv = recv, a.count = sendcount;
+  return enqueue_coll(comm, s, a);
+}
+ncclResult_t ncclGroupStart(void) {
+  t_in_group = true;
+  t_p2p.clear();
+  t_group_comm = nullptr;
+  t_group_stream = nullptr;
+  return ncclSuccess;
+}
+static ncclResult_t p2p(bool send, const void* sbuf, void* rbuf, size_t count, int peer, ncclComm_t comm, hipStream_t s) {
+  if (!t_in_group) return ncclInvalidArgument;  // the pipeline only issues grouped point-to-point calls
+  if ((t_group_comm && t_group_comm != comm) || (t_group_comm && t_group_stream != s)) return ncclInvalidArgument;
+  t_group_comm = comm;
+  t_group_stream = s;
+  t_p2p.push_back(P2P{send, peer, sbuf, rbuf, count});
+  return ncclSuccess;
+}
+ncclResult_t ncclSend(const void* send, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t s) {
+  return p2p(true, send, nullptr, count, peer, comm, s);
+}
+ncclResult_t ncclRecv(void* recv, size_t count, ncclDataType_t, int peer, ncclComm_t comm, hipStream_t s) {
+  return p2p(false, nullptr, recv, count, peer, comm, s);
+}
+ncclResult_t ncclGroupEnd(void) {
+  t_in_group = false;
+  if (!t_group_comm) return ncclSuccess;
+  CollArg a;
+  a.type = 2;
+  a.p2p = t_p2p;
+  return enqueue_coll(t_group_comm, t_group_stream, a);
+}
+
+// ------------------------------------------------------------------------------------------- the stand-in engine (C-ABI)
+int ddt_create(ddt_engine** out, int device_id) {
+  if (!out || device_id < 0 || device_id >= g_devices) return DDT_EINVAL;
+  ddt_engine* e = new ddt_engine();
+  e->device = device_id;
+  *out = e;
+  return DDT_OK;
+}
+void ddt_destroy(ddt_engine* e) {
+  if (!e) return;
+  {
+    std::lock_guard<std::mutex> lk(M);
+    g_models.erase(e);
+  }
+  delete e;
+}
+static int mock_load(ddt_engine* e, const ddt_params* p, uint32_t classes, uint32_t shard, uint32_t count) {
+  if (!e || !p || count == 0 || shard >= count) return DDT_EINVAL;
+  e->p = *p;
+  e->num_classes = classes;
+  e->loaded = true;
+  std::lock_guard<std::mutex> lk(M);
+  g_models[e] = MockModel{shard, count, classes};
+  return DDT_OK;
+}
+int ddt_load_model_shard(ddt_engine* e, const ddt_params* p, const void*, size_t, const void*, size_t, uint32_t shard, uint32_t count) {
+  return mock_load(e, p, 1, shard, count);
+}
+int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const void*, size_t, const uint64_t*, uint32_t shard, uint32_t count) {
+  return mock_load(e, p, 1, shard, count);
+}
+int ddt_load_model_multiclass(ddt_engine* e, const ddt_params* p, const void*, size_t, const void*, size_t, uint32_t classes, int, uint32_t shard,
+                              uint32_t count) {
+  return mock_load(e, p, classes, shard, count);
+}
+const char* ddt_strerror(int) { return "mock"; }
+const char* ddt_last_error(const ddt_engine* e) { return e ? e->err : ""; }
+
+// ------------------------------------------------------------------------------------------------------ test control
+void mock_reset(int policy, uint64_t seed, int devices) {
+  std::lock_guard<std::mutex> lk(M);
+  g_policy = policy;
+  g_rng.seed(seed);
+  g_devices = devices;
+  g_errors = 0;
+  g_executed = 0;
+}
+int mock_errors(void) { return g_errors; }
+uint64_t mock_executed(void) { return g_executed; }
+float mock_partial(uint32_t shard, uint32_t cls, uint32_t row) { return partial(shard, cls, row); }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------- what ddt_comm.cpp takes from the other units
+namespace ddt {
+
+uint32_t tuple_words(const ddt_params& p) { return (p.num_features + 3u) / 4u * 4u; }
+
+int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
+  MockModel m;
+  {
+    std::lock_guard<std::mutex> lk(M);
+    m = g_models[e];
+  }
+  const uint32_t W = tuple_words(e->p);
+  const uint32_t* t = reinterpret_cast<const uint32_t*>(d_tuples);
+  Op* op = new Op();
+  op->run = [=] {
+    for (size_t i = 0; i < n; ++i) d_scores[i] = partial(m.shard, 0, t[i * W]);
+  };
+  enqueue(s, op);
+  return DDT_OK;
+}
+
+int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s) {
+  MockModel m;
+  {
+    std::lock_guard<std::mutex> lk(M);
+    m = g_models[e];
+  }
+  const uint32_t W = tuple_words(e->p);
+  const uint32_t* t = reinterpret_cast<const uint32_t*>(d_tuples);
+  Op* op = new Op();
+  op->run = [=] {
+    for (uint32_t k = 0; k < m.classes; ++k)
+      for (size_t i = 0; i < n; ++i) d_class_scores[(size_t)k * n + i] = partial(m.shard, k, t[i * W]);
+    if (d_labels)
+      for (size_t i = 0; i < n; ++i) {
+        uint32_t best = 0;
+        for (uint32_t k = 1; k < m.classes; ++k)
+          if (d_class_scores[(size_t)k * n + i] > d_class_scores[(size_t)best * n + i]) best = k;
+        d_labels[i] = (int32_t)best;
+      }
+  };
+  enqueue(s, op);
+  return DDT_OK;
+}
+
+hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s) {
+  Op* op = new Op();
+  op->run = [=] {
+    for (size_t i = 0; i < n; ++i) {
+      volatile float acc = parts[i];
+      for (uint32_t g = 1; g < n_parts; ++g) acc = acc + parts[(size_t)g * n + i];  // p0 + p1 + ... (ResultsCombiner.sv:292-311)
+      out[i] = acc;
+    }
+  };
+  enqueue(s, op);
+  return hipSuccess;
+}
+
+hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s) {
+  Op* op = new Op();
+  op->run = [=] {
+    for (size_t i = 0; i < n; ++i) {
+      uint32_t best = 0;
+      for (uint32_t k = 1; k < K; ++k)
+        if (scores[(size_t)k * n + i] > scores[(size_t)best * n + i]) best = k;  // lowest index wins ties
+      labels[i] = (int32_t)best;
+    }
+  };
+  enqueue(s, op);
+  return hipSuccess;
+}
+
+}  // namespace ddt

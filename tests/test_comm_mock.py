@@ -1,0 +1,325 @@
+"""The REAL multi-GPU pipeline code (csrc/ddt_comm.cpp) with 2 .. 8 ranks, on a machine without GPUs.
+
+csrc/ddt_comm.cpp is compiled unchanged against tests/mock_hip/: a deferred-execution model of HIP streams / events and of
+the RCCL collectives (mock_runtime.cpp), and a stand-in engine whose partial scores are integer-valued floats (any summation
+order gives the same bits).  Ranks are threads.  Operations run only when a scheduler picks them -- lowest stream id first,
+highest first, or seeded random -- honouring nothing but stream order and event dependencies, so that a missing wait in the
+pipeline shows up as a wrong result under some schedule (the last test removes one on purpose to prove it does).
+
+What this covers that one GPU cannot: shard arithmetic with G > 1, the all-to-all segment layout of the chain combine, the
+[K][n] class layout through the workspace slots, ragged row partitions, the tapered tail, back-to-back calls on reused
+slots, the host-buffer form, and the single-process group with one worker thread per device."""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import ddt
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MOCK = os.path.join(HERE, "mock_hip")
+CSRC = os.path.join(os.path.dirname(HERE), "distributed-decisiontrees_amd", "csrc")
+vp, sz, u32, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int
+
+
+def _build(name, comm_source):
+    out = os.path.join(MOCK, name)
+    deps = [comm_source, os.path.join(MOCK, "mock_runtime.cpp"), os.path.join(MOCK, "hip", "hip_runtime.h"), os.path.join(MOCK, "rccl", "rccl.h"),
+            os.path.join(CSRC, "ddt_engine_priv.h"), os.path.join(CSRC, "ddt_internal.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wall", "-I" + MOCK, "-I" + CSRC, comm_source,
+                               os.path.join(MOCK, "mock_runtime.cpp"), "-o", out])
+    L = C.CDLL(out)
+    L.ddt_create.argtypes, L.ddt_destroy.argtypes, L.ddt_destroy.restype = [C.POINTER(vp), i32], [vp], None
+    L.ddt_load_model_shard.argtypes = [vp, C.POINTER(ddt.Params), vp, sz, vp, sz, u32, u32]
+    L.ddt_load_model_multiclass.argtypes = [vp, C.POINTER(ddt.Params), vp, sz, vp, sz, u32, i32, u32, u32]
+    L.ddt_comm_get_unique_id.argtypes = [vp]
+    L.ddt_comm_create.argtypes, L.ddt_comm_destroy.argtypes, L.ddt_comm_destroy.restype = [C.POINTER(vp), vp, i32, i32, vp], [vp], None
+    L.ddt_comm_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.ddt_comm_last_error.argtypes, L.ddt_comm_last_error.restype = [vp], C.c_char_p
+    L.ddt_score_sharded_device.argtypes = [vp, vp, sz, vp, i32, vp]
+    L.ddt_score_rowsharded_device.argtypes = [vp, vp, sz, vp, vp]
+    L.ddt_classify_sharded_device.argtypes = [vp, vp, sz, vp, vp, i32, vp]
+    L.ddt_comm_score.argtypes = [vp, vp, sz, vp, i32]
+    L.ddt_group_create.argtypes, L.ddt_group_destroy.argtypes, L.ddt_group_destroy.restype = [C.POINTER(vp), i32, vp], [vp], None
+    L.ddt_group_load_model.argtypes = [vp, C.POINTER(ddt.Params), vp, sz, vp, sz]
+    L.ddt_group_load_model_multiclass.argtypes = [vp, C.POINTER(ddt.Params), vp, sz, vp, sz, u32, i32]
+    L.ddt_group_score.argtypes = [vp, vp, sz, vp, i32]
+    L.ddt_group_classify.argtypes = [vp, vp, sz, vp, vp, i32]
+    L.ddt_group_last_error.argtypes, L.ddt_group_last_error.restype = [vp], C.c_char_p
+    L.hipSetDevice.argtypes = [i32]
+    L.hipStreamCreateWithFlags.argtypes, L.hipStreamSynchronize.argtypes, L.hipStreamDestroy.argtypes = [C.POINTER(vp), C.c_uint], [vp], [vp]
+    L.mock_reset.argtypes, L.mock_reset.restype = [i32, u64, i32], None
+    L.mock_executed.restype = u64
+    return L
+
+
+@pytest.fixture(scope="module")
+def mock():
+    return _build("libddt_comm_mock.so", os.path.join(CSRC, "ddt_comm.cpp"))
+
+
+F, W = 6, 8   # 6 features -> two tuple lines
+
+
+def _tuples(n):
+    x = np.zeros((n, W), np.uint32)
+    x[:, 0] = np.arange(n)                       # the stand-in engine scores a tuple by its row id
+    x[:, 1:] = 0xDEAD0000
+    return x
+
+
+def _partial(shard, cls, rows):
+    return (((rows.astype(np.int64) * 7 + shard * 13 + cls * 101) % 1000) - 500).astype(np.float32)
+
+
+def _expected(G, n, K=1):
+    rows = np.arange(n)
+    out = np.zeros((K, n), np.float32)
+    for k in range(K):
+        for g in range(G):
+            out[k] += _partial(g, k, rows)
+    return out
+
+
+def _params(T=64):
+    return ddt.make_params(T, 4, F)
+
+
+def _run_ranks(G, body):
+    """body(rank, barrier, shared) on G threads; any exception fails the test."""
+    barrier, shared, errors = threading.Barrier(G), {}, []
+
+    def wrap(r):
+        try:
+            body(r, barrier, shared)
+        except BaseException as ex:  # noqa: BLE001
+            errors.append((r, repr(ex)))
+            barrier.abort()
+
+    th = [threading.Thread(target=wrap, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in th), "a rank is stuck"
+
+
+class Rank:
+    """One rank of a process-per-GPU style job: engine + communicator + the caller's stream."""
+
+    def __init__(self, L, r, G, barrier, shared, classes=1, stream_first=True, whole_model=False):
+        self.L, self.r, self.G = L, r, G
+        assert L.hipSetDevice(r) == 0
+        self.s = vp()
+        if stream_first:
+            assert L.hipStreamCreateWithFlags(C.byref(self.s), 1) == 0
+        self.e = vp()
+        assert L.ddt_create(C.byref(self.e), r) == 0
+        p = _params()
+        shard = (0, 1) if whole_model else (r, G)
+        if classes > 1:
+            assert L.ddt_load_model_multiclass(self.e, C.byref(p), None, 0, None, 0, classes, 1, *shard) == 0
+        else:
+            assert L.ddt_load_model_shard(self.e, C.byref(p), None, 0, None, 0, *shard) == 0
+        if r == 0:
+            shared["id"] = C.create_string_buffer(128)
+            assert L.ddt_comm_get_unique_id(shared["id"]) == 0
+        barrier.wait()
+        self.c = vp()
+        assert L.ddt_comm_create(C.byref(self.c), self.e, r, G, shared["id"]) == 0
+        if not stream_first:
+            assert L.hipStreamCreateWithFlags(C.byref(self.s), 1) == 0
+
+    def opt(self, key, value):
+        assert self.L.ddt_comm_set_option(self.c, key.encode(), value) == 0
+
+    def sync(self):
+        assert self.L.hipStreamSynchronize(self.s) == 0
+
+    def close(self, barrier):
+        barrier.wait()                           # nobody tears down while a peer still needs the collective
+        self.L.ddt_comm_destroy(self.c)
+        self.L.ddt_destroy(self.e)
+        self.L.hipStreamDestroy(self.s)
+
+
+SCHEDULES = [(0, 0), (1, 0), (2, 11), (2, 12), (2, 13)]
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES)
+@pytest.mark.parametrize("G,n,chunk", [(2, 5003, 1024), (3, 1000, 12_500_000), (4, 4097, 700), (8, 3001, 1000), (8, 1, 5)])
+def test_tree_sharded_scores(mock, G, n, chunk, policy, seed):
+    mock.mock_reset(policy, seed, 8)
+    x, want = _tuples(n), _expected(G, n)[0]
+
+    def body(r, barrier, shared):
+        k = Rank(mock, r, G, barrier, shared, stream_first=(seed % 2 == 0))
+        k.opt("chunk_rows", chunk)
+        k.opt("taper_min_rows", 16)              # the tapered tail (default with peers) at test sizes
+        outs = []
+        for combine in (0, 1, 1, 0):             # back to back, no host synchronisation in between: workspace slots are reused
+            out = np.full(n, np.nan, np.float32)
+            assert mock.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, combine, k.s) == 0, mock.ddt_comm_last_error(k.c)
+            outs.append(out)
+        k.sync()
+        for out in outs:
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (r, np.flatnonzero(out != want)[:5])
+        k.opt("taper_tail", 0)
+        out = np.full(n, np.nan, np.float32)
+        assert mock.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, 0, k.s) == 0
+        k.sync()
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+        k.close(barrier)
+
+    _run_ranks(G, body)
+    assert mock.mock_errors() == 0 and mock.mock_executed() > 0
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES)
+@pytest.mark.parametrize("G,n,chunk,K", [(2, 2500, 700, 3), (4, 1029, 12_500_000, 10), (8, 777, 100, 2)])
+def test_tree_sharded_classes(mock, G, n, chunk, K, policy, seed):
+    mock.mock_reset(policy, seed, 8)
+    x, want = _tuples(n), _expected(G, n, K)
+    want_labels = np.argmax(want, axis=0).astype(np.int32)      # first maximum = lowest index wins ties
+
+    def body(r, barrier, shared):
+        k = Rank(mock, r, G, barrier, shared, classes=K, stream_first=(seed % 2 == 1))
+        k.opt("chunk_rows", chunk)
+        k.opt("taper_min_rows", 16)
+        res = []
+        for combine in (0, 1, 0):
+            cs, lab = np.full((K, n), np.nan, np.float32), np.full(n, -1, np.int32)
+            assert mock.ddt_classify_sharded_device(k.c, x.ctypes.data, n, cs.ctypes.data, lab.ctypes.data, combine, k.s) == 0
+            res.append((cs, lab))
+        k.sync()
+        for cs, lab in res:
+            assert np.array_equal(cs.view(np.uint32), want.view(np.uint32)) and np.array_equal(lab, want_labels), r
+        k.close(barrier)
+
+    _run_ranks(G, body)
+    assert mock.mock_errors() == 0
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+@pytest.mark.parametrize("G,n", [(2, 1000), (3, 1000), (8, 5), (8, 4096), (5, 4099)])
+def test_row_sharded_replicas(mock, G, n, policy, seed):
+    mock.mock_reset(policy, seed, 8)
+    x, want = _tuples(n), _partial(0, 0, np.arange(n))          # every rank holds the whole model (shard 0 of 1)
+
+    def body(r, barrier, shared):
+        k = Rank(mock, r, G, barrier, shared, whole_model=True)
+        outs = []
+        for _ in range(3):
+            out = np.full(n, np.nan, np.float32)
+            assert mock.ddt_score_rowsharded_device(k.c, x.ctypes.data, n, out.ctypes.data, k.s) == 0
+            outs.append(out)
+        k.sync()
+        for out in outs:
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), r
+        k.close(barrier)
+
+    _run_ranks(G, body)
+    assert mock.mock_errors() == 0
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+def test_host_buffer_form(mock, policy, seed):
+    G, n = 4, 6007
+    mock.mock_reset(policy, seed, 8)
+    x, want = _tuples(n), _expected(G, n)[0]
+
+    def body(r, barrier, shared):
+        k = Rank(mock, r, G, barrier, shared)
+        k.opt("host_rows", 2500)                 # three super-chunks, the last one ragged
+        k.opt("chunk_rows", 900)
+        k.opt("taper_min_rows", 16)
+        for combine in (0, 1):
+            out = np.full(n, np.nan, np.float32)
+            assert mock.ddt_comm_score(k.c, x.ctypes.data, n, out.ctypes.data, combine) == 0
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), r
+        k.close(barrier)
+
+    _run_ranks(G, body)
+    assert mock.mock_errors() == 0
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+@pytest.mark.parametrize("G", [2, 8])
+def test_single_process_group(mock, G, policy, seed):
+    """ddt_group_*: one process, one worker thread per device (ncclCommInitAll)."""
+    mock.mock_reset(policy, seed, 8)
+    n, K = 9001, 4
+    x = _tuples(n)
+    g = vp()
+    assert mock.ddt_group_create(C.byref(g), G, None) == 0
+    p = _params()
+    assert mock.ddt_group_load_model(g, C.byref(p), x.ctypes.data, 1 << 20, x.ctypes.data, 1 << 20) == 0
+    for combine in (0, 1):
+        out = np.full(n, np.nan, np.float32)
+        assert mock.ddt_group_score(g, x.ctypes.data, n, out.ctypes.data, combine) == 0, mock.ddt_group_last_error(g)
+        assert np.array_equal(out.view(np.uint32), _expected(G, n)[0].view(np.uint32))
+    assert mock.ddt_group_load_model_multiclass(g, C.byref(p), x.ctypes.data, 1 << 20, x.ctypes.data, 1 << 20, K, 1) == 0
+    want = _expected(G, n, K)
+    lab, cs = np.full(n, -1, np.int32), np.full((K, n), np.nan, np.float32)
+    assert mock.ddt_group_classify(g, x.ctypes.data, n, lab.ctypes.data, cs.ctypes.data, 0) == 0
+    assert np.array_equal(cs.view(np.uint32), want.view(np.uint32)) and np.array_equal(lab, np.argmax(want, axis=0))
+    mock.ddt_group_destroy(g)
+    assert mock.mock_errors() == 0
+
+
+REMOVED_WAITS = {
+    # the collective of a chunk no longer waits for the chunk's scoring launch (in-place all-reduce path)
+    "scored_inplace": ("      CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));\n      CNCCL(c, ncclAllReduce(dst + lo, dst + lo, m, ncclFloat, ncclSum, c->comm, c->cs));",
+                       "      CNCCL(c, ncclAllReduce(dst + lo, dst + lo, m, ncclFloat, ncclSum, c->comm, c->cs));", 0),
+    # ... the same on the staged path (chain combine / classes)
+    "scored_staged": ("    CHIP(c, hipEventRecord(c->ev_scored[b], s));\n    CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));\n    const float* res;",
+                      "    const float* res;", 1),
+    # the scoring launch of chunk k+2 no longer waits until slot b has been consumed by chunk k's collective
+    "slot_free": ("    if (c->slot_used[b]) CHIP(c, hipStreamWaitEvent(s, c->ev_free[b], 0));  // slot b still feeds chunk k-2's collective\n", "", 1),
+    # the caller's stream no longer waits for the last collective
+    "done": ("  CHIP(c, hipStreamWaitEvent(s, c->ev_done, 0));  // results are ready in stream order on the caller's stream\n", "", 1),
+}
+
+
+@pytest.mark.parametrize("which", sorted(REMOVED_WAITS))
+def test_the_model_catches_a_missing_dependency(which):
+    """Remove ONE wait of the event protocol from the source: some schedule must then give wrong scores -- the proof that
+    the schedules above would have exposed such a hole in the shipped pipeline."""
+    needle, repl, combine = REMOVED_WAITS[which]
+    src = open(os.path.join(CSRC, "ddt_comm.cpp")).read()
+    assert src.count(needle) == 1, which
+    broken, so = os.path.join(MOCK, f"_broken_{which}.cpp"), f"libddt_comm_mock_broken_{which}.so"
+    open(broken, "w").write(src.replace(needle, repl))
+    try:
+        bad = _build(so, broken)
+        G, n = 2, 3000
+        x, want = _tuples(n), _expected(G, n)[0]
+        wrong = 0
+        for policy, seed in SCHEDULES:
+            bad.mock_reset(policy, seed, 8)
+            seen = []
+
+            def body(r, barrier, shared):
+                k = Rank(bad, r, G, barrier, shared, stream_first=True)
+                k.opt("chunk_rows", 300)
+                outs = []
+                for _ in range(2):
+                    out = np.full(n, np.nan, np.float32)
+                    assert bad.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, combine, k.s) == 0
+                    outs.append(out)
+                k.sync()
+                seen.append(all(np.array_equal(o.view(np.uint32), want.view(np.uint32)) for o in outs))
+                k.close(barrier)
+
+            _run_ranks(G, body)
+            wrong += not all(seen)
+        assert wrong > 0, f"no schedule noticed the missing wait ({which})"
+    finally:
+        for f in (broken, os.path.join(MOCK, so)):
+            if os.path.exists(f):
+                os.remove(f)
