@@ -216,6 +216,27 @@ def main():
     ms_per_step = dt / max(1, args.steps) * 1e3
     mtuples = N / (dt / max(1, args.steps)) / 1e6
 
+    # ---- N>1 (or --force-collectives): the same shard scored WITHOUT the collectives, so that the line itself shows what the
+    # combine costs on top of the per-rank compute (max over ranks, 2 steps, outside the timed region) -----------------------
+    scaling_detail = None
+    if comm is not None and classes == 1 and not rows_mode:
+        try:
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                eng.score_device(tuples, out=out)
+            fence()
+            cdt = (time.perf_counter() - t1) / 2
+            if world > 1:
+                tmax = torch.tensor([cdt], dtype=torch.float64, device=tuples.device)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                cdt = float(tmax.item())
+            scaling_detail = {"shard_compute_only_ms": round(cdt * 1e3, 4), "combine_overhead_ms": round(ms_per_step - cdt * 1e3, 4),
+                              "trees_on_this_rank": int(info.tree_end - info.tree_begin), "chunk_rows": args.chunk_rows,
+                              "note": "ms_per_step minus one pass of the rank's shard over all tuples with no collective (max over ranks)"}
+        except Exception as ex:  # diagnostics must never cost the headline line
+            scaling_detail = {"error": repr(ex)}
+
     # ---- roofline of the dominant kernel (the per-shard scoring kernel) ----------------------------
     # tuples in, scores out, model once; config 5 writes the K per-class sums and the label (argmax not fused)
     alg_bytes_per_launch = N * (4 * F + 4 * (classes + 1 if classes > 1 else 1)) + int(info.model_bytes_unpadded)
@@ -353,6 +374,8 @@ def main():
             line["parity"] = parity
         if streamed:
             line["streamed"] = streamed
+        if scaling_detail:
+            line["scaling_detail"] = scaling_detail
     if comm is not None:
         comm.close()
     if multi:
