@@ -56,44 +56,6 @@ def test_one_rank_sharded_job_equals_plain_call(eng, comm, T, D, F, rows, dist):
     comm.set_option("chunk_rows", 12_500_000)
 
 
-def test_one_rank_tapered_tail_equals_plain_call(eng, comm):
-    """The last chunk cut into 1/2, 1/4, 1/4 (what a communicator with real peers does by default): same scores, same labels."""
-    import torch
-
-    T, D, F, rows = 300, 8, 32, 9000
-    m = O.gen_model(T, D, F, 1)
-    x = O.gen_tuples(0, rows, F, 1)
-    want = O.score(m, x)
-    eng.load_model(ddt.make_params(T, D, F), m.wlines, m.flines, 0, 1)
-    d = torch.from_numpy(x.view(np.int32)).cuda()
-    comm.set_option("taper_tail", 1)
-    comm.set_option("taper_min_rows", 64)
-    try:
-        for chunk in (12_500_000, 4096, 2000, 1024):  # the whole call is the tail; two chunks + tail; ragged; many chunks
-            comm.set_option("chunk_rows", chunk)
-            for combine in (ddt.COMBINE_ALLREDUCE, ddt.COMBINE_CHAIN):
-                outs = [comm.score_sharded(d, combine=combine) for _ in range(2)]  # back to back: slots reused
-                torch.cuda.synchronize()
-                for got in outs:
-                    assert np.array_equal(_bits(got.cpu().numpy()), _bits(want)), (chunk, combine)
-        K = 3
-        mc = O.gen_model(90, 6, 16, 1)
-        xc = O.gen_tuples(0, 5000, 16, 1)
-        labels, cs = O.classify(mc, xc, K)
-        eng.load_model_multiclass(ddt.make_params(90, 6, 16, clusters=1), mc.wlines, mc.flines, K, True, 0, 1)
-        dc = torch.from_numpy(xc.view(np.int32)).cuda()
-        for chunk in (12_500_000, 1500):
-            comm.set_option("chunk_rows", chunk)
-            for combine in (0, 1):
-                gl, gs = comm.classify_sharded(dc, combine=combine)
-                torch.cuda.synchronize()
-                assert np.array_equal(gl.cpu().numpy(), labels) and np.array_equal(_bits(gs.cpu().numpy()), _bits(cs)), (chunk, combine)
-    finally:
-        comm.set_option("taper_tail", -1)
-        comm.set_option("taper_min_rows", 1 << 20)
-        comm.set_option("chunk_rows", 12_500_000)
-
-
 def test_one_rank_sharded_sparse_and_back_to_back_calls(eng, comm):
     import torch
 
@@ -174,46 +136,3 @@ def test_cli_runs_the_multi_gpu_job_without_python(tmp_path):
         assert f"scored {n} tuples on 1 device(s)" in out and "RCCL" in out
         res = np.fromfile(pre + ".results", np.float32)
         assert np.array_equal(res[:n].view(np.uint32), want.view(np.uint32))
-
-
-def test_host_buffer_form_of_one_rank(eng, comm):
-    """ddt_comm_score: host tuples -> this rank's device in super-chunks -> the sharded job -> host scores."""
-    import ctypes as C
-
-    T, D, F, rows = 260, 8, 32, 7001
-    m = O.gen_model(T, D, F, 1)
-    x = O.gen_tuples(0, rows, F, 1)
-    want = O.score(m, x)
-    eng.load_model(ddt.make_params(T, D, F), m.wlines, m.flines, 0, 1)
-    L = ddt.lib()
-    out = np.zeros(rows, np.float32)
-    try:
-        for host_rows, chunk in ((8 << 20, 12_500_000), (3000, 1024), (1000, 7000)):   # one super-chunk; ragged super-chunks and chunks
-            comm.set_option("host_rows", host_rows)
-            comm.set_option("chunk_rows", chunk)
-            for combine in (ddt.COMBINE_ALLREDUCE, ddt.COMBINE_CHAIN):
-                out[:] = 0
-                assert L.ddt_comm_score(comm._h, x.ctypes.data, rows, out.ctypes.data, combine) == 0
-                assert np.array_equal(_bits(out), _bits(want)), (host_rows, chunk, combine)
-        assert L.ddt_comm_score(comm._h, x.ctypes.data, 0, out.ctypes.data, 0) == 0
-        assert L.ddt_comm_score(comm._h, None, rows, out.ctypes.data, 0) < 0
-    finally:
-        comm.set_option("host_rows", 8 << 20)
-        comm.set_option("chunk_rows", 12_500_000)
-
-
-def test_cli_runs_as_one_rank_of_a_process_per_gpu_job(tmp_path):
-    """`ddt_cli score --ranks 1 --rank 0 --id-file ...`: C++ host -> ddt_comm_* (ncclCommInitRank), the id through a file."""
-    pre = str(tmp_path / "job")
-    T, D, F, n = 120, 6, 28, 2051
-    subprocess.check_call([ddt.CLI_PATH, "gen", "--trees", str(T), "--levels", str(D), "--features", str(F), "--rows", str(n),
-                           "--dist", "1", "--prefix", pre])
-    want = O.score(O.gen_model(T, D, F, dist=1), O.gen_tuples(0, n, F, dist=1))
-    out = subprocess.check_output([ddt.CLI_PATH, "score", "--csr", pre + ".csr", "--weights", pre + ".weights", "--findex", pre + ".findex",
-                                   "--tuples", pre + ".tuples", "--out", pre + ".results", "--ranks", "1", "--rank", "0",
-                                   "--id-file", pre + ".id", "--combine", "chain"],
-                                  env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).decode()
-    assert f"rank 0 of 1: scored {n} tuples" in out and "RCCL" in out
-    assert os.path.getsize(pre + ".id") == 128
-    res = np.fromfile(pre + ".results", np.float32)
-    assert np.array_equal(res[:n].view(np.uint32), want.view(np.uint32))
