@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--combine", default="allreduce", choices=["allreduce", "chain"])
     ap.add_argument("--shard", default="trees", choices=["trees", "rows"],
                     help="N>1: 'trees' = the headline mode (ensemble sharded tree-wise, partial scores all-reduced); "
-                         "'rows' = the reference's other mode (replicated ensemble, tuples partitioned, scores all-gathered)")
+                         "'rows' = the reference's other mode (replicated ensemble, tuples partitioned, every step of scores handed to all peers while the next is scored)")
     ap.add_argument("--chunk-rows", type=int, default=12_500_000, help="rows per pipelined collective (N>1)")
     ap.add_argument("--taper", type=int, default=-1, choices=[-1, 0, 1],
                     help="N>1 / --force-collectives: cut the last chunk into 1/2, 1/4, 1/4 so that the exposed collective is a quarter "
@@ -344,7 +344,7 @@ def main():
 
     if rank == 0:
         par = "single engine" if world == 1 else (
-            f"row-sharded {world}x (replicas) + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-gather" if rows_mode else
+            f"row-sharded {world}x (replicas) + {'RCCL send/recv all-gather, pipelined' if comm is not None else 'gloo all-gather'}" if rows_mode else
             f"tree-sharded {world}x + {'RCCL' if args.backend == 'nccl' else 'gloo (functional test)'} {args.combine}")
         shape = (f"{T} sparse trees (depth <= {D}, {lines.shape[0]} internal nodes) x {F} fp32 features" if sparse
                  else f"{classes}-class one-vs-all, {T // classes} trees/class x depth {D} x {F} fp32 features, argmax labels" if classes > 1

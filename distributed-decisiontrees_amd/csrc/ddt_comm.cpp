@@ -389,34 +389,41 @@ int ddt_score_rowsharded_device(ddt_comm* c, const void* d_tuples, size_t n, flo
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   ddt_engine* e = c->e;
   const size_t W = tuple_words(e->p), G = (size_t)c->n, per = (n + G - 1) / G;
-  const size_t lo = std::min((size_t)c->rank * per, n), hi = std::min(lo + per, n);
+  // rank r owns rows [r * per, min((r + 1) * per, n)) and scores them IN PLACE in the caller's buffer, `step` rows at a time;
+  // while step j + 1 is being scored the comm stream hands step j to every peer with grouped ncclSend / ncclRecv straight into
+  // its place in their buffers (results are interleaved, not summed: ResultsCombiner.sv:371-391).  xGMI is a point-to-point
+  // mesh: one message per link at once is how an all-gather uses it best, and exact per-peer counts need no padding or staging.
+  auto len_of = [&](size_t r) { return std::min(per, n - std::min(r * per, n)); };
+  size_t step = (std::min(c->chunk_rows, n) + G - 1) / G;
+  if (step >= 1024) step = (step + 1023) / 1024 * 1024;  // whole tiles of the scoring kernels
+  const size_t me = (size_t)c->rank, lo = std::min(me * per, n), mine = len_of(me);
   c->err[0] = 0;
-  const bool exact = per * G == n;  // the gather can land in the caller's buffer directly
-  float* full = d_scores;
-  if (!exact) {
-    rc = comm_reserve(c, per * G);
-    if (rc) return rc;
-    full = c->full[0];
-    if (c->slot_used[0]) CHIP(c, hipStreamWaitEvent(s, c->ev_free[0], 0));
+  const uint32_t* tup = reinterpret_cast<const uint32_t*>(d_tuples);
+  size_t k = 0;
+  for (size_t off = 0; off < per; off += step, ++k) {
+    const int b = (int)(k & 1);
+    auto cnt = [&](size_t r) { return len_of(r) > off ? std::min(step, len_of(r) - off) : (size_t)0; };
+    if (cnt(me)) {
+      rc = engine_score_device(e, tup + (lo + off) * W, cnt(me), d_scores + lo + off, s);
+      if (rc) return cfail(c, rc, "%s", e->err);
+    }
+    if (G == 1) continue;
+    CHIP(c, hipEventRecord(c->ev_scored[b], s));
+    CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));
+    CNCCL(c, ncclGroupStart());
+    for (size_t r = 0; r < G; ++r) {
+      if (r == me) continue;
+      if (cnt(me)) CNCCL(c, ncclSend(d_scores + lo + off, cnt(me), ncclFloat, (int)r, c->comm, c->cs));
+      if (cnt(r)) CNCCL(c, ncclRecv(d_scores + r * per + off, cnt(r), ncclFloat, (int)r, c->comm, c->cs));
+    }
+    CNCCL(c, ncclGroupEnd());
   }
-  float* mine = full + (size_t)c->rank * per;
-  if (hi - lo < per) CHIP(c, hipMemsetAsync(mine + (hi - lo), 0, (per - (hi - lo)) * sizeof(float), s));
-  if (hi > lo) {
-    rc = engine_score_device(e, reinterpret_cast<const uint32_t*>(d_tuples) + lo * W, hi - lo, mine, s);
-    if (rc) return cfail(c, rc, "%s", e->err);
+  if (G > 1) {
+    CHIP(c, hipEventRecord(c->ev_done, c->cs));
+    CHIP(c, hipStreamWaitEvent(s, c->ev_done, 0));  // every peer's rows have landed before the caller's stream moves on
   }
-  CHIP(c, hipEventRecord(c->ev_scored[0], s));
-  CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[0], 0));
-  CNCCL(c, ncclAllGather(mine, full, per, ncclFloat, c->comm, c->cs));  // results interleaved, not summed (ResultsCombiner.sv:371-391)
-  if (!exact) {
-    CHIP(c, hipMemcpyAsync(d_scores, full, n * sizeof(float), hipMemcpyDeviceToDevice, c->cs));
-    CHIP(c, hipEventRecord(c->ev_free[0], c->cs));
-    c->slot_used[0] = true;
-  }
-  CHIP(c, hipEventRecord(c->ev_done, c->cs));
-  CHIP(c, hipStreamWaitEvent(s, c->ev_done, 0));
   e->st.score_calls++;
-  e->st.tuples_in += hi - lo;
+  e->st.tuples_in += mine;
   e->st.tuples_out += n;
   return DDT_OK;
 }

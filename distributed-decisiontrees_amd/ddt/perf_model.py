@@ -140,6 +140,17 @@ def tree_sharded_ms(trees: int, n_gpus: int, depth: int = 8, rows: float = 1e8, 
     return {"ms": ms, "mtuples_per_s": rows / ms / 1e3, "path": e["path"], "score_ms": e["ms"], "exposed_comm_ms": comm}
 
 
+def row_sharded_ms(trees: int, n_gpus: int, depth: int = 8, rows: float = 1e8, g: Mi355x = Mi355x(), chunks: int = 8) -> dict:
+    """Whole-job time of the row-sharded mode ("replicas only", csrc/ddt_comm.cpp ddt_score_rowsharded_device): every rank scores
+    rows / G tuples against the WHOLE ensemble; each finished step goes to all peers while the next one is scored, so only the
+    last step's messages (rows / chunks scores to G - 1 peers, one xGMI link each) are exposed."""
+    e = engine_ms(trees, depth, rows / n_gpus)
+    link = 153e9 / 2                       # one xGMI link, one direction
+    comm = 0.0 if n_gpus == 1 else (rows / chunks / n_gpus) * 4 / link * 1e3 + 0.05
+    ms = e["ms"] + comm
+    return {"ms": ms, "mtuples_per_s": rows / ms / 1e3, "path": e["path"], "score_ms": e["ms"], "exposed_comm_ms": comm}
+
+
 # ---- part 4: sparse forests (config 4): the vector-memory lane-address ceiling ---------------------------------
 @dataclass
 class SparseCosts:

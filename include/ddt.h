@@ -189,8 +189,11 @@ int ddt_load_model_sparse_multiclass(ddt_engine* e, const ddt_params* p, const v
  *                      DDT_COMBINE_CHAIN      deterministic: all-to-all (grouped ncclSend / ncclRecv of 1/G slices),
  *                                             fixed-order add p0 + p1 + ... on the owner (ResultsCombiner.sv:292-311's
  *                                             host -> dev1 -> ... order), ncclAllGather: bit-exact with the chain.
- *      row-sharded   every rank holds the whole ensemble and scores rows [r*ceil(n/G), ...); ncclAllGather returns the
- *                    full score vector to every rank ("replicas only": no arithmetic crosses devices).
+ *      row-sharded   every rank holds the whole ensemble and scores rows [r*ceil(n/G), ...) in place in the caller's buffer,
+ *                    "chunk_rows" / G rows at a time; while the next step is being scored the comm stream hands the finished one
+ *                    to every peer with grouped ncclSend / ncclRecv straight into its place in their buffers (one message per
+ *                    xGMI link at once; exact per-peer counts: no padding, no staging) -- every rank ends up with the full
+ *                    score vector ("replicas only": no arithmetic crosses devices).
  *    One ddt_comm per (process or thread) x device; the calls are collective: every rank calls them with the same
  *    arguments (tuples replicated on every rank for the tree-sharded calls).  They are asynchronous on `hip_stream`
  *    like ddt_score_device; workspace buffers are (re)allocated synchronously when a call needs more than before.

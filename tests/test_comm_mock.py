@@ -212,9 +212,10 @@ def test_row_sharded_replicas(mock, G, n, policy, seed):
     x, want = _tuples(n), _partial(0, 0, np.arange(n))          # every rank holds the whole model (shard 0 of 1)
 
     def body(r, barrier, shared):
-        k = Rank(mock, r, G, barrier, shared, whole_model=True)
+        k = Rank(mock, r, G, barrier, shared, whole_model=True, stream_first=(seed % 2 == 0))
         outs = []
-        for _ in range(3):
+        for chunk in (12_500_000, 300, 64):       # one step; a few; many (every rank sends its step to every peer, in place)
+            k.opt("chunk_rows", chunk)
             out = np.full(n, np.nan, np.float32)
             assert mock.ddt_score_rowsharded_device(k.c, x.ctypes.data, n, out.ctypes.data, k.s) == 0
             outs.append(out)
@@ -283,6 +284,9 @@ REMOVED_WAITS = {
     "slot_free": ("    if (c->slot_used[b]) CHIP(c, hipStreamWaitEvent(s, c->ev_free[b], 0));  // slot b still feeds chunk k-2's collective\n", "", 1),
     # the caller's stream no longer waits for the last collective
     "done": ("  CHIP(c, hipStreamWaitEvent(s, c->ev_done, 0));  // results are ready in stream order on the caller's stream\n", "", 1),
+    # row-sharded job: a step is handed to the peers before it has been scored / the caller does not wait for the peers' rows
+    "rows_scored": ("    CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));\n    CNCCL(c, ncclGroupStart());", "    CNCCL(c, ncclGroupStart());", -1),
+    "rows_done": ("    CHIP(c, hipStreamWaitEvent(s, c->ev_done, 0));  // every peer's rows have landed before the caller's stream moves on\n", "", -1),
 }
 
 
@@ -298,19 +302,22 @@ def test_the_model_catches_a_missing_dependency(which):
     try:
         bad = _build(so, broken)
         G, n = 2, 3000
-        x, want = _tuples(n), _expected(G, n)[0]
+        x, want = _tuples(n), (_expected(G, n)[0] if combine >= 0 else _partial(0, 0, np.arange(n)))
         wrong = 0
         for policy, seed in SCHEDULES:
             bad.mock_reset(policy, seed, 8)
             seen = []
 
             def body(r, barrier, shared):
-                k = Rank(bad, r, G, barrier, shared, stream_first=True)
+                k = Rank(bad, r, G, barrier, shared, stream_first=True, whole_model=combine < 0)
                 k.opt("chunk_rows", 300)
                 outs = []
                 for _ in range(2):
                     out = np.full(n, np.nan, np.float32)
-                    assert bad.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, combine, k.s) == 0
+                    if combine < 0:
+                        assert bad.ddt_score_rowsharded_device(k.c, x.ctypes.data, n, out.ctypes.data, k.s) == 0
+                    else:
+                        assert bad.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, combine, k.s) == 0
                     outs.append(out)
                 k.sync()
                 seen.append(all(np.array_equal(o.view(np.uint32), want.view(np.uint32)) for o in outs))

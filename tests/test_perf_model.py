@@ -66,3 +66,13 @@ def test_sparse_forest_model_matches_the_config4_measurement():
     assert abs(r["mtuples_per_s"] - 213.7) / 213.7 < 0.2
     assert 280 < r["ceiling_mtuples_per_s"] < 310  # the lane-address ceiling of this model at K = 8
     assert P.predict_sparse(512, 12.059, top_levels=9)["ceiling_mtuples_per_s"] > r["ceiling_mtuples_per_s"]
+
+
+def test_row_sharded_model_beats_tree_sharding_when_the_ensemble_fits_one_gpu():
+    from ddt.perf_model import row_sharded_ms, tree_sharded_ms
+
+    one = row_sharded_ms(1000, 1)["ms"]
+    assert abs(one - tree_sharded_ms(1000, 1)["ms"]) < 1e-9
+    for g in (2, 4, 8):
+        r, t = row_sharded_ms(1000, g), tree_sharded_ms(1000, g)
+        assert r["ms"] < t["ms"] and one / r["ms"] > 0.95 * g and r["exposed_comm_ms"] < 0.5
