@@ -75,6 +75,11 @@ def main():
                          "gloo lets N ranks share one GPU for a functional test")
     ap.add_argument("--force-collectives", action="store_true",
                     help="N=1 only: run the multi-GPU chunk pipeline and the collectives in a one-rank group (overhead / sanity run)")
+    ap.add_argument("--no-other-modes", action="store_true",
+                    help="N>1 / --force-collectives: skip the extra legs behind the timed region (chain combine, untapered all-reduce, "
+                         "row-sharded replicas) that land in `other_modes` on the line")
+    ap.add_argument("--other-modes-timeout", type=float, default=120.0,
+                    help="seconds after which a stuck extra leg is abandoned: the headline line is printed and the process exits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -376,6 +381,66 @@ def main():
             line["streamed"] = streamed
         if scaling_detail:
             line["scaling_detail"] = scaling_detail
+    # ---- N>1 (or --force-collectives): the OTHER ways this library can run the same multi-GPU job, measured behind the timed
+    # region so that the driver's scaling run records them too (never `value`).  These collectives have run in one-rank
+    # communicators and in the CPU model of tests/test_comm_mock.py only: a watchdog keeps a stuck leg from costing the line.
+    if comm is not None and classes == 1 and not sparse and not rows_mode and not args.no_other_modes:
+        import threading
+
+        other = {}
+
+        def bail():
+            try:
+                if rank == 0:
+                    other["status"] = f"abandoned after {args.other_modes_timeout:.0f} s (a leg did not return)"
+                    line["other_modes"] = other
+                    os.dup2(saved_stdout, 1)
+                    os.write(1, (json.dumps(line) + "\n").encode())
+            finally:
+                os._exit(0)
+
+        wd = threading.Timer(args.other_modes_timeout, bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            def leg(fn, steps=2):
+                fn()
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    fn()
+                fence()
+                ldt = (time.perf_counter() - t1) / steps
+                if world > 1:
+                    tm = torch.tensor([ldt], dtype=torch.float64, device=tuples.device)
+                    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                    ldt = float(tm.item())
+                return round(ldt * 1e3, 4)
+
+            other["tree_sharded_chain_ms"] = leg(lambda: comm.score_sharded(tuples, out=out, combine=ddt.COMBINE_CHAIN))
+            comm.set_option("taper_tail", 0)
+            other["tree_sharded_allreduce_untapered_ms"] = leg(lambda: comm.score_sharded(tuples, out=out, combine=ddt.COMBINE_ALLREDUCE))
+            comm.set_option("taper_tail", args.taper)
+            tree_scores = out.clone()                            # combined scores of the tree-sharded job (all-reduce order)
+            eng2 = ddt.Engine(local)                             # row-sharded replicas: every rank holds the WHOLE ensemble
+            eng2.load_model(params, w, f, 0, 1)
+            box2 = [ddt.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box2, src=0)
+            comm2 = ddt.Comm(eng2, rank, world, box2[0])
+            comm2.set_option("chunk_rows", args.chunk_rows)
+            other["row_sharded_ms"] = leg(lambda: comm2.score_rowsharded(tuples, out=out))
+            other["row_sharded_mtuples_per_s"] = round(N / other["row_sharded_ms"] / 1e3, 3)
+            scale = float(tree_scores.abs().max().item()) or 1.0
+            other["row_vs_tree_max_abs_diff_rel"] = float((out - tree_scores).abs().max().item()) / scale   # summation order differs
+            other["note"] = ("ms per step, max over ranks, 2 steps each after one warm-up, outside the timed region; row-sharded = replicas "
+                             "only (whole ensemble per GPU, tuples partitioned, every step of scores handed to all peers), exact reference-order sums")
+            comm2.close()
+            eng2.close()
+        except Exception as ex:  # never at the price of the headline line
+            other["error"] = repr(ex)
+        wd.cancel()
+        if rank == 0:
+            line["other_modes"] = other
     if comm is not None:
         comm.close()
     if multi:

@@ -155,3 +155,7 @@ def test_multi_gpu_branch_in_a_one_rank_communicator(extra):
     assert "error" not in d, d
     assert d["shard_compute_only_ms"] > 0 and d["trees_on_this_rank"] == 200
     assert abs(d["combine_overhead_ms"] - (j["ms_per_step"] - d["shard_compute_only_ms"])) < 1e-3
+    o = j["other_modes"]
+    assert "error" not in o and "status" not in o, o
+    assert o["tree_sharded_chain_ms"] > 0 and o["tree_sharded_allreduce_untapered_ms"] > 0 and o["row_sharded_ms"] > 0
+    assert o["row_vs_tree_max_abs_diff_rel"] == 0.0        # one rank: every mode computes the same reference-order sums
