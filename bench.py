@@ -384,6 +384,7 @@ def main():
     # ---- N>1 (or --force-collectives): the OTHER ways this library can run the same multi-GPU job, measured behind the timed
     # region so that the driver's scaling run records them too (never `value`).  These collectives have run in one-rank
     # communicators and in the CPU model of tests/test_comm_mock.py only: a watchdog keeps a stuck leg from costing the line.
+    wd = None
     if comm is not None and classes == 1 and not sparse and not rows_mode and not args.no_other_modes:
         import threading
 
@@ -392,7 +393,7 @@ def main():
         def bail():
             try:
                 if rank == 0:
-                    other["status"] = f"abandoned after {args.other_modes_timeout:.0f} s (a leg did not return)"
+                    other["status"] = f"abandoned after {args.other_modes_timeout:.0f} s (an extra leg or the teardown behind it did not return)"
                     line["other_modes"] = other
                     os.dup2(saved_stdout, 1)
                     os.write(1, (json.dumps(line) + "\n").encode())
@@ -438,7 +439,6 @@ def main():
             eng2.close()
         except Exception as ex:  # never at the price of the headline line
             other["error"] = repr(ex)
-        wd.cancel()
         if rank == 0:
             line["other_modes"] = other
     if comm is not None:
@@ -446,6 +446,8 @@ def main():
     if multi:
         dist.destroy_process_group()
     eng.close()
+    if wd is not None:  # the watchdog also covers the teardown: a rank that failed a leg alone must not leave the others waiting
+        wd.cancel()
     import ctypes
     ctypes.CDLL(None).fflush(None)  # C stdio buffers of native libraries -> stderr, before stdout comes back
     sys.stdout.flush()
