@@ -39,6 +39,7 @@ struct Op {
   std::vector<uint64_t> deps;
   uint64_t record = 0;
   Coll* coll = nullptr;
+  double cost = 0.0;  // model time units (see "timeline" below)
 };
 }  // namespace
 
@@ -46,6 +47,7 @@ struct MockStream {
   int dev = 0, id = 0;
   std::deque<Op*> q;
   uint64_t enq = 0, done = 0;
+  double t = 0.0;  // timeline: when the stream's last executed operation ended
 };
 struct MockEvent {
   uint64_t serial = 0;  // last record enqueued on this event (0 = never recorded: a wait is a no-op, as in HIP)
@@ -91,6 +93,13 @@ struct Group {
 };
 
 std::set<uint64_t> g_done;
+std::map<uint64_t, double> g_done_at;  // timeline: when an event record completed
+// Timeline: besides executing the operations the model keeps an as-soon-as-possible clock -- an operation starts when its
+// stream is free and its event dependencies (for a collective: those of every rank) have completed, and lasts `cost` units:
+// scoring kernels g_cost_row per row, an all-reduce / all-gather g_cost_float per float of its result, grouped point-to-point
+// messages g_cost_float per float of the LONGEST message (one message per link at once), copies g_cost_copy per float.
+// mock_makespan() = the latest end over all streams: what the pipeline's overlap structure makes of those costs.
+double g_cost_row = 0.0, g_cost_float = 0.0, g_cost_copy = 0.0;
 uint64_t g_serial = 1, g_executed = 0;
 std::vector<MockStream*> g_streams;
 std::map<int, MockStream*> g_null;
@@ -188,10 +197,20 @@ void run_coll(Coll* c) {
   }
 }
 
+double deps_time(const Op* op) {
+  double t = 0.0;
+  for (uint64_t d : op->deps) t = std::max(t, g_done_at[d]);
+  return t;
+}
+
 void finish(MockStream* st, Op* op) {
   st->q.pop_front();
   ++st->done;
-  if (op->record) g_done.insert(op->record);
+  if (!op->coll) st->t = std::max(st->t, deps_time(op)) + op->cost;  // collectives: set for all ranks in step()
+  if (op->record) {
+    g_done.insert(op->record);
+    g_done_at[op->record] = st->t;
+  }
   delete op;
   ++g_executed;
 }
@@ -219,6 +238,16 @@ bool step() {
   if (op->coll) {
     Coll* c = op->coll;
     run_coll(c);
+    double start = 0.0, cost = 0.0;
+    for (CollArg& a : c->arg) {
+      start = std::max(start, std::max(a.st->t, deps_time(a.op)));
+      size_t floats = a.count * (a.type == 1 ? (size_t)c->g->n : 1u);
+      const int self = (int)(&a - c->arg.data());
+      for (const P2P& p : a.p2p)  // point-to-point messages to different peers travel on different links: the longest one counts
+        if (p.send && p.peer != self && p.count > floats) floats = p.count;
+      cost = std::max(cost, (double)floats * g_cost_float);
+    }
+    for (CollArg& a : c->arg) a.st->t = start + cost;
     c->g->pending.erase(c->seq);
     for (CollArg& a : c->arg) finish(a.st, a.op);
     delete c;
@@ -386,6 +415,7 @@ hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKin
 }
 hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t s) {
   Op* op = new Op();
+  op->cost = (double)(width / 4 * height) * g_cost_copy;
   op->run = [=] {
     for (size_t r = 0; r < height; ++r) memmove(reinterpret_cast<char*>(dst) + r * dpitch, reinterpret_cast<const char*>(src) + r * spitch, width);
   };
@@ -526,6 +556,18 @@ void mock_reset(int policy, uint64_t seed, int devices) {
   g_errors = 0;
   g_executed = 0;
 }
+void mock_costs(double per_row, double per_float_moved, double per_float_copied) {
+  std::lock_guard<std::mutex> lk(M);
+  g_cost_row = per_row, g_cost_float = per_float_moved, g_cost_copy = per_float_copied;
+  for (MockStream* st : g_streams) st->t = 0.0;
+  g_done_at.clear();
+}
+double mock_makespan(void) {
+  std::lock_guard<std::mutex> lk(M);
+  double t = 0.0;
+  for (MockStream* st : g_streams) t = std::max(t, st->t);
+  return t;
+}
 int mock_errors(void) { return g_errors; }
 uint64_t mock_executed(void) { return g_executed; }
 float mock_partial(uint32_t shard, uint32_t cls, uint32_t row) { return partial(shard, cls, row); }
@@ -546,6 +588,7 @@ int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_
   const uint32_t W = tuple_words(e->p);
   const uint32_t* t = reinterpret_cast<const uint32_t*>(d_tuples);
   Op* op = new Op();
+  op->cost = (double)n * g_cost_row;
   op->run = [=] {
     for (size_t i = 0; i < n; ++i) d_scores[i] = partial(m.shard, 0, t[i * W]);
   };
@@ -562,6 +605,7 @@ int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float*
   const uint32_t W = tuple_words(e->p);
   const uint32_t* t = reinterpret_cast<const uint32_t*>(d_tuples);
   Op* op = new Op();
+  op->cost = (double)n * g_cost_row * m.classes;
   op->run = [=] {
     for (uint32_t k = 0; k < m.classes; ++k)
       for (size_t i = 0; i < n; ++i) d_class_scores[(size_t)k * n + i] = partial(m.shard, k, t[i * W]);
@@ -579,6 +623,7 @@ int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float*
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s) {
   Op* op = new Op();
+  op->cost = (double)n * n_parts * g_cost_copy;
   op->run = [=] {
     for (size_t i = 0; i < n; ++i) {
       volatile float acc = parts[i];

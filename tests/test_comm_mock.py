@@ -54,6 +54,8 @@ def _build(name, comm_source):
     L.hipStreamCreateWithFlags.argtypes, L.hipStreamSynchronize.argtypes, L.hipStreamDestroy.argtypes = [C.POINTER(vp), C.c_uint], [vp], [vp]
     L.mock_reset.argtypes, L.mock_reset.restype = [i32, u64, i32], None
     L.mock_executed.restype = u64
+    L.mock_costs.argtypes, L.mock_costs.restype = [C.c_double, C.c_double, C.c_double], None
+    L.mock_makespan.restype = C.c_double
     return L
 
 
@@ -271,6 +273,63 @@ def test_single_process_group(mock, G, policy, seed):
     assert np.array_equal(cs.view(np.uint32), want.view(np.uint32)) and np.array_equal(lab, np.argmax(want, axis=0))
     mock.ddt_group_destroy(g)
     assert mock.mock_errors() == 0
+
+
+def _makespan(mock, G, n, chunk, call, taper, cost_row=1.0, cost_float=0.25):
+    """ASAP timeline of one call on every rank: scoring costs `cost_row` per row, a collective `cost_float` per float a rank
+    moves (mock_runtime.cpp "Timeline")."""
+    mock.mock_reset(0, 0, 8)
+    x = _tuples(n)
+    spans = []
+
+    def body(r, barrier, shared):
+        k = Rank(mock, r, G, barrier, shared, whole_model=(call == "rows"))
+        k.opt("chunk_rows", chunk)
+        k.opt("taper_tail", taper)
+        k.opt("taper_min_rows", 16)
+        barrier.wait()
+        if r == 0:
+            mock.mock_costs(cost_row, cost_float, 0.0)           # clocks start here
+        barrier.wait()
+        out = np.full(n, np.nan, np.float32)
+        if call == "rows":
+            assert mock.ddt_score_rowsharded_device(k.c, x.ctypes.data, n, out.ctypes.data, k.s) == 0
+        else:
+            assert mock.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, 1 if call == "chain" else 0, k.s) == 0
+        k.sync()
+        barrier.wait()
+        if r == 0:
+            spans.append(mock.mock_makespan())
+            mock.mock_costs(0.0, 0.0, 0.0)
+        k.close(barrier)
+
+    _run_ranks(G, body)
+    return spans[0]
+
+
+def test_only_the_last_collective_is_exposed():
+    """The overlap the pipeline is built for, read off the model's clock: with a chunk's collective cheaper than the next chunk's
+    scoring, a tree-sharded call takes the scoring of all rows plus ONE collective -- the last piece's, a quarter chunk with the
+    tapered tail -- and a row-sharded call the scoring of n / G rows plus the last step's messages."""
+    mock = _build("libddt_comm_mock.so", os.path.join(CSRC, "ddt_comm.cpp"))
+    G, n, chunk, cf = 8, 80_000, 10_000, 0.25
+    plain = _makespan(mock, G, n, chunk, "allreduce", 0)
+    assert plain == pytest.approx(n * 1.0 + chunk * cf)                       # 8 chunks scored back to back + the 8th all-reduce
+    L = ddt.lib()
+    k = L.ddt_comm_chunk_schedule(n, chunk, 1, 16, None, 0)
+    lens = np.zeros(k, np.uint64)
+    L.ddt_comm_chunk_schedule(n, chunk, 1, 16, lens.ctypes.data, k)
+    tapered = _makespan(mock, G, n, chunk, "allreduce", 1)
+    assert tapered == pytest.approx(n * 1.0 + int(lens[-1]) * cf) and int(lens[-1]) <= chunk // 4 + 1024
+    assert tapered < plain
+    chain = _makespan(mock, G, n, chunk, "chain", 1)                           # all-to-all + all-gather: two collectives per piece
+    assert n * 1.0 < chain <= n * 1.0 + 2 * int(lens[-1]) * cf + 1
+    rows = _makespan(mock, G, n, chunk, "rows", 0)
+    step = -(-chunk // G)
+    step = -(-step // 1024) * 1024 if step >= 1024 else step
+    last = (n // G) - ((n // G - 1) // step) * step                            # rows of the last step of a rank
+    assert rows == pytest.approx(n / G * 1.0 + last * cf)                       # one message per link at once
+    assert rows < tapered / 4                                                   # replicas: an eighth of the rows per rank
 
 
 REMOVED_WAITS = {
