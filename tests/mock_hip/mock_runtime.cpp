@@ -10,8 +10,9 @@
 // missing dependency in the pipeline gives a wrong result under some schedule.  A collective executes when all ranks'
 // copies are runnable (that is RCCL's rendezvous).  "Device memory" is host memory; kernels are host functions.
 //
-// Stand-in engine: a rank's partial score of tuple `row` (word 0 of the tuple line) for class k is the integer-valued
-// float f(shard, k, row) below -- sums over ranks are exact in any order, so every result is checked bit for bit.
+// This file is #included by the two translation units that complete a build: mock_engine.cpp (a stand-in engine with
+// integer-valued partial scores: the communicator tests) or mock_kernels.cpp (CPU stand-ins for the kernels that read the REAL
+// packed images, under the real csrc/ddt_engine.cpp: the engine tests).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -303,13 +304,6 @@ ncclResult_t enqueue_coll(MockComm* c, hipStream_t s, CollArg a) {
   return ncclSuccess;
 }
 
-// the stand-in engine's arithmetic
-inline float partial(uint32_t shard, uint32_t cls, uint32_t row) { return (float)((int)((row * 7u + shard * 13u + cls * 101u) % 1000u) - 500); }
-struct MockModel {
-  uint32_t shard = 0, count = 1, classes = 1;
-};
-std::map<ddt_engine*, MockModel> g_models;
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------ HIP
@@ -509,44 +503,6 @@ ncclResult_t ncclGroupEnd(void) {
   return enqueue_coll(t_group_comm, t_group_stream, a);
 }
 
-// ------------------------------------------------------------------------------------------- the stand-in engine (C-ABI)
-int ddt_create(ddt_engine** out, int device_id) {
-  if (!out || device_id < 0 || device_id >= g_devices) return DDT_EINVAL;
-  ddt_engine* e = new ddt_engine();
-  e->device = device_id;
-  *out = e;
-  return DDT_OK;
-}
-void ddt_destroy(ddt_engine* e) {
-  if (!e) return;
-  {
-    std::lock_guard<std::mutex> lk(M);
-    g_models.erase(e);
-  }
-  delete e;
-}
-static int mock_load(ddt_engine* e, const ddt_params* p, uint32_t classes, uint32_t shard, uint32_t count) {
-  if (!e || !p || count == 0 || shard >= count) return DDT_EINVAL;
-  e->p = *p;
-  e->num_classes = classes;
-  e->loaded = true;
-  std::lock_guard<std::mutex> lk(M);
-  g_models[e] = MockModel{shard, count, classes};
-  return DDT_OK;
-}
-int ddt_load_model_shard(ddt_engine* e, const ddt_params* p, const void*, size_t, const void*, size_t, uint32_t shard, uint32_t count) {
-  return mock_load(e, p, 1, shard, count);
-}
-int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const void*, size_t, const uint64_t*, uint32_t shard, uint32_t count) {
-  return mock_load(e, p, 1, shard, count);
-}
-int ddt_load_model_multiclass(ddt_engine* e, const ddt_params* p, const void*, size_t, const void*, size_t, uint32_t classes, int, uint32_t shard,
-                              uint32_t count) {
-  return mock_load(e, p, classes, shard, count);
-}
-const char* ddt_strerror(int) { return "mock"; }
-const char* ddt_last_error(const ddt_engine* e) { return e ? e->err : ""; }
-
 // ------------------------------------------------------------------------------------------------------ test control
 void mock_reset(int policy, uint64_t seed, int devices) {
   std::lock_guard<std::mutex> lk(M);
@@ -570,56 +526,11 @@ double mock_makespan(void) {
 }
 int mock_errors(void) { return g_errors; }
 uint64_t mock_executed(void) { return g_executed; }
-float mock_partial(uint32_t shard, uint32_t cls, uint32_t row) { return partial(shard, cls, row); }
 
 }  // extern "C"
 
-// ------------------------------------------------------------------------- what ddt_comm.cpp takes from the other units
+// ------------------------------------------------------------------- the two streaming kernels every build needs
 namespace ddt {
-
-uint32_t tuple_words(const ddt_params& p) { return (p.num_features + 3u) / 4u * 4u; }
-
-int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
-  MockModel m;
-  {
-    std::lock_guard<std::mutex> lk(M);
-    m = g_models[e];
-  }
-  const uint32_t W = tuple_words(e->p);
-  const uint32_t* t = reinterpret_cast<const uint32_t*>(d_tuples);
-  Op* op = new Op();
-  op->cost = (double)n * g_cost_row;
-  op->run = [=] {
-    for (size_t i = 0; i < n; ++i) d_scores[i] = partial(m.shard, 0, t[i * W]);
-  };
-  enqueue(s, op);
-  return DDT_OK;
-}
-
-int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s) {
-  MockModel m;
-  {
-    std::lock_guard<std::mutex> lk(M);
-    m = g_models[e];
-  }
-  const uint32_t W = tuple_words(e->p);
-  const uint32_t* t = reinterpret_cast<const uint32_t*>(d_tuples);
-  Op* op = new Op();
-  op->cost = (double)n * g_cost_row * m.classes;
-  op->run = [=] {
-    for (uint32_t k = 0; k < m.classes; ++k)
-      for (size_t i = 0; i < n; ++i) d_class_scores[(size_t)k * n + i] = partial(m.shard, k, t[i * W]);
-    if (d_labels)
-      for (size_t i = 0; i < n; ++i) {
-        uint32_t best = 0;
-        for (uint32_t k = 1; k < m.classes; ++k)
-          if (d_class_scores[(size_t)k * n + i] > d_class_scores[(size_t)best * n + i]) best = k;
-        d_labels[i] = (int32_t)best;
-      }
-  };
-  enqueue(s, op);
-  return DDT_OK;
-}
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s) {
   Op* op = new Op();

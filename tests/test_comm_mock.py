@@ -27,11 +27,12 @@ vp, sz, u32, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int
 
 def _build(name, comm_source):
     out = os.path.join(MOCK, name)
-    deps = [comm_source, os.path.join(MOCK, "mock_runtime.cpp"), os.path.join(MOCK, "hip", "hip_runtime.h"), os.path.join(MOCK, "rccl", "rccl.h"),
+    deps = [comm_source, os.path.join(MOCK, "mock_runtime.cpp"), os.path.join(MOCK, "mock_engine.cpp"), os.path.join(MOCK, "hip", "hip_runtime.h"),
+            os.path.join(MOCK, "rccl", "rccl.h"),
             os.path.join(CSRC, "ddt_engine_priv.h"), os.path.join(CSRC, "ddt_internal.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wall", "-I" + MOCK, "-I" + CSRC, comm_source,
-                               os.path.join(MOCK, "mock_runtime.cpp"), "-o", out])
+                               os.path.join(MOCK, "mock_engine.cpp"), "-o", out])
     L = C.CDLL(out)
     L.ddt_create.argtypes, L.ddt_destroy.argtypes, L.ddt_destroy.restype = [C.POINTER(vp), i32], [vp], None
     L.ddt_load_model_shard.argtypes = [vp, C.POINTER(ddt.Params), vp, sz, vp, sz, u32, u32]
