@@ -83,7 +83,12 @@ def lib():
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the pure C-ABI use
         pass
-    L = C.CDLL(LIB_PATH)
+    _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def bind(L):
+    """Set the prototypes of include/ddt.h on a loaded library (libddt.so; tests also bind their CPU-model build of the host side)."""
     vp, sz, u32, u64, i32, i64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int, C.c_int64
     PP = C.POINTER(Params)
     L.ddt_create.restype, L.ddt_create.argtypes = i32, [C.POINTER(vp), i32]
@@ -145,5 +150,4 @@ def lib():
     L.ddt_synth_model.restype, L.ddt_synth_model.argtypes = i32, [u32, u32, u32, i32, vp, vp]
     L.ddt_synth_tuples_host.restype, L.ddt_synth_tuples_host.argtypes = i32, [vp, u64, sz, u32, i32, u32]
     L.ddt_synth_tuples_device.restype, L.ddt_synth_tuples_device.argtypes = i32, [vp, vp, u64, sz, u32, i32, u32, vp]
-    _lib = L
     return L

@@ -25,9 +25,11 @@ struct uint4 {
 };
 struct hipDeviceProp_t {
   char name[256];
+  char gcnArchName[256];
   int multiProcessorCount, clockRate;
-  size_t sharedMemPerBlock;
+  size_t sharedMemPerBlock, maxSharedMemoryPerMultiProcessor;
 };
+enum { hipHostMallocDefault = 0 };
 
 extern "C" {
 const char* hipGetErrorString(hipError_t e);
@@ -44,6 +46,14 @@ hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int device);
+hipError_t hipGetLastError(void);
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
+hipError_t hipHostFree(void* p);
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t s);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
 hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind,

@@ -1,0 +1,223 @@
+// mock_kernels.cpp -- TEST INFRASTRUCTURE (tests/test_engine_mock.py): CPU stand-ins for the scoring kernels, so that the REAL
+// host side of libddt (csrc/ddt_engine.cpp, ddt_comm.cpp, ddt_codec.cpp, ddt_sparse_host.cpp) can be built against the
+// deferred-execution HIP / RCCL model of mock_runtime.cpp and run without a GPU: model load, image packing, variant choice,
+// the feeder's double buffering, the class launches on two streams, the rank-quantised path's workspace slots, the sharded
+// jobs -- all under adversarial stream schedules.
+//
+// A stand-in "launch" enqueues deferred operations that read what the real kernels read -- the packed image the engine
+// uploaded (csrc/ddt_internal.h layouts), the tuple lines, for the rank-quantised path the threshold tables and the rank
+// workspace (written by a separate "pre-pass" operation, exactly the producer / consumer pair whose ordering the engine is
+// responsible for) -- and reduce the leaves in the reference order (RefAcc of ddt_kernels.hip; Core.sv:291-316,486-541), so
+// results are checked against the oracle bit for bit.  These functions are NOT the product's compute path and are never
+// linked into libddt.so; the GPU parity tests are what holds the real kernels to the oracle.
+#include "mock_runtime.cpp"
+
+#include <algorithm>
+
+namespace ddt {
+
+namespace {
+
+// group g = i / 8 -> ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)); acc[g % C] <- s_g + acc[g % C]; total = acc[0] + 0, + acc[1], ...
+float reduce(const float* leaf, uint32_t n_trees, uint32_t C, uint32_t sum_mode) {
+  if (sum_mode == 1) {
+    double d = 0.0;
+    for (uint32_t i = 0; i < n_trees; ++i) d += (double)leaf[i];
+    return (float)d;
+  }
+  volatile float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t g = 0; g * 8u < n_trees; ++g) {
+    float l[8];
+    for (uint32_t u = 0; u < 8; ++u) l[u] = g * 8u + u < n_trees ? leaf[g * 8u + u] : 0.0f;
+    volatile float a0 = l[0] + l[1], a1 = l[2] + l[3], a2 = l[4] + l[5], a3 = l[6] + l[7];
+    volatile float h0 = a0 + a1, h1 = a2 + a3;
+    volatile float s = h0 + h1;
+    acc[g % C] = s + acc[g % C];
+  }
+  volatile float tot = 0.0f;
+  for (uint32_t k = 0; k < C; ++k) tot = acc[k] + tot;
+  return tot;
+}
+
+inline float f_of(uint32_t b) {
+  float f;
+  memcpy(&f, &b, 4);
+  return f;
+}
+
+// tile / stream / generic images: 8-byte records {key, word} in a 1-based heap, leaves behind them, or layout 1 (fused last level)
+hipError_t launch_records(const ScoreArgs& args, const Variant& var, hipStream_t s) {
+  const ScoreArgs a = args;
+  const Variant v = var;
+  if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
+  Op* op = new Op();
+  op->cost = (double)a.n * g_cost_row;
+  op->run = [=] {
+    const uint32_t D = a.levels, W = a.tuple_words, tw = (12u << D) / 4u;
+    const uint32_t* img = reinterpret_cast<const uint32_t*>(a.img);
+    const bool fused = v.kind == kKindTile && (v.opt & 1);
+    const uint32_t feat_off = v.kind == kKindTile ? v.feat_off() : v.kind == kKindStream ? v.feat_off_stream(a.n_trees) : 0u;
+    std::vector<float> leaf(a.n_trees);
+    for (uint64_t i = 0; i < a.n; ++i) {
+      const uint32_t* x = a.tuples + i * W;
+      for (uint32_t t = 0; t < a.n_trees; ++t) {
+        const uint32_t* tr = img + (size_t)t * tw;
+        uint32_t m = 1, lf = 0;
+        for (uint32_t lvl = 0; lvl < D; ++lvl) {
+          const bool last = fused && lvl == D - 1;
+          const uint32_t* rec = last ? tr + (4u << D) / 4u + 4u * (m - (1u << (D - 1))) : tr + 2u * m;
+          const uint32_t key = rec[0], word = rec[1], addr = word & 0x7FFFFFFFu;
+          const uint32_t j = v.kind == kKindGeneric ? addr : (addr - feat_off) / v.row_bytes();
+          const uint32_t raw = x[j], xk = a.ieee ? ieee_key(raw) : raw;
+          const uint32_t right = raw == a.miss_raw ? word >> 31 : (uint32_t)!((int32_t)xk < (int32_t)key);
+          if (last) lf = rec[2 + right];
+          m = 2u * m + right;
+        }
+        leaf[t] = f_of(fused ? lf : tr[(8u << D) / 4u + m - (1u << D)]);
+      }
+      a.out[i] = reduce(leaf.data(), a.n_trees, a.clusters, a.sum_mode);
+    }
+  };
+  enqueue(s, op);
+  return hipSuccess;
+}
+
+// rank-quantised path: a PRE-PASS operation writes the feature ranks and the per-tile missing flags into the engine's
+// workspace, a SCORING operation reads them (and the fast or the slow image per tile) -- two operations, like the kernels
+hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) {
+  const ScoreArgs a = args;
+  const Variant v = var;
+  const Q16Aux x = *reinterpret_cast<const Q16Aux*>(args.aux);
+  const uint32_t W = a.tuple_words;
+  if (!x.skip_prepass) {
+    Op* pre = new Op();
+    pre->cost = (double)a.n * g_cost_row * 0.05;
+    pre->run = [=] {
+      const uint64_t tiles = (a.n + 1023) / 1024;
+      for (uint64_t t = 0; t < tiles; ++t) x.tile_flags[t] = 0u;
+      for (uint64_t i = 0; i < a.n; ++i)
+        for (uint32_t j = 0; j < W; ++j) {
+          const uint32_t raw = a.tuples[i * W + j];
+          uint16_t r;
+          if (raw == a.miss_raw) {
+            r = 0xFFFFu;
+            x.tile_flags[i / 1024] = 1u;
+          } else {
+            const int32_t key = (int32_t)(a.ieee ? ieee_key(raw) : raw);
+            const int32_t* tab = reinterpret_cast<const int32_t*>(x.tables) + (size_t)j * x.Kpad;
+            r = (uint16_t)(std::upper_bound(tab, tab + x.tabP[j * 8u], key) - tab);  // keys <= x among the K real ones
+          }
+          x.q[i * W + j] = r;
+        }
+    };
+    enqueue(s, pre);
+  }
+  if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
+  Op* op = new Op();
+  op->cost = (double)a.n * g_cost_row;
+  op->run = [=] {
+    const uint32_t D = a.levels, half = 1u << D, tw = 2u * half, CT = (uint32_t)v.chunk_trees, row = v.tile() * 2u;
+    const bool gl = (v.opt & 1) != 0;
+    std::vector<float> leaf(a.n_trees);
+    for (uint64_t i = 0; i < a.n; ++i) {
+      const bool slow = x.tile_flags[i / 1024] != 0u;
+      const uint32_t* img = reinterpret_cast<const uint32_t*>(slow ? x.img_slow : a.img);
+      const uint16_t* rk = x.q + i * W;
+      for (uint32_t t = 0; t < a.n_trees; ++t) {
+        const size_t rec_off = gl ? (size_t)(t / CT) * CT * tw + (size_t)(t % CT) * half : (size_t)t * tw;
+        const size_t leaf_off = gl ? (size_t)(t / CT) * CT * tw + (size_t)CT * half + (size_t)(t % CT) * half : (size_t)t * tw + half;
+        uint32_t m = 1;
+        for (uint32_t lvl = 0; lvl < D; ++lvl) {
+          const uint32_t nd = img[rec_off + m];
+          const uint32_t off = slow ? ((nd >> 16) & 0xFFFEu) : (nd >> 16);
+          const uint32_t f = rk[off / row];
+          bool right = f >= (nd & 0xFFFFu);
+          if (slow && f == 0xFFFFu) right = ((nd >> 16) & 1u) != 0u;
+          m = 2u * m + (right ? 1u : 0u);
+        }
+        leaf[t] = f_of(img[leaf_off + m - half]);
+      }
+      a.out[i] = reduce(leaf.data(), a.n_trees, a.clusters, a.sum_mode);
+    }
+  };
+  enqueue(s, op);
+  return hipSuccess;
+}
+
+// sparse (explicit-children) forests: per PU group of 8 trees the top image (first K levels as a perfect heap, level K-1 as
+// 16-byte records), then the deep records -- csrc/ddt_internal.h "Sparse forests", csrc/ddt_sparse.hip
+hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t s) {
+  const ScoreArgs a = args;
+  const Variant v = var;
+  const SparseAux x = *reinterpret_cast<const SparseAux*>(args.aux);
+  Op* op = new Op();
+  op->cost = (double)a.n * g_cost_row;
+  op->run = [=] {
+    const uint32_t K = a.levels, W = a.tuple_words, tw = (12u << K) / 4u, feat_off = v.feat_off_sparse(), row = v.row_bytes();
+    const uint32_t* top = reinterpret_cast<const uint32_t*>(a.img);
+    const uint32_t* deep = reinterpret_cast<const uint32_t*>(x.deep);
+    std::vector<float> leaf(a.n_trees);
+    for (uint64_t i = 0; i < a.n; ++i) {
+      const uint32_t* t = a.tuples + i * W;
+      auto right = [&](uint32_t key, uint32_t w) -> uint32_t {
+        const uint32_t raw = t[((w & kSpAddrMask) - feat_off) / row], xk = a.ieee ? ieee_key(raw) : raw;
+        return raw == a.miss_raw ? (uint32_t)((w & kSpMissRight) != 0u) : (uint32_t)!((int32_t)xk < (int32_t)key);
+      };
+      for (uint32_t slot = 0; slot < a.n_trees; ++slot) {
+        const uint32_t* tr = top + (size_t)slot * tw;
+        uint32_t m = 1;
+        for (uint32_t lvl = 0; lvl + 1 < K; ++lvl) m = 2u * m + right(tr[2u * m], tr[2u * m + 1u]);
+        const uint32_t* rec = tr + (4u << K) / 4u + 4u * (m - (1u << (K - 1)));
+        for (int guard = 0; guard < 100; ++guard) {
+          const uint32_t r = right(rec[0], rec[1]), nxt = rec[2 + r];
+          if (rec[1] & (r ? kSpRightLeaf : kSpLeftLeaf)) {
+            leaf[slot] = f_of(nxt);
+            break;
+          }
+          rec = deep + (size_t)nxt * 4u;
+        }
+      }
+      a.out[i] = reduce(leaf.data(), a.n_trees, a.clusters, a.sum_mode);
+    }
+  };
+  enqueue(s, op);
+  return hipSuccess;
+}
+
+// a few of the real table's entries (same names and geometry: csrc/ddt_kernels.hip g_variants); the engine's preference
+// lists fall through to what exists
+const Variant g_mock_variants[] = {
+    Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_records},
+    Variant{"q16_d8_c8_u4_gl", kKindQ16, 8, 1024, 1, 8, 4, 1, 1, &launch_q16},
+    Variant{"q16_d8_c4_u4", kKindQ16, 8, 1024, 1, 4, 4, 1, 0, &launch_q16},
+    Variant{"q16_d6_c16_u4", kKindQ16, 6, 1024, 1, 16, 4, 1, 0, &launch_q16},
+    Variant{"d8_t1024_r1_c4_u4_dma_f", kKindTile, 8, 1024, 1, 4, 4, 1, 1, &launch_records},
+    Variant{"d6_t1024_r1_c16_u4_dma", kKindTile, 6, 1024, 1, 16, 4, 1, 0, &launch_records},
+    Variant{"d4_t256_r1_c64_u8_dma", kKindTile, 4, 256, 1, 64, 8, 1, 0, &launch_records},
+};
+
+}  // namespace
+
+namespace {
+const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
+    Variant{"sparse_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 0, &launch_sparse},
+    Variant{"sparse_k8_u8_t512", kKindSparse, 8, 512, 1, 8, 8, 1, 0, &launch_sparse},
+    Variant{"sparse_k9_u8_t128", kKindSparse, 9, 128, 1, 8, 8, 1, 0, &launch_sparse},
+};
+constexpr int kMockDense = (int)(sizeof(g_mock_variants) / sizeof(g_mock_variants[0]));
+}  // namespace
+int num_sparse_variants() { return (int)(sizeof(g_mock_sparse) / sizeof(g_mock_sparse[0])); }
+const Variant& sparse_variant(int i) { return g_mock_sparse[i]; }
+int num_variants() { return kMockDense + num_sparse_variants(); }
+const Variant& variant(int i) { return i < kMockDense ? g_mock_variants[i] : sparse_variant(i - kMockDense); }
+
+uint32_t generic_lds_bytes(uint32_t, uint32_t, bool* feat_in_lds, bool* tree_in_lds, uint32_t* top_levels) {
+  if (feat_in_lds) *feat_in_lds = false;
+  if (tree_in_lds) *tree_in_lds = false;
+  if (top_levels) *top_levels = 0;
+  return 64u * 1024u;
+}
+uint32_t stream_blocks_per_cu(uint32_t) { return 1; }
+hipError_t launch_synth_tuples(uint32_t*, uint64_t, size_t, uint32_t, int, uint32_t, hipStream_t) { return hipErrorInvalidValue; }
+
+}  // namespace ddt

@@ -395,6 +395,43 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
   enqueue(s, op);
   return hipSuccess;
 }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int device) {
+  if (device < 0 || device >= g_devices) return hipErrorInvalidDevice;
+  memset(p, 0, sizeof(*p));
+  snprintf(p->name, sizeof(p->name), "mock device %d", device);
+  snprintf(p->gcnArchName, sizeof(p->gcnArchName), "gfx950:mock");
+  p->multiProcessorCount = 256;
+  p->clockRate = 2400000;
+  p->sharedMemPerBlock = p->maxSharedMemoryPerMultiProcessor = 160 * 1024;
+  return hipSuccess;
+}
+hipError_t hipGetLastError(void) { return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+  *p = malloc(bytes ? bytes : 1);
+  if (*p) memset(*p, 0x5A, bytes);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void* p) {
+  free(p);
+  return hipSuccess;
+}
+hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0); }
+hipError_t hipEventSynchronize(hipEvent_t e) {
+  std::unique_lock<std::mutex> lk(M);
+  const uint64_t target = e->serial;
+  if (!target) return hipSuccess;
+  return drive(lk, [&] { return g_done.count(target) != 0; });
+}
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  std::lock_guard<std::mutex> lk(M);
+  *ms = (float)(g_done_at[b->serial] - g_done_at[a->serial]);  // model time units
+  return hipSuccess;
+}
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) {
+  (void)hipDeviceSynchronize();  // the blocking copy is ordered behind everything the device has been given
+  memmove(dst, src, bytes);
+  return hipSuccess;
+}
 hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t s) {
   Op* op = new Op();
   op->run = [=] { memset(p, value, bytes); };

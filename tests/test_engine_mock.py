@@ -1,0 +1,297 @@
+"""The REAL host side of libddt -- csrc/ddt_engine.cpp, ddt_comm.cpp, ddt_codec.cpp, ddt_sparse_host.cpp, compiled unchanged --
+run without a GPU against the deferred-execution HIP / RCCL model of tests/mock_hip/ (see test_comm_mock.py) and CPU
+stand-ins for the kernels (mock_kernels.cpp) that read what the real kernels read: the packed images the engine uploads, the
+tuple lines, the threshold tables and the rank workspace of the rank-quantised path.  Results are held to the oracle bit for
+bit, under five stream schedules each.
+
+What this exercises that CPU tests could not reach before: ddt_load_model -> variant choice -> image upload -> launch
+arguments; the feeder of ddt_score / ddt_classify (two pinned buffers, two streams, two rank-workspace slots); the class
+launches alternating between two streams around a shared pre-pass; back-to-back asynchronous calls; and the tree-sharded
+multi-GPU jobs with the real engine on every rank against the oracle's multi-device model.  Two tests remove a dependency
+from the engine source and require some schedule to notice.  (The real kernels are held to the oracle by the GPU tests.)"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import ddt
+from ddt import _lib
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MOCK = os.path.join(HERE, "mock_hip")
+CSRC = os.path.join(os.path.dirname(HERE), "distributed-decisiontrees_amd", "csrc")
+vp = C.c_void_p
+SOURCES = ["ddt_engine.cpp", "ddt_comm.cpp", "ddt_codec.cpp", "ddt_sparse_host.cpp"]
+SCHEDULES = [(0, 0), (1, 0), (2, 21), (2, 22), (2, 23)]
+
+
+def _build(name, engine_source=None):
+    out = os.path.join(MOCK, name)
+    srcs = [engine_source or os.path.join(CSRC, "ddt_engine.cpp")] + [os.path.join(CSRC, f) for f in SOURCES[1:]] + [os.path.join(MOCK, "mock_kernels.cpp")]
+    deps = srcs + [os.path.join(MOCK, "mock_runtime.cpp"), os.path.join(MOCK, "hip", "hip_runtime.h"), os.path.join(MOCK, "rccl", "rccl.h"),
+                   os.path.join(CSRC, "ddt_engine_priv.h"), os.path.join(CSRC, "ddt_internal.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-w", "-I" + MOCK, "-I" + CSRC, *srcs, "-o", out])
+    L = _lib.bind(C.CDLL(out))
+    L.hipSetDevice.argtypes = [C.c_int]
+    L.hipStreamCreateWithFlags.argtypes, L.hipStreamSynchronize.argtypes, L.hipStreamDestroy.argtypes = [C.POINTER(vp), C.c_uint], [vp], [vp]
+    L.mock_reset.argtypes, L.mock_reset.restype = [C.c_int, C.c_uint64, C.c_int], None
+    return L
+
+
+@pytest.fixture(scope="module")
+def mock():
+    return _build("libddt_host_mock.so")
+
+
+def _variant(L, name):
+    for i in range(L.ddt_num_variants()):
+        b = C.create_string_buffer(64)
+        L.ddt_variant_name(i, b, 64)
+        if b.value.decode() == name:
+            return i
+    raise KeyError(name)
+
+
+def _engine(L, dev=0):
+    e = vp()
+    assert L.ddt_create(C.byref(e), dev) == 0
+    return e
+
+
+def _stream(L):
+    s = vp()
+    assert L.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+    return s
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _load(L, e, m, params, variant=None, shard=(0, 1)):
+    assert L.ddt_set_option(e, b"variant", -1 if variant is None else _variant(L, variant)) == 0
+    rc = L.ddt_load_model_shard(e, C.byref(params), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8, *shard)
+    assert rc == 0, L.ddt_last_error(e)
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+@pytest.mark.parametrize("T,D,F,variant,dist", [(37, 8, 32, "q16_d8_c8_u4_gl", 1), (300, 8, 32, None, 0), (21, 8, 20, "q16_d8_c4_u4", 1),
+                                                (100, 6, 28, None, 1), (9, 8, 32, "d8_t1024_r1_c4_u4_dma_f", 1), (12, 11, 40, None, 1),
+                                                (64, 4, 16, "d4_t256_r1_c64_u8_dma", 1)])
+def test_load_choose_upload_launch(mock, T, D, F, variant, dist, policy, seed):
+    """ddt_load_model -> variant -> image -> launch arguments -> scores == oracle, resident tuples, three calls in flight."""
+    mock.mock_reset(policy, seed, 8)
+    m, x = O.gen_model(T, D, F, dist), O.gen_tuples(0, 1500, F, dist)
+    want = O.score(m, x)
+    e, s = _engine(mock), _stream(mock)
+    _load(mock, e, m, ddt.make_params(T, D, F), variant)
+    outs = [np.full(1500, np.nan, np.float32) for _ in range(3)]
+    for o in outs:
+        assert mock.ddt_score_device(e, x.ctypes.data, 1500, o.ctypes.data, s) == 0
+    assert mock.hipStreamSynchronize(s) == 0
+    for o in outs:
+        assert np.array_equal(_bits(o), _bits(want))
+    info = ddt.Info()
+    assert mock.ddt_get_info(e, C.byref(info)) == 0
+    if variant:
+        assert info.variant_name.decode() == variant
+    elif T * D >= 640 and D in (6, 8) and F <= 32:
+        assert info.variant_name.decode().startswith("q16_")           # the engine's own choice above the break-even
+    mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES)
+@pytest.mark.parametrize("variant,feeder_rows", [("q16_d8_c8_u4_gl", 1024), ("q16_d8_c8_u4_gl", 700), ("d8_t1024_r1_c4_u4_dma_f", 333)])
+def test_feeder_double_buffering(mock, variant, feeder_rows, policy, seed):
+    """ddt_score from host memory: two pinned buffers, two streams, (rank-quantised:) two workspace slots, many chunks."""
+    mock.mock_reset(policy, seed, 8)
+    T, D, F, n = 40, 8, 32, 6001
+    m, x = O.gen_model(T, D, F, 1), O.gen_tuples(0, n, F, 1)
+    want = O.score(m, x)
+    e = _engine(mock)
+    _load(mock, e, m, ddt.make_params(T, D, F), variant)
+    assert mock.ddt_set_option(e, b"feeder_rows", feeder_rows) == 0
+    for _ in range(2):
+        out = np.full(n, np.nan, np.float32)
+        assert mock.ddt_score(e, x.ctypes.data, n, out.ctypes.data) == 0, mock.ddt_last_error(e)
+        assert np.array_equal(_bits(out), _bits(want))
+    st = ddt.Stats()
+    assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.tuples_in == 2 * n and st.tuples_out == 2 * n
+    mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES)
+@pytest.mark.parametrize("T,D,F,K,variant", [(100, 8, 32, 10, "q16_d8_c8_u4_gl"), (60, 6, 16, 3, None), (35, 8, 32, 5, "d8_t1024_r1_c4_u4_dma_f")])
+def test_class_launches_on_two_streams(mock, T, D, F, K, variant, policy, seed):
+    """One-vs-all classes: class 0 (+ the shared rank pre-pass) on the caller's stream, odd classes on the engine's own stream."""
+    mock.mock_reset(policy, seed, 8)
+    n = 2100
+    m, x = O.gen_model(T, D, F, 1), O.gen_tuples(0, n, F, 1)
+    p = ddt.make_params(T, D, F, clusters=1)
+    labels, cs = O.classify(m, x, K)
+    e, s = _engine(mock), _stream(mock)
+    assert mock.ddt_set_option(e, b"variant", -1 if variant is None else _variant(mock, variant)) == 0
+    assert mock.ddt_load_model_multiclass(e, C.byref(p), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8, K, 1, 0, 1) == 0
+    res = []
+    for _ in range(3):                                                   # back to back: the shared workspace must not be overwritten early
+        gs, gl = np.full((K, n), np.nan, np.float32), np.full(n, -1, np.int32)
+        assert mock.ddt_classify_device(e, x.ctypes.data, n, gs.ctypes.data, gl.ctypes.data, s) == 0
+        res.append((gs, gl))
+    assert mock.hipStreamSynchronize(s) == 0
+    for gs, gl in res:
+        assert np.array_equal(_bits(gs), _bits(cs)) and np.array_equal(gl, labels)
+    assert mock.ddt_set_option(e, b"feeder_rows", 512) == 0               # and through the feeder: both feeder streams share the class stream
+    hl, hs = np.full(n, -1, np.int32), np.full((K, n), np.nan, np.float32)
+    assert mock.ddt_classify(e, x.ctypes.data, n, hl.ctypes.data, hs.ctypes.data) == 0
+    assert np.array_equal(hl, labels) and np.array_equal(_bits(hs), _bits(cs))
+    mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+@pytest.mark.parametrize("G,T,C_", [(2, 64, 1), (4, 300, 2), (8, 1000, 8), (4, 9, 1)])
+def test_tree_sharded_job_with_the_real_engine_equals_the_oracles_multi_device_model(mock, G, T, C_, policy, seed):
+    """Rank g loads shard g (ddt_load_model_shard), the partial scores are combined by the C++ pipeline: the chain combine adds
+    p0 + p1 + ... in the reference's hop order, and so does this model's all-reduce -- both must equal orc_score(n_devices = G)."""
+    mock.mock_reset(policy, seed, 8)
+    D, F, n = 8, 32, 1300
+    m, x = O.gen_model(T, D, F, 1, clusters=C_), O.gen_tuples(0, n, F, 1)
+    want = O.score(m, x, n_devices=G)
+    p = ddt.make_params(T, D, F, clusters=C_)
+    barrier, shared, errors = threading.Barrier(G), {}, []
+
+    def body(r):
+        try:
+            assert mock.hipSetDevice(r) == 0
+            e, s = _engine(mock, r), _stream(mock)
+            _load(mock, e, m, p, None, (r, G))
+            if r == 0:
+                shared["id"] = C.create_string_buffer(128)
+                assert mock.ddt_comm_get_unique_id(shared["id"]) == 0
+            barrier.wait()
+            c = vp()
+            assert mock.ddt_comm_create(C.byref(c), e, r, G, shared["id"]) == 0
+            assert mock.ddt_comm_set_option(c, b"chunk_rows", 500) == 0 and mock.ddt_comm_set_option(c, b"taper_min_rows", 32) == 0
+            outs = []
+            for combine in (1, 0, 1):
+                o = np.full(n, np.nan, np.float32)
+                assert mock.ddt_score_sharded_device(c, x.ctypes.data, n, o.ctypes.data, combine, s) == 0, mock.ddt_comm_last_error(c)
+                outs.append(o)
+            assert mock.hipStreamSynchronize(s) == 0
+            for o in outs:
+                assert np.array_equal(_bits(o), _bits(want)), r
+            barrier.wait()
+            mock.ddt_comm_destroy(c)
+            mock.ddt_destroy(e)
+        except BaseException as ex:  # noqa: BLE001
+            errors.append((r, repr(ex)))
+            barrier.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(180) for t in th]
+    assert not errors, errors
+    assert mock.mock_errors() == 0
+
+
+def test_single_process_group_with_the_real_engine(mock):
+    mock.mock_reset(2, 5, 8)
+    T, D, F, n, G = 200, 8, 32, 2500, 4
+    m, x = O.gen_model(T, D, F, 0), O.gen_tuples(0, n, F, 0)
+    p = ddt.make_params(T, D, F)
+    g = vp()
+    assert mock.ddt_group_create(C.byref(g), G, None) == 0
+    assert mock.ddt_group_load_model(g, C.byref(p), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8) == 0
+    out = np.full(n, np.nan, np.float32)
+    assert mock.ddt_group_score(g, x.ctypes.data, n, out.ctypes.data, 1) == 0, mock.ddt_group_last_error(g)
+    assert np.array_equal(_bits(out), _bits(O.score(m, x, n_devices=G)))
+    mock.ddt_group_destroy(g)
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+@pytest.mark.parametrize("T,depth,F,full,pm,G", [(24, 13, 20, 4, 650, 1), (40, 16, 64, 3, 700, 1), (19, 9, 12, 2, 500, 4), (9, 3, 5, 1, 400, 2)])
+def test_sparse_forests(mock, T, depth, F, full, pm, G, policy, seed):
+    """ddt_load_model_sparse: validation, re-basing, top / deep image packing, kernel geometry choice -> launch -> the oracle's walk
+    of the explicit-children stream; with G > 1 every virtual rank loads its shard and the partial scores are chain-added."""
+    mock.mock_reset(policy, seed, 8)
+    sp = O.gen_sparse_model(T, depth, F, full, pm, 1)
+    n = 900
+    x = O.gen_tuples(0, n, F, 1)
+    want = O.score_sparse(sp, x, n_devices=G)
+    p = ddt.make_sparse_params(T, depth, F)
+    mock.ddt_load_model_sparse.argtypes = [vp, C.POINTER(ddt.Params), vp, C.c_size_t, vp, C.c_uint32, C.c_uint32]
+    s = _stream(mock)
+    parts = []
+    for g in range(G):
+        e = _engine(mock)
+        lines = np.ascontiguousarray(sp.node_lines, np.uint32)
+        first = np.ascontiguousarray(sp.first, np.uint64)
+        assert mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, g, G) == 0, mock.ddt_last_error(e)
+        o = np.full(n, np.nan, np.float32)
+        assert mock.ddt_score_device(e, x.ctypes.data, n, o.ctypes.data, s) == 0
+        assert mock.hipStreamSynchronize(s) == 0
+        h = np.full(n, np.nan, np.float32)
+        assert mock.ddt_set_option(e, b"feeder_rows", 256) == 0 and mock.ddt_score(e, x.ctypes.data, n, h.ctypes.data) == 0   # and through the feeder
+        assert np.array_equal(_bits(h), _bits(o))
+        parts.append(o)
+        mock.ddt_destroy(e)
+    acc = parts[0]
+    for q in parts[1:]:
+        acc = O.fpadd_bits_batch(_bits(acc), _bits(q)).view(np.float32)                # host -> dev1 -> ... (ResultsCombiner.sv:292-311)
+    assert np.array_equal(_bits(acc), _bits(want))
+
+
+REMOVED = {
+    # the odd classes no longer wait for class 0's launch (and the rank pre-pass in front of it) on the caller's stream
+    "class_stream_start": ("      HIP_TRY(e, hipEventRecord(e->class_ev[0], s));\n      HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));\n    }\n  }\n  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));",
+                           "      HIP_TRY(e, hipEventRecord(e->class_ev[0], s));\n    }\n  }\n  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));"),
+    # the caller's stream no longer waits for the classes that ran on the engine's stream
+    "class_stream_end": ("  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));\n    HIP_TRY(e, hipStreamWaitEvent(s, e->class_ev[1], 0));\n",
+                         "  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));\n"),
+    # the feeder refills a pinned buffer without waiting for the chunk that still uses it
+    "feeder_drain": ("    if (pending_n[b] && (rc = drain(b))) return rc;\n    parallel_copy(", "    parallel_copy("),
+}
+
+
+@pytest.mark.parametrize("which", sorted(REMOVED))
+def test_the_model_catches_a_missing_dependency_in_the_engine(which):
+    needle, repl = REMOVED[which]
+    src = open(os.path.join(CSRC, "ddt_engine.cpp")).read()
+    assert src.count(needle) == 1, which
+    broken, so = os.path.join(MOCK, f"_broken_engine_{which}.cpp"), f"libddt_host_mock_broken_{which}.so"
+    open(broken, "w").write(src.replace(needle, repl))
+    try:
+        bad = _build(so, broken)
+        T, D, F, K, n = 60, 8, 32, 6, 3000
+        m, x = O.gen_model(T, D, F, 1), O.gen_tuples(0, n, F, 1)
+        p = ddt.make_params(T, D, F, clusters=1)
+        labels, cs = O.classify(m, x, K)
+        wrong = 0
+        for policy, seed in SCHEDULES:
+            bad.mock_reset(policy, seed, 8)
+            e, s = _engine(bad), _stream(bad)
+            assert bad.ddt_set_option(e, b"variant", _variant(bad, "q16_d8_c8_u4_gl")) == 0
+            assert bad.ddt_load_model_multiclass(e, C.byref(p), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8, K, 1, 0, 1) == 0
+            ok = True
+            if which == "feeder_drain":
+                assert bad.ddt_set_option(e, b"feeder_rows", 256) == 0
+                hl, hs = np.full(n, -1, np.int32), np.full((K, n), np.nan, np.float32)
+                assert bad.ddt_classify(e, x.ctypes.data, n, hl.ctypes.data, hs.ctypes.data) == 0
+                ok = np.array_equal(hl, labels) and np.array_equal(_bits(hs), _bits(cs))
+            else:
+                for _ in range(2):
+                    gs, gl = np.full((K, n), np.nan, np.float32), np.full(n, -1, np.int32)
+                    assert bad.ddt_classify_device(e, x.ctypes.data, n, gs.ctypes.data, gl.ctypes.data, s) == 0
+                    assert bad.hipStreamSynchronize(s) == 0
+                    ok = ok and np.array_equal(_bits(gs), _bits(cs)) and np.array_equal(gl, labels)
+            wrong += not ok
+            bad.ddt_destroy(e)
+        assert wrong > 0, f"no schedule noticed the missing dependency ({which})"
+    finally:
+        for f in (broken, os.path.join(MOCK, so)):
+            if os.path.exists(f):
+                os.remove(f)
