@@ -198,6 +198,48 @@ def test_tree_sharded_job_with_the_real_engine_equals_the_oracles_multi_device_m
     assert mock.mock_errors() == 0
 
 
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+def test_row_sharded_job_with_the_real_engine(mock, policy, seed):
+    """Replicas only: every rank holds the whole ensemble and scores its rows; every rank ends up with the reference-order scores."""
+    mock.mock_reset(policy, seed, 8)
+    G, T, D, F, n = 4, 120, 8, 32, 2307
+    m, x = O.gen_model(T, D, F, 1), O.gen_tuples(0, n, F, 1)
+    want = O.score(m, x)
+    p = ddt.make_params(T, D, F)
+    barrier, shared, errors = threading.Barrier(G), {}, []
+
+    def body(r):
+        try:
+            assert mock.hipSetDevice(r) == 0
+            e, s = _engine(mock, r), _stream(mock)
+            _load(mock, e, m, p)
+            if r == 0:
+                shared["id"] = C.create_string_buffer(128)
+                assert mock.ddt_comm_get_unique_id(shared["id"]) == 0
+            barrier.wait()
+            c = vp()
+            assert mock.ddt_comm_create(C.byref(c), e, r, G, shared["id"]) == 0
+            assert mock.ddt_comm_set_option(c, b"chunk_rows", 400) == 0
+            outs = [np.full(n, np.nan, np.float32) for _ in range(2)]
+            for o in outs:
+                assert mock.ddt_score_rowsharded_device(c, x.ctypes.data, n, o.ctypes.data, s) == 0
+            assert mock.hipStreamSynchronize(s) == 0
+            for o in outs:
+                assert np.array_equal(_bits(o), _bits(want)), r
+            barrier.wait()
+            mock.ddt_comm_destroy(c)
+            mock.ddt_destroy(e)
+        except BaseException as ex:  # noqa: BLE001
+            errors.append((r, repr(ex)))
+            barrier.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(180) for t in th]
+    assert not errors, errors
+    assert mock.mock_errors() == 0
+
+
 def test_single_process_group_with_the_real_engine(mock):
     mock.mock_reset(2, 5, 8)
     T, D, F, n, G = 200, 8, 32, 2500, 4
@@ -243,6 +285,35 @@ def test_sparse_forests(mock, T, depth, F, full, pm, G, policy, seed):
     for q in parts[1:]:
         acc = O.fpadd_bits_batch(_bits(acc), _bits(q)).view(np.float32)                # host -> dev1 -> ... (ResultsCombiner.sv:292-311)
     assert np.array_equal(_bits(acc), _bits(want))
+
+
+def test_the_cli_host_program_on_the_model(mock, tmp_path):
+    """csrc/ddt_cli.cpp linked against the model build: gen -> score (one engine through the feeder; --shard i --of n; the
+    single-process multi-GPU job --devices 4) -> whole result lines equal to the oracle / its multi-device model."""
+    cli = os.path.join(MOCK, "ddt_cli_mock")
+    so = os.path.join(MOCK, "libddt_host_mock.so")
+    src = os.path.join(CSRC, "ddt_cli.cpp")
+    if not os.path.exists(cli) or os.path.getmtime(cli) < max(os.path.getmtime(src), os.path.getmtime(so)):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", src, "-o", cli, so, "-Wl,-rpath," + MOCK, "-pthread"])
+    pre = str(tmp_path / "job")
+    T, D, F, n = 96, 6, 28, 1203
+    subprocess.check_call([cli, "gen", "--trees", str(T), "--levels", str(D), "--features", str(F), "--rows", str(n), "--dist", "1",
+                           "--devices", "4", "--prefix", pre])
+    m, x = O.gen_model(T, D, F, dist=1, clusters=1), O.gen_tuples(0, n, F, dist=1)
+    base = [cli, "score", "--csr", pre + ".csr", "--weights", pre + ".weights", "--findex", pre + ".findex", "--tuples", pre + ".tuples", "--out", pre + ".res"]
+    out = subprocess.check_output(base + ["--devices", "4", "--combine", "chain"]).decode()
+    assert f"scored {n} tuples on 4 device(s)" in out
+    res = np.fromfile(pre + ".res", np.float32)
+    assert res.size == (n + 3) // 4 * 4 and not res[n:].any()
+    assert np.array_equal(_bits(res[:n]), _bits(O.score(m, x, n_devices=4)))
+    parts = []
+    for g in range(4):                                           # the same job as four single-engine runs, combined by the oracle's hop adder
+        subprocess.check_output(base + ["--shard", str(g), "--of", "4"])
+        parts.append(np.fromfile(pre + ".res", np.float32)[:n])
+    acc = parts[0]
+    for q in parts[1:]:
+        acc = O.fpadd_bits_batch(_bits(acc), _bits(q)).view(np.float32)
+    assert np.array_equal(_bits(acc), _bits(O.score(m, x, n_devices=4)))
 
 
 REMOVED = {
