@@ -316,6 +316,76 @@ def test_the_cli_host_program_on_the_model(mock, tmp_path):
     assert np.array_equal(_bits(acc), _bits(O.score(m, x, n_devices=4)))
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_models_options_and_call_sequences(mock, seed):
+    """A trimmed copy of the exploratory fuzz loop (720 scenarios run once, no failure): random models (depth, width, classes,
+    compare and summation mode, clusters, shard), random variant and option settings, reloads on the same engine, resident and
+    host calls of awkward sizes -- every result equal to the oracle."""
+    rng = np.random.default_rng(seed)
+    nvar = mock.ddt_num_variants()
+    for _ in range(14):
+        mock.mock_reset(int(rng.integers(0, 3)), int(rng.integers(0, 1000)), 8)
+        e, s = _engine(mock), _stream(mock)
+        for _round in range(int(rng.integers(1, 4))):
+            D, T, F = int(rng.choice([4, 6, 8, 8, 8, 11, 3])), int(rng.integers(1, 120)), int(rng.choice([5, 16, 28, 32, 32, 40, 64]))
+            cmp_mode, sum_mode, Cc = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.choice([1, 2, 4, 8]))
+            K = min(int(rng.choice([1, 1, 1, 2, 3, 7])), T)
+            m = O.gen_model(T, D, F, 1, cmp_mode=cmp_mode, clusters=Cc)
+            p = ddt.make_params(T, D, F, cmp_mode=cmp_mode, clusters=Cc, sum_mode=sum_mode)
+            G = int(rng.choice([1, 1, 2, 3]))
+            g = int(rng.integers(0, G))
+            v = -1 if rng.random() < 0.5 else int(rng.integers(0, nvar))
+            if mock.ddt_set_option(e, b"variant", v) != 0:                # does not fit the model that is still loaded
+                v = -1
+                assert mock.ddt_set_option(e, b"variant", -1) == 0
+            for opt, val in ((b"class_streams", int(rng.integers(0, 2))), (b"q16_fused_prepass", int(rng.integers(0, 2))),
+                             (b"q16_grouped_prepass", int(rng.integers(0, 2))), (b"feeder_rows", int(rng.choice([64, 300, 1024, 5000]))),
+                             (b"kernel_timing", int(rng.integers(0, 2)))):
+                assert mock.ddt_set_option(e, opt, val) == 0
+            args = (C.byref(p), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8)
+            if K > 1:
+                if G > -(-T // K):
+                    G, g = 1, 0
+                rc = mock.ddt_load_model_multiclass(e, *args, K, 1, g, G)
+            else:
+                if G > T:
+                    G, g = 1, 0
+                rc = mock.ddt_load_model_shard(e, *args, g, G)
+            if rc == -5 and v >= 0:
+                continue                                                     # the forced variant does not fit this model
+            assert rc == 0, (mock.ddt_last_error(e), T, D, F, K, G, g, v)
+            sm = O.SUM_REF_FLOPOCO if sum_mode == 0 else O.SUM_F64_SEQ
+            for _call in range(int(rng.integers(1, 4))):
+                n = int(rng.choice([0, 1, 7, 1023, 1024, 1025, 2500]))
+                x = O.gen_tuples(int(rng.integers(0, 1000)), max(n, 1), F, 1)[:n]
+                host = rng.random() < 0.5
+                ctx = dict(T=T, D=D, F=F, K=K, G=G, g=g, v=v, n=n, host=host, cmp=cmp_mode, sum=sum_mode, C=Cc)
+                if K == 1:
+                    per = -(-T // G)
+                    b0 = min(g * per, T)
+                    b1 = min(b0 + per, T)
+                    want = O.score_shard(m, x, b0, b1, sum_mode=sm) if (n and b1 > b0) else np.zeros(n, np.float32)
+                    out = np.full(n, np.nan, np.float32)
+                    if host:
+                        rc = mock.ddt_score(e, x.ctypes.data if n else None, n, out.ctypes.data if n else None)
+                    else:
+                        rc = mock.ddt_score_device(e, x.ctypes.data if n else None, n, out.ctypes.data if n else None, s)
+                        assert mock.hipStreamSynchronize(s) == 0
+                    assert rc == 0 and np.array_equal(_bits(out), _bits(want)), ctx
+                elif n:
+                    gs, gl = np.full((K, n), np.nan, np.float32), np.full(n, -1, np.int32)
+                    if host:
+                        rc = mock.ddt_classify(e, x.ctypes.data, n, gl.ctypes.data, gs.ctypes.data)
+                    else:
+                        rc = mock.ddt_classify_device(e, x.ctypes.data, n, gs.ctypes.data, gl.ctypes.data, s)
+                        assert mock.hipStreamSynchronize(s) == 0
+                    assert rc == 0, ctx
+                    if G == 1:
+                        labels, cs = O.classify(m, x, K, True, sum_mode=sm)
+                        assert np.array_equal(_bits(gs), _bits(cs)) and np.array_equal(gl, labels), ctx
+        mock.ddt_destroy(e)
+
+
 REMOVED = {
     # the odd classes no longer wait for class 0's launch (and the rank pre-pass in front of it) on the caller's stream
     "class_stream_start": ("      HIP_TRY(e, hipEventRecord(e->class_ev[0], s));\n      HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));\n    }\n  }\n  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));",
