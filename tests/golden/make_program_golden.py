@@ -20,6 +20,7 @@ land in the PU memories, and which base offsets the per-tree instructions carry 
       core/Mem1in2out.v, core/dualport_mem.v   line address / word offset split around the vendor RAMs (the RAM IP itself
                                is absent from the reference: modelled as an array of lines at the address its wrapper passes)
       core/PipelinedMUX.sv     the word select, ELABORATED from its generate blocks for the instance parameters
+      core/FPAggregator.v      the accumulator WITH its control, cycle by cycle (part 5): from which input spacing it is sequential
       ResultsCombiner.sv:131-160,193  scores -> 128-bit result lines (four to a line, word k = score 4L + k)
       core/DTPU.sv:579-760     the walk itself (datapath evaluator of make_rtl_golden.py), every memory read going
                                through the wrappers above -- no address or word order is asserted by this script
@@ -613,6 +614,7 @@ def program_vectors(consts):
     out["full_pu_all_zero"] = np.array([int((f["out"] == 0).all())], np.int64)
     out["instr_fields"] = np.array([consts_pu["TREE_OFFSET_BITS"], consts_pu["TUPLE_OFFSET_BITS"]], np.uint64)
     out["result_scores"], out["result_lines"] = result_line_vectors(consts)
+    out.update(aggregator_timing_vectors())
     np.savez_compressed(OUT_PROG, **out)
     print(f"wrote {OUT_PROG}: idle_tfi_advance={out['idle_tfi_advance'][0]} idle_read_hits_prog_addr={out['idle_read_hits_prog_addr'][0]}")
 
@@ -768,6 +770,74 @@ def result_line_vectors(consts):
             clock(local_core_result_valid=0, local_core_result=0xDEADBEEF)            # a gap in the score stream
     clock(local_core_result_valid=0)
     return scores, np.array([[(ln >> (32 * w)) & 0xFFFFFFFF for w in range(4)] for ln in lines], np.uint32)
+
+
+# ------------------------------------------------------------------------------------------ part 5: the accumulator's control
+def aggregator_timing_vectors():
+    """core/FPAggregator.v as a WHOLE -- its clocked block (latency counter, running sum, output rule) executed by the interpreter,
+    the 2-cycle `delay` of valid / last and the 2-stage FloPoCo adder (evaluated from its source) as two-deep pipelines -- with the
+    one module the reference does not contain, `quick_fifo`, modelled as a show-ahead FIFO (valid = not empty, `re` pops): the only
+    semantics under which the module's `re = ready` does not lose data.  Values arrive `spacing` cycles apart.
+    Result (recorded, asserted by tests/test_oracle_program.py): from 3 cycles apart the module computes the strictly sequential
+    sum the datapath vectors pin (acc <- x + acc); 1 or 2 cycles apart it pops a value every 2 cycles while a sum re-enters the
+    adder after 3, keeps two interleaved chains and outputs only the one that holds the last value."""
+    from make_rtl_golden import SRC, load_modules, rtl_add
+
+    text = _strip(open(f"{REF}/core/FPAggregator.v").read())
+    m = re.search(r"parameter\s+FP_ADDER_LATENCY\s*=\s*(\d+)", text)
+    assert m and int(m.group(1)) == 2
+    text = re.sub(r"\bFP_ADDER_LATENCY\b", m.group(1), text)
+    blk = [ast for _s, ast, _p in always_blocks(text) if "prev_aggreg_value" in assigned_names(ast, set())]
+    assert len(blk) == 1
+    width = {"rst_n": 1, "prev_aggreg_value": 34, "fpadder_latency_count": 4, "aggreg_out_valid_d1": 1, "aggreg_out_d1": 32, "aggregator_ready": 1,
+             "aggreg_in_fifo_valid": 1, "fp_in_valid_delayed": 1, "fp_in_last_delayed": 1, "aggreg_value": 34, "aggreg_out_fifo_almfull": 1,
+             "aggreg_in_fifo_dout": 33}
+    ready_e = expr(re.search(r"assign\s+aggregator_ready\s*=\s*([^;]+);", text).group(1))
+    in_a = expr(re.search(r"assign\s+input_A\s*=\s*([^;]+);", text).group(1))
+    assert re.search(r"assign\s+aggreg_in_fifo_re\s*=\s*aggregator_ready\s*;", text) and re.search(r"\.DELAY_CYCLES\(2\)", text)
+    mods = load_modules(SRC)
+
+    def run(values, spacing):
+        sim = Sim(width)
+        s = sim.sig
+        fifo, outs = deque(), []
+        adder, dly = deque([None, None]), deque([(0, 0), (0, 0)])
+        nxt = {}
+        sim.run(blk[0], dict(s, rst_n=0), nxt, False)
+        s.update(nxt)
+        s["rst_n"] = 1
+        arrivals = {k * spacing: (int(v), int(k == len(values) - 1)) for k, v in enumerate(values)}
+        for c in range(len(values) * max(spacing, 3) + 12):
+            if c in arrivals:
+                fifo.append(arrivals[c])
+            valid = int(len(fifo) > 0)
+            val, last = fifo[0] if fifo else (0, 0)
+            ready = sim.ev(ready_e, dict(s)) & 1
+            x_in = sim.ev(in_a, {"aggreg_in_fifo_dout": (last << 32) | val})
+            r = adder[0]
+            dv, dl = dly[0]
+            env = dict(s, aggregator_ready=ready, aggreg_in_fifo_valid=valid, fp_in_valid_delayed=dv, fp_in_last_delayed=dl,
+                       aggreg_value=rtl_add(mods, r[0], r[1]) if r else 0)
+            nxt = {}
+            sim.run(blk[0], env, nxt, False)
+            adder.popleft()
+            adder.append((x_in, s["prev_aggreg_value"]))              # X = new value, Y = running sum, sampled this cycle
+            dly.popleft()
+            dly.append((valid & ready, last))
+            if ready and valid:
+                fifo.popleft()
+            s.update(nxt)
+            if s["aggreg_out_valid_d1"]:
+                outs.append(s["aggreg_out_d1"])
+        assert len(outs) == 1 and not fifo
+        return outs[0]
+
+    rng = np.random.default_rng(3)
+    seqs = [(rng.random(n).astype(np.float32) * 4 - 2).view(np.uint32) for n in (2, 5, 8, 9, 16)]
+    spacings = (1, 2, 3, 4, 7)
+    out = np.array([[run(v, sp) for sp in spacings] for v in seqs], np.uint32)
+    return {"agg_values": np.concatenate(seqs), "agg_lengths": np.array([len(v) for v in seqs], np.uint32), "agg_spacings": np.array(spacings, np.uint32),
+            "agg_out": out}
 
 
 if __name__ == "__main__":

@@ -117,6 +117,29 @@ def test_scores_fill_result_lines_four_to_a_line_in_tuple_order(prog):
     assert np.array_equal(lines.reshape(-1), scores[:lines.size])
 
 
+def test_accumulator_with_its_control_is_sequential_from_three_cycles_apart(prog):
+    """core/FPAggregator.v executed as a whole (clocked block by the interpreter, 2-stage adder and delay as pipelines, the absent
+    quick_fifo as a show-ahead FIFO): values that arrive >= 3 cycles apart are summed strictly in arrival order -- orc_aggregate,
+    acc <- x + acc, the order the oracle and the engine implement.  Closer together the published module is defective (#8 of
+    DESIGN.md's table): it pops every 2 cycles, a sum re-enters the adder after 3, and the output is the interleaved chain that
+    holds the last value -- there is no other "reference order" hiding there, just lost addends."""
+    lens, spacings, out = prog["agg_lengths"], [int(x) for x in prog["agg_spacings"]], prog["agg_out"]
+    L = O.lib()
+    pos = 0
+    for i, n in enumerate(int(x) for x in lens):
+        v = np.ascontiguousarray(prog["agg_values"][pos:pos + n])
+        pos += n
+        want = L.orc_aggregate(v.ctypes.data, n)
+        chain = np.ascontiguousarray(v[(n - 1) % 2::2])                       # the values of the last one's parity, in order
+        lost = L.orc_aggregate(chain.ctypes.data, len(chain))
+        for j, sp in enumerate(spacings):
+            if sp >= 3:
+                assert int(out[i, j]) == want, (n, sp)
+            else:
+                assert int(out[i, j]) == lost, (n, sp)
+                assert n < 3 or lost != want
+
+
 # ---------------------------------------------------------------------------------------------------- the CSR chain
 COLS = ("T", "D", "F", "C", "missing", "wl", "fl", "n", "devices", "mode", "index")
 
