@@ -422,6 +422,14 @@ def main():
             comm.set_option("taper_tail", 0)
             other["tree_sharded_allreduce_untapered_ms"] = leg(lambda: comm.score_sharded(tuples, out=out, combine=ddt.COMBINE_ALLREDUCE))
             comm.set_option("taper_tail", args.taper)
+            for rows_per_chunk in (args.chunk_rows // 2, args.chunk_rows * 2):
+                comm.set_option("chunk_rows", max(1024, rows_per_chunk))
+                other[f"tree_sharded_allreduce_chunk_{max(1024, rows_per_chunk)}_ms"] = leg(
+                    lambda: comm.score_sharded(tuples, out=out, combine=ddt.COMBINE_ALLREDUCE))
+            comm.set_option("chunk_rows", args.chunk_rows)
+            comm.set_option("comm_stream_priority", 1)
+            other["tree_sharded_allreduce_comm_priority_ms"] = leg(lambda: comm.score_sharded(tuples, out=out, combine=ddt.COMBINE_ALLREDUCE))
+            comm.set_option("comm_stream_priority", 0)
             tree_scores = out.clone()                            # combined scores of the tree-sharded job (all-reduce order)
             eng2 = ddt.Engine(local)                             # row-sharded replicas: every rank holds the WHOLE ensemble
             eng2.load_model(params, w, f, 0, 1)

@@ -217,6 +217,25 @@ int ddt_comm_set_option(ddt_comm* c, const char* key, int64_t value) {
     c->chunk_rows = (size_t)value;
     return DDT_OK;
   }
+  if (!strcmp(key, "comm_stream_priority")) {  // 1 = the comm stream gets the device's highest stream priority (collective blocks are
+    // dispatched ahead of the scoring launch's queued blocks as CUs free up), 0 = default priority
+    if (value != 0 && value != 1) return cfail(c, DDT_EINVAL, "comm_stream_priority must be 0 or 1");
+    DeviceGuard dg(c->e ? c->e->device : 0);
+    hipStream_t ns = nullptr;
+    if (value) {
+      int least = 0, greatest = 0;
+      CHIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+      CHIP(c, hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, greatest));
+    } else {
+      CHIP(c, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+    }
+    if (c->cs) {
+      CHIP(c, hipStreamSynchronize(c->cs));
+      (void)hipStreamDestroy(c->cs);
+    }
+    c->cs = ns;
+    return DDT_OK;
+  }
   if (!strcmp(key, "host_rows")) {
     if (value < 1) return cfail(c, DDT_EINVAL, "host_rows must be >= 1");
     c->host_rows = (size_t)value;

@@ -209,7 +209,8 @@ void ddt_comm_destroy(ddt_comm* c);
 const char* ddt_comm_last_error(const ddt_comm* c);
 /* "chunk_rows": rows per pipelined collective (default 12,500,000); "taper_tail": 1 = the last chunk is cut into 1/2, 1/4, 1/4
  * (whole 1024-tuple tiles, pieces of at least "taper_min_rows" = 2^20 rows) so that the collective left exposed behind the last
- * scoring launch is a quarter of the size, 0 = never, -1 (default) = when the communicator has more than one rank */
+ * scoring launch is a quarter of the size, 0 = never, -1 (default) = when the communicator has more than one rank;
+ * "comm_stream_priority": 1 = run the collectives on a stream of the device's highest priority (default 0) */
 int  ddt_comm_set_option(ddt_comm* c, const char* key, int64_t value);
 /* the chunk lengths a sharded call of n_tuples rows uses (host-only; every rank derives the same list): returns their number,
  * lens_out (may be NULL to count) receives them */

@@ -40,6 +40,8 @@ hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest);
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int priority);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize(void);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);

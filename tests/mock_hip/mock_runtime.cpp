@@ -342,6 +342,12 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
   *s = st;
   return hipSuccess;
 }
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) {
+  *least = 0;
+  *greatest = -1;
+  return hipSuccess;
+}
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int) { return hipStreamCreateWithFlags(s, flags); }  // order only
 hipError_t hipStreamSynchronize(hipStream_t s) {
   std::unique_lock<std::mutex> lk(M);
   MockStream* st = resolve(s);

@@ -173,6 +173,7 @@ def test_tree_sharded_scores(mock, G, n, chunk, policy, seed):
         for out in outs:
             assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (r, np.flatnonzero(out != want)[:5])
         k.opt("taper_tail", 0)
+        k.opt("comm_stream_priority", 1)          # the comm stream is replaced (after it has drained) by a high-priority one
         out = np.full(n, np.nan, np.float32)
         assert mock.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, 0, k.s) == 0
         k.sync()
