@@ -24,6 +24,12 @@ Extra objects on the JSON line:
                bounded prefix of the same batch on this box's host cores (rank 0, N=1 only).
   streamed     N=1: the same model fed from HOST memory through the pinned double-buffered hipMemcpyAsync feeder
                (PCIe-inclusive rate on a bounded sample; never `value`).
+  scaling_detail / other_modes
+               N>1 (or --force-collectives), measured BEHIND the timed region and never `value`: the rank's shard scored with no
+               collective (what the combine costs is then on the line), and the same batch through the library's other ways of
+               running the job -- chain combine, untapered all-reduce, half / double chunk_rows, a high-priority comm stream, and
+               the row-sharded replicas (whole ensemble per GPU, tuples partitioned).  A watchdog prints the headline line and
+               exits if one of these legs -- none has run with real peers before the driver's scaling run -- does not return.
 """
 import argparse
 import json
