@@ -36,6 +36,14 @@
  *                              222 walks over 10 PU programs; tests/test_oracle_program.py (also holds the PRODUCT's CSR
  *                              codec to the executed EngineCSR.sv:146-308)
  *
+ *               orc_score(n_devices) / orc_score_shard   the per-device tree split (PCIeReceiver.sv:136-316 executed on the
+ *                              registers of the executed EngineCSR.sv) and the result chain host -> dev1 -> ... (the forwarding
+ *                              blocks of ResultsCombiner.sv:355-393,422-453 executed around the hop adders):
+ *                              tests/golden/make_receiver_golden.py, tests/test_oracle_receiver.py
+ *               orc_aggregate  also WITH the module's control: core/FPAggregator.v executed cycle by cycle (show-ahead FIFO for
+ *                              the absent quick_fifo): strictly sequential from 3 cycles between inputs (closer: the published
+ *                              module loses addends, a defect) -- make_program_golden.py part 5
+ *
  *      *** PARITY UNPINNED for everything else *** -- valid / ready handshakes, FIFO depths and back-pressure, the
  *      time-stamp alignment of the PUs, the PCIe stream splitter, the multi-device plumbing:
  *      sequential SystemVerilog that nothing here can execute as a whole.  The SPARSE format (section further
