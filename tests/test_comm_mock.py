@@ -155,7 +155,8 @@ SCHEDULES = [(0, 0), (1, 0), (2, 11), (2, 12), (2, 13)]
 
 
 @pytest.mark.parametrize("policy,seed", SCHEDULES)
-@pytest.mark.parametrize("G,n,chunk", [(2, 5003, 1024), (3, 1000, 12_500_000), (4, 4097, 700), (8, 3001, 1000), (8, 1, 5)])
+@pytest.mark.parametrize("G,n,chunk", [(1, 5000, 1024), (1, 9000, 12_500_000), (2, 5003, 1024), (3, 1000, 12_500_000), (4, 4097, 700), (8, 3001, 1000),
+                                       (8, 1, 5)])
 def test_tree_sharded_scores(mock, G, n, chunk, policy, seed):
     mock.mock_reset(policy, seed, 8)
     x, want = _tuples(n), _expected(G, n)[0]
@@ -185,7 +186,7 @@ def test_tree_sharded_scores(mock, G, n, chunk, policy, seed):
 
 
 @pytest.mark.parametrize("policy,seed", SCHEDULES)
-@pytest.mark.parametrize("G,n,chunk,K", [(2, 2500, 700, 3), (4, 1029, 12_500_000, 10), (8, 777, 100, 2)])
+@pytest.mark.parametrize("G,n,chunk,K", [(1, 2500, 700, 3), (2, 2500, 700, 3), (4, 1029, 12_500_000, 10), (8, 777, 100, 2)])
 def test_tree_sharded_classes(mock, G, n, chunk, K, policy, seed):
     mock.mock_reset(policy, seed, 8)
     x, want = _tuples(n), _expected(G, n, K)
@@ -210,7 +211,7 @@ def test_tree_sharded_classes(mock, G, n, chunk, K, policy, seed):
 
 
 @pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
-@pytest.mark.parametrize("G,n", [(2, 1000), (3, 1000), (8, 5), (8, 4096), (5, 4099)])
+@pytest.mark.parametrize("G,n", [(1, 5000), (2, 1000), (3, 1000), (8, 5), (8, 4096), (5, 4099)])
 def test_row_sharded_replicas(mock, G, n, policy, seed):
     mock.mock_reset(policy, seed, 8)
     x, want = _tuples(n), _partial(0, 0, np.arange(n))          # every rank holds the whole model (shard 0 of 1)
