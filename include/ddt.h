@@ -222,7 +222,10 @@ int  ddt_score_rowsharded_device(ddt_comm* c, const void* d_tuple_lines, size_t 
                                  void* hip_stream);
 /* host buffers (the per-rank counterpart of ddt_group_score; `ddt_cli score --ranks N --rank r` is built on it): the tuples
  * go to this rank's device in super-chunks ("host_rows" option, default 2^23 rows), through ddt_score_sharded_device, and the
- * combined scores come back to every rank.  Collective and synchronous. */
+ * combined scores come back to every rank.  With peers the host tuples cross PCIe ONCE: rank r copies 1/n of a super-chunk and
+ * every rank hands its rows to all peers over xGMI (the reference re-broadcasts tuple lines along its ring,
+ * InputDistributor.sv:199-204); option "tuple_broadcast" = 0 makes every rank copy everything from the host instead.  The same
+ * holds for ddt_group_score / ddt_group_classify.  Collective and synchronous. */
 int  ddt_comm_score(ddt_comm* c, const void* tuple_lines, size_t n_tuples, float* scores_out, int combine);
 /* multi-class (ddt_load_model_multiclass with shard_index = rank): per-class partial sums [K][n] combined like the
  * scalar scores, then the argmax over the combined sums (d_labels may be NULL) */

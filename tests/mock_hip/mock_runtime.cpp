@@ -101,7 +101,7 @@ std::map<uint64_t, double> g_done_at;  // timeline: when an event record complet
 // messages g_cost_float per float of the LONGEST message (one message per link at once), copies g_cost_copy per float.
 // mock_makespan() = the latest end over all streams: what the pipeline's overlap structure makes of those costs.
 double g_cost_row = 0.0, g_cost_float = 0.0, g_cost_copy = 0.0;
-uint64_t g_serial = 1, g_executed = 0;
+uint64_t g_serial = 1, g_executed = 0, g_h2d_bytes = 0;  // g_h2d_bytes: what crossed "PCIe" towards the devices
 std::vector<MockStream*> g_streams;
 std::map<int, MockStream*> g_null;
 std::map<std::string, Group*> g_groups;  // by unique id
@@ -444,7 +444,11 @@ hipError_t hipMemsetAsync(void* p, int value, size_t bytes, hipStream_t s) {
   enqueue(s, op);
   return hipSuccess;
 }
-hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t s) {
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+  if (kind == hipMemcpyHostToDevice) {
+    std::lock_guard<std::mutex> lk(M);
+    g_h2d_bytes += bytes;
+  }
   Op* op = new Op();
   op->run = [=] { memmove(dst, src, bytes); };
   enqueue(s, op);
@@ -554,7 +558,9 @@ void mock_reset(int policy, uint64_t seed, int devices) {
   g_devices = devices;
   g_errors = 0;
   g_executed = 0;
+  g_h2d_bytes = 0;
 }
+uint64_t mock_h2d_bytes(void) { return g_h2d_bytes; }
 void mock_costs(double per_row, double per_float_moved, double per_float_copied) {
   std::lock_guard<std::mutex> lk(M);
   g_cost_row = per_row, g_cost_float = per_float_moved, g_cost_copy = per_float_copied;

@@ -54,7 +54,7 @@ def _build(name, comm_source):
     L.hipSetDevice.argtypes = [i32]
     L.hipStreamCreateWithFlags.argtypes, L.hipStreamSynchronize.argtypes, L.hipStreamDestroy.argtypes = [C.POINTER(vp), C.c_uint], [vp], [vp]
     L.mock_reset.argtypes, L.mock_reset.restype = [i32, u64, i32], None
-    L.mock_executed.restype = u64
+    L.mock_executed.restype = L.mock_h2d_bytes.restype = u64
     L.mock_costs.argtypes, L.mock_costs.restype = [C.c_double, C.c_double, C.c_double], None
     L.mock_makespan.restype = C.c_double
     return L
@@ -244,14 +244,25 @@ def test_host_buffer_form(mock, policy, seed):
         k.opt("host_rows", 2500)                 # three super-chunks, the last one ragged
         k.opt("chunk_rows", 900)
         k.opt("taper_min_rows", 16)
-        for combine in (0, 1):
-            out = np.full(n, np.nan, np.float32)
-            assert mock.ddt_comm_score(k.c, x.ctypes.data, n, out.ctypes.data, combine) == 0
-            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), r
+        for bcast in (1, 0):                     # tuples cross "PCIe" once and travel on between the devices / every rank copies all
+            k.opt("tuple_broadcast", bcast)
+            barrier.wait()
+            before = mock.mock_h2d_bytes()
+            barrier.wait()
+            for combine in (0, 1):
+                out = np.full(n, np.nan, np.float32)
+                assert mock.ddt_comm_score(k.c, x.ctypes.data, n, out.ctypes.data, combine) == 0
+                assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (r, bcast)
+            barrier.wait()
+            if r == 0:
+                traffic.append((mock.mock_h2d_bytes() - before) / (2 * n * W * 4))
+            barrier.wait()
         k.close(barrier)
 
+    traffic = []
     _run_ranks(G, body)
     assert mock.mock_errors() == 0
+    assert traffic == [1.0, float(G)]            # host tuples: once with the broadcast, G times without
 
 
 @pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
