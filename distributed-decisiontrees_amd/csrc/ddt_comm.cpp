@@ -9,7 +9,9 @@
 // caller's stream scores chunk k+1 while the comm's own stream combines chunk k -- with either one ncclAllReduce per
 // chunk (the collective BASELINE.json names) or the deterministic chain: grouped ncclSend/ncclRecv all-to-all of 1/G
 // slices, fixed-order add on the owner, ncclAllGather.  xGMI is point-to-point (fully connected mesh), so the
-// all-to-all form puts one slice on every link at once.
+// all-to-all form puts one slice on every link at once.  The other two jobs are written for the mesh the same way: the row-sharded
+// replicas hand every finished step of scores to all peers with grouped send / recv while the next step is scored, and host tuples
+// cross PCIe once (1/n per rank) before the ranks hand their rows to each other (tuples_to_device).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
