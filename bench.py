@@ -447,6 +447,14 @@ def main():
             other["row_sharded_mtuples_per_s"] = round(N / other["row_sharded_ms"] / 1e3, 3)
             scale = float(tree_scores.abs().max().item()) or 1.0
             other["row_vs_tree_max_abs_diff_rel"] = float((out - tree_scores).abs().max().item()) / scale   # summation order differs
+            # host buffers through the tree-sharded job (ddt_comm_score): tuples over PCIe once + xGMI hand-over, or G full copies
+            srows = min(N, 8_000_000)
+            host_t = tuples[:srows].cpu().numpy().view(np.uint32)
+            for bc in (1, 0):
+                comm.set_option("tuple_broadcast", bc)
+                ms = leg(lambda: comm.score(host_t), steps=1)
+                other[f"host_buffers_tuple_broadcast_{bc}_mtuples_per_s"] = round(srows / ms / 1e3, 2)
+            comm.set_option("tuple_broadcast", -1)
             other["note"] = ("ms per step, max over ranks, 2 steps each after one warm-up, outside the timed region; row-sharded = replicas "
                              "only (whole ensemble per GPU, tuples partitioned, every step of scores handed to all peers), exact reference-order sums")
             comm2.close()

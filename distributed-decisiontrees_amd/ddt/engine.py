@@ -335,6 +335,14 @@ class Comm:
         self._check(self._L.ddt_score_sharded_device(self._h, d_tuples.data_ptr(), n, out.data_ptr(), combine, s.cuda_stream))
         return out
 
+    def score(self, tuple_lines: np.ndarray, combine: int = COMBINE_ALLREDUCE) -> np.ndarray:
+        """Host buffers (ddt_comm_score): with peers the tuples cross PCIe once (1/n per rank) and travel on over xGMI; every rank
+        gets the combined scores.  Collective and synchronous."""
+        t = np.ascontiguousarray(tuple_lines).view(np.uint32).reshape(-1, tuple_words(self.engine.params.num_features))
+        out = np.empty(t.shape[0], np.float32)
+        self._check(self._L.ddt_comm_score(self._h, t.ctypes.data, t.shape[0], out.ctypes.data, combine))
+        return out
+
     def score_rowsharded(self, d_tuples, out=None, stream=None):
         """Row-sharded job ("replicas only"): every rank holds the whole ensemble and scores its slice of the rows."""
         import torch
