@@ -83,3 +83,18 @@ def test_group_of_four_devices(on_model):
     g.close()
     with pytest.raises(ddt.DDTError):
         ddt.Group([0, 0])                                             # one communicator rank per device
+
+
+def test_comm_host_buffer_call(on_model):
+    T, D, F, n = 90, 8, 32, 2100
+    m, x = O.gen_model(T, D, F, 1), O.gen_tuples(0, n, F, 1)
+    e = ddt.Engine(0)
+    e.load_model(ddt.make_params(T, D, F), m.wlines, m.flines)
+    c = ddt.Comm(e, 0, 1, ddt.comm_unique_id())
+    c.set_option("host_rows", 800)
+    for combine in (ddt.COMBINE_ALLREDUCE, ddt.COMBINE_CHAIN):
+        assert np.array_equal(c.score(x, combine=combine).view(np.uint32), O.score(m, x).view(np.uint32))
+    with pytest.raises(ddt.DDTError):
+        c.set_option("tuple_broadcast", 2)
+    c.close()
+    e.close()
