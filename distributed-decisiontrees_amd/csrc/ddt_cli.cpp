@@ -12,6 +12,8 @@
 //                 [--device 0] [--shard i --of n] [--cmp-mode 0|1] [--sum-mode 0|1] [--variant v]
 //                 [--devices G [--combine allreduce|chain]]   the whole multi-GPU job in this process: tree shard g on
 //                                                             device g, partial scores combined over RCCL (ddt_group_*)
+//                 [--devices G --mode rows]                   the reference's other mode: the whole ensemble on every device, the
+//                                                             tuples partitioned, every device feeds itself; no collective
 //                 [--ranks N --rank r --id-file PATH [--combine allreduce|chain] [--device d]]   one process per GPU: this
 //                                                             process is rank r (tree shard r, device r unless --device), the RCCL
 //                                                             id is published by rank 0 through PATH (fresh per job); every
@@ -202,8 +204,15 @@ int cmd_score(const std::map<std::string, std::string>& o) {
     if (rc) return die(rc, nullptr, "ddt_group_create");
     if (o.count("variant"))
       for (int i = 0; i < G; ++i) ddt_set_option(ddt_group_engine(g, i), "variant", (int64_t)num(o, "variant", 0));
-    rc = ddt_group_load_model(g, &p, w.data(), w.size() / 16, f.data(), f.size() / 16);
-    if (!rc) rc = ddt_group_score(g, x.data(), n, scores.data(), cmb == "chain" ? DDT_COMBINE_CHAIN : DDT_COMBINE_ALLREDUCE);
+    const bool rows_mode = o.count("mode") && o.at("mode") == "rows";  // the ensemble on every device, the tuples partitioned
+    if (o.count("mode") && !rows_mode && o.at("mode") != "trees") return die(DDT_EINVAL, nullptr, "--mode trees|rows");
+    if (rows_mode) {
+      rc = ddt_group_load_model_replicated(g, &p, w.data(), w.size() / 16, f.data(), f.size() / 16);
+      if (!rc) rc = ddt_group_score_rows(g, x.data(), n, scores.data());
+    } else {
+      rc = ddt_group_load_model(g, &p, w.data(), w.size() / 16, f.data(), f.size() / 16);
+      if (!rc) rc = ddt_group_score(g, x.data(), n, scores.data(), cmb == "chain" ? DDT_COMBINE_CHAIN : DDT_COMBINE_ALLREDUCE);
+    }
     if (rc) {
       fprintf(stderr, "ddt_cli: multi-GPU job failed: %s (%s)\n", ddt_strerror(rc), ddt_group_last_error(g));
       ddt_group_destroy(g);
@@ -212,8 +221,12 @@ int cmd_score(const std::map<std::string, std::string>& o) {
     if (!write_file(str(o, "out"), scores.data(), scores.size() * 4)) return die(DDT_EINVAL, nullptr, "write results");
     ddt_info info;
     ddt_get_info(ddt_group_engine(g, 0), &info);
-    printf("scored %" PRIu64 " tuples on %d device(s), %u trees sharded tree-wise (device 0: [%u, %u), kernel %s), combine %s over RCCL\n",
-           n, G, p.num_trees, info.tree_begin, info.tree_end, info.variant_name, cmb.c_str());
+    if (rows_mode)
+      printf("scored %" PRIu64 " tuples on %d device(s), %u trees on every device, tuples partitioned (kernel %s), no collective\n", n, G, p.num_trees,
+             info.variant_name);
+    else
+      printf("scored %" PRIu64 " tuples on %d device(s), %u trees sharded tree-wise (device 0: [%u, %u), kernel %s), combine %s over RCCL\n",
+             n, G, p.num_trees, info.tree_begin, info.tree_end, info.variant_name, cmb.c_str());
     ddt_group_destroy(g);
     return 0;
   }

@@ -724,6 +724,40 @@ int ddt_group_score(ddt_group* g, const void* tuple_lines, size_t n, float* scor
   return group_run(g, tuple_lines, n, scores_out, nullptr, nullptr, combine);
 }
 
+// The reference's other mode for a single process: every device holds the WHOLE ensemble (DTInference.sv:33-36 "trees
+// broadcast") and scores its share of the rows through its own engine's feeder -- no collective, G PCIe links in parallel.
+int ddt_group_load_model_replicated(ddt_group* g, const ddt_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines) {
+  if (!g) return DDT_EINVAL;
+  int rc = for_each_device(g, [&](int i) { return ddt_load_model(g->eng[(size_t)i], p, wl, n_wlines, fl, n_flines); });
+  if (rc)
+    for (int i = 0; i < g->n; ++i)
+      if (g->eng[(size_t)i]->err[0]) return gfail(g, rc, "device %d: %s", g->devices[(size_t)i], g->eng[(size_t)i]->err);
+  return rc;
+}
+
+int ddt_group_score_rows(ddt_group* g, const void* tuple_lines, size_t n, float* scores_out) {
+  if (!g) return DDT_EINVAL;
+  if (n == 0) return DDT_OK;
+  if (!tuple_lines || !scores_out) return gfail(g, DDT_EINVAL, "NULL host buffer");
+  for (int i = 0; i < g->n; ++i) {
+    const ddt_engine* e = g->eng[(size_t)i];
+    if (!e->loaded || e->num_classes != 1) return gfail(g, DDT_ESTATE, "device %d: no scalar model loaded", g->devices[(size_t)i]);
+    ddt_info info;
+    if (ddt_get_info(e, &info) || info.tree_begin != 0 || info.tree_end != e->p.num_trees)
+      return gfail(g, DDT_ESTATE, "device %d holds a tree shard: row partitioning needs ddt_group_load_model_replicated", g->devices[(size_t)i]);
+  }
+  const size_t W = tuple_words(g->eng[0]->p), G = (size_t)g->n, per = ((n + G - 1) / G + 3) / 4 * 4;  // whole result lines per device
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(tuple_lines);
+  int rc = for_each_device(g, [&](int i) -> int {
+    const size_t lo = std::min((size_t)i * per, n), hi = std::min(lo + per, n);
+    return hi > lo ? ddt_score(g->eng[(size_t)i], src + lo * W, hi - lo, scores_out + lo) : DDT_OK;
+  });
+  if (rc)
+    for (int i = 0; i < g->n; ++i)
+      if (g->eng[(size_t)i]->err[0]) return gfail(g, rc, "device %d: %s", g->devices[(size_t)i], g->eng[(size_t)i]->err);
+  return rc;
+}
+
 int ddt_group_classify(ddt_group* g, const void* tuple_lines, size_t n, int32_t* labels_out, float* class_scores_out, int combine) {
   if (!g) return DDT_EINVAL;
   if (n == 0) return DDT_OK;

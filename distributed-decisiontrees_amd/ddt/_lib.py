@@ -21,7 +21,7 @@ SYMBOLS = [
     "ddt_score_sharded_device", "ddt_score_rowsharded_device", "ddt_classify_sharded_device",
     "ddt_group_create", "ddt_group_destroy", "ddt_group_last_error", "ddt_group_engine", "ddt_group_load_model",
     "ddt_group_load_model_sparse", "ddt_group_score", "ddt_group_load_model_multiclass", "ddt_group_classify", "ddt_debug_prepass_image", "ddt_debug_sparse_image",
-    "ddt_shard_range", "ddt_debug_model_image", "ddt_comm_chunk_schedule", "ddt_comm_score",
+    "ddt_shard_range", "ddt_debug_model_image", "ddt_comm_chunk_schedule", "ddt_comm_score", "ddt_group_load_model_replicated", "ddt_group_score_rows",
 ]
 
 
@@ -124,6 +124,8 @@ def bind(L):
                                     C.POINTER(u32), C.POINTER(C.c_uint8 * 20)]
     L.ddt_debug_model_image.restype = i32
     L.ddt_debug_model_image.argtypes = [PP, vp, sz, vp, sz, i32, vp, vp, sz, vp, sz, C.POINTER(u64 * 12)]
+    L.ddt_group_load_model_replicated.restype, L.ddt_group_load_model_replicated.argtypes = i32, [vp, PP, vp, sz, vp, sz]
+    L.ddt_group_score_rows.restype, L.ddt_group_score_rows.argtypes = i32, [vp, vp, sz, vp]
     L.ddt_comm_score.restype, L.ddt_comm_score.argtypes = i32, [vp, vp, sz, vp, i32]
     L.ddt_comm_chunk_schedule.restype, L.ddt_comm_chunk_schedule.argtypes = C.c_int64, [sz, sz, i32, sz, vp, sz]
     L.ddt_shard_range.restype, L.ddt_shard_range.argtypes = i32, [u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]

@@ -417,6 +417,21 @@ class Group:
         self.params, self.num_classes = params, num_classes
         return self
 
+    def load_model_replicated(self, params: Params, wlines: np.ndarray, flines: np.ndarray):
+        """Every device holds the whole ensemble (the reference's tuple-partitioned mode): use with score_rows()."""
+        w = np.ascontiguousarray(wlines).view(np.uint32).reshape(-1)
+        f = np.ascontiguousarray(flines).view(np.uint16).reshape(-1)
+        self._check(self._L.ddt_group_load_model_replicated(self._h, C.byref(params), w.ctypes.data, w.size // 4, f.ctypes.data, f.size // 8))
+        self.params = params
+        return self
+
+    def score_rows(self, tuple_lines: np.ndarray) -> np.ndarray:
+        """Device d scores its share of the rows through its own feeder; no collective."""
+        t = np.ascontiguousarray(tuple_lines).view(np.uint32).reshape(-1, tuple_words(self.params.num_features))
+        out = np.empty(t.shape[0], np.float32)
+        self._check(self._L.ddt_group_score_rows(self._h, t.ctypes.data, t.shape[0], out.ctypes.data))
+        return out
+
     def score(self, tuple_lines: np.ndarray, combine: int = COMBINE_ALLREDUCE) -> np.ndarray:
         t = np.ascontiguousarray(tuple_lines).view(np.uint32).reshape(-1, tuple_words(self.params.num_features))
         out = np.empty(t.shape[0], np.float32)

@@ -247,6 +247,12 @@ int  ddt_group_load_model(ddt_group* g, const ddt_params* p, const void* weights
 int  ddt_group_load_model_sparse(ddt_group* g, const ddt_params* p, const void* node_lines, size_t n_lines,
                                  const uint64_t* tree_first_line);
 int  ddt_group_score(ddt_group* g, const void* tuple_lines, size_t n_tuples, float* scores_out, int combine);
+/* the reference's OTHER mode in one process (DTInference.sv:33-36: the ensemble fits one device, the tuples are partitioned):
+ * every device loads the whole ensemble; device d scores rows [d * per, ...) of the host buffer through its own engine's feeder
+ * (pinned double buffer over ITS PCIe link) and writes them to their place in scores_out -- no collective at all */
+int  ddt_group_load_model_replicated(ddt_group* g, const ddt_params* p, const void* weights_lines, size_t n_wlines,
+                                     const void* findex_lines, size_t n_flines);
+int  ddt_group_score_rows(ddt_group* g, const void* tuple_lines, size_t n_tuples, float* scores_out);
 /* multi-class models (config 5): class k's trees sharded tree-wise like the scalar ensemble; labels_out [n] int32 argmax of
  * the combined per-class sums, class_scores_out (may be NULL) [num_classes][n] */
 int  ddt_group_load_model_multiclass(ddt_group* g, const ddt_params* p, const void* weights_lines, size_t n_wlines,

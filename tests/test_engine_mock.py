@@ -251,6 +251,13 @@ def test_single_process_group_with_the_real_engine(mock):
     out = np.full(n, np.nan, np.float32)
     assert mock.ddt_group_score(g, x.ctypes.data, n, out.ctypes.data, 1) == 0, mock.ddt_group_last_error(g)
     assert np.array_equal(_bits(out), _bits(O.score(m, x, n_devices=G)))
+    assert mock.ddt_group_score_rows(g, x.ctypes.data, n, out.ctypes.data) == -4          # the devices hold tree shards
+    # the reference's other mode: the whole ensemble on every device, every device scores its rows through its own feeder
+    assert mock.ddt_group_load_model_replicated(g, C.byref(p), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8) == 0
+    for rows in (n, 7, 1, 2499):
+        out = np.full(rows, np.nan, np.float32)
+        assert mock.ddt_group_score_rows(g, x.ctypes.data, rows, out.ctypes.data) == 0, mock.ddt_group_last_error(g)
+        assert np.array_equal(_bits(out), _bits(O.score(m, x[:rows])))
     mock.ddt_group_destroy(g)
 
 
@@ -306,6 +313,9 @@ def test_the_cli_host_program_on_the_model(mock, tmp_path):
     res = np.fromfile(pre + ".res", np.float32)
     assert res.size == (n + 3) // 4 * 4 and not res[n:].any()
     assert np.array_equal(_bits(res[:n]), _bits(O.score(m, x, n_devices=4)))
+    out = subprocess.check_output(base + ["--devices", "4", "--mode", "rows"]).decode()
+    assert "tuples partitioned" in out and "no collective" in out
+    assert np.array_equal(_bits(np.fromfile(pre + ".res", np.float32)[:n]), _bits(O.score(m, x)))
     parts = []
     for g in range(4):                                           # the same job as four single-engine runs, combined by the oracle's hop adder
         subprocess.check_output(base + ["--shard", str(g), "--of", "4"])

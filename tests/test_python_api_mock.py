@@ -80,6 +80,10 @@ def test_group_of_four_devices(on_model):
     g.load_model(ddt.make_params(T, D, F), m.wlines, m.flines)
     for combine in (ddt.COMBINE_ALLREDUCE, ddt.COMBINE_CHAIN):
         assert np.array_equal(g.score(x, combine=combine).view(np.uint32), O.score(m, x, n_devices=4).view(np.uint32))
+    with pytest.raises(ddt.DDTError):
+        g.score_rows(x)                                              # tree shards loaded: not the row mode
+    g.load_model_replicated(ddt.make_params(T, D, F), m.wlines, m.flines)
+    assert np.array_equal(g.score_rows(x).view(np.uint32), O.score(m, x).view(np.uint32))
     g.close()
     with pytest.raises(ddt.DDTError):
         ddt.Group([0, 0])                                             # one communicator rank per device
