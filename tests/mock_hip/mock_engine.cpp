@@ -4,6 +4,8 @@
 // result is checked bit for bit.
 #include "mock_runtime.cpp"
 
+#include <algorithm>
+
 namespace {
 
 // the stand-in engine's arithmetic
@@ -51,6 +53,29 @@ int ddt_load_model_sparse(ddt_engine* e, const ddt_params* p, const void*, size_
 int ddt_load_model_multiclass(ddt_engine* e, const ddt_params* p, const void*, size_t, const void*, size_t, uint32_t classes, int, uint32_t shard,
                               uint32_t count) {
   return mock_load(e, p, classes, shard, count);
+}
+int ddt_load_model(ddt_engine* e, const ddt_params* p, const void*, size_t, const void*, size_t) { return mock_load(e, p, 1, 0, 1); }
+int ddt_get_info(const ddt_engine* e, ddt_info* out) {
+  if (!e || !out) return DDT_EINVAL;
+  memset(out, 0, sizeof(*out));
+  std::lock_guard<std::mutex> lk(M);
+  const MockModel m = g_models[const_cast<ddt_engine*>(e)];
+  const uint32_t T = e->p.num_trees, per = (T + m.count - 1) / m.count;
+  out->tree_begin = std::min(m.shard * per, T);
+  out->tree_end = std::min(out->tree_begin + per, T);
+  return DDT_OK;
+}
+int ddt_score(ddt_engine* e, const void* tuple_lines, size_t n, float* scores_out) {  // host buffers, synchronous
+  if (!e || !e->loaded) return DDT_ESTATE;
+  MockModel m;
+  {
+    std::lock_guard<std::mutex> lk(M);
+    m = g_models[e];
+  }
+  const uint32_t W = (e->p.num_features + 3u) / 4u * 4u;
+  const uint32_t* t = reinterpret_cast<const uint32_t*>(tuple_lines);
+  for (size_t i = 0; i < n; ++i) scores_out[i] = partial(m.shard, 0, t[i * W]);
+  return DDT_OK;
 }
 const char* ddt_strerror(int) { return "mock"; }
 const char* ddt_last_error(const ddt_engine* e) { return e ? e->err : ""; }

@@ -285,6 +285,13 @@ def test_single_process_group(mock, G, policy, seed):
     lab, cs = np.full(n, -1, np.int32), np.full((K, n), np.nan, np.float32)
     assert mock.ddt_group_classify(g, x.ctypes.data, n, lab.ctypes.data, cs.ctypes.data, 0) == 0
     assert np.array_equal(cs.view(np.uint32), want.view(np.uint32)) and np.array_equal(lab, np.argmax(want, axis=0))
+    mock.ddt_group_load_model_replicated.argtypes = [vp, C.POINTER(ddt.Params), vp, sz, vp, sz]
+    mock.ddt_group_score_rows.argtypes = [vp, vp, sz, vp]
+    out = np.full(n, np.nan, np.float32)
+    assert mock.ddt_group_score_rows(g, x.ctypes.data, n, out.ctypes.data) < 0            # tree shards (or classes) loaded: refused
+    assert mock.ddt_group_load_model_replicated(g, C.byref(p), x.ctypes.data, 1 << 20, x.ctypes.data, 1 << 20) == 0
+    assert mock.ddt_group_score_rows(g, x.ctypes.data, n, out.ctypes.data) == 0
+    assert np.array_equal(out.view(np.uint32), _partial(0, 0, np.arange(n)).view(np.uint32))
     mock.ddt_group_destroy(g)
     assert mock.mock_errors() == 0
 
