@@ -35,7 +35,7 @@ def _cases(v):
         T, D, F, G, mode, pad, wl, fl, tl, n = (int(x) for x in row)
         rec = v[f"rec_{T}_{D}_{F}_{G}_{mode}_{pad}"]
         yield dict(T=T, D=D, F=F, G=G, mode=mode, wl=wl, fl=fl, tl=tl, n=n, w=rec[:T * wl], f=rec[T * wl:T * (wl + fl)],
-                   x=rec[T * (wl + fl):], csr=v[f"csr_{T}_{D}_{F}_{G}_{mode}_{pad}"])
+                   x=rec[T * (wl + fl):], csr=v[f"csr_{T}_{D}_{F}_{G}_{mode}_{pad}"], last=v[f"last_{T}_{D}_{F}_{G}_{mode}_{pad}"])
 
 
 def _product_owner(T, G):
@@ -126,3 +126,41 @@ def test_result_chain_adds_in_device_list_order_and_the_host_forwards(vec, G):
     acc = acc.reshape(final.shape)
     assert clean.mean() > 0.9                                    # words with an exact cancellation on some hop are the RTL's defect
     assert np.array_equal(acc[clean], final[clean])
+
+
+def test_last_is_stamped_on_the_final_line_of_every_tree_and_tuple(vec):
+    """InputDistributor.sv:247-288 executed on the receiver's stamps and the executed registers: the local core sees `last` on line
+    lines-per-tree - 1 of every tree's weights, of every tree's feature indexes and on the final line of every tuple -- the
+    boundaries the PU programming vectors (tests/test_oracle_program.py) are driven with.  Here the *_minus_one registers are used
+    as a compare value, correctly: defect 1 is confined to the control word's stride fields."""
+    for c in _cases(vec):
+        T, wl, fl, tl, n = c["T"], c["wl"], c["fl"], c["tl"], c["n"]
+        w, f, x = c["last"][:T * wl].reshape(T, wl), c["last"][T * wl:T * (wl + fl)].reshape(T, fl), c["last"][T * (wl + fl):].reshape(n, tl)
+        for part in (w, f, x):
+            assert (part[:, -1] == 1).all() and not part[:, :-1].any()
+
+
+def test_ring_rebroadcast_reaches_every_device_once(vec):
+    """InputDistributor.sv:199-232 executed: in the tree-sharded mode (broadcast_data) a tuple line goes to the local core AND on
+    to the next device unless this is the last node; tree lines stay local (the receiver already routed them).  With the mode
+    flags the codec writes per device (host, ..., last) every device of the list therefore sees every tuple line exactly once --
+    what "tuples replicated on every rank" (and tuples_to_device's hand-over) provide.  Row mode: the trees travel, the data stays."""
+    route = {tuple(int(v) for v in r[:4]): (int(r[4]), int(r[5])) for r in vec["route"]}     # (data line, bcast_data, bcast_trees, last) -> (core, next)
+    for last_node in (0, 1):
+        assert route[(1, 1, 0, last_node)] == (1, 1 - last_node)         # tree-sharded mode, tuple line
+        assert route[(0, 1, 0, last_node)] == (1, 0)                     #                    tree line
+        assert route[(0, 0, 1, last_node)] == (1, 1 - last_node)         # row mode, tree line
+        assert route[(1, 0, 1, last_node)] == (1, 0)                     #           tuple line: scored where the receiver sent it
+    for G in (2, 5, 8):                                                  # walk the ring with the per-device flags of ddt_csr_encode_ex
+        p = ddt.make_params(64, 4, 16)
+        seen = []
+        for d in range(G):
+            buf = (C.c_uint64 * 12)()
+            assert ddt.lib().ddt_csr_encode_ex(C.byref(p), 1000, G, 0, d, C.byref(buf)) == 0
+            flags = int(buf[1]) & 0xFF
+            core, nxt = route[(1, (flags >> 2) & 1, (flags >> 3) & 1, (flags >> 7) & 1)]
+            seen.append(core)
+            if not nxt:
+                assert d == G - 1, "the ring must carry the line to the last device of the list"
+                break
+        assert seen == [1] * G
