@@ -36,8 +36,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
-from make_program_golden import (REF, Params, assigned_names, csr_design, expr, package_consts, py_const, rtl_csr_write,  # noqa: E402
-                                 subst)
+from make_program_golden import (REF, Params, assigned_names, csr_design, expr, find_instance, package_consts, py_const,  # noqa: E402
+                                 rtl_csr_write, subst)
 from make_rtl_golden import Evaluator, Module, _strip  # noqa: E402
 from make_schedule_golden import Sim, always_blocks  # noqa: E402
 
@@ -253,6 +253,18 @@ def main():
     design = csr_design(consts)
     rx = Receiver(consts)
     dist = Distributor(consts)
+    # the registers reach these modules under their own names: DTInference.sv connects every parameter port of the receiver and the
+    # distributor to the wire the EngineCSR output of the same name drives (only the SL3 / core stream ports are renamed)
+    top = _strip(open(f"{REF}/DTInference.sv").read())
+    _, csr_ports = find_instance(top, "EngineCSR")
+    for typ, used in (("PCIeReceiver", ("pcie_receiver_enabled", "host_node", "data_distributed", "broadcast_trees", "broadcast_data",
+                                        "core_data_batch_cls_minus_one", "total_num_trees_cls", "total_num_weights_cls", "numcls_local_weights_minus_one",
+                                        "numcls_local_findexes_minus_one", "numDevs_minus_one")),
+                      ("InputDistributor", ("broadcast_data", "broadcast_trees", "last_node", "tree_weights_numcls_minus_one",
+                                            "tree_feature_index_numcls_minus_one", "tuple_numcls_minus_one"))):
+        _, ports = find_instance(top, typ)
+        for name in used:
+            assert ports[name] == name == csr_ports[name], (typ, name, ports.get(name), csr_ports.get(name))
     lib = ctypes.CDLL(os.path.join(ROOT, "distributed-decisiontrees_amd", "lib", "libddt.so"))
     enc = lib.ddt_csr_encode_ex
     enc.argtypes = [ctypes.POINTER(Params), ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
