@@ -26,12 +26,13 @@ vp, sz, u32, u64, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int
 
 
 def _build(name, comm_source):
-    out = os.path.join(MOCK, name)
+    san = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g"] if os.environ.get("DDT_MOCK_SANITIZE") else []   # see tests/mock_hip/README
+    out = os.path.join(MOCK, name.replace(".so", "_asan.so") if san else name)
     deps = [comm_source, os.path.join(MOCK, "mock_runtime.cpp"), os.path.join(MOCK, "mock_engine.cpp"), os.path.join(MOCK, "hip", "hip_runtime.h"),
             os.path.join(MOCK, "rccl", "rccl.h"),
             os.path.join(CSRC, "ddt_engine_priv.h"), os.path.join(CSRC, "ddt_internal.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wall", "-I" + MOCK, "-I" + CSRC, comm_source,
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wall", *san, "-I" + MOCK, "-I" + CSRC, comm_source,
                                os.path.join(MOCK, "mock_engine.cpp"), "-o", out])
     L = C.CDLL(out)
     L.ddt_create.argtypes, L.ddt_destroy.argtypes, L.ddt_destroy.restype = [C.POINTER(vp), i32], [vp], None
@@ -170,6 +171,7 @@ def test_tree_sharded_scores(mock, G, n, chunk, policy, seed):
             out = np.full(n, np.nan, np.float32)
             assert mock.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, combine, k.s) == 0, mock.ddt_comm_last_error(k.c)
             outs.append(out)
+        barrier.wait()                           # all ranks have enqueued their calls: from here on the schedule decides the order
         k.sync()
         for out in outs:
             assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (r, np.flatnonzero(out != want)[:5])
@@ -399,6 +401,7 @@ def test_the_model_catches_a_missing_dependency(which):
                     else:
                         assert bad.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, combine, k.s) == 0
                     outs.append(out)
+                barrier.wait()                    # every rank has enqueued everything: the schedule, not thread timing, decides the order
                 k.sync()
                 seen.append(all(np.array_equal(o.view(np.uint32), want.view(np.uint32)) for o in outs))
                 k.close(barrier)

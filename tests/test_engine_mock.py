@@ -30,12 +30,13 @@ SCHEDULES = [(0, 0), (1, 0), (2, 21), (2, 22), (2, 23)]
 
 
 def _build(name, engine_source=None):
-    out = os.path.join(MOCK, name)
+    san = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g"] if os.environ.get("DDT_MOCK_SANITIZE") else []   # see tests/mock_hip/README
+    out = os.path.join(MOCK, name.replace(".so", "_asan.so") if san else name)
     srcs = [engine_source or os.path.join(CSRC, "ddt_engine.cpp")] + [os.path.join(CSRC, f) for f in SOURCES[1:]] + [os.path.join(MOCK, "mock_kernels.cpp")]
     deps = srcs + [os.path.join(MOCK, "mock_runtime.cpp"), os.path.join(MOCK, "hip", "hip_runtime.h"), os.path.join(MOCK, "rccl", "rccl.h"),
                    os.path.join(CSRC, "ddt_engine_priv.h"), os.path.join(CSRC, "ddt_internal.h")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-w", "-I" + MOCK, "-I" + CSRC, *srcs, "-o", out])
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-w", *san, "-I" + MOCK, "-I" + CSRC, *srcs, "-o", out])
     L = _lib.bind(C.CDLL(out))
     L.hipSetDevice.argtypes = [C.c_int]
     L.hipStreamCreateWithFlags.argtypes, L.hipStreamSynchronize.argtypes, L.hipStreamDestroy.argtypes = [C.POINTER(vp), C.c_uint], [vp], [vp]
