@@ -372,6 +372,7 @@ REMOVED_WAITS = {
 }
 
 
+@pytest.mark.skipif(bool(os.environ.get("DDT_MOCK_SANITIZE")), reason="the broken builds race on purpose")
 @pytest.mark.parametrize("which", sorted(REMOVED_WAITS))
 def test_the_model_catches_a_missing_dependency(which):
     """Remove ONE wait of the event protocol from the source: some schedule must then give wrong scores -- the proof that

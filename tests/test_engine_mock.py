@@ -409,6 +409,7 @@ REMOVED = {
 }
 
 
+@pytest.mark.skipif(bool(os.environ.get("DDT_MOCK_SANITIZE")), reason="the broken builds race on purpose")
 @pytest.mark.parametrize("which", sorted(REMOVED))
 def test_the_model_catches_a_missing_dependency_in_the_engine(which):
     needle, repl = REMOVED[which]
@@ -423,6 +424,7 @@ def test_the_model_catches_a_missing_dependency_in_the_engine(which):
         p = ddt.make_params(T, D, F, clusters=1)
         labels, cs = O.classify(m, x, K)
         wrong = 0
+        keep = []   # buffers that operations still queued on the engine's own stream may write: alive until the engine is gone
         for policy, seed in SCHEDULES:
             bad.mock_reset(policy, seed, 8)
             e, s = _engine(bad), _stream(bad)
@@ -432,11 +434,13 @@ def test_the_model_catches_a_missing_dependency_in_the_engine(which):
             if which == "feeder_drain":
                 assert bad.ddt_set_option(e, b"feeder_rows", 256) == 0
                 hl, hs = np.full(n, -1, np.int32), np.full((K, n), np.nan, np.float32)
+                keep.append((hl, hs))
                 assert bad.ddt_classify(e, x.ctypes.data, n, hl.ctypes.data, hs.ctypes.data) == 0
                 ok = np.array_equal(hl, labels) and np.array_equal(_bits(hs), _bits(cs))
             else:
                 for _ in range(2):
                     gs, gl = np.full((K, n), np.nan, np.float32), np.full(n, -1, np.int32)
+                    keep.append((gs, gl))
                     assert bad.ddt_classify_device(e, x.ctypes.data, n, gs.ctypes.data, gl.ctypes.data, s) == 0
                     assert bad.hipStreamSynchronize(s) == 0
                     ok = ok and np.array_equal(_bits(gs), _bits(cs)) and np.array_equal(gl, labels)
