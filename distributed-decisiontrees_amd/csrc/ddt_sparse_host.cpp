@@ -284,12 +284,15 @@ using namespace ddt;
 namespace {
 
 // validate the trees `ids` of the stream and copy them (re-based) into `out`
-int take_trees(ddt_engine* e, const ddt_params* p, const uint32_t* lines, const uint64_t* first, std::vector<uint32_t> ids, SparseForest* out) {
+int take_trees(ddt_engine* e, const ddt_params* p, const uint32_t* lines, size_t n_lines, const uint64_t* first, std::vector<uint32_t> ids,
+               SparseForest* out) {
   SparseForest sp;
   sp.first.assign(1, 0u);
   std::vector<uint8_t> depth;
   for (uint32_t id : ids) {
     if (first[id + 1] <= first[id]) return fail(e, DDT_EINVAL, "tree %u has no lines", id);
+    if (first[id + 1] > n_lines)  // an inner entry of tree_first_line may point past the stream even when the last one does not
+      return fail(e, DDT_EINVAL, "tree %u ends at line %llu of a stream of %zu lines", id, (unsigned long long)first[id + 1], n_lines);
     const uint64_t cnt = first[id + 1] - first[id];
     if (cnt > 0xFFFFFFFFull) return fail(e, DDT_EUNSUPPORTED, "tree %u has more than 2^32 nodes", id);
     const uint32_t* t = lines + first[id] * 4u;
@@ -360,7 +363,7 @@ extern "C" int ddt_load_model_sparse_multiclass(ddt_engine* e, const ddt_params*
       if (cls == k) ids.push_back(i);
     }
     // contiguous shards of ceil(T_class / G) trees (PCIeReceiver.sv:241-264); trailing shards may be empty: EMPTY slots, +0
-    int rc = take_trees(e, p, lines, first, shard_of(ids, shard_index, shard_count), &sps[k]);
+    int rc = take_trees(e, p, lines, n_lines, first, shard_of(ids, shard_index, shard_count), &sps[k]);
     if (rc) return rc;
     model_lines += sps[k].lines.size() / 4u;
   }
@@ -406,7 +409,7 @@ extern "C" int ddt_debug_sparse_image(const ddt_params* p, const void* node_line
   std::vector<uint32_t> ids(p->num_trees);
   for (uint32_t i = 0; i < p->num_trees; ++i) ids[i] = i;
   SparseForest sp;
-  int rc = take_trees(e.get(), p, reinterpret_cast<const uint32_t*>(node_lines), first, std::move(ids), &sp);
+  int rc = take_trees(e.get(), p, reinterpret_cast<const uint32_t*>(node_lines), n_lines, first, std::move(ids), &sp);
   if (rc) return rc;
   const Variant& v = variant(variant_id);
   std::vector<uint32_t> top, deep;

@@ -67,3 +67,19 @@ def test_random_and_corrupted_streams_never_crash_the_host_half(seed):
         seen.add(("sparse", mode, rcs[0]))
     assert ("model", 0) in seen or ("model", -5) in seen
     assert any(k[0] == "sparse" and k[2] == -1 for k in seen) and any(k[0] == "sparse" and k[2] == 0 for k in seen)
+
+
+def test_inner_entry_of_tree_first_line_past_the_stream_is_refused():
+    """Found by the AddressSanitizer run of the fuzz loop on the model build (tests/mock_hip/README.md): tree_first_line[0] = 0 and
+    tree_first_line[T] <= n_lines were checked, an INNER entry pointing past the stream was not -- the validator read the lines of a
+    tree that was not there before it reached the entry that is out of order."""
+    L = ddt.lib()
+    s = O.gen_sparse_model(3, 6, 8, 2, 600, 1)
+    lines = np.ascontiguousarray(s.node_lines, np.uint32).reshape(-1, 4)
+    first = np.ascontiguousarray(s.first, np.uint64).copy()
+    n = lines.shape[0]
+    first[1], first[2] = n + 50, n + 60                      # strictly increasing up to there, then back inside the stream
+    sinfo = (C.c_uint64 * 6)()
+    vid = [i for i, nm in enumerate(ddt.variant_names()) if nm.startswith("sparse")][0]
+    p = ddt.make_sparse_params(3, 6, 8)
+    assert L.ddt_debug_sparse_image(C.byref(p), lines.ctypes.data, n, first.ctypes.data, vid, 0, None, 0, None, 0, C.byref(sinfo)) == -1
