@@ -27,6 +27,7 @@ using namespace ddt;
 
 struct ddt_comm {
   ddt_engine* e = nullptr;
+  int device = 0;  // e->device at creation: the teardown must not read an engine that may already be gone
   int rank = 0, n = 1;
   ncclComm_t comm = nullptr;
   hipStream_t cs = nullptr;                       // the comm's own stream: collectives + chain adds
@@ -169,6 +170,7 @@ int ddt_comm_create(ddt_comm** out, ddt_engine* e, int rank, int n_ranks, const 
   std::unique_ptr<ddt_comm> c(new (std::nothrow) ddt_comm());
   if (!c) return DDT_ENOMEM;
   c->e = e;
+  c->device = e->device;
   c->rank = rank;
   c->n = n_ranks;
   DeviceGuard dg(e->device);
@@ -189,7 +191,7 @@ int ddt_comm_create(ddt_comm** out, ddt_engine* e, int rank, int n_ranks, const 
 
 void ddt_comm_destroy(ddt_comm* c) {
   if (!c) return;
-  DeviceGuard dg(c->e ? c->e->device : 0);
+  DeviceGuard dg(c->device);  // not c->e->device: a caller may have destroyed the engine first
   if (c->cs) (void)hipStreamSynchronize(c->cs);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   for (int b = 0; b < 2; ++b) {
@@ -211,7 +213,7 @@ void ddt_comm_destroy(ddt_comm* c) {
 
 const char* ddt_comm_last_error(const ddt_comm* c) {
   if (!c) return "";
-  return c->err[0] ? c->err : (c->e ? c->e->err : "");
+  return c->err;  // (engine failures are copied into c->err where they happen)
 }
 
 int ddt_comm_set_option(ddt_comm* c, const char* key, int64_t value) {
@@ -224,7 +226,7 @@ int ddt_comm_set_option(ddt_comm* c, const char* key, int64_t value) {
   if (!strcmp(key, "comm_stream_priority")) {  // 1 = the comm stream gets the device's highest stream priority (collective blocks are
     // dispatched ahead of the scoring launch's queued blocks as CUs free up), 0 = default priority
     if (value != 0 && value != 1) return cfail(c, DDT_EINVAL, "comm_stream_priority must be 0 or 1");
-    DeviceGuard dg(c->e ? c->e->device : 0);
+    DeviceGuard dg(c->device);
     hipStream_t ns = nullptr;
     if (value) {
       int least = 0, greatest = 0;
@@ -578,6 +580,7 @@ int ddt_group_create(ddt_group** out, int n_devices, const int* device_ids) {
       break;
     }
     c->e = g->eng[(size_t)i];
+    c->device = g->devices[(size_t)i];
     c->rank = i;
     c->n = n_devices;
     c->comm = comms[(size_t)i];

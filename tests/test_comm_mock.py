@@ -298,6 +298,23 @@ def test_single_process_group(mock, G, policy, seed):
     assert mock.mock_errors() == 0
 
 
+def test_teardown_in_either_order(mock):
+    """ddt_comm_destroy must not read the engine: a caller (or a garbage collector) may destroy the engine first."""
+    mock.mock_reset(0, 0, 8)
+
+    def body(r, barrier, shared):
+        k = Rank(mock, r, 2, barrier, shared)
+        x, out = _tuples(100), np.zeros(100, np.float32)
+        assert mock.ddt_score_sharded_device(k.c, x.ctypes.data, 100, out.ctypes.data, 1, k.s) == 0
+        k.sync()
+        barrier.wait()
+        mock.ddt_destroy(k.e)                     # engine first ...
+        mock.ddt_comm_destroy(k.c)                # ... then the communicator (run under DDT_MOCK_SANITIZE to see a stale read)
+        mock.hipStreamDestroy(k.s)
+
+    _run_ranks(2, body)
+
+
 def _makespan(mock, G, n, chunk, call, taper, cost_row=1.0, cost_float=0.25):
     """ASAP timeline of one call on every rank: scoring costs `cost_row` per row, a collective `cost_float` per float a rank
     moves (mock_runtime.cpp "Timeline")."""
