@@ -1227,24 +1227,22 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   if (!e || !key) return DDT_EINVAL;
   if (!strcmp(key, "variant")) {
     if (value >= num_variants()) return fail(e, DDT_EINVAL, "variant %lld out of range", (long long)value);
+    const int before = e->forced_variant;
     e->forced_variant = value < 0 ? -1 : (int)value;
-    if (e->loaded && e->sparse) {  // re-pack for the forced sparse kernel (or back to the automatic choice)
+    if (e->loaded) {  // re-pack the loaded model for the forced kernel (or back to the automatic choice)
       DeviceGuard dg(e->device);
       if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
       HIP_TRY(e, hipDeviceSynchronize());
       e->loaded = false;
-      int rc = sparse_rebuild(e);
-      if (rc) return rc;
-      e->loaded = true;
-      return DDT_OK;
-    }
-    if (e->loaded && !e->sparse) {
-      DeviceGuard dg(e->device);
-      if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
-      HIP_TRY(e, hipDeviceSynchronize());
-      e->loaded = false;
-      int rc = select_and_build(e);
-      if (rc) return rc;
+      int rc = e->sparse ? sparse_rebuild(e) : select_and_build(e);
+      if (rc) {  // e.g. the variant does not fit this model: the setting is not taken and the model stays loaded as it was
+        char why[sizeof(e->err)];
+        snprintf(why, sizeof(why), "%s", e->err);
+        e->forced_variant = before;
+        if ((e->sparse ? sparse_rebuild(e) : select_and_build(e)) == DDT_OK) e->loaded = true;
+        snprintf(e->err, sizeof(e->err), "%s", why);
+        return rc;
+      }
       e->loaded = true;
     }
     return DDT_OK;

@@ -397,6 +397,39 @@ def test_random_models_options_and_call_sequences(mock, seed):
         mock.ddt_destroy(e)
 
 
+def test_failed_changes_leave_the_loaded_model_in_place(mock):
+    """A variant that does not fit, an out-of-range variant id, a malformed reload, unknown or absurd options: each is refused with
+    an error code and the model that was loaded keeps scoring."""
+    mock.mock_reset(0, 0, 8)
+    e = _engine(mock)
+    m, x = O.gen_model(30, 8, 32, 1), O.gen_tuples(0, 500, 32, 1)
+    want, out = O.score(m, x), np.zeros(500, np.float32)
+    p = ddt.make_params(30, 8, 32)
+
+    def scores_still_right():
+        out[:] = np.nan
+        return mock.ddt_score(e, x.ctypes.data, 500, out.ctypes.data) == 0 and np.array_equal(_bits(out), _bits(want))
+
+    assert mock.ddt_score(e, x.ctypes.data, 500, out.ctypes.data) == -4                        # nothing loaded yet
+    _load(mock, e, m, p)
+    assert scores_still_right()
+    assert mock.ddt_set_option(e, b"variant", _variant(mock, "q16_d6_c16_u4")) == -5 and b"does not fit" in mock.ddt_last_error(e)
+    assert scores_still_right()
+    assert mock.ddt_set_option(e, b"variant", 9999) == -1 and scores_still_right()
+    bad = m.flines.copy()
+    bad[0] = 40                                                                                  # feature index >= F
+    assert mock.ddt_load_model(e, C.byref(p), m.wlines.ctypes.data, m.wlines.size // 4, bad.ctypes.data, bad.size // 8) == -1
+    assert scores_still_right()
+    for key in (b"feeder_rows", b"feeder_threads", b"reserve_rows", b"leaf_domain_check", b"nonsense"):
+        for val in (-5, 0, 1, 1 << 40):
+            mock.ddt_set_option(e, key, val)
+    assert mock.ddt_set_option(e, b"feeder_rows", 1 << 20) == 0 and scores_still_right()
+    mock.ddt_destroy(e)
+    mock.ddt_destroy(None)
+    mock.ddt_comm_destroy(None)
+    mock.ddt_group_destroy(None)
+
+
 REMOVED = {
     # the odd classes no longer wait for class 0's launch (and the rank pre-pass in front of it) on the caller's stream
     "class_stream_start": ("      HIP_TRY(e, hipEventRecord(e->class_ev[0], s));\n      HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));\n    }\n  }\n  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));",
