@@ -842,9 +842,71 @@ __device__ __forceinline__ void walk_trees_q16(const uint32_t base, const uint32
   }
 }
 
-template <int D, int CT, int U, bool GL = false>
+// "_s2": the records of levels 0 and 1 are wave-uniform data, so they do not have to come out of LDS: one s_load_dwordx4 per
+// tree fetches {padding, root, left, right} (bytes 0..15 of the tree's records in the GLOBAL image) through the scalar cache
+// into SGPRs, one sub-group of U trees ahead of the walk.  6 node reads per depth-8 tree on the LDS pipe instead of 8, for
+// two v_mov + one v_cndmask more on the VALU (the level-1 record is selected per lane).  The loads go through inline asm:
+// hipcc neither sinks them to their first use nor turns every LDS wait into lgkmcnt(0) while they are in flight (an older
+// outstanding SMEM only makes hipcc's own counted LDS waits stricter, never unsafe; top_wait() is the one full wait).
+// tools/ubench `walk`: 8.17 vs 7.84 T node visits/s for the bare walk.
+template <int U>
+struct TopRecs {
+  u32x4 t[U];
+};
+template <int TREE_STRIDE>
+__device__ __forceinline__ void top_issue(TopRecs<4>& q, const void* tree0) {
+  asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, %5\n\ts_load_dwordx4 %2, %4, %6\n\ts_load_dwordx4 %3, %4, %7"
+               : "=&s"(q.t[0]), "=&s"(q.t[1]), "=&s"(q.t[2]), "=&s"(q.t[3])
+               : "s"(tree0), "i"(TREE_STRIDE), "i"(2 * TREE_STRIDE), "i"(3 * TREE_STRIDE));
+}
+__device__ __forceinline__ void top_wait(TopRecs<4>& q) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.t[0]), "+s"(q.t[1]), "+s"(q.t[2]), "+s"(q.t[3]));
+}
+
+template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW>
+__device__ __forceinline__ void walk_trees_q16_s2(const TopRecs<U>& q, const uint32_t base, const uint32_t lane2, float (&leaf)[U],
+                                                  const float* __restrict__ gleaf) {
+  static_assert(D >= 3, "two scalar levels + at least one LDS level");
+  uint32_t m4[U], nd[U], f[U];
+  auto rank_at = [&](uint32_t rec) -> uint32_t {
+    const uint32_t off = SLOW ? ((rec >> 16) & 0xFFFEu) : (rec >> 16);
+    return *reinterpret_cast<const DDT_LDS(uint16_t)*>((off | lane2) + (uint32_t)FEAT_OFF);
+  };
+  auto goes_right = [&](uint32_t rec, uint32_t fv) -> bool {
+    bool right = fv >= (rec & 0xFFFFu);
+    if (SLOW) right = (fv == kQMissing) ? ((rec >> 16) & 1u) != 0u : right;
+    return right;
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) f[u] = rank_at(q.t[u].y);  // level 0: the root, uniform
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool r0 = goes_right(q.t[u].y, f[u]);
+    nd[u] = r0 ? q.t[u].w : q.t[u].z;  // level-1 record
+    m4[u] = r0 ? 12u : 8u;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) f[u] = rank_at(nd[u]);
+#pragma unroll
+  for (int u = 0; u < U; ++u) m4[u] = (m4[u] << 1) + (goes_right(nd[u], f[u]) ? 4u : 0u);
+#pragma unroll
+  for (int lvl = 2; lvl < D; ++lvl) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) nd[u] = lds_u32(m4[u] + (base + (uint32_t)(u * TREE_BYTES)));
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = rank_at(nd[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) m4[u] = (m4[u] << 1) + (goes_right(nd[u], f[u]) ? 4u : 0u);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) leaf[u] = gleaf[(m4[u] >> 2) - (1u << D) + (uint32_t)(u << D)];
+}
+
+template <int D, int CT, int U, int OPT = 0>
 __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, const Q16Aux x) {
   constexpr int THREADS = kQTile;
+  constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0;
+  static_assert(!S2 || (GL && U == 4), "_s2 is built on the _gl layout, 4 trees in flight");
   constexpr int TREE_BYTES = GL ? (4 << D) : (8 << D);  // bytes of a tree in LDS (GL: node records only)
   constexpr int CHUNK_BYTES = TREE_BYTES * CT;          // bytes of a chunk in LDS
   constexpr int GCHUNK_UNITS = (8 << D) * CT / 16;      // 16-byte units of a chunk in the global image
@@ -877,13 +939,27 @@ __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, co
   const uint32_t C = a.clusters, lane2 = (((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1);  // see rank_kernel
   const int SUM1 = (int)a.sum_mode;
 
+  // _s2: `top` holds the level-0/1 records of the sub-group about to be walked; the next sub-group's (same chunk, or the first
+  // of the next chunk; past the end: chunk 0 again, never used) are requested before the walk
+  TopRecs<4> top, top_next;
+  if constexpr (S2) top_issue<TREE_BYTES>(top, img);
 #define DDT_QCOMPUTE(BUF, PH, KIDX)                                                                    \
   do {                                                                                                 \
     _Pragma("unroll") for (int sg = 0; sg < CT / U; ++sg) {                                            \
       float lf[1][U];                                                                                  \
       const float* gl = GL ? reinterpret_cast<const float*>(img + (size_t)(KIDX) * GCHUNK_UNITS) + (CT + sg * U) * (1 << D) : nullptr; \
-      if (!slow) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
-      else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+      if constexpr (S2) {                                                                              \
+        const uint32_t kn = (sg + 1 < CT / U) ? (uint32_t)(KIDX) : ((uint32_t)(KIDX) + 1u < n_chunks ? (uint32_t)(KIDX) + 1u : 0u); \
+        const int sn = (sg + 1 < CT / U) ? sg + 1 : 0;                                                 \
+        top_wait(top);                                                                                 \
+        top_issue<TREE_BYTES>(top_next, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
+        if (!slow) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false>(top, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+        else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true>(top, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+        top = top_next;                                                                                \
+      } else {                                                                                         \
+        if (!slow) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+        else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+      }                                                                                                \
       if (SUM1 == 0) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc);                           \
       else fold_leaves<U, 1, 1>(lf, ((PH) + sg) & 1, C, ra, dacc);                                     \
     }                                                                                                  \
@@ -892,7 +968,7 @@ __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, co
   // (tried twice, both slower, both removed -- numbers in profiles/r01_tile_overhead.md: levels 0-1 from SGPRs via
   // hidden s_load_dwordx4 of the next chunk's top records, and levels 0-1 tested against ranks kept in 16 VGPRs with
   // a wave-uniform register index; 15 DS ops per tree instead of 17 either way, but the extra wait points cost more
-  // than the LDS cycles they save.)
+  // than the LDS cycles they save.  Round 3's _s2 form above differs in where the loads are issued and waited for.)
   constexpr int PH1 = (CT == 4) ? 1 : 0;
   for (uint32_t k = 0; k < n_chunks; k += 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -907,19 +983,20 @@ __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, co
     DDT_QCOMPUTE(1, PH1, k + 1);
   }
 #undef DDT_QCOMPUTE
+  if constexpr (S2) top_wait(top);  // the last request (never used) must not outlive the wave
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (SUM1 == 0) ? ra.total(0, C) : (float)dacc[0];
 }
 
-template <int D, int CT, int U, bool GL = false>
+template <int D, int CT, int U, int OPT = 0>
 static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const Q16Aux& x = *reinterpret_cast<const Q16Aux*>(a.aux);
   const uint64_t tiles = (a.n + kQTile - 1) / kQTile;
   if (tiles == 0) return hipSuccess;
   if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
   const uint32_t W = a.tuple_words;
-  auto kern = score_q16_kernel<D, CT, U, GL>;
+  auto kern = score_q16_kernel<D, CT, U, OPT>;
   const uint32_t lds = v.lds_bytes_q16(W);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1235,7 +1312,9 @@ hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t 
 #define DDT_Q(NAME, D, CT, U) \
   Variant { NAME, kKindQ16, D, kQTile, 1, CT, U, 1, 0, &launch_q16<D, CT, U> }
 #define DDT_QG(NAME, D, CT, U) /* leaves gathered from global memory: only the node records are staged, twice the trees per chunk */ \
-  Variant { NAME, kKindQ16, D, kQTile, 1, CT, U, 1, 1, &launch_q16<D, CT, U, true> }
+  Variant { NAME, kKindQ16, D, kQTile, 1, CT, U, 1, 1, &launch_q16<D, CT, U, 1> }
+#define DDT_QGS(NAME, D, CT, U) /* _gl + levels 0-1 from SGPRs (scalar loads) */ \
+  Variant { NAME, kKindQ16, D, kQTile, 1, CT, U, 1, 3, &launch_q16<D, CT, U, 3> }
 
 static const Variant g_variants[] = {
     Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_generic},
@@ -1245,6 +1324,7 @@ static const Variant g_variants[] = {
     // records are staged: the most conflict-laden LDS read of a tree (256 leaves behind 32 banks) is gone and a chunk holds 8
     // trees, so half the barriers.  1000 trees x 50 M tuples: 56.4 vs 59.4 ms; 8 trees in flight per lane (u8): 58.6
     DDT_QG("q16_d8_c8_u4_gl", 8, 8, 4),
+    DDT_QGS("q16_d8_c8_u4_gl_s2", 8, 8, 4),
     DDT_Q("q16_d6_c16_u4", 6, 16, 4),
     DDT_Q("q16_d4_c64_u8", 4, 64, 8),
     // odd depths (XGBoost / scikit-learn defaults 3, 5, 7): same 8 KiB chunks

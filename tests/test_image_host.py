@@ -148,16 +148,16 @@ def _check(T, D, F, variant_name, dist, cmp_mode=0, n=96, expect_auto=None):
 
 
 def test_headline_model_takes_the_gl_rank_quantised_image():
-    nfo = _check(1000, 8, 32, None, 0, n=48, expect_auto="q16_d8_c8_u4_gl")
+    nfo = _check(1000, 8, 32, None, 0, n=48, expect_auto="q16_d8_c8_u4_gl_s2")
     assert nfo["kind"] == Q16 and nfo["opt"] & 1 and nfo["chunk_trees"] == 8 and nfo["Tpad"] == 1000 and nfo["tile"] == 1024
 
 
 def test_eight_way_shard_of_the_headline_model():
-    nfo = _check(125, 8, 32, None, 0, n=48, expect_auto="q16_d8_c8_u4_gl")
+    nfo = _check(125, 8, 32, None, 0, n=48, expect_auto="q16_d8_c8_u4_gl_s2")
     assert nfo["Tpad"] == 128                                          # whole chunks of 8: three EMPTY trees
 
 
-@pytest.mark.parametrize("name,T,D,F", [("q16_d8_c8_u4_gl", 37, 8, 32), ("q16_d8_c4_u4", 37, 8, 32), ("q16_d6_c16_u4", 100, 6, 28),
+@pytest.mark.parametrize("name,T,D,F", [("q16_d8_c8_u4_gl_s2", 37, 8, 32), ("q16_d8_c8_u4_gl", 37, 8, 32), ("q16_d8_c4_u4", 37, 8, 32), ("q16_d6_c16_u4", 100, 6, 28),
                                         ("q16_d4_c64_u8", 9, 4, 16), ("q16_d3_c128_u8", 130, 3, 7), ("q16_d10_c4_u4", 5, 10, 20)])
 def test_rank_quantised_images_with_missing_values(name, T, D, F):
     _check(T, D, F, name, 1)

@@ -28,7 +28,7 @@ def _params(m, sum_mode=0):
     return ddt.make_params(p.num_trees, p.num_levels, p.num_features, p.missing_bits, p.cmp_mode, p.clusters_per_tuple, sum_mode)
 
 
-@pytest.mark.parametrize("kernel", ["q16_d8_c8_u4_gl", "q16_d8_c4_u4"])  # leaves gathered from global memory / leaves staged in LDS
+@pytest.mark.parametrize("kernel", ["q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4"])  # levels 0-1 from SGPRs / leaves gathered from global memory / leaves staged in LDS
 @pytest.mark.parametrize("cmp_mode", [0, 1])
 def test_values_on_and_next_to_thresholds(cmp_mode, kernel):
     T, D, F, n = 200, 8, 32, 4096
@@ -58,15 +58,15 @@ def test_auto_selection_and_fallbacks():
     e = ddt.Engine(0)
     w, f = ddt.synth_model(1000, 8, 32)
     e.load_model(ddt.make_params(1000, 8, 32), w, f)
-    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl"        # many trees: the pre-pass pays off
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2"        # many trees: the pre-pass pays off
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)          # 125 trees per engine (8-way shard): all rank tables
-    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl"        # fit LDS together -> fused pre-pass -> q16 still pays
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2"        # fit LDS together -> fused pre-pass -> q16 still pays
     _prepass(e, -1)                                                 # with the transpose + rank kernels the fixed pre-pass cost is too high
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)
     assert e.info().variant_name.decode() == "d8_t1024_r1_c4_u4_dma_f"
     _prepass(e, 0)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 12)         # 84 trees x 8 levels >= 640: q16 with the LDS-resident pre-pass
-    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl" and e.info().prepass_groups in (1, 2, 4, 8)
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2" and e.info().prepass_groups in (1, 2, 4, 8)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 16)         # 63 trees: below the break-even either way
     assert e.info().prepass_groups == 0
     with pytest.raises(ddt.DDTError):

@@ -1,0 +1,771 @@
+// ubench.hip -- gfx950 microbenchmarks that pin the ceilings the scoring kernels are judged against
+// (VERDICT r2 item 3).  Stand-alone: hipcc --offload-arch=gfx950 -O3 ubench.hip -o ubench; prints one JSON object.
+//   valu    issue rate of the VALU instructions the walk is made of (cycles per wave instruction and SIMD)
+//   lds     ds_read_b32 / u16 / b64 rates, conflict-free and at per-lane random addresses
+//   walk    the bare tree walk (no DMA, no barriers, model resident in LDS, 32 waves per CU) in the forms
+//           under study: v0 = 4-byte records, leaves in LDS; v0gl = leaves gathered from global memory (the
+//           shipped q16 kernel's inner loop); v1 = 8-byte records with explicit child pointers (3 VALU per
+//           visit); v2 = v1 with the last level + leaves as one 16-byte global record per node
+//   gather  vector-memory gather rate out of an L1-resident window (4 / 8 / 16 bytes per lane)
+//   hbm     read-only HBM probe (16 B per lane, persistent blocks)
+// Measurement infrastructure, not product code: nothing in libddt.so includes or links this file.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#define CK(x)                                                                          \
+  do {                                                                                 \
+    hipError_t e_ = (x);                                                               \
+    if (e_ != hipSuccess) {                                                            \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(1);                                                                         \
+    }                                                                                  \
+  } while (0)
+
+#define LDS(T) __attribute__((address_space(3))) T
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_u32(uint32_t a) { return *reinterpret_cast<const LDS(uint32_t)*>(a); }
+__device__ __forceinline__ uint32_t lds_u16(uint32_t a) { return *reinterpret_cast<const LDS(uint16_t)*>(a); }
+__device__ __forceinline__ u32x2 lds_u64(uint32_t a) { return *reinterpret_cast<const LDS(u32x2)*>(a); }
+__device__ __forceinline__ float lds_f32(uint32_t a) { return *reinterpret_cast<const LDS(float)*>(a); }
+__device__ __forceinline__ void lds_st4(uint32_t a, u32x4 v) { *reinterpret_cast<LDS(u32x4)*>(a) = v; }
+
+static double g_clock_ghz = 2.4;
+static int g_cus = 256;
+
+struct Timer {
+  hipEvent_t a, b;
+  Timer() {
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+  }
+  void start() { CK(hipEventRecord(a, 0)); }
+  double stop_ms() {
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// VALU issue rates: 8 independent chains, 64 instructions per loop body, 8 waves per SIMD
+// ------------------------------------------------------------------------------------------------
+enum { OP_ADD = 0, OP_OR_SDWA, OP_CMP_CND, OP_CMP_SDWA_CND, OP_LSHL_ADD, OP_AND_OR, OP_CND_SDWA, OP_ADDC, OP_ALIGNBIT, OP_FMA, OP_PK_ADD_U16,
+       OP_LSHL_OR, OP_BFE, OP_PERM, OP_CND_E64, OP_SEQ_CUR, OP_SEQ_VCC, OP_SEQ_ADDC, OP_LSHLREV, OP_CMP16, OP_COUNT };
+static const char* kOpName[OP_COUNT] = {"v_add_u32", "v_or_b32_sdwa", "v_cmp_ge_u32+v_cndmask", "v_cmp_ge_u32_sdwa+v_cndmask", "v_lshl_add_u32",
+                                        "v_and_or_b32", "v_cndmask_b32_sdwa", "v_addc_co_u32", "v_alignbit_b32", "v_fma_f32", "v_pk_add_u16",
+                                        "v_lshl_or_b32", "v_bfe_u32", "v_perm_b32", "v_cmp_ge_u32_e64->sgpr + v_cndmask_b32_e64",
+                                        "visit: or_sdwa + cmp_sdwa->sgpr + cndmask_e64 + lshl_or (hipcc today)", "visit: or_sdwa + cmp_sdwa->vcc + cndmask_e32 + lshl_or",
+                                        "visit: or_sdwa + cmp_sdwa->vcc + addc_e32 + lshlrev_e32", "v_lshlrev_b32_e32", "v_cmp_eq_u16_e32 (exact-sum suspect test)"};
+static const int kOpInsts[OP_COUNT] = {1, 1, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 4, 4, 4, 1, 1};
+
+template <int OP>
+__global__ __launch_bounds__(256) void valu_kernel(uint32_t* out, int iters, uint32_t seed) {
+  uint32_t x[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = seed * (threadIdx.x + 1) + k * 977u;
+  const uint32_t y = seed ^ 0x9E3779B9u ^ threadIdx.x;
+  uint32_t z = threadIdx.x * 4u, vzero = 0u;
+  asm volatile("" : "+v"(z), "+v"(vzero));
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int rep = 0; rep < 8; ++rep) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (OP == OP_ADD) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[k]) : "v"(y));
+        if (OP == OP_OR_SDWA) asm volatile("v_or_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(x[k]) : "v"(y));
+        if (OP == OP_CMP_CND) asm volatile("v_cmp_ge_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[k]) : "v"(y) : "vcc");
+        if (OP == OP_CMP_SDWA_CND)
+          asm volatile("v_cmp_ge_u32_sdwa vcc, %0, %1 src0_sel:DWORD src1_sel:WORD_0\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[k]) : "v"(y) : "vcc");
+        if (OP == OP_LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x[k]) : "v"(y));
+        if (OP == OP_AND_OR) asm volatile("v_and_or_b32 %0, %0, %2, %1" : "+v"(x[k]) : "v"(y), "s"(0xf800u));
+        if (OP == OP_CND_SDWA)
+          asm volatile("v_cndmask_b32_sdwa %0, %0, %1, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "+v"(x[k]) : "v"(y) : "vcc");
+        if (OP == OP_ADDC) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x[k]) : : "vcc");
+        if (OP == OP_ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 10" : "+v"(x[k]) : "v"(y));
+        if (OP == OP_FMA) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[k]) : "v"(y));
+        if (OP == OP_PK_ADD_U16) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x[k]) : "v"(y));
+        if (OP == OP_LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(x[k]) : "v"(y));
+        if (OP == OP_BFE) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(x[k]));
+        if (OP == OP_PERM) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(x[k]) : "v"(y));
+        if (OP == OP_CND_E64) {
+          uint64_t mk;
+          asm volatile("v_cmp_ge_u32_e64 %1, %0, %2\n\tv_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(x[k]), "=&s"(mk) : "v"(y));
+        }
+        if (OP == OP_SEQ_CUR) {
+          uint64_t mk;
+          uint32_t t;
+          asm volatile("v_or_b32_sdwa %1, %3, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                       "v_cmp_gt_u32_sdwa %2, %3, %1 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                       "v_cndmask_b32_e64 %1, 4, 0, %2\n\t"
+                       "v_lshl_or_b32 %0, %0, 1, %1"
+                       : "+v"(x[k]), "=&v"(t), "=&s"(mk)
+                       : "v"(y), "v"(z));
+        }
+        if (OP == OP_SEQ_VCC) {
+          uint32_t t;
+          asm volatile("v_or_b32_sdwa %1, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                       "v_cmp_gt_u32_sdwa vcc, %2, %1 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                       "v_cndmask_b32_e32 %1, 4, %4, vcc\n\t"
+                       "v_lshl_or_b32 %0, %0, 1, %1"
+                       : "+v"(x[k]), "=&v"(t)
+                       : "v"(y), "v"(z), "v"(vzero)
+                       : "vcc");
+        }
+        if (OP == OP_SEQ_ADDC) {
+          uint32_t t;
+          asm volatile("v_or_b32_sdwa %1, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                       "v_cmp_le_u32_sdwa vcc, %2, %1 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                       "v_addc_co_u32_e32 %0, vcc, %0, %0, vcc\n\t"
+                       "v_lshlrev_b32_e32 %1, 2, %0"
+                       : "+v"(x[k]), "=&v"(t)
+                       : "v"(y), "v"(z)
+                       : "vcc");
+        }
+        if (OP == OP_LSHLREV) asm volatile("v_lshlrev_b32_e32 %0, 1, %0" : "+v"(x[k]));
+        if (OP == OP_CMP16) asm volatile("v_cmp_eq_u16_e32 vcc, -1, %0" : : "v"(x[k]) : "vcc");
+      }
+    }
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s ^= x[k];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int OP>
+static void run_valu(uint32_t* d_out, std::string& js) {
+  const int iters = 4000, blocks = g_cus * 8;  // 8 blocks x 4 waves = 32 waves per CU = 8 per SIMD
+  Timer t;
+  hipLaunchKernelGGL(valu_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 10, 12345u);
+  CK(hipDeviceSynchronize());
+  t.start();
+  hipLaunchKernelGGL(valu_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 12345u);
+  const double ms = t.stop_ms();
+  const double wave_insts_per_simd = (double)iters * 64.0 * kOpInsts[OP] * 8.0;  // 8 waves per SIMD
+  const double cycles = ms * 1e-3 * g_clock_ghz * 1e9;
+  char buf[256];
+  snprintf(buf, sizeof buf, "    {\"op\": \"%s\", \"ms\": %.3f, \"cycles_per_wave_inst_per_simd\": %.3f},\n", kOpName[OP], ms, cycles / wave_insts_per_simd);
+  js += buf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS read rates.  MODE 0: ds_read_b32 conflict-free (lane*4), 1: ds_read_u16 conflict-free (the rank gather's
+// pattern), 2: ds_read_b32 random within 1 KiB, 3: ds_read_b64 conflict-free, 4: ds_read_b64 random (8-byte
+// aligned) within 1 KiB, 5: random within 512 B b32, 6: b64 random within 512 B, 7: b32 random within 256 B
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(1024) void lds_kernel(uint32_t* out, int iters) {
+  extern __shared__ uint32_t smem[];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < 16384; i += 1024) smem[i] = (i * 2654435761u) >> 7;
+  __syncthreads();
+  const uint32_t lane = tid & 63u;
+  uint32_t a[8], acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t r = (tid * 2654435761u + k * 40503u) >> 5;
+    if (MODE == 0) a[k] = lane * 4u + k * 2048u;
+    if (MODE == 1) a[k] = lane * 4u + ((tid >> 9) << 1) + k * 2048u;
+    if (MODE == 2) a[k] = (r & 0x3FCu) + k * 1024u;
+    if (MODE == 3) a[k] = lane * 8u + k * 2048u;
+    if (MODE == 4) a[k] = (r & 0x3F8u) + k * 1024u;
+    if (MODE == 5) a[k] = (r & 0x1FCu) + k * 1024u;
+    if (MODE == 6) a[k] = (r & 0x1F8u) + k * 1024u;
+    if (MODE == 7) a[k] = (r & 0xFCu) + k * 1024u;
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+      uint32_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (MODE == 1) v[k] = lds_u16(a[k]);
+        else if (MODE == 3 || MODE == 4 || MODE == 6) {
+          const u32x2 t = lds_u64(a[k]);
+          v[k] = t.x ^ t.y;
+        } else v[k] = lds_u32(a[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += v[k];
+      asm volatile("" ::: "memory");
+    }
+  }
+  out[blockIdx.x * 1024 + tid] = acc;
+}
+
+template <int MODE>
+static void run_lds(uint32_t* d_out, std::string& js, const char* name) {
+  const int iters = 2000, blocks = g_cus * 2;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  Timer t;
+  hipLaunchKernelGGL(lds_kernel<MODE>, dim3(blocks), dim3(1024), 65536, 0, d_out, 10);
+  CK(hipDeviceSynchronize());
+  t.start();
+  hipLaunchKernelGGL(lds_kernel<MODE>, dim3(blocks), dim3(1024), 65536, 0, d_out, iters);
+  const double ms = t.stop_ms();
+  const double wave_insts_per_cu = (double)iters * 32.0 * 32.0;  // 32 DS ops per iteration, 32 waves per CU
+  const double cycles = ms * 1e-3 * g_clock_ghz * 1e9;
+  char buf[256];
+  snprintf(buf, sizeof buf, "    {\"pattern\": \"%s\", \"ms\": %.3f, \"cycles_per_wave_inst_per_cu\": %.3f},\n", name, ms, cycles / wave_insts_per_cu);
+  js += buf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The bare walk.  Block = 1024 lanes (tuples), 2 blocks per CU (80 KiB each, the product's geometry); LDS: [0, 16 KiB)
+// model region (resident: the kernel loops over it), [16 KiB, 80 KiB) u16 rank tile [32 features][1024] laid out as in
+// the product (tuple t: dword t % 512, half t / 512).  D = 8, U = 4 trees in flight per lane, no DMA, no barriers.
+//   LEAF 0: 4-byte records + leaves in LDS (2 KiB per tree)        LEAF 1: leaves gathered from global memory (1 KiB)
+//   LEAF 2: levels 0..6 in LDS (512 B per tree), level 7 = one 16-byte global record {rank | row << 16, 0, leafL, leafR}
+//   FORM 0: plain C++ (hipcc: v_or_b32_sdwa, v_cmp_*_sdwa -> SGPR pair, v_cndmask_b32_e64, v_lshl_or_b32)
+//   FORM 1: compare -> VCC and v_cndmask_b32_e32 (32-bit encodings) through inline asm
+//   FORM 2: heap index in record units, m <- m + m + VCC (v_addc_co_u32_e32), address = m << 2
+//   PTR   : 8-byte records with explicit child offsets, select by v_cndmask_b32_sdwa (measured: a trap, 23 cycles)
+// ------------------------------------------------------------------------------------------------
+constexpr int kD = 8, kTrees = 32, kFeatOff = 16384, kRow = 2048;
+struct WalkArgs {
+  const u32x4* model;   // LDS model image of the variant (16 KiB)
+  const u32x4* tile;    // 64 KiB rank tile
+  const float* gleaf;   // leaves [kTrees][256]
+  const u32x4* glast;   // level-7 records [kTrees][128]
+  const u32x4* tops;    // {root, left, right, 0} records of levels 0-1 per tree (scalar loads, FORM 3)
+  float* out;
+  int groups;           // passes over the resident trees
+};
+
+template <int FORM>
+__device__ __forceinline__ void visit(uint32_t& m, const uint32_t nd, const uint32_t f, const uint32_t vzero) {
+  if (FORM == 0) m = (m << 1) + ((f >= (nd & 0xFFFFu)) ? 4u : 0u);
+  if (FORM == 1) {
+    uint32_t sel;
+    asm("v_cmp_gt_u32_sdwa vcc, %1, %2 src0_sel:WORD_0 src1_sel:DWORD\n\tv_cndmask_b32_e32 %0, 4, %3, vcc" : "=v"(sel) : "v"(nd), "v"(f), "v"(vzero) : "vcc");
+    m = (m << 1) | sel;
+  }
+  if (FORM == 2) asm("v_cmp_le_u32_sdwa vcc, %1, %2 src0_sel:WORD_0 src1_sel:DWORD\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(nd), "v"(f) : "vcc");
+}
+
+template <int LEAF, int FORM>
+__device__ __forceinline__ void walk_rec4(const uint32_t base, const uint32_t lane2, const uint32_t vzero, float (&leaf)[4], const float* gleaf,
+                                          const char* glast) {
+  constexpr int TB = LEAF == 0 ? (8 << kD) : LEAF == 1 ? (4 << kD) : (2 << kD);
+  constexpr int LV = LEAF == 2 ? kD - 1 : kD;
+  constexpr uint32_t SC = FORM == 2 ? 1u : 4u;  // units of m: records or bytes
+  uint32_t m[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) m[u] = SC;
+#pragma unroll
+  for (int lvl = 0; lvl < LV; ++lvl) {
+    uint32_t nd[4], f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) nd[u] = lds_u32((FORM == 2 ? m[u] << 2 : m[u]) + (base + (uint32_t)(u * TB)));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = lds_u16(((nd[u] >> 16) | lane2) + (uint32_t)kFeatOff);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) visit<FORM>(m[u], nd[u], f[u], vzero);
+  }
+  if (LEAF == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) leaf[u] = lds_f32(m[u] * (4u / SC) + (base + (uint32_t)(u * TB)));
+  } else if (LEAF == 1) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) leaf[u] = gleaf[m[u] / SC - (1u << kD) + (uint32_t)(u << kD)];
+  } else {
+    u32x4 rec[4];
+    uint32_t f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)  // record j of the tree at byte 16 j; m / SC = 128 + j
+      rec[u] = *reinterpret_cast<const u32x4*>(glast + (m[u] * (16u / SC)) + (uint32_t)(u * 2048) - 2048u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = lds_u16(((rec[u].x >> 16) | lane2) + (uint32_t)kFeatOff);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) leaf[u] = __uint_as_float((f[u] >= (rec[u].x & 0xFFFFu)) ? rec[u].w : rec[u].z);
+  }
+}
+
+// FORM 3 ("top2"): the records of levels 0 and 1 are wave-uniform data: they come through the scalar cache into SGPRs
+// (s_load_dwordx4 per tree, issued one sub-group ahead through inline asm so that hipcc neither moves them nor turns every
+// LDS wait into lgkmcnt(0) while they are in flight) and never touch the LDS pipe: 6 node reads per tree instead of 8.
+struct Top4 {
+  u32x4 t[4];
+};
+__device__ __forceinline__ void top_issue(Top4& q, const u32x4* p) {
+  asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\ts_load_dwordx4 %3, %4, 0x30"
+               : "=&s"(q.t[0]), "=&s"(q.t[1]), "=&s"(q.t[2]), "=&s"(q.t[3])
+               : "s"(p));
+}
+__device__ __forceinline__ void top_wait(Top4& q) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.t[0]), "+s"(q.t[1]), "+s"(q.t[2]), "+s"(q.t[3]));
+}
+template <int LEAF>
+__device__ __forceinline__ void walk_top2(const Top4& q, const uint32_t base, const uint32_t lane2, float (&leaf)[4], const float* gleaf, const char* glast) {
+  constexpr int TB = LEAF == 1 ? (4 << kD) : (2 << kD);
+  constexpr int LV = LEAF == 2 ? kD - 1 : kD;
+  uint32_t m[4], f[4], nd[4];
+  // level 0: uniform record in SGPRs
+#pragma unroll
+  for (int u = 0; u < 4; ++u) f[u] = lds_u16(((q.t[u].x >> 16) | lane2) + (uint32_t)kFeatOff);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const bool r0 = f[u] >= (q.t[u].x & 0xFFFFu);
+    nd[u] = r0 ? q.t[u].z : q.t[u].y;  // level-1 record
+    m[u] = r0 ? 12u : 8u;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) f[u] = lds_u16(((nd[u] >> 16) | lane2) + (uint32_t)kFeatOff);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) visit<0>(m[u], nd[u], f[u], 0u);
+#pragma unroll
+  for (int lvl = 2; lvl < LV; ++lvl) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) nd[u] = lds_u32(m[u] + (base + (uint32_t)(u * TB)));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = lds_u16(((nd[u] >> 16) | lane2) + (uint32_t)kFeatOff);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) visit<0>(m[u], nd[u], f[u], 0u);
+  }
+  if (LEAF == 1) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) leaf[u] = gleaf[m[u] / 4u - (1u << kD) + (uint32_t)(u << kD)];
+  } else {
+    u32x4 rec[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rec[u] = *reinterpret_cast<const u32x4*>(glast + (m[u] * 4u) + (uint32_t)(u * 2048) - 2048u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = lds_u16(((rec[u].x >> 16) | lane2) + (uint32_t)kFeatOff);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) leaf[u] = __uint_as_float((f[u] >= (rec[u].x & 0xFFFFu)) ? rec[u].w : rec[u].z);
+  }
+}
+
+__device__ __forceinline__ uint32_t sel_ptr(uint32_t f, uint32_t lo, uint32_t hi) {
+  uint32_t r;
+  asm("v_cmp_ge_u32_sdwa vcc, %1, %2 src0_sel:DWORD src1_sel:WORD_0\n\t"
+      "v_cndmask_b32_sdwa %0, %3, %3, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+      : "=v"(r)
+      : "v"(f), "v"(lo), "v"(hi)
+      : "vcc");
+  return r;
+}
+__device__ __forceinline__ void walk_ptr(const uint32_t base, const uint32_t lane2, float (&leaf)[4], const float* gleaf) {
+  constexpr int TB = 8 << kD;
+  uint32_t p[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) p[u] = 0u;  // root record at offset 0 of the tree
+#pragma unroll
+  for (int lvl = 0; lvl < kD; ++lvl) {
+    u32x2 nd[4];
+    uint32_t f[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) nd[u] = lds_u64(p[u] + (base + (uint32_t)(u * TB)));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = lds_u16(((nd[u].x >> 16) | lane2) + (uint32_t)kFeatOff);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = sel_ptr(f[u], nd[u].x, nd[u].y);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) leaf[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(gleaf) + p[u]);
+}
+
+// VAR = LEAF * 4 + FORM for the 4-byte-record forms; 12 = pointer form
+template <int VAR>
+__global__ __launch_bounds__(1024) void walk_kernel(const WalkArgs a) {
+  const uint32_t tid = threadIdx.x;
+  constexpr int LEAF = VAR / 4, FORM = VAR % 4;
+  constexpr int TB = VAR == 12 ? (8 << kD) : LEAF == 0 ? (8 << kD) : LEAF == 1 ? (4 << kD) : (2 << kD);  // LDS bytes per tree
+  constexpr int NT = 16384 / TB;  // resident trees
+  for (uint32_t i = tid; i < 16384u / 16u; i += 1024) lds_st4(i * 16u, a.model[i]);
+  for (uint32_t i = tid; i < 65536u / 16u; i += 1024) lds_st4((uint32_t)kFeatOff + i * 16u, a.tile[i]);
+  __syncthreads();
+  uint32_t lane2 = ((tid & 511u) << 2) | ((tid >> 9) << 1), vzero = 0u;
+  float acc = 0.f;
+  if (VAR != 12 && FORM == 3) {
+    constexpr int L3 = LEAF == 0 ? 1 : LEAF;
+    Top4 cur, nxt;
+    top_issue(cur, a.tops);
+    for (int g = 0; g < a.groups; ++g) {
+      asm volatile("" : "+v"(lane2));
+#pragma unroll
+      for (int sg = 0; sg < NT / 4; ++sg) {
+        float lf[4];
+        top_wait(cur);
+        top_issue(nxt, a.tops + ((sg + 1) % (NT / 4)) * 4);
+        walk_top2<L3>(cur, (uint32_t)(sg * 4 * TB), lane2, lf, a.gleaf + sg * 4 * (1 << kD), reinterpret_cast<const char*>(a.glast) + sg * 4 * 2048);
+        acc += (lf[0] + lf[1]) + (lf[2] + lf[3]);
+        cur = nxt;
+      }
+    }
+    top_wait(cur);
+    a.out[(size_t)blockIdx.x * 1024 + tid] = acc;
+    return;
+  }
+  for (int g = 0; g < a.groups; ++g) {
+    asm volatile("" : "+v"(lane2), "+v"(vzero));  // opaque per pass: keeps hipcc from hoisting the (loop-invariant) walk
+#pragma unroll
+    for (int sg = 0; sg < NT / 4; ++sg) {
+      float lf[4];
+      if (VAR == 12) walk_ptr((uint32_t)(sg * 4 * TB), lane2, lf, a.gleaf + sg * 4 * (1 << kD));
+      else
+        walk_rec4<LEAF, FORM>((uint32_t)(sg * 4 * TB), lane2, vzero, lf, a.gleaf + sg * 4 * (1 << kD),
+                              reinterpret_cast<const char*>(a.glast) + sg * 4 * 2048);
+      acc += (lf[0] + lf[1]) + (lf[2] + lf[3]);
+    }
+  }
+  a.out[(size_t)blockIdx.x * 1024 + tid] = acc;
+}
+
+struct HostTrees {
+  std::vector<uint32_t> thr, feat;  // [kTrees][255], 0-based heap
+  std::vector<float> leaf;          // [kTrees][256]
+  std::vector<uint16_t> tile;       // [32][1024] in product layout
+};
+
+static uint64_t sm64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static float cpu_walk(const HostTrees& h, uint32_t t, int groups, int nt) {
+  // mirrors walk_kernel's sum: per sub-group (l0+l1)+(l2+l3), accumulated sequentially, `groups` times
+  const uint32_t dword = t & 511u, half = t >> 9;
+  float acc = 0.f;
+  for (int g = 0; g < groups; ++g)
+    for (int sg = 0; sg < nt / 4; ++sg) {
+      float lf[4];
+      for (int u = 0; u < 4; ++u) {
+        const int i = sg * 4 + u;
+        uint32_t n = 0;
+        for (int l = 0; l < kD; ++l) {
+          const uint32_t f = h.tile[(size_t)h.feat[i * 255 + n] * 1024 + dword * 2 + half];
+          n = 2 * n + 1 + (f >= h.thr[i * 255 + n] ? 1u : 0u);
+        }
+        lf[u] = h.leaf[i * 256 + (n - 255)];
+      }
+      acc += (lf[0] + lf[1]) + (lf[2] + lf[3]);
+    }
+  return acc;
+}
+
+struct WalkVariant {
+  int var, nt;
+  const char* name;
+};
+static const WalkVariant kWalks[] = {
+    {0, 8, "rec4 leaves in LDS, C++"},
+    {4, 16, "rec4 leaves global (the shipped q16_gl inner loop), C++"},
+    {5, 16, "rec4 leaves global, cmp->vcc + v_cndmask_e32 (asm)"},
+    {6, 16, "rec4 leaves global, v_addc index (asm)"},
+    {7, 16, "rec4 leaves global, levels 0-1 from SGPRs (s_load one sub-group ahead)"},
+    {11, 32, "gl2 + levels 0-1 from SGPRs"},
+    {8, 32, "rec4 levels 0-6 in LDS, level 7 + leaves = 16-byte global record (gl2), C++"},
+    {9, 32, "gl2, cmp->vcc + v_cndmask_e32 (asm)"},
+    {10, 32, "gl2, v_addc index (asm)"},
+    {12, 8, "ptr8 explicit children, v_cndmask_b32_sdwa select, leaves global"},
+};
+
+template <int VAR>
+static void launch_walk(const WalkArgs& a, int blocks, uint32_t lds) {
+  static bool attr = false;
+  if (!attr) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(walk_kernel<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  attr = true;
+  hipLaunchKernelGGL(walk_kernel<VAR>, dim3(blocks), dim3(1024), lds, 0, a);
+}
+
+static void run_walks(std::string& js) {
+  HostTrees h;
+  uint64_t s = 42;
+  h.thr.resize(kTrees * 255);
+  h.feat.resize(kTrees * 255);
+  h.leaf.resize(kTrees * 256);
+  h.tile.resize(32 * 1024);
+  for (auto& v : h.thr) v = 1u + (uint32_t)(sm64(s) % 8000u);
+  for (auto& v : h.feat) v = (uint32_t)(sm64(s) % 32u);
+  for (auto& v : h.leaf) v = ((float)(sm64(s) >> 40) / 16777216.f - 0.5f) * 0.2f;
+  for (auto& v : h.tile) v = (uint16_t)(sm64(s) % 8001u);
+
+  // 16 KiB LDS images: leaf 0: 8 trees x {256 records, 256 leaves}; leaf 1: 16 x 256 records; leaf 2: 32 x 128 records;
+  // pointer form: 8 trees x 255 records of 8 bytes
+  std::vector<uint32_t> img[4];
+  for (auto& v : img) v.assign(4096, 0u);
+  std::vector<uint32_t> glast(kTrees * 128 * 4, 0u), tops(kTrees * 4, 0u);
+  for (int i = 0; i < kTrees; ++i) {
+    for (int n = 0; n < 255; ++n) {
+      const uint32_t rec = h.thr[i * 255 + n] | ((h.feat[i * 255 + n] * kRow) << 16);
+      if (n < 3) tops[i * 4 + n] = rec;
+      const int lvl = 31 - __builtin_clz(n + 1);
+      const uint32_t l = 2 * n + 1, r = 2 * n + 2;
+      if (i < 8) img[0][i * 512 + n + 1] = rec;
+      if (i < 16) img[1][i * 256 + n + 1] = rec;
+      if (lvl < kD - 1) img[2][i * 128 + n + 1] = rec;
+      else {
+        uint32_t* g = &glast[((size_t)i * 128 + (n - 127)) * 4];
+        g[0] = rec;
+        memcpy(&g[2], &h.leaf[i * 256 + (l - 255)], 4);
+        memcpy(&g[3], &h.leaf[i * 256 + (r - 255)], 4);
+      }
+      if (i < 8) {
+        uint32_t pl, pr;
+        if (lvl < kD - 1) pl = 8u * l, pr = 8u * r;
+        else pl = ((uint32_t)(i % 4) * 256u + (l - 255u)) * 4u, pr = ((uint32_t)(i % 4) * 256u + (r - 255u)) * 4u;  // leaf byte offset in the 4-tree block
+        img[3][i * 512 + 2 * n + 0] = rec;
+        img[3][i * 512 + 2 * n + 1] = pl | (pr << 16);
+      }
+    }
+    if (i < 8)
+      for (int l = 0; l < 256; ++l) memcpy(&img[0][i * 512 + 256 + l], &h.leaf[i * 256 + l], 4);
+  }
+  const int blocks = g_cus * 2, groups = 800;
+  void *d_img[4], *d_tile, *d_leaf, *d_glast, *d_out, *d_tops;
+  CK(hipMalloc(&d_tops, tops.size() * 4));
+  CK(hipMemcpy(d_tops, tops.data(), tops.size() * 4, hipMemcpyHostToDevice));
+  for (int v = 0; v < 4; ++v) {
+    CK(hipMalloc(&d_img[v], 16384));
+    CK(hipMemcpy(d_img[v], img[v].data(), 16384, hipMemcpyHostToDevice));
+  }
+  CK(hipMalloc(&d_tile, 65536));
+  CK(hipMemcpy(d_tile, h.tile.data(), 65536, hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_leaf, h.leaf.size() * 4));
+  CK(hipMemcpy(d_leaf, h.leaf.data(), h.leaf.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_glast, glast.size() * 4));
+  CK(hipMemcpy(d_glast, glast.data(), glast.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&d_out, (size_t)blocks * 1024 * 4));
+  std::vector<float> want(1024), got(1024);
+  const uint32_t lds_bytes = kFeatOff + 65536;
+  auto launch = [&](int var, int g) {
+    const int im = var == 12 ? 3 : var / 4;
+    WalkArgs a{(const u32x4*)d_img[im], (const u32x4*)d_tile, (const float*)d_leaf, (const u32x4*)d_glast, (const u32x4*)d_tops, (float*)d_out, g};
+    switch (var) {
+      case 0: launch_walk<0>(a, blocks, lds_bytes); break;
+      case 4: launch_walk<4>(a, blocks, lds_bytes); break;
+      case 5: launch_walk<5>(a, blocks, lds_bytes); break;
+      case 6: launch_walk<6>(a, blocks, lds_bytes); break;
+      case 7: launch_walk<7>(a, blocks, lds_bytes); break;
+      case 11: launch_walk<11>(a, blocks, lds_bytes); break;
+      case 8: launch_walk<8>(a, blocks, lds_bytes); break;
+      case 9: launch_walk<9>(a, blocks, lds_bytes); break;
+      case 10: launch_walk<10>(a, blocks, lds_bytes); break;
+      case 12: launch_walk<12>(a, blocks, lds_bytes); break;
+    }
+  };
+  for (const WalkVariant& w : kWalks) {
+    for (uint32_t t = 0; t < 1024; ++t) want[t] = cpu_walk(h, t, 3, w.nt);
+    launch(w.var, 3);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(got.data(), (char*)d_out + (size_t)(blocks - 1) * 4096, 4096, hipMemcpyDeviceToHost));
+    const bool ok = memcmp(got.data(), want.data(), 4096) == 0;
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+      Timer t;
+      t.start();
+      launch(w.var, groups * 16 / w.nt);
+      const double ms = t.stop_ms();
+      best = ms < best ? ms : best;
+    }
+    const double visits = (double)blocks * 1024.0 * (groups * 16 / w.nt) * w.nt * kD;
+    char buf[400];
+    snprintf(buf, sizeof buf, "    {\"variant\": \"%s\", \"bit_exact_vs_cpu\": %s, \"ms\": %.3f, \"T_visits_per_s\": %.3f, \"visits_per_cycle_per_cu\": %.3f},\n", w.name,
+             ok ? "true" : "false", best, visits / (best * 1e-3) / 1e12, visits / (best * 1e-3 * g_clock_ghz * 1e9) / g_cus);
+    js += buf;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather: every lane reads S bytes at a pseudo-random record of a window of WIN bytes that all waves of the
+// chip share (L1-resident when WIN <= ~16 KiB), 8 independent gathers in flight per lane
+// ------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(1024) void gather_kernel(const char* __restrict__ win, uint32_t win_bytes, uint32_t region_bytes, uint32_t* out, int iters) {
+  const uint32_t tid = threadIdx.x;
+  uint32_t idx[8], acc = 0;
+  const uint32_t regions = win_bytes / region_bytes, recs = region_bytes / S;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) idx[k] = (tid * 2654435761u + k * 40503u) >> 4;
+  for (int it = 0; it < iters; ++it) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      // all lanes of a wave read the same region (a "tree"), each its own record
+      const uint32_t off = (((uint32_t)it * 8u + k) % regions) * region_bytes + (idx[k] % recs) * S;
+      if (S == 4) v[k] = *reinterpret_cast<const uint32_t*>(win + off);
+      if (S == 8) {
+        const u32x2 t = *reinterpret_cast<const u32x2*>(win + off);
+        v[k] = t.x ^ t.y;
+      }
+      if (S == 16) {
+        const u32x4 t = *reinterpret_cast<const u32x4*>(win + off);
+        v[k] = t.x ^ t.y ^ t.z ^ t.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc += v[k];
+      idx[k] = idx[k] * 1664525u + 1013904223u + (v[k] & 1u);
+    }
+  }
+  out[blockIdx.x * 1024 + tid] = acc;
+}
+
+template <int S>
+static void run_gather(uint32_t* d_out, const char* d_win, uint32_t win_bytes, uint32_t region_bytes, std::string& js) {
+  const int iters = 400, blocks = g_cus * 2;
+  Timer t;
+  hipLaunchKernelGGL(gather_kernel<S>, dim3(blocks), dim3(1024), 0, 0, d_win, win_bytes, region_bytes, d_out, 4);
+  CK(hipDeviceSynchronize());
+  t.start();
+  hipLaunchKernelGGL(gather_kernel<S>, dim3(blocks), dim3(1024), 0, 0, d_win, win_bytes, region_bytes, d_out, iters);
+  const double ms = t.stop_ms();
+  const double wave_insts_per_cu = (double)iters * 8.0 * 32.0;
+  const double cycles = ms * 1e-3 * g_clock_ghz * 1e9;
+  char buf[256];
+  snprintf(buf, sizeof buf, "    {\"bytes_per_lane\": %d, \"window_bytes\": %u, \"region_bytes\": %u, \"ms\": %.3f, \"cycles_per_wave_gather_per_cu\": %.2f},\n", S, win_bytes,
+           region_bytes, ms, cycles / wave_insts_per_cu);
+  js += buf;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HBM read-only probe: persistent blocks, 16 B per lane, UNROLL independent loads in flight per lane
+// ------------------------------------------------------------------------------------------------
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void hbm_read_kernel(const u32x4* __restrict__ src, size_t n16, uint32_t* out) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t acc = 0;
+  for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+    u32x4 v[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) v[k] = NT ? __builtin_nontemporal_load(src + i + k * stride) : src[i + k * stride];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+  }
+  if (acc == 0x12345678u) out[0] = acc;  // keep the loads alive, (almost) never written
+}
+
+template <int UNROLL, bool NT>
+static void run_hbm(const u32x4* d_src, size_t bytes, uint32_t* d_out, int blocks_per_cu, std::string& js) {
+  const int blocks = g_cus * blocks_per_cu;
+  Timer t;
+  hipLaunchKernelGGL((hbm_read_kernel<UNROLL, NT>), dim3(blocks), dim3(256), 0, 0, d_src, bytes / 16, d_out);
+  CK(hipDeviceSynchronize());
+  double best = 1e30;
+  for (int r = 0; r < 3; ++r) {
+    t.start();
+    hipLaunchKernelGGL((hbm_read_kernel<UNROLL, NT>), dim3(blocks), dim3(256), 0, 0, d_src, bytes / 16, d_out);
+    const double ms = t.stop_ms();
+    best = ms < best ? ms : best;
+  }
+  char buf[256];
+  snprintf(buf, sizeof buf, "    {\"loads_in_flight_per_lane\": %d, \"nontemporal\": %s, \"blocks_per_cu\": %d, \"ms\": %.3f, \"TB_per_s\": %.3f},\n", UNROLL, NT ? "true" : "false",
+           blocks_per_cu, best, (double)bytes / (best * 1e-3) / 1e12);
+  js += buf;
+}
+
+static void strip_comma(std::string& js) {
+  const size_t p = js.rfind(",\n");
+  if (p != std::string::npos && p + 2 == js.size()) js.erase(p, 1);
+}
+
+int main(int argc, char** argv) {
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  g_cus = prop.multiProcessorCount;
+  g_clock_ghz = prop.clockRate * 1e-6;  // kHz -> GHz
+  const char* what = argc > 1 ? argv[1] : "all";
+  auto on = [&](const char* k) { return !strcmp(what, "all") || !strcmp(what, k); };
+  uint32_t* d_out;
+  CK(hipMalloc(&d_out, (size_t)g_cus * 8 * 1024 * 4));
+  std::string js;
+  char head[256];
+  snprintf(head, sizeof head, "{\n  \"device\": \"%s\", \"cus\": %d, \"clock_ghz\": %.3f,\n", prop.name, g_cus, g_clock_ghz);
+  js += head;
+  if (on("valu")) {
+    js += "  \"valu\": [\n";
+    run_valu<OP_ADD>(d_out, js);
+    run_valu<OP_OR_SDWA>(d_out, js);
+    run_valu<OP_CMP_CND>(d_out, js);
+    run_valu<OP_CMP_SDWA_CND>(d_out, js);
+    run_valu<OP_LSHL_ADD>(d_out, js);
+    run_valu<OP_AND_OR>(d_out, js);
+    run_valu<OP_CND_SDWA>(d_out, js);
+    run_valu<OP_ADDC>(d_out, js);
+    run_valu<OP_ALIGNBIT>(d_out, js);
+    run_valu<OP_FMA>(d_out, js);
+    run_valu<OP_PK_ADD_U16>(d_out, js);
+    run_valu<OP_LSHL_OR>(d_out, js);
+    run_valu<OP_BFE>(d_out, js);
+    run_valu<OP_PERM>(d_out, js);
+    run_valu<OP_CND_E64>(d_out, js);
+    run_valu<OP_LSHLREV>(d_out, js);
+    run_valu<OP_CMP16>(d_out, js);
+    run_valu<OP_SEQ_CUR>(d_out, js);
+    run_valu<OP_SEQ_VCC>(d_out, js);
+    run_valu<OP_SEQ_ADDC>(d_out, js);
+    strip_comma(js);
+    js += "  ],\n";
+  }
+  if (on("lds")) {
+    js += "  \"lds\": [\n";
+    run_lds<0>(d_out, js, "ds_read_b32 conflict-free");
+    run_lds<1>(d_out, js, "ds_read_u16 conflict-free (rank gather)");
+    run_lds<2>(d_out, js, "ds_read_b32 random in 1 KiB (256 dwords / 32 banks)");
+    run_lds<5>(d_out, js, "ds_read_b32 random in 512 B");
+    run_lds<7>(d_out, js, "ds_read_b32 random in 256 B");
+    run_lds<3>(d_out, js, "ds_read_b64 conflict-free");
+    run_lds<4>(d_out, js, "ds_read_b64 random in 1 KiB");
+    run_lds<6>(d_out, js, "ds_read_b64 random in 512 B");
+    strip_comma(js);
+    js += "  ],\n";
+  }
+  if (on("walk")) {
+    js += "  \"walk\": [\n";
+    run_walks(js);
+    strip_comma(js);
+    js += "  ],\n";
+  }
+  if (on("gather")) {
+    js += "  \"gather\": [\n";
+    char* d_win;
+    CK(hipMalloc(&d_win, 1 << 20));
+    CK(hipMemset(d_win, 1, 1 << 20));
+    run_gather<4>(d_out, d_win, 8192, 1024, js);
+    run_gather<8>(d_out, d_win, 8192, 1024, js);
+    run_gather<8>(d_out, d_win, 16384, 2048, js);
+    run_gather<16>(d_out, d_win, 16384, 2048, js);
+    run_gather<16>(d_out, d_win, 32768, 2048, js);
+    run_gather<16>(d_out, d_win, 65536, 2048, js);
+    run_gather<4>(d_out, d_win, 1 << 20, 1024, js);
+    run_gather<16>(d_out, d_win, 1 << 20, 2048, js);
+    strip_comma(js);
+    js += "  ],\n";
+    CK(hipFree(d_win));
+  }
+  if (on("hbm")) {
+    js += "  \"hbm_read\": [\n";
+    const size_t bytes = 12800000000ull / 4096 * 4096;
+    u32x4* d_src;
+    CK(hipMalloc((void**)&d_src, bytes));
+    CK(hipMemset(d_src, 0x5A, bytes));
+    CK(hipDeviceSynchronize());
+    run_hbm<4, false>(d_src, bytes, d_out, 8, js);
+    run_hbm<8, false>(d_src, bytes, d_out, 8, js);
+    run_hbm<8, true>(d_src, bytes, d_out, 8, js);
+    run_hbm<16, false>(d_src, bytes, d_out, 8, js);
+    run_hbm<16, true>(d_src, bytes, d_out, 8, js);
+    run_hbm<8, false>(d_src, bytes, d_out, 4, js);
+    run_hbm<16, false>(d_src, bytes, d_out, 2, js);
+    strip_comma(js);
+    js += "  ],\n";
+    CK(hipFree(d_src));
+  }
+  js += "  \"note\": \"cycles use the device's reported clock; the chip clocks to its power budget, so ratios between rows are firmer than absolutes\"\n}\n";
+  fputs(js.c_str(), stdout);
+  return 0;
+}
