@@ -300,19 +300,19 @@ def main():
             m = O.SparseModel(O.make_sparse_params(T, D, F), lines, first)
 
             def cpu_score(xs):
-                return O.score_sparse_fast(m, xs, sum_mode=O.SUM_REF_NATIVE if args.sum_mode == 0 else O.SUM_F64_SEQ)
+                return O.score_sparse_fast(m, xs, sum_mode={0: O.SUM_REF_NATIVE, 1: O.SUM_F64_SEQ, 2: O.SUM_REF_FLOPOCO}[args.sum_mode])
             what = "oracle/ddt_oracle.c orc_score_sparse_fast: one tree at a time over a 1024-row block, 8 rows in flight per thread"
         elif classes > 1:
             m = O.Model(O.make_params(T, D, F, clusters=ddt.default_clusters(T // classes)), w, f)
 
             def cpu_score(xs):
-                return O.classify(m, xs, classes, True, sum_mode=O.SUM_REF_NATIVE if args.sum_mode == 0 else O.SUM_F64_SEQ)[0]
+                return O.classify(m, xs, classes, True, sum_mode={0: O.SUM_REF_NATIVE, 1: O.SUM_F64_SEQ, 2: O.SUM_REF_FLOPOCO}[args.sum_mode])[0]
             what = "oracle/ddt_oracle.c orc_classify: per-class reference-order sums, argmax"
         else:
             m = O.Model(O.make_params(T, D, F), w, f)
 
             def cpu_score(xs):
-                return O.score_fast(m, xs, sum_mode=O.SUM_REF_NATIVE if args.sum_mode == 0 else O.SUM_F64_SEQ)
+                return O.score_fast(m, xs, sum_mode={0: O.SUM_REF_NATIVE, 1: O.SUM_F64_SEQ, 2: O.SUM_REF_FLOPOCO}[args.sum_mode])
             what = "oracle/ddt_oracle.c orc_score_fast: cache-blocked 8-byte nodes, 8 walks in flight per thread"
         cpu_score(tuples[: min(N, 4096)].cpu().numpy().view(np.uint32))  # thread-pool warm-up
         probe = min(N, 262_144)
@@ -374,7 +374,7 @@ def main():
                        "tapered_tail": ((args.taper == 1 or (args.taper < 0 and world > 1)) if comm is not None else None),
                        "collectives": (("C-ABI ddt_comm (csrc/ddt_comm.cpp)" if comm is not None else "torch.distributed") if multi else None),
                        "collective_backend": (args.backend if multi else None), "kernel": info.variant_name.decode(),
-                       "sum_mode": "reference-order fp32" if args.sum_mode == 0 else "fp64 accumulate",
+                       "sum_mode": {0: "reference order, IEEE fp32 adds", 1: "fp64 accumulate", 2: "reference order, reference (FloPoCo) adder"}[args.sum_mode],
                        "device": info.device_name.decode()},
         }
         if roofline:

@@ -34,6 +34,21 @@ __device__ __forceinline__ void lds_st_u4(uint32_t a, uint4 v) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The reference's fp32 adder vs IEEE-754 (sum_mode 2, include/ddt.h).  On the leaf domain the loader enforces (+0 or
+// normal, 2^-102 <= |leaf| < 2^96: no partial sum can be sub-normal, overflow or be -0) the FloPoCo adder of
+// rtl/DTEngine/common/FPAdder_2cycles_latency.v IS the IEEE round-to-nearest-even add, with ONE exception
+// (:325-326, `shiftedOut = (expDiff >= 25)` forces the alignment shift to 26 already at an exponent difference of 25): an
+// effective subtraction whose larger operand is an exact power of two, exponents 25 apart, smaller mantissa != 0.  IEEE
+// rounds to the float just below the power of two; the RTL returns the power of two unchanged.
+// sum_suspect(): a cheap NECESSARY condition on the IEEE result (its mantissa is all ones there; the low 16 bits are tested:
+// one v_cmp_eq_u16 per add); radd_exact(): the reference adder's result.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sum_suspect(float s) { return (uint16_t)__float_as_uint(s) == (uint16_t)0xFFFFu; }
+__device__ __forceinline__ float radd_exact(float a, float b) { return ref_add_exact(a, b); }
+template <bool EX>
+__device__ __forceinline__ float radd(float a, float b) { return EX ? radd_exact(a, b) : a + b; }
+
+// ---------------------------------------------------------------------------------------------------
 // reference-order fp32 accumulation state (per lane, per tuple)
 //   tree i -> PU i%8; group g=i/8 -> cluster g%C; per cluster acc <- s_g + acc in slot order; final
 //   sequential add over clusters.  SURVEY.md 8(a) A4/A11/A12.
@@ -69,10 +84,10 @@ struct RefAcc {
       }
     }
   }
-  // s[r] = 8-way pairwise sum of one PU group: acc <- s + acc on the group's cluster (FPAggregator.v:124-131)
-  __device__ __forceinline__ void push_group(const float (&s)[R], uint32_t C) {
+  // the current cluster's accumulator takes its new value (s_g + acc, FPAggregator.v:124-131) and the ring moves on
+  __device__ __forceinline__ void commit_group(const float (&acc_new)[R], uint32_t C) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) a[r][0] = s[r] + a[r][0];
+    for (int r = 0; r < R; ++r) a[r][0] = acc_new[r];
     rotate(C);
     pos = (pos + 1u == C) ? 0u : pos + 1u;
   }
@@ -83,45 +98,87 @@ struct RefAcc {
       pos = (pos + 1u == C) ? 0u : pos + 1u;
     }
   }
-  // sequential add over clusters c = 0..C-1 (Core.sv:486-541); call align() first
-  __device__ __forceinline__ float total(int r, uint32_t C) const {
+  // sequential add over clusters c = 0..C-1 (Core.sv:486-541); call align() first.  `exact`: sum_mode 2
+  __device__ __forceinline__ float total(int r, uint32_t C, bool exact = false) const {
     float t = 0.f;
+    if (!exact) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if ((uint32_t)k < C) t = a[r][k] + t;
+      for (int k = 0; k < 8; ++k)
+        if ((uint32_t)k < C) t = a[r][k] + t;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((uint32_t)k < C) t = radd_exact(a[r][k], t);
+    }
     return t;
   }
 };
 
-// fold the leaves of one sub-group of U trees (stream order) into the accumulators
+// fold the leaves of one sub-group of U trees (stream order) into the accumulators.  SUM 1: fp64 in stream order.
+// SUM 0: the reference's adder network -- FPAddersReduceTree.sv:94-141 ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7)) per PU group,
+// then acc <- s + acc on the group's cluster; with IEEE adds (sum_mode 0), or `exact` (sum_mode 2) = the reference adder
+// itself: the IEEE adds run as always, every result is tested with sum_suspect(), and only a wave in which some lane
+// trips the test recomputes the group with radd_exact() (a wave-uniform branch around the rare path).
+template <int U, int R, bool EX>
+__device__ __forceinline__ void fold_ref(const float (&lf)[R][U], const int phase, const uint32_t C, RefAcc<R>& ra) {
+  bool sus = false;
+  auto add = [&](float x, float y) -> float {
+    const float v = x + y;
+    if (EX) sus = sus || sum_suspect(v);
+    return v;
+  };
+  if (U == 8) {
+    float s[R], acc_new[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      s[r] = add(add(add(lf[r][0], lf[r][1]), add(lf[r][2], lf[r][3])), add(add(lf[r][4 % U], lf[r][5 % U]), add(lf[r][6 % U], lf[r][7 % U])));
+      acc_new[r] = add(s[r], ra.a[r][0]);
+    }
+    if (EX && __ballot(sus) != 0ull) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float e = radd_exact(radd_exact(radd_exact(lf[r][0], lf[r][1]), radd_exact(lf[r][2], lf[r][3])),
+                                   radd_exact(radd_exact(lf[r][4 % U], lf[r][5 % U]), radd_exact(lf[r][6 % U], lf[r][7 % U])));
+        acc_new[r] = radd_exact(e, ra.a[r][0]);
+      }
+    }
+    ra.commit_group(acc_new, C);
+  } else if (phase == 0) {
+    float p[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) p[r] = add(add(lf[r][0], lf[r][1]), add(lf[r][2], lf[r][3]));
+    if (EX && __ballot(sus) != 0ull) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) p[r] = radd_exact(radd_exact(lf[r][0], lf[r][1]), radd_exact(lf[r][2], lf[r][3]));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) ra.half[r] = p[r];
+  } else {
+    float acc_new[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc_new[r] = add(add(ra.half[r], add(add(lf[r][0], lf[r][1]), add(lf[r][2], lf[r][3]))), ra.a[r][0]);
+    if (EX && __ballot(sus) != 0ull) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        acc_new[r] = radd_exact(radd_exact(ra.half[r], radd_exact(radd_exact(lf[r][0], lf[r][1]), radd_exact(lf[r][2], lf[r][3]))), ra.a[r][0]);
+    }
+    ra.commit_group(acc_new, C);
+  }
+}
+
 template <int U, int R, int SUM>
 __device__ __forceinline__ void fold_leaves(const float (&lf)[R][U], const int phase /*U==4: 0 first half, 1 second*/,
-                                            const uint32_t C, RefAcc<R>& ra, double (&dacc)[R]) {
+                                            const uint32_t C, RefAcc<R>& ra, double (&dacc)[R], const bool exact = false) {
   static_assert(U == 4 || U == 8, "sub-group = half a PU group or a whole one");
   if (SUM == 1) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int r = 0; r < R; ++r) dacc[r] += (double)lf[r][u];  // stream order, fp64
-  } else if (U == 8) {
-    float s[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r)  // FPAddersReduceTree.sv:94-141: ((l0+l1)+(l2+l3))+((l4+l5)+(l6+l7))
-      s[r] = ((lf[r][0] + lf[r][1]) + (lf[r][2] + lf[r][3])) + ((lf[r][4 % U] + lf[r][5 % U]) + (lf[r][6 % U] + lf[r][7 % U]));
-    ra.push_group(s, C);
+  } else if (!exact) {
+    fold_ref<U, R, false>(lf, phase, C, ra);
   } else {
-    float p[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) p[r] = (lf[r][0] + lf[r][1]) + (lf[r][2] + lf[r][3]);
-    if (phase == 0) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) ra.half[r] = p[r];
-    } else {
-      float s[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) s[r] = ra.half[r] + p[r];
-      ra.push_group(s, C);
-    }
+    fold_ref<U, R, true>(lf, phase, C, ra);
   }
 }
 

@@ -34,7 +34,7 @@ int validate(ddt_engine* e, const ddt_params* p, size_t n_wlines, size_t n_fline
   if (p->num_levels < 1 || p->num_levels > 16) return fail(e, DDT_EINVAL, "num_levels %u not in 1..16 (CSR205 is 4 bits)", p->num_levels);
   if (p->num_features < 1 || p->num_features > 2048) return fail(e, DDT_EINVAL, "num_features %u not in 1..2048 (DTPU.sv:72)", p->num_features);
   if (p->cmp_mode > 1) return fail(e, DDT_EINVAL, "cmp_mode %u", p->cmp_mode);
-  if (p->sum_mode > 1) return fail(e, DDT_EINVAL, "sum_mode %u", p->sum_mode);
+  if (p->sum_mode > 2) return fail(e, DDT_EINVAL, "sum_mode %u", p->sum_mode);
   const uint32_t c = p->clusters_per_tuple;
   if (c != 1 && c != 2 && c != 4 && c != 8) return fail(e, DDT_EINVAL, "clusters_per_tuple %u not in {1,2,4,8}", c);
   if (p->reserved[0] | p->reserved[1] | p->reserved[2]) return fail(e, DDT_EINVAL, "reserved fields must be 0");
@@ -77,13 +77,16 @@ int parse_trees(ddt_engine* eng, const ddt_params* p, const uint32_t* w, const u
     }
     for (uint32_t l = 0; l < nleaf; ++l) {
       const uint32_t lb = wt[nint + l];
-      // The GPU adds are IEEE-754; the reference's FloPoCo adder treats sub-normal / Inf / NaN inputs as normals and
-      // keeps -0 (FPAdder_2cycles_latency.v:313-320,376-385 behind the {0, |bits} wrapper of FPAddersReduceTree.sv:94-95):
-      // outside normal values and +0 "bit-exact with the reference" cannot be promised in the reference-order sum
-      if (p->sum_mode == 0 && eng && eng->leaf_domain_check && leaf_outside_exact_domain(lb))
+      // The GPU adds are IEEE-754; the reference's FloPoCo adder treats sub-normal / Inf / NaN inputs as normals, keeps -0
+      // and has no sub-normal results (FPAdder_2cycles_latency.v:313-320,376-385 behind the {0, |bits} wrapper of
+      // FPAddersReduceTree.sv:94-95).  With every leaf +0 or normal in [2^-102, 2^96) no partial sum of fewer than 2^32 leaves
+      // can be sub-normal (sums are multiples of the smallest leaf ulp, >= 2^-125), overflow or be -0: on that domain the two
+      // adders differ in exactly one case, which sum_mode 2 reproduces (ddt_device.h radd_exact).
+      if (p->sum_mode != 1 && eng && eng->leaf_domain_check && leaf_outside_exact_domain(lb))
         return fail(eng, DDT_EUNSUPPORTED,
-                    "tree %u leaf %u = 0x%08X: -0 / sub-normal / Inf / NaN leaves are outside the domain where IEEE adds equal the "
-                    "reference adder (flush them to +0 when exporting, use sum_mode 1, or set option leaf_domain_check = 0)",
+                    "tree %u leaf %u = 0x%08X: leaves other than +0 and normal values with 2^-102 <= |v| < 2^96 (-0, sub-normal, tiny, huge, "
+                    "Inf, NaN) are outside the domain where the IEEE adds are held to the reference adder (flush them to +0 when "
+                    "exporting, use sum_mode 1, or set option leaf_domain_check = 0)",
                     ids[i], l, lb);
       m.leaf[(size_t)i * nleaf + l] = lb;
     }
@@ -95,7 +98,7 @@ int parse_trees(ddt_engine* eng, const ddt_params* p, const uint32_t* w, const u
 
 bool leaf_outside_exact_domain(uint32_t bits) {
   const uint32_t ex = (bits >> 23) & 0xFFu;
-  return bits != 0u && (ex == 0u || ex == 0xFFu);  // -0, sub-normals, Inf, NaN
+  return bits != 0u && (ex < 25u || ex > 222u);  // -0, sub-normals, |v| < 2^-102, |v| >= 2^96, Inf, NaN
 }
 
 uint32_t thr_key(const ddt_params& p, uint32_t bits) {
@@ -1121,7 +1124,7 @@ int ddt_chain_sum_device(ddt_engine* e, const float* d_parts, uint32_t n_parts, 
   if (n_parts == 0 || (!d_parts && n) || (!d_out && n)) return fail(e, DDT_EINVAL, "bad chain-sum arguments");
   DeviceGuard dg(e->device);
   if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
-  hipError_t r = launch_chain_sum(d_parts, n_parts, n, d_out, reinterpret_cast<hipStream_t>(stream));
+  hipError_t r = launch_chain_sum(d_parts, n_parts, n, d_out, e->loaded && e->p.sum_mode == 2, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(e, DDT_EHIP, "chain_sum -> %s", hipGetErrorString(r));
   return DDT_OK;
 }

@@ -158,10 +158,31 @@ uint32_t stream_blocks_per_cu(uint32_t lds_bytes);
 int num_sparse_variants();                 // ddt_sparse.hip: appended to the variant table after the perfect-tree kernels
 const Variant& sparse_variant(int i);
 
-hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s);
+hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact /* sum_mode 2 */, hipStream_t s);
 hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s);
 hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits,
                                hipStream_t s);
+
+// The reference's fp32 adder on the exact leaf domain (sum_mode 2; the one case where it is not the IEEE add is described in
+// ddt_device.h).  Host + device: the kernels call it on their rare path, the CPU model of the kernels (tests/mock_hip) always.
+__host__ __device__ inline uint32_t f32_bits(float f) {
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  return u;
+}
+__host__ __device__ inline float ref_add_exact(float a, float b) {
+  const float s = a + b;
+  const uint32_t ua = f32_bits(a), ub = f32_bits(b);
+  const uint32_t ma = ua & 0x7FFFFFFFu, mb = ub & 0x7FFFFFFFu;
+  const uint32_t big = ma >= mb ? ua : ub, small = ma >= mb ? ub : ua;
+  const uint32_t eb = (big >> 23) & 0xFFu, es = (small >> 23) & 0xFFu;
+  // FPAdder_2cycles_latency.v:325-326: effective subtraction, larger operand a power of two, exponents exactly 25 apart,
+  // smaller mantissa != 0 -> the RTL returns the larger operand, IEEE the float just below it
+  const bool corner = (big & 0x7FFFFFu) == 0u && ((ua ^ ub) >> 31) != 0u && eb - es == 25u && es != 0u && (small & 0x7FFFFFu) != 0u;
+  float r;
+  __builtin_memcpy(&r, &big, 4);
+  return corner ? r : s;
+}
 
 // splitmix64 / synthetic definitions; shared by host generator and kernels
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {

@@ -33,14 +33,14 @@ namespace ddt {
 // ---------------------------------------------------------------------------------------------------
 template <int D, int U, int R, int CT, int BUF_OFF, int PHASE0, bool SLOW, int SUM, bool FUSED>
 __device__ __forceinline__ void compute_chunk(const uint32_t (&lane_off)[R], const uint32_t miss_key, const uint32_t C,
-                                              RefAcc<R>& ra, double (&dacc)[R]) {
+                                              RefAcc<R>& ra, double (&dacc)[R], const bool exact) {
   constexpr int TREE_BYTES = 12 << D;
   static_assert(CT % U == 0, "sub-group geometry");
 #pragma unroll
   for (int sg = 0; sg < CT / U; ++sg) {
     float lf[R][U];
     walk_trees<D, U, R, TREE_BYTES, SLOW, FUSED>((uint32_t)(BUF_OFF + sg * U * TREE_BYTES), lane_off, miss_key, lf);
-    fold_leaves<U, R, SUM>(lf, (PHASE0 + sg) & 1, C, ra, dacc);
+    fold_leaves<U, R, SUM>(lf, (PHASE0 + sg) & 1, C, ra, dacc, exact);
   }
 }
 
@@ -121,17 +121,18 @@ __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) 
 #pragma unroll
   for (int r = 0; r < R; ++r) dacc[r] = 0.0;
   const uint32_t C = a.clusters, miss_key = a.miss_key;
-  const int SUM1 = (int)a.sum_mode;
+  const int SUM1 = (int)a.sum_mode;  // 0 reference order / IEEE adds, 1 fp64, 2 reference order / reference adder
+  const bool exact = SUM1 == 2;
 
   // chunk k lives in buffer k&1; the loop is unrolled by two so buffer offsets are immediates
 #define DDT_COMPUTE(BUF, PH)                                                                                          \
   do {                                                                                                                \
-    if (SUM1 == 0) {                                                                                                  \
-      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 0, FUSED>(lane_off, miss_key, C, ra, dacc); \
-      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 0, FUSED>(lane_off, miss_key, C, ra, dacc);        \
+    if (SUM1 != 1) {                                                                                                  \
+      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 0, FUSED>(lane_off, miss_key, C, ra, dacc, exact); \
+      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 0, FUSED>(lane_off, miss_key, C, ra, dacc, exact);        \
     } else {                                                                                                          \
-      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 1, FUSED>(lane_off, miss_key, C, ra, dacc); \
-      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 1, FUSED>(lane_off, miss_key, C, ra, dacc);        \
+      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 1, FUSED>(lane_off, miss_key, C, ra, dacc, false); \
+      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 1, FUSED>(lane_off, miss_key, C, ra, dacc, false);        \
     }                                                                                                                 \
   } while (0)
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) 
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint64_t row = tile0 + (uint64_t)(r * THREADS + tid);
-    if (row < a.n) a.out[row] = (SUM1 == 0) ? ra.total(r, C) : (float)dacc[r];
+    if (row < a.n) a.out[row] = (SUM1 != 1) ? ra.total(r, C, exact) : (float)dacc[r];
   }
 }
 
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(THREADS) void score_tile_persist_kernel(const Score
   const uint64_t n_tiles = (a.n + TILE - 1) / TILE;
   const uint32_t lane_off[R] = {(uint32_t)tid * 4u};
   const uint32_t C = a.clusters, miss_key = a.miss_key;
-  const int SUM1 = (int)a.sum_mode;
+  const int SUM1 = (int)a.sum_mode;  // 0 reference order / IEEE adds, 1 fp64, 2 reference order / reference adder
+  const bool exact = SUM1 == 2;
   const uint32_t t4 = (uint32_t)tid & 3u;
   const uint32_t quad_col = (uint32_t)tid & ~3u;
 
@@ -277,12 +279,12 @@ __global__ __launch_bounds__(THREADS) void score_tile_persist_kernel(const Score
 
 #define DDT_COMPUTE(BUF, PH)                                                                                          \
   do {                                                                                                                \
-    if (SUM1 == 0) {                                                                                                  \
-      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 0, FUSED>(lane_off, miss_key, C, ra, dacc); \
-      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 0, FUSED>(lane_off, miss_key, C, ra, dacc);        \
+    if (SUM1 != 1) {                                                                                                  \
+      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 0, FUSED>(lane_off, miss_key, C, ra, dacc, exact); \
+      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 0, FUSED>(lane_off, miss_key, C, ra, dacc, exact);        \
     } else {                                                                                                          \
-      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 1, FUSED>(lane_off, miss_key, C, ra, dacc); \
-      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 1, FUSED>(lane_off, miss_key, C, ra, dacc);        \
+      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 1, FUSED>(lane_off, miss_key, C, ra, dacc, false); \
+      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 1, FUSED>(lane_off, miss_key, C, ra, dacc, false);        \
     }                                                                                                                 \
   } while (0)
 
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(THREADS) void score_tile_persist_kernel(const Score
     ra.align(C);
     quad_transpose(pre[0], t4);  // hipcc's wait for the prefetch sits here, before the store goes out
     quad_transpose(pre[1], t4);
-    if (valid) a.out[row] = (SUM1 == 0) ? ra.total(0, C) : (float)dacc[0];
+    if (valid) a.out[row] = (SUM1 != 1) ? ra.total(0, C, exact) : (float)dacc[0];
     if (!has_next) break;
     tile = next;
   }
@@ -399,12 +401,12 @@ __global__ __launch_bounds__(kStreamThreads) void score_stream_kernel(const Scor
       const int phase = (int)((t0 / (uint32_t)U) & 1u);
       if (!slow) walk_trees<D, U, 1, TREE_BYTES, false, false>(base, lane_off, miss_key, lf);
       else walk_trees<D, U, 1, TREE_BYTES, true, false>(base, lane_off, miss_key, lf);
-      if (a.sum_mode == 0) fold_leaves<U, 1, 0>(lf, phase, C, ra, dacc);
+      if (a.sum_mode != 1) fold_leaves<U, 1, 0>(lf, phase, C, ra, dacc, a.sum_mode == 2);
       else fold_leaves<U, 1, 1>(lf, phase, C, ra, dacc);
     }
     ra.align(C);
     const uint64_t row = tile * TILE + (uint64_t)tid;
-    if (row < a.n) a.out[row] = (a.sum_mode == 0) ? ra.total(0, C) : (float)dacc[0];
+    if (row < a.n) a.out[row] = (a.sum_mode != 1) ? ra.total(0, C, a.sum_mode == 2) : (float)dacc[0];
   }
 }
 
@@ -937,7 +939,8 @@ __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, co
   ra.init();
   double dacc[1] = {0.0};
   const uint32_t C = a.clusters, lane2 = (((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1);  // see rank_kernel
-  const int SUM1 = (int)a.sum_mode;
+  const int SUM1 = (int)a.sum_mode;  // 0 reference order / IEEE adds, 1 fp64, 2 reference order / reference adder
+  const bool exact = SUM1 == 2;
 
   // _s2: `top` holds the level-0/1 records of the sub-group about to be walked; the next sub-group's (same chunk, or the first
   // of the next chunk; past the end: chunk 0 again, never used) are requested before the walk
@@ -960,7 +963,7 @@ __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, co
         if (!slow) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
         else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
       }                                                                                                \
-      if (SUM1 == 0) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc);                           \
+      if (SUM1 != 1) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc, exact);                    \
       else fold_leaves<U, 1, 1>(lf, ((PH) + sg) & 1, C, ra, dacc);                                     \
     }                                                                                                  \
   } while (0)
@@ -986,7 +989,7 @@ __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, co
   if constexpr (S2) top_wait(top);  // the last request (never used) must not outlive the wave
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
-  if (row < a.n) a.out[row] = (SUM1 == 0) ? ra.total(0, C) : (float)dacc[0];
+  if (row < a.n) a.out[row] = (SUM1 != 1) ? ra.total(0, C, exact) : (float)dacc[0];
 }
 
 template <int D, int CT, int U, int OPT = 0>
@@ -1182,12 +1185,13 @@ __global__ __launch_bounds__(kGenericThreads) void score_generic_kernel(const Sc
       }
     }
     if (a.sum_mode != 1) {
-      const float s[1] = {((grp[0] + grp[1]) + (grp[2] + grp[3])) + ((grp[4] + grp[5]) + (grp[6] + grp[7]))};
-      ra.push_group(s, a.clusters);
+      const float lf[1][8] = {{grp[0], grp[1], grp[2], grp[3], grp[4], grp[5], grp[6], grp[7]}};
+      double unused[1] = {0.0};
+      fold_leaves<8, 1, 0>(lf, 0, a.clusters, ra, unused, a.sum_mode == 2);
     }
   }
   ra.align(a.clusters);
-  if (valid) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, a.clusters);
+  if (valid) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, a.clusters, a.sum_mode == 2);
 }
 
 hipError_t launch_generic(const ScoreArgs& a_in, const Variant&, hipStream_t s) {
@@ -1216,21 +1220,25 @@ hipError_t launch_generic(const ScoreArgs& a_in, const Variant&, hipStream_t s) 
 // chain sum of partial score vectors: out = (((p0 + p1) + p2) + ...)  (ResultsCombiner.sv:292-311)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void chain_sum_kernel(const float* __restrict__ parts, uint32_t n_parts, size_t n,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const bool exact) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float run = parts[i];
-    for (uint32_t p = 1; p < n_parts; ++p) run = parts[(size_t)p * n + i] + run;  // local + upstream
+    if (!exact) {
+      for (uint32_t p = 1; p < n_parts; ++p) run = parts[(size_t)p * n + i] + run;  // local + upstream
+    } else {
+      for (uint32_t p = 1; p < n_parts; ++p) run = radd_exact(parts[(size_t)p * n + i], run);  // sum_mode 2: the hop adders are the same FloPoCo adder
+    }
     out[i] = run;
   }
 }
 
-hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, hipStream_t s) {
+hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact, hipStream_t s) {
   if (n == 0) return hipSuccess;
   (void)hipGetLastError();  // do not inherit a stale error
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048 * 8) blocks = 2048 * 8;
-  hipLaunchKernelGGL(chain_sum_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, parts, n_parts, n, out);
+  hipLaunchKernelGGL(chain_sum_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, parts, n_parts, n, out, exact);
   return hipGetLastError();
 }
 

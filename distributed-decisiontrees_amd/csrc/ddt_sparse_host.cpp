@@ -307,10 +307,10 @@ int take_trees(ddt_engine* e, const ddt_params* p, const uint32_t* lines, size_t
       for (uint32_t side = 0; side < 2; ++side) {
         const uint32_t cw = t[4u * n + 2u + side];
         if ((en >> (14u + side)) & 1u) {
-          if (p->sum_mode == 0 && e->leaf_domain_check && leaf_outside_exact_domain(cw))
+          if (p->sum_mode != 1 && e->leaf_domain_check && leaf_outside_exact_domain(cw))
             return fail(e, DDT_EUNSUPPORTED,
-                        "tree %u node %llu: leaf 0x%08X is -0 / sub-normal / Inf / NaN, outside the domain where IEEE adds equal the reference "
-                        "adder (flush to +0 when exporting, use sum_mode 1, or set option leaf_domain_check = 0)", id, (unsigned long long)n, cw);
+                        "tree %u node %llu: leaf 0x%08X is not +0 or a normal value with 2^-102 <= |v| < 2^96: outside the domain where the IEEE adds are "
+                        "held to the reference adder (flush to +0 when exporting, use sum_mode 1, or set option leaf_domain_check = 0)", id, (unsigned long long)n, cw);
           continue;
         }
         if (cw <= n || cw >= cnt)  // children after their parent: every walk terminates
@@ -341,7 +341,7 @@ extern "C" int ddt_load_model_sparse_multiclass(ddt_engine* e, const ddt_params*
   if (p->num_trees == 0) return fail(e, DDT_EINVAL, "num_trees == 0");
   if (p->num_levels < 1 || p->num_levels > 64) return fail(e, DDT_EINVAL, "num_levels %u not in 1..64 (depth bound of a sparse model)", p->num_levels);
   if (p->num_features < 1 || p->num_features > 2048) return fail(e, DDT_EINVAL, "num_features %u not in 1..2048 (DTPU.sv:72)", p->num_features);
-  if (p->cmp_mode > 1 || p->sum_mode > 1) return fail(e, DDT_EINVAL, "cmp_mode %u / sum_mode %u", p->cmp_mode, p->sum_mode);
+  if (p->cmp_mode > 1 || p->sum_mode > 2) return fail(e, DDT_EINVAL, "cmp_mode %u / sum_mode %u", p->cmp_mode, p->sum_mode);
   const uint32_t c = p->clusters_per_tuple;
   if (c != 1 && c != 2 && c != 4 && c != 8) return fail(e, DDT_EINVAL, "clusters_per_tuple %u not in {1,2,4,8}", c);
   if (p->reserved[0] | p->reserved[1] | p->reserved[2]) return fail(e, DDT_EINVAL, "reserved fields must be 0");

@@ -25,17 +25,19 @@ float reduce(const float* leaf, uint32_t n_trees, uint32_t C, uint32_t sum_mode)
     for (uint32_t i = 0; i < n_trees; ++i) d += (double)leaf[i];
     return (float)d;
   }
-  volatile float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto add = [sum_mode](float x, float y) -> float {  // sum_mode 2: the reference adder (ddt_internal.h)
+    volatile float v = sum_mode == 2 ? ref_add_exact(x, y) : x + y;
+    return v;
+  };
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t g = 0; g * 8u < n_trees; ++g) {
     float l[8];
     for (uint32_t u = 0; u < 8; ++u) l[u] = g * 8u + u < n_trees ? leaf[g * 8u + u] : 0.0f;
-    volatile float a0 = l[0] + l[1], a1 = l[2] + l[3], a2 = l[4] + l[5], a3 = l[6] + l[7];
-    volatile float h0 = a0 + a1, h1 = a2 + a3;
-    volatile float s = h0 + h1;
-    acc[g % C] = s + acc[g % C];
+    const float s = add(add(add(l[0], l[1]), add(l[2], l[3])), add(add(l[4], l[5]), add(l[6], l[7])));
+    acc[g % C] = add(s, acc[g % C]);
   }
-  volatile float tot = 0.0f;
-  for (uint32_t k = 0; k < C; ++k) tot = acc[k] + tot;
+  float tot = 0.0f;
+  for (uint32_t k = 0; k < C; ++k) tot = add(acc[k], tot);
   return tot;
 }
 
