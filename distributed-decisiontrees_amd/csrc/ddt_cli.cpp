@@ -113,6 +113,7 @@ bool read_csr(const std::string& path, uint64_t csr[DDT_CSR_COUNT]) {
 bool exchange_id(const std::string& path, int rank, int timeout_s, unsigned char id[DDT_COMM_ID_BYTES]) {
   if (rank == 0) {
     if (ddt_comm_get_unique_id(id) != DDT_OK) return false;
+    (void)remove(path.c_str());  // a file left by an earlier job holds a dead id: the launcher starts rank 0 first (or passes a fresh --id-file per job)
     const std::string tmp = path + ".tmp";
     if (!write_file(tmp, id, DDT_COMM_ID_BYTES)) return false;
     return rename(tmp.c_str(), path.c_str()) == 0;
@@ -267,6 +268,7 @@ int cmd_score(const std::map<std::string, std::string>& o) {
   if (rc) return die(rc, nullptr, "ddt_create");
   if (o.count("variant")) ddt_set_option(e, "variant", (int64_t)num(o, "variant", 0));
   const uint32_t of = (uint32_t)num(o, "of", 1), shard = (uint32_t)num(o, "shard", 0);
+  if (of == 0 || shard >= of) return die(DDT_EINVAL, e, "--shard / --of: need of >= 1 and shard < of");
   rc = ddt_load_model_shard(e, &p, w.data(), w.size() / 16, f.data(), f.size() / 16, shard, of);
   if (rc) return die(rc, e, "load model");
   rc = ddt_score(e, x.data(), n, scores.data());
@@ -322,6 +324,7 @@ int cmd_score_sparse(const std::map<std::string, std::string>& o) {
   p.cmp_mode = (uint32_t)num(o, "cmp-mode", 0);
   p.sum_mode = (uint32_t)num(o, "sum-mode", 0);
   const uint32_t of = (uint32_t)num(o, "of", 1), shard = (uint32_t)num(o, "shard", 0);
+  if (of == 0 || shard >= of) return die(DDT_EINVAL, nullptr, "--shard / --of: need of >= 1 and shard < of");
   const uint32_t per_dev = (p.num_trees + of - 1) / of;
   p.clusters_per_tuple = (uint32_t)num(o, "clusters", per_dev <= 128 ? 1 : per_dev <= 256 ? 2 : per_dev <= 512 ? 4 : 8);
   const size_t tuple_bytes = (size_t)(p.num_features + 3) / 4 * 16;

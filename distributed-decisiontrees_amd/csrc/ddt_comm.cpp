@@ -78,6 +78,23 @@ int cfail(ddt_comm* c, int code, const char* fmt, ...) {
     if (_r != ncclSuccess) return cfail((c), DDT_EHIP, "%s -> %s", #call, ncclGetErrorString(_r)); \
   } while (0)
 
+// closes the NCCL group when a CNCCL / CHIP in the middle of it returns early: an open group would swallow every later call on this thread
+struct GroupGuard {
+  bool open = false;
+  ncclResult_t start() {
+    const ncclResult_t r = ncclGroupStart();
+    open = r == ncclSuccess;
+    return r;
+  }
+  ncclResult_t end() {
+    open = false;
+    return ncclGroupEnd();
+  }
+  ~GroupGuard() {
+    if (open) (void)ncclGroupEnd();
+  }
+};
+
 int comm_init_common(ddt_comm* c) {
   CHIP(c, hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking));
   for (int b = 0; b < 2; ++b) {
@@ -110,12 +127,13 @@ int comm_reserve(ddt_comm* c, size_t floats) {
 int chain_combine(ddt_comm* c, int b, size_t count) {
   const size_t G = (size_t)c->n, seg = (count + G - 1) / G;
   // all-to-all: my slice r goes to rank r; I receive every rank's slice of MY segment
-  CNCCL(c, ncclGroupStart());
+  GroupGuard grp;
+  CNCCL(c, grp.start());
   for (int r = 0; r < c->n; ++r) {
     CNCCL(c, ncclSend(c->part[b] + (size_t)r * seg, seg, ncclFloat, r, c->comm, c->cs));
     CNCCL(c, ncclRecv(c->recv[b] + (size_t)r * seg, seg, ncclFloat, r, c->comm, c->cs));
   }
-  CNCCL(c, ncclGroupEnd());
+  CNCCL(c, grp.end());
   // p0 + p1 + ... in rank order: the reference's hop order (ResultsCombiner.sv:292-311: local + upstream)
   hipError_t r = launch_chain_sum(c->recv[b], (uint32_t)c->n, seg, c->full[b] + (size_t)c->rank * seg, c->e && c->e->p.sum_mode == 2, c->cs);
   if (r != hipSuccess) return cfail(c, DDT_EHIP, "chain_sum -> %s", hipGetErrorString(r));
@@ -266,7 +284,7 @@ int ddt_comm_set_option(ddt_comm* c, const char* key, int64_t value) {
 }
 
 int64_t ddt_comm_chunk_schedule(size_t n, size_t chunk_rows, int taper, size_t taper_min_rows, size_t* lens_out, size_t cap) {
-  if (chunk_rows == 0) return DDT_EINVAL;
+  if (chunk_rows == 0 || n / chunk_rows > (1u << 20)) return DDT_EINVAL;
   const std::vector<size_t> v = chunk_schedule(n, chunk_rows, taper != 0, taper_min_rows);
   if (lens_out) {
     if (cap < v.size()) return DDT_EINVAL;
@@ -290,6 +308,8 @@ static int sharded_pipeline(ddt_comm* c, const void* d_tuples, size_t n, float* 
   }
   const uint32_t* tup = reinterpret_cast<const uint32_t*>(d_tuples);
   const bool taper = c->taper_tail < 0 ? c->n > 1 : c->taper_tail != 0;
+  // a schedule of more than 2^20 pieces is a mis-set chunk_rows, not a job (and its vector could throw across the C ABI)
+  if (rows && n / rows > (1u << 20)) return cfail(c, DDT_EINVAL, "chunk_rows %zu cuts %zu rows into more than 2^20 chunks", c->chunk_rows, n);
   const std::vector<size_t> sched = chunk_schedule(n, rows, taper, c->taper_min_rows);  // every piece <= rows: fits the workspaces
   size_t lo = 0;
   for (size_t k = 0; k < sched.size(); lo += sched[k], ++k) {
@@ -363,13 +383,14 @@ static int tuples_to_device(ddt_comm* c, const uint32_t* src, size_t m, size_t W
   auto lo_of = [&](size_t r) { return std::min(r * per, m); };
   auto len_of = [&](size_t r) { return std::min(per, m - lo_of(r)); };
   if (len_of(me)) CHIP(c, hipMemcpyAsync(d_tuples + lo_of(me) * W, src + lo_of(me) * W, len_of(me) * W * 4, hipMemcpyHostToDevice, s));
-  CNCCL(c, ncclGroupStart());
+  GroupGuard grp;
+  CNCCL(c, grp.start());
   for (size_t r = 0; r < G; ++r) {
     if (r == me) continue;
     if (len_of(me)) CNCCL(c, ncclSend(d_tuples + lo_of(me) * W, len_of(me) * W, ncclFloat, (int)r, c->comm, s));  // 4-byte words
     if (len_of(r)) CNCCL(c, ncclRecv(d_tuples + lo_of(r) * W, len_of(r) * W, ncclFloat, (int)r, c->comm, s));
   }
-  CNCCL(c, ncclGroupEnd());
+  CNCCL(c, grp.end());
   return DDT_OK;
 }
 
@@ -466,13 +487,14 @@ int ddt_score_rowsharded_device(ddt_comm* c, const void* d_tuples, size_t n, flo
     if (G == 1) continue;
     CHIP(c, hipEventRecord(c->ev_scored[b], s));
     CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));
-    CNCCL(c, ncclGroupStart());
+    GroupGuard grp;
+    CNCCL(c, grp.start());
     for (size_t r = 0; r < G; ++r) {
       if (r == me) continue;
       if (cnt(me)) CNCCL(c, ncclSend(d_scores + lo + off, cnt(me), ncclFloat, (int)r, c->comm, c->cs));
       if (cnt(r)) CNCCL(c, ncclRecv(d_scores + r * per + off, cnt(r), ncclFloat, (int)r, c->comm, c->cs));
     }
-    CNCCL(c, ncclGroupEnd());
+    CNCCL(c, grp.end());
   }
   if (G > 1) {
     CHIP(c, hipEventRecord(c->ev_done, c->cs));

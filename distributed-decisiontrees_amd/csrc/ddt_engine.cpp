@@ -1256,14 +1256,33 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     const bool top = key[7] == 't';
     if (top && value >= 0 && (value < kSparseMinTop || value > kSparseMaxTop)) return fail(e, DDT_EINVAL, "sparse_top_levels must be -1 or %d..%d", kSparseMinTop, kSparseMaxTop);
     if (!top && (value < 0 || value > 1)) return fail(e, DDT_EINVAL, "sparse_deep_order must be 0 or 1");
-    (top ? e->sparse_top_levels : e->sparse_deep_order) = (int)value;
+    int& opt = top ? e->sparse_top_levels : e->sparse_deep_order;
+    const int previous = opt;
+    opt = (int)value;
     if (e->loaded && e->sparse) {
       DeviceGuard dg(e->device);
-      if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
-      HIP_TRY(e, hipDeviceSynchronize());
+      if (!dg.ok) {
+        opt = previous;
+        return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
+      }
+      hipError_t hr = hipDeviceSynchronize();
+      if (hr != hipSuccess) {
+        opt = previous;
+        return fail(e, DDT_EHIP, "hipDeviceSynchronize -> %s", hipGetErrorString(hr));
+      }
       e->loaded = false;
       int rc = sparse_rebuild(e);
-      if (rc) return rc;
+      if (rc) {
+        // a refused change (no kernel fits that K for this tuple width, out of memory) keeps the previous setting AND the loaded
+        // model, like a refused "variant": re-pack with the old value, report the original error
+        char why[sizeof(e->err)];
+        memcpy(why, e->err, sizeof(why));
+        opt = previous;
+        const int rc2 = sparse_rebuild(e);
+        e->loaded = rc2 == 0;
+        memcpy(e->err, why, sizeof(why));
+        return rc;
+      }
       e->loaded = true;
     }
     return DDT_OK;

@@ -132,6 +132,7 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
   std::vector<Cursor> cur, nxt;
   std::vector<std::pair<uint32_t, uint32_t*>> pending;  // (tree node at depth K, slot of the parent's child word to patch)
   std::vector<uint32_t> order, stack;
+  try {  // every container below grows with the model: an allocation failure is DDT_ENOMEM, never an exception across the C ABI
   for (uint32_t i = 0; i < groups * 8u; ++i) {
     uint32_t* t = top.data() + (size_t)i * top_words;
     uint32_t* last = t + (4u << K) / 4u;  // 16-byte records of level K-1
@@ -230,6 +231,9 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
     }
     for (auto& pe : pending) *pe.second = where[pe.first];
   }
+  } catch (const std::bad_alloc&) {
+    return fail(e, DDT_ENOMEM, "sparse image allocation failed");
+  }
   *groups_out = groups;
   return DDT_OK;
 }
@@ -288,7 +292,7 @@ int take_trees(ddt_engine* e, const ddt_params* p, const uint32_t* lines, size_t
                SparseForest* out) {
   SparseForest sp;
   sp.first.assign(1, 0u);
-  std::vector<uint8_t> depth;
+  std::vector<uint8_t> depth, seen;
   for (uint32_t id : ids) {
     if (first[id + 1] <= first[id]) return fail(e, DDT_EINVAL, "tree %u has no lines", id);
     if (first[id + 1] > n_lines)  // an inner entry of tree_first_line may point past the stream even when the last one does not
@@ -296,8 +300,17 @@ int take_trees(ddt_engine* e, const ddt_params* p, const uint32_t* lines, size_t
     const uint64_t cnt = first[id + 1] - first[id];
     if (cnt > 0xFFFFFFFFull) return fail(e, DDT_EUNSUPPORTED, "tree %u has more than 2^32 nodes", id);
     const uint32_t* t = lines + first[id] * 4u;
-    depth.assign(cnt, 0);
+    try {
+      depth.assign(cnt, 0);
+      seen.assign(cnt, 0);
+    } catch (const std::bad_alloc&) {
+      return fail(e, DDT_ENOMEM, "host model allocation failed");
+    }
+    seen[0] = 1;  // the root
     for (uint64_t n = 0; n < cnt; ++n) {
+      // The lines of a tree must BE a tree: every node but the root is the child of exactly one earlier node.  (A shared child -- a DAG --
+      // would walk fine, but the packers expand paths: 2^depth records from a few hundred bytes of stream.)
+      if (!seen[n]) return fail(e, DDT_EINVAL, "tree %u node %llu is not the child of any earlier node", id, (unsigned long long)n);
       const uint32_t en = t[4u * n + 1u];
       if (en >> 16) return fail(e, DDT_EINVAL, "tree %u node %llu: word 1 bits [31:16] must be 0", id, (unsigned long long)n);
       if ((en & 0x7FFu) >= p->num_features)
@@ -316,6 +329,8 @@ int take_trees(ddt_engine* e, const ddt_params* p, const uint32_t* lines, size_t
         if (cw <= n || cw >= cnt)  // children after their parent: every walk terminates
           return fail(e, DDT_EINVAL, "tree %u node %llu: child index %u out of order / range (%llu nodes)", id, (unsigned long long)n, cw,
                       (unsigned long long)cnt);
+        if (seen[cw]) return fail(e, DDT_EINVAL, "tree %u node %llu: child %u already has a parent (the lines of a tree must form a tree)", id, (unsigned long long)n, cw);
+        seen[cw] = 1;
         depth[cw] = (uint8_t)(depth[n] + 1u);
       }
     }

@@ -384,7 +384,7 @@ REMOVED_WAITS = {
     # the caller's stream no longer waits for the last collective
     "done": ("  CHIP(c, hipStreamWaitEvent(s, c->ev_done, 0));  // results are ready in stream order on the caller's stream\n", "", 1),
     # row-sharded job: a step is handed to the peers before it has been scored / the caller does not wait for the peers' rows
-    "rows_scored": ("    CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));\n    CNCCL(c, ncclGroupStart());", "    CNCCL(c, ncclGroupStart());", -1),
+    "rows_scored": ("    CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));\n    GroupGuard grp;\n    CNCCL(c, grp.start());", "    GroupGuard grp;\n    CNCCL(c, grp.start());", -1),
     "rows_done": ("    CHIP(c, hipStreamWaitEvent(s, c->ev_done, 0));  // every peer's rows have landed before the caller's stream moves on\n", "", -1),
 }
 

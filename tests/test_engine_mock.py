@@ -484,3 +484,37 @@ def test_the_model_catches_a_missing_dependency_in_the_engine(which):
         for f in (broken, os.path.join(MOCK, so)):
             if os.path.exists(f):
                 os.remove(f)
+
+
+def test_a_refused_sparse_option_keeps_the_model(mock):
+    """a refused sparse_top_levels (no kernel of that K fits) left the engine without a model and with the bad value
+    stored; it must behave like a refused "variant": previous setting kept, model still loaded, original error reported."""
+    mock.mock_reset(0, 0, 8)
+    T, depth, F, n = 12, 12, 20, 700
+    sp = O.gen_sparse_model(T, depth, F, 3, 600, 1)
+    x = O.gen_tuples(0, n, F, 1)
+    want = O.score_sparse(sp, x)
+    p = ddt.make_sparse_params(T, depth, F)
+    mock.ddt_load_model_sparse.argtypes = [vp, C.POINTER(ddt.Params), vp, C.c_size_t, vp, C.c_uint32, C.c_uint32]
+    lines, first = np.ascontiguousarray(sp.node_lines).reshape(-1), np.ascontiguousarray(sp.first)
+    e = _engine(mock)
+    assert mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, 0, 1) == 0, mock.ddt_last_error(e)
+    out = np.zeros(n, np.float32)
+
+    def scores_still_right():
+        out[:] = np.nan
+        return mock.ddt_score(e, x.ctypes.data, n, out.ctypes.data) == 0 and np.array_equal(_bits(out), _bits(want))
+
+    assert scores_still_right()
+    info = ddt.Info()
+    assert mock.ddt_get_info(e, C.byref(info)) == 0
+    before = info.variant_name.decode()
+    assert mock.ddt_set_option(e, b"sparse_top_levels", 7) == -5 and b"no sparse kernel fits" in mock.ddt_last_error(e)   # the CPU model has K = 6, 8, 9 only
+    assert scores_still_right()
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == before
+    assert mock.ddt_set_option(e, b"sparse_deep_order", 1) == 0 and scores_still_right()      # an accepted change re-packs and keeps scoring
+    assert mock.ddt_set_option(e, b"sparse_top_levels", 6) == 0 and scores_still_right()
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_k6")
+    assert mock.ddt_set_option(e, b"sparse_top_levels", 10) == -5 and scores_still_right()     # refused again: K = 6 stays
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_k6")
+    mock.ddt_destroy(e)

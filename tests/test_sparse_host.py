@@ -104,3 +104,31 @@ def test_hook_rejects_what_the_loader_rejects():
     assert call(bad) < 0
     assert call(nl, ddt.make_sparse_params(4, 3, 5)) < 0   # deeper than num_levels
     assert call(nl, p, 0) < 0                              # not a sparse kernel variant
+
+
+def test_a_stream_must_be_a_tree_not_a_dag():
+    """a chain whose nodes share a child passed validation and the packers then expanded 2^depth paths (bad_alloc across the
+    C ABI from a 480-byte stream).  Every node but the root must be the child of exactly one earlier node."""
+    L = _lib.lib()
+    vid = _sparse_variants()[0][0]
+    depth = 30
+    lines = np.zeros((depth, 4), np.uint32)
+    for n in range(depth):
+        last = n == depth - 1
+        lines[n] = [np.float32(0.5).view(np.uint32), (3 << 14) if last else 0, 0 if last else n + 1, 0 if last else n + 1]  # both children = node n + 1
+    first = np.array([0, depth], np.uint64)
+    p = ddt.make_sparse_params(1, 40, 4)
+    info = np.zeros(6, np.uint64)
+    rc = L.ddt_debug_sparse_image(C.byref(p), lines.ctypes.data, depth, first.ctypes.data, vid, 0, None, 0, None, 0, info.ctypes.data)
+    assert rc == -1  # DDT_EINVAL, not a crash and not an exponential image
+    # a node nobody points to
+    s = O.gen_sparse_model(1, 6, 5, 2, 600, 1)
+    nl = np.ascontiguousarray(s.node_lines).view(np.uint32).reshape(-1, 4).copy()
+    internal = np.flatnonzero((nl[:, 1] >> 14) & 1 == 0)
+    assert internal.size
+    n = int(internal[0])
+    nl[n, 1] |= 1 << 14                    # its left child becomes a leaf: the old left sub-tree is unreachable now
+    nl[n, 2] = 0
+    first = np.ascontiguousarray(s.first, dtype=np.uint64)
+    p = ddt.make_sparse_params(1, 6, 5)
+    assert L.ddt_debug_sparse_image(C.byref(p), nl.ctypes.data, nl.shape[0], first.ctypes.data, vid, 0, None, 0, None, 0, info.ctypes.data) == -1
