@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the scoring hot path (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W        (N>1: one rank per GPU -- under torch.distributed.run as the driver starts it,
+                                                        or on its own: without WORLD_SIZE it launches the ranks itself)
 
 Default workload (BASELINE.json `metric` / configs[2]): 1000 trees, depth 8, 32 fp32 features, 100 M synthetic
 tuples (SURVEY.md 8(d) generator, resident in HBM before the timed region).  One "step" = one pass of the hot path
@@ -48,6 +49,26 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def self_launch_command(n_gpus, argv=None, port=None):
+    """The command line `python bench.py --gpus N ...` turns itself into when no launcher set WORLD_SIZE."""
+    if port is None:
+        import socket
+
+        with socket.socket() as sk:  # a free rendezvous port (two benches on one box must not collide on a fixed one)
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+
+
+def self_launch(n_gpus):
+    import subprocess
+
+    cmd = self_launch_command(n_gpus)
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (n_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +112,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without a launcher around it: become the launcher (one rank per GPU through torch.distributed.run on
+    # 127.0.0.1, a free port), pass the ranks' stdout through -- rank 0 prints the ONE JSON line -- and exit with their status
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
     # stdout discipline: the driver wants ONE JSON line.  Native libraries (RCCL prints a version banner through C stdio)
     # must not add lines to it: everything but the final print goes to stderr.
     sys.stdout.flush()
@@ -113,9 +139,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs one rank per GPU: launch with python -m torch.distributed.run "
-                     f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
         sys.exit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the scoring path has no CPU fallback)")
@@ -176,8 +199,10 @@ def main():
         comm.set_option("chunk_rows", args.chunk_rows)
         comm.set_option("taper_tail", args.taper)
     elif multi:
-        scorer = (ddt.RowShardedScorer(eng) if rows_mode else
-                  ddt.ShardedScorer.from_engine(eng, mode=args.combine, chunk_rows=args.chunk_rows,
+        from tests import sharded_ref  # --collectives torch: the Python mirror of the pipeline (test infrastructure; needed for gloo ranks sharing a GPU)
+
+        scorer = (sharded_ref.RowShardedScorer(eng) if rows_mode else
+                  sharded_ref.ShardedScorer.from_engine(eng, mode=args.combine, chunk_rows=args.chunk_rows,
                                                 force_collectives=args.force_collectives))
 
     # per-launch HIP-event times of the pass, taken by the library on the launch stream ("kernel_timing"):

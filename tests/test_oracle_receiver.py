@@ -7,7 +7,7 @@ from the CSR blocks of the PRODUCT's codec (ddt_csr_encode_ex).  Per stream line
 data_valid, device index, stays-local}.
 
 Held to it: the product's tree -> device map (ddt_shard_range: the shards ddt_load_model_shard / ddt_comm / ddt_group
-load; Python mirror ddt.sharded.shard_bounds), the oracle's multi-device model (orc_score with n_devices), the stamp the
+load; Python mirror ddt.shard_bounds), the oracle's multi-device model (orc_score with n_devices), the stamp the
 PU programming golden assumes (weights lines first with prog_mode 1, then feature-index lines with 0, tuples with
 data_valid 1), and the row mode's dealing of tuples.  One more defect of the published RTL is asserted as recorded."""
 import ctypes as C
@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 import ddt
-from ddt.sharded import shard_bounds
+from ddt import shard_bounds
 from oracle import oracle as O
 
 VEC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "receiver_rtl_vectors.npz")

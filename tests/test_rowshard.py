@@ -1,5 +1,5 @@
 """The reference's second multi-device mode (trees replicated, tuples partitioned, results interleaved:
-rtl/DTEngine/DTInference.sv:28-37, PCIeReceiver.sv:289-312) -- ddt.RowShardedScorer: no arithmetic crosses
+rtl/DTEngine/DTInference.sv:28-37, PCIeReceiver.sv:289-312) -- SR.RowShardedScorer: no arithmetic crosses
 devices, so the gathered scores are bit-identical to a single-engine run."""
 import os
 import socket
@@ -9,6 +9,7 @@ import pytest
 
 from oracle import oracle as O
 import ddt
+from tests import sharded_ref as SR
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +27,7 @@ def _worker(rank, world, port, ret):
         e = ddt.Engine(0)
         e.load_model(ddt.make_params(T, D, F), w, f)
         d = e.synth_tuples_device(0, n, F)
-        got = ddt.RowShardedScorer(e).score(d)
+        got = SR.RowShardedScorer(e).score(d)
         torch.cuda.synchronize()
         want = O.score(O.Model(O.make_params(T, D, F), w, f), d.cpu().numpy().view(np.uint32))
         ret[rank] = bool(np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))) and \

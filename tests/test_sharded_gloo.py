@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 (and 4) gloo process groups exercise ddt.ShardedScorer -- shard split,
+"""N>1 path on CPU: world_size-2 (and 4) gloo process groups exercise SR.ShardedScorer -- shard split,
 chunking, both combine modes -- with the per-rank partial scores supplied by the oracle (checker role:
 the product's scorer needs a GPU; what is under test here is the host-side combine logic)."""
 import os
@@ -12,6 +12,7 @@ import torch.multiprocessing as mp
 
 from oracle import oracle as O
 import ddt
+from tests import sharded_ref as SR
 
 
 def _free_port():
@@ -34,7 +35,7 @@ def _worker(rank, world, port, mode, chunk_rows, ret):
         def partial(tuples, out):
             out.copy_(torch.from_numpy(O.score_shard(m, tuples.numpy().view(np.uint32), b, e)))
 
-        sc = ddt.ShardedScorer(partial, ddt.tuple_words(F), mode=mode, chunk_rows=chunk_rows)
+        sc = SR.ShardedScorer(partial, ddt.tuple_words(F), mode=mode, chunk_rows=chunk_rows)
         got = sc.score(torch.from_numpy(x.view(np.int32))).numpy()
         want_chain = O.score(m, x, n_devices=world)
         gold = O.score(m, x, want_gold=True)[1]
@@ -65,7 +66,7 @@ def test_sharded_scorer_gloo(world, mode, chunk):
 def test_chain_sum_is_the_reference_hop_order():
     parts = torch.tensor([[1.0], [2.0 ** -24], [2.0 ** -24], [2.0 ** -24]], dtype=torch.float32)
     # ((1 + e) + e) + e = 1 (each add ties to even); any pairwise order would give 1 + 2^-23
-    assert ddt.chain_sum(parts)[0].item() == 1.0
+    assert SR.chain_sum(parts)[0].item() == 1.0
 
 
 def _cls_worker(rank, world, port, mode, chunk_rows, ret):
@@ -86,7 +87,7 @@ def _cls_worker(rank, world, port, mode, chunk_rows, ret):
         def argmax(scores):
             return torch.from_numpy(np.argmax(scores.numpy(), axis=0).astype(np.int32))  # first maximum wins
 
-        sc = ddt.ShardedClassifier(partial, ddt.tuple_words(F), K, argmax, mode=mode, chunk_rows=chunk_rows)
+        sc = SR.ShardedClassifier(partial, ddt.tuple_words(F), K, argmax, mode=mode, chunk_rows=chunk_rows)
         labels, scores = sc.classify(torch.from_numpy(x.view(np.int32)))
         want_l, want_cs = O.classify(m, x, K, interleaved=False, n_devices=world)
         if mode == "chain" or world == 2:
