@@ -369,8 +369,9 @@ uint32_t total_trees(const ddt_engine* e) {
   return t;
 }
 
-constexpr uint32_t kQ16MinTreeLevels = 640;  // trees x levels from which the rank-quantised path wins with the LDS-resident pre-pass
-                                             // (profiles/r02_sweep_q16_small.json: 60 x d8 +4 %, 80 x d8 +5 %, 100 x d6 +1 %, 112 x d8 +7 %, 200 x d6 +9 %)
+constexpr uint32_t kQ16MinTreeLevels = 480;  // trees x levels from which the rank-quantised path wins with the LDS-resident pre-pass
+                                             // (profiles/r02_sweep_q16_small.json: 60 x d8 +4 %, 80 x d8 +5 %, 112 x d8 +7 %, 200 x d6 +9 %; round 3 with the _s2 walk,
+                                             // profiles/r03_sweep_fused_rank_experiment_ilp8_s2.json: 100 x d6 +17 %, 100 x d8 +11 %, while 30 x d6 still loses 15 %)
 constexpr uint32_t kQ16MaxTable = 32767;  // ranks must stay below 0xFFFF and a table (x4 B) must fit LDS in the rank kernel
 
 bool variant_fits(const Variant& v, const ddt_engine* e) {
@@ -416,7 +417,7 @@ int auto_variant(const ddt_engine* e) {
   if (tuple_words(e->p) <= 32u && total_trees(e) * e->p.num_levels >= kQ16MinTreeLevels && total_trees(e) < 224u && prepass_plan_exists(e))
     q16_min = total_trees(e);
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
-    static const char* qpref[] = {"q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4", "q16_d5_c32_u4", "q16_d3_c128_u8",
+    static const char* qpref[] = {"q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4", "q16_d6_c16_u4_s2", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4_s2", "q16_d7_c8_u4", "q16_d5_c32_u4_s2", "q16_d5_c32_u4", "q16_d3_c128_u8",
                                   "q16_d9_c4_u4", "q16_d10_c4_u4"};
     for (const char* name : qpref) {
       const int i = find_variant(name);

@@ -136,6 +136,7 @@ struct Variant {
   uint32_t tree_bytes_q16() const { return 8u << levels; }
   uint32_t lds_tree_bytes_q16() const { return (opt & 1) ? (4u << levels) : (8u << levels); }
   uint32_t feat_off_q16() const { return 2u * lds_tree_bytes_q16() * (uint32_t)chunk_trees; }
+  // opt bit 1 ("_s2"): the records of levels 0-1 come from SGPRs (scalar loads), see ddt_kernels.hip
   uint32_t lds_bytes_q16(uint32_t tuple_words) const { return feat_off_q16() + tuple_words * tile() * 2u; }
   // ---- sparse kernels (levels = K, the top levels staged in LDS): LDS = [top image of one PU group][feature tile] ----
   uint32_t top_bytes_sparse() const { return 12u << levels; }

@@ -865,7 +865,7 @@ __device__ __forceinline__ void top_wait(TopRecs<4>& q) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.t[0]), "+s"(q.t[1]), "+s"(q.t[2]), "+s"(q.t[3]));
 }
 
-template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW>
+template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW, bool GL>
 __device__ __forceinline__ void walk_trees_q16_s2(const TopRecs<U>& q, const uint32_t base, const uint32_t lane2, float (&leaf)[U],
                                                   const float* __restrict__ gleaf) {
   static_assert(D >= 3, "two scalar levels + at least one LDS level");
@@ -900,15 +900,20 @@ __device__ __forceinline__ void walk_trees_q16_s2(const TopRecs<U>& q, const uin
 #pragma unroll
     for (int u = 0; u < U; ++u) m4[u] = (m4[u] << 1) + (goes_right(nd[u], f[u]) ? 4u : 0u);
   }
+  if (GL) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) leaf[u] = gleaf[(m4[u] >> 2) - (1u << D) + (uint32_t)(u << D)];
+    for (int u = 0; u < U; ++u) leaf[u] = gleaf[(m4[u] >> 2) - (1u << D) + (uint32_t)(u << D)];
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) leaf[u] = lds_f32(m4[u] + (base + (uint32_t)(u * TREE_BYTES)));
+  }
 }
 
 template <int D, int CT, int U, int OPT = 0>
-__global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, const Q16Aux x) {
+__global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a, const Q16Aux x) {  // 8 waves per SIMD = two blocks per CU
   constexpr int THREADS = kQTile;
   constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0;
-  static_assert(!S2 || (GL && U == 4), "_s2 is built on the _gl layout, 4 trees in flight");
+  static_assert(!S2 || U == 4, "_s2: 4 trees in flight");
   constexpr int TREE_BYTES = GL ? (4 << D) : (8 << D);  // bytes of a tree in LDS (GL: node records only)
   constexpr int CHUNK_BYTES = TREE_BYTES * CT;          // bytes of a chunk in LDS
   constexpr int GCHUNK_UNITS = (8 << D) * CT / 16;      // 16-byte units of a chunk in the global image
@@ -919,10 +924,10 @@ __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, co
   const int tid = threadIdx.x;
   const uint64_t tile = blockIdx.x, tile0 = tile * kQTile;
   const uint32_t W = a.tuple_words, n_chunks = a.n_chunks;
-  const bool slow = x.tile_flags[tile] != 0u;  // block-uniform
+  constexpr int GSKIP = GCHUNK_UNITS - CHUNK_BYTES / 16;  // dma_chunk strides by the LDS chunk: skip the leaves of the chunks before
+  const bool slow = x.tile_flags[tile] != 0u;  // block-uniform: the tile holds a missing value
   const uint4* img = slow ? x.img_slow : a.img;
 
-  constexpr int GSKIP = GCHUNK_UNITS - CHUNK_BYTES / 16;  // dma_chunk strides by the LDS chunk: skip the leaves of the chunks before
   dma_chunk<THREADS, CHUNK_BYTES>(img, 0, 0, tid);
   {  // the whole feature tile is one contiguous block of W*2048 bytes: DMA it in
     const uint4* src = reinterpret_cast<const uint4*>(x.q + tile * (uint64_t)W * kQTile);
@@ -956,8 +961,8 @@ __global__ __launch_bounds__(kQTile) void score_q16_kernel(const ScoreArgs a, co
         const int sn = (sg + 1 < CT / U) ? sg + 1 : 0;                                                 \
         top_wait(top);                                                                                 \
         top_issue<TREE_BYTES>(top_next, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
-        if (!slow) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false>(top, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
-        else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true>(top, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+        if (!slow) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+        else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
         top = top_next;                                                                                \
       } else {                                                                                         \
         if (!slow) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
@@ -1323,6 +1328,8 @@ hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t 
   Variant { NAME, kKindQ16, D, kQTile, 1, CT, U, 1, 1, &launch_q16<D, CT, U, 1> }
 #define DDT_QGS(NAME, D, CT, U) /* _gl + levels 0-1 from SGPRs (scalar loads) */ \
   Variant { NAME, kKindQ16, D, kQTile, 1, CT, U, 1, 3, &launch_q16<D, CT, U, 3> }
+#define DDT_QO(NAME, D, CT, U, OPT) /* any q16 option set: bit 0 _gl, bit 1 _s2 */ \
+  Variant { NAME, kKindQ16, D, kQTile, 1, CT, U, 1, OPT, &launch_q16<D, CT, U, OPT> }
 
 static const Variant g_variants[] = {
     Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_generic},
@@ -1333,6 +1340,10 @@ static const Variant g_variants[] = {
     // trees, so half the barriers.  1000 trees x 50 M tuples: 56.4 vs 59.4 ms; 8 trees in flight per lane (u8): 58.6
     DDT_QG("q16_d8_c8_u4_gl", 8, 8, 4),
     DDT_QGS("q16_d8_c8_u4_gl_s2", 8, 8, 4),
+    // _s2 on the layouts that keep their leaves in LDS (depths 5-7): 100 x d6 x 28 features, 10 M tuples: 1.297 vs 1.333 ms
+    DDT_QO("q16_d6_c16_u4_s2", 6, 16, 4, 2),
+    DDT_QO("q16_d7_c8_u4_s2", 7, 8, 4, 2),
+    DDT_QO("q16_d5_c32_u4_s2", 5, 32, 4, 2),
     DDT_Q("q16_d6_c16_u4", 6, 16, 4),
     DDT_Q("q16_d4_c64_u8", 4, 64, 8),
     // odd depths (XGBoost / scikit-learn defaults 3, 5, 7): same 8 KiB chunks

@@ -182,7 +182,8 @@ def test_ieee_compare_mode(name):
 
 
 def test_config_2_and_1_choices():
-    assert ddt.variant_names()[_check(100, 6, 28, None, 0, n=32)["variant"]].startswith("d6_t1024")
+    assert ddt.variant_names()[_check(100, 6, 28, None, 0, n=32)["variant"]] == "q16_d6_c16_u4_s2"   # config 2: 600 tree-levels, above the q16 break-even since round 3
+    assert ddt.variant_names()[_check(40, 6, 28, None, 0, n=32)["variant"]].startswith("d6_t1024")      # small ensembles stay on the fp32 tile kernel
     assert ddt.variant_names()[_check(8, 4, 16, None, 0, n=32)["variant"]].startswith("stream_d4")
 
 

@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="1000x8x32x8000000,100x6x28x10000000,8x4x16x10000000")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--only", default="", help="substring filter on variant names")
+    ap.add_argument("--only", default="", help="substring filter on variant names (comma separated: any of them)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep.json"))
     ap.add_argument("--opt", default="", help="engine options, comma separated key=value (e.g. q16_fused_prepass=0)")
     a = ap.parse_args()
@@ -40,7 +40,7 @@ def main():
         want = O.score(m, xs)
         out = torch.empty(N, dtype=torch.float32, device="cuda")
         for v, name in enumerate(names):
-            if a.only and a.only not in name:
+            if a.only and not any(k in name for k in a.only.split(",")):
                 continue
             if name == "generic" and N * T * D > 2e12:
                 continue
