@@ -338,6 +338,10 @@ static hipError_t launch_tile_persist(const ScoreArgs& a, const Variant& v, hipS
 // AHEAD of the compute, and written transposed into LDS.  The transposed write is LPT-way bank conflicted
 // (LPT = lines per tuple); that costs ~LPT LDS cycles per tuple, negligible against the HBM time here and
 // the price of perfectly coalesced reads.  Model image: classic layout at LDS [0, img_bytes).
+// Round 3 tried, on config 1 (profiles/r03_sweep_stream_*.json), and did not keep: quad-coalesced loads + DPP transpose
+// (conflict-free LDS writes: 3.07 vs 3.00 ms -- the LDS pipe is not what holds the kernel back), two tiles in flight per
+// block (103 VGPRs -> 4 blocks per CU: 2.94 vs 2.90), register caps for 6 / 8 blocks per CU (spills: 3.04 / 3.89).  The
+// kernel keeps 83 VGPRs = 5 resident blocks per CU = 80 KiB of loads in flight per CU at ~4.5 us of loaded HBM latency.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 256;
 constexpr uint32_t kStreamRow = kStreamThreads * 4u;
@@ -366,7 +370,11 @@ __global__ __launch_bounds__(kStreamThreads) void score_stream_kernel(const Scor
 #pragma unroll
     for (int i = 0; i < MAXLPT; ++i) {
       const uint32_t e = (uint32_t)tid + (uint32_t)i * THREADS;
-      pre[i] = ((uint32_t)i < LPT && e < avail) ? src[e] : make_uint4(0u, 0u, 0u, 0u);
+      // nontemporal: the tuple stream is read once (tools/ubench `hbm`: 6.5 vs 5.9 TB/s read-only; this kernel on config 1: 2.90 vs 3.04 ms)
+      if ((uint32_t)i < LPT && e < avail) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + e);
+        pre[i] = make_uint4(v.x, v.y, v.z, v.w);
+      } else pre[i] = make_uint4(0u, 0u, 0u, 0u);
     }
   };
 

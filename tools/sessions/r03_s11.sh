@@ -1,0 +1,6 @@
+#!/bin/bash
+set -u
+cd "$GRAFT_REPO_ROOT"
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r03_s11
+rm -rf "$OUT"; mkdir -p "$OUT"
+( timeout 900 python tools/sweep.py --shapes 8x4x16x200000000,8x4x32x100000000 --only stream_d4 --reps 5 --out $OUT/sweep_stream.json ) > $OUT/sweep.log 2>&1; grep -v "^W\|^E\|amdgpu.ids" $OUT/sweep.log | tail -30
