@@ -15,10 +15,78 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
 #include "ddt_engine_priv.h"
+
+// Persistent staging threads of one engine (round 2 spawned std::threads per chunk).  The caller's thread takes slice 0.
+struct ddt_copy_pool {
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable cv_go, cv_done;
+  uint64_t generation = 0;
+  size_t remaining = 0;
+  bool stop = false;
+  char* dst = nullptr;
+  const char* src = nullptr;
+  size_t bytes = 0, slice = 0, parts = 0;
+
+  explicit ddt_copy_pool(int n_workers) {
+    for (int w = 0; w < n_workers; ++w) workers.emplace_back([this, w] { run((size_t)w + 1u); });
+  }
+  ~ddt_copy_pool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv_go.notify_all();
+    for (std::thread& t : workers) t.join();
+  }
+  void piece(size_t i) const {
+    const size_t b = i * slice;
+    if (i < parts && b < bytes) memcpy(dst + b, src + b, b + slice <= bytes ? slice : bytes - b);
+  }
+  void run(size_t index) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(m);
+      cv_go.wait(lk, [&] { return stop || generation != seen; });
+      if (stop) return;
+      seen = generation;
+      lk.unlock();
+      piece(index);
+      lk.lock();
+      if (--remaining == 0) cv_done.notify_one();
+    }
+  }
+  void copy(void* d, const void* s, size_t n) {
+    const size_t min_slice = 2u << 20;
+    size_t want = n / min_slice;
+    if (want > workers.size() + 1u) want = workers.size() + 1u;
+    if (want <= 1) {
+      memcpy(d, s, n);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      dst = static_cast<char*>(d);
+      src = static_cast<const char*>(s);
+      bytes = n;
+      parts = want;
+      slice = ((n + want - 1) / want + 4095u) & ~(size_t)4095u;
+      remaining = workers.size();  // every worker reports back, the ones without a piece at once
+      ++generation;
+    }
+    cv_go.notify_all();
+    piece(0);
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return remaining == 0; });
+  }
+};
+
 
 using namespace ddt;
 
@@ -442,7 +510,7 @@ void free_images(ddt_engine* e) {
 }
 
 void free_q16_workspace(ddt_engine* e) {
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < kQSlots; ++k) {
     for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k]}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
@@ -710,7 +778,7 @@ void fill_args(const ddt_engine* e, const Ensemble& m, const void* d_tuples, siz
 }
 
 void feeder_free(ddt_engine* e) {
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < kFeederSlots; ++b) {
     if (e->pin_in[b]) (void)hipHostFree(e->pin_in[b]);
     if (e->pin_out[b]) (void)hipHostFree(e->pin_out[b]);
     if (e->dev_in[b]) (void)hipFree(e->dev_in[b]);
@@ -724,9 +792,11 @@ void feeder_free(ddt_engine* e) {
 int feeder_reserve(ddt_engine* e, size_t rows, size_t words, size_t outs) {
   if (e->feeder_cap_rows >= rows && e->feeder_cap_words >= words && e->feeder_cap_outs >= outs) return DDT_OK;
   feeder_free(e);
-  for (int b = 0; b < 2; ++b) {
+  if (!e->copy_stream) HIP_TRY(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  for (int b = 0; b < kFeederSlots; ++b) {
     if (!e->fs[b]) HIP_TRY(e, hipStreamCreateWithFlags(&e->fs[b], hipStreamNonBlocking));
     if (!e->fe[b]) HIP_TRY(e, hipEventCreateWithFlags(&e->fe[b], hipEventDisableTiming));
+    if (!e->fe_in[b]) HIP_TRY(e, hipEventCreateWithFlags(&e->fe_in[b], hipEventDisableTiming));
     HIP_TRY(e, hipHostMalloc(&e->pin_in[b], rows * words * 4, hipHostMallocDefault));
     HIP_TRY(e, hipHostMalloc(&e->pin_out[b], rows * outs * 4, hipHostMallocDefault));
     HIP_TRY(e, hipMalloc(&e->dev_in[b], rows * words * 4));
@@ -956,10 +1026,14 @@ void ddt_destroy(ddt_engine* e) {
   DeviceGuard dg(e->device);
   (void)hipDeviceSynchronize();  // asynchronous ddt_*_device work may still read the images / workspaces
   feeder_free(e);
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < kFeederSlots; ++b) {
     if (e->fs[b]) (void)hipStreamDestroy(e->fs[b]);
     if (e->fe[b]) (void)hipEventDestroy(e->fe[b]);
+    if (e->fe_in[b]) (void)hipEventDestroy(e->fe_in[b]);
   }
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  delete e->pool;
+  for (const auto& r : e->pinned) (void)hipHostUnregister(r.first);  // ranges the caller forgot to hand back
   if (e->ws) (void)hipFree(e->ws);
   for (hipEvent_t ev : e->tev)
     if (ev) (void)hipEventDestroy(ev);
@@ -1030,25 +1104,25 @@ int ddt_argmax_device(ddt_engine* e, const float* d_class_scores, uint32_t K, si
 // the other.  classify: per chunk the device output is [K][cn] class scores followed by cn int32 labels.
 // staging copy host -> pinned buffer on several threads: a single thread moves ~26 GB/s, less than the
 // ~55 GB/s the PCIe Gen5 x16 link takes (the feeder would then be bound by memcpy, not by the link)
-static void parallel_copy(void* dst, const void* src, size_t bytes, int threads) {
-  const size_t min_slice = 4u << 20;
-  size_t parts = bytes / min_slice;
-  if (parts > (size_t)threads) parts = (size_t)threads;
-  if (parts <= 1) {
+static void parallel_copy(ddt_engine* e, void* dst, const void* src, size_t bytes) {
+  if (e->feeder_threads <= 1 || bytes < (4u << 20)) {
     memcpy(dst, src, bytes);
     return;
   }
-  const size_t slice = ((bytes + parts - 1) / parts + 4095u) & ~(size_t)4095u;
-  std::vector<std::thread> th;
-  th.reserve(parts - 1);
-  for (size_t i = 1; i < parts; ++i) {
-    const size_t b = i * slice;
-    if (b >= bytes) break;
-    const size_t len = b + slice <= bytes ? slice : bytes - b;
-    th.emplace_back([=] { memcpy(static_cast<char*>(dst) + b, static_cast<const char*>(src) + b, len); });
+  if (e->pool && (int)e->pool->workers.size() != e->feeder_threads - 1) {
+    delete e->pool;
+    e->pool = nullptr;
   }
-  memcpy(dst, src, slice < bytes ? slice : bytes);
-  for (std::thread& t : th) t.join();
+  if (!e->pool) e->pool = new ddt_copy_pool(e->feeder_threads - 1);
+  e->pool->copy(dst, src, bytes);
+}
+
+// is [p, p + bytes) inside a range the caller pinned with ddt_host_register?  (then the DMA engine reads / writes it directly)
+static bool host_registered(const ddt_engine* e, const void* p, size_t bytes) {
+  const char* q = static_cast<const char*>(p);
+  for (const auto& r : e->pinned)
+    if (q >= static_cast<const char*>(r.first) && q + bytes <= static_cast<const char*>(r.first) + r.second) return true;
+  return false;
 }
 
 static int score_host(ddt_engine* e, const void* tuple_lines, size_t n, float* scores_out, int32_t* labels_out,
@@ -1064,12 +1138,17 @@ static int score_host(ddt_engine* e, const void* tuple_lines, size_t n, float* s
   int rc = feeder_reserve(e, rows, W, outs);
   if (rc) return rc;
   const uint32_t* src = reinterpret_cast<const uint32_t*>(tuple_lines);
-  size_t pending_off[2] = {0, 0}, pending_n[2] = {0, 0};
+  // buffers the caller pinned (ddt_host_register) go through the DMA engine directly: no staging copy in, no drain copy out
+  const bool in_direct = host_registered(e, tuple_lines, n * W * 4);
+  const bool out_direct = !classify && host_registered(e, scores_out, n * 4);
+  size_t pending_off[kFeederSlots] = {}, pending_n[kFeederSlots] = {};
   auto drain = [&](int b) -> int {
     HIP_TRY(e, hipEventSynchronize(e->fe[b]));
     const size_t cn = pending_n[b], off = pending_off[b];
     const float* po = reinterpret_cast<const float*>(e->pin_out[b]);
-    if (!classify) {
+    if (out_direct) {
+      // the scores went straight into the caller's buffer
+    } else if (!classify) {
       memcpy(scores_out + off, po, cn * 4);
     } else {
       if (class_scores_out)
@@ -1079,28 +1158,69 @@ static int score_host(ddt_engine* e, const void* tuple_lines, size_t n, float* s
     pending_n[b] = 0;
     return DDT_OK;
   };
+  // Three slots, three streams: while chunk k computes, chunk k+1 crosses the link and chunk k+2 is being staged by the host
+  // threads (with two slots the staging of k+2 could only begin once chunk k had left its slot).
   for (size_t off = 0, i = 0; off < n; off += rows, ++i) {
-    const int b = (int)(i & 1);
+    const int b = (int)(i % kFeederSlots);
     const size_t cn = (n - off < rows) ? n - off : rows;
     if (pending_n[b] && (rc = drain(b))) return rc;
-    parallel_copy(e->pin_in[b], src + off * W, cn * W * 4, e->feeder_threads);
-    HIP_TRY(e, hipMemcpyAsync(e->dev_in[b], e->pin_in[b], cn * W * 4, hipMemcpyHostToDevice, e->fs[b]));
+    // ALL host-to-device copies go down ONE stream, in order: copies issued on three streams at once share the copy engines and
+    // the link badly (tools/h2d_probe.py on the GPU box: 1 GiB in 128 MiB pieces -- one stream 56 GB/s, three streams 40 GB/s);
+    // the slot's own stream (kernels, scores back) waits for its chunk's event
+    if (!in_direct) parallel_copy(e, e->pin_in[b], src + off * W, cn * W * 4);
+    HIP_TRY(e, hipMemcpyAsync(e->dev_in[b], in_direct ? static_cast<const void*>(src + off * W) : e->pin_in[b], cn * W * 4, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(e, hipEventRecord(e->fe_in[b], e->copy_stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->fs[b], e->fe_in[b], 0));
     float* dout = reinterpret_cast<float*>(e->dev_out[b]);
-    e->q_slot = 1 + b;  // the two feeder streams run concurrently: separate q16 workspaces
+    e->q_slot = 1 + b;  // the feeder streams run concurrently: separate q16 workspaces
     if (!classify) rc = engine_score_device(e, e->dev_in[b], cn, dout, e->fs[b]);
     else rc = engine_classify_device(e, e->dev_in[b], cn, dout, reinterpret_cast<int32_t*>(dout + (size_t)K * cn), e->fs[b]);
     e->q_slot = 0;
     if (rc) return rc;
-    HIP_TRY(e, hipMemcpyAsync(e->pin_out[b], e->dev_out[b], cn * outs * 4, hipMemcpyDeviceToHost, e->fs[b]));
+    HIP_TRY(e, hipMemcpyAsync(out_direct ? static_cast<void*>(scores_out + off) : e->pin_out[b], e->dev_out[b], cn * outs * 4, hipMemcpyDeviceToHost, e->fs[b]));
     HIP_TRY(e, hipEventRecord(e->fe[b], e->fs[b]));
     pending_off[b] = off;
     pending_n[b] = cn;
   }
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < kFeederSlots; ++b)
     if (pending_n[b] && (rc = drain(b))) return rc;
   count_job(e, n);
   e->st.exec_ms += now_ms() - t0;
   return DDT_OK;
+}
+
+int ddt_host_register(ddt_engine* e, void* ptr, size_t bytes) {
+  if (!e) return DDT_EINVAL;
+  if (!ptr || !bytes) return fail(e, DDT_EINVAL, "ddt_host_register: NULL / empty range");
+  DeviceGuard dg(e->device);
+  if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
+  for (const auto& r : e->pinned)
+    if (r.first == ptr) return fail(e, DDT_EINVAL, "ddt_host_register: %p is registered already", ptr);
+  const hipError_t r = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  if (r != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(e, DDT_EHIP, "hipHostRegister(%p, %zu) -> %s", ptr, bytes, hipGetErrorString(r));
+  }
+  try {
+    e->pinned.emplace_back(ptr, bytes);
+  } catch (const std::bad_alloc&) {
+    (void)hipHostUnregister(ptr);
+    return fail(e, DDT_ENOMEM, "ddt_host_register");
+  }
+  return DDT_OK;
+}
+
+int ddt_host_unregister(ddt_engine* e, void* ptr) {
+  if (!e) return DDT_EINVAL;
+  DeviceGuard dg(e->device);
+  for (size_t i = 0; i < e->pinned.size(); ++i)
+    if (e->pinned[i].first == ptr) {
+      (void)hipDeviceSynchronize();
+      (void)hipHostUnregister(ptr);
+      e->pinned.erase(e->pinned.begin() + (long)i);
+      return DDT_OK;
+    }
+  return fail(e, DDT_EINVAL, "ddt_host_unregister: %p was not registered through this engine", ptr);
 }
 
 int ddt_score(ddt_engine* e, const void* tuple_lines, size_t n, float* scores_out) {

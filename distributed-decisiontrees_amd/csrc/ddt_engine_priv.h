@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "ddt_internal.h"
@@ -15,6 +16,7 @@ namespace ddt {
 
 constexpr uint32_t kMaxLdsBytes = 160u * 1024u;     // MI355X: 160 KiB LDS per CU / workgroup
 constexpr uint32_t kStreamLdsBudget = 40u * 1024u;  // stream kernels: keep >= 4 resident blocks per CU
+constexpr int kFeederSlots = 3, kQSlots = 1 + kFeederSlots;
 
 inline double now_ms() {
   using namespace std::chrono;
@@ -65,6 +67,8 @@ struct SparseForest {
 
 }  // namespace ddt
 
+struct ddt_copy_pool;  // ddt_engine.cpp
+
 struct ddt_engine {
   using Ensemble = ddt::Ensemble;
   using PrepassPlan = ddt::PrepassPlan;
@@ -80,22 +84,26 @@ struct ddt_engine {
   // feeder
   size_t feeder_rows = 1u << 20;
   int feeder_threads = 8;   // host threads that copy a chunk into the pinned staging buffer (one thread: ~26 GB/s < PCIe)
-  hipStream_t fs[2] = {nullptr, nullptr};
-  hipEvent_t fe[2] = {nullptr, nullptr};
-  void* pin_in[2] = {nullptr, nullptr};
-  void* pin_out[2] = {nullptr, nullptr};
-  void* dev_in[2] = {nullptr, nullptr};
-  void* dev_out[2] = {nullptr, nullptr};
+  hipStream_t fs[ddt::kFeederSlots] = {};   // three slots: staging of chunk k+2 | link transfer of k+1 | compute of k
+  hipEvent_t fe[ddt::kFeederSlots] = {};
+  hipStream_t copy_stream = nullptr;        // every host-to-device copy of the feeder, in order (one stream: full link rate)
+  hipEvent_t fe_in[ddt::kFeederSlots] = {};  // chunk b has arrived on the device
+  void* pin_in[ddt::kFeederSlots] = {};
+  void* pin_out[ddt::kFeederSlots] = {};
+  void* dev_in[ddt::kFeederSlots] = {};
+  void* dev_out[ddt::kFeederSlots] = {};
+  ddt_copy_pool* pool = nullptr;                         // persistent staging threads (feeder_threads - 1 workers + the caller)
+  std::vector<std::pair<void*, size_t>> pinned;          // host ranges the caller pinned through ddt_host_register
   size_t feeder_cap_rows = 0, feeder_cap_words = 0, feeder_cap_outs = 0;
   // classify workspace (grow-only)
   void* ws = nullptr;
   size_t ws_bytes = 0;
   // rank-quantised path workspace (grow-only): transposed tuples, ranks, per-tile flags
-  // slot 0: ddt_score_device / ddt_classify_device (stream ordered); slots 1, 2: the feeder's two streams
-  void* q_xT[3] = {nullptr, nullptr, nullptr};
-  void* q_q[3] = {nullptr, nullptr, nullptr};
-  void* q_flags[3] = {nullptr, nullptr, nullptr};
-  uint64_t q_rows[3] = {0, 0, 0};  // capacity in rows (multiple of 1024)
+  // slot 0: ddt_score_device / ddt_classify_device (stream ordered); slots 1..: the feeder's streams
+  void* q_xT[ddt::kQSlots] = {};
+  void* q_q[ddt::kQSlots] = {};
+  void* q_flags[ddt::kQSlots] = {};
+  uint64_t q_rows[ddt::kQSlots] = {};  // capacity in rows (multiple of 1024)
   int q_slot = 0;
   int q16_grouped_prepass = 1;  // option "q16_grouped_prepass": 0 = never split the pre-pass over feature groups
   int q16_prepass_groups = 0;   // option "q16_prepass_groups": force the number of feature groups (A/B), 0 = automatic

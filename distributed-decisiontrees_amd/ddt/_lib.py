@@ -22,6 +22,7 @@ SYMBOLS = [
     "ddt_group_create", "ddt_group_destroy", "ddt_group_last_error", "ddt_group_engine", "ddt_group_load_model",
     "ddt_group_load_model_sparse", "ddt_group_score", "ddt_group_load_model_multiclass", "ddt_group_classify", "ddt_debug_prepass_image", "ddt_debug_sparse_image",
     "ddt_shard_range", "ddt_debug_model_image", "ddt_comm_chunk_schedule", "ddt_comm_score", "ddt_group_load_model_replicated", "ddt_group_score_rows",
+    "ddt_host_register", "ddt_host_unregister",
 ]
 
 
@@ -97,6 +98,8 @@ def bind(L):
     L.ddt_load_model_shard.restype, L.ddt_load_model_shard.argtypes = i32, [vp, PP, vp, sz, vp, sz, u32, u32]
     L.ddt_score.restype, L.ddt_score.argtypes = i32, [vp, vp, sz, vp]
     L.ddt_score_device.restype, L.ddt_score_device.argtypes = i32, [vp, vp, sz, vp, vp]
+    L.ddt_host_register.restype, L.ddt_host_register.argtypes = i32, [vp, vp, sz]
+    L.ddt_host_unregister.restype, L.ddt_host_unregister.argtypes = i32, [vp, vp]
     L.ddt_chain_sum_device.restype, L.ddt_chain_sum_device.argtypes = i32, [vp, vp, u32, sz, vp, vp]
     L.ddt_load_model_multiclass.restype = i32
     L.ddt_load_model_multiclass.argtypes = [vp, PP, vp, sz, vp, sz, u32, i32, u32, u32]

@@ -208,16 +208,26 @@ class Engine:
         self._check(self._L.ddt_set_option(self._h, key.encode(), int(value)))
 
     # ---- scoring ----------------------------------------------------------------------------------
-    def score(self, tuple_lines: np.ndarray) -> np.ndarray:
-        """Host buffers through the pinned double-buffered feeder (the PCIe tuple stream)."""
+    def score(self, tuple_lines: np.ndarray, out: np.ndarray | None = None) -> np.ndarray:
+        """Host buffers through the pinned, pipelined feeder (the PCIe tuple stream); buffers pinned with host_register skip the staging."""
         t = np.ascontiguousarray(tuple_lines).view(np.uint32)
         if self.params is None:  # let the library report DDT_ESTATE
             self._check(self._L.ddt_score(self._h, t.ctypes.data, 1, t.ctypes.data))
         W = tuple_words(self.params.num_features)
         t = t.reshape(-1, W)
-        out = np.empty(t.shape[0], np.float32)
+        if out is None:
+            out = np.empty(t.shape[0], np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size >= t.shape[0]
         self._check(self._L.ddt_score(self._h, t.ctypes.data, t.shape[0], out.ctypes.data))
         return out
+
+    def host_register(self, a: np.ndarray):
+        """Pin a host array for this engine's device (ddt_host_register): ddt_score then DMAs it directly."""
+        assert a.flags.c_contiguous
+        self._check(self._L.ddt_host_register(self._h, a.ctypes.data, a.nbytes))
+
+    def host_unregister(self, a: np.ndarray):
+        self._check(self._L.ddt_host_unregister(self._h, a.ctypes.data))
 
     def score_device(self, d_tuples, out=None, stream=None):
         """torch CUDA tensor of tuple lines ([n, W] int32/uint32/float32) -> torch float32 [n], asynchronous."""

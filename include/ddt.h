@@ -128,6 +128,14 @@ int ddt_shard_range(uint32_t num_trees, uint32_t shard_index, uint32_t shard_cou
 
 /* -- scoring (replaces: the tuple PCIe stream in / result stream out, PCIeReceiver.sv:276-312,
  *    ResultsCombiner.sv:136-160,193; N need not be a multiple of 4 here, unlike A14) ------------------ */
+/* -- pinned host buffers (replaces: the host-side DMA "slots" of the reference's PCIe path, PCIeShim.sv:99-130 -- the host
+ *    program of the reference hands the FPGA buffers the DMA engine can read; pageable memory has to be staged first).
+ *    ddt_host_register pins [ptr, ptr + bytes) for this engine's device (hipHostRegister); ddt_score / ddt_classify calls whose
+ *    tuple buffer (and, for ddt_score, score buffer) lies inside a registered range then move the data with the DMA engine
+ *    directly -- no staging copy through the engine's own pinned buffers.  Unregister before freeing the memory.          -- */
+int ddt_host_register(ddt_engine* e, void* ptr, size_t bytes);
+int ddt_host_unregister(ddt_engine* e, void* ptr);
+
 /* Host buffers: tuple_lines = n_tuples * ceil(F/4) lines of 16 B; scores_out = n_tuples fp32.
  * Streams the batch through a pinned, double-buffered hipMemcpyAsync feeder (the PCIe feeder).      */
 int ddt_score(ddt_engine* e, const void* tuple_lines, size_t n_tuples, float* scores_out);

@@ -29,7 +29,7 @@ struct hipDeviceProp_t {
   int multiProcessorCount, clockRate;
   size_t sharedMemPerBlock, maxSharedMemoryPerMultiProcessor;
 };
-enum { hipHostMallocDefault = 0 };
+enum { hipHostMallocDefault = 0, hipHostRegisterDefault = 0 };
 
 extern "C" {
 const char* hipGetErrorString(hipError_t e);
@@ -52,6 +52,8 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int device);
 hipError_t hipGetLastError(void);
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
 hipError_t hipHostFree(void* p);
+hipError_t hipHostRegister(void* p, size_t bytes, unsigned flags);
+hipError_t hipHostUnregister(void* p);
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);

@@ -421,6 +421,8 @@ hipError_t hipHostFree(void* p) {
   free(p);
   return hipSuccess;
 }
+hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+hipError_t hipHostUnregister(void*) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0); }
 hipError_t hipEventSynchronize(hipEvent_t e) {
   std::unique_lock<std::mutex> lk(M);

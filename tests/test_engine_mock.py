@@ -438,7 +438,9 @@ REMOVED = {
     "class_stream_end": ("  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));\n    HIP_TRY(e, hipStreamWaitEvent(s, e->class_ev[1], 0));\n",
                          "  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));\n"),
     # the feeder refills a pinned buffer without waiting for the chunk that still uses it
-    "feeder_drain": ("    if (pending_n[b] && (rc = drain(b))) return rc;\n    parallel_copy(", "    parallel_copy("),
+    "feeder_drain": ("    if (pending_n[b] && (rc = drain(b))) return rc;\n    // ALL host-to-device copies", "    // ALL host-to-device copies"),
+    # a slot's kernels no longer wait for their chunk to arrive over the (separate) copy stream
+    "feeder_h2d_event": ("    HIP_TRY(e, hipStreamWaitEvent(e->fs[b], e->fe_in[b], 0));\n", ""),
 }
 
 
@@ -464,7 +466,7 @@ def test_the_model_catches_a_missing_dependency_in_the_engine(which):
             assert bad.ddt_set_option(e, b"variant", _variant(bad, "q16_d8_c8_u4_gl")) == 0
             assert bad.ddt_load_model_multiclass(e, C.byref(p), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8, K, 1, 0, 1) == 0
             ok = True
-            if which == "feeder_drain":
+            if which.startswith("feeder"):
                 assert bad.ddt_set_option(e, b"feeder_rows", 256) == 0
                 hl, hs = np.full(n, -1, np.int32), np.full((K, n), np.nan, np.float32)
                 keep.append((hl, hs))
@@ -518,3 +520,28 @@ def test_a_refused_sparse_option_keeps_the_model(mock):
     assert mock.ddt_set_option(e, b"sparse_top_levels", 10) == -5 and scores_still_right()     # refused again: K = 6 stays
     assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_k6")
     mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+def test_registered_host_buffers_skip_the_staging(mock, policy, seed):
+    """ddt_host_register: tuples and scores move straight between the caller's (pinned) buffers and the device; same results, many
+    chunks through the three feeder slots; a buffer outside the registered range still takes the staged path."""
+    mock.mock_reset(policy, seed, 8)
+    T, D, F, n = 40, 8, 32, 5003
+    m, x = O.gen_model(T, D, F, 1), O.gen_tuples(0, n, F, 1)
+    want = O.score(m, x)
+    e = _engine(mock)
+    _load(mock, e, m, ddt.make_params(T, D, F), "q16_d8_c8_u4_gl_s2")
+    assert mock.ddt_set_option(e, b"feeder_rows", 600) == 0
+    out = np.full(n, np.nan, np.float32)
+    assert mock.ddt_host_register(e, x.ctypes.data, x.nbytes) == 0
+    assert mock.ddt_host_register(e, x.ctypes.data, x.nbytes) == -1            # twice
+    assert mock.ddt_host_register(e, out.ctypes.data, out.nbytes) == 0
+    assert mock.ddt_score(e, x.ctypes.data, n, out.ctypes.data) == 0, mock.ddt_last_error(e)
+    assert np.array_equal(_bits(out), _bits(want))
+    other = np.full(n, np.nan, np.float32)                                     # unregistered output: drained through the pinned slot
+    assert mock.ddt_score(e, x.ctypes.data, n, other.ctypes.data) == 0 and np.array_equal(_bits(other), _bits(want))
+    assert mock.ddt_host_unregister(e, x.ctypes.data) == 0 and mock.ddt_host_unregister(e, x.ctypes.data) == -1
+    out[:] = np.nan
+    assert mock.ddt_score(e, x.ctypes.data, n, out.ctypes.data) == 0 and np.array_equal(_bits(out), _bits(want))   # staged in, direct out
+    mock.ddt_destroy(e)                                                        # hands back what is still registered
