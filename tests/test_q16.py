@@ -65,9 +65,9 @@ def test_auto_selection_and_fallbacks():
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)
     assert e.info().variant_name.decode() == "d8_t1024_r1_c4_u4_dma_f"
     _prepass(e, 0)
-    e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 12)         # 84 trees x 8 levels >= 640: q16 with the LDS-resident pre-pass
+    e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 12)         # 84 trees x 8 levels >= 480: q16 with the LDS-resident pre-pass
     assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2" and e.info().prepass_groups in (1, 2, 4, 8)
-    e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 16)         # 63 trees: below the break-even either way
+    e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 20)         # 50 trees: below the break-even either way
     assert e.info().prepass_groups == 0
     with pytest.raises(ddt.DDTError):
         e.set_option("q16_prepass_groups", 3)                       # 0, 1, 2, 4 or 8

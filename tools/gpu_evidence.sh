@@ -12,6 +12,9 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 ( timeout 300 python __graft_entry__.py smoke ) > $OUT/smoke.log 2>&1; grep "smoke ok" $OUT/smoke.log
 ( timeout 900 python bench.py ) > $OUT/bench_cfg3.log 2> $OUT/bench_cfg3.err; tail -1 $OUT/bench_cfg3.log | cut -c1-300
 ( timeout 900 python bench.py --config 4 ) > $OUT/bench_cfg4.log 2> $OUT/bench_cfg4.err; tail -1 $OUT/bench_cfg4.log | cut -c1-300
+for cfg in 1 2 5; do
+  ( timeout 900 python bench.py --config $cfg ) > $OUT/bench_cfg$cfg.log 2> $OUT/bench_cfg$cfg.err; tail -1 $OUT/bench_cfg$cfg.log | cut -c1-300
+done
 for cfg in 3 4; do
   B="python $GRAFT_REPO_ROOT/bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-streamed"
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats_cfg$cfg -o bench -- $B ) > $OUT/stats_cfg$cfg.log 2>&1; echo "cfg$cfg stats rc=$?"
@@ -26,3 +29,9 @@ done
 ( timeout 600 python bench.py --steps 3 --warmup 1 --trees 125 --force-collectives --taper 1 --no-cpu-baseline --no-streamed ) > $OUT/bench_force_t125_taper.log 2>/dev/null
 ( timeout 600 python bench.py --steps 3 --warmup 1 --force-collectives --taper 1 --no-cpu-baseline --no-streamed ) > $OUT/bench_force_allreduce_taper.log 2>/dev/null
 tail -qn1 $OUT/bench_force_*.log $OUT/bench_t125.log | cut -c1-160
+# SQ / LDS / TA counters of the shipped depth-8 kernel (separate passes, 8 M rows)
+S="python $GRAFT_REPO_ROOT/tools/sweep.py --shapes 1000x8x32x8000000 --only q16_d8_c8_u4_gl_s2"
+tools/pmc_session.sh $tag/pmc_q16 "$S" \
+  "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVES GRBM_GUI_ACTIVE" \
+  "TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" | tail -4
