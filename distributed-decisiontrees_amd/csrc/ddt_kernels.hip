@@ -1,7 +1,7 @@
 // ddt_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4).  No MFMA: the path is
 // compare + gather.  Measured binding resources on the headline shape (profiles/): the CU's
-// LDS pipe (2 DS ops per node visit) together with VALU issue (4 ops per visit); on the rank-quantised path
-// both sit at 82-90 % of their issue ceilings.
+// LDS pipe (2 DS ops per node visit) together with VALU issue (4 ops per visit, ~4 cycles each per wave and SIMD);
+// the rank-quantised depth-8 walk runs at 95 % of its VALU bound (tools/ubench).
 //
 // Hot path replaced: the DTPU traversal loop + leaf reduce of the reference
 //   rtl/DTEngine/core/DTPU.sv:579-760       read node -> gather feature -> compare -> next node -> leaf

@@ -27,7 +27,7 @@ land in the PU memories, and which base offsets the per-tree instructions carry 
 
 Stimulus: the lines arrive back to back (what the input FIFO delivers while it is non-empty).  Observations about the
 published RTL made while writing this (recorded in the vectors, asserted by tests/test_oracle_program.py, documented in
-DESIGN.md section 2; none is replicated by oracle or engine):
+profiles/EXPERIMENTS.md, last table; none is replicated by oracle or engine):
   (3) TFI_wen = ~mode[0] & ~mode[1] & (pu == PU_ID) has no valid qualifier (DTPU.sv:343): "feature-index line" and "idle"
       are the same encoding, so EVERY idle cycle -- and every line addressed to a disabled cluster, Core.sv:467 -- whose pu
       field equals the PU's id writes the feature-index memory and advances its pointer (`idle_tfi_advance`)

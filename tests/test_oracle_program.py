@@ -121,7 +121,7 @@ def test_accumulator_with_its_control_is_sequential_from_three_cycles_apart(prog
     """core/FPAggregator.v executed as a whole (clocked block by the interpreter, 2-stage adder and delay as pipelines, the absent
     quick_fifo as a show-ahead FIFO): values that arrive >= 3 cycles apart are summed strictly in arrival order -- orc_aggregate,
     acc <- x + acc, the order the oracle and the engine implement.  Closer together the published module is defective (#8 of
-    DESIGN.md's table): it pops every 2 cycles, a sum re-enters the adder after 3, and the output is the interleaved chain that
+    the table in profiles/EXPERIMENTS.md): it pops every 2 cycles, a sum re-enters the adder after 3, and the output is the interleaved chain that
     holds the last value -- there is no other "reference order" hiding there, just lost addends."""
     lens, spacings, out = prog["agg_lengths"], [int(x) for x in prog["agg_spacings"]], prog["agg_out"]
     L = O.lib()
