@@ -614,6 +614,45 @@ __global__ __launch_bounds__(1024) void gather_kernel(const char* __restrict__ w
   out[blockIdx.x * 1024 + tid] = acc;
 }
 
+// gather cost vs live lanes: only lanes < live issue the (16-byte) gather -- exec-masked, the others skip it
+__global__ __launch_bounds__(1024) void gather_live_kernel(const char* __restrict__ win, uint32_t win_bytes, uint32_t region_bytes, uint32_t* out, int iters,
+                                                           uint32_t live, int same_line_for_dead) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  uint32_t idx[8], acc = 0;
+  const uint32_t regions = win_bytes / region_bytes, recs = region_bytes / 16u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) idx[k] = (tid * 2654435761u + k * 40503u) >> 4;
+  for (int it = 0; it < iters; ++it) {
+    u32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t off = (((uint32_t)it * 8u + k) % regions) * region_bytes + (idx[k] % recs) * 16u;
+      v[k] = u32x4{0u, 0u, 0u, 0u};
+      if (same_line_for_dead) v[k] = *reinterpret_cast<const u32x4*>(win + (lane < live ? off : 0u));  // dead lanes re-read record 0 (the sparse kernel's form)
+      else if (lane < live) v[k] = *reinterpret_cast<const u32x4*>(win + off);                        // dead lanes masked off
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      acc += v[k].x ^ v[k].w;
+      idx[k] = idx[k] * 1664525u + 1013904223u + (v[k].y & 1u);
+    }
+  }
+  out[blockIdx.x * 1024 + tid] = acc;
+}
+static void run_gather_live(uint32_t* d_out, const char* d_win, uint32_t live, int same, std::string& js) {
+  const int iters = 400, blocks = g_cus * 2;
+  Timer t;
+  hipLaunchKernelGGL(gather_live_kernel, dim3(blocks), dim3(1024), 0, 0, d_win, 1u << 20, 2048u, d_out, 4, live, same);
+  CK(hipDeviceSynchronize());
+  t.start();
+  hipLaunchKernelGGL(gather_live_kernel, dim3(blocks), dim3(1024), 0, 0, d_win, 1u << 20, 2048u, d_out, iters, live, same);
+  const double ms = t.stop_ms();
+  char buf[256];
+  snprintf(buf, sizeof buf, "    {\"live_lanes\": %u, \"dead_lanes\": \"%s\", \"ms\": %.3f, \"cycles_per_wave_gather_per_cu\": %.2f},\n", live,
+           same ? "re-read record 0" : "exec-masked", ms, ms * 1e-3 * g_clock_ghz * 1e9 / ((double)iters * 8.0 * 32.0));
+  js += buf;
+}
+
 template <int S>
 static void run_gather(uint32_t* d_out, const char* d_win, uint32_t win_bytes, uint32_t region_bytes, std::string& js) {
   const int iters = 400, blocks = g_cus * 2;
@@ -743,6 +782,10 @@ int main(int argc, char** argv) {
     run_gather<16>(d_out, d_win, 65536, 2048, js);
     run_gather<4>(d_out, d_win, 1 << 20, 1024, js);
     run_gather<16>(d_out, d_win, 1 << 20, 2048, js);
+    strip_comma(js);
+    js += "  ],\n  \"gather_live_lanes_16B_1MiB_window\": [\n";
+    for (int same = 0; same < 2; ++same)
+      for (uint32_t live : {64u, 32u, 16u, 8u, 2u}) run_gather_live(d_out, d_win, live, same, js);
     strip_comma(js);
     js += "  ],\n";
     CK(hipFree(d_win));
