@@ -112,6 +112,35 @@ struct RefAcc {
     }
     return t;
   }
+  // the same sum WITHOUT align(): ring slot k holds cluster (pos + k) mod C, so cluster c sits in slot (c - pos) mod C; one
+  // wave-uniform branch per possible pos instead of up to C - 1 rotations of 8 moves (the stream kernel's 56 v_mov per
+  // tuple).  sum_mode 2 keeps the align() route (its adds are long; fifteen inlined orders of them would only grow the code).
+  template <int CC, int P>
+  __device__ __forceinline__ float seq(int r) const {
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < CC; ++c) t = a[r][(c - P + CC) % CC] + t;
+    return t;
+  }
+  template <int CC, int P = 0>
+  __device__ __forceinline__ float by_pos(int r) const {
+    if constexpr (P == CC - 1) {
+      return seq<CC, P>(r);
+    } else {
+      if (pos == (uint32_t)P) return seq<CC, P>(r);
+      return by_pos<CC, P + 1>(r);
+    }
+  }
+  __device__ __forceinline__ float total_ring(int r, uint32_t C, bool exact = false) {
+    if (exact) {
+      align(C);
+      return total(r, C, true);
+    }
+    if (C == 8u) return by_pos<8>(r);
+    if (C == 4u) return by_pos<4>(r);
+    if (C == 2u) return by_pos<2>(r);
+    return seq<1, 0>(r);
+  }
 };
 
 // fold the leaves of one sub-group of U trees (stream order) into the accumulators.  SUM 1: fp64 in stream order.
@@ -190,6 +219,13 @@ __device__ __forceinline__ void fold_leaves(const float (&lf)[R][U], const int p
 //   level is 16-byte records {thr, w2, leafL, leafR} at 4*2^D + 16*(m - 2^(D-1)), so the leaf comes
 //   with its parent (one LDS round trip and one DS op less per tree).
 // ---------------------------------------------------------------------------------------------------
+// (x & 0xFFFFFF) + y in one VALU instruction (hipcc turns the multiply by one into v_and + v_add)
+__device__ __forceinline__ uint32_t low24_plus(uint32_t x, uint32_t y) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, 1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+
 template <bool SLOW>
 __device__ __forceinline__ bool go_right(uint32_t f, uint32_t thr, uint32_t w2, uint32_t miss_key) {
   bool right = (int32_t)f >= (int32_t)thr;                         // !(feature < threshold), DTPU.sv:655-657
@@ -197,7 +233,10 @@ __device__ __forceinline__ bool go_right(uint32_t f, uint32_t thr, uint32_t w2, 
   return right;
 }
 
-template <int D, int U, int R, int TREE_BYTES, bool SLOW, bool FUSED>
+// ADD (stream kernel): the feature rows are not multiples of the row size apart (Variant::feat_word_stream), so the lane's
+// column offset is ADDED to the low 24 bits of the node's feature word -- one v_mad_u32_u24 (x1), which also drops the
+// miss_right flag in bit 31 -- instead of OR-ed (v_and_or_b32)
+template <int D, int U, int R, int TREE_BYTES, bool SLOW, bool FUSED, bool ADD = false>
 __device__ __forceinline__ void walk_trees(const uint32_t base, const uint32_t (&lane_off)[R], const uint32_t miss_key,
                                            float (&leaf)[R][U]) {
   constexpr int LAST = FUSED ? D - 1 : D;  // levels walked over 8-byte records
@@ -218,13 +257,15 @@ __device__ __forceinline__ void walk_trees(const uint32_t base, const uint32_t (
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int u = 0; u < U; ++u) f[r][u] = lds_u32((nd[r][u].y & 0x7FFFFFFFu) | lane_off[r]);  // ds_read_b32, conflict-free
+      for (int u = 0; u < U; ++u)  // ds_read_b32, conflict-free
+        f[r][u] = lds_u32(ADD ? low24_plus(nd[r][u].y, lane_off[r]) : ((nd[r][u].y & 0x7FFFFFFFu) | lane_off[r]));
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int u = 0; u < U; ++u)
         m8[r][u] = (m8[r][u] << 1) + (go_right<SLOW>(f[r][u], nd[r][u].x, nd[r][u].y, miss_key) ? 8u : 0u);
   }
+  static_assert(!(FUSED && ADD), "the fused last level is the tile kernel's");
   if (FUSED) {
     uint4 rec[R][U];
 #pragma unroll

@@ -534,7 +534,9 @@ int pack_image(ddt_engine* e, const Variant& v, const Ensemble& m, std::vector<u
   // feature word of feature j: generic = j itself; tile/stream = absolute LDS byte address of row j
   const uint32_t row = v.row_bytes();
   const uint32_t feat_off = v.kind == kKindTile ? v.feat_off() : v.kind == kKindStream ? v.feat_off_stream(Tpad) : 0u;
-  auto feature_word = [&](uint32_t j) { return v.kind == kKindGeneric ? j : feat_off + j * row; };
+  auto feature_word = [&](uint32_t j) {
+    return v.kind == kKindGeneric ? j : v.kind == kKindStream ? v.feat_word_stream(Tpad, j) : feat_off + j * row;
+  };
   const bool fused = v.kind == kKindTile && (v.opt & 1);
   const uint32_t first_last = 1u << (D - 1);  // 1-based index of the first last-level node
   for (uint32_t i = 0; i < Tpad; ++i) {
@@ -775,6 +777,7 @@ void fill_args(const ddt_engine* e, const Ensemble& m, const void* d_tuples, siz
   a->top_levels = 0;
   a->ev_mid = nullptr;
   a->num_cus = e->prop.multiProcessorCount > 0 ? (uint32_t)e->prop.multiProcessorCount : 256u;
+  a->stream_blocks_per_cu = (uint32_t)e->stream_blocks_per_cu;
 }
 
 void feeder_free(ddt_engine* e) {
@@ -1421,6 +1424,11 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     DeviceGuard dg(e->device);
     if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
     return ensure_q16_workspace(e, (size_t)value);
+  }
+  if (!strcmp(key, "stream_blocks_per_cu")) {  // persistent stream kernel: blocks per CU, 0 (default) = the resident number
+    if (value < 0 || value > 16) return fail(e, DDT_EINVAL, "stream_blocks_per_cu %lld not in 0..16", (long long)value);
+    e->stream_blocks_per_cu = (int)value;
+    return DDT_OK;
   }
   if (!strcmp(key, "class_streams")) {  // 1 (default): the classes of a multi-class model alternate between two streams; 0: one stream
     e->class_streams = value != 0;

@@ -116,6 +116,7 @@ struct ddt_engine {
   hipStream_t class_stream = nullptr;
   hipEvent_t class_ev[2] = {nullptr, nullptr};
   int class_streams = 1;
+  int stream_blocks_per_cu = 0;  // option "stream_blocks_per_cu": persistent stream kernel, blocks per CU (0 = resident blocks)
   // sparse forests (ddt_load_model_sparse)
   bool sparse = false;
   std::vector<ddt::SparseForest> sps;  // one per class (single-output models: exactly one)

@@ -43,6 +43,7 @@ struct ScoreArgs {
   uint32_t top_levels;     // generic kernel, deep trees: levels of each tree staged in LDS (set by launch_generic)
   hipEvent_t ev_mid;       // optional ("kernel_timing"): recorded right before the scoring kernel proper
   uint32_t num_cus;        // hipDeviceProp_t::multiProcessorCount: sizes the persistent grids
+  uint32_t stream_blocks_per_cu;  // stream kernel: 0 = as many blocks per CU as are resident, else forced (option, A/B)
 };
 
 constexpr uint32_t kQ16RankBuckets = 4096;
@@ -96,6 +97,7 @@ struct SparseAux {           // ScoreArgs::aux of the sparse kernels
 
 enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2, kKindQ16 = 3, kKindSparse = 4 };
 
+constexpr uint32_t kStreamSkew = 64u;  // bytes, see Variant::feat_word_stream
 struct Variant {
   const char* name;
   int kind;
@@ -126,8 +128,13 @@ struct Variant {
     const uint32_t row = row_bytes(), need = n_trees_padded * tree_bytes();
     return (need + row - 1u) / row * row;
   }
+  // the rows of tuple line q (features 4q..4q+3) start kStreamSkew * q bytes late: the four lanes that stage the four lines
+  // of one tuple then hit four different groups of 16 banks (conflict-free transposed stores; it was 4-way)
+  uint32_t feat_word_stream(uint32_t n_trees_padded, uint32_t j) const {
+    return feat_off_stream(n_trees_padded) + j * row_bytes() + kStreamSkew * (j / 4u);
+  }
   uint32_t lds_bytes_stream(uint32_t n_trees_padded, uint32_t tuple_words) const {
-    return feat_off_stream(n_trees_padded) + tuple_words * row_bytes() + 64u;
+    return feat_off_stream(n_trees_padded) + tuple_words * row_bytes() + kStreamSkew * (tuple_words / 4u) + 64u;
   }
   // ---- q16 kernels: 4-byte node records + fp32 leaves = 8*2^D bytes per tree; u16 feature tile ----
   // opt bit 0 ("_gl"): only the node records are staged in LDS (4*2^D bytes per tree); the leaves stay in global memory and

@@ -23,6 +23,8 @@
 //   chain_sum_kernel, argmax_kernel, synth_tuples_kernel   multi-device combine, class labels, bench inputs.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "ddt_device.h"
 #include "ddt_internal.h"
 
@@ -333,71 +335,88 @@ static hipError_t launch_tile_persist(const ScoreArgs& a, const Variant& v, hipS
 // ---------------------------------------------------------------------------------------------------
 // the stream kernel: small ensembles whose whole image fits in LDS next to one tile of tuples -- the
 // HBM-bound regime (e.g. BASELINE config 1: 8 trees x depth 4 = 32 node visits per 68 compulsory bytes).
-// Persistent blocks (grid = CUs x blocks/CU) walk the tiles with a grid stride.  Tuples are read with
-// fully coalesced 16-byte loads (thread t takes float4 #t of the tile's contiguous byte range), one tile
-// AHEAD of the compute, and written transposed into LDS.  The transposed write is LPT-way bank conflicted
-// (LPT = lines per tuple); that costs ~LPT LDS cycles per tuple, negligible against the HBM time here and
-// the price of perfectly coalesced reads.  Model image: classic layout at LDS [0, img_bytes).
-// Round 3 tried, on config 1 (profiles/r03_sweep_stream_*.json), and did not keep: quad-coalesced loads + DPP transpose
-// (conflict-free LDS writes: 3.07 vs 3.00 ms -- the LDS pipe is not what holds the kernel back), two tiles in flight per
-// block (103 VGPRs -> 4 blocks per CU: 2.94 vs 2.90), register caps for 6 / 8 blocks per CU (spills: 3.04 / 3.89).  The
-// kernel keeps 83 VGPRs = 5 resident blocks per CU = 80 KiB of loads in flight per CU at ~4.5 us of loaded HBM latency.
+// Persistent blocks (grid = CUs x resident blocks per CU) walk the tiles with a grid stride.  Tuples are read with
+// fully coalesced, nontemporal 16-byte loads (thread t takes float4 #t of the tile's contiguous byte range), one tile
+// AHEAD of the compute, and written transposed into LDS; the rows of tuple line q start 64 q bytes late
+// (Variant::feat_word_stream), which makes those stores conflict-free.  Model image: classic layout at LDS [0, img_bytes).
+// What bounds it (profiles/EXPERIMENTS.md, round 3): the memory pattern itself.  tools/ubench `tilepat` -- this kernel's loads
+// and stores without any compute -- reads 6.6-6.9 TB/s with no result store and 4.7-5.3 TB/s with the 4-byte result per
+// 64-byte tuple (any store shape: 4 B or 16 B per lane, nontemporal, 4 KiB bursts); this kernel runs at 4.8-5.3.  Getting
+// there took a VALU trim (488 -> 258 VALU instructions per tuple: 2.90 -> 2.73 ms per 200 M tuples).  Not kept, all equal
+// within box noise once the trim was in: 7 / 8 waves per SIMD, two tiles in flight per block, quad loads + DPP transpose.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 256;
 constexpr uint32_t kStreamRow = kStreamThreads * 4u;
 
-template <int D, int U, int MAXLPT>
-__global__ __launch_bounds__(kStreamThreads) void score_stream_kernel(const ScoreArgs a) {
+// FIXED: the tuple has exactly MAXLPT lines (config 1: 16 features = 4 lines), so element -> (tuple, line) is a shift and the
+// sixteen LDS stores of a thread share one address register.  Round 3 counters (profiles/r03_pmc_stream_cfg1.md) showed this
+// kernel VALU-bound, not HBM-bound: 488 VALU instructions per tuple = 92 % VALU issue; staging (runtime division, per-word
+// missing bookkeeping) and the accumulator ring's align() were 60 % of them.
+template <int D, int U, int MAXLPT, bool FIXED>
+__device__ __forceinline__ void stream_body(const ScoreArgs& a) {
   constexpr int THREADS = kStreamThreads, TILE = kStreamThreads;
   constexpr int TREE_BYTES = 12 << D;
   const int tid = threadIdx.x;
-  const uint32_t W = a.tuple_words, LPT = W / 4u;
+  const uint32_t W = a.tuple_words, LPT = FIXED ? (uint32_t)MAXLPT : W / 4u;
   const uint32_t img_bytes = a.n_trees * (uint32_t)TREE_BYTES;
   const uint32_t feat_off = (img_bytes + kStreamRow - 1u) / kStreamRow * kStreamRow;  // == host's Variant::feat_off
-  const uint32_t flags = feat_off + W * kStreamRow;
+  const uint32_t flags = feat_off + W * kStreamRow + LPT * kStreamSkew;
   const uint64_t n_tiles = (a.n + TILE - 1) / TILE;
-  const uint32_t C = a.clusters, miss_key = a.miss_key;
+  const uint32_t C = a.clusters, miss_key = a.miss_key, miss_raw = a.miss_raw;
 
   // resident model
   for (uint32_t off = (uint32_t)tid * 16u; off < img_bytes; off += THREADS * 16u)
     lds_st_u4(off, a.img[off / 16u]);
 
   // element e (0..TILE*LPT) of a tile = float4 #e of its byte range: tuple e / LPT, line e % LPT
-  uint4 pre[MAXLPT];
-  auto prefetch = [&](uint64_t tile) {
-    const uint4* src = reinterpret_cast<const uint4*>(a.tuples + tile * TILE * W);
-    const uint64_t avail = (a.n - tile * TILE < (uint64_t)TILE ? a.n - tile * TILE : (uint64_t)TILE) * LPT;
+  auto prefetch = [&](uint64_t tile, u32x4 (&pre)[MAXLPT]) {
+    // nontemporal: the tuple stream is read once (tools/ubench `hbm`: 6.5 vs 5.9 TB/s read-only; this kernel on config 1: 2.90 vs 3.04 ms)
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.tuples + tile * TILE * W);
+    const uint64_t rows_left = a.n - tile * TILE;
+    if (rows_left >= (uint64_t)TILE) {  // wave-uniform: a full tile loads unguarded
 #pragma unroll
-    for (int i = 0; i < MAXLPT; ++i) {
-      const uint32_t e = (uint32_t)tid + (uint32_t)i * THREADS;
-      // nontemporal: the tuple stream is read once (tools/ubench `hbm`: 6.5 vs 5.9 TB/s read-only; this kernel on config 1: 2.90 vs 3.04 ms)
-      if ((uint32_t)i < LPT && e < avail) {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src) + e);
-        pre[i] = make_uint4(v.x, v.y, v.z, v.w);
-      } else pre[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-  };
-
-  uint64_t tile = blockIdx.x;
-  if (tile < n_tiles) prefetch(tile);
-  for (; tile < n_tiles; tile += gridDim.x) {
-    __syncthreads();  // previous tile fully consumed (first pass: model image written)
-    uint32_t miss_any = 0;
+      for (int i = 0; i < MAXLPT; ++i)
+        if (FIXED || (uint32_t)i < LPT) pre[i] = __builtin_nontemporal_load(src + ((uint32_t)tid + (uint32_t)i * THREADS));
+    } else {
+      const uint32_t avail = (uint32_t)rows_left * LPT;
 #pragma unroll
-    for (int i = 0; i < MAXLPT; ++i) {
-      if ((uint32_t)i < LPT) {
+      for (int i = 0; i < MAXLPT; ++i) {
         const uint32_t e = (uint32_t)tid + (uint32_t)i * THREADS;
-        const uint32_t t = e / LPT, q = e - t * LPT;
-        const bool valid = tile * TILE + t < a.n;
-        const uint32_t fa = feat_off + (4u * q) * kStreamRow + t * 4u;
-        lds_st_u32(fa + 0 * kStreamRow, stage_word(pre[i].x, a, miss_any, valid));
-        lds_st_u32(fa + 1 * kStreamRow, stage_word(pre[i].y, a, miss_any, valid));
-        lds_st_u32(fa + 2 * kStreamRow, stage_word(pre[i].z, a, miss_any, valid));
-        lds_st_u32(fa + 3 * kStreamRow, stage_word(pre[i].w, a, miss_any, valid));
+        if ((FIXED || (uint32_t)i < LPT) && e < avail) pre[i] = __builtin_nontemporal_load(src + e);
+        else pre[i] = u32x4{0u, 0u, 0u, 0u};  // rows past n: zeros (may only make the last tile take the slow walk)
       }
     }
-    const bool slow = block_any<THREADS>(miss_any, flags, tid);
-    if (tile + gridDim.x < n_tiles) prefetch(tile + gridDim.x);  // next tile's HBM reads fly during the walk
+  };
+  // raw / IEEE-key transform of the staged words + missing detection; the detection is a compare into a lane mask that
+  // the scalar unit ORs together
+  auto stage = [&](auto ieee_tag, const u32x4 (&pre)[MAXLPT]) -> bool {
+    constexpr bool IEEE = decltype(ieee_tag)::value;
+    bool miss_any = false;
+#pragma unroll
+    for (int i = 0; i < MAXLPT; ++i) {
+      if (FIXED || (uint32_t)i < LPT) {
+        const uint32_t e = (uint32_t)tid + (uint32_t)i * THREADS;
+        const uint32_t t = e / LPT, q = e - t * LPT;
+        const uint32_t fa = feat_off + (4u * q) * kStreamRow + q * kStreamSkew + t * 4u;  // Variant::feat_word_stream
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          uint32_t v = pre[i][c];
+          const bool m = v == miss_raw;
+          miss_any |= m;
+          if (IEEE) v = m ? kMissSentinelIeee : ieee_key(v);
+          lds_st_u32(fa + (uint32_t)c * kStreamRow, v);
+        }
+      }
+    }
+    return miss_any;
+  };
+  const uint64_t G = gridDim.x;
+  // one tile: stage `pre`, refill it with the block's next tile (its HBM reads fly during the walks), walk, store
+  auto step = [&](uint64_t tile, u32x4 (&pre)[MAXLPT]) {
+    __syncthreads();  // previous tile fully consumed (first pass: model image written)
+    const bool miss_any = a.ieee ? stage(std::true_type{}, pre) : stage(std::false_type{}, pre);  // wave-uniform
+    const bool slow = block_any<THREADS>(miss_any ? 1u : 0u, flags, tid);
+    if (tile + G < n_tiles) prefetch(tile + G, pre);
 
     RefAcc<1> ra;
     ra.init();
@@ -407,15 +426,25 @@ __global__ __launch_bounds__(kStreamThreads) void score_stream_kernel(const Scor
       float lf[1][U];
       const uint32_t base = t0 * (uint32_t)TREE_BYTES;
       const int phase = (int)((t0 / (uint32_t)U) & 1u);
-      if (!slow) walk_trees<D, U, 1, TREE_BYTES, false, false>(base, lane_off, miss_key, lf);
-      else walk_trees<D, U, 1, TREE_BYTES, true, false>(base, lane_off, miss_key, lf);
+      if (!slow) walk_trees<D, U, 1, TREE_BYTES, false, false, true>(base, lane_off, miss_key, lf);
+      else walk_trees<D, U, 1, TREE_BYTES, true, false, true>(base, lane_off, miss_key, lf);
       if (a.sum_mode != 1) fold_leaves<U, 1, 0>(lf, phase, C, ra, dacc, a.sum_mode == 2);
       else fold_leaves<U, 1, 1>(lf, phase, C, ra, dacc);
     }
-    ra.align(C);
     const uint64_t row = tile * TILE + (uint64_t)tid;
-    if (row < a.n) a.out[row] = (a.sum_mode != 1) ? ra.total(0, C, a.sum_mode == 2) : (float)dacc[0];
-  }
+    if (row < a.n) a.out[row] = (a.sum_mode != 1) ? ra.total_ring(0, C, a.sum_mode == 2) : (float)dacc[0];
+  };
+
+  uint64_t tile = blockIdx.x;
+  u32x4 pre[MAXLPT];
+  if (tile < n_tiles) prefetch(tile, pre);
+  for (; tile < n_tiles; tile += G) step(tile, pre);
+}
+
+template <int D, int U, int MAXLPT>
+__global__ __launch_bounds__(kStreamThreads) void score_stream_kernel(const ScoreArgs a) {
+  if (a.tuple_words == 4u * (uint32_t)MAXLPT) stream_body<D, U, MAXLPT, true>(a);
+  else stream_body<D, U, MAXLPT, false>(a);
 }
 
 uint32_t stream_blocks_per_cu(uint32_t lds_bytes) {
@@ -432,7 +461,20 @@ static hipError_t launch_stream(const ScoreArgs& a, const Variant& v, hipStream_
   if (e != hipSuccess) return e;
   const uint64_t tiles = (a.n + kStreamThreads - 1) / kStreamThreads;
   if (tiles == 0) return hipSuccess;
-  uint64_t grid = (uint64_t)a.num_cus * stream_blocks_per_cu(lds);  // persistent: CUs x resident blocks per CU
+  // persistent: CUs x the blocks that are actually resident per CU (registers bound this before the LDS does: a grid of
+  // LDS-many blocks per CU would run as one full wave of blocks and a thinner second one)
+  static thread_local uint32_t occ_lds = ~0u, occ_blocks = 0;
+  if (occ_lds != lds) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), kStreamThreads, lds) != hipSuccess || occ < 1)
+      occ = (int)stream_blocks_per_cu(lds);
+    occ_lds = lds;
+    occ_blocks = (uint32_t)occ;
+  }
+  uint32_t per_cu = stream_blocks_per_cu(lds);
+  if (a.stream_blocks_per_cu) per_cu = a.stream_blocks_per_cu;  // option "stream_blocks_per_cu" (A/B)
+  else if (occ_blocks < per_cu) per_cu = occ_blocks;
+  uint64_t grid = (uint64_t)a.num_cus * per_cu;
   if (grid > tiles) grid = tiles;
   hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(kStreamThreads), lds, s, a);
   return hipGetLastError();

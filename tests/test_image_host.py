@@ -73,8 +73,10 @@ def _walk_records(img, nfo, D, x, missing, cmp_mode):
             if nfo["kind"] == GENERIC:
                 j = addr
             else:
-                assert ((addr - nfo["feat_off"]) % nfo["row"] == 0).all()
                 j = (addr - nfo["feat_off"]) // nfo["row"]
+                # stream kernels: the rows of tuple line q start 64 * q bytes late (Variant::feat_word_stream)
+                skew = 64 * (j // 4) if nfo["kind"] == STREAM else 0
+                assert (addr - nfo["feat_off"] == j * nfo["row"] + skew).all()
             right = np.where(miss[rows, j], word >> 31, ~(keys[rows, j] < key.view(np.int32))).astype(np.int64)
             if last:
                 leaf = np.where(right == 1, t[base + 3], t[base + 2])

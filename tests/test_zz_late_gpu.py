@@ -159,3 +159,36 @@ def test_multi_gpu_branch_in_a_one_rank_communicator(extra):
     assert "error" not in o and "status" not in o, o
     assert o["tree_sharded_chain_ms"] > 0 and o["tree_sharded_allreduce_untapered_ms"] > 0 and o["row_sharded_ms"] > 0
     assert o["row_vs_tree_max_abs_diff_rel"] == 0.0        # one rank: every mode computes the same reference-order sums
+
+
+# ---------------------------------------------------------------------------------------------- feeder: pinned caller buffers
+def test_registered_host_buffers_on_the_gpu():
+    """ddt_host_register: the feeder DMAs the caller's pinned buffers directly (no staging / drain copies): same bits as the staged path
+    and as the resident call, many chunks through the three slots, ragged last chunk; unregister hands the pages back."""
+    import torch
+
+    T, D, F, n = 300, 8, 32, 700_001
+    m = O.gen_model(T, D, F, dist=1)
+    x = O.gen_tuples(5, n, F, dist=1)
+    e = ddt.Engine(0)
+    e.load_model(ddt.make_params(T, D, F), m.wlines, m.flines)
+    e.set_option("feeder_rows", 65_536)
+    want = e.score_device(torch.from_numpy(x.view(np.int32)).cuda()).cpu().numpy()
+    staged = e.score(x)
+    assert np.array_equal(staged.view(np.uint32), want.view(np.uint32))
+    out = np.full(n, np.nan, np.float32)
+    e.host_register(x)
+    e.host_register(out)
+    e.score(x, out=out)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    with pytest.raises(ddt.DDTError):
+        e.host_register(x)                       # twice
+    e.host_unregister(x)
+    out[:] = np.nan
+    e.score(x, out=out)                          # staged in, direct out
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    e.host_unregister(out)
+    with pytest.raises(ddt.DDTError):
+        e.host_unregister(out)
+    assert np.array_equal(O.score(m, x[:4096], sum_mode=O.SUM_REF_NATIVE).view(np.uint32), want[:4096].view(np.uint32))
+    e.close()

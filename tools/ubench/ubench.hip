@@ -8,6 +8,7 @@
 //           visit); v2 = v1 with the last level + leaves as one 16-byte global record per node
 //   gather  vector-memory gather rate out of an L1-resident window (4 / 8 / 16 bytes per lane)
 //   hbm     read-only HBM probe (16 B per lane, persistent blocks)
+//   tilepat the stream kernel's memory pattern (tile per block and step, one ahead, result store, barrier, dummy VALU work)
 // Measurement infrastructure, not product code: nothing in libddt.so includes or links this file.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -304,7 +305,7 @@ __device__ __forceinline__ void top_issue(Top4& q, const u32x4* p) {
 __device__ __forceinline__ void top_wait(Top4& q) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.t[0]), "+s"(q.t[1]), "+s"(q.t[2]), "+s"(q.t[3]));
 }
-template <int LEAF>
+template <int LEAF, int TOP = 2>
 __device__ __forceinline__ void walk_top2(const Top4& q, const uint32_t base, const uint32_t lane2, float (&leaf)[4], const float* gleaf, const char* glast) {
   constexpr int TB = LEAF == 1 ? (4 << kD) : (2 << kD);
   constexpr int LV = LEAF == 2 ? kD - 1 : kD;
@@ -312,18 +313,23 @@ __device__ __forceinline__ void walk_top2(const Top4& q, const uint32_t base, co
   // level 0: uniform record in SGPRs
 #pragma unroll
   for (int u = 0; u < 4; ++u) f[u] = lds_u16(((q.t[u].x >> 16) | lane2) + (uint32_t)kFeatOff);
+  if (TOP == 2) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const bool r0 = f[u] >= (q.t[u].x & 0xFFFFu);
-    nd[u] = r0 ? q.t[u].z : q.t[u].y;  // level-1 record
-    m[u] = r0 ? 12u : 8u;
+    for (int u = 0; u < 4; ++u) {
+      const bool r0 = f[u] >= (q.t[u].x & 0xFFFFu);
+      nd[u] = r0 ? q.t[u].z : q.t[u].y;  // level-1 record
+      m[u] = r0 ? 12u : 8u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f[u] = lds_u16(((nd[u] >> 16) | lane2) + (uint32_t)kFeatOff);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) visit<0>(m[u], nd[u], f[u], 0u);
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m[u] = (f[u] >= (q.t[u].x & 0xFFFFu)) ? 12u : 8u;
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) f[u] = lds_u16(((nd[u] >> 16) | lane2) + (uint32_t)kFeatOff);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) visit<0>(m[u], nd[u], f[u], 0u);
-#pragma unroll
-  for (int lvl = 2; lvl < LV; ++lvl) {
+  for (int lvl = TOP; lvl < LV; ++lvl) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) nd[u] = lds_u32(m[u] + (base + (uint32_t)(u * TB)));
 #pragma unroll
@@ -379,15 +385,16 @@ template <int VAR>
 __global__ __launch_bounds__(1024) void walk_kernel(const WalkArgs a) {
   const uint32_t tid = threadIdx.x;
   constexpr int LEAF = VAR / 4, FORM = VAR % 4;
-  constexpr int TB = VAR == 12 ? (8 << kD) : LEAF == 0 ? (8 << kD) : LEAF == 1 ? (4 << kD) : (2 << kD);  // LDS bytes per tree
+  constexpr int TB = VAR == 12 ? (8 << kD) : VAR == 13 ? (4 << kD) : LEAF == 0 ? (8 << kD) : LEAF == 1 ? (4 << kD) : (2 << kD);  // LDS bytes per tree
   constexpr int NT = 16384 / TB;  // resident trees
   for (uint32_t i = tid; i < 16384u / 16u; i += 1024) lds_st4(i * 16u, a.model[i]);
   for (uint32_t i = tid; i < 65536u / 16u; i += 1024) lds_st4((uint32_t)kFeatOff + i * 16u, a.tile[i]);
   __syncthreads();
   uint32_t lane2 = ((tid & 511u) << 2) | ((tid >> 9) << 1), vzero = 0u;
   float acc = 0.f;
-  if (VAR != 12 && FORM == 3) {
-    constexpr int L3 = LEAF == 0 ? 1 : LEAF;
+  if ((VAR != 12 && FORM == 3) || VAR == 13) {
+    constexpr int L3 = VAR == 13 ? 1 : (LEAF == 0 ? 1 : LEAF);
+    constexpr int TOPL = VAR == 13 ? 1 : 2;
     Top4 cur, nxt;
     top_issue(cur, a.tops);
     for (int g = 0; g < a.groups; ++g) {
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(1024) void walk_kernel(const WalkArgs a) {
         float lf[4];
         top_wait(cur);
         top_issue(nxt, a.tops + ((sg + 1) % (NT / 4)) * 4);
-        walk_top2<L3>(cur, (uint32_t)(sg * 4 * TB), lane2, lf, a.gleaf + sg * 4 * (1 << kD), reinterpret_cast<const char*>(a.glast) + sg * 4 * 2048);
+        walk_top2<L3, TOPL>(cur, (uint32_t)(sg * 4 * TB), lane2, lf, a.gleaf + sg * 4 * (1 << kD), reinterpret_cast<const char*>(a.glast) + sg * 4 * 2048);
         acc += (lf[0] + lf[1]) + (lf[2] + lf[3]);
         cur = nxt;
       }
@@ -465,6 +472,7 @@ static const WalkVariant kWalks[] = {
     {5, 16, "rec4 leaves global, cmp->vcc + v_cndmask_e32 (asm)"},
     {6, 16, "rec4 leaves global, v_addc index (asm)"},
     {7, 16, "rec4 leaves global, levels 0-1 from SGPRs (s_load one sub-group ahead)"},
+    {13, 16, "rec4 leaves global, level 0 only from SGPRs"},
     {11, 32, "gl2 + levels 0-1 from SGPRs"},
     {8, 32, "rec4 levels 0-6 in LDS, level 7 + leaves = 16-byte global record (gl2), C++"},
     {9, 32, "gl2, cmp->vcc + v_cndmask_e32 (asm)"},
@@ -541,7 +549,7 @@ static void run_walks(std::string& js) {
   std::vector<float> want(1024), got(1024);
   const uint32_t lds_bytes = kFeatOff + 65536;
   auto launch = [&](int var, int g) {
-    const int im = var == 12 ? 3 : var / 4;
+    const int im = var == 12 ? 3 : var == 13 ? 1 : var / 4;
     WalkArgs a{(const u32x4*)d_img[im], (const u32x4*)d_tile, (const float*)d_leaf, (const u32x4*)d_glast, (const u32x4*)d_tops, (float*)d_out, g};
     switch (var) {
       case 0: launch_walk<0>(a, blocks, lds_bytes); break;
@@ -549,6 +557,7 @@ static void run_walks(std::string& js) {
       case 5: launch_walk<5>(a, blocks, lds_bytes); break;
       case 6: launch_walk<6>(a, blocks, lds_bytes); break;
       case 7: launch_walk<7>(a, blocks, lds_bytes); break;
+      case 13: launch_walk<13>(a, blocks, lds_bytes); break;
       case 11: launch_walk<11>(a, blocks, lds_bytes); break;
       case 8: launch_walk<8>(a, blocks, lds_bytes); break;
       case 9: launch_walk<9>(a, blocks, lds_bytes); break;
@@ -707,6 +716,74 @@ static void run_hbm(const u32x4* d_src, size_t bytes, uint32_t* d_out, int block
   js += buf;
 }
 
+// ------------------------------------------------------------------------------------------------
+// the stream kernel's memory pattern without its compute: persistent blocks, a 16 KiB tile per block and step (4 x 16 B per
+// lane, nontemporal), loaded one tile ahead, optionally a 1 KiB result store per tile, a block barrier per tile and WORK
+// dependent VALU instructions per lane and tile
+// ------------------------------------------------------------------------------------------------
+// WR: 0 no store, 1 4 B per lane (all lanes), 2 the same nontemporal, 3 16 B per lane from the first wave only, 4 the same
+// nontemporal, 5 like 3 but a block owns CONSECUTIVE tiles and stores 4 KiB (four tiles' results) at a time from all lanes
+template <int WR, bool BARRIER, int WORK>
+__global__ __launch_bounds__(256) void tile_pattern_kernel(const u32x4* __restrict__ src, size_t n_tiles, uint32_t* __restrict__ out) {
+  const size_t G = gridDim.x;
+  const size_t per = (n_tiles + G - 1) / G;
+  size_t tile = WR == 5 ? blockIdx.x * per : blockIdx.x;
+  const size_t end = WR == 5 ? (tile + per < n_tiles ? tile + per : n_tiles) : n_tiles;
+  const size_t step = WR == 5 ? 1 : G;
+  u32x4 pre[4];
+  auto fetch = [&](size_t t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[i] = __builtin_nontemporal_load(src + t * 1024 + threadIdx.x + i * 256);
+  };
+  if (tile < end) fetch(tile);
+  uint32_t keep = 0;
+  u32x4 four = {0u, 0u, 0u, 0u};
+  int nfour = 0;
+  for (; tile < end; tile += step) {
+    if (BARRIER) __syncthreads();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc ^= pre[i].x ^ pre[i].y ^ pre[i].z ^ pre[i].w;
+    if (tile + step < end) fetch(tile + step);
+#pragma unroll 16
+    for (int k = 0; k < WORK; ++k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(acc) : "v"(acc));
+    if (WR == 1) out[tile * 256 + threadIdx.x] = acc;
+    else if (WR == 2) __builtin_nontemporal_store(acc, out + tile * 256 + threadIdx.x);
+    else if (WR == 3 || WR == 4) {
+      if (threadIdx.x < 64) {
+        const u32x4 v = {acc, acc, acc, acc};
+        u32x4* dst = reinterpret_cast<u32x4*>(out + tile * 256) + threadIdx.x;
+        if (WR == 3) *dst = v;
+        else __builtin_nontemporal_store(v, dst);
+      }
+    } else if (WR == 5) {
+      four[nfour & 3] = acc;  // (register-indexed in the probe only; the real kernel would pass through LDS)
+      if ((++nfour & 3) == 0) reinterpret_cast<u32x4*>(out + (tile - 3) * 256)[threadIdx.x] = four;
+    } else keep ^= acc;
+  }
+  if (WR == 0 && keep == 0x12345678u) out[0] = keep;
+}
+
+template <int WR, bool BARRIER, int WORK>
+static void run_tile_pattern(const u32x4* d_src, size_t bytes, uint32_t* d_res, int blocks_per_cu, std::string& js) {
+  const int blocks = g_cus * blocks_per_cu;
+  const size_t n_tiles = bytes / 16384;
+  Timer t;
+  double best = 1e30;
+  for (int r = 0; r < 4; ++r) {
+    t.start();
+    hipLaunchKernelGGL((tile_pattern_kernel<WR, BARRIER, WORK>), dim3(blocks), dim3(256), 0, 0, d_src, n_tiles, d_res);
+    const double ms = t.stop_ms();
+    if (r) best = ms < best ? ms : best;
+  }
+  static const char* const names[] = {"none", "4 B per lane", "4 B per lane, nontemporal", "16 B per lane from one wave", "16 B per lane from one wave, nontemporal",
+                                      "consecutive tiles per block, 16 B per lane every 4 tiles"};
+  char buf[400];
+  snprintf(buf, sizeof buf, "    {\"result_store\": \"%s\", \"barrier\": %s, \"valu_per_lane_and_tile\": %d, \"blocks_per_cu\": %d, \"ms\": %.3f, \"TB_per_s_read\": %.3f},\n",
+           names[WR], BARRIER ? "true" : "false", WORK, blocks_per_cu, best, (double)bytes / (best * 1e-3) / 1e12);
+  js += buf;
+}
+
 static void strip_comma(std::string& js) {
   const size_t p = js.rfind(",\n");
   if (p != std::string::npos && p + 2 == js.size()) js.erase(p, 1);
@@ -807,6 +884,33 @@ int main(int argc, char** argv) {
     strip_comma(js);
     js += "  ],\n";
     CK(hipFree(d_src));
+  }
+  if (on("tilepat")) {
+    js += "  \"tile_pattern\": [\n";
+    const size_t bytes = 12800000000ull / 16384 * 16384;
+    u32x4* d_src;
+    uint32_t* d_res;
+    CK(hipMalloc((void**)&d_src, bytes));
+    CK(hipMalloc((void**)&d_res, bytes / 16));
+    CK(hipMemset(d_src, 0x5A, bytes));
+    CK(hipDeviceSynchronize());
+    for (int bpc : {6, 8}) {
+      run_tile_pattern<0, false, 0>(d_src, bytes, d_res, bpc, js);
+      run_tile_pattern<1, false, 0>(d_src, bytes, d_res, bpc, js);
+      run_tile_pattern<2, false, 0>(d_src, bytes, d_res, bpc, js);
+      run_tile_pattern<3, false, 0>(d_src, bytes, d_res, bpc, js);
+      run_tile_pattern<4, false, 0>(d_src, bytes, d_res, bpc, js);
+      run_tile_pattern<5, false, 0>(d_src, bytes, d_res, bpc, js);
+      run_tile_pattern<1, true, 0>(d_src, bytes, d_res, bpc, js);
+      run_tile_pattern<1, true, 256>(d_src, bytes, d_res, bpc, js);
+      run_tile_pattern<2, true, 256>(d_src, bytes, d_res, bpc, js);
+      run_tile_pattern<4, true, 256>(d_src, bytes, d_res, bpc, js);
+      run_tile_pattern<0, true, 256>(d_src, bytes, d_res, bpc, js);
+    }
+    strip_comma(js);
+    js += "  ],\n";
+    CK(hipFree(d_src));
+    CK(hipFree(d_res));
   }
   js += "  \"note\": \"cycles use the device's reported clock; the chip clocks to its power budget, so ratios between rows are firmer than absolutes\"\n}\n";
   fputs(js.c_str(), stdout);
