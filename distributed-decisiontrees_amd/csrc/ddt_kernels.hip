@@ -997,10 +997,13 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   const int SUM1 = (int)a.sum_mode;  // 0 reference order / IEEE adds, 1 fp64, 2 reference order / reference adder
   const bool exact = SUM1 == 2;
 
-  // _s2: `top` holds the level-0/1 records of the sub-group about to be walked; the next sub-group's (same chunk, or the first
-  // of the next chunk; past the end: chunk 0 again, never used) are requested before the walk
-  TopRecs<4> top, top_next;
-  if constexpr (S2) top_issue<TREE_BYTES>(top, img);
+  // _s2: two SGPR sets take turns (even / odd sub-group of a chunk; a chunk has an even number of sub-groups, so every chunk
+  // starts on top_a): one holds the level-0/1 records of the sub-group being walked, the other receives the next sub-group's
+  // (same chunk, or the first of the next chunk; past the end: chunk 0 again, never used), requested before the walk.  No set
+  // is ever copied: a copy would read registers whose loads may still be in flight.
+  static_assert(!S2 || (CT / U) % 2 == 0, "_s2: even number of sub-groups per chunk");
+  TopRecs<4> top_a, top_b;
+  if constexpr (S2) top_issue<TREE_BYTES>(top_a, img);
 #define DDT_QCOMPUTE(BUF, PH, KIDX)                                                                    \
   do {                                                                                                 \
     _Pragma("unroll") for (int sg = 0; sg < CT / U; ++sg) {                                            \
@@ -1009,11 +1012,12 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
       if constexpr (S2) {                                                                              \
         const uint32_t kn = (sg + 1 < CT / U) ? (uint32_t)(KIDX) : ((uint32_t)(KIDX) + 1u < n_chunks ? (uint32_t)(KIDX) + 1u : 0u); \
         const int sn = (sg + 1 < CT / U) ? sg + 1 : 0;                                                 \
-        top_wait(top);                                                                                 \
-        top_issue<TREE_BYTES>(top_next, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
-        if (!slow) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
-        else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
-        top = top_next;                                                                                \
+        TopRecs<4>& top_cur = (sg & 1) ? top_b : top_a;                                                \
+        TopRecs<4>& top_nxt = (sg & 1) ? top_a : top_b;                                                \
+        top_wait(top_cur);                                                                             \
+        top_issue<TREE_BYTES>(top_nxt, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
+        if (!slow) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+        else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
       } else {                                                                                         \
         if (!slow) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
         else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
@@ -1028,6 +1032,8 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   // a wave-uniform register index; 15 DS ops per tree instead of 17 either way, but the extra wait points cost more
   // than the LDS cycles they save.  Round 3's _s2 form above differs in where the loads are issued and waited for.)
   constexpr int PH1 = (CT == 4) ? 1 : 0;
+  // (round 3: the common case -- no missing value, sum_mode 0 -- dispatched once into straight-line code without the per-sub-group
+  // branches: equal within noise at depth 6 and 8, not kept)
   for (uint32_t k = 0; k < n_chunks; k += 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1041,7 +1047,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
     DDT_QCOMPUTE(1, PH1, k + 1);
   }
 #undef DDT_QCOMPUTE
-  if constexpr (S2) top_wait(top);  // the last request (never used) must not outlive the wave
+  if constexpr (S2) top_wait(top_a);  // the last request (never used; it went to top_a) must not outlive the wave
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (SUM1 != 1) ? ra.total(0, C, exact) : (float)dacc[0];
