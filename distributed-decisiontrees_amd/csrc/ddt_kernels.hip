@@ -962,7 +962,7 @@ __device__ __forceinline__ void walk_trees_q16_s2(const TopRecs<U>& q, const uin
 template <int D, int CT, int U, int OPT = 0>
 __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a, const Q16Aux x) {  // 8 waves per SIMD = two blocks per CU
   constexpr int THREADS = kQTile;
-  constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0;
+  constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0, HOTDISP = S2;
   static_assert(!S2 || U == 4, "_s2: 4 trees in flight");
   constexpr int TREE_BYTES = GL ? (4 << D) : (8 << D);  // bytes of a tree in LDS (GL: node records only)
   constexpr int CHUNK_BYTES = TREE_BYTES * CT;          // bytes of a chunk in LDS
@@ -1003,7 +1003,6 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   // is ever copied: a copy would read registers whose loads may still be in flight.
   static_assert(!S2 || (CT / U) % 2 == 0, "_s2: even number of sub-groups per chunk");
   TopRecs<4> top_a, top_b;
-  if constexpr (S2) top_issue<TREE_BYTES>(top_a, img);
 #define DDT_QCOMPUTE(BUF, PH, KIDX)                                                                    \
   do {                                                                                                 \
     _Pragma("unroll") for (int sg = 0; sg < CT / U; ++sg) {                                            \
@@ -1016,13 +1015,13 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
         TopRecs<4>& top_nxt = (sg & 1) ? top_a : top_b;                                                \
         top_wait(top_cur);                                                                             \
         top_issue<TREE_BYTES>(top_nxt, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
-        if (!slow) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+        if (!slow_l) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
         else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
       } else {                                                                                         \
-        if (!slow) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+        if (!slow_l) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
         else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
       }                                                                                                \
-      if (SUM1 != 1) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc, exact);                    \
+      if (sum_l != 1) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc, exact_l);                    \
       else fold_leaves<U, 1, 1>(lf, ((PH) + sg) & 1, C, ra, dacc);                                     \
     }                                                                                                  \
   } while (0)
@@ -1032,22 +1031,37 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   // a wave-uniform register index; 15 DS ops per tree instead of 17 either way, but the extra wait points cost more
   // than the LDS cycles they save.  Round 3's _s2 form above differs in where the loads are issued and waited for.)
   constexpr int PH1 = (CT == 4) ? 1 : 0;
-  // (round 3: the common case -- no missing value, sum_mode 0 -- dispatched once into straight-line code without the per-sub-group
-  // branches: equal within noise at depth 6 and 8, not kept)
-  for (uint32_t k = 0; k < n_chunks; k += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const bool more1 = k + 1 < n_chunks;
-    if (more1) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 1) * GSKIP, k + 1, CHUNK_BYTES, tid);
-    DDT_QCOMPUTE(0, 0, k);
-    if (!more1) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (k + 2 < n_chunks) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 2) * GSKIP, k + 2, 0, tid);
-    DDT_QCOMPUTE(1, PH1, k + 1);
+  // HOT (the _s2 kernels): the common case -- no missing value in the tile, sum_mode 0 -- is dispatched ONCE into a copy of the
+  // chunk loop without the per-sub-group branches on `slow` / the sum mode; a chunk is then one basic block and the leaf gathers
+  // and adds of one sub-group schedule into the next sub-group's walk: 21.90 vs 23.04 ms at 1000 trees x depth 8 x 20 M tuples
+  // (profiles/r03_sweep_q16_hot_dispatch_d8.json; depth 6: equal).  Each path issues its own first record set: a set requested
+  // in front of the dispatch would be copied into each path's registers while still in flight (tools/check_s2_isa.py).
+  auto chunks = [&](auto hot_tag) {
+    constexpr bool HOT = decltype(hot_tag)::value;
+    const bool slow_l = HOT ? false : slow, exact_l = HOT ? false : exact;
+    const int sum_l = HOT ? 0 : SUM1;
+    if constexpr (S2) top_issue<TREE_BYTES>(top_a, img);
+    for (uint32_t k = 0; k < n_chunks; k += 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const bool more1 = k + 1 < n_chunks;
+      if (more1) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 1) * GSKIP, k + 1, CHUNK_BYTES, tid);
+      DDT_QCOMPUTE(0, 0, k);
+      if (!more1) break;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (k + 2 < n_chunks) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 2) * GSKIP, k + 2, 0, tid);
+      DDT_QCOMPUTE(1, PH1, k + 1);
+    }
+    if constexpr (S2) top_wait(top_a);  // the last request (never used; it went to top_a) must not outlive the wave
+  };
+  if constexpr (HOTDISP) {
+    if (!slow && SUM1 == 0) chunks(std::true_type{});
+    else chunks(std::false_type{});
+  } else {
+    chunks(std::false_type{});
   }
 #undef DDT_QCOMPUTE
-  if constexpr (S2) top_wait(top_a);  // the last request (never used; it went to top_a) must not outlive the wave
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (SUM1 != 1) ? ra.total(0, C, exact) : (float)dacc[0];
