@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
         if (!slow_l) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
         else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
       }                                                                                                \
-      if (sum_l != 1) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc, exact_l);                    \
+      if (sum_l != 1) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc, exact_l);                 \
       else fold_leaves<U, 1, 1>(lf, ((PH) + sg) & 1, C, ra, dacc);                                     \
     }                                                                                                  \
   } while (0)
@@ -1038,6 +1038,8 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   // in front of the dispatch would be copied into each path's registers while still in flight (tools/check_s2_isa.py).
   auto chunks = [&](auto hot_tag) {
     constexpr bool HOT = decltype(hot_tag)::value;
+    // (deferred folds -- a sub-group's leaves folded one sub-group later, so that the gathers of a chunk's last sub-group fly
+    // across the chunk barrier, which then only waits for the DMA: 22.06 vs 21.84 ms, profiles/r03_sweep_q16_deferred_folds.json)
     const bool slow_l = HOT ? false : slow, exact_l = HOT ? false : exact;
     const int sum_l = HOT ? 0 : SUM1;
     if constexpr (S2) top_issue<TREE_BYTES>(top_a, img);

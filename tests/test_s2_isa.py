@@ -39,3 +39,15 @@ def test_checker_sees_a_copy_in_flight():
     assert sets == 1 and found and found[0][2] == [22, 23]
     partial = ["s_load_dwordx4 s[20:23], s[4:5], 0x0", "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v0, s21", "s_waitcnt vmcnt(0) lgkmcnt(0)"]
     assert chk.check_kernel("k", partial)[1], "a counted wait does not cover scalar loads (they return out of order)"
+
+
+def test_checker_follows_branches():
+    # 0x00 load; 0x08 branch over the wait to 0x14; 0x0c wait; 0x10 (fall-through use, fine); 0x14 use with the load in flight
+    listing = [(0x00, "s_load_dwordx4 s[20:23], s[4:5], 0x0"), (0x08, "s_cbranch_scc1 2"), (0x0C, "s_waitcnt lgkmcnt(0)"),
+               (0x10, "s_mov_b32 s1, s20"), (0x14, "s_mov_b32 s2, s21"), (0x18, "s_endpgm")]
+    sets, found = chk.check_kernel("k", listing)
+    assert sets == 1 and [f[0] for f in found] == [4]  # only the instruction the branch reaches without the wait
+    # a loop: the load at the bottom is still in flight at the top of the next iteration
+    loop = [(0x00, "s_mov_b32 s1, s20"), (0x04, "s_waitcnt lgkmcnt(0)"), (0x08, "s_load_dwordx4 s[20:23], s[4:5], 0x0"),
+            (0x10, "s_cbranch_scc1 65531"), (0x14, "s_endpgm")]
+    assert [f[0] for f in chk.check_kernel("k", loop)[1]] == [0]

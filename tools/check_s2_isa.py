@@ -48,7 +48,7 @@ def disassemble(lib):
 
 
 def kernels(dis):
-    """yield (symbol, [instruction text, ...]) per function of the disassembly"""
+    """yield (symbol, [(address, instruction text), ...]) per function of the disassembly"""
     name, body = None, []
     for line in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
@@ -58,43 +58,102 @@ def kernels(dis):
             name, body = m.group(1), []
             continue
         if name and "\t" in line:
-            ins = line.split("//")[0].strip()
+            ins, _, tail = line.partition("//")
+            ins = ins.strip()
+            m = re.match(r"\s*([0-9A-Fa-f]+):", tail)
             if ins:
-                body.append(ins)
+                body.append((int(m.group(1), 16) if m else None, ins))
     if name:
         yield name, body
 
 
 def check_kernel(name, body):
-    """returns (number of record sets issued, [violations])"""
-    sets, bad = 0, []
-    pending = {}  # sgpr -> index of the s_load that writes it
-    for i, ins in enumerate(body):
+    """returns (number of s_load_dwordx4 seen, [violations]).  A may-analysis over the control-flow graph: an SGPR is pending
+    from a scalar load that writes it until the next `s_waitcnt lgkmcnt(0)` on EVERY path; an instruction that reads or writes
+    a pending SGPR is a violation.  `body` = [(address, text)] (addresses may be None in hand-made straight-line listings)."""
+    body = [x if isinstance(x, tuple) else (None, x) for x in body]
+    n = len(body)
+    index_of = {a: i for i, (a, _) in enumerate(body) if a is not None}
+
+    def target(i):
+        a, ins = body[i]
+        if a is None or i + 1 >= n or body[i + 1][0] is None:
+            return None
+        simm = int(ins.split()[1])
+        if simm >= 0x8000:
+            simm -= 0x10000
+        return index_of.get(body[i + 1][0] + 4 * simm)
+
+    # basic blocks
+    leaders = {0}
+    for i, (_, ins) in enumerate(body):
         op = ins.split()[0]
-        if op == "s_waitcnt" and "lgkmcnt(0)" in ins:
-            pending.clear()
+        if op == "s_branch" or op.startswith("s_cbranch"):
+            t = target(i)
+            if t is not None:
+                leaders.add(t)
+            if i + 1 < n:
+                leaders.add(i + 1)
+        elif op == "s_endpgm" and i + 1 < n:
+            leaders.add(i + 1)
+    starts = sorted(leaders)
+    block_of = {}
+    for b, st in enumerate(starts):
+        for i in range(st, starts[b + 1] if b + 1 < len(starts) else n):
+            block_of[i] = b
+    succs = [[] for _ in starts]
+    for b, st in enumerate(starts):
+        end = (starts[b + 1] if b + 1 < len(starts) else n) - 1
+        op = body[end][1].split()[0]
+        if op == "s_endpgm":
             continue
-        touched = sregs(ins)
-        if op == "s_load_dwordx4":
-            dst = sregs(ins.split(",")[0])
-            src = touched - dst
-            hit = (dst | src) & set(pending)
-            if hit:
-                bad.append((i, ins, sorted(hit)))
-            # the asm's loads come in fours off one base pointer; the compiler's own s_loads are waited for by its own waits
-            for r in dst:
-                pending[r] = i
-            sets += 1
-            continue
-        if op.startswith("s_load") or op.startswith("s_buffer_load"):
-            # compiler-issued scalar loads (kernel arguments): tracked the same way, hipcc waits before it uses them
-            for r in sregs(ins.split(",")[0]):
-                pending[r] = i
-            continue
-        hit = touched & set(pending)
-        if hit:
-            bad.append((i, ins, sorted(hit)))
-    return sets, bad
+        if op == "s_branch" or op.startswith("s_cbranch"):
+            t = target(end)
+            if t is not None:
+                succs[b].append(block_of[t])
+            if op == "s_branch":
+                continue
+        if end + 1 < n:
+            succs[b].append(block_of[end + 1])
+
+    sets = sum(1 for _, ins in body if ins.split()[0] == "s_load_dwordx4")
+    pend_in = [set() for _ in starts]
+    bad = {}
+
+    def run_block(b, record):
+        pending = set(pend_in[b])
+        st = starts[b]
+        end = starts[b + 1] if b + 1 < len(starts) else n
+        for i in range(st, end):
+            ins = body[i][1]
+            op = ins.split()[0]
+            if op == "s_waitcnt" and "lgkmcnt(0)" in ins:
+                pending.clear()
+                continue
+            touched = sregs(ins)
+            if op.startswith("s_load") or op.startswith("s_buffer_load"):
+                dst = sregs(ins.split(",")[0])
+                hit = touched & pending
+                if hit and record:
+                    bad[i] = (i, ins, sorted(hit))
+                pending |= dst
+                continue
+            hit = touched & pending
+            if hit and record:
+                bad[i] = (i, ins, sorted(hit))
+        return pending
+
+    work = list(range(len(starts)))
+    while work:
+        b = work.pop()
+        out = run_block(b, False)
+        for s2 in succs[b]:
+            if not out <= pend_in[s2]:
+                pend_in[s2] |= out
+                work.append(s2)
+    for b in range(len(starts)):
+        run_block(b, True)
+    return sets, [bad[i] for i in sorted(bad)]
 
 
 def main():
