@@ -860,10 +860,23 @@ __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint3
   }
 }
 
+// "_gl": the leaves stay in the global image and are gathered through a buffer resource over it: leaf m4 / 4 - 2^D of tree u of
+// the sub-group whose leaves start `soff + 4 * 2^D` bytes into the image.  m4 is already a byte offset, so the gather is
+// buffer_load_dword v, v_m4, s[rsrc], s_soff offen offset:u*4*2^D -- no address arithmetic on the VALU at all (the pointer form
+// cost 24 of a PU group's 303 VALU instructions: a 64-bit add per gather plus the chunk offset)
+struct LeafSrc {
+  __amdgpu_buffer_rsrc_t rsrc;  // the whole image
+  uint32_t soff;                // wave-uniform: byte offset of the sub-group's leaves, minus 4 * 2^D
+};
+template <int D>
+__device__ __forceinline__ float gather_leaf(const LeafSrc& g, int u, uint32_t m4) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g.rsrc, m4 + (uint32_t)(u * (4 << D)), g.soff, 0));
+}
+
 // walk over 4-byte records {R (lo16), feature row byte offset (hi16, bit 16 = miss_right in the slow image)};
 // m4 = 4 * (1-based heap index); leaves start at byte 4*2^D of the tree, so leaf address = tree + m4.
 template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW, bool GL = false>
-__device__ __forceinline__ void walk_trees_q16(const uint32_t base, const uint32_t lane2, float (&leaf)[U], const float* __restrict__ gleaf = nullptr) {
+__device__ __forceinline__ void walk_trees_q16(const uint32_t base, const uint32_t lane2, float (&leaf)[U], const LeafSrc& gleaf) {
   uint32_t m4[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) m4[u] = 4u;
@@ -887,7 +900,7 @@ __device__ __forceinline__ void walk_trees_q16(const uint32_t base, const uint32
   }
   if (GL) {  // leaves of this sub-group in global memory, 2^D floats per tree: one 4-byte gather per tree on the vector-memory path
 #pragma unroll
-    for (int u = 0; u < U; ++u) leaf[u] = gleaf[(m4[u] >> 2) - (1u << D) + (uint32_t)(u << D)];
+    for (int u = 0; u < U; ++u) leaf[u] = gather_leaf<D>(gleaf, u, m4[u]);
   } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) leaf[u] = lds_f32(m4[u] + (base + (uint32_t)(u * TREE_BYTES)));
@@ -917,7 +930,7 @@ __device__ __forceinline__ void top_wait(TopRecs<4>& q) {
 
 template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW, bool GL>
 __device__ __forceinline__ void walk_trees_q16_s2(const TopRecs<U>& q, const uint32_t base, const uint32_t lane2, float (&leaf)[U],
-                                                  const float* __restrict__ gleaf) {
+                                                  const LeafSrc& gleaf) {
   static_assert(D >= 3, "two scalar levels + at least one LDS level");
   uint32_t m4[U], nd[U], f[U];
   auto rank_at = [&](uint32_t rec) -> uint32_t {
@@ -952,7 +965,7 @@ __device__ __forceinline__ void walk_trees_q16_s2(const TopRecs<U>& q, const uin
   }
   if (GL) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) leaf[u] = gleaf[(m4[u] >> 2) - (1u << D) + (uint32_t)(u << D)];
+    for (int u = 0; u < U; ++u) leaf[u] = gather_leaf<D>(gleaf, u, m4[u]);
   } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) leaf[u] = lds_f32(m4[u] + (base + (uint32_t)(u * TREE_BYTES)));
@@ -975,7 +988,9 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   const uint64_t tile = blockIdx.x, tile0 = tile * kQTile;
   const uint32_t W = a.tuple_words, n_chunks = a.n_chunks;
   constexpr int GSKIP = GCHUNK_UNITS - CHUNK_BYTES / 16;  // dma_chunk strides by the LDS chunk: skip the leaves of the chunks before
-  const bool slow = x.tile_flags[tile] != 0u;  // block-uniform: the tile holds a missing value
+  // block-uniform: the tile holds a missing value.  readfirstlane: the flag arrives through a vector load, and without it hipcc
+  // treats `img` (and every leaf-gather address derived from it) as lane-varying: 64-bit VALU address arithmetic per gather
+  const bool slow = __builtin_amdgcn_readfirstlane((int)x.tile_flags[tile]) != 0;
   const uint4* img = slow ? x.img_slow : a.img;
 
   dma_chunk<THREADS, CHUNK_BYTES>(img, 0, 0, tid);
@@ -1003,11 +1018,14 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   // is ever copied: a copy would read registers whose loads may still be in flight.
   static_assert(!S2 || (CT / U) % 2 == 0, "_s2: even number of sub-groups per chunk");
   TopRecs<4> top_a, top_b;
+  // _gl: buffer resource over the image in use (built from wave-uniform values only); non-_gl kernels never load through it
+  const __amdgpu_buffer_rsrc_t leaf_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(img), 0, (int)(n_chunks * (uint32_t)(GCHUNK_UNITS * 16)), 0x00020000);
 #define DDT_QCOMPUTE(BUF, PH, KIDX)                                                                    \
   do {                                                                                                 \
     _Pragma("unroll") for (int sg = 0; sg < CT / U; ++sg) {                                            \
       float lf[1][U];                                                                                  \
-      const float* gl = GL ? reinterpret_cast<const float*>(img + (size_t)(KIDX) * GCHUNK_UNITS) + (CT + sg * U) * (1 << D) : nullptr; \
+      const LeafSrc gl = {leaf_rsrc, (uint32_t)(KIDX) * (uint32_t)(GCHUNK_UNITS * 16) + (uint32_t)((CT + sg * U - 1) * (4 << D))}; \
       if constexpr (S2) {                                                                              \
         const uint32_t kn = (sg + 1 < CT / U) ? (uint32_t)(KIDX) : ((uint32_t)(KIDX) + 1u < n_chunks ? (uint32_t)(KIDX) + 1u : 0u); \
         const int sn = (sg + 1 < CT / U) ? sg + 1 : 0;                                                 \
