@@ -200,11 +200,7 @@ RankTables rank_tables(const ddt_engine* e) {
     for (uint32_t i = 0; i < m.trees(); ++i)
       for (uint32_t n = 0; n < nint; ++n)
         rt.keys[m.fidx[(size_t)i * nint + n]].push_back(thr_key(e->p, m.thr[(size_t)i * nint + n]));
-  for (auto& k : rt.keys) {
-    std::sort(k.begin(), k.end(), [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; });
-    k.erase(std::unique(k.begin(), k.end()), k.end());
-    if (k.size() > rt.max_len) rt.max_len = (uint32_t)k.size();
-  }
+  finish_rank_tables(rt);
   return rt;
 }
 
@@ -440,7 +436,6 @@ uint32_t total_trees(const ddt_engine* e) {
 constexpr uint32_t kQ16MinTreeLevels = 480;  // trees x levels from which the rank-quantised path wins with the LDS-resident pre-pass
                                              // (profiles/r02_sweep_q16_small.json: 60 x d8 +4 %, 80 x d8 +5 %, 112 x d8 +7 %, 200 x d6 +9 %; round 3 with the _s2 walk,
                                              // profiles/r03_sweep_fused_rank_experiment_ilp8_s2.json: 100 x d6 +17 %, 100 x d8 +11 %, while 30 x d6 still loses 15 %)
-constexpr uint32_t kQ16MaxTable = 32767;  // ranks must stay below 0xFFFF and a table (x4 B) must fit LDS in the rank kernel
 
 bool variant_fits(const Variant& v, const ddt_engine* e) {
   if (v.kind == kKindSparse) return false;  // sparse forests pick their kernel in ddt_sparse_host.cpp
@@ -584,31 +579,29 @@ int build_image(ddt_engine* e, const Variant& v, Ensemble& m) {
   return DDT_OK;
 }
 
-// q16 images: per tree 2^D records {R (lo16) | row offset (hi16)} in a 1-based heap, then 2^D fp32 leaves.
-// R = 1 + index of the node's threshold in its feature's table; the slow image carries miss_right in bit 16.
-struct Q16HostImage {
-  std::vector<uint32_t> fast, slow, tab, tabK, pimg;
-  std::vector<uint16_t> tabS;
-  PrepassPlan pplan{};
-  uint32_t Tpad = 0, Kpad = 0;
-};
+void finish_rank_tables(RankTables& rt) {
+  rt.max_len = 0;
+  for (auto& k : rt.keys) {
+    std::sort(k.begin(), k.end(), [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; });
+    k.erase(std::unique(k.begin(), k.end()), k.end());
+    if (k.size() > rt.max_len) rt.max_len = (uint32_t)k.size();
+  }
+}
 
-// host half of build_image_q16 (no HIP call; also behind the test hook ddt_debug_model_image)
-int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const RankTables& rt, bool upload_tables, Q16HostImage& h) {
-  const uint32_t D = e->p.num_levels, T = m.trees(), nint = e->nint, nleaf = e->nleaf, W = tuple_words(e->p);
-  const uint32_t tree_words = (8u << D) / 4u, Tpad = padded_trees(v, T);
+// flat tables of rank_kernel ([W][Kpad] keys, per-feature search parameters, bucket starts) and -- want_prepass -- the LDS
+// images of the LDS-resident pre-pass, from the sorted distinct threshold keys per feature
+int pack_rank_tables(ddt_engine* e, const RankTables& rt, uint32_t W, bool want_prepass, RankHostTables& h) {
   uint32_t Kpad = 2;
   while (Kpad <= rt.max_len) Kpad <<= 1;  // power of two > max_len: the search reads indices < Kpad - 1
-  std::vector<uint32_t>&fast = h.fast, &slow = h.slow, &tab = h.tab, &tabK = h.tabK, &pimg = h.pimg;
+  std::vector<uint32_t>&tab = h.tab, &tabK = h.tabK, &pimg = h.pimg;
   std::vector<uint16_t>& tabS = h.tabS;
   PrepassPlan& pplan = h.pplan;
   try {
-    fast.assign((size_t)Tpad * tree_words, 0u);
     tab.assign((size_t)W * Kpad, 0x7FFFFFFFu);
     tabK.assign((size_t)W * 8u, 0u);
     tabS.assign((size_t)W * kQ16RankBuckets, 0u);
   } catch (const std::bad_alloc&) {
-    return fail(e, DDT_ENOMEM, "q16 image allocation failed");
+    return fail(e, DDT_ENOMEM, "rank table allocation failed");
   }
   for (uint32_t j = 0; j < W; ++j) {
     const std::vector<uint32_t>& k = rt.keys[j];
@@ -642,12 +635,72 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
     }
   }
   pplan = PrepassPlan{};
-  if (upload_tables)
+  if (want_prepass)
     (void)build_prepass_image(rt, W, (uint32_t)e->q16_prepass_groups, e->q16_fused_prepass != 0, e->q16_grouped_prepass != 0, &pimg, &pplan);
-  if (upload_tables && getenv("DDT_DEBUG_PREPASS")) {
+  if (want_prepass && getenv("DDT_DEBUG_PREPASS")) {
     fprintf(stderr, "[ddt] rank pre-pass: %u feature group(s) of %u line(s), longest table %u keys;", pplan.groups, pplan.lines, rt.max_len);
     for (uint32_t g = 0; g < pplan.groups; ++g) fprintf(stderr, " [P=%u, %u B]", pplan.P[g], pplan.bytes[g]);
     fprintf(stderr, "\n");
+  }
+  h.Kpad = Kpad;
+  return DDT_OK;
+}
+
+void free_rank_device(RankDevice& d) {
+  for (void** p : {&d.d_tables, &d.d_tabK, &d.d_tabS, &d.d_prepass}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  d.prepass = PrepassPlan{};
+  d.Kpad = 0;
+}
+
+int upload_rank_tables(ddt_engine* e, const RankHostTables& h, RankDevice& d) {
+  free_rank_device(d);
+  HIP_TRY(e, hipMalloc(&d.d_tables, h.tab.size() * 4));
+  HIP_TRY(e, hipMalloc(&d.d_tabK, h.tabK.size() * 4));
+  HIP_TRY(e, hipMalloc(&d.d_tabS, h.tabS.size() * 2));
+  HIP_TRY(e, hipMemcpy(d.d_tables, h.tab.data(), h.tab.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(d.d_tabK, h.tabK.data(), h.tabK.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(d.d_tabS, h.tabS.data(), h.tabS.size() * 2, hipMemcpyHostToDevice));
+  if (h.pplan.groups && !h.pimg.empty()) {
+    HIP_TRY(e, hipMalloc(&d.d_prepass, h.pimg.size() * 4));
+    HIP_TRY(e, hipMemcpy(d.d_prepass, h.pimg.data(), h.pimg.size() * 4, hipMemcpyHostToDevice));
+    d.prepass = h.pplan;
+  }
+  d.Kpad = h.Kpad;
+  return DDT_OK;
+}
+
+// q16 images: per tree 2^D records {R (lo16) | row offset (hi16)} in a 1-based heap, then 2^D fp32 leaves.
+// R = 1 + index of the node's threshold in its feature's table; the slow image carries miss_right in bit 16.
+struct Q16HostImage {
+  std::vector<uint32_t> fast, slow, tab, tabK, pimg;
+  std::vector<uint16_t> tabS;
+  PrepassPlan pplan{};
+  uint32_t Tpad = 0, Kpad = 0;
+};
+
+// host half of build_image_q16 (no HIP call; also behind the test hook ddt_debug_model_image)
+int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const RankTables& rt, bool upload_tables, Q16HostImage& h) {
+  const uint32_t D = e->p.num_levels, T = m.trees(), nint = e->nint, nleaf = e->nleaf, W = tuple_words(e->p);
+  const uint32_t tree_words = (8u << D) / 4u, Tpad = padded_trees(v, T);
+  std::vector<uint32_t>&fast = h.fast, &slow = h.slow;
+  try {
+    fast.assign((size_t)Tpad * tree_words, 0u);
+  } catch (const std::bad_alloc&) {
+    return fail(e, DDT_ENOMEM, "q16 image allocation failed");
+  }
+  {
+    RankHostTables rk;
+    const int rc = pack_rank_tables(e, rt, W, upload_tables, rk);
+    if (rc) return rc;
+    h.tab.swap(rk.tab);
+    h.tabK.swap(rk.tabK);
+    h.tabS.swap(rk.tabS);
+    h.pimg.swap(rk.pimg);
+    h.pplan = rk.pplan;
+    h.Kpad = rk.Kpad;
   }
   const uint32_t row = v.tile() * 2u;  // bytes per feature row of the u16 tile
   // word offsets of tree i's records and leaves: tree by tree (records, then leaves), or -- "_gl" variants -- per chunk the
@@ -672,7 +725,6 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
     for (uint32_t n = 0; n < nint; ++n)
       if (m.mright[(size_t)i * nint + n]) slow[rec_off(i) + n + 1] |= 1u << 16;
   h.Tpad = Tpad;
-  h.Kpad = Kpad;
   return DDT_OK;
 }
 
@@ -721,7 +773,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint64_t rows = (n + 1023) / 1024 * 1024;
   const int k = e->q_slot;
   // the transposed fp32 intermediate is only needed by the two-kernel pre-pass
-  const bool need_xT = e->ens.empty() || e->ens[0].prepass.groups == 0;
+  const bool need_xT = e->sparse ? e->sp_rank.prepass.groups == 0 : (e->ens.empty() || e->ens[0].prepass.groups == 0);
   if (rows <= e->q_rows[k] && (!need_xT || e->q_xT[k])) return DDT_OK;
   HIP_TRY(e, hipDeviceSynchronize());
   for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k]}) {
@@ -894,7 +946,7 @@ int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_
     for (hipEvent_t& ev : e->tev)
       if (!ev) HIP_TRY(e, hipEventCreate(&ev));
     HIP_TRY(e, hipEventRecord(e->tev[0], s));
-    HIP_TRY(e, hipEventRecord(e->tev[1], s));  // no pre-pass on this path
+    if (!(variant(e->variant_id).opt & 1)) HIP_TRY(e, hipEventRecord(e->tev[1], s));  // fp32 tiles: no pre-pass (else: sparse_launch)
   }
   int rc = sparse_launch(e, 0, d_tuples, n, d_scores, s);
   if (rc) return rc;
@@ -913,14 +965,16 @@ int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float*
       HIP_TRY(e, hipStreamCreateWithFlags(&e->class_stream, hipStreamNonBlocking));
       for (hipEvent_t& ev : e->class_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     }
-    if (two) {  // the other stream starts behind whatever the caller's stream has queued (the tuples may come from there)
-      HIP_TRY(e, hipEventRecord(e->class_ev[0], s));
-      HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));
-    }
     for (uint32_t k = 0; k < e->num_classes; ++k) {
-      int rc = sparse_launch(e, k, d_tuples, n, d_class_scores + (size_t)k * n, (two && (k & 1u)) ? e->class_stream : s);
+      // rank-quantised kernels: the ranks of this batch are computed by the first class's launch and reused
+      int rc = sparse_launch(e, k, d_tuples, n, d_class_scores + (size_t)k * n, (two && (k & 1u)) ? e->class_stream : s, k > 0);
       if (rc) return rc;
       e->st.kernel_launches++;
+      if (two && k == 0) {  // the other stream starts behind whatever the caller's stream has queued up to here: the tuples may
+                            // come from there, and the rank pre-pass of the batch is part of class 0's launch
+        HIP_TRY(e, hipEventRecord(e->class_ev[0], s));
+        HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));
+      }
     }
     if (two) {
       HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));
@@ -1374,13 +1428,13 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     }
     return DDT_OK;
   }
-  if (!strcmp(key, "sparse_top_levels") || !strcmp(key, "sparse_deep_order")) {
+  if (!strcmp(key, "sparse_top_levels") || !strcmp(key, "sparse_deep_order") || !strcmp(key, "sparse_q16")) {
     // sparse forests: K = levels staged in LDS (-1 = as many as fit), order of the deep records (0 level order,
-    // 1 depth-first per sub-tree); a loaded sparse model is re-packed
-    const bool top = key[7] == 't';
+    // 1 depth-first per sub-tree), rank-quantised kernels (1 = when they fit, 0 = never); a loaded sparse model is re-packed
+    const bool top = key[7] == 't', rq = key[7] == 'q';
     if (top && value >= 0 && (value < kSparseMinTop || value > kSparseMaxTop)) return fail(e, DDT_EINVAL, "sparse_top_levels must be -1 or %d..%d", kSparseMinTop, kSparseMaxTop);
-    if (!top && (value < 0 || value > 1)) return fail(e, DDT_EINVAL, "sparse_deep_order must be 0 or 1");
-    int& opt = top ? e->sparse_top_levels : e->sparse_deep_order;
+    if (!top && (value < 0 || value > 1)) return fail(e, DDT_EINVAL, "%s must be 0 or 1", key);
+    int& opt = top ? e->sparse_top_levels : rq ? e->sparse_q16 : e->sparse_deep_order;
     const int previous = opt;
     opt = (int)value;
     if (e->loaded && e->sparse) {
@@ -1420,7 +1474,9 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     // rows, so that the asynchronous ddt_*_device calls never have to synchronise and allocate on first use / growth
     if (value < 0) return fail(e, DDT_EINVAL, "reserve_rows must be >= 0");
     if (!e->loaded) return fail(e, DDT_ESTATE, "reserve_rows: load a model first (the workspace depends on its tuple width)");
-    if (e->sparse || variant(e->variant_id).kind != kKindQ16 || value == 0) return DDT_OK;  // nothing to reserve on the other paths
+    const Variant& cur = variant(e->variant_id);
+    const bool ranked = e->sparse ? (cur.opt & 1) != 0 : cur.kind == kKindQ16;
+    if (!ranked || value == 0) return DDT_OK;  // nothing to reserve on the other paths
     DeviceGuard dg(e->device);
     if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
     return ensure_q16_workspace(e, (size_t)value);

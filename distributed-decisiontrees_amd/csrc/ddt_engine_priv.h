@@ -51,6 +51,23 @@ struct RankTables {
   uint32_t max_len = 0;
 };
 
+// host form of the rank tables of the q16 pre-pass (rank_kernel's flat tables + the LDS images of the LDS-resident pre-pass)
+struct RankHostTables {
+  std::vector<uint32_t> tab, tabK, pimg;
+  std::vector<uint16_t> tabS;
+  PrepassPlan pplan{};
+  uint32_t Kpad = 0;
+};
+// ... and their device copies when no Ensemble owns them (rank-quantised sparse forests)
+struct RankDevice {
+  void* d_tables = nullptr;
+  void* d_tabK = nullptr;
+  void* d_tabS = nullptr;
+  void* d_prepass = nullptr;
+  PrepassPlan prepass;
+  uint32_t Kpad = 0;
+};
+
 // A sparse (explicit-children) forest as loaded: this engine's shard, node lines re-based per tree (include/ddt.h
 // ddt_load_model_sparse); device images: ddt_internal.h "Sparse forests".
 struct SparseForest {
@@ -122,6 +139,8 @@ struct ddt_engine {
   std::vector<ddt::SparseForest> sps;  // one per class (single-output models: exactly one)
   int sparse_top_levels = -1;   // option "sparse_top_levels": K, -1 = the most the LDS takes
   int sparse_deep_order = 0;    // option "sparse_deep_order": 0 = level order (default: measured faster), 1 = depth-first per sub-tree
+  int sparse_q16 = 1;           // option "sparse_q16": 1 = rank-quantised sparse kernels when they fit (default), 0 = fp32 feature tiles
+  ddt::RankDevice sp_rank;      // rank tables of the loaded sparse forests (rank-quantised kernels only)
   int leaf_domain_check = 1;    // option "leaf_domain_check": reject leaves outside the exact domain of the reference adder
   ddt_stats st{};
   char err[256] = {0};
@@ -171,9 +190,16 @@ bool leaf_outside_exact_domain(uint32_t bits);
 // one scoring pass of the loaded model (perfect or sparse) over device-resident tuples, asynchronous on `s`
 int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s);
 int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s);
+int ensure_q16_workspace(ddt_engine* e, size_t n);
+// rank tables: host packing (no HIP call) and upload; tables longer than kQ16MaxTable keys do not fit the u16 ranks
+constexpr uint32_t kQ16MaxTable = 32767;  // ranks must stay below 0xFFFF and a table (x4 B) must fit LDS in the rank kernel
+void finish_rank_tables(RankTables& rt);  // sort + unique every feature's keys, set max_len
+int pack_rank_tables(ddt_engine* e, const RankTables& rt, uint32_t W, bool want_prepass, RankHostTables& h);
+int upload_rank_tables(ddt_engine* e, const RankHostTables& h, RankDevice& d);
+void free_rank_device(RankDevice& d);
 // ddt_sparse_host.cpp
 void sparse_free(ddt_engine* e);
-int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, float* d_scores, hipStream_t s);
+int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, float* d_scores, hipStream_t s, bool reuse_prepass = false);
 int sparse_rebuild(ddt_engine* e);
 
 }  // namespace ddt

@@ -46,6 +46,7 @@ struct ScoreArgs {
   uint32_t stream_blocks_per_cu;  // stream kernel: 0 = as many blocks per CU as are resident, else forced (option, A/B)
 };
 
+constexpr uint32_t kQMissing = 0xFFFFu;  // rank of a missing feature value in the u16 tiles
 constexpr uint32_t kQ16RankBuckets = 4096;
 // LDS-resident rank pre-pass (no transposed fp32 intermediate): the features are cut into `groups` groups of `lines`
 // tuple lines (4 features each); a block keeps the tables of ONE group resident in LDS (image = bytes[g] at byte offset
@@ -93,6 +94,9 @@ constexpr int kSparseMinTop = 6, kSparseMaxTop = 10;
 struct SparseAux {           // ScoreArgs::aux of the sparse kernels
   const uint4* deep;         // deep records (at least one, record 0 is a valid dummy)
   uint32_t n_groups;         // PU groups of 8 trees in the top image
+  // rank-quantised sparse kernels ("sparse_q_*", Variant::opt bit 0): thresholds are ranks, the features arrive as the u16 tiles
+  // of the q16 pre-pass (the same tables / workspace / kernels as the perfect-tree q16 path); slow images = the same images
+  Q16Aux q16;
 };
 
 enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2, kKindQ16 = 3, kKindSparse = 4 };
@@ -146,12 +150,15 @@ struct Variant {
   // opt bit 1 ("_s2"): the records of levels 0-1 come from SGPRs (scalar loads), see ddt_kernels.hip
   uint32_t lds_bytes_q16(uint32_t tuple_words) const { return feat_off_q16() + tuple_words * tile() * 2u; }
   // ---- sparse kernels (levels = K, the top levels staged in LDS): LDS = [top image of one PU group][feature tile] ----
+  // opt bit 0 ("sparse_q_*"): rank-quantised -- u16 feature tile (half the LDS per tuple: 1024 tuples = 16 waves share a CU
+  // where the fp32 tile holds 512), node thresholds are ranks
   uint32_t top_bytes_sparse() const { return 12u << levels; }
+  uint32_t row_bytes_sparse() const { return (opt & 1) ? tile() * 2u : tile() * 4u; }
   uint32_t feat_off_sparse() const {  // chunk_trees = trees walked in lock-step = top images resident per pass
-    const uint32_t row = row_bytes(), need = (uint32_t)chunk_trees * top_bytes_sparse();
+    const uint32_t row = row_bytes_sparse(), need = (uint32_t)chunk_trees * top_bytes_sparse();
     return (need + row - 1u) / row * row;
   }
-  uint32_t lds_bytes_sparse(uint32_t tuple_words) const { return feat_off_sparse() + tuple_words * row_bytes() + 64u; }
+  uint32_t lds_bytes_sparse(uint32_t tuple_words) const { return feat_off_sparse() + tuple_words * row_bytes_sparse() + 64u; }
 };
 
 int num_variants();
@@ -162,6 +169,8 @@ constexpr int kGenericThreads = 256;
 hipError_t launch_generic(const ScoreArgs& a, const Variant& v, hipStream_t s);
 uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds, uint32_t* top_levels);
 uint32_t stream_blocks_per_cu(uint32_t lds_bytes);
+
+hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s);  // ddt_kernels.hip: rank pre-pass of one batch
 
 int num_sparse_variants();                 // ddt_sparse.hip: appended to the variant table after the perfect-tree kernels
 const Variant& sparse_variant(int i);

@@ -494,7 +494,6 @@ static hipError_t launch_stream(const ScoreArgs& a, const Variant& v, hipStream_
 //   score_q16_kernel  the walk over u16 ranks; the tile arrives by global->LDS DMA, no transpose needed
 // ---------------------------------------------------------------------------------------------------
 constexpr int kQTile = 1024;        // tuples per q tile == threads per scoring block
-constexpr uint32_t kQMissing = 0xFFFFu;
 constexpr uint32_t kRankBuckets = kQ16RankBuckets;  // slices of a feature's key range (first level of the rank search)
 
 __global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restrict__ tuples, uint32_t W, uint64_t n,
@@ -504,21 +503,24 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restri
   const uint64_t row0 = (uint64_t)blockIdx.x * 256u;
   const uint32_t rows = row0 >= n ? 0u : (uint32_t)((n - row0) < 256u ? (n - row0) : 256u);  // blocks past n only write the zero padding
   const uint4* src = reinterpret_cast<const uint4*>(tuples + row0 * W);
-  const uint32_t LPT = W / 4u;  // 16-byte lines per tuple (<= 8 on this path)
-  uint4 v[8];
+  const uint32_t LPT = W / 4u;  // 16-byte lines per tuple; eight at a time (the perfect-tree q16 path has <= 8, sparse forests up to 19)
+  for (uint32_t i0 = 0; i0 < LPT; i0 += 8u) {
+    uint4 v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {  // all loads first (coalesced, independent), then the LDS scatter
-    const uint32_t e = tid + (uint32_t)i * 256u;
-    v[i] = ((uint32_t)i < LPT && e / LPT < rows) ? src[e] : make_uint4(0u, 0u, 0u, 0u);
-  }
+    for (int i = 0; i < 8; ++i) {  // all loads first (coalesced, independent), then the LDS scatter
+      const uint32_t k = i0 + (uint32_t)i, e = tid + k * 256u;
+      v[i] = (k < LPT && e / LPT < rows) ? src[e] : make_uint4(0u, 0u, 0u, 0u);
+    }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if ((uint32_t)i < LPT) {
-      const uint32_t e = tid + (uint32_t)i * 256u, r = e / LPT, c = (e - r * LPT) * 4u;
-      lds_st_u32((r * S + c + 0u) * 4u, v[i].x);
-      lds_st_u32((r * S + c + 1u) * 4u, v[i].y);
-      lds_st_u32((r * S + c + 2u) * 4u, v[i].z);
-      lds_st_u32((r * S + c + 3u) * 4u, v[i].w);
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t k = i0 + (uint32_t)i;
+      if (k < LPT) {
+        const uint32_t e = tid + k * 256u, r = e / LPT, c = (e - r * LPT) * 4u;
+        lds_st_u32((r * S + c + 0u) * 4u, v[i].x);
+        lds_st_u32((r * S + c + 1u) * 4u, v[i].y);
+        lds_st_u32((r * S + c + 2u) * 4u, v[i].z);
+        lds_st_u32((r * S + c + 3u) * 4u, v[i].w);
+      }
     }
   }
   __syncthreads();
@@ -1087,62 +1089,74 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   if (row < a.n) a.out[row] = (SUM1 != 1) ? ra.total(0, C, exact) : (float)dacc[0];
 }
 
+// the rank pre-pass of one batch: q tiles + per-tile missing flags into the workspace of `x` (shared by the perfect-tree q16
+// kernels and the rank-quantised sparse kernels, ddt_sparse.hip)
+hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s) {
+  const uint64_t tiles = (a.n + kQTile - 1) / kQTile;
+  if (tiles == 0) return hipSuccess;
+  const uint32_t W = a.tuple_words;
+  const uint32_t rank_lds = (x.Kpad + (x.Kpad >> 5) + 1u) * 4u + kRankBuckets * 2u;  // skewed table + bucket starts, see rank_kernel
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds);
+  if (e != hipSuccess) return e;
+  // tile flags + (8-byte aligned, right behind them) the work counters of the fused / grouped pre-pass
+  unsigned long long* counter = reinterpret_cast<unsigned long long*>(x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u));
+  e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters) * 4, s);
+  if (e != hipSuccess) return e;
+  const PrepassPlan& pp = x.prepass;
+  if (pp.groups && pp.lines >= 4u) {
+    // 1 group (all tables fit one CU's LDS together) or 2 groups of 4 lines: quad-coalesced loads, every 64-byte sector a block
+    // pulls is used whole (fused_rank_kernel); at most one block per CU
+    uint32_t lds = 0;
+    for (uint32_t g = 0; g < pp.groups; ++g) lds = pp.bytes[g] > lds ? pp.bytes[g] : lds;
+    const uint32_t parts = (pp.groups > 1u && a.num_cus >= 8u * pp.groups && tiles >= 8u) ? 8u : 1u;
+    uint32_t per_pair = a.num_cus / (parts * pp.groups);
+    if (per_pair < 1u) per_pair = 1u;
+    const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
+    if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fused_rank_kernel, dim3(parts * pp.groups * per_pair), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp,
+                       parts, a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
+  } else if (pp.groups) {  // one launch, blocks split over feature groups x row partitions (XCDs)
+    uint32_t lds = 0;
+    for (uint32_t g = 0; g < pp.groups; ++g) lds = pp.bytes[g] > lds ? pp.bytes[g] : lds;
+    // one block per CU (the image takes most of the LDS); 8 row partitions when every (group, partition) gets a block
+    const uint32_t parts = (a.num_cus >= 8u * pp.groups && tiles >= 8u) ? 8u : 1u;
+    uint32_t per_pair = a.num_cus / (parts * pp.groups);
+    if (per_pair < 1u) per_pair = 1u;
+    const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
+    if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
+    const uint32_t grid = parts * pp.groups * per_pair;
+    auto gk = pp.lines == 1u ? grouped_rank_kernel<1> : grouped_rank_kernel<2>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gk, dim3(grid), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp, parts, a.miss_raw, a.ieee,
+                       reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(transpose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((W + 1) * 256 * 4));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
+    uint32_t bx = (uint32_t)((x.n_pad / kQTile + 3) / 4);  // 4 tiles (kRankThreads x 4 rows) per block and pass
+    if (bx > 512u) bx = 512u;  // grid-stride over tiles; blockIdx.y = feature (the table is loaded once per block)
+    hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabP, x.tabS, a.miss_raw,
+                       a.ieee, W, x.q, x.tile_flags);
+  }
+  return hipGetLastError();
+}
+
 template <int D, int CT, int U, int OPT = 0>
 static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const Q16Aux& x = *reinterpret_cast<const Q16Aux*>(a.aux);
   const uint64_t tiles = (a.n + kQTile - 1) / kQTile;
   if (tiles == 0) return hipSuccess;
   if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  const uint32_t W = a.tuple_words;
   auto kern = score_q16_kernel<D, CT, U, OPT>;
-  const uint32_t lds = v.lds_bytes_q16(W);
+  const uint32_t lds = v.lds_bytes_q16(a.tuple_words);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  const uint32_t rank_lds = (x.Kpad + (x.Kpad >> 5) + 1u) * 4u + kRankBuckets * 2u;  // skewed table + bucket starts, see rank_kernel
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds);
-  if (e != hipSuccess) return e;
   if (!x.skip_prepass) {
-    // tile flags + (8-byte aligned, right behind them) the work counters of the fused / grouped pre-pass
-    unsigned long long* counter = reinterpret_cast<unsigned long long*>(x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u));
-    e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters) * 4, s);
+    e = launch_q16_prepass(a, x, s);
     if (e != hipSuccess) return e;
-    const PrepassPlan& pp = x.prepass;
-    if (pp.groups && pp.lines >= 4u) {
-      // 1 group (all tables fit one CU's LDS together) or 2 groups of 4 lines: quad-coalesced loads, every 64-byte sector a block
-      // pulls is used whole (fused_rank_kernel); at most one block per CU
-      uint32_t lds = 0;
-      for (uint32_t g = 0; g < pp.groups; ++g) lds = pp.bytes[g] > lds ? pp.bytes[g] : lds;
-      const uint32_t parts = (pp.groups > 1u && a.num_cus >= 8u * pp.groups && tiles >= 8u) ? 8u : 1u;
-      uint32_t per_pair = a.num_cus / (parts * pp.groups);
-      if (per_pair < 1u) per_pair = 1u;
-      const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
-      if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(fused_rank_kernel, dim3(parts * pp.groups * per_pair), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp,
-                         parts, a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
-    } else if (pp.groups) {  // one launch, blocks split over feature groups x row partitions (XCDs)
-      uint32_t lds = 0;
-      for (uint32_t g = 0; g < pp.groups; ++g) lds = pp.bytes[g] > lds ? pp.bytes[g] : lds;
-      // one block per CU (the image takes most of the LDS); 8 row partitions when every (group, partition) gets a block
-      const uint32_t parts = (a.num_cus >= 8u * pp.groups && tiles >= 8u) ? 8u : 1u;
-      uint32_t per_pair = a.num_cus / (parts * pp.groups);
-      if (per_pair < 1u) per_pair = 1u;
-      const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
-      if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
-      const uint32_t grid = parts * pp.groups * per_pair;
-      auto gk = pp.lines == 1u ? grouped_rank_kernel<1> : grouped_rank_kernel<2>;
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(gk, dim3(grid), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp, parts, a.miss_raw, a.ieee,
-                         reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
-    } else {
-      hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
-      uint32_t bx = (uint32_t)((x.n_pad / kQTile + 3) / 4);  // 4 tiles (kRankThreads x 4 rows) per block and pass
-      if (bx > 512u) bx = 512u;  // grid-stride over tiles; blockIdx.y = feature (the table is loaded once per block)
-      hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabP, x.tabS, a.miss_raw,
-                         a.ieee, W, x.q, x.tile_flags);
-    }
   }
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kQTile), lds, s, a, x);

@@ -26,21 +26,32 @@ namespace ddt {
 // Compare rule on a sparse record (thr, w): DTPU.sv:653-667, the missing direction in kSpMissRight.  Written with
 // logical operators on purpose: hipcc keeps such lane predicates as SGPR masks (s_and / s_or), whereas a ternary
 // between two predicates is lowered to 0/1 VGPRs and four extra VALU instructions per visit.
-template <bool SLOW>
+// Q (rank-quantised kernels): f is the u16 rank of the feature value, thr the node's rank R; x >= t  <=>  rank(x) >= R
+// (ddt_kernels.hip "The rank-quantised path"), a missing value has the rank kQMissing.
+template <bool SLOW, bool Q>
 __device__ __forceinline__ bool sp_right(uint32_t f, uint32_t thr, uint32_t w, uint32_t miss_key) {
-  const bool ge = (int32_t)f >= (int32_t)thr;
+  const bool ge = Q ? f >= thr : (int32_t)f >= (int32_t)thr;
   if (!SLOW) return ge;
-  const bool miss = f == miss_key, mr = (int32_t)(w << 2) < 0;  // kSpMissRight = bit 29
+  const bool miss = f == (Q ? kQMissing : miss_key), mr = (int32_t)(w << 2) < 0;  // kSpMissRight = bit 29
   return (miss && mr) || (!miss && ge);
+}
+
+template <bool Q>
+__device__ __forceinline__ uint32_t sp_feature(uint32_t w, uint32_t lane_off) {
+  const uint32_t addr = (w & kSpAddrMask) | lane_off;
+  if (Q) return *reinterpret_cast<const DDT_LDS(uint16_t)*>(addr);  // ds_read_u16
+  return lds_u32(addr);
 }
 
 // The walk of all PU groups for one tile.  SLOW = the tile holds a missing value: apply the per-node missing rule
 // (block-uniform choice, like the perfect-tree kernels).
-template <int K, int U, int THREADS, bool SLOW>
+template <int K, int U, int THREADS, bool SLOW, bool Q>
 __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
   constexpr int TOPB = 12 << K;
   constexpr int STEPB = U * TOPB;  // U trees per pass: one PU group (or two)
-  const uint32_t lane_off = (uint32_t)tid * 4u, miss_key = a.miss_key, C = a.clusters;
+  // Q: the u16 tile of the q16 pre-pass -- tuples t and t + 512 of a tile share a dword (rank_kernel)
+  const uint32_t lane_off = Q ? ((((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1)) : (uint32_t)tid * 4u;
+  const uint32_t miss_key = a.miss_key, C = a.clusters;
   const uint4* __restrict__ deep = x.deep;
   const uint32_t n_steps = x.n_groups * 8u / (uint32_t)U;  // the host pads the image to whole passes
   for (uint32_t g = 0; g < n_steps; ++g) {
@@ -58,9 +69,9 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
       for (int u = 0; u < U; ++u) nd[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
       uint32_t f[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) f[u] = lds_u32((nd[u].y & kSpAddrMask) | lane_off);
+      for (int u = 0; u < U; ++u) f[u] = sp_feature<Q>(nd[u].y, lane_off);
 #pragma unroll
-      for (int u = 0; u < U; ++u) m8[u] = (m8[u] << 1) + (sp_right<SLOW>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
+      for (int u = 0; u < U; ++u) m8[u] = (m8[u] << 1) + (sp_right<SLOW, Q>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
     }
     uint4 r[U];  // m8 = 8 * heap index in [2^(K-1), 2^K): record at 4*2^K + 16*(m - 2^(K-1)) = 2*m8 - 4*2^K
 #pragma unroll
@@ -83,8 +94,8 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
       bool any = false;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t f = lds_u32((r[u].y & kSpAddrMask) | lane_off);
-        const bool right = sp_right<SLOW>(f, r[u].x, r[u].y, miss_key);
+        const uint32_t f = sp_feature<Q>(r[u].y, lane_off);
+        const bool right = sp_right<SLOW, Q>(f, r[u].x, r[u].y, miss_key);
         const uint32_t lw = right ? (r[u].y << 1) : r[u].y;  // kSpRightLeaf (bit 30) or kSpLeftLeaf (bit 31) into the sign bit
         const bool leaf = (int32_t)lw < 0;
         nxt[u] = right ? r[u].w : r[u].z;
@@ -119,20 +130,36 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
   }
 }
 
-template <int K, int U, int THREADS>
+template <int K, int U, int THREADS, bool Q>
 __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 12 << K;          // bytes of one tree's top image
   constexpr int STEPB = U * TOPB;  // top images resident per pass: U trees walked in lock-step = U independent load chains per lane
-  constexpr int ROW = THREADS * 4;
+  constexpr int ROW = Q ? THREADS * 2 : THREADS * 4;
   constexpr int FEAT_OFF = (STEPB + ROW - 1) / ROW * ROW;
   static_assert(U == 8 || U == 16, "one or two PU groups per pass");
   static_assert((STEPB / 16) % 64 == 0, "whole waves per DMA");
+  static_assert(!Q || THREADS == 1024, "the rank pre-pass writes tiles of 1024 tuples");
   const int tid = threadIdx.x;
   const uint64_t tile0 = (uint64_t)blockIdx.x * THREADS;
   const uint32_t W = a.tuple_words, lpt = W / 4u;
 
   dma_chunk<THREADS, STEPB>(a.img, 0, 0, tid);  // top images of the first pass
 
+  bool slow;
+  if constexpr (Q) {
+    // the feature tile is one contiguous block of W * 2048 bytes of the pre-pass's output: DMA it in (score_q16_kernel); the
+    // first barrier of the walk publishes it
+    const uint4* src = reinterpret_cast<const uint4*>(x.q16.q + (uint64_t)blockIdx.x * W * (uint32_t)THREADS);
+    const uint32_t units = W * (ROW / 16);
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    for (uint32_t u0 = 0; u0 < units; u0 += THREADS) {
+      const uint32_t lds_addr = (uint32_t)FEAT_OFF + (u0 + (uint32_t)wave_base) * 16u;
+      const uint4* g = src + (u0 + (uint32_t)tid);
+      if (u0 + (uint32_t)wave_base < units)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
+    }
+    slow = __builtin_amdgcn_readfirstlane((int)x.q16.tile_flags[blockIdx.x]) != 0;  // the tile holds a missing value
+  } else {
   // ---- stage the tuple tile feature-major (quad-coalesced loads + in-quad DPP transpose, see score_tile_kernel) ----
   uint32_t miss_any = 0;
   {
@@ -167,39 +194,50 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
       }
     }
   }
-
   // the barrier inside publishes the staged tile; tiles without a missing value skip the missing rule altogether
-  const bool slow = block_any<THREADS>(miss_any, (uint32_t)FEAT_OFF + W * (uint32_t)ROW, tid);
+  slow = block_any<THREADS>(miss_any, (uint32_t)FEAT_OFF + W * (uint32_t)ROW, tid);
+  }
+
   RefAcc<1> ra;
   ra.init();
   double dacc = 0.0;
   const uint32_t C = a.clusters;
-  if (!slow) sparse_walk<K, U, THREADS, false>(a, x, tid, ra, dacc);
-  else sparse_walk<K, U, THREADS, true>(a, x, tid, ra, dacc);
+  if (!slow) sparse_walk<K, U, THREADS, false, Q>(a, x, tid, ra, dacc);
+  else sparse_walk<K, U, THREADS, true, Q>(a, x, tid, ra, dacc);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
 }
 
-template <int K, int U, int THREADS>
+template <int K, int U, int THREADS, bool Q>
 static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_kernel<K, U, THREADS>;
+  auto kern = score_sparse_kernel<K, U, THREADS, Q>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  if (Q && !x.q16.skip_prepass) {  // ranks + per-tile missing flags of this batch (reused by the other classes' launches)
+    e = launch_q16_prepass(a, x.q16, s);
+    if (e != hipSuccess) return e;
+  }
+  if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(THREADS), lds, s, a, x);
   return hipGetLastError();
 }
 
 #define DDT_SP(K, U, T) \
-  Variant { "sparse_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 0, &launch_sparse_v<K, U, T> }
+  Variant { "sparse_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 0, &launch_sparse_v<K, U, T, false> }
+#define DDT_SPQ(K, U) /* rank-quantised: u16 feature tile of 1024 tuples = 16 waves per CU */ \
+  Variant { "sparse_q_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 1, &launch_sparse_v<K, U, 1024, true> }
 
 // `levels` = K (top levels staged in LDS), `chunk_trees` = trees walked in lock-step, `threads` = tuples per tile
 static const Variant g_sparse_variants[] = {
+    // rank-quantised (thresholds -> ranks, features -> the u16 tiles of the q16 pre-pass): half the LDS per tuple, so a CU holds
+    // 1024 walkers = 16 waves instead of 512 = 8 -- the deep phase is latency-bound, walkers in flight are what it needs
+    DDT_SPQ(6, 8), DDT_SPQ(7, 8), DDT_SPQ(8, 8), DDT_SPQ(9, 8),
     // measured and NOT instantiated (profiles/r02_sparse_sweep_*.log): 16 trees in lock-step (u16: no gain over u8), half a
     // PU group per pass (u4: K + 1 at the same occupancy, but 4 loads in flight per lane: 159 vs 196 Mtuples/s)
     DDT_SP(6, 8, 256), DDT_SP(7, 8, 256), DDT_SP(8, 8, 256), DDT_SP(9, 8, 256), DDT_SP(10, 8, 256),

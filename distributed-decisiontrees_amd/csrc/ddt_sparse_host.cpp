@@ -26,11 +26,25 @@ struct Cursor {  // a position while expanding the top heap: an internal node of
 // BASELINE config 4 (512 trees x depth 16 x 64 features, profiles/r02_sparse_sweep*.json): the deep phase is bound by the
 // vector-memory pipe's lane-address rate, and hiding its latency needs >= 8 waves per CU, so a smaller K that lets two
 // 256-tuple blocks share a CU beats a larger K with one.
-int pick_variant(ddt_engine* e, uint32_t max_depth) {
+int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {
   const uint32_t W = tuple_words(e->p);
-  auto fits = [&](int vid, uint32_t budget) { return vid >= 0 && variant(vid).kind == kKindSparse && variant(vid).lds_bytes_sparse(W) <= budget; };
+  auto fits = [&](int vid, uint32_t budget) {
+    if (vid < 0 || variant(vid).kind != kKindSparse || variant(vid).lds_bytes_sparse(W) > budget) return false;
+    return !(variant(vid).opt & 1) || ranks_fit;  // rank-quantised kernels: every feature's table must fit 16-bit ranks
+  };
   if (e->forced_variant >= 0) return fits(e->forced_variant, kMaxLdsBytes) ? e->forced_variant : -1;
   char name[40];
+  // Rank-quantised kernels first (option "sparse_q16", default on): a u16 feature tile is half the LDS per tuple, so one block of
+  // 1024 tuples = 16 waves holds the CU that the fp32 tile fills with 512 = 8; the deep phase is latency-bound and takes the
+  // walkers (BASELINE config 4: profiles/r03_sweep_sparse_q.json).  Largest K whose top images fit next to the tile.
+  if (e->sparse_q16 && ranks_fit) {
+    const int kq = e->sparse_top_levels >= 0 ? e->sparse_top_levels : (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, kSparseMinTop), 9u);
+    for (int K = kq; K >= (e->sparse_top_levels >= 0 ? kq : kSparseMinTop); --K) {
+      snprintf(name, sizeof(name), "sparse_q_k%d_u8_t1024", K);
+      const int vid = find_variant(name);
+      if (fits(vid, kMaxLdsBytes)) return vid;
+    }
+  }
   if (e->sparse_top_levels >= 0) {
     for (int T : {256, 128, 64}) {
       snprintf(name, sizeof(name), "sparse_k%d_u8_t%d", e->sparse_top_levels, T);
@@ -66,7 +80,18 @@ int pick_variant(ddt_engine* e, uint32_t max_depth) {
 
 }  // namespace
 
+// sorted distinct threshold keys per feature over the forests of every class (they share one pre-pass per batch)
+static RankTables sparse_rank_tables(const ddt_params& p, const std::vector<const SparseForest*>& sps) {
+  RankTables rt;
+  rt.keys.resize(tuple_words(p));
+  for (const SparseForest* sp : sps)
+    for (size_t n = 0; n < sp->lines.size() / 4u; ++n) rt.keys[sp->lines[4u * n + 1u] & 0x7FFu].push_back(thr_key(p, sp->lines[4u * n]));
+  finish_rank_tables(rt);
+  return rt;
+}
+
 void sparse_free(ddt_engine* e) {
+  free_rank_device(e->sp_rank);
   for (SparseForest& sp : e->sps) {
     for (void** p : {&sp.d_top, &sp.d_deep}) {
       if (*p) (void)hipFree(*p);
@@ -77,21 +102,39 @@ void sparse_free(ddt_engine* e) {
   }
 }
 
-static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp);
-static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest& sp, std::vector<uint32_t>& top, std::vector<uint32_t>& deep,
-                            uint32_t* groups_out);
+static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp, const RankTables* rt);
+static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest& sp, const RankTables* rt, std::vector<uint32_t>& top,
+                            std::vector<uint32_t>& deep, uint32_t* groups_out);
 
 // Choose the kernel for the loaded forest(s) and pack the device images of every class for it.
 int sparse_rebuild(ddt_engine* e) {
   uint32_t max_depth = 0;
-  for (const SparseForest& sp : e->sps) max_depth = sp.max_depth > max_depth ? sp.max_depth : max_depth;
-  const int vid = pick_variant(e, max_depth);
+  std::vector<const SparseForest*> all;
+  for (const SparseForest& sp : e->sps) {
+    max_depth = sp.max_depth > max_depth ? sp.max_depth : max_depth;
+    all.push_back(&sp);
+  }
+  RankTables rt;
+  try {
+    rt = sparse_rank_tables(e->p, all);
+  } catch (const std::bad_alloc&) {
+    return fail(e, DDT_ENOMEM, "rank table allocation failed");
+  }
+  const int vid = pick_variant(e, max_depth, rt.max_len <= kQ16MaxTable);
   if (vid < 0)
     return fail(e, DDT_EUNSUPPORTED, "no sparse kernel fits: %u tuple words need more than %u bytes of LDS (or the forced variant %d / "
                 "sparse_top_levels %d is not a sparse kernel that fits)", tuple_words(e->p), kMaxLdsBytes, e->forced_variant, e->sparse_top_levels);
   sparse_free(e);
+  const bool q = (variant(vid).opt & 1) != 0;
+  if (q) {  // the tables of the rank pre-pass (shared by all classes)
+    RankHostTables h;
+    int rc = pack_rank_tables(e, rt, tuple_words(e->p), true, h);
+    if (rc) return rc;
+    rc = upload_rank_tables(e, h, e->sp_rank);
+    if (rc) return rc;
+  }
   for (SparseForest& sp : e->sps) {
-    int rc = sparse_pack(e, variant(vid), sp);
+    int rc = sparse_pack(e, variant(vid), sp, q ? &rt : nullptr);
     if (rc) return rc;
   }
   e->variant_id = vid;
@@ -100,14 +143,16 @@ int sparse_rebuild(ddt_engine* e) {
 
 // Pack the device images of one forest for kernel `v` and upload them.
 // the host half of the packing (no HIP call: also behind the test hook ddt_debug_sparse_image)
-static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest& sp, std::vector<uint32_t>& top, std::vector<uint32_t>& deep,
-                            uint32_t* groups_out) {
+// `rt` (rank-quantised kernels): a node's threshold word is its rank R = 1 + index of the threshold among the sorted distinct
+// keys of its feature (x >= t  <=>  rank(x) >= R), else the threshold key itself
+static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest& sp, const RankTables* rt, std::vector<uint32_t>& top,
+                            std::vector<uint32_t>& deep, uint32_t* groups_out) {
   const uint32_t K = (uint32_t)v.levels, T = sp.trees();
   const uint32_t per_pass = std::max(1u, (uint32_t)v.chunk_trees / 8u);  // PU groups walked in lock-step (half groups: 1)
   uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
   groups = (groups + per_pass - 1u) / per_pass * per_pass;  // whole passes: the padding groups are EMPTY slots too (+0)
   const uint32_t top_words = (12u << K) / 4u;       // per tree
-  const uint32_t feat_off = v.feat_off_sparse(), row = v.row_bytes();
+  const uint32_t feat_off = v.feat_off_sparse(), row = v.row_bytes_sparse();
   auto feat_word = [&](uint32_t j) { return feat_off + j * row; };
 
   try {
@@ -144,6 +189,12 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
     const uint32_t* L = sp.lines.data() + sp.first[i] * 4u;
     auto child = [&](uint32_t n, uint32_t side) { return Cursor{((L[4u * n + 1u] >> (14u + side)) & 1u) != 0u, L[4u * n + 2u + side]}; };
     auto node_w = [&](uint32_t n) { return feat_word(L[4u * n + 1u] & 0x7FFu) | (((L[4u * n + 1u] >> 13) & 1u) ? kSpMissRight : 0u); };
+    auto node_key = [&](uint32_t n) -> uint32_t {
+      const uint32_t key = thr_key(e->p, L[4u * n]);
+      if (!rt) return key;
+      const auto& k = rt->keys[L[4u * n + 1u] & 0x7FFu];
+      return 1u + (uint32_t)(std::lower_bound(k.begin(), k.end(), key, [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; }) - k.begin());
+    };
     // ---- top heap, level by level ----
     cur.assign(1, Cursor{false, 0u});
     for (uint32_t lvl = 0; lvl + 1u < K; ++lvl) {
@@ -156,7 +207,7 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
           nxt.push_back(cur[k]);
         } else {
           const uint32_t n = cur[k].v;
-          put8(t, m, thr_key(e->p, L[4u * n]), node_w(n));
+          put8(t, m, node_key(n), node_w(n));
           nxt.push_back(child(n, 0));
           nxt.push_back(child(n, 1));
         }
@@ -182,7 +233,7 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
           pending.push_back({c.v, rec + 2u + side});
         }
       }
-      rec[0] = thr_key(e->p, L[4u * n]);
+      rec[0] = node_key(n);
       rec[1] = w;
     }
     // ---- deep records of this tree: the sub-trees hanging below level K-1 ----
@@ -226,7 +277,7 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
         if (c.leaf) w |= side ? kSpRightLeaf : kSpLeftLeaf;
         rec[2u + side] = c.leaf ? c.v : where[c.v];
       }
-      rec[0] = thr_key(e->p, L[4u * n]);
+      rec[0] = node_key(n);
       rec[1] = w;
     }
     for (auto& pe : pending) *pe.second = where[pe.first];
@@ -238,10 +289,10 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
   return DDT_OK;
 }
 
-static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp) {
+static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp, const RankTables* rt) {
   std::vector<uint32_t> top, deep;
   uint32_t groups = 0;
-  int rc = sparse_pack_host(e, v, sp, top, deep, &groups);
+  int rc = sparse_pack_host(e, v, sp, rt, top, deep, &groups);
   if (rc) return rc;
   HIP_TRY(e, hipMalloc(&sp.d_top, top.size() * 4u));
   HIP_TRY(e, hipMalloc(&sp.d_deep, deep.size() * 4u));
@@ -253,7 +304,7 @@ static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp) {
   return DDT_OK;
 }
 
-int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
+int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, float* d_scores, hipStream_t s, bool reuse_prepass) {
   const SparseForest& sp = e->sps[cls];
   const Variant& v = variant(e->variant_id);
   ScoreArgs a{};
@@ -271,9 +322,27 @@ int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, f
   a.ieee = e->p.cmp_mode;
   a.sum_mode = e->p.sum_mode;
   a.num_cus = e->prop.multiProcessorCount > 0 ? (uint32_t)e->prop.multiProcessorCount : 256u;
-  SparseAux x;
+  SparseAux x{};
   x.deep = reinterpret_cast<const uint4*>(sp.d_deep);
   x.n_groups = sp.groups;
+  if (v.opt & 1) {  // rank-quantised: the batch's ranks + per-tile missing flags come from the q16 pre-pass (workspace slot e->q_slot)
+    int rc = ensure_q16_workspace(e, n);
+    if (rc) return rc;
+    Q16Aux& qa = x.q16;
+    qa.xT = reinterpret_cast<uint32_t*>(e->q_xT[e->q_slot]);
+    qa.q = reinterpret_cast<uint16_t*>(e->q_q[e->q_slot]);
+    qa.tile_flags = reinterpret_cast<uint32_t*>(e->q_flags[e->q_slot]);
+    qa.tables = reinterpret_cast<const uint32_t*>(e->sp_rank.d_tables);
+    qa.tabP = reinterpret_cast<const uint32_t*>(e->sp_rank.d_tabK);
+    qa.tabS = reinterpret_cast<const uint16_t*>(e->sp_rank.d_tabS);
+    qa.Kpad = e->sp_rank.Kpad;
+    qa.skip_prepass = reuse_prepass ? 1u : 0u;
+    qa.prepass_img = reinterpret_cast<const uint4*>(e->sp_rank.d_prepass);
+    qa.prepass = e->sp_rank.prepass;
+    qa.img_slow = nullptr;  // the sparse images carry the missing direction in every record
+    qa.n_pad = (n + 1023) / 1024 * 1024;
+    if (e->kernel_timing && e->q_slot == 0) a.ev_mid = e->tev[1];  // recorded between the pre-pass and the scoring kernel
+  }
   a.aux = &x;
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   hipError_t r = v.launch(a, v, s);
@@ -429,14 +498,24 @@ extern "C" int ddt_debug_sparse_image(const ddt_params* p, const void* node_line
   const Variant& v = variant(variant_id);
   std::vector<uint32_t> top, deep;
   uint32_t groups = 0;
-  rc = sparse_pack_host(e.get(), v, sp, top, deep, &groups);
+  RankTables rt;
+  const bool q = (v.opt & 1) != 0;
+  if (q) {
+    try {
+      rt = sparse_rank_tables(*p, {&sp});
+    } catch (const std::bad_alloc&) {
+      return DDT_ENOMEM;
+    }
+    if (rt.max_len > kQ16MaxTable) return DDT_EUNSUPPORTED;
+  }
+  rc = sparse_pack_host(e.get(), v, sp, q ? &rt : nullptr, top, deep, &groups);
   if (rc) return rc;
   info_out[0] = top.size();
   info_out[1] = deep.size();
   info_out[2] = groups;
   info_out[3] = (uint64_t)v.levels;
   info_out[4] = v.feat_off_sparse();
-  info_out[5] = v.row_bytes();
+  info_out[5] = v.row_bytes_sparse();
   if (top_out) {
     if (top_cap_words < top.size()) return DDT_EINVAL;
     memcpy(top_out, top.data(), top.size() * 4u);

@@ -299,7 +299,10 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * workspace of the rank-quantised path for calls of up to that many rows: the *_device calls then never allocate),
  * "leaf_domain_check" (1 = default: refuse -0 / sub-normal / Inf / NaN leaves in the reference-order sum, where the
  * GPU's IEEE adds and the reference's adder differ), "sparse_top_levels" (-1 = auto, or 6..10 levels of a sparse
- * forest staged in LDS), "sparse_deep_order" (0 = level order, default; 1 = depth-first per sub-tree). */
+ * forest staged in LDS), "sparse_deep_order" (0 = level order, default; 1 = depth-first per sub-tree), "sparse_q16" (1 =
+ * default: sparse forests whose distinct thresholds per feature fit 16-bit ranks -- at most 32767, e.g. histogram-trained
+ * models -- and whose tuples have at most 64..76 words run on the rank-quantised sparse kernels: u16 feature tile, 1024
+ * tuples per block; 0 = always the fp32-tile kernels).  A refused sparse_* value keeps the previous one and the loaded model. */
 int ddt_set_option(ddt_engine* e, const char* key, int64_t value);
 int ddt_num_variants(void);
 int ddt_variant_name(int variant, char* buf, size_t buflen);

@@ -84,6 +84,32 @@ hipError_t launch_records(const ScoreArgs& args, const Variant& var, hipStream_t
   return hipSuccess;
 }
 
+// the rank pre-pass of one batch (mock layout of the workspace: q[row][feature])
+void enqueue_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s) {
+  const uint32_t W = a.tuple_words;
+  Op* pre = new Op();
+  pre->cost = (double)a.n * g_cost_row * 0.05;
+  pre->run = [=] {
+    const uint64_t tiles = (a.n + 1023) / 1024;
+    for (uint64_t t = 0; t < tiles; ++t) x.tile_flags[t] = 0u;
+    for (uint64_t i = 0; i < a.n; ++i)
+      for (uint32_t j = 0; j < W; ++j) {
+        const uint32_t raw = a.tuples[i * W + j];
+        uint16_t r;
+        if (raw == a.miss_raw) {
+          r = 0xFFFFu;
+          x.tile_flags[i / 1024] = 1u;
+        } else {
+          const int32_t key = (int32_t)(a.ieee ? ieee_key(raw) : raw);
+          const int32_t* tab = reinterpret_cast<const int32_t*>(x.tables) + (size_t)j * x.Kpad;
+          r = (uint16_t)(std::upper_bound(tab, tab + x.tabP[j * 8u], key) - tab);  // keys <= x among the K real ones
+        }
+        x.q[i * W + j] = r;
+      }
+  };
+  enqueue(s, pre);
+}
+
 // rank-quantised path: a PRE-PASS operation writes the feature ranks and the per-tile missing flags into the engine's
 // workspace, a SCORING operation reads them (and the fast or the slow image per tile) -- two operations, like the kernels
 hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) {
@@ -91,29 +117,7 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
   const Variant v = var;
   const Q16Aux x = *reinterpret_cast<const Q16Aux*>(args.aux);
   const uint32_t W = a.tuple_words;
-  if (!x.skip_prepass) {
-    Op* pre = new Op();
-    pre->cost = (double)a.n * g_cost_row * 0.05;
-    pre->run = [=] {
-      const uint64_t tiles = (a.n + 1023) / 1024;
-      for (uint64_t t = 0; t < tiles; ++t) x.tile_flags[t] = 0u;
-      for (uint64_t i = 0; i < a.n; ++i)
-        for (uint32_t j = 0; j < W; ++j) {
-          const uint32_t raw = a.tuples[i * W + j];
-          uint16_t r;
-          if (raw == a.miss_raw) {
-            r = 0xFFFFu;
-            x.tile_flags[i / 1024] = 1u;
-          } else {
-            const int32_t key = (int32_t)(a.ieee ? ieee_key(raw) : raw);
-            const int32_t* tab = reinterpret_cast<const int32_t*>(x.tables) + (size_t)j * x.Kpad;
-            r = (uint16_t)(std::upper_bound(tab, tab + x.tabP[j * 8u], key) - tab);  // keys <= x among the K real ones
-          }
-          x.q[i * W + j] = r;
-        }
-    };
-    enqueue(s, pre);
-  }
+  if (!x.skip_prepass) enqueue_prepass(a, x, s);
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   Op* op = new Op();
   op->cost = (double)a.n * g_cost_row;
@@ -152,17 +156,23 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
   const ScoreArgs a = args;
   const Variant v = var;
   const SparseAux x = *reinterpret_cast<const SparseAux*>(args.aux);
+  const bool ranked = (v.opt & 1) != 0;  // "sparse_q_*": thresholds are ranks, features come from the pre-pass's workspace
+  if (ranked && !x.q16.skip_prepass) enqueue_prepass(a, x.q16, s);
+  if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   Op* op = new Op();
   op->cost = (double)a.n * g_cost_row;
   op->run = [=] {
-    const uint32_t K = a.levels, W = a.tuple_words, tw = (12u << K) / 4u, feat_off = v.feat_off_sparse(), row = v.row_bytes();
+    const uint32_t K = a.levels, W = a.tuple_words, tw = (12u << K) / 4u, feat_off = v.feat_off_sparse(), row = v.row_bytes_sparse();
     const uint32_t* top = reinterpret_cast<const uint32_t*>(a.img);
     const uint32_t* deep = reinterpret_cast<const uint32_t*>(x.deep);
     std::vector<float> leaf(a.n_trees);
     for (uint64_t i = 0; i < a.n; ++i) {
       const uint32_t* t = a.tuples + i * W;
+      const uint16_t* rk = ranked ? x.q16.q + i * W : nullptr;
       auto right = [&](uint32_t key, uint32_t w) -> uint32_t {
-        const uint32_t raw = t[((w & kSpAddrMask) - feat_off) / row], xk = a.ieee ? ieee_key(raw) : raw;
+        const uint32_t j = ((w & kSpAddrMask) - feat_off) / row;
+        if (ranked) return rk[j] == 0xFFFFu ? (uint32_t)((w & kSpMissRight) != 0u) : (uint32_t)(rk[j] >= key);
+        const uint32_t raw = t[j], xk = a.ieee ? ieee_key(raw) : raw;
         return raw == a.miss_raw ? (uint32_t)((w & kSpMissRight) != 0u) : (uint32_t)!((int32_t)xk < (int32_t)key);
       };
       for (uint32_t slot = 0; slot < a.n_trees; ++slot) {
@@ -203,6 +213,8 @@ const Variant g_mock_variants[] = {
 
 namespace {
 const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
+    Variant{"sparse_q_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 1, &launch_sparse},
+    Variant{"sparse_q_k6_u8_t1024", kKindSparse, 6, 1024, 1, 8, 8, 1, 1, &launch_sparse},
     Variant{"sparse_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 0, &launch_sparse},
     Variant{"sparse_k8_u8_t512", kKindSparse, 8, 512, 1, 8, 8, 1, 0, &launch_sparse},
     Variant{"sparse_k9_u8_t128", kKindSparse, 9, 128, 1, 8, 8, 1, 0, &launch_sparse},

@@ -171,7 +171,7 @@ def test_cli_scores_a_sparse_forest(tmp_path):
     assert np.array_equal(np.fromfile(pre + ".first", np.uint64), s.first)
     out = subprocess.check_output([ddt.CLI_PATH, "score-sparse", "--nodes", pre + ".nodes", "--first", pre + ".first", "--tuples", pre + ".tuples",
                                    "--features", str(F), "--max-depth", str(D), "--out", pre + ".results"]).decode()
-    assert f"scored {n} tuples with sparse trees [0, {T})" in out and "sparse_k" in out
+    assert f"scored {n} tuples with sparse trees [0, {T})" in out and "sparse_" in out
     res = np.fromfile(pre + ".results", np.float32)
     want = O.score_sparse(s, O.gen_tuples(0, n, F, dist=1))
     assert res.size == (n + 3) // 4 * 4 and np.array_equal(res[:n].view(np.uint32), want.view(np.uint32))

@@ -177,17 +177,23 @@ def test_gpu_sparse_bit_exact_all_top_levels_and_orders(eng, shape):
         want = O.score_sparse(s, x)
         for top in (-1, 6, 7, 8, 9, 10):
             for order in (0, 1):
-                try:
-                    got = _gpu_sparse(eng, s, x, top=top, order=order)
-                except ddt.DDTError as ex:  # a forced K whose top images do not fit the LDS next to the feature tile
-                    assert ex.code == -5 and top == 10 and F > 60
-                    continue
-                assert np.array_equal(_bits(got), _bits(want)), (shape, cmp_mode, top, order, eng.info().variant_name)
+                for ranked in (1, 0):  # rank-quantised kernels (u16 tile of the q16 pre-pass) and the fp32-tile kernels
+                    eng.set_option("sparse_q16", ranked)
+                    try:
+                        got = _gpu_sparse(eng, s, x, top=top, order=order)
+                    except ddt.DDTError as ex:  # a forced K whose top images do not fit the LDS next to the feature tile
+                        assert ex.code == -5 and top == 10 and F > 60
+                        continue
+                    name = eng.info().variant_name.decode()
+                    assert ranked or not name.startswith("sparse_q_"), (name, ranked, top)
+                    assert not (ranked and top == -1 and F <= 64) or name.startswith("sparse_q_"), (name, ranked, top)
+                    assert np.array_equal(_bits(got), _bits(want)), (shape, cmp_mode, top, order, name)
+        eng.set_option("sparse_q16", 1)
         want64 = O.score_sparse(s, x, sum_mode=O.SUM_F64_SEQ)
         assert np.array_equal(_bits(_gpu_sparse(eng, s, x, sum_mode=1)), _bits(want64))
         assert np.array_equal(_bits(eng.score(x)), _bits(want64))  # host feeder path on the loaded model
     info = eng.info()
-    assert info.variant_name.decode().startswith("sparse_k") and info.local_trees == T
+    assert info.variant_name.decode().startswith("sparse_") and info.local_trees == T
     assert info.model_bytes_unpadded == s.n_lines * 16
 
 

@@ -4,6 +4,7 @@ array in level or depth-first order) come back through the 
 are walked in numpy the way `score_sparse_kernel` walks them; every (tuple, tree) must end on the leaf the oracle's walk of
 the wire format ends on, EMPTY slots on +0."""
 import ctypes as C
+import re
 
 import numpy as np
 import pytest
@@ -31,15 +32,25 @@ def _images(s, variant, order):
     return top, deep.reshape(-1, 4), [int(v) for v in info]
 
 
-def _walk(top, deep, info, slot, x, miss_bits):
-    """score_sparse_kernel's walk of one tree slot for one tuple (cmp_mode 0: signed compare of the raw bits)"""
+def _rank_tables(s):
+    """per feature: the sorted distinct threshold keys of the forest (cmp_mode 0: the raw bits in int32 order)"""
+    nl = np.ascontiguousarray(s.node_lines).view(np.uint32).reshape(-1, 4)
+    return [np.unique(nl[(nl[:, 1] & 0x7FF) == j, 0].view(np.int32)) for j in range(int(s.params.num_features))]
+
+
+def _walk(top, deep, info, slot, x, miss_bits, tables=None):
+    """score_sparse_kernel's walk of one tree slot for one tuple (cmp_mode 0: signed compare of the raw bits); `tables`
+    (rank-quantised kernels): the node word is the threshold's rank, the feature value is replaced by ITS rank = number of keys <= x"""
     _, _, _, K, feat_off, row = info
     t = top[slot * (12 << K) // 4: (slot + 1) * (12 << K) // 4]
 
     def right(key, w):
-        f = int(x[((w & ADDR) - feat_off) // row])
+        j = ((w & ADDR) - feat_off) // row
+        f = int(x[j])
         if f == miss_bits:
             return (w & MISS_RIGHT) != 0
+        if tables is not None:
+            return int(np.searchsorted(tables[j], np.uint32(f).view(np.int32), side="right")) >= key if j < len(tables) else 0 >= key
         return np.int32(np.uint32(f).view(np.int32)) >= np.uint32(key).view(np.int32)
 
     m = 1
@@ -69,19 +80,22 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
     x = O.gen_tuples(3, 60, F, dist=1, missing_bits=s.params.missing_bits)
     x[::7, 0] = s.params.missing_bits  # missing values on the feature most roots test
     seen_k = set()
+    tables = _rank_tables(s)
     for vid, name in _sparse_variants():
-        K = int(name.split("_")[1][1:])
-        if K in seen_k:  # one variant per K: the packing depends on K and on the tile geometry only through the feature-row addresses
+        ranked = name.startswith("sparse_q_")
+        K = int(re.search(r"_k(\d+)_", name).group(1))
+        if (ranked, K) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
             continue
-        seen_k.add(K)
+        seen_k.add((ranked, K))
         top, deep, info = _images(s, vid, order)
         assert info[3] == K and info[2] * 8 >= T and top.size == info[2] * 8 * (12 << K) // 4
+        assert info[5] == (2048 if ranked else 4 * int(name.rsplit("_t", 1)[1]))  # u16 rows of 1024 tuples / fp32 rows of the tile
         for r in range(x.shape[0]):
             for i in range(info[2] * 8):
-                got = _walk(top, deep, info, i, x[r], int(s.params.missing_bits))
+                got = _walk(top, deep, info, i, x[r], int(s.params.missing_bits), tables if ranked else None)
                 want = O.traverse_sparse(s, x[r], i) if i < T else 0
                 assert got == want, (name, order, r, i, hex(got), hex(want))
-    assert len(seen_k) >= 4
+    assert len([k for k in seen_k if not k[0]]) >= 4 and len([k for k in seen_k if k[0]]) >= 4
 
 
 def test_hook_rejects_what_the_loader_rejects():

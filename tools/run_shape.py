@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--sparse", action="store_true")
     ap.add_argument("--full-levels", type=int, default=10)
     ap.add_argument("--permille", type=int, default=700)
+    ap.add_argument("--bins", type=int, default=0, help="sparse: snap every threshold to one of N values per feature (histogram-trained models)")
     ap.add_argument("--variant", default="", help="kernel variant name")
     ap.add_argument("--opt", default="", help="engine options, comma separated key=value")
     a = ap.parse_args()
@@ -36,6 +37,11 @@ def main():
         eng.set_option("variant", ddt.variant_names().index(a.variant))
     if a.sparse:
         lines, first = ddt.synth_sparse_model(T, D, F, a.full_levels, a.permille, 0)
+        if a.bins:  # thresholds of dist 0 are uniform in [0, 1)
+            import numpy as np
+            ln = np.asarray(lines).view(np.uint32).reshape(-1, 4)
+            thr = ln[:, 0].view(np.float32)
+            ln[:, 0] = (np.floor(thr * a.bins) / np.float32(a.bins)).astype(np.float32).view(np.uint32)
         eng.load_model_sparse(ddt.make_sparse_params(T, D, F), lines, first)
     else:
         w, f = ddt.synth_model(T, D, F, 0)
