@@ -15,6 +15,10 @@
 //   deep   16-byte records {thr, w, left, right} gathered from L2 / HBM: child pointers or leaf values are IN the
 //          parent's record, so a visit is ONE 16-byte load and the leaf needs no extra access.  Lanes that reached a
 //          leaf idle until the wave's deepest lane is done (__ballot early exit, per tree and per wave).
+//   deep2  ("sparse_b2_*", Variant::opt bit 1) the same sub-trees as TWO-LEVEL BLOCKS of 32 bytes {t0, t1, t2, meta, v0..v3}: a node,
+//          its two children and where the four grand-children are (ddt_internal.h).  One 16-byte gather advances a walker TWO
+//          levels, and one 4-byte gather at the end fetches its leaf: 4 + 1 dependent rounds where `deep` needs 8 (the deep phase
+//          is bound by the number of gather wave-instructions and by their latency chain, not by bytes).
 // No MFMA: compare + gather.  Bound by the vector-memory gather rate of the deep phase.
 #include <hip/hip_runtime.h>
 
@@ -45,7 +49,16 @@ __device__ __forceinline__ uint32_t sp_feature(uint32_t w, uint32_t lane_off) {
 
 // The walk of all PU groups for one tile.  SLOW = the tile holds a missing value: apply the per-node missing rule
 // (block-uniform choice, like the perfect-tree kernels).
-template <int K, int U, int THREADS, bool SLOW, bool Q>
+// Compare rule inside a two-level block: the missing direction is bit `mr_bit` of the block's meta word.
+template <bool SLOW>
+__device__ __forceinline__ bool b2_right(uint32_t f, uint32_t thr, uint32_t meta, uint32_t mr_bit, uint32_t miss_key) {
+  const bool ge = (int32_t)f >= (int32_t)thr;
+  if (!SLOW) return ge;
+  const bool miss = f == miss_key, mr = ((meta >> mr_bit) & 1u) != 0u;
+  return (miss && mr) || (!miss && ge);
+}
+
+template <int K, int U, int THREADS, bool SLOW, bool Q, bool B2>
 __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
   constexpr int TOPB = 12 << K;
   constexpr int STEPB = U * TOPB;  // U trees per pass: one PU group (or two)
@@ -79,10 +92,70 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
     __syncthreads();  // every wave holds its level K-1 records: the top image buffer is free
     if (g + 1 < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
 
+    float leafv[U];
+    if constexpr (B2) {
+      // ---- deep phase over two-level blocks (32 bytes: {t0, t1, t2, meta} + the four grand-children's leaf values) ----
+      constexpr uint32_t ROW = (uint32_t)THREADS * 4u, FEAT_OFF = ((uint32_t)STEPB + ROW - 1u) / ROW * ROW;
+      constexpr uint32_t RSH = (uint32_t)__builtin_ctz(ROW);
+      const uint32_t lane_base = FEAT_OFF + (uint32_t)tid * 4u;
+      // the blocks are gathered through a buffer resource (32-bit byte offsets, no 64-bit address arithmetic; and hipcc cannot
+      // turn "select between two words of a loaded block" into a second, dependent load of the selected word, which it does
+      // with plain pointer loads)
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(deep), 0, (int)x.deep_bytes, 0x00020000);
+      bool act[U], inl[U];   // still walking / the leaf came inline out of the level K-1 record
+      uint32_t B[U], la[U];  // byte offset of the walker's block / of its leaf value (16 = v0 of the dummy block: +0)
+      // level K-1: the 16-byte records out of LDS (classic format; a child is a leaf value or a block index)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t f = sp_feature<Q>(r[u].y, lane_off);
+        const bool right = sp_right<SLOW, Q>(f, r[u].x, r[u].y, miss_key);
+        const uint32_t lw = right ? (r[u].y << 1) : r[u].y;
+        const bool leaf = (int32_t)lw < 0;
+        const uint32_t nxt = right ? r[u].w : r[u].z;
+        inl[u] = leaf;
+        leafv[u] = __uint_as_float(nxt);
+        act[u] = !leaf;
+        B[u] = leaf ? 0u : (nxt << 5);
+        la[u] = 16u;
+      }
+      for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) any = any || act[u];
+        if (__ballot(any) == 0ull) break;
+        // all block gathers of this round back to back, UNCONDITIONAL (a finished walker re-reads block 0) so that hipcc counts
+        // them: visit u then waits with vmcnt(U-1-u)
+        u32x4 blk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) blk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, B[u], 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t meta = blk[u].w;
+          const uint32_t fa = lds_u32(((meta & 63u) << RSH) + lane_base);
+          const uint32_t c0 = b2_right<SLOW>(fa, blk[u].x, meta, 18u, miss_key) ? 1u : 0u;  // 0/1 arithmetic below: no branches
+          const uint32_t tc = c0 ? blk[u].z : blk[u].y;
+          const uint32_t fc = (meta >> (6u + 6u * c0)) & 63u;
+          const uint32_t fb = lds_u32((fc << RSH) + lane_base);
+          const uint32_t c1 = b2_right<SLOW>(fb, tc, meta, 19u + c0, miss_key) ? 1u : 0u;
+          const uint32_t j = 2u * c0 + c1;       // grand-child slot
+          const uint32_t bm = meta >> 21;        // [3:0] which grand-children are blocks, [10:4] rel
+          const bool isblk = ((bm >> j) & 1u) != 0u;
+          const uint32_t below = bm & ((1u << j) - 1u);  // j <= 3: only mask bits below slot j survive
+          const uint32_t nb = B[u] + (((bm >> 4) + (uint32_t)__popc(below)) << 5);
+          if (act[u] && !isblk) la[u] = B[u] + 16u + (j << 2);
+          act[u] = act[u] && isblk;
+          B[u] = act[u] ? nb : 0u;
+        }
+      }
+      float lv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) lv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, la[u], 0, 0));
+#pragma unroll
+      for (int u = 0; u < U; ++u) leafv[u] = inl[u] ? leafv[u] : lv[u];
+    } else {
     // ---- deep phase: one 16-byte gather per visit; lanes whose tree has reached its leaf are masked off (the
     //      vector-memory pipe takes one lane address per cycle: an idle lane must not cost one) ----
     bool act[U];  // per lane: tree still walking (kept as lane masks in SGPRs, not as bits of a VGPR)
-    float leafv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       act[u] = true;
@@ -115,6 +188,8 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
       }
     }
 
+    }
+
 #pragma unroll
     for (int h = 0; h < U / 8; ++h) {
       if (a.sum_mode == 1) {
@@ -130,7 +205,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
   }
 }
 
-template <int K, int U, int THREADS, bool Q>
+template <int K, int U, int THREADS, bool Q, bool B2>
 __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 12 << K;          // bytes of one tree's top image
   constexpr int STEPB = U * TOPB;  // top images resident per pass: U trees walked in lock-step = U independent load chains per lane
@@ -139,6 +214,7 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   static_assert(U == 8 || U == 16, "one or two PU groups per pass");
   static_assert((STEPB / 16) % 64 == 0, "whole waves per DMA");
   static_assert(!Q || THREADS == 1024, "the rank pre-pass writes tiles of 1024 tuples");
+  static_assert(!(Q && B2), "two-level blocks hold fp32 threshold keys");
   const int tid = threadIdx.x;
   const uint64_t tile0 = (uint64_t)blockIdx.x * THREADS;
   const uint32_t W = a.tuple_words, lpt = W / 4u;
@@ -202,18 +278,18 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   ra.init();
   double dacc = 0.0;
   const uint32_t C = a.clusters;
-  if (!slow) sparse_walk<K, U, THREADS, false, Q>(a, x, tid, ra, dacc);
-  else sparse_walk<K, U, THREADS, true, Q>(a, x, tid, ra, dacc);
+  if (!slow) sparse_walk<K, U, THREADS, false, Q, B2>(a, x, tid, ra, dacc);
+  else sparse_walk<K, U, THREADS, true, Q, B2>(a, x, tid, ra, dacc);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
 }
 
-template <int K, int U, int THREADS, bool Q>
+template <int K, int U, int THREADS, bool Q, bool B2>
 static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_kernel<K, U, THREADS, Q>;
+  auto kern = score_sparse_kernel<K, U, THREADS, Q, B2>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
@@ -229,9 +305,11 @@ static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStrea
 }
 
 #define DDT_SP(K, U, T) \
-  Variant { "sparse_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 0, &launch_sparse_v<K, U, T, false> }
+  Variant { "sparse_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 0, &launch_sparse_v<K, U, T, false, false> }
+#define DDT_SPB(K, U, T) /* two-level blocks below level K-1 (opt bit 1): F <= 64, trees of at most K + 8 levels */ \
+  Variant { "sparse_b2_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2, &launch_sparse_v<K, U, T, false, true> }
 #define DDT_SPQ(K, U) /* rank-quantised: u16 feature tile of 1024 tuples = 16 waves per CU */ \
-  Variant { "sparse_q_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 1, &launch_sparse_v<K, U, 1024, true> }
+  Variant { "sparse_q_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 1, &launch_sparse_v<K, U, 1024, true, false> }
 
 // `levels` = K (top levels staged in LDS), `chunk_trees` = trees walked in lock-step, `threads` = tuples per tile
 static const Variant g_sparse_variants[] = {
@@ -246,6 +324,9 @@ static const Variant g_sparse_variants[] = {
     // narrower tiles for wide tuples (the feature tile is 4 * W bytes per tuple)
     DDT_SP(6, 8, 128), DDT_SP(7, 8, 128), DDT_SP(8, 8, 128), DDT_SP(9, 8, 128), DDT_SP(10, 8, 128),
     DDT_SP(8, 8, 64), DDT_SP(9, 8, 64), DDT_SP(10, 8, 64),
+    // two-level blocks (at most 64 features: 256- and 512-tuple tiles cover every width that qualifies)
+    DDT_SPB(6, 8, 256), DDT_SPB(7, 8, 256), DDT_SPB(8, 8, 256), DDT_SPB(9, 8, 256), DDT_SPB(10, 8, 256),
+    DDT_SPB(6, 8, 512), DDT_SPB(7, 8, 512), DDT_SPB(8, 8, 512), DDT_SPB(9, 8, 512),
 };
 
 int num_sparse_variants() { return (int)(sizeof(g_sparse_variants) / sizeof(g_sparse_variants[0])); }
