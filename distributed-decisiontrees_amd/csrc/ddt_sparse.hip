@@ -58,7 +58,7 @@ __device__ __forceinline__ bool b2_right(uint32_t f, uint32_t thr, uint32_t meta
   return (miss && mr) || (!miss && ge);
 }
 
-template <int K, int U, int THREADS, bool SLOW, bool Q, bool B2>
+template <int K, int U, int THREADS, bool SLOW, bool Q, bool B2, int ROT>
 __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
   constexpr int TOPB = 12 << K;
   constexpr int STEPB = U * TOPB;  // U trees per pass: one PU group (or two)
@@ -93,17 +93,22 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
     if (g + 1 < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
 
     float leafv[U];
+    // ROT (deep-phase schedule): 0 = two-phase rounds (all U visits, then all U gathers back to back); 1 / 2 = rotating pipeline
+    // of U chains -- the gather of tree u's next record is issued right after ITS visit (1: visit by visit, 2: two visits at a
+    // time, their LDS reads overlapping) and flies while the other trees are visited.  All gathers are UNCONDITIONAL (a finished
+    // walker re-reads record 0: one shared line) and in a fixed order, so that hipcc counts them: a visit waits with
+    // vmcnt(U - P) instead of draining the queue.  They go through a buffer resource: 32-bit byte offsets, no 64-bit address
+    // arithmetic, and hipcc cannot turn "select between two words of a loaded record" into a second, dependent load.
+    constexpr int P = ROT == 2 ? 2 : 1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(deep), 0, (int)x.deep_bytes, 0x00020000);
     if constexpr (B2) {
       // ---- deep phase over two-level blocks (32 bytes: {t0, t1, t2, meta} + the four grand-children's leaf values) ----
       constexpr uint32_t ROW = (uint32_t)THREADS * 4u, FEAT_OFF = ((uint32_t)STEPB + ROW - 1u) / ROW * ROW;
       constexpr uint32_t RSH = (uint32_t)__builtin_ctz(ROW);
       const uint32_t lane_base = FEAT_OFF + (uint32_t)tid * 4u;
-      // the blocks are gathered through a buffer resource (32-bit byte offsets, no 64-bit address arithmetic; and hipcc cannot
-      // turn "select between two words of a loaded block" into a second, dependent load of the selected word, which it does
-      // with plain pointer loads)
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(deep), 0, (int)x.deep_bytes, 0x00020000);
       bool act[U], inl[U];   // still walking / the leaf came inline out of the level K-1 record
-      uint32_t B[U], la[U];  // byte offset of the walker's block / of its leaf value (16 = v0 of the dummy block: +0)
+      uint32_t B[U], la[U];  // byte offset of the walker's block / of its leaf value - 16 (0 = the dummy block's v0: +0)
+      u32x4 blk[U];
       // level K-1: the 16-byte records out of LDS (classic format; a child is a leaf value or a block index)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -116,78 +121,122 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
         leafv[u] = __uint_as_float(nxt);
         act[u] = !leaf;
         B[u] = leaf ? 0u : (nxt << 5);
-        la[u] = 16u;
+        la[u] = 0u;
+        if (ROT) blk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, B[u], 0, 0);
       }
-      for (;;) {
+      for (;;) {  // one round = one block visit per tree
         bool any = false;
 #pragma unroll
         for (int u = 0; u < U; ++u) any = any || act[u];
         if (__ballot(any) == 0ull) break;
-        // all block gathers of this round back to back, UNCONDITIONAL (a finished walker re-reads block 0) so that hipcc counts
-        // them: visit u then waits with vmcnt(U-1-u)
-        u32x4 blk[U];
+        if (!ROT) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) blk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, B[u], 0, 0);
+          for (int u = 0; u < U; ++u) blk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, B[u], 0, 0);
+        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint32_t meta = blk[u].w;
-          const uint32_t fa = lds_u32(((meta & 63u) << RSH) + lane_base);
-          const uint32_t c0 = b2_right<SLOW>(fa, blk[u].x, meta, 18u, miss_key) ? 1u : 0u;  // 0/1 arithmetic below: no branches
-          const uint32_t tc = c0 ? blk[u].z : blk[u].y;
-          const uint32_t fc = (meta >> (6u + 6u * c0)) & 63u;
-          const uint32_t fb = lds_u32((fc << RSH) + lane_base);
-          const uint32_t c1 = b2_right<SLOW>(fb, tc, meta, 19u + c0, miss_key) ? 1u : 0u;
-          const uint32_t j = 2u * c0 + c1;       // grand-child slot
-          const uint32_t bm = meta >> 21;        // [3:0] which grand-children are blocks, [10:4] rel
-          const bool isblk = ((bm >> j) & 1u) != 0u;
-          const uint32_t below = bm & ((1u << j) - 1u);  // j <= 3: only mask bits below slot j survive
-          const uint32_t nb = B[u] + (((bm >> 4) + (uint32_t)__popc(below)) << 5);
-          if (act[u] && !isblk) la[u] = B[u] + 16u + (j << 2);
-          act[u] = act[u] && isblk;
-          B[u] = act[u] ? nb : 0u;
+        for (int u0 = 0; u0 < U; u0 += P) {
+          // ROT: a block stays opaque until its own visit (or pieces of later visits are hoisted in front of the earlier gathers
+          // and the first wait of a round covers half the queue)
+#pragma unroll
+          for (int u = u0; u < u0 + P; ++u)
+            if (ROT) asm volatile("" : "+v"(blk[u].x), "+v"(blk[u].y), "+v"(blk[u].z), "+v"(blk[u].w));
+#pragma unroll
+          for (int u = u0; u < u0 + P; ++u) {
+            // all three features of the block are read at once (the children's speculatively: the LDS pipe idles in this phase, and
+            // the visit then has ONE LDS latency on its critical path); the second step is a select between two lane masks
+            const uint32_t meta = blk[u].w;
+            const uint32_t x0 = lds_u32(((meta & 63u) << RSH) + lane_base);
+            const uint32_t x1 = lds_u32((__builtin_amdgcn_ubfe(meta, 6u, 6u) << RSH) + lane_base);
+            const uint32_t x2 = lds_u32((__builtin_amdgcn_ubfe(meta, 12u, 6u) << RSH) + lane_base);
+            const bool c0 = b2_right<SLOW>(x0, blk[u].x, meta, 18u, miss_key);
+            const bool cl = b2_right<SLOW>(x1, blk[u].y, meta, 19u, miss_key);
+            const bool cr = b2_right<SLOW>(x2, blk[u].z, meta, 20u, miss_key);
+            const bool c1 = (c0 && cr) || (!c0 && cl);
+            const uint32_t j = (c0 ? 2u : 0u) + (c1 ? 1u : 0u);  // grand-child slot
+            const uint32_t bm = meta >> 21;                        // [3:0] which grand-children are blocks, [10:4] rel
+            const bool isblk = ((bm >> j) & 1u) != 0u;
+            const uint32_t below = __builtin_amdgcn_ubfe(bm, 0u, j);  // the mask bits below slot j (j = 0: none)
+            const uint32_t nb = B[u] + (((meta >> 25) + (uint32_t)__popc(below)) << 5);
+            if (act[u] && !isblk) la[u] = B[u] + (j << 2);
+            act[u] = act[u] && isblk;
+            B[u] = act[u] ? nb : 0u;
+          }
+          if (ROT) {
+#pragma unroll
+            for (int u = u0; u < u0 + P; ++u) blk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, B[u], 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // or the scheduler gathers the loads at the end of the round again
+          }
         }
       }
       float lv[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) lv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, la[u], 0, 0));
+      for (int u = 0; u < U; ++u) lv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, la[u], 16, 0));
 #pragma unroll
       for (int u = 0; u < U; ++u) leafv[u] = inl[u] ? leafv[u] : lv[u];
     } else {
-    // ---- deep phase: one 16-byte gather per visit; lanes whose tree has reached its leaf are masked off (the
-    //      vector-memory pipe takes one lane address per cycle: an idle lane must not cost one) ----
-    bool act[U];  // per lane: tree still walking (kept as lane masks in SGPRs, not as bits of a VGPR)
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      act[u] = true;
-      leafv[u] = 0.f;
-    }
-    for (;;) {
-      // phase A: one visit per tree on the records in registers (no memory access besides the LDS feature gather)
-      uint32_t nxt[U];
-      bool any = false;
+      // ---- deep phase: one 16-byte gather per visit; lanes whose tree has reached its leaf are masked off (the
+      //      vector-memory pipe takes one lane address per cycle: an idle lane must not cost one) ----
+      bool act[U];  // per lane: tree still walking (kept as lane masks in SGPRs, not as bits of a VGPR)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t f = sp_feature<Q>(r[u].y, lane_off);
-        const bool right = sp_right<SLOW, Q>(f, r[u].x, r[u].y, miss_key);
-        const uint32_t lw = right ? (r[u].y << 1) : r[u].y;  // kSpRightLeaf (bit 30) or kSpLeftLeaf (bit 31) into the sign bit
-        const bool leaf = (int32_t)lw < 0;
-        nxt[u] = right ? r[u].w : r[u].z;
-        if (act[u] && leaf) leafv[u] = __uint_as_float(nxt[u]);
-        act[u] = act[u] && !leaf;
-        any = any || act[u];
+        act[u] = true;
+        leafv[u] = 0.f;
       }
-      if (__ballot(any) == 0ull) break;
-      // phase B: all gathers of this round back to back, UNCONDITIONAL (a finished lane re-reads record 0: one shared
-      // line, no cost in the memory pipe) so that hipcc can count them: the next round then waits for record u with
-      // vmcnt(U-1-u) instead of draining everything before the first visit (with the loads under per-lane branches it
-      // emitted vmcnt(0) there).  32-bit byte offset from a uniform base (the host keeps the deep array below 2^28 records)
+      if constexpr (ROT != 0) {
+        u32x4 rr[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t off = act[u] ? (nxt[u] << 4) : 0u;
-        r[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(deep) + off);
+        for (int u = 0; u < U; ++u) rr[u] = u32x4{r[u].x, r[u].y, r[u].z, r[u].w};
+        for (;;) {
+          bool any = false;
+#pragma unroll
+          for (int u0 = 0; u0 < U; u0 += P) {
+#pragma unroll
+            for (int u = u0; u < u0 + P; ++u) asm volatile("" : "+v"(rr[u].x), "+v"(rr[u].y), "+v"(rr[u].z), "+v"(rr[u].w));
+            uint32_t off[P];
+#pragma unroll
+            for (int u = u0; u < u0 + P; ++u) {
+              const uint32_t f = sp_feature<Q>(rr[u].y, lane_off);
+              const bool right = sp_right<SLOW, Q>(f, rr[u].x, rr[u].y, miss_key);
+              const uint32_t lw = right ? (rr[u].y << 1) : rr[u].y;
+              const bool leaf = (int32_t)lw < 0;
+              const uint32_t nxt = right ? rr[u].w : rr[u].z;
+              if (act[u] && leaf) leafv[u] = __uint_as_float(nxt);
+              act[u] = act[u] && !leaf;
+              any = any || act[u];
+              off[u - u0] = act[u] ? (nxt << 4) : 0u;
+            }
+#pragma unroll
+            for (int u = u0; u < u0 + P; ++u) rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[u - u0], 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // or the scheduler gathers the loads at the end of the round again
+          }
+          if (__ballot(any) == 0ull) break;
+        }
+      } else {
+        for (;;) {
+          // phase A: one visit per tree on the records in registers (no memory access besides the LDS feature gather)
+          uint32_t nxt[U];
+          bool any = false;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t f = sp_feature<Q>(r[u].y, lane_off);
+            const bool right = sp_right<SLOW, Q>(f, r[u].x, r[u].y, miss_key);
+            const uint32_t lw = right ? (r[u].y << 1) : r[u].y;  // kSpRightLeaf (bit 30) or kSpLeftLeaf (bit 31) into the sign bit
+            const bool leaf = (int32_t)lw < 0;
+            nxt[u] = right ? r[u].w : r[u].z;
+            if (act[u] && leaf) leafv[u] = __uint_as_float(nxt[u]);
+            act[u] = act[u] && !leaf;
+            any = any || act[u];
+          }
+          if (__ballot(any) == 0ull) break;
+          // phase B: all gathers of this round back to back; the next round waits for record u with vmcnt(U-1-u) (with the loads
+          // under per-lane branches hipcc drained the queue before the first visit)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint32_t off = act[u] ? (nxt[u] << 4) : 0u;
+            r[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(deep) + off);
+          }
+        }
       }
-    }
-
     }
 
 #pragma unroll
@@ -205,7 +254,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
   }
 }
 
-template <int K, int U, int THREADS, bool Q, bool B2>
+template <int K, int U, int THREADS, bool Q, bool B2, int ROT>
 __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 12 << K;          // bytes of one tree's top image
   constexpr int STEPB = U * TOPB;  // top images resident per pass: U trees walked in lock-step = U independent load chains per lane
@@ -278,18 +327,18 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   ra.init();
   double dacc = 0.0;
   const uint32_t C = a.clusters;
-  if (!slow) sparse_walk<K, U, THREADS, false, Q, B2>(a, x, tid, ra, dacc);
-  else sparse_walk<K, U, THREADS, true, Q, B2>(a, x, tid, ra, dacc);
+  if (!slow) sparse_walk<K, U, THREADS, false, Q, B2, ROT>(a, x, tid, ra, dacc);
+  else sparse_walk<K, U, THREADS, true, Q, B2, ROT>(a, x, tid, ra, dacc);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
 }
 
-template <int K, int U, int THREADS, bool Q, bool B2>
+template <int K, int U, int THREADS, bool Q, bool B2, int ROT = 0>
 static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_kernel<K, U, THREADS, Q, B2>;
+  auto kern = score_sparse_kernel<K, U, THREADS, Q, B2, ROT>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
@@ -327,6 +376,12 @@ static const Variant g_sparse_variants[] = {
     // two-level blocks (at most 64 features: 256- and 512-tuple tiles cover every width that qualifies)
     DDT_SPB(6, 8, 256), DDT_SPB(7, 8, 256), DDT_SPB(8, 8, 256), DDT_SPB(9, 8, 256), DDT_SPB(10, 8, 256),
     DDT_SPB(6, 8, 512), DDT_SPB(7, 8, 512), DDT_SPB(8, 8, 512), DDT_SPB(9, 8, 512),
+    // EXPERIMENT: rotating pipeline (r1: gather u issued right after visit u; r2: two visits per step)
+#define DDT_SPX(NAME, K, T, Q, B2, ROT) Variant{NAME, kKindSparse, K, T, 1, 8, 8, 1, (Q ? 1 : 0) | (B2 ? 2 : 0), &launch_sparse_v<K, 8, T, Q, B2, ROT>}
+    DDT_SPX("sparse_r1_k8_u8_t512", 8, 512, false, false, 1), DDT_SPX("sparse_r2_k8_u8_t512", 8, 512, false, false, 2),
+    DDT_SPX("sparse_r1_k7_u8_t256", 7, 256, false, false, 1), DDT_SPX("sparse_r2_k7_u8_t256", 7, 256, false, false, 2),
+    DDT_SPX("sparse_b2r1_k8_u8_t512", 8, 512, false, true, 1), DDT_SPX("sparse_b2r2_k8_u8_t512", 8, 512, false, true, 2),
+    DDT_SPX("sparse_qr1_k8_u8_t1024", 8, 1024, true, false, 1), DDT_SPX("sparse_qr2_k8_u8_t1024", 8, 1024, true, false, 2),
 };
 
 int num_sparse_variants() { return (int)(sizeof(g_sparse_variants) / sizeof(g_sparse_variants[0])); }

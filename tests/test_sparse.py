@@ -207,7 +207,11 @@ def test_gpu_sparse_bit_exact_all_top_levels_and_orders(eng, shape):
                     assert blocks or not name.startswith("sparse_b2_"), (name, blocks, top)
                     assert not (ranked and top == -1 and F <= 64) or name.startswith("sparse_q_"), (name, ranked, top)
                     K = int(name.split("_k")[1].split("_")[0])
-                    assert name.startswith("sparse_b2_") == (not name.startswith("sparse_q_") and bool(blocks) and F <= 64 and K + 2 < md <= K + 8), (name, shape, top)
+                    T_ = int(name.rsplit("_t", 1)[1])  # two-level blocks exist for the 256- and 512-tuple tiles
+                    if name.startswith("sparse_b2_"):
+                        assert blocks and F <= 64 and K + 2 < md <= K + 8, (name, shape, top)
+                    elif not name.startswith("sparse_q_") and blocks and F <= 64 and K + 2 < md <= K + 8:
+                        assert T_ < 256, (name, shape, top)
                     assert np.array_equal(_bits(got), _bits(want)), (shape, cmp_mode, top, order, name)
         eng.set_option("sparse_b2", 1)
         eng.set_option("sparse_q16", 1)
