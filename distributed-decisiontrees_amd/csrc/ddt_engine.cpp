@@ -1428,14 +1428,13 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     }
     return DDT_OK;
   }
-  if (!strcmp(key, "sparse_top_levels") || !strcmp(key, "sparse_deep_order") || !strcmp(key, "sparse_q16") || !strcmp(key, "sparse_b2")) {
+  if (!strcmp(key, "sparse_top_levels") || !strcmp(key, "sparse_deep_order") || !strcmp(key, "sparse_q16")) {
     // sparse forests: K = levels staged in LDS (-1 = as many as fit), order of the deep records (0 level order,
-    // 1 depth-first per sub-tree), rank-quantised kernels (1 = when they fit, 0 = never), two-level blocks (1 = when the forest
-    // qualifies, 0 = never); a loaded sparse model is re-packed
-    const bool top = key[7] == 't', rq = key[7] == 'q', bb = key[7] == 'b';
+    // 1 depth-first per sub-tree), rank-quantised kernels (1 = when they fit, 0 = never); a loaded sparse model is re-packed
+    const bool top = key[7] == 't', rq = key[7] == 'q';
     if (top && value >= 0 && (value < kSparseMinTop || value > kSparseMaxTop)) return fail(e, DDT_EINVAL, "sparse_top_levels must be -1 or %d..%d", kSparseMinTop, kSparseMaxTop);
     if (!top && (value < 0 || value > 1)) return fail(e, DDT_EINVAL, "%s must be 0 or 1", key);
-    int& opt = top ? e->sparse_top_levels : rq ? e->sparse_q16 : bb ? e->sparse_b2 : e->sparse_deep_order;
+    int& opt = top ? e->sparse_top_levels : rq ? e->sparse_q16 : e->sparse_deep_order;
     const int previous = opt;
     opt = (int)value;
     if (e->loaded && e->sparse) {

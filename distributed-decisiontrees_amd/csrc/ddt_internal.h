@@ -87,16 +87,6 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
 //                 leaf flags sit in bits 31 / 30 so that each is ONE sign test (of w, of w << 1)
 //   left/right  = index into the deep array (< 2^28: the kernel addresses it with a 32-bit byte offset), or the leaf's
 //                 fp32 bits when the matching flag is set
-//   two-level blocks ("sparse_b2_*", Variant::opt bit 1; at most 64 tuple words, trees of at most K + 8 levels): the deep
-//               array holds one 32-byte BLOCK per internal node at depth K, K+2, K+4, ... of a sub-tree hanging below
-//               level K-1 (whose records then carry block indices): {t0, t1, t2, meta, v0, v1, v2, v3} = the keys of the node
-//               and of its left / right child, and the leaf values of the four grand-children (slot 2*first + second step).
-//               meta: [5:0] [11:6] [17:12] feature index of node / left / right child, [18] [19] [20] their miss_right
-//               bits, [24:21] which grand-children are blocks, [31:25] rel = distance in blocks to the first of them; the
-//               block children of a block are adjacent (breadth-first order per sub-tree), grand-child j is block
-//               b + rel + popcount(mask below j).  A child that is a leaf is a dummy node (key 0, feature 0) over two
-//               copies of its value.  A walker needs ONE 16-byte gather per two levels and one 4-byte gather (byte
-//               32 b + 16 + 4 j) for its leaf; block 0 is an all-zero dummy.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kSpLeftLeaf = 0x80000000u, kSpRightLeaf = 0x40000000u, kSpMissRight = 0x20000000u, kSpAddrMask = 0x1FFFFFFFu;
 constexpr int kSparseMinTop = 6, kSparseMaxTop = 10;
@@ -104,7 +94,7 @@ constexpr int kSparseMinTop = 6, kSparseMaxTop = 10;
 struct SparseAux {           // ScoreArgs::aux of the sparse kernels
   const uint4* deep;         // deep records (at least one, record 0 is a valid dummy)
   uint32_t n_groups;         // PU groups of 8 trees in the top image
-  uint32_t deep_bytes;       // bytes of the deep array (two-level blocks: the range of the buffer resource they are gathered through)
+  uint32_t deep_bytes;       // bytes of the deep array: the range of the buffer resource its records are gathered through
   // rank-quantised sparse kernels ("sparse_q_*", Variant::opt bit 0): thresholds are ranks, the features arrive as the u16 tiles
   // of the q16 pre-pass (the same tables / workspace / kernels as the perfect-tree q16 path); slow images = the same images
   Q16Aux q16;
@@ -163,7 +153,6 @@ struct Variant {
   // ---- sparse kernels (levels = K, the top levels staged in LDS): LDS = [top image of one PU group][feature tile] ----
   // opt bit 0 ("sparse_q_*"): rank-quantised -- u16 feature tile (half the LDS per tuple: 1024 tuples = 16 waves share a CU
   // where the fp32 tile holds 512), node thresholds are ranks
-  // opt bit 1 ("sparse_b2_*"): two-level blocks below level K-1 (above: "Sparse forests")
   uint32_t top_bytes_sparse() const { return 12u << levels; }
   uint32_t row_bytes_sparse() const { return (opt & 1) ? tile() * 2u : tile() * 4u; }
   uint32_t feat_off_sparse() const {  // chunk_trees = trees walked in lock-step = top images resident per pass

@@ -13,12 +13,10 @@
 //          single buffer: the DMA of group g+1 is issued right after the last LDS read of group g and overlaps the
 //          deep phase of group g)
 //   deep   16-byte records {thr, w, left, right} gathered from L2 / HBM: child pointers or leaf values are IN the
-//          parent's record, so a visit is ONE 16-byte load and the leaf needs no extra access.  Lanes that reached a
-//          leaf idle until the wave's deepest lane is done (__ballot early exit, per tree and per wave).
-//   deep2  ("sparse_b2_*", Variant::opt bit 1) the same sub-trees as TWO-LEVEL BLOCKS of 32 bytes {t0, t1, t2, meta, v0..v3}: a node,
-//          its two children and where the four grand-children are (ddt_internal.h).  One 16-byte gather advances a walker TWO
-//          levels, and one 4-byte gather at the end fetches its leaf: 4 + 1 dependent rounds where `deep` needs 8 (the deep phase
-//          is bound by the number of gather wave-instructions and by their latency chain, not by bytes).
+//          parent's record, so a visit is ONE 16-byte load and the leaf needs no extra access.  The 8 walks of a lane form a
+//          ROTATING pipeline: the gather of tree u's next record is issued right after ITS visit and flies while the other
+//          seven trees are visited.  Lanes that reached a leaf idle until the wave's deepest lane is done (__ballot early
+//          exit, per wave).
 // No MFMA: compare + gather.  Bound by the vector-memory gather rate of the deep phase.
 #include <hip/hip_runtime.h>
 
@@ -49,16 +47,7 @@ __device__ __forceinline__ uint32_t sp_feature(uint32_t w, uint32_t lane_off) {
 
 // The walk of all PU groups for one tile.  SLOW = the tile holds a missing value: apply the per-node missing rule
 // (block-uniform choice, like the perfect-tree kernels).
-// Compare rule inside a two-level block: the missing direction is bit `mr_bit` of the block's meta word.
-template <bool SLOW>
-__device__ __forceinline__ bool b2_right(uint32_t f, uint32_t thr, uint32_t meta, uint32_t mr_bit, uint32_t miss_key) {
-  const bool ge = (int32_t)f >= (int32_t)thr;
-  if (!SLOW) return ge;
-  const bool miss = f == miss_key, mr = ((meta >> mr_bit) & 1u) != 0u;
-  return (miss && mr) || (!miss && ge);
-}
-
-template <int K, int U, int THREADS, bool SLOW, bool Q, bool B2, int ROT>
+template <int K, int U, int THREADS, bool SLOW, bool Q>
 __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
   constexpr int TOPB = 12 << K;
   constexpr int STEPB = U * TOPB;  // U trees per pass: one PU group (or two)
@@ -92,151 +81,42 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
     __syncthreads();  // every wave holds its level K-1 records: the top image buffer is free
     if (g + 1 < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
 
-    float leafv[U];
-    // ROT (deep-phase schedule): 0 = two-phase rounds (all U visits, then all U gathers back to back); 1 / 2 = rotating pipeline
-    // of U chains -- the gather of tree u's next record is issued right after ITS visit (1: visit by visit, 2: two visits at a
-    // time, their LDS reads overlapping) and flies while the other trees are visited.  All gathers are UNCONDITIONAL (a finished
-    // walker re-reads record 0: one shared line) and in a fixed order, so that hipcc counts them: a visit waits with
-    // vmcnt(U - P) instead of draining the queue.  They go through a buffer resource: 32-bit byte offsets, no 64-bit address
-    // arithmetic, and hipcc cannot turn "select between two words of a loaded record" into a second, dependent load.
-    constexpr int P = ROT == 2 ? 2 : 1;
+    // ---- deep phase: one 16-byte gather per visit; lanes whose tree has reached its leaf are masked off.  A rotating pipeline of U
+    //      chains: the gather of tree u's next record is issued right after ITS visit, in a fixed order and UNCONDITIONALLY (a
+    //      finished lane re-reads record 0: one shared line), so that hipcc counts the loads and every visit waits with vmcnt(U-1)
+    //      for the oldest one only.  (Round 2's form -- all U visits, then all U gathers back to back -- left the queue empty
+    //      during the visits: 212 vs 237 Mtuples/s on BASELINE config 4, profiles/r03_sparse_schedules_and_blocks.json.)
+    //      The gathers go through a buffer resource: 32-bit byte offsets (the host keeps the deep array below 2^28 records), no
+    //      64-bit address arithmetic on the VALU.
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(deep), 0, (int)x.deep_bytes, 0x00020000);
-    if constexpr (B2) {
-      // ---- deep phase over two-level blocks (32 bytes: {t0, t1, t2, meta} + the four grand-children's leaf values) ----
-      constexpr uint32_t ROW = (uint32_t)THREADS * 4u, FEAT_OFF = ((uint32_t)STEPB + ROW - 1u) / ROW * ROW;
-      constexpr uint32_t RSH = (uint32_t)__builtin_ctz(ROW);
-      const uint32_t lane_base = FEAT_OFF + (uint32_t)tid * 4u;
-      bool act[U], inl[U];   // still walking / the leaf came inline out of the level K-1 record
-      uint32_t B[U], la[U];  // byte offset of the walker's block / of its leaf value - 16 (0 = the dummy block's v0: +0)
-      u32x4 blk[U];
-      // level K-1: the 16-byte records out of LDS (classic format; a child is a leaf value or a block index)
+    bool act[U];  // per lane: tree still walking (kept as lane masks in SGPRs, not as bits of a VGPR)
+    float leafv[U];
+    u32x4 rr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      act[u] = true;
+      leafv[u] = 0.f;
+      rr[u] = u32x4{r[u].x, r[u].y, r[u].z, r[u].w};
+    }
+    for (;;) {
+      bool any = false;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t f = sp_feature<Q>(r[u].y, lane_off);
-        const bool right = sp_right<SLOW, Q>(f, r[u].x, r[u].y, miss_key);
-        const uint32_t lw = right ? (r[u].y << 1) : r[u].y;
+        // the record stays opaque until its own visit: otherwise pieces of later visits are hoisted in front of the earlier gathers
+        // and the first wait of a round covers half the queue
+        asm volatile("" : "+v"(rr[u].x), "+v"(rr[u].y), "+v"(rr[u].z), "+v"(rr[u].w));
+        const uint32_t f = sp_feature<Q>(rr[u].y, lane_off);
+        const bool right = sp_right<SLOW, Q>(f, rr[u].x, rr[u].y, miss_key);
+        const uint32_t lw = right ? (rr[u].y << 1) : rr[u].y;  // kSpRightLeaf (bit 30) or kSpLeftLeaf (bit 31) into the sign bit
         const bool leaf = (int32_t)lw < 0;
-        const uint32_t nxt = right ? r[u].w : r[u].z;
-        inl[u] = leaf;
-        leafv[u] = __uint_as_float(nxt);
-        act[u] = !leaf;
-        B[u] = leaf ? 0u : (nxt << 5);
-        la[u] = 0u;
-        if (ROT) blk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, B[u], 0, 0);
+        const uint32_t nxt = right ? rr[u].w : rr[u].z;
+        if (act[u] && leaf) leafv[u] = __uint_as_float(nxt);
+        act[u] = act[u] && !leaf;
+        any = any || act[u];
+        rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, act[u] ? (nxt << 4) : 0u, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // or the scheduler collects the loads at the end of the round again
       }
-      for (;;) {  // one round = one block visit per tree
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < U; ++u) any = any || act[u];
-        if (__ballot(any) == 0ull) break;
-        if (!ROT) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) blk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, B[u], 0, 0);
-        }
-#pragma unroll
-        for (int u0 = 0; u0 < U; u0 += P) {
-          // ROT: a block stays opaque until its own visit (or pieces of later visits are hoisted in front of the earlier gathers
-          // and the first wait of a round covers half the queue)
-#pragma unroll
-          for (int u = u0; u < u0 + P; ++u)
-            if (ROT) asm volatile("" : "+v"(blk[u].x), "+v"(blk[u].y), "+v"(blk[u].z), "+v"(blk[u].w));
-#pragma unroll
-          for (int u = u0; u < u0 + P; ++u) {
-            // all three features of the block are read at once (the children's speculatively: the LDS pipe idles in this phase, and
-            // the visit then has ONE LDS latency on its critical path); the second step is a select between two lane masks
-            const uint32_t meta = blk[u].w;
-            const uint32_t x0 = lds_u32(((meta & 63u) << RSH) + lane_base);
-            const uint32_t x1 = lds_u32((__builtin_amdgcn_ubfe(meta, 6u, 6u) << RSH) + lane_base);
-            const uint32_t x2 = lds_u32((__builtin_amdgcn_ubfe(meta, 12u, 6u) << RSH) + lane_base);
-            const bool c0 = b2_right<SLOW>(x0, blk[u].x, meta, 18u, miss_key);
-            const bool cl = b2_right<SLOW>(x1, blk[u].y, meta, 19u, miss_key);
-            const bool cr = b2_right<SLOW>(x2, blk[u].z, meta, 20u, miss_key);
-            const bool c1 = (c0 && cr) || (!c0 && cl);
-            const uint32_t j = (c0 ? 2u : 0u) + (c1 ? 1u : 0u);  // grand-child slot
-            const uint32_t bm = meta >> 21;                        // [3:0] which grand-children are blocks, [10:4] rel
-            const bool isblk = ((bm >> j) & 1u) != 0u;
-            const uint32_t below = __builtin_amdgcn_ubfe(bm, 0u, j);  // the mask bits below slot j (j = 0: none)
-            const uint32_t nb = B[u] + (((meta >> 25) + (uint32_t)__popc(below)) << 5);
-            if (act[u] && !isblk) la[u] = B[u] + (j << 2);
-            act[u] = act[u] && isblk;
-            B[u] = act[u] ? nb : 0u;
-          }
-          if (ROT) {
-#pragma unroll
-            for (int u = u0; u < u0 + P; ++u) blk[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, B[u], 0, 0);
-            __builtin_amdgcn_sched_barrier(0);  // or the scheduler gathers the loads at the end of the round again
-          }
-        }
-      }
-      float lv[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) lv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, la[u], 16, 0));
-#pragma unroll
-      for (int u = 0; u < U; ++u) leafv[u] = inl[u] ? leafv[u] : lv[u];
-    } else {
-      // ---- deep phase: one 16-byte gather per visit; lanes whose tree has reached its leaf are masked off (the
-      //      vector-memory pipe takes one lane address per cycle: an idle lane must not cost one) ----
-      bool act[U];  // per lane: tree still walking (kept as lane masks in SGPRs, not as bits of a VGPR)
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        act[u] = true;
-        leafv[u] = 0.f;
-      }
-      if constexpr (ROT != 0) {
-        u32x4 rr[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) rr[u] = u32x4{r[u].x, r[u].y, r[u].z, r[u].w};
-        for (;;) {
-          bool any = false;
-#pragma unroll
-          for (int u0 = 0; u0 < U; u0 += P) {
-#pragma unroll
-            for (int u = u0; u < u0 + P; ++u) asm volatile("" : "+v"(rr[u].x), "+v"(rr[u].y), "+v"(rr[u].z), "+v"(rr[u].w));
-            uint32_t off[P];
-#pragma unroll
-            for (int u = u0; u < u0 + P; ++u) {
-              const uint32_t f = sp_feature<Q>(rr[u].y, lane_off);
-              const bool right = sp_right<SLOW, Q>(f, rr[u].x, rr[u].y, miss_key);
-              const uint32_t lw = right ? (rr[u].y << 1) : rr[u].y;
-              const bool leaf = (int32_t)lw < 0;
-              const uint32_t nxt = right ? rr[u].w : rr[u].z;
-              if (act[u] && leaf) leafv[u] = __uint_as_float(nxt);
-              act[u] = act[u] && !leaf;
-              any = any || act[u];
-              off[u - u0] = act[u] ? (nxt << 4) : 0u;
-            }
-#pragma unroll
-            for (int u = u0; u < u0 + P; ++u) rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[u - u0], 0, 0);
-            __builtin_amdgcn_sched_barrier(0);  // or the scheduler gathers the loads at the end of the round again
-          }
-          if (__ballot(any) == 0ull) break;
-        }
-      } else {
-        for (;;) {
-          // phase A: one visit per tree on the records in registers (no memory access besides the LDS feature gather)
-          uint32_t nxt[U];
-          bool any = false;
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const uint32_t f = sp_feature<Q>(r[u].y, lane_off);
-            const bool right = sp_right<SLOW, Q>(f, r[u].x, r[u].y, miss_key);
-            const uint32_t lw = right ? (r[u].y << 1) : r[u].y;  // kSpRightLeaf (bit 30) or kSpLeftLeaf (bit 31) into the sign bit
-            const bool leaf = (int32_t)lw < 0;
-            nxt[u] = right ? r[u].w : r[u].z;
-            if (act[u] && leaf) leafv[u] = __uint_as_float(nxt[u]);
-            act[u] = act[u] && !leaf;
-            any = any || act[u];
-          }
-          if (__ballot(any) == 0ull) break;
-          // phase B: all gathers of this round back to back; the next round waits for record u with vmcnt(U-1-u) (with the loads
-          // under per-lane branches hipcc drained the queue before the first visit)
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const uint32_t off = act[u] ? (nxt[u] << 4) : 0u;
-            r[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(deep) + off);
-          }
-        }
-      }
+      if (__ballot(any) == 0ull) break;
     }
 
 #pragma unroll
@@ -254,7 +134,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
   }
 }
 
-template <int K, int U, int THREADS, bool Q, bool B2, int ROT>
+template <int K, int U, int THREADS, bool Q>
 __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 12 << K;          // bytes of one tree's top image
   constexpr int STEPB = U * TOPB;  // top images resident per pass: U trees walked in lock-step = U independent load chains per lane
@@ -263,7 +143,6 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   static_assert(U == 8 || U == 16, "one or two PU groups per pass");
   static_assert((STEPB / 16) % 64 == 0, "whole waves per DMA");
   static_assert(!Q || THREADS == 1024, "the rank pre-pass writes tiles of 1024 tuples");
-  static_assert(!(Q && B2), "two-level blocks hold fp32 threshold keys");
   const int tid = threadIdx.x;
   const uint64_t tile0 = (uint64_t)blockIdx.x * THREADS;
   const uint32_t W = a.tuple_words, lpt = W / 4u;
@@ -327,18 +206,18 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   ra.init();
   double dacc = 0.0;
   const uint32_t C = a.clusters;
-  if (!slow) sparse_walk<K, U, THREADS, false, Q, B2, ROT>(a, x, tid, ra, dacc);
-  else sparse_walk<K, U, THREADS, true, Q, B2, ROT>(a, x, tid, ra, dacc);
+  if (!slow) sparse_walk<K, U, THREADS, false, Q>(a, x, tid, ra, dacc);
+  else sparse_walk<K, U, THREADS, true, Q>(a, x, tid, ra, dacc);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
 }
 
-template <int K, int U, int THREADS, bool Q, bool B2, int ROT = 0>
+template <int K, int U, int THREADS, bool Q>
 static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_kernel<K, U, THREADS, Q, B2, ROT>;
+  auto kern = score_sparse_kernel<K, U, THREADS, Q>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
@@ -354,11 +233,9 @@ static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStrea
 }
 
 #define DDT_SP(K, U, T) \
-  Variant { "sparse_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 0, &launch_sparse_v<K, U, T, false, false> }
-#define DDT_SPB(K, U, T) /* two-level blocks below level K-1 (opt bit 1): F <= 64, trees of at most K + 8 levels */ \
-  Variant { "sparse_b2_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2, &launch_sparse_v<K, U, T, false, true> }
+  Variant { "sparse_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 0, &launch_sparse_v<K, U, T, false> }
 #define DDT_SPQ(K, U) /* rank-quantised: u16 feature tile of 1024 tuples = 16 waves per CU */ \
-  Variant { "sparse_q_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 1, &launch_sparse_v<K, U, 1024, true, false> }
+  Variant { "sparse_q_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 1, &launch_sparse_v<K, U, 1024, true> }
 
 // `levels` = K (top levels staged in LDS), `chunk_trees` = trees walked in lock-step, `threads` = tuples per tile
 static const Variant g_sparse_variants[] = {
@@ -373,15 +250,6 @@ static const Variant g_sparse_variants[] = {
     // narrower tiles for wide tuples (the feature tile is 4 * W bytes per tuple)
     DDT_SP(6, 8, 128), DDT_SP(7, 8, 128), DDT_SP(8, 8, 128), DDT_SP(9, 8, 128), DDT_SP(10, 8, 128),
     DDT_SP(8, 8, 64), DDT_SP(9, 8, 64), DDT_SP(10, 8, 64),
-    // two-level blocks (at most 64 features: 256- and 512-tuple tiles cover every width that qualifies)
-    DDT_SPB(6, 8, 256), DDT_SPB(7, 8, 256), DDT_SPB(8, 8, 256), DDT_SPB(9, 8, 256), DDT_SPB(10, 8, 256),
-    DDT_SPB(6, 8, 512), DDT_SPB(7, 8, 512), DDT_SPB(8, 8, 512), DDT_SPB(9, 8, 512),
-    // EXPERIMENT: rotating pipeline (r1: gather u issued right after visit u; r2: two visits per step)
-#define DDT_SPX(NAME, K, T, Q, B2, ROT) Variant{NAME, kKindSparse, K, T, 1, 8, 8, 1, (Q ? 1 : 0) | (B2 ? 2 : 0), &launch_sparse_v<K, 8, T, Q, B2, ROT>}
-    DDT_SPX("sparse_r1_k8_u8_t512", 8, 512, false, false, 1), DDT_SPX("sparse_r2_k8_u8_t512", 8, 512, false, false, 2),
-    DDT_SPX("sparse_r1_k7_u8_t256", 7, 256, false, false, 1), DDT_SPX("sparse_r2_k7_u8_t256", 7, 256, false, false, 2),
-    DDT_SPX("sparse_b2r1_k8_u8_t512", 8, 512, false, true, 1), DDT_SPX("sparse_b2r2_k8_u8_t512", 8, 512, false, true, 2),
-    DDT_SPX("sparse_qr1_k8_u8_t1024", 8, 1024, true, false, 1), DDT_SPX("sparse_qr2_k8_u8_t1024", 8, 1024, true, false, 2),
 };
 
 int num_sparse_variants() { return (int)(sizeof(g_sparse_variants) / sizeof(g_sparse_variants[0])); }

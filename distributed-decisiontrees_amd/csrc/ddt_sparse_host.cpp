@@ -30,8 +30,6 @@ int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {
   const uint32_t W = tuple_words(e->p);
   auto fits = [&](int vid, uint32_t budget) {
     if (vid < 0 || variant(vid).kind != kKindSparse || variant(vid).lds_bytes_sparse(W) > budget) return false;
-    // two-level blocks: 6-bit feature fields, and sub-trees of at most 8 levels below the top K keep the 7-bit block distance
-    if ((variant(vid).opt & 2) && (W > 64u || max_depth > (uint32_t)variant(vid).levels + 8u)) return false;
     return !(variant(vid).opt & 1) || ranks_fit;  // rank-quantised kernels: every feature's table must fit 16-bit ranks
   };
   if (e->forced_variant >= 0) return fits(e->forced_variant, kMaxLdsBytes) ? e->forced_variant : -1;
@@ -47,17 +45,12 @@ int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {
       if (fits(vid, kMaxLdsBytes)) return vid;
     }
   }
-  // Two-level blocks (option "sparse_b2", default on) wherever the forest goes more than two levels below the staged top: the deep
-  // phase is bound by gather wave-instructions and their dependent latency, and a block advances a walker two levels per gather.
-  const auto blocks_pay = [&](int K) { return e->sparse_b2 && max_depth > (uint32_t)K + 2u; };
   if (e->sparse_top_levels >= 0) {
-    for (int b = 1; b >= 0; --b)
-      for (int T : {256, 128, 64}) {
-        if (b && !blocks_pay(e->sparse_top_levels)) continue;
-        snprintf(name, sizeof(name), b ? "sparse_b2_k%d_u8_t%d" : "sparse_k%d_u8_t%d", e->sparse_top_levels, T);
-        const int vid = find_variant(name);
-        if (fits(vid, kMaxLdsBytes)) return vid;
-      }
+    for (int T : {256, 128, 64}) {
+      snprintf(name, sizeof(name), "sparse_k%d_u8_t%d", e->sparse_top_levels, T);
+      const int vid = find_variant(name);
+      if (fits(vid, kMaxLdsBytes)) return vid;
+    }
     return -1;
   }
   // deepest K worth staging: nothing is left for the deep phase beyond the deepest tree
@@ -71,12 +64,8 @@ int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {
     const uint32_t waves = (uint32_t)g.T / 64u * g.blocks;
     if (best >= 0 && waves < best_waves) break;  // only fall to fewer waves when nothing fitted with more
     for (int K = kcap; K >= kSparseMinTop; --K) {
-      snprintf(name, sizeof(name), "sparse_b2_k%d_u8_t%d", K, g.T);
-      int vid = blocks_pay(K) ? find_variant(name) : -1;
-      if (!fits(vid, kMaxLdsBytes / g.blocks)) {
-        snprintf(name, sizeof(name), "sparse_k%d_u8_t%d", K, g.T);
-        vid = find_variant(name);
-      }
+      snprintf(name, sizeof(name), "sparse_k%d_u8_t%d", K, g.T);
+      const int vid = find_variant(name);
       if (!fits(vid, kMaxLdsBytes / g.blocks)) continue;
       if (K > best_k) {
         best = vid;
@@ -182,14 +171,8 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
     rec[2] = l;
     rec[3] = r;
   };
-  const bool b2 = (v.opt & 2) != 0;  // two-level blocks below level K-1 (ddt_internal.h)
-  if (b2 && (rt || tuple_words(e->p) > 64u)) return fail(e, DDT_EUNSUPPORTED, "two-level blocks: fp32 keys, at most 64 tuple words");
-  if (b2) {
-    deep.assign(8u, 0u);  // block 0: a valid dummy (no grand-child is a block, every leaf value +0)
-  } else {
-    deep.assign(4u, 0u);  // record 0: a valid dummy (finished lanes keep re-reading it)
-    put16(deep.data(), 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
-  }
+  deep.assign(4u, 0u);  // record 0: a valid dummy (finished lanes keep re-reading it)
+  put16(deep.data(), 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
 
   std::vector<Cursor> cur, nxt;
   std::vector<std::pair<uint32_t, uint32_t*>> pending;  // (tree node at depth K, slot of the parent's child word to patch)
@@ -252,47 +235,6 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
       }
       rec[0] = node_key(n);
       rec[1] = w;
-    }
-    if (b2) {
-      // ---- two-level blocks: each sub-tree hanging below level K-1 on its own, its blocks in breadth-first order, so the block
-      //      children of a block are adjacent and at most `rel` <= 127 blocks away (<= 79 for sub-trees of <= 8 levels) ----
-      const auto fidx = [&](uint32_t n) { return L[4u * n + 1u] & 0x7FFu; };
-      const auto missr = [&](uint32_t n) { return (L[4u * n + 1u] >> 13) & 1u; };
-      for (auto& pe : pending) {
-        const size_t base = deep.size() / 8u;
-        order.assign(1, pe.first);
-        for (size_t q = 0; q < order.size(); ++q) {
-          const uint32_t n = order[q];
-          uint32_t blk[8] = {node_key(n), 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-          uint32_t meta = fidx(n) | (missr(n) << 18), mask = 0u;
-          const size_t first_child = order.size();
-          for (uint32_t side = 0; side < 2; ++side) {
-            const Cursor c = child(n, side);
-            if (c.leaf) {  // a dummy node whose two children are this leaf (key 0 on feature 0: either outcome is right)
-              blk[4u + 2u * side] = blk[5u + 2u * side] = c.v;
-              continue;
-            }
-            blk[1u + side] = node_key(c.v);
-            meta |= (fidx(c.v) << (6u + 6u * side)) | (missr(c.v) << (19u + side));
-            for (uint32_t s2 = 0; s2 < 2; ++s2) {
-              const Cursor g = child(c.v, s2);
-              if (g.leaf) {
-                blk[4u + 2u * side + s2] = g.v;
-              } else {
-                mask |= 1u << (2u * side + s2);
-                order.push_back(g.v);
-              }
-            }
-          }
-          const size_t rel = mask ? first_child - q : 0u;
-          if (rel > 127u) return fail(e, DDT_EUNSUPPORTED, "two-level blocks: a sub-tree below level %u is too large (block distance %zu > 127)", K - 1u, rel);
-          blk[3] = meta | (mask << 21) | ((uint32_t)rel << 25);
-          deep.insert(deep.end(), blk, blk + 8);
-        }
-        if (deep.size() / 8u >= (1ull << 27)) return fail(e, DDT_EUNSUPPORTED, "more than 2^27 two-level blocks (4 GiB of 32-byte blocks)");
-        *pe.second = (uint32_t)base;
-      }
-      continue;
     }
     // ---- deep records of this tree: the sub-trees hanging below level K-1 ----
     // order 0: all of them level by level (breadth-first over the whole remainder of the tree);

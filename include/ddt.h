@@ -302,9 +302,7 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * forest staged in LDS), "sparse_deep_order" (0 = level order, default; 1 = depth-first per sub-tree), "sparse_q16" (1 =
  * default: sparse forests whose distinct thresholds per feature fit 16-bit ranks -- at most 32767, e.g. histogram-trained
  * models -- and whose tuples have at most 64..76 words run on the rank-quantised sparse kernels: u16 feature tile, 1024
- * tuples per block; 0 = always the fp32-tile kernels), "sparse_b2" (1 = default: forests of at most 64 features that go 3..8
- * levels below the staged top are packed as two-level blocks -- one gather per two levels of the walk; 0 = always one record
- * per node).  A refused sparse_* value keeps the previous one and the loaded model. */
+ * tuples per block; 0 = always the fp32-tile kernels).  A refused sparse_* value keeps the previous one and the loaded model. */
 int ddt_set_option(ddt_engine* e, const char* key, int64_t value);
 int ddt_num_variants(void);
 int ddt_variant_name(int variant, char* buf, size_t buflen);
@@ -371,8 +369,7 @@ int ddt_debug_model_image(const ddt_params* p, const void* weights_lines, size_t
 /*    the device images of a sparse forest as sparse kernel variant `variant_id` wants them: the whole
  *    stream is validated like ddt_load_model_sparse does, then packed -- top heap images per PU group and the deep record
  *    array.  info_out = {top words, deep words, PU groups, top levels K, LDS byte offset of feature row 0, bytes per
- *    feature row}; top_out / deep_out may be NULL to size them ("sparse_b2_*" variants: the deep words are 8-word two-level
- *    blocks; a forest they cannot hold is DDT_EUNSUPPORTED).  tests/test_sparse_host.py walks the images in numpy. */
+ *    feature row}; top_out / deep_out may be NULL to size them.  tests/test_sparse_host.py walks the images in numpy. */
 int ddt_debug_sparse_image(const ddt_params* p, const void* node_lines, size_t n_lines, const uint64_t* tree_first_line,
                            int variant_id, int deep_order, uint32_t* top_out, size_t top_cap_words, uint32_t* deep_out,
                            size_t deep_cap_words, uint64_t info_out[6]);

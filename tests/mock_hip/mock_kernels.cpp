@@ -157,7 +157,6 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
   const Variant v = var;
   const SparseAux x = *reinterpret_cast<const SparseAux*>(args.aux);
   const bool ranked = (v.opt & 1) != 0;  // "sparse_q_*": thresholds are ranks, features come from the pre-pass's workspace
-  const bool blocks = (v.opt & 2) != 0;  // "sparse_b2_*"
   if (ranked && !x.q16.skip_prepass) enqueue_prepass(a, x.q16, s);
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   Op* op = new Op();
@@ -185,26 +184,6 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
           const uint32_t r = right(rec[0], rec[1]), nxt = rec[2 + r];
           if (rec[1] & (r ? kSpRightLeaf : kSpLeftLeaf)) {
             leaf[slot] = f_of(nxt);
-            break;
-          }
-          if (blocks) {  // "sparse_b2_*": 32-byte two-level blocks below level K-1 (csrc/ddt_internal.h)
-            uint32_t b = nxt;
-            for (;; ++guard) {
-              const uint32_t* k = deep + (size_t)b * 8u;
-              const uint32_t meta = k[3];
-              auto step = [&](uint32_t key, uint32_t f, uint32_t mr) -> uint32_t {
-                const uint32_t raw = t[f], xk = a.ieee ? ieee_key(raw) : raw;
-                return raw == a.miss_raw ? mr : (uint32_t)!((int32_t)xk < (int32_t)key);
-              };
-              const uint32_t c0 = step(k[0], meta & 63u, (meta >> 18) & 1u);
-              const uint32_t c1 = step(k[1u + c0], (meta >> (6u + 6u * c0)) & 63u, (meta >> (19u + c0)) & 1u);
-              const uint32_t j = 2u * c0 + c1, mask = (meta >> 21) & 15u;
-              if (!((mask >> j) & 1u) || guard >= 100) {
-                leaf[slot] = f_of(k[4u + j]);
-                break;
-              }
-              b += (meta >> 25) + (uint32_t)__builtin_popcount(mask & ((1u << j) - 1u));
-            }
             break;
           }
           rec = deep + (size_t)nxt * 4u;
@@ -239,8 +218,6 @@ const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
     Variant{"sparse_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 0, &launch_sparse},
     Variant{"sparse_k8_u8_t512", kKindSparse, 8, 512, 1, 8, 8, 1, 0, &launch_sparse},
     Variant{"sparse_k9_u8_t128", kKindSparse, 9, 128, 1, 8, 8, 1, 0, &launch_sparse},
-    Variant{"sparse_b2_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 2, &launch_sparse},
-    Variant{"sparse_b2_k8_u8_t512", kKindSparse, 8, 512, 1, 8, 8, 1, 2, &launch_sparse},
 };
 constexpr int kMockDense = (int)(sizeof(g_mock_variants) / sizeof(g_mock_variants[0]));
 }  // namespace

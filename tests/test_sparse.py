@@ -153,20 +153,6 @@ def eng():
     e.close()
 
 
-def _max_depth(s):
-    """levels of internal nodes of the deepest tree (what the loader measures to choose a kernel)"""
-    nl, first, best = np.asarray(s.node_lines).view(np.uint32).reshape(-1, 4), np.asarray(s.first), 0
-    for i in range(len(first) - 1):
-        t = nl[int(first[i]):int(first[i + 1])]
-        depth = np.zeros(len(t), np.int64)
-        for n in range(len(t)):
-            for side in (0, 1):
-                if not (int(t[n, 1]) >> (14 + side)) & 1:
-                    depth[int(t[n, 2 + side])] = depth[n] + 1
-        best = max(best, int(depth.max()) + 1)
-    return best
-
-
 def _gpu_sparse(eng, s, x, sum_mode=0, shard=(0, 1), top=-1, order=0):
     import torch
 
@@ -189,14 +175,10 @@ def test_gpu_sparse_bit_exact_all_top_levels_and_orders(eng, shape):
         s = O.gen_sparse_model(T, D, F, full, pm, dist, cmp_mode=cmp_mode)
         x = O.gen_tuples(0, rows, F, dist)
         want = O.score_sparse(s, x)
-        md = _max_depth(s)
         for top in (-1, 6, 7, 8, 9, 10):
             for order in (0, 1):
-                # rank-quantised kernels (u16 tile of the q16 pre-pass), the fp32-tile kernels over two-level blocks where the forest
-                # qualifies (F <= 64, at most K + 8 levels, more than K + 2), and over one record per node
-                for ranked, blocks in ((1, 1), (0, 1), (0, 0)):
+                for ranked in (1, 0):  # rank-quantised kernels (u16 tile of the q16 pre-pass) and the fp32-tile kernels
                     eng.set_option("sparse_q16", ranked)
-                    eng.set_option("sparse_b2", blocks)
                     try:
                         got = _gpu_sparse(eng, s, x, top=top, order=order)
                     except ddt.DDTError as ex:  # a forced K whose top images do not fit the LDS next to the feature tile
@@ -204,16 +186,8 @@ def test_gpu_sparse_bit_exact_all_top_levels_and_orders(eng, shape):
                         continue
                     name = eng.info().variant_name.decode()
                     assert ranked or not name.startswith("sparse_q_"), (name, ranked, top)
-                    assert blocks or not name.startswith("sparse_b2_"), (name, blocks, top)
                     assert not (ranked and top == -1 and F <= 64) or name.startswith("sparse_q_"), (name, ranked, top)
-                    K = int(name.split("_k")[1].split("_")[0])
-                    T_ = int(name.rsplit("_t", 1)[1])  # two-level blocks exist for the 256- and 512-tuple tiles
-                    if name.startswith("sparse_b2_"):
-                        assert blocks and F <= 64 and K + 2 < md <= K + 8, (name, shape, top)
-                    elif not name.startswith("sparse_q_") and blocks and F <= 64 and K + 2 < md <= K + 8:
-                        assert T_ < 256, (name, shape, top)
                     assert np.array_equal(_bits(got), _bits(want)), (shape, cmp_mode, top, order, name)
-        eng.set_option("sparse_b2", 1)
         eng.set_option("sparse_q16", 1)
         want64 = O.score_sparse(s, x, sum_mode=O.SUM_F64_SEQ)
         assert np.array_equal(_bits(_gpu_sparse(eng, s, x, sum_mode=1)), _bits(want64))

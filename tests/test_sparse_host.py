@@ -29,37 +29,13 @@ def _images(s, variant, order):
     rc = L.ddt_debug_sparse_image(C.byref(p), nl.ctypes.data, nl.shape[0], first.ctypes.data, variant, order, top.ctypes.data, top.size,
                                   deep.ctypes.data, deep.size, info.ctypes.data)
     assert rc == 0, rc
-    b2 = ddt.variant_names()[variant].startswith("sparse_b2_")
-    return top, deep.reshape(-1, 8 if b2 else 4), [int(v) for v in info]
+    return top, deep.reshape(-1, 4), [int(v) for v in info]
 
 
 def _rank_tables(s):
     """per feature: the sorted distinct threshold keys of the forest (cmp_mode 0: the raw bits in int32 order)"""
     nl = np.ascontiguousarray(s.node_lines).view(np.uint32).reshape(-1, 4)
     return [np.unique(nl[(nl[:, 1] & 0x7FF) == j, 0].view(np.int32)) for j in range(int(s.params.num_features))]
-
-
-def _walk_blocks(deep, b, x, miss_bits):
-    """the deep phase of the "sparse_b2_*" kernels: 32-byte two-level blocks {t0, t1, t2, meta, v0..v3} (ddt_internal.h), one block per two
-    levels, the leaf out of the last block's value words"""
-    def right(f, key, mr):
-        if f == miss_bits:
-            return mr != 0
-        return np.uint32(f).view(np.int32) >= np.uint32(key).view(np.int32)
-
-    for _ in range(80):
-        assert 0 < b < deep.shape[0]
-        t0, t1, t2, meta = (int(v) for v in deep[b, :4])
-        c0 = int(right(int(x[meta & 63]), t0, (meta >> 18) & 1))
-        fc = (meta >> (12 if c0 else 6)) & 63
-        c1 = int(right(int(x[fc]), t2 if c0 else t1, (meta >> (20 if c0 else 19)) & 1))
-        j = 2 * c0 + c1
-        mask, rel = (meta >> 21) & 15, meta >> 25
-        if not (mask >> j) & 1:
-            return int(deep[b, 4 + j])
-        assert rel >= 1
-        b = b + rel + bin(mask & ((1 << j) - 1)).count("1")
-    raise AssertionError("walk does not terminate")
 
 
 def _walk(top, deep, info, slot, x, miss_bits, tables=None):
@@ -88,8 +64,6 @@ def _walk(top, deep, info, slot, x, miss_bits, tables=None):
         if w & (RIGHT_LEAF if r else LEFT_LEAF):
             return nxt
         assert 0 < nxt < deep.shape[0]
-        if deep.shape[1] == 8:  # two-level blocks below level K-1
-            return _walk_blocks(deep, nxt, x, miss_bits)
         rec = deep[nxt]
     raise AssertionError("walk does not terminate")
 
@@ -108,16 +82,12 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
     seen_k = set()
     tables = _rank_tables(s)
     for vid, name in _sparse_variants():
-        ranked, blocks = name.startswith("sparse_q_"), name.startswith("sparse_b2_")
+        ranked = name.startswith("sparse_q_")
         K = int(re.search(r"_k(\d+)_", name).group(1))
-        if (ranked, blocks, K) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
+        if (ranked, K) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
             continue
-        if blocks and depth > K + 8:  # the loader never picks two-level blocks there (and the hook refuses when a sub-tree is too large)
-            continue
-        seen_k.add((ranked, blocks, K))
+        seen_k.add((ranked, K))
         top, deep, info = _images(s, vid, order)
-        if blocks:
-            assert not deep[0].any() and (deep[1:, 3] >> 25).max(initial=0) <= 127
         assert info[3] == K and info[2] * 8 >= T and top.size == info[2] * 8 * (12 << K) // 4
         assert info[5] == (2048 if ranked else 4 * int(name.rsplit("_t", 1)[1]))  # u16 rows of 1024 tuples / fp32 rows of the tile
         for r in range(x.shape[0]):
@@ -125,8 +95,7 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
                 got = _walk(top, deep, info, i, x[r], int(s.params.missing_bits), tables if ranked else None)
                 want = O.traverse_sparse(s, x[r], i) if i < T else 0
                 assert got == want, (name, order, r, i, hex(got), hex(want))
-    assert len([k for k in seen_k if not k[0] and not k[1]]) >= 4 and len([k for k in seen_k if k[0]]) >= 4
-    assert len([k for k in seen_k if k[1]]) == len([K for K in range(6, 11) if depth <= K + 8])
+    assert len([k for k in seen_k if not k[0]]) >= 4 and len([k for k in seen_k if k[0]]) >= 4
 
 
 def test_hook_rejects_what_the_loader_rejects():
