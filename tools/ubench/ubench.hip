@@ -7,6 +7,9 @@
 //           shipped q16 kernel's inner loop); v1 = 8-byte records with explicit child pointers (3 VALU per
 //           visit); v2 = v1 with the last level + leaves as one 16-byte global record per node
 //   gather  vector-memory gather rate out of an L1-resident window (4 / 8 / 16 bytes per lane)
+//   coal    COALESCED 2-byte loads (every lane its own u16 of one wave-uniform row of a 64 KiB tile, buffer_load_ushort with the
+//           row in the scalar offset: no VALU address) alone and mixed 3 : 1 with random 4-byte gathers -- what the vector-memory
+//           pipe would charge for reading wave-uniform-row features from the global rank tile instead of from LDS
 //   hbm     read-only HBM probe (16 B per lane, persistent blocks)
 //   tilepat the stream kernel's memory pattern (tile per block and step, one ahead, result store, barrier, dummy VALU work)
 // Measurement infrastructure, not product code: nothing in libddt.so includes or links this file.
@@ -623,6 +626,52 @@ __global__ __launch_bounds__(1024) void gather_kernel(const char* __restrict__ w
   out[blockIdx.x * 1024 + tid] = acc;
 }
 
+// MIX: 0 = coalesced loads only (8 per iteration), 1 = per iteration 6 coalesced + 2 random 4-byte gathers, 2 = 2 gathers only
+template <int MIX>
+__global__ __launch_bounds__(1024) void coal_kernel(const char* __restrict__ tile, const char* __restrict__ win, uint32_t* out, int iters) {
+  const uint32_t tid = threadIdx.x, lane2 = ((tid & 511u) << 2) | ((tid >> 9) << 1);  // the rank tile's lane offset (ddt_kernels.hip)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tile), 0, 65536, 0x00020000);
+  uint32_t acc = 0, idx0 = (tid * 2654435761u) >> 4, idx1 = (tid * 40503u + 77u) >> 3;
+  for (int it = 0; it < iters; ++it) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0;
+    const uint32_t row0 = __builtin_amdgcn_readfirstlane((uint32_t)it * 8u);
+    if (MIX != 2) {
+#pragma unroll
+      for (int k = 0; k < (MIX == 0 ? 8 : 6); ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b16(rs, lane2, ((row0 + k) & 31u) * 2048u, 0);
+    }
+    if (MIX != 0) {
+      v[6] = *reinterpret_cast<const uint32_t*>(win + ((uint32_t)it * 2u % 8u) * 1024u + (idx0 % 256u) * 4u);
+      v[7] = *reinterpret_cast<const uint32_t*>(win + (((uint32_t)it * 2u + 1u) % 8u) * 1024u + (idx1 % 256u) * 4u);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += v[k];
+    idx0 = idx0 * 1664525u + 1013904223u + (v[6] & 1u);
+    idx1 = idx1 * 22695477u + 1u + (v[7] & 1u);
+  }
+  out[blockIdx.x * 1024 + tid] = acc;
+}
+template <int MIX>
+static void run_coal(uint32_t* d_out, const char* d_tile, const char* d_win, std::string& js) {
+  const int iters = 400, blocks = g_cus * 2;
+  Timer t;
+  hipLaunchKernelGGL(coal_kernel<MIX>, dim3(blocks), dim3(1024), 0, 0, d_tile, d_win, d_out, 4);
+  CK(hipDeviceSynchronize());
+  double best = 1e30;
+  for (int r = 0; r < 3; ++r) {
+    t.start();
+    hipLaunchKernelGGL(coal_kernel<MIX>, dim3(blocks), dim3(1024), 0, 0, d_tile, d_win, d_out, iters);
+    const double ms = t.stop_ms();
+    best = ms < best ? ms : best;
+  }
+  static const char* const names[] = {"8 coalesced u16 loads", "6 coalesced u16 loads + 2 random 4-byte gathers", "2 random 4-byte gathers"};
+  char buf[300];
+  snprintf(buf, sizeof buf, "    {\"per_iteration\": \"%s\", \"ms\": %.3f, \"cycles_per_iteration_per_wave_and_cu\": %.2f},\n", names[MIX], best,
+           best * 1e-3 * g_clock_ghz * 1e9 / ((double)iters * 32.0));
+  js += buf;
+}
+
 // gather cost vs live lanes: only lanes < live issue the (16-byte) gather -- exec-masked, the others skip it
 __global__ __launch_bounds__(1024) void gather_live_kernel(const char* __restrict__ win, uint32_t win_bytes, uint32_t region_bytes, uint32_t* out, int iters,
                                                            uint32_t live, int same_line_for_dead) {
@@ -865,6 +914,21 @@ int main(int argc, char** argv) {
       for (uint32_t live : {64u, 32u, 16u, 8u, 2u}) run_gather_live(d_out, d_win, live, same, js);
     strip_comma(js);
     js += "  ],\n";
+    CK(hipFree(d_win));
+  }
+  if (on("coal")) {
+    js += "  \"coalesced_vs_gather\": [\n";
+    char *d_tile, *d_win;
+    CK(hipMalloc(&d_tile, 65536));
+    CK(hipMalloc(&d_win, 8192));
+    CK(hipMemset(d_tile, 1, 65536));
+    CK(hipMemset(d_win, 1, 8192));
+    run_coal<0>(d_out, d_tile, d_win, js);
+    run_coal<1>(d_out, d_tile, d_win, js);
+    run_coal<2>(d_out, d_tile, d_win, js);
+    strip_comma(js);
+    js += "  ],\n";
+    CK(hipFree(d_tile));
     CK(hipFree(d_win));
   }
   if (on("hbm")) {
