@@ -1428,13 +1428,14 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     }
     return DDT_OK;
   }
-  if (!strcmp(key, "sparse_top_levels") || !strcmp(key, "sparse_deep_order") || !strcmp(key, "sparse_q16")) {
+  if (!strcmp(key, "sparse_top_levels") || !strcmp(key, "sparse_deep_order") || !strcmp(key, "sparse_q16") || !strcmp(key, "sparse_dk")) {
     // sparse forests: K = levels staged in LDS (-1 = as many as fit), order of the deep records (0 level order,
-    // 1 depth-first per sub-tree), rank-quantised kernels (1 = when they fit, 0 = never); a loaded sparse model is re-packed
-    const bool top = key[7] == 't', rq = key[7] == 'q';
+    // 1 depth-first per sub-tree), rank-quantised kernels (1 = when they fit, 0 = never), dense level K (1 = where such a kernel
+    // exists, 0 = never); a loaded sparse model is re-packed
+    const bool top = key[7] == 't', rq = key[7] == 'q', dk = !strcmp(key, "sparse_dk");
     if (top && value >= 0 && (value < kSparseMinTop || value > kSparseMaxTop)) return fail(e, DDT_EINVAL, "sparse_top_levels must be -1 or %d..%d", kSparseMinTop, kSparseMaxTop);
     if (!top && (value < 0 || value > 1)) return fail(e, DDT_EINVAL, "%s must be 0 or 1", key);
-    int& opt = top ? e->sparse_top_levels : rq ? e->sparse_q16 : e->sparse_deep_order;
+    int& opt = top ? e->sparse_top_levels : rq ? e->sparse_q16 : dk ? e->sparse_dk : e->sparse_deep_order;
     const int previous = opt;
     opt = (int)value;
     if (e->loaded && e->sparse) {

@@ -87,6 +87,14 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
 //                 leaf flags sit in bits 31 / 30 so that each is ONE sign test (of w, of w << 1)
 //   left/right  = index into the deep array (< 2^28: the kernel addresses it with a 32-bit byte offset), or the leaf's
 //                 fp32 bits when the matching flag is set
+//   dense level K ("sparse_dk_*", Variant::opt bit 1): the top image holds ALL K levels as 8-byte records (8 * 2^K bytes per
+//               tree; record 0 = {cbase, 0}), and level K is a DENSE block of 2^K deep records per tree (a leaf or the padding
+//               under an early leaf is a dummy record whose two children are that leaf value): the record below heap node m
+//               of level K-1 on side s is deep[base + 2 (m - 2^(K-1)) + s], byte offset 2 * (8 * child heap index) + cbase with
+//               cbase = 16 * base - 16 * 2^K (mod 2^32) -- no child words in LDS.  A third less LDS per tree: two K = 8 blocks of
+//               256 tuples x 64 features share a CU (2 x 80 KiB), or one block of 512 holds K = 9 (160 KiB); the per-wave flags
+//               of the missing-value test live at LDS offset 0 before the first image arrives.  EMPTY slots share the dummy
+//               block deep[0, 2^K).
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kSpLeftLeaf = 0x80000000u, kSpRightLeaf = 0x40000000u, kSpMissRight = 0x20000000u, kSpAddrMask = 0x1FFFFFFFu;
 constexpr int kSparseMinTop = 6, kSparseMaxTop = 10;
@@ -153,13 +161,14 @@ struct Variant {
   // ---- sparse kernels (levels = K, the top levels staged in LDS): LDS = [top image of one PU group][feature tile] ----
   // opt bit 0 ("sparse_q_*"): rank-quantised -- u16 feature tile (half the LDS per tuple: 1024 tuples = 16 waves share a CU
   // where the fp32 tile holds 512), node thresholds are ranks
-  uint32_t top_bytes_sparse() const { return 12u << levels; }
+  // opt bit 1 ("sparse_dk_*"): dense level K -- 8-byte records only in LDS, no flag bytes behind the tile (above: "Sparse forests")
+  uint32_t top_bytes_sparse() const { return ((opt & 2) ? 8u : 12u) << levels; }
   uint32_t row_bytes_sparse() const { return (opt & 1) ? tile() * 2u : tile() * 4u; }
   uint32_t feat_off_sparse() const {  // chunk_trees = trees walked in lock-step = top images resident per pass
     const uint32_t row = row_bytes_sparse(), need = (uint32_t)chunk_trees * top_bytes_sparse();
     return (need + row - 1u) / row * row;
   }
-  uint32_t lds_bytes_sparse(uint32_t tuple_words) const { return feat_off_sparse() + tuple_words * row_bytes_sparse() + 64u; }
+  uint32_t lds_bytes_sparse(uint32_t tuple_words) const { return feat_off_sparse() + tuple_words * row_bytes_sparse() + ((opt & 2) ? 0u : 64u); }
 };
 
 int num_variants();

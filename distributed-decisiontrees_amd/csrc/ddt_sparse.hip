@@ -17,6 +17,9 @@
 //          ROTATING pipeline: the gather of tree u's next record is issued right after ITS visit and flies while the other
 //          seven trees are visited.  Lanes that reached a leaf idle until the wave's deepest lane is done (__ballot early
 //          exit, per wave).
+//   "sparse_dk_*" (dense level K, Variant::opt bit 1): ALL K top levels are 8-byte records in LDS and level K is a dense block of
+//          2^K deep records per tree addressed by the heap index (ddt_internal.h): a third less LDS per tree, so two K = 8 blocks
+//          of 256 tuples x 64 features share a CU (one's top phase overlaps the other's deep phase) or one block of 512 holds K = 9.
 // No MFMA: compare + gather.  Bound by the vector-memory gather rate of the deep phase.
 #include <hip/hip_runtime.h>
 
@@ -47,9 +50,9 @@ __device__ __forceinline__ uint32_t sp_feature(uint32_t w, uint32_t lane_off) {
 
 // The walk of all PU groups for one tile.  SLOW = the tile holds a missing value: apply the per-node missing rule
 // (block-uniform choice, like the perfect-tree kernels).
-template <int K, int U, int THREADS, bool SLOW, bool Q>
+template <int K, int U, int THREADS, bool SLOW, bool Q, bool DK>
 __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
-  constexpr int TOPB = 12 << K;
+  constexpr int TOPB = (DK ? 8 : 12) << K;
   constexpr int STEPB = U * TOPB;  // U trees per pass: one PU group (or two)
   // Q: the u16 tile of the q16 pre-pass -- tuples t and t + 512 of a tile share a dword (rank_kernel)
   const uint32_t lane_off = Q ? ((((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1)) : (uint32_t)tid * 4u;
@@ -60,7 +63,8 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the top images of this pass (and, first pass, the feature tile) are in LDS for everyone
 
-    // ---- top phase: levels 0..K-2 over 8-byte heap records, level K-1 over 16-byte records ----
+    // ---- top phase: levels 0..K-2 over 8-byte heap records, level K-1 over 16-byte records (dense level K: all K levels over
+    //      8-byte records, the level-K record's byte offset in the deep array follows from the heap index) ----
     uint32_t m8[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) m8[u] = 8u;
@@ -76,8 +80,19 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
       for (int u = 0; u < U; ++u) m8[u] = (m8[u] << 1) + (sp_right<SLOW, Q>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
     }
     uint4 r[U];  // m8 = 8 * heap index in [2^(K-1), 2^K): record at 4*2^K + 16*(m - 2^(K-1)) = 2*m8 - 4*2^K
+    // dense level K: the level K-1 record is 8 bytes {key, w}; its children are deep records at byte 2 * (8 * child heap index) +
+    // cbase, cbase = word 0 of the tree's image.  Like the 16-byte record it is visited in the first round of the deep phase.
+    uint2 r8[U];
+    uint32_t cb[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) r[u] = lds_u4((m8[u] << 1) - (uint32_t)(4 << K) + (uint32_t)(u * TOPB));
+    for (int u = 0; u < U; ++u) {
+      if (DK) {
+        r8[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
+        cb[u] = lds_u32((uint32_t)(u * TOPB)) + (m8[u] << 2);  // byte offset of the LEFT child's record
+      } else {
+        r[u] = lds_u4((m8[u] << 1) - (uint32_t)(4 << K) + (uint32_t)(u * TOPB));
+      }
+    }
     __syncthreads();  // every wave holds its level K-1 records: the top image buffer is free
     if (g + 1 < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
 
@@ -96,7 +111,16 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
     for (int u = 0; u < U; ++u) {
       act[u] = true;
       leafv[u] = 0.f;
-      rr[u] = u32x4{r[u].x, r[u].y, r[u].z, r[u].w};
+      if (!DK) rr[u] = u32x4{r[u].x, r[u].y, r[u].z, r[u].w};
+    }
+    if constexpr (DK) {  // first round: level K-1 out of the registers, every walker goes on to its level-K record
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t f = sp_feature<Q>(r8[u].y, lane_off);
+        const bool right = sp_right<SLOW, Q>(f, r8[u].x, r8[u].y, miss_key);
+        rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (right ? 16u : 0u), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     for (;;) {
       bool any = false;
@@ -134,9 +158,9 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
   }
 }
 
-template <int K, int U, int THREADS, bool Q>
+template <int K, int U, int THREADS, bool Q, bool DK>
 __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
-  constexpr int TOPB = 12 << K;          // bytes of one tree's top image
+  constexpr int TOPB = (DK ? 8 : 12) << K;  // bytes of one tree's top image
   constexpr int STEPB = U * TOPB;  // top images resident per pass: U trees walked in lock-step = U independent load chains per lane
   constexpr int ROW = Q ? THREADS * 2 : THREADS * 4;
   constexpr int FEAT_OFF = (STEPB + ROW - 1) / ROW * ROW;
@@ -147,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   const uint64_t tile0 = (uint64_t)blockIdx.x * THREADS;
   const uint32_t W = a.tuple_words, lpt = W / 4u;
 
-  dma_chunk<THREADS, STEPB>(a.img, 0, 0, tid);  // top images of the first pass
+  if (!DK) dma_chunk<THREADS, STEPB>(a.img, 0, 0, tid);  // top images of the first pass (dense level K: after the missing-value test)
 
   bool slow;
   if constexpr (Q) {
@@ -199,25 +223,30 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
     }
   }
   // the barrier inside publishes the staged tile; tiles without a missing value skip the missing rule altogether
-  slow = block_any<THREADS>(miss_any, (uint32_t)FEAT_OFF + W * (uint32_t)ROW, tid);
+  // (dense level K has no flag bytes behind the tile: its LDS is full to the byte; the flags use offset 0 before the first image)
+  slow = block_any<THREADS>(miss_any, DK ? 0u : (uint32_t)FEAT_OFF + W * (uint32_t)ROW, tid);
+  }
+  if (DK) {
+    __syncthreads();  // every wave has read the flags: the image may land on them
+    dma_chunk<THREADS, STEPB>(a.img, 0, 0, tid);
   }
 
   RefAcc<1> ra;
   ra.init();
   double dacc = 0.0;
   const uint32_t C = a.clusters;
-  if (!slow) sparse_walk<K, U, THREADS, false, Q>(a, x, tid, ra, dacc);
-  else sparse_walk<K, U, THREADS, true, Q>(a, x, tid, ra, dacc);
+  if (!slow) sparse_walk<K, U, THREADS, false, Q, DK>(a, x, tid, ra, dacc);
+  else sparse_walk<K, U, THREADS, true, Q, DK>(a, x, tid, ra, dacc);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
 }
 
-template <int K, int U, int THREADS, bool Q>
+template <int K, int U, int THREADS, bool Q, bool DK = false>
 static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_kernel<K, U, THREADS, Q>;
+  auto kern = score_sparse_kernel<K, U, THREADS, Q, DK>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
@@ -234,6 +263,10 @@ static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStrea
 
 #define DDT_SP(K, U, T) \
   Variant { "sparse_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 0, &launch_sparse_v<K, U, T, false> }
+#define DDT_SPD(K, U, T) /* dense level K: 8-byte records only in LDS (8 * 2^K bytes per tree) */ \
+  Variant { "sparse_dk_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2, &launch_sparse_v<K, U, T, false, true> }
+#define DDT_SPQD(K, U) /* rank-quantised + dense level K */ \
+  Variant { "sparse_qd_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 3, &launch_sparse_v<K, U, 1024, true, true> }
 #define DDT_SPQ(K, U) /* rank-quantised: u16 feature tile of 1024 tuples = 16 waves per CU */ \
   Variant { "sparse_q_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 1, &launch_sparse_v<K, U, 1024, true> }
 
@@ -242,6 +275,7 @@ static const Variant g_sparse_variants[] = {
     // rank-quantised (thresholds -> ranks, features -> the u16 tiles of the q16 pre-pass): half the LDS per tuple, so a CU holds
     // 1024 walkers = 16 waves instead of 512 = 8 -- the deep phase is latency-bound, walkers in flight are what it needs
     DDT_SPQ(6, 8), DDT_SPQ(7, 8), DDT_SPQ(8, 8), DDT_SPQ(9, 8),
+    DDT_SPQD(6, 8), DDT_SPQD(7, 8), DDT_SPQD(8, 8), DDT_SPQD(9, 8), DDT_SPQD(10, 8),
     // measured and NOT instantiated (profiles/r02_sparse_sweep_*.log): 16 trees in lock-step (u16: no gain over u8), half a
     // PU group per pass (u4: K + 1 at the same occupancy, but 4 loads in flight per lane: 159 vs 196 Mtuples/s)
     DDT_SP(6, 8, 256), DDT_SP(7, 8, 256), DDT_SP(8, 8, 256), DDT_SP(9, 8, 256), DDT_SP(10, 8, 256),
@@ -250,6 +284,9 @@ static const Variant g_sparse_variants[] = {
     // narrower tiles for wide tuples (the feature tile is 4 * W bytes per tuple)
     DDT_SP(6, 8, 128), DDT_SP(7, 8, 128), DDT_SP(8, 8, 128), DDT_SP(9, 8, 128), DDT_SP(10, 8, 128),
     DDT_SP(8, 8, 64), DDT_SP(9, 8, 64), DDT_SP(10, 8, 64),
+    // dense level K: K = 8 at two 256-tuple blocks per CU / K = 9 in one block of 512 where the 16-byte level K-1 records allow 7 / 8
+    DDT_SPD(6, 8, 256), DDT_SPD(7, 8, 256), DDT_SPD(8, 8, 256), DDT_SPD(9, 8, 256), DDT_SPD(10, 8, 256),
+    DDT_SPD(7, 8, 512), DDT_SPD(8, 8, 512), DDT_SPD(9, 8, 512), DDT_SPD(10, 8, 512),
 };
 
 int num_sparse_variants() { return (int)(sizeof(g_sparse_variants) / sizeof(g_sparse_variants[0])); }

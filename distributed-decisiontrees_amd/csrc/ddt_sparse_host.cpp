@@ -38,38 +38,50 @@ int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {
   // 1024 tuples = 16 waves holds the CU that the fp32 tile fills with 512 = 8; the deep phase is latency-bound and takes the
   // walkers (BASELINE config 4: profiles/r03_sweep_sparse_q.json).  Largest K whose top images fit next to the tile.
   if (e->sparse_q16 && ranks_fit) {
-    const int kq = e->sparse_top_levels >= 0 ? e->sparse_top_levels : (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, kSparseMinTop), 9u);
-    for (int K = kq; K >= (e->sparse_top_levels >= 0 ? kq : kSparseMinTop); --K) {
-      snprintf(name, sizeof(name), "sparse_q_k%d_u8_t1024", K);
-      const int vid = find_variant(name);
-      if (fits(vid, kMaxLdsBytes)) return vid;
-    }
+    const int kq = e->sparse_top_levels >= 0 ? e->sparse_top_levels : (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, kSparseMinTop), kSparseMaxTop);
+    for (int K = kq; K >= (e->sparse_top_levels >= 0 ? kq : kSparseMinTop); --K)
+      for (int d = e->sparse_dk ? 1 : 0; d >= 0; --d) {  // dense level K first: one more level fits next to the tile
+        snprintf(name, sizeof(name), d ? "sparse_qd_k%d_u8_t1024" : "sparse_q_k%d_u8_t1024", K);
+        const int vid = find_variant(name);
+        if (fits(vid, kMaxLdsBytes)) return vid;
+      }
   }
+  // Dense level K (option "sparse_dk", default on): the same walk with a third less LDS per tree -- where it exists (256- and
+  // 512-tuple tiles) it is tried first, so a geometry reaches a larger K or a second block per CU.
   if (e->sparse_top_levels >= 0) {
-    for (int T : {256, 128, 64}) {
-      snprintf(name, sizeof(name), "sparse_k%d_u8_t%d", e->sparse_top_levels, T);
-      const int vid = find_variant(name);
-      if (fits(vid, kMaxLdsBytes)) return vid;
-    }
+    for (int d = e->sparse_dk ? 1 : 0; d >= 0; --d)
+      for (int T : {256, 128, 64}) {
+        snprintf(name, sizeof(name), d ? "sparse_dk_k%d_u8_t%d" : "sparse_k%d_u8_t%d", e->sparse_top_levels, T);
+        const int vid = find_variant(name);
+        if (fits(vid, kMaxLdsBytes)) return vid;
+      }
     return -1;
   }
   // deepest K worth staging: nothing is left for the deep phase beyond the deepest tree
   const int kcap = (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, kSparseMinTop), kSparseMaxTop);
   // Geometries that keep >= 8 waves on a CU (then fewer, for very wide tuples), each with the largest K whose top
-  // images fit next to the feature tile; the largest K wins, ties go to the earlier geometry.
+  // images fit next to the feature tile.
   static const struct { int T; uint32_t blocks; } geo[] = {{256, 2}, {512, 1}, {128, 4}, {256, 1}, {128, 2}, {128, 1}, {64, 2}, {64, 1}};
-  int best = -1, best_k = -1;
+  // The largest K wins, where a geometry with two or more blocks per CU counts one level more (one block's top phase overlaps the
+  // others' deep phase: BASELINE config 4, profiles/r03_sparse_dense_level_k.json -- K = 8 in two blocks 256.6 Mtuples/s, K = 9 in one
+  // 243.4, K = 8 in one 232.5); ties go to the earlier geometry.
+  int best = -1, best_score = -1;
   uint32_t best_waves = 0;
   for (const auto& g : geo) {
     const uint32_t waves = (uint32_t)g.T / 64u * g.blocks;
     if (best >= 0 && waves < best_waves) break;  // only fall to fewer waves when nothing fitted with more
     for (int K = kcap; K >= kSparseMinTop; --K) {
-      snprintf(name, sizeof(name), "sparse_k%d_u8_t%d", K, g.T);
-      const int vid = find_variant(name);
+      snprintf(name, sizeof(name), "sparse_dk_k%d_u8_t%d", K, g.T);
+      int vid = e->sparse_dk ? find_variant(name) : -1;
+      if (!fits(vid, kMaxLdsBytes / g.blocks)) {
+        snprintf(name, sizeof(name), "sparse_k%d_u8_t%d", K, g.T);
+        vid = find_variant(name);
+      }
       if (!fits(vid, kMaxLdsBytes / g.blocks)) continue;
-      if (K > best_k) {
+      const int score = K + (g.blocks >= 2u && (uint32_t)K < max_depth ? 1 : 0);  // (nothing to overlap when the whole forest is in LDS)
+      if (score > best_score) {
         best = vid;
-        best_k = K;
+        best_score = score;
         best_waves = waves;
       }
       break;
@@ -151,7 +163,9 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
   const uint32_t per_pass = std::max(1u, (uint32_t)v.chunk_trees / 8u);  // PU groups walked in lock-step (half groups: 1)
   uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
   groups = (groups + per_pass - 1u) / per_pass * per_pass;  // whole passes: the padding groups are EMPTY slots too (+0)
-  const uint32_t top_words = (12u << K) / 4u;       // per tree
+  const bool dk = (v.opt & 2) != 0;  // dense level K: all K levels as 8-byte records in LDS, level K a dense block of deep records
+  const uint32_t top_words = v.top_bytes_sparse() / 4u;  // per tree
+  const uint32_t lvl8 = dk ? K : K - 1u;                 // levels stored as 8-byte heap records
   const uint32_t feat_off = v.feat_off_sparse(), row = v.row_bytes_sparse();
   auto feat_word = [&](uint32_t j) { return feat_off + j * row; };
 
@@ -171,19 +185,33 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
     rec[2] = l;
     rec[3] = r;
   };
-  deep.assign(4u, 0u);  // record 0: a valid dummy (finished lanes keep re-reading it)
-  put16(deep.data(), 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
+  // record 0: a valid dummy (finished lanes keep re-reading it); dense level K: a whole block of 2^K of them, the level K of every
+  // EMPTY slot
+  try {
+    deep.assign(dk ? (size_t)4u << K : 4u, 0u);
+  } catch (const std::bad_alloc&) {
+    return fail(e, DDT_ENOMEM, "sparse image allocation failed");
+  }
+  for (size_t q = 0; q < deep.size() / 4u; ++q) put16(deep.data() + 4u * q, 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
+  const auto cbase_of = [&](size_t first_record) { return (uint32_t)(first_record << 4) - (16u << K); };  // see ddt_internal.h
 
   std::vector<Cursor> cur, nxt;
-  std::vector<std::pair<uint32_t, uint32_t*>> pending;  // (tree node at depth K, slot of the parent's child word to patch)
+  struct Patch {  // a child word to patch with the deep index of tree node `node` once the deep records of the tree are placed
+    uint32_t node;
+    bool in_deep;  // the word lives in `deep` (which grows: keep its index) / in `top`
+    size_t word;
+  };
+  std::vector<Patch> pending;
   std::vector<uint32_t> order, stack;
   try {  // every container below grows with the model: an allocation failure is DDT_ENOMEM, never an exception across the C ABI
   for (uint32_t i = 0; i < groups * 8u; ++i) {
     uint32_t* t = top.data() + (size_t)i * top_words;
-    uint32_t* last = t + (4u << K) / 4u;  // 16-byte records of level K-1
+    uint32_t* last = t + (4u << K) / 4u;  // 16-byte records of level K-1 (not dense level K)
     if (i >= T) {  // EMPTY slot: contributes exactly +0 (DTPU.sv:544,760)
-      for (uint32_t m = 1; m < (1u << (K - 1)); ++m) put8(t, m, 0u, feat_word(0));
-      for (uint32_t r = 0; r < (1u << (K - 1)); ++r) put16(last + 4u * r, 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
+      for (uint32_t m = 1; m < (1u << lvl8); ++m) put8(t, m, 0u, feat_word(0));
+      if (dk) t[0] = cbase_of(0);  // the shared dummy block
+      else
+        for (uint32_t r = 0; r < (1u << (K - 1)); ++r) put16(last + 4u * r, 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
       continue;
     }
     const uint32_t* L = sp.lines.data() + sp.first[i] * 4u;
@@ -197,7 +225,7 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
     };
     // ---- top heap, level by level ----
     cur.assign(1, Cursor{false, 0u});
-    for (uint32_t lvl = 0; lvl + 1u < K; ++lvl) {
+    for (uint32_t lvl = 0; lvl < lvl8; ++lvl) {
       nxt.clear();
       for (uint32_t k = 0; k < cur.size(); ++k) {
         const uint32_t m = (1u << lvl) + k;
@@ -214,10 +242,18 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
       }
       cur.swap(nxt);
     }
-    // ---- level K-1: 16-byte records whose children are leaves or deep records ----
+    // ---- the first 16-byte records, whose children are leaves or deep records: level K-1 in the top image, or (dense level K) the
+    //      tree's dense block of 2^K records at the end of the deep array ----
     pending.clear();
+    const size_t dense0 = deep.size() / 4u;
+    if (dk) {
+      if (dense0 + cur.size() >= (1ull << 28)) return fail(e, DDT_EUNSUPPORTED, "more than 2^28 deep records (4 GiB of 16-byte records)");
+      deep.resize(deep.size() + cur.size() * 4u);
+      t[0] = cbase_of(dense0);
+    }
     for (uint32_t k = 0; k < cur.size(); ++k) {
-      uint32_t* rec = last + 4u * k;
+      const size_t word = dk ? (dense0 + k) * 4u : (size_t)(last + 4u * k - top.data());
+      uint32_t* rec = (dk ? deep.data() : top.data()) + word;
       if (cur[k].leaf) {
         put16(rec, 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, cur[k].v, cur[k].v);
         continue;
@@ -230,7 +266,7 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
           w |= side ? kSpRightLeaf : kSpLeftLeaf;
           rec[2u + side] = c.v;
         } else {
-          pending.push_back({c.v, rec + 2u + side});
+          pending.push_back(Patch{c.v, dk, word + 2u + side});
         }
       }
       rec[0] = node_key(n);
@@ -242,7 +278,7 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
     //          record: half of the steps of a walk stay inside the cache line they are in)
     order.clear();
     if (e->sparse_deep_order == 0) {
-      for (auto& pe : pending) order.push_back(pe.first);
+      for (auto& pe : pending) order.push_back(pe.node);
       for (size_t q = 0; q < order.size(); ++q)
         for (uint32_t side = 0; side < 2; ++side) {
           const Cursor c = child(order[q], side);
@@ -250,7 +286,7 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
         }
     } else {
       for (auto& pe : pending) {
-        stack.assign(1, pe.first);
+        stack.assign(1, pe.node);
         while (!stack.empty()) {
           const uint32_t n = stack.back();
           stack.pop_back();
@@ -280,7 +316,7 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
       rec[0] = node_key(n);
       rec[1] = w;
     }
-    for (auto& pe : pending) *pe.second = where[pe.first];
+    for (auto& pe : pending) (pe.in_deep ? deep.data() : top.data())[pe.word] = where[pe.node];
   }
   } catch (const std::bad_alloc&) {
     return fail(e, DDT_ENOMEM, "sparse image allocation failed");

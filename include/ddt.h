@@ -302,7 +302,9 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * forest staged in LDS), "sparse_deep_order" (0 = level order, default; 1 = depth-first per sub-tree), "sparse_q16" (1 =
  * default: sparse forests whose distinct thresholds per feature fit 16-bit ranks -- at most 32767, e.g. histogram-trained
  * models -- and whose tuples have at most 64..76 words run on the rank-quantised sparse kernels: u16 feature tile, 1024
- * tuples per block; 0 = always the fp32-tile kernels).  A refused sparse_* value keeps the previous one and the loaded model. */
+ * tuples per block; 0 = always the fp32-tile kernels), "sparse_dk" (1 = default: the "dense level K" sparse kernels where they
+ * exist -- all top levels as 8-byte records in LDS, the first deep level addressed by the heap index; 0 = never).  A refused
+ * sparse_* value keeps the previous one and the loaded model. */
 int ddt_set_option(ddt_engine* e, const char* key, int64_t value);
 int ddt_num_variants(void);
 int ddt_variant_name(int variant, char* buf, size_t buflen);

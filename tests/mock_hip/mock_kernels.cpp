@@ -162,7 +162,8 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
   Op* op = new Op();
   op->cost = (double)a.n * g_cost_row;
   op->run = [=] {
-    const uint32_t K = a.levels, W = a.tuple_words, tw = (12u << K) / 4u, feat_off = v.feat_off_sparse(), row = v.row_bytes_sparse();
+    const uint32_t K = a.levels, W = a.tuple_words, tw = v.top_bytes_sparse() / 4u, feat_off = v.feat_off_sparse(), row = v.row_bytes_sparse();
+    const bool dense = (v.opt & 2) != 0;  // "sparse_dk_*": K levels of 8-byte records, level K = deep record at byte 16 m + cbase
     const uint32_t* top = reinterpret_cast<const uint32_t*>(a.img);
     const uint32_t* deep = reinterpret_cast<const uint32_t*>(x.deep);
     std::vector<float> leaf(a.n_trees);
@@ -178,8 +179,8 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
       for (uint32_t slot = 0; slot < a.n_trees; ++slot) {
         const uint32_t* tr = top + (size_t)slot * tw;
         uint32_t m = 1;
-        for (uint32_t lvl = 0; lvl + 1 < K; ++lvl) m = 2u * m + right(tr[2u * m], tr[2u * m + 1u]);
-        const uint32_t* rec = tr + (4u << K) / 4u + 4u * (m - (1u << (K - 1)));
+        for (uint32_t lvl = 0; lvl + (dense ? 0u : 1u) < K; ++lvl) m = 2u * m + right(tr[2u * m], tr[2u * m + 1u]);
+        const uint32_t* rec = dense ? deep + (size_t)((16u * m + tr[0]) / 16u) * 4u : tr + (4u << K) / 4u + 4u * (m - (1u << (K - 1)));
         for (int guard = 0; guard < 100; ++guard) {
           const uint32_t r = right(rec[0], rec[1]), nxt = rec[2 + r];
           if (rec[1] & (r ? kSpRightLeaf : kSpLeftLeaf)) {
@@ -218,6 +219,10 @@ const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
     Variant{"sparse_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 0, &launch_sparse},
     Variant{"sparse_k8_u8_t512", kKindSparse, 8, 512, 1, 8, 8, 1, 0, &launch_sparse},
     Variant{"sparse_k9_u8_t128", kKindSparse, 9, 128, 1, 8, 8, 1, 0, &launch_sparse},
+    Variant{"sparse_dk_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 2, &launch_sparse},
+    Variant{"sparse_dk_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2, &launch_sparse},
+    Variant{"sparse_dk_k9_u8_t512", kKindSparse, 9, 512, 1, 8, 8, 1, 2, &launch_sparse},
+    Variant{"sparse_qd_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3, &launch_sparse},
 };
 constexpr int kMockDense = (int)(sizeof(g_mock_variants) / sizeof(g_mock_variants[0]));
 }  // namespace

@@ -520,8 +520,14 @@ def test_a_refused_sparse_option_keeps_the_model(mock):
     assert mock.ddt_set_option(e, b"sparse_top_levels", 10) == -5 and scores_still_right()     # refused again: K = 6 stays
     assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_q_k6")
     # rank-quantised kernels off: the fp32-tile kernel of the same K, same scores; a bad value is refused and changes nothing
+    # (the fp32-tile path prefers the dense-level-K kernel of the same K where one exists; option sparse_dk = 0: 16-byte level K-1 records)
     assert mock.ddt_set_option(e, b"sparse_q16", 0) == 0 and scores_still_right()
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_dk_k6")
+    assert mock.ddt_set_option(e, b"sparse_dk", 0) == 0 and scores_still_right()
     assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_k6")
+    assert mock.ddt_set_option(e, b"sparse_dk", 2) == -1 and scores_still_right()
+    assert mock.ddt_set_option(e, b"sparse_dk", 1) == 0 and scores_still_right()
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_dk_k6")
     assert mock.ddt_set_option(e, b"sparse_q16", 2) == -1 and scores_still_right()
     assert mock.ddt_set_option(e, b"sparse_q16", 1) == 0 and scores_still_right()
     assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_q_k6")

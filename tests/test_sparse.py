@@ -177,17 +177,23 @@ def test_gpu_sparse_bit_exact_all_top_levels_and_orders(eng, shape):
         want = O.score_sparse(s, x)
         for top in (-1, 6, 7, 8, 9, 10):
             for order in (0, 1):
-                for ranked in (1, 0):  # rank-quantised kernels (u16 tile of the q16 pre-pass) and the fp32-tile kernels
+                # rank-quantised kernels (u16 tile of the q16 pre-pass), the fp32-tile kernels with dense level K (all top levels as 8-byte
+                # records in LDS) and with 16-byte level K-1 records
+                for ranked, dense in ((1, 1), (0, 1), (0, 0)):
                     eng.set_option("sparse_q16", ranked)
+                    eng.set_option("sparse_dk", dense)
                     try:
                         got = _gpu_sparse(eng, s, x, top=top, order=order)
                     except ddt.DDTError as ex:  # a forced K whose top images do not fit the LDS next to the feature tile
                         assert ex.code == -5 and top == 10 and F > 60
                         continue
                     name = eng.info().variant_name.decode()
-                    assert ranked or not name.startswith("sparse_q_"), (name, ranked, top)
-                    assert not (ranked and top == -1 and F <= 64) or name.startswith("sparse_q_"), (name, ranked, top)
+                    assert ranked or not name.startswith(("sparse_q_", "sparse_qd_")), (name, ranked, top)
+                    assert dense or not name.startswith(("sparse_dk_", "sparse_qd_")), (name, dense, top)
+                    assert not (ranked and top == -1 and F <= 64) or name.startswith(("sparse_q_", "sparse_qd_")), (name, ranked, top)
+                    assert not (not ranked and dense and top in (-1, 6, 7, 8, 9) and F <= 32) or name.startswith("sparse_dk_"), (name, top)
                     assert np.array_equal(_bits(got), _bits(want)), (shape, cmp_mode, top, order, name)
+        eng.set_option("sparse_dk", 1)
         eng.set_option("sparse_q16", 1)
         want64 = O.score_sparse(s, x, sum_mode=O.SUM_F64_SEQ)
         assert np.array_equal(_bits(_gpu_sparse(eng, s, x, sum_mode=1)), _bits(want64))

@@ -42,7 +42,9 @@ def _walk(top, deep, info, slot, x, miss_bits, tables=None):
     """score_sparse_kernel's walk of one tree slot for one tuple (cmp_mode 0: signed compare of the raw bits); `tables`
     (rank-quantised kernels): the node word is the threshold's rank, the feature value is replaced by ITS rank = number of keys <= x"""
     _, _, _, K, feat_off, row = info
-    t = top[slot * (12 << K) // 4: (slot + 1) * (12 << K) // 4]
+    per_tree = top.size // (info[2] * 8)  # 12 * 2^K bytes, or 8 * 2^K (dense level K: all K levels as 8-byte records)
+    t = top[slot * per_tree: (slot + 1) * per_tree]
+    dense = per_tree == (8 << K) // 4
 
     def right(key, w):
         j = ((w & ADDR) - feat_off) // row
@@ -54,9 +56,14 @@ def _walk(top, deep, info, slot, x, miss_bits, tables=None):
         return np.int32(np.uint32(f).view(np.int32)) >= np.uint32(key).view(np.int32)
 
     m = 1
-    for _ in range(K - 1):
+    for _ in range(K if dense else K - 1):
         m = 2 * m + int(right(int(t[2 * m]), int(t[2 * m + 1])))
-    rec = t[(4 << K) // 4 + 4 * (m - (1 << (K - 1))):][:4]
+    if dense:  # level K: deep record at byte 2 * (8 m) + cbase (mod 2^32), cbase in word 0 of the tree's image
+        off = (16 * m + int(t[0])) & 0xFFFFFFFF
+        assert off % 16 == 0 and off // 16 < deep.shape[0]
+        rec = deep[off // 16]
+    else:
+        rec = t[(4 << K) // 4 + 4 * (m - (1 << (K - 1))):][:4]
     for _ in range(80):
         key, w, lo, hi = (int(v) for v in rec)
         r = bool(right(key, w))
@@ -82,20 +89,20 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
     seen_k = set()
     tables = _rank_tables(s)
     for vid, name in _sparse_variants():
-        ranked = name.startswith("sparse_q_")
+        ranked, dense = name.startswith(("sparse_q_", "sparse_qd_")), name.startswith(("sparse_dk_", "sparse_qd_"))
         K = int(re.search(r"_k(\d+)_", name).group(1))
-        if (ranked, K) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
+        if (ranked, dense, K) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
             continue
-        seen_k.add((ranked, K))
+        seen_k.add((ranked, dense, K))
         top, deep, info = _images(s, vid, order)
-        assert info[3] == K and info[2] * 8 >= T and top.size == info[2] * 8 * (12 << K) // 4
+        assert info[3] == K and info[2] * 8 >= T and top.size == info[2] * 8 * ((8 if dense else 12) << K) // 4
         assert info[5] == (2048 if ranked else 4 * int(name.rsplit("_t", 1)[1]))  # u16 rows of 1024 tuples / fp32 rows of the tile
         for r in range(x.shape[0]):
             for i in range(info[2] * 8):
                 got = _walk(top, deep, info, i, x[r], int(s.params.missing_bits), tables if ranked else None)
                 want = O.traverse_sparse(s, x[r], i) if i < T else 0
                 assert got == want, (name, order, r, i, hex(got), hex(want))
-    assert len([k for k in seen_k if not k[0]]) >= 4 and len([k for k in seen_k if k[0]]) >= 4
+    assert len([k for k in seen_k if not k[0] and not k[1]]) >= 4 and len([k for k in seen_k if k[0]]) >= 4 and len([k for k in seen_k if k[1]]) >= 4
 
 
 def test_hook_rejects_what_the_loader_rejects():
