@@ -154,10 +154,12 @@ def row_sharded_ms(trees: int, n_gpus: int, depth: int = 8, rows: float = 1e8, g
 # ---- part 4: sparse forests (config 4): the vector-memory lane-address ceiling ---------------------------------
 @dataclass
 class SparseCosts:
-    """Measured on one MI355X (profiles/r02_pmc_sparse_k8_t512.md, r02_sparse_sweep_final.json): the deep phase gathers one
-    16-byte record per lane and visit; the vector-memory path takes about ONE lane address per cycle and CU."""
+    """Measured on one MI355X (profiles/r03_sparse_dense_level_k.json, r03_sparse_schedules_and_blocks.json; round 2:
+    r02_pmc_sparse_k8_t512.md): the deep phase gathers one 16-byte record per lane and visit; the vector-memory path takes about ONE
+    lane address per cycle and CU."""
     lane_addresses_per_cycle_per_cu: float = 1.0
-    efficiency_k8: float = 0.72          # 0.44 T gathers/s reached at K = 8 against CUs x clock = 0.61 T/s
+    efficiency_k8: float = 0.87          # 0.53 T gathers/s at K = 8 (two blocks per CU, rotating deep phase) against CUs x clock = 0.61 T/s
+    top_overlapped: bool = True          # two blocks per CU: one block's top phase runs under the other's deep phase (round 2: 0.72, serial)
     lds_visit_rate: float = 7.0e12       # top-phase visits run at the LDS rate of the dense kernels; a minor term
 
 
@@ -169,6 +171,6 @@ def predict_sparse(trees: int, mean_visits_per_tree: float, top_levels: int = 8,
     ceiling = g.cus * g.clock_hz * c.lane_addresses_per_cycle_per_cu
     t_deep = rows * trees * deep / (ceiling * c.efficiency_k8)
     t_top = rows * trees * min(mean_visits_per_tree, top_levels) / c.lds_visit_rate
-    t = t_deep + t_top
+    t = max(t_deep, t_top) if c.top_overlapped else t_deep + t_top
     return {"seconds": t, "mtuples_per_s": rows / t / 1e6, "gather_ceiling_per_s": ceiling, "deep_visits_per_tree": deep,
             "ceiling_mtuples_per_s": (ceiling / (trees * deep) / 1e6) if deep else float("inf")}
