@@ -445,6 +445,7 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
   if (v.kind == kKindQ16) {
     // depth <= 8: two blocks per CU or it is not worth it; deeper trees have no other specialised kernel: one block
     if (W > 32u || v.lds_bytes_q16(W) > (v.levels <= 8 ? kMaxLdsBytes / 2u : kMaxLdsBytes)) return false;
+    if ((v.opt & 4) && e->p.sum_mode == 1u) return false;  // cluster-major image order: not the stream order the fp64 sum is defined on
     return rank_tables(e).max_len <= kQ16MaxTable;
   }
   if (v.kind == kKindStream)
@@ -480,6 +481,12 @@ int auto_variant(const ddt_engine* e) {
   if (tuple_words(e->p) <= 32u && total_trees(e) * e->p.num_levels >= kQ16MinTreeLevels && total_trees(e) < 224u && prepass_plan_exists(e))
     q16_min = total_trees(e);
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
+    // (the cluster-major form only where there is a ring to save -- more than one cluster -- and the sum follows the reference's
+    // order: the fp64 sum of sum_mode 1 runs in stream order, which a permuted image would change)
+    if (e->p.clusters_per_tuple > 1u && e->p.sum_mode != 1u) {
+      const int i = find_variant("q16_d8_c8_u4_gl_s2_cm");
+      if (i >= 0 && variant_fits(variant(i), e)) return i;
+    }
     static const char* qpref[] = {"q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4", "q16_d6_c16_u4_s2", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4_s2", "q16_d7_c8_u4", "q16_d5_c32_u4_s2", "q16_d5_c32_u4", "q16_d3_c128_u8",
                                   "q16_d9_c4_u4", "q16_d10_c4_u4"};
     for (const char* name : qpref) {
@@ -709,21 +716,32 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
   const bool gl = (v.opt & 1) != 0;
   auto rec_off = [&](uint32_t i) { return gl ? (size_t)(i / CT) * CT * tree_words + (size_t)(i % CT) * half : (size_t)i * tree_words; };
   auto leaf_off = [&](uint32_t i) { return gl ? (size_t)(i / CT) * CT * tree_words + (size_t)CT * half + (size_t)(i % CT) * half : (size_t)i * tree_words + half; };
+  // "_cm" variants (opt bit 2): cluster-major image order -- the PU groups of cluster 0 (g % C == 0) first, in their order, then
+  // cluster 1's, ...; padding groups stay behind the last real one.  Tree i sits at image position cm_pos(i).
+  const bool cm = (v.opt & 4) != 0;
+  const uint32_t Cc = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, groups_real = (T + 7u) / 8u;
+  auto cm_pos = [&](uint32_t i) -> uint32_t {
+    if (!cm) return i;
+    const uint32_t g = i / 8u, c = g % Cc;
+    uint32_t start = 0;  // groups of the clusters before c
+    for (uint32_t k = 0; k < c; ++k) start += (groups_real + Cc - 1u - k) / Cc;
+    return (start + g / Cc) * 8u + i % 8u;
+  };
   for (uint32_t i = 0; i < T; ++i) {
-    uint32_t* t = fast.data() + rec_off(i);
+    uint32_t* t = fast.data() + rec_off(cm_pos(i));
     for (uint32_t n = 0; n < nint; ++n) {
       const uint32_t j = m.fidx[(size_t)i * nint + n], key = thr_key(e->p, m.thr[(size_t)i * nint + n]);
       const auto& k = rt.keys[j];
       const uint32_t idx = (uint32_t)(std::lower_bound(k.begin(), k.end(), key, [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; }) - k.begin());
       t[n + 1] = (idx + 1u) | ((j * row) << 16);
     }
-    uint32_t* lf = fast.data() + leaf_off(i);
+    uint32_t* lf = fast.data() + leaf_off(cm_pos(i));
     for (uint32_t l = 0; l < nleaf; ++l) lf[l] = m.leaf[(size_t)i * nleaf + l];
   }
   slow = fast;
   for (uint32_t i = 0; i < T; ++i)
     for (uint32_t n = 0; n < nint; ++n)
-      if (m.mright[(size_t)i * nint + n]) slow[rec_off(i) + n + 1] |= 1u << 16;
+      if (m.mright[(size_t)i * nint + n]) slow[rec_off(cm_pos(i)) + n + 1] |= 1u << 16;
   h.Tpad = Tpad;
   return DDT_OK;
 }
@@ -887,6 +905,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     qa.prepass = tm.prepass;
     qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
     qa.n_pad = (n + 1023) / 1024 * 1024;
+    qa.real_groups = (m.trees() + 7u) / 8u;
     a.aux = &qa;
   }
   const bool timing = e->kernel_timing && e->q_slot == 0;

@@ -75,6 +75,7 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   uint32_t skip_prepass;      // 1 = q / tile_flags already hold this batch (2nd..Kth class of a multi-class model)
   const uint4* prepass_img;   // LDS-resident pre-pass: concatenated LDS images, one per feature group
   PrepassPlan prepass;        // groups == 0: use transpose_kernel + rank_kernel
+  uint32_t real_groups;       // "_cm" kernels: PU groups that hold a real tree, ceil(T / 8) (the image may be padded with EMPTY groups)
 };
 
 // ---------------------------------------------------------------------------------------------------

@@ -977,7 +977,7 @@ __device__ __forceinline__ void walk_trees_q16_s2(const TopRecs<U>& q, const uin
 template <int D, int CT, int U, int OPT = 0>
 __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a, const Q16Aux x) {  // 8 waves per SIMD = two blocks per CU
   constexpr int THREADS = kQTile;
-  constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0, HOTDISP = S2;
+  constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0, HOTDISP = S2, CM = (OPT & 4) != 0;
   static_assert(!S2 || U == 4, "_s2: 4 trees in flight");
   constexpr int TREE_BYTES = GL ? (4 << D) : (8 << D);  // bytes of a tree in LDS (GL: node records only)
   constexpr int CHUNK_BYTES = TREE_BYTES * CT;          // bytes of a chunk in LDS
@@ -1010,7 +1010,14 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   RefAcc<1> ra;
   ra.init();
   double dacc[1] = {0.0};
-  const uint32_t C = a.clusters, lane2 = (((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1);  // see rank_kernel
+  // "_cm" (cluster-major image): the PU groups of cluster 0 come first in the image, then cluster 1's, ... (each in its slot order,
+  // which is all the reference's accumulate needs: FPAggregator.v:79-131 keeps one accumulator per cluster; Core.sv:486-541 adds
+  // the clusters in order afterwards).  The kernel then carries ONE accumulator and a running total instead of a ring of C that is
+  // rotated after every group (8 v_mov per PU group at C = 8): at a cluster's last group, total <- acc + total, acc <- 0.
+  const uint32_t Cc = a.clusters, C = CM ? 1u : Cc, lane2 = (((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1);  // see rank_kernel
+  const uint32_t cm_lg = (uint32_t)__builtin_ctz(Cc | 0x100u), cm_real = x.real_groups;
+  uint32_t cm_groups = 0, cm_cluster = 0, cm_bound = (cm_real + Cc - 1u) >> cm_lg;  // wave-uniform: groups done, cluster, its end
+  float cm_total = 0.f;
   const int SUM1 = (int)a.sum_mode;  // 0 reference order / IEEE adds, 1 fp64, 2 reference order / reference adder
   const bool exact = SUM1 == 2;
 
@@ -1043,6 +1050,16 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
       }                                                                                                \
       if (sum_l != 1) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc, exact_l);                 \
       else fold_leaves<U, 1, 1>(lf, ((PH) + sg) & 1, C, ra, dacc);                                     \
+      if constexpr (CM) {                                                                              \
+        if (U == 8 || (((PH) + sg) & 1) == 1) { /* a PU group is complete */                           \
+          if (++cm_groups == cm_bound) { /* ... and it was its cluster's last */                       \
+            cm_total = exact_l ? radd_exact(ra.a[0][0], cm_total) : ra.a[0][0] + cm_total;            \
+            ra.a[0][0] = 0.f;                                                                          \
+            ++cm_cluster;                                                                              \
+            cm_bound += cm_cluster < Cc ? (cm_real + Cc - 1u - cm_cluster) >> cm_lg : 0u;              \
+          }                                                                                            \
+        }                                                                                              \
+      }                                                                                                \
     }                                                                                                  \
   } while (0)
 
@@ -1086,7 +1103,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
 #undef DDT_QCOMPUTE
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
-  if (row < a.n) a.out[row] = (SUM1 != 1) ? ra.total(0, C, exact) : (float)dacc[0];
+  if (row < a.n) a.out[row] = (SUM1 == 1) ? (float)dacc[0] : CM ? cm_total : ra.total(0, C, exact);
 }
 
 // the rank pre-pass of one batch: q tiles + per-tile missing flags into the workspace of `x` (shared by the perfect-tree q16
@@ -1444,6 +1461,8 @@ static const Variant g_variants[] = {
     // trees, so half the barriers.  1000 trees x 50 M tuples: 56.4 vs 59.4 ms; 8 trees in flight per lane (u8): 58.6
     DDT_QG("q16_d8_c8_u4_gl", 8, 8, 4),
     DDT_QGS("q16_d8_c8_u4_gl_s2", 8, 8, 4),
+    // _cm: cluster-major image order, one accumulator + a running total instead of the ring of C accumulators (sum modes 0 and 2)
+    DDT_QO("q16_d8_c8_u4_gl_s2_cm", 8, 8, 4, 7),
     // _s2 on the layouts that keep their leaves in LDS (depths 5-7): 100 x d6 x 28 features, 10 M tuples: 1.297 vs 1.333 ms
     DDT_QO("q16_d6_c16_u4_s2", 6, 16, 4, 2),
     DDT_QO("q16_d7_c8_u4_s2", 7, 8, 4, 2),

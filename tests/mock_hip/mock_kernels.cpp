@@ -123,8 +123,19 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
   op->cost = (double)a.n * g_cost_row;
   op->run = [=] {
     const uint32_t D = a.levels, half = 1u << D, tw = 2u * half, CT = (uint32_t)v.chunk_trees, row = v.tile() * 2u;
-    const bool gl = (v.opt & 1) != 0;
-    std::vector<float> leaf(a.n_trees);
+    const bool gl = (v.opt & 1) != 0, cm = (v.opt & 4) != 0;
+    std::vector<float> leaf(a.n_trees), img_order(a.n_trees);
+    // "_cm" images: PU groups in cluster-major order (csrc/ddt_engine.cpp pack_image_q16); original group g sits at position pos[g]
+    std::vector<uint32_t> pos(a.n_trees / 8u);
+    for (uint32_t g = 0; g < (uint32_t)pos.size(); ++g) {
+      pos[g] = g;
+      if (cm && g < x.real_groups) {
+        const uint32_t Cc = a.clusters, c = g % Cc;
+        uint32_t start = 0;
+        for (uint32_t k = 0; k < c; ++k) start += (x.real_groups + Cc - 1u - k) / Cc;
+        pos[g] = start + g / Cc;
+      }
+    }
     for (uint64_t i = 0; i < a.n; ++i) {
       const bool slow = x.tile_flags[i / 1024] != 0u;
       const uint32_t* img = reinterpret_cast<const uint32_t*>(slow ? x.img_slow : a.img);
@@ -141,8 +152,9 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
           if (slow && f == 0xFFFFu) right = ((nd >> 16) & 1u) != 0u;
           m = 2u * m + (right ? 1u : 0u);
         }
-        leaf[t] = f_of(img[leaf_off + m - half]);
+        img_order[t] = f_of(img[leaf_off + m - half]);
       }
+      for (uint32_t t = 0; t < a.n_trees; ++t) leaf[t] = img_order[pos[t / 8u] * 8u + t % 8u];  // back to the stream order the sum is defined on
       a.out[i] = reduce(leaf.data(), a.n_trees, a.clusters, a.sum_mode);
     }
   };
@@ -201,6 +213,7 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
 // lists fall through to what exists
 const Variant g_mock_variants[] = {
     Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_records},
+    Variant{"q16_d8_c8_u4_gl_s2_cm", kKindQ16, 8, 1024, 1, 8, 4, 1, 7, &launch_q16},
     Variant{"q16_d8_c8_u4_gl_s2", kKindQ16, 8, 1024, 1, 8, 4, 1, 3, &launch_q16},
     Variant{"q16_d8_c8_u4_gl", kKindQ16, 8, 1024, 1, 8, 4, 1, 1, &launch_q16},
     Variant{"q16_d8_c4_u4", kKindQ16, 8, 1024, 1, 4, 4, 1, 0, &launch_q16},

@@ -534,6 +534,34 @@ def test_a_refused_sparse_option_keeps_the_model(mock):
     mock.ddt_destroy(e)
 
 
+@pytest.mark.parametrize("T,clusters", [(1000, 8), (999, 8), (520, 4), (130, 2), (129, 8), (17, 8), (3, 8), (250, 1)])
+def test_cluster_major_image_order(mock, T, clusters):
+    """`_cm` kernels: the packer stores the PU groups of a cluster together (cluster-major), the launch tells the kernel how many PU
+    groups are real, and the scores are the reference-order sums -- checked through the CPU model of the kernel, which reads the
+    packed image in that order; the fp64 sum (stream order) refuses such an image; the automatic choice takes it exactly when
+    there is more than one cluster."""
+    mock.mock_reset(0, 0, 8)
+    D, F, n = 8, 32, 400
+    m, x = O.gen_model(T, D, F, 1, clusters=clusters), O.gen_tuples(0, n, F, 1)
+    out = np.zeros(n, np.float32)
+    e = _engine(mock)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        p = ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode)
+        _load(mock, e, m, p, "q16_d8_c8_u4_gl_s2_cm")
+        assert mock.ddt_score(e, x.ctypes.data, n, out.ctypes.data) == 0, mock.ddt_last_error(e)
+        assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=ref))), (T, clusters, sum_mode)
+    p64 = ddt.make_params(T, D, F, clusters=clusters, sum_mode=1)
+    assert mock.ddt_set_option(e, b"variant", _variant(mock, "q16_d8_c8_u4_gl_s2_cm")) == 0   # (a refused forced variant keeps the loaded model)
+    rc = mock.ddt_load_model_shard(e, C.byref(p64), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8, 0, 1)
+    assert rc == -5, rc
+    if T * D >= 224 * 8:
+        _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters), None)
+        info = ddt.Info()
+        assert mock.ddt_get_info(e, C.byref(info)) == 0
+        assert info.variant_name.decode() == ("q16_d8_c8_u4_gl_s2_cm" if clusters > 1 else "q16_d8_c8_u4_gl_s2")
+    mock.ddt_destroy(e)
+
+
 @pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
 def test_registered_host_buffers_skip_the_staging(mock, policy, seed):
     """ddt_host_register: tuples and scores move straight between the caller's (pinned) buffers and the device; same results, many

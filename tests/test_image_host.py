@@ -39,7 +39,9 @@ def _image(p, w, f, variant):
                                  slow.ctypes.data if slow.size else None, img.size, tab.ctypes.data if tab.size else None, tab.size, C.byref(info))
     assert rc == 0, rc
     keys = ("words", "Tpad", "kind", "opt", "chunk_trees", "tile", "feat_off", "row", "Kpad", "W", "variant", "table_words")
-    return img, slow, tab, dict(zip(keys, (int(x) for x in info)))
+    nfo = dict(zip(keys, (int(x) for x in info)))
+    nfo["T"], nfo["clusters"] = int(p.num_trees), int(p.clusters_per_tuple)  # what the cluster-major ("_cm") image order depends on
+    return img, slow, tab, nfo
 
 
 def _ieee_key(b):
@@ -102,7 +104,11 @@ def _walk_q16(img, nfo, D, rank, slow):
     tw = 2 * half
     gl = nfo["opt"] & 1
     out = np.zeros((n, nfo["Tpad"]), np.uint32)
-    for i in range(nfo["Tpad"]):
+    for tree in range(nfo["Tpad"]):
+        i = tree
+        g, C_, G = tree // 8, nfo["clusters"], (nfo["T"] + 7) // 8
+        if nfo["opt"] & 4 and g < G:  # "_cm": the real PU groups in cluster-major order (cluster = group % C), each cluster's in their order
+            i = (sum((G + C_ - 1 - k) // C_ for k in range(g % C_)) + g // C_) * 8 + tree % 8
         rec_off = (i // CT) * CT * tw + (i % CT) * half if gl else i * tw
         leaf_off = (i // CT) * CT * tw + CT * half + (i % CT) * half if gl else i * tw + half
         m = np.ones(n, np.int64)
@@ -115,7 +121,7 @@ def _walk_q16(img, nfo, D, rank, slow):
             if slow:
                 right = np.where(f == 0xFFFF, ((rec >> 16) & 1) != 0, right)
             m = 2 * m + right.astype(np.int64)
-        out[:, i] = img[leaf_off + m - half]
+        out[:, tree] = img[leaf_off + m - half]
     return out
 
 
@@ -150,7 +156,7 @@ def _check(T, D, F, variant_name, dist, cmp_mode=0, n=96, expect_auto=None):
 
 
 def test_headline_model_takes_the_gl_rank_quantised_image():
-    nfo = _check(1000, 8, 32, None, 0, n=48, expect_auto="q16_d8_c8_u4_gl_s2")
+    nfo = _check(1000, 8, 32, None, 0, n=48, expect_auto="q16_d8_c8_u4_gl_s2_cm")   # 8 clusters: cluster-major image, no accumulator ring
     assert nfo["kind"] == Q16 and nfo["opt"] & 1 and nfo["chunk_trees"] == 8 and nfo["Tpad"] == 1000 and nfo["tile"] == 1024
 
 
@@ -159,7 +165,7 @@ def test_eight_way_shard_of_the_headline_model():
     assert nfo["Tpad"] == 128                                          # whole chunks of 8: three EMPTY trees
 
 
-@pytest.mark.parametrize("name,T,D,F", [("q16_d8_c8_u4_gl_s2", 37, 8, 32), ("q16_d8_c8_u4_gl", 37, 8, 32), ("q16_d8_c4_u4", 37, 8, 32), ("q16_d6_c16_u4", 100, 6, 28),
+@pytest.mark.parametrize("name,T,D,F", [("q16_d8_c8_u4_gl_s2_cm", 37, 8, 32), ("q16_d8_c8_u4_gl_s2_cm", 300, 8, 32), ("q16_d8_c8_u4_gl_s2_cm", 1000, 8, 20), ("q16_d8_c8_u4_gl_s2", 37, 8, 32), ("q16_d8_c8_u4_gl", 37, 8, 32), ("q16_d8_c4_u4", 37, 8, 32), ("q16_d6_c16_u4", 100, 6, 28),
                                         ("q16_d4_c64_u8", 9, 4, 16), ("q16_d3_c128_u8", 130, 3, 7), ("q16_d10_c4_u4", 5, 10, 20)])
 def test_rank_quantised_images_with_missing_values(name, T, D, F):
     _check(T, D, F, name, 1)

@@ -28,7 +28,8 @@ def _params(m, sum_mode=0):
     return ddt.make_params(p.num_trees, p.num_levels, p.num_features, p.missing_bits, p.cmp_mode, p.clusters_per_tuple, sum_mode)
 
 
-@pytest.mark.parametrize("kernel", ["q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4"])  # levels 0-1 from SGPRs / leaves gathered from global memory / leaves staged in LDS
+# cluster-major image + one accumulator / levels 0-1 from SGPRs / leaves gathered from global memory / leaves staged in LDS
+@pytest.mark.parametrize("kernel", ["q16_d8_c8_u4_gl_s2_cm", "q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4"])
 @pytest.mark.parametrize("cmp_mode", [0, 1])
 def test_values_on_and_next_to_thresholds(cmp_mode, kernel):
     T, D, F, n = 200, 8, 32, 4096
@@ -45,12 +46,33 @@ def test_values_on_and_next_to_thresholds(cmp_mode, kernel):
     e = ddt.Engine(0)
     e.set_option("variant", _variant(kernel))
     want = O.score(m, x)
-    for sum_mode in (0, 1):
+    for sum_mode in (0, 1, 2):
+        if kernel.endswith("_cm") and sum_mode == 1:  # the fp64 sum runs in stream order: a cluster-major image is refused for it
+            with pytest.raises(ddt.DDTError):
+                e.load_model(_params(m, sum_mode), m.wlines, m.flines)
+            continue
         e.load_model(_params(m, sum_mode), m.wlines, m.flines)
         assert e.info().variant_name.decode() == kernel
         got = e.score(x)
-        ref = want if sum_mode == 0 else O.score(m, x, sum_mode=O.SUM_F64_SEQ)
-        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        ref = O.score(m, x, sum_mode=(O.SUM_REF_NATIVE, O.SUM_F64_SEQ, O.SUM_REF_FLOPOCO)[sum_mode])
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (kernel, sum_mode)
+    e.close()
+
+
+@pytest.mark.parametrize("T,clusters", [(1000, 8), (999, 8), (520, 4), (130, 2), (129, 8), (17, 8), (8, 4), (3, 8), (250, 1)])
+def test_cluster_major_image_equals_the_ring(T, clusters):
+    """`_cm` kernels: the PU groups of a cluster are stored together and one accumulator + a running total replace the ring of C
+    accumulators; every (tree count, cluster count) -- partial last group, fewer groups than clusters, one cluster -- must give the
+    reference-order sums bit for bit, with IEEE adds and with the reference adder, also on tiles with missing values."""
+    D, F, n = 8, 32, 3000
+    m = O.gen_model(T, D, F, dist=1, clusters=clusters)
+    x = O.gen_tuples(1, n, F, dist=1)
+    e = ddt.Engine(0)
+    e.set_option("variant", _variant("q16_d8_c8_u4_gl_s2_cm"))
+    for sum_mode, ref_mode in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        e.load_model(_params(m, sum_mode), m.wlines, m.flines)
+        assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm"
+        assert np.array_equal(e.score(x).view(np.uint32), O.score(m, x, sum_mode=ref_mode).view(np.uint32)), (T, clusters, sum_mode)
     e.close()
 
 
@@ -58,15 +80,15 @@ def test_auto_selection_and_fallbacks():
     e = ddt.Engine(0)
     w, f = ddt.synth_model(1000, 8, 32)
     e.load_model(ddt.make_params(1000, 8, 32), w, f)
-    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2"        # many trees: the pre-pass pays off
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm"     # many trees: the pre-pass pays off (8 clusters: cluster-major image)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)          # 125 trees per engine (8-way shard): all rank tables
-    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2"        # fit LDS together -> fused pre-pass -> q16 still pays
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm"     # fit LDS together -> fused pre-pass -> q16 still pays
     _prepass(e, -1)                                                 # with the transpose + rank kernels the fixed pre-pass cost is too high
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)
     assert e.info().variant_name.decode() == "d8_t1024_r1_c4_u4_dma_f"
     _prepass(e, 0)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 12)         # 84 trees x 8 levels >= 480: q16 with the LDS-resident pre-pass
-    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2" and e.info().prepass_groups in (1, 2, 4, 8)
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm" and e.info().prepass_groups in (1, 2, 4, 8)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 20)         # 50 trees: below the break-even either way
     assert e.info().prepass_groups == 0
     with pytest.raises(ddt.DDTError):
