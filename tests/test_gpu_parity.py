@@ -36,8 +36,11 @@ def _bits(a):
 def _gpu_score(eng, m, x, sum_mode=0, variant=-1, shard=(0, 1)):
     import torch
 
-    eng.set_option("variant", variant)
+    # load with the automatic choice first, then force the kernel: forcing it while the PREVIOUS call's model is still loaded would
+    # re-pack that model, and a kernel may refuse its sum mode (the cluster-major "_cm" image and the fp64 sum)
+    eng.set_option("variant", -1)
     eng.load_model(_params(m, sum_mode), m.wlines, m.flines, *shard)
+    eng.set_option("variant", variant)
     d = torch.from_numpy(x.view(np.int32)).cuda()
     out = eng.score_device(d)
     torch.cuda.synchronize()

@@ -64,7 +64,7 @@ def test_cluster_major_image_equals_the_ring(T, clusters):
     """`_cm` kernels: the PU groups of a cluster are stored together and one accumulator + a running total replace the ring of C
     accumulators; every (tree count, cluster count) -- partial last group, fewer groups than clusters, one cluster -- must give the
     reference-order sums bit for bit, with IEEE adds and with the reference adder, also on tiles with missing values."""
-    D, F, n = 8, 32, 3000
+    D, F, n = 8, 32, 1200
     m = O.gen_model(T, D, F, dist=1, clusters=clusters)
     x = O.gen_tuples(1, n, F, dist=1)
     e = ddt.Engine(0)

@@ -16,5 +16,5 @@ python tools/prof_summary.py ${R}_final_bench_cfg4 --stats $E/stats_cfg4 --pmc $
 grep "score_q16\|rank_kernel\|transpose_k\|score_sparse" profiles/${R}_final_bench_cfg3.md profiles/${R}_final_bench_cfg4.md | cut -c1-200 | head
 if [ -d $E/pmc_q16 ]; then
   python tools/prof_summary.py ${R}_pmc_q16_gl_s2 --stats $E/pmc_q16/stats --pmc $E/pmc_q16/pmc1 $E/pmc_q16/pmc2 $E/pmc_q16/pmc3 --kernel score_q16 --rows 8000000 \
-    --cmd "rocprofv3 --pmc <set> -- python tools/sweep.py --shapes 1000x8x32x8000000 --only q16_d8_c8_u4_gl_s2 (3 separate passes)" > /dev/null
+    --cmd "rocprofv3 --pmc <set> -- python tools/sweep.py --shapes 1000x8x32x8000000 --only q16_d8_c8_u4_gl_s2_cm (3 separate passes)" > /dev/null
 fi

@@ -38,7 +38,7 @@ def main():
         if f2 or w2:
             pre[name] = {"FETCH_SIZE": kib(f2, "FETCH_SIZE"), "WRITE_SIZE": kib(w2, "WRITE_SIZE")}
     step = 2 * fr + wr + sum(2 * v["FETCH_SIZE"] + v["WRITE_SIZE"] for v in pre.values())
-    j = {"rows": 100000000, "trees": 1000, "kernel": "score_q16_kernel<8,8,4,3> (q16_d8_c8_u4_gl_s2)",
+    j = {"rows": 100000000, "trees": 1000, "kernel": "score_q16_kernel<8,8,4,7> (q16_d8_c8_u4_gl_s2_cm)",
          "fetch_bytes_raw_per_launch": fr, "fetch_bytes_x2_corrected_per_launch": 2 * fr, "write_bytes_per_launch": wr,
          "hbm_bytes_per_launch": 2 * fr + wr,
          "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), averaged over the launches of the scoring kernel; FETCH_SIZE "
