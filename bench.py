@@ -270,6 +270,14 @@ def main():
             scaling_detail = {"shard_compute_only_ms": round(cdt * 1e3, 4), "combine_overhead_ms": round(ms_per_step - cdt * 1e3, 4),
                               "trees_on_this_rank": int(info.tree_end - info.tree_begin), "chunk_rows": args.chunk_rows,
                               "note": "ms_per_step minus one pass of the rank's shard over all tuples with no collective (max over ranks)"}
+            # rank 0's kernels in such a pass, timed by the library with HIP events on the launch stream: the `roofline` object of an
+            # N>1 line (the dominant kernel = this rank's shard of the scoring kernel; one more pass, outside the timed region)
+            eng.set_option("kernel_timing", 1)
+            eng.score_device(tuples, out=out)
+            st = eng.stats()
+            kernel_ms.append((st.last_prepass_ms, st.last_score_ms))
+            eng.set_option("kernel_timing", 0)
+            fence()
         except Exception as ex:  # diagnostics must never cost the headline line
             scaling_detail = {"error": repr(ex)}
 
@@ -277,7 +285,7 @@ def main():
     # tuples in, scores out, model once; config 5 writes the K per-class sums and the label (argmax not fused)
     alg_bytes_per_launch = N * (4 * F + 4 * (classes + 1 if classes > 1 else 1)) + int(info.model_bytes_unpadded)
     roofline = None
-    if not multi and kernel_ms:
+    if kernel_ms:
         pre_ms = sum(a for a, _ in kernel_ms) / len(kernel_ms)
         k_ms = sum(b for _, b in kernel_ms) / len(kernel_ms)  # the dominant (scoring) kernel
         if classes > 1:  # the library times the LAST class's launch: the K launches are alike, the pre-pass ran once with the first
@@ -285,7 +293,7 @@ def main():
         ach = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic_cfg4.json" if sparse else "pmc_traffic.json")
-        if os.path.exists(pmc):  # HBM bytes per launch of this kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of THIS command, collected in its own run
+        if os.path.exists(pmc) and not multi:  # HBM bytes per launch of this kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of THIS command, collected in its own run
             try:
                 pj = json.load(open(pmc))
                 if pj.get("rows") == N and pj.get("trees") == T:
@@ -301,6 +309,9 @@ def main():
                     "prepass_groups": info.prepass_groups,  # feature groups of the LDS-resident pre-pass (0: transpose + rank kernels / n.a.)
                     "alg_bytes_per_launch": alg_bytes_per_launch,
                     "device": {"cus": info.num_cus, "clock_mhz": round(clock_hz / 1e6, 1), "lds_bytes_per_cu": info.lds_bytes_per_cu}}
+        if multi:
+            roofline["scope"] = (f"rank 0's shard ({int(info.tree_end - info.tree_begin)} of {T} trees, all {N} tuples): one pass with no collective, "
+                                 "behind the timed region; achieved / frac are per GPU")
         if sparse:
             # leaf depth of the model = node visits per tuple and tree: measured on a sample with the oracle below
             roofline["binding_resource"] = ("vector-memory gathers of the deep phase: one 16-byte load per lane and visit "

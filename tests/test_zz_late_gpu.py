@@ -155,6 +155,9 @@ def test_multi_gpu_branch_in_a_one_rank_communicator(extra):
     assert "error" not in d, d
     assert d["shard_compute_only_ms"] > 0 and d["trees_on_this_rank"] == 200
     assert abs(d["combine_overhead_ms"] - (j["ms_per_step"] - d["shard_compute_only_ms"])) < 1e-3
+    ro = j["roofline"]                                     # N>1 lines carry the per-rank roofline of the shard's scoring kernel
+    assert ro["kernel_ms"] > 0 and ro["kernel_ms"] + ro["prepass_ms"] <= d["shard_compute_only_ms"] * 1.5 and "rank 0's shard" in ro["scope"]
+    assert ro["traffic"] is None and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-4
     o = j["other_modes"]
     assert "error" not in o and "status" not in o, o
     assert o["tree_sharded_chain_ms"] > 0 and o["tree_sharded_allreduce_untapered_ms"] > 0 and o["row_sharded_ms"] > 0
