@@ -97,9 +97,6 @@ def main():
                          "driven from Python through torch.distributed (needed for --backend gloo)")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant id (-1 = engine's choice)")
     ap.add_argument("--sum-mode", type=int, default=0)
-    ap.add_argument("--overlap-rows", type=int, default=None,
-                    help="engine option prepass_overlap_rows (rank-quantised kernels): rows per piece of the pre-pass / scoring overlap, "
-                         "-1 = automatic, 0 = one launch (default: the library's setting)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend used for the barrier / timing reduction (and for --collectives torch); "
                          "gloo lets N ranks share one GPU for a functional test")
@@ -167,8 +164,6 @@ def main():
     W = ddt.tuple_words(F)
     eng = ddt.Engine(local)
     eng.set_option("variant", args.variant)
-    if args.overlap_rows is not None:
-        eng.set_option("prepass_overlap_rows", args.overlap_rows)
     rows_mode = world > 1 and args.shard == "rows"
     shard = (0, 1) if rows_mode else (rank, world)
     if sparse:

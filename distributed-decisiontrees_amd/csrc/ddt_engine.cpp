@@ -883,27 +883,6 @@ int feeder_reserve(ddt_engine* e, size_t rows, size_t words, size_t outs) {
 
 int ensure_q16_workspace(ddt_engine* e, size_t n);
 
-// the rank-quantised kernels' view of the engine's workspace slot e->q_slot (grown to n rows) and of the rank tables
-static int fill_q16_aux(ddt_engine* e, const Ensemble& m, size_t n, bool reuse_prepass, Q16Aux* qa) {
-  int rc = ensure_q16_workspace(e, n);
-  if (rc) return rc;
-  qa->xT = reinterpret_cast<uint32_t*>(e->q_xT[e->q_slot]);
-  qa->q = reinterpret_cast<uint16_t*>(e->q_q[e->q_slot]);
-  qa->tile_flags = reinterpret_cast<uint32_t*>(e->q_flags[e->q_slot]);
-  const Ensemble& tm = e->ens[0];  // the rank tables are shared by all classes and owned by the first ensemble
-  qa->tables = reinterpret_cast<const uint32_t*>(tm.d_tables);
-  qa->tabP = reinterpret_cast<const uint32_t*>(tm.d_tabK);
-  qa->tabS = reinterpret_cast<const uint16_t*>(tm.d_tabS);
-  qa->Kpad = tm.Kpad;
-  qa->skip_prepass = reuse_prepass ? 1u : 0u;
-  qa->prepass_img = reinterpret_cast<const uint4*>(tm.d_prepass);
-  qa->prepass = tm.prepass;
-  qa->img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
-  qa->n_pad = (n + 1023) / 1024 * 1024;
-  qa->real_groups = (m.trees() + 7u) / 8u;
-  return DDT_OK;
-}
-
 int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t n, float* d_scores, hipStream_t s,
                  bool reuse_prepass = false) {
   ScoreArgs a;
@@ -911,8 +890,22 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
   const Variant& v = variant(e->variant_id);
   Q16Aux qa;
   if (v.kind == kKindQ16) {
-    int rc = fill_q16_aux(e, m, n, reuse_prepass, &qa);
+    int rc = ensure_q16_workspace(e, n);
     if (rc) return rc;
+    qa.xT = reinterpret_cast<uint32_t*>(e->q_xT[e->q_slot]);
+    qa.q = reinterpret_cast<uint16_t*>(e->q_q[e->q_slot]);
+    qa.tile_flags = reinterpret_cast<uint32_t*>(e->q_flags[e->q_slot]);
+    const Ensemble& tm = e->ens[0];  // the rank tables are shared by all classes and owned by the first ensemble
+    qa.tables = reinterpret_cast<const uint32_t*>(tm.d_tables);
+    qa.tabP = reinterpret_cast<const uint32_t*>(tm.d_tabK);
+    qa.tabS = reinterpret_cast<const uint16_t*>(tm.d_tabS);
+    qa.Kpad = tm.Kpad;
+    qa.skip_prepass = reuse_prepass ? 1u : 0u;
+    qa.prepass_img = reinterpret_cast<const uint4*>(tm.d_prepass);
+    qa.prepass = tm.prepass;
+    qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
+    qa.n_pad = (n + 1023) / 1024 * 1024;
+    qa.real_groups = (m.trees() + 7u) / 8u;
     a.aux = &qa;
   }
   const bool timing = e->kernel_timing && e->q_slot == 0;
@@ -929,100 +922,9 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
   if (timing) {
     HIP_TRY(e, hipEventRecord(e->tev[2], s));
     e->timing_pending = true;
-    e->ov_timed_pieces = 0;
   }
   e->st.kernel_launches++;
   return DDT_OK;
-}
-
-void overlap_free(ddt_engine* e) {
-  if (e->ov_stream) (void)hipStreamDestroy(e->ov_stream);
-  e->ov_stream = nullptr;
-  for (hipEvent_t* ev : {&e->ov_fork, &e->ov_ready[0], &e->ov_ready[1], &e->ov_free[0], &e->ov_free[1]}) {
-    if (*ev) (void)hipEventDestroy(*ev);
-    *ev = nullptr;
-  }
-  for (hipEvent_t ev : e->ov_tev) (void)hipEventDestroy(ev);
-  e->ov_tev.clear();
-  e->ov_timed_pieces = 0;
-  for (bool& b : e->ov_free_recorded) b = false;
-}
-
-// Pre-pass / scoring overlap (rank-quantised perfect-tree kernels, option "prepass_overlap_rows"): the two kernels of this path use
-// different parts of the chip -- the rank pre-pass streams the fp32 tuples through HBM, the scoring kernel walks LDS-resident trees -- so
-// the batch is cut into pieces and the pre-pass of piece k+1 runs on the engine's own stream while the scoring kernel of piece k runs on
-// the caller's.  Two workspace slots: the pre-pass of piece k waits for the scoring kernel that read slot k & 1 last (also across calls
-// and caller streams), the scoring kernel of piece k for its pre-pass.  Everything the caller may wait for is on ITS stream.
-static int score_overlapped(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t n, float* d_scores, hipStream_t s, size_t piece_rows) {
-  const size_t piece = (piece_rows + 1023) / 1024 * 1024, W = tuple_words(e->p);
-  const size_t pieces = (n + piece - 1) / piece;
-  if (!e->ov_stream) {
-    int least = 0, greatest = 0;
-    if (e->overlap_priority) HIP_TRY(e, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIP_TRY(e, hipStreamCreateWithPriority(&e->ov_stream, hipStreamNonBlocking, e->overlap_priority ? greatest : 0));
-    for (hipEvent_t* ev : {&e->ov_fork, &e->ov_ready[0], &e->ov_ready[1], &e->ov_free[0], &e->ov_free[1]})
-      HIP_TRY(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
-  }
-  const bool timing = e->kernel_timing;
-  if (timing) {
-    try {
-      e->ov_tev.reserve(4 * pieces);
-    } catch (const std::bad_alloc&) {
-      return fail(e, DDT_ENOMEM, "timing events of %zu pieces", pieces);
-    }
-    while (e->ov_tev.size() < 4 * pieces) {
-      hipEvent_t ev = nullptr;
-      HIP_TRY(e, hipEventCreate(&ev));
-      e->ov_tev.push_back(ev);
-    }
-    e->ov_timed_pieces = 0;
-    e->timing_pending = false;
-  }
-  const Variant& v = variant(e->variant_id);
-  const uint32_t* tup = reinterpret_cast<const uint32_t*>(d_tuples);
-  HIP_TRY(e, hipEventRecord(e->ov_fork, s));  // the tuples may be produced by work the caller queued on its stream
-  HIP_TRY(e, hipStreamWaitEvent(e->ov_stream, e->ov_fork, 0));
-  struct SlotGuard {  // every exit leaves the engine on workspace slot 0
-    ddt_engine* e;
-    ~SlotGuard() { e->q_slot = 0; }
-  } slot_guard{e};
-  int rc = DDT_OK;
-  size_t k = 0;
-  for (size_t off = 0; off < n && rc == DDT_OK; off += piece, ++k) {
-    const size_t cn = n - off < piece ? n - off : piece;
-    const int slot = (int)(k & 1u);
-    e->q_slot = kOverlapSlot0 + slot;
-    ScoreArgs a;
-    fill_args(e, m, tup + off * W, cn, d_scores + off, &a);
-    Q16Aux qa;
-    if ((rc = fill_q16_aux(e, m, cn, false, &qa))) break;  // (grows the slot on first use: synchronises the device)
-    a.aux = &qa;
-    if (e->ov_free_recorded[slot]) HIP_TRY(e, hipStreamWaitEvent(e->ov_stream, e->ov_free[slot], 0));
-    if (timing) HIP_TRY(e, hipEventRecord(e->ov_tev[4 * k + 0], e->ov_stream));
-    (void)hipGetLastError();
-    hipError_t r = launch_q16_prepass(a, qa, e->ov_stream);
-    if (r != hipSuccess) {
-      rc = fail(e, DDT_EHIP, "rank pre-pass -> %s", hipGetErrorString(r));
-      break;
-    }
-    if (timing) HIP_TRY(e, hipEventRecord(e->ov_tev[4 * k + 1], e->ov_stream));
-    HIP_TRY(e, hipEventRecord(e->ov_ready[slot], e->ov_stream));
-    HIP_TRY(e, hipStreamWaitEvent(s, e->ov_ready[slot], 0));
-    if (timing) HIP_TRY(e, hipEventRecord(e->ov_tev[4 * k + 2], s));
-    qa.skip_prepass = 1u;
-    r = v.launch(a, v, s);
-    if (r != hipSuccess) {
-      rc = fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
-      break;
-    }
-    if (timing) HIP_TRY(e, hipEventRecord(e->ov_tev[4 * k + 3], s));
-    HIP_TRY(e, hipEventRecord(e->ov_free[slot], s));
-    e->ov_free_recorded[slot] = true;
-    e->st.kernel_launches++;
-    if (timing) e->ov_timed_pieces = k + 1;
-  }
-  if (timing && rc == DDT_OK) e->timing_pending = true;
-  return rc;
 }
 
 // class scores [K][n] into d_class_scores, then argmax into d_labels (if non-NULL)
@@ -1057,14 +959,7 @@ int launch_classify(ddt_engine* e, const void* d_tuples, size_t n, float* d_clas
 }
 
 int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
-  if (!e->sparse) {
-    // (only calls on workspace slot 0: the feeder's chunks already run on three streams with a slot each)
-    if (e->q_slot == 0 && variant(e->variant_id).kind == kKindQ16) {
-      const size_t piece = e->overlap_auto ? std::max<size_t>((n + kOverlapAutoPieces - 1) / kOverlapAutoPieces, kOverlapAutoMinRows) : e->overlap_rows;
-      if (piece && n > piece) return score_overlapped(e, e->ens[0], d_tuples, n, d_scores, s, piece);
-    }
-    return launch_score(e, e->ens[0], d_tuples, n, d_scores, s);
-  }
+  if (!e->sparse) return launch_score(e, e->ens[0], d_tuples, n, d_scores, s);
   const bool timing = e->kernel_timing && e->q_slot == 0;
   if (timing) {
     for (hipEvent_t& ev : e->tev)
@@ -1077,7 +972,6 @@ int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_
   if (timing) {
     HIP_TRY(e, hipEventRecord(e->tev[2], s));
     e->timing_pending = true;
-    e->ov_timed_pieces = 0;
   }
   e->st.kernel_launches++;
   return DDT_OK;
@@ -1214,7 +1108,6 @@ void ddt_destroy(ddt_engine* e) {
     if (e->fe_in[b]) (void)hipEventDestroy(e->fe_in[b]);
   }
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
-  overlap_free(e);
   delete e->pool;
   for (const auto& r : e->pinned) (void)hipHostUnregister(r.first);  // ranges the caller forgot to hand back
   if (e->ws) (void)hipFree(e->ws);
@@ -1502,22 +1395,6 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
 int ddt_get_stats(const ddt_engine* e_, ddt_stats* out) {
   if (!e_ || !out) return DDT_EINVAL;
   ddt_engine* e = const_cast<ddt_engine*>(e_);  // resolving pending event times is a logically-const refresh
-  if (e->timing_pending && e->ov_timed_pieces) {  // an overlapped call: the pieces' kernel times, summed (they overlap in wall time)
-    double pre = 0.0, sc = 0.0;
-    bool ok = hipEventSynchronize(e->ov_tev[4 * e->ov_timed_pieces - 1]) == hipSuccess;
-    for (size_t k = 0; ok && k < e->ov_timed_pieces; ++k) {
-      float a = 0.f, b = 0.f;
-      ok = hipEventElapsedTime(&a, e->ov_tev[4 * k], e->ov_tev[4 * k + 1]) == hipSuccess &&
-           hipEventElapsedTime(&b, e->ov_tev[4 * k + 2], e->ov_tev[4 * k + 3]) == hipSuccess;
-      pre += a;
-      sc += b;
-    }
-    if (ok) {
-      e->st.last_prepass_ms = pre;
-      e->st.last_score_ms = sc;
-    }
-    e->timing_pending = false;
-  }
   if (e->timing_pending) {
     float pre = 0.f, sc = 0.f;
     if (hipEventSynchronize(e->tev[2]) == hipSuccess && hipEventElapsedTime(&pre, e->tev[0], e->tev[1]) == hipSuccess &&
@@ -1622,16 +1499,7 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     if (!ranked || value == 0) return DDT_OK;  // nothing to reserve on the other paths
     DeviceGuard dg(e->device);
     if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
-    int rc = ensure_q16_workspace(e, (size_t)value);
-    // ... and the two slots of the pre-pass / scoring overlap, when it is on, for the pieces of such a call
-    const size_t piece = e->overlap_auto ? std::max<size_t>(((size_t)value + kOverlapAutoPieces - 1) / kOverlapAutoPieces, kOverlapAutoMinRows) : e->overlap_rows;
-    if (!e->sparse && piece && (size_t)value > piece)
-      for (int k = 0; k < kOverlapSlots && rc == DDT_OK; ++k) {
-        e->q_slot = kOverlapSlot0 + k;
-        rc = ensure_q16_workspace(e, piece);
-        e->q_slot = 0;
-      }
-    return rc;
+    return ensure_q16_workspace(e, (size_t)value);
   }
   if (!strcmp(key, "stream_blocks_per_cu")) {  // persistent stream kernel: blocks per CU, 0 (default) = the resident number
     if (value < 0 || value > 16) return fail(e, DDT_EINVAL, "stream_blocks_per_cu %lld not in 0..16", (long long)value);
@@ -1640,23 +1508,6 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   }
   if (!strcmp(key, "class_streams")) {  // 1 (default): the classes of a multi-class model alternate between two streams; 0: one stream
     e->class_streams = value != 0;
-    return DDT_OK;
-  }
-  if (!strcmp(key, "prepass_overlap_rows")) {  // rows per piece of the pre-pass / scoring overlap (ddt_score_device, rank-quantised kernels); 0 = one launch
-    // -1 = automatic: an eighth of the batch, at least kOverlapAutoMinRows
-    if (value < -1 || (value > 0 && value < 1024)) return fail(e, DDT_EINVAL, "prepass_overlap_rows must be -1 (automatic), 0 (off) or >= 1024 (one tile of the rank pre-pass)");
-    e->overlap_auto = value == -1;
-    e->overlap_rows = value > 0 ? (size_t)value : 0;
-    return DDT_OK;
-  }
-  if (!strcmp(key, "prepass_overlap_priority")) {  // 1: the engine's pre-pass stream is created with the device's highest priority
-    if ((value != 0) != (e->overlap_priority != 0) && e->ov_stream) {
-      DeviceGuard dg(e->device);
-      if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
-      HIP_TRY(e, hipDeviceSynchronize());
-      overlap_free(e);
-    }
-    e->overlap_priority = value != 0;
     return DDT_OK;
   }
   if (!strcmp(key, "kernel_timing")) {

@@ -16,8 +16,7 @@ namespace ddt {
 
 constexpr uint32_t kMaxLdsBytes = 160u * 1024u;     // MI355X: 160 KiB LDS per CU / workgroup
 constexpr uint32_t kStreamLdsBudget = 40u * 1024u;  // stream kernels: keep >= 4 resident blocks per CU
-constexpr size_t kOverlapAutoPieces = 8, kOverlapAutoMinRows = 1u << 20;
-constexpr int kFeederSlots = 3, kOverlapSlots = 2, kOverlapSlot0 = 1 + kFeederSlots, kQSlots = 1 + kFeederSlots + kOverlapSlots;
+constexpr int kFeederSlots = 3, kQSlots = 1 + kFeederSlots;
 
 inline double now_ms() {
   using namespace std::chrono;
@@ -117,8 +116,7 @@ struct ddt_engine {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   // rank-quantised path workspace (grow-only): transposed tuples, ranks, per-tile flags
-  // slot 0: ddt_score_device / ddt_classify_device (stream ordered); slots 1..kFeederSlots: the feeder's streams; the last two: the pieces of
-  // a pre-pass / scoring overlap (below)
+  // slot 0: ddt_score_device / ddt_classify_device (stream ordered); slots 1..: the feeder's streams
   void* q_xT[ddt::kQSlots] = {};
   void* q_q[ddt::kQSlots] = {};
   void* q_flags[ddt::kQSlots] = {};
@@ -130,17 +128,6 @@ struct ddt_engine {
   // optional per-call kernel timing (option "kernel_timing"): start / before scoring kernel / end
   bool kernel_timing = false, timing_pending = false;
   hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
-  // pre-pass / scoring overlap (option "prepass_overlap_rows" > 0, rank-quantised perfect-tree kernels, ddt_score_device): the batch is
-  // cut into pieces; the rank pre-pass of piece k+1 (HBM-bound) runs on the engine's own stream while the scoring kernel of piece k
-  // (LDS / VALU-bound) runs on the caller's -- two workspace slots, kOverlapSlot0 + (k & 1)
-  size_t overlap_rows = 0;                     // rows per piece (0 with overlap_auto false = off: one launch)
-  bool overlap_auto = false;                   // option value -1: an eighth of the batch, at least kOverlapAutoMinRows
-  int overlap_priority = 0;                    // option "prepass_overlap_priority": 1 = the pre-pass stream gets the device's highest priority
-  hipStream_t ov_stream = nullptr;
-  hipEvent_t ov_fork = nullptr, ov_ready[ddt::kOverlapSlots] = {}, ov_free[ddt::kOverlapSlots] = {};
-  bool ov_free_recorded[ddt::kOverlapSlots] = {};
-  std::vector<hipEvent_t> ov_tev;              // kernel_timing: four events per piece (pre-pass start / end, scoring start / end)
-  size_t ov_timed_pieces = 0;
   // multi-class models: the classes' scoring launches alternate between the caller's stream and this one, so that the tail of
   // one launch (the last, partly filled wave of blocks) overlaps the next class's launch (option "class_streams", default 1)
   hipStream_t class_stream = nullptr;

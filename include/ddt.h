@@ -304,13 +304,7 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * models -- and whose tuples have at most 64..76 words run on the rank-quantised sparse kernels: u16 feature tile, 1024
  * tuples per block; 0 = always the fp32-tile kernels), "sparse_dk" (1 = default: the "dense level K" sparse kernels where they
  * exist -- all top levels as 8-byte records in LDS, the first deep level addressed by the heap index; 0 = never).  A refused
- * sparse_* value keeps the previous one and the loaded model.
- * "prepass_overlap_rows" (rank-quantised perfect-tree kernels, ddt_score_device and the multi-GPU jobs built on it): N >= 1024 = a call of
- * more than N rows is cut into pieces of N rows (rounded up to 1024) and the rank pre-pass of piece k+1 runs on a stream of the engine
- * while the scoring kernel of piece k runs on the caller's -- the pre-pass is HBM-bound, the scoring kernel LDS / VALU-bound; -1 =
- * automatic (an eighth of the call, at least 2^20 rows); 0 = one pre-pass and one scoring launch per call.  Same bits either way;
- * everything the caller may wait for stays on the caller's stream; with "kernel_timing" the pieces' kernel times are summed.
- * "prepass_overlap_priority" (1 = that stream gets the device's highest priority; default 0). */
+ * sparse_* value keeps the previous one and the loaded model. */
 int ddt_set_option(ddt_engine* e, const char* key, int64_t value);
 int ddt_num_variants(void);
 int ddt_variant_name(int variant, char* buf, size_t buflen);

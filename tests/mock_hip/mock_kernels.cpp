@@ -225,12 +225,6 @@ const Variant g_mock_variants[] = {
 
 }  // namespace
 
-// the pre-pass alone (the engine's pre-pass / scoring overlap launches it on its own stream)
-hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s) {
-  enqueue_prepass(a, x, s);
-  return hipSuccess;
-}
-
 namespace {
 const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
     Variant{"sparse_q_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 1, &launch_sparse},

@@ -441,12 +441,6 @@ REMOVED = {
     "feeder_drain": ("    if (pending_n[b] && (rc = drain(b))) return rc;\n    // ALL host-to-device copies", "    // ALL host-to-device copies"),
     # a slot's kernels no longer wait for their chunk to arrive over the (separate) copy stream
     "feeder_h2d_event": ("    HIP_TRY(e, hipStreamWaitEvent(e->fs[b], e->fe_in[b], 0));\n", ""),
-    # pre-pass / scoring overlap: the scoring kernel of a piece no longer waits for the piece's pre-pass on the engine's stream
-    "overlap_ready": ("    HIP_TRY(e, hipStreamWaitEvent(s, e->ov_ready[slot], 0));\n", ""),
-    # ... the pre-pass of piece k + 2 no longer waits for the scoring kernel of piece k to be done with the workspace slot
-    "overlap_free": ("    if (e->ov_free_recorded[slot]) HIP_TRY(e, hipStreamWaitEvent(e->ov_stream, e->ov_free[slot], 0));\n", ""),
-    # ... the engine's stream no longer waits for the work the caller queued before the call (here: the copy that fills the tuples)
-    "overlap_fork": ("  HIP_TRY(e, hipStreamWaitEvent(e->ov_stream, e->ov_fork, 0));\n", ""),
 }
 
 
@@ -472,11 +466,7 @@ def test_the_model_catches_a_missing_dependency_in_the_engine(which):
             assert bad.ddt_set_option(e, b"variant", _variant(bad, "q16_d8_c8_u4_gl")) == 0
             assert bad.ddt_load_model_multiclass(e, C.byref(p), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8, K, 1, 0, 1) == 0
             ok = True
-            if which.startswith("overlap"):
-                bad.ddt_destroy(e)
-                e = _engine(bad)
-                ok = _overlap_calls_are_exact(bad, e, s, keep)
-            elif which.startswith("feeder"):
+            if which.startswith("feeder"):
                 assert bad.ddt_set_option(e, b"feeder_rows", 256) == 0
                 hl, hs = np.full(n, -1, np.int32), np.full((K, n), np.nan, np.float32)
                 keep.append((hl, hs))
@@ -595,80 +585,3 @@ def test_registered_host_buffers_skip_the_staging(mock, policy, seed):
     out[:] = np.nan
     assert mock.ddt_score(e, x.ctypes.data, n, out.ctypes.data) == 0 and np.array_equal(_bits(out), _bits(want))   # staged in, direct out
     mock.ddt_destroy(e)                                                        # hands back what is still registered
-
-
-# ---------------------------------------------------------------------------------------------- pre-pass / scoring overlap
-def _overlap_calls_are_exact(L, e, s, keep, T=40, D=8, F=32, n=7000, piece=2048, clusters=None, variant="q16_d8_c8_u4_gl"):
-    """Two back-to-back overlapped calls on tuples that a copy queued on the caller's stream delivers; True when both are bit-exact."""
-    L.hipMemcpyAsync.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
-    m, x = (O.gen_model(T, D, F, 1, clusters=clusters) if clusters else O.gen_model(T, D, F, 1)), O.gen_tuples(3, n, F, 1)
-    want = O.score(m, x)
-    _load(L, e, m, ddt.make_params(T, D, F, clusters=clusters), variant)
-    assert L.ddt_set_option(e, b"prepass_overlap_rows", piece) == 0
-    ok = True
-    for call in range(2):
-        dev, out = np.zeros_like(x), np.full(n, np.nan, np.float32)
-        keep.append((dev, out))
-        assert L.hipMemcpyAsync(dev.ctypes.data, x.ctypes.data, x.nbytes, 3, s) == 0      # the tuples arrive through the caller's stream
-        assert L.ddt_score_device(e, dev.ctypes.data, n, out.ctypes.data, s) == 0, L.ddt_last_error(e)
-        if call == 1:
-            assert L.hipStreamSynchronize(s) == 0
-    assert L.hipStreamSynchronize(s) == 0
-    for _, out in keep[-2:]:
-        ok = ok and np.array_equal(_bits(out), _bits(want))
-    return ok
-
-
-@pytest.mark.parametrize("policy,seed", SCHEDULES)
-@pytest.mark.parametrize("variant,clusters,n,piece", [("q16_d8_c8_u4_gl", None, 7000, 2048), ("q16_d8_c8_u4_gl_s2_cm", 4, 5001, 1024),
-                                                     ("q16_d8_c4_u4", None, 2049, 2048), ("q16_d8_c8_u4_gl", None, 2048, 2048)])
-def test_prepass_scoring_overlap_is_bit_exact(mock, variant, clusters, n, piece, policy, seed):
-    """Option prepass_overlap_rows: ddt_score_device cuts the batch into pieces, the rank pre-pass of piece k+1 runs on the engine's
-    own stream while the scoring kernel of piece k runs on the caller's (two workspace slots): same bits as one launch, ragged last
-    piece, a batch of exactly one piece (no overlap: one launch), per-piece kernel times summed by kernel_timing."""
-    mock.mock_reset(policy, seed, 8)
-    e, s = _engine(mock), _stream(mock)
-    keep = []
-    assert _overlap_calls_are_exact(mock, e, s, keep, n=n, piece=piece, clusters=clusters, variant=variant)
-    st = ddt.Stats()
-    assert mock.ddt_get_stats(e, C.byref(st)) == 0
-    pieces = (n + piece - 1) // piece if n > piece else 1
-    assert st.kernel_launches == 2 * pieces
-    assert mock.ddt_set_option(e, b"kernel_timing", 1) == 0
-    dev, out = keep[0]
-    assert mock.ddt_score_device(e, dev.ctypes.data, n, out.ctypes.data, s) == 0
-    assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.last_score_ms >= 0 and st.last_prepass_ms >= 0
-    assert np.array_equal(_bits(out), _bits(keep[1][1]))
-    assert mock.ddt_set_option(e, b"prepass_overlap_rows", 1000) != 0            # refused: a piece is at least one tile of 1024 rows
-    assert mock.ddt_set_option(e, b"prepass_overlap_priority", 1) == 0           # the stream is rebuilt with the device's highest priority
-    assert mock.ddt_score_device(e, dev.ctypes.data, n, out.ctypes.data, s) == 0 and mock.hipStreamSynchronize(s) == 0
-    assert np.array_equal(_bits(out), _bits(keep[1][1]))
-    for rows in (-1, 0):                                                          # automatic (an eighth of the batch, >= 1 Mi rows: one launch here) / off
-        assert mock.ddt_set_option(e, b"prepass_overlap_rows", rows) == 0
-        assert mock.ddt_score_device(e, dev.ctypes.data, n, out.ctypes.data, s) == 0 and mock.hipStreamSynchronize(s) == 0
-        assert np.array_equal(_bits(out), _bits(keep[1][1]))
-    assert mock.ddt_set_option(e, b"prepass_overlap_rows", -2) != 0
-    mock.ddt_destroy(e)
-
-
-def test_prepass_scoring_overlap_hides_the_prepass(mock):
-    """On the model's clock (a pre-pass costs 5 % of a scoring pass per row) the overlapped call takes the scoring time plus ONE piece's
-    pre-pass; one launch takes both in full."""
-    mock.mock_costs.argtypes, mock.mock_makespan.restype = [C.c_double, C.c_double, C.c_double], C.c_double
-    T, D, F, n, piece = 16, 8, 32, 8 * 2048, 2048
-    m, x = O.gen_model(T, D, F, 1), O.gen_tuples(0, n, F, 1)
-    spans = {}
-    for rows in (0, piece):
-        mock.mock_reset(0, 0, 8)
-        e, s = _engine(mock), _stream(mock)
-        _load(mock, e, m, ddt.make_params(T, D, F), "q16_d8_c8_u4_gl")
-        assert mock.ddt_set_option(e, b"prepass_overlap_rows", rows) == 0
-        out = np.empty(n, np.float32)
-        assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0 and mock.hipStreamSynchronize(s) == 0   # workspaces exist
-        mock.mock_costs(1.0, 0.0, 0.0)
-        assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0 and mock.hipStreamSynchronize(s) == 0
-        spans[rows] = mock.mock_makespan()
-        mock.mock_costs(0.0, 0.0, 0.0)
-        mock.ddt_destroy(e)
-    assert abs(spans[0] - 1.05 * n) < 1e-6 * n
-    assert abs(spans[piece] - (n + 0.05 * piece)) < 1e-6 * n, spans

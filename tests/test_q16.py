@@ -223,44 +223,3 @@ def test_grouped_and_two_kernel_prepass_agree(T, F):
             got = e.score(x)
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"groups={groups} n={n}"
     e.close()
-
-
-@pytest.mark.parametrize("kernel,T,D,F,shard", [("q16_d8_c8_u4_gl_s2_cm", 300, 8, 32, (0, 1)), ("q16_d8_c8_u4_gl_s2_cm", 1000, 8, 32, (3, 8)),
-                                                ("q16_d6_c16_u4_s2", 100, 6, 28, (0, 1)), ("q16_d8_c4_u4", 60, 8, 20, (0, 1))])
-def test_prepass_scoring_overlap(kernel, T, D, F, shard):
-    """Option prepass_overlap_rows: the batch in pieces, the rank pre-pass of piece k+1 on the engine's own stream against the scoring
-    kernel of piece k on the caller's (two workspace slots).  Same bits as one launch and as the oracle: ragged last piece, tiles with
-    missing values, back-to-back calls (slot reuse across calls), a high-priority pre-pass stream, kernel_timing summed over the pieces."""
-    import torch
-
-    n = 5 * 65_536 + 777
-    m = O.gen_model(T, D, F, dist=1)
-    x = O.gen_tuples(2, n, F, dist=1)
-    x[70_000:70_003, 1] = m.params.missing_bits                     # one tile of the second piece takes the missing-value image
-    b, en = ddt.shard_bounds(T, shard[1])[shard[0]]
-    want = O.score_shard(m, x, b, en, sum_mode=O.SUM_REF_NATIVE)
-    e = ddt.Engine(0)
-    e.set_option("variant", _variant(kernel))
-    e.load_model(_params(m), m.wlines, m.flines, *shard)
-    assert e.info().variant_name.decode() == kernel
-    d = torch.from_numpy(x.view(np.int32)).cuda()
-    one = e.score_device(d).cpu().numpy()
-    assert np.array_equal(one.view(np.uint32), want.view(np.uint32))
-    launches = e.stats().kernel_launches
-    for prio in (0, 1):
-        e.set_option("prepass_overlap_priority", prio)
-        for piece in (65_536, 100_000, 2 * 65_536):
-            e.set_option("prepass_overlap_rows", piece)
-            outs = [e.score_device(d) for _ in range(3)]            # three calls in flight on one stream
-            for o in outs:
-                assert np.array_equal(o.cpu().numpy().view(np.uint32), want.view(np.uint32)), (kernel, prio, piece)
-            pieces = -(-n // (-(-piece // 1024) * 1024))
-            assert e.stats().kernel_launches == launches + 3 * pieces
-            launches += 3 * pieces
-    e.set_option("kernel_timing", 1)
-    got = e.score_device(d).cpu().numpy()
-    st = e.stats()
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and st.last_score_ms > 0 and st.last_prepass_ms > 0
-    e.set_option("prepass_overlap_rows", n)                         # a batch of at most one piece: one launch
-    assert np.array_equal(e.score_device(d).cpu().numpy().view(np.uint32), want.view(np.uint32))
-    e.close()
