@@ -883,6 +883,45 @@ int feeder_reserve(ddt_engine* e, size_t rows, size_t words, size_t outs) {
 
 int ensure_q16_workspace(ddt_engine* e, size_t n);
 
+// ---- kernel_timing: a ring of event triples {start, before the scoring kernel, end} ----------------------------------------------
+// fold the oldest pending triples into the counters until at most keep_pending are left (waits for their end events)
+void timing_resolve(ddt_engine* e, int keep_pending) {
+  while (e->tev_pending > keep_pending) {
+    hipEvent_t* t = e->tev[(e->tev_head - e->tev_pending + 2 * ddt_engine::kTimingRing) % ddt_engine::kTimingRing];
+    float pre = 0.f, sc = 0.f;
+    if (hipEventSynchronize(t[2]) == hipSuccess && hipEventElapsedTime(&pre, t[0], t[1]) == hipSuccess &&
+        hipEventElapsedTime(&sc, t[1], t[2]) == hipSuccess) {
+      e->st.last_prepass_ms = pre;
+      e->st.last_score_ms = sc;
+      e->st.sum_prepass_ms += pre;
+      e->st.sum_score_ms += sc;
+      e->st.timed_launches++;
+    } else {
+      (void)hipGetLastError();
+    }
+    e->tev_pending--;
+  }
+}
+
+int timing_begin(ddt_engine* e, hipStream_t s) {
+  timing_resolve(e, ddt_engine::kTimingRing - 1);  // a full ring: wait for the oldest launch
+  hipEvent_t* t = e->tev[e->tev_head];
+  for (int i = 0; i < 3; ++i)
+    if (!t[i]) HIP_TRY(e, hipEventCreate(&t[i]));
+  HIP_TRY(e, hipEventRecord(t[0], s));
+  e->tev_cur = t;
+  return DDT_OK;
+}
+
+int timing_end(ddt_engine* e, hipStream_t s) {
+  hipEvent_t* t = e->tev_cur;
+  e->tev_cur = nullptr;
+  HIP_TRY(e, hipEventRecord(t[2], s));
+  e->tev_head = (e->tev_head + 1) % ddt_engine::kTimingRing;
+  e->tev_pending++;
+  return DDT_OK;
+}
+
 int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t n, float* d_scores, hipStream_t s,
                  bool reuse_prepass = false) {
   ScoreArgs a;
@@ -909,19 +948,22 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     a.aux = &qa;
   }
   const bool timing = e->kernel_timing && e->q_slot == 0;
+  e->tev_cur = nullptr;
   if (timing) {
-    for (hipEvent_t& ev : e->tev)
-      if (!ev) HIP_TRY(e, hipEventCreate(&ev));
-    HIP_TRY(e, hipEventRecord(e->tev[0], s));
-    if (v.kind == kKindQ16) a.ev_mid = e->tev[1];
-    else HIP_TRY(e, hipEventRecord(e->tev[1], s));
+    int rc = timing_begin(e, s);
+    if (rc) return rc;
+    if (v.kind == kKindQ16) a.ev_mid = e->tev_cur[1];
+    else HIP_TRY(e, hipEventRecord(e->tev_cur[1], s));
   }
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   hipError_t r = v.launch(a, v, s);
-  if (r != hipSuccess) return fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
+  if (r != hipSuccess) {
+    e->tev_cur = nullptr;
+    return fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
+  }
   if (timing) {
-    HIP_TRY(e, hipEventRecord(e->tev[2], s));
-    e->timing_pending = true;
+    int rc = timing_end(e, s);
+    if (rc) return rc;
   }
   e->st.kernel_launches++;
   return DDT_OK;
@@ -961,18 +1003,18 @@ int launch_classify(ddt_engine* e, const void* d_tuples, size_t n, float* d_clas
 int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
   if (!e->sparse) return launch_score(e, e->ens[0], d_tuples, n, d_scores, s);
   const bool timing = e->kernel_timing && e->q_slot == 0;
+  e->tev_cur = nullptr;
   if (timing) {
-    for (hipEvent_t& ev : e->tev)
-      if (!ev) HIP_TRY(e, hipEventCreate(&ev));
-    HIP_TRY(e, hipEventRecord(e->tev[0], s));
-    if (!(variant(e->variant_id).opt & 1)) HIP_TRY(e, hipEventRecord(e->tev[1], s));  // fp32 tiles: no pre-pass (else: sparse_launch)
+    int rc = timing_begin(e, s);
+    if (rc) return rc;
+    if (!(variant(e->variant_id).opt & 1)) HIP_TRY(e, hipEventRecord(e->tev_cur[1], s));  // fp32 tiles: no pre-pass (else: sparse_launch)
   }
   int rc = sparse_launch(e, 0, d_tuples, n, d_scores, s);
-  if (rc) return rc;
-  if (timing) {
-    HIP_TRY(e, hipEventRecord(e->tev[2], s));
-    e->timing_pending = true;
+  if (rc) {
+    e->tev_cur = nullptr;
+    return rc;
   }
+  if (timing && (rc = timing_end(e, s))) return rc;
   e->st.kernel_launches++;
   return DDT_OK;
 }
@@ -1111,8 +1153,9 @@ void ddt_destroy(ddt_engine* e) {
   delete e->pool;
   for (const auto& r : e->pinned) (void)hipHostUnregister(r.first);  // ranges the caller forgot to hand back
   if (e->ws) (void)hipFree(e->ws);
-  for (hipEvent_t ev : e->tev)
-    if (ev) (void)hipEventDestroy(ev);
+  for (auto& t : e->tev)
+    for (hipEvent_t ev : t)
+      if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->class_ev)
     if (ev) (void)hipEventDestroy(ev);
   if (e->class_stream) (void)hipStreamDestroy(e->class_stream);
@@ -1395,15 +1438,7 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
 int ddt_get_stats(const ddt_engine* e_, ddt_stats* out) {
   if (!e_ || !out) return DDT_EINVAL;
   ddt_engine* e = const_cast<ddt_engine*>(e_);  // resolving pending event times is a logically-const refresh
-  if (e->timing_pending) {
-    float pre = 0.f, sc = 0.f;
-    if (hipEventSynchronize(e->tev[2]) == hipSuccess && hipEventElapsedTime(&pre, e->tev[0], e->tev[1]) == hipSuccess &&
-        hipEventElapsedTime(&sc, e->tev[1], e->tev[2]) == hipSuccess) {
-      e->st.last_prepass_ms = pre;
-      e->st.last_score_ms = sc;
-    }
-    e->timing_pending = false;
-  }
+  timing_resolve(e, 0);
   *out = e->st;
   return DDT_OK;
 }

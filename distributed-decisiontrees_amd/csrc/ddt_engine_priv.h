@@ -126,8 +126,13 @@ struct ddt_engine {
   int q16_prepass_groups = 0;   // option "q16_prepass_groups": force the number of feature groups (A/B), 0 = automatic
   int q16_fused_prepass = 1;  // option "q16_fused_prepass": 0 forces the transpose + rank kernels (A/B, tests)
   // optional per-call kernel timing (option "kernel_timing"): start / before scoring kernel / end
-  bool kernel_timing = false, timing_pending = false;
-  hipEvent_t tev[3] = {nullptr, nullptr, nullptr};
+  // Every timed launch takes an event triple from a ring; ddt_get_stats resolves the pending ones (waiting for the newest), so a caller
+  // may queue up to kTimingRing launches without a host synchronisation in between.
+  bool kernel_timing = false;
+  static constexpr int kTimingRing = 64;
+  hipEvent_t tev[kTimingRing][3] = {};
+  int tev_head = 0, tev_pending = 0;   // pending triples: tev_head - tev_pending .. tev_head - 1 (mod kTimingRing)
+  hipEvent_t* tev_cur = nullptr;       // the triple of the launch being issued (its middle event is recorded by the kernel launcher)
   // multi-class models: the classes' scoring launches alternate between the caller's stream and this one, so that the tail of
   // one launch (the last, partly filled wave of blocks) overlaps the next class's launch (option "class_streams", default 1)
   hipStream_t class_stream = nullptr;
@@ -192,6 +197,10 @@ bool leaf_outside_exact_domain(uint32_t bits);
 int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s);
 int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s);
 int ensure_q16_workspace(ddt_engine* e, size_t n);
+// kernel_timing: open / close the event triple of one launch on stream s (timing_begin records the start event)
+int timing_begin(ddt_engine* e, hipStream_t s);
+int timing_end(ddt_engine* e, hipStream_t s);
+void timing_resolve(ddt_engine* e, int keep_pending);
 // rank tables: host packing (no HIP call) and upload; tables longer than kQ16MaxTable keys do not fit the u16 ranks
 constexpr uint32_t kQ16MaxTable = 32767;  // ranks must stay below 0xFFFF and a table (x4 B) must fit LDS in the rank kernel
 void finish_rank_tables(RankTables& rt);  // sort + unique every feature's keys, set max_len

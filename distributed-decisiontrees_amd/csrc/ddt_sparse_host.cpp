@@ -378,7 +378,7 @@ int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, f
     qa.prepass = e->sp_rank.prepass;
     qa.img_slow = nullptr;  // the sparse images carry the missing direction in every record
     qa.n_pad = (n + 1023) / 1024 * 1024;
-    if (e->kernel_timing && e->q_slot == 0) a.ev_mid = e->tev[1];  // recorded between the pre-pass and the scoring kernel
+    if (e->tev_cur) a.ev_mid = e->tev_cur[1];  // recorded between the pre-pass and the scoring kernel
   }
   a.aux = &x;
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch

@@ -55,6 +55,7 @@ class Stats(C.Structure):
         ("result_lines_out", C.c_uint64), ("model_lines_in", C.c_uint64), ("score_calls", C.c_uint64),
         ("kernel_launches", C.c_uint64), ("prog_ms", C.c_double), ("exec_ms", C.c_double),
         ("last_prepass_ms", C.c_double), ("last_score_ms", C.c_double),
+        ("timed_launches", C.c_uint64), ("sum_prepass_ms", C.c_double), ("sum_score_ms", C.c_double),
     ]
 
 

@@ -100,9 +100,13 @@ typedef struct ddt_stats {
   uint64_t tuple_lines_in, result_lines_out, model_lines_in;
   uint64_t score_calls, kernel_launches;
   double   prog_ms, exec_ms;         /* progCycles / execCycles equivalents (host wall, ms)          */
-  /* with ddt_set_option(e, "kernel_timing", 1): HIP-event times of the LAST ddt_score_device call on its stream
-   * (ddt_get_stats waits for that call): pre-pass (transpose + rank, 0 for the fp32 kernels) and scoring kernel */
+  /* with ddt_set_option(e, "kernel_timing", 1): HIP-event times of the ddt_score_device launches on their stream -- pre-pass (rank
+   * kernels, 0 for the fp32 kernels) and scoring kernel: of the LAST launch, and summed over all `timed_launches` so far.  The library
+   * keeps the events of up to 64 launches; ddt_get_stats folds them in (it waits for the newest), so a loop of calls needs no host
+   * synchronisation per call -- read the sums before and after it. */
   double   last_prepass_ms, last_score_ms;
+  uint64_t timed_launches;
+  double   sum_prepass_ms, sum_score_ms;
 } ddt_stats;
 
 /* -- lifecycle (replaces: CSR 200 start / reset, EngineCSR.sv:191-193, Core.sv:167-187) -------------- */

@@ -585,3 +585,33 @@ def test_registered_host_buffers_skip_the_staging(mock, policy, seed):
     out[:] = np.nan
     assert mock.ddt_score(e, x.ctypes.data, n, out.ctypes.data) == 0 and np.array_equal(_bits(out), _bits(want))   # staged in, direct out
     mock.ddt_destroy(e)                                                        # hands back what is still registered
+
+
+def test_kernel_timing_ring(mock):
+    """kernel_timing: every timed launch takes an event triple from a ring of 64; the counters are folded in when they are read, a full
+    ring waits for its oldest launch, a sparse model and a refused call leave the ring consistent."""
+    mock.mock_reset(2, 9, 8)
+    T, D, F, n = 40, 8, 32, 1100
+    m, x = O.gen_model(T, D, F, 1), O.gen_tuples(0, n, F, 1)
+    want = O.score(m, x)
+    e, s = _engine(mock), _stream(mock)
+    st = ddt.Stats()
+    for variant in ("q16_d8_c8_u4_gl", "d8_t1024_r1_c4_u4_dma_f"):
+        _load(mock, e, m, ddt.make_params(T, D, F), variant)
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0
+        before = st.timed_launches
+        assert mock.ddt_set_option(e, b"kernel_timing", 1) == 0
+        outs = [np.full(n, np.nan, np.float32) for _ in range(150)]
+        for o in outs:
+            assert mock.ddt_score_device(e, x.ctypes.data, n, o.ctypes.data, s) == 0
+        assert mock.ddt_score_device(e, None, n, outs[0].ctypes.data, s) != 0          # refused before anything is recorded
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.timed_launches == before + 150
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.timed_launches == before + 150   # nothing is counted twice
+        assert st.sum_score_ms >= st.last_score_ms >= 0 and st.sum_prepass_ms >= 0
+        assert mock.ddt_set_option(e, b"kernel_timing", 0) == 0
+        assert mock.ddt_score_device(e, x.ctypes.data, n, outs[0].ctypes.data, s) == 0
+        assert mock.hipStreamSynchronize(s) == 0
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.timed_launches == before + 150
+        for o in outs:
+            assert np.array_equal(_bits(o), _bits(want))
+    mock.ddt_destroy(e)

@@ -124,6 +124,20 @@ def test_kernel_timing_counters():
     e.score_device(d)
     st = e.stats()
     assert st.last_score_ms > 0.2 and st.last_prepass_ms < 0.05    # fp32 kernel: no pre-pass
+    # a loop of calls without a host synchronisation in between: the library keeps the events of up to 64 launches and folds them
+    # into the sums when the counters are read; more than 64 in flight only makes a launch wait for the oldest
+    e.set_option("variant", -1)
+    n0, s0, p0 = st.timed_launches, st.sum_score_ms, st.sum_prepass_ms
+    assert n0 == 2
+    for _ in range(70):
+        e.score_device(d)
+    st = e.stats()
+    assert st.timed_launches == n0 + 70
+    per_launch = (st.sum_score_ms - s0) / 70
+    assert 0.5 * st.last_score_ms < per_launch < 2.0 * st.last_score_ms and st.sum_prepass_ms > p0
+    e.set_option("kernel_timing", 0)
+    e.score_device(d)
+    assert e.stats().timed_launches == n0 + 70
     torch.cuda.synchronize()
     e.close()
 
