@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--shard", default="trees", choices=["trees", "rows"],
                     help="N>1: 'trees' = the headline mode (ensemble sharded tree-wise, partial scores all-reduced); "
                          "'rows' = the reference's other mode (replicated ensemble, tuples partitioned, every step of scores handed to all peers while the next is scored)")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="N=1 only: load shard 3 (or the last) of a G-way tree-sharded job of the configured model and score it with no "
+                         "collective -- exactly what one of G ranks computes (same cluster count, same kernel choice); no CPU / host-feeder legs")
     ap.add_argument("--chunk-rows", type=int, default=12_500_000, help="rows per pipelined collective (N>1)")
     ap.add_argument("--taper", type=int, default=-1, choices=[-1, 0, 1],
                     help="N>1 / --force-collectives: cut the last chunk into 1/2, 1/4, 1/4 so that the exposed collective is a quarter "
@@ -166,6 +169,11 @@ def main():
     eng.set_option("variant", args.variant)
     rows_mode = world > 1 and args.shard == "rows"
     shard = (0, 1) if rows_mode else (rank, world)
+    if args.shard_of > 1:
+        if world > 1 or args.force_collectives or sparse or classes > 1:
+            sys.exit("--shard-of: one plain engine on one GPU")
+        shard = (min(3, args.shard_of - 1), args.shard_of)
+        args.no_cpu_baseline = args.no_streamed = True   # the CPU legs below score the whole ensemble
     if sparse:
         lines, first = ddt.synth_sparse_model(T, D, F, args.full_levels, args.permille, 0)
         params = ddt.make_sparse_params(T, D, F, sum_mode=args.sum_mode)
@@ -298,7 +306,7 @@ def main():
         ach = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic_cfg4.json" if sparse else "pmc_traffic.json")
-        if os.path.exists(pmc) and not multi:  # HBM bytes per launch of this kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of THIS command, collected in its own run
+        if os.path.exists(pmc) and not multi and args.shard_of <= 1:  # HBM bytes per launch of this kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of THIS command, collected in its own run
             try:
                 pj = json.load(open(pmc))
                 if pj.get("rows") == N and pj.get("trees") == T:
@@ -423,7 +431,8 @@ def main():
                               "bit_exact_vs_resident": bool(np.array_equal(hs2.view(np.uint32), want_bits))}
 
     if rank == 0:
-        par = "single engine" if world == 1 else (
+        par = (f"shard {shard[0]} of a {shard[1]}-way tree-sharded job ({int(info.tree_end - info.tree_begin)} trees) on one GPU, no collective" if args.shard_of > 1 else
+               "single engine") if world == 1 else (
             f"row-sharded {world}x (replicas) + {'RCCL send/recv all-gather, pipelined' if comm is not None else 'gloo all-gather'}" if rows_mode else
             f"tree-sharded {world}x + {'RCCL' if args.backend == 'nccl' else 'gloo (functional test)'} {args.combine}")
         shape = (f"{T} sparse trees (depth <= {D}, {lines.shape[0]} internal nodes) x {F} fp32 features" if sparse
@@ -438,7 +447,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{shape}, {N} tuples/step, {par}",
                        "trees": T, "levels": D, "features": F, "rows": N,
-                       "parallelism": f"row-shard{world}" if rows_mode else f"tree-shard{world}",
+                       "parallelism": f"row-shard{world}" if rows_mode else (f"one-of-tree-shard{args.shard_of}" if args.shard_of > 1 else f"tree-shard{world}"),
                        "combine": args.combine if multi else None,
                        "tapered_tail": ((args.taper == 1 or (args.taper < 0 and world > 1)) if comm is not None else None),
                        "collectives": (("C-ABI ddt_comm (csrc/ddt_comm.cpp)" if comm is not None else "torch.distributed") if multi else None),
@@ -446,6 +455,8 @@ def main():
                        "sum_mode": {0: "reference order, IEEE fp32 adds", 1: "fp64 accumulate", 2: "reference order, reference (FloPoCo) adder"}[args.sum_mode],
                        "device": info.device_name.decode()},
         }
+        if args.shard_of > 1:
+            line["metric"] += f" -- one shard of {args.shard_of} only (not the job's rate)"
         if roofline:
             line["roofline"] = roofline
         if cpu:

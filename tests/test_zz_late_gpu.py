@@ -164,6 +164,14 @@ def test_multi_gpu_branch_in_a_one_rank_communicator(extra):
     assert o["row_vs_tree_max_abs_diff_rel"] == 0.0        # one rank: every mode computes the same reference-order sums
 
 
+def test_one_shard_of_a_tree_sharded_job_on_one_gpu():
+    """bench.py --shard-of G: what one of G ranks computes (the shard's trees with the whole model's cluster count), no collective."""
+    j = _bench("--rows", "300000", "--steps", "2", "--warmup", "1", "--shard-of", "8")
+    assert j["n_gpus"] == 1 and j["value"] > 0 and "one shard of 8" in j["metric"] and j["config"]["parallelism"] == "one-of-tree-shard8"
+    assert "125 trees" in j["config"]["workload"] and j["config"]["kernel"] == "q16_d8_c8_u4_gl_s2_cm"
+    assert j["roofline"]["kernel_ms"] > 0 and "cpu_baseline" not in j and "streamed" not in j
+
+
 # ---------------------------------------------------------------------------------------------- feeder: pinned caller buffers
 def test_registered_host_buffers_on_the_gpu():
     """ddt_host_register: the feeder DMAs the caller's pinned buffers directly (no staging / drain copies): same bits as the staged path
