@@ -30,8 +30,10 @@ SCHEDULES = [(0, 0), (1, 0), (2, 21), (2, 22), (2, 23)]
 
 
 def _build(name, engine_source=None):
-    san = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g"] if os.environ.get("DDT_MOCK_SANITIZE") else []   # see tests/mock_hip/README
-    out = os.path.join(MOCK, name.replace(".so", "_asan.so") if san else name)
+    mode = os.environ.get("DDT_MOCK_SANITIZE", "")   # "1" / "address": AddressSanitizer; "undefined": UBSan (aborts on a finding); see tests/mock_hip/README
+    san = (["-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g"] if mode == "undefined" else
+           ["-fsanitize=address", "-fno-omit-frame-pointer", "-g"] if mode else [])
+    out = os.path.join(MOCK, name.replace(".so", "_ubsan.so" if mode == "undefined" else "_asan.so") if san else name)
     srcs = [engine_source or os.path.join(CSRC, "ddt_engine.cpp")] + [os.path.join(CSRC, f) for f in SOURCES[1:]] + [os.path.join(MOCK, "mock_kernels.cpp")]
     deps = srcs + [os.path.join(MOCK, "mock_runtime.cpp"), os.path.join(MOCK, "hip", "hip_runtime.h"), os.path.join(MOCK, "rccl", "rccl.h"),
                    os.path.join(CSRC, "ddt_engine_priv.h"), os.path.join(CSRC, "ddt_internal.h")]
