@@ -28,8 +28,8 @@ Extra objects on the JSON line:
   scaling_detail / other_modes
                N>1 (or --force-collectives), measured BEHIND the timed region and never `value`: the rank's shard scored with no
                collective (what the combine costs is then on the line), and the same batch through the library's other ways of
-               running the job -- chain combine, untapered all-reduce, half / double chunk_rows, a high-priority comm stream, and
-               the row-sharded replicas (whole ensemble per GPU, tuples partitioned).  A watchdog prints the headline line and
+               running the job -- chain combine, untapered all-reduce, half / double chunk_rows, a high-priority comm stream, the
+               row-sharded replicas (whole ensemble per GPU, tuples partitioned) and the hybrids (tree groups of 2 / 4 ranks x row groups).  A watchdog prints the headline line and
                exits if one of these legs -- none has run with real peers before the driver's scaling run -- does not return.
 """
 import argparse
@@ -59,6 +59,18 @@ def self_launch_command(n_gpus, argv=None, port=None):
             port = sk.getsockname()[1]
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
             "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+
+
+def hybrid_tree_groups(world):
+    """Tree-group sizes Gt of the hybrid legs: proper divisors of the job that leave at least two row groups."""
+    return [Gt for Gt in (2, 4) if world % Gt == 0 and world // Gt >= 2]
+
+
+def hybrid_rows(n, row_groups, rg):
+    """Row slice [lo, hi) of row group rg: equal slices in whole tiles of 1024 tuples, the last one takes the rest."""
+    per = (n + row_groups - 1) // row_groups
+    per = (per + 1023) // 1024 * 1024
+    return min(n, rg * per), min(n, (rg + 1) * per)
 
 
 def self_launch(n_gpus):
@@ -527,6 +539,27 @@ def main():
             other["row_sharded_mtuples_per_s"] = round(N / other["row_sharded_ms"] / 1e3, 3)
             scale = float(tree_scores.abs().max().item()) or 1.0
             other["row_vs_tree_max_abs_diff_rel"] = float((out - tree_scores).abs().max().item()) / scale   # summation order differs
+            # hybrid: Gr independent tree-sharded jobs of Gt ranks each on disjoint row slices (consecutive ranks form a tree group).  Each
+            # rank ranks and scores N/Gr tuples against T/Gt trees -- the replicated rank pre-pass shrinks by Gr -- and the all-reduce runs
+            # inside a tree group; the scores stay distributed by row group, as the reference returns them per device.  Built from the
+            # same C-ABI calls: a communicator per tree group.
+            for Gt in hybrid_tree_groups(world):
+                Gr, tg, rg = world // Gt, rank % Gt, rank // Gt
+                engh = ddt.Engine(local)
+                engh.load_model(params, w, f, tg, Gt)
+                ids = [None] * world
+                dist.all_gather_object(ids, ddt.comm_unique_id() if tg == 0 else None)    # every group leader makes its group's id
+                commh = ddt.Comm(engh, tg, Gt, ids[rg * Gt])
+                lo, hi = hybrid_rows(N, Gr, rg)
+                commh.set_option("chunk_rows", max(1024, args.chunk_rows // Gr))
+                key = f"hybrid_tree{Gt}_x_rows{Gr}"
+                other[key + "_ms"] = leg(lambda: commh.score_sharded(tuples[lo:hi], out=out[lo:hi], combine=ddt.COMBINE_ALLREDUCE))
+                other[key + "_mtuples_per_s"] = round(N / other[key + "_ms"] / 1e3, 3)
+                diff = torch.tensor([float((out[lo:hi] - tree_scores[lo:hi]).abs().max().item()) / scale if hi > lo else 0.0], dtype=torch.float64, device=tuples.device)
+                dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+                other[key + "_vs_tree_max_abs_diff_rel"] = float(diff.item())              # summation order differs (fewer partials per tuple)
+                commh.close()
+                engh.close()
             # host buffers through the tree-sharded job (ddt_comm_score): tuples over PCIe once + xGMI hand-over, or G full copies
             srows = min(N, 8_000_000)
             host_t = tuples[:srows].cpu().numpy().view(np.uint32)
@@ -536,7 +569,9 @@ def main():
                 other[f"host_buffers_tuple_broadcast_{bc}_mtuples_per_s"] = round(srows / ms / 1e3, 2)
             comm.set_option("tuple_broadcast", -1)
             other["note"] = ("ms per step, max over ranks, 2 steps each after one warm-up, outside the timed region; row-sharded = replicas "
-                             "only (whole ensemble per GPU, tuples partitioned, every step of scores handed to all peers), exact reference-order sums")
+                             "only (whole ensemble per GPU, tuples partitioned, every step of scores handed to all peers), exact reference-order sums; "
+                             "hybrid_treeA_x_rowsB = B independent tree-sharded jobs of A consecutive ranks each on disjoint row slices "
+                             "(a communicator per tree group; scores stay with their row group)")
             comm2.close()
             eng2.close()
         except Exception as ex:  # never at the price of the headline line

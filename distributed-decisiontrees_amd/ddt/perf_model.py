@@ -87,8 +87,9 @@ def predict(g: Mi355x, n_trees: int, depth: int, n_features: int, n_gpus: int = 
 @dataclass
 class PathCosts:
     """Measured on one MI355X, milliseconds per 100 M tuples of 32 fp32 features, depth-8 trees
-    (profiles/r01_final_bench.md, r01_sweep_shard_regime.json, r01_tile_overhead.md; pre-pass: profiles/r02_prepass_ab.log)."""
-    q16_ms_per_tree: float = 0.1065       # score_q16_kernel (leaves gathered from global memory, 8-tree chunks): 7.46 T node visits/s
+    (profiles/r01_final_bench.md, r01_sweep_shard_regime.json, r01_tile_overhead.md; pre-pass: profiles/r02_prepass_ab.log;
+    q16 scoring kernel: profiles/r03_bench_cfg3.log, r03_bench_shard_of_8.log)."""
+    q16_ms_per_tree: float = 0.0980       # score_q16_kernel<8,8,4,gl|s2|cm>: 98.8 ms per 1000 trees, 13.44 ms per 125 (+ 3 EMPTY): 8.1 T node visits/s
     fp32_ms_per_tree: float = 0.147       # score_tile_kernel: 5.4 T node visits/s
     q16_fixed: float = 0.8                # per-tile fixed cost of the q16 scoring kernel
     fp32_fixed: float = 3.2               # per-tile fixed cost of the fp32 tile kernel (tuple load phase)
@@ -147,6 +148,17 @@ def row_sharded_ms(trees: int, n_gpus: int, depth: int = 8, rows: float = 1e8, g
     e = engine_ms(trees, depth, rows / n_gpus)
     link = 153e9 / 2                       # one xGMI link, one direction
     comm = 0.0 if n_gpus == 1 else (rows / chunks / n_gpus) * 4 / link * 1e3 + 0.05
+    ms = e["ms"] + comm
+    return {"ms": ms, "mtuples_per_s": rows / ms / 1e3, "path": e["path"], "score_ms": e["ms"], "exposed_comm_ms": comm}
+
+
+def hybrid_ms(trees: int, tree_groups: int, row_groups: int, depth: int = 8, rows: float = 1e8, g: Mi355x = Mi355x(), chunks: int = 8) -> dict:
+    """Whole-job time of `row_groups` independent tree-sharded jobs of `tree_groups` ranks each on disjoint row slices (bench.py
+    other_modes "hybrid_tree{Gt}_x_rows{Gr}"): a rank ranks and scores rows / Gr tuples against ceil(T / Gt) trees, so the replicated
+    rank pre-pass of the tree-sharded mode shrinks by Gr; the all-reduce stays inside a tree group (its last quarter chunk exposed)."""
+    per = -(-trees // tree_groups)
+    e = engine_ms(per, depth, rows / row_groups)
+    comm = 0.0 if tree_groups == 1 else (rows / row_groups) * 4 / g.allreduce_alg_bytes_per_s * 1e3 / chunks / 4.0
     ms = e["ms"] + comm
     return {"ms": ms, "mtuples_per_s": rows / ms / 1e3, "path": e["path"], "score_ms": e["ms"], "exposed_comm_ms": comm}
 

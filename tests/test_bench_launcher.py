@@ -56,3 +56,16 @@ def test_gpus_2_self_launched_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["unit"] == "Mtuples/s" and j["scaling"] == "strong"
     assert abs(j["value"] - 2000000 / j["ms_per_step"] / 1e3) / j["value"] < 1e-3
+
+
+def test_hybrid_legs_geometry():
+    """other_modes' hybrid legs: tree groups of 2 / 4 consecutive ranks that leave >= 2 row groups; row slices in whole 1024-tuple tiles
+    that cover every tuple exactly once."""
+    import bench
+
+    assert bench.hybrid_tree_groups(8) == [2, 4] and bench.hybrid_tree_groups(4) == [2] and bench.hybrid_tree_groups(2) == []
+    assert bench.hybrid_tree_groups(1) == [] and bench.hybrid_tree_groups(6) == [2]
+    for n, Gr in ((100_000_000, 4), (100_000_000, 2), (10_000_001, 4), (3000, 2), (1000, 4)):
+        cuts = [bench.hybrid_rows(n, Gr, rg) for rg in range(Gr)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        assert all(lo % 1024 == 0 for lo, _ in cuts if lo < n)

@@ -49,15 +49,18 @@ def test_mi355x_model_matches_measurements_within_20_percent():
 
 def test_engine_cost_model_matches_the_measured_shard_regime():
     # per-rank scoring time of the headline job's shards, measured on one MI355X (profiles/r01_*), ms per 100 M tuples
-    measured = {1000: 113.0, 125: 18.5}  # profiles/r02_bench_cfg3.log, r02_bench_t125.log (q16_d8_c8_u4_gl)
+    measured = {1000: 104.5, 125: 17.58}  # profiles/r03_bench_cfg3.log, r03_bench_shard_of_8.log (q16_d8_c8_u4_gl_s2_cm)
     for trees, ms in measured.items():
         e = P.engine_ms(trees)
         assert e["path"] == "q16"
-        assert abs(e["ms"] - ms) <= 0.08 * ms, (trees, e, ms)
+        assert abs(e["ms"] - ms) <= 0.04 * ms, (trees, e, ms)
     assert P.engine_ms(100, depth=6)["path"] == "fp32"                       # config 2 stays on the fp32 tile kernel
     assert abs(P.engine_ms(125)["fp32_ms"] - 21.4) < 1.5                     # what the 8-way shard cost before the fused pre-pass
     s = {n: P.tree_sharded_ms(1000, n)["mtuples_per_s"] for n in (1, 2, 4, 8)}
-    assert 850 < s[1] < 920 and 5.5 < s[8] / s[1] < 6.6                      # north star: >= 6x aggregate at 8 GPUs is within reach
+    assert 930 < s[1] < 990 and 5.4 < s[8] / s[1] < 6.2                      # the replicated rank pre-pass holds tree sharding just below 6x
+    # two tree groups x four row groups: the pre-pass runs on a quarter of the rows per rank
+    h = {(gt, 8 // gt): P.hybrid_ms(1000, gt, 8 // gt)["mtuples_per_s"] / s[1] for gt in (1, 2, 4, 8)}
+    assert h[(1, 8)] > h[(2, 4)] > h[(4, 2)] > h[(8, 1)] and h[(2, 4)] > 7.0 and abs(h[(8, 1)] - s[8] / s[1]) < 0.05
 
 
 def test_sparse_forest_model_matches_the_config4_measurement():
