@@ -431,3 +431,48 @@ def test_the_model_catches_a_missing_dependency(which):
         for f in (broken, os.path.join(MOCK, so)):
             if os.path.exists(f):
                 os.remove(f)
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+@pytest.mark.parametrize("Gt,Gr", [(2, 2), (2, 4), (4, 2)])
+def test_hybrid_row_groups_of_tree_sharded_jobs(mock, Gt, Gr, policy, seed):
+    """bench.py's hybrid legs: Gr independent tree-sharded jobs of Gt consecutive ranks each, a communicator per tree group (its own
+    unique id), every group on its own row slice, all running at once -- the communicators must not share state."""
+    mock.mock_reset(policy, seed, 8)
+    n = 6000
+    per = (-(-n // Gr) + 1023) // 1024 * 1024
+    x = _tuples(n)
+    want = _expected(Gt, n)[0]                     # every tuple: the sum of its tree group's Gt partials
+
+    def body(rank, barrier, shared):
+        tg, rg = rank % Gt, rank // Gt
+        assert mock.hipSetDevice(rank) == 0
+        s, e, c = vp(), vp(), vp()
+        assert mock.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+        assert mock.ddt_create(C.byref(e), rank) == 0
+        p = _params()
+        assert mock.ddt_load_model_shard(e, C.byref(p), None, 0, None, 0, tg, Gt) == 0
+        if tg == 0:
+            shared[rg] = C.create_string_buffer(128)
+            assert mock.ddt_comm_get_unique_id(shared[rg]) == 0
+        barrier.wait()
+        assert mock.ddt_comm_create(C.byref(c), e, tg, Gt, shared[rg]) == 0
+        assert mock.ddt_comm_set_option(c, b"chunk_rows", 700) == 0
+        assert mock.ddt_comm_set_option(c, b"taper_min_rows", 16) == 0
+        lo, hi = min(n, rg * per), min(n, (rg + 1) * per)
+        outs = []
+        for combine in (0, 1):
+            out = np.full(n, np.nan, np.float32)
+            assert mock.ddt_score_sharded_device(c, x[lo:hi].ctypes.data, hi - lo, out[lo:hi].ctypes.data, combine, s) == 0, mock.ddt_comm_last_error(c)
+            outs.append(out)
+        barrier.wait()
+        assert mock.hipStreamSynchronize(s) == 0
+        for out in outs:
+            assert np.array_equal(out[lo:hi], want[lo:hi]) and np.isnan(out[:lo]).all() and np.isnan(out[hi:]).all()
+        barrier.wait()
+        mock.ddt_comm_destroy(c)
+        mock.ddt_destroy(e)
+        mock.hipStreamDestroy(s)
+
+    _run_ranks(Gt * Gr, body)
+    assert mock.mock_errors() == 0
