@@ -164,12 +164,18 @@ struct Variant {
   // where the fp32 tile holds 512), node thresholds are ranks
   // opt bit 1 ("sparse_dk_*"): dense level K -- 8-byte records only in LDS, no flag bytes behind the tile (above: "Sparse forests")
   uint32_t top_bytes_sparse() const { return ((opt & 2) ? 8u : 12u) << levels; }
-  uint32_t row_bytes_sparse() const { return (opt & 1) ? tile() * 2u : tile() * 4u; }
+  // opt bit 2 ("sparse_gf_*", any tuple width): no feature tile -- a feature is gathered from the tuple's row in global memory, the
+  // record's address field is the byte offset of the feature inside the row (row 0 at 0, 4 bytes per feature)
+  uint32_t row_bytes_sparse() const { return (opt & 4) ? 4u : (opt & 1) ? tile() * 2u : tile() * 4u; }
   uint32_t feat_off_sparse() const {  // chunk_trees = trees walked in lock-step = top images resident per pass
+    if (opt & 4) return 0u;
     const uint32_t row = row_bytes_sparse(), need = (uint32_t)chunk_trees * top_bytes_sparse();
     return (need + row - 1u) / row * row;
   }
-  uint32_t lds_bytes_sparse(uint32_t tuple_words) const { return feat_off_sparse() + tuple_words * row_bytes_sparse() + ((opt & 2) ? 0u : 64u); }
+  uint32_t lds_bytes_sparse(uint32_t tuple_words) const {
+    if (opt & 4) return (uint32_t)chunk_trees * top_bytes_sparse() + 64u;
+    return feat_off_sparse() + tuple_words * row_bytes_sparse() + ((opt & 2) ? 0u : 64u);
+  }
 };
 
 int num_variants();

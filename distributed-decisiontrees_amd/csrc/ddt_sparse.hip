@@ -41,21 +41,35 @@ __device__ __forceinline__ bool sp_right(uint32_t f, uint32_t thr, uint32_t w, u
   return (miss && mr) || (!miss && ge);
 }
 
-template <bool Q>
-__device__ __forceinline__ uint32_t sp_feature(uint32_t w, uint32_t lane_off) {
-  const uint32_t addr = (w & kSpAddrMask) | lane_off;
-  if (Q) return *reinterpret_cast<const DDT_LDS(uint16_t)*>(addr);  // ds_read_u16
-  return lds_u32(addr);
+// GF ("sparse_gf_*", tuples too wide for a feature tile in LDS): the feature comes from the tuple's own row in global memory --
+// gsrc = buffer resource over the block's rows, lane_off = byte offset of the lane's row in it, the record's address field = byte offset
+// of the feature in the row -- and gets here the raw -> key transform the staged tiles get once (stage_word)
+struct GfSrc {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t miss_raw, ieee;
+};
+
+template <bool Q, bool GF>
+__device__ __forceinline__ uint32_t sp_feature(uint32_t w, uint32_t lane_off, const GfSrc& gs) {
+  if constexpr (GF) {
+    uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(gs.rsrc, (w & kSpAddrMask) + lane_off, 0, 0);
+    if (gs.ieee) v = (v == gs.miss_raw) ? kMissSentinelIeee : ieee_key(v);  // wave-uniform branch
+    return v;
+  } else {
+    const uint32_t addr = (w & kSpAddrMask) | lane_off;
+    if (Q) return *reinterpret_cast<const DDT_LDS(uint16_t)*>(addr);  // ds_read_u16
+    return lds_u32(addr);
+  }
 }
 
 // The walk of all PU groups for one tile.  SLOW = the tile holds a missing value: apply the per-node missing rule
 // (block-uniform choice, like the perfect-tree kernels).
-template <int K, int U, int THREADS, bool SLOW, bool Q, bool DK>
-__device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
+template <int K, int U, int THREADS, bool SLOW, bool Q, bool DK, bool GF = false>
+__device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc, const GfSrc& gs) {
   constexpr int TOPB = (DK ? 8 : 12) << K;
   constexpr int STEPB = U * TOPB;  // U trees per pass: one PU group (or two)
   // Q: the u16 tile of the q16 pre-pass -- tuples t and t + 512 of a tile share a dword (rank_kernel)
-  const uint32_t lane_off = Q ? ((((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1)) : (uint32_t)tid * 4u;
+  const uint32_t lane_off = GF ? (uint32_t)tid * a.tuple_words * 4u : Q ? ((((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1)) : (uint32_t)tid * 4u;
   const uint32_t miss_key = a.miss_key, C = a.clusters;
   const uint4* __restrict__ deep = x.deep;
   const uint32_t n_steps = x.n_groups * 8u / (uint32_t)U;  // the host pads the image to whole passes
@@ -75,7 +89,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
       for (int u = 0; u < U; ++u) nd[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
       uint32_t f[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) f[u] = sp_feature<Q>(nd[u].y, lane_off);
+      for (int u = 0; u < U; ++u) f[u] = sp_feature<Q, GF>(nd[u].y, lane_off, gs);
 #pragma unroll
       for (int u = 0; u < U; ++u) m8[u] = (m8[u] << 1) + (sp_right<SLOW, Q>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
     }
@@ -116,7 +130,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
     if constexpr (DK) {  // first round: level K-1 out of the registers, every walker goes on to its level-K record
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t f = sp_feature<Q>(r8[u].y, lane_off);
+        const uint32_t f = sp_feature<Q, GF>(r8[u].y, lane_off, gs);
         const bool right = sp_right<SLOW, Q>(f, r8[u].x, r8[u].y, miss_key);
         rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (right ? 16u : 0u), 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -129,7 +143,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
         // the record stays opaque until its own visit: otherwise pieces of later visits are hoisted in front of the earlier gathers
         // and the first wait of a round covers half the queue
         asm volatile("" : "+v"(rr[u].x), "+v"(rr[u].y), "+v"(rr[u].z), "+v"(rr[u].w));
-        const uint32_t f = sp_feature<Q>(rr[u].y, lane_off);
+        const uint32_t f = sp_feature<Q, GF>(rr[u].y, lane_off, gs);
         const bool right = sp_right<SLOW, Q>(f, rr[u].x, rr[u].y, miss_key);
         const uint32_t lw = right ? (rr[u].y << 1) : rr[u].y;  // kSpRightLeaf (bit 30) or kSpLeftLeaf (bit 31) into the sign bit
         const bool leaf = (int32_t)lw < 0;
@@ -158,8 +172,9 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
   }
 }
 
-template <int K, int U, int THREADS, bool Q, bool DK>
+template <int K, int U, int THREADS, bool Q, bool DK, bool GF = false>
 __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
+  static_assert(!GF || (!Q && !DK), "global-feature fallback: fp32 keys, 16-byte level K-1 records");
   constexpr int TOPB = (DK ? 8 : 12) << K;  // bytes of one tree's top image
   constexpr int STEPB = U * TOPB;  // top images resident per pass: U trees walked in lock-step = U independent load chains per lane
   constexpr int ROW = Q ? THREADS * 2 : THREADS * 4;
@@ -174,7 +189,17 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   if (!DK) dma_chunk<THREADS, STEPB>(a.img, 0, 0, tid);  // top images of the first pass (dense level K: after the missing-value test)
 
   bool slow;
-  if constexpr (Q) {
+  GfSrc gs{};
+  if constexpr (GF) {
+    // no tile: the walk gathers its features from the block's rows (rows past n read as 0 through the resource's range check); the
+    // missing rule is applied at every visit
+    const uint64_t left = a.n - tile0;
+    const uint32_t rows_here = left < (uint64_t)THREADS ? (uint32_t)left : (uint32_t)THREADS;
+    gs.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.tuples + tile0 * W), 0, (int)(rows_here * W * 4u), 0x00020000);
+    gs.miss_raw = a.miss_raw;
+    gs.ieee = a.ieee;
+    slow = true;
+  } else if constexpr (Q) {
     // the feature tile is one contiguous block of W * 2048 bytes of the pre-pass's output: DMA it in (score_q16_kernel); the
     // first barrier of the walk publishes it
     const uint4* src = reinterpret_cast<const uint4*>(x.q16.q + (uint64_t)blockIdx.x * W * (uint32_t)THREADS);
@@ -235,18 +260,19 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   ra.init();
   double dacc = 0.0;
   const uint32_t C = a.clusters;
-  if (!slow) sparse_walk<K, U, THREADS, false, Q, DK>(a, x, tid, ra, dacc);
-  else sparse_walk<K, U, THREADS, true, Q, DK>(a, x, tid, ra, dacc);
+  if constexpr (GF) sparse_walk<K, U, THREADS, true, Q, DK, true>(a, x, tid, ra, dacc, gs);
+  else if (!slow) sparse_walk<K, U, THREADS, false, Q, DK>(a, x, tid, ra, dacc, gs);
+  else sparse_walk<K, U, THREADS, true, Q, DK>(a, x, tid, ra, dacc, gs);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
 }
 
-template <int K, int U, int THREADS, bool Q, bool DK = false>
+template <int K, int U, int THREADS, bool Q, bool DK = false, bool GF = false>
 static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_kernel<K, U, THREADS, Q, DK>;
+  auto kern = score_sparse_kernel<K, U, THREADS, Q, DK, GF>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
@@ -267,6 +293,8 @@ static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStrea
   Variant { "sparse_dk_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2, &launch_sparse_v<K, U, T, false, true> }
 #define DDT_SPQD(K, U) /* rank-quantised + dense level K */ \
   Variant { "sparse_qd_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 3, &launch_sparse_v<K, U, 1024, true, true> }
+#define DDT_SPG(K, U, T) /* global features: no tile in LDS, any tuple width */ \
+  Variant { "sparse_gf_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 4, &launch_sparse_v<K, U, T, false, false, true> }
 #define DDT_SPQ(K, U) /* rank-quantised: u16 feature tile of 1024 tuples = 16 waves per CU */ \
   Variant { "sparse_q_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 1, &launch_sparse_v<K, U, 1024, true> }
 
@@ -287,6 +315,9 @@ static const Variant g_sparse_variants[] = {
     // dense level K: K = 8 at two 256-tuple blocks per CU / K = 9 in one block of 512 where the 16-byte level K-1 records allow 7 / 8
     DDT_SPD(6, 8, 256), DDT_SPD(7, 8, 256), DDT_SPD(8, 8, 256), DDT_SPD(9, 8, 256), DDT_SPD(10, 8, 256),
     DDT_SPD(7, 8, 512), DDT_SPD(8, 8, 512), DDT_SPD(9, 8, 512), DDT_SPD(10, 8, 512),
+    // tuples too wide for any feature tile (more than ~540 words): every feature is gathered from the tuple's row in global memory.
+    // The correctness path of the sparse format, like the generic kernel of the perfect-tree format -- not a tuned kernel.
+    DDT_SPG(6, 8, 256),
 };
 
 int num_sparse_variants() { return (int)(sizeof(g_sparse_variants) / sizeof(g_sparse_variants[0])); }

@@ -87,6 +87,8 @@ int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {
       break;
     }
   }
+  // tuples too wide for any feature tile: the kernel that gathers its features from global memory (any width; the correctness path)
+  if (best < 0) best = find_variant("sparse_gf_k6_u8_t256");
   return best;
 }
 

@@ -186,9 +186,10 @@ int ddt_argmax_device(ddt_engine* e, const float* d_class_scores, uint32_t num_c
  *    Children must have larger indices than their parent (BFS, DFS pre-order, ...) and the lines of a tree must form a
  *    TREE: every node but the root is the child of exactly one earlier node (a shared child or an unreachable node is
  *    DDT_EINVAL).  tree_first_line[num_trees + 1] delimits the trees; a tree that is a single leaf is one line with
- *    both leaf flags set and the value twice.  Width limit of this build: the narrowest sparse kernel keeps a 64-tuple
- *    feature tile next to its top images, so num_features up to ~540 (tuple words * 256 B + 24 KiB <= 160 KiB of LDS);
- *    wider sparse models are refused with DDT_EUNSUPPORTED at load (dense models fall back to the generic kernel).
+ *    both leaf flags set and the value twice.  Width: the tuned sparse kernels keep a feature tile of 64..1024 tuples in
+ *    LDS next to their top images, which takes tuples of up to ~540 words (tuple words * 256 B + 24 KiB <= 160 KiB); wider
+ *    sparse models (num_features up to 2048) run on "sparse_gf_k6_u8_t256", which gathers every feature from the tuple's row in
+ *    global memory -- the correctness path of this format, like the generic kernel of the perfect-tree format.
  *    ddt_params: num_levels = upper bound of the depth (1..64), weights/findex lines per tree ignored.  Compare rule,
  *    missing rule, EMPTY slots, summation order and tree sharding are exactly those of the perfect format; the model
  *    is then scored with ddt_score / ddt_score_device.                                                           -- */

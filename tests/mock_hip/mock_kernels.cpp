@@ -236,6 +236,7 @@ const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
     Variant{"sparse_dk_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2, &launch_sparse},
     Variant{"sparse_dk_k9_u8_t512", kKindSparse, 9, 512, 1, 8, 8, 1, 2, &launch_sparse},
     Variant{"sparse_qd_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3, &launch_sparse},
+    Variant{"sparse_gf_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 4, &launch_sparse},
 };
 constexpr int kMockDense = (int)(sizeof(g_mock_variants) / sizeof(g_mock_variants[0]));
 }  // namespace

@@ -265,7 +265,8 @@ def test_single_process_group_with_the_real_engine(mock):
 
 
 @pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
-@pytest.mark.parametrize("T,depth,F,full,pm,G", [(24, 13, 20, 4, 650, 1), (40, 16, 64, 3, 700, 1), (19, 9, 12, 2, 500, 4), (9, 3, 5, 1, 400, 2)])
+@pytest.mark.parametrize("T,depth,F,full,pm,G", [(24, 13, 20, 4, 650, 1), (40, 16, 64, 3, 700, 1), (19, 9, 12, 2, 500, 4), (9, 3, 5, 1, 400, 2),
+                                                 (10, 11, 700, 2, 600, 1), (7, 5, 2048, 1, 500, 2)])   # tuples too wide for a feature tile in LDS
 def test_sparse_forests(mock, T, depth, F, full, pm, G, policy, seed):
     """ddt_load_model_sparse: validation, re-basing, top / deep image packing, kernel geometry choice -> launch -> the oracle's walk
     of the explicit-children stream; with G > 1 every virtual rank loads its shard and the partial scores are chain-added."""
@@ -283,6 +284,9 @@ def test_sparse_forests(mock, T, depth, F, full, pm, G, policy, seed):
         lines = np.ascontiguousarray(sp.node_lines, np.uint32)
         first = np.ascontiguousarray(sp.first, np.uint64)
         assert mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, g, G) == 0, mock.ddt_last_error(e)
+        if F > 600:   # no tile fits: the kernel that gathers its features from global memory
+            info = ddt.Info()
+            assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == "sparse_gf_k6_u8_t256"
         o = np.full(n, np.nan, np.float32)
         assert mock.ddt_score_device(e, x.ctypes.data, n, o.ctypes.data, s) == 0
         assert mock.hipStreamSynchronize(s) == 0

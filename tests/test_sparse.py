@@ -233,6 +233,27 @@ def test_gpu_every_sparse_kernel_variant(eng):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("F", [600, 2048])
+def test_gpu_sparse_tuples_too_wide_for_a_feature_tile(eng, F):
+    """More than ~540 tuple words: no feature tile fits next to the top images, the engine takes `sparse_gf_k6_u8_t256` (features
+    gathered from the tuple's row in global memory) -- both comparators, missing values with both directions, a ragged last block,
+    all three sums, the host feeder."""
+    T, D, rows = 19, 12, 777
+    for cmp_mode in (0, 1):
+        s = O.gen_sparse_model(T, D, F, 3, 650, 1, cmp_mode=cmp_mode)
+        x = O.gen_tuples(5, rows, F, 1)
+        used = np.unique(s.node_lines[:, 1] & 0x7FF)
+        x[::5, used[0]] = s.params.missing_bits
+        x[1::9, used[-1]] = s.params.missing_bits
+        for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (1, O.SUM_F64_SEQ), (2, O.SUM_REF_FLOPOCO)):
+            got = _gpu_sparse(eng, s, x, sum_mode=sum_mode)
+            assert eng.info().variant_name.decode() == "sparse_gf_k6_u8_t256"
+            want = O.score_sparse(s, x, sum_mode=ref)
+            assert np.array_equal(_bits(got), _bits(want)), (F, cmp_mode, sum_mode)
+        assert np.array_equal(_bits(eng.score(x)), _bits(want))
+
+
+@pytest.mark.gpu
 def test_gpu_sparse_tree_shards_and_chain(eng):
     import torch
 

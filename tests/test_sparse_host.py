@@ -91,18 +91,21 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
     for vid, name in _sparse_variants():
         ranked, dense = name.startswith(("sparse_q_", "sparse_qd_")), name.startswith(("sparse_dk_", "sparse_qd_"))
         K = int(re.search(r"_k(\d+)_", name).group(1))
-        if (ranked, dense, K) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
+        gf = name.startswith("sparse_gf_")   # features gathered from global memory: the address field is the byte offset in the tuple's row
+        if (ranked, dense, K, gf) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
             continue
-        seen_k.add((ranked, dense, K))
+        seen_k.add((ranked, dense, K, gf))
         top, deep, info = _images(s, vid, order)
         assert info[3] == K and info[2] * 8 >= T and top.size == info[2] * 8 * ((8 if dense else 12) << K) // 4
-        assert info[5] == (2048 if ranked else 4 * int(name.rsplit("_t", 1)[1]))  # u16 rows of 1024 tuples / fp32 rows of the tile
+        assert info[5] == (4 if gf else 2048 if ranked else 4 * int(name.rsplit("_t", 1)[1]))  # u16 rows of 1024 tuples / fp32 rows of the tile
+        assert not gf or info[4] == 0
         for r in range(x.shape[0]):
             for i in range(info[2] * 8):
                 got = _walk(top, deep, info, i, x[r], int(s.params.missing_bits), tables if ranked else None)
                 want = O.traverse_sparse(s, x[r], i) if i < T else 0
                 assert got == want, (name, order, r, i, hex(got), hex(want))
     assert len([k for k in seen_k if not k[0] and not k[1]]) >= 4 and len([k for k in seen_k if k[0]]) >= 4 and len([k for k in seen_k if k[1]]) >= 4
+    assert any(k[3] for k in seen_k)
 
 
 def test_hook_rejects_what_the_loader_rejects():
