@@ -214,6 +214,8 @@ def test_gpu_every_sparse_kernel_variant(eng):
         want = O.score_sparse(s, x)
         d = torch.from_numpy(x.view(np.int32)).cuda()
         ran = 0
+        eng.set_option("variant", -1)
+        eng.load_model_sparse(ddt.make_sparse_params(T, D, F), s.node_lines, s.first)   # (forcing a variant re-packs the LOADED model: this one)
         for vid, name in enumerate(ddt.variant_names()):
             if not name.startswith("sparse_"):
                 continue
