@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDT_ABI_VERSION 2
+#define DDT_ABI_VERSION 3 /* 3: ddt_stats grew (timed_launches, sum_prepass_ms, sum_score_ms) */
 
 /* Threading: an engine is not thread-safe -- calls on ONE engine must not overlap; different engines (also on the
  * same device) are independent.  ddt_*_device calls are asynchronous on the given stream; ddt_destroy and
