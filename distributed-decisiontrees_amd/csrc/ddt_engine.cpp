@@ -35,15 +35,24 @@ struct ddt_copy_pool {
   size_t bytes = 0, slice = 0, parts = 0;
 
   explicit ddt_copy_pool(int n_workers) {
-    for (int w = 0; w < n_workers; ++w) workers.emplace_back([this, w] { run((size_t)w + 1u); });
+    try {
+      workers.reserve((size_t)n_workers);
+      for (int w = 0; w < n_workers; ++w) workers.emplace_back([this, w] { run((size_t)w + 1u); });
+    } catch (...) {  // a thread could not be started: the ones that run must be joined before the members go away
+      shutdown();
+      throw;
+    }
   }
-  ~ddt_copy_pool() {
+  ~ddt_copy_pool() { shutdown(); }
+  void shutdown() {
     {
       std::lock_guard<std::mutex> lk(m);
       stop = true;
     }
     cv_go.notify_all();
-    for (std::thread& t : workers) t.join();
+    for (std::thread& t : workers)
+      if (t.joinable()) t.join();
+    workers.clear();
   }
   void piece(size_t i) const {
     const size_t b = i * slice;
@@ -1232,7 +1241,15 @@ static void parallel_copy(ddt_engine* e, void* dst, const void* src, size_t byte
     delete e->pool;
     e->pool = nullptr;
   }
-  if (!e->pool) e->pool = new ddt_copy_pool(e->feeder_threads - 1);
+  if (!e->pool) {
+    try {
+      e->pool = new ddt_copy_pool(e->feeder_threads - 1);
+    } catch (...) {  // no threads / no memory for the pool (std::system_error, std::bad_alloc): copy on the calling thread
+      e->pool = nullptr;
+      memcpy(dst, src, bytes);
+      return;
+    }
+  }
   e->pool->copy(dst, src, bytes);
 }
 
