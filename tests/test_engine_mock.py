@@ -621,3 +621,67 @@ def test_kernel_timing_ring(mock):
         for o in outs:
             assert np.array_equal(_bits(o), _bits(want))
     mock.ddt_destroy(e)
+
+
+def test_random_sparse_forests_options_and_call_sequences(mock):
+    """A trimmed copy of a fuzz loop run once over 300 seeds without a failure: random sparse forests (depth, width up to 1500 features,
+    compare / summation mode, clusters, shard), random sparse_* options incl. refused ones, reloads on one engine, resident and host
+    calls of awkward sizes with missing values -- every result equal to the oracle's score of the shard's sub-forest."""
+    mock.ddt_load_model_sparse.argtypes = [vp, C.POINTER(ddt.Params), vp, C.c_size_t, vp, C.c_uint32, C.c_uint32]
+    seen = set()
+    for seed in range(4, 16):
+        _sparse_fuzz_round(mock, seed, seen)
+    assert {"sparse_gf", "sparse_qd", "sparse_dk", "sparse"} <= seen, seen
+
+
+def _sparse_fuzz_round(mock, seed, seen):
+    rng = np.random.default_rng(seed)
+    mock.mock_reset(int(rng.integers(0, 3)), int(rng.integers(0, 1000)), 8)
+    e, s = _engine(mock), _stream(mock)
+    for _round in range(int(rng.integers(1, 4))):
+        T, depth = int(rng.integers(1, 30)), int(rng.integers(1, 15))
+        F = int(rng.choice([1, 5, 20, 64, 65, 130, 600, 1500]))
+        full, pm, cmp_mode = min(depth, int(rng.integers(0, 6))), int(rng.integers(0, 1000)), int(rng.integers(0, 2))
+        sp = O.gen_sparse_model(T, depth, F, full, pm, 1, cmp_mode=cmp_mode)
+        sum_mode = int(rng.choice([0, 1, 2]))
+        Cc = int(rng.choice([1, 2, 4, 8]))
+        p = ddt.make_sparse_params(T, depth, F, sp.params.missing_bits, cmp_mode, Cc, sum_mode)
+        spm = O.SparseModel(O.make_sparse_params(T, depth, F, cmp_mode=cmp_mode, clusters=Cc), sp.node_lines, sp.first)
+        G = int(rng.choice([1, 1, 2, 3])); G = min(G, T); g = int(rng.integers(0, G))
+        opts = {}
+        for opt, vals in ((b"sparse_top_levels", [-1, -1, 6, 7, 8, 9, 10]), (b"sparse_dk", [0, 1]), (b"sparse_q16", [0, 1]), (b"sparse_deep_order", [0, 1]),
+                          (b"feeder_rows", [64, 300, 5000]), (b"kernel_timing", [0, 1])):
+            v = int(rng.choice(vals)); opts[opt] = v
+            rc = mock.ddt_set_option(e, opt, v)
+            assert rc in (0, -5), (opt, v, rc)
+        lines = np.ascontiguousarray(sp.node_lines, np.uint32); first = np.ascontiguousarray(sp.first, np.uint64)
+        rc = mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, g, G)
+        if rc == -5:
+            continue   # forced K does not fit
+        assert rc == 0, (seed, mock.ddt_last_error(e), T, depth, F, opts)
+        info = ddt.Info(); mock.ddt_get_info(e, C.byref(info))
+        for _call in range(int(rng.integers(1, 3))):
+            n = int(rng.choice([0, 1, 63, 257, 1024, 1500]))
+            x = O.gen_tuples(int(rng.integers(0, 100)), max(n, 1), F, 1, missing_bits=int(sp.params.missing_bits))[:n]
+            if n and rng.random() < 0.5:
+                x[:: 3, int(rng.integers(0, F))] = sp.params.missing_bits
+            per = -(-T // G); b0 = min(g * per, T); b1 = min(b0 + per, T)
+            sm = (O.SUM_REF_NATIVE, O.SUM_F64_SEQ, O.SUM_REF_FLOPOCO)[sum_mode]
+            if b1 > b0:
+                f0, f1 = int(sp.first[b0]), int(sp.first[b1])
+                sub = O.SparseModel(O.make_sparse_params(b1 - b0, depth, F, cmp_mode=cmp_mode, clusters=Cc), np.ascontiguousarray(sp.node_lines).reshape(-1, 4)[f0:f1].copy(),
+                                    (np.asarray(sp.first[b0:b1 + 1], np.uint64) - np.uint64(f0)))
+                want = O.score_sparse(sub, x, sum_mode=sm) if n else np.zeros(0, np.float32)
+            else:
+                want = np.zeros(n, np.float32)
+            out = np.full(n, np.nan, np.float32)
+            if rng.random() < 0.5:
+                rc = mock.ddt_score(e, x.ctypes.data if n else None, n, out.ctypes.data if n else None)
+            else:
+                rc = mock.ddt_score_device(e, x.ctypes.data if n else None, n, out.ctypes.data if n else None, s)
+                assert mock.hipStreamSynchronize(s) == 0
+            ctx = dict(seed=seed, T=T, depth=depth, F=F, G=G, g=g, n=n, sum=sum_mode, C=Cc, cmp=cmp_mode, opts=opts, var=info.variant_name.decode())
+            assert rc == 0, ctx
+            assert np.array_equal(_bits(out), _bits(want)), ctx
+            seen.add(info.variant_name.decode().rsplit("_k", 1)[0])
+    mock.ddt_destroy(e)
