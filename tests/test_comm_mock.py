@@ -476,3 +476,64 @@ def test_hybrid_row_groups_of_tree_sharded_jobs(mock, Gt, Gr, policy, seed):
 
     _run_ranks(Gt * Gr, body)
     assert mock.mock_errors() == 0
+
+
+def _fuzz_job(mock, seed):
+    rng = np.random.default_rng(seed)
+    mock.mock_reset(int(rng.integers(0, 3)), int(rng.integers(0, 1000)), 8)
+    G = int(rng.choice([1, 2, 3, 4, 5, 8]))
+    K = int(rng.choice([1, 1, 1, 2, 5]))
+    rows_mode = K == 1 and rng.random() < 0.25
+    plan = []
+    for _ in range(int(rng.integers(1, 5))):
+        plan.append(dict(n=int(rng.choice([1, 5, 700, 1024, 4097, 9001])), chunk=int(rng.choice([5, 64, 700, 1024, 12_500_000])), taper=int(rng.choice([-1, 0, 1])),
+                         tmin=int(rng.choice([1, 16, 1024])), combine=int(rng.integers(0, 2)), host=bool(rng.random() < 0.3 and K == 1 and not rows_mode), prio=int(rng.integers(0, 2)),
+                         host_rows=int(rng.choice([300, 2500, 8 << 20])), bcast=int(rng.choice([-1, 0, 1])), sync=bool(rng.random() < 0.5)))
+    stream_first = bool(rng.integers(0, 2))
+    def body(r, barrier, shared):
+        k = Rank(mock, r, G, barrier, shared, classes=K, stream_first=stream_first, whole_model=rows_mode)
+        keep = []
+        for st in plan:
+            n = st["n"]
+            x = _tuples(n)
+            k.opt("chunk_rows", st["chunk"]); k.opt("taper_tail", st["taper"]); k.opt("taper_min_rows", st["tmin"]); k.opt("comm_stream_priority", st["prio"])
+            k.opt("host_rows", st["host_rows"]); k.opt("tuple_broadcast", st["bcast"])
+            if K > 1:
+                cs, lab = np.full((K, n), np.nan, np.float32), np.full(n, -1, np.int32)
+                assert mock.ddt_classify_sharded_device(k.c, x.ctypes.data, n, cs.ctypes.data, lab.ctypes.data, st["combine"], k.s) == 0, mock.ddt_comm_last_error(k.c)
+                keep.append((x, "cls", cs, lab, n))
+            elif rows_mode:
+                out = np.full(n, np.nan, np.float32)
+                assert mock.ddt_score_rowsharded_device(k.c, x.ctypes.data, n, out.ctypes.data, k.s) == 0, mock.ddt_comm_last_error(k.c)
+                keep.append((x, "rows", out, None, n))
+            elif st["host"]:
+                out = np.full(n, np.nan, np.float32)
+                assert mock.ddt_comm_score(k.c, x.ctypes.data, n, out.ctypes.data, st["combine"]) == 0, mock.ddt_comm_last_error(k.c)
+                keep.append((x, "tree", out, None, n))
+            else:
+                out = np.full(n, np.nan, np.float32)
+                assert mock.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, st["combine"], k.s) == 0, mock.ddt_comm_last_error(k.c)
+                keep.append((x, "tree", out, None, n))
+            if st["sync"]:
+                k.sync()
+        barrier.wait()
+        k.sync()
+        for x, kind, a, b, n in keep:
+            if kind == "cls":
+                want = _expected(G, n, K)
+                assert np.array_equal(a.view(np.uint32), want.view(np.uint32)) and np.array_equal(b, np.argmax(want, axis=0).astype(np.int32)), (seed, r, kind, n)
+            elif kind == "rows":
+                assert np.array_equal(a.view(np.uint32), _partial(0, 0, np.arange(n)).view(np.uint32)), (seed, r, kind, n)
+            else:
+                assert np.array_equal(a.view(np.uint32), _expected(G, n)[0].view(np.uint32)), (seed, r, kind, n)
+        k.close(barrier)
+    _run_ranks(G, body)
+    assert mock.mock_errors() == 0, seed
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8, 13, 21, 34])
+def test_random_jobs_options_and_call_sequences(mock, seed):
+    """A trimmed copy of a fuzz loop run once over 400 seeds without a failure: 1-8 ranks, scalar / class / replica jobs, resident and
+    host calls of awkward sizes back to back, chunk sizes from 5 rows up, tapered and untapered tails, both combines, stream priority,
+    tuple broadcast on and off, random schedules."""
+    _fuzz_job(mock, seed)
