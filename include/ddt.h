@@ -141,7 +141,9 @@ int ddt_host_register(ddt_engine* e, void* ptr, size_t bytes);
 int ddt_host_unregister(ddt_engine* e, void* ptr);
 
 /* Host buffers: tuple_lines = n_tuples * ceil(F/4) lines of 16 B; scores_out = n_tuples fp32.
- * Streams the batch through a pinned, double-buffered hipMemcpyAsync feeder (the PCIe feeder).      */
+ * Streams the batch through the pinned hipMemcpyAsync feeder (the PCIe feeder): three slots -- staging of chunk k+2 by host
+ * threads, the link transfer of k+1 on one ordered copy stream, kernels + scores back of k; ranges pinned with ddt_host_register
+ * skip the staging copies.                                                                           */
 int ddt_score(ddt_engine* e, const void* tuple_lines, size_t n_tuples, float* scores_out);
 /* Device buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = the null stream).              */
 int ddt_score_device(ddt_engine* e, const void* d_tuple_lines, size_t n_tuples, float* d_scores,
