@@ -1269,7 +1269,11 @@ static int score_host(ddt_engine* e, const void* tuple_lines, size_t n, float* s
   DeviceGuard dg(e->device);
   if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
   const size_t W = tuple_words(e->p);
-  const size_t rows = e->feeder_rows < n ? e->feeder_rows : n;
+  // rows per chunk: the option, but never more than kFeederMaxChunkBytes of tuples per slot (a 2048-feature model at the default 2^20
+  // rows would pin 3 x 8 GiB of host memory and as much of the device's)
+  size_t rows = e->feeder_rows < n ? e->feeder_rows : n;
+  const size_t by_bytes = std::max<size_t>(kFeederMaxChunkBytes / (W * 4u) / 1024u * 1024u, 1024u);
+  if (rows > by_bytes) rows = by_bytes;
   const size_t outs = classify ? K + 1 : 1;
   int rc = feeder_reserve(e, rows, W, outs);
   if (rc) return rc;

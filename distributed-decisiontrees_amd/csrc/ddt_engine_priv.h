@@ -16,6 +16,7 @@ namespace ddt {
 
 constexpr uint32_t kMaxLdsBytes = 160u * 1024u;     // MI355X: 160 KiB LDS per CU / workgroup
 constexpr uint32_t kStreamLdsBudget = 40u * 1024u;  // stream kernels: keep >= 4 resident blocks per CU
+constexpr size_t kFeederMaxChunkBytes = 512u << 20;  // tuples per feeder slot (three pinned + three device buffers of this size at most)
 constexpr int kFeederSlots = 3, kQSlots = 1 + kFeederSlots;
 
 inline double now_ms() {

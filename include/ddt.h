@@ -294,7 +294,7 @@ const char* ddt_strerror(int code);
 const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure on this engine */
 /* Tuning knobs: "variant" (kernel variant id, -1 = auto; a loaded model is re-packed -- a variant that does not fit it is refused with
  * DDT_EUNSUPPORTED and the model stays loaded as it was), "feeder_rows" (rows per feeder
- * chunk), "feeder_threads" (host threads of the staging copy, default 8), "kernel_timing" (see ddt_stats),
+ * chunk, default 2^20; a chunk never holds more than 512 MiB of tuples), "feeder_threads" (host threads of the staging copy, default 8), "kernel_timing" (see ddt_stats),
  * "q16_fused_prepass" / "q16_grouped_prepass" (1 = default; 0 = never rank with all tables resident together / never
  * split the rank pre-pass over feature groups; both 0 = the transpose + rank kernels) and "q16_prepass_groups" (0 =
  * cheapest, default; 1, 2, 4, 8 = exactly that many feature groups): A/B switches, effective at the next model load;
