@@ -95,6 +95,10 @@ struct GroupGuard {
   }
 };
 
+// rows of a host-buffer super-chunk: the option, but never more than 2 GiB of tuples on the device at once (8 Mi rows of 2048
+// features would ask for 64 GiB); whole 1024-tuple tiles
+size_t host_rows_cap(size_t words) { return std::max<size_t>(((size_t)2u << 30) / (words * 4u) / 1024u * 1024u, 1024u); }
+
 int comm_init_common(ddt_comm* c) {
   CHIP(c, hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking));
   for (int b = 0; b < 2; ++b) {
@@ -406,7 +410,7 @@ int ddt_comm_score(ddt_comm* c, const void* tuple_lines, size_t n, float* scores
   if (!tuple_lines || !scores_out) return cfail(c, DDT_EINVAL, "NULL host buffer");
   DeviceGuard dg(c->e->device);
   if (!dg.ok) return cfail(c, DDT_EHIP, "hipSetDevice(%d) failed", c->e->device);
-  const size_t W = tuple_words(c->e->p), rows = std::min(c->host_rows, n);
+  const size_t W = tuple_words(c->e->p), rows = std::min(std::min(c->host_rows, n), host_rows_cap(W));
   if (!c->hs) CHIP(c, hipStreamCreateWithFlags(&c->hs, hipStreamNonBlocking));
   if (rows > c->h_rows || W > c->h_words) {
     CHIP(c, hipStreamSynchronize(c->hs));
@@ -687,7 +691,7 @@ int group_run(ddt_group* g, const void* tuple_lines, size_t n, float* scores_out
   const bool classify = labels_out != nullptr || class_scores_out != nullptr;
   if (classify != (K > 1)) return gfail(g, DDT_ESTATE, K > 1 ? "multi-class model loaded: use ddt_group_classify" : "scalar model loaded: use ddt_group_score");
   const size_t W = tuple_words(g->eng[0]->p);
-  const size_t rows = std::min(g->group_rows, n);
+  const size_t rows = std::min(std::min(g->group_rows, n), host_rows_cap(W));
   int prev = -1;
   (void)hipGetDevice(&prev);
   if (rows > g->cap_rows || W > g->cap_words || K > g->cap_classes) {
