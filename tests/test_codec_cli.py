@@ -188,3 +188,32 @@ def test_cli_rejects_a_bad_rank_before_touching_a_device(tmp_path):
         assert r.returncode == 1 and b"--ranks / --rank / --combine" in r.stderr
     r = subprocess.run(base + ["--ranks", "2"], capture_output=True)          # --rank is required
     assert r.returncode == 2 and b"missing --rank" in r.stderr
+
+
+def test_csr_blocks_round_trip_and_corrupted_blocks_are_refused_or_decoded():
+    """Encode -> decode recovers what the wire carries (tuple lines x 4 features, result lines x 4 tuples) for random run parameters;
+    a block with one field flipped or replaced decodes to something or is refused with DDT_EINVAL, never anything else."""
+    L = ddt.lib()
+    A = C.c_uint64 * 12
+    rng = np.random.default_rng(7)
+    seen = set()
+    for _ in range(4000):
+        T, D, F = int(rng.integers(1, 3000)), int(rng.integers(1, 12)), int(rng.integers(1, 2049))
+        p, csr = ddt.make_params(T, D, F), A()
+        n, G = int(rng.integers(0, 1 << 33)), int(rng.integers(1, 21))
+        rc = L.ddt_csr_encode(C.byref(p), n, G, C.byref(csr))
+        assert rc in (0, -5), rc                                   # -5: the count does not fit CSR207's 32 bits of result lines
+        if rc:
+            continue
+        mode, k = int(rng.integers(0, 3)), int(rng.integers(0, 12))
+        if mode == 1:
+            csr[k] ^= 1 << int(rng.integers(0, 64))
+        elif mode == 2:
+            csr[k] = int(rng.integers(0, 1 << 63))
+        q, nt, nd = ddt.Params(), C.c_uint64(), C.c_uint32()
+        rc = L.ddt_csr_decode(C.byref(csr), C.byref(q), C.byref(nt), C.byref(nd))
+        assert rc in (0, -1), rc
+        seen.add((mode, rc))
+        if mode == 0:
+            assert rc == 0 and (q.num_trees, q.num_levels, q.num_features, nt.value, nd.value) == (T, D, (F + 3) // 4 * 4, (n + 3) // 4 * 4, G)
+    assert {(0, 0), (1, 0), (1, -1), (2, -1)} <= seen
