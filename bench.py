@@ -112,6 +112,8 @@ def main():
                          "driven from Python through torch.distributed (needed for --backend gloo)")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant id (-1 = engine's choice)")
     ap.add_argument("--sum-mode", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="engine option set before the model is loaded (ddt_set_option; A/B switches such as q16_persistent=1, q16_prepass_nt=1); repeatable")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend used for the barrier / timing reduction (and for --collectives torch); "
                          "gloo lets N ranks share one GPU for a functional test")
@@ -179,6 +181,9 @@ def main():
     W = ddt.tuple_words(F)
     eng = ddt.Engine(local)
     eng.set_option("variant", args.variant)
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        eng.set_option(key, int(val))
     rows_mode = world > 1 and args.shard == "rows"
     shard = (0, 1) if rows_mode else (rank, world)
     if args.shard_of > 1:

@@ -446,6 +446,9 @@ constexpr uint32_t kQ16MinTreeLevels = 480;  // trees x levels from which the ra
                                              // (profiles/r02_sweep_q16_small.json: 60 x d8 +4 %, 80 x d8 +5 %, 112 x d8 +7 %, 200 x d6 +9 %; round 3 with the _s2 walk,
                                              // profiles/r03_sweep_fused_rank_experiment_ilp8_s2.json: 100 x d6 +17 %, 100 x d8 +11 %, while 30 x d6 still loses 15 %)
 
+constexpr bool kQ16PersistentAuto = false;       // (first measurements pending: the automatic choice stays as it was)
+constexpr uint32_t kQ16PersistentMaxTrees = 512;  // per engine and class: above this the plain launch is as fast (measured, profiles/r04_*)
+
 bool variant_fits(const Variant& v, const ddt_engine* e) {
   if (v.kind == kKindSparse) return false;  // sparse forests pick their kernel in ddt_sparse_host.cpp
   if (v.kind == kKindGeneric) return true;
@@ -492,6 +495,13 @@ int auto_variant(const ddt_engine* e) {
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
     // (the cluster-major form only where there is a ring to save -- more than one cluster -- and the sum follows the reference's
     // order: the fp64 sum of sum_mode 1 runs in stream order, which a permuted image would change)
+    // persistent blocks ("_p", depth 8): what they save is the block turn-over per tile, a fixed cost -- it pays where a tile is
+    // short (few chunks: the shards of a tree-sharded job, ensembles of a few hundred trees); and a one-vs-all model whose classes
+    // hold equally many trees is walked in ONE launch (profiles/r04_*)
+    if (e->p.sum_mode != 1u && e->q16_persistent != 0) {
+      const int i = find_variant("q16_d8_c8_u4_gl_s2_cm_p");
+      if (i >= 0 && variant_fits(variant(i), e) && (e->q16_persistent == 1 || (kQ16PersistentAuto && (e->num_classes > 1 || max_trees(e) <= kQ16PersistentMaxTrees)))) return i;
+    }
     if (e->p.clusters_per_tuple > 1u && e->p.sum_mode != 1u) {
       const int i = find_variant("q16_d8_c8_u4_gl_s2_cm");
       if (i >= 0 && variant_fits(variant(i), e)) return i;
@@ -511,6 +521,11 @@ int auto_variant(const ddt_engine* e) {
 }
 
 void free_images(ddt_engine* e) {
+  for (void** p : {&e->d_mc_img, &e->d_mc_img_slow}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  e->mc_seg_chunks = 0;
   for (Ensemble& m : e->ens) {
     for (void** p : {&m.d_img, &m.d_img_slow, &m.d_tables, &m.d_tabK, &m.d_tabS, &m.d_prepass}) {
       if (*p) (void)hipFree(*p);
@@ -812,7 +827,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint32_t W = tuple_words(e->p);
   if (need_xT) HIP_TRY(e, hipMalloc(&e->q_xT[k], cap * W * 4));
   HIP_TRY(e, hipMalloc(&e->q_q[k], cap * W * 2));
-  HIP_TRY(e, hipMalloc(&e->q_flags[k], (cap / 1024 + 2 + 2 * kQ16GroupedCounters) * 4));  // + the 8-byte work counters of the fused / grouped pre-pass
+  HIP_TRY(e, hipMalloc(&e->q_flags[k], (cap / 1024 + 2 + 2 * kQ16GroupedCounters + kQ16TileCounterWords) * 4));  // + the 8-byte work counters of the fused / grouped pre-pass + the _p kernels' tile counter
   e->q_rows[k] = cap;
   return DDT_OK;
 }
@@ -833,6 +848,27 @@ int select_and_build(ddt_engine* e) {
     int rc = variant(vid).kind == kKindQ16 ? build_image_q16(e, variant(vid), m, rt, &m == &e->ens[0])  // tables live in ens[0]
                                           : build_image(e, variant(vid), m);
     if (rc) return rc;
+  }
+  // "_p" kernels walk every class of a one-vs-all model in ONE launch when the classes' images can stand back to back: equally
+  // many trees per class (=> equally many chunks and real PU groups).  Otherwise: one launch per class, as with every other kernel.
+  for (void** p : {&e->d_mc_img, &e->d_mc_img_slow}) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  e->mc_seg_chunks = 0;
+  if (variant(vid).kind == kKindQ16 && (variant(vid).opt & 8) && e->num_classes > 1) {
+    bool same = true;
+    for (const Ensemble& m : e->ens) same = same && m.trees() == e->ens[0].trees() && m.img_bytes == e->ens[0].img_bytes;
+    if (same && e->ens[0].img_bytes) {
+      const size_t b = e->ens[0].img_bytes;
+      HIP_TRY(e, hipMalloc(&e->d_mc_img, b * e->num_classes));
+      HIP_TRY(e, hipMalloc(&e->d_mc_img_slow, b * e->num_classes));
+      for (uint32_t k = 0; k < e->num_classes; ++k) {
+        HIP_TRY(e, hipMemcpy(static_cast<char*>(e->d_mc_img) + k * b, e->ens[k].d_img, b, hipMemcpyDeviceToDevice));
+        HIP_TRY(e, hipMemcpy(static_cast<char*>(e->d_mc_img_slow) + k * b, e->ens[k].d_img_slow, b, hipMemcpyDeviceToDevice));
+      }
+      e->mc_seg_chunks = e->ens[0].img_chunks;
+    }
   }
   e->variant_id = vid;
   return DDT_OK;
@@ -931,8 +967,10 @@ int timing_end(ddt_engine* e, hipStream_t s) {
   return DDT_OK;
 }
 
+// all_classes (only with e->mc_seg_chunks != 0, a "_p" kernel): ONE launch walks every class -- d_scores = [K][n] per-class sums (may
+// be NULL), labels (may be NULL) = their argmax
 int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t n, float* d_scores, hipStream_t s,
-                 bool reuse_prepass = false) {
+                 bool reuse_prepass = false, bool all_classes = false, int32_t* labels = nullptr) {
   ScoreArgs a;
   fill_args(e, m, d_tuples, n, d_scores, &a);
   const Variant& v = variant(e->variant_id);
@@ -954,6 +992,16 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
     qa.n_pad = (n + 1023) / 1024 * 1024;
     qa.real_groups = (m.trees() + 7u) / 8u;
+    qa.prepass_nt = (uint32_t)e->q16_prepass_nt;
+    if (all_classes) {
+      a.img = reinterpret_cast<const uint4*>(e->d_mc_img);
+      qa.img_slow = reinterpret_cast<const uint4*>(e->d_mc_img_slow);
+      a.n_trees = m.img_trees * e->num_classes;
+      a.n_chunks = e->mc_seg_chunks * e->num_classes;
+      qa.n_segs = e->num_classes;
+      qa.seg_chunks = e->mc_seg_chunks;
+      qa.labels = labels;
+    }
     a.aux = &qa;
   }
   const bool timing = e->kernel_timing && e->q_slot == 0;
@@ -980,6 +1028,8 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
 
 // class scores [K][n] into d_class_scores, then argmax into d_labels (if non-NULL)
 int launch_classify(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s) {
+  // "_p" kernels: every class in one pass over the tuples, sums and labels written by the scoring kernel itself
+  if (e->mc_seg_chunks) return launch_score(e, e->ens[0], d_tuples, n, d_class_scores, s, false, true, d_labels);
   // Two streams: class 0 (with the shared pre-pass) on the caller's stream, then odd classes on the engine's own stream and
   // even ones on the caller's.  Each class is one launch of n / tile blocks; its last wave of blocks leaves most CUs idle
   // for one block time (5 % of a 100-tree launch over 10 M tuples) -- with a second launch in flight those CUs have work.
@@ -1582,6 +1632,16 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   if (!strcmp(key, "q16_fused_prepass")) {  // 0: never the single-group form (all tables resident together); both 0: transpose + rank kernels.
                                             // These three take effect at the next model load (A/B and tests); defaults 1, 1, 0
     e->q16_fused_prepass = value != 0;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "q16_prepass_nt")) {  // A/B: bit 0 = nontemporal stores of the rank tiles, bit 1 = nontemporal tuple loads (effective at the next call)
+    if (value < 0 || value > 3) return fail(e, DDT_EINVAL, "q16_prepass_nt must be 0..3");
+    e->q16_prepass_nt = (int)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "q16_persistent")) {  // 1 / 0: prefer / never pick the persistent "_p" rank-quantised kernel; -1: automatic.  Effective at the next model load
+    if (value < -1 || value > 1) return fail(e, DDT_EINVAL, "q16_persistent must be -1, 0 or 1");
+    e->q16_persistent = (int)value;
     return DDT_OK;
   }
   if (!strcmp(key, "feeder_threads")) {

@@ -126,6 +126,13 @@ struct ddt_engine {
   int q16_grouped_prepass = 1;  // option "q16_grouped_prepass": 0 = never split the pre-pass over feature groups
   int q16_prepass_groups = 0;   // option "q16_prepass_groups": force the number of feature groups (A/B), 0 = automatic
   int q16_fused_prepass = 1;  // option "q16_fused_prepass": 0 forces the transpose + rank kernels (A/B, tests)
+  int q16_prepass_nt = 0;     // option "q16_prepass_nt": bit 0 = nontemporal stores of the rank tiles, bit 1 = nontemporal tuple loads (A/B)
+  int q16_persistent = -1;    // option "q16_persistent": 1 / 0 = prefer / never pick the persistent "_p" kernel, -1 = automatic
+  // "_p" kernels, multi-class models whose classes hold equally many trees: the classes' images back to back (fast / slow), so that
+  // ONE launch walks every class (Q16Aux::n_segs); mc_seg_chunks = chunks per class, 0 = not built (one launch per class)
+  void* d_mc_img = nullptr;
+  void* d_mc_img_slow = nullptr;
+  uint32_t mc_seg_chunks = 0;
   // optional per-call kernel timing (option "kernel_timing"): start / before scoring kernel / end
   // Every timed launch takes an event triple from a ring; ddt_get_stats resolves the pending ones (waiting for the newest), so a caller
   // may queue up to kTimingRing launches without a host synchronisation in between.

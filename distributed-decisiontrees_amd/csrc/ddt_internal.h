@@ -76,7 +76,16 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   const uint4* prepass_img;   // LDS-resident pre-pass: concatenated LDS images, one per feature group
   PrepassPlan prepass;        // groups == 0: use transpose_kernel + rank_kernel
   uint32_t real_groups;       // "_cm" kernels: PU groups that hold a real tree, ceil(T / 8) (the image may be padded with EMPTY groups)
+  // "_p" (persistent) kernels.  The image may hold SEVERAL ensembles back to back ("segments": the classes of a one-vs-all model,
+  // each padded to seg_chunks whole chunks, real_groups real PU groups in each): segment k's sum goes to out[k * n + row] and the
+  // label (argmax over the segments, lowest index on ties, a NaN never beats a number) to labels[row].  n_segs == 1: plain scores.
+  uint32_t n_segs = 1;        // ensembles in the image
+  uint32_t seg_chunks = 0;    // chunks per ensemble (0 = all of ScoreArgs::n_chunks)
+  int32_t* labels = nullptr;  // n_segs > 1: argmax over the segments (may be NULL); `ScoreArgs::out` (may be NULL then) = [n_segs][n] sums
+  uint32_t* tile_counter = nullptr;  // work counter of the persistent blocks (zeroed per launch; engine workspace behind the pre-pass counters)
+  uint32_t prepass_nt = 0;    // A/B (option "q16_prepass_nt"): bit 0 = the pre-pass writes the rank tiles with nontemporal stores, bit 1 = reads the tuples with nontemporal loads
 };
+constexpr uint32_t kQ16TileCounterWords = 2;  // behind the kQ16GroupedCounters 8-byte counters
 
 // ---------------------------------------------------------------------------------------------------
 // Sparse (explicit-children) forests -- include/ddt.h ddt_load_model_sparse, kernel in ddt_sparse.hip.

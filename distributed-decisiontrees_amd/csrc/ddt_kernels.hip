@@ -687,7 +687,7 @@ constexpr int kFusedThreads = 1024;  // two tiles per block and pass; 16 waves x
 __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
                                                                    const uint4* __restrict__ img_base, const PrepassPlan pl, uint32_t parts,
                                                                    uint32_t miss_raw, uint32_t ieee, uint32_t* __restrict__ q32,
-                                                                   uint32_t* __restrict__ tile_flags, unsigned long long* __restrict__ counters) {
+                                                                   uint32_t* __restrict__ tile_flags, unsigned long long* __restrict__ counters, const uint32_t nt) {
   const uint32_t tid = threadIdx.x, t4 = tid & 3u, lpt = W / 4u;
   // one group (all tables resident): every block the same image, parts = 1.  Two groups of 4 lines: block b works for
   // group (b / parts) % 2 on row partition b % parts (see grouped_rank_kernel for why the partitions follow the XCDs)
@@ -713,7 +713,8 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint64_t rj = slice_row + 16u * (uint32_t)j;
-        v[h][j] = (rj < n && line < lpt) ? *reinterpret_cast<const u32x4*>(tuples + rj * W + 4u * line) : u32x4{0u, 0u, 0u, 0u};
+        const u32x4* src = reinterpret_cast<const u32x4*>(tuples + rj * W + 4u * line);
+        v[h][j] = (rj < n && line < lpt) ? ((nt & 2u) ? __builtin_nontemporal_load(src) : *src) : u32x4{0u, 0u, 0u, 0u};
       }
     }
   };
@@ -730,7 +731,11 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
       const u32x4 r = rank_line(par_off + 4u * (line - line_lo) * 32u, P, ieee, miss_raw, tile * kQTile + own < n,
                                 tile * kQTile + own + 512u < n, v[0][i], v[1][i], any_missing);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + own] = r[c];
+      for (int c = 0; c < 4; ++c) {
+        uint32_t* dst = q32 + (tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + own;
+        if (nt & 1u) __builtin_nontemporal_store(r[c], dst);
+        else *dst = r[c];
+      }
     }
     return any_missing;
   };
@@ -780,7 +785,7 @@ template <int L>
 __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
                                                                      const uint4* __restrict__ img_base, const PrepassPlan pl, uint32_t parts,
                                                                      uint32_t miss_raw, uint32_t ieee, uint32_t* __restrict__ q32,
-                                                                     uint32_t* __restrict__ tile_flags, unsigned long long* __restrict__ counters) {
+                                                                     uint32_t* __restrict__ tile_flags, unsigned long long* __restrict__ counters, const uint32_t nt) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, lpt = W / 4u;
   const uint32_t part = blockIdx.x % parts, g = (blockIdx.x / parts) % pl.groups;
   const uint64_t tiles = n_pad / kQTile;
@@ -805,7 +810,8 @@ __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint3
       for (int h = 0; h < 2; ++h) {
         const uint64_t row = tile * kQTile + 512u * (uint32_t)h + (L == 2 ? (lt & ~63u) + 32u * (uint32_t)l + ((lt >> 1) & 31u) : lt);
         const uint32_t line = line_lo + (L == 2 ? t2 : (uint32_t)l);
-        v[l][h] = (row < n && line < lpt) ? *reinterpret_cast<const u32x4*>(tuples + row * W + 4u * line) : u32x4{0u, 0u, 0u, 0u};
+        const u32x4* src = reinterpret_cast<const u32x4*>(tuples + row * W + 4u * line);
+        v[l][h] = (row < n && line < lpt) ? ((nt & 2u) ? __builtin_nontemporal_load(src) : *src) : u32x4{0u, 0u, 0u, 0u};
       }
     }
   };
@@ -848,7 +854,11 @@ __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint3
         const u32x4 r = rank_line(par_off + 4u * (uint32_t)l * 32u, P, ieee, miss_raw, tile * kQTile + own < n, tile * kQTile + own + 512u < n,
                                   cur[l][0], cur[l][1], miss);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) q32[(tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + own] = r[c];
+        for (int c = 0; c < 4; ++c) {
+          uint32_t* dst = q32 + (tile * W + 4u * line + (uint32_t)c) * (uint64_t)(kQTile / 2) + own;
+          if (nt & 1u) __builtin_nontemporal_store(r[c], dst);
+          else *dst = r[c];
+        }
       }
       if (k + 1u < 4u) {
 #pragma unroll
@@ -1117,7 +1127,7 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
   if (e != hipSuccess) return e;
   // tile flags + (8-byte aligned, right behind them) the work counters of the fused / grouped pre-pass
   unsigned long long* counter = reinterpret_cast<unsigned long long*>(x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u));
-  e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters) * 4, s);
+  e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters + kQ16TileCounterWords) * 4, s);  // + the _p kernels' tile counter
   if (e != hipSuccess) return e;
   const PrepassPlan& pp = x.prepass;
   if (pp.groups && pp.lines >= 4u) {
@@ -1133,7 +1143,7 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fused_rank_kernel, dim3(parts * pp.groups * per_pair), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp,
-                       parts, a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
+                       parts, a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter, x.prepass_nt);
   } else if (pp.groups) {  // one launch, blocks split over feature groups x row partitions (XCDs)
     uint32_t lds = 0;
     for (uint32_t g = 0; g < pp.groups; ++g) lds = pp.bytes[g] > lds ? pp.bytes[g] : lds;
@@ -1148,7 +1158,7 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gk, dim3(grid), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp, parts, a.miss_raw, a.ieee,
-                       reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter);
+                       reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter, x.prepass_nt);
   } else {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(transpose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((W + 1) * 256 * 4));
     if (e != hipSuccess) return e;
@@ -1177,6 +1187,212 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
   }
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kQTile), lds, s, a, x);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// "_p": the persistent form of the rank-quantised kernel (always _gl + _s2 + _cm).  What the plain form pays per tile is the
+// block turn-over: a new block DMAs its 64 KiB rank tile and its first chunk and only then starts to walk, while the CU's
+// other block runs alone at 16 waves -- 9 % of a 125-tree shard's time (16 chunks per tile), 1 % at 1000 trees.  Here a block
+// (two per CU, grid = 2 x CUs) stays, and while it walks tile t the rank tile of its NEXT tile sits in 16 VGPRs per lane
+// (four coalesced 16-byte loads, issued right after the tile switch): the switch is barrier -> four ds_write_b128 -> barrier.
+// With an even chunk count the chunk ring continues across tiles (chunk 0 of the next tile is requested during the last
+// chunk, into the buffer that is free then).  Tiles are handed out two ahead: the first two statically (block b: b, b + grid),
+// the rest through one atomic counter -- thread 0 takes the ticket during the last chunk and leaves it in the padding word
+// (record 0 of tree 0, never read by the _s2 walk) of chunk buffer 1, where every wave finds it behind the tile-end barrier.
+// Several ensembles in one image ("segments", Q16Aux): the classes of a one-vs-all model are walked in ONE pass over the tile --
+// at a segment's last chunk the lane's sum is stored to out[k][row] and compared with the best so far; the label is written
+// once per tuple (BASELINE config 5: K launches + an argmax pass before).  Per class the order of the adds is the reference's
+// (FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131, Core.sv:486-541): each segment is a cluster-major image of its own.
+// ---------------------------------------------------------------------------------------------------
+template <int D, int CT, int U>
+__global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a, const Q16Aux x) {
+  constexpr int THREADS = kQTile;
+  constexpr bool GL = true, S2 = true;
+  static_assert(U == 4 && CT % U == 0 && (CT / U) % 2 == 0 && CT % 8 == 0, "geometry (_s2: an even number of sub-groups per chunk)");
+  constexpr int TREE_BYTES = 4 << D;                    // records only: the leaves are gathered from the global image
+  constexpr int CHUNK_BYTES = TREE_BYTES * CT;
+  constexpr int GCHUNK_UNITS = (8 << D) * CT / 16;
+  constexpr int GSKIP = GCHUNK_UNITS - CHUNK_BYTES / 16;
+  constexpr int FEAT_OFF = 2 * CHUNK_BYTES;
+  constexpr int ROW = kQTile * 2;
+  constexpr uint32_t PAD_WORD = (uint32_t)CHUNK_BYTES;  // LDS address of record 0 of tree 0 in chunk buffer 1 (padding: never walked)
+  static_assert(FEAT_OFF % ROW == 0, "row|lane OR trick");
+  const int tid = threadIdx.x;
+  const uint32_t W = a.tuple_words, n_chunks = a.n_chunks;
+  const uint32_t n_segs = x.n_segs, seg_chunks = x.seg_chunks ? x.seg_chunks : n_chunks;
+  const uint32_t tiles = (uint32_t)(x.n_pad / kQTile), grid = gridDim.x;
+  const uint32_t units = W * (ROW / 16);  // 16-byte units of one rank tile
+  const bool ring = (n_chunks & 1u) == 0u;
+  const uint32_t lane2 = (((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1);  // see rank_kernel
+  const uint32_t Cc = a.clusters, C = 1u;
+  const uint32_t cm_lg = (uint32_t)__builtin_ctz(Cc | 0x100u), cm_real = x.real_groups;
+  const int SUM1 = (int)a.sum_mode;  // 0 or 2 (the fp64 sum is defined on the stream order: never a _cm image)
+  const bool exact = SUM1 == 2;
+
+  // rank tile of tile t -> 4 x 16 bytes per lane; always four loads per wave (units past the tile re-read its last one)
+  auto prefetch = [&](u32x4 (&pre)[4], uint32_t t) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(x.q + (uint64_t)t * W * kQTile);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t u = (uint32_t)tid + (uint32_t)i * THREADS;
+      pre[i] = __builtin_nontemporal_load(src + (u < units ? u : units - 1u));  // read once
+    }
+  };
+
+  uint32_t cur = blockIdx.x, nxt = cur + grid;  // cur < tiles: the launcher never starts more blocks than tiles
+  u32x4 pre[4];
+  prefetch(pre, cur);
+  bool slow = __builtin_amdgcn_readfirstlane((int)x.tile_flags[cur]) != 0;
+  bool pre0 = false;  // chunk 0 of `cur` was requested during the previous tile's last chunk
+  TopRecs<4> top_a, top_b;
+
+  for (;;) {
+    const uint4* img = slow ? x.img_slow : a.img;
+    const bool has_next = nxt < tiles;
+    // the next tile's flag, needed at this tile's last chunk (which image its chunk 0 comes from)
+    const bool slow_n = has_next && __builtin_amdgcn_readfirstlane((int)x.tile_flags[has_next ? nxt : cur]) != 0;
+    const uint4* img_n = slow_n ? x.img_slow : a.img;
+    if (!pre0) dma_chunk<THREADS, CHUNK_BYTES>(img, 0, 0, tid);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // every wave is behind the tile-end barrier: the old tile is dead
+      const uint32_t u = (uint32_t)tid + (uint32_t)i * THREADS;
+      if (u < units) *reinterpret_cast<DDT_LDS(u32x4)*>((uint32_t)FEAT_OFF + u * 16u) = pre[i];
+    }
+    prefetch(pre, has_next ? nxt : cur);  // flies during this tile's walks
+
+    const __amdgpu_buffer_rsrc_t leaf_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(img), 0, (int)(n_chunks * (uint32_t)(GCHUNK_UNITS * 16)), 0x00020000);
+    RefAcc<1> ra;
+    ra.init();
+    double dacc[1] = {0.0};
+    uint32_t cm_groups = 0, cm_cluster = 0, cm_bound = (cm_real + Cc - 1u) >> cm_lg;
+    float cm_total = 0.f;
+    uint32_t seg = 0, seg_left = seg_chunks;
+    float best = 0.f;
+    int32_t arg = 0;
+    uint32_t ticket = 0;
+    const uint64_t row = (uint64_t)cur * kQTile + (uint64_t)tid;
+
+#define DDT_QPCOMPUTE(BUF, KIDX)                                                                       \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int sg = 0; sg < CT / U; ++sg) {                                            \
+      float lf[1][U];                                                                                  \
+      const LeafSrc gl = {leaf_rsrc, (uint32_t)(KIDX) * (uint32_t)(GCHUNK_UNITS * 16) + (uint32_t)((CT + sg * U - 1) * (4 << D))}; \
+      const uint32_t kn = (sg + 1 < CT / U) ? (uint32_t)(KIDX) : ((uint32_t)(KIDX) + 1u < n_chunks ? (uint32_t)(KIDX) + 1u : 0u); \
+      const int sn = (sg + 1 < CT / U) ? sg + 1 : 0;                                                   \
+      TopRecs<4>& top_cur = (sg & 1) ? top_b : top_a;                                                  \
+      TopRecs<4>& top_nxt = (sg & 1) ? top_a : top_b;                                                  \
+      top_wait(top_cur);                                                                               \
+      top_issue<TREE_BYTES>(top_nxt, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
+      if (!slow_l) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+      else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+      fold_leaves<U, 1, 0>(lf, sg & 1, C, ra, dacc, exact_l);                                          \
+      if ((sg & 1) == 1) { /* a PU group is complete */                                                \
+        if (++cm_groups == cm_bound) { /* ... and it was its cluster's last */                         \
+          cm_total = exact_l ? radd_exact(ra.a[0][0], cm_total) : ra.a[0][0] + cm_total;              \
+          ra.a[0][0] = 0.f;                                                                            \
+          ++cm_cluster;                                                                                \
+          cm_bound += cm_cluster < Cc ? (cm_real + Cc - 1u - cm_cluster) >> cm_lg : 0u;                \
+        }                                                                                              \
+      }                                                                                                \
+    }                                                                                                  \
+    if (--seg_left == 0u) { /* wave-uniform: the ensemble ends with this chunk */                      \
+      if (n_segs == 1u) {                                                                              \
+        if (row < a.n) a.out[row] = cm_total;                                                          \
+      } else {                                                                                         \
+        if (a.out && row < a.n) a.out[(uint64_t)seg * a.n + row] = cm_total;                           \
+        if (seg == 0u || cm_total > best || (best != best && cm_total == cm_total)) {                  \
+          best = cm_total;                                                                             \
+          arg = (int32_t)seg;                                                                          \
+        }                                                                                              \
+      }                                                                                                \
+      ++seg;                                                                                           \
+      seg_left = seg_chunks;                                                                           \
+      ra.a[0][0] = 0.f;                                                                                \
+      cm_groups = 0u;                                                                                  \
+      cm_cluster = 0u;                                                                                 \
+      cm_bound = (cm_real + Cc - 1u) >> cm_lg;                                                         \
+      cm_total = 0.f;                                                                                  \
+    }                                                                                                  \
+  } while (0)
+
+    // the tile's last chunk: thread 0 takes the block's ticket for the tile after next (begin), and leaves it in the padding
+    // word of chunk buffer 1 (end) -- that buffer is the live one (ring) or dead since the previous chunk barrier (odd chunk
+    // count), and the next DMA into it is only issued behind the barrier after the tile-end barrier
+    auto last_begin = [&]() {
+      if (tid == 0) ticket = has_next ? 2u * grid + atomicAdd(x.tile_counter, 1u) : 0xFFFFFFFFu;
+    };
+    auto last_end = [&]() {
+      if (tid == 0) lds_st_u32(PAD_WORD, ticket);
+    };
+
+    auto chunks = [&](auto hot_tag) {
+      constexpr bool HOT = decltype(hot_tag)::value;
+      const bool slow_l = HOT ? false : slow, exact_l = HOT ? false : exact;
+      top_issue<TREE_BYTES>(top_a, img);
+      for (uint32_t k = 0; k < n_chunks; k += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // chunk k is in buffer 0 (k = 0: and the rank tile is in place); everyone is done with buffer 1
+        const bool more1 = k + 1 < n_chunks;
+        if (more1) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 1) * GSKIP, k + 1, CHUNK_BYTES, tid);
+        else last_begin();
+        DDT_QPCOMPUTE(0, k);
+        if (!more1) {
+          last_end();
+          break;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const bool more2 = k + 2 < n_chunks;
+        if (more2) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 2) * GSKIP, k + 2, 0, tid);
+        else {
+          if (has_next) dma_chunk<THREADS, CHUNK_BYTES>(img_n, 0, 0, tid);  // ring: chunk 0 of the next tile
+          last_begin();
+        }
+        DDT_QPCOMPUTE(1, k + 1);
+        if (!more2) last_end();
+      }
+      top_wait(top_a);  // the last request (never used; it went to top_a) must not outlive this pass
+    };
+    if (!slow && SUM1 == 0) chunks(std::true_type{});
+    else chunks(std::false_type{});
+#undef DDT_QPCOMPUTE
+    if (n_segs > 1u && x.labels && row < a.n) x.labels[row] = arg;
+    if (!has_next) break;
+    __syncthreads();  // tile end: every walk of this tile is done (rank tile, chunk buffers), the ticket is in place
+    const uint32_t nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_u32(PAD_WORD));
+    cur = nxt;
+    nxt = nn;
+    slow = slow_n;
+    pre0 = ring;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing requested may outlive the wave
+}
+
+template <int D, int CT, int U>
+static hipError_t launch_q16p(const ScoreArgs& a, const Variant& v, hipStream_t s) {
+  Q16Aux x = *reinterpret_cast<const Q16Aux*>(a.aux);
+  const uint64_t tiles = (a.n + kQTile - 1) / kQTile;
+  if (tiles == 0) return hipSuccess;
+  if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  if (x.n_segs == 0u || (x.seg_chunks ? x.seg_chunks * x.n_segs : a.n_chunks) != a.n_chunks || a.sum_mode == 1u) return hipErrorInvalidValue;
+  x.tile_counter = x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters;  // behind the pre-pass counters (launch_q16_prepass)
+  auto kern = score_q16p_kernel<D, CT, U>;
+  const uint32_t lds = v.lds_bytes_q16(a.tuple_words);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  if (!x.skip_prepass) {
+    e = launch_q16_prepass(a, x, s);  // its memset also zeroes the tile counter
+    if (e != hipSuccess) return e;
+  } else {
+    e = hipMemsetAsync(x.tile_counter, 0, kQ16TileCounterWords * 4, s);
+    if (e != hipSuccess) return e;
+  }
+  if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
+  uint64_t grid = 2ull * a.num_cus;  // two resident blocks per CU (LDS: 2 x 80 KiB at 32 words per tuple; 8 waves per SIMD)
+  if (grid > tiles) grid = tiles;
+  hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(kQTile), lds, s, a, x);
   return hipGetLastError();
 }
 
@@ -1463,6 +1679,8 @@ static const Variant g_variants[] = {
     DDT_QGS("q16_d8_c8_u4_gl_s2", 8, 8, 4),
     // _cm: cluster-major image order, one accumulator + a running total instead of the ring of C accumulators (sum modes 0 and 2)
     DDT_QO("q16_d8_c8_u4_gl_s2_cm", 8, 8, 4, 7),
+    // _p: persistent blocks, the next rank tile prefetched into registers, several ensembles (classes) per pass (opt bit 3)
+    Variant{"q16_d8_c8_u4_gl_s2_cm_p", kKindQ16, 8, kQTile, 1, 8, 4, 1, 15, &launch_q16p<8, 8, 4>},
     // _s2 on the layouts that keep their leaves in LDS (depths 5-7): 100 x d6 x 28 features, 10 M tuples: 1.297 vs 1.333 ms
     DDT_QO("q16_d6_c16_u4_s2", 6, 16, 4, 2),
     DDT_QO("q16_d7_c8_u4_s2", 7, 8, 4, 2),

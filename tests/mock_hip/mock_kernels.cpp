@@ -124,9 +124,11 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
   op->run = [=] {
     const uint32_t D = a.levels, half = 1u << D, tw = 2u * half, CT = (uint32_t)v.chunk_trees, row = v.tile() * 2u;
     const bool gl = (v.opt & 1) != 0, cm = (v.opt & 4) != 0;
-    std::vector<float> leaf(a.n_trees), img_order(a.n_trees);
+    // "_p" kernels: the image may hold n_segs ensembles (classes) back to back, each with its own cluster-major order
+    const uint32_t S = x.n_segs ? x.n_segs : 1u, seg_trees = a.n_trees / S;
+    std::vector<float> leaf(seg_trees), img_order(a.n_trees);
     // "_cm" images: PU groups in cluster-major order (csrc/ddt_engine.cpp pack_image_q16); original group g sits at position pos[g]
-    std::vector<uint32_t> pos(a.n_trees / 8u);
+    std::vector<uint32_t> pos(seg_trees / 8u);
     for (uint32_t g = 0; g < (uint32_t)pos.size(); ++g) {
       pos[g] = g;
       if (cm && g < x.real_groups) {
@@ -154,8 +156,22 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
         }
         img_order[t] = f_of(img[leaf_off + m - half]);
       }
-      for (uint32_t t = 0; t < a.n_trees; ++t) leaf[t] = img_order[pos[t / 8u] * 8u + t % 8u];  // back to the stream order the sum is defined on
-      a.out[i] = reduce(leaf.data(), a.n_trees, a.clusters, a.sum_mode);
+      float best = 0.0f;
+      int32_t arg = 0;
+      for (uint32_t sg = 0; sg < S; ++sg) {
+        for (uint32_t t = 0; t < seg_trees; ++t) leaf[t] = img_order[sg * seg_trees + pos[t / 8u] * 8u + t % 8u];  // back to the stream order the sum is defined on
+        const float v = reduce(leaf.data(), seg_trees, a.clusters, a.sum_mode);
+        if (S == 1u) {
+          a.out[i] = v;
+        } else {
+          if (a.out) a.out[(size_t)sg * a.n + i] = v;
+          if (sg == 0u || v > best || (best != best && v == v)) {
+            best = v;
+            arg = (int32_t)sg;
+          }
+        }
+      }
+      if (S > 1u && x.labels) x.labels[i] = arg;
     }
   };
   enqueue(s, op);
@@ -213,6 +229,7 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
 // lists fall through to what exists
 const Variant g_mock_variants[] = {
     Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_records},
+    Variant{"q16_d8_c8_u4_gl_s2_cm_p", kKindQ16, 8, 1024, 1, 8, 4, 1, 15, &launch_q16},
     Variant{"q16_d8_c8_u4_gl_s2_cm", kKindQ16, 8, 1024, 1, 8, 4, 1, 7, &launch_q16},
     Variant{"q16_d8_c8_u4_gl_s2", kKindQ16, 8, 1024, 1, 8, 4, 1, 3, &launch_q16},
     Variant{"q16_d8_c8_u4_gl", kKindQ16, 8, 1024, 1, 8, 4, 1, 1, &launch_q16},

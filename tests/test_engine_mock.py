@@ -129,7 +129,10 @@ def test_feeder_double_buffering(mock, variant, feeder_rows, policy, seed):
 
 
 @pytest.mark.parametrize("policy,seed", SCHEDULES)
-@pytest.mark.parametrize("T,D,F,K,variant", [(100, 8, 32, 10, "q16_d8_c8_u4_gl"), (60, 6, 16, 3, None), (35, 8, 32, 5, "d8_t1024_r1_c4_u4_dma_f")])
+@pytest.mark.parametrize("T,D,F,K,variant", [(100, 8, 32, 10, "q16_d8_c8_u4_gl"), (60, 6, 16, 3, None), (35, 8, 32, 5, "d8_t1024_r1_c4_u4_dma_f"),
+                                             # the persistent kernel: every class in ONE launch (classes of equal size: the images stand back
+                                             # to back) / one launch per class (37 trees over 5 classes: 8, 8, 7, 7, 7)
+                                             (100, 8, 32, 10, "q16_d8_c8_u4_gl_s2_cm_p"), (35, 8, 32, 5, "q16_d8_c8_u4_gl_s2_cm_p"), (37, 8, 32, 5, "q16_d8_c8_u4_gl_s2_cm_p")])
 def test_class_launches_on_two_streams(mock, T, D, F, K, variant, policy, seed):
     """One-vs-all classes: class 0 (+ the shared rank pre-pass) on the caller's stream, odd classes on the engine's own stream."""
     mock.mock_reset(policy, seed, 8)
@@ -553,9 +556,10 @@ def test_cluster_major_image_order(mock, T, clusters):
     e = _engine(mock)
     for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
         p = ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode)
-        _load(mock, e, m, p, "q16_d8_c8_u4_gl_s2_cm")
-        assert mock.ddt_score(e, x.ctypes.data, n, out.ctypes.data) == 0, mock.ddt_last_error(e)
-        assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=ref))), (T, clusters, sum_mode)
+        for name in ("q16_d8_c8_u4_gl_s2_cm", "q16_d8_c8_u4_gl_s2_cm_p"):     # the persistent kernel reads the same image
+            _load(mock, e, m, p, name)
+            assert mock.ddt_score(e, x.ctypes.data, n, out.ctypes.data) == 0, mock.ddt_last_error(e)
+            assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=ref))), (T, clusters, sum_mode, name)
     p64 = ddt.make_params(T, D, F, clusters=clusters, sum_mode=1)
     assert mock.ddt_set_option(e, b"variant", _variant(mock, "q16_d8_c8_u4_gl_s2_cm")) == 0   # (a refused forced variant keeps the loaded model)
     rc = mock.ddt_load_model_shard(e, C.byref(p64), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8, 0, 1)

@@ -106,7 +106,7 @@ def test_bit_exact_vs_oracle_all_variants(eng, T, D, F, rows, dist):
         assert np.array_equal(_bits(got), _bits(want_ieee)), f"variant {names[v]} differs from the reference-order sum (IEEE adds)"
         got2 = _gpu_score(eng, m, x, 2, v)
         assert np.array_equal(_bits(got2), _bits(want)), f"variant {names[v]} differs from the reference adder network"
-        if names[v].endswith("_cm"):  # cluster-major image order: refused for the fp64 sum, which is defined on the stream order
+        if "_cm" in names[v]:  # cluster-major image order: refused for the fp64 sum, which is defined on the stream order
             with pytest.raises(ddt.DDTError) as ei:
                 _gpu_score(eng, m, x, 1, v)
             assert ei.value.code == -5

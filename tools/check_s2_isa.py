@@ -161,7 +161,7 @@ def main():
     dis = disassemble(lib)
     n_kernels, n_sets, failed = 0, 0, 0
     for name, body in kernels(dis):
-        if "score_q16_kernel" not in name:
+        if "score_q16_kernel" not in name and "score_q16p_kernel" not in name:
             continue
         sets, bad = check_kernel(name, body)
         if sets < 8:  # kernels without _s2 only have the compiler's argument loads
