@@ -203,6 +203,7 @@ const Variant& sparse_variant(int i);
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact /* sum_mode 2 */, hipStream_t s);
 hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s);
+hipError_t launch_argmax_strided(const float* scores, uint32_t K, size_t pitch, size_t n, int32_t* labels, hipStream_t s);
 hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits,
                                hipStream_t s);
 

@@ -984,11 +984,64 @@ __device__ __forceinline__ void walk_trees_q16_s2(const TopRecs<U>& q, const uin
   }
 }
 
+// The same walk with the ORDER OF THE LDS READS pinned (round 4).  Left to itself hipcc interleaves only two of the four trees of a
+// sub-group (26 VGPRs: counted waits lgkmcnt(1)), and none at all once a kernel carries more live registers (the persistent kernel
+// with its 16 prefetch registers: every wait lgkmcnt(0), one chain at a time, 9 % slower).  Here every stage issues its four reads
+// back to back -- 4 x node record, 4 x feature rank, ... -- and a sched_barrier that only VALU / SALU / VMEM instructions may
+// cross keeps the stages apart: a wave has four dependent chains in flight, the waits come out as lgkmcnt(3).
+#define DDT_PIN_DS() __builtin_amdgcn_sched_barrier(0x0016)
+template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW, bool GL>
+__device__ __forceinline__ void walk_trees_q16_s2_pin(const TopRecs<U>& q, const uint32_t base, const uint32_t lane2, float (&leaf)[U],
+                                                      const LeafSrc& gleaf) {
+  static_assert(D >= 3, "two scalar levels + at least one LDS level");
+  uint32_t m4[U], nd[U], f[U];
+  auto rank_at = [&](uint32_t rec) -> uint32_t {
+    const uint32_t off = SLOW ? ((rec >> 16) & 0xFFFEu) : (rec >> 16);
+    return *reinterpret_cast<const DDT_LDS(uint16_t)*>((off | lane2) + (uint32_t)FEAT_OFF);
+  };
+  auto goes_right = [&](uint32_t rec, uint32_t fv) -> bool {
+    bool right = fv >= (rec & 0xFFFFu);
+    if (SLOW) right = (fv == kQMissing) ? ((rec >> 16) & 1u) != 0u : right;
+    return right;
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) f[u] = rank_at(q.t[u].y);  // level 0: the root, uniform
+  DDT_PIN_DS();
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool r0 = goes_right(q.t[u].y, f[u]);
+    nd[u] = r0 ? q.t[u].w : q.t[u].z;  // level-1 record
+    m4[u] = r0 ? 12u : 8u;
+    f[u] = rank_at(nd[u]);
+  }
+  DDT_PIN_DS();
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    m4[u] = (m4[u] << 1) + (goes_right(nd[u], f[u]) ? 4u : 0u);
+    nd[u] = lds_u32(m4[u] + (base + (uint32_t)(u * TREE_BYTES)));
+  }
+  DDT_PIN_DS();
+#pragma unroll
+  for (int lvl = 2; lvl < D; ++lvl) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) f[u] = rank_at(nd[u]);
+    DDT_PIN_DS();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      m4[u] = (m4[u] << 1) + (goes_right(nd[u], f[u]) ? 4u : 0u);
+      if (lvl + 1 < D) nd[u] = lds_u32(m4[u] + (base + (uint32_t)(u * TREE_BYTES)));
+      else leaf[u] = GL ? gather_leaf<D>(gleaf, u, m4[u]) : lds_f32(m4[u] + (base + (uint32_t)(u * TREE_BYTES)));
+    }
+    DDT_PIN_DS();
+  }
+}
+
 template <int D, int CT, int U, int OPT = 0>
 __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a, const Q16Aux x) {  // 8 waves per SIMD = two blocks per CU
   constexpr int THREADS = kQTile;
-  constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0, HOTDISP = S2, CM = (OPT & 4) != 0;
+  constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0, HOTDISP = S2, CM = (OPT & 4) != 0, PIN = (OPT & 16) != 0;
   static_assert(!S2 || U == 4, "_s2: 4 trees in flight");
+  static_assert(!PIN || S2, "the pinned read order exists for the _s2 walk");
   constexpr int TREE_BYTES = GL ? (4 << D) : (8 << D);  // bytes of a tree in LDS (GL: node records only)
   constexpr int CHUNK_BYTES = TREE_BYTES * CT;          // bytes of a chunk in LDS
   constexpr int GCHUNK_UNITS = (8 << D) * CT / 16;      // 16-byte units of a chunk in the global image
@@ -1052,8 +1105,13 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
         TopRecs<4>& top_nxt = (sg & 1) ? top_a : top_b;                                                \
         top_wait(top_cur);                                                                             \
         top_issue<TREE_BYTES>(top_nxt, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
-        if (!slow_l) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
-        else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+        if constexpr (PIN) {                                                                           \
+          if (!slow_l) walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+          else walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+        } else {                                                                                       \
+          if (!slow_l) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+          else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+        }                                                                                              \
       } else {                                                                                         \
         if (!slow_l) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
         else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
@@ -1205,10 +1263,10 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
 // once per tuple (BASELINE config 5: K launches + an argmax pass before).  Per class the order of the adds is the reference's
 // (FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131, Core.sv:486-541): each segment is a cluster-major image of its own.
 // ---------------------------------------------------------------------------------------------------
-template <int D, int CT, int U>
+template <int D, int CT, int U, bool PIN>
 __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a, const Q16Aux x) {
   constexpr int THREADS = kQTile;
-  constexpr bool GL = true, S2 = true;
+  constexpr bool GL = true;  // leaves gathered from the global image; levels 0-1 always from SGPRs (_s2)
   static_assert(U == 4 && CT % U == 0 && (CT / U) % 2 == 0 && CT % 8 == 0, "geometry (_s2: an even number of sub-groups per chunk)");
   constexpr int TREE_BYTES = 4 << D;                    // records only: the leaves are gathered from the global image
   constexpr int CHUNK_BYTES = TREE_BYTES * CT;
@@ -1285,8 +1343,13 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
       TopRecs<4>& top_nxt = (sg & 1) ? top_a : top_b;                                                  \
       top_wait(top_cur);                                                                               \
       top_issue<TREE_BYTES>(top_nxt, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
-      if (!slow_l) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
-      else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+      if constexpr (PIN) {                                                                             \
+        if (!slow_l) walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+        else walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+      } else {                                                                                         \
+        if (!slow_l) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+        else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+      }                                                                                                \
       fold_leaves<U, 1, 0>(lf, sg & 1, C, ra, dacc, exact_l);                                          \
       if ((sg & 1) == 1) { /* a PU group is complete */                                                \
         if (++cm_groups == cm_bound) { /* ... and it was its cluster's last */                         \
@@ -1370,7 +1433,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing requested may outlive the wave
 }
 
-template <int D, int CT, int U>
+template <int D, int CT, int U, bool PIN>
 static hipError_t launch_q16p(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   Q16Aux x = *reinterpret_cast<const Q16Aux*>(a.aux);
   const uint64_t tiles = (a.n + kQTile - 1) / kQTile;
@@ -1378,7 +1441,7 @@ static hipError_t launch_q16p(const ScoreArgs& a, const Variant& v, hipStream_t 
   if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
   if (x.n_segs == 0u || (x.seg_chunks ? x.seg_chunks * x.n_segs : a.n_chunks) != a.n_chunks || a.sum_mode == 1u) return hipErrorInvalidValue;
   x.tile_counter = x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters;  // behind the pre-pass counters (launch_q16_prepass)
-  auto kern = score_q16p_kernel<D, CT, U>;
+  auto kern = score_q16p_kernel<D, CT, U, PIN>;
   const uint32_t lds = v.lds_bytes_q16(a.tuple_words);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1589,14 +1652,14 @@ hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, floa
 // wins against a number (BASELINE config 5: one-vs-all, per-class sums then argmax -- an extension, the
 // reference has no classes)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ scores, uint32_t K, size_t n,
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ scores, uint32_t K, size_t pitch, size_t n,
                                                      int32_t* __restrict__ labels) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float best = scores[i];
     int32_t arg = 0;
     for (uint32_t k = 1; k < K; ++k) {
-      const float s = scores[(size_t)k * n + i];
+      const float s = scores[(size_t)k * pitch + i];
       if (s > best || (best != best && s == s)) {
         best = s;
         arg = (int32_t)k;
@@ -1606,14 +1669,16 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ s
   }
 }
 
-hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s) {
+// n columns of a [K][pitch] block (a row group's slice of the class sums of a hybrid job: pitch = rows of the whole batch)
+hipError_t launch_argmax_strided(const float* scores, uint32_t K, size_t pitch, size_t n, int32_t* labels, hipStream_t s) {
   if (n == 0) return hipSuccess;
   (void)hipGetLastError();  // do not inherit a stale error
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048 * 8) blocks = 2048 * 8;
-  hipLaunchKernelGGL(argmax_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, scores, K, n, labels);
+  hipLaunchKernelGGL(argmax_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, scores, K, pitch, n, labels);
   return hipGetLastError();
 }
+hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s) { return launch_argmax_strided(scores, K, n, n, labels, s); }
 
 // ---------------------------------------------------------------------------------------------------
 // synthetic tuple generator: x[r][j] = unit(splitmix64(SEED_X + r*F + j))
@@ -1680,7 +1745,10 @@ static const Variant g_variants[] = {
     // _cm: cluster-major image order, one accumulator + a running total instead of the ring of C accumulators (sum modes 0 and 2)
     DDT_QO("q16_d8_c8_u4_gl_s2_cm", 8, 8, 4, 7),
     // _p: persistent blocks, the next rank tile prefetched into registers, several ensembles (classes) per pass (opt bit 3)
-    Variant{"q16_d8_c8_u4_gl_s2_cm_p", kKindQ16, 8, kQTile, 1, 8, 4, 1, 15, &launch_q16p<8, 8, 4>},
+    Variant{"q16_d8_c8_u4_gl_s2_cm_p", kKindQ16, 8, kQTile, 1, 8, 4, 1, 15, &launch_q16p<8, 8, 4, true>},
+    Variant{"q16_d8_c8_u4_gl_s2_cm_pu", kKindQ16, 8, kQTile, 1, 8, 4, 1, 15, &launch_q16p<8, 8, 4, false>},  // the compiler's read order (A/B)
+    // _x: the plain launch with the pinned read order (four chains in flight per lane)
+    Variant{"q16_d8_c8_u4_gl_s2_cm_x", kKindQ16, 8, kQTile, 1, 8, 4, 1, 7, &launch_q16<8, 8, 4, 23>},
     // _s2 on the layouts that keep their leaves in LDS (depths 5-7): 100 x d6 x 28 features, 10 M tuples: 1.297 vs 1.333 ms
     DDT_QO("q16_d6_c16_u4_s2", 6, 16, 4, 2),
     DDT_QO("q16_d7_c8_u4_s2", 7, 8, 4, 2),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDT_ABI_VERSION 3 /* 3: ddt_stats grew (timed_launches, sum_prepass_ms, sum_score_ms) */
+#define DDT_ABI_VERSION 4 /* 4: hybrid jobs (ddt_comm_create_hybrid, ddt_score_hybrid_device, ...), ddt_comm_abort; 3: ddt_stats grew */
 
 /* Threading: an engine is not thread-safe -- calls on ONE engine must not overlap; different engines (also on the
  * same device) are independent.  ddt_*_device calls are asynchronous on the given stream; ddt_destroy and
@@ -259,6 +259,44 @@ int  ddt_comm_score(ddt_comm* c, const void* tuple_lines, size_t n_tuples, float
 int  ddt_classify_sharded_device(ddt_comm* c, const void* d_tuple_lines, size_t n_tuples, float* d_class_scores,
                                  int32_t* d_labels, int combine, void* hip_stream);
 
+/* -- the two modes composed ("hybrid": tree groups x row groups) -----------------------------------------------------------
+ *    The reference runs either mode (DTInference.sv:28-37): the ensemble spread over the devices and the partial results added along
+ *    the chain (PCIeReceiver.sv:241-264, ResultsCombiner.sv:292-311), or the ensemble on every device and the tuples dealt out, results
+ *    interleaved (PCIeReceiver.sv:289-312, ResultsCombiner.sv:371-391).  On a node of 8 GPUs the composition is the fast one: the n
+ *    ranks form n / tree_ranks ROW GROUPS of tree_ranks consecutive ranks; rank r holds tree shard r % tree_ranks of tree_ranks
+ *    (ddt_load_model_shard / _sparse / _multiclass with exactly that shard_index / shard_count) and its row group r / tree_ranks scores
+ *    rows [lo, hi) = ddt_hybrid_rows(n, row groups, row group) of a batch.  Inside a row group the job is the tree-sharded one (chunk
+ *    pipeline, all-reduce or chain, on a communicator split off the world communicator with ncclCommSplit); the work a tree-sharded
+ *    rank does for EVERY tuple (reading it, ranking it against the shard's thresholds) shrinks by the number of row groups, and the
+ *    all-reduce spans tree_ranks ranks.  tree_ranks == n_ranks is the tree-sharded job, tree_ranks == 1 the row-sharded replicas.
+ *    gather != 0: while the next piece is scored, every finished piece is handed to the ranks with the same tree shard in the other row
+ *    groups (grouped ncclSend / ncclRecv on the world communicator, straight into place): every rank ends up with all n rows, as in the
+ *    other two jobs.  gather == 0: a rank only writes rows [lo, hi) of the result (scores stay with their row group, the way the
+ *    reference returns a device's rows from that device).  Only rows [lo, hi) of d_tuple_lines are read.
+ *    ddt_comm_score on a hybrid communicator: host tuples cross PCIe once in the whole job (1 / n_ranks per rank, handed on inside the
+ *    row group over xGMI), every rank receives all scores.  ddt_score_sharded_device / ddt_classify_sharded_device /
+ *    ddt_score_rowsharded_device refuse a hybrid communicator (DDT_ESTATE), and the hybrid calls refuse a plain one.               -- */
+typedef struct ddt_comm_layout_t {
+  int rank, n_ranks;           /* in the world communicator */
+  int tree_ranks, tree_rank;   /* size of / rank inside the communicator the partial scores are combined over = shard_count / shard_index
+                                  this rank's engine must hold (plain communicator: n_ranks, rank) */
+  int row_groups, row_group;   /* plain communicator: 1, 0 */
+} ddt_comm_layout_t;
+int  ddt_comm_create_hybrid(ddt_comm** out, ddt_engine* e, int rank, int n_ranks, int tree_ranks, const void* unique_id);
+int  ddt_comm_layout(const ddt_comm* c, ddt_comm_layout_t* out);
+/* host-only: rows [*lo, *hi) of row group `row_group` of `row_groups`: equal slices in whole 1024-tuple tiles (whole result lines), the
+ * last group takes what is left, groups past the end are empty */
+int  ddt_hybrid_rows(size_t n_tuples, int row_groups, int row_group, size_t* lo, size_t* hi);
+int  ddt_score_hybrid_device(ddt_comm* c, const void* d_tuple_lines, size_t n_tuples, float* d_scores, int combine, int gather,
+                             void* hip_stream);
+int  ddt_classify_hybrid_device(ddt_comm* c, const void* d_tuple_lines, size_t n_tuples, float* d_class_scores, int32_t* d_labels,
+                                int combine, int gather, void* hip_stream);
+/* A peer failed before (or inside) its collective -- its call returned an error, or its process died: the other ranks' streams would
+ * wait for it for ever (RCCL has no timeout of its own).  The launcher tells the survivors, they call ddt_comm_abort (ncclCommAbort on
+ * the communicators): their queued collectives end, streams and ddt_comm_destroy return; the results of the job are undefined and the
+ * communicator refuses every further call with DDT_ESTATE.  (The reference has no such path: a stalled device stalls the ring.) */
+int  ddt_comm_abort(ddt_comm* c);
+
 /* Single-process multi-GPU job: n engines + one RCCL communicator over them (ncclCommInitAll), one worker thread per
  * device.  ddt_group_load_model* gives device g tree shard g; ddt_group_score takes HOST buffers, replicates the
  * tuples on every device (one H2D copy per device, the analogue of the reference's tuple broadcast), runs the
@@ -266,6 +304,10 @@ int  ddt_classify_sharded_device(ddt_comm* c, const void* d_tuple_lines, size_t 
  * (options, stats). */
 typedef struct ddt_group ddt_group;
 int  ddt_group_create(ddt_group** out, int n_devices, const int* device_ids);
+/* the hybrid layout in one process: row groups of tree_ranks consecutive devices (tree_ranks divides n_devices);
+ * ddt_group_load_model* gives device i tree shard i % tree_ranks of tree_ranks, ddt_group_score / ddt_group_classify run the hybrid job
+ * (tuples over PCIe once, 1 / n_devices per device) and return all rows from device 0 */
+int  ddt_group_create_hybrid(ddt_group** out, int n_devices, const int* device_ids, int tree_ranks);
 void ddt_group_destroy(ddt_group* g);
 const char* ddt_group_last_error(const ddt_group* g);
 ddt_engine* ddt_group_engine(ddt_group* g, int index);

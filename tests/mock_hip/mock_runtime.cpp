@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -60,7 +61,7 @@ struct Group;
 struct MockComm {
   Group* g = nullptr;
   int rank = 0;
-  uint64_t next_seq = 0;
+  uint64_t next_seq = 0, next_split = 0;
 };
 
 namespace {
@@ -73,6 +74,7 @@ struct P2P {
   size_t count;
 };
 struct CollArg {
+  int rank = -1;  // of the communicator
   int type = -1;  // 0 all-reduce, 1 all-gather, 2 grouped send / recv
   const void* send = nullptr;
   void* recv = nullptr;
@@ -87,10 +89,18 @@ struct Coll {
   int arrived = 0;
   std::vector<CollArg> arg;
 };
+struct Split {  // one ncclCommSplit call of a communicator: every rank brings (colour, key), the last one builds the new groups
+  int arrived = 0;
+  std::vector<int> color, key;
+  std::vector<MockComm*> out;
+  bool done = false;
+};
 struct Group {
   int n = 0, joined = 0;
   std::vector<MockComm*> comm;
   std::map<uint64_t, Coll*> pending;
+  std::map<uint64_t, Split> splits;
+  std::vector<char> aborted;  // per rank: ncclCommAbort was called -- that rank's queued collectives end without running
 };
 
 std::set<uint64_t> g_done;
@@ -132,10 +142,19 @@ bool deps_done(const Op* op) {
   return true;
 }
 
+bool rank_aborted(const Group* g, int rank) { return rank >= 0 && (size_t)rank < g->aborted.size() && g->aborted[(size_t)rank]; }
+
+// the rank of the communicator whose copy of collective c is operation op
+int coll_rank_of(const Coll* c, const Op* op) {
+  for (const CollArg& a : c->arg)
+    if (a.op == op) return a.rank;
+  return -1;
+}
+
 bool coll_ready(const Coll* c) {
   if (c->arrived != c->g->n) return false;
   for (const CollArg& a : c->arg)
-    if (a.st->q.empty() || a.st->q.front() != a.op || !deps_done(a.op)) return false;
+    if (!a.st || !a.op || a.st->q.empty() || a.st->q.front() != a.op || !deps_done(a.op)) return false;  // (a rank that aborted: never)
   return true;
 }
 
@@ -222,7 +241,8 @@ bool step() {
   for (MockStream* st : g_streams) {
     if (st->q.empty()) continue;
     Op* op = st->q.front();
-    if (op->coll ? coll_ready(op->coll) : deps_done(op)) cand.push_back(st);
+    if (op->coll && rank_aborted(op->coll->g, coll_rank_of(op->coll, op)) && deps_done(op)) cand.push_back(st);  // ends alone, without running
+    else if (op->coll ? coll_ready(op->coll) : deps_done(op)) cand.push_back(st);
   }
   if (cand.empty()) return false;
   MockStream* st = cand[0];
@@ -236,7 +256,12 @@ bool step() {
       if (c->id < st->id) st = c;
   }
   Op* op = st->q.front();
-  if (op->coll) {
+  if (op->coll && rank_aborted(op->coll->g, coll_rank_of(op->coll, op))) {
+    for (CollArg& a : op->coll->arg)
+      if (a.op == op) a.op = nullptr, a.st = nullptr;  // (the Coll object is left to the process: peers may still point at it)
+    op->coll = nullptr;
+    finish(st, op);
+  } else if (op->coll) {
     Coll* c = op->coll;
     run_coll(c);
     double start = 0.0, cost = 0.0;
@@ -296,6 +321,7 @@ ncclResult_t enqueue_coll(MockComm* c, hipStream_t s, CollArg a) {
   op->coll = k;
   a.op = op;
   a.st = st;
+  a.rank = c->rank;
   k->arg[(size_t)c->rank] = a;
   ++k->arrived;
   st->q.push_back(op);
@@ -481,6 +507,7 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int n, ncclUniqueId id, int rank
     g = new Group();
     g->n = n;
     g->comm.assign((size_t)n, nullptr);
+    g->aborted.assign((size_t)n, 0);
   }
   if (g->n != n || rank < 0 || rank >= n || g->comm[(size_t)rank]) return ncclInvalidArgument;
   MockComm* c = new MockComm();
@@ -499,6 +526,7 @@ ncclResult_t ncclCommInitAll(ncclComm_t* comms, int n, const int*) {
   std::lock_guard<std::mutex> lk(M);
   Group* g = new Group();
   g->n = g->joined = n;
+  g->aborted.assign((size_t)n, 0);
   for (int r = 0; r < n; ++r) {
     MockComm* c = new MockComm();
     c->g = g;
@@ -511,6 +539,52 @@ ncclResult_t ncclCommInitAll(ncclComm_t* comms, int n, const int*) {
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   delete comm;  // the group object is left to the process (tests are short lived)
   return ncclSuccess;
+}
+// every rank of `comm` calls it (a rendezvous, like ncclCommInitRank); ranks of one colour form a new communicator, ordered by key
+ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm, ncclConfig_t*) {
+  std::unique_lock<std::mutex> lk(M);
+  Group* g = comm->g;
+  const uint64_t idx = comm->next_split++;
+  Split& sp = g->splits[idx];
+  if (sp.color.empty()) {
+    sp.color.assign((size_t)g->n, -2);
+    sp.key.assign((size_t)g->n, 0);
+    sp.out.assign((size_t)g->n, nullptr);
+  }
+  sp.color[(size_t)comm->rank] = color;
+  sp.key[(size_t)comm->rank] = key;
+  if (++sp.arrived == g->n) {
+    std::map<int, std::vector<std::pair<int, int>>> by_color;  // colour -> (key, parent rank)
+    for (int r = 0; r < g->n; ++r)
+      if (sp.color[(size_t)r] >= 0) by_color[sp.color[(size_t)r]].emplace_back(sp.key[(size_t)r], r);
+    for (auto& kv : by_color) {
+      std::sort(kv.second.begin(), kv.second.end());
+      Group* ng = new Group();
+      ng->n = ng->joined = (int)kv.second.size();
+      ng->aborted.assign(kv.second.size(), 0);
+      for (size_t i = 0; i < kv.second.size(); ++i) {
+        MockComm* c = new MockComm();
+        c->g = ng;
+        c->rank = (int)i;
+        ng->comm.push_back(c);
+        sp.out[(size_t)kv.second[i].second] = c;
+      }
+    }
+    sp.done = true;
+    CV.notify_all();
+  }
+  while (!sp.done)
+    if (CV.wait_for(lk, std::chrono::seconds(20)) == std::cv_status::timeout) return ncclInternalError;
+  *newcomm = sp.out[(size_t)comm->rank];
+  return ncclSuccess;
+}
+// local, like RCCL's: THIS rank's queued collectives of the communicator end without running (its streams drain); the peers' copies
+// keep waiting for a rendezvous that will not come until they abort too
+ncclResult_t ncclCommAbort(ncclComm_t comm) {
+  std::lock_guard<std::mutex> lk(M);
+  comm->g->aborted[(size_t)comm->rank] = 1;
+  CV.notify_all();
+  return ncclSuccess;  // (the MockComm is left to the process: queued operations still point at its group)
 }
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t, ncclRedOp_t, ncclComm_t comm, hipStream_t s) {
   CollArg a;
@@ -598,18 +672,19 @@ hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, floa
   return hipSuccess;
 }
 
-hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s) {
+hipError_t launch_argmax_strided(const float* scores, uint32_t K, size_t pitch, size_t n, int32_t* labels, hipStream_t s) {
   Op* op = new Op();
   op->run = [=] {
     for (size_t i = 0; i < n; ++i) {
       uint32_t best = 0;
       for (uint32_t k = 1; k < K; ++k)
-        if (scores[(size_t)k * n + i] > scores[(size_t)best * n + i]) best = k;  // lowest index wins ties
+        if (scores[(size_t)k * pitch + i] > scores[(size_t)best * pitch + i]) best = k;  // lowest index wins ties
       labels[i] = (int32_t)best;
     }
   };
   enqueue(s, op);
   return hipSuccess;
 }
+hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s) { return launch_argmax_strided(scores, K, n, n, labels, s); }
 
 }  // namespace ddt

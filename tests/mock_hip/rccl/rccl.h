@@ -19,6 +19,9 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id);
 ncclResult_t ncclCommInitRank(ncclComm_t* comm, int n, ncclUniqueId id, int rank);
 ncclResult_t ncclCommInitAll(ncclComm_t* comms, int n, const int* devices);
 ncclResult_t ncclCommDestroy(ncclComm_t comm);
+typedef struct ncclConfig_v21700 ncclConfig_t;
+ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm, ncclConfig_t* config);
+ncclResult_t ncclCommAbort(ncclComm_t comm);
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t t, ncclRedOp_t op, ncclComm_t comm, hipStream_t s);
 ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclDataType_t t, ncclComm_t comm, hipStream_t s);
 ncclResult_t ncclSend(const void* send, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t s);

@@ -17,8 +17,8 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-def _vid():
-    return ddt.variant_names().index(NAME)
+def _vid(name=NAME):
+    return ddt.variant_names().index(name)
 
 
 def _tuples(n, F, seed, holes):
@@ -26,7 +26,7 @@ def _tuples(n, F, seed, holes):
     x = O.gen_tuples(seed, n, F, dist=0)
     rng = np.random.default_rng(seed)
     for r in rng.integers(0, n, holes):
-        x[r, rng.integers(0, F)] = ddt.MISSING_DEFAULT
+        x[r, rng.integers(0, F)] = 0x7FC00000  # the default missing pattern
     return x
 
 
@@ -47,13 +47,15 @@ def test_persistent_blocks_over_many_tiles(T, clusters, n):
         want = O.score_fast(m, x, sum_mode=ref)
         e.set_option("variant", -1)
         e.load_model(ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), m.wlines, m.flines)
+        for name in (NAME, NAME + "u", "q16_d8_c8_u4_gl_s2_cm_x"):   # pinned read order / the compiler's; the plain launch with the pinned order
+            e.set_option("variant", _vid(name))
+            assert e.info().variant_name.decode() == name
+            for _ in range(2):                                  # twice: the tile counter is zeroed per launch
+                got = e.score_device(d)
+                torch.cuda.synchronize()
+                bad = np.flatnonzero(_bits(got.cpu().numpy()) != _bits(want))
+                assert bad.size == 0, (name, T, sum_mode, bad[:8], bad.size)
         e.set_option("variant", _vid())
-        assert e.info().variant_name.decode() == NAME
-        for _ in range(2):                                      # twice: the tile counter is zeroed per launch
-            got = e.score_device(d)
-            torch.cuda.synchronize()
-            bad = np.flatnonzero(_bits(got.cpu().numpy()) != _bits(want))
-            assert bad.size == 0, (T, sum_mode, bad[:8], bad.size)
     # a ragged batch smaller than one tile, and one of exactly two tiles
     for k in (777, 2048):
         got = e.score_device(d[:k])
