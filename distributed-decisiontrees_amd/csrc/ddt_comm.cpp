@@ -642,6 +642,7 @@ int ddt_score_rowsharded_device(ddt_comm* c, const void* d_tuples, size_t n, flo
   int rc = check_call(c, d_tuples, d_scores, n);
   if (rc) return rc;
   if (c->e->num_classes != 1) return cfail(c, DDT_ESTATE, "multi-class model loaded");
+  if (c->world) return cfail(c, DDT_ESTATE, "hybrid communicator: use ddt_score_hybrid_device (tree_ranks 1 = replicas)");
   if (n == 0) return DDT_OK;
   DeviceGuard dg(c->e->device);
   if (!dg.ok) return cfail(c, DDT_EHIP, "hipSetDevice(%d) failed", c->e->device);

@@ -1308,16 +1308,15 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
   for (;;) {
     const uint4* img = slow ? x.img_slow : a.img;
     const bool has_next = nxt < tiles;
-    // the next tile's flag, needed at this tile's last chunk (which image its chunk 0 comes from)
-    const bool slow_n = has_next && __builtin_amdgcn_readfirstlane((int)x.tile_flags[has_next ? nxt : cur]) != 0;
-    const uint4* img_n = slow_n ? x.img_slow : a.img;
     if (!pre0) dma_chunk<THREADS, CHUNK_BYTES>(img, 0, 0, tid);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // every wave is behind the tile-end barrier: the old tile is dead
       const uint32_t u = (uint32_t)tid + (uint32_t)i * THREADS;
       if (u < units) *reinterpret_cast<DDT_LDS(u32x4)*>((uint32_t)FEAT_OFF + u * 16u) = pre[i];
     }
-    prefetch(pre, has_next ? nxt : cur);  // flies during this tile's walks
+    // (the next tile's ranks and flag are requested behind the first chunk barrier, see chunks(): in front of it the barrier's
+    // vmcnt(0) would expose their whole HBM latency, 4 us per tile)
+    uint32_t flag_n = 0;
 
     const __amdgpu_buffer_rsrc_t leaf_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(img), 0, (int)(n_chunks * (uint32_t)(GCHUNK_UNITS * 16)), 0x00020000);
@@ -1399,7 +1398,11 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
         __syncthreads();  // chunk k is in buffer 0 (k = 0: and the rank tile is in place); everyone is done with buffer 1
         const bool more1 = k + 1 < n_chunks;
         if (more1) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 1) * GSKIP, k + 1, CHUNK_BYTES, tid);
-        else last_begin();
+        if (k == 0u) {  // the next tile's ranks fly during this tile's walks; nobody waits for them before the next chunk barrier
+          prefetch(pre, has_next ? nxt : cur);
+          flag_n = x.tile_flags[has_next ? nxt : cur];
+        }
+        if (!more1) last_begin();
         DDT_QPCOMPUTE(0, k);
         if (!more1) {
           last_end();
@@ -1410,7 +1413,8 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
         const bool more2 = k + 2 < n_chunks;
         if (more2) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 2) * GSKIP, k + 2, 0, tid);
         else {
-          if (has_next) dma_chunk<THREADS, CHUNK_BYTES>(img_n, 0, 0, tid);  // ring: chunk 0 of the next tile
+          // ring: chunk 0 of the next tile, from the image that tile's flag selects
+          if (has_next) dma_chunk<THREADS, CHUNK_BYTES>(__builtin_amdgcn_readfirstlane((int)flag_n) != 0 ? x.img_slow : a.img, 0, 0, tid);
           last_begin();
         }
         DDT_QPCOMPUTE(1, k + 1);
@@ -1427,7 +1431,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
     const uint32_t nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_u32(PAD_WORD));
     cur = nxt;
     nxt = nn;
-    slow = slow_n;
+    slow = __builtin_amdgcn_readfirstlane((int)flag_n) != 0;
     pre0 = ring;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing requested may outlive the wave

@@ -3,7 +3,7 @@
 The product is the HIP library behind the C-ABI in include/ddt.h; this package is plumbing (ctypes +
 torch device memory / streams / torch.distributed)."""
 from ._lib import Info, Params, Stats, build, lib  # noqa: F401
-from .engine import (COMBINE_ALLREDUCE, COMBINE_CHAIN, Comm, DDTError, Engine, Group, comm_unique_id, default_clusters, findex_lines_per_tree, make_params,  # noqa: F401
+from .engine import (COMBINE_ALLREDUCE, COMBINE_CHAIN, Comm, DDTError, Engine, Group, comm_unique_id, hybrid_rows, default_clusters, findex_lines_per_tree, make_params,  # noqa: F401
                      make_sparse_params, shard_bounds, synth_model, synth_sparse_model, synth_tuples_host, tuple_words, variant_names, weights_lines_per_tree)
 from . import importer  # noqa: F401
 

@@ -23,6 +23,8 @@ SYMBOLS = [
     "ddt_group_load_model_sparse", "ddt_group_score", "ddt_group_load_model_multiclass", "ddt_group_classify", "ddt_debug_prepass_image", "ddt_debug_sparse_image",
     "ddt_shard_range", "ddt_debug_model_image", "ddt_comm_chunk_schedule", "ddt_comm_score", "ddt_group_load_model_replicated", "ddt_group_score_rows",
     "ddt_host_register", "ddt_host_unregister",
+    "ddt_comm_create_hybrid", "ddt_comm_layout", "ddt_hybrid_rows", "ddt_score_hybrid_device", "ddt_classify_hybrid_device", "ddt_comm_abort",
+    "ddt_group_create_hybrid",
 ]
 
 
@@ -35,6 +37,12 @@ class Params(C.Structure):
         ("findex_lines_per_tree", C.c_uint32), ("cmp_mode", C.c_uint32), ("clusters_per_tuple", C.c_uint32),
         ("sum_mode", C.c_uint32), ("reserved", C.c_uint32 * 3),
     ]
+
+
+class CommLayout(C.Structure):
+    """ddt_comm_layout_t (include/ddt.h)"""
+
+    _fields_ = [("rank", C.c_int), ("n_ranks", C.c_int), ("tree_ranks", C.c_int), ("tree_rank", C.c_int), ("row_groups", C.c_int), ("row_group", C.c_int)]
 
 
 class Info(C.Structure):
@@ -142,6 +150,13 @@ def bind(L):
     L.ddt_score_sharded_device.restype, L.ddt_score_sharded_device.argtypes = i32, [vp, vp, sz, vp, i32, vp]
     L.ddt_score_rowsharded_device.restype, L.ddt_score_rowsharded_device.argtypes = i32, [vp, vp, sz, vp, vp]
     L.ddt_classify_sharded_device.restype, L.ddt_classify_sharded_device.argtypes = i32, [vp, vp, sz, vp, vp, i32, vp]
+    L.ddt_comm_create_hybrid.restype, L.ddt_comm_create_hybrid.argtypes = i32, [C.POINTER(vp), vp, i32, i32, i32, vp]
+    L.ddt_comm_layout.restype, L.ddt_comm_layout.argtypes = i32, [vp, C.POINTER(CommLayout)]
+    L.ddt_hybrid_rows.restype, L.ddt_hybrid_rows.argtypes = i32, [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]
+    L.ddt_score_hybrid_device.restype, L.ddt_score_hybrid_device.argtypes = i32, [vp, vp, sz, vp, i32, i32, vp]
+    L.ddt_classify_hybrid_device.restype, L.ddt_classify_hybrid_device.argtypes = i32, [vp, vp, sz, vp, vp, i32, i32, vp]
+    L.ddt_comm_abort.restype, L.ddt_comm_abort.argtypes = i32, [vp]
+    L.ddt_group_create_hybrid.restype, L.ddt_group_create_hybrid.argtypes = i32, [C.POINTER(vp), i32, C.POINTER(i32), i32]
     L.ddt_group_create.restype, L.ddt_group_create.argtypes = i32, [C.POINTER(vp), i32, C.POINTER(i32)]
     L.ddt_group_destroy.restype, L.ddt_group_destroy.argtypes = None, [vp]
     L.ddt_group_last_error.restype, L.ddt_group_last_error.argtypes = C.c_char_p, [vp]

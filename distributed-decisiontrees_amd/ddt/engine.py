@@ -293,6 +293,15 @@ COMBINE_ALLREDUCE, COMBINE_CHAIN = 0, 1
 COMM_ID_BYTES = 128
 
 
+def hybrid_rows(n: int, row_groups: int, row_group: int):
+    """rows [lo, hi) of a row group of a hybrid job (ddt_hybrid_rows)"""
+    lo, hi = C.c_size_t(), C.c_size_t()
+    rc = _lib.lib().ddt_hybrid_rows(n, row_groups, row_group, C.byref(lo), C.byref(hi))
+    if rc:
+        raise DDTError(rc, "ddt_hybrid_rows")
+    return lo.value, hi.value
+
+
 def comm_unique_id() -> bytes:
     """ncclGetUniqueId through the C-ABI: rank 0 makes it, the launcher hands it to every rank."""
     buf = C.create_string_buffer(COMM_ID_BYTES)
@@ -306,14 +315,51 @@ class Comm:
     """One rank of a multi-GPU job: an RCCL communicator bound to an Engine (include/ddt.h ddt_comm_*).  The sharded
     calls are collective: every rank calls them with the same arguments."""
 
-    def __init__(self, engine: Engine, rank: int, n_ranks: int, unique_id: bytes):
-        self._L, self.engine, self.rank, self.n_ranks = _lib.lib(), engine, rank, n_ranks
+    def __init__(self, engine: Engine, rank: int, n_ranks: int, unique_id: bytes, tree_ranks: int = 0):
+        """tree_ranks = 0: a plain communicator (tree-sharded over all ranks, or row-sharded replicas).  tree_ranks = Gt >= 1: the hybrid
+        layout (ddt_comm_create_hybrid) -- row groups of Gt consecutive ranks, the engine must hold tree shard rank % Gt of Gt."""
+        self._L, self.engine, self.rank, self.n_ranks, self.tree_ranks = _lib.lib(), engine, rank, n_ranks, tree_ranks
         assert len(unique_id) == COMM_ID_BYTES
         h = C.c_void_p()
-        rc = self._L.ddt_comm_create(C.byref(h), engine._h, rank, n_ranks, unique_id)
+        if tree_ranks:
+            rc = self._L.ddt_comm_create_hybrid(C.byref(h), engine._h, rank, n_ranks, tree_ranks, unique_id)
+        else:
+            rc = self._L.ddt_comm_create(C.byref(h), engine._h, rank, n_ranks, unique_id)
         if rc:
             raise DDTError(rc, self._L.ddt_last_error(engine._h).decode())
         self._h = h
+
+    def layout(self):
+        lay = _lib.CommLayout()
+        self._check(self._L.ddt_comm_layout(self._h, C.byref(lay)))
+        return lay
+
+    def abort(self):
+        """A peer failed: free this rank's queued collectives (ddt_comm_abort); the communicator is dead afterwards."""
+        self._check(self._L.ddt_comm_abort(self._h))
+
+    def score_hybrid(self, d_tuples, out=None, combine: int = COMBINE_ALLREDUCE, gather: bool = True, stream=None):
+        """Hybrid job: this rank's row group scores its slice of the rows against the group's tree shards; gather: all rows on every rank."""
+        import torch
+
+        n, s = self._args(d_tuples, stream)
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=d_tuples.device)
+        self._check(self._L.ddt_score_hybrid_device(self._h, d_tuples.data_ptr(), n, out.data_ptr(), combine, 1 if gather else 0, s.cuda_stream))
+        return out
+
+    def classify_hybrid(self, d_tuples, combine: int = COMBINE_ALLREDUCE, gather: bool = True, want_labels: bool = True, stream=None,
+                        class_scores=None, labels=None):
+        import torch
+
+        n, s = self._args(d_tuples, stream)
+        cs = class_scores if class_scores is not None else torch.empty((self.engine.num_classes, n), dtype=torch.float32, device=d_tuples.device)
+        if labels is None and want_labels:
+            labels = torch.empty(n, dtype=torch.int32, device=d_tuples.device)
+        want_labels = labels is not None
+        self._check(self._L.ddt_classify_hybrid_device(self._h, d_tuples.data_ptr(), n, cs.data_ptr(), labels.data_ptr() if want_labels else None,
+                                                       combine, 1 if gather else 0, s.cuda_stream))
+        return labels, cs
 
     def close(self):
         if getattr(self, "_h", None):
@@ -387,11 +433,13 @@ class Comm:
 class Group:
     """Single-process multi-GPU job (include/ddt.h ddt_group_*): n engines + one RCCL communicator over them."""
 
-    def __init__(self, device_ids):
+    def __init__(self, device_ids, tree_ranks: int = 0):
+        """tree_ranks = Gt >= 1: the hybrid layout (row groups of Gt consecutive devices, ddt_group_create_hybrid)"""
         self._L = _lib.lib()
         ids = (C.c_int * len(device_ids))(*device_ids)
         h = C.c_void_p()
-        rc = self._L.ddt_group_create(C.byref(h), len(device_ids), ids)
+        rc = (self._L.ddt_group_create_hybrid(C.byref(h), len(device_ids), ids, tree_ranks) if tree_ranks
+              else self._L.ddt_group_create(C.byref(h), len(device_ids), ids))
         if rc:
             raise DDTError(rc, "ddt_group_create")
         self._h, self.n, self.params = h, len(device_ids), None

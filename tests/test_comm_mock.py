@@ -46,6 +46,12 @@ def _build(name, comm_source):
     L.ddt_score_rowsharded_device.argtypes = [vp, vp, sz, vp, vp]
     L.ddt_classify_sharded_device.argtypes = [vp, vp, sz, vp, vp, i32, vp]
     L.ddt_comm_score.argtypes = [vp, vp, sz, vp, i32]
+    L.ddt_comm_create_hybrid.argtypes = [C.POINTER(vp), vp, i32, i32, i32, vp]
+    L.ddt_score_hybrid_device.argtypes = [vp, vp, sz, vp, i32, i32, vp]
+    L.ddt_classify_hybrid_device.argtypes = [vp, vp, sz, vp, vp, i32, i32, vp]
+    L.ddt_comm_abort.argtypes = [vp]
+    L.ddt_hybrid_rows.argtypes = [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]
+    L.ddt_group_create_hybrid.argtypes = [C.POINTER(vp), i32, vp, i32]
     L.ddt_group_create.argtypes, L.ddt_group_destroy.argtypes, L.ddt_group_destroy.restype = [C.POINTER(vp), i32, vp], [vp], None
     L.ddt_group_load_model.argtypes = [vp, C.POINTER(ddt.Params), vp, sz, vp, sz]
     L.ddt_group_load_model_multiclass.argtypes = [vp, C.POINTER(ddt.Params), vp, sz, vp, sz, u32, i32]
@@ -116,7 +122,7 @@ def _run_ranks(G, body):
 class Rank:
     """One rank of a process-per-GPU style job: engine + communicator + the caller's stream."""
 
-    def __init__(self, L, r, G, barrier, shared, classes=1, stream_first=True, whole_model=False):
+    def __init__(self, L, r, G, barrier, shared, classes=1, stream_first=True, whole_model=False, tree_ranks=0):
         self.L, self.r, self.G = L, r, G
         assert L.hipSetDevice(r) == 0
         self.s = vp()
@@ -125,7 +131,7 @@ class Rank:
         self.e = vp()
         assert L.ddt_create(C.byref(self.e), r) == 0
         p = _params()
-        shard = (0, 1) if whole_model else (r, G)
+        shard = (0, 1) if whole_model else (r % tree_ranks, tree_ranks) if tree_ranks else (r, G)
         if classes > 1:
             assert L.ddt_load_model_multiclass(self.e, C.byref(p), None, 0, None, 0, classes, 1, *shard) == 0
         else:
@@ -135,7 +141,10 @@ class Rank:
             assert L.ddt_comm_get_unique_id(shared["id"]) == 0
         barrier.wait()
         self.c = vp()
-        assert L.ddt_comm_create(C.byref(self.c), self.e, r, G, shared["id"]) == 0
+        if tree_ranks:   # hybrid: row groups of tree_ranks consecutive ranks (ncclCommSplit behind the C-ABI)
+            assert L.ddt_comm_create_hybrid(C.byref(self.c), self.e, r, G, tree_ranks, shared["id"]) == 0
+        else:
+            assert L.ddt_comm_create(C.byref(self.c), self.e, r, G, shared["id"]) == 0
         if not stream_first:
             assert L.hipStreamCreateWithFlags(C.byref(self.s), 1) == 0
 
@@ -374,13 +383,13 @@ def test_only_the_last_collective_is_exposed():
 
 REMOVED_WAITS = {
     # the collective of a chunk no longer waits for the chunk's scoring launch (in-place all-reduce path)
-    "scored_inplace": ("      CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));\n      CNCCL(c, ncclAllReduce(dst + lo, dst + lo, m, ncclFloat, ncclSum, c->comm, c->cs));",
-                       "      CNCCL(c, ncclAllReduce(dst + lo, dst + lo, m, ncclFloat, ncclSum, c->comm, c->cs));", 0),
+    "scored_inplace": ("        CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));\n        CNCCL(c, ncclAllReduce(dst + lo, dst + lo, m, ncclFloat, ncclSum, c->comm, c->cs));",
+                       "        CNCCL(c, ncclAllReduce(dst + lo, dst + lo, m, ncclFloat, ncclSum, c->comm, c->cs));", 0),
     # ... the same on the staged path (chain combine / classes)
-    "scored_staged": ("    CHIP(c, hipEventRecord(c->ev_scored[b], s));\n    CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));\n    const float* res;",
-                      "    const float* res;", 1),
+    "scored_staged": ("        CHIP(c, hipEventRecord(c->ev_scored[b], s));\n        CHIP(c, hipStreamWaitEvent(c->cs, c->ev_scored[b], 0));\n        const float* res;",
+                      "        const float* res;", 1),
     # the scoring launch of chunk k+2 no longer waits until slot b has been consumed by chunk k's collective
-    "slot_free": ("    if (c->slot_used[b]) CHIP(c, hipStreamWaitEvent(s, c->ev_free[b], 0));  // slot b still feeds chunk k-2's collective\n", "", 1),
+    "slot_free": ("        if (c->slot_used[b]) CHIP(c, hipStreamWaitEvent(s, c->ev_free[b], 0));  // slot b still feeds chunk k-2's collective\n", "", 1),
     # the caller's stream no longer waits for the last collective
     "done": ("  CHIP(c, hipStreamWaitEvent(s, c->ev_done, 0));  // results are ready in stream order on the caller's stream\n", "", 1),
     # row-sharded job: a step is handed to the peers before it has been scored / the caller does not wait for the peers' rows
@@ -390,31 +399,34 @@ REMOVED_WAITS = {
 
 
 @pytest.mark.skipif(bool(os.environ.get("DDT_MOCK_SANITIZE")), reason="the broken builds race on purpose")
-@pytest.mark.parametrize("which", sorted(REMOVED_WAITS))
-def test_the_model_catches_a_missing_dependency(which):
+@pytest.mark.parametrize("which,hybrid", [(w, False) for w in sorted(REMOVED_WAITS)] + [("scored_inplace", True), ("scored_staged", True), ("done", True)])
+def test_the_model_catches_a_missing_dependency(which, hybrid):
     """Remove ONE wait of the event protocol from the source: some schedule must then give wrong scores -- the proof that
-    the schedules above would have exposed such a hole in the shipped pipeline."""
+    the schedules above would have exposed such a hole in the shipped pipeline.  hybrid: the same holes seen through a 2 x 2 hybrid job
+    (the pieces a row group hands to the other one come from the same streams)."""
     needle, repl, combine = REMOVED_WAITS[which]
     src = open(os.path.join(CSRC, "ddt_comm.cpp")).read()
     assert src.count(needle) == 1, which
-    broken, so = os.path.join(MOCK, f"_broken_{which}.cpp"), f"libddt_comm_mock_broken_{which}.so"
+    broken, so = os.path.join(MOCK, f"_broken_{which}_{int(hybrid)}.cpp"), f"libddt_comm_mock_broken_{which}_{int(hybrid)}.so"
     open(broken, "w").write(src.replace(needle, repl))
     try:
         bad = _build(so, broken)
-        G, n = 2, 3000
-        x, want = _tuples(n), (_expected(G, n)[0] if combine >= 0 else _partial(0, 0, np.arange(n)))
+        G, n = (4, 5000) if hybrid else (2, 3000)
+        x, want = _tuples(n), (_expected(2, n)[0] if combine >= 0 else _partial(0, 0, np.arange(n)))
         wrong = 0
         for policy, seed in SCHEDULES:
             bad.mock_reset(policy, seed, 8)
             seen = []
 
             def body(r, barrier, shared):
-                k = Rank(bad, r, G, barrier, shared, stream_first=True, whole_model=combine < 0)
+                k = Rank(bad, r, G, barrier, shared, stream_first=True, whole_model=combine < 0, tree_ranks=2 if hybrid else 0)
                 k.opt("chunk_rows", 300)
                 outs = []
                 for _ in range(2):
                     out = np.full(n, np.nan, np.float32)
-                    if combine < 0:
+                    if hybrid:
+                        assert bad.ddt_score_hybrid_device(k.c, x.ctypes.data, n, out.ctypes.data, combine, 1, k.s) == 0
+                    elif combine < 0:
                         assert bad.ddt_score_rowsharded_device(k.c, x.ctypes.data, n, out.ctypes.data, k.s) == 0
                     else:
                         assert bad.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, combine, k.s) == 0
@@ -426,56 +438,172 @@ def test_the_model_catches_a_missing_dependency(which):
 
             _run_ranks(G, body)
             wrong += not all(seen)
-        assert wrong > 0, f"no schedule noticed the missing wait ({which})"
+        assert wrong > 0, f"no schedule noticed the missing wait ({which}, hybrid {hybrid})"
     finally:
         for f in (broken, os.path.join(MOCK, so)):
             if os.path.exists(f):
                 os.remove(f)
 
 
-@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
-@pytest.mark.parametrize("Gt,Gr", [(2, 2), (2, 4), (4, 2)])
-def test_hybrid_row_groups_of_tree_sharded_jobs(mock, Gt, Gr, policy, seed):
-    """bench.py's hybrid legs: Gr independent tree-sharded jobs of Gt consecutive ranks each, a communicator per tree group (its own
-    unique id), every group on its own row slice, all running at once -- the communicators must not share state."""
-    mock.mock_reset(policy, seed, 8)
-    n = 6000
-    per = (-(-n // Gr) + 1023) // 1024 * 1024
-    x = _tuples(n)
-    want = _expected(Gt, n)[0]                     # every tuple: the sum of its tree group's Gt partials
+def _rows(mock, n, Gr, rg):
+    lo, hi = sz(), sz()
+    assert mock.ddt_hybrid_rows(n, Gr, rg, C.byref(lo), C.byref(hi)) == 0
+    return lo.value, hi.value
 
-    def body(rank, barrier, shared):
-        tg, rg = rank % Gt, rank // Gt
-        assert mock.hipSetDevice(rank) == 0
-        s, e, c = vp(), vp(), vp()
-        assert mock.hipStreamCreateWithFlags(C.byref(s), 1) == 0
-        assert mock.ddt_create(C.byref(e), rank) == 0
-        p = _params()
-        assert mock.ddt_load_model_shard(e, C.byref(p), None, 0, None, 0, tg, Gt) == 0
-        if tg == 0:
-            shared[rg] = C.create_string_buffer(128)
-            assert mock.ddt_comm_get_unique_id(shared[rg]) == 0
-        barrier.wait()
-        assert mock.ddt_comm_create(C.byref(c), e, tg, Gt, shared[rg]) == 0
-        assert mock.ddt_comm_set_option(c, b"chunk_rows", 700) == 0
-        assert mock.ddt_comm_set_option(c, b"taper_min_rows", 16) == 0
-        lo, hi = min(n, rg * per), min(n, (rg + 1) * per)
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES)
+@pytest.mark.parametrize("Gt,Gr,n,chunk", [(2, 2, 6000, 700), (2, 4, 9001, 1024), (4, 2, 5003, 300), (1, 4, 4100, 500), (8, 1, 3001, 1000), (2, 4, 1500, 12_500_000),
+                                           (2, 2, 3, 5)])
+def test_hybrid_job(mock, Gt, Gr, n, chunk, policy, seed):
+    """ddt_comm_create_hybrid + ddt_score_hybrid_device: Gr row groups of Gt consecutive ranks; a row group is a tree-sharded job on its
+    slice of the rows (communicator split off the world communicator), the finished pieces travel to the other row groups while the
+    next piece is scored.  gather: every rank ends up with all rows; no gather: a rank writes its row group's rows only.  Ragged row
+    counts (a last group that is shorter, or empty), both combines, back-to-back calls on the reused workspace slots."""
+    mock.mock_reset(policy, seed, 8)
+    x, want = _tuples(n), _expected(Gt, n)[0]          # every tuple: the sum of the Gt shards' partials (the groups hold the same Gt shards)
+
+    def body(r, barrier, shared):
+        k = Rank(mock, r, Gt * Gr, barrier, shared, stream_first=(seed % 2 == 0), tree_ranks=Gt)
+        k.opt("chunk_rows", chunk)
+        k.opt("taper_min_rows", 16)
+        lo, hi = _rows(mock, n, Gr, r // Gt)
         outs = []
-        for combine in (0, 1):
+        for combine, gather in ((0, 1), (1, 1), (0, 0), (1, 0), (0, 1)):
             out = np.full(n, np.nan, np.float32)
-            assert mock.ddt_score_sharded_device(c, x[lo:hi].ctypes.data, hi - lo, out[lo:hi].ctypes.data, combine, s) == 0, mock.ddt_comm_last_error(c)
-            outs.append(out)
-        barrier.wait()
-        assert mock.hipStreamSynchronize(s) == 0
-        for out in outs:
-            assert np.array_equal(out[lo:hi], want[lo:hi]) and np.isnan(out[:lo]).all() and np.isnan(out[hi:]).all()
-        barrier.wait()
-        mock.ddt_comm_destroy(c)
-        mock.ddt_destroy(e)
-        mock.hipStreamDestroy(s)
+            assert mock.ddt_score_hybrid_device(k.c, x.ctypes.data, n, out.ctypes.data, combine, gather, k.s) == 0, mock.ddt_comm_last_error(k.c)
+            outs.append((out, gather))
+        barrier.wait()                               # all ranks have enqueued their calls: from here on the schedule decides the order
+        k.sync()
+        for out, gather in outs:
+            if gather:
+                assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (r, np.flatnonzero(out != want)[:5])
+            else:
+                assert np.array_equal(out[lo:hi], want[lo:hi]) and np.isnan(out[:lo]).all() and np.isnan(out[hi:]).all(), r
+        # the other jobs' calls refuse a hybrid communicator
+        out = np.zeros(n, np.float32)
+        assert mock.ddt_score_sharded_device(k.c, x.ctypes.data, n, out.ctypes.data, 0, k.s) == -4
+        assert mock.ddt_score_rowsharded_device(k.c, x.ctypes.data, n, out.ctypes.data, k.s) == -4
+        k.close(barrier)
+
+    _run_ranks(Gt * Gr, body)
+    assert mock.mock_errors() == 0 and mock.mock_executed() > 0
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+@pytest.mark.parametrize("Gt,Gr,n,chunk,K", [(2, 2, 2500, 700, 3), (2, 4, 3333, 400, 10), (4, 2, 1029, 12_500_000, 2)])
+def test_hybrid_classes(mock, Gt, Gr, n, chunk, K, policy, seed):
+    mock.mock_reset(policy, seed, 8)
+    x, want = _tuples(n), _expected(Gt, n, K)
+    want_labels = np.argmax(want, axis=0).astype(np.int32)
+
+    def body(r, barrier, shared):
+        k = Rank(mock, r, Gt * Gr, barrier, shared, classes=K, stream_first=(seed % 2 == 1), tree_ranks=Gt)
+        k.opt("chunk_rows", chunk)
+        k.opt("taper_min_rows", 16)
+        lo, hi = _rows(mock, n, Gr, r // Gt)
+        res = []
+        for combine, gather in ((0, 1), (1, 0), (1, 1)):
+            cs, lab = np.full((K, n), np.nan, np.float32), np.full(n, -1, np.int32)
+            assert mock.ddt_classify_hybrid_device(k.c, x.ctypes.data, n, cs.ctypes.data, lab.ctypes.data, combine, gather, k.s) == 0
+            res.append((cs, lab, gather))
+        k.sync()
+        for cs, lab, gather in res:
+            if gather:
+                assert np.array_equal(cs.view(np.uint32), want.view(np.uint32)) and np.array_equal(lab, want_labels), r
+            else:
+                assert np.array_equal(cs[:, lo:hi], want[:, lo:hi]) and np.array_equal(lab[lo:hi], want_labels[lo:hi]), r
+                assert np.isnan(cs[:, :lo]).all() and np.isnan(cs[:, hi:]).all() and (lab[:lo] == -1).all() and (lab[hi:] == -1).all()
+        k.close(barrier)
 
     _run_ranks(Gt * Gr, body)
     assert mock.mock_errors() == 0
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+def test_hybrid_host_buffer_form_moves_the_tuples_once(mock, policy, seed):
+    """ddt_comm_score on a hybrid communicator: a rank copies 1 / n_ranks of every super-chunk over "PCIe" (its share of its row group's
+    slice) and the row group hands the rows on; every rank gets all scores."""
+    Gt, Gr, n = 2, 2, 6007
+    mock.mock_reset(policy, seed, 8)
+    x, want = _tuples(n), _expected(Gt, n)[0]
+    traffic = []
+
+    def body(r, barrier, shared):
+        k = Rank(mock, r, Gt * Gr, barrier, shared, tree_ranks=Gt)
+        k.opt("host_rows", 2500)
+        k.opt("chunk_rows", 300)
+        k.opt("taper_min_rows", 16)
+        barrier.wait()
+        before = mock.mock_h2d_bytes()
+        barrier.wait()
+        for combine in (0, 1):
+            out = np.full(n, np.nan, np.float32)
+            assert mock.ddt_comm_score(k.c, x.ctypes.data, n, out.ctypes.data, combine) == 0, mock.ddt_comm_last_error(k.c)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), r
+        barrier.wait()
+        if r == 0:
+            traffic.append((mock.mock_h2d_bytes() - before) / (2 * n * W * 4))
+        k.close(barrier)
+
+    _run_ranks(Gt * Gr, body)
+    assert mock.mock_errors() == 0 and traffic == [1.0]
+
+
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
+@pytest.mark.parametrize("G,Gt", [(4, 2), (8, 2), (8, 4)])
+def test_single_process_hybrid_group(mock, G, Gt, policy, seed):
+    """ddt_group_create_hybrid: device i holds tree shard i % Gt of Gt; ddt_group_score / ddt_group_classify run the hybrid job."""
+    mock.mock_reset(policy, seed, 8)
+    n, K = 9001, 4
+    x = _tuples(n)
+    g = vp()
+    assert mock.ddt_group_create_hybrid(C.byref(g), G, None, 3) == -1        # 3 does not divide the device count
+    assert mock.ddt_group_create_hybrid(C.byref(g), G, None, Gt) == 0
+    p = _params()
+    assert mock.ddt_group_load_model(g, C.byref(p), x.ctypes.data, 1 << 20, x.ctypes.data, 1 << 20) == 0
+    for combine in (0, 1):
+        out = np.full(n, np.nan, np.float32)
+        assert mock.ddt_group_score(g, x.ctypes.data, n, out.ctypes.data, combine) == 0, mock.ddt_group_last_error(g)
+        assert np.array_equal(out.view(np.uint32), _expected(Gt, n)[0].view(np.uint32))
+    assert mock.ddt_group_load_model_multiclass(g, C.byref(p), x.ctypes.data, 1 << 20, x.ctypes.data, 1 << 20, K, 1) == 0
+    want = _expected(Gt, n, K)
+    lab, cs = np.full(n, -1, np.int32), np.full((K, n), np.nan, np.float32)
+    assert mock.ddt_group_classify(g, x.ctypes.data, n, lab.ctypes.data, cs.ctypes.data, 0) == 0
+    assert np.array_equal(cs.view(np.uint32), want.view(np.uint32)) and np.array_equal(lab, np.argmax(want, axis=0))
+    mock.ddt_group_destroy(g)
+    assert mock.mock_errors() == 0
+
+
+def test_a_rank_that_fails_before_its_collective(mock):
+    """2 x 2 hybrid job; rank 3's call fails before it has enqueued anything (here: a NULL tuple pointer -> DDT_EINVAL).  Its peers
+    have queued collectives that can never complete: rank 2's all-reduce needs rank 3, ranks 0 / 1 wait for row group 1's pieces.  The
+    launcher tells them; ddt_comm_abort frees their streams, the communicator refuses further calls, teardown works in any order."""
+    mock.mock_reset(0, 0, 8)
+    Gt, G, n = 2, 4, 4000
+    x = _tuples(n)
+    failed = threading.Event()
+
+    def body(r, barrier, shared):
+        k = Rank(mock, r, G, barrier, shared, tree_ranks=Gt)
+        k.opt("chunk_rows", 500)
+        out = np.full(n, np.nan, np.float32)
+        barrier.wait()
+        if r == 3:
+            assert mock.ddt_score_hybrid_device(k.c, None, n, out.ctypes.data, 0, 1, k.s) == -1      # refused before anything is enqueued
+            failed.set()
+        else:
+            assert mock.ddt_score_hybrid_device(k.c, x.ctypes.data, n, out.ctypes.data, 0, 1, k.s) == 0
+            assert failed.wait(30)
+            assert mock.ddt_comm_abort(k.c) == 0                          # told by the launcher that a peer is gone
+            k.sync()                                                      # returns: the queued collectives ended without running
+            assert mock.ddt_score_hybrid_device(k.c, x.ctypes.data, n, out.ctypes.data, 0, 1, k.s) == -4     # dead communicator
+            assert mock.ddt_comm_abort(k.c) == 0                          # idempotent
+        barrier.wait()
+        mock.ddt_comm_destroy(k.c)
+        mock.ddt_destroy(k.e)
+        mock.hipStreamDestroy(k.s)
+
+    _run_ranks(G, body)
 
 
 def _fuzz_job(mock, seed):

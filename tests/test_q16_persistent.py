@@ -74,8 +74,8 @@ def test_all_classes_in_one_launch(T, K, inter, n):
     x = _tuples(n, F, 5 + K, 25)
     want_l, want_cs = O.classify(m, x, K, interleaved=inter)
     e = ddt.Engine(0)
-    e.set_option("q16_persistent", 1)
     e.load_model_multiclass(ddt.make_params(T, D, F, clusters=C), m.wlines, m.flines, K, inter)
+    e.set_option("variant", _vid())                            # (small models would not take a rank-quantised kernel by themselves)
     assert e.info().variant_name.decode() == NAME
     launches = e.stats().kernel_launches
     d = torch.from_numpy(x.view(np.int32)).cuda()
@@ -100,8 +100,8 @@ def test_classes_of_unequal_size_fall_back_to_one_launch_per_class():
     x = O.gen_tuples(3, n, F, dist=1)
     want_l, want_cs = O.classify(m, x, K, interleaved=True)
     e = ddt.Engine(0)
-    e.set_option("q16_persistent", 1)
     e.load_model_multiclass(ddt.make_params(T, D, F, clusters=1), m.wlines, m.flines, K, True)
+    e.set_option("variant", _vid())
     assert e.info().variant_name.decode() == NAME
     launches = e.stats().kernel_launches
     dl, dcs = e.classify_device(torch.from_numpy(x.view(np.int32)).cuda())
