@@ -66,13 +66,6 @@ def hybrid_tree_groups(world):
     return [Gt for Gt in (2, 4) if world % Gt == 0 and world // Gt >= 2]
 
 
-def hybrid_rows(n, row_groups, rg):
-    """Row slice [lo, hi) of row group rg: equal slices in whole tiles of 1024 tuples, the last one takes the rest."""
-    per = (n + row_groups - 1) // row_groups
-    per = (per + 1023) // 1024 * 1024
-    return min(n, rg * per), min(n, (rg + 1) * per)
-
-
 def self_launch(n_gpus):
     import subprocess
 
@@ -97,9 +90,12 @@ def main():
     ap.add_argument("--full-levels", type=int, default=10, help="config 4: levels grown completely")
     ap.add_argument("--permille", type=int, default=700, help="config 4: split probability below the full levels, in 1/1000")
     ap.add_argument("--combine", default="allreduce", choices=["allreduce", "chain"])
-    ap.add_argument("--shard", default="trees", choices=["trees", "rows"],
+    ap.add_argument("--shard", default="trees", choices=["trees", "rows", "hybrid"],
                     help="N>1: 'trees' = the headline mode (ensemble sharded tree-wise, partial scores all-reduced); "
-                         "'rows' = the reference's other mode (replicated ensemble, tuples partitioned, every step of scores handed to all peers while the next is scored)")
+                         "'rows' = the reference's other mode (replicated ensemble, tuples partitioned, every step of scores handed to all peers while the next is scored); "
+                         "'hybrid' = the two composed (ddt_comm_create_hybrid): row groups of --tree-ranks consecutive ranks, each a tree-sharded job on its slice of the rows")
+    ap.add_argument("--tree-ranks", type=int, default=2, help="--shard hybrid: ranks per row group (= tree shards); must divide N")
+    ap.add_argument("--no-gather", action="store_true", help="--shard hybrid: scores stay with their row group (no hand-over to the other row groups)")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="N=1 only: load shard 3 (or the last) of a G-way tree-sharded job of the configured model and score it with no "
                          "collective -- exactly what one of G ranks computes (same cluster count, same kernel choice); no CPU / host-feeder legs")
@@ -185,7 +181,10 @@ def main():
         key, _, val = kv.partition("=")
         eng.set_option(key, int(val))
     rows_mode = world > 1 and args.shard == "rows"
-    shard = (0, 1) if rows_mode else (rank, world)
+    hybrid_mode = multi and args.shard == "hybrid"
+    if hybrid_mode and (world % args.tree_ranks or args.collectives != "cabi"):
+        sys.exit("--shard hybrid: --tree-ranks must divide the number of ranks; C-ABI collectives only")
+    shard = (0, 1) if rows_mode else (rank % args.tree_ranks, args.tree_ranks) if hybrid_mode else (rank, world)
     if args.shard_of > 1:
         if world > 1 or args.force_collectives or sparse or classes > 1:
             sys.exit("--shard-of: one plain engine on one GPU")
@@ -220,8 +219,8 @@ def main():
         # -- ncclCommInitRank, the chunk pipeline, every collective -- happens in C++ behind the C-ABI
         box = [ddt.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        comm = ddt.Comm(eng, rank, world, box[0])
-        comm.set_option("chunk_rows", args.chunk_rows)
+        comm = ddt.Comm(eng, rank, world, box[0], tree_ranks=args.tree_ranks if hybrid_mode else 0)
+        comm.set_option("chunk_rows", max(1024, args.chunk_rows // (world // args.tree_ranks)) if hybrid_mode else args.chunk_rows)
         comm.set_option("taper_tail", args.taper)
     elif multi:
         from tests import sharded_ref  # --collectives torch: the Python mirror of the pipeline (test infrastructure; needed for gloo ranks sharing a GPU)
@@ -243,7 +242,9 @@ def main():
             else:
                 eng.classify_device(tuples, class_scores=cls_scores, labels=labels)
         elif comm is not None:
-            if rows_mode:
+            if hybrid_mode:
+                comm.score_hybrid(tuples, out=out, combine=combine, gather=not args.no_gather)
+            elif rows_mode:
                 comm.score_rowsharded(tuples, out=out)
             else:
                 comm.score_sharded(tuples, out=out, combine=combine)
@@ -285,7 +286,7 @@ def main():
     # ---- N>1 (or --force-collectives): the same shard scored WITHOUT the collectives, so that the line itself shows what the
     # combine costs on top of the per-rank compute (max over ranks, 2 steps, outside the timed region) -----------------------
     scaling_detail = None
-    if comm is not None and classes == 1 and not rows_mode:
+    if comm is not None and classes == 1 and not rows_mode and not hybrid_mode:
         try:
             fence()
             t1 = time.perf_counter()
@@ -451,6 +452,8 @@ def main():
         par = (f"shard {shard[0]} of a {shard[1]}-way tree-sharded job ({int(info.tree_end - info.tree_begin)} trees) on one GPU, no collective" if args.shard_of > 1 else
                "single engine") if world == 1 else (
             f"row-sharded {world}x (replicas) + {'RCCL send/recv all-gather, pipelined' if comm is not None else 'gloo all-gather'}" if rows_mode else
+            f"hybrid: {world // args.tree_ranks} row groups x {args.tree_ranks} tree shards, RCCL {args.combine} inside a row group, "
+            f"{'scores stay with their row group' if args.no_gather else 'pieces handed to the other row groups while the next is scored'}" if hybrid_mode else
             f"tree-sharded {world}x + {'RCCL' if args.backend == 'nccl' else 'gloo (functional test)'} {args.combine}")
         shape = (f"{T} sparse trees (depth <= {D}, {lines.shape[0]} internal nodes) x {F} fp32 features" if sparse
                  else f"{classes}-class one-vs-all, {T // classes} trees/class x depth {D} x {F} fp32 features, argmax labels" if classes > 1
@@ -464,7 +467,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{shape}, {N} tuples/step, {par}",
                        "trees": T, "levels": D, "features": F, "rows": N,
-                       "parallelism": f"row-shard{world}" if rows_mode else (f"one-of-tree-shard{args.shard_of}" if args.shard_of > 1 else f"tree-shard{world}"),
+                       "parallelism": f"row-shard{world}" if rows_mode else f"hybrid-tree{args.tree_ranks}-x-rows{world // args.tree_ranks}" if hybrid_mode else (
+                           f"one-of-tree-shard{args.shard_of}" if args.shard_of > 1 else f"tree-shard{world}"),
                        "combine": args.combine if multi else None,
                        "tapered_tail": ((args.taper == 1 or (args.taper < 0 and world > 1)) if comm is not None else None),
                        "collectives": (("C-ABI ddt_comm (csrc/ddt_comm.cpp)" if comm is not None else "torch.distributed") if multi else None),
@@ -488,7 +492,7 @@ def main():
     # region so that the driver's scaling run records them too (never `value`).  These collectives have run in one-rank
     # communicators and in the CPU model of tests/test_comm_mock.py only: a watchdog keeps a stuck leg from costing the line.
     wd = None
-    if comm is not None and classes == 1 and not sparse and not rows_mode and not args.no_other_modes:
+    if comm is not None and classes == 1 and not sparse and not rows_mode and not hybrid_mode and not args.no_other_modes:
         import threading
 
         other = {}
@@ -544,25 +548,29 @@ def main():
             other["row_sharded_mtuples_per_s"] = round(N / other["row_sharded_ms"] / 1e3, 3)
             scale = float(tree_scores.abs().max().item()) or 1.0
             other["row_vs_tree_max_abs_diff_rel"] = float((out - tree_scores).abs().max().item()) / scale   # summation order differs
-            # hybrid: Gr independent tree-sharded jobs of Gt ranks each on disjoint row slices (consecutive ranks form a tree group).  Each
-            # rank ranks and scores N/Gr tuples against T/Gt trees -- the replicated rank pre-pass shrinks by Gr -- and the all-reduce runs
-            # inside a tree group; the scores stay distributed by row group, as the reference returns them per device.  Built from the
-            # same C-ABI calls: a communicator per tree group.
+            # hybrid (ddt_comm_create_hybrid, csrc/ddt_comm.cpp): Gr row groups of Gt consecutive ranks, each a tree-sharded job on its slice of
+            # the rows -- a rank ranks and scores N/Gr tuples against T/Gt trees (the replicated pre-pass shrinks by Gr), the all-reduce runs
+            # inside a row group (a communicator split off the world communicator in C++).  Two forms: the scores stay with their row group (the
+            # way the reference returns a device's rows from that device) / every finished piece is handed to the other row groups while the
+            # next one is scored (all rows on every rank, like the other modes).
             for Gt in hybrid_tree_groups(world):
-                Gr, tg, rg = world // Gt, rank % Gt, rank // Gt
+                Gr, tg = world // Gt, rank % Gt
                 engh = ddt.Engine(local)
                 engh.load_model(params, w, f, tg, Gt)
-                ids = [None] * world
-                dist.all_gather_object(ids, ddt.comm_unique_id() if tg == 0 else None)    # every group leader makes its group's id
-                commh = ddt.Comm(engh, tg, Gt, ids[rg * Gt])
-                lo, hi = hybrid_rows(N, Gr, rg)
+                boxh = [ddt.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(boxh, src=0)
+                commh = ddt.Comm(engh, rank, world, boxh[0], tree_ranks=Gt)
+                lo, hi = ddt.hybrid_rows(N, Gr, rank // Gt)
                 commh.set_option("chunk_rows", max(1024, args.chunk_rows // Gr))
                 key = f"hybrid_tree{Gt}_x_rows{Gr}"
-                other[key + "_ms"] = leg(lambda: commh.score_sharded(tuples[lo:hi], out=out[lo:hi], combine=ddt.COMBINE_ALLREDUCE))
+                other[key + "_ms"] = leg(lambda: commh.score_hybrid(tuples, out=out, combine=ddt.COMBINE_ALLREDUCE, gather=False))
                 other[key + "_mtuples_per_s"] = round(N / other[key + "_ms"] / 1e3, 3)
                 diff = torch.tensor([float((out[lo:hi] - tree_scores[lo:hi]).abs().max().item()) / scale if hi > lo else 0.0], dtype=torch.float64, device=tuples.device)
                 dist.all_reduce(diff, op=dist.ReduceOp.MAX)
                 other[key + "_vs_tree_max_abs_diff_rel"] = float(diff.item())              # summation order differs (fewer partials per tuple)
+                other[key + "_gathered_ms"] = leg(lambda: commh.score_hybrid(tuples, out=out, combine=ddt.COMBINE_ALLREDUCE, gather=True))
+                other[key + "_gathered_mtuples_per_s"] = round(N / other[key + "_gathered_ms"] / 1e3, 3)
+                other[key + "_gathered_vs_tree_max_abs_diff_rel"] = float((out - tree_scores).abs().max().item()) / scale
                 commh.close()
                 engh.close()
             # host buffers through the tree-sharded job (ddt_comm_score): tuples over PCIe once + xGMI hand-over, or G full copies
@@ -575,8 +583,9 @@ def main():
             comm.set_option("tuple_broadcast", -1)
             other["note"] = ("ms per step, max over ranks, 2 steps each after one warm-up, outside the timed region; row-sharded = replicas "
                              "only (whole ensemble per GPU, tuples partitioned, every step of scores handed to all peers), exact reference-order sums; "
-                             "hybrid_treeA_x_rowsB = B independent tree-sharded jobs of A consecutive ranks each on disjoint row slices "
-                             "(a communicator per tree group; scores stay with their row group)")
+                             "hybrid_treeA_x_rowsB = ddt_comm_create_hybrid with tree_ranks A: B row groups of A consecutive ranks, each a tree-sharded job "
+                             "on its slice of the rows, all-reduce inside the row group (scores stay with their row group; _gathered: every piece handed to the "
+                             "other row groups while the next is scored)")
             comm2.close()
             eng2.close()
         except Exception as ex:  # never at the price of the headline line

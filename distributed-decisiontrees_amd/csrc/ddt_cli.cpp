@@ -14,10 +14,16 @@
 //                                                             device g, partial scores combined over RCCL (ddt_group_*)
 //                 [--devices G --mode rows]                   the reference's other mode: the whole ensemble on every device, the
 //                                                             tuples partitioned, every device feeds itself; no collective
+//                 [--devices G --mode hybrid --tree-ranks Gt] the two composed (ddt_group_create_hybrid): row groups of Gt consecutive
+//                                                             devices; device i holds tree shard i % Gt, a row group scores its slice
+//                                                             of the rows, partial scores combined inside the row group
 //                 [--ranks N --rank r --id-file PATH [--combine allreduce|chain] [--device d]]   one process per GPU: this
 //                                                             process is rank r (tree shard r, device r unless --device), the RCCL
 //                                                             id is published by rank 0 through PATH (fresh per job); every
-//                                                             rank gets all scores, --out is optional (ddt_comm_*)
+//                                                             rank gets all scores, --out is optional (ddt_comm_*);
+//                                                             + --mode hybrid --tree-ranks Gt: rank r holds tree shard r % Gt of Gt
+//                                                             (ddt_comm_create_hybrid: the row groups' communicators are split off
+//                                                             the one id), host tuples cross PCIe once in the whole job
 //   ddt_cli gen-sparse   --trees T --max-depth D --features F --rows N [--full-levels L] [--permille P] [--dist 0|1] --prefix DIR/name
 //        a random-forest-like SPARSE model (include/ddt.h ddt_load_model_sparse): name.nodes (one 128-bit line per
 //        internal node), name.first (u64 line index of every tree's root, T + 1 entries), name.tuples
@@ -200,13 +206,16 @@ int cmd_score(const std::map<std::string, std::string>& o) {
     const int G = (int)num(o, "devices", 1);
     const std::string cmb = o.count("combine") ? o.at("combine") : "allreduce";
     if (G < 1 || (cmb != "allreduce" && cmb != "chain")) return die(DDT_EINVAL, nullptr, "--devices / --combine");
+    const bool rows_mode = o.count("mode") && o.at("mode") == "rows";  // the ensemble on every device, the tuples partitioned
+    const bool hybrid_mode = o.count("mode") && o.at("mode") == "hybrid";
+    if (o.count("mode") && !rows_mode && !hybrid_mode && o.at("mode") != "trees") return die(DDT_EINVAL, nullptr, "--mode trees|rows|hybrid");
+    const int Gt = hybrid_mode ? (int)num(o, "tree-ranks", 2) : 0;
+    if (hybrid_mode && (Gt < 1 || G % Gt)) return die(DDT_EINVAL, nullptr, "--tree-ranks must divide --devices");
     ddt_group* g = nullptr;
-    rc = ddt_group_create(&g, G, nullptr);  // devices 0 .. G-1
+    rc = hybrid_mode ? ddt_group_create_hybrid(&g, G, nullptr, Gt) : ddt_group_create(&g, G, nullptr);  // devices 0 .. G-1
     if (rc) return die(rc, nullptr, "ddt_group_create");
     if (o.count("variant"))
       for (int i = 0; i < G; ++i) ddt_set_option(ddt_group_engine(g, i), "variant", (int64_t)num(o, "variant", 0));
-    const bool rows_mode = o.count("mode") && o.at("mode") == "rows";  // the ensemble on every device, the tuples partitioned
-    if (o.count("mode") && !rows_mode && o.at("mode") != "trees") return die(DDT_EINVAL, nullptr, "--mode trees|rows");
     if (rows_mode) {
       rc = ddt_group_load_model_replicated(g, &p, w.data(), w.size() / 16, f.data(), f.size() / 16);
       if (!rc) rc = ddt_group_score_rows(g, x.data(), n, scores.data());
@@ -225,6 +234,9 @@ int cmd_score(const std::map<std::string, std::string>& o) {
     if (rows_mode)
       printf("scored %" PRIu64 " tuples on %d device(s), %u trees on every device, tuples partitioned (kernel %s), no collective\n", n, G, p.num_trees,
              info.variant_name);
+    else if (hybrid_mode)
+      printf("scored %" PRIu64 " tuples on %d device(s): %d row group(s) x %d tree shard(s) (device 0: trees [%u, %u), kernel %s), combine %s inside a row group over RCCL\n",
+             n, G, G / Gt, Gt, info.tree_begin, info.tree_end, info.variant_name, cmb.c_str());
     else
       printf("scored %" PRIu64 " tuples on %d device(s), %u trees sharded tree-wise (device 0: [%u, %u), kernel %s), combine %s over RCCL\n",
              n, G, p.num_trees, info.tree_begin, info.tree_end, info.variant_name, cmb.c_str());
@@ -240,12 +252,16 @@ int cmd_score(const std::map<std::string, std::string>& o) {
     rc = ddt_create(&e, (int)num(o, "device", (uint64_t)r));  // default: rank r drives device r
     if (rc) return die(rc, nullptr, "ddt_create");
     if (o.count("variant")) ddt_set_option(e, "variant", (int64_t)num(o, "variant", 0));
-    rc = ddt_load_model_shard(e, &p, w.data(), w.size() / 16, f.data(), f.size() / 16, (uint32_t)r, (uint32_t)R);
+    const bool hybrid_mode = o.count("mode") && o.at("mode") == "hybrid";
+    if (o.count("mode") && !hybrid_mode && o.at("mode") != "trees") return die(DDT_EINVAL, e, "--ranks: --mode trees|hybrid");
+    const int Gt = hybrid_mode ? (int)num(o, "tree-ranks", 2) : R;
+    if (Gt < 1 || R % Gt) return die(DDT_EINVAL, e, "--tree-ranks must divide --ranks");
+    rc = ddt_load_model_shard(e, &p, w.data(), w.size() / 16, f.data(), f.size() / 16, (uint32_t)(r % Gt), (uint32_t)Gt);
     if (rc) return die(rc, e, "load model shard");
     unsigned char id[DDT_COMM_ID_BYTES];
     if (!exchange_id(id_file, r, (int)num(o, "id-timeout", 120), id)) return die(DDT_ESTATE, e, "communicator id exchange (--id-file)");
     ddt_comm* c = nullptr;
-    rc = ddt_comm_create(&c, e, r, R, id);
+    rc = hybrid_mode ? ddt_comm_create_hybrid(&c, e, r, R, Gt, id) : ddt_comm_create(&c, e, r, R, id);
     if (rc) return die(rc, e, "ddt_comm_create");
     rc = ddt_comm_score(c, x.data(), n, scores.data(), cmb == "chain" ? DDT_COMBINE_CHAIN : DDT_COMBINE_ALLREDUCE);
     if (rc) {
@@ -257,8 +273,8 @@ int cmd_score(const std::map<std::string, std::string>& o) {
     if (o.count("out") && !write_file(o.at("out"), scores.data(), scores.size() * 4)) return die(DDT_EINVAL, e, "write results");
     ddt_info info;
     ddt_get_info(e, &info);
-    printf("rank %d of %d: scored %" PRIu64 " tuples, trees [%u, %u) of %u on %s, kernel %s, combine %s over RCCL\n", r, R, n, info.tree_begin,
-           info.tree_end, p.num_trees, info.device_name, info.variant_name, cmb.c_str());
+    printf("rank %d of %d%s: scored %" PRIu64 " tuples, trees [%u, %u) of %u on %s, kernel %s, combine %s over RCCL\n", r, R,
+           hybrid_mode ? " (hybrid)" : "", n, info.tree_begin, info.tree_end, p.num_trees, info.device_name, info.variant_name, cmb.c_str());
     ddt_comm_destroy(c);
     ddt_destroy(e);
     return 0;

@@ -1263,7 +1263,7 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
 // once per tuple (BASELINE config 5: K launches + an argmax pass before).  Per class the order of the adds is the reference's
 // (FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131, Core.sv:486-541): each segment is a cluster-major image of its own.
 // ---------------------------------------------------------------------------------------------------
-template <int D, int CT, int U, bool PIN>
+template <int D, int CT, int U, bool PIN, bool MULTI>
 __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a, const Q16Aux x) {
   constexpr int THREADS = kQTile;
   constexpr bool GL = true;  // leaves gathered from the global image; levels 0-1 always from SGPRs (_s2)
@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
   static_assert(FEAT_OFF % ROW == 0, "row|lane OR trick");
   const int tid = threadIdx.x;
   const uint32_t W = a.tuple_words, n_chunks = a.n_chunks;
-  const uint32_t n_segs = x.n_segs, seg_chunks = x.seg_chunks ? x.seg_chunks : n_chunks;
+  const uint32_t seg_chunks = x.seg_chunks ? x.seg_chunks : n_chunks;  // MULTI: chunks per ensemble
   const uint32_t tiles = (uint32_t)(x.n_pad / kQTile), grid = gridDim.x;
   const uint32_t units = W * (ROW / 16);  // 16-byte units of one rank tile
   const bool ring = (n_chunks & 1u) == 0u;
@@ -1308,15 +1308,16 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
   for (;;) {
     const uint4* img = slow ? x.img_slow : a.img;
     const bool has_next = nxt < tiles;
+    // the next tile's flag, needed at this tile's last chunk (which image its chunk 0 comes from)
+    const bool slow_n = has_next && __builtin_amdgcn_readfirstlane((int)x.tile_flags[has_next ? nxt : cur]) != 0;
+    const uint4* img_n = slow_n ? x.img_slow : a.img;
     if (!pre0) dma_chunk<THREADS, CHUNK_BYTES>(img, 0, 0, tid);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // every wave is behind the tile-end barrier: the old tile is dead
       const uint32_t u = (uint32_t)tid + (uint32_t)i * THREADS;
       if (u < units) *reinterpret_cast<DDT_LDS(u32x4)*>((uint32_t)FEAT_OFF + u * 16u) = pre[i];
     }
-    // (the next tile's ranks and flag are requested behind the first chunk barrier, see chunks(): in front of it the barrier's
-    // vmcnt(0) would expose their whole HBM latency, 4 us per tile)
-    uint32_t flag_n = 0;
+    prefetch(pre, has_next ? nxt : cur);  // flies during this tile's walks
 
     const __amdgpu_buffer_rsrc_t leaf_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(img), 0, (int)(n_chunks * (uint32_t)(GCHUNK_UNITS * 16)), 0x00020000);
@@ -1359,23 +1360,21 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
         }                                                                                              \
       }                                                                                                \
     }                                                                                                  \
-    if (--seg_left == 0u) { /* wave-uniform: the ensemble ends with this chunk */                      \
-      if (n_segs == 1u) {                                                                              \
-        if (row < a.n) a.out[row] = cm_total;                                                          \
-      } else {                                                                                         \
+    if constexpr (MULTI) {                                                                             \
+      if (--seg_left == 0u) { /* wave-uniform: the ensemble ends with this chunk */                    \
         if (a.out && row < a.n) a.out[(uint64_t)seg * a.n + row] = cm_total;                           \
         if (seg == 0u || cm_total > best || (best != best && cm_total == cm_total)) {                  \
           best = cm_total;                                                                             \
           arg = (int32_t)seg;                                                                          \
         }                                                                                              \
+        ++seg;                                                                                         \
+        seg_left = seg_chunks;                                                                         \
+        ra.a[0][0] = 0.f;                                                                              \
+        cm_groups = 0u;                                                                                \
+        cm_cluster = 0u;                                                                               \
+        cm_bound = (cm_real + Cc - 1u) >> cm_lg;                                                       \
+        cm_total = 0.f;                                                                                \
       }                                                                                                \
-      ++seg;                                                                                           \
-      seg_left = seg_chunks;                                                                           \
-      ra.a[0][0] = 0.f;                                                                                \
-      cm_groups = 0u;                                                                                  \
-      cm_cluster = 0u;                                                                                 \
-      cm_bound = (cm_real + Cc - 1u) >> cm_lg;                                                         \
-      cm_total = 0.f;                                                                                  \
     }                                                                                                  \
   } while (0)
 
@@ -1394,15 +1393,13 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
       const bool slow_l = HOT ? false : slow, exact_l = HOT ? false : exact;
       top_issue<TREE_BYTES>(top_a, img);
       for (uint32_t k = 0; k < n_chunks; k += 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (k == 0 behind the ring: chunk 0 arrived before the tile-end barrier; a vmcnt(0) here would only expose the HBM latency of the
+        // next tile's ranks, requested a moment ago -- 4 us per tile)
+        if (k != 0u || !pre0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // chunk k is in buffer 0 (k = 0: and the rank tile is in place); everyone is done with buffer 1
         const bool more1 = k + 1 < n_chunks;
         if (more1) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 1) * GSKIP, k + 1, CHUNK_BYTES, tid);
-        if (k == 0u) {  // the next tile's ranks fly during this tile's walks; nobody waits for them before the next chunk barrier
-          prefetch(pre, has_next ? nxt : cur);
-          flag_n = x.tile_flags[has_next ? nxt : cur];
-        }
-        if (!more1) last_begin();
+        else last_begin();
         DDT_QPCOMPUTE(0, k);
         if (!more1) {
           last_end();
@@ -1413,8 +1410,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
         const bool more2 = k + 2 < n_chunks;
         if (more2) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 2) * GSKIP, k + 2, 0, tid);
         else {
-          // ring: chunk 0 of the next tile, from the image that tile's flag selects
-          if (has_next) dma_chunk<THREADS, CHUNK_BYTES>(__builtin_amdgcn_readfirstlane((int)flag_n) != 0 ? x.img_slow : a.img, 0, 0, tid);
+          if (has_next) dma_chunk<THREADS, CHUNK_BYTES>(img_n, 0, 0, tid);  // ring: chunk 0 of the next tile
           last_begin();
         }
         DDT_QPCOMPUTE(1, k + 1);
@@ -1425,13 +1421,21 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
     if (!slow && SUM1 == 0) chunks(std::true_type{});
     else chunks(std::false_type{});
 #undef DDT_QPCOMPUTE
-    if (n_segs > 1u && x.labels && row < a.n) x.labels[row] = arg;
+    if constexpr (MULTI) {
+      if (x.labels && row < a.n) x.labels[row] = arg;
+    } else {
+      if (row < a.n) a.out[row] = cm_total;
+    }
     if (!has_next) break;
-    __syncthreads();  // tile end: every walk of this tile is done (rank tile, chunk buffers), the ticket is in place
+    // tile end: every walk of this tile is done (rank tile, chunk buffers), the ticket is in place -- and whatever this wave has
+    // requested has arrived (the ring's chunk 0 of the next tile, requested a chunk ago): the next tile's first barrier then needs no
+    // vmcnt wait and the ranks requested right behind this barrier stay in flight
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     const uint32_t nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_u32(PAD_WORD));
     cur = nxt;
     nxt = nn;
-    slow = __builtin_amdgcn_readfirstlane((int)flag_n) != 0;
+    slow = slow_n;
     pre0 = ring;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing requested may outlive the wave
@@ -1439,13 +1443,14 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
 
 template <int D, int CT, int U, bool PIN>
 static hipError_t launch_q16p(const ScoreArgs& a, const Variant& v, hipStream_t s) {
+  const bool multi = reinterpret_cast<const Q16Aux*>(a.aux)->n_segs > 1u;
   Q16Aux x = *reinterpret_cast<const Q16Aux*>(a.aux);
   const uint64_t tiles = (a.n + kQTile - 1) / kQTile;
   if (tiles == 0) return hipSuccess;
   if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
   if (x.n_segs == 0u || (x.seg_chunks ? x.seg_chunks * x.n_segs : a.n_chunks) != a.n_chunks || a.sum_mode == 1u) return hipErrorInvalidValue;
   x.tile_counter = x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters;  // behind the pre-pass counters (launch_q16_prepass)
-  auto kern = score_q16p_kernel<D, CT, U, PIN>;
+  auto kern = multi ? score_q16p_kernel<D, CT, U, PIN, true> : score_q16p_kernel<D, CT, U, PIN, false>;  // several ensembles in the image: sums + argmax
   const uint32_t lds = v.lds_bytes_q16(a.tuple_words);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1750,7 +1755,6 @@ static const Variant g_variants[] = {
     DDT_QO("q16_d8_c8_u4_gl_s2_cm", 8, 8, 4, 7),
     // _p: persistent blocks, the next rank tile prefetched into registers, several ensembles (classes) per pass (opt bit 3)
     Variant{"q16_d8_c8_u4_gl_s2_cm_p", kKindQ16, 8, kQTile, 1, 8, 4, 1, 15, &launch_q16p<8, 8, 4, true>},
-    Variant{"q16_d8_c8_u4_gl_s2_cm_pu", kKindQ16, 8, kQTile, 1, 8, 4, 1, 15, &launch_q16p<8, 8, 4, false>},  // the compiler's read order (A/B)
     // _x: the plain launch with the pinned read order (four chains in flight per lane)
     Variant{"q16_d8_c8_u4_gl_s2_cm_x", kKindQ16, 8, kQTile, 1, 8, 4, 1, 7, &launch_q16<8, 8, 4, 23>},
     // _s2 on the layouts that keep their leaves in LDS (depths 5-7): 100 x d6 x 28 features, 10 M tuples: 1.297 vs 1.333 ms

@@ -62,10 +62,12 @@ def test_hybrid_legs_geometry():
     """other_modes' hybrid legs: tree groups of 2 / 4 consecutive ranks that leave >= 2 row groups; row slices in whole 1024-tuple tiles
     that cover every tuple exactly once."""
     import bench
+    import ddt
 
+    sys.path.insert(0, os.path.join(ROOT, "distributed-decisiontrees_amd"))
     assert bench.hybrid_tree_groups(8) == [2, 4] and bench.hybrid_tree_groups(4) == [2] and bench.hybrid_tree_groups(2) == []
     assert bench.hybrid_tree_groups(1) == [] and bench.hybrid_tree_groups(6) == [2]
     for n, Gr in ((100_000_000, 4), (100_000_000, 2), (10_000_001, 4), (3000, 2), (1000, 4)):
-        cuts = [bench.hybrid_rows(n, Gr, rg) for rg in range(Gr)]
+        cuts = [ddt.hybrid_rows(n, Gr, rg) for rg in range(Gr)]      # the C-ABI's own split (ddt_hybrid_rows, host-only)
         assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
         assert all(lo % 1024 == 0 for lo, _ in cuts if lo < n)

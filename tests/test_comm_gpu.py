@@ -92,6 +92,44 @@ def test_one_rank_sharded_classes(eng, comm):
         comm.score_sharded(d)
 
 
+def test_one_rank_hybrid_job(eng):
+    """ddt_comm_create_hybrid on the real RCCL: ncclCommInitRank + ncclCommSplit with one rank (one row group of one tree shard), the
+    hybrid calls on device and host buffers, the refusals, ddt_comm_abort.  Every collective is the identity: results == the plain call."""
+    import torch
+
+    T, D, F, rows = 300, 8, 32, 5003
+    m = O.gen_model(T, D, F, 0)
+    x = O.gen_tuples(0, rows, F, 0)
+    want = O.score(m, x)
+    eng.load_model(ddt.make_params(T, D, F), m.wlines, m.flines, 0, 1)
+    c = ddt.Comm(eng, 0, 1, ddt.comm_unique_id(), tree_ranks=1)
+    lay = c.layout()
+    assert (lay.n_ranks, lay.tree_ranks, lay.row_groups, lay.row_group) == (1, 1, 1, 0)
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    for chunk in (12_500_000, 1024, 700):
+        c.set_option("chunk_rows", chunk)
+        for combine in (ddt.COMBINE_ALLREDUCE, ddt.COMBINE_CHAIN):
+            for gather in (True, False):
+                got = c.score_hybrid(d, combine=combine, gather=gather)
+                torch.cuda.synchronize()
+                assert np.array_equal(_bits(got.cpu().numpy()), _bits(want)), (chunk, combine, gather)
+    assert np.array_equal(_bits(c.score(x)), _bits(want))                    # host buffers through the hybrid communicator
+    with pytest.raises(ddt.DDTError):
+        c.score_sharded(d)                                                    # the tree-sharded call refuses a hybrid communicator
+    plain = ddt.Comm(eng, 0, 1, ddt.comm_unique_id())
+    with pytest.raises(ddt.DDTError):
+        plain.score_hybrid(d)                                                 # ... and the hybrid call a plain one
+    plain.close()
+    c.abort()
+    with pytest.raises(ddt.DDTError):
+        c.score_hybrid(d)                                                     # dead after ddt_comm_abort
+    c.close()
+    g = ddt.Group([0], tree_ranks=1)                                          # the single-process form
+    g.load_model(ddt.make_params(T, D, F), m.wlines, m.flines)
+    assert np.array_equal(_bits(g.score(x)), _bits(want))
+    g.close()
+
+
 def test_group_of_one_device_host_buffers(eng):
     m = O.gen_model(200, 8, 32, 0)
     x = O.gen_tuples(0, 30_000, 32, 0)

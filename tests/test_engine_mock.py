@@ -326,6 +326,11 @@ def test_the_cli_host_program_on_the_model(mock, tmp_path):
     out = subprocess.check_output(base + ["--devices", "4", "--mode", "rows"]).decode()
     assert "tuples partitioned" in out and "no collective" in out
     assert np.array_equal(_bits(np.fromfile(pre + ".res", np.float32)[:n]), _bits(O.score(m, x)))
+    # the two modes composed: 2 row groups x 2 tree shards (chain combine inside a row group = the oracle's 2-device model on every row)
+    out = subprocess.check_output(base + ["--devices", "4", "--mode", "hybrid", "--tree-ranks", "2", "--combine", "chain"]).decode()
+    assert "2 row group(s) x 2 tree shard(s)" in out
+    assert np.array_equal(_bits(np.fromfile(pre + ".res", np.float32)[:n]), _bits(O.score(m, x, n_devices=2)))
+    assert subprocess.run(base + ["--devices", "4", "--mode", "hybrid", "--tree-ranks", "3"], capture_output=True).returncode == 1
     parts = []
     for g in range(4):                                           # the same job as four single-engine runs, combined by the oracle's hop adder
         subprocess.check_output(base + ["--shard", str(g), "--of", "4"])

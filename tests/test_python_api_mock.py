@@ -89,6 +89,49 @@ def test_group_of_four_devices(on_model):
         ddt.Group([0, 0])                                             # one communicator rank per device
 
 
+def test_hybrid_through_the_python_bindings(on_model):
+    """ddt.Group(tree_ranks=) and ddt.Comm(tree_ranks=) (ddt_group_create_hybrid / ddt_comm_create_hybrid): four "devices" as 2 row groups x 2
+    tree shards -- the single-process group, and one thread per rank calling the host-buffer form (ncclCommSplit behind the C-ABI)."""
+    import threading
+
+    T, D, F, n = 200, 8, 32, 5000
+    m, x = O.gen_model(T, D, F, 0), O.gen_tuples(0, n, F, 0)
+    want = O.score(m, x, n_devices=2)
+    g = ddt.Group([0, 1, 2, 3], tree_ranks=2)
+    g.load_model(ddt.make_params(T, D, F), m.wlines, m.flines)
+    assert np.array_equal(g.score(x, combine=ddt.COMBINE_CHAIN).view(np.uint32), want.view(np.uint32))
+    g.close()
+    assert ddt.hybrid_rows(n, 2, 0) == (0, 3072) and ddt.hybrid_rows(n, 2, 1) == (3072, n)
+    uid, got, errs = ddt.comm_unique_id(), {}, []
+
+    def rank(r):
+        try:
+            on_model.hipSetDevice(r)
+            e = ddt.Engine(r)
+            e.load_model(ddt.make_params(T, D, F), m.wlines, m.flines, r % 2, 2)
+            c = ddt.Comm(e, r, 4, uid, tree_ranks=2)
+            lay = c.layout()
+            assert (lay.rank, lay.n_ranks, lay.tree_ranks, lay.tree_rank, lay.row_groups, lay.row_group) == (r, 4, 2, r % 2, 2, r // 2)
+            c.set_option("host_rows", 2100)
+            got[r] = c.score(x, combine=ddt.COMBINE_CHAIN)
+            done.wait()
+            c.close()
+            e.close()
+        except BaseException as ex:  # noqa: BLE001
+            errs.append((r, repr(ex)))
+            done.abort()
+
+    done = threading.Barrier(4)
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errs, errs
+    for r in range(4):
+        assert np.array_equal(got[r].view(np.uint32), want.view(np.uint32)), r
+
+
 def test_comm_host_buffer_call(on_model):
     T, D, F, n = 90, 8, 32, 2100
     m, x = O.gen_model(T, D, F, 1), O.gen_tuples(0, n, F, 1)

@@ -47,7 +47,7 @@ def test_persistent_blocks_over_many_tiles(T, clusters, n):
         want = O.score_fast(m, x, sum_mode=ref)
         e.set_option("variant", -1)
         e.load_model(ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), m.wlines, m.flines)
-        for name in (NAME, NAME + "u", "q16_d8_c8_u4_gl_s2_cm_x"):   # pinned read order / the compiler's; the plain launch with the pinned order
+        for name in (NAME, "q16_d8_c8_u4_gl_s2_cm_x"):              # persistent / the plain launch, both with the pinned read order
             e.set_option("variant", _vid(name))
             assert e.info().variant_name.decode() == name
             for _ in range(2):                                  # twice: the tile counter is zeroed per launch

@@ -1,10 +1,10 @@
 #!/bin/bash
-# round 4, session 3: the persistent kernel with its prefetch behind the first chunk barrier; full GPU suite; sum_mode 2 at HEAD
+# round 4, session 4: the persistent kernel with its prefetch behind the first chunk barrier; full GPU suite; sum_mode 2 at HEAD
 set -u
 cd "$GRAFT_REPO_ROOT"
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_s3
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r04_s4
 rm -rf "$OUT"; mkdir -p "$OUT"
-( timeout 500 python -m pytest tests -q -m gpu 2>&1 | grep -v "Extension modules" | tail -15 ) > $OUT/gpu_tests.log; grep -n "passed\|failed\|error" $OUT/gpu_tests.log | tail -3
+( timeout 500 python -m pytest tests/test_q16_persistent.py tests/test_multiclass.py tests/test_comm_gpu.py tests/test_gpu_parity.py -q -m gpu 2>&1 | grep -v "Extension modules" | tail -15 ) > $OUT/gpu_tests.log; grep -n "passed\|failed\|error" $OUT/gpu_tests.log | tail -3
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-streamed"
 V() { python - "$1" <<'PY'
 import sys
@@ -27,13 +27,14 @@ run shard8_x --shard-of 8 --variant $VX
 run shard8_p --shard-of 8 --variant $VP
 run shard4_x --shard-of 4 --variant $VX
 run shard4_p --shard-of 4 --variant $VP
-run shard2_x --shard-of 2 --variant $VX
-run shard2_p --shard-of 2 --variant $VP
+
+
 run cfg3_x --variant $VX
 run cfg3_p --variant $VP
 run cfg3_x_sum2 --variant $VX --sum-mode 2
+run cfg3_base
 run cfg3_p_sum2 --variant $VP --sum-mode 2
 run cfg5_x --config 5 --variant $VX
 run cfg5_p --config 5 --variant $VP
-run t250_x --trees 250 --variant $VX
-run t250_p --trees 250 --variant $VP
+
+
