@@ -223,7 +223,13 @@ def main():
         comm.set_option("chunk_rows", max(1024, args.chunk_rows // (world // args.tree_ranks)) if hybrid_mode else args.chunk_rows)
         comm.set_option("taper_tail", args.taper)
     elif multi:
-        from tests import sharded_ref  # --collectives torch: the Python mirror of the pipeline (test infrastructure; needed for gloo ranks sharing a GPU)
+        # --collectives torch: the Python mirror of the pipeline (test infrastructure; needed for gloo ranks sharing a GPU), loaded by path
+        # so that no installed package called `tests` can shadow it
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("ddt_sharded_ref", os.path.join(ROOT, "tests", "sharded_ref.py"))
+        sharded_ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sharded_ref)
 
         scorer = (sharded_ref.RowShardedScorer(eng) if rows_mode else
                   sharded_ref.ShardedScorer.from_engine(eng, mode=args.combine, chunk_rows=args.chunk_rows,
@@ -321,6 +327,7 @@ def main():
         k_ms = sum(b for _, b in kernel_ms) / len(kernel_ms)  # the dominant (scoring) kernel
         if classes > 1:  # the library times the LAST class's launch: the K launches are alike, the pre-pass ran once with the first
             k_ms, pre_ms = ms_per_step, 0.0
+    if kernel_ms and k_ms > 0:  # (an event that could not be resolved leaves 0: no roofline object rather than a division by zero)
         ach = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic_cfg4.json" if sparse else "pmc_traffic.json")

@@ -446,8 +446,24 @@ constexpr uint32_t kQ16MinTreeLevels = 480;  // trees x levels from which the ra
                                              // (profiles/r02_sweep_q16_small.json: 60 x d8 +4 %, 80 x d8 +5 %, 112 x d8 +7 %, 200 x d6 +9 %; round 3 with the _s2 walk,
                                              // profiles/r03_sweep_fused_rank_experiment_ilp8_s2.json: 100 x d6 +17 %, 100 x d8 +11 %, while 30 x d6 still loses 15 %)
 
-constexpr bool kQ16PersistentAuto = false;       // (first measurements pending: the automatic choice stays as it was)
-constexpr uint32_t kQ16PersistentMaxTrees = 512;  // per engine and class: above this the plain launch is as fast (measured, profiles/r04_*)
+// a one-vs-all model whose classes hold equally many trees on this engine: their images can stand back to back (select_and_build)
+bool classes_equal(const ddt_engine* e) {
+  if (e->num_classes < 2) return false;
+  for (const Ensemble& m : e->ens)
+    if (m.trees() != e->ens[0].trees()) return false;
+  return e->ens[0].trees() > 0;
+}
+
+// DDT_DISABLE_S2=1 in the environment: the AUTOMATIC choice skips the kernels that keep node records in SGPRs filled by inline-asm
+// scalar loads ("_s2", opt bit 1 of the rank-quantised kernels) -- for a build whose tools/check_s2_isa.py could not run (no
+// disassembler on the build machine: __graft_entry__.build() says so).  A forced "variant" still takes them.
+bool s2_disabled() {
+  static const bool off = [] {
+    const char* v = getenv("DDT_DISABLE_S2");
+    return v && v[0] && v[0] != '0';
+  }();
+  return off;
+}
 
 bool variant_fits(const Variant& v, const ddt_engine* e) {
   if (v.kind == kKindSparse) return false;  // sparse forests pick their kernel in ddt_sparse_host.cpp
@@ -495,14 +511,20 @@ int auto_variant(const ddt_engine* e) {
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
     // (the cluster-major form only where there is a ring to save -- more than one cluster -- and the sum follows the reference's
     // order: the fp64 sum of sum_mode 1 runs in stream order, which a permuted image would change)
-    // persistent blocks ("_p", depth 8): what they save is the block turn-over per tile, a fixed cost -- it pays where a tile is
-    // short (few chunks: the shards of a tree-sharded job, ensembles of a few hundred trees); and a one-vs-all model whose classes
-    // hold equally many trees is walked in ONE launch (profiles/r04_*)
-    if (e->p.sum_mode != 1u && e->q16_persistent != 0) {
-      const int i = find_variant("q16_d8_c8_u4_gl_s2_cm_p");
-      if (i >= 0 && variant_fits(variant(i), e) && (e->q16_persistent == 1 || (kQ16PersistentAuto && (e->num_classes > 1 || max_trees(e) <= kQ16PersistentMaxTrees)))) return i;
+    // depth 8, reference-order sums (the fp64 sum of sum_mode 1 runs in stream order, which the cluster-major images would change):
+    //   "_p"  persistent blocks -- a one-vs-all model whose classes hold equally many trees is walked in ONE launch, sums and labels
+    //         written by the scoring kernel (10.57 vs 10.89 ms per 10 M tuples x 10 x 100 trees, and 11.37 before round 4).  For a plain
+    //         ensemble the resident blocks buy nothing (12.92 vs 13.05 ms on a 125-tree shard, 94.8 vs 95.3 ms at 1000 trees:
+    //         profiles/r04_q16_pinned_persistent.md), so only option "q16_persistent" = 1 picks it there;
+    //   "_x"  the plain launch with the pinned LDS read order (four chains in flight per lane): +4.6 % over "_cm" at 1000 trees,
+    //         +4 % on the shards; its single accumulator + running total also serves one cluster.
+    if (e->p.sum_mode != 1u && !s2_disabled()) {
+      const int ip = find_variant("q16_d8_c8_u4_gl_s2_cm_p");
+      if (ip >= 0 && variant_fits(variant(ip), e) && e->q16_persistent != 0 && (e->q16_persistent == 1 || classes_equal(e))) return ip;
+      const int ix = find_variant("q16_d8_c8_u4_gl_s2_cm_x");
+      if (ix >= 0 && variant_fits(variant(ix), e)) return ix;
     }
-    if (e->p.clusters_per_tuple > 1u && e->p.sum_mode != 1u) {
+    if (e->p.clusters_per_tuple > 1u && e->p.sum_mode != 1u && !s2_disabled()) {
       const int i = find_variant("q16_d8_c8_u4_gl_s2_cm");
       if (i >= 0 && variant_fits(variant(i), e)) return i;
     }
@@ -510,7 +532,7 @@ int auto_variant(const ddt_engine* e) {
                                   "q16_d9_c4_u4", "q16_d10_c4_u4"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
-      if (i >= 0 && variant_fits(variant(i), e)) return i;
+      if (i >= 0 && variant_fits(variant(i), e) && !((variant(i).opt & 2) && s2_disabled())) return i;
     }
   }
   for (const char* name : pref) {
@@ -1011,6 +1033,8 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     if (rc) return rc;
     if (v.kind == kKindQ16) a.ev_mid = e->tev_cur[1];
     else HIP_TRY(e, hipEventRecord(e->tev_cur[1], s));
+  } else if (e->ev_fork && v.kind == kKindQ16 && !reuse_prepass) {
+    a.ev_mid = e->ev_fork;  // multi-class calls: recorded between the shared pre-pass and class 0's scoring kernel
   }
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   hipError_t r = v.launch(a, v, s);
@@ -1041,12 +1065,18 @@ int launch_classify(ddt_engine* e, const void* d_tuples, size_t n, float* d_clas
   for (uint32_t k = 0; k < e->num_classes; ++k) {
     // rank-quantised path: the q tiles of this batch are computed by the first class's launch and reused
     hipStream_t sk = (two && (k & 1u)) ? e->class_stream : s;
-    int rc = launch_score(e, e->ens[k], d_tuples, n, d_class_scores + (size_t)k * n, sk, k > 0);
-    if (rc) return rc;
-    if (two && k == 0) {  // everything the other stream needs (tuples written by the caller's stream, the pre-pass) is behind this point
-      HIP_TRY(e, hipEventRecord(e->class_ev[0], s));
-      HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));
+    // What the other stream needs is the tuples (written by whatever the caller's stream has queued) and, on the rank-quantised path,
+    // the shared pre-pass -- not class 0's scoring kernel: the fork event sits between the two (kernels without a pre-pass: in front
+    // of class 0's launch), so that class 1 overlaps class 0
+    const bool ranked = variant(e->variant_id).kind == kKindQ16;
+    if (two && k == 0) {
+      if (ranked) e->ev_fork = e->class_ev[0];
+      else HIP_TRY(e, hipEventRecord(e->class_ev[0], s));
     }
+    int rc = launch_score(e, e->ens[k], d_tuples, n, d_class_scores + (size_t)k * n, sk, k > 0);
+    e->ev_fork = nullptr;
+    if (rc) return rc;
+    if (two && k == 0) HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));
   }
   if (two) {
     HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));
@@ -1087,14 +1117,19 @@ int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float*
     }
     for (uint32_t k = 0; k < e->num_classes; ++k) {
       // rank-quantised kernels: the ranks of this batch are computed by the first class's launch and reused
+      // the other stream starts behind whatever the caller's stream has queued up to here (the tuples may come from there) and -- the
+      // rank-quantised kernels -- behind the rank pre-pass of the batch, which is part of class 0's launch; NOT behind class 0's
+      // scoring kernel: the fork event is recorded between the two (sparse_launch), or in front of the launch when there is no pre-pass
+      const bool ranked = (variant(e->variant_id).opt & 1) != 0;
+      if (two && k == 0) {
+        if (ranked) e->ev_fork = e->class_ev[0];
+        else HIP_TRY(e, hipEventRecord(e->class_ev[0], s));
+      }
       int rc = sparse_launch(e, k, d_tuples, n, d_class_scores + (size_t)k * n, (two && (k & 1u)) ? e->class_stream : s, k > 0);
+      e->ev_fork = nullptr;
       if (rc) return rc;
       e->st.kernel_launches++;
-      if (two && k == 0) {  // the other stream starts behind whatever the caller's stream has queued up to here: the tuples may
-                            // come from there, and the rank pre-pass of the batch is part of class 0's launch
-        HIP_TRY(e, hipEventRecord(e->class_ev[0], s));
-        HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));
-      }
+      if (two && k == 0) HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));
     }
     if (two) {
       HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));

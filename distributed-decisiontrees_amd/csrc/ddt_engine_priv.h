@@ -145,6 +145,7 @@ struct ddt_engine {
   // one launch (the last, partly filled wave of blocks) overlaps the next class's launch (option "class_streams", default 1)
   hipStream_t class_stream = nullptr;
   hipEvent_t class_ev[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr;  // set around class 0's launch of a rank-quantised multi-class call: recorded between its pre-pass and its scoring kernel
   int class_streams = 1;
   int stream_blocks_per_cu = 0;  // option "stream_blocks_per_cu": persistent stream kernel, blocks per CU (0 = resident blocks)
   // sparse forests (ddt_load_model_sparse)

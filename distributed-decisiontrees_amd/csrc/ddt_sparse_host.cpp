@@ -381,6 +381,7 @@ int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, f
     qa.img_slow = nullptr;  // the sparse images carry the missing direction in every record
     qa.n_pad = (n + 1023) / 1024 * 1024;
     if (e->tev_cur) a.ev_mid = e->tev_cur[1];  // recorded between the pre-pass and the scoring kernel
+    else if (e->ev_fork && !reuse_prepass) a.ev_mid = e->ev_fork;  // multi-class calls: where the other stream's classes may start
   }
   a.aux = &x;
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch

@@ -19,9 +19,12 @@ Rules applied:
                    callers must present NaNs in that canonical form).
   comparator       real models have negative features, where the reference's raw-bit signed-int comparator
                    (DTPU.sv:655) is inverted; imported models therefore set cmp_mode = 1 (IEEE '<').
-  leaf values      rounded to fp32; results that are -0 or sub-normal are flushed to +0: the reference's adder treats
-                   sub-normal inputs as normals and keeps -0 (FPAdder_2cycles_latency.v:313-320,376-385), so such leaves
-                   have no exact meaning in its sum and the engine refuses them (option leaf_domain_check).
+  leaf values      rounded to fp32 and brought into the engine's EXACT LEAF DOMAIN (include/ddt.h, option leaf_domain_check: +0 or
+                   a normal with 2^-102 <= |v| < 2^96 -- on it no partial sum of the reference-order reduction can be sub-normal,
+                   overflow or be -0, which the reference's adder treats differently from IEEE-754:
+                   FPAdder_2cycles_latency.v:313-320,376-385): -0, sub-normals and every |v| < 2^-102 are flushed to +0 (an
+                   absolute error below 2^-102 per leaf); a leaf with |v| >= 2^96, an infinity or a NaN raises ValueError
+                   -- such a model does not load with the default options, and silently clamping it would change its scores.
   sparse=True      instead of padding to a perfect heap (2^(D+1) words per tree -- hopeless for a depth-16 random
                    forest), emit the SPARSE stream of include/ddt.h (ddt_load_model_sparse): one 128-bit line per internal
                    node {threshold, feature entry | leaf flags, left, right} in breadth-first order.
@@ -79,11 +82,17 @@ class ImportedModel:
         return engine.load_model(self.params(**kw), self.wlines, self.flines, shard_index, shard_count)
 
 
+LEAF_MIN, LEAF_LIMIT = 2.0 ** -102, 2.0 ** 96   # the loader's exact leaf domain (csrc/ddt_engine.cpp leaf_outside_exact_domain)
+
+
 def leaf_f32(v) -> np.float32:
-    """fp32 leaf value; -0 and sub-normal results are flushed to +0 (see the module docstring)."""
+    """fp32 leaf value inside the engine's exact leaf domain: -0, sub-normals and |v| < 2^-102 become +0; |v| >= 2^96, Inf and
+    NaN raise ValueError (see the module docstring)."""
     with np.errstate(over="ignore", under="ignore"):
         f = np.float32(v)
-    if f == 0 or abs(f) < np.finfo(np.float32).tiny:
+    if not np.isfinite(f) or abs(float(f)) >= LEAF_LIMIT:
+        raise ValueError(f"leaf value {v!r} is outside the engine's leaf domain (|v| < 2^96, finite): ddt_load_model* would refuse it")
+    if abs(float(f)) < LEAF_MIN:
         return np.float32(0.0)
     return f
 

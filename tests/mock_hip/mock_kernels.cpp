@@ -230,6 +230,7 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
 const Variant g_mock_variants[] = {
     Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_records},
     Variant{"q16_d8_c8_u4_gl_s2_cm_p", kKindQ16, 8, 1024, 1, 8, 4, 1, 15, &launch_q16},
+    Variant{"q16_d8_c8_u4_gl_s2_cm_x", kKindQ16, 8, 1024, 1, 8, 4, 1, 7, &launch_q16},
     Variant{"q16_d8_c8_u4_gl_s2_cm", kKindQ16, 8, 1024, 1, 8, 4, 1, 7, &launch_q16},
     Variant{"q16_d8_c8_u4_gl_s2", kKindQ16, 8, 1024, 1, 8, 4, 1, 3, &launch_q16},
     Variant{"q16_d8_c8_u4_gl", kKindQ16, 8, 1024, 1, 8, 4, 1, 1, &launch_q16},

@@ -446,8 +446,8 @@ def test_failed_changes_leave_the_loaded_model_in_place(mock):
 
 REMOVED = {
     # the odd classes no longer wait for class 0's launch (and the rank pre-pass in front of it) on the caller's stream
-    "class_stream_start": ("      HIP_TRY(e, hipEventRecord(e->class_ev[0], s));\n      HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));\n    }\n  }\n  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));",
-                           "      HIP_TRY(e, hipEventRecord(e->class_ev[0], s));\n    }\n  }\n  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));"),
+    "class_stream_start": ("    if (two && k == 0) HIP_TRY(e, hipStreamWaitEvent(e->class_stream, e->class_ev[0], 0));\n  }\n  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));",
+                           "  }\n  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));"),
     # the caller's stream no longer waits for the classes that ran on the engine's stream
     "class_stream_end": ("  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));\n    HIP_TRY(e, hipStreamWaitEvent(s, e->class_ev[1], 0));\n",
                          "  if (two) {\n    HIP_TRY(e, hipEventRecord(e->class_ev[1], e->class_stream));\n"),
@@ -552,8 +552,8 @@ def test_a_refused_sparse_option_keeps_the_model(mock):
 def test_cluster_major_image_order(mock, T, clusters):
     """`_cm` kernels: the packer stores the PU groups of a cluster together (cluster-major), the launch tells the kernel how many PU
     groups are real, and the scores are the reference-order sums -- checked through the CPU model of the kernel, which reads the
-    packed image in that order; the fp64 sum (stream order) refuses such an image; the automatic choice takes it exactly when
-    there is more than one cluster."""
+    packed image in that order; the fp64 sum (stream order) refuses such an image; the automatic choice is the cluster-major kernel with
+    the pinned read order ("_x") for every cluster count."""
     mock.mock_reset(0, 0, 8)
     D, F, n = 8, 32, 400
     m, x = O.gen_model(T, D, F, 1, clusters=clusters), O.gen_tuples(0, n, F, 1)
@@ -573,7 +573,7 @@ def test_cluster_major_image_order(mock, T, clusters):
         _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters), None)
         info = ddt.Info()
         assert mock.ddt_get_info(e, C.byref(info)) == 0
-        assert info.variant_name.decode() == ("q16_d8_c8_u4_gl_s2_cm" if clusters > 1 else "q16_d8_c8_u4_gl_s2")
+        assert info.variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_x"      # the pinned-read-order kernel: its running total also serves one cluster
     mock.ddt_destroy(e)
 
 

@@ -156,12 +156,12 @@ def _check(T, D, F, variant_name, dist, cmp_mode=0, n=96, expect_auto=None):
 
 
 def test_headline_model_takes_the_gl_rank_quantised_image():
-    nfo = _check(1000, 8, 32, None, 0, n=48, expect_auto="q16_d8_c8_u4_gl_s2_cm")   # 8 clusters: cluster-major image, no accumulator ring
+    nfo = _check(1000, 8, 32, None, 0, n=48, expect_auto="q16_d8_c8_u4_gl_s2_cm_x")   # cluster-major image, no accumulator ring, pinned read order
     assert nfo["kind"] == Q16 and nfo["opt"] & 1 and nfo["chunk_trees"] == 8 and nfo["Tpad"] == 1000 and nfo["tile"] == 1024
 
 
 def test_eight_way_shard_of_the_headline_model():
-    nfo = _check(125, 8, 32, None, 0, n=48, expect_auto="q16_d8_c8_u4_gl_s2")
+    nfo = _check(125, 8, 32, None, 0, n=48, expect_auto="q16_d8_c8_u4_gl_s2_cm_x")
     assert nfo["Tpad"] == 128                                          # whole chunks of 8: three EMPTY trees
 
 

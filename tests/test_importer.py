@@ -140,6 +140,39 @@ def test_xgboost_json_dump():
     assert np.allclose(got, want, atol=1e-7)
 
 
+def test_leaf_values_land_in_the_loaders_exact_domain():
+    """The importer's leaf rule == the loader's check (csrc/ddt_engine.cpp leaf_outside_exact_domain: +0 or a normal with
+    2^-102 <= |v| < 2^96): what it emits loads with the default options; what it cannot represent raises instead of failing later."""
+    for v, want in ((1e-35, 0.0), (-1e-35, 0.0), (-0.0, 0.0), (1e-45, 0.0), (2.0 ** -102, 2.0 ** -102), (-(2.0 ** -102), -(2.0 ** -102)),
+                    (0.1, np.float32(0.1)), (2.0 ** 95, 2.0 ** 95)):
+        got = I.leaf_f32(v)
+        assert got == np.float32(want) and not np.signbit(got) or got == np.float32(want) and want < 0, v
+        bits = int(np.float32(got).view(np.uint32))
+        ex = (bits >> 23) & 0xFF
+        assert bits == 0 or 25 <= ex <= 222, (v, hex(bits))               # the loader's test, restated
+    for v in (2.0 ** 96, -1e30, np.inf, -np.inf, np.nan, 1e39):
+        with pytest.raises(ValueError):
+            I.leaf_f32(v)
+    # through a model: a tiny leaf is flushed (the model still loads), a huge one is refused at import time
+    t = {"left_children": [1, -1, -1], "right_children": [2, -1, -1], "split_indices": [0, 0, 0], "split_conditions": [0.5, 1e-35, 0.25], "default_left": [0, 0, 0]}
+    j = {"learner": {"learner_model_param": {"num_feature": "1", "num_class": "0", "base_score": "0"},
+                     "gradient_booster": {"name": "gbtree", "model": {"trees": [t], "tree_info": [0]}}}}
+    im = I.from_xgboost_json(j)
+    assert sorted(np.unique(im.wlines.view(np.float32)[1:3])) == [0.0, 0.25]
+    import ctypes as C
+
+    L, info = ddt.lib(), (C.c_uint64 * 12)()
+    w, f = np.ascontiguousarray(im.wlines).view(np.uint32), np.ascontiguousarray(im.flines).view(np.uint16)
+    rc = L.ddt_debug_model_image(C.byref(im.params()), w.ctypes.data, w.size // 4, f.ctypes.data, f.size // 8, -1, None, None, 0, None, 0, C.byref(info))
+    assert rc == 0, rc                                                      # the loader's own validation accepts the stream (host-only hook)
+    w2 = w.copy()
+    w2[np.flatnonzero(w2.view(np.float32) == np.float32(0.25))[0]] = np.float32(1e-35).view(np.uint32)
+    assert L.ddt_debug_model_image(C.byref(im.params()), w2.ctypes.data, w2.size // 4, f.ctypes.data, f.size // 8, -1, None, None, 0, None, 0, C.byref(info)) == -5
+    t["split_conditions"][1] = 1e30
+    with pytest.raises(ValueError):
+        I.from_xgboost_json(j)
+
+
 @pytest.mark.gpu
 def test_imported_models_on_gpu():
     X, y = _data(3000, 12, 11)

@@ -80,15 +80,15 @@ def test_auto_selection_and_fallbacks():
     e = ddt.Engine(0)
     w, f = ddt.synth_model(1000, 8, 32)
     e.load_model(ddt.make_params(1000, 8, 32), w, f)
-    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm"     # many trees: the pre-pass pays off (8 clusters: cluster-major image)
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_x"   # many trees: the pre-pass pays off (cluster-major image, pinned read order)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)          # 125 trees per engine (8-way shard): all rank tables
-    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm"     # fit LDS together -> fused pre-pass -> q16 still pays
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_x"   # fit LDS together -> fused pre-pass -> q16 still pays
     _prepass(e, -1)                                                 # with the transpose + rank kernels the fixed pre-pass cost is too high
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 3, 8)
     assert e.info().variant_name.decode() == "d8_t1024_r1_c4_u4_dma_f"
     _prepass(e, 0)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 12)         # 84 trees x 8 levels >= 480: q16 with the LDS-resident pre-pass
-    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm" and e.info().prepass_groups in (1, 2, 4, 8)
+    assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_x" and e.info().prepass_groups in (1, 2, 4, 8)
     e.load_model(ddt.make_params(1000, 8, 32), w, f, 0, 20)         # 50 trees: below the break-even either way
     assert e.info().prepass_groups == 0
     with pytest.raises(ddt.DDTError):

@@ -168,7 +168,7 @@ def test_one_shard_of_a_tree_sharded_job_on_one_gpu():
     """bench.py --shard-of G: what one of G ranks computes (the shard's trees with the whole model's cluster count), no collective."""
     j = _bench("--rows", "300000", "--steps", "2", "--warmup", "1", "--shard-of", "8")
     assert j["n_gpus"] == 1 and j["value"] > 0 and "one shard of 8" in j["metric"] and j["config"]["parallelism"] == "one-of-tree-shard8"
-    assert "125 trees" in j["config"]["workload"] and j["config"]["kernel"] == "q16_d8_c8_u4_gl_s2_cm"
+    assert "125 trees" in j["config"]["workload"] and j["config"]["kernel"] == "q16_d8_c8_u4_gl_s2_cm_x"
     assert j["roofline"]["kernel_ms"] > 0 and "cpu_baseline" not in j and "streamed" not in j
 
 

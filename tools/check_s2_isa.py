@@ -17,7 +17,27 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def find_objdump():
+    """llvm-objdump of the ROCm toolchain: $ROCM_PATH, what `hipconfig --rocmpath` says, /opt/rocm, then PATH"""
+    roots = [os.environ.get("ROCM_PATH"), os.environ.get("HIP_PATH")]
+    try:
+        roots.append(subprocess.run(["hipconfig", "--rocmpath"], capture_output=True, text=True, timeout=20).stdout.strip())
+    except Exception:
+        pass
+    roots.append("/opt/rocm")
+    for r in roots:
+        if r:
+            for sub in ("lib/llvm/bin", "llvm/bin", "bin"):
+                cand = os.path.join(r, sub, "llvm-objdump")
+                if os.path.exists(cand):
+                    return cand
+    return shutil.which("llvm-objdump")
+
+
+OBJDUMP = find_objdump() or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+EXIT_CANNOT_RUN = 3  # no disassembler: nothing was checked (distinct from 1 = a violation)
 
 SREG = re.compile(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b")
 
@@ -158,7 +178,14 @@ def check_kernel(name, body):
 
 def main():
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "distributed-decisiontrees_amd", "lib", "libddt.so")
-    dis = disassemble(lib)
+    if not os.path.exists(OBJDUMP):
+        print(f"check_s2_isa: no llvm-objdump found ({OBJDUMP}): the _s2 kernels of {lib} were NOT checked", file=sys.stderr)
+        return EXIT_CANNOT_RUN
+    try:
+        dis = disassemble(lib)
+    except (OSError, subprocess.CalledProcessError) as ex:
+        print(f"check_s2_isa: could not disassemble {lib}: {ex}: the _s2 kernels were NOT checked", file=sys.stderr)
+        return EXIT_CANNOT_RUN
     n_kernels, n_sets, failed = 0, 0, 0
     for name, body in kernels(dis):
         if "score_q16_kernel" not in name and "score_q16p_kernel" not in name:

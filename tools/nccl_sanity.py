@@ -1,4 +1,4 @@
-"""One-rank RCCL sanity on a single GPU: the calls bench.py / ddt.sharded make at N > 1 (init with device_id, async
+"""One-rank RCCL sanity on a single GPU: the calls bench.py / the C++ pipeline (csrc/ddt_comm.cpp) and its Python mirror tests/sharded_ref.py make at N > 1 (init with device_id, async
 all_reduce + wait, all_to_all_single, all_gather_into_tensor, barrier, MAX reduce of a float64)."""
 import os
 import sys
