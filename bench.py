@@ -347,6 +347,17 @@ def main():
                     "prepass_groups": info.prepass_groups,  # feature groups of the LDS-resident pre-pass (0: transpose + rank kernels / n.a.)
                     "alg_bytes_per_launch": alg_bytes_per_launch,
                     "device": {"cus": info.num_cus, "clock_mhz": round(clock_hz / 1e6, 1), "lds_bytes_per_cu": info.lds_bytes_per_cu}}
+        # the whole step (pre-pass + scoring kernel(s)) against the same algorithmic bytes; traffic = the step's HBM bytes from the same PMC file
+        step_traffic = None
+        if traffic is not None:
+            try:
+                step_traffic = json.load(open(pmc)).get("step_hbm_bytes_x2_corrected")
+            except Exception:
+                step_traffic = None
+        if not multi and args.shard_of <= 1:
+            step_ach = alg_bytes_per_launch / (ms_per_step * 1e-3) / 1e9
+            roofline["step"] = {"ms": round(ms_per_step, 4), "achieved": round(step_ach, 2), "frac": round(step_ach / HBM_PEAK_GBS, 5), "traffic": step_traffic,
+                                "note": "one whole step of the timed region (rank pre-pass + scoring; wall time / steps) against the same algorithmic bytes"}
         if multi:
             roofline["scope"] = (f"rank 0's shard ({int(info.tree_end - info.tree_begin)} of {T} trees, all {N} tuples): one pass with no collective, "
                                  "behind the timed region; achieved / frac are per GPU")
@@ -455,6 +466,37 @@ def main():
                               "note": "caller's buffers pinned once with ddt_host_register (time given, outside the rate): no staging copy",
                               "bit_exact_vs_resident": bool(np.array_equal(hs2.view(np.uint32), want_bits))}
 
+    # ---- the RTL-exact sums (sum_mode 2: the reference's FloPoCo adder itself, FPAdder_2cycles_latency.v:325-326) on the same batch, measured at
+    # HEAD behind the timed region: the strongest parity claim the library makes gets its own throughput figure on the line ----------------------
+    sum2 = None
+    if world == 1 and rank == 0 and not multi and classes == 1 and not sparse and args.sum_mode == 0 and args.shard_of <= 1 and not args.no_cpu_baseline:
+        try:
+            eng2 = ddt.Engine(local)
+            eng2.set_option("variant", args.variant)
+            for kv in args.opt:
+                key, _, val = kv.partition("=")
+                eng2.set_option(key, int(val))
+            eng2.load_model(ddt.make_params(T, D, F, sum_mode=2), w, f)
+            out2 = torch.empty(N, dtype=torch.float32, device=tuples.device)
+            eng2.score_device(tuples, out=out2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                eng2.score_device(tuples, out=out2)
+            torch.cuda.synchronize()
+            s2_ms = (time.perf_counter() - t1) / 3 * 1e3
+            chk = min(N, 262_144)
+            ref2 = O.score_fast(m, tuples[:chk].cpu().numpy().view(np.uint32), sum_mode=O.SUM_REF_FLOPOCO)
+            got2 = out2[:chk].cpu().numpy()
+            sum2 = {"value": round(N / s2_ms / 1e3, 3), "unit": "Mtuples/s", "ms_per_step": round(s2_ms, 4), "kernel": eng2.info().variant_name.decode(),
+                    "bit_exact_vs_reference_adder": bool(np.array_equal(got2.view(np.uint32), ref2.view(np.uint32))), "rows_checked": chk,
+                    "rows_that_differ_from_sum_mode0": int((out2[:chk] != out[:chk]).sum().item()),
+                    "note": "sum_mode 2 = reference order with the reference's own adder (bit-exact with oracle SUM_REF_FLOPOCO on the checked prefix); "
+                            "3 steps behind the timed region; never `value`"}
+            eng2.close()
+        except Exception as ex:  # diagnostics must never cost the headline line
+            sum2 = {"error": repr(ex)}
+
     if rank == 0:
         par = (f"shard {shard[0]} of a {shard[1]}-way tree-sharded job ({int(info.tree_end - info.tree_begin)} trees) on one GPU, no collective" if args.shard_of > 1 else
                "single engine") if world == 1 else (
@@ -495,6 +537,8 @@ def main():
             line["streamed"] = streamed
         if scaling_detail:
             line["scaling_detail"] = scaling_detail
+        if sum2:
+            line["other_modes"] = {"sum_mode2": sum2}
     # ---- N>1 (or --force-collectives): the OTHER ways this library can run the same multi-GPU job, measured behind the timed
     # region so that the driver's scaling run records them too (never `value`).  These collectives have run in one-rank
     # communicators and in the CPU model of tests/test_comm_mock.py only: a watchdog keeps a stuck leg from costing the line.
