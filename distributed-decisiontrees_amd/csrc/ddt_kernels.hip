@@ -1761,6 +1761,10 @@ static const Variant g_variants[] = {
     DDT_QO("q16_d6_c16_u4_s2", 6, 16, 4, 2),
     DDT_QO("q16_d7_c8_u4_s2", 7, 8, 4, 2),
     DDT_QO("q16_d5_c32_u4_s2", 5, 32, 4, 2),
+    // ... and with the pinned read order (round 4): the host sees the same image (opt 2), the kernel is instantiated with bit 4
+    Variant{"q16_d6_c16_u4_s2_x", kKindQ16, 6, kQTile, 1, 16, 4, 1, 2, &launch_q16<6, 16, 4, 18>},
+    Variant{"q16_d7_c8_u4_s2_x", kKindQ16, 7, kQTile, 1, 8, 4, 1, 2, &launch_q16<7, 8, 4, 18>},
+    Variant{"q16_d5_c32_u4_s2_x", kKindQ16, 5, kQTile, 1, 32, 4, 1, 2, &launch_q16<5, 32, 4, 18>},
     DDT_Q("q16_d6_c16_u4", 6, 16, 4),
     DDT_Q("q16_d4_c64_u8", 4, 64, 8),
     // odd depths (XGBoost / scikit-learn defaults 3, 5, 7): same 8 KiB chunks

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--shard-of", type=int, default=8)
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--masked", default="0,8,16,32,64")
+    ap.add_argument("--one-xcd", action="store_true", help="take all masked CUs from XCD 0 (at most 24) instead of k / 8 from every XCD")
     args = ap.parse_args()
     import torch
 
@@ -42,14 +43,17 @@ def main():
     eng.set_option("reserve_rows", args.rows)
     eng.score_device(tuples, out=out)
     torch.cuda.synchronize()
-    res = {"trees_on_this_shard": int(info.tree_end - info.tree_begin), "rows": args.rows, "kernel": info.variant_name.decode(), "cus": cus, "runs": []}
+    res = {"trees_on_this_shard": int(info.tree_end - info.tree_begin), "rows": args.rows, "kernel": info.variant_name.decode(), "cus": cus,
+           "masked_from": "XCD 0 only" if args.one_xcd else "every XCD alike", "runs": []}
     for k in [int(v) for v in args.masked.split(",")]:
         words = (cus + 31) // 32
         mask = [0xFFFFFFFF] * words
         if k:
-            step = cus / k
-            for i in range(k):                       # every (cus / k)-th CU off: spread over the XCDs like a collective's workgroups
-                cu = int(i * step)
+            # CU index = XCD + 8 * (CU inside the XCD) (measured round 4: every 32nd CU off = 8 CUs of ONE XCD, 1.31x slower; a mask
+            # that empties an XCD is ignored).  even: k / 8 CUs off in every XCD, like a collective's workgroups, which the dispatcher
+            # deals round-robin over the XCDs; uneven (--one-xcd): all k in XCD 0
+            for i in range(k):
+                cu = (i % 8) + 8 * (i // 8) if not args.one_xcd else 8 * i
                 mask[cu // 32] &= ~(1 << (cu % 32))
         arr = (C.c_uint32 * words)(*mask)
         s = C.c_void_p()
