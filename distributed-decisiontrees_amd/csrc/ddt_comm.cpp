@@ -254,6 +254,7 @@ static int comm_create(ddt_comm** out, ddt_engine* e, int rank, int n_ranks, int
     if (c->world) (void)ncclCommDestroy(c->world);
     return rc;
   }
+  if (n_ranks > 1) engine_enter_collective_job(e);  // collectives will share the device's CUs with the scoring kernels
   *out = c.release();
   return DDT_OK;
 }
@@ -782,7 +783,10 @@ static int group_create(ddt_group** out, int n_devices, const int* device_ids, i
   g->d_scores.assign((size_t)n_devices, nullptr);
   g->d_labels.assign((size_t)n_devices, nullptr);
   int rc = DDT_OK;
-  for (int i = 0; i < n_devices && !rc; ++i) rc = ddt_create(&g->eng[(size_t)i], g->devices[(size_t)i]);
+  for (int i = 0; i < n_devices && !rc; ++i) {
+    rc = ddt_create(&g->eng[(size_t)i], g->devices[(size_t)i]);
+    if (!rc && n_devices > 1) engine_enter_collective_job(g->eng[(size_t)i]);
+  }
   std::vector<ncclComm_t> comms((size_t)n_devices, nullptr), subs((size_t)n_devices, nullptr);
   if (!rc && ncclCommInitAll(comms.data(), n_devices, g->devices.data()) != ncclSuccess) rc = DDT_EHIP;
   // hybrid: one more communicator per row group of tree_ranks consecutive devices (one process: ncclCommInitAll over the group's devices)

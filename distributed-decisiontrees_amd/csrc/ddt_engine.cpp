@@ -474,7 +474,10 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
     // depth <= 8: two blocks per CU or it is not worth it; deeper trees have no other specialised kernel: one block
     if (W > 32u || v.lds_bytes_q16(W) > (v.levels <= 8 ? kMaxLdsBytes / 2u : kMaxLdsBytes)) return false;
     if ((v.opt & 4) && e->p.sum_mode == 1u) return false;  // cluster-major image order: not the stream order the fp64 sum is defined on
-    return rank_tables(e).max_len <= kQ16MaxTable;
+    if (rank_tables(e).max_len <= kQ16MaxTable) return true;
+    // more distinct thresholds on a feature than u16 ranks hold: the plain cluster-major kernels score the ensemble in PARTS with
+    // rank tables of their own (Q16Aux::state_in / state_out); one chunk of 8 trees never exceeds the limit
+    return (v.opt & 4) && !(v.opt & 8) && e->num_classes == 1;
   }
   if (v.kind == kKindStream)
     return W <= 4u * (uint32_t)v.opt && v.lds_bytes_stream(padded_trees(v, max_trees(e)), W) <= kStreamLdsBudget;
@@ -514,13 +517,16 @@ int auto_variant(const ddt_engine* e) {
     // depth 8, reference-order sums (the fp64 sum of sum_mode 1 runs in stream order, which the cluster-major images would change):
     //   "_p"  persistent blocks -- a one-vs-all model whose classes hold equally many trees is walked in ONE launch, sums and labels
     //         written by the scoring kernel (10.57 vs 10.89 ms per 10 M tuples x 10 x 100 trees, and 11.37 before round 4).  For a plain
-    //         ensemble the resident blocks buy nothing (12.92 vs 13.05 ms on a 125-tree shard, 94.8 vs 95.3 ms at 1000 trees:
-    //         profiles/r04_q16_pinned_persistent.md), so only option "q16_persistent" = 1 picks it there;
+    //         ensemble on a GPU of its own the resident blocks buy nothing (12.92 vs 13.05 ms on a 125-tree shard, 94.8 vs 95.3 ms at
+    //         1000 trees: profiles/r04_q16_pinned_persistent.md) -- but they take tiles from a ticket counter, so they do not wait for
+    //         CUs that something else occupies: with 8 / 16 CUs of ONE XCD masked a shard's step takes 1.09x / 1.25x against 1.34x /
+    //         1.97x for the plain launch, whose blocks the dispatcher deals round-robin over the XCDs (profiles/r04_cu_mask_probe.md).
+    //         An engine inside a multi-rank job (RCCL's kernels on the same device) therefore takes it too;
     //   "_x"  the plain launch with the pinned LDS read order (four chains in flight per lane): +4.6 % over "_cm" at 1000 trees,
     //         +4 % on the shards; its single accumulator + running total also serves one cluster.
     if (e->p.sum_mode != 1u && !s2_disabled()) {
       const int ip = find_variant("q16_d8_c8_u4_gl_s2_cm_p");
-      if (ip >= 0 && variant_fits(variant(ip), e) && e->q16_persistent != 0 && (e->q16_persistent == 1 || classes_equal(e))) return ip;
+      if (ip >= 0 && variant_fits(variant(ip), e) && e->q16_persistent != 0 && (e->q16_persistent == 1 || classes_equal(e) || e->collective_job)) return ip;
       const int ix = find_variant("q16_d8_c8_u4_gl_s2_cm_x");
       if (ix >= 0 && variant_fits(variant(ix), e)) return ix;
     }
@@ -528,7 +534,7 @@ int auto_variant(const ddt_engine* e) {
       const int i = find_variant("q16_d8_c8_u4_gl_s2_cm");
       if (i >= 0 && variant_fits(variant(i), e)) return i;
     }
-    static const char* qpref[] = {"q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4", "q16_d6_c16_u4_s2_x", "q16_d6_c16_u4_s2", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4_s2_x", "q16_d7_c8_u4_s2", "q16_d7_c8_u4", "q16_d5_c32_u4_s2_x", "q16_d5_c32_u4_s2", "q16_d5_c32_u4", "q16_d3_c128_u8",
+    static const char* qpref[] = {"q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4", "q16_d6_c16_u4_s2", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4_s2", "q16_d7_c8_u4", "q16_d5_c32_u4_s2", "q16_d5_c32_u4", "q16_d3_c128_u8",
                                   "q16_d9_c4_u4", "q16_d10_c4_u4"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
@@ -553,13 +559,15 @@ void free_images(ddt_engine* e) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
+    for (Q16Part& part : m.parts) free_rank_device(part.rank);
+    m.parts.clear();
     m.img_bytes = 0;
   }
 }
 
 void free_q16_workspace(ddt_engine* e) {
   for (int k = 0; k < kQSlots; ++k) {
-    for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k]}) {
+    for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k], &e->q_state[k]}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
@@ -732,7 +740,62 @@ struct Q16HostImage {
   std::vector<uint16_t> tabS;
   PrepassPlan pplan{};
   uint32_t Tpad = 0, Kpad = 0;
+  // ensembles scored in parts (more than kQ16MaxTable distinct thresholds on a feature): chunk ranges of the image and their tables
+  std::vector<uint32_t> part_chunk_begin;  // [parts + 1]; empty = one part, tables above
+  std::vector<RankTables> part_tables;
 };
+
+// position of tree i in a cluster-major ("_cm") image: the PU groups of cluster 0 (g % C == 0) first, in their order, then cluster 1's, ...
+uint32_t cm_position(uint32_t i, uint32_t T, uint32_t Cc) {
+  const uint32_t groups_real = (T + 7u) / 8u, g = i / 8u, c = g % Cc;
+  uint32_t start = 0;  // groups of the clusters before c
+  for (uint32_t k = 0; k < c; ++k) start += (groups_real + Cc - 1u - k) / Cc;
+  return (start + g / Cc) * 8u + i % 8u;
+}
+
+// Cut a cluster-major image into parts whose distinct thresholds per feature fit the u16 ranks: chunks are taken in image order while
+// every feature's key set stays within kQ16MaxTable (greedy; a chunk of 8 trees alone never exceeds it).
+int plan_q16_parts(ddt_engine* e, const Variant& v, const Ensemble& m, Q16HostImage& h) {
+  const uint32_t T = m.trees(), nint = e->nint, W = tuple_words(e->p), CT = (uint32_t)v.chunk_trees;
+  const uint32_t Cc = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, Tpad = padded_trees(v, T), n_chunks = Tpad / CT;
+  std::vector<std::vector<uint32_t>> trees_of_chunk(n_chunks);
+  for (uint32_t i = 0; i < T; ++i) trees_of_chunk[cm_position(i, T, Cc) / CT].push_back(i);
+  try {
+    h.part_chunk_begin.assign(1, 0u);
+    h.part_tables.clear();
+    RankTables cur;
+    cur.keys.assign(W, {});
+    auto merged_fits = [&](const std::vector<std::vector<uint32_t>>& add, RankTables* out) {
+      RankTables t = cur;
+      for (uint32_t j = 0; j < W; ++j) t.keys[j].insert(t.keys[j].end(), add[j].begin(), add[j].end());
+      finish_rank_tables(t);
+      if (t.max_len > kQ16MaxTable) return false;
+      *out = std::move(t);
+      return true;
+    };
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      std::vector<std::vector<uint32_t>> add(W);
+      for (uint32_t i : trees_of_chunk[c])
+        for (uint32_t n = 0; n < nint; ++n) add[m.fidx[(size_t)i * nint + n]].push_back(thr_key(e->p, m.thr[(size_t)i * nint + n]));
+      RankTables next;
+      if (merged_fits(add, &next)) {
+        cur = std::move(next);
+        continue;
+      }
+      h.part_tables.push_back(cur);  // close the part in front of chunk c
+      h.part_chunk_begin.push_back(c);
+      cur = RankTables{};
+      cur.keys.assign(W, {});
+      if (!merged_fits(add, &next)) return fail(e, DDT_EUNSUPPORTED, "one chunk of %u trees has more than %u distinct thresholds on a feature", CT, kQ16MaxTable);
+      cur = std::move(next);
+    }
+    h.part_tables.push_back(cur);
+    h.part_chunk_begin.push_back(n_chunks);
+  } catch (const std::bad_alloc&) {
+    return fail(e, DDT_ENOMEM, "rank table allocation failed");
+  }
+  return DDT_OK;
+}
 
 // host half of build_image_q16 (no HIP call; also behind the test hook ddt_debug_model_image)
 int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const RankTables& rt, bool upload_tables, Q16HostImage& h) {
@@ -744,7 +807,11 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
   } catch (const std::bad_alloc&) {
     return fail(e, DDT_ENOMEM, "q16 image allocation failed");
   }
-  {
+  const bool in_parts = rt.max_len > kQ16MaxTable;  // (variant_fits has checked that this kernel can score in parts)
+  if (in_parts) {
+    const int rc = plan_q16_parts(e, v, m, h);
+    if (rc) return rc;
+  } else {
     RankHostTables rk;
     const int rc = pack_rank_tables(e, rt, W, upload_tables, rk);
     if (rc) return rc;
@@ -765,19 +832,22 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
   // "_cm" variants (opt bit 2): cluster-major image order -- the PU groups of cluster 0 (g % C == 0) first, in their order, then
   // cluster 1's, ...; padding groups stay behind the last real one.  Tree i sits at image position cm_pos(i).
   const bool cm = (v.opt & 4) != 0;
-  const uint32_t Cc = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, groups_real = (T + 7u) / 8u;
-  auto cm_pos = [&](uint32_t i) -> uint32_t {
-    if (!cm) return i;
-    const uint32_t g = i / 8u, c = g % Cc;
-    uint32_t start = 0;  // groups of the clusters before c
-    for (uint32_t k = 0; k < c; ++k) start += (groups_real + Cc - 1u - k) / Cc;
-    return (start + g / Cc) * 8u + i % 8u;
+  const uint32_t Cc = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u;
+  auto cm_pos = [&](uint32_t i) -> uint32_t { return cm ? cm_position(i, T, Cc) : i; };
+  // the tables a tree's thresholds are ranked against: the ensemble's, or those of the part its chunk belongs to
+  auto tables_of = [&](uint32_t pos) -> const RankTables& {
+    if (!in_parts) return rt;
+    const uint32_t c = pos / CT;
+    size_t part = 0;
+    while (h.part_chunk_begin[part + 1] <= c) ++part;
+    return h.part_tables[part];
   };
   for (uint32_t i = 0; i < T; ++i) {
     uint32_t* t = fast.data() + rec_off(cm_pos(i));
+    const RankTables& trt = tables_of(cm_pos(i));
     for (uint32_t n = 0; n < nint; ++n) {
       const uint32_t j = m.fidx[(size_t)i * nint + n], key = thr_key(e->p, m.thr[(size_t)i * nint + n]);
-      const auto& k = rt.keys[j];
+      const auto& k = trt.keys[j];
       const uint32_t idx = (uint32_t)(std::lower_bound(k.begin(), k.end(), key, [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; }) - k.begin());
       t[n + 1] = (idx + 1u) | ((j * row) << 16);
     }
@@ -804,9 +874,31 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
+  for (Q16Part& part : m.parts) free_rank_device(part.rank);
+  m.parts.clear();
   const size_t bytes = fast.size() * 4;
   HIP_TRY(e, hipMalloc(&m.d_img, bytes));
   HIP_TRY(e, hipMalloc(&m.d_img_slow, bytes));
+  if (!h.part_tables.empty()) {  // scored in parts: every part brings its own tables (+ LDS images of its pre-pass)
+    HIP_TRY(e, hipMemcpy(m.d_img, fast.data(), bytes, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(m.d_img_slow, slow.data(), bytes, hipMemcpyHostToDevice));
+    m.parts.resize(h.part_tables.size());
+    for (size_t k = 0; k < m.parts.size(); ++k) {
+      RankHostTables rk;
+      int rc2 = pack_rank_tables(e, h.part_tables[k], tuple_words(e->p), true, rk);
+      if (!rc2) rc2 = upload_rank_tables(e, rk, m.parts[k].rank);
+      if (rc2) return rc2;
+      m.parts[k].chunk_begin = h.part_chunk_begin[k];
+      m.parts[k].chunks = h.part_chunk_begin[k + 1] - h.part_chunk_begin[k];
+    }
+    m.prepass = PrepassPlan{};
+    m.img_bytes = bytes;
+    m.img_trees = Tpad;
+    m.img_chunks = Tpad / (uint32_t)v.chunk_trees;
+    m.Kpad = 0;
+    if (getenv("DDT_DEBUG_PREPASS")) fprintf(stderr, "[ddt] the ensemble is scored in %zu parts (rank tables of their own)\n", m.parts.size());
+    return DDT_OK;
+  }
   if (upload_tables) {
     HIP_TRY(e, hipMalloc(&m.d_tables, tab.size() * 4));
     HIP_TRY(e, hipMalloc(&m.d_tabK, tabK.size() * 4));
@@ -837,10 +929,15 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint64_t rows = (n + 1023) / 1024 * 1024;
   const int k = e->q_slot;
   // the transposed fp32 intermediate is only needed by the two-kernel pre-pass
-  const bool need_xT = e->sparse ? e->sp_rank.prepass.groups == 0 : (e->ens.empty() || e->ens[0].prepass.groups == 0);
-  if (rows <= e->q_rows[k] && (!need_xT || e->q_xT[k])) return DDT_OK;
+  bool need_xT = e->sparse ? e->sp_rank.prepass.groups == 0 : (e->ens.empty() || e->ens[0].prepass.groups == 0);
+  const bool in_parts = !e->sparse && !e->ens.empty() && e->ens[0].parts.size() > 1;  // the sum's state between the parts' launches
+  if (in_parts) {
+    need_xT = false;
+    for (const Q16Part& part : e->ens[0].parts) need_xT = need_xT || part.rank.prepass.groups == 0;
+  }
+  if (rows <= e->q_rows[k] && (!need_xT || e->q_xT[k]) && (!in_parts || e->q_state[k])) return DDT_OK;
   HIP_TRY(e, hipDeviceSynchronize());
-  for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k]}) {
+  for (void** p : {&e->q_xT[k], &e->q_q[k], &e->q_flags[k], &e->q_state[k]}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -849,6 +946,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint32_t W = tuple_words(e->p);
   if (need_xT) HIP_TRY(e, hipMalloc(&e->q_xT[k], cap * W * 4));
   HIP_TRY(e, hipMalloc(&e->q_q[k], cap * W * 2));
+  if (in_parts) HIP_TRY(e, hipMalloc(&e->q_state[k], cap * 2 * sizeof(float)));
   HIP_TRY(e, hipMalloc(&e->q_flags[k], (cap / 1024 + 2 + 2 * kQ16GroupedCounters + kQ16TileCounterWords) * 4));  // + the 8-byte work counters of the fused / grouped pre-pass + the _p kernels' tile counter
   e->q_rows[k] = cap;
   return DDT_OK;
@@ -1037,7 +1135,37 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     a.ev_mid = e->ev_fork;  // multi-class calls: recorded between the shared pre-pass and class 0's scoring kernel
   }
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
-  hipError_t r = v.launch(a, v, s);
+  hipError_t r = hipSuccess;
+  if (v.kind == kKindQ16 && m.parts.size() > 1) {
+    // the ensemble in parts: per part its rank pre-pass (the same workspace, stream order) and a scoring launch over its chunks of the
+    // image; the reference-order sum is handed from launch to launch through the state workspace (Q16Aux)
+    const size_t chunk_bytes = (size_t)v.tree_bytes_q16() * (size_t)v.chunk_trees;
+    float* state = reinterpret_cast<float*>(e->q_state[e->q_slot]);
+    uint32_t groups_before = 0;
+    for (size_t k = 0; k < m.parts.size() && r == hipSuccess; ++k) {
+      const Q16Part& part = m.parts[k];
+      a.img = reinterpret_cast<const uint4*>(static_cast<const char*>(m.d_img) + part.chunk_begin * chunk_bytes);
+      qa.img_slow = reinterpret_cast<const uint4*>(static_cast<const char*>(m.d_img_slow) + part.chunk_begin * chunk_bytes);
+      a.n_chunks = part.chunks;
+      a.n_trees = part.chunks * (uint32_t)v.chunk_trees;
+      qa.tables = reinterpret_cast<const uint32_t*>(part.rank.d_tables);
+      qa.tabP = reinterpret_cast<const uint32_t*>(part.rank.d_tabK);
+      qa.tabS = reinterpret_cast<const uint16_t*>(part.rank.d_tabS);
+      qa.Kpad = part.rank.Kpad;
+      qa.prepass_img = reinterpret_cast<const uint4*>(part.rank.d_prepass);
+      qa.prepass = part.rank.prepass;
+      qa.group0 = groups_before;
+      qa.state_in = k > 0 ? state : nullptr;
+      qa.state_out = k + 1 < m.parts.size() ? state : nullptr;
+      if (k > 0) a.ev_mid = nullptr;  // (kernel_timing: the first part's pre-pass against everything behind it)
+      r = v.launch(a, v, s);
+      groups_before += a.n_trees / 8u;
+      e->st.kernel_launches++;
+    }
+    if (r == hipSuccess) e->st.kernel_launches--;  // (counted once more below)
+  } else {
+    r = v.launch(a, v, s);
+  }
   if (r != hipSuccess) {
     e->tev_cur = nullptr;
     return fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
@@ -1142,6 +1270,20 @@ int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float*
     return DDT_OK;
   }
   return launch_classify(e, d_tuples, n, d_class_scores, d_labels, s);
+}
+
+void engine_enter_collective_job(ddt_engine* e) {
+  if (!e || e->collective_job) return;
+  e->collective_job = true;
+  if (!e->loaded || e->sparse || e->forced_variant >= 0 || e->q16_persistent == 0) return;
+  // the model that is already loaded: the persistent kernel reads the very image the plain cluster-major kernels read (same chunk
+  // size, same order), so the choice can change without re-packing -- unless the ensemble is scored in parts (plain launch only)
+  const Variant& cur = variant(e->variant_id);
+  const int ip = find_variant("q16_d8_c8_u4_gl_s2_cm_p");
+  if (ip < 0 || cur.kind != kKindQ16 || !(cur.opt & 4) || (cur.opt & 8) || e->num_classes != 1 || cur.levels != variant(ip).levels ||
+      cur.chunk_trees != variant(ip).chunk_trees || e->ens.empty() || e->ens[0].parts.size() > 1)
+    return;
+  e->variant_id = ip;
 }
 
 void count_job(ddt_engine* e, size_t n) {
@@ -1773,6 +1915,7 @@ int ddt_debug_model_image(const ddt_params* p, const void* wl, size_t n_wlines, 
   if (v.kind == kKindQ16) {
     rc = pack_image_q16(e.get(), v, e->ens[0], rank_tables(e.get()), true, h);
     Tpad = h.Tpad;
+    if (!rc && !h.part_tables.empty()) return DDT_EUNSUPPORTED;  // an ensemble scored in parts has one table set per part: not exposed through this hook
   } else {
     rc = pack_image(e.get(), v, e->ens[0], img, &Tpad);
   }

@@ -24,28 +24,6 @@ inline double now_ms() {
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
-// One ensemble as parsed from the reference wire format: the trees this engine holds of one class
-// (single-output models have exactly one ensemble), plus its device image for the active variant.
-struct Ensemble {
-  std::vector<uint32_t> ids;    // global tree ids in stream order
-  std::vector<uint32_t> thr;    // [T][nint]   raw fp32 bit patterns (heap order, 0-based)
-  std::vector<uint16_t> fidx;   // [T][nint]
-  std::vector<uint8_t> mright;  // [T][nint]
-  std::vector<uint32_t> leaf;   // [T][nleaf]
-  void* d_img = nullptr;
-  size_t img_bytes = 0;
-  uint32_t img_trees = 0, img_chunks = 0;
-  // rank-quantised path only: image with miss_right flags, per-feature threshold tables
-  void* d_img_slow = nullptr;
-  void* d_tables = nullptr;
-  void* d_tabK = nullptr;   // q16: per-feature search parameters (Q16Aux::tabP)
-  void* d_tabS = nullptr;   // q16: bucket starts (Q16Aux::tabS)
-  void* d_prepass = nullptr;  // q16: LDS images of the LDS-resident rank pre-pass (Q16Aux::prepass_img), one per feature group
-  PrepassPlan prepass;        // geometry of those images; groups == 0: transpose + rank kernels
-  uint32_t Kpad = 0;
-  uint32_t trees() const { return (uint32_t)ids.size(); }
-};
-
 // sorted distinct threshold keys per feature of one ensemble (q16 path)
 struct RankTables {
   std::vector<std::vector<uint32_t>> keys;  // [W], ascending as signed int32
@@ -67,6 +45,36 @@ struct RankDevice {
   void* d_prepass = nullptr;
   PrepassPlan prepass;
   uint32_t Kpad = 0;
+};
+
+// One part of a rank-quantised ensemble that is scored in parts (more than 32767 distinct thresholds on a feature: Q16Aux): chunks
+// [chunk_begin, chunk_begin + chunks) of the cluster-major image, ranked against tables of their own
+struct Q16Part {
+  uint32_t chunk_begin = 0, chunks = 0;
+  RankDevice rank;
+};
+
+// One ensemble as parsed from the reference wire format: the trees this engine holds of one class
+// (single-output models have exactly one ensemble), plus its device image for the active variant.
+struct Ensemble {
+  std::vector<uint32_t> ids;    // global tree ids in stream order
+  std::vector<uint32_t> thr;    // [T][nint]   raw fp32 bit patterns (heap order, 0-based)
+  std::vector<uint16_t> fidx;   // [T][nint]
+  std::vector<uint8_t> mright;  // [T][nint]
+  std::vector<uint32_t> leaf;   // [T][nleaf]
+  void* d_img = nullptr;
+  size_t img_bytes = 0;
+  uint32_t img_trees = 0, img_chunks = 0;
+  // rank-quantised path only: image with miss_right flags, per-feature threshold tables
+  void* d_img_slow = nullptr;
+  void* d_tables = nullptr;
+  void* d_tabK = nullptr;   // q16: per-feature search parameters (Q16Aux::tabP)
+  void* d_tabS = nullptr;   // q16: bucket starts (Q16Aux::tabS)
+  void* d_prepass = nullptr;  // q16: LDS images of the LDS-resident rank pre-pass (Q16Aux::prepass_img), one per feature group
+  PrepassPlan prepass;        // geometry of those images; groups == 0: transpose + rank kernels
+  uint32_t Kpad = 0;
+  std::vector<Q16Part> parts;  // >= 2: the ensemble is scored in parts (their tables live here, d_tables .. d_prepass above stay empty)
+  uint32_t trees() const { return (uint32_t)ids.size(); }
 };
 
 // A sparse (explicit-children) forest as loaded: this engine's shard, node lines re-based per tree (include/ddt.h
@@ -121,6 +129,7 @@ struct ddt_engine {
   void* q_xT[ddt::kQSlots] = {};
   void* q_q[ddt::kQSlots] = {};
   void* q_flags[ddt::kQSlots] = {};
+  void* q_state[ddt::kQSlots] = {};    // ensembles scored in parts: [2][rows] fp32 accumulator + running total between the parts' launches
   uint64_t q_rows[ddt::kQSlots] = {};  // capacity in rows (multiple of 1024)
   int q_slot = 0;
   int q16_grouped_prepass = 1;  // option "q16_grouped_prepass": 0 = never split the pre-pass over feature groups
@@ -128,6 +137,7 @@ struct ddt_engine {
   int q16_fused_prepass = 1;  // option "q16_fused_prepass": 0 forces the transpose + rank kernels (A/B, tests)
   int q16_prepass_nt = 0;     // option "q16_prepass_nt": bit 0 = nontemporal stores of the rank tiles, bit 1 = nontemporal tuple loads (A/B)
   int q16_persistent = -1;    // option "q16_persistent": 1 / 0 = prefer / never pick the persistent "_p" kernel, -1 = automatic
+  bool collective_job = false;  // set by ddt_comm_create* / ddt_group_create* with more than one rank: collectives share the CUs with the scoring
   // "_p" kernels, multi-class models whose classes hold equally many trees: the classes' images back to back (fast / slow), so that
   // ONE launch walks every class (Q16Aux::n_segs); mc_seg_chunks = chunks per class, 0 = not built (one launch per class)
   void* d_mc_img = nullptr;
@@ -206,6 +216,10 @@ bool leaf_outside_exact_domain(uint32_t bits);
 int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s);
 int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_class_scores, int32_t* d_labels, hipStream_t s);
 int ensure_q16_workspace(ddt_engine* e, size_t n);
+// a multi-rank job was set up on this engine: from now on (and for the model that may already be loaded) the automatic kernel choice
+// prefers the persistent rank-quantised kernel, whose blocks take tiles from a ticket counter and therefore do not wait for the
+// CUs a collective's kernels occupy (profiles/r04_cu_mask_probe.md)
+void engine_enter_collective_job(ddt_engine* e);
 // kernel_timing: open / close the event triple of one launch on stream s (timing_begin records the start event)
 int timing_begin(ddt_engine* e, hipStream_t s);
 int timing_end(ddt_engine* e, hipStream_t s);

@@ -84,6 +84,13 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   int32_t* labels = nullptr;  // n_segs > 1: argmax over the segments (may be NULL); `ScoreArgs::out` (may be NULL then) = [n_segs][n] sums
   uint32_t* tile_counter = nullptr;  // work counter of the persistent blocks (zeroed per launch; engine workspace behind the pre-pass counters)
   uint32_t prepass_nt = 0;    // A/B (option "q16_prepass_nt"): bit 0 = the pre-pass writes the rank tiles with nontemporal stores, bit 1 = reads the tuples with nontemporal loads
+  // Ensembles with more than 32767 distinct thresholds on a feature (u16 ranks stop there; DTPU.sv:22,74 allows 8192 nodes x 64 PUs on one
+  // feature) are scored in PARTS ("_cm" kernels only): consecutive chunks of the cluster-major image with rank tables of their own, one
+  // pre-pass + scoring launch per part.  The reference-order sum runs THROUGH the parts: a launch starts from the accumulator and the
+  // running total its predecessor left per tuple (state_in) after group0 PU groups, and leaves them (state_out) instead of the score.
+  const float* state_in = nullptr;   // [2][n_pad]: accumulator of the cluster in progress, running total over the finished clusters
+  float* state_out = nullptr;
+  uint32_t group0 = 0;               // PU groups (cluster-major order) in front of this launch's image
 };
 constexpr uint32_t kQ16TileCounterWords = 2;  // behind the kQ16GroupedCounters 8-byte counters
 

@@ -1081,6 +1081,20 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   const uint32_t cm_lg = (uint32_t)__builtin_ctz(Cc | 0x100u), cm_real = x.real_groups;
   uint32_t cm_groups = 0, cm_cluster = 0, cm_bound = (cm_real + Cc - 1u) >> cm_lg;  // wave-uniform: groups done, cluster, its end
   float cm_total = 0.f;
+  if constexpr (CM) {  // a later part of an ensemble scored in parts (Q16Aux): take up the sum where the launch before left it
+    if (x.group0) {
+      cm_groups = x.group0;
+      while (cm_cluster < Cc && cm_groups >= cm_bound) {  // (a cluster that ended exactly there was closed by that launch)
+        ++cm_cluster;
+        cm_bound += cm_cluster < Cc ? (cm_real + Cc - 1u - cm_cluster) >> cm_lg : 0u;
+      }
+    }
+    if (x.state_in) {
+      const uint64_t r0 = tile0 + (uint64_t)tid;  // (rows of the padding read the workspace's own padding: never stored)
+      ra.a[0][0] = x.state_in[r0];
+      cm_total = x.state_in[x.n_pad + r0];
+    }
+  }
   const int SUM1 = (int)a.sum_mode;  // 0 reference order / IEEE adds, 1 fp64, 2 reference order / reference adder
   const bool exact = SUM1 == 2;
 
@@ -1171,6 +1185,13 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
 #undef DDT_QCOMPUTE
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
+  if constexpr (CM) {
+    if (x.state_out) {  // not the ensemble's last part: the sum's state instead of the score
+      x.state_out[row] = ra.a[0][0];
+      x.state_out[x.n_pad + row] = cm_total;
+      return;
+    }
+  }
   if (row < a.n) a.out[row] = (SUM1 == 1) ? (float)dacc[0] : CM ? cm_total : ra.total(0, C, exact);
 }
 
@@ -1761,10 +1782,8 @@ static const Variant g_variants[] = {
     DDT_QO("q16_d6_c16_u4_s2", 6, 16, 4, 2),
     DDT_QO("q16_d7_c8_u4_s2", 7, 8, 4, 2),
     DDT_QO("q16_d5_c32_u4_s2", 5, 32, 4, 2),
-    // ... and with the pinned read order (round 4): the host sees the same image (opt 2), the kernel is instantiated with bit 4
-    Variant{"q16_d6_c16_u4_s2_x", kKindQ16, 6, kQTile, 1, 16, 4, 1, 2, &launch_q16<6, 16, 4, 18>},
-    Variant{"q16_d7_c8_u4_s2_x", kKindQ16, 7, kQTile, 1, 8, 4, 1, 2, &launch_q16<7, 8, 4, 18>},
-    Variant{"q16_d5_c32_u4_s2_x", kKindQ16, 5, kQTile, 1, 32, 4, 1, 2, &launch_q16<5, 32, 4, 18>},
+    // (the pinned read order of the depth-8 "_x" kernel does not pay at depth 6: 0.896 vs 0.876 ms per 10 M tuples x 100 trees,
+    // gpurun_out r04_s6 -- with the leaves in LDS and six levels hipcc's own order is the better one; not instantiated)
     DDT_Q("q16_d6_c16_u4", 6, 16, 4),
     DDT_Q("q16_d4_c64_u8", 4, 64, 8),
     // odd depths (XGBoost / scikit-learn defaults 3, 5, 7): same 8 KiB chunks

@@ -87,6 +87,9 @@ float mock_partial(uint32_t shard, uint32_t cls, uint32_t row) { return partial(
 namespace ddt {
 
 uint32_t tuple_words(const ddt_params& p) { return (p.num_features + 3u) / 4u * 4u; }
+void engine_enter_collective_job(ddt_engine* e) {
+  if (e) e->collective_job = true;
+}
 
 int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s) {
   MockModel m;

@@ -156,6 +156,36 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
         }
         img_order[t] = f_of(img[leaf_off + m - half]);
       }
+      if (cm && (x.state_in || x.state_out || x.group0)) {
+        // one PART of an ensemble scored in parts: the kernel's own accumulate over the groups of this image in cluster-major order,
+        // starting from / leaving the sum's state (csrc/ddt_kernels.hip score_q16_kernel, "_cm")
+        auto add = [&](float p, float q) -> float {
+          volatile float r = a.sum_mode == 2 ? ref_add_exact(p, q) : p + q;
+          return r;
+        };
+        const uint32_t Cc = a.clusters, real = x.real_groups;
+        auto size_of = [&](uint32_t c) { return c < Cc ? (real + Cc - 1u - c) / Cc : 0u; };
+        uint32_t groups = x.group0, cluster = 0, bound = size_of(0);
+        while (cluster < Cc && groups >= bound) bound += size_of(++cluster);
+        float acc = x.state_in ? x.state_in[i] : 0.0f, total = x.state_in ? x.state_in[x.n_pad + i] : 0.0f;
+        for (uint32_t g = 0; g < a.n_trees / 8u; ++g) {
+          const float* l = img_order.data() + g * 8u;
+          const float sg = add(add(add(l[0], l[1]), add(l[2], l[3])), add(add(l[4], l[5]), add(l[6], l[7])));
+          acc = add(sg, acc);
+          if (++groups == bound) {
+            total = add(acc, total);
+            acc = 0.0f;
+            bound += size_of(++cluster);
+          }
+        }
+        if (x.state_out) {
+          x.state_out[i] = acc;
+          x.state_out[x.n_pad + i] = total;
+        } else {
+          a.out[i] = total;
+        }
+        continue;
+      }
       float best = 0.0f;
       int32_t arg = 0;
       for (uint32_t sg = 0; sg < S; ++sg) {

@@ -180,7 +180,14 @@ def test_tree_sharded_job_with_the_real_engine_equals_the_oracles_multi_device_m
                 assert mock.ddt_comm_get_unique_id(shared["id"]) == 0
             barrier.wait()
             c = vp()
+            info = ddt.Info()
+            assert mock.ddt_get_info(e, C.byref(info)) == 0
+            alone = info.variant_name.decode()
             assert mock.ddt_comm_create(C.byref(c), e, r, G, shared["id"]) == 0
+            # inside a multi-rank job the rank-quantised depth-8 choice becomes the persistent kernel (tiles from a ticket counter: its blocks
+            # do not wait for the CUs the collectives' kernels occupy) -- on the image that is already loaded, without re-packing
+            assert mock.ddt_get_info(e, C.byref(info)) == 0
+            assert info.variant_name.decode() == ("q16_d8_c8_u4_gl_s2_cm_p" if alone == "q16_d8_c8_u4_gl_s2_cm_x" else alone)
             assert mock.ddt_comm_set_option(c, b"chunk_rows", 500) == 0 and mock.ddt_comm_set_option(c, b"taper_min_rows", 32) == 0
             outs = []
             for combine in (1, 0, 1):
@@ -574,6 +581,43 @@ def test_cluster_major_image_order(mock, T, clusters):
         info = ddt.Info()
         assert mock.ddt_get_info(e, C.byref(info)) == 0
         assert info.variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_x"      # the pinned-read-order kernel: its running total also serves one cluster
+    mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("T,F,clusters,parts", [(600, 4, 1, 2), (600, 4, 8, 2), (1100, 4, 4, 3), (300, 4, 2, 1)])
+def test_more_thresholds_than_u16_ranks_hold_is_scored_in_parts(mock, T, F, clusters, parts):
+    """u16 ranks stop at 32767 distinct thresholds per feature (the reference allows 8192 nodes x 64 PUs on one feature, DTPU.sv:22,74).
+    Beyond that the cluster-major kernels score the ensemble in PARTS -- consecutive chunks of the image with rank tables of their own, a
+    pre-pass + a scoring launch per part, the reference-order sum handed from launch to launch (accumulator + running total per tuple):
+    bit-exact with the oracle for every cluster count and both adders, through resident and host calls, back to back."""
+    mock.mock_reset(2, 5, 8)
+    D, n = 8, 700
+    m, x = O.gen_model(T, D, F, 0, clusters=clusters), O.gen_tuples(0, n, F, 0)
+    x[5, 1] = 0x7FC00000                                                       # one tile with a missing value: the parts' slow images
+    e, st = _engine(mock), ddt.Stats()
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), None)
+        info = ddt.Info()
+        assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_x"
+        want = O.score(m, x, sum_mode=ref)
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0
+        before = st.kernel_launches
+        outs = [np.full(n, np.nan, np.float32) for _ in range(2)]
+        s = _stream(mock)
+        for out in outs:                                                         # back to back: the state workspace is reused in stream order
+            assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0, mock.ddt_last_error(e)
+        assert mock.hipStreamSynchronize(s) == 0
+        for out in outs:
+            assert np.array_equal(_bits(out), _bits(want)), (T, clusters, sum_mode)
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.kernel_launches - before == 2 * parts    # one scoring launch per part
+        host = np.full(n, np.nan, np.float32)
+        assert mock.ddt_set_option(e, b"feeder_rows", 256) == 0
+        assert mock.ddt_score(e, x.ctypes.data, n, host.ctypes.data) == 0 and np.array_equal(_bits(host), _bits(want))
+    # the fp64 sum (stream order) cannot run on a cluster-major image: such a model falls back to the fp32 tile kernel
+    _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=1), None)
+    info = ddt.Info()
+    assert mock.ddt_get_info(e, C.byref(info)) == 0
+    assert info.variant_name.decode().startswith("q16_") == (parts == 1)
     mock.ddt_destroy(e)
 
 

@@ -237,3 +237,29 @@ def test_grouped_and_two_kernel_prepass_agree(T, F):
             got = e.score(x)
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"groups={groups} n={n}"
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,F,clusters,n", [(600, 4, 1, 5000), (1100, 4, 8, 3000), (4000, 16, 8, 2500)])
+def test_ensembles_beyond_the_u16_rank_range_are_scored_in_parts(T, F, clusters, n):
+    """More than 32767 distinct thresholds on a feature (4000 trees x 255 nodes over 16 features: ~64 k each): the cluster-major kernel
+    scores the ensemble in parts with rank tables of their own, the reference-order sum handed from launch to launch -- bit-exact, both adders."""
+    import torch
+
+    D = 8
+    m = O.gen_model(T, D, F, dist=0, clusters=clusters)
+    x = O.gen_tuples(7, n, F, dist=0)
+    x[11, 2] = 0x7FC00000                                                    # a tile with a missing value: the parts' slow images
+    e = ddt.Engine(0)
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        e.load_model(_params(m, sum_mode), m.wlines, m.flines)
+        assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_x"
+        before = e.stats().kernel_launches
+        got = e.score_device(d)
+        torch.cuda.synchronize()
+        assert e.stats().kernel_launches - before >= 2                       # at least two parts
+        want = O.score_fast(m, x, sum_mode=ref)
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), (T, clusters, sum_mode)
+        assert np.array_equal(e.score(x).view(np.uint32), want.view(np.uint32))   # host feeder path
+    e.close()
