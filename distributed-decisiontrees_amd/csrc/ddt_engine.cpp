@@ -404,7 +404,7 @@ bool build_prepass_groups(const RankTables& rt, uint32_t W, uint32_t G, std::vec
 }
 
 // groups_wanted: 0 = the cheapest G that fits, else exactly that G.  allow_one / allow_many: engine options.
-// Cost of a candidate, ms per 100 M tuples of 32 features on one MI355X (fitted to profiles/r02_prepass_ab_grid.log): a floor set by how
+// Cost of a candidate, ms per 100 M tuples of 32 features on one MI355X (fitted to profiles/archive/r02_prepass_ab_grid.log): a floor set by how
 // the rows are read (G <= 2: whole 64-byte sectors per block; G = 4: half; G = 8: a quarter of every sector pulled
 // through the L1) + the probes (log2 P dependent LDS reads with ~3.5-way bank conflicts), which hide less behind the
 // loads the more of the time is load-bound.
@@ -443,7 +443,7 @@ uint32_t total_trees(const ddt_engine* e) {
 }
 
 constexpr uint32_t kQ16MinTreeLevels = 480;  // trees x levels from which the rank-quantised path wins with the LDS-resident pre-pass
-                                             // (profiles/r02_sweep_q16_small.json: 60 x d8 +4 %, 80 x d8 +5 %, 112 x d8 +7 %, 200 x d6 +9 %; round 3 with the _s2 walk,
+                                             // (profiles/archive/r02_sweep_q16_small.json: 60 x d8 +4 %, 80 x d8 +5 %, 112 x d8 +7 %, 200 x d6 +9 %; round 3 with the _s2 walk,
                                              // profiles/r03_sweep_fused_rank_experiment_ilp8_s2.json: 100 x d6 +17 %, 100 x d8 +11 %, while 30 x d6 still loses 15 %)
 
 // a one-vs-all model whose classes hold equally many trees on this engine: their images can stand back to back (select_and_build)
@@ -504,7 +504,7 @@ int auto_variant(const ddt_engine* e) {
                                "d5_t1024_r1_c32_u4_dma", "d5_t256_r1_c32_u4_dma", "d5_t128_r1_c32_u8_dma",
                                "d3_t256_r1_c128_u8_dma", "d3_t128_r1_c128_u8_dma"};
   // Rank-quantised path: its scoring kernel is ~1.3x faster per tree (32 waves/CU) but it pays a fixed transpose +
-  // rank pre-pass per tuple.  Measured per 100 M tuples (profiles/r01_*): q16 = 10.9 ms + 0.113 ms/tree, fp32 tile =
+  // rank pre-pass per tuple.  Measured per 100 M tuples (profiles/archive/r01_*): q16 = 10.9 ms + 0.113 ms/tree, fp32 tile =
   // 3.2 ms + 0.147 ms/tree => break-even near 200 trees per engine; 250 trees (4-way shard of 1000) goes to q16.
   // With small tables (they all fit LDS together, e.g. a 125-tree shard) the pre-pass is one fused kernel and the
   // break-even drops accordingly (kQ16MinTreeLevels).

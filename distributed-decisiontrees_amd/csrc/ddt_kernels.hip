@@ -81,7 +81,7 @@ __global__ __launch_bounds__(THREADS) void score_tile_kernel(const ScoreArgs a) 
     // Quad-coalesced loads: the four lanes of a quad read 64 contiguous bytes (lines 4g..4g+3) of ONE row per
     // instruction, rows quad_base+0..3 over four instructions, and a 4x4 transpose inside the quad (DPP) hands
     // every lane the four lines of its own row.  One-row-per-lane loads touch 64 cache lines per instruction
-    // (8192 L1 accesses per 1024x32 tile, ~7.8 us per tile exposed: profiles/r01_tile_overhead.md); this is 16.
+    // (8192 L1 accesses per 1024x32 tile, ~7.8 us per tile exposed: profiles/archive/r01_tile_overhead.md); this is 16.
     const uint32_t t4 = (uint32_t)tid & 3u;
     const uint64_t quad_row = tile0 + (uint64_t)(col & ~3u);
     const uint32_t lpt = W / 4u;
@@ -189,7 +189,7 @@ static hipError_t launch_tile(const ScoreArgs& a, const Variant& v, hipStream_t 
 // grid stride; the model chunks stream through the two LDS buffers as ONE continuous ring across tiles (the
 // chunk count is even, so chunk 0 of the next tile always lands in buffer 0), and the next tile's tuples are
 // loaded into registers while the current tile is being scored.  What the plain form pays per tile is pure
-// latency (profiles/r01_tile_overhead.md): with one block per CU all 16 waves sit in the tuple-load phase
+// latency (profiles/archive/r01_tile_overhead.md): with one block per CU all 16 waves sit in the tuple-load phase
 // together, then wait for the first model chunk.  VMEM issue order per tile and the waits that go with it:
 //   stage `pre` (already transposed) -> LDS | DMA(1) | PF x8 (next tile) | compute(0)
 //   B(k=0): vmcnt(8)  -> DMA(1) landed, the prefetch may still fly       | DMA(2) | compute(1)
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
     }                                                                                                  \
   } while (0)
 
-  // (tried twice, both slower, both removed -- numbers in profiles/r01_tile_overhead.md: levels 0-1 from SGPRs via
+  // (tried twice, both slower, both removed -- numbers in profiles/archive/r01_tile_overhead.md: levels 0-1 from SGPRs via
   // hidden s_load_dwordx4 of the next chunk's top records, and levels 0-1 tested against ranks kept in 16 VGPRs with
   // a wave-uniform register index; 15 DS ops per tree instead of 17 either way, but the extra wait points cost more
   // than the LDS cycles they save.  Round 3's _s2 form above differs in where the loads are issued and waited for.)
@@ -1795,7 +1795,7 @@ static const Variant g_variants[] = {
     DDT_Q("q16_d10_c4_u4", 10, 4, 4),
     // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB.  suffix _f = last level fused with its leaves.  Experiment variants
     // that no choice uses any more were removed in round 2 (register-staged chunks, R = 2, the unfused forms, 8-chain
-    // stream kernels; their measurements stay in profiles/r01_sweep_*.json)
+    // stream kernels; their measurements stay in profiles/archive/r01_sweep_*.json)
     DDT_VP("d8_t1024_r1_c4_u4_dma_fp", 8, 1024, 1, 4, 4, 1, 3),  // _p = persistent blocks + register prefetch
     DDT_V("d8_t1024_r1_c4_u4_dma_f", 8, 1024, 1, 4, 4, 1, 1),
     DDT_V("d8_t512_r1_c8_u8_dma_f", 8, 512, 1, 8, 8, 1, 1),

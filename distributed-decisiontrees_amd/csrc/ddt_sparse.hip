@@ -304,7 +304,7 @@ static const Variant g_sparse_variants[] = {
     // 1024 walkers = 16 waves instead of 512 = 8 -- the deep phase is latency-bound, walkers in flight are what it needs
     DDT_SPQ(6, 8), DDT_SPQ(7, 8), DDT_SPQ(8, 8), DDT_SPQ(9, 8),
     DDT_SPQD(6, 8), DDT_SPQD(7, 8), DDT_SPQD(8, 8), DDT_SPQD(9, 8), DDT_SPQD(10, 8),
-    // measured and NOT instantiated (profiles/r02_sparse_sweep_*.log): 16 trees in lock-step (u16: no gain over u8), half a
+    // measured and NOT instantiated (profiles/archive/r02_sparse_sweep_*.log): 16 trees in lock-step (u16: no gain over u8), half a
     // PU group per pass (u4: K + 1 at the same occupancy, but 4 loads in flight per lane: 159 vs 196 Mtuples/s)
     DDT_SP(6, 8, 256), DDT_SP(7, 8, 256), DDT_SP(8, 8, 256), DDT_SP(9, 8, 256), DDT_SP(10, 8, 256),
     // 512-tuple tiles: one block of 8 waves per CU shares ONE set of top images (two 256-tuple blocks hold two)

@@ -23,7 +23,7 @@ struct Cursor {  // a position while expanding the top heap: an internal node of
 
 // Kernel choice for a sparse forest.  A forced id (option "variant") wins when it is a sparse kernel that fits; option
 // "sparse_top_levels" fixes K and takes the widest tile that fits; otherwise the preference list below -- measured on
-// BASELINE config 4 (512 trees x depth 16 x 64 features, profiles/r02_sparse_sweep*.json): the deep phase is bound by the
+// BASELINE config 4 (512 trees x depth 16 x 64 features, profiles/archive/r02_sparse_sweep*.json): the deep phase is bound by the
 // vector-memory pipe's lane-address rate, and hiding its latency needs >= 8 waves per CU, so a smaller K that lets two
 // 256-tuple blocks share a CU beats a larger K with one.
 int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {

@@ -154,7 +154,7 @@ def _tables_of_model(T, D, F, shard=None):
 
 
 def test_plan_of_the_headline_model_and_its_shards():
-    """What the engine picks for BASELINE config 3 and its tree shards (profiles/r02_prepass_ab_grid.log): 1000 trees
+    """What the engine picks for BASELINE config 3 and its tree shards (profiles/archive/r02_prepass_ab_grid.log): 1000 trees
     -> 8 feature groups (one tuple line each), 500 -> 4, 250 -> 4 or 2, the 125-tree shard of an 8-GPU job -> 2 groups with P = 8."""
     expect = {None: (8, 16), (0, 2): (4, 16), (1, 4): (None, None), (3, 8): (2, 8)}
     for shard, (groups, P) in expect.items():
