@@ -1121,6 +1121,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
       qa.n_segs = e->num_classes;
       qa.seg_chunks = e->mc_seg_chunks;
       qa.labels = labels;
+      qa.seg_tail_empty = (m.trees() % 8u >= 1u && m.trees() % 8u <= 4u) ? 1u : 0u;  // the classes' last sub-group is all padding
     }
     a.aux = &qa;
   }

@@ -82,6 +82,8 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   uint32_t n_segs = 1;        // ensembles in the image
   uint32_t seg_chunks = 0;    // chunks per ensemble (0 = all of ScoreArgs::n_chunks)
   int32_t* labels = nullptr;  // n_segs > 1: argmax over the segments (may be NULL); `ScoreArgs::out` (may be NULL then) = [n_segs][n] sums
+  uint32_t seg_tail_empty = 0;  // n_segs > 1: the last four trees of every ensemble's last chunk are EMPTY padding (trees per ensemble mod 8 in
+                              // 1..4): their walk is skipped, their +0 leaves are added as always
   uint32_t* tile_counter = nullptr;  // work counter of the persistent blocks (zeroed per launch; engine workspace behind the pre-pass counters)
   uint32_t prepass_nt = 0;    // A/B (option "q16_prepass_nt"): bit 0 = the pre-pass writes the rank tiles with nontemporal stores, bit 1 = reads the tuples with nontemporal loads
   // Ensembles with more than 32767 distinct thresholds on a feature (u16 ranks stop there; DTPU.sv:22,74 allows 8192 nodes x 64 PUs on one

@@ -1364,7 +1364,10 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
       TopRecs<4>& top_nxt = (sg & 1) ? top_a : top_b;                                                  \
       top_wait(top_cur);                                                                               \
       top_issue<TREE_BYTES>(top_nxt, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
-      if constexpr (PIN) {                                                                             \
+      if (MULTI && sg == CT / U - 1 && seg_left == 1u && x.seg_tail_empty) {                          \
+        /* the ensemble's last four trees are EMPTY padding (100 trees per class in whole chunks of 8): no walk, their +0 leaves */ \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) lf[0][u] = 0.f;                                  \
+      } else if constexpr (PIN) {                                                                      \
         if (!slow_l) walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
         else walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
       } else {                                                                                         \
