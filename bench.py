@@ -220,6 +220,7 @@ def main():
         box = [ddt.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         comm = ddt.Comm(eng, rank, world, box[0], tree_ranks=args.tree_ranks if hybrid_mode else 0)
+        info = eng.info()   # (inside a multi-rank job the engine may have switched to the persistent kernel: csrc/ddt_engine.cpp engine_enter_collective_job)
         comm.set_option("chunk_rows", max(1024, args.chunk_rows // (world // args.tree_ranks)) if hybrid_mode else args.chunk_rows)
         comm.set_option("taper_tail", args.taper)
     elif multi:

@@ -38,14 +38,14 @@ def main():
         if f2 or w2:
             pre[name] = {"FETCH_SIZE": kib(f2, "FETCH_SIZE"), "WRITE_SIZE": kib(w2, "WRITE_SIZE")}
     step = 2 * fr + wr + sum(2 * v["FETCH_SIZE"] + v["WRITE_SIZE"] for v in pre.values())
-    j = {"rows": 100000000, "trees": 1000, "kernel": "score_q16_kernel<8,8,4,7> (q16_d8_c8_u4_gl_s2_cm)",
+    j = {"rows": 100000000, "trees": 1000, "kernel": "score_q16_kernel<8,8,4,23> (q16_d8_c8_u4_gl_s2_cm_x)",
          "fetch_bytes_raw_per_launch": fr, "fetch_bytes_x2_corrected_per_launch": 2 * fr, "write_bytes_per_launch": wr,
          "hbm_bytes_per_launch": 2 * fr + wr,
          "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), averaged over the launches of the scoring kernel; FETCH_SIZE "
                  "doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950 (the q tiles arrive by 16 B/lane global->LDS DMA). "
                  "The scoring kernel reads the u16 rank tiles (6.4 GB) + the model image's L2 misses and writes 0.4 GB of scores; the fp32 tuples "
                  "(12.8 GB) are read once, by the rank pre-pass (`prepass`: raw counter bytes per launch of its kernel(s)).",
-         "prepass": pre, "step_hbm_bytes_x2_corrected": step, "round": 3,
+         "prepass": pre, "step_hbm_bytes_x2_corrected": step, "round": 4,
          "source": f"{ev} (tools/gpu_evidence.sh): `{cmd.format(3)}`"}
     json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print("config 3: scoring kernel", j["hbm_bytes_per_launch"], "B/launch; whole step", step, "B;", pre)
