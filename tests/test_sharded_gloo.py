@@ -1,6 +1,8 @@
-"""N>1 path on CPU: world_size-2 (and 4) gloo process groups exercise SR.ShardedScorer -- shard split,
-chunking, both combine modes -- with the per-rank partial scores supplied by the oracle (checker role:
-the product's scorer needs a GPU; what is under test here is the host-side combine logic)."""
+"""World-size-2 (and 4) gloo process groups on CPU driving the PYTHON MIRROR of the multi-GPU pipeline (tests/sharded_ref.py, test
+infrastructure) with per-rank partial scores supplied by the oracle: what this covers is the shard arithmetic, the chunk schedule and the
+chain order as a specification -- NOT the product's C++ pipeline (csrc/ddt_comm.cpp), which has no CPU backend to talk to.  The product
+pipeline's multi-rank coverage is tests/test_comm_mock.py / test_engine_mock.py (the C++ compiled unchanged against a deferred-execution
+model of HIP streams + RCCL, 2-8 ranks, incl. the hybrid jobs) and tests/test_comm_gpu.py (one-rank communicators on the real RCCL)."""
 import os
 import socket
 
