@@ -1813,7 +1813,7 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     return DDT_OK;
   }
   if (!strcmp(key, "q16_prepass_nt")) {  // A/B: bit 0 = nontemporal stores of the rank tiles, bit 1 = nontemporal tuple loads (effective at the next call)
-    if (value < 0 || value > 15) return fail(e, DDT_EINVAL, "q16_prepass_nt must be 0..15");  // (bits 2, 3: experiment switches of the persistent kernel)
+    if (value < 0 || value > 3) return fail(e, DDT_EINVAL, "q16_prepass_nt must be 0..3");
     e->q16_prepass_nt = (int)value;
     return DDT_OK;
   }

@@ -1330,8 +1330,8 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
     const uint4* img = slow ? x.img_slow : a.img;
     const bool has_next = nxt < tiles;
     // the next tile's flag, needed at this tile's last chunk (which image its chunk 0 comes from)
-    const bool slow_n = has_next && !(x.prepass_nt & 8u) /* A/B: no flag load (only valid without missing values) */ &&
-                        __builtin_amdgcn_readfirstlane((int)x.tile_flags[has_next ? nxt : cur]) != 0;
+    // (this load is waited for on the spot; without it the shard measured the same 13.04 ms: profiles/r04_raw/r04_s9)
+    const bool slow_n = has_next && __builtin_amdgcn_readfirstlane((int)x.tile_flags[has_next ? nxt : cur]) != 0;
     const uint4* img_n = slow_n ? x.img_slow : a.img;
     if (!pre0) dma_chunk<THREADS, CHUNK_BYTES>(img, 0, 0, tid);
 #pragma unroll
@@ -1407,7 +1407,9 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
     // word of chunk buffer 1 (end) -- that buffer is the live one (ring) or dead since the previous chunk barrier (odd chunk
     // count), and the next DMA into it is only issued behind the barrier after the tile-end barrier
     auto last_begin = [&]() {
-      if (tid == 0) ticket = !has_next ? 0xFFFFFFFFu : (x.prepass_nt & 4u) ? nxt + grid /* A/B: static tile assignment */ : 2u * grid + atomicAdd(x.tile_counter, 1u);
+      // (static assignment instead -- tile + 2 * grid, no atomic -- measured 14.72 vs 13.04 ms on a 125-tree shard: the blocks do not run
+      // at one speed, and a ticket counter is what the hardware dispatcher gives the plain launch; profiles/r04_raw/r04_s9)
+      if (tid == 0) ticket = has_next ? 2u * grid + atomicAdd(x.tile_counter, 1u) : 0xFFFFFFFFu;
     };
     auto last_end = [&]() {
       if (tid == 0) lds_st_u32(PAD_WORD, ticket);
