@@ -74,7 +74,11 @@ def self_launch(n_gpus):
     return subprocess.call(cmd)
 
 
-def main():
+def main(argv=None, inproc_env=None):
+    """inproc_env (tests only): a dict standing in for the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE) -- several ranks then run
+    as THREADS of one process (tests/test_bench_multirank_mock.py: the whole N > 1 orchestration below against the CPU model of the host side),
+    stdout is left alone, no watchdog is armed, and rank 0 RETURNS the line instead of printing it."""
+    env = os.environ if inproc_env is None else inproc_env
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -123,18 +127,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     # `python bench.py --gpus N` without a launcher around it: become the launcher (one rank per GPU through torch.distributed.run on
     # 127.0.0.1, a free port), pass the ranks' stdout through -- rank 0 prints the ONE JSON line -- and exit with their status
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and "WORLD_SIZE" not in env:
         sys.exit(self_launch(args.gpus))
 
     # stdout discipline: the driver wants ONE JSON line.  Native libraries (RCCL prints a version banner through C stdio)
     # must not add lines to it: everything but the final print goes to stderr.
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
+    saved_stdout = None
+    if inproc_env is None:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -148,9 +154,9 @@ def main():
              4: (512, 16, 64, 10_000_000), 5: (1000, 8, 32, 10_000_000)}[args.config]
     T, D, F, N = (args.trees or shape[0], args.levels or shape[1], args.features or shape[2], args.rows or shape[3])
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    local = int(env.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         sys.exit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
@@ -561,9 +567,10 @@ def main():
             finally:
                 os._exit(0)
 
-        wd = threading.Timer(args.other_modes_timeout, bail)
-        wd.daemon = True
-        wd.start()
+        if inproc_env is None:
+            wd = threading.Timer(args.other_modes_timeout, bail)
+            wd.daemon = True
+            wd.start()
         try:
             def leg(fn, steps=2):
                 fn()
@@ -653,6 +660,8 @@ def main():
     eng.close()
     if wd is not None:  # the watchdog also covers the teardown: a rank that failed a leg alone must not leave the others waiting
         wd.cancel()
+    if inproc_env is not None:
+        return line if rank == 0 else None
     import ctypes
     ctypes.CDLL(None).fflush(None)  # C stdio buffers of native libraries -> stderr, before stdout comes back
     sys.stdout.flush()

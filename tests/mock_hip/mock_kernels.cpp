@@ -300,6 +300,29 @@ uint32_t generic_lds_bytes(uint32_t, uint32_t, bool* feat_in_lds, bool* tree_in_
   return 64u * 1024u;
 }
 uint32_t stream_blocks_per_cu(uint32_t) { return 1; }
-hipError_t launch_synth_tuples(uint32_t*, uint64_t, size_t, uint32_t, int, uint32_t, hipStream_t) { return hipErrorInvalidValue; }
+// the synthetic tuple generator (csrc/ddt_kernels.hip synth_tuples_kernel) as a deferred operation on the stream
+hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits, hipStream_t s) {
+  Op* op = new Op();
+  op->run = [=] {
+    const uint32_t W = (F + 3u) / 4u * 4u;
+    for (size_t r = 0; r < n; ++r)
+      for (uint32_t j = 0; j < W; ++j) {
+        uint32_t bits = 0u;
+        if (j < F) {
+          const uint64_t h = splitmix64(kSeedX + (row0 + r) * (uint64_t)F + j);
+          float v = (float)(h >> 40) * (1.0f / 16777216.0f);
+          if (dist == 1) {
+            v = v * 2.0f - 1.0f;
+            bits = (((h >> 8) & 0xFFFFull) % 20ull == 0ull) ? missing_bits : f32_bits(v);
+          } else {
+            bits = f32_bits(v);
+          }
+        }
+        out[r * W + j] = bits;
+      }
+  };
+  enqueue(s, op);
+  return hipSuccess;
+}
 
 }  // namespace ddt

@@ -1,0 +1,129 @@
+"""bench.py's N > 1 orchestration, run end to end on the CPU: 2, 4 and 8 ranks as THREADS, each calling bench.main() exactly as a rank
+process would (same argv the driver passes, RANK / LOCAL_RANK / WORLD_SIZE handed in), against the REAL csrc/*.cpp host side built on the
+deferred-execution model of HIP streams + RCCL (tests/mock_hip/) and a stand-in for the few torch calls bench.py makes
+(tests/fake_torch.py).  What this covers that nothing else on the CPU does: the communicator-id exchange, the timed tree-sharded job,
+scaling_detail, EVERY leg of other_modes (chain, untapered, chunk sizes, comm priority, row-sharded replicas, both hybrid forms for each
+split, host buffers with and without tuple broadcast), the --shard hybrid / --shard rows headline paths, and the teardown order -- the
+path the driver runs at round end on 8 GPUs, which no single-GPU box can exercise."""
+import importlib.util
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import ddt
+from ddt import _lib
+from oracle import oracle as O
+from tests import fake_torch
+from tests.test_engine_mock import _build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _run(monkeypatch, world_size, extra, rows=6000, trees=96):
+    L = _build("libddt_host_mock.so")
+    L.mock_reset(2, 11, 8)
+    monkeypatch.setattr(_lib, "_lib", L)
+    world = fake_torch.World(world_size)
+    ft = fake_torch.make(world, L)
+    monkeypatch.setitem(sys.modules, "torch", ft)
+    monkeypatch.setitem(sys.modules, "torch.distributed", ft.distributed)
+    monkeypatch.setitem(sys.modules, "torch.cuda", ft.cuda)
+    bench = _bench_module()
+    argv = ["--gpus", str(world_size), "--steps", "2", "--warmup", "1", "--rows", str(rows), "--trees", str(trees), "--chunk-rows", "2048"] + extra
+    res, errs = [None] * world_size, [None] * world_size
+
+    def rank_main(r):
+        world.local.rank = r
+        try:
+            res[r] = bench.main(argv, inproc_env={"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world_size)})
+        except BaseException as ex:  # noqa: BLE001  (SystemExit of a rank is a failure here too)
+            errs[r] = ex
+            world.barrier.abort()
+
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world_size)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(600)
+    assert not any(t.is_alive() for t in ths), "a rank hung"
+    assert errs == [None] * world_size, errs
+    assert all(r is None for r in res[1:]) and res[0] is not None
+    return res[0], L
+
+
+@pytest.mark.parametrize("world_size", [2, 4, 8])
+def test_tree_sharded_line_and_every_other_mode(monkeypatch, world_size):
+    line, L = _run(monkeypatch, world_size, [])
+    assert line["n_gpus"] == world_size and line["config"]["parallelism"] == f"tree-shard{world_size}" and line["value"] > 0
+    assert line["config"]["collectives"].startswith("C-ABI ddt_comm")
+    sd = line["scaling_detail"]
+    assert "error" not in sd and sd["trees_on_this_rank"] == 96 // world_size
+    assert "roofline" not in line or "scope" in line["roofline"]     # (the model's events measure no time: no roofline object rather than a division by zero)
+    om = line["other_modes"]
+    assert "error" not in om and "status" not in om, om
+    want = ["tree_sharded_chain_ms", "tree_sharded_allreduce_untapered_ms", "tree_sharded_allreduce_chunk_1024_ms", "tree_sharded_allreduce_chunk_4096_ms",
+            "tree_sharded_allreduce_comm_priority_ms", "row_sharded_ms", "host_buffers_tuple_broadcast_1_mtuples_per_s", "host_buffers_tuple_broadcast_0_mtuples_per_s"]
+    splits = bench_splits(world_size)
+    for Gt in splits:
+        k = f"hybrid_tree{Gt}_x_rows{world_size // Gt}"
+        want += [k + "_ms", k + "_gathered_ms"]
+        assert om[k + "_vs_tree_max_abs_diff_rel"] < 1e-5 and om[k + "_gathered_vs_tree_max_abs_diff_rel"] < 1e-5   # summation order only
+    assert world_size == 2 or splits, "no hybrid split exercised"
+    for k in want:
+        assert k in om and om[k] > 0, (k, om)
+    assert om["row_vs_tree_max_abs_diff_rel"] < 1e-5
+    assert L.mock_errors() == 0
+
+
+def bench_splits(world_size):
+    return _bench_module().hybrid_tree_groups(world_size)
+
+
+@pytest.mark.parametrize("extra,par", [(["--shard", "hybrid", "--tree-ranks", "2"], "hybrid-tree2-x-rows4"),
+                                       (["--shard", "hybrid", "--tree-ranks", "4", "--no-gather"], "hybrid-tree4-x-rows2"),
+                                       (["--shard", "rows"], "row-shard8"),
+                                       (["--combine", "chain"], "tree-shard8")])
+def test_other_headline_shardings_on_eight_ranks(monkeypatch, extra, par):
+    line, L = _run(monkeypatch, 8, extra + ["--no-other-modes"])
+    assert line["config"]["parallelism"] == par and line["n_gpus"] == 8 and line["value"] > 0
+    assert L.mock_errors() == 0
+
+
+def test_the_scores_of_the_timed_job_are_the_oracles(monkeypatch):
+    """the timed job of an 8-rank bench run (here the hybrid 2 x 4 job with its pieces handed round: nothing overwrites `out` behind it, the
+    tree-sharded line's scaling_detail pass does) leaves, on every rank, the oracle's scores for all rows within the summation-order
+    tolerance -- read back through a hook on the stand-in's buffers.  The tree-sharded job's scores are tied to these by the
+    *_vs_tree_max_abs_diff_rel figures asserted above."""
+    kept = {}
+    real_make = fake_torch.make
+
+    def spy(world, L):
+        ft = real_make(world, L)
+        inner = ft.empty
+
+        def empty(shape, dtype=fake_torch.float32, device=None):
+            t = inner(shape, dtype, device)
+            if dtype == fake_torch.float32 and not isinstance(shape, tuple):
+                kept.setdefault(world.local.rank, t)        # the first fp32 vector a rank allocates is bench.py's `out`
+            return t
+
+        ft.empty = empty
+        return ft
+
+    monkeypatch.setattr(fake_torch, "make", spy)
+    line, L = _run(monkeypatch, 8, ["--no-other-modes", "--shard", "hybrid", "--tree-ranks", "4"], rows=5000, trees=80)
+    m, x = O.gen_model(80, 8, 32, 0), O.gen_tuples(0, 5000, 32, 0)
+    gold = O.score(m, x, want_gold=True)[1]
+    for r in range(8):
+        assert np.allclose(kept[r].a, gold, rtol=1e-5, atol=1e-5), r
+    assert line["config"]["trees"] == 80
