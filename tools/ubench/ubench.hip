@@ -796,6 +796,7 @@ __global__ __launch_bounds__(256) void tile_pattern_kernel(const u32x4* __restri
     if (tile + step < end) fetch(tile + step);
 #pragma unroll 16
     for (int k = 0; k < WORK; ++k) asm volatile("v_add_u32 %0, %0, %1" : "+v"(acc) : "v"(acc));
+    if (WR == 1 || WR == 12 || WR == 13) acc ^= (uint32_t)(tile * 256 + threadIdx.x);  // (src is 0x5A everywhere: the stored word = its own index, checked on the host)
     if (WR == 1) out[tile * 256 + threadIdx.x] = acc;
     else if (WR == 2) __builtin_nontemporal_store(acc, out + tile * 256 + threadIdx.x);
     else if (WR == 3 || WR == 4) {
@@ -805,11 +806,41 @@ __global__ __launch_bounds__(256) void tile_pattern_kernel(const u32x4* __restri
         if (WR == 3) *dst = v;
         else __builtin_nontemporal_store(v, dst);
       }
+    } else if (WR >= 6 && WR <= 8) {  // cache-policy bits on the 4-byte store: sc1 (write-through to the fabric), sc0 sc1, sc0 sc1 nt
+      uint32_t* dst = out + tile * 256 + threadIdx.x;
+      if (WR == 6) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(acc) : "memory");
+      else if (WR == 7) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(dst), "v"(acc) : "memory");
+      else asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(acc) : "memory");
+    } else if (WR == 12) {  // a no-return atomic swap as the store: executed in the L2, not a TCP write
+      uint32_t* dst = out + tile * 256 + threadIdx.x;
+      asm volatile("global_atomic_swap %0, %1, off" ::"v"(dst), "v"(acc) : "memory");
+    } else if (WR == 13) {  // the wave's 64 results through the scalar unit: 64 v_readlane + 16 s_store_dwordx4 (no TA / TCP involved)
+      uint32_t* wbase = out + tile * 256 + (threadIdx.x & ~63u);
+      const uint64_t wb = (uint64_t)wbase;
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)wb), hi = __builtin_amdgcn_readfirstlane((uint32_t)(wb >> 32));
+      const uint64_t sb = ((uint64_t)hi << 32) | lo;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        u32x4 v;
+        v.x = __builtin_amdgcn_readlane(acc, 4 * q), v.y = __builtin_amdgcn_readlane(acc, 4 * q + 1);
+        v.z = __builtin_amdgcn_readlane(acc, 4 * q + 2), v.w = __builtin_amdgcn_readlane(acc, 4 * q + 3);
+        asm volatile("s_store_dwordx4 %0, %1, %2" ::"s"(v), "s"(sb), "n"(16 * q) : "memory");
+      }
+    } else if (WR >= 9 && WR <= 11) {  // the rank pre-pass's mix: 32 bytes written per 64 read (two 16-byte stores per lane), plain / nontemporal / sc1
+      u32x4* dst = reinterpret_cast<u32x4*>(out) + tile * 512 + threadIdx.x;
+      const u32x4 v = {acc, acc ^ pre[1].x, acc ^ pre[2].y, acc ^ pre[3].z};
+      if (WR == 9) dst[0] = v, dst[256] = v;
+      else if (WR == 10) __builtin_nontemporal_store(v, dst), __builtin_nontemporal_store(v, dst + 256);
+      else {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + 256), "v"(v) : "memory");
+      }
     } else if (WR == 5) {
       four[nfour & 3] = acc;  // (register-indexed in the probe only; the real kernel would pass through LDS)
       if ((++nfour & 3) == 0) reinterpret_cast<u32x4*>(out + (tile - 3) * 256)[threadIdx.x] = four;
     } else keep ^= acc;
   }
+  if (WR == 13) asm volatile("s_dcache_wb" ::: "memory");
   if (WR == 0 && keep == 0x12345678u) out[0] = keep;
 }
 
@@ -825,11 +856,23 @@ static void run_tile_pattern(const u32x4* d_src, size_t bytes, uint32_t* d_res, 
     const double ms = t.stop_ms();
     if (r) best = ms < best ? ms : best;
   }
+  long bad = -1;
+  if (WR == 1 || WR == 12 || WR == 13) {  // do the unusual store forms store?  
+    CK(hipMemset(d_res, 0xFF, n_tiles * 1024));
+    hipLaunchKernelGGL((tile_pattern_kernel<WR, BARRIER, WORK>), dim3(blocks), dim3(256), 0, 0, d_src, n_tiles, d_res);
+    CK(hipDeviceSynchronize());
+    std::vector<uint32_t> h(n_tiles * 256);
+    CK(hipMemcpy(h.data(), d_res, h.size() * 4, hipMemcpyDeviceToHost));
+    bad = 0;
+    for (size_t i = 0; i < h.size(); ++i) bad += h[i] != (uint32_t)i;
+  }
   static const char* const names[] = {"none", "4 B per lane", "4 B per lane, nontemporal", "16 B per lane from one wave", "16 B per lane from one wave, nontemporal",
-                                      "consecutive tiles per block, 16 B per lane every 4 tiles"};
+                                      "consecutive tiles per block, 16 B per lane every 4 tiles", "4 B per lane, sc1", "4 B per lane, sc0 sc1", "4 B per lane, sc0 sc1 nt",
+                                      "32 B per lane (pre-pass mix)", "32 B per lane, nontemporal", "32 B per lane, sc1",
+                                      "4 B per lane as a no-return atomic swap", "4 B per lane through the scalar unit (v_readlane + s_store_dwordx4)"};
   char buf[400];
-  snprintf(buf, sizeof buf, "    {\"result_store\": \"%s\", \"barrier\": %s, \"valu_per_lane_and_tile\": %d, \"blocks_per_cu\": %d, \"ms\": %.3f, \"TB_per_s_read\": %.3f},\n",
-           names[WR], BARRIER ? "true" : "false", WORK, blocks_per_cu, best, (double)bytes / (best * 1e-3) / 1e12);
+  snprintf(buf, sizeof buf, "    {\"result_store\": \"%s\", \"barrier\": %s, \"valu_per_lane_and_tile\": %d, \"blocks_per_cu\": %d, \"ms\": %.3f, \"TB_per_s_read\": %.3f, \"result_words_not_written\": %ld},\n",
+           names[WR], BARRIER ? "true" : "false", WORK, blocks_per_cu, best, (double)bytes / (best * 1e-3) / 1e12, bad);
   js += buf;
 }
 
@@ -971,6 +1014,33 @@ int main(int argc, char** argv) {
       run_tile_pattern<4, true, 256>(d_src, bytes, d_res, bpc, js);
       run_tile_pattern<0, true, 256>(d_src, bytes, d_res, bpc, js);
     }
+    strip_comma(js);
+    js += "  ],\n";
+    CK(hipFree(d_src));
+    CK(hipFree(d_res));
+  }
+  if (!strcmp(what, "storepol")) {  // (not part of "all") the result store's cache policy, 6 blocks per CU, and read-only for reference -- run under rocprofv3 --pmc for the L2 <-> fabric counters
+    js += "  \"store_policy\": [\n";
+    const size_t bytes = 12800000000ull / 16384 * 16384;
+    u32x4* d_src;
+    uint32_t* d_res;
+    CK(hipMalloc((void**)&d_src, bytes));
+    CK(hipMalloc((void**)&d_res, bytes / 2));
+    CK(hipMemset(d_src, 0x5A, bytes));
+    CK(hipMemset(d_res, 0, bytes / 2));
+    CK(hipDeviceSynchronize());
+    run_tile_pattern<0, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<1, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<2, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<6, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<7, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<8, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<9, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<10, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<11, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<12, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<13, false, 0>(d_src, bytes, d_res, 6, js);
+    run_tile_pattern<1, false, 0>(d_src, bytes, d_res, 6, js);
     strip_comma(js);
     js += "  ],\n";
     CK(hipFree(d_src));
