@@ -1013,6 +1013,9 @@ void fill_args(const ddt_engine* e, const Ensemble& m, const void* d_tuples, siz
   a->ev_mid = nullptr;
   a->num_cus = e->prop.multiProcessorCount > 0 ? (uint32_t)e->prop.multiProcessorCount : 256u;
   a->stream_blocks_per_cu = (uint32_t)e->stream_blocks_per_cu;
+  a->stream_res_tiles = (uint32_t)e->stream_res_tiles;
+  a->stream_window_ticks = (uint32_t)e->stream_window_ticks;
+  a->stream_res_off = 0;
 }
 
 void feeder_free(ddt_engine* e) {
@@ -1788,6 +1791,16 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   if (!strcmp(key, "stream_blocks_per_cu")) {  // persistent stream kernel: blocks per CU, 0 (default) = the resident number
     if (value < 0 || value > 16) return fail(e, DDT_EINVAL, "stream_blocks_per_cu %lld not in 0..16", (long long)value);
     e->stream_blocks_per_cu = (int)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "stream_res_tiles")) {  // stream kernel, phased result stores: 0 (default) = as many LDS slots as fit, 1 = direct stores, n = at most n
+    if (value < 0 || value > 64) return fail(e, DDT_EINVAL, "stream_res_tiles %lld not in 0..64", (long long)value);
+    e->stream_res_tiles = (int)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "stream_window_ticks")) {  // ... the write window's period in 10 ns ticks of the constant 100 MHz clock; 0 = default (3000)
+    if (value < 0 || (value != 0 && value < 100) || value > 10000000) return fail(e, DDT_EINVAL, "stream_window_ticks %lld not 0 or in 100..10000000", (long long)value);
+    e->stream_window_ticks = (int)value;
     return DDT_OK;
   }
   if (!strcmp(key, "class_streams")) {  // 1 (default): the classes of a multi-class model alternate between two streams; 0: one stream

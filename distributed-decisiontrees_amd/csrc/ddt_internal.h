@@ -44,6 +44,12 @@ struct ScoreArgs {
   hipEvent_t ev_mid;       // optional ("kernel_timing"): recorded right before the scoring kernel proper
   uint32_t num_cus;        // hipDeviceProp_t::multiProcessorCount: sizes the persistent grids
   uint32_t stream_blocks_per_cu;  // stream kernel: 0 = as many blocks per CU as are resident, else forced (option, A/B)
+  // stream kernel, phased result stores (ddt_kernels.hip).  From the engine: the options "stream_res_tiles" (0 = as many slots as
+  // the LDS leaves, 1 = direct stores, n = at most n) and "stream_window_ticks" (0 = default); launch_stream() fills in what the
+  // kernel reads: the slots per wave (0 = direct stores), the window in 10 ns ticks and the LDS byte offset of the slots.
+  uint32_t stream_res_tiles;
+  uint32_t stream_window_ticks;
+  uint32_t stream_res_off;
 };
 
 constexpr uint32_t kQMissing = 0xFFFFu;  // rank of a missing feature value in the u16 tiles

@@ -344,9 +344,20 @@ static hipError_t launch_tile_persist(const ScoreArgs& a, const Variant& v, hipS
 // 64-byte tuple (any store shape: 4 B or 16 B per lane, nontemporal, 4 KiB bursts); this kernel runs at 4.8-5.3.  Getting
 // there took a VALU trim (488 -> 258 VALU instructions per tuple: 2.90 -> 2.73 ms per 200 M tuples).  Not kept, all equal
 // within box noise once the trim was in: 7 / 8 waves per SIMD, two tiles in flight per block, quad loads + DPP transpose.
+// Round 4, PHASED RESULT STORES: the store's cost is paid in the DRAM, not on the chip (tools/ubench/storephase.hip: the same
+// stores into an L2-resident window cost nothing; a vector store, an L2 atomic and a scalar store cost the same; L2 <-> fabric
+// write queues idle, read latency unchanged) -- the HBM serves a read stream with a few writes sprinkled in at ~70 % of its
+// read-only rate whatever the write share.  So the writes are taken out of the read stream IN TIME: a wave parks its 64 scores
+// per tile in LDS (ScoreArgs::stream_res_tiles slots of 256 bytes, private to the wave: no barrier) and all waves of the chip
+// write them, nontemporally, when the 100 MHz s_memrealtime clock passes a multiple of ScoreArgs::stream_window_ticks (or the
+// wave's slots are full): the memory sees read-only traffic for ~30 us, then a short burst of writes.  Pattern alone: 2.08-2.25 ms
+// per 12.8 GB against 2.24-2.56 (direct nontemporal stores) and 2.70 (direct plain stores), box by box.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kStreamThreads = 256;
 constexpr uint32_t kStreamRow = kStreamThreads * 4u;
+constexpr uint32_t kStreamResMin = 4, kStreamResMax = 24;  // phased result stores: tiles a wave may park in LDS
+constexpr uint32_t kStreamResWant = 10, kStreamFewVisits = 64;  // ... models of at most that many node visits per tuple give up resident blocks (down to 4) for that many slots
+constexpr uint32_t kStreamWindowTicks = 3000;              // ... and the write window's period in 10 ns ticks (30 us)
 
 // FIXED: the tuple has exactly MAXLPT lines (config 1: 16 features = 4 lines), so element -> (tuple, line) is a shift and the
 // sixteen LDS stores of a thread share one address register.  Round 3 counters (profiles/r03_pmc_stream_cfg1.md) showed this
@@ -360,15 +371,20 @@ __device__ __forceinline__ void stream_body(const ScoreArgs& a) {
   const uint32_t W = a.tuple_words, LPT = FIXED ? (uint32_t)MAXLPT : W / 4u;
   const uint32_t img_bytes = a.n_trees * (uint32_t)TREE_BYTES;
   const uint32_t feat_off = (img_bytes + kStreamRow - 1u) / kStreamRow * kStreamRow;  // == host's Variant::feat_off
-  const uint32_t flags = feat_off + W * kStreamRow + LPT * kStreamSkew;
   const uint64_t n_tiles = (a.n + TILE - 1) / TILE;
   const uint32_t C = a.clusters, miss_key = a.miss_key, miss_raw = a.miss_raw;
 
   // resident model
   for (uint32_t off = (uint32_t)tid * 16u; off < img_bytes; off += THREADS * 16u)
     lds_st_u4(off, a.img[off / 16u]);
+  __syncthreads();  // the only block barrier: from here on the waves run on their own
 
-  // element e (0..TILE*LPT) of a tile = float4 #e of its byte range: tuple e / LPT, line e % LPT
+  // element e (0..TILE*LPT) of a tile = float4 #e of its byte range: tuple e / LPT, line e % LPT.  WAVE-PRIVATE tiles (round 4): a
+  // wave loads, stages and walks the SAME 64 tuples -- lane l takes elements 64 w LPT + l + 64 i of the tile, the contiguous
+  // 64 LPT float4 of the wave's tuples (coalesced as before) -- so nothing a wave reads from the tile was written by another wave
+  // and the two block barriers per tile (tile consumed / tile staged + the block-wide missing flag) are gone: the missing flag
+  // is a wave ballot, the waves of a block drift apart and fill each other's stalls.
+  const uint32_t wave_e0 = (uint32_t)(tid & ~63) * LPT + (uint32_t)(tid & 63);
   auto prefetch = [&](uint64_t tile, u32x4 (&pre)[MAXLPT]) {
     // nontemporal: the tuple stream is read once (tools/ubench `hbm`: 6.5 vs 5.9 TB/s read-only; this kernel on config 1: 2.90 vs 3.04 ms)
     const u32x4* src = reinterpret_cast<const u32x4*>(a.tuples + tile * TILE * W);
@@ -376,12 +392,12 @@ __device__ __forceinline__ void stream_body(const ScoreArgs& a) {
     if (rows_left >= (uint64_t)TILE) {  // wave-uniform: a full tile loads unguarded
 #pragma unroll
       for (int i = 0; i < MAXLPT; ++i)
-        if (FIXED || (uint32_t)i < LPT) pre[i] = __builtin_nontemporal_load(src + ((uint32_t)tid + (uint32_t)i * THREADS));
+        if (FIXED || (uint32_t)i < LPT) pre[i] = __builtin_nontemporal_load(src + (wave_e0 + (uint32_t)i * 64u));
     } else {
       const uint32_t avail = (uint32_t)rows_left * LPT;
 #pragma unroll
       for (int i = 0; i < MAXLPT; ++i) {
-        const uint32_t e = (uint32_t)tid + (uint32_t)i * THREADS;
+        const uint32_t e = wave_e0 + (uint32_t)i * 64u;
         if ((FIXED || (uint32_t)i < LPT) && e < avail) pre[i] = __builtin_nontemporal_load(src + e);
         else pre[i] = u32x4{0u, 0u, 0u, 0u};  // rows past n: zeros (may only make the last tile take the slow walk)
       }
@@ -395,7 +411,7 @@ __device__ __forceinline__ void stream_body(const ScoreArgs& a) {
 #pragma unroll
     for (int i = 0; i < MAXLPT; ++i) {
       if (FIXED || (uint32_t)i < LPT) {
-        const uint32_t e = (uint32_t)tid + (uint32_t)i * THREADS;
+        const uint32_t e = wave_e0 + (uint32_t)i * 64u;
         const uint32_t t = e / LPT, q = e - t * LPT;
         const uint32_t fa = feat_off + (4u * q) * kStreamRow + q * kStreamSkew + t * 4u;  // Variant::feat_word_stream
 #pragma unroll
@@ -411,11 +427,36 @@ __device__ __forceinline__ void stream_body(const ScoreArgs& a) {
     return miss_any;
   };
   const uint64_t G = gridDim.x;
+  // phased result stores (see above): NB slots of one tile's 64 scores per wave; 32-bit clock arithmetic (wrap-safe differences)
+  const uint32_t NB = a.stream_res_tiles, window = a.stream_window_ticks;
+  auto ring_addr = [&]() -> uint32_t {  // (recomputed at a tile's end: one VGPR less across the walk; the asm keeps hipcc from hoisting it)
+    uint32_t t = (uint32_t)tid;
+    asm volatile("" : "+v"(t));
+    return a.stream_res_off + (t >> 6) * NB * 256u + (t & 63u) * 4u;
+  };
+  uint32_t r_count = 0, deadline = 0;
+  uint64_t r_first = blockIdx.x;
+  if (NB) {
+    const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    deadline = now - now % window + window;  // windows are aligned to multiples of `window` in absolute time: chip-wide
+  }
+  auto flush = [&](uint64_t next_first) {
+    const uint32_t ring = ring_addr();
+    for (uint32_t j = 0; j < r_count; ++j) {
+      const uint64_t row = (r_first + (uint64_t)j * G) * TILE + (uint64_t)tid;
+      if (row < a.n) __builtin_nontemporal_store(lds_f32(ring + j * 256u), a.out + row);
+    }
+    r_count = 0;
+    r_first = next_first;
+  };
   // one tile: stage `pre`, refill it with the block's next tile (its HBM reads fly during the walks), walk, store
   auto step = [&](uint64_t tile, u32x4 (&pre)[MAXLPT]) {
-    __syncthreads();  // previous tile fully consumed (first pass: model image written)
-    const bool miss_any = a.ieee ? stage(std::true_type{}, pre) : stage(std::false_type{}, pre);  // wave-uniform
-    const bool slow = block_any<THREADS>(miss_any ? 1u : 0u, flags, tid);
+    const bool miss_any = a.ieee ? stage(std::true_type{}, pre) : stage(std::false_type{}, pre);
+    const bool slow = __ballot(miss_any) != 0ull;  // wave-uniform: one of the wave's 64 tuples holds a missing value
+    // the walk reads what OTHER lanes of this wave staged: the LDS executes a wave's instructions in order; the fence keeps hipcc from
+    // moving the reads in front of the stores (wavefront scope: no instruction)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (tile + G < n_tiles) prefetch(tile + G, pre);
 
     RefAcc<1> ra;
@@ -431,18 +472,32 @@ __device__ __forceinline__ void stream_body(const ScoreArgs& a) {
       if (a.sum_mode != 1) fold_leaves<U, 1, 0>(lf, phase, C, ra, dacc, a.sum_mode == 2);
       else fold_leaves<U, 1, 1>(lf, phase, C, ra, dacc);
     }
-    const uint64_t row = tile * TILE + (uint64_t)tid;
-    if (row < a.n) a.out[row] = (a.sum_mode != 1) ? ra.total_ring(0, C, a.sum_mode == 2) : (float)dacc[0];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next tile's staging stays behind this tile's walk)
+    __builtin_amdgcn_wave_barrier();
+    const float score = (a.sum_mode != 1) ? ra.total_ring(0, C, a.sum_mode == 2) : (float)dacc[0];
+    if (NB == 0u) {
+      const uint64_t row = tile * TILE + (uint64_t)tid;
+      if (row < a.n) a.out[row] = score;
+    } else {
+      lds_st_u32(ring_addr() + r_count * 256u, __float_as_uint(score));
+      ++r_count;
+      const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
+      const bool due = (int32_t)(now - deadline) >= 0;  // wave-uniform
+      if (due) deadline = now - (now - deadline) % window + window;  // the next multiple (the phase of the old deadline is kept)
+      if (due || r_count == NB) flush(tile + G);
+    }
   };
 
   uint64_t tile = blockIdx.x;
   u32x4 pre[MAXLPT];
   if (tile < n_tiles) prefetch(tile, pre);
   for (; tile < n_tiles; tile += G) step(tile, pre);
+  if (NB) flush(0);
 }
 
 template <int D, int U, int MAXLPT>
-__global__ __launch_bounds__(kStreamThreads) void score_stream_kernel(const ScoreArgs a) {
+// (6 blocks per CU only where the walk fits 80 VGPRs: the depth-6 instance spilled two registers under that bound)
+__global__ __launch_bounds__(kStreamThreads, (MAXLPT <= 4 && D <= 4) ? 6 : 4) void score_stream_kernel(const ScoreArgs a) {
   if (a.tuple_words == 4u * (uint32_t)MAXLPT) stream_body<D, U, MAXLPT, true>(a);
   else stream_body<D, U, MAXLPT, false>(a);
 }
@@ -474,9 +529,53 @@ static hipError_t launch_stream(const ScoreArgs& a, const Variant& v, hipStream_
   uint32_t per_cu = stream_blocks_per_cu(lds);
   if (a.stream_blocks_per_cu) per_cu = a.stream_blocks_per_cu;  // option "stream_blocks_per_cu" (A/B)
   else if (occ_blocks < per_cu) per_cu = occ_blocks;
+  // phased result stores: the LDS the resident blocks leave free holds the waves' score slots (1 KiB per tile and block).
+  // option "stream_res_tiles": 0 = as many as fit (up to kStreamResMax; fewer than kStreamResMin: direct stores), 1 = direct
+  // stores (A/B), n = at most n.  Only when a block has enough tiles for the windows to matter.
+  ScoreArgs b = a;
+  b.stream_res_tiles = 0;
+  b.stream_res_off = (lds + 255u) & ~255u;
+  b.stream_window_ticks = a.stream_window_ticks ? a.stream_window_ticks : kStreamWindowTicks;
+  uint32_t lds_launch = lds;
+  if (a.stream_res_tiles != 1u) {
+    const uint32_t cap = a.stream_res_tiles ? a.stream_res_tiles : kStreamResMax;
+    // a block's LDS is allocated in granules (1280 bytes assumed: with 512 the occupancy query said five blocks of 32256 bytes fit
+    // a CU, and four ran)
+    auto slots_for = [&](uint32_t blocks) -> uint32_t {
+      const uint32_t budget = (160u * 1024u) / blocks / 1280u * 1280u;
+      const uint32_t nb = budget > b.stream_res_off ? (budget - b.stream_res_off) / 1024u : 0u;
+      return nb > cap ? cap : nb;
+    };
+    uint32_t pc = per_cu;
+    // few node visits per tuple (BASELINE config 1's regime, HBM-bound): one resident block fewer buys more slots than it costs --
+    // 8 trees x depth 4 x 16 features, 200 M tuples on one box: 6 blocks x 7 slots 2.58-2.65 ms, 5 x 12 2.41-2.44, 4 x 21 2.45-2.52,
+    // direct stores 2.71-2.90 (profiles/r04_stream_phased_stores.md)
+    if (!a.stream_blocks_per_cu && a.n_trees * a.levels <= kStreamFewVisits)
+      while (pc > 4u && slots_for(pc) < kStreamResWant) --pc;
+    uint32_t nb = slots_for(pc);
+    if (nb >= kStreamResMin && tiles >= 8ull * a.num_cus * pc) {
+      static thread_local uint32_t ok_lds = ~0u, ok_pc = 0, ok_cap = 0, ok_nb = 0;  // the occupancy query per (lds, blocks, cap)
+      if (ok_lds != lds || ok_pc != pc || ok_cap != cap) {
+        for (; nb >= kStreamResMin; --nb) {  // the blocks the grid counts on must be resident together
+          int occ = 0;
+          const uint32_t want = b.stream_res_off + nb * 1024u;
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) continue;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), kStreamThreads, want) == hipSuccess && (uint32_t)occ >= pc) break;
+        }
+        ok_lds = lds, ok_pc = pc, ok_cap = cap, ok_nb = nb >= kStreamResMin ? nb : 0u;
+      }
+      if (ok_nb) {
+        per_cu = pc;
+        b.stream_res_tiles = ok_nb;
+        lds_launch = b.stream_res_off + ok_nb * 1024u;
+      }
+    }
+  }
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch);
+  if (e != hipSuccess) return e;
   uint64_t grid = (uint64_t)a.num_cus * per_cu;
   if (grid > tiles) grid = tiles;
-  hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(kStreamThreads), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(kStreamThreads), lds_launch, s, b);
   return hipGetLastError();
 }
 
