@@ -81,8 +81,8 @@ def main(argv=None, inproc_env=None):
     env = os.environ if inproc_env is None else inproc_env
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5; configs 1 and 2, whose step is 1-3 ms: 30)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 2; configs 1 and 2: 5)")
     ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5],
                     help="BASELINE.json config: 3 = headline (default); 1 = 8 trees x d4 x 16 features (HBM-bound shape, 200 M rows "
                          "instead of the 1 K rows of the CPU plumbing case); 2 = 100 x d6 x 28, 10 M rows; 4 = sparse random forest; "
@@ -128,6 +128,12 @@ def main(argv=None, inproc_env=None):
     ap.add_argument("--no-streamed", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     args = ap.parse_args(argv)
+    # a step of configs 1 / 2 takes 1-3 ms: five of them time the first launches after the allocations (~4 % slower) more than the kernel
+    short = args.config in (1, 2)
+    if args.steps is None:
+        args.steps = 30 if short else 5
+    if args.warmup is None:
+        args.warmup = 5 if short else 2
 
     # `python bench.py --gpus N` without a launcher around it: become the launcher (one rank per GPU through torch.distributed.run on
     # 127.0.0.1, a free port), pass the ranks' stdout through -- rank 0 prints the ONE JSON line -- and exit with their status

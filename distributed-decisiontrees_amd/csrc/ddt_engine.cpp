@@ -1115,6 +1115,10 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     qa.img_slow = reinterpret_cast<const uint4*>(m.d_img_slow);
     qa.n_pad = (n + 1023) / 1024 * 1024;
     qa.real_groups = (m.trees() + 7u) / 8u;
+    // the image's EMPTY padding (trees up to whole chunks) is not walked: in tree order the real trees end after ceil(T / U) sub-groups,
+    // in a cluster-major image the partly filled PU group may sit in the middle -- whole PU groups count there
+    const uint32_t U = (uint32_t)v.ilp_trees;
+    qa.walk_subgroups = e->q16_walk_padding ? 0u : (v.opt & 4) ? qa.real_groups * 8u / U : (m.trees() + U - 1u) / U;
     qa.prepass_nt = (uint32_t)e->q16_prepass_nt;
     if (all_classes) {
       a.img = reinterpret_cast<const uint4*>(e->d_mc_img);
@@ -1146,6 +1150,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     const size_t chunk_bytes = (size_t)v.tree_bytes_q16() * (size_t)v.chunk_trees;
     float* state = reinterpret_cast<float*>(e->q_state[e->q_slot]);
     uint32_t groups_before = 0;
+    const uint32_t walk_all = qa.walk_subgroups;
     for (size_t k = 0; k < m.parts.size() && r == hipSuccess; ++k) {
       const Q16Part& part = m.parts[k];
       a.img = reinterpret_cast<const uint4*>(static_cast<const char*>(m.d_img) + part.chunk_begin * chunk_bytes);
@@ -1161,6 +1166,9 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
       qa.group0 = groups_before;
       qa.state_in = k > 0 ? state : nullptr;
       qa.state_out = k + 1 < m.parts.size() ? state : nullptr;
+      const uint32_t sgs_before = part.chunk_begin * (uint32_t)v.chunk_trees / (uint32_t)v.ilp_trees;
+      qa.walk_subgroups = (walk_all > sgs_before) ? walk_all - sgs_before : 0u;  // (0 = everything: only the last part has padding)
+      if (k + 1 < m.parts.size()) qa.walk_subgroups = 0u;
       if (k > 0) a.ev_mid = nullptr;  // (kernel_timing: the first part's pre-pass against everything behind it)
       r = v.launch(a, v, s);
       groups_before += a.n_trees / 8u;
@@ -1801,6 +1809,10 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   if (!strcmp(key, "stream_window_ticks")) {  // ... the write window's period in 10 ns ticks of the constant 100 MHz clock; 0 = default (3000)
     if (value < 0 || (value != 0 && value < 100) || value > 10000000) return fail(e, DDT_EINVAL, "stream_window_ticks %lld not 0 or in 100..10000000", (long long)value);
     e->stream_window_ticks = (int)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "q16_walk_padding")) {  // A/B: 1 = the plain rank-quantised kernels walk the EMPTY padding trees of the last chunk too (as before round 4)
+    e->q16_walk_padding = value != 0;
     return DDT_OK;
   }
   if (!strcmp(key, "class_streams")) {  // 1 (default): the classes of a multi-class model alternate between two streams; 0: one stream

@@ -82,6 +82,10 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   const uint4* prepass_img;   // LDS-resident pre-pass: concatenated LDS images, one per feature group
   PrepassPlan prepass;        // groups == 0: use transpose_kernel + rank_kernel
   uint32_t real_groups;       // "_cm" kernels: PU groups that hold a real tree, ceil(T / 8) (the image may be padded with EMPTY groups)
+  // plain (non-persistent) kernels: sub-groups (of the kernel's U trees in flight) at the front of this launch's image that hold a
+  // real tree; the rest -- EMPTY padding up to whole chunks, always at the image's end -- is not walked, its +0 leaves are added as
+  // always (the result is the same bit for bit: an EMPTY tree's walk ends in a +0 leaf whatever the tuple).  0 = walk everything.
+  uint32_t walk_subgroups = 0;
   // "_p" (persistent) kernels.  The image may hold SEVERAL ensembles back to back ("segments": the classes of a one-vs-all model,
   // each padded to seg_chunks whole chunks, real_groups real PU groups in each): segment k's sum goes to out[k * n + row] and the
   // label (argmax over the segments, lowest index on ties, a NaN never beats a number) to labels[row].  n_segs == 1: plain scores.

@@ -1196,6 +1196,13 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   }
   const int SUM1 = (int)a.sum_mode;  // 0 reference order / IEEE adds, 1 fp64, 2 reference order / reference adder
   const bool exact = SUM1 == 2;
+  // Sub-groups that hold a real tree (Q16Aux::walk_subgroups): the EMPTY padding behind them is not walked.  A branch per sub-group,
+  // so only where the chunk body is no single basic block worth keeping (the depth-7/8 hot path is: +5 %; at depth 6 it measured
+  // equal) -- and never as a second copy of the chunk code: at the join of two copies hipcc moves the _s2 record sets while their
+  // loads are in flight (tools/check_s2_isa.py refused that build).  Shallow kernels are also the ones with many trees per chunk
+  // (16..128), i.e. with the most padding to lose.
+  constexpr bool TAILSKIP = D <= 6;
+  const uint32_t walk_sgs = x.walk_subgroups ? x.walk_subgroups : 0xFFFFFFFFu;
 
   // _s2: two SGPR sets take turns (even / odd sub-group of a chunk; a chunk has an even number of sub-groups, so every chunk
   // starts on top_a): one holds the level-0/1 records of the sub-group being walked, the other receives the next sub-group's
@@ -1211,6 +1218,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
     _Pragma("unroll") for (int sg = 0; sg < CT / U; ++sg) {                                            \
       float lf[1][U];                                                                                  \
       const LeafSrc gl = {leaf_rsrc, (uint32_t)(KIDX) * (uint32_t)(GCHUNK_UNITS * 16) + (uint32_t)((CT + sg * U - 1) * (4 << D))}; \
+      const bool pad_sg = TAILSKIP && (uint32_t)(KIDX) * (uint32_t)(CT / U) + (uint32_t)sg >= walk_sgs; /* wave-uniform */ \
       if constexpr (S2) {                                                                              \
         const uint32_t kn = (sg + 1 < CT / U) ? (uint32_t)(KIDX) : ((uint32_t)(KIDX) + 1u < n_chunks ? (uint32_t)(KIDX) + 1u : 0u); \
         const int sn = (sg + 1 < CT / U) ? sg + 1 : 0;                                                 \
@@ -1218,13 +1226,17 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
         TopRecs<4>& top_nxt = (sg & 1) ? top_a : top_b;                                                \
         top_wait(top_cur);                                                                             \
         top_issue<TREE_BYTES>(top_nxt, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
-        if constexpr (PIN) {                                                                           \
+        if (pad_sg) { /* EMPTY padding behind the last real tree: no walk, the +0 leaves it would end in */ \
+          _Pragma("unroll") for (int u = 0; u < U; ++u) lf[0][u] = 0.f;                                \
+        } else if constexpr (PIN) {                                                                    \
           if (!slow_l) walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
           else walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
         } else {                                                                                       \
           if (!slow_l) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
           else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
         }                                                                                              \
+      } else if (pad_sg) {                                                                             \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) lf[0][u] = 0.f;                                  \
       } else {                                                                                         \
         if (!slow_l) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
         else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \

@@ -343,7 +343,9 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * "q16_persistent" (-1 = default: the persistent depth-8 rank-quantised kernel -- resident blocks that take tiles from a ticket
  * counter -- where it wins: one-vs-all models whose classes hold equally many trees, scored in ONE launch, and engines inside a
  * multi-rank job; 1 = wherever it fits; 0 = never), "q16_prepass_nt" (A/B: bit 0 / 1 = nontemporal stores / loads in the rank
- * pre-pass; measured no gain, default 0);
+ * pre-pass; measured no gain, default 0), "q16_walk_padding" (A/B: 0 = default, the plain rank-quantised kernels do not walk the
+ * EMPTY trees that pad the image to whole chunks -- their +0 leaves are added as always, the scores are the same bit for bit; 1 =
+ * walk them, as before round 4);
  * (environment DDT_DEBUG_PREPASS=1 prints the chosen plan -- groups, P, image bytes -- to stderr at load);
  * "class_streams" (1 = default: the per-class scoring launches of a multi-class model alternate between the caller's stream and
  * one stream of the engine, joined before the argmax / before the call's work is visible on the caller's stream; 0 = one stream);

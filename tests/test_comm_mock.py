@@ -18,6 +18,7 @@ import numpy as np
 import pytest
 
 import ddt
+from tests.mock_hip.build_lock import build_if_stale
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MOCK = os.path.join(HERE, "mock_hip")
@@ -31,9 +32,8 @@ def _build(name, comm_source):
     deps = [comm_source, os.path.join(MOCK, "mock_runtime.cpp"), os.path.join(MOCK, "mock_engine.cpp"), os.path.join(MOCK, "hip", "hip_runtime.h"),
             os.path.join(MOCK, "rccl", "rccl.h"),
             os.path.join(CSRC, "ddt_engine_priv.h"), os.path.join(CSRC, "ddt_internal.h")]
-    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wall", *san, "-I" + MOCK, "-I" + CSRC, comm_source,
-                               os.path.join(MOCK, "mock_engine.cpp"), "-o", out])
+    build_if_stale(out, deps, ["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-Wall", *san, "-I" + MOCK, "-I" + CSRC, comm_source,
+                               os.path.join(MOCK, "mock_engine.cpp")])
     L = C.CDLL(out)
     L.ddt_create.argtypes, L.ddt_destroy.argtypes, L.ddt_destroy.restype = [C.POINTER(vp), i32], [vp], None
     L.ddt_load_model_shard.argtypes = [vp, C.POINTER(ddt.Params), vp, sz, vp, sz, u32, u32]

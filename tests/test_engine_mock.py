@@ -20,6 +20,7 @@ import pytest
 import ddt
 from ddt import _lib
 from oracle import oracle as O
+from tests.mock_hip.build_lock import build_if_stale
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MOCK = os.path.join(HERE, "mock_hip")
@@ -37,8 +38,7 @@ def _build(name, engine_source=None):
     srcs = [engine_source or os.path.join(CSRC, "ddt_engine.cpp")] + [os.path.join(CSRC, f) for f in SOURCES[1:]] + [os.path.join(MOCK, "mock_kernels.cpp")]
     deps = srcs + [os.path.join(MOCK, "mock_runtime.cpp"), os.path.join(MOCK, "hip", "hip_runtime.h"), os.path.join(MOCK, "rccl", "rccl.h"),
                    os.path.join(CSRC, "ddt_engine_priv.h"), os.path.join(CSRC, "ddt_internal.h")]
-    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-w", *san, "-I" + MOCK, "-I" + CSRC, *srcs, "-o", out])
+    build_if_stale(out, deps, ["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-w", *san, "-I" + MOCK, "-I" + CSRC, *srcs])
     L = _lib.bind(C.CDLL(out))
     L.hipSetDevice.argtypes = [C.c_int]
     L.hipStreamCreateWithFlags.argtypes, L.hipStreamSynchronize.argtypes, L.hipStreamDestroy.argtypes = [C.POINTER(vp), C.c_uint], [vp], [vp]
@@ -317,8 +317,7 @@ def test_the_cli_host_program_on_the_model(mock, tmp_path):
     cli = os.path.join(MOCK, "ddt_cli_mock")
     so = os.path.join(MOCK, "libddt_host_mock.so")
     src = os.path.join(CSRC, "ddt_cli.cpp")
-    if not os.path.exists(cli) or os.path.getmtime(cli) < max(os.path.getmtime(src), os.path.getmtime(so)):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", src, "-o", cli, so, "-Wl,-rpath," + MOCK, "-pthread"])
+    build_if_stale(cli, [src, so], ["g++", "-std=c++17", "-O1", "-Wall", src, so, "-Wl,-rpath," + MOCK, "-pthread"])
     pre = str(tmp_path / "job")
     T, D, F, n = 96, 6, 28, 1203
     subprocess.check_call([cli, "gen", "--trees", str(T), "--levels", str(D), "--features", str(F), "--rows", str(n), "--dist", "1",
