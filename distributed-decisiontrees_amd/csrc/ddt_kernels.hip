@@ -1266,11 +1266,11 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   // and adds of one sub-group schedule into the next sub-group's walk: 21.90 vs 23.04 ms at 1000 trees x depth 8 x 20 M tuples
   // (profiles/r03_sweep_q16_hot_dispatch_d8.json; depth 6: equal).  Each path issues its own first record set: a set requested
   // in front of the dispatch would be copied into each path's registers while still in flight (tools/check_s2_isa.py).
-  auto chunks = [&](auto hot_tag) {
-    constexpr bool HOT = decltype(hot_tag)::value;
+  auto chunks = [&](auto hot_tag, auto exact_tag) {
+    constexpr bool HOT = decltype(hot_tag)::value, HOT_EXACT = decltype(exact_tag)::value;  // HOT_EXACT: the hot copy for sum_mode 2
     // (deferred folds -- a sub-group's leaves folded one sub-group later, so that the gathers of a chunk's last sub-group fly
     // across the chunk barrier, which then only waits for the DMA: 22.06 vs 21.84 ms, profiles/r03_sweep_q16_deferred_folds.json)
-    const bool slow_l = HOT ? false : slow, exact_l = HOT ? false : exact;
+    const bool slow_l = HOT ? false : slow, exact_l = HOT ? HOT_EXACT : exact;
     const int sum_l = HOT ? 0 : SUM1;
     if constexpr (S2) top_issue<TREE_BYTES>(top_a, img);
     for (uint32_t k = 0; k < n_chunks; k += 2) {
@@ -1288,10 +1288,11 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
     if constexpr (S2) top_wait(top_a);  // the last request (never used; it went to top_a) must not outlive the wave
   };
   if constexpr (HOTDISP) {
-    if (!slow && SUM1 == 0) chunks(std::true_type{});
-    else chunks(std::false_type{});
+    if (!slow && SUM1 == 0) chunks(std::true_type{}, std::false_type{});
+    else if (!slow && SUM1 == 2) chunks(std::true_type{}, std::true_type{});  // the reference adder: its suspect tests are the only branches
+    else chunks(std::false_type{}, std::false_type{});
   } else {
-    chunks(std::false_type{});
+    chunks(std::false_type{}, std::false_type{});
   }
 #undef DDT_QCOMPUTE
   ra.align(C);
@@ -1526,9 +1527,9 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
       if (tid == 0) lds_st_u32(PAD_WORD, ticket);
     };
 
-    auto chunks = [&](auto hot_tag) {
-      constexpr bool HOT = decltype(hot_tag)::value;
-      const bool slow_l = HOT ? false : slow, exact_l = HOT ? false : exact;
+    auto chunks = [&](auto hot_tag, auto exact_tag) {
+      constexpr bool HOT = decltype(hot_tag)::value, HOT_EXACT = decltype(exact_tag)::value;
+      const bool slow_l = HOT ? false : slow, exact_l = HOT ? HOT_EXACT : exact;
       top_issue<TREE_BYTES>(top_a, img);
       for (uint32_t k = 0; k < n_chunks; k += 2) {
         // (k == 0 behind the ring: chunk 0 arrived before the tile-end barrier; a vmcnt(0) here would only expose the HBM latency of the
@@ -1556,8 +1557,9 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
       }
       top_wait(top_a);  // the last request (never used; it went to top_a) must not outlive this pass
     };
-    if (!slow && SUM1 == 0) chunks(std::true_type{});
-    else chunks(std::false_type{});
+    if (!slow && SUM1 == 0) chunks(std::true_type{}, std::false_type{});
+    else if (!slow && SUM1 == 2) chunks(std::true_type{}, std::true_type{});
+    else chunks(std::false_type{}, std::false_type{});
 #undef DDT_QPCOMPUTE
     if constexpr (MULTI) {
       if (x.labels && row < a.n) x.labels[row] = arg;
