@@ -86,6 +86,7 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   // real tree; the rest -- EMPTY padding up to whole chunks, always at the image's end -- is not walked, its +0 leaves are added as
   // always (the result is the same bit for bit: an EMPTY tree's walk ends in a +0 leaf whatever the tuple).  0 = walk everything.
   uint32_t walk_subgroups = 0;
+  unsigned long long* dbg = nullptr;  // "_p" kernels, environment DDT_Q16P_PROFILE: per block 8 x 64-bit phase sums in 10 ns ticks (launch_q16p prints them)
   // "_p" (persistent) kernels.  The image may hold SEVERAL ensembles back to back ("segments": the classes of a one-vs-all model,
   // each padded to seg_chunks whole chunks, real_groups real PU groups in each): segment k's sum goes to out[k * n + row] and the
   // label (argmax over the segments, lowest index on ties, a NaN never beats a number) to labels[row].  n_segs == 1: plain scores.

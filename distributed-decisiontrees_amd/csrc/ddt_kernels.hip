@@ -23,7 +23,10 @@
 //   chain_sum_kernel, argmax_kernel, synth_tuples_kernel   multi-device combine, class labels, bench inputs.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "ddt_device.h"
 #include "ddt_internal.h"
@@ -1396,7 +1399,7 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
 // once per tuple (BASELINE config 5: K launches + an argmax pass before).  Per class the order of the adds is the reference's
 // (FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131, Core.sv:486-541): each segment is a cluster-major image of its own.
 // ---------------------------------------------------------------------------------------------------
-template <int D, int CT, int U, bool PIN, bool MULTI>
+template <int D, int CT, int U, bool PIN, bool MULTI, bool PROF = false>  // PROF: the diagnostic build of DDT_Q16P_PROFILE (launch_q16p), never the product's
 __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a, const Q16Aux x) {
   constexpr int THREADS = kQTile;
   constexpr bool GL = true;  // leaves gathered from the global image; levels 0-1 always from SGPRs (_s2)
@@ -1437,6 +1440,26 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
   bool slow = __builtin_amdgcn_readfirstlane((int)x.tile_flags[cur]) != 0;
   bool pre0 = false;  // chunk 0 of `cur` was requested during the previous tile's last chunk
   TopRecs<4> top_a, top_b;
+  // DDT_Q16P_PROFILE: where a tile's time goes, by wave 0's 100 MHz clock: [0] tile switch (loop top -> rank tile in LDS, next tile's
+  // ranks requested), [1] -> first chunk barrier passed, [2] -> last chunk walked, [3] -> tile-end barrier passed, [4] tiles
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};  // [5]: the first two chunks of the tile (the rest of the walk stays in [2])
+  unsigned long long t_mark = (PROF && x.dbg) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  // ... and per chunk index k < 128: [0] barrier passed -> chunk k walked, [1] chunk k-1 walked -> barrier of chunk k passed (global atomics)
+  unsigned long long t_chunk = (PROF && x.dbg) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  auto lapk = [&](uint32_t k, int which) {
+    if (PROF && x.dbg) {  // (the run-time test on top of the compile-time one: without it hipcc fails with "illegal VGPR to SGPR copy")
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (tid == 0 && k < 128u) atomicAdd(x.dbg + (size_t)gridDim.x * 8u + (size_t)which * 128u + k, now - t_chunk);
+      t_chunk = now;
+    }
+  };
+  auto lap = [&](int i) {
+    if (PROF && x.dbg) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      pt[i] += now - t_mark;
+      t_mark = now;
+    }
+  };
 
   for (;;) {
     const uint4* img = slow ? x.img_slow : a.img;
@@ -1452,6 +1475,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
       if (u < units) *reinterpret_cast<DDT_LDS(u32x4)*>((uint32_t)FEAT_OFF + u * 16u) = pre[i];
     }
     prefetch(pre, has_next ? nxt : cur);  // flies during this tile's walks
+    lap(0);
 
     const __amdgpu_buffer_rsrc_t leaf_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(img), 0, (int)(n_chunks * (uint32_t)(GCHUNK_UNITS * 16)), 0x00020000);
@@ -1536,16 +1560,20 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
         // next tile's ranks, requested a moment ago -- 4 us per tile)
         if (k != 0u || !pre0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // chunk k is in buffer 0 (k = 0: and the rank tile is in place); everyone is done with buffer 1
+        if (k == 0u) lap(1);
+        lapk(k, 1);
         const bool more1 = k + 1 < n_chunks;
         if (more1) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 1) * GSKIP, k + 1, CHUNK_BYTES, tid);
         else last_begin();
         DDT_QPCOMPUTE(0, k);
+        lapk(k, 0);
         if (!more1) {
           last_end();
           break;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        lapk(k + 1u, 1);
         const bool more2 = k + 2 < n_chunks;
         if (more2) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 2) * GSKIP, k + 2, 0, tid);
         else {
@@ -1553,6 +1581,8 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
           last_begin();
         }
         DDT_QPCOMPUTE(1, k + 1);
+        lapk(k + 1u, 0);
+        if (k == 0u) lap(5);
         if (!more2) last_end();
       }
       top_wait(top_a);  // the last request (never used; it went to top_a) must not outlive this pass
@@ -1566,12 +1596,15 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
     } else {
       if (row < a.n) a.out[row] = cm_total;
     }
+    lap(2);
+    if (PROF && x.dbg) ++pt[4];
     if (!has_next) break;
     // tile end: every walk of this tile is done (rank tile, chunk buffers), the ticket is in place -- and whatever this wave has
     // requested has arrived (the ring's chunk 0 of the next tile, requested a chunk ago): the next tile's first barrier then needs no
     // vmcnt wait and the ranks requested right behind this barrier stay in flight
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    lap(3);
     const uint32_t nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_u32(PAD_WORD));
     cur = nxt;
     nxt = nn;
@@ -1579,6 +1612,10 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
     pre0 = ring;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing requested may outlive the wave
+  if (PROF && x.dbg && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x.dbg[(size_t)blockIdx.x * 8u + (size_t)i] = pt[i];
+  }
 }
 
 template <int D, int CT, int U, bool PIN>
@@ -1604,6 +1641,39 @@ static hipError_t launch_q16p(const ScoreArgs& a, const Variant& v, hipStream_t 
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   uint64_t grid = 2ull * a.num_cus;  // two resident blocks per CU (LDS: 2 x 80 KiB at 32 words per tuple; 8 waves per SIMD)
   if (grid > tiles) grid = tiles;
+  if (getenv("DDT_Q16P_PROFILE")) {  // diagnostic: synchronous, prints the phase sums of this launch (see the kernel)
+    unsigned long long* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), grid * 64 + 2048) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemsetAsync(d, 0, grid * 64 + 2048, s);
+    x.dbg = d;
+    auto pkern = score_q16p_kernel<D, CT, U, PIN, false, true>;
+    if (multi) return hipErrorInvalidValue;  // (one ensemble per launch only)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(pkern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pkern, dim3((uint32_t)grid), dim3(kQTile), lds, s, a, x);
+    std::vector<unsigned long long> h(grid * 8 + 256);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h.data(), d, grid * 64 + 2048, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    double sum[6] = {0, 0, 0, 0, 0, 0}, mx_total = 0;
+    for (uint64_t b = 0; b < grid; ++b) {
+      double tot = 0;
+      for (int i = 0; i < 6; ++i) sum[i] += (double)h[b * 8 + i];
+      tot = (double)(h[b * 8] + h[b * 8 + 1] + h[b * 8 + 2] + h[b * 8 + 3] + h[b * 8 + 5]);
+      mx_total = tot > mx_total ? tot : mx_total;
+    }
+    const double tl = sum[4] > 0 ? sum[4] : 1;
+    fprintf(stderr, "{\"q16p_profile\": {\"blocks\": %llu, \"tiles\": %.0f, \"chunks_per_tile\": %u, \"us_per_tile\": {\"switch\": %.3f, \"to_first_barrier\": %.3f, "
+                    "\"first_two_chunks\": %.3f, \"other_chunks\": %.3f, \"tile_end_barrier\": %.3f}, \"slowest_block_ms\": %.3f, \"mean_block_ms\": %.3f}}\n",
+            (unsigned long long)grid, sum[4], a.n_chunks, sum[0] / tl * 0.01, sum[1] / tl * 0.01, sum[5] / tl * 0.01, sum[2] / tl * 0.01, sum[3] / tl * 0.01, mx_total * 1e-5,
+            (sum[0] + sum[1] + sum[2] + sum[3] + sum[5]) / (double)grid * 1e-5);
+    fprintf(stderr, "{\"q16p_chunk_us\": {\"walk\": [");
+    for (uint32_t k = 0; k < a.n_chunks && k < 128u; ++k) fprintf(stderr, "%s%.3f", k ? ", " : "", (double)h[grid * 8 + k] / tl * 0.01);
+    fprintf(stderr, "], \"wait_before\": [");
+    for (uint32_t k = 0; k < a.n_chunks && k < 128u; ++k) fprintf(stderr, "%s%.3f", k ? ", " : "", (double)h[grid * 8 + 128 + k] / tl * 0.01);
+    fprintf(stderr, "]}}\n");
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(kQTile), lds, s, a, x);
   return hipGetLastError();
 }
