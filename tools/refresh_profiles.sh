@@ -13,6 +13,10 @@ python tools/prof_summary.py ${R}_final_bench_cfg3 --stats $E/stats_cfg3 --pmc $
   --levels 8 --features 32 --cmd "python bench.py --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-streamed" > /dev/null
 python tools/prof_summary.py ${R}_final_bench_cfg4 --stats $E/stats_cfg4 --pmc $E/fetch_cfg4 $E/write_cfg4 --kernel score_sparse --rows 10000000 --trees 512 \
   --levels 12 --features 64 --cmd "python bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline --no-streamed" > /dev/null
+if [ -d $E/stats_cfg1 ]; then
+  python tools/prof_summary.py ${R}_final_bench_cfg1 --stats $E/stats_cfg1 --pmc $E/fetch_cfg1 $E/write_cfg1 --kernel score_stream --rows 200000000 --trees 8 \
+    --levels 4 --features 16 --cmd "python bench.py --config 1 --steps 10 --warmup 3 --no-cpu-baseline --no-streamed" > /dev/null
+fi
 grep "score_q16\|rank_kernel\|transpose_k\|score_sparse" profiles/${R}_final_bench_cfg3.md profiles/${R}_final_bench_cfg4.md | cut -c1-200 | head
 if [ -d $E/pmc_q16 ]; then
   python tools/prof_summary.py ${R}_pmc_q16_x --stats $E/pmc_q16/stats --pmc $E/pmc_q16/pmc1 $E/pmc_q16/pmc2 $E/pmc_q16/pmc3 --kernel score_q16 --rows 8000000 \

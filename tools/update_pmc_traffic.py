@@ -49,6 +49,19 @@ def main():
          "source": f"{ev} (tools/gpu_evidence.sh): `{cmd.format(3)}`"}
     json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print("config 3: scoring kernel", j["hbm_bytes_per_launch"], "B/launch; whole step", step, "B;", pre)
+    # ---- config 1: stream kernel (each tuple read once, each score written once) ----------------------------------------
+    f, w = pmc(ev + "/fetch_cfg1", "score_stream"), pmc(ev + "/write_cfg1", "score_stream")
+    if f and w:
+        fr1, wr1 = kib(f, "FETCH_SIZE"), kib(w, "WRITE_SIZE")
+        j1 = {"rows": 200000000, "trees": 8, "kernel": "score_stream_kernel<4,4,4> (stream_d4_u4_l4, phased result stores)",
+              "fetch_bytes_raw_per_launch": fr1, "fetch_bytes_x2_corrected_per_launch": 2 * fr1, "write_bytes_per_launch": wr1,
+              "hbm_bytes_per_launch": 2 * fr1 + wr1, "step_hbm_bytes_x2_corrected": 2 * fr1 + wr1,
+              "algorithmic_bytes_per_launch": 200000000 * 68,
+              "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of the config-1 bench command, averaged over the launches of "
+                      "the stream kernel; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950 (16 B/lane nontemporal loads).",
+              "round": 4, "source": f"{ev} (tools/gpu_evidence_slim.sh): `python bench.py --config 1 --steps 10 --warmup 3 --no-cpu-baseline --no-streamed`"}
+        json.dump(j1, open(os.path.join(ROOT, "profiles", "pmc_traffic_cfg1.json"), "w"), indent=1)
+        print("config 1:", j1["hbm_bytes_per_launch"], "B/launch against", j1["algorithmic_bytes_per_launch"], "algorithmic")
     # ---- config 4: sparse forest -----------------------------------------------------------------------------------
     p4 = os.path.join(ROOT, "profiles", "pmc_traffic_cfg4.json")
     c4 = json.load(open(p4))
