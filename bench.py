@@ -389,7 +389,7 @@ def main(argv=None, inproc_env=None):
             # 2 conflict-free DS wave-instructions per 64 visits at 2 LDS cycles each (MI355X_MICROARCH.md, LDS table)
             roofline["lds_ceiling_visits_per_s"] = info.num_cus * clock_hz * 64 / 4
             # VALU issue bound of the lane = tuple mapping: a wave instruction takes ~4 cycles on its SIMD (16 lanes per cycle; tools/ubench valu,
-            # profiles/r03_ubench_valu.json) and the shipped depth-8 walk spends 4.36 of them per node visit (profiles/r03_pmc_q16_gl_s2.md)
+            # profiles/archive/r03_ubench_valu.json) and the shipped depth-8 walk spends 4.36 of them per node visit (profiles/archive/r03_pmc_q16_gl_s2.md)
             roofline["valu_issue_bound_visits_per_s"] = round(info.num_cus * 4 * clock_hz / (4.0 * 4.36) * 64, 1)
             # the BARE depth-8 walk of round 3 (no DMA, no barriers, model resident in LDS; hipcc's own read order: two chains in flight per lane),
             # measured on an MI355X and committed -- round 4's pinned read order (four chains in flight) runs the PRODUCT kernel above it

@@ -444,7 +444,7 @@ uint32_t total_trees(const ddt_engine* e) {
 
 constexpr uint32_t kQ16MinTreeLevels = 480;  // trees x levels from which the rank-quantised path wins with the LDS-resident pre-pass
                                              // (profiles/archive/r02_sweep_q16_small.json: 60 x d8 +4 %, 80 x d8 +5 %, 112 x d8 +7 %, 200 x d6 +9 %; round 3 with the _s2 walk,
-                                             // profiles/r03_sweep_fused_rank_experiment_ilp8_s2.json: 100 x d6 +17 %, 100 x d8 +11 %, while 30 x d6 still loses 15 %)
+                                             // profiles/archive/r03_sweep_fused_rank_experiment_ilp8_s2.json: 100 x d6 +17 %, 100 x d8 +11 %, while 30 x d6 still loses 15 %)
 
 // a one-vs-all model whose classes hold equally many trees on this engine: their images can stand back to back (select_and_build)
 bool classes_equal(const ddt_engine* e) {

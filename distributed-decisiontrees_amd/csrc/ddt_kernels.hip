@@ -363,7 +363,7 @@ constexpr uint32_t kStreamResWant = 10, kStreamFewVisits = 64;  // ... models of
 constexpr uint32_t kStreamWindowTicks = 3000;              // ... and the write window's period in 10 ns ticks (30 us)
 
 // FIXED: the tuple has exactly MAXLPT lines (config 1: 16 features = 4 lines), so element -> (tuple, line) is a shift and the
-// sixteen LDS stores of a thread share one address register.  Round 3 counters (profiles/r03_pmc_stream_cfg1.md) showed this
+// sixteen LDS stores of a thread share one address register.  Round 3 counters (profiles/archive/r03_pmc_stream_cfg1.md) showed this
 // kernel VALU-bound, not HBM-bound: 488 VALU instructions per tuple = 92 % VALU issue; staging (runtime division, per-word
 // missing bookkeeping) and the accumulator ring's align() were 60 % of them.
 template <int D, int U, int MAXLPT, bool FIXED>
@@ -1267,12 +1267,12 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   // HOT (the _s2 kernels): the common case -- no missing value in the tile, sum_mode 0 -- is dispatched ONCE into a copy of the
   // chunk loop without the per-sub-group branches on `slow` / the sum mode; a chunk is then one basic block and the leaf gathers
   // and adds of one sub-group schedule into the next sub-group's walk: 21.90 vs 23.04 ms at 1000 trees x depth 8 x 20 M tuples
-  // (profiles/r03_sweep_q16_hot_dispatch_d8.json; depth 6: equal).  Each path issues its own first record set: a set requested
+  // (profiles/archive/r03_sweep_q16_hot_dispatch_d8.json; depth 6: equal).  Each path issues its own first record set: a set requested
   // in front of the dispatch would be copied into each path's registers while still in flight (tools/check_s2_isa.py).
   auto chunks = [&](auto hot_tag, auto exact_tag) {
     constexpr bool HOT = decltype(hot_tag)::value, HOT_EXACT = decltype(exact_tag)::value;  // HOT_EXACT: the hot copy for sum_mode 2
     // (deferred folds -- a sub-group's leaves folded one sub-group later, so that the gathers of a chunk's last sub-group fly
-    // across the chunk barrier, which then only waits for the DMA: 22.06 vs 21.84 ms, profiles/r03_sweep_q16_deferred_folds.json)
+    // across the chunk barrier, which then only waits for the DMA: 22.06 vs 21.84 ms, profiles/archive/r03_sweep_q16_deferred_folds.json)
     const bool slow_l = HOT ? false : slow, exact_l = HOT ? HOT_EXACT : exact;
     const int sum_l = HOT ? 0 : SUM1;
     if constexpr (S2) top_issue<TREE_BYTES>(top_a, img);

@@ -114,7 +114,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
     //      chains: the gather of tree u's next record is issued right after ITS visit, in a fixed order and UNCONDITIONALLY (a
     //      finished lane re-reads record 0: one shared line), so that hipcc counts the loads and every visit waits with vmcnt(U-1)
     //      for the oldest one only.  (Round 2's form -- all U visits, then all U gathers back to back -- left the queue empty
-    //      during the visits: 212 vs 237 Mtuples/s on BASELINE config 4, profiles/r03_sparse_schedules_and_blocks.json.)
+    //      during the visits: 212 vs 237 Mtuples/s on BASELINE config 4, profiles/archive/r03_sparse_schedules_and_blocks.json.)
     //      The gathers go through a buffer resource: 32-bit byte offsets (the host keeps the deep array below 2^28 records), no
     //      64-bit address arithmetic on the VALU.
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(deep), 0, (int)x.deep_bytes, 0x00020000);

@@ -36,7 +36,7 @@ int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {
   char name[40];
   // Rank-quantised kernels first (option "sparse_q16", default on): a u16 feature tile is half the LDS per tuple, so one block of
   // 1024 tuples = 16 waves holds the CU that the fp32 tile fills with 512 = 8; the deep phase is latency-bound and takes the
-  // walkers (BASELINE config 4: profiles/r03_sweep_sparse_q.json).  Largest K whose top images fit next to the tile.
+  // walkers (BASELINE config 4: profiles/archive/r03_sweep_sparse_q.json).  Largest K whose top images fit next to the tile.
   if (e->sparse_q16 && ranks_fit) {
     const int kq = e->sparse_top_levels >= 0 ? e->sparse_top_levels : (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, kSparseMinTop), kSparseMaxTop);
     for (int K = kq; K >= (e->sparse_top_levels >= 0 ? kq : kSparseMinTop); --K)
@@ -63,7 +63,7 @@ int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {
   // images fit next to the feature tile.
   static const struct { int T; uint32_t blocks; } geo[] = {{256, 2}, {512, 1}, {128, 4}, {256, 1}, {128, 2}, {128, 1}, {64, 2}, {64, 1}};
   // The largest K wins, where a geometry with two or more blocks per CU counts one level more (one block's top phase overlaps the
-  // others' deep phase: BASELINE config 4, profiles/r03_sparse_dense_level_k.json -- K = 8 in two blocks 256.6 Mtuples/s, K = 9 in one
+  // others' deep phase: BASELINE config 4, profiles/archive/r03_sparse_dense_level_k.json -- K = 8 in two blocks 256.6 Mtuples/s, K = 9 in one
   // 243.4, K = 8 in one 232.5); ties go to the earlier geometry.
   int best = -1, best_score = -1;
   uint32_t best_waves = 0;

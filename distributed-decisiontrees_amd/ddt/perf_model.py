@@ -59,7 +59,7 @@ class Mi355x:
     cus: int = 256
     clock_hz: float = 2.4e9
     hbm_bytes_per_s: float = 8.0e12        # spec peak; ~6.3e12 achievable (MI355X_MICROARCH.md)
-    ds_ops_per_visit: float = 1.75         # the shipped _gl_s2 walk (profiles/r03_pmc_q16_gl_s2.md: 1.75 DS + 4.36 VALU per visit)
+    ds_ops_per_visit: float = 1.75         # the shipped _gl_s2 walk (profiles/archive/r03_pmc_q16_gl_s2.md: 1.75 DS + 4.36 VALU per visit)
     lds_cycles_per_ds_op: float = 2.48     # measured incl. bank conflicts
     lds_efficiency: float = 0.93           # achieved / LDS-pipe ceiling: 8.4-8.5 T visits/s of 9.06 T (round 4, pinned read order: four chains in
                                            # flight per lane); the VALU issue bound, 4 cycles x 4.36 instructions per visit = 9.0 T/s, is as near
@@ -74,7 +74,7 @@ def lds_visit_ceiling(g: Mi355x) -> float:
     return g.cus * g.clock_hz * 64.0 / (g.ds_ops_per_visit * g.lds_cycles_per_ds_op)
 
 
-# VALU instructions per node visit of the shipped rank-quantised walks (rocprofv3 SQ_INSTS_VALU / visits: profiles/r03_pmc_q16_gl_s2.md depth 8,
+# VALU instructions per node visit of the shipped rank-quantised walks (rocprofv3 SQ_INSTS_VALU / visits: profiles/archive/r03_pmc_q16_gl_s2.md depth 8,
 # r03_pmc_cfg2_q16.md depth 6); other depths: the walk's 4 + per-tree work (leaf read, adder tree, scalar levels) spread over D visits
 VALU_PER_VISIT = {8: 4.36, 6: 5.61}
 
@@ -210,7 +210,7 @@ def hybrid_ms(trees: int, tree_ranks: int, row_groups: int, depth: int = 8, rows
 # ---- part 4: sparse forests (config 4): the vector-memory lane-address ceiling ---------------------------------
 @dataclass
 class SparseCosts:
-    """Measured on one MI355X (profiles/r03_sparse_dense_level_k.json, r03_sparse_schedules_and_blocks.json; round 2:
+    """Measured on one MI355X (profiles/archive/r03_sparse_dense_level_k.json, r03_sparse_schedules_and_blocks.json; round 2:
     r02_pmc_sparse_k8_t512.md): the deep phase gathers one 16-byte record per lane and visit; the vector-memory path takes about ONE
     lane address per cycle and CU."""
     lane_addresses_per_cycle_per_cu: float = 1.0

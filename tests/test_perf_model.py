@@ -81,7 +81,7 @@ def test_what_masked_cus_cost_matches_the_probe():
 
 
 def test_sparse_forest_model_matches_the_config4_measurement():
-    """profiles/r03_sparse_dense_level_k.json: 512 sparse trees, 12.06 visits per tuple and tree, K = 8 in two blocks per CU -> 256.6
+    """profiles/archive/r03_sparse_dense_level_k.json: 512 sparse trees, 12.06 visits per tuple and tree, K = 8 in two blocks per CU -> 256.6
     Mtuples/s measured (round 2, one phase-locked block, two-phase deep rounds: 213.7)."""
     r = P.predict_sparse(512, 12.059, top_levels=8)
     assert abs(r["mtuples_per_s"] - 256.6) / 256.6 < 0.1
