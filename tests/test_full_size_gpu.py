@@ -53,18 +53,21 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-# (config, T, D, F, rows, P, dist): the bench's own synthetic models (ddt.synth_model seed 0) and shapes
+# (config, T, D, F, rows, P, dist, sum_mode): the bench's own synthetic models (ddt.synth_model seed 0) and shapes; sum_mode 2 = the
+# reference's own adder (FPAdder_2cycles_latency.v:210-387) against the oracle's bit-level model of it (slower: a shorter period)
 DENSE = [
-    pytest.param(1, 8, 4, 16, 200_000_000, 1_000_003, 0, id="config1-200M"),
-    pytest.param(2, 100, 6, 28, 10_000_000, 1_000_003, 0, id="config2-10M"),
-    pytest.param(3, 1000, 8, 32, 100_000_000, 1_000_003, 0, id="config3-100M"),
-    pytest.param(3, 1000, 8, 32, 20_000_000, 300_007, 1, id="config3-20M-missing-values"),
-    pytest.param(1, 8, 4, 16, 50_000_000, 300_007, 1, id="config1-50M-missing-values"),
+    pytest.param(1, 8, 4, 16, 200_000_000, 1_000_003, 0, 0, id="config1-200M"),
+    pytest.param(2, 100, 6, 28, 10_000_000, 1_000_003, 0, 0, id="config2-10M"),
+    pytest.param(3, 1000, 8, 32, 100_000_000, 1_000_003, 0, 0, id="config3-100M"),
+    pytest.param(3, 1000, 8, 32, 20_000_000, 300_007, 1, 0, id="config3-20M-missing-values"),
+    pytest.param(1, 8, 4, 16, 50_000_000, 300_007, 1, 0, id="config1-50M-missing-values"),
+    pytest.param(3, 1000, 8, 32, 100_000_000, 300_007, 0, 2, id="config3-100M-reference-adder"),
+    pytest.param(2, 100, 6, 28, 10_000_000, 300_007, 1, 2, id="config2-10M-reference-adder-missing-values"),
 ]
 
 
-@pytest.mark.parametrize("config,T,D,F,rows,P,dist", DENSE)
-def test_every_row_of_the_full_batch_is_the_oracles(eng, config, T, D, F, rows, P, dist):
+@pytest.mark.parametrize("config,T,D,F,rows,P,dist,sum_mode", DENSE)
+def test_every_row_of_the_full_batch_is_the_oracles(eng, config, T, D, F, rows, P, dist, sum_mode):
     import torch
 
     if dist == 0:
@@ -74,13 +77,13 @@ def test_every_row_of_the_full_batch_is_the_oracles(eng, config, T, D, F, rows, 
         m = O.gen_model(T, D, F, dist=1)
     p = m.params
     eng.set_option("variant", -1)
-    eng.load_model(ddt.make_params(p.num_trees, p.num_levels, p.num_features, p.missing_bits, p.cmp_mode, p.clusters_per_tuple, 0), m.wlines, m.flines)
+    eng.load_model(ddt.make_params(p.num_trees, p.num_levels, p.num_features, p.missing_bits, p.cmp_mode, p.clusters_per_tuple, sum_mode), m.wlines, m.flines)
     base = O.gen_tuples(17, P, F, dist=dist, missing_bits=p.missing_bits)
     d = _periodic(base, rows)
     out = torch.full((rows,), float("nan"), dtype=torch.float32, device="cuda")
     eng.score_device(d, out=out)
     torch.cuda.synchronize()
-    want = O.score_fast(m, base, sum_mode=O.SUM_REF_NATIVE)
+    want = O.score_fast(m, base, sum_mode=O.SUM_REF_FLOPOCO if sum_mode == 2 else O.SUM_REF_NATIVE)
     assert np.array_equal(_bits(out[:P].cpu().numpy()), _bits(want)), f"config {config}: the first period differs from the oracle"
     _assert_periodic(out.view(torch.int32), P, f"config {config} ({eng.info().variant_name.decode()})")
     del d, out
