@@ -1014,7 +1014,8 @@ void fill_args(const ddt_engine* e, const Ensemble& m, const void* d_tuples, siz
   a->num_cus = e->prop.multiProcessorCount > 0 ? (uint32_t)e->prop.multiProcessorCount : 256u;
   a->stream_blocks_per_cu = (uint32_t)e->stream_blocks_per_cu;
   a->stream_res_tiles = (uint32_t)e->stream_res_tiles;
-  a->stream_window_ticks = (uint32_t)e->stream_window_ticks;
+  // (default: a window every 30 us, in ticks of the device's wall clock)
+  a->stream_window_ticks = e->stream_window_ticks ? (uint32_t)e->stream_window_ticks : (uint32_t)(30ull * (uint64_t)e->wall_clock_khz / 1000ull);
   a->stream_res_off = 0;
 }
 
@@ -1383,6 +1384,9 @@ int ddt_create(ddt_engine** out, int device_id) {
   if (!dg.ok) return DDT_EHIP;
   if (hipGetDeviceProperties(&e->prop, device_id) != hipSuccess) return DDT_EHIP;
   if (strncmp(e->prop.gcnArchName, "gfx950", 6) != 0) return DDT_ENODEVICE;  // kernels are built for gfx950 only
+  int khz = 0;  // the constant clock behind s_memrealtime (100 MHz on MI355X): the stream kernel's write windows are timed by it
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id) == hipSuccess && khz > 0) e->wall_clock_khz = khz;
+  else (void)hipGetLastError();
   *out = e.release();
   return DDT_OK;
 }

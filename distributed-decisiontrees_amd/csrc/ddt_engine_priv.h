@@ -159,6 +159,7 @@ struct ddt_engine {
   int class_streams = 1;
   bool q16_walk_padding = false;  // option "q16_walk_padding" (A/B): walk the EMPTY padding trees of the last chunk as well
   int stream_blocks_per_cu = 0;  // option "stream_blocks_per_cu": persistent stream kernel, blocks per CU (0 = resident blocks)
+  int wall_clock_khz = 100000;   // hipDeviceAttributeWallClockRate: the clock s_memrealtime counts (10 ns ticks on MI355X)
   int stream_res_tiles = 0;      // option "stream_res_tiles": stream kernel, score slots per wave for the phased result stores (0 = auto, 1 = direct stores)
   int stream_window_ticks = 0;   // option "stream_window_ticks": ... write window in 10 ns ticks (0 = default)
   // sparse forests (ddt_load_model_sparse)

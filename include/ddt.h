@@ -353,7 +353,7 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * forces the number: A/B switch), "stream_res_tiles" / "stream_window_ticks" (the stream kernel's phased result stores: every
  * wave parks its scores in LDS and all waves of the chip write them in the same short window, so that the HBM serves an unmixed
  * read stream in between; 0 = default: as many score slots as the LDS leaves / a window every 30 us; stream_res_tiles 1 = direct
- * stores, n = at most n slots; stream_window_ticks in 10 ns ticks of the device's constant 100 MHz clock), "reserve_rows" (pre-size the
+ * stores, n = at most n slots; stream_window_ticks in ticks of the device's wall clock -- hipDeviceAttributeWallClockRate, 100 MHz = 10 ns on MI355X), "reserve_rows" (pre-size the
  * workspace of the rank-quantised path for calls of up to that many rows: the *_device calls then never allocate),
  * "leaf_domain_check" (1 = default: refuse -0 / sub-normal / Inf / NaN leaves in the reference-order sum, where the
  * GPU's IEEE adds and the reference's adder differ), "sparse_top_levels" (-1 = auto, or 6..10 levels of a sparse

@@ -49,6 +49,8 @@ hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int device);
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 10017 };
+hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t attr, int device);
 hipError_t hipGetLastError(void);
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
 hipError_t hipHostFree(void* p);

@@ -427,6 +427,13 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
   enqueue(s, op);
   return hipSuccess;
 }
+hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t attr, int device) {
+  if (device < 0 || device >= g_devices) return hipErrorInvalidDevice;
+  if (attr != hipDeviceAttributeWallClockRate) return hipErrorInvalidValue;
+  *value = 100000;  // kHz: the constant 100 MHz clock s_memrealtime reads
+  return hipSuccess;
+}
+
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int device) {
   if (device < 0 || device >= g_devices) return hipErrorInvalidDevice;
   memset(p, 0, sizeof(*p));
