@@ -148,22 +148,37 @@ struct RefAcc {
 // then acc <- s + acc on the group's cluster; with IEEE adds (sum_mode 0), or `exact` (sum_mode 2) = the reference adder
 // itself: the IEEE adds run as always, every result is tested with sum_suspect(), and only a wave in which some lane
 // trips the test recomputes the group with radd_exact() (a wave-uniform branch around the rare path).
+// maximum of the low 16 bits of three registers (inline asm: written as a C++ maximum of uint16_t, hipcc emits v_cmp_gt_u32_sdwa +
+// v_cndmask per operand)
+__device__ __forceinline__ uint32_t max3_lo16(uint32_t p, uint32_t q, uint32_t r) {
+  uint32_t d;
+  asm("v_max3_u16 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(q), "v"(r));
+  return d;
+}
+__device__ __forceinline__ uint32_t fbits(float v) { return __float_as_uint(v); }
+
+// EX (sum_mode 2): every IEEE sum of the fold has to pass sum_suspect().  Round 4: not one v_cmp_eq_u16 per sum, but the running
+// MAXIMUM of the sums' low 16 bits -- 0xFFFF iff some sum is suspect -- taken two sums per v_max3_u16, and ONE test per fold.
 template <int U, int R, bool EX>
 __device__ __forceinline__ void fold_ref(const float (&lf)[R][U], const int phase, const uint32_t C, RefAcc<R>& ra) {
-  bool sus = false;
-  auto add = [&](float x, float y) -> float {
-    const float v = x + y;
-    if (EX) sus = sus || sum_suspect(v);
-    return v;
-  };
+  uint32_t mx = 0u;  // EX only
+  auto any_suspect = [&]() -> bool { return __ballot((uint16_t)mx == (uint16_t)0xFFFFu) != 0ull; };  // wave-uniform
   if (U == 8) {
-    float s[R], acc_new[R];
+    float acc_new[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      s[r] = add(add(add(lf[r][0], lf[r][1]), add(lf[r][2], lf[r][3])), add(add(lf[r][4 % U], lf[r][5 % U]), add(lf[r][6 % U], lf[r][7 % U])));
-      acc_new[r] = add(s[r], ra.a[r][0]);
+      const float s1 = lf[r][0] + lf[r][1], s2 = lf[r][2] + lf[r][3], s3 = s1 + s2;
+      const float s4 = lf[r][4 % U] + lf[r][5 % U], s5 = lf[r][6 % U] + lf[r][7 % U], s6 = s4 + s5, s7 = s3 + s6;
+      acc_new[r] = s7 + ra.a[r][0];
+      if (EX) {
+        mx = r == 0 ? max3_lo16(fbits(s1), fbits(s2), fbits(s3)) : max3_lo16(mx, fbits(s1), fbits(s2));
+        if (r != 0) mx = max3_lo16(mx, fbits(s3), fbits(s3));
+        mx = max3_lo16(mx, fbits(s4), fbits(s5));
+        mx = max3_lo16(mx, fbits(s6), fbits(s7));
+        mx = max3_lo16(mx, fbits(acc_new[r]), fbits(acc_new[r]));
+      }
     }
-    if (EX && __ballot(sus) != 0ull) {
+    if (EX && any_suspect()) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const float e = radd_exact(radd_exact(radd_exact(lf[r][0], lf[r][1]), radd_exact(lf[r][2], lf[r][3])),
@@ -175,8 +190,15 @@ __device__ __forceinline__ void fold_ref(const float (&lf)[R][U], const int phas
   } else if (phase == 0) {
     float p[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) p[r] = add(add(lf[r][0], lf[r][1]), add(lf[r][2], lf[r][3]));
-    if (EX && __ballot(sus) != 0ull) {
+    for (int r = 0; r < R; ++r) {
+      const float s1 = lf[r][0] + lf[r][1], s2 = lf[r][2] + lf[r][3];
+      p[r] = s1 + s2;
+      if (EX) {
+        mx = r == 0 ? max3_lo16(fbits(s1), fbits(s2), fbits(p[r])) : max3_lo16(mx, fbits(s1), fbits(s2));
+        if (r != 0) mx = max3_lo16(mx, fbits(p[r]), fbits(p[r]));
+      }
+    }
+    if (EX && any_suspect()) {
 #pragma unroll
       for (int r = 0; r < R; ++r) p[r] = radd_exact(radd_exact(lf[r][0], lf[r][1]), radd_exact(lf[r][2], lf[r][3]));
     }
@@ -185,8 +207,16 @@ __device__ __forceinline__ void fold_ref(const float (&lf)[R][U], const int phas
   } else {
     float acc_new[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc_new[r] = add(add(ra.half[r], add(add(lf[r][0], lf[r][1]), add(lf[r][2], lf[r][3]))), ra.a[r][0]);
-    if (EX && __ballot(sus) != 0ull) {
+    for (int r = 0; r < R; ++r) {
+      const float s1 = lf[r][0] + lf[r][1], s2 = lf[r][2] + lf[r][3], s3 = s1 + s2, s4 = ra.half[r] + s3;
+      acc_new[r] = s4 + ra.a[r][0];
+      if (EX) {
+        mx = r == 0 ? max3_lo16(fbits(s1), fbits(s2), fbits(s3)) : max3_lo16(mx, fbits(s1), fbits(s2));
+        if (r != 0) mx = max3_lo16(mx, fbits(s3), fbits(s3));
+        mx = max3_lo16(mx, fbits(s4), fbits(acc_new[r]));
+      }
+    }
+    if (EX && any_suspect()) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
         acc_new[r] = radd_exact(radd_exact(ra.half[r], radd_exact(radd_exact(lf[r][0], lf[r][1]), radd_exact(lf[r][2], lf[r][3]))), ra.a[r][0]);
