@@ -63,7 +63,8 @@ class Mi355x:
     lds_cycles_per_ds_op: float = 2.48     # measured incl. bank conflicts
     lds_efficiency: float = 0.93           # achieved / LDS-pipe ceiling: 8.4-8.5 T visits/s of 9.06 T (round 4, pinned read order: four chains in
                                            # flight per lane); the VALU issue bound, 4 cycles x 4.36 instructions per visit = 9.0 T/s, is as near
-    hbm_efficiency: float = 0.60           # streaming kernel, measured on config 1
+    hbm_efficiency: float = 0.715          # streaming kernel with phased result stores, measured on config 1 (5.73 TB/s of 8; round 3, direct stores: 0.60)
+    prepass_hbm_efficiency: float = 0.60   # the rank pre-pass's 2 : 1 read : write mix (4.7-5.0 TB/s: profiles/r04_stream_phased_stores.md section 4)
     allreduce_alg_bytes_per_s: float = 87e9  # ring over xGMI: ~153 GB/s link x 8/14; NOT measured: no multi-GPU box
     rccl_cus: int = 32                       # CUs a collective's kernels hold while it runs -- an ASSUMPTION (RCCL's channel count on this
                                              # node is unknown until the driver's 8-GPU run); what k CUs cost is measured: collective_cu_slowdown()
@@ -93,7 +94,7 @@ def predict(g: Mi355x, n_trees: int, depth: int, n_features: int, n_gpus: int = 
     t_lds = rows * visits / (lds_visit_ceiling(g) * g.lds_efficiency)
     t_hbm = rows * (4 * n_features + 4) / (g.hbm_bytes_per_s * g.hbm_efficiency)
     t_walk = max(t_valu, t_lds)
-    t_pre = rows * 6 * n_features / (g.hbm_bytes_per_s * g.hbm_efficiency) if visits >= 480 else 0.0
+    t_pre = rows * 6 * n_features / (g.hbm_bytes_per_s * g.prepass_hbm_efficiency) if visits >= 480 else 0.0
     t_score = max(t_walk, t_hbm) + t_pre
     t_comm = 0.0 if n_gpus == 1 else rows * 4 / g.allreduce_alg_bytes_per_s
     t = max(t_score, t_comm) + (0.0 if n_gpus == 1 else min(t_score, t_comm) / 8.0)  # 8 pipelined chunks: one is exposed
