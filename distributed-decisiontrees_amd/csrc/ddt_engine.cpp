@@ -6,6 +6,7 @@
 // rtl/DTEngine/PCIeReceiver.sv:136-139,230-312; line packing rtl/DTEngine/core/PipelinedMUX.sv:65;
 // model store rtl/DTEngine/core/DTPU.sv:282-354; result packing rtl/DTEngine/ResultsCombiner.sv:136-160.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -457,10 +458,23 @@ bool classes_equal(const ddt_engine* e) {
 // DDT_DISABLE_S2=1 in the environment: the AUTOMATIC choice skips the kernels that keep node records in SGPRs filled by inline-asm
 // scalar loads ("_s2", opt bit 1 of the rank-quantised kernels) -- for a build whose tools/check_s2_isa.py could not run (no
 // disassembler on the build machine: __graft_entry__.build() says so).  A forced "variant" still takes them.
+// The build itself can switch them off too: when __graft_entry__.build() could not run the check it leaves the marker file S2_UNCHECKED next to
+// libddt.so (and removes it once a check has passed); DDT_DISABLE_S2=0 overrides the marker (an explicit opt-in to the unchecked kernels).
 bool s2_disabled() {
   static const bool off = [] {
     const char* v = getenv("DDT_DISABLE_S2");
-    return v && v[0] && v[0] != '0';
+    if (v && v[0]) return v[0] != '0';
+    Dl_info di;
+    if (dladdr(reinterpret_cast<const void*>(&ddt_num_variants), &di) && di.dli_fname) {
+      std::string path(di.dli_fname);
+      const size_t slash = path.rfind('/');
+      path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/S2_UNCHECKED";
+      if (FILE* f = fopen(path.c_str(), "r")) {
+        fclose(f);
+        return true;
+      }
+    }
+    return false;
   }();
   return off;
 }
@@ -526,7 +540,10 @@ int auto_variant(const ddt_engine* e) {
     //         +4 % on the shards; its single accumulator + running total also serves one cluster.
     if (e->p.sum_mode != 1u && !s2_disabled()) {
       const int ip = find_variant("q16_d8_c8_u4_gl_s2_cm_p");
-      if (ip >= 0 && variant_fits(variant(ip), e) && e->q16_persistent != 0 && (e->q16_persistent == 1 || classes_equal(e) || e->collective_job)) return ip;
+      // (a one-vs-all model with UNEQUAL classes is one launch per class whatever the kernel: the plain launch then, also inside a job)
+      if (ip >= 0 && variant_fits(variant(ip), e) && e->q16_persistent != 0 &&
+          (e->q16_persistent == 1 || classes_equal(e) || (e->collective_job && e->num_classes == 1)))
+        return ip;
       const int ix = find_variant("q16_d8_c8_u4_gl_s2_cm_x");
       if (ix >= 0 && variant_fits(variant(ix), e)) return ix;
     }
@@ -1129,7 +1146,15 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
       qa.n_segs = e->num_classes;
       qa.seg_chunks = e->mc_seg_chunks;
       qa.labels = labels;
-      qa.seg_tail_empty = (m.trees() % 8u >= 1u && m.trees() % 8u <= 4u) ? 1u : 0u;  // the classes' last sub-group is all padding
+      // trees per class mod 8 in 1..4: the second sub-group of the partly filled PU group is all padding.  That group is the last of its
+      // CLUSTER's run in the cluster-major image (cm_position), which is the image's end only for some (trees, clusters): the kernel is
+      // told the chunk (one PU group per chunk at CT = 8) instead of assuming the last one
+      qa.seg_tail_left = 0u;
+      if (m.trees() % 8u >= 1u && m.trees() % 8u <= 4u && (uint32_t)v.chunk_trees == 8u) {
+        const uint32_t Cc = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u;
+        const uint32_t pos_chunk = cm_position((m.trees() - 1u) / 8u * 8u, m.trees(), Cc) / 8u;
+        qa.seg_tail_left = e->mc_seg_chunks - pos_chunk;
+      }
     }
     a.aux = &qa;
   }
@@ -1198,7 +1223,10 @@ int launch_classify(ddt_engine* e, const void* d_tuples, size_t n, float* d_clas
   // Two streams: class 0 (with the shared pre-pass) on the caller's stream, then odd classes on the engine's own stream and
   // even ones on the caller's.  Each class is one launch of n / tile blocks; its last wave of blocks leaves most CUs idle
   // for one block time (5 % of a 100-tree launch over 10 M tuples) -- with a second launch in flight those CUs have work.
-  const bool two = e->class_streams && e->num_classes > 2 && !e->kernel_timing;
+  // (never with a "_p" kernel launched once per class: its persistent blocks take their tiles from ONE ticket counter in the batch's
+  // workspace, which a second launch in flight would reset and share)
+  const bool persistent = variant(e->variant_id).kind == kKindQ16 && (variant(e->variant_id).opt & 8) != 0;
+  const bool two = e->class_streams && e->num_classes > 2 && !e->kernel_timing && !persistent;
   if (two && !e->class_stream) {
     HIP_TRY(e, hipStreamCreateWithFlags(&e->class_stream, hipStreamNonBlocking));
     for (hipEvent_t& ev : e->class_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1296,6 +1324,7 @@ void engine_enter_collective_job(ddt_engine* e) {
   if (ip < 0 || cur.kind != kKindQ16 || !(cur.opt & 4) || (cur.opt & 8) || e->num_classes != 1 || cur.levels != variant(ip).levels ||
       cur.chunk_trees != variant(ip).chunk_trees || e->ens.empty() || e->ens[0].parts.size() > 1)
     return;
+  if (s2_disabled() || !variant_fits(variant(ip), e)) return;  // the same gates the automatic choice at load time goes through
   e->variant_id = ip;
 }
 

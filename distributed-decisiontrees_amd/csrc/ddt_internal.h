@@ -93,8 +93,12 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   uint32_t n_segs = 1;        // ensembles in the image
   uint32_t seg_chunks = 0;    // chunks per ensemble (0 = all of ScoreArgs::n_chunks)
   int32_t* labels = nullptr;  // n_segs > 1: argmax over the segments (may be NULL); `ScoreArgs::out` (may be NULL then) = [n_segs][n] sums
-  uint32_t seg_tail_empty = 0;  // n_segs > 1: the last four trees of every ensemble's last chunk are EMPTY padding (trees per ensemble mod 8 in
-                              // 1..4): their walk is skipped, their +0 leaves are added as always
+  // n_segs > 1, trees per ensemble mod 8 in 1..4: the second half of every ensemble's partly filled PU group (= its chunk's second
+  // sub-group) is EMPTY padding; that sub-group's walk is skipped, its +0 leaves are added as always.  The value is what the kernel's
+  // count-down of an ensemble's chunks (seg_chunks .. 1) reads AT that chunk: seg_chunks - (the chunk's index in the ensemble's image).  In a
+  // cluster-major image the partial group is the last of ITS cluster's run, not necessarily of the image (ddt_engine.cpp cm_position).
+  // 0 = nothing to skip (the count-down never reads 0).
+  uint32_t seg_tail_left = 0;
   uint32_t* tile_counter = nullptr;  // work counter of the persistent blocks (zeroed per launch; engine workspace behind the pre-pass counters)
   uint32_t prepass_nt = 0;    // A/B (option "q16_prepass_nt"): bit 0 = the pre-pass writes the rank tiles with nontemporal stores, bit 1 = reads the tuples with nontemporal loads
   // Ensembles with more than 32767 distinct thresholds on a feature (u16 ranks stop there; DTPU.sv:22,74 allows 8192 nodes x 64 PUs on one

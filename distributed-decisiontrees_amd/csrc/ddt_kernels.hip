@@ -440,8 +440,11 @@ __device__ __forceinline__ void stream_body(const ScoreArgs& a) {
   uint32_t r_count = 0, deadline = 0;
   uint64_t r_first = blockIdx.x;
   if (NB) {
-    const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
-    deadline = now - now % window + window;  // windows are aligned to multiples of `window` in absolute time: chip-wide
+    // windows are aligned to multiples of `window` in ABSOLUTE time, chip-wide: the phase comes from the 64-bit clock (the low 32 bits wrap
+    // every 43 s, and a window that does not divide 2^32 would shift its phase there); differences stay 32-bit
+    const uint64_t now64 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t now = (uint32_t)now64;
+    deadline = now - (uint32_t)(now64 % (uint64_t)window) + window;
   }
   auto flush = [&](uint64_t next_first) {
     const uint32_t ring = ring_addr();
@@ -521,8 +524,14 @@ static hipError_t launch_stream(const ScoreArgs& a, const Variant& v, hipStream_
   if (tiles == 0) return hipSuccess;
   // persistent: CUs x the blocks that are actually resident per CU (registers bound this before the LDS does: a grid of
   // LDS-many blocks per CU would run as one full wave of blocks and a thinner second one)
+  // (these caches are per kernel instantiation -- statics of a function template -- and keyed on the device as well: another GPU of the
+  // process may hold a different number of blocks)
+  int dev = -1;
+  (void)hipGetDevice(&dev);
   static thread_local uint32_t occ_lds = ~0u, occ_blocks = 0;
-  if (occ_lds != lds) {
+  static thread_local int occ_dev = -2;
+  if (occ_lds != lds || occ_dev != dev) {
+    occ_dev = dev;
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), kStreamThreads, lds) != hipSuccess || occ < 1)
       occ = (int)stream_blocks_per_cu(lds);
@@ -557,8 +566,10 @@ static hipError_t launch_stream(const ScoreArgs& a, const Variant& v, hipStream_
       while (pc > 4u && slots_for(pc) < kStreamResWant) --pc;
     uint32_t nb = slots_for(pc);
     if (nb >= kStreamResMin && tiles >= 8ull * a.num_cus * pc) {
-      static thread_local uint32_t ok_lds = ~0u, ok_pc = 0, ok_cap = 0, ok_nb = 0;  // the occupancy query per (lds, blocks, cap)
-      if (ok_lds != lds || ok_pc != pc || ok_cap != cap) {
+      static thread_local uint32_t ok_lds = ~0u, ok_pc = 0, ok_cap = 0, ok_nb = 0;  // the occupancy query per (device, lds, blocks, cap)
+      static thread_local int ok_dev = -2;
+      if (ok_lds != lds || ok_pc != pc || ok_cap != cap || ok_dev != dev) {
+        ok_dev = dev;
         for (; nb >= kStreamResMin; --nb) {  // the blocks the grid counts on must be resident together
           int occ = 0;
           const uint32_t want = b.stream_res_off + nb * 1024u;
@@ -1501,8 +1512,8 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16p_kernel(const ScoreArgs a
       TopRecs<4>& top_nxt = (sg & 1) ? top_a : top_b;                                                  \
       top_wait(top_cur);                                                                               \
       top_issue<TREE_BYTES>(top_nxt, img + (size_t)kn * GCHUNK_UNITS + (size_t)(sn * U) * (TREE_BYTES / 16)); \
-      if (MULTI && sg == CT / U - 1 && seg_left == 1u && x.seg_tail_empty) {                          \
-        /* the ensemble's last four trees are EMPTY padding (100 trees per class in whole chunks of 8): no walk, their +0 leaves */ \
+      if (MULTI && sg == CT / U - 1 && seg_left == x.seg_tail_left) {                                 \
+        /* the second half of the ensemble's partly filled PU group is EMPTY padding (100 trees per class): no walk, their +0 leaves */ \
         _Pragma("unroll") for (int u = 0; u < U; ++u) lf[0][u] = 0.f;                                  \
       } else if constexpr (PIN) {                                                                      \
         if (!slow_l) walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \

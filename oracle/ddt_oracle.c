@@ -16,6 +16,7 @@
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -638,6 +639,218 @@ int orc_score_fast(const orc_params* p, const void* wl, size_t n_wlines, const v
   }
   free(nodes);
   free(leaf);
+  (void)nthreads;
+  return 0;
+}
+
+/* =============================================================================================
+ * 8b. The cache-blocked scorer for the OTHER results of orc_score: the reference's own adder (ORC_SUM_REF_FLOPOCO) and the
+ *    multi-device chain (n_devices > 1; PCIeReceiver.sv:241-264 contiguous shards, ResultsCombiner.sv:292-311 local + upstream),
+ *    optionally per class of a one-vs-all model.  Same walk organisation as orc_score_fast; the reduction keeps orc_tree8 /
+ *    orc_aggregate's 34-bit values but takes each add through fp34_add_fast: on two NORMAL operands whose IEEE sum is normal the
+ *    FloPoCo adder is the IEEE add except for the shiftedOut case (FPAdder_2cycles_latency.v:325-326), which is decided from the
+ *    operands; everything else (zero / exception operands, exponent fields 0 or 255, cancellation, sub-normal results) goes through
+ *    the bit-level model orc_fp34_add.  orc_fast_add_selftest + tests/test_oracle_kat.py hold the shortcut to the model (and thereby
+ *    to the RTL vectors the model is pinned with); tests hold orc_score_fast_ex to orc_score / orc_classify bit for bit.
+ * ============================================================================================= */
+static inline uint64_t fp34_add_fast(uint64_t X, uint64_t Y) {
+  if (EXC(X) == 1u && EXC(Y) == 1u) {
+    const uint32_t a = (uint32_t)X, b = (uint32_t)Y;
+    if (EXPF(a) - 1u < 254u && EXPF(b) - 1u < 254u) {
+      volatile float sv = f_from(a) + f_from(b);
+      const uint32_t r = b_from(sv);
+      if (EXPF(r) - 1u < 254u) {
+        const uint32_t ma = a & 0x7FFFFFFFu, mb = b & 0x7FFFFFFFu;
+        const uint32_t big = ma >= mb ? a : b, small = ma >= mb ? b : a;
+        /* effective subtraction, larger operand a power of two, exponents exactly 25 apart, smaller mantissa != 0:
+           the alignment shift is forced to 26 (shiftedOut), the smaller operand only leaves its sticky bit, the result is the
+           larger operand; IEEE gives the float just below it */
+        if (((a ^ b) >> 31) && FRAC(big) == 0u && EXPF(big) - EXPF(small) == 25u && FRAC(small) != 0u)
+          return (1ull << 32) | big;
+        return (1ull << 32) | r;
+      }
+    }
+  }
+  return orc_fp34_add(X, Y);
+}
+
+/* mismatches of fp34_add_fast against orc_fp34_add over n structured pseudo-random operand pairs (exponent distances 0..30
+   over-represented, power-of-two and all-ones mantissas, zeros, exponent fields 0 / 1 / 254 / 255, every exception code) */
+uint64_t orc_fast_add_selftest(uint64_t seed, uint64_t n) {
+  uint64_t bad = 0, s = seed * 0x9E3779B97F4A7C15ull + 1u;
+  for (uint64_t i = 0; i < n; ++i) {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    const uint64_t h = s;
+    uint32_t ea = (uint32_t)(h & 0xFFu), fa = (uint32_t)((h >> 8) & 0x7FFFFFu), fb = (uint32_t)((h >> 31) & 0x7FFFFFu);
+    const uint32_t kind = (uint32_t)((h >> 54) & 7u), dist = (uint32_t)((h >> 57) & 31u);
+    uint32_t eb = (kind & 1u) ? (uint32_t)((h >> 20) & 0xFFu) : (ea >= dist ? ea - dist : ea + dist) & 0xFFu;
+    if (kind == 2u) fa = 0u;                       /* power of two */
+    if (kind == 3u) fa = 0x7FFFFFu;                /* all ones */
+    if (kind == 4u) { fa = 0u; fb = (fb & 1u) ? fb : 1u; }
+    if (kind == 5u) { const uint32_t t = ea; ea = eb; eb = t; fb = (fb & 3u) ? fb : 0u; }
+    const uint32_t a = ((uint32_t)((h >> 62) & 1u) << 31) | (ea << 23) | fa, b = ((uint32_t)((h >> 63) & 1u) << 31) | (eb << 23) | fb;
+    uint64_t X = orc_fp34_wrap(a), Y = orc_fp34_wrap(b);
+    if (((h >> 40) & 0x3Fu) == 0u) X = ((uint64_t)((h >> 46) & 3u) << 32) | a;   /* any exception code now and then */
+    if (((h >> 41) & 0x3Fu) == 0u) Y = ((uint64_t)((h >> 48) & 3u) << 32) | b;
+    bad += fp34_add_fast(X, Y) != orc_fp34_add(X, Y);
+    bad += fp34_add_fast(Y, X) != orc_fp34_add(Y, X);
+  }
+  return bad;
+}
+
+typedef struct { uint32_t tree[8]; uint32_t cluster; uint32_t shard_end; /* 1: last group of its shard */ uint32_t extra0, extra1; /* EMPTY slots [extra0, extra1) appended then */ } ex_group;
+
+/* num_classes 0 = plain scores into out[n]; K >= 1 = one-vs-all: class_scores [K][n] (may be NULL) and labels[n] (may be NULL) */
+int orc_score_fast_ex(const orc_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines, const void* tl,
+                      size_t n_tuples, float* out, int sum_mode, int n_devices, uint32_t num_classes, int interleaved,
+                      int32_t* labels, float* class_scores, double* gold, double* gold_abs, int nthreads) {
+  int rc = check_params(p, n_wlines, n_flines);
+  if (rc) return rc;
+  const uint32_t T = p->num_trees, D = p->num_levels, nint = (1u << D) - 1u, nleaf = 1u << D;
+  const uint32_t K = num_classes ? num_classes : 1u;
+  if (p->cmp_mode != 0 || sum_mode == ORC_SUM_F64_SEQ || n_devices < 1 || K > T || (num_classes && !interleaved && T % K)) return -8;
+  if (!num_classes && (uint32_t)n_devices > T) return -5;
+  const uint32_t C = p->clusters_per_tuple, tw = orc_tuple_lines(p->num_features) * 4u, miss = p->missing_bits;
+  const int flopoco = sum_mode == ORC_SUM_REF_FLOPOCO;
+  const size_t ws = (size_t)p->weights_lines_per_tree * 4u, fs = (size_t)p->findex_lines_per_tree * 8u;
+  fast_node* nodes = (fast_node*)calloc((size_t)(T + 1u) * nint, sizeof(fast_node)); /* tree T = an EMPTY slot: leaves +0 */
+  uint32_t* leaf = (uint32_t*)calloc((size_t)(T + 1u) * nleaf, sizeof(uint32_t));
+  /* groups in walking order: class by class, device by device, the shard's PU groups in local stream order */
+  ex_group* G = (ex_group*)calloc((size_t)T / 8u + (size_t)K * (size_t)n_devices + 8u, sizeof(ex_group));
+  uint32_t* ids = (uint32_t*)malloc(sizeof(uint32_t) * T);
+  if (!nodes || !leaf || !G || !ids) { free(nodes); free(leaf); free(G); free(ids); return -7; }
+  for (uint32_t i = 0; i < T; ++i) {
+    const uint32_t* w = (const uint32_t*)wl + (size_t)i * ws;
+    const uint16_t* f = (const uint16_t*)fl + (size_t)i * fs;
+    for (uint32_t n = 0; n < nint; ++n) {
+      nodes[(size_t)i * nint + n].thr = w[n];
+      nodes[(size_t)i * nint + n].fi = (uint32_t)(f[n] & 0x7FFu) | ((uint32_t)((f[n] >> 13) & 1u) << 31);
+    }
+    memcpy(leaf + (size_t)i * nleaf, w + nint, (size_t)nleaf * 4u);
+  }
+  size_t ng = 0;
+  uint32_t* dev_groups = (uint32_t*)calloc((size_t)K * (size_t)n_devices, sizeof(uint32_t)); /* groups per (class, device); 0 = empty shard */
+  for (uint32_t k = 0; k < K; ++k) {
+    uint32_t nk = 0;
+    for (uint32_t i = 0; i < T; ++i) {
+      const uint32_t cls = !num_classes ? 0u : interleaved ? i % K : i / (T / K);
+      if (cls == k) ids[nk++] = i;
+    }
+    const uint32_t per_dev = (nk + (uint32_t)n_devices - 1u) / (uint32_t)n_devices;
+    for (int d = 0; d < n_devices; ++d) {
+      const uint32_t b = (uint32_t)d * per_dev < nk ? (uint32_t)d * per_dev : nk, e = (b + per_dev < nk) ? b + per_dev : nk;
+      const uint32_t groups = (e - b + 7u) / 8u, slots = (groups + C - 1u) / C;
+      dev_groups[(size_t)k * n_devices + d] = groups;
+      for (uint32_t g = 0; g < groups; ++g) {
+        ex_group* q = &G[ng++];
+        for (uint32_t u = 0; u < 8u; ++u) q->tree[u] = b + g * 8u + u < e ? ids[b + g * 8u + u] : T;
+        q->cluster = g % C;
+        q->shard_end = g + 1u == groups;
+        q->extra0 = groups;
+        q->extra1 = slots * C;
+      }
+    }
+  }
+  const uint32_t* t = (const uint32_t*)tl;
+  enum { RB = 256 };
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = orc_hw_threads();
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    uint64_t* acc = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)RB * 8u);  /* per row, per cluster: 34-bit running value (native: fp32 bits) */
+    uint32_t* run = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)RB);       /* chain over the devices */
+    float* best = (float*)malloc(sizeof(float) * (size_t)RB);
+    int32_t* arg = (int32_t*)malloc(sizeof(int32_t) * (size_t)RB);
+    double* gsum = (double*)malloc(sizeof(double) * (size_t)RB * 2u); /* per row: fp64 sum of the leaves in walking order, and of their magnitudes */
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 2)
+#endif
+    for (long long b0 = 0; b0 < (long long)n_tuples; b0 += RB) {
+      const uint32_t rows = (uint32_t)((long long)n_tuples - b0 < RB ? (long long)n_tuples - b0 : RB);
+      size_t gi = 0;
+      for (uint32_t k = 0; k < K; ++k) {
+        for (uint32_t i = 0; i < rows * 2u; ++i) gsum[i] = 0.0;
+        for (int d = 0; d < n_devices; ++d) {
+          const uint32_t groups = dev_groups[(size_t)k * n_devices + d];
+          for (uint32_t i = 0; i < rows * 8u; ++i) acc[i] = 0u; /* prev_aggreg_value reset (FPAggregator.v:83); native: +0 */
+          for (uint32_t g = 0; g < groups; ++g, ++gi) {
+            const ex_group* q = &G[gi];
+            const uint32_t c = q->cluster;
+            for (uint32_t r = 0; r < rows; ++r) {
+              const uint32_t* x = t + ((size_t)b0 + r) * tw;
+              uint32_t n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+              for (uint32_t lvl = 0; lvl < D; ++lvl)
+                for (int u = 0; u < 8; ++u) {
+                  const fast_node nd = nodes[(size_t)q->tree[u] * nint + n[u]];
+                  const uint32_t f = x[nd.fi & 0x7FFu];
+                  const uint32_t ge = (uint32_t)!((int32_t)f < (int32_t)nd.thr);   /* DTPU.sv:655-657 */
+                  const uint32_t right = f == miss ? nd.fi >> 31 : ge;             /* DTPU.sv:653,667 */
+                  n[u] = 2u * n[u] + 1u + right;
+                }
+              uint32_t l[8];
+              for (int u = 0; u < 8; ++u) l[u] = leaf[(size_t)q->tree[u] * nleaf + (n[u] - nint)];
+              if (gold || gold_abs)
+                for (int u = 0; u < 8; ++u)
+                  if (q->tree[u] < T) { /* (plain scores: tree order 0..T-1, the order of orc_score's gold) */
+                    gsum[2u * r] += (double)f_from(l[u]);
+                    gsum[2u * r + 1u] += fabs((double)f_from(l[u]));
+                  }
+              if (flopoco) { /* orc_tree8 + one step of orc_aggregate, the adds through fp34_add_fast */
+                uint64_t w8[8];
+                for (int u = 0; u < 8; ++u) w8[u] = orc_fp34_wrap(l[u]);
+                const uint64_t a0 = fp34_add_fast(w8[0], w8[1]), a1 = fp34_add_fast(w8[2], w8[3]);
+                const uint64_t a2 = fp34_add_fast(w8[4], w8[5]), a3 = fp34_add_fast(w8[6], w8[7]);
+                const uint64_t h0 = fp34_add_fast(a0, a1), h1 = fp34_add_fast(a2, a3);
+                const uint32_t s8 = orc_fp34_unwrap(fp34_add_fast(h0, h1));
+                acc[(size_t)r * 8u + c] = fp34_add_fast(orc_fp34_wrap(s8), acc[(size_t)r * 8u + c]);
+              } else {
+                volatile float a0 = f_from(l[0]) + f_from(l[1]), a1 = f_from(l[2]) + f_from(l[3]);
+                volatile float a2 = f_from(l[4]) + f_from(l[5]), a3 = f_from(l[6]) + f_from(l[7]);
+                volatile float h0 = a0 + a1, h1 = a2 + a3;
+                volatile float s8 = h0 + h1;
+                volatile float na = s8 + f_from((uint32_t)acc[(size_t)r * 8u + c]);
+                acc[(size_t)r * 8u + c] = b_from(na);
+              }
+            }
+          }
+          /* the shard is complete (an empty one: +0): EMPTY extra slots, cluster accumulate, chain hop */
+          for (uint32_t r = 0; r < rows; ++r) {
+            uint32_t part = 0u;
+            if (groups) {
+              const ex_group* q = &G[gi - 1u];
+              uint64_t* a = acc + (size_t)r * 8u;
+              if (flopoco) {
+                for (uint32_t g = q->extra0; g < q->extra1; ++g) a[g % C] = fp34_add_fast(orc_fp34_wrap(0u), a[g % C]);
+                uint64_t tot = 0u;
+                for (uint32_t c = 0; c < C; ++c) tot = fp34_add_fast(orc_fp34_wrap(orc_fp34_unwrap(a[c])), tot);
+                part = orc_fp34_unwrap(tot);
+              } else {
+                for (uint32_t g = q->extra0; g < q->extra1; ++g) { volatile float z = 0.0f + f_from((uint32_t)a[g % C]); a[g % C] = b_from(z); }
+                volatile float tot = 0.0f;
+                for (uint32_t c = 0; c < C; ++c) tot = f_from((uint32_t)a[c]) + tot;
+                part = b_from(tot);
+              }
+            }
+            if (d == 0) run[r] = part;
+            else if (flopoco) run[r] = orc_fp34_unwrap(fp34_add_fast(orc_fp34_wrap(part), orc_fp34_wrap(run[r])));
+            else { volatile float sv = f_from(part) + f_from(run[r]); run[r] = b_from(sv); }
+          }
+        }
+        for (uint32_t r = 0; r < rows; ++r) {
+          const float sc = f_from(run[r]);
+          if (gold) gold[(size_t)k * n_tuples + (size_t)b0 + r] = gsum[2u * r];
+          if (gold_abs) gold_abs[(size_t)k * n_tuples + (size_t)b0 + r] = gsum[2u * r + 1u];
+          if (!num_classes) { out[(size_t)b0 + r] = sc; continue; }
+          if (class_scores) class_scores[(size_t)k * n_tuples + (size_t)b0 + r] = sc;
+          if (k == 0 || sc > best[r] || (best[r] != best[r] && sc == sc)) { best[r] = sc; arg[r] = (int32_t)k; }
+          if (k + 1u == K && labels) labels[(size_t)b0 + r] = arg[r];
+        }
+      }
+    }
+    free(acc); free(run); free(best); free(arg); free(gsum);
+  }
+  free(nodes); free(leaf); free(G); free(ids); free(dev_groups);
   (void)nthreads;
   return 0;
 }

@@ -130,6 +130,17 @@ int orc_score(const orc_params* p, const void* weights_lines, size_t n_wlines,
 int orc_score_fast(const orc_params* p, const void* weights_lines, size_t n_wlines, const void* findex_lines,
                    size_t n_flines, const void* tuple_lines, size_t n_tuples, float* out, int sum_mode, int nthreads);
 
+/* The cache-blocked form of the rest of orc_score / orc_classify (ddt_oracle.c section 8b; cmp_mode 0, ORC_SUM_REF_NATIVE or
+ * ORC_SUM_REF_FLOPOCO): any n_devices (the chain of ResultsCombiner.sv:292-311 over contiguous shards), num_classes 0 = plain scores
+ * into out[n], K >= 1 = one-vs-all (labels[n], class_scores[K][n], either may be NULL); gold / gold_abs (may be NULL; [n] or [K][n]):
+ * the fp64 sum of a row's leaves (plain scores: orc_score's gold, same order) and of their magnitudes.  Identical bits; used where bench.py checks
+ * millions of rows of a multi-rank job or of sum_mode 2 in seconds.  orc_fast_add_selftest: mismatches of its adder shortcut against
+ * orc_fp34_add over n structured pseudo-random operand pairs (must be 0). */
+int orc_score_fast_ex(const orc_params* p, const void* weights_lines, size_t n_wlines, const void* findex_lines, size_t n_flines,
+                      const void* tuple_lines, size_t n_tuples, float* out, int sum_mode, int n_devices, uint32_t num_classes,
+                      int interleaved, int32_t* labels, float* class_scores, double* gold, double* gold_abs, int nthreads);
+uint64_t orc_fast_add_selftest(uint64_t seed, uint64_t n);
+
 /* Partial (per-shard) scores: trees [tree_begin, tree_end) only, reduced as one device. */
 int orc_score_shard(const orc_params* p, const void* weights_lines, size_t n_wlines,
                     const void* findex_lines, size_t n_flines, const void* tuple_lines, size_t n_tuples,

@@ -70,6 +70,9 @@ def lib():
         L.orc_score.argtypes = [PP, vp, sz, vp, sz, vp, sz, vp, vp, C.c_int, C.c_int, C.c_int]
         L.orc_score_fast.restype = C.c_int
         L.orc_score_fast.argtypes = [PP, vp, sz, vp, sz, vp, sz, vp, C.c_int, C.c_int]
+        L.orc_score_fast_ex.restype = C.c_int
+        L.orc_score_fast_ex.argtypes = [PP, vp, sz, vp, sz, vp, sz, vp, C.c_int, C.c_int, u32, C.c_int, vp, vp, vp, vp, C.c_int]
+        L.orc_fast_add_selftest.restype, L.orc_fast_add_selftest.argtypes = u64, [u64, u64]
         L.orc_score_shard.restype = C.c_int
         L.orc_score_shard.argtypes = [PP, vp, sz, vp, sz, vp, sz, u32, u32, vp, C.c_int, C.c_int]
         L.orc_classify.restype = C.c_int
@@ -195,10 +198,24 @@ def score(m: Model, tuples: np.ndarray, sum_mode: int = SUM_REF_FLOPOCO, n_devic
     return (out, gold) if want_gold else out
 
 
-def score_fast(m: Model, tuples: np.ndarray, sum_mode: int = SUM_REF_NATIVE, nthreads: int = 0) -> np.ndarray:
-    """The CPU-baseline form of score(): identical bits, cache-blocked (oracle/ddt_oracle.c section 8)."""
+def score_fast(m: Model, tuples: np.ndarray, sum_mode: int = SUM_REF_NATIVE, nthreads: int = 0, n_devices: int = 1, want_gold: bool = False):
+    """The CPU-baseline form of score(): identical bits, cache-blocked (oracle/ddt_oracle.c sections 8 and 8b).
+    want_gold: -> (scores, gold, gold_abs): per row the fp64 sum of its leaves (score()'s gold) and of their magnitudes."""
     t = np.ascontiguousarray(tuples, np.uint32)
     out = np.zeros(t.shape[0], np.float32)
+    if m.params.cmp_mode == 0 and sum_mode != SUM_F64_SEQ and (sum_mode == SUM_REF_FLOPOCO or n_devices > 1 or want_gold):
+        gold = np.zeros(t.shape[0], np.float64) if want_gold else None
+        gabs = np.zeros(t.shape[0], np.float64) if want_gold else None
+        rc = lib().orc_score_fast_ex(C.byref(m.params), _p(m.wlines), m.n_wlines, _p(m.flines), m.n_flines, _p(t), t.shape[0],
+                                     _p(out), sum_mode, n_devices, 0, 1, None, None, _p(gold) if want_gold else None,
+                                     _p(gabs) if want_gold else None, nthreads)
+        if rc:
+            raise ValueError(f"orc_score_fast_ex rc={rc}")
+        return (out, gold, gabs) if want_gold else out
+    if n_devices > 1 or want_gold:
+        if want_gold:
+            raise ValueError("score_fast(want_gold): cmp_mode 0 and a reference-order sum only")
+        return score(m, t, sum_mode=sum_mode, n_devices=n_devices, nthreads=nthreads)
     rc = lib().orc_score_fast(C.byref(m.params), _p(m.wlines), m.n_wlines, _p(m.flines), m.n_flines, _p(t), t.shape[0],
                               _p(out), sum_mode, nthreads)
     if rc:
@@ -229,6 +246,32 @@ def classify(m: Model, tuples: np.ndarray, num_classes: int, interleaved: bool =
     if rc:
         raise ValueError(f"orc_classify rc={rc}")
     return labels, cs
+
+
+def classify_fast(m: Model, tuples: np.ndarray, num_classes: int, interleaved: bool = True,
+                  sum_mode: int = SUM_REF_NATIVE, n_devices: int = 1, nthreads: int = 0, want_gold: bool = False):
+    """classify() in the cache-blocked form (identical bits; oracle/ddt_oracle.c section 8b).
+    want_gold: -> (labels, class_scores, gold [K, n], gold_abs [K, n])"""
+    if m.params.cmp_mode != 0 or sum_mode == SUM_F64_SEQ:
+        if want_gold:
+            raise ValueError("classify_fast(want_gold): cmp_mode 0 and a reference-order sum only")
+        return classify(m, tuples, num_classes, interleaved, sum_mode, n_devices)
+    t = np.ascontiguousarray(tuples, np.uint32)
+    n = t.shape[0]
+    labels = np.zeros(n, np.int32)
+    cs = np.zeros((num_classes, n), np.float32)
+    gold = np.zeros((num_classes, n), np.float64) if want_gold else None
+    gabs = np.zeros((num_classes, n), np.float64) if want_gold else None
+    rc = lib().orc_score_fast_ex(C.byref(m.params), _p(m.wlines), m.n_wlines, _p(m.flines), m.n_flines, _p(t), n,
+                                 None, sum_mode, n_devices, num_classes, int(interleaved), _p(labels), _p(cs),
+                                 _p(gold) if want_gold else None, _p(gabs) if want_gold else None, nthreads)
+    if rc:
+        raise ValueError(f"orc_score_fast_ex rc={rc}")
+    return (labels, cs, gold, gabs) if want_gold else (labels, cs)
+
+
+def fast_add_selftest(seed: int, n: int) -> int:
+    return int(lib().orc_fast_add_selftest(seed, n))
 
 
 def leaves(m: Model, tuple_row: np.ndarray) -> np.ndarray:

@@ -251,3 +251,36 @@ def test_gpu_sparse_forest_corner():
         got = e.score(x)
         assert np.array_equal(_bits(got), _bits(want)), sum_mode
     e.close()
+
+
+# ---- the oracle's cache-blocked scorer (orc_score_fast_ex: what bench.py checks millions of rows of a multi-rank job or of sum_mode 2
+# against) is held to the plain oracle -- and its adder shortcut to the bit-level model of the FloPoCo adder -- exactly where they could part
+def test_fast_oracle_adder_shortcut_equals_the_bit_level_model():
+    for seed in (1, 2, 3):
+        assert O.fast_add_selftest(seed, 4_000_000) == 0
+    # the shortcut is exercised, not bypassed: the documented case and its mirror images through the batch scorer
+    for where in WHERE:
+        m, nd = _crafted(where, D=4, F=8)
+        x = O.gen_tuples(1, 64, 8, 0)
+        want = O.score(m, x, sum_mode=O.SUM_REF_FLOPOCO, n_devices=nd)
+        assert _bits(want)[0] == RTL_BITS
+        assert np.array_equal(_bits(O.score_fast(m, x, sum_mode=O.SUM_REF_FLOPOCO, n_devices=nd)), _bits(want))
+        assert _bits(O.score_fast(m, x, sum_mode=O.SUM_REF_NATIVE, n_devices=nd))[0] == IEEE_BITS
+
+
+@pytest.mark.parametrize("T,D,F,seed", [(64, 5, 12, 1), (100, 6, 28, 2), (250, 4, 16, 3)])
+def test_fast_oracle_equals_plain_oracle_on_corner_rich_models(T, D, F, seed):
+    m = _corner_rich(T, D, F, seed)
+    x = O.gen_tuples(seed, 4000, F, 0)
+    differ = 0
+    for nd in (1, 2, 4, 8):
+        for sm in (O.SUM_REF_NATIVE, O.SUM_REF_FLOPOCO):
+            assert np.array_equal(_bits(O.score_fast(m, x, sum_mode=sm, n_devices=nd)), _bits(O.score(m, x, sum_mode=sm, n_devices=nd))), (nd, sm)
+        differ += int((_bits(O.score(m, x, sum_mode=O.SUM_REF_NATIVE, n_devices=nd)) != _bits(O.score(m, x, sum_mode=O.SUM_REF_FLOPOCO, n_devices=nd))).sum())
+    assert differ > 0   # the two adders really part on these models
+    for K, inter in ((4, True), (2, False)):
+        for nd in (1, 3):
+            for sm in (O.SUM_REF_NATIVE, O.SUM_REF_FLOPOCO):
+                la, ca = O.classify(m, x[:1500], K, inter, sum_mode=sm, n_devices=nd)
+                lb, cb = O.classify_fast(m, x[:1500], K, inter, sum_mode=sm, n_devices=nd)
+                assert np.array_equal(la, lb) and np.array_equal(_bits(ca), _bits(cb)), (K, inter, nd, sm)
