@@ -61,6 +61,11 @@ def self_launch_command(n_gpus, argv=None, port=None):
             "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
 
 
+# BASELINE.json configs (1: at 200 M rows, the HBM-bound shape; 6: the reference's own example configuration, profiler/profiler.cpp:32-38)
+CONFIG_SHAPES = {1: (8, 4, 16, 200_000_000), 2: (100, 6, 28, 10_000_000), 3: (1000, 8, 32, 100_000_000),
+                 4: (512, 16, 64, 10_000_000), 5: (1000, 8, 32, 10_000_000), 6: (512, 12, 32, 10_000_000)}
+
+
 def hybrid_tree_groups(world):
     """Tree-group sizes Gt of the hybrid legs: proper divisors of the job that leave at least two row groups."""
     return [Gt for Gt in (2, 4) if world % Gt == 0 and world // Gt >= 2]
@@ -74,6 +79,85 @@ def self_launch(n_gpus):
     return subprocess.call(cmd)
 
 
+def run_side_config(cfg, device_index, check_rows=262_144):
+    """One SHORT run of another BASELINE config on the same GPU, behind the default command's timed region (`other_configs` on the line): the
+    config's model and full row count, a few steps, HIP-event kernel times from the library, and a prefix of the result against the oracle."""
+    import numpy as np
+    import torch
+
+    import ddt
+    from oracle import oracle as O
+
+    t_begin = time.perf_counter()
+    T, D, F, N = CONFIG_SHAPES[cfg]
+    sparse, classes = cfg == 4, (10 if cfg == 5 else 1)
+    steps, warm = {1: (10, 3), 2: (30, 5), 3: (3, 1), 4: (3, 1), 5: (5, 2), 6: (3, 1)}[cfg]
+    eng = ddt.Engine(device_index)
+    try:
+        if sparse:
+            lines, first = ddt.synth_sparse_model(T, D, F, 10, 700, 0)
+            eng.load_model_sparse(ddt.make_sparse_params(T, D, F), lines, first)
+        elif classes > 1:
+            w, f = ddt.synth_model(T, D, F, 0)
+            eng.load_model_multiclass(ddt.make_params(T, D, F, clusters=ddt.default_clusters(T // classes)), w, f, classes, True)
+        else:
+            w, f = ddt.synth_model(T, D, F, 0)
+            eng.load_model(ddt.make_params(T, D, F), w, f)
+        info = eng.info()
+        tuples = eng.synth_tuples_device(0, N, F, 0)
+        out = torch.empty(N, dtype=torch.float32, device=tuples.device)
+        labels = cls = None
+        if classes > 1:
+            labels = torch.empty(N, dtype=torch.int32, device=tuples.device)
+            cls = torch.empty((classes, N), dtype=torch.float32, device=tuples.device)
+        else:
+            eng.set_option("kernel_timing", 1)
+
+        def step():
+            if classes > 1:
+                eng.classify_device(tuples, class_scores=cls, labels=labels)
+            else:
+                eng.score_device(tuples, out=out)
+
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        st0 = eng.stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        st1 = eng.stats()
+        k = st1.timed_launches - st0.timed_launches
+        k_ms = (st1.sum_score_ms - st0.sum_score_ms) / k if k > 0 else ms
+        pre_ms = (st1.sum_prepass_ms - st0.sum_prepass_ms) / k if k > 0 else 0.0
+        alg = N * (4 * F + 4 * (classes + 1 if classes > 1 else 1)) + int(info.model_bytes_unpadded)
+        rows = min(N, check_rows if not sparse else min(check_rows, 32_768))
+        xs = tuples[:rows].cpu().numpy().view(np.uint32)
+        if sparse:
+            ref = O.score_sparse_fast(O.SparseModel(O.make_sparse_params(T, D, F), lines, first), xs)
+            same = bool(np.array_equal(out[:rows].cpu().numpy().view(np.uint32), ref.view(np.uint32)))
+        elif classes > 1:
+            ref_l, ref_cs = O.classify_fast(O.Model(O.make_params(T, D, F, clusters=ddt.default_clusters(T // classes)), w, f), xs, classes, True)
+            same = bool(np.array_equal(labels[:rows].cpu().numpy(), ref_l) and
+                        np.array_equal(cls[:, :rows].cpu().numpy().view(np.uint32), ref_cs.view(np.uint32)))
+        else:
+            ref = O.score_fast(O.Model(O.make_params(T, D, F), w, f), xs)
+            same = bool(np.array_equal(out[:rows].cpu().numpy().view(np.uint32), ref.view(np.uint32)))
+        return {"workload": f"{T} {'sparse ' if sparse else ''}trees x depth {'<= ' if sparse else ''}{D} x {F} features"
+                            + (f", {classes} classes" if classes > 1 else "") + f", {N} tuples/step",
+                "value": round(N / ms / 1e3, 3), "unit": "Mtuples/s", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warm,
+                "kernel": info.variant_name.decode(), "fallback_kernel": bool(info.fallback_kernel),
+                "roofline": {"bound": "hbm", "kernel_ms": round(k_ms, 4), "prepass_ms": round(pre_ms, 4), "alg_bytes_per_launch": alg,
+                             "achieved": round(alg / (k_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                             "step_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                "parity": {"rows_checked": rows, "bit_exact": same, "what": "int32 labels + fp32 class sums" if classes > 1 else "fp32 scores"},
+                "seconds": round(time.perf_counter() - t_begin, 2)}
+    finally:
+        eng.close()
+
+
 def main(argv=None, inproc_env=None):
     """inproc_env (tests only): a dict standing in for the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE) -- several ranks then run
     as THREADS of one process (tests/test_bench_multirank_mock.py: the whole N > 1 orchestration below against the CPU model of the host side),
@@ -83,10 +167,11 @@ def main(argv=None, inproc_env=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5; configs 1 and 2, whose step is 1-3 ms: 30)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 2; configs 1 and 2: 5)")
-    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5],
+    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5, 6],
                     help="BASELINE.json config: 3 = headline (default); 1 = 8 trees x d4 x 16 features (HBM-bound shape, 200 M rows "
                          "instead of the 1 K rows of the CPU plumbing case); 2 = 100 x d6 x 28, 10 M rows; 4 = sparse random forest; "
-                         "5 = 10-class one-vs-all, 100 trees/class, d8, 32 features, 10 M rows (value = tuples classified)")
+                         "5 = 10-class one-vs-all, 100 trees/class, d8, 32 features, 10 M rows (value = tuples classified); "
+                         "6 = the REFERENCE's own example configuration (profiler/profiler.cpp:32-38): 512 trees x depth 12 x 32 features, perfect format, 10 M rows")
     ap.add_argument("--rows", type=int, default=0, help="tuples per step (default: the config's)")
     ap.add_argument("--trees", type=int, default=0)
     ap.add_argument("--levels", type=int, default=0)
@@ -127,6 +212,12 @@ def main(argv=None, inproc_env=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streamed", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--check-rows", type=int, default=4_194_304,
+                    help="rows of the timed job's result that are checked against the oracle where the check is a leg of its own (N>1 tolerance check, sum_mode 2)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N=1 default workload only: skip the short runs of the other BASELINE configs behind the timed region (`other_configs` on the line)")
+    ap.add_argument("--other-configs-budget", type=float, default=40.0,
+                    help="seconds the `other_configs` legs may take in all: a config that would start past the budget is skipped and says so")
     args = ap.parse_args(argv)
     # a step of configs 1 / 2 takes 1-3 ms: five of them time the first launches after the allocations (~4 % slower) more than the kernel
     short = args.config in (1, 2)
@@ -156,8 +247,7 @@ def main(argv=None, inproc_env=None):
 
     sparse = args.config == 4
     classes = 10 if args.config == 5 else 1
-    shape = {1: (8, 4, 16, 200_000_000), 2: (100, 6, 28, 10_000_000), 3: (1000, 8, 32, 100_000_000),
-             4: (512, 16, 64, 10_000_000), 5: (1000, 8, 32, 10_000_000)}[args.config]
+    shape = CONFIG_SHAPES[args.config]
     T, D, F, N = (args.trees or shape[0], args.levels or shape[1], args.features or shape[2], args.rows or shape[3])
 
     world = int(env.get("WORLD_SIZE", "1"))
@@ -301,6 +391,11 @@ def main(argv=None, inproc_env=None):
         dt = float(tmax.item())
     ms_per_step = dt / max(1, args.steps) * 1e3
     mtuples = N / (dt / max(1, args.steps)) / 1e6
+    # the combined result of the TIMED job, kept on rank 0 for the parity leg below: the passes behind the timed region (scaling_detail,
+    # other_modes) overwrite `out`
+    timed_result = None
+    if multi and rank == 0 and not args.no_cpu_baseline:
+        timed_result = (labels.clone(), cls_scores.clone()) if classes > 1 else out.clone()
 
     # ---- N>1 (or --force-collectives): the same shard scored WITHOUT the collectives, so that the line itself shows what the
     # combine costs on top of the per-rank compute (max over ranks, 2 steps, outside the timed region) -----------------------
@@ -400,36 +495,50 @@ def main(argv=None, inproc_env=None):
             except Exception:
                 pass
 
-    # ---- CPU baseline (oracle = port of the reference RTL semantics), rank 0 / N=1 only ---------------
+    # ---- CPU baseline + parity (oracle = a CPU restatement of the reference RTL semantics), on rank 0.  N > 1 (and --force-collectives): the
+    # combined result of the TIMED job -- kept above -- is checked against the oracle's model of the job as it ran (the chain of
+    # ResultsCombiner.sv:292-311,359-369 over n_dev contiguous shards, PCIeReceiver.sv:241-264; rows mode / one rank: one device), and the
+    # other ranks wait behind a barrier while rank 0 times the oracle, so the sample has the box's cores to itself.
     cpu = parity = streamed = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    sum_ref = None
+    if rank == 0 and not args.no_cpu_baseline and (not multi or timed_result is not None):
         from oracle import oracle as O
 
+        sum_ref = {0: O.SUM_REF_NATIVE, 1: O.SUM_F64_SEQ, 2: O.SUM_REF_FLOPOCO}[args.sum_mode]
+        n_dev = 1 if (not multi or rows_mode) else (args.tree_ranks if hybrid_mode else world)
+        valid_rows = N
+        if hybrid_mode and args.no_gather:                       # rank 0 holds the rows of its own row group only
+            valid_rows = ddt.hybrid_rows(N, world // args.tree_ranks, 0)[1]
         if sparse:
             m = O.SparseModel(O.make_sparse_params(T, D, F), lines, first)
-
-            def cpu_score(xs):
-                return O.score_sparse_fast(m, xs, sum_mode={0: O.SUM_REF_NATIVE, 1: O.SUM_F64_SEQ, 2: O.SUM_REF_FLOPOCO}[args.sum_mode])
-            what = "oracle/ddt_oracle.c orc_score_sparse_fast: one tree at a time over a 1024-row block, 8 rows in flight per thread"
+            if n_dev == 1:
+                def cpu_score(xs):
+                    return O.score_sparse_fast(m, xs, sum_mode=sum_ref)
+                what = "oracle/ddt_oracle.c orc_score_sparse_fast: one tree at a time over a 1024-row block, 8 rows in flight per thread"
+            else:
+                def cpu_score(xs):
+                    return O.score_sparse(m, xs, sum_mode=sum_ref, n_devices=n_dev)
+                what = f"oracle/ddt_oracle.c orc_score_sparse, {n_dev}-device chain model"
         elif classes > 1:
             m = O.Model(O.make_params(T, D, F, clusters=ddt.default_clusters(T // classes)), w, f)
 
             def cpu_score(xs):
-                return O.classify(m, xs, classes, True, sum_mode={0: O.SUM_REF_NATIVE, 1: O.SUM_F64_SEQ, 2: O.SUM_REF_FLOPOCO}[args.sum_mode])[0]
-            what = "oracle/ddt_oracle.c orc_classify: per-class reference-order sums, argmax"
+                return O.classify_fast(m, xs, classes, True, sum_mode=sum_ref, n_devices=n_dev)
+            what = "oracle/ddt_oracle.c orc_score_fast_ex: per-class reference-order sums" + (f" over a {n_dev}-device chain" if n_dev > 1 else "") + ", argmax"
         else:
             m = O.Model(O.make_params(T, D, F), w, f)
 
             def cpu_score(xs):
-                return O.score_fast(m, xs, sum_mode={0: O.SUM_REF_NATIVE, 1: O.SUM_F64_SEQ, 2: O.SUM_REF_FLOPOCO}[args.sum_mode])
-            what = "oracle/ddt_oracle.c orc_score_fast: cache-blocked 8-byte nodes, 8 walks in flight per thread"
+                return O.score_fast(m, xs, sum_mode=sum_ref, n_devices=n_dev)
+            what = ("oracle/ddt_oracle.c orc_score_fast: cache-blocked 8-byte nodes, 8 walks in flight per thread" if n_dev == 1 and args.sum_mode != 2 else
+                    f"oracle/ddt_oracle.c orc_score_fast_ex: the same walk, {n_dev}-device chain model" + (", the reference's adder" if args.sum_mode == 2 else ""))
         cpu_score(tuples[: min(N, 4096)].cpu().numpy().view(np.uint32))  # thread-pool warm-up
-        probe = min(N, 262_144)
+        probe = min(valid_rows, 262_144)
         xs = tuples[:probe].cpu().numpy().view(np.uint32)
         t1 = time.perf_counter()
         cpu_score(xs)
         rate = probe / max(1e-9, time.perf_counter() - t1)
-        rows = int(max(probe, min(N, 64_000_000, rate * args.cpu_seconds)))
+        rows = int(max(probe, min(valid_rows, 64_000_000, rate * args.cpu_seconds)))
         xs = tuples[:rows].cpu().numpy().view(np.uint32)
         t1 = time.perf_counter()
         ref = cpu_score(xs)
@@ -437,10 +546,49 @@ def main(argv=None, inproc_env=None):
         cpu = {"value": round(rows / cdt / 1e6, 4), "unit": "Mtuples/s", "cores": O.hw_threads(), "kind": "port",
                "sample": f"first {rows} rows of the same synthetic batch, all {T} trees, OpenMP over row blocks on {O.hw_threads()} threads "
                          f"(= the CPUs this process may use: affinity mask and cgroup quota, of {os.cpu_count()} logical CPUs on the box), "
-                         f"{cdt:.1f} s ({what}; a CPU restatement of the reference RTL semantics, the reference has no CPU scorer)"}
-        got = (labels if classes > 1 else out)[:rows].cpu().numpy()
-        parity = {"rows_checked": rows, "bit_exact": bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32))),
-                  "what": "int32 class labels" if classes > 1 else "fp32 scores"}
+                         f"{cdt:.1f} s ({what}; a CPU restatement of the reference RTL semantics, the reference has no CPU scorer)"
+                         + ("; the other ranks wait behind a barrier meanwhile" if world > 1 else "")}
+        res = timed_result if timed_result is not None else ((labels, cls_scores) if classes > 1 else out)
+        if classes > 1:
+            got_l, got_cs = res[0][:rows].cpu().numpy(), res[1][:, :rows].cpu().numpy()
+            ref_l, ref_cs = ref
+            same_l = bool(np.array_equal(got_l, ref_l))
+            same_cs = bool(np.array_equal(got_cs.view(np.uint32), ref_cs.view(np.uint32)))
+            parity = {"rows_checked": rows, "bit_exact": same_l and (same_cs or not multi), "what": "int32 class labels" + (" and fp32 class sums" if multi else ""),
+                      "labels_that_differ": int((got_l != ref_l).sum()), "class_sums_bit_exact": same_cs}
+        else:
+            got = res[:rows].cpu().numpy()
+            parity = {"rows_checked": rows, "bit_exact": bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32))), "what": "fp32 scores"}
+        if multi:
+            # the job as it ran: which combine, against which model.  The chain IS the reference's order (bit-exact required); RCCL's
+            # all-reduce adds the partials in its own order: north_star's 1e-6 is shown against the fp64 sum of the leaves, and the rows
+            # that differ from the chain's result are counted
+            parity["combine"] = "none (replicas)" if rows_mode else args.combine
+            parity["oracle"] = f"{n_dev}-device chain of the reference (ResultsCombiner.sv:292-311), reference-order sums per device"
+            chk = min(rows, args.check_rows)
+            if classes > 1:
+                _, cs_ref, gold, gabs = O.classify_fast(m, xs[:chk], classes, True, sum_mode=sum_ref, n_devices=n_dev, want_gold=True)
+                err = np.abs(res[1][:, :chk].cpu().numpy().astype(np.float64) - gold)
+                parity["rows_that_differ_from_chain_oracle"] = int((got_cs.view(np.uint32) != ref_cs.view(np.uint32)).any(axis=0).sum())
+            elif not sparse:
+                _, gold, gabs = O.score_fast(m, xs[:chk], sum_mode=sum_ref if args.sum_mode != 1 else O.SUM_REF_NATIVE, n_devices=n_dev, want_gold=True)
+                err = np.abs(got[:chk].astype(np.float64) - gold)
+                parity["rows_that_differ_from_chain_oracle"] = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+            else:
+                chk = min(chk, 65_536)
+                _, gold = O.score_sparse(m, xs[:chk], sum_mode=sum_ref, n_devices=n_dev, want_gold=True)
+                gabs = np.abs(gold)
+                err = np.abs(got[:chk].astype(np.float64) - gold)
+                parity["rows_that_differ_from_chain_oracle"] = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+            tol = 1e-6 * np.maximum(np.abs(gold), gabs)
+            parity["within_tolerance"] = bool((err <= tol).all())
+            parity["tolerance"] = "|score - fp64 sum of the row's leaves| <= 1e-6 * max(|that sum|, sum of the leaves' magnitudes)"
+            parity["tolerance_rows_checked"] = int(chk)
+            parity["max_err_over_tolerance"] = float((err / np.maximum(tol, 1e-300)).max()) if err.size else 0.0
+            if args.combine == "chain" or rows_mode or n_dev == 1:
+                parity["required"] = "bit_exact"
+            else:
+                parity["required"] = "within_tolerance"
         if sparse and roofline is not None:
             depth = O.sparse_mean_depth(m, xs[:2048])  # node visits per (tuple, tree) on a sample
             k_s = roofline["kernel_ms"] * 1e-3
@@ -448,6 +596,8 @@ def main(argv=None, inproc_env=None):
                                  "mean_visits_per_tuple_and_tree": round(depth, 3)}
             roofline["node_visits_per_s"] = round(N * T * depth / k_s, 1)
             roofline["deep_gathers_per_s"] = round(N * T * max(0.0, depth - int(info.variant_name.decode().split("_k")[1].split("_")[0])) / k_s, 1)
+    if world > 1 and not args.no_cpu_baseline:
+        fence()   # the other ranks wait here while rank 0 runs the CPU leg
 
     # ---- PCIe-inclusive "streamed" mode (SURVEY 8(d) timing protocol): host buffers through the pinned feeder ----
     if world == 1 and rank == 0 and not args.no_streamed and not multi and classes == 1:
@@ -500,7 +650,7 @@ def main(argv=None, inproc_env=None):
                 eng2.score_device(tuples, out=out2)
             torch.cuda.synchronize()
             s2_ms = (time.perf_counter() - t1) / 3 * 1e3
-            chk = min(N, 262_144)
+            chk = min(N, args.check_rows)   # (the oracle's cache-blocked scorer with the reference adder: ddt_oracle.c section 8b)
             ref2 = O.score_fast(m, tuples[:chk].cpu().numpy().view(np.uint32), sum_mode=O.SUM_REF_FLOPOCO)
             got2 = out2[:chk].cpu().numpy()
             sum2 = {"value": round(N / s2_ms / 1e3, 3), "unit": "Mtuples/s", "ms_per_step": round(s2_ms, 4), "kernel": eng2.info().variant_name.decode(),
@@ -511,6 +661,27 @@ def main(argv=None, inproc_env=None):
             eng2.close()
         except Exception as ex:  # diagnostics must never cost the headline line
             sum2 = {"error": repr(ex)}
+
+    # ---- the other BASELINE configs, each as a short run behind the timed region of the DEFAULT command (N = 1, config 3, no overrides): the
+    # driver's line then carries a value, the dominant kernel's roofline fraction and an oracle check for every config, not for the headline alone
+    other_configs = None
+    default_cmd = (args.config == 3 and not (args.rows or args.trees or args.levels or args.features) and args.variant < 0 and not args.opt
+                   and args.sum_mode == 0 and args.shard_of <= 1)
+    if world == 1 and rank == 0 and not multi and default_cmd and not args.no_other_configs and not args.no_cpu_baseline:
+        other_configs = {}
+        t_oc = time.perf_counter()
+        for cfg in (1, 2, 5, 6, 4):
+            spent = time.perf_counter() - t_oc
+            if spent > args.other_configs_budget:
+                other_configs[str(cfg)] = {"skipped": f"the legs before it took {spent:.0f} s of the {args.other_configs_budget:.0f} s budget"}
+                continue
+            try:
+                other_configs[str(cfg)] = run_side_config(cfg, local)
+            except Exception as ex:  # diagnostics must never cost the headline line
+                other_configs[str(cfg)] = {"error": repr(ex)}
+        other_configs["note"] = ("BASELINE configs 1, 2, 4, 5 and 6 (= the reference's own example, 512 x d12 x 32) on the same GPU behind the timed region: full row "
+                                 "counts, a few steps each, HIP-event kernel time -> roofline.frac, a prefix of the result bit for bit against the oracle; never `value`")
+        other_configs["seconds"] = round(time.perf_counter() - t_oc, 1)
 
     if rank == 0:
         par = (f"shard {shard[0]} of a {shard[1]}-way tree-sharded job ({int(info.tree_end - info.tree_begin)} trees) on one GPU, no collective" if args.shard_of > 1 else
@@ -525,7 +696,7 @@ def main(argv=None, inproc_env=None):
         line = {
             "metric": "Mtuples/s scored, 1000 trees depth-8 / 32 feat" if (T, D, F, sparse, classes) == (1000, 8, 32, False, 1)
             else f"Mtuples/s {'classified' if classes > 1 else 'scored'}, {T} trees depth-{D} / {F} feat"
-                 + (" (sparse random forest, BASELINE config 4)" if sparse else f" (BASELINE config {args.config})" if args.config != 3 else ""),
+                 + (" (sparse random forest, BASELINE config 4)" if sparse else f" (the reference's own example configuration, profiler/profiler.cpp:32-38)" if args.config == 6 else f" (BASELINE config {args.config})" if args.config != 3 else ""),
             "value": round(mtuples, 3), "unit": "Mtuples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -554,6 +725,11 @@ def main(argv=None, inproc_env=None):
             line["scaling_detail"] = scaling_detail
         if sum2:
             line["other_modes"] = {"sum_mode2": sum2}
+        if other_configs:
+            line["other_configs"] = other_configs
+        line["config"]["fallback_kernel"] = bool(info.fallback_kernel)
+        if info.fallback_kernel:
+            print(f"bench.py: WARNING: this model runs on the fallback kernel '{info.variant_name.decode()}' (no tuned kernel for this shape)", file=sys.stderr, flush=True)
     # ---- N>1 (or --force-collectives): the OTHER ways this library can run the same multi-GPU job, measured behind the timed
     # region so that the driver's scaling run records them too (never `value`).  These collectives have run in one-rank
     # communicators and in the CPU model of tests/test_comm_mock.py only: a watchdog keeps a stuck leg from costing the line.
@@ -646,7 +822,7 @@ def main(argv=None, inproc_env=None):
             for bc in (1, 0):
                 comm.set_option("tuple_broadcast", bc)
                 ms = leg(lambda: comm.score(host_t), steps=1)
-                other[f"host_buffers_tuple_broadcast_{bc}_mtuples_per_s"] = round(srows / ms / 1e3, 2)
+                other[f"host_buffers_tuple_broadcast_{bc}_mtuples_per_s"] = round(srows / ms / 1e3, 4)
             comm.set_option("tuple_broadcast", -1)
             other["note"] = ("ms per step, max over ranks, 2 steps each after one warm-up, outside the timed region; row-sharded = replicas "
                              "only (whole ensemble per GPU, tuples partitioned, every step of scores handed to all peers), exact reference-order sums; "

@@ -45,6 +45,13 @@
 
 namespace {
 
+// a model that landed on a correctness kernel (ddt_info::fallback_kernel): never silently
+void warn_fallback(const ddt_info& info) {
+  if (info.fallback_kernel)
+    fprintf(stderr, "ddt_cli: WARNING: this model runs on the fallback kernel '%s' (no tuned kernel for depth %u / %u features): results are exact, "
+                    "throughput is far below the tuned paths\n", info.variant_name, info.num_levels, info.num_features);
+}
+
 std::map<std::string, std::string> parse(int argc, char** argv, int first) {
   std::map<std::string, std::string> o;
   for (int i = first; i + 1 < argc; i += 2) {
@@ -231,6 +238,7 @@ int cmd_score(const std::map<std::string, std::string>& o) {
     if (!write_file(str(o, "out"), scores.data(), scores.size() * 4)) return die(DDT_EINVAL, nullptr, "write results");
     ddt_info info;
     ddt_get_info(ddt_group_engine(g, 0), &info);
+    warn_fallback(info);
     if (rows_mode)
       printf("scored %" PRIu64 " tuples on %d device(s), %u trees on every device, tuples partitioned (kernel %s), no collective\n", n, G, p.num_trees,
              info.variant_name);
@@ -273,6 +281,7 @@ int cmd_score(const std::map<std::string, std::string>& o) {
     if (o.count("out") && !write_file(o.at("out"), scores.data(), scores.size() * 4)) return die(DDT_EINVAL, e, "write results");
     ddt_info info;
     ddt_get_info(e, &info);
+    warn_fallback(info);
     printf("rank %d of %d%s: scored %" PRIu64 " tuples, trees [%u, %u) of %u on %s, kernel %s, combine %s over RCCL\n", r, R,
            hybrid_mode ? " (hybrid)" : "", n, info.tree_begin, info.tree_end, p.num_trees, info.device_name, info.variant_name, cmb.c_str());
     ddt_comm_destroy(c);
@@ -293,6 +302,7 @@ int cmd_score(const std::map<std::string, std::string>& o) {
   ddt_info info;
   ddt_stats st;
   ddt_get_info(e, &info);
+  warn_fallback(info);
   ddt_get_stats(e, &st);
   printf("scored %" PRIu64 " tuples with trees [%u, %u) of %u on %s, kernel %s, %.3f ms (%.2f Mtuples/s incl. PCIe), %" PRIu64
          " result lines\n",
@@ -358,6 +368,7 @@ int cmd_score_sparse(const std::map<std::string, std::string>& o) {
   ddt_info info;
   ddt_stats st;
   ddt_get_info(e, &info);
+  warn_fallback(info);
   ddt_get_stats(e, &st);
   printf("scored %" PRIu64 " tuples with sparse trees [%u, %u) of %u on %s, kernel %s, %.3f ms (%.2f Mtuples/s incl. PCIe)\n", n,
          info.tree_begin, info.tree_end, p.num_trees, info.device_name, info.variant_name, st.exec_ms,

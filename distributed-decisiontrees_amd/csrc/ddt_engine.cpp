@@ -1674,6 +1674,7 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   if (!e->loaded) return DDT_OK;
   const Variant& v = variant(e->variant_id);
   if (!e->sparse && v.kind == kKindQ16 && !e->ens.empty()) out->prepass_groups = e->ens[0].prepass.groups;
+  out->fallback_kernel = (v.kind == kKindGeneric || (v.kind == kKindSparse && (v.opt & 4))) ? 1u : 0u;
   if (e->sparse) {
     uint32_t trees = 0, depth = 0;
     uint64_t lines = 0, img = 0;

@@ -54,6 +54,7 @@ class Info(C.Structure):
         ("model_bytes_unpadded", C.c_uint64), ("image_bytes", C.c_uint64),
         ("variant_name", C.c_char * 64), ("device_name", C.c_char * 64),
         ("num_cus", C.c_uint32), ("clock_khz", C.c_uint32), ("lds_bytes_per_cu", C.c_uint32), ("prepass_groups", C.c_uint32),
+        ("fallback_kernel", C.c_uint32), ("reserved_info", C.c_uint32),
     ]
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDT_ABI_VERSION 4 /* 4: hybrid jobs (ddt_comm_create_hybrid, ddt_score_hybrid_device, ...), ddt_comm_abort; 3: ddt_stats grew */
+#define DDT_ABI_VERSION 5 /* 5: ddt_info grew (fallback_kernel); 4: hybrid jobs (ddt_comm_create_hybrid, ddt_score_hybrid_device, ...), ddt_comm_abort; 3: ddt_stats grew */
 
 /* Threading: an engine is not thread-safe -- calls on ONE engine must not overlap; different engines (also on the
  * same device) are independent.  ddt_*_device calls are asynchronous on the given stream; ddt_destroy and
@@ -91,6 +91,10 @@ typedef struct ddt_info {
   uint32_t prepass_groups;           /* rank-quantised path: feature groups of the LDS-resident rank pre-pass (1 = all tables
                                         resident together, 2/4/8 = one launch split over groups), 0 = transpose + rank kernels
                                         or not the rank-quantised path                                                  */
+  uint32_t fallback_kernel;          /* 1 = the model landed on a CORRECTNESS kernel ("generic" for perfect trees, "sparse_gf_*" for
+                                        sparse forests): right results, no tuned path for this shape (depth / tuple width).  Callers
+                                        that care about throughput should say so loudly (ddt_cli and bench.py do).              */
+  uint32_t reserved_info;            /* 0 */
 } ddt_info;
 
 /* Observability counters, the analogue of CSR 220-226 / appStatus (EngineCSR.sv:113-126,

@@ -49,13 +49,17 @@ def test_gpus_2_self_launched_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rows", "2000000", "--steps", "2", "--warmup", "1",
-                        "--no-other-modes"], capture_output=True, env=env, timeout=900)
+                        "--no-other-modes", "--cpu-seconds", "0.5"], capture_output=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["unit"] == "Mtuples/s" and j["scaling"] == "strong"
     assert abs(j["value"] - 2000000 / j["ms_per_step"] / 1e3) / j["value"] < 1e-3
+    # two real ranks (gloo, one GPU): the combined result of the timed job against the oracle's 2-device model, the oracle timed on rank 0
+    par = j["parity"]
+    assert par["required"] == "within_tolerance" and par["within_tolerance"] is True and par["rows_checked"] > 0, par
+    assert j["cpu_baseline"]["value"] > 0 and "wait behind a barrier" in j["cpu_baseline"]["sample"]
 
 
 def test_hybrid_legs_geometry():

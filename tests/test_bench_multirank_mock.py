@@ -83,6 +83,17 @@ def test_tree_sharded_line_and_every_other_mode(monkeypatch, world_size):
         assert k in om and om[k] > 0, (k, om)
     assert om["row_vs_tree_max_abs_diff_rel"] < 1e-5
     assert L.mock_errors() == 0
+    _check_parity_and_cpu(line, "within_tolerance", world_size)
+
+
+def _check_parity_and_cpu(line, required, world_size, rows=6000):
+    """every N > 1 line carries `parity` (the TIMED job's combined result against the oracle's model of the job) and `cpu_baseline`"""
+    par, cpu = line["parity"], line["cpu_baseline"]
+    assert par["required"] == required and par[required] is True, par
+    assert par["within_tolerance"] is True and par["max_err_over_tolerance"] <= 1.0, par   # north_star's 1e-6, whatever the combine
+    assert 0 < par["rows_checked"] <= rows and par["tolerance_rows_checked"] == par["rows_checked"]
+    assert par["rows_that_differ_from_chain_oracle"] == 0 or required != "bit_exact"
+    assert cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["kind"] == "port" and "wait behind a barrier" in cpu["sample"]
 
 
 def bench_splits(world_size):
@@ -97,6 +108,33 @@ def test_other_headline_shardings_on_eight_ranks(monkeypatch, extra, par):
     line, L = _run(monkeypatch, 8, extra + ["--no-other-modes"])
     assert line["config"]["parallelism"] == par and line["n_gpus"] == 8 and line["value"] > 0
     assert L.mock_errors() == 0
+    # chain combine and replicas: the reference's own order, bit for bit; all-reduce inside a row group: north_star's tolerance
+    _check_parity_and_cpu(line, "bit_exact" if ("chain" in extra or "rows" in extra) else "within_tolerance", 8)
+
+
+@pytest.mark.parametrize("world_size,extra", [(2, ["--combine", "chain"]), (4, ["--combine", "chain"]), (4, ["--shard", "hybrid", "--tree-ranks", "2", "--combine", "chain"]),
+                                              (2, ["--shard", "rows"]), (4, ["--shard", "hybrid", "--tree-ranks", "2", "--no-gather"])])
+def test_parity_of_the_timed_job_on_fewer_ranks(monkeypatch, world_size, extra):
+    line, L = _run(monkeypatch, world_size, extra + ["--no-other-modes"], rows=5000, trees=72)
+    required = "bit_exact" if ("chain" in extra or "rows" in extra) else "within_tolerance"
+    _check_parity_and_cpu(line, required, world_size, rows=5000)
+    assert L.mock_errors() == 0
+
+
+def test_a_wrong_combined_score_fails_the_parity_leg(monkeypatch):
+    """the check has teeth: one score of the timed job's result disturbed by one ulp -> bit_exact false (and counted)"""
+    orig_clone = fake_torch.Tensor.clone
+
+    def bad_clone(self):
+        t = orig_clone(self)
+        if t.a.dtype == np.float32 and t.a.ndim == 1 and t.a.size == 5000:
+            t.a.view(np.uint32)[17] ^= 1
+        return t
+
+    monkeypatch.setattr(fake_torch.Tensor, "clone", bad_clone)
+    line, _ = _run(monkeypatch, 2, ["--combine", "chain", "--no-other-modes"], rows=5000, trees=72)
+    par = line["parity"]
+    assert par["required"] == "bit_exact" and par["bit_exact"] is False and par["rows_that_differ_from_chain_oracle"] == 1
 
 
 def test_the_scores_of_the_timed_job_are_the_oracles(monkeypatch):

@@ -147,9 +147,14 @@ def test_default_line_has_the_contract_keys_and_the_added_objects():
 
 @pytest.mark.parametrize("extra", [[], ["--combine", "chain"], ["--taper", "1", "--chunk-rows", "70000"]])
 def test_multi_gpu_branch_in_a_one_rank_communicator(extra):
-    j = _bench("--rows", "300000", "--trees", "200", "--steps", "2", "--warmup", "1", "--force-collectives", "--no-cpu-baseline", "--no-streamed",
+    j = _bench("--rows", "300000", "--trees", "200", "--steps", "2", "--warmup", "1", "--force-collectives", "--cpu-seconds", "0.3", "--no-streamed",
                *extra)
     assert KEYS <= set(j) and j["n_gpus"] == 1 and j["value"] > 0
+    # the multi-GPU branch checks the TIMED job's combined result against the oracle and times the oracle: one rank =
+    # one device, so whichever combine ran the result is the reference-order sum bit for bit
+    par = j["parity"]
+    assert par["required"] == "bit_exact" and par["bit_exact"] is True and par["within_tolerance"] is True and par["rows_that_differ_from_chain_oracle"] == 0, par
+    assert par["rows_checked"] > 0 and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1
     assert j["config"]["collectives"].startswith("C-ABI") and j["config"]["combine"] in ("allreduce", "chain")
     d = j["scaling_detail"]
     assert "error" not in d, d
@@ -162,6 +167,21 @@ def test_multi_gpu_branch_in_a_one_rank_communicator(extra):
     assert "error" not in o and "status" not in o, o
     assert o["tree_sharded_chain_ms"] > 0 and o["tree_sharded_allreduce_untapered_ms"] > 0 and o["row_sharded_ms"] > 0
     assert o["row_vs_tree_max_abs_diff_rel"] == 0.0        # one rank: every mode computes the same reference-order sums
+
+
+def test_default_command_carries_the_other_baseline_configs():
+    """`python bench.py` (the driver's command; here with fewer steps and a short CPU sample): behind the timed region every other BASELINE
+    config runs briefly on the same GPU -- value, kernel, roofline fraction and an oracle check per config on the ONE line."""
+    j = _bench("--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--no-streamed")
+    assert j["config"]["rows"] == 100_000_000 and j["parity"]["bit_exact"] is True and j["config"]["fallback_kernel"] is False
+    oc = j["other_configs"]
+    for cfg in ("1", "2", "4", "5", "6"):
+        c = oc[cfg]
+        assert "error" not in c and "skipped" not in c, (cfg, c)
+        assert c["value"] > 0 and c["parity"]["bit_exact"] is True and c["parity"]["rows_checked"] > 0, (cfg, c)
+        assert 0 < c["roofline"]["frac"] < 1 and c["roofline"]["kernel_ms"] <= c["ms_per_step"] * 1.05 and c["fallback_kernel"] is False, (cfg, c)
+    assert oc["1"]["roofline"]["frac"] > 0.5            # the HBM-bound shape
+    assert j["other_modes"]["sum_mode2"]["bit_exact_vs_reference_adder"] is True and j["other_modes"]["sum_mode2"]["rows_checked"] >= 4_000_000
 
 
 def test_one_shard_of_a_tree_sharded_job_on_one_gpu():
