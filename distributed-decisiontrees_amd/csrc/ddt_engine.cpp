@@ -486,7 +486,9 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
   const uint32_t W = tuple_words(e->p);
   if (v.kind == kKindQ16) {
     // depth <= 8: two blocks per CU or it is not worth it; deeper trees have no other specialised kernel: one block
-    if (W > 32u || v.lds_bytes_q16(W) > (v.levels <= 8 ? kMaxLdsBytes / 2u : kMaxLdsBytes)) return false;
+    if (W > 32u || v.lds_bytes_q16(W) > ((v.levels <= 8 || v.deep()) ? kMaxLdsBytes / 2u : kMaxLdsBytes)) return false;
+    // deep kernels: their stage gathers address the image with 32-bit byte offsets through one buffer resource
+    if (v.deep() && (uint64_t)padded_trees(v, max_trees(e)) * v.tree_bytes_q16() >= (1ull << 31)) return false;
     if ((v.opt & 4) && e->p.sum_mode == 1u) return false;  // cluster-major image order: not the stream order the fp64 sum is defined on
     if (rank_tables(e).max_len <= kQ16MaxTable) return true;
     // more distinct thresholds on a feature than u16 ranks hold: the plain cluster-major kernels score the ensemble in PARTS with
@@ -522,6 +524,13 @@ int auto_variant(const ddt_engine* e) {
   // 3.2 ms + 0.147 ms/tree => break-even near 200 trees per engine; 250 trees (4-way shard of 1000) goes to q16.
   // With small tables (they all fit LDS together, e.g. a 125-tree shard) the pre-pass is one fused kernel and the
   // break-even drops accordingly (kQ16MinTreeLevels).
+  // Perfect trees deeper than 8 levels (the reference's own example is 512 x depth 12, profiler/profiler.cpp:32-38; a depth-12 tree is exactly
+  // one PU's memory, DTPU.sv:22-25): the deep rank-quantised kernels -- K = 8 / 9 levels out of LDS at two blocks per CU, the rest in
+  // (D - K + 1) / 2 gathers of 16-byte records per tree.  Whatever the number of trees: the alternative is the generic kernel.
+  if (e->p.num_levels > 8u && e->p.sum_mode != 1u && tuple_words(e->p) <= 32u) {
+    for (int i = 0; i < num_variants(); ++i)
+      if (variant(i).kind == kKindQ16 && variant(i).deep() && variant_fits(variant(i), e)) return i;
+  }
   uint32_t q16_min = 224u;
   if (tuple_words(e->p) <= 32u && total_trees(e) * e->p.num_levels >= kQ16MinTreeLevels && total_trees(e) < 224u && prepass_plan_exists(e))
     q16_min = total_trees(e);
@@ -775,8 +784,11 @@ uint32_t cm_position(uint32_t i, uint32_t T, uint32_t Cc) {
 int plan_q16_parts(ddt_engine* e, const Variant& v, const Ensemble& m, Q16HostImage& h) {
   const uint32_t T = m.trees(), nint = e->nint, W = tuple_words(e->p), CT = (uint32_t)v.chunk_trees;
   const uint32_t Cc = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, Tpad = padded_trees(v, T), n_chunks = Tpad / CT;
+  // (a part ends on a whole PU group -- the sum's state between two launches is {cluster accumulator, running total}, not a half group: the
+  // deep kernels' chunks of 4 trees are taken in pairs)
+  const uint32_t pc = CT < 8u ? 8u / CT : 1u;  // chunks per planning step
   std::vector<std::vector<uint32_t>> trees_of_chunk(n_chunks);
-  for (uint32_t i = 0; i < T; ++i) trees_of_chunk[cm_position(i, T, Cc) / CT].push_back(i);
+  for (uint32_t i = 0; i < T; ++i) trees_of_chunk[cm_position(i, T, Cc) / CT / pc * pc].push_back(i);
   try {
     h.part_chunk_begin.assign(1, 0u);
     h.part_tables.clear();
@@ -790,7 +802,7 @@ int plan_q16_parts(ddt_engine* e, const Variant& v, const Ensemble& m, Q16HostIm
       *out = std::move(t);
       return true;
     };
-    for (uint32_t c = 0; c < n_chunks; ++c) {
+    for (uint32_t c = 0; c < n_chunks; c += pc) {
       std::vector<std::vector<uint32_t>> add(W);
       for (uint32_t i : trees_of_chunk[c])
         for (uint32_t n = 0; n < nint; ++n) add[m.fidx[(size_t)i * nint + n]].push_back(thr_key(e->p, m.thr[(size_t)i * nint + n]));
@@ -803,7 +815,7 @@ int plan_q16_parts(ddt_engine* e, const Variant& v, const Ensemble& m, Q16HostIm
       h.part_chunk_begin.push_back(c);
       cur = RankTables{};
       cur.keys.assign(W, {});
-      if (!merged_fits(add, &next)) return fail(e, DDT_EUNSUPPORTED, "one chunk of %u trees has more than %u distinct thresholds on a feature", CT, kQ16MaxTable);
+      if (!merged_fits(add, &next)) return fail(e, DDT_EUNSUPPORTED, "one PU group of trees has more than %u distinct thresholds on a feature", kQ16MaxTable);
       cur = std::move(next);
     }
     h.part_tables.push_back(cur);
@@ -817,7 +829,7 @@ int plan_q16_parts(ddt_engine* e, const Variant& v, const Ensemble& m, Q16HostIm
 // host half of build_image_q16 (no HIP call; also behind the test hook ddt_debug_model_image)
 int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const RankTables& rt, bool upload_tables, Q16HostImage& h) {
   const uint32_t D = e->p.num_levels, T = m.trees(), nint = e->nint, nleaf = e->nleaf, W = tuple_words(e->p);
-  const uint32_t tree_words = (8u << D) / 4u, Tpad = padded_trees(v, T);
+  const uint32_t tree_words = v.tree_bytes_q16() / 4u, Tpad = padded_trees(v, T);
   std::vector<uint32_t>&fast = h.fast, &slow = h.slow;
   try {
     fast.assign((size_t)Tpad * tree_words, 0u);
@@ -859,6 +871,47 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
     while (h.part_chunk_begin[part + 1] <= c) ++part;
     return h.part_tables[part];
   };
+  if (v.deep()) {
+    // deep kernels (ddt_internal.h "deep rank-quantised kernels"): per chunk the tops of its CT trees, then their stage blocks
+    const uint32_t K = (uint32_t)v.top, topw = (4u << K) / 4u, deepw = v.deep_bytes() / 4u, G = v.deep_stages();
+    auto top_off = [&](uint32_t pos) { return (size_t)(pos / CT) * CT * tree_words + (size_t)(pos % CT) * topw; };
+    auto deep_off = [&](uint32_t pos) { return (size_t)(pos / CT) * CT * tree_words + (size_t)CT * topw + (size_t)(pos % CT) * deepw; };
+    slow = fast;
+    for (uint32_t i = 0; i < T; ++i) {
+      const uint32_t pos = cm_pos(i);
+      const RankTables& trt = tables_of(pos);
+      auto record = [&](uint32_t n, bool with_flag) -> uint32_t {  // node n of tree i (0-based heap)
+        const uint32_t j = m.fidx[(size_t)i * nint + n], key = thr_key(e->p, m.thr[(size_t)i * nint + n]);
+        const auto& k = trt.keys[j];
+        const uint32_t idx = (uint32_t)(std::lower_bound(k.begin(), k.end(), key, [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; }) - k.begin());
+        return (idx + 1u) | ((j * row) << 16) | ((with_flag && m.mright[(size_t)i * nint + n]) ? 1u << 16 : 0u);
+      };
+      for (int sl = 0; sl < 2; ++sl) {
+        std::vector<uint32_t>& im = sl ? slow : fast;
+        uint32_t* t = im.data() + top_off(pos);
+        for (uint32_t n = 0; n + 1u < (1u << K); ++n) t[n + 1] = record(n, sl != 0);
+        for (uint32_t g = 0; g < G; ++g) {
+          const uint32_t L = v.deep_stage_level(g), first = (1u << L) - 1u;  // first node of level L, 0-based heap
+          uint32_t* st = im.data() + deep_off(pos) + v.deep_stage_off(g) / 4u;
+          for (uint32_t q = 0; q < (1u << L); ++q) {
+            const uint32_t n = first + q;
+            st[4u * q + 0u] = record(n, sl != 0);
+            if (g + 1u < G) {  // pair: the node, its two children, the byte offset of its first grandchild's record in the next stage
+              st[4u * q + 1u] = record(2u * n + 1u, sl != 0);
+              st[4u * q + 2u] = record(2u * n + 2u, sl != 0);
+              st[4u * q + 3u] = 64u * q;
+            } else {  // terminal: level D-1 with its two leaves
+              st[4u * q + 1u] = m.leaf[(size_t)i * nleaf + 2u * q];
+              st[4u * q + 2u] = m.leaf[(size_t)i * nleaf + 2u * q + 1u];
+              st[4u * q + 3u] = 0u;
+            }
+          }
+        }
+      }
+    }
+    h.Tpad = Tpad;
+    return DDT_OK;
+  }
   for (uint32_t i = 0; i < T; ++i) {
     uint32_t* t = fast.data() + rec_off(cm_pos(i));
     const RankTables& trt = tables_of(cm_pos(i));

@@ -156,6 +156,7 @@ struct Variant {
   int stage;          // tile: 0 = model chunks staged through registers, 1 = global->LDS DMA
   int opt;            // tile: bit 0 = last level fused with its leaves (image layout 1); stream: max lines per tuple
   hipError_t (*launch)(const ScoreArgs&, const Variant&, hipStream_t);
+  int top = 0;        // rank-quantised DEEP kernels ("q16d_*", opt bit 5): K, the levels of a tree staged in LDS; the levels below are gathered
 
   uint32_t tile() const { return (uint32_t)threads * (uint32_t)tuples_per_lane; }
   uint32_t row_bytes() const { return tile() * 4u; }
@@ -187,8 +188,25 @@ struct Variant {
   // opt bit 0 ("_gl"): only the node records are staged in LDS (4*2^D bytes per tree); the leaves stay in global memory and
   // are gathered through the vector-memory path.  The image keeps 8*2^D bytes per tree either way: per chunk the records
   // of its trees, then (opt 1) the leaves of its trees / (opt 0) records and leaves tree by tree.
-  uint32_t tree_bytes_q16() const { return 8u << levels; }
-  uint32_t lds_tree_bytes_q16() const { return (opt & 1) ? (4u << levels) : (8u << levels); }
+  // ---- deep rank-quantised kernels ("q16d_dD_kK_*", opt bit 5; always cluster-major, opt bit 2): perfect trees of depth D > K.  Per tree
+  //   top     4 * 2^K bytes: the records of levels 0..K-1 (1-based heap, record 0 padding) -- the part of a chunk that is staged in LDS
+  //   stages  G = (D - K + 1) / 2 blocks of 16-byte records (D - K is odd), gathered through a buffer resource, ONE gather per stage:
+  //           stage g < G-1 ("pair", level L = K + 2g, 2^L records): {record of node i, record of its left child, of its right child, 64 * i}
+  //                         -- two levels per gather; the next stage's record of the grandchild is at byte  w + 32 * right0 + 16 * right1
+  //           stage G-1     ("terminal", level D-1, 2^(D-1) records): {record of node i, left leaf, right leaf, 0}
+  //   Records are the q16 records {rank (lo16) | feature row byte offset (hi16; bit 16 = miss_right in the slow image)}.
+  //   Image = per chunk of chunk_trees trees their tops, then their stage blocks tree by tree.
+  bool deep() const { return kind == kKindQ16 && (opt & 32) != 0; }
+  uint32_t deep_stages() const { return ((uint32_t)levels - (uint32_t)top + 1u) / 2u; }
+  uint32_t deep_stage_level(uint32_t g) const { return g + 1u < deep_stages() ? (uint32_t)top + 2u * g : (uint32_t)levels - 1u; }
+  uint32_t deep_stage_off(uint32_t g) const {  // byte offset of stage g inside a tree's stage blocks
+    uint32_t off = 0;
+    for (uint32_t k = 0; k < g; ++k) off += 16u << deep_stage_level(k);
+    return off;
+  }
+  uint32_t deep_bytes() const { return deep_stage_off(deep_stages()); }
+  uint32_t tree_bytes_q16() const { return deep() ? (4u << top) + deep_bytes() : (8u << levels); }
+  uint32_t lds_tree_bytes_q16() const { return deep() ? (4u << top) : (opt & 1) ? (4u << levels) : (8u << levels); }
   uint32_t feat_off_q16() const { return 2u * lds_tree_bytes_q16() * (uint32_t)chunk_trees; }
   // opt bit 1 ("_s2"): the records of levels 0-1 come from SGPRs (scalar loads), see ddt_kernels.hip
   uint32_t lds_bytes_q16(uint32_t tuple_words) const { return feat_off_q16() + tuple_words * tile() * 2u; }

@@ -142,7 +142,32 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
       const bool slow = x.tile_flags[i / 1024] != 0u;
       const uint32_t* img = reinterpret_cast<const uint32_t*>(slow ? x.img_slow : a.img);
       const uint16_t* rk = x.q + i * W;
-      for (uint32_t t = 0; t < a.n_trees; ++t) {
+      for (uint32_t t = 0; t < a.n_trees && v.deep(); ++t) {
+        // deep kernels (csrc/ddt_internal.h): K levels over the tree's top records, then one 16-byte record per stage -- pairs carry the
+        // node, its two children and the byte offset of the next stage's record block, the terminal stage the last level and its leaves
+        const uint32_t K = (uint32_t)v.top, treew = v.tree_bytes_q16() / 4u, topw = (4u << K) / 4u, deepw = v.deep_bytes() / 4u, G = v.deep_stages();
+        const uint32_t* top = img + (size_t)(t / CT) * CT * treew + (size_t)(t % CT) * topw;
+        const uint32_t* deep = img + (size_t)(t / CT) * CT * treew + (size_t)CT * topw + (size_t)(t % CT) * deepw;
+        auto goes_right = [&](uint32_t nd) -> uint32_t {
+          const uint32_t off = slow ? ((nd >> 16) & 0xFFFEu) : (nd >> 16);
+          const uint32_t f = rk[off / row];
+          bool right = f >= (nd & 0xFFFFu);
+          if (slow && f == 0xFFFFu) right = ((nd >> 16) & 1u) != 0u;
+          return right ? 1u : 0u;
+        };
+        uint32_t m = 1;
+        for (uint32_t lvl = 0; lvl < K; ++lvl) m = 2u * m + goes_right(top[m]);
+        uint32_t byte = 16u * (m - (1u << K));
+        float lf = 0.0f;
+        for (uint32_t g = 0; g < G; ++g) {
+          const uint32_t* rec = deep + v.deep_stage_off(g) / 4u + byte / 4u;
+          const uint32_t r0 = goes_right(rec[0]);
+          if (g + 1u < G) byte = rec[3] + 32u * r0 + 16u * goes_right(rec[1u + r0]);
+          else lf = f_of(rec[1u + r0]);
+        }
+        img_order[t] = lf;
+      }
+      for (uint32_t t = 0; t < a.n_trees && !v.deep(); ++t) {
         const size_t rec_off = gl ? (size_t)(t / CT) * CT * tw + (size_t)(t % CT) * half : (size_t)t * tw;
         const size_t leaf_off = gl ? (size_t)(t / CT) * CT * tw + (size_t)CT * half + (size_t)(t % CT) * half : (size_t)t * tw + half;
         uint32_t m = 1;
@@ -155,6 +180,13 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
           m = 2u * m + (right ? 1u : 0u);
         }
         img_order[t] = f_of(img[leaf_off + m - half]);
+        // the one-launch multi-class kernel does NOT walk the second sub-group of the chunk the host names (Q16Aux::seg_tail_left: the
+        // padding half of a class's partly filled PU group) and adds +0 for its four trees: do exactly that, so that a host that names
+        // the wrong chunk drops real trees here as it would on the GPU
+        if (S > 1u && x.seg_tail_left && x.seg_chunks && CT == 8u) {
+          const uint32_t in_seg = t % seg_trees, chunk = in_seg / CT;
+          if (x.seg_chunks - chunk == x.seg_tail_left && in_seg % CT >= 4u) img_order[t] = 0.0f;
+        }
       }
       if (cm && (x.state_in || x.state_out || x.group0)) {
         // one PART of an ensemble scored in parts: the kernel's own accumulate over the groups of this image in cluster-major order,
@@ -266,6 +298,12 @@ const Variant g_mock_variants[] = {
     Variant{"q16_d8_c8_u4_gl", kKindQ16, 8, 1024, 1, 8, 4, 1, 1, &launch_q16},
     Variant{"q16_d8_c4_u4", kKindQ16, 8, 1024, 1, 4, 4, 1, 0, &launch_q16},
     Variant{"q16_d6_c16_u4", kKindQ16, 6, 1024, 1, 16, 4, 1, 0, &launch_q16},
+    // deep rank-quantised kernels (opt 4 | 32: cluster-major, deep; last field = K)
+    Variant{"q16d_d12_k9_c4_u4", kKindQ16, 12, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
+    Variant{"q16d_d10_k9_c4_u4", kKindQ16, 10, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
+    Variant{"q16d_d11_k8_c8_u4", kKindQ16, 11, 1024, 1, 8, 4, 1, 36, &launch_q16, 8},
+    Variant{"q16d_d9_k8_c8_u4", kKindQ16, 9, 1024, 1, 8, 4, 1, 36, &launch_q16, 8},
+    Variant{"q16d_d14_k9_c4_u4", kKindQ16, 14, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
     Variant{"d8_t1024_r1_c4_u4_dma_f", kKindTile, 8, 1024, 1, 4, 4, 1, 1, &launch_records},
     Variant{"d6_t1024_r1_c16_u4_dma", kKindTile, 6, 1024, 1, 16, 4, 1, 0, &launch_records},
     Variant{"d4_t256_r1_c64_u8_dma", kKindTile, 4, 256, 1, 64, 8, 1, 0, &launch_records},

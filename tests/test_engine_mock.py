@@ -132,13 +132,20 @@ def test_feeder_double_buffering(mock, variant, feeder_rows, policy, seed):
 @pytest.mark.parametrize("T,D,F,K,variant", [(100, 8, 32, 10, "q16_d8_c8_u4_gl"), (60, 6, 16, 3, None), (35, 8, 32, 5, "d8_t1024_r1_c4_u4_dma_f"),
                                              # the persistent kernel: every class in ONE launch (classes of equal size: the images stand back
                                              # to back) / one launch per class (37 trees over 5 classes: 8, 8, 7, 7, 7)
-                                             (100, 8, 32, 10, "q16_d8_c8_u4_gl_s2_cm_p"), (35, 8, 32, 5, "q16_d8_c8_u4_gl_s2_cm_p"), (37, 8, 32, 5, "q16_d8_c8_u4_gl_s2_cm_p")])
-def test_class_launches_on_two_streams(mock, T, D, F, K, variant, policy, seed):
-    """One-vs-all classes: class 0 (+ the shared rank pre-pass) on the caller's stream, odd classes on the engine's own stream."""
+                                             (100, 8, 32, 10, "q16_d8_c8_u4_gl_s2_cm_p"), (35, 8, 32, 5, "q16_d8_c8_u4_gl_s2_cm_p"), (37, 8, 32, 5, "q16_d8_c8_u4_gl_s2_cm_p"),
+                                             (300, 8, 32, 3, "q16_d8_c8_u4_gl_s2_cm_p"), (264, 8, 32, 2, "q16_d8_c8_u4_gl_s2_cm_p")])
+@pytest.mark.parametrize("clusters", [1, 2, 4])
+def test_class_launches_on_two_streams(mock, T, D, F, K, variant, policy, seed, clusters):
+    """One-vs-all classes: class 0 (+ the shared rank pre-pass) on the caller's stream, odd classes on the engine's own stream.
+    clusters > 1 with the one-launch persistent kernel: a class's partly filled PU group sits in the MIDDLE of its cluster-major image
+    (10 trees per class, 2 clusters: groups {0}, {1} -> the partial group 1 is last; 100 per class, 2 clusters: group 12 of 13 lands at
+    position 6) -- the kernel skips the padding half of the chunk the host names."""
+    if clusters > 1 and (variant is None or "_cm" not in variant):
+        pytest.skip("cluster-major images only")
     mock.mock_reset(policy, seed, 8)
     n = 2100
-    m, x = O.gen_model(T, D, F, 1), O.gen_tuples(0, n, F, 1)
-    p = ddt.make_params(T, D, F, clusters=1)
+    m, x = O.gen_model(T, D, F, 1, clusters=clusters), O.gen_tuples(0, n, F, 1)
+    p = ddt.make_params(T, D, F, clusters=clusters)
     labels, cs = O.classify(m, x, K)
     e, s = _engine(mock), _stream(mock)
     assert mock.ddt_set_option(e, b"variant", -1 if variant is None else _variant(mock, variant)) == 0
@@ -736,4 +743,51 @@ def _sparse_fuzz_round(mock, seed, seen):
             assert rc == 0, ctx
             assert np.array_equal(_bits(out), _bits(want)), ctx
             seen.add(info.variant_name.decode().rsplit("_k", 1)[0])
+    mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("T,D,F,clusters,name,parts", [(20, 12, 32, 1, "q16d_d12_k9_c4_u4", 1), (13, 12, 8, 4, "q16d_d12_k9_c4_u4", 1),
+                                                        (40, 12, 4, 2, "q16d_d12_k9_c4_u4", 2), (70, 12, 3, 8, "q16d_d12_k9_c4_u4", 4),
+                                                        (11, 10, 16, 1, "q16d_d10_k9_c4_u4", 1), (9, 11, 20, 8, "q16d_d11_k8_c8_u4", 1),
+                                                        (17, 9, 32, 2, "q16d_d9_k8_c8_u4", 1), (5, 14, 12, 1, "q16d_d14_k9_c4_u4", 1)])
+def test_deep_perfect_trees_on_the_deep_kernels(mock, T, D, F, clusters, name, parts):
+    """Perfect trees deeper than 8 levels (the reference's own example: 512 x depth 12, profiler/profiler.cpp:32-38) take the deep
+    rank-quantised kernels by themselves: K levels as a heap of 4-byte records, then pair / terminal records of 16 bytes per stage
+    (csrc/ddt_internal.h).  The host side -- image packing in cluster-major order, the records' own next-block offsets, parts with rank
+    tables of their own when a feature carries more than 32767 distinct thresholds, the sum's state between the parts -- against the
+    oracle bit for bit, both adders, tiles with and without missing values, resident and host calls."""
+    mock.mock_reset(2, 9, 8)
+    n = 1300
+    m, x = O.gen_model(T, D, F, 0, clusters=clusters), O.gen_tuples(0, n, F, 0)
+    x[1100, F - 1] = 0x7FC00000                                                  # the second tile holds a missing value: slow image there
+    e, st, info = _engine(mock), ddt.Stats(), ddt.Info()
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), None)
+        assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == name and info.fallback_kernel == 0
+        want = O.score_fast(m, x, sum_mode=ref)
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0
+        before = st.kernel_launches
+        s = _stream(mock)
+        outs = [np.full(n, np.nan, np.float32) for _ in range(2)]
+        for out in outs:
+            assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0, mock.ddt_last_error(e)
+        assert mock.hipStreamSynchronize(s) == 0
+        for out in outs:
+            assert np.array_equal(_bits(out), _bits(want)), (T, D, clusters, sum_mode)
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.kernel_launches - before == 2 * parts
+        host = np.full(n, np.nan, np.float32)
+        assert mock.ddt_set_option(e, b"feeder_rows", 512) == 0
+        assert mock.ddt_score(e, x.ctypes.data, n, host.ctypes.data) == 0 and np.array_equal(_bits(host), _bits(want))
+    # a shard of a tree-sharded job (trees [b, e) of the list, the whole model's cluster count)
+    if T >= 16:
+        _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters), None, shard=(1, 2))
+        out = np.full(n, np.nan, np.float32)
+        assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
+        assert np.array_equal(_bits(out), _bits(O.score_shard(m, x, (T + 1) // 2, T, sum_mode=O.SUM_REF_NATIVE)))
+    # the fp64 sum runs in stream order: not on a cluster-major image -> the generic kernel, and the engine says so
+    _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=1), None)
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == "generic" and info.fallback_kernel == 1
+    out = np.full(n, np.nan, np.float32)
+    assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
+    assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=O.SUM_F64_SEQ)))
     mock.ddt_destroy(e)

@@ -1,0 +1,93 @@
+"""The deep rank-quantised kernels (`q16d_dD_kK_*`, csrc/ddt_kernels.hip score_q16d_kernel) against the oracle on the GPU: perfect trees
+of depth 9..14 -- the reference's own example configuration is 512 trees x depth 12 x 32 features (profiler/profiler.cpp:32-38; a depth-12
+tree is one PU's memory, DTPU.sv:22-25).  K levels out of LDS, then (D - K + 1) / 2 gathers of 16-byte pair / terminal records per tree, as
+a pipeline that rotates across sub-groups and chunk barriers; cluster-major sums; ensembles with more than 32767 thresholds on a feature
+in parts.  Every row compared bit for bit, both adders, tiles with and without missing values, ragged sizes, many tiles per CU."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import ddt
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _tuples(n, F, seed, holes):
+    x = O.gen_tuples(seed, n, F, dist=0)
+    rng = np.random.default_rng(seed)
+    for r in rng.integers(0, n, holes):
+        x[r, rng.integers(0, F)] = 0x7FC00000
+    return x
+
+
+@pytest.mark.parametrize("T,D,F,clusters,name,n", [(20, 12, 32, 1, "q16d_d12_k9_c4_u4", 700_001), (13, 12, 8, 4, "q16d_d12_k9_c4_u4", 150_000),
+                                                    (64, 12, 32, 8, "q16d_d12_k9_c4_u4", 300_000),
+                                                    (40, 12, 4, 2, "q16d_d12_k9_c4_u4", 120_000),      # 41 k thresholds per feature: two parts
+                                                    (11, 10, 16, 1, "q16d_d10_k9_c4_u4", 200_000), (9, 11, 20, 8, "q16d_d11_k8_c8_u4", 200_000),
+                                                    (17, 9, 32, 2, "q16d_d9_k8_c8_u4", 200_000), (6, 13, 24, 1, "q16d_d13_k8_c8_u4", 100_000),
+                                                    (5, 14, 12, 1, "q16d_d14_k9_c4_u4", 100_000)])
+def test_deep_kernels_equal_the_oracle(T, D, F, clusters, name, n):
+    import torch
+
+    m = O.gen_model(T, D, F, dist=1, clusters=clusters)
+    x = _tuples(n, F, 3 + T + D, 30)
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    e = ddt.Engine(0)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        want = O.score_fast(m, x, sum_mode=ref)
+        e.load_model(ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), m.wlines, m.flines)
+        info = e.info()
+        assert info.variant_name.decode() == name and info.fallback_kernel == 0      # the engine's own choice
+        for _ in range(2):
+            got = e.score_device(d)
+            torch.cuda.synchronize()
+            bad = np.flatnonzero(_bits(got.cpu().numpy()) != _bits(want))
+            assert bad.size == 0, (name, sum_mode, bad[:8], bad.size)
+        for k in (1, 777, 2048, 5000):                                                   # ragged, one tile, two tiles
+            got = e.score_device(d[:k])
+            torch.cuda.synchronize()
+            assert np.array_equal(_bits(got.cpu().numpy()), _bits(want[:k])), k
+        assert np.array_equal(_bits(e.score(x[:40_000])), _bits(want[:40_000]))         # host feeder path
+    # the generic kernel gives the same bits (it is what these shapes ran on before) -- and says that it is the fallback
+    e.set_option("variant", 0)
+    assert e.info().variant_name.decode() == "generic" and e.info().fallback_kernel == 1
+    got = e.score_device(d[:20_000])
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(got.cpu().numpy()), _bits(want[:20_000]))
+    e.close()
+
+
+def test_the_references_own_configuration():
+    """512 trees x depth 12 x 32 features (profiler/profiler.cpp:32-38): 65 k distinct thresholds per feature -> parts; a shard of it; classes"""
+    import torch
+
+    T, D, F, n = 512, 12, 32, 400_003
+    m = O.gen_model(T, D, F, dist=0)
+    x = _tuples(n, F, 12, 20)
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    e = ddt.Engine(0)
+    e.load_model(ddt.make_params(T, D, F), m.wlines, m.flines)
+    assert e.info().variant_name.decode() == "q16d_d12_k9_c4_u4"
+    want = O.score_fast(m, x)
+    launches = e.stats().kernel_launches
+    got = e.score_device(d)
+    torch.cuda.synchronize()
+    assert e.stats().kernel_launches - launches >= 2                                     # scored in parts
+    assert np.array_equal(_bits(got.cpu().numpy()), _bits(want))
+    e.load_model(ddt.make_params(T, D, F), m.wlines, m.flines, 3, 8)                     # shard 3 of 8: 64 trees
+    got = e.score_device(d[:100_000])
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(got.cpu().numpy()), _bits(O.score_shard(m, x[:100_000], 192, 256, sum_mode=O.SUM_REF_NATIVE)))
+    # four classes of 128 trees, one launch per class (and per part)
+    e.load_model_multiclass(ddt.make_params(T, D, F, clusters=ddt.default_clusters(T // 4)), m.wlines, m.flines, 4, True)
+    assert e.info().variant_name.decode() == "q16d_d12_k9_c4_u4"
+    mc = O.Model(O.make_params(T, D, F, clusters=ddt.default_clusters(T // 4)), m.wlines, m.flines)
+    want_l, want_cs = O.classify_fast(mc, x[:150_000], 4, True)
+    dl, dcs = e.classify_device(d[:150_000])
+    torch.cuda.synchronize()
+    assert np.array_equal(dl.cpu().numpy(), want_l) and np.array_equal(_bits(dcs.cpu().numpy()), _bits(want_cs))
+    e.close()

@@ -109,3 +109,52 @@ def test_classes_of_unequal_size_fall_back_to_one_launch_per_class():
     assert e.stats().kernel_launches == launches + K
     assert np.array_equal(dl.cpu().numpy(), want_l) and np.array_equal(_bits(dcs.cpu().numpy()), _bits(want_cs))
     e.close()
+
+
+@pytest.mark.parametrize("per_class,C,K", [(100, 2, 3), (132, 4, 3), (100, 8, 2), (12, 2, 4), (260, 4, 2)])
+def test_partial_pu_group_inside_a_cluster_major_image(per_class, C, K):
+    """with more than one cluster the partly filled PU group of a class (trees per class mod 8 in 1..4) is the last group of ITS
+    cluster's run in the cluster-major image, not of the image; the one-launch kernel must skip the padding half of THAT group and walk every
+    real tree (it used to drop four real trees and walk the padding whenever G > C and G % C != 0)."""
+    import torch
+
+    D, F, T, n = 8, 32, per_class * K, 300_000
+    m = O.gen_model(T, D, F, dist=1, clusters=C)
+    x = _tuples(n, F, 40 + per_class, 15)
+    want_l, want_cs = O.classify_fast(m, x, K, True)
+    e = ddt.Engine(0)
+    e.load_model_multiclass(ddt.make_params(T, D, F, clusters=C), m.wlines, m.flines, K, True)
+    e.set_option("variant", _vid())
+    assert e.info().variant_name.decode() == NAME
+    launches = e.stats().kernel_launches
+    dl, dcs = e.classify_device(torch.from_numpy(x.view(np.int32)).cuda())
+    torch.cuda.synchronize()
+    assert e.stats().kernel_launches == launches + 1
+    assert np.array_equal(_bits(dcs.cpu().numpy()), _bits(want_cs)) and np.array_equal(dl.cpu().numpy(), want_l)
+    e.close()
+
+
+def test_unequal_classes_one_launch_per_class_share_no_tile_counter():
+    """unequal classes fall back to one "_p" launch per class; those launches take their tiles from ONE ticket counter, so they
+    must not overlap on two streams.  More tiles than 2 x resident blocks (the tickets are used), more than two classes (the two-stream
+    alternation would apply), every row compared."""
+    import torch
+
+    T, K, D, F, n = 37, 3, 8, 32, 2_300_001                      # interleaved: 13, 12, 12 trees
+    m = O.gen_model(T, D, F, dist=1, clusters=1)
+    x = _tuples(n, F, 77, 50)
+    want_l, want_cs = O.classify_fast(m, x, K, True)
+    e = ddt.Engine(0)
+    e.load_model_multiclass(ddt.make_params(T, D, F, clusters=1), m.wlines, m.flines, K, True)
+    e.set_option("variant", _vid())
+    assert e.info().variant_name.decode() == NAME
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    for _ in range(2):
+        launches = e.stats().kernel_launches
+        dl, dcs = e.classify_device(d)
+        torch.cuda.synchronize()
+        assert e.stats().kernel_launches == launches + K
+        bad = np.flatnonzero((_bits(dcs.cpu().numpy()) != _bits(want_cs)).any(axis=0))
+        assert bad.size == 0, (bad[:8], bad.size)
+        assert np.array_equal(dl.cpu().numpy(), want_l)
+    e.close()
