@@ -1741,7 +1741,7 @@ __global__ __launch_bounds__(kQTile, (D - K + 1) / 2 >= 3 ? 4 : 8) void score_q1
   static_assert(FEAT_OFF % ROW == 0, "row|lane OR trick");
   const int tid = threadIdx.x;
   const uint64_t tile = blockIdx.x, tile0 = tile * kQTile;
-  const uint32_t W = a.tuple_words, n_chunks = a.n_chunks;  // even (whole PU groups; an ensemble's part ends on a whole group too)
+  const uint32_t W = a.tuple_words, n_chunks = a.n_chunks;  // whole PU groups (an ensemble's part ends on a whole group too)
   const bool slow = __builtin_amdgcn_readfirstlane((int)x.tile_flags[tile]) != 0;
   const uint4* img = slow ? x.img_slow : a.img;
 
@@ -1895,9 +1895,11 @@ __global__ __launch_bounds__(kQTile, (D - K + 1) / 2 >= 3 ? 4 : 8) void score_q1
       else if (SGS * G * U == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       __syncthreads();
-      dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 1) * GSKIP, k + 1, CHUNK_BYTES, tid);  // n_chunks is even
+      const bool more1 = k + 1 < n_chunks;  // (chunks of 4 trees come in pairs: whole PU groups; chunks of 8 may end here)
+      if (more1) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 1) * GSKIP, k + 1, CHUNK_BYTES, tid);
       step(slow_tag, I0{}, I0{}, std::true_type{}, I0{}, k, s_index++);
       if constexpr (SGS == 2) step(slow_tag, I0{}, I1{}, std::true_type{}, I0{}, k, s_index++);
+      if (!more1) break;
       if (SGS * G * U == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else if (SGS * G * U == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (SGS * G * U == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -1930,7 +1932,7 @@ static hipError_t launch_q16d(const ScoreArgs& a, const Variant& v, hipStream_t 
   const Q16Aux& x = *reinterpret_cast<const Q16Aux*>(a.aux);
   const uint64_t tiles = (a.n + kQTile - 1) / kQTile;
   if (tiles == 0) return hipSuccess;
-  if (tiles > 0x7FFFFFFFull || (a.n_chunks & 1u) || a.sum_mode == 1u) return hipErrorInvalidValue;
+  if (tiles > 0x7FFFFFFFull || (CT == 4 && (a.n_chunks & 1u)) || a.sum_mode == 1u) return hipErrorInvalidValue;
   auto kern = score_q16d_kernel<D, K, CT>;
   const uint32_t lds = v.lds_bytes_q16(a.tuple_words);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
