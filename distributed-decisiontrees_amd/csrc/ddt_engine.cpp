@@ -486,14 +486,15 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
   const uint32_t W = tuple_words(e->p);
   if (v.kind == kKindQ16) {
     // depth <= 8: two blocks per CU or it is not worth it; deeper trees have no other specialised kernel: one block
-    if (W > 32u || v.lds_bytes_q16(W) > ((v.levels <= 8 || v.deep()) ? kMaxLdsBytes / 2u : kMaxLdsBytes)) return false;
+    if (W > v.max_tuple_words_q16() || v.lds_bytes_q16(W) > (((v.levels <= 8 || v.deep()) && !v.wide()) ? kMaxLdsBytes / 2u : kMaxLdsBytes)) return false;
     // deep kernels: their stage gathers address the image with 32-bit byte offsets through one buffer resource
     if (v.deep() && (uint64_t)padded_trees(v, max_trees(e)) * v.tree_bytes_q16() >= (1ull << 31)) return false;
     if ((v.opt & 4) && e->p.sum_mode == 1u) return false;  // cluster-major image order: not the stream order the fp64 sum is defined on
     if (rank_tables(e).max_len <= kQ16MaxTable) return true;
     // more distinct thresholds on a feature than u16 ranks hold: the plain cluster-major kernels score the ensemble in PARTS with
     // rank tables of their own (Q16Aux::state_in / state_out); one chunk of 8 trees never exceeds the limit
-    return (v.opt & 4) && !(v.opt & 8) && e->num_classes == 1;
+    // (the classes of a one-vs-all model are then scored one launch sequence per class, each class cut into parts of its own)
+    return (v.opt & 4) && !(v.opt & 8);
   }
   if (v.kind == kKindStream)
     return W <= 4u * (uint32_t)v.opt && v.lds_bytes_stream(padded_trees(v, max_trees(e)), W) <= kStreamLdsBudget;
@@ -527,9 +528,18 @@ int auto_variant(const ddt_engine* e) {
   // Perfect trees deeper than 8 levels (the reference's own example is 512 x depth 12, profiler/profiler.cpp:32-38; a depth-12 tree is exactly
   // one PU's memory, DTPU.sv:22-25): the deep rank-quantised kernels -- K = 8 / 9 levels out of LDS at two blocks per CU, the rest in
   // (D - K + 1) / 2 gathers of 16-byte records per tree.  Whatever the number of trees: the alternative is the generic kernel.
-  if (e->p.num_levels > 8u && e->p.sum_mode != 1u && tuple_words(e->p) <= 32u) {
-    for (int i = 0; i < num_variants(); ++i)
+  if (e->p.num_levels > 8u && e->p.sum_mode != 1u && tuple_words(e->p) <= 64u) {
+    for (int i = 0; i < num_variants(); ++i)  // (table order: the two-blocks-per-CU forms first, then the wide ones for 33..64 words)
       if (variant(i).kind == kKindQ16 && variant(i).deep() && variant_fits(variant(i), e)) return i;
+  }
+  // Tuples of 33..64 words, depth <= 8: the wide rank-quantised kernels (one block of 16 waves per CU, transpose + rank pre-pass) from the
+  // same tree count on as the narrow ones; below it and beyond 64 words the fp32 tile kernels
+  if (tuple_words(e->p) > 32u && tuple_words(e->p) <= 64u && total_trees(e) >= 224u) {
+    static const char* wpref[] = {"q16w_d8_c8_u4_gl_s2_cm_x", "q16w_d8_c8_u4_gl", "q16w_d6_c16_u4_s2", "q16w_d7_c8_u4_s2", "q16w_d5_c32_u4_s2"};
+    for (const char* name : wpref) {
+      const int i = find_variant(name);
+      if (i >= 0 && variant_fits(variant(i), e) && !((variant(i).opt & 2) && s2_disabled())) return i;
+    }
   }
   uint32_t q16_min = 224u;
   if (tuple_words(e->p) <= 32u && total_trees(e) * e->p.num_levels >= kQ16MinTreeLevels && total_trees(e) < 224u && prepass_plan_exists(e))
@@ -851,7 +861,7 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
     h.pplan = rk.pplan;
     h.Kpad = rk.Kpad;
   }
-  const uint32_t row = v.tile() * 2u;  // bytes per feature row of the u16 tile
+  const uint32_t row = v.wide() ? v.tile() : v.tile() * 2u;  // what a record's row-offset field counts in: bytes of a feature row of the u16 tile (wide: half of it)
   // word offsets of tree i's records and leaves: tree by tree (records, then leaves), or -- "_gl" variants -- per chunk the
   // records of its CT trees followed by the leaves of its CT trees (only the first half of a chunk is staged in LDS)
   const uint32_t CT = (uint32_t)v.chunk_trees, half = 1u << D;
@@ -1000,10 +1010,13 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const int k = e->q_slot;
   // the transposed fp32 intermediate is only needed by the two-kernel pre-pass
   bool need_xT = e->sparse ? e->sp_rank.prepass.groups == 0 : (e->ens.empty() || e->ens[0].prepass.groups == 0);
-  const bool in_parts = !e->sparse && !e->ens.empty() && e->ens[0].parts.size() > 1;  // the sum's state between the parts' launches
+  bool in_parts = false;  // the sum's state between the parts' launches; tables per part
+  if (!e->sparse)
+    for (const Ensemble& m : e->ens) in_parts = in_parts || !m.parts.empty();
   if (in_parts) {
     need_xT = false;
-    for (const Q16Part& part : e->ens[0].parts) need_xT = need_xT || part.rank.prepass.groups == 0;
+    for (const Ensemble& m : e->ens)
+      for (const Q16Part& part : m.parts) need_xT = need_xT || part.rank.prepass.groups == 0;
   }
   if (rows <= e->q_rows[k] && (!need_xT || e->q_xT[k]) && (!in_parts || e->q_state[k])) return DDT_OK;
   HIP_TRY(e, hipDeviceSynchronize());
@@ -1223,7 +1236,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
   }
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   hipError_t r = hipSuccess;
-  if (v.kind == kKindQ16 && m.parts.size() > 1) {
+  if (v.kind == kKindQ16 && !m.parts.empty()) {
     // the ensemble in parts: per part its rank pre-pass (the same workspace, stream order) and a scoring launch over its chunks of the
     // image; the reference-order sum is handed from launch to launch through the state workspace (Q16Aux)
     const size_t chunk_bytes = (size_t)v.tree_bytes_q16() * (size_t)v.chunk_trees;
@@ -1242,6 +1255,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
       qa.Kpad = part.rank.Kpad;
       qa.prepass_img = reinterpret_cast<const uint4*>(part.rank.d_prepass);
       qa.prepass = part.rank.prepass;
+      qa.skip_prepass = 0u;  // every part ranks the batch against its own tables (also the 2nd..Kth class of a multi-class model)
       qa.group0 = groups_before;
       qa.state_in = k > 0 ? state : nullptr;
       qa.state_out = k + 1 < m.parts.size() ? state : nullptr;
@@ -1279,7 +1293,10 @@ int launch_classify(ddt_engine* e, const void* d_tuples, size_t n, float* d_clas
   // (never with a "_p" kernel launched once per class: its persistent blocks take their tiles from ONE ticket counter in the batch's
   // workspace, which a second launch in flight would reset and share)
   const bool persistent = variant(e->variant_id).kind == kKindQ16 && (variant(e->variant_id).opt & 8) != 0;
-  const bool two = e->class_streams && e->num_classes > 2 && !e->kernel_timing && !persistent;
+  // ... nor with ensembles scored in parts: every part of every class writes the batch's rank workspace anew
+  bool in_parts = false;
+  for (const Ensemble& m : e->ens) in_parts = in_parts || !m.parts.empty();
+  const bool two = e->class_streams && e->num_classes > 2 && !e->kernel_timing && !persistent && !in_parts;
   if (two && !e->class_stream) {
     HIP_TRY(e, hipStreamCreateWithFlags(&e->class_stream, hipStreamNonBlocking));
     for (hipEvent_t& ev : e->class_ev) HIP_TRY(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1375,7 +1392,7 @@ void engine_enter_collective_job(ddt_engine* e) {
   const Variant& cur = variant(e->variant_id);
   const int ip = find_variant("q16_d8_c8_u4_gl_s2_cm_p");
   if (ip < 0 || cur.kind != kKindQ16 || !(cur.opt & 4) || (cur.opt & 8) || e->num_classes != 1 || cur.levels != variant(ip).levels ||
-      cur.chunk_trees != variant(ip).chunk_trees || e->ens.empty() || e->ens[0].parts.size() > 1)
+      cur.chunk_trees != variant(ip).chunk_trees || e->ens.empty() || !e->ens[0].parts.empty())
     return;
   if (s2_disabled() || !variant_fits(variant(ip), e)) return;  // the same gates the automatic choice at load time goes through
   e->variant_id = ip;

@@ -197,6 +197,10 @@ struct Variant {
   //   Records are the q16 records {rank (lo16) | feature row byte offset (hi16; bit 16 = miss_right in the slow image)}.
   //   Image = per chunk of chunk_trees trees their tops, then their stage blocks tree by tree.
   bool deep() const { return kind == kKindQ16 && (opt & 32) != 0; }
+  // opt bit 6 ("q16w_*" / "q16dw_*"): tuples of up to 64 words -- a record's row-offset field holds HALF the byte offset (the kernel shifts it
+  // back), the block takes up to 144 KiB of LDS (one block of 16 waves per CU)
+  bool wide() const { return kind == kKindQ16 && (opt & 64) != 0; }
+  uint32_t max_tuple_words_q16() const { return wide() ? 64u : 32u; }
   uint32_t deep_stages() const { return ((uint32_t)levels - (uint32_t)top + 1u) / 2u; }
   uint32_t deep_stage_level(uint32_t g) const { return g + 1u < deep_stages() ? (uint32_t)top + 2u * g : (uint32_t)levels - 1u; }
   uint32_t deep_stage_off(uint32_t g) const {  // byte offset of stage g inside a tree's stage blocks

@@ -1000,7 +1000,10 @@ __device__ __forceinline__ float gather_leaf(const LeafSrc& g, int u, uint32_t m
 
 // walk over 4-byte records {R (lo16), feature row byte offset (hi16, bit 16 = miss_right in the slow image)};
 // m4 = 4 * (1-based heap index); leaves start at byte 4*2^D of the tree, so leaf address = tree + m4.
-template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW, bool GL = false>
+// WIDE ("q16w_*", Variant::opt bit 6): tuples of 33..64 words -- the row offset j * 2048 no longer fits the record's 16-bit field, so the
+// record carries HALF of it (j * 1024; bit 0 stays free for the slow image's miss_right flag) and the walk shifts it back: one more VALU
+// instruction per visit, against the fp32 tile kernels at 8 waves per CU that such tuples ran on before
+template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW, bool GL = false, bool WIDE = false>
 __device__ __forceinline__ void walk_trees_q16(const uint32_t base, const uint32_t lane2, float (&leaf)[U], const LeafSrc& gleaf) {
   uint32_t m4[U];
 #pragma unroll
@@ -1012,7 +1015,8 @@ __device__ __forceinline__ void walk_trees_q16(const uint32_t base, const uint32
     for (int u = 0; u < U; ++u) nd[u] = lds_u32(m4[u] + (base + (uint32_t)(u * TREE_BYTES)));
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t off = SLOW ? ((nd[u] >> 16) & 0xFFFEu) : (nd[u] >> 16);
+      uint32_t off = SLOW ? ((nd[u] >> 16) & 0xFFFEu) : (nd[u] >> 16);
+      if (WIDE) off <<= 1;
       // ds_read_u16 with FEAT_OFF as the DS immediate; conflict-free (bank = lane/2, two lanes share a dword)
       f[u] = *reinterpret_cast<const DDT_LDS(uint16_t)*>((off | lane2) + (uint32_t)FEAT_OFF);
     }
@@ -1053,13 +1057,14 @@ __device__ __forceinline__ void top_wait(TopRecs<4>& q) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.t[0]), "+s"(q.t[1]), "+s"(q.t[2]), "+s"(q.t[3]));
 }
 
-template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW, bool GL>
+template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW, bool GL, bool WIDE = false>
 __device__ __forceinline__ void walk_trees_q16_s2(const TopRecs<U>& q, const uint32_t base, const uint32_t lane2, float (&leaf)[U],
                                                   const LeafSrc& gleaf) {
   static_assert(D >= 3, "two scalar levels + at least one LDS level");
   uint32_t m4[U], nd[U], f[U];
   auto rank_at = [&](uint32_t rec) -> uint32_t {
-    const uint32_t off = SLOW ? ((rec >> 16) & 0xFFFEu) : (rec >> 16);
+    uint32_t off = SLOW ? ((rec >> 16) & 0xFFFEu) : (rec >> 16);
+    if (WIDE) off <<= 1;
     return *reinterpret_cast<const DDT_LDS(uint16_t)*>((off | lane2) + (uint32_t)FEAT_OFF);
   };
   auto goes_right = [&](uint32_t rec, uint32_t fv) -> bool {
@@ -1103,13 +1108,14 @@ __device__ __forceinline__ void walk_trees_q16_s2(const TopRecs<U>& q, const uin
 // back to back -- 4 x node record, 4 x feature rank, ... -- and a sched_barrier that only VALU / SALU / VMEM instructions may
 // cross keeps the stages apart: a wave has four dependent chains in flight, the waits come out as lgkmcnt(3).
 #define DDT_PIN_DS() __builtin_amdgcn_sched_barrier(0x0016)
-template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW, bool GL>
+template <int D, int U, int TREE_BYTES, int FEAT_OFF, bool SLOW, bool GL, bool WIDE = false>
 __device__ __forceinline__ void walk_trees_q16_s2_pin(const TopRecs<U>& q, const uint32_t base, const uint32_t lane2, float (&leaf)[U],
                                                       const LeafSrc& gleaf) {
   static_assert(D >= 3, "two scalar levels + at least one LDS level");
   uint32_t m4[U], nd[U], f[U];
   auto rank_at = [&](uint32_t rec) -> uint32_t {
-    const uint32_t off = SLOW ? ((rec >> 16) & 0xFFFEu) : (rec >> 16);
+    uint32_t off = SLOW ? ((rec >> 16) & 0xFFFEu) : (rec >> 16);
+    if (WIDE) off <<= 1;
     return *reinterpret_cast<const DDT_LDS(uint16_t)*>((off | lane2) + (uint32_t)FEAT_OFF);
   };
   auto goes_right = [&](uint32_t rec, uint32_t fv) -> bool {
@@ -1152,7 +1158,7 @@ __device__ __forceinline__ void walk_trees_q16_s2_pin(const TopRecs<U>& q, const
 template <int D, int CT, int U, int OPT = 0>
 __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a, const Q16Aux x) {  // 8 waves per SIMD = two blocks per CU
   constexpr int THREADS = kQTile;
-  constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0, HOTDISP = S2, CM = (OPT & 4) != 0, PIN = (OPT & 16) != 0;
+  constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0, HOTDISP = S2, CM = (OPT & 4) != 0, PIN = (OPT & 16) != 0, WIDE = (OPT & 64) != 0;
   static_assert(!S2 || U == 4, "_s2: 4 trees in flight");
   static_assert(!PIN || S2, "the pinned read order exists for the _s2 walk");
   constexpr int TREE_BYTES = GL ? (4 << D) : (8 << D);  // bytes of a tree in LDS (GL: node records only)
@@ -1243,17 +1249,17 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
         if (pad_sg) { /* EMPTY padding behind the last real tree: no walk, the +0 leaves it would end in */ \
           _Pragma("unroll") for (int u = 0; u < U; ++u) lf[0][u] = 0.f;                                \
         } else if constexpr (PIN) {                                                                    \
-          if (!slow_l) walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
-          else walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+          if (!slow_l) walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, false, GL, WIDE>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+          else walk_trees_q16_s2_pin<D, U, TREE_BYTES, FEAT_OFF, true, GL, WIDE>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
         } else {                                                                                       \
-          if (!slow_l) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
-          else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+          if (!slow_l) walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, false, GL, WIDE>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+          else walk_trees_q16_s2<D, U, TREE_BYTES, FEAT_OFF, true, GL, WIDE>(top_cur, (uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
         }                                                                                              \
       } else if (pad_sg) {                                                                             \
         _Pragma("unroll") for (int u = 0; u < U; ++u) lf[0][u] = 0.f;                                  \
       } else {                                                                                         \
-        if (!slow_l) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
-        else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true, GL>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
+        if (!slow_l) walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, false, GL, WIDE>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl); \
+        else walk_trees_q16<D, U, TREE_BYTES, FEAT_OFF, true, GL, WIDE>((uint32_t)((BUF) * CHUNK_BYTES + sg * U * TREE_BYTES), lane2, lf[0], gl);        \
       }                                                                                                \
       if (sum_l != 1) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc, exact_l);                 \
       else fold_leaves<U, 1, 1>(lf, ((PH) + sg) & 1, C, ra, dacc);                                     \
@@ -1705,9 +1711,10 @@ static hipError_t launch_q16p(const ScoreArgs& a, const Variant& v, hipStream_t 
 // barriers: the gathers do not touch the chunk buffers, and the barrier's wait counts them out (vmcnt(N): the DMA of the next chunk is older
 // than the N gathers issued behind it; loads return in order).
 // ---------------------------------------------------------------------------------------------------
-template <int FEAT_OFF, bool SLOW>
+template <int FEAT_OFF, bool SLOW, bool WIDE = false>
 __device__ __forceinline__ uint32_t q16_rank_at(uint32_t rec, uint32_t lane2) {
-  const uint32_t off = SLOW ? ((rec >> 16) & 0xFFFEu) : (rec >> 16);
+  uint32_t off = SLOW ? ((rec >> 16) & 0xFFFEu) : (rec >> 16);
+  if (WIDE) off <<= 1;
   return *reinterpret_cast<const DDT_LDS(uint16_t)*>((off | lane2) + (uint32_t)FEAT_OFF);
 }
 template <bool SLOW>
@@ -1724,8 +1731,8 @@ constexpr uint32_t q16d_stage_off(int D, int K, int g) {
 }
 
 // (three gathers per tree in flight -- depths 13 and 14 -- need more than the 64 VGPRs of two blocks per CU: one block of 16 waves then)
-template <int D, int K, int CT>
-__global__ __launch_bounds__(kQTile, (D - K + 1) / 2 >= 3 ? 4 : 8) void score_q16d_kernel(const ScoreArgs a, const Q16Aux x) {
+template <int D, int K, int CT, bool WIDE = false>
+__global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) void score_q16d_kernel(const ScoreArgs a, const Q16Aux x) {
   constexpr int THREADS = kQTile, U = 4;
   constexpr int G = (D - K + 1) / 2;  // gathers per tree
   static_assert((D - K) % 2 == 1 && G >= 1 && G <= 3 && K >= 3, "D - K odd: pair stages and one terminal stage");
@@ -1809,7 +1816,7 @@ __global__ __launch_bounds__(kQTile, (D - K + 1) / 2 >= 3 ? 4 : 8) void score_q1
 #pragma unroll
         for (int u = 0; u < U; ++u) nd[u] = lds_u32(m4[u] + (uint32_t)(BUF * CHUNK_BYTES + (SG * U + u) * TOPB));
 #pragma unroll
-        for (int u = 0; u < U; ++u) f[u] = q16_rank_at<FEAT_OFF, SLOW>(nd[u], lane2);
+        for (int u = 0; u < U; ++u) f[u] = q16_rank_at<FEAT_OFF, SLOW, WIDE>(nd[u], lane2);
 #pragma unroll
         for (int u = 0; u < U; ++u) m4[u] = (m4[u] << 1) + (q16_goes_right<SLOW>(nd[u], f[u]) ? 4u : 0u);
       }
@@ -1826,7 +1833,7 @@ __global__ __launch_bounds__(kQTile, (D - K + 1) / 2 >= 3 ? 4 : 8) void score_q1
         // (the unused fourth word is kept alive up to here: hipcc otherwise narrows the load to three registers and hands the fourth to the
         // walk as a temporary -- a write to the destination of a load in flight, i.e. a vmcnt wait at the top of every walk)
         asm volatile("" : : "v"(pend[G - 1][u].w));
-        f[u] = q16_rank_at<FEAT_OFF, SLOW>(pend[G - 1][u].x, lane2);
+        f[u] = q16_rank_at<FEAT_OFF, SLOW, WIDE>(pend[G - 1][u].x, lane2);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) lf[0][u] = __uint_as_float(q16_goes_right<SLOW>(pend[G - 1][u].x, f[u]) ? pend[G - 1][u].z : pend[G - 1][u].y);
@@ -1851,13 +1858,13 @@ __global__ __launch_bounds__(kQTile, (D - K + 1) / 2 >= 3 ? 4 : 8) void score_q1
       if (DRAIN >= g) continue;  // (drain: that sub-group does not exist)
       uint32_t f0[U], f1[U], c[U], voff[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) f0[u] = q16_rank_at<FEAT_OFF, SLOW>(pend[g - 1][u].x, lane2);
+      for (int u = 0; u < U; ++u) f0[u] = q16_rank_at<FEAT_OFF, SLOW, WIDE>(pend[g - 1][u].x, lane2);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const bool r0 = q16_goes_right<SLOW>(pend[g - 1][u].x, f0[u]);
         c[u] = r0 ? pend[g - 1][u].z : pend[g - 1][u].y;
         voff[u] = pend[g - 1][u].w + (r0 ? 32u : 0u);
-        f1[u] = q16_rank_at<FEAT_OFF, SLOW>(c[u], lane2);
+        f1[u] = q16_rank_at<FEAT_OFF, SLOW, WIDE>(c[u], lane2);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) voff[u] += q16_goes_right<SLOW>(c[u], f1[u]) ? 16u : 0u;
@@ -1927,13 +1934,13 @@ __global__ __launch_bounds__(kQTile, (D - K + 1) / 2 >= 3 ? 4 : 8) void score_q1
   if (row < a.n) a.out[row] = cm_total;
 }
 
-template <int D, int K, int CT>
+template <int D, int K, int CT, bool WIDE = false>
 static hipError_t launch_q16d(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const Q16Aux& x = *reinterpret_cast<const Q16Aux*>(a.aux);
   const uint64_t tiles = (a.n + kQTile - 1) / kQTile;
   if (tiles == 0) return hipSuccess;
   if (tiles > 0x7FFFFFFFull || (CT == 4 && (a.n_chunks & 1u)) || a.sum_mode == 1u) return hipErrorInvalidValue;
-  auto kern = score_q16d_kernel<D, K, CT>;
+  auto kern = score_q16d_kernel<D, K, CT, WIDE>;
   const uint32_t lds = v.lds_bytes_q16(a.tuple_words);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -2222,6 +2229,8 @@ hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t 
 
 #define DDT_QD(NAME, D, K, CT) \
   Variant { NAME, kKindQ16, D, kQTile, 1, CT, 4, 1, 36, &launch_q16d<D, K, CT>, K }
+#define DDT_QDW(NAME, D, K, CT) /* wide tuples (33..64 words): one block per CU */ \
+  Variant { NAME, kKindQ16, D, kQTile, 1, CT, 4, 1, 36 | 64, &launch_q16d<D, K, CT, true>, K }
 
 static const Variant g_variants[] = {
     Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_generic},
@@ -2255,12 +2264,23 @@ static const Variant g_variants[] = {
     DDT_Q("q16_d10_c4_u4", 10, 4, 4),
     // deep perfect trees (the reference's own example is 512 x depth 12): K levels out of LDS at two blocks per CU, (D - K + 1) / 2 gathers of
     // 16-byte records per tree below them (score_q16d_kernel); opt = cluster-major | deep, last field = K
-    DDT_QD("q16d_d12_k9_c4_u4", 12, 9, 4),
-    DDT_QD("q16d_d11_k8_c8_u4", 11, 8, 8),
-    DDT_QD("q16d_d10_k9_c4_u4", 10, 9, 4),
-    DDT_QD("q16d_d9_k8_c8_u4", 9, 8, 8),
-    DDT_QD("q16d_d13_k8_c8_u4", 13, 8, 8),
-    DDT_QD("q16d_d14_k9_c4_u4", 14, 9, 4),
+    DDT_QD("q16d_d12_k9_c4_u4_cm", 12, 9, 4),
+    DDT_QD("q16d_d11_k8_c8_u4_cm", 11, 8, 8),
+    DDT_QD("q16d_d10_k9_c4_u4_cm", 10, 9, 4),
+    DDT_QD("q16d_d9_k8_c8_u4_cm", 9, 8, 8),
+    DDT_QD("q16d_d13_k8_c8_u4_cm", 13, 8, 8),
+    DDT_QD("q16d_d14_k9_c4_u4_cm", 14, 9, 4),
+    // tuples of 33..64 words ("q16w" / "q16dw": the record carries half the row offset, one block of 16 waves per CU: 16 KiB of chunks + up to
+    // 128 KiB of ranks): the shapes that used to fall to the fp32 tile kernels at 8 waves per CU (depth <= 8) or to the generic kernel (deeper)
+    Variant{"q16w_d8_c8_u4_gl_s2_cm_x", kKindQ16, 8, kQTile, 1, 8, 4, 1, 7 | 64, &launch_q16<8, 8, 4, 23 | 64>},
+    Variant{"q16w_d8_c8_u4_gl", kKindQ16, 8, kQTile, 1, 8, 4, 1, 1 | 64, &launch_q16<8, 8, 4, 1 | 64>},   // (stream-order image: also the fp64 sum)
+    Variant{"q16w_d6_c16_u4_s2", kKindQ16, 6, kQTile, 1, 16, 4, 1, 2 | 64, &launch_q16<6, 16, 4, 2 | 64>},
+    Variant{"q16w_d7_c8_u4_s2", kKindQ16, 7, kQTile, 1, 8, 4, 1, 2 | 64, &launch_q16<7, 8, 4, 2 | 64>},
+    Variant{"q16w_d5_c32_u4_s2", kKindQ16, 5, kQTile, 1, 32, 4, 1, 2 | 64, &launch_q16<5, 32, 4, 2 | 64>},
+    DDT_QDW("q16dw_d12_k9_c4_u4_cm", 12, 9, 4),
+    DDT_QDW("q16dw_d11_k8_c8_u4_cm", 11, 8, 8),
+    DDT_QDW("q16dw_d10_k9_c4_u4_cm", 10, 9, 4),
+    DDT_QDW("q16dw_d9_k8_c8_u4_cm", 9, 8, 8),
     // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB.  suffix _f = last level fused with its leaves.  Experiment variants
     // that no choice uses any more were removed in round 2 (register-staged chunks, R = 2, the unfused forms, 8-chain
     // stream kernels; their measurements stay in profiles/archive/r01_sweep_*.json)

@@ -122,7 +122,8 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
   Op* op = new Op();
   op->cost = (double)a.n * g_cost_row;
   op->run = [=] {
-    const uint32_t D = a.levels, half = 1u << D, tw = 2u * half, CT = (uint32_t)v.chunk_trees, row = v.tile() * 2u;
+    const uint32_t D = a.levels, half = 1u << D, tw = 2u * half, CT = (uint32_t)v.chunk_trees;
+    const uint32_t row = v.wide() ? v.tile() : v.tile() * 2u;  // what a record's row-offset field counts in (wide kernels: half the row's bytes)
     const bool gl = (v.opt & 1) != 0, cm = (v.opt & 4) != 0;
     // "_p" kernels: the image may hold n_segs ensembles (classes) back to back, each with its own cluster-major order
     const uint32_t S = x.n_segs ? x.n_segs : 1u, seg_trees = a.n_trees / S;
@@ -299,11 +300,17 @@ const Variant g_mock_variants[] = {
     Variant{"q16_d8_c4_u4", kKindQ16, 8, 1024, 1, 4, 4, 1, 0, &launch_q16},
     Variant{"q16_d6_c16_u4", kKindQ16, 6, 1024, 1, 16, 4, 1, 0, &launch_q16},
     // deep rank-quantised kernels (opt 4 | 32: cluster-major, deep; last field = K)
-    Variant{"q16d_d12_k9_c4_u4", kKindQ16, 12, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
-    Variant{"q16d_d10_k9_c4_u4", kKindQ16, 10, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
-    Variant{"q16d_d11_k8_c8_u4", kKindQ16, 11, 1024, 1, 8, 4, 1, 36, &launch_q16, 8},
-    Variant{"q16d_d9_k8_c8_u4", kKindQ16, 9, 1024, 1, 8, 4, 1, 36, &launch_q16, 8},
-    Variant{"q16d_d14_k9_c4_u4", kKindQ16, 14, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
+    Variant{"q16d_d12_k9_c4_u4_cm", kKindQ16, 12, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
+    Variant{"q16d_d10_k9_c4_u4_cm", kKindQ16, 10, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
+    Variant{"q16d_d11_k8_c8_u4_cm", kKindQ16, 11, 1024, 1, 8, 4, 1, 36, &launch_q16, 8},
+    Variant{"q16d_d9_k8_c8_u4_cm", kKindQ16, 9, 1024, 1, 8, 4, 1, 36, &launch_q16, 8},
+    Variant{"q16d_d14_k9_c4_u4_cm", kKindQ16, 14, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
+    // wide tuples (33..64 words; opt bit 6)
+    Variant{"q16w_d8_c8_u4_gl_s2_cm_x", kKindQ16, 8, 1024, 1, 8, 4, 1, 7 | 64, &launch_q16},
+    Variant{"q16w_d8_c8_u4_gl", kKindQ16, 8, 1024, 1, 8, 4, 1, 1 | 64, &launch_q16},
+    Variant{"q16w_d6_c16_u4_s2", kKindQ16, 6, 1024, 1, 16, 4, 1, 2 | 64, &launch_q16},
+    Variant{"q16dw_d12_k9_c4_u4_cm", kKindQ16, 12, 1024, 1, 4, 4, 1, 36 | 64, &launch_q16, 9},
+    Variant{"q16dw_d10_k9_c4_u4_cm", kKindQ16, 10, 1024, 1, 4, 4, 1, 36 | 64, &launch_q16, 9},
     Variant{"d8_t1024_r1_c4_u4_dma_f", kKindTile, 8, 1024, 1, 4, 4, 1, 1, &launch_records},
     Variant{"d6_t1024_r1_c16_u4_dma", kKindTile, 6, 1024, 1, 16, 4, 1, 0, &launch_records},
     Variant{"d4_t256_r1_c64_u8_dma", kKindTile, 4, 256, 1, 64, 8, 1, 0, &launch_records},

@@ -746,10 +746,10 @@ def _sparse_fuzz_round(mock, seed, seen):
     mock.ddt_destroy(e)
 
 
-@pytest.mark.parametrize("T,D,F,clusters,name,parts", [(20, 12, 32, 1, "q16d_d12_k9_c4_u4", 1), (13, 12, 8, 4, "q16d_d12_k9_c4_u4", 1),
-                                                        (40, 12, 4, 2, "q16d_d12_k9_c4_u4", 2), (70, 12, 3, 8, "q16d_d12_k9_c4_u4", 4),
-                                                        (11, 10, 16, 1, "q16d_d10_k9_c4_u4", 1), (9, 11, 20, 8, "q16d_d11_k8_c8_u4", 1),
-                                                        (17, 9, 32, 2, "q16d_d9_k8_c8_u4", 1), (5, 14, 12, 1, "q16d_d14_k9_c4_u4", 1)])
+@pytest.mark.parametrize("T,D,F,clusters,name,parts", [(20, 12, 32, 1, "q16d_d12_k9_c4_u4_cm", 1), (13, 12, 8, 4, "q16d_d12_k9_c4_u4_cm", 1),
+                                                        (40, 12, 4, 2, "q16d_d12_k9_c4_u4_cm", 2), (70, 12, 3, 8, "q16d_d12_k9_c4_u4_cm", 4),
+                                                        (11, 10, 16, 1, "q16d_d10_k9_c4_u4_cm", 1), (9, 11, 20, 8, "q16d_d11_k8_c8_u4_cm", 1),
+                                                        (17, 9, 32, 2, "q16d_d9_k8_c8_u4_cm", 1), (5, 14, 12, 1, "q16d_d14_k9_c4_u4_cm", 1)])
 def test_deep_perfect_trees_on_the_deep_kernels(mock, T, D, F, clusters, name, parts):
     """Perfect trees deeper than 8 levels (the reference's own example: 512 x depth 12, profiler/profiler.cpp:32-38) take the deep
     rank-quantised kernels by themselves: K levels as a heap of 4-byte records, then pair / terminal records of 16 bytes per stage
@@ -790,4 +790,62 @@ def test_deep_perfect_trees_on_the_deep_kernels(mock, T, D, F, clusters, name, p
     out = np.full(n, np.nan, np.float32)
     assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
     assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=O.SUM_F64_SEQ)))
+    mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("T,D,F,clusters,sum_mode,name", [(230, 8, 64, 2, 0, "q16w_d8_c8_u4_gl_s2_cm_x"), (240, 8, 33, 1, 2, "q16w_d8_c8_u4_gl_s2_cm_x"),
+                                                           (226, 8, 50, 4, 1, "q16w_d8_c8_u4_gl"), (300, 6, 40, 1, 0, "q16w_d6_c16_u4_s2"),
+                                                           (9, 12, 64, 1, 0, "q16dw_d12_k9_c4_u4_cm"), (12, 10, 37, 2, 2, "q16dw_d10_k9_c4_u4_cm"),
+                                                           (40, 8, 64, 1, 0, None), (230, 8, 72, 1, 0, None)])
+def test_tuples_of_33_to_64_words_take_the_wide_rank_quantised_kernels(mock, T, D, F, clusters, sum_mode, name):
+    """the rank-quantised path stopped at 32 tuple words (1000 x d8 x 33 features fell to the fp32 tile kernel, deep trees to the
+    generic one).  The wide kernels' records carry half the row offset; the host side (choice, image, transpose + rank pre-pass tables for
+    up to 64 words) against the oracle.  Small ensembles and tuples beyond 64 words stay where they were."""
+    mock.mock_reset(2, 3, 8)
+    n = 1200
+    m, x = O.gen_model(T, D, F, 1, clusters=clusters), O.gen_tuples(0, n, F, 1)
+    ref = {0: O.SUM_REF_NATIVE, 1: O.SUM_F64_SEQ, 2: O.SUM_REF_FLOPOCO}[sum_mode]
+    want = O.score_fast(m, x, sum_mode=ref) if sum_mode != 1 else O.score(m, x, sum_mode=ref)
+    e, info = _engine(mock), ddt.Info()
+    _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), None)
+    assert mock.ddt_get_info(e, C.byref(info)) == 0
+    if name is not None:
+        assert info.variant_name.decode() == name, info.variant_name
+    else:
+        assert not info.variant_name.decode().startswith("q16")
+    s = _stream(mock)
+    outs = [np.full(n, np.nan, np.float32) for _ in range(2)]
+    for out in outs:
+        assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0, mock.ddt_last_error(e)
+    assert mock.hipStreamSynchronize(s) == 0
+    for out in outs:
+        assert np.array_equal(_bits(out), _bits(want))
+    host = np.full(n, np.nan, np.float32)
+    assert mock.ddt_set_option(e, b"feeder_rows", 500) == 0
+    assert mock.ddt_score(e, x.ctypes.data, n, host.ctypes.data) == 0 and np.array_equal(_bits(host), _bits(want))
+    mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("T,K,F,clusters", [(60, 3, 3, 1), (120, 2, 3, 2), (66, 3, 4, 4)])
+def test_multiclass_deep_models_scored_in_parts(mock, T, K, F, clusters):
+    """The classes of a one-vs-all model share one set of rank tables; when those exceed the u16 ranks (here 512-tree-like threshold counts on 3-4
+    features) every class is cut into parts of its own -- a class may come out as ONE part with tables of its own -- and the classes run one
+    after the other on one stream (every part rewrites the batch's rank workspace)."""
+    mock.mock_reset(2, 4, 8)
+    D, n = 12, 900
+    m, x = O.gen_model(T, D, F, 0, clusters=clusters), O.gen_tuples(0, n, F, 0)
+    x[7, 0] = 0x7FC00000
+    labels, cs = O.classify_fast(m, x, K, True)
+    e, s, info = _engine(mock), _stream(mock), ddt.Info()
+    p = ddt.make_params(T, D, F, clusters=clusters)
+    assert mock.ddt_load_model_multiclass(e, C.byref(p), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8, K, 1, 0, 1) == 0, mock.ddt_last_error(e)
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == "q16d_d12_k9_c4_u4_cm"
+    res = []
+    for _ in range(2):
+        gs, gl = np.full((K, n), np.nan, np.float32), np.full(n, -1, np.int32)
+        assert mock.ddt_classify_device(e, x.ctypes.data, n, gs.ctypes.data, gl.ctypes.data, s) == 0, mock.ddt_last_error(e)
+        res.append((gs, gl))
+    assert mock.hipStreamSynchronize(s) == 0
+    for gs, gl in res:
+        assert np.array_equal(_bits(gs), _bits(cs)) and np.array_equal(gl, labels)
     mock.ddt_destroy(e)
