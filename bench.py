@@ -341,6 +341,7 @@ def main(argv=None, inproc_env=None):
     # per-launch HIP-event times of the pass, taken by the library on the launch stream ("kernel_timing"):
     # pre-pass kernels (rank-quantised path only) and the scoring kernel proper
     kernel_ms = []
+    launches_per_step = 1.0
     if not multi and classes == 1:  # (the per-launch events would pin the classes of config 5 to one stream)
         eng.set_option("kernel_timing", 1)
 
@@ -383,6 +384,7 @@ def main(argv=None, inproc_env=None):
         k = st1.timed_launches - st0.timed_launches
         if k > 0:                                              # the timed region's launches, averaged (the library keeps 64 launches' events)
             kernel_ms.append(((st1.sum_prepass_ms - st0.sum_prepass_ms) / k, (st1.sum_score_ms - st0.sum_score_ms) / k))
+        launches_per_step = (st1.kernel_launches - st0.kernel_launches) / max(1, args.steps)
     elif comm is None and scorer is None:
         kernel_ms.append((0.0, 0.0))                           # classes: the roofline below takes the whole step (K scoring launches + argmax)
     if world > 1:
@@ -454,6 +456,9 @@ def main(argv=None, inproc_env=None):
                     "prepass_ms": round(pre_ms, 4),  # rank pre-pass of the rank-quantised path (0 otherwise)
                     "prepass_groups": info.prepass_groups,  # feature groups of the LDS-resident pre-pass (0: transpose + rank kernels / n.a.)
                     "alg_bytes_per_launch": alg_bytes_per_launch,
+                    # an ensemble with more than 32767 distinct thresholds on a feature is scored in PARTS (one rank pre-pass + one scoring launch
+                    # each, the reference-order sum handed on): kernel_ms is then everything behind the FIRST part's pre-pass
+                    "scoring_launches_per_step": round(launches_per_step, 2),
                     "device": {"cus": info.num_cus, "clock_mhz": round(clock_hz / 1e6, 1), "lds_bytes_per_cu": info.lds_bytes_per_cu}}
         # the whole step (pre-pass + scoring kernel(s)) against the same algorithmic bytes; traffic = the step's HBM bytes from the same PMC file
         step_traffic = None

@@ -532,10 +532,11 @@ int auto_variant(const ddt_engine* e) {
     for (int i = 0; i < num_variants(); ++i)  // (table order: the two-blocks-per-CU forms first, then the wide ones for 33..64 words)
       if (variant(i).kind == kKindQ16 && variant(i).deep() && variant_fits(variant(i), e)) return i;
   }
-  // Tuples of 33..64 words, depth <= 8: the wide rank-quantised kernels (one block of 16 waves per CU, transpose + rank pre-pass) from the
-  // same tree count on as the narrow ones; below it and beyond 64 words the fp32 tile kernels
+  // Tuples of 33..64 words, depth 8: the wide rank-quantised kernels (one block of 16 waves per CU, transpose + rank pre-pass) from the
+  // same tree count on as the narrow ones -- 1000 x d8 x 64 / 48 / 33 features: 619 / 635 / 656 Mtuples/s against 432 / 533 / 535 on the fp32
+  // tile kernels (profiles/r05_wide_and_deep_ab.md); below that tree count and beyond 64 words the fp32 tile kernels
   if (tuple_words(e->p) > 32u && tuple_words(e->p) <= 64u && total_trees(e) >= 224u) {
-    static const char* wpref[] = {"q16w_d8_c8_u4_gl_s2_cm_x", "q16w_d8_c8_u4_gl", "q16w_d6_c16_u4_s2", "q16w_d7_c8_u4_s2", "q16w_d5_c32_u4_s2"};
+    static const char* wpref[] = {"q16w_d8_c8_u4_gl_s2_cm_x", "q16w_d8_c8_u4_gl"};  // (depth 8 only: at depth 6 the fp32 tile kernel is as fast)
     for (const char* name : wpref) {
       const int i = find_variant(name);
       if (i >= 0 && variant_fits(variant(i), e) && !((variant(i).opt & 2) && s2_disabled())) return i;
@@ -1243,6 +1244,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     float* state = reinterpret_cast<float*>(e->q_state[e->q_slot]);
     uint32_t groups_before = 0;
     const uint32_t walk_all = qa.walk_subgroups;
+    bool xT_valid = false;  // the transposed tuples of this batch (transpose + rank pre-pass) serve every part that needs them
     for (size_t k = 0; k < m.parts.size() && r == hipSuccess; ++k) {
       const Q16Part& part = m.parts[k];
       a.img = reinterpret_cast<const uint4*>(static_cast<const char*>(m.d_img) + part.chunk_begin * chunk_bytes);
@@ -1256,6 +1258,8 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
       qa.prepass_img = reinterpret_cast<const uint4*>(part.rank.d_prepass);
       qa.prepass = part.rank.prepass;
       qa.skip_prepass = 0u;  // every part ranks the batch against its own tables (also the 2nd..Kth class of a multi-class model)
+      qa.skip_transpose = (part.rank.prepass.groups == 0u && xT_valid) ? 1u : 0u;
+      xT_valid = xT_valid || part.rank.prepass.groups == 0u;
       qa.group0 = groups_before;
       qa.state_in = k > 0 ? state : nullptr;
       qa.state_out = k + 1 < m.parts.size() ? state : nullptr;

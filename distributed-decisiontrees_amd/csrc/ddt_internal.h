@@ -79,6 +79,8 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   const uint4* img_slow;      // image with the miss_right flags (used by tiles that contain a missing value)
   uint64_t n_pad;             // rows rounded up to whole tiles of 1024
   uint32_t skip_prepass;      // 1 = q / tile_flags already hold this batch (2nd..Kth class of a multi-class model)
+  uint32_t skip_transpose = 0;  // transpose + rank pre-pass: xT already holds this batch's transposed tuples (a later part of an ensemble scored
+                              // in parts: the tables differ from part to part, the transposed tuples do not)
   const uint4* prepass_img;   // LDS-resident pre-pass: concatenated LDS images, one per feature group
   PrepassPlan prepass;        // groups == 0: use transpose_kernel + rank_kernel
   uint32_t real_groups;       // "_cm" kernels: PU groups that hold a real tree, ceil(T / 8) (the image may be padded with EMPTY groups)

@@ -1373,7 +1373,8 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
   } else {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(transpose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((W + 1) * 256 * 4));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
+    if (!x.skip_transpose)
+      hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
     uint32_t bx = (uint32_t)((x.n_pad / kQTile + 3) / 4);  // 4 tiles (kRankThreads x 4 rows) per block and pass
     if (bx > 512u) bx = 512u;  // grid-stride over tiles; blockIdx.y = feature (the table is loaded once per block)
     hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabP, x.tabS, a.miss_raw,
@@ -1925,7 +1926,10 @@ __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) voi
   if (!slow) run(std::false_type{});
   else run(std::true_type{});
 
-  const uint64_t row = tile0 + (uint64_t)tid;
+  // (the row index is recomputed here from an opaque copy of the thread id: kept across the walk it costs the 64th and 65th VGPR, i.e. a spill)
+  uint32_t tid_end = (uint32_t)threadIdx.x;
+  asm volatile("" : "+v"(tid_end));
+  const uint64_t row = (uint64_t)blockIdx.x * kQTile + (uint64_t)tid_end;
   if (x.state_out) {  // not the ensemble's last part: the sum's state instead of the score
     x.state_out[row] = ra.a[0][0];
     x.state_out[x.n_pad + row] = cm_total;
@@ -2274,9 +2278,8 @@ static const Variant g_variants[] = {
     // 128 KiB of ranks): the shapes that used to fall to the fp32 tile kernels at 8 waves per CU (depth <= 8) or to the generic kernel (deeper)
     Variant{"q16w_d8_c8_u4_gl_s2_cm_x", kKindQ16, 8, kQTile, 1, 8, 4, 1, 7 | 64, &launch_q16<8, 8, 4, 23 | 64>},
     Variant{"q16w_d8_c8_u4_gl", kKindQ16, 8, kQTile, 1, 8, 4, 1, 1 | 64, &launch_q16<8, 8, 4, 1 | 64>},   // (stream-order image: also the fp64 sum)
-    Variant{"q16w_d6_c16_u4_s2", kKindQ16, 6, kQTile, 1, 16, 4, 1, 2 | 64, &launch_q16<6, 16, 4, 2 | 64>},
-    Variant{"q16w_d7_c8_u4_s2", kKindQ16, 7, kQTile, 1, 8, 4, 1, 2 | 64, &launch_q16<7, 8, 4, 2 | 64>},
-    Variant{"q16w_d5_c32_u4_s2", kKindQ16, 5, kQTile, 1, 32, 4, 1, 2 | 64, &launch_q16<5, 32, 4, 2 | 64>},
+    // (depth 6 measured and NOT instantiated: 300 x d6 x 40 / 64 features, 10 M tuples -- 2164 / 1808 Mtuples/s against 2146 / 2085 on the fp32
+    // tile kernel d6_t512_r1_c16_u8_dma: with 8 chains per lane the fp32 kernel holds its own at shallow depth; profiles/r05_wide_and_deep_ab.md)
     DDT_QDW("q16dw_d12_k9_c4_u4_cm", 12, 9, 4),
     DDT_QDW("q16dw_d11_k8_c8_u4_cm", 11, 8, 8),
     DDT_QDW("q16dw_d10_k9_c4_u4_cm", 10, 9, 4),

@@ -308,7 +308,6 @@ const Variant g_mock_variants[] = {
     // wide tuples (33..64 words; opt bit 6)
     Variant{"q16w_d8_c8_u4_gl_s2_cm_x", kKindQ16, 8, 1024, 1, 8, 4, 1, 7 | 64, &launch_q16},
     Variant{"q16w_d8_c8_u4_gl", kKindQ16, 8, 1024, 1, 8, 4, 1, 1 | 64, &launch_q16},
-    Variant{"q16w_d6_c16_u4_s2", kKindQ16, 6, 1024, 1, 16, 4, 1, 2 | 64, &launch_q16},
     Variant{"q16dw_d12_k9_c4_u4_cm", kKindQ16, 12, 1024, 1, 4, 4, 1, 36 | 64, &launch_q16, 9},
     Variant{"q16dw_d10_k9_c4_u4_cm", kKindQ16, 10, 1024, 1, 4, 4, 1, 36 | 64, &launch_q16, 9},
     Variant{"d8_t1024_r1_c4_u4_dma_f", kKindTile, 8, 1024, 1, 4, 4, 1, 1, &launch_records},

@@ -794,8 +794,7 @@ def test_deep_perfect_trees_on_the_deep_kernels(mock, T, D, F, clusters, name, p
 
 
 @pytest.mark.parametrize("T,D,F,clusters,sum_mode,name", [(230, 8, 64, 2, 0, "q16w_d8_c8_u4_gl_s2_cm_x"), (240, 8, 33, 1, 2, "q16w_d8_c8_u4_gl_s2_cm_x"),
-                                                           (226, 8, 50, 4, 1, "q16w_d8_c8_u4_gl"), (300, 6, 40, 1, 0, "q16w_d6_c16_u4_s2"),
-                                                           (9, 12, 64, 1, 0, "q16dw_d12_k9_c4_u4_cm"), (12, 10, 37, 2, 2, "q16dw_d10_k9_c4_u4_cm"),
+                                                           (226, 8, 50, 4, 1, "q16w_d8_c8_u4_gl"), (9, 12, 64, 1, 0, "q16dw_d12_k9_c4_u4_cm"), (12, 10, 37, 2, 2, "q16dw_d10_k9_c4_u4_cm"),
                                                            (40, 8, 64, 1, 0, None), (230, 8, 72, 1, 0, None)])
 def test_tuples_of_33_to_64_words_take_the_wide_rank_quantised_kernels(mock, T, D, F, clusters, sum_mode, name):
     """the rank-quantised path stopped at 32 tuple words (1000 x d8 x 33 features fell to the fp32 tile kernel, deep trees to the

@@ -94,8 +94,7 @@ def test_the_references_own_configuration():
 
 
 @pytest.mark.parametrize("T,D,F,clusters,sum_modes,name", [(300, 8, 64, 2, (0, 2), "q16w_d8_c8_u4_gl_s2_cm_x"), (240, 8, 33, 1, (0, 2), "q16w_d8_c8_u4_gl_s2_cm_x"),
-                                                            (226, 8, 50, 4, (1,), "q16w_d8_c8_u4_gl"), (300, 6, 40, 1, (0, 1, 2), "q16w_d6_c16_u4_s2"),
-                                                            (250, 7, 60, 2, (0, 2), "q16w_d7_c8_u4_s2"), (260, 5, 48, 1, (0, 1), "q16w_d5_c32_u4_s2"),
+                                                            (226, 8, 50, 4, (1,), "q16w_d8_c8_u4_gl"),
                                                             (9, 12, 64, 1, (0, 2), "q16dw_d12_k9_c4_u4_cm"), (12, 10, 37, 2, (0, 2), "q16dw_d10_k9_c4_u4_cm"),
                                                             (10, 11, 50, 8, (0,), "q16dw_d11_k8_c8_u4_cm"), (20, 9, 64, 1, (0, 2), "q16dw_d9_k8_c8_u4_cm")])
 def test_tuples_of_33_to_64_words_on_the_wide_kernels(T, D, F, clusters, sum_modes, name):
