@@ -63,6 +63,11 @@ DENSE = [
     pytest.param(1, 8, 4, 16, 50_000_000, 300_007, 1, 0, id="config1-50M-missing-values"),
     pytest.param(3, 1000, 8, 32, 100_000_000, 300_007, 0, 2, id="config3-100M-reference-adder"),
     pytest.param(2, 100, 6, 28, 10_000_000, 300_007, 1, 2, id="config2-10M-reference-adder-missing-values"),
+    # round 5: the reference's own example configuration (profiler/profiler.cpp:32-38) on the deep kernel, in parts; with missing values and
+    # the reference adder; and tuples of 64 words on the wide kernel
+    pytest.param(6, 512, 12, 32, 10_000_000, 300_007, 0, 0, id="config6-10M-512xd12"),
+    pytest.param(6, 512, 12, 32, 10_000_000, 100_003, 1, 2, id="config6-10M-reference-adder-missing-values"),
+    pytest.param(3, 1000, 8, 64, 20_000_000, 300_007, 1, 0, id="wide-1000xd8x64-20M-missing-values"),
 ]
 
 
