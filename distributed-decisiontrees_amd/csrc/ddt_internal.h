@@ -246,7 +246,10 @@ uint32_t stream_blocks_per_cu(uint32_t lds_bytes);
 
 hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s);  // ddt_kernels.hip: rank pre-pass of one batch
 
-int num_sparse_variants();                 // ddt_sparse.hip: appended to the variant table after the perfect-tree kernels
+constexpr int kQTile = 1024;               // tuples per u16 rank tile == threads of a rank-quantised scoring block
+int num_deep_variants();                   // ddt_deep.hip: deep perfect trees, appended to the variant table after the kernels of ddt_kernels.hip
+const Variant& deep_variant(int i);
+int num_sparse_variants();                 // ddt_sparse.hip: appended after those
 const Variant& sparse_variant(int i);
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact /* sum_mode 2 */, hipStream_t s);
