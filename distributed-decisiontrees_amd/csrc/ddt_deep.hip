@@ -1,4 +1,4 @@
-// ddt_deep.hip -- scoring kernel for DEEP perfect trees (depth 9..14): the reference's own example configuration is 512 trees of depth 12
+// ddt_deep.hip -- scoring kernel for DEEP perfect trees (depth 9..16): the reference's own example configuration is 512 trees of depth 12
 // over 32 features (profiler/profiler.cpp:32-38; a depth-12 tree is exactly one PU's 8192 words, rtl/DTEngine/core/DTPU.sv:22-25).
 //
 // What it replaces: the same DTPU traversal loop + leaf reduce as ddt_kernels.hip (DTPU.sv:579-760; FPAddersReduceTree.sv:94-141,
@@ -49,12 +49,12 @@ constexpr uint32_t q16d_stage_off(int D, int K, int g) {
   return off;
 }
 
-// (three gathers per tree in flight -- depths 13 and 14 -- need more than the 64 VGPRs of two blocks per CU: one block of 16 waves then)
+// (three or four gathers per tree in flight -- depths 13..16 -- need more than the 64 VGPRs of two blocks per CU: one block of 16 waves then)
 template <int D, int K, int CT, bool WIDE = false>
 __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) void score_q16d_kernel(const ScoreArgs a, const Q16Aux x) {
   constexpr int THREADS = kQTile, U = 4;
   constexpr int G = (D - K + 1) / 2;  // gathers per tree
-  static_assert((D - K) % 2 == 1 && G >= 1 && G <= 3 && K >= 3, "D - K odd: pair stages and one terminal stage");
+  static_assert((D - K) % 2 == 1 && G >= 1 && G <= 4 && K >= 3, "D - K odd: pair stages and one terminal stage");
   static_assert(CT % U == 0 && (CT == 4 || CT == 8), "a chunk = half a PU group or a whole one");
   constexpr int TOPB = 4 << K;                      // a tree's records in LDS
   constexpr int CHUNK_BYTES = TOPB * CT;
@@ -207,6 +207,17 @@ __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) voi
     }
   };
 
+  // s_waitcnt vmcnt(N), N = the gathers a chunk's steps issue behind its DMA (the counter's field is 6 bits: N <= 63)
+  auto wait_for_dma = [&]() {
+    constexpr int N = SGS * G * U;
+    static_assert(N == 4 || N == 8 || N == 12 || N == 16 || N == 24 || N == 32, "vmcnt immediate");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+  };
   auto run = [&](auto slow_tag) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -215,22 +226,14 @@ __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) voi
       // the DMA of this chunk is older than the SGS * G * U gathers issued behind it since the last barrier (every step issues all of its
       // gathers, valid or not): count them out.  The first chunk and the rank tile have nothing behind them.
       if (k == 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (SGS * G * U == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (SGS * G * U == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (SGS * G * U == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (SGS * G * U == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else wait_for_dma();
       __syncthreads();
       const bool more1 = k + 1 < n_chunks;  // (chunks of 4 trees come in pairs: whole PU groups; chunks of 8 may end here)
       if (more1) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 1) * GSKIP, k + 1, CHUNK_BYTES, tid);
       step(slow_tag, I0{}, I0{}, std::true_type{}, I0{}, k, s_index++);
       if constexpr (SGS == 2) step(slow_tag, I0{}, I1{}, std::true_type{}, I0{}, k, s_index++);
       if (!more1) break;
-      if (SGS * G * U == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (SGS * G * U == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (SGS * G * U == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (SGS * G * U == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      wait_for_dma();
       __syncthreads();
       if (k + 2 < n_chunks) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 2) * GSKIP, k + 2, 0, tid);
       step(slow_tag, I1{}, I0{}, std::true_type{}, I0{}, k + 1, s_index++);
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) voi
     step(slow_tag, I0{}, I0{}, std::false_type{}, I0{}, 0u, s_index++);
     if constexpr (G >= 2) step(slow_tag, I0{}, I0{}, std::false_type{}, I1{}, 0u, s_index++);
     if constexpr (G >= 3) step(slow_tag, I0{}, I0{}, std::false_type{}, std::integral_constant<int, 2>{}, 0u, s_index++);
+    if constexpr (G >= 4) step(slow_tag, I0{}, I0{}, std::false_type{}, std::integral_constant<int, 3>{}, 0u, s_index++);
   };
   if (!slow) run(std::false_type{});
   else run(std::true_type{});
@@ -290,6 +294,8 @@ static const Variant g_deep_variants[] = {
     DDT_QD("q16d_d9_k8_c8_u4_cm", 9, 8, 8),
     DDT_QD("q16d_d13_k8_c8_u4_cm", 13, 8, 8),
     DDT_QD("q16d_d14_k9_c4_u4_cm", 14, 9, 4),
+    DDT_QD("q16d_d15_k8_c8_u4_cm", 15, 8, 8),
+    DDT_QD("q16d_d16_k9_c4_u4_cm", 16, 9, 4),
     DDT_QDW("q16dw_d12_k9_c4_u4_cm", 12, 9, 4),
     DDT_QDW("q16dw_d11_k8_c8_u4_cm", 11, 8, 8),
     DDT_QDW("q16dw_d10_k9_c4_u4_cm", 10, 9, 4),

@@ -479,6 +479,8 @@ bool s2_disabled() {
   return off;
 }
 
+uint32_t cm_position(uint32_t i, uint32_t T, uint32_t Cc);
+
 bool variant_fits(const Variant& v, const ddt_engine* e) {
   if (v.kind == kKindSparse) return false;  // sparse forests pick their kernel in ddt_sparse_host.cpp
   if (v.kind == kKindGeneric) return true;
@@ -491,6 +493,23 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
     if (v.deep() && (uint64_t)padded_trees(v, max_trees(e)) * v.tree_bytes_q16() >= (1ull << 31)) return false;
     if ((v.opt & 4) && e->p.sum_mode == 1u) return false;  // cluster-major image order: not the stream order the fp64 sum is defined on
     if (rank_tables(e).max_len <= kQ16MaxTable) return true;
+    // ... provided every PU group of 8 trees (the unit the parts are planned in: plan_q16_parts) stays within the u16 ranks by itself.  Up to
+    // depth 12 it always does (8 x 4095 nodes); deeper trees on few features may not: counted per group and feature (nodes, an upper bound
+    // of the distinct thresholds), in cluster-major order
+    if (e->p.num_levels > 12u) {
+      const uint32_t Cc = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, nint = e->nint;
+      for (const Ensemble& m : e->ens) {
+        const uint32_t T = m.trees(), groups = (T + 7u) / 8u;
+        std::vector<std::vector<uint32_t>> cnt(groups, std::vector<uint32_t>(W, 0u));
+        for (uint32_t i = 0; i < T; ++i) {
+          std::vector<uint32_t>& c = cnt[cm_position(i, T, Cc) / 8u];
+          for (uint32_t n = 0; n < nint; ++n) ++c[m.fidx[(size_t)i * nint + n]];
+        }
+        for (const auto& c : cnt)
+          for (uint32_t k : c)
+            if (k > kQ16MaxTable) return false;
+      }
+    }
     // more distinct thresholds on a feature than u16 ranks hold: the plain cluster-major kernels score the ensemble in PARTS with
     // rank tables of their own (Q16Aux::state_in / state_out); one chunk of 8 trees never exceeds the limit
     // (the classes of a one-vs-all model are then scored one launch sequence per class, each class cut into parts of its own)

@@ -749,7 +749,8 @@ def _sparse_fuzz_round(mock, seed, seen):
 @pytest.mark.parametrize("T,D,F,clusters,name,parts", [(20, 12, 32, 1, "q16d_d12_k9_c4_u4_cm", 1), (13, 12, 8, 4, "q16d_d12_k9_c4_u4_cm", 1),
                                                         (40, 12, 4, 2, "q16d_d12_k9_c4_u4_cm", 2), (70, 12, 3, 8, "q16d_d12_k9_c4_u4_cm", 4),
                                                         (11, 10, 16, 1, "q16d_d10_k9_c4_u4_cm", 1), (9, 11, 20, 8, "q16d_d11_k8_c8_u4_cm", 1),
-                                                        (17, 9, 32, 2, "q16d_d9_k8_c8_u4_cm", 1), (5, 14, 12, 1, "q16d_d14_k9_c4_u4_cm", 1)])
+                                                        (17, 9, 32, 2, "q16d_d9_k8_c8_u4_cm", 1), (5, 14, 12, 1, "q16d_d14_k9_c4_u4_cm", 1),
+                                                        (3, 16, 20, 1, "q16d_d16_k9_c4_u4_cm", 1), (9, 15, 12, 2, "q16d_d15_k8_c8_u4_cm", 1), (16, 15, 9, 2, "q16d_d15_k8_c8_u4_cm", 2)])
 def test_deep_perfect_trees_on_the_deep_kernels(mock, T, D, F, clusters, name, parts):
     """Perfect trees deeper than 8 levels (the reference's own example: 512 x depth 12, profiler/profiler.cpp:32-38) take the deep
     rank-quantised kernels by themselves: K levels as a heap of 4-byte records, then pair / terminal records of 16 bytes per stage
@@ -779,7 +780,7 @@ def test_deep_perfect_trees_on_the_deep_kernels(mock, T, D, F, clusters, name, p
         assert mock.ddt_set_option(e, b"feeder_rows", 512) == 0
         assert mock.ddt_score(e, x.ctypes.data, n, host.ctypes.data) == 0 and np.array_equal(_bits(host), _bits(want))
     # a shard of a tree-sharded job (trees [b, e) of the list, the whole model's cluster count)
-    if T >= 16:
+    if T >= 16 and D <= 14:
         _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters), None, shard=(1, 2))
         out = np.full(n, np.nan, np.float32)
         assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
@@ -847,4 +848,19 @@ def test_multiclass_deep_models_scored_in_parts(mock, T, K, F, clusters):
     assert mock.hipStreamSynchronize(s) == 0
     for gs, gl in res:
         assert np.array_equal(_bits(gs), _bits(cs)) and np.array_equal(gl, labels)
+    mock.ddt_destroy(e)
+
+
+def test_a_pu_group_beyond_the_u16_ranks_falls_back_and_says_so(mock):
+    """9 trees of depth 15 on 4 features: one PU group of 8 trees carries ~65 k thresholds per feature -- no part of it fits u16 ranks.  The deep
+    kernel must not be chosen (the load used to fail with 'not supported' while planning the parts); the generic kernel scores it, flagged."""
+    mock.mock_reset(2, 1, 8)
+    T, D, F, n = 9, 15, 4, 300
+    m, x = O.gen_model(T, D, F, 0), O.gen_tuples(0, n, F, 0)
+    e, info = _engine(mock), ddt.Info()
+    _load(mock, e, m, ddt.make_params(T, D, F), None)
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == "generic" and info.fallback_kernel == 1
+    out = np.full(n, np.nan, np.float32)
+    assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
+    assert np.array_equal(_bits(out), _bits(O.score_fast(m, x)))
     mock.ddt_destroy(e)
