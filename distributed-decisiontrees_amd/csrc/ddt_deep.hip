@@ -1,4 +1,4 @@
-// ddt_deep.hip -- scoring kernel for DEEP perfect trees (depth 9..16): the reference's own example configuration is 512 trees of depth 12
+// ddt_deep.hip -- scoring kernel for DEEP perfect trees (depth 9..15): the reference's own example configuration is 512 trees of depth 12
 // over 32 features (profiler/profiler.cpp:32-38; a depth-12 tree is exactly one PU's 8192 words, rtl/DTEngine/core/DTPU.sv:22-25).
 //
 // What it replaces: the same DTPU traversal loop + leaf reduce as ddt_kernels.hip (DTPU.sv:579-760; FPAddersReduceTree.sv:94-141,
@@ -49,7 +49,7 @@ constexpr uint32_t q16d_stage_off(int D, int K, int g) {
   return off;
 }
 
-// (three or four gathers per tree in flight -- depths 13..16 -- need more than the 64 VGPRs of two blocks per CU: one block of 16 waves then)
+// (three or four gathers per tree in flight -- depths 13..15 -- need more than the 64 VGPRs of two blocks per CU: one block of 16 waves then)
 template <int D, int K, int CT, bool WIDE = false>
 __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) void score_q16d_kernel(const ScoreArgs a, const Q16Aux x) {
   constexpr int THREADS = kQTile, U = 4;
@@ -295,7 +295,8 @@ static const Variant g_deep_variants[] = {
     DDT_QD("q16d_d13_k8_c8_u4_cm", 13, 8, 8),
     DDT_QD("q16d_d14_k9_c4_u4_cm", 14, 9, 4),
     DDT_QD("q16d_d15_k8_c8_u4_cm", 15, 8, 8),
-    DDT_QD("q16d_d16_k9_c4_u4_cm", 16, 9, 4),
+    // (depth 16 measured and NOT instantiated: 64 trees x 32 features, 4 M tuples -- 693 Mtuples/s against 725 on the generic kernel: 131 k
+    // thresholds per feature = four parts, each with a transpose + rank pre-pass, and four gathers per tree at one block per CU)
     DDT_QDW("q16dw_d12_k9_c4_u4_cm", 12, 9, 4),
     DDT_QDW("q16dw_d11_k8_c8_u4_cm", 11, 8, 8),
     DDT_QDW("q16dw_d10_k9_c4_u4_cm", 10, 9, 4),

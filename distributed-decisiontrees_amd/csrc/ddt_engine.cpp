@@ -1907,6 +1907,10 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     }
     return DDT_OK;
   }
+  if (!strcmp(key, "sparse_idle_oob")) {  // A/B: 0 = finished walkers of the sparse kernels re-read record 0 (as before round 5); effective at the next call
+    e->sparse_idle_oob = value != 0;
+    return DDT_OK;
+  }
   if (!strcmp(key, "leaf_domain_check")) {  // 1 (default): refuse -0 / sub-normal / Inf / NaN leaves in the reference-order sum
     e->leaf_domain_check = value != 0;
     return DDT_OK;

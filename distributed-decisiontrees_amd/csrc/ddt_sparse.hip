@@ -118,6 +118,11 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
     //      The gathers go through a buffer resource: 32-bit byte offsets (the host keeps the deep array below 2^28 records), no
     //      64-bit address arithmetic on the VALU.
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(deep), 0, (int)x.deep_bytes, 0x00020000);
+    // Round 5: a finished lane's gather goes BEYOND the resource's range: the range check answers it with zeros and nothing reaches the L1.
+    // Until then it re-read record 0 -- "one shared line", but the texture cache merges lanes only within small groups, and the counters
+    // showed 11.3 G cache accesses per 4 M tuples for 8.3 G live lane visits (profiles/r05_pmc_cfg2_cfg4_cfg6.md): a quarter of the
+    // kernel's accesses were finished lanes.  (Its LDS feature read then uses row 0 of the tile: in range, unused.)
+    const uint32_t idle_off = x.idle_off;
     bool act[U];  // per lane: tree still walking (kept as lane masks in SGPRs, not as bits of a VGPR)
     float leafv[U];
     u32x4 rr[U];
@@ -151,7 +156,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
         if (act[u] && leaf) leafv[u] = __uint_as_float(nxt);
         act[u] = act[u] && !leaf;
         any = any || act[u];
-        rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, act[u] ? (nxt << 4) : 0u, 0, 0);
+        rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, act[u] ? (nxt << 4) : idle_off, 0, 0);
         __builtin_amdgcn_sched_barrier(0);  // or the scheduler collects the loads at the end of the round again
       }
       if (__ballot(any) == 0ull) break;

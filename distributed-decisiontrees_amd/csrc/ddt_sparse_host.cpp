@@ -364,6 +364,7 @@ int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, f
   x.deep = reinterpret_cast<const uint4*>(sp.d_deep);
   x.n_groups = sp.groups;
   x.deep_bytes = (uint32_t)std::min<uint64_t>(sp.deep_bytes, 0xFFFFFFFFull);
+  x.idle_off = e->sparse_idle_oob ? 0xFFFFFFF0u : 0u;  // (the packers keep the deep array below 2^28 records, i.e. deep_bytes <= 0xFFFFFFF0: that offset is always out of range)
   if (v.opt & 1) {  // rank-quantised: the batch's ranks + per-tile missing flags come from the q16 pre-pass (workspace slot e->q_slot)
     int rc = ensure_q16_workspace(e, n);
     if (rc) return rc;

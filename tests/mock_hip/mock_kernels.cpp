@@ -306,7 +306,6 @@ const Variant g_mock_variants[] = {
     Variant{"q16d_d9_k8_c8_u4_cm", kKindQ16, 9, 1024, 1, 8, 4, 1, 36, &launch_q16, 8},
     Variant{"q16d_d14_k9_c4_u4_cm", kKindQ16, 14, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
     Variant{"q16d_d15_k8_c8_u4_cm", kKindQ16, 15, 1024, 1, 8, 4, 1, 36, &launch_q16, 8},
-    Variant{"q16d_d16_k9_c4_u4_cm", kKindQ16, 16, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
     // wide tuples (33..64 words; opt bit 6)
     Variant{"q16w_d8_c8_u4_gl_s2_cm_x", kKindQ16, 8, 1024, 1, 8, 4, 1, 7 | 64, &launch_q16},
     Variant{"q16w_d8_c8_u4_gl", kKindQ16, 8, 1024, 1, 8, 4, 1, 1 | 64, &launch_q16},
