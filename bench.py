@@ -79,7 +79,28 @@ def self_launch(n_gpus):
     return subprocess.call(cmd)
 
 
-def run_side_config(cfg, device_index, check_rows=262_144):
+def collect_other_configs(device_index, budget_s, runner=None, configs=(1, 2, 5, 6, 4)):
+    """`other_configs` of the default command's line: every other BASELINE config as a short run (run_side_config), within a time budget;
+    a leg that fails or would start past the budget says so instead of costing the line."""
+    runner = runner or run_side_config
+    out = {}
+    t0 = time.perf_counter()
+    for cfg in configs:
+        spent = time.perf_counter() - t0
+        if spent > budget_s:
+            out[str(cfg)] = {"skipped": f"the legs before it took {spent:.0f} s of the {budget_s:.0f} s budget"}
+            continue
+        try:
+            out[str(cfg)] = runner(cfg, device_index)
+        except Exception as ex:  # diagnostics must never cost the headline line
+            out[str(cfg)] = {"error": repr(ex)}
+    out["note"] = ("BASELINE configs 1, 2, 4, 5 and 6 (= the reference's own example, 512 x d12 x 32) on the same GPU behind the timed region: full row "
+                   "counts, a few steps each, HIP-event kernel time -> roofline.frac, a prefix of the result bit for bit against the oracle; never `value`")
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+def run_side_config(cfg, device_index, check_rows=262_144, rows=None):
     """One SHORT run of another BASELINE config on the same GPU, behind the default command's timed region (`other_configs` on the line): the
     config's model and full row count, a few steps, HIP-event kernel times from the library, and a prefix of the result against the oracle."""
     import numpy as np
@@ -90,8 +111,9 @@ def run_side_config(cfg, device_index, check_rows=262_144):
 
     t_begin = time.perf_counter()
     T, D, F, N = CONFIG_SHAPES[cfg]
+    N = rows or N   # (tests: the plumbing on a few thousand rows)
     sparse, classes = cfg == 4, (10 if cfg == 5 else 1)
-    steps, warm = {1: (10, 3), 2: (30, 5), 3: (3, 1), 4: (3, 1), 5: (5, 2), 6: (3, 1)}[cfg]
+    steps, warm = {1: (30, 5), 2: (30, 5), 3: (3, 1), 4: (3, 1), 5: (5, 2), 6: (3, 1)}[cfg]
     eng = ddt.Engine(device_index)
     try:
         if sparse:
@@ -131,6 +153,8 @@ def run_side_config(cfg, device_index, check_rows=262_144):
         st1 = eng.stats()
         k = st1.timed_launches - st0.timed_launches
         k_ms = (st1.sum_score_ms - st0.sum_score_ms) / k if k > 0 else ms
+        if k_ms <= 0:   # (events that could not be resolved: the step's wall time instead of a division by zero)
+            k_ms = ms
         pre_ms = (st1.sum_prepass_ms - st0.sum_prepass_ms) / k if k > 0 else 0.0
         alg = N * (4 * F + 4 * (classes + 1 if classes > 1 else 1)) + int(info.model_bytes_unpadded)
         rows = min(N, check_rows if not sparse else min(check_rows, 32_768))
@@ -673,20 +697,7 @@ def main(argv=None, inproc_env=None):
     default_cmd = (args.config == 3 and not (args.rows or args.trees or args.levels or args.features) and args.variant < 0 and not args.opt
                    and args.sum_mode == 0 and args.shard_of <= 1)
     if world == 1 and rank == 0 and not multi and default_cmd and not args.no_other_configs and not args.no_cpu_baseline:
-        other_configs = {}
-        t_oc = time.perf_counter()
-        for cfg in (1, 2, 5, 6, 4):
-            spent = time.perf_counter() - t_oc
-            if spent > args.other_configs_budget:
-                other_configs[str(cfg)] = {"skipped": f"the legs before it took {spent:.0f} s of the {args.other_configs_budget:.0f} s budget"}
-                continue
-            try:
-                other_configs[str(cfg)] = run_side_config(cfg, local)
-            except Exception as ex:  # diagnostics must never cost the headline line
-                other_configs[str(cfg)] = {"error": repr(ex)}
-        other_configs["note"] = ("BASELINE configs 1, 2, 4, 5 and 6 (= the reference's own example, 512 x d12 x 32) on the same GPU behind the timed region: full row "
-                                 "counts, a few steps each, HIP-event kernel time -> roofline.frac, a prefix of the result bit for bit against the oracle; never `value`")
-        other_configs["seconds"] = round(time.perf_counter() - t_oc, 1)
+        other_configs = collect_other_configs(local, args.other_configs_budget)
 
     if rank == 0:
         par = (f"shard {shard[0]} of a {shard[1]}-way tree-sharded job ({int(info.tree_end - info.tree_begin)} trees) on one GPU, no collective" if args.shard_of > 1 else

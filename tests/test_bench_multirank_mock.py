@@ -165,3 +165,43 @@ def test_the_scores_of_the_timed_job_are_the_oracles(monkeypatch):
     for r in range(8):
         assert np.allclose(kept[r].a, gold, rtol=1e-5, atol=1e-5), r
     assert line["config"]["trees"] == 80
+
+
+# ---------------------------------------------------------------------------------------------- other_configs (N = 1, the default command)
+def test_other_configs_plumbing_on_the_cpu_model(monkeypatch):
+    """`other_configs` of the driver's line: run_side_config for the dense configs end to end on the CPU model of the host
+    side (a few thousand rows instead of BASELINE's 10^7..10^8): model load, the engine's own kernel choice -- config 6, the reference's 512 x
+    depth 12, on the deep kernel in parts -- the timed steps, the roofline arithmetic and the oracle check of a prefix."""
+    L = _build("libddt_host_mock.so")
+    L.mock_reset(2, 5, 8)
+    monkeypatch.setattr(_lib, "_lib", L)
+    world = fake_torch.World(1)
+    ft = fake_torch.make(world, L)
+    monkeypatch.setitem(sys.modules, "torch", ft)
+    monkeypatch.setitem(sys.modules, "torch.distributed", ft.distributed)
+    monkeypatch.setitem(sys.modules, "torch.cuda", ft.cuda)
+    world.local.rank = 0
+    bench = _bench_module()
+    for cfg, kernel in ((2, "q16_d6_c16_u4"), (5, "q16_d8_c8_u4_gl_s2_cm_p"), (6, "q16d_d12_k9_c4_u4_cm")):
+        r = bench.run_side_config(cfg, 0, check_rows=1500, rows=2100)
+        assert r["kernel"] == kernel and r["fallback_kernel"] is False, r
+        assert r["parity"]["bit_exact"] is True and r["parity"]["rows_checked"] == 1500 and r["value"] > 0 and r["steps"] >= 3, r
+        assert r["roofline"]["alg_bytes_per_launch"] > 2100 * 4 * 28 and r["roofline"]["peak"] == 8000.0, r
+    assert L.mock_errors() == 0
+
+
+def test_other_configs_budget_and_failures_never_cost_the_line():
+    bench = _bench_module()
+    calls = []
+
+    def runner(cfg, dev):
+        calls.append(cfg)
+        if cfg == 2:
+            raise RuntimeError("boom")
+        import time as _t
+        _t.sleep(0.3)
+        return {"value": 1.0}
+
+    oc = bench.collect_other_configs(0, 0.5, runner=runner)
+    assert oc["1"] == {"value": 1.0} and "boom" in oc["2"]["error"] and oc["5"] == {"value": 1.0}
+    assert "skipped" in oc["6"] and "skipped" in oc["4"] and calls == [1, 2, 5] and oc["seconds"] >= 0.5

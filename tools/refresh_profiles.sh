@@ -5,7 +5,7 @@ set -eu
 cd "$(dirname "$0")/.."
 E=gpurun_out/$1
 R=${2:-r04}
-for f in bench_cfg1 bench_cfg2 bench_cfg3 bench_cfg4 bench_cfg5 bench_force_allreduce bench_force_chain bench_force_t125 bench_force_hybrid bench_shard_of_8 bench_t125 gpu_tests smoke; do
+for f in bench_cfg1 bench_cfg2 bench_cfg3 bench_cfg4 bench_cfg5 bench_cfg6 bench_cfg6_shard_of_8 bench_force_allreduce bench_force_chain bench_force_t125 bench_force_hybrid bench_shard_of_8 bench_t125 gpu_tests smoke; do
   [ -f $E/$f.log ] && cp $E/$f.log profiles/${R}_$f.log || true
 done
 python tools/update_pmc_traffic.py $E
@@ -13,6 +13,10 @@ python tools/prof_summary.py ${R}_final_bench_cfg3 --stats $E/stats_cfg3 --pmc $
   --levels 8 --features 32 --cmd "python bench.py --config 3 --steps 3 --warmup 1 --no-cpu-baseline --no-streamed" > /dev/null
 python tools/prof_summary.py ${R}_final_bench_cfg4 --stats $E/stats_cfg4 --pmc $E/fetch_cfg4 $E/write_cfg4 --kernel score_sparse --rows 10000000 --trees 512 \
   --levels 12 --features 64 --cmd "python bench.py --config 4 --steps 3 --warmup 1 --no-cpu-baseline --no-streamed" > /dev/null
+if [ -d $E/stats_cfg6 ]; then
+  python tools/prof_summary.py ${R}_final_bench_cfg6 --stats $E/stats_cfg6 --pmc $E/fetch_cfg6 $E/write_cfg6 --kernel score_q16d --rows 10000000 --trees 512 \
+    --levels 12 --features 32 --cmd "python bench.py --config 6 --steps 3 --warmup 1 --no-cpu-baseline --no-streamed" > /dev/null
+fi
 if [ -d $E/stats_cfg1 ]; then
   python tools/prof_summary.py ${R}_final_bench_cfg1 --stats $E/stats_cfg1 --pmc $E/fetch_cfg1 $E/write_cfg1 --kernel score_stream --rows 200000000 --trees 8 \
     --levels 4 --features 16 --cmd "python bench.py --config 1 --steps 10 --warmup 3 --no-cpu-baseline --no-streamed" > /dev/null
