@@ -1869,6 +1869,11 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     }
     return DDT_OK;
   }
+  if (!strcmp(key, "sparse_dm")) {  // dense mid levels (ddt_sparse_host.cpp sparse_rebuild): -1 automatic, 0 never, 1..3 exactly; effective at the next sparse load
+    if (value < -1 || value > 3) return fail(e, DDT_EINVAL, "sparse_dm must be -1..3");
+    e->sparse_dm = (int)value;
+    return DDT_OK;
+  }
   if (!strcmp(key, "sparse_top_levels") || !strcmp(key, "sparse_deep_order") || !strcmp(key, "sparse_q16") || !strcmp(key, "sparse_dk")) {
     // sparse forests: K = levels staged in LDS (-1 = as many as fit), order of the deep records (0 level order,
     // 1 depth-first per sub-tree), rank-quantised kernels (1 = when they fit, 0 = never), dense level K (1 = where such a kernel

@@ -64,8 +64,15 @@ __device__ __forceinline__ uint32_t sp_feature(uint32_t w, uint32_t lane_off, co
 
 // The walk of all PU groups for one tile.  SLOW = the tile holds a missing value: apply the per-node missing rule
 // (block-uniform choice, like the perfect-tree kernels).
-template <int K, int U, int THREADS, bool SLOW, bool Q, bool DK, bool GF = false>
+// M ("sparse_dm<M>_*", dense MID levels, round 5; only with DK): the levels K .. K+M-1 are dense too, as 8-BYTE records {thr, w} that continue
+// the heap in global memory (record of heap node h at byte cbase + 8 h; no child words: children by index, early leaves padded with dummies
+// like the top image), and the dense block of 16-byte records is level K+M (byte cbase - 8 * 2^(K+M) + 16 h).  Why: the counters of round 5
+// (profiles/r05_pmc_cfg2_cfg4_cfg6.md) put the kernel's bound at the L2's service of L1 misses -- 1.03 misses per tree and tuple, most of
+// them on the levels right below the top image, whose 16-byte records (96 KiB per PU group for levels 8-9) overflow a CU's 32 KiB L1.  Half
+// the bytes per hot record = twice the records per line and per L1.
+template <int K, int U, int THREADS, bool SLOW, bool Q, bool DK, bool GF = false, int M = 0>
 __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc, const GfSrc& gs) {
+  static_assert(M == 0 || DK, "dense mid levels extend the dense level K");
   constexpr int TOPB = (DK ? 8 : 12) << K;
   constexpr int STEPB = U * TOPB;  // U trees per pass: one PU group (or two)
   // Q: the u16 tile of the q16 pre-pass -- tuples t and t + 512 of a tile share a dword (rank_kernel)
@@ -102,7 +109,8 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
     for (int u = 0; u < U; ++u) {
       if (DK) {
         r8[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
-        cb[u] = lds_u32((uint32_t)(u * TOPB)) + (m8[u] << 2);  // byte offset of the LEFT child's record
+        if (M == 0) cb[u] = lds_u32((uint32_t)(u * TOPB)) + (m8[u] << 2);  // byte offset of the LEFT child's record
+        else cb[u] = lds_u32((uint32_t)(u * TOPB));                        // dense mid levels: cbase itself (8-byte records at cbase + 8 h)
       } else {
         r[u] = lds_u4((m8[u] << 1) - (uint32_t)(4 << K) + (uint32_t)(u * TOPB));
       }
@@ -132,13 +140,39 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
       leafv[u] = 0.f;
       if (!DK) rr[u] = u32x4{r[u].x, r[u].y, r[u].z, r[u].w};
     }
-    if constexpr (DK) {  // first round: level K-1 out of the registers, every walker goes on to its level-K record
+    if constexpr (DK && M == 0) {  // first round: level K-1 out of the registers, every walker goes on to its level-K record
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t f = sp_feature<Q, GF>(r8[u].y, lane_off, gs);
         const bool right = sp_right<SLOW, Q>(f, r8[u].x, r8[u].y, miss_key);
         rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (right ? 16u : 0u), 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (DK && M > 0) {
+      // dense mid levels: M rounds in which every walker is alive (no leaf flags: early leaves are padded), 8 gathers of 8 bytes in
+      // flight per lane and round, the same rotation as below; the last round fetches the 16-byte record of level K+M
+      u32x2 d8[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t f = sp_feature<Q, GF>(r8[u].y, lane_off, gs);
+        const bool right = sp_right<SLOW, Q>(f, r8[u].x, r8[u].y, miss_key);
+        m8[u] = (m8[u] << 1) + (right ? 8u : 0u);  // 8 * heap index at level K
+        d8[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, cb[u] + m8[u], 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 1; j <= M; ++j) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          asm volatile("" : "+v"(d8[u].x), "+v"(d8[u].y));
+          const uint32_t f = sp_feature<Q, GF>(d8[u].y, lane_off, gs);
+          const bool right = sp_right<SLOW, Q>(f, d8[u].x, d8[u].y, miss_key);
+          m8[u] = (m8[u] << 1) + (right ? 8u : 0u);
+          if (j < M) d8[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, cb[u] + m8[u], 0, 0);
+          else rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m8[u] << 1) - (uint32_t)(8u << (K + M)), 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     for (;;) {
@@ -177,7 +211,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
   }
 }
 
-template <int K, int U, int THREADS, bool Q, bool DK, bool GF = false>
+template <int K, int U, int THREADS, bool Q, bool DK, bool GF = false, int M = 0>
 __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
   static_assert(!GF || (!Q && !DK), "global-feature fallback: fp32 keys, 16-byte level K-1 records");
   constexpr int TOPB = (DK ? 8 : 12) << K;  // bytes of one tree's top image
@@ -266,18 +300,18 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   double dacc = 0.0;
   const uint32_t C = a.clusters;
   if constexpr (GF) sparse_walk<K, U, THREADS, true, Q, DK, true>(a, x, tid, ra, dacc, gs);
-  else if (!slow) sparse_walk<K, U, THREADS, false, Q, DK>(a, x, tid, ra, dacc, gs);
-  else sparse_walk<K, U, THREADS, true, Q, DK>(a, x, tid, ra, dacc, gs);
+  else if (!slow) sparse_walk<K, U, THREADS, false, Q, DK, false, M>(a, x, tid, ra, dacc, gs);
+  else sparse_walk<K, U, THREADS, true, Q, DK, false, M>(a, x, tid, ra, dacc, gs);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
 }
 
-template <int K, int U, int THREADS, bool Q, bool DK = false, bool GF = false>
+template <int K, int U, int THREADS, bool Q, bool DK = false, bool GF = false, int M = 0>
 static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_kernel<K, U, THREADS, Q, DK, GF>;
+  auto kern = score_sparse_kernel<K, U, THREADS, Q, DK, GF, M>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
@@ -296,6 +330,8 @@ static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStrea
   Variant { "sparse_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 0, &launch_sparse_v<K, U, T, false> }
 #define DDT_SPD(K, U, T) /* dense level K: 8-byte records only in LDS (8 * 2^K bytes per tree) */ \
   Variant { "sparse_dk_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2, &launch_sparse_v<K, U, T, false, true> }
+#define DDT_SPM(M, K, U, T) /* dense level K+M behind M dense levels of 8-byte records (opt bit 3; Variant::top = M) */ \
+  Variant { "sparse_dm" #M "_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2 | 8, &launch_sparse_v<K, U, T, false, true, false, M>, M }
 #define DDT_SPQD(K, U) /* rank-quantised + dense level K */ \
   Variant { "sparse_qd_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 3, &launch_sparse_v<K, U, 1024, true, true> }
 #define DDT_SPG(K, U, T) /* global features: no tile in LDS, any tuple width */ \
@@ -320,6 +356,8 @@ static const Variant g_sparse_variants[] = {
     // dense level K: K = 8 at two 256-tuple blocks per CU / K = 9 in one block of 512 where the 16-byte level K-1 records allow 7 / 8
     DDT_SPD(6, 8, 256), DDT_SPD(7, 8, 256), DDT_SPD(8, 8, 256), DDT_SPD(9, 8, 256), DDT_SPD(10, 8, 256),
     DDT_SPD(7, 8, 512), DDT_SPD(8, 8, 512), DDT_SPD(9, 8, 512), DDT_SPD(10, 8, 512),
+    // dense mid levels (round 5): forests whose levels right below the top image are (nearly) complete
+    DDT_SPM(1, 8, 8, 256), DDT_SPM(2, 8, 8, 256), DDT_SPM(3, 8, 8, 256), DDT_SPM(2, 7, 8, 256), DDT_SPM(2, 7, 8, 128), DDT_SPM(2, 8, 8, 128),
     // tuples too wide for any feature tile (more than ~540 words): every feature is gathered from the tuple's row in global memory.
     // The correctness path of the sparse format, like the generic kernel of the perfect-tree format -- not a tuned kernel.
     DDT_SPG(6, 8, 256),

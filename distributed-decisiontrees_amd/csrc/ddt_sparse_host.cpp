@@ -134,7 +134,44 @@ int sparse_rebuild(ddt_engine* e) {
   } catch (const std::bad_alloc&) {
     return fail(e, DDT_ENOMEM, "rank table allocation failed");
   }
-  const int vid = pick_variant(e, max_depth, rt.max_len <= kQ16MaxTable);
+  int vid = pick_variant(e, max_depth, rt.max_len <= kQ16MaxTable);
+  // Dense mid levels (option "sparse_dm": -1 automatic, 0 never, M = exactly M): where the choice is a dense-level-K kernel that has
+  // "sparse_dm<M>_*" siblings, the levels K .. K+M-1 become 8-byte heap records when the forest fills them at least half (the padding
+  // under early leaves doubles per level): the largest such M <= 3
+  if (vid >= 0 && e->forced_variant < 0 && e->sparse_dm != 0 && (variant(vid).opt & 2) && !(variant(vid).opt & (1 | 4 | 8))) {
+    const Variant& dkv = variant(vid);
+    const uint32_t K = (uint32_t)dkv.levels;
+    std::vector<double> nodes(K + 4u, 0.0);  // internal nodes per level K .. K+3 over all forests
+    double trees = 0.0;
+    std::vector<uint32_t> cur, nxt;
+    for (const SparseForest& sp : e->sps) {
+      trees += sp.trees();
+      for (uint32_t i = 0; i < sp.trees(); ++i) {
+        const uint32_t* L = sp.lines.data() + sp.first[i] * 4u;
+        cur.assign(1, 0u);
+        for (uint32_t lvl = 0; lvl < K + 3u && !cur.empty(); ++lvl) {
+          if (lvl >= K) nodes[lvl] += (double)cur.size();
+          nxt.clear();
+          for (uint32_t n : cur)
+            for (uint32_t side = 0; side < 2; ++side)
+              if (!((L[4u * n + 1u] >> (14u + side)) & 1u)) nxt.push_back(L[4u * n + 2u + side]);
+          cur.swap(nxt);
+        }
+      }
+    }
+    for (int M = 3; M >= 1; --M) {
+      if (e->sparse_dm > 0 && M != e->sparse_dm) continue;
+      bool full = trees > 0.0;
+      for (uint32_t lvl = K; lvl < K + (uint32_t)M; ++lvl) full = full && nodes[lvl] >= 0.5 * trees * (double)(1u << lvl);
+      char name[48];
+      snprintf(name, sizeof(name), "sparse_dm%d_k%u_u8_t%d", M, K, dkv.threads);
+      const int vm = find_variant(name);
+      if ((full || e->sparse_dm > 0) && vm >= 0 && variant(vm).lds_bytes_sparse(tuple_words(e->p)) <= dkv.lds_bytes_sparse(tuple_words(e->p))) {
+        vid = vm;
+        break;
+      }
+    }
+  }
   if (vid < 0)
     return fail(e, DDT_EUNSUPPORTED, "no sparse kernel fits: %u tuple words need more than %u bytes of LDS (or the forced variant %d / "
                 "sparse_top_levels %d is not a sparse kernel that fits)", tuple_words(e->p), kMaxLdsBytes, e->forced_variant, e->sparse_top_levels);
@@ -166,8 +203,12 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
   uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
   groups = (groups + per_pass - 1u) / per_pass * per_pass;  // whole passes: the padding groups are EMPTY slots too (+0)
   const bool dk = (v.opt & 2) != 0;  // dense level K: all K levels as 8-byte records in LDS, level K a dense block of deep records
+  // dense MID levels ("sparse_dm<M>_*", opt bit 3): the levels K .. K+M-1 continue the heap as 8-byte records in the deep array (record of heap
+  // node h at byte cbase + 8 h), the dense block of 16-byte records is level K+M (ddt_sparse.hip sparse_walk)
+  const uint32_t M = (dk && (v.opt & 8)) ? (uint32_t)v.top : 0u, KD = K + M;  // KD = the level of the dense 16-byte block
   const uint32_t top_words = v.top_bytes_sparse() / 4u;  // per tree
-  const uint32_t lvl8 = dk ? K : K - 1u;                 // levels stored as 8-byte heap records
+  const uint32_t lvl8 = dk ? K : K - 1u;                 // levels stored as 8-byte heap records in the top image
+  const uint32_t mid_words = 2u * ((1u << KD) - (1u << K));  // words of a tree's mid levels (8 bytes per record)
   const uint32_t feat_off = v.feat_off_sparse(), row = v.row_bytes_sparse();
   auto feat_word = [&](uint32_t j) { return feat_off + j * row; };
 
@@ -190,12 +231,19 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
   // record 0: a valid dummy (finished lanes keep re-reading it); dense level K: a whole block of 2^K of them, the level K of every
   // EMPTY slot
   try {
-    deep.assign(dk ? (size_t)4u << K : 4u, 0u);
+    deep.assign(dk ? (size_t)mid_words + ((size_t)4u << KD) : 4u, 0u);
   } catch (const std::bad_alloc&) {
     return fail(e, DDT_ENOMEM, "sparse image allocation failed");
   }
-  for (size_t q = 0; q < deep.size() / 4u; ++q) put16(deep.data() + 4u * q, 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
-  const auto cbase_of = [&](size_t first_record) { return (uint32_t)(first_record << 4) - (16u << K); };  // see ddt_internal.h
+  for (size_t q = 0; q < mid_words / 2u; ++q) {  // (dense mid levels: the EMPTY slots' dummy heap)
+    deep[2u * q] = 0u;
+    deep[2u * q + 1u] = feat_word(0);
+  }
+  for (size_t q = 0; q < (deep.size() - mid_words) / 4u; ++q) put16(deep.data() + mid_words + 4u * q, 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
+  // word 0 of a tree's top image: the byte offset the kernel adds a heap index to -- 16 h for the dense level K, 8 h for dense mid levels
+  const auto cbase_of = [&](size_t first_record) {
+    return M ? (uint32_t)(first_record << 4) - (8u << K) : (uint32_t)(first_record << 4) - (16u << K);
+  };  // see ddt_internal.h
 
   std::vector<Cursor> cur, nxt;
   struct Patch {  // a child word to patch with the deep index of tree node `node` once the deep records of the tree are placed
@@ -245,16 +293,36 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
       cur.swap(nxt);
     }
     // ---- the first 16-byte records, whose children are leaves or deep records: level K-1 in the top image, or (dense level K) the
-    //      tree's dense block of 2^K records at the end of the deep array ----
+    //      tree's dense block of 2^K records at the end of the deep array -- behind its M dense mid levels of 8-byte records ----
     pending.clear();
     const size_t dense0 = deep.size() / 4u;
     if (dk) {
-      if (dense0 + cur.size() >= (1ull << 28)) return fail(e, DDT_EUNSUPPORTED, "more than 2^28 deep records (4 GiB of 16-byte records)");
-      deep.resize(deep.size() + cur.size() * 4u);
+      if (dense0 + mid_words / 4u + ((size_t)1u << KD) >= (1ull << 28)) return fail(e, DDT_EUNSUPPORTED, "more than 2^28 deep records (4 GiB of 16-byte records)");
+      deep.resize(deep.size() + mid_words + ((size_t)4u << KD));
       t[0] = cbase_of(dense0);
+      for (uint32_t lvl = K; lvl < KD; ++lvl) {  // the mid levels continue the heap (cur = the 2^lvl cursors of level lvl)
+        uint32_t* d8 = deep.data() + dense0 * 4u;
+        nxt.clear();
+        for (uint32_t k = 0; k < cur.size(); ++k) {
+          const size_t w2 = 2u * (((size_t)1u << lvl) + k - ((size_t)1u << K));
+          if (cur[k].leaf) {
+            d8[w2] = 0u;
+            d8[w2 + 1u] = feat_word(0);
+            nxt.push_back(cur[k]);
+            nxt.push_back(cur[k]);
+          } else {
+            const uint32_t n = cur[k].v;
+            d8[w2] = node_key(n);
+            d8[w2 + 1u] = node_w(n);
+            nxt.push_back(child(n, 0));
+            nxt.push_back(child(n, 1));
+          }
+        }
+        cur.swap(nxt);
+      }
     }
     for (uint32_t k = 0; k < cur.size(); ++k) {
-      const size_t word = dk ? (dense0 + k) * 4u : (size_t)(last + 4u * k - top.data());
+      const size_t word = dk ? dense0 * 4u + mid_words + (size_t)k * 4u : (size_t)(last + 4u * k - top.data());
       uint32_t* rec = (dk ? deep.data() : top.data()) + word;
       if (cur[k].leaf) {
         put16(rec, 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, cur[k].v, cur[k].v);

@@ -271,7 +271,14 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
         const uint32_t* tr = top + (size_t)slot * tw;
         uint32_t m = 1;
         for (uint32_t lvl = 0; lvl + (dense ? 0u : 1u) < K; ++lvl) m = 2u * m + right(tr[2u * m], tr[2u * m + 1u]);
-        const uint32_t* rec = dense ? deep + (size_t)((16u * m + tr[0]) / 16u) * 4u : tr + (4u << K) / 4u + 4u * (m - (1u << (K - 1)));
+        const uint32_t mid = (dense && (v.opt & 8)) ? (uint32_t)v.top : 0u;  // "sparse_dm<M>_*": M levels of 8-byte records continue the heap in the deep array
+        for (uint32_t j = 0; j < mid; ++j) {
+          const uint32_t* r8 = deep + (size_t)((8u * m + tr[0]) / 4u);
+          m = 2u * m + right(r8[0], r8[1]);
+        }
+        const uint32_t* rec = !dense ? tr + (4u << K) / 4u + 4u * (m - (1u << (K - 1)))
+                              : mid  ? deep + (size_t)((16u * m + tr[0] - (8u << (K + mid))) / 16u) * 4u
+                                     : deep + (size_t)((16u * m + tr[0]) / 16u) * 4u;
         for (int guard = 0; guard < 100; ++guard) {
           const uint32_t r = right(rec[0], rec[1]), nxt = rec[2 + r];
           if (rec[1] & (r ? kSpRightLeaf : kSpLeftLeaf)) {
@@ -327,6 +334,9 @@ const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
     Variant{"sparse_k9_u8_t128", kKindSparse, 9, 128, 1, 8, 8, 1, 0, &launch_sparse},
     Variant{"sparse_dk_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 2, &launch_sparse},
     Variant{"sparse_dk_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2, &launch_sparse},
+    Variant{"sparse_dm1_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 8, &launch_sparse, 1},
+    Variant{"sparse_dm2_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 8, &launch_sparse, 2},
+    Variant{"sparse_dm3_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 8, &launch_sparse, 3},
     Variant{"sparse_dk_k9_u8_t512", kKindSparse, 9, 512, 1, 8, 8, 1, 2, &launch_sparse},
     Variant{"sparse_qd_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3, &launch_sparse},
     Variant{"sparse_gf_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 4, &launch_sparse},

@@ -38,7 +38,7 @@ def _rank_tables(s):
     return [np.unique(nl[(nl[:, 1] & 0x7FF) == j, 0].view(np.int32)) for j in range(int(s.params.num_features))]
 
 
-def _walk(top, deep, info, slot, x, miss_bits, tables=None):
+def _walk(top, deep, info, slot, x, miss_bits, tables=None, mid=0):
     """score_sparse_kernel's walk of one tree slot for one tuple (cmp_mode 0: signed compare of the raw bits); `tables`
     (rank-quantised kernels): the node word is the threshold's rank, the feature value is replaced by ITS rank = number of keys <= x"""
     _, _, _, K, feat_off, row = info
@@ -58,7 +58,17 @@ def _walk(top, deep, info, slot, x, miss_bits, tables=None):
     m = 1
     for _ in range(K if dense else K - 1):
         m = 2 * m + int(right(int(t[2 * m]), int(t[2 * m + 1])))
-    if dense:  # level K: deep record at byte 2 * (8 m) + cbase (mod 2^32), cbase in word 0 of the tree's image
+    if dense and mid:  # dense mid levels ("sparse_dm<M>_*"): M levels of 8-byte records that continue the heap at byte cbase + 8 h, then the
+        # dense block of 16-byte records of level K + M at byte cbase - 8 * 2^(K+M) + 16 h
+        words = deep.reshape(-1)
+        for _ in range(mid):
+            off = (8 * m + int(t[0])) & 0xFFFFFFFF
+            assert off % 8 == 0 and off // 4 + 1 < words.size
+            m = 2 * m + int(right(int(words[off // 4]), int(words[off // 4 + 1])))
+        off = (16 * m + int(t[0]) - (8 << (K + mid))) & 0xFFFFFFFF
+        assert off % 16 == 0 and off // 16 < deep.shape[0]
+        rec = deep[off // 16]
+    elif dense:  # level K: deep record at byte 2 * (8 m) + cbase (mod 2^32), cbase in word 0 of the tree's image
         off = (16 * m + int(t[0])) & 0xFFFFFFFF
         assert off % 16 == 0 and off // 16 < deep.shape[0]
         rec = deep[off // 16]
@@ -89,23 +99,24 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
     seen_k = set()
     tables = _rank_tables(s)
     for vid, name in _sparse_variants():
-        ranked, dense = name.startswith(("sparse_q_", "sparse_qd_")), name.startswith(("sparse_dk_", "sparse_qd_"))
+        ranked, dense = name.startswith(("sparse_q_", "sparse_qd_")), name.startswith(("sparse_dk_", "sparse_qd_", "sparse_dm"))
+        mid = int(re.match(r"sparse_dm(\d)_", name).group(1)) if name.startswith("sparse_dm") else 0
         K = int(re.search(r"_k(\d+)_", name).group(1))
         gf = name.startswith("sparse_gf_")   # features gathered from global memory: the address field is the byte offset in the tuple's row
-        if (ranked, dense, K, gf) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
+        if (ranked, dense, K, gf, mid) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
             continue
-        seen_k.add((ranked, dense, K, gf))
+        seen_k.add((ranked, dense, K, gf, mid))
         top, deep, info = _images(s, vid, order)
         assert info[3] == K and info[2] * 8 >= T and top.size == info[2] * 8 * ((8 if dense else 12) << K) // 4
         assert info[5] == (4 if gf else 2048 if ranked else 4 * int(name.rsplit("_t", 1)[1]))  # u16 rows of 1024 tuples / fp32 rows of the tile
         assert not gf or info[4] == 0
         for r in range(x.shape[0]):
             for i in range(info[2] * 8):
-                got = _walk(top, deep, info, i, x[r], int(s.params.missing_bits), tables if ranked else None)
+                got = _walk(top, deep, info, i, x[r], int(s.params.missing_bits), tables if ranked else None, mid)
                 want = O.traverse_sparse(s, x[r], i) if i < T else 0
                 assert got == want, (name, order, r, i, hex(got), hex(want))
     assert len([k for k in seen_k if not k[0] and not k[1]]) >= 4 and len([k for k in seen_k if k[0]]) >= 4 and len([k for k in seen_k if k[1]]) >= 4
-    assert any(k[3] for k in seen_k)
+    assert any(k[3] for k in seen_k) and {k[4] for k in seen_k} >= {0, 1, 2, 3}
 
 
 def test_hook_rejects_what_the_loader_rejects():
