@@ -357,7 +357,9 @@ static const Variant g_sparse_variants[] = {
     DDT_SPD(6, 8, 256), DDT_SPD(7, 8, 256), DDT_SPD(8, 8, 256), DDT_SPD(9, 8, 256), DDT_SPD(10, 8, 256),
     DDT_SPD(7, 8, 512), DDT_SPD(8, 8, 512), DDT_SPD(9, 8, 512), DDT_SPD(10, 8, 512),
     // dense mid levels (round 5): forests whose levels right below the top image are (nearly) complete
-    DDT_SPM(1, 8, 8, 256), DDT_SPM(2, 8, 8, 256), DDT_SPM(3, 8, 8, 256), DDT_SPM(2, 7, 8, 256), DDT_SPM(2, 7, 8, 128), DDT_SPM(2, 8, 8, 128),
+    // (BASELINE config 4, one box, alternating: M = 0 / 1 / 2 / 3 -> 265-270 / 275 / 271-272 / 214-227 Mtuples/s, profiles/r05_pmc_cfg2_cfg4_cfg6.md:
+    // one mid level pays a little, three lose a fifth -- the padding under the early leaves of level 10 turns finished walkers into live gathers)
+    DDT_SPM(1, 8, 8, 256), DDT_SPM(2, 8, 8, 256), DDT_SPM(1, 7, 8, 256), DDT_SPM(1, 8, 8, 128), DDT_SPM(1, 7, 8, 128),
     // tuples too wide for any feature tile (more than ~540 words): every feature is gathered from the tuple's row in global memory.
     // The correctness path of the sparse format, like the generic kernel of the perfect-tree format -- not a tuned kernel.
     DDT_SPG(6, 8, 256),

@@ -866,9 +866,9 @@ def test_a_pu_group_beyond_the_u16_ranks_falls_back_and_says_so(mock):
     mock.ddt_destroy(e)
 
 
-@pytest.mark.parametrize("T,depth,F,full,pm,dm,name", [(20, 14, 64, 10, 700, -1, "sparse_dm3_k8_u8_t256"), (20, 14, 64, 9, 400, -1, "sparse_dm1_k8_u8_t256"),
+@pytest.mark.parametrize("T,depth,F,full,pm,dm,name", [(20, 14, 64, 10, 700, -1, "sparse_dm1_k8_u8_t256"), (20, 14, 64, 9, 400, -1, "sparse_dm1_k8_u8_t256"),
                                                        (20, 14, 64, 8, 300, -1, "sparse_dk_k8_u8_t256"), (20, 14, 64, 10, 700, 2, "sparse_dm2_k8_u8_t256"),
-                                                       (20, 14, 64, 10, 700, 0, "sparse_dk_k8_u8_t256"), (12, 9, 64, 3, 500, 3, "sparse_dm3_k8_u8_t256")])
+                                                       (20, 14, 64, 10, 700, 0, "sparse_dk_k8_u8_t256"), (12, 9, 64, 3, 500, 2, "sparse_dm2_k8_u8_t256")])
 def test_sparse_forests_with_dense_mid_levels(mock, T, depth, F, full, pm, dm, name):
     """Round 5: the levels right below the top image as 8-byte heap records when the forest fills them (option sparse_dm: automatic by the
     levels' fill, or forced -- then also on a forest shallower than the dense block, which is all padding there): choice, packing (padding
