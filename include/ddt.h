@@ -230,7 +230,10 @@ int ddt_load_model_sparse_multiclass(ddt_engine* e, const ddt_params* p, const v
  *    like ddt_score_device; workspace buffers are (re)allocated synchronously when a call needs more than before.
  *    Multi-process (one process per GPU): rank 0 calls ddt_comm_get_unique_id and hands the 128 bytes to every rank
  *    (any launcher-side channel: a file, MPI, torch.distributed's store), then every rank calls ddt_comm_create.
- *    Single process driving several GPUs: ddt_group_* below (ncclCommInitAll + one worker thread per device).      -- */
+ *    Single process driving several GPUs: ddt_group_* below (ncclCommInitAll + one worker thread per device).
+ *    An engine that has been given a communicator of more than one rank stays in "job mode" for its lifetime (its automatic kernel
+ *    choice prefers the persistent depth-8 kernel, whose blocks do not wait for CUs that collective kernels occupy): the communicator
+ *    may outlive or predecease the engine, so destroying it does not touch the engine; use a fresh engine for stand-alone scoring.  -- */
 typedef struct ddt_comm ddt_comm;
 #define DDT_COMM_ID_BYTES 128
 enum { DDT_COMBINE_ALLREDUCE = 0, DDT_COMBINE_CHAIN = 1 };
