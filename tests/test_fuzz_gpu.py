@@ -19,6 +19,15 @@ def _cases():
         F = int(rng.integers(1, 41)) if D in (4, 6, 8, 9, 10) else int(rng.integers(1, 80))
         n = int(rng.integers(1, 7000))
         out.append((i, T, D, F, n, int(rng.integers(0, 2)), int(rng.choice([1, 2, 4, 8])), int(rng.integers(0, 2))))
+    # round 5: deep perfect trees (depth 11..15 on the deep kernels, tuples of up to 64 words on their wide forms, beyond that the generic
+    # kernel), a stream of their own so that the cases above stay what they were
+    rng = np.random.default_rng(20260923)
+    for i in range(44, 60):
+        D = int(rng.choice([11, 12, 12, 13, 14, 15]))
+        T = int(rng.integers(1, 40)) if D <= 13 else int(rng.integers(1, 12))
+        F = int(rng.integers(1, 70))
+        n = int(rng.integers(1, 5000))
+        out.append((i, T, D, F, n, int(rng.integers(0, 2)), int(rng.choice([1, 2, 4, 8])), int(rng.integers(0, 2))))
     return out
 
 
