@@ -464,7 +464,8 @@ def main(argv=None, inproc_env=None):
     if kernel_ms and k_ms > 0:  # (an event that could not be resolved leaves 0: no roofline object rather than a division by zero)
         ach = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic_cfg4.json" if sparse else "pmc_traffic_cfg1.json" if args.config == 1 else "pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic_cfg4.json" if sparse else "pmc_traffic_cfg1.json" if args.config == 1 else
+                           "pmc_traffic_cfg6.json" if args.config == 6 else "pmc_traffic.json")
         if os.path.exists(pmc) and not multi and args.shard_of <= 1:  # HBM bytes per launch of this kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of THIS command, collected in its own run
             try:
                 pj = json.load(open(pmc))

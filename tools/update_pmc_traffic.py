@@ -72,6 +72,29 @@ def main():
                    "hbm_bytes_per_launch": fr4 + c4["tuple_stream_bytes"] // 2 + wr4, "source": f"{ev}: `{cmd.format(4)}`"})
         json.dump(c4, open(p4, "w"), indent=1)
         print("config 4:", c4["hbm_bytes_per_launch"], "B/launch")
+    # ---- config 6: the reference's own 512 x d12 x 32 on the deep kernel, in parts (round 5) -------------------------------------------
+    f, w = pmc(ev + "/fetch_cfg6", "score_q16d"), pmc(ev + "/write_cfg6", "score_q16d")
+    if f and w:
+        fr6, wr6 = kib(f, "FETCH_SIZE"), kib(w, "WRITE_SIZE")
+        parts = 3
+        pre6 = {}
+        for name, like, calls in (("rank", "ddt::rank_kernel", 2), ("transpose", "transpose_kernel", 1), ("fused_rank", "fused_rank_kernel", 1)):
+            f2, w2 = pmc(ev + "/fetch_cfg6", like), pmc(ev + "/write_cfg6", like)
+            if f2 or w2:
+                pre6[name] = {"FETCH_SIZE": kib(f2, "FETCH_SIZE"), "WRITE_SIZE": kib(w2, "WRITE_SIZE"), "launches_per_step": calls}
+        scoring = parts * (2 * fr6 + wr6)
+        step6 = scoring + sum(v["launches_per_step"] * (2 * (v["FETCH_SIZE"] or 0) + (v["WRITE_SIZE"] or 0)) for v in pre6.values())
+        j6 = {"rows": 10000000, "trees": 512, "kernel": "score_q16d_kernel<12,9,4> (q16d_d12_k9_c4_u4_cm), 3 parts per step",
+              "fetch_bytes_raw_per_launch": fr6, "fetch_bytes_x2_corrected_per_launch": 2 * fr6, "write_bytes_per_launch": wr6,
+              "hbm_bytes_per_launch": scoring,
+              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the config-6 bench command.  The ensemble is scored in 3 parts: "
+                      "`hbm_bytes_per_launch` is the sum over the three scoring launches of one step (2 x FETCH + WRITE each; the u16 rank tiles, the "
+                      "stage records' L2 misses, the sum's state between the parts), which is what the line's `kernel_ms` spans together with two "
+                      "of the pre-passes; `prepass`: raw counter bytes per launch of the pre-pass kernels and their launches per step.",
+              "prepass": pre6, "step_hbm_bytes_x2_corrected": step6, "algorithmic_bytes_per_step": 10000000 * 132 + 512 * (4 * 8191 + 2 * 4095),
+              "round": 5, "source": f"{ev} (tools/gpu_evidence_r05.sh): `{cmd.format(6)}`"}
+        json.dump(j6, open(os.path.join(ROOT, "profiles", "pmc_traffic_cfg6.json"), "w"), indent=1)
+        print("config 6: scoring launches", scoring, "B/step; whole step", step6, "B")
 
 
 if __name__ == "__main__":
