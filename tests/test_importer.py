@@ -187,6 +187,17 @@ def test_imported_models_on_gpu():
         assert np.allclose(got, rf.predict(Xt), rtol=2e-5, atol=2e-5)
         om = _omodel(im, im.params().clusters_per_tuple)
         assert np.array_equal(got.view(np.uint32), O.score(om, tl, sum_mode=O.SUM_REF_FLOPOCO if sum_mode == 0 else O.SUM_F64_SEQ).view(np.uint32))
+    # a DEEP forest in the perfect format (early leaves padded down to depth 11 / 12): the deep rank-quantised kernels (round 5)
+    for depth, name in ((11, "q16d_d11_k8_c8_u4_cm"), (12, "q16d_d12_k9_c4_u4_cm")):
+        rfd = ensemble.RandomForestRegressor(n_estimators=24, max_depth=depth, random_state=1).fit(X, y)
+        im = I.from_sklearn(rfd)
+        assert im.num_levels == depth
+        e.load_model(im.params(), im.wlines, im.flines)
+        assert e.info().variant_name.decode() == name and e.info().fallback_kernel == 0
+        got = e.score(tl)
+        assert np.allclose(got, rfd.predict(Xt), rtol=2e-5, atol=2e-5)
+        om = _omodel(im, im.params().clusters_per_tuple)
+        assert np.array_equal(got.view(np.uint32), O.score_fast(om, tl).view(np.uint32))
     lab = np.digitize(y, np.quantile(y, [0.33, 0.66]))
     gbc = ensemble.GradientBoostingClassifier(n_estimators=20, max_depth=4, random_state=0).fit(X, lab)
     im = I.from_sklearn(gbc)
