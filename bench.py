@@ -607,7 +607,12 @@ def main(argv=None, inproc_env=None):
             else:
                 chk = min(chk, 65_536)
                 _, gold = O.score_sparse(m, xs[:chk], sum_mode=sum_ref, n_devices=n_dev, want_gold=True)
-                gabs = np.abs(gold)
+                # the sum of the leaves' magnitudes: the same forest with |leaf| in every leaf field (entry bits 14 / 15 flag them), same walks
+                la = np.array(lines, np.uint32, copy=True).reshape(-1, 4)
+                for side in (0, 1):
+                    is_leaf = ((la[:, 1] >> (14 + side)) & 1) != 0
+                    la[is_leaf, 2 + side] &= 0x7FFFFFFF
+                _, gabs = O.score_sparse(O.SparseModel(O.make_sparse_params(T, D, F), la, first), xs[:chk], sum_mode=sum_ref, n_devices=n_dev, want_gold=True)
                 err = np.abs(got[:chk].astype(np.float64) - gold)
                 parity["rows_that_differ_from_chain_oracle"] = int((got.view(np.uint32) != ref.view(np.uint32)).sum())
             tol = 1e-6 * np.maximum(np.abs(gold), gabs)
