@@ -46,6 +46,7 @@ def main():
     out = torch.empty(N, dtype=torch.float32, device="cuda")
     p = ddt.make_sparse_params(T, D, F)
     res = []
+    ref_out = None
     names = ddt.variant_names()
     only = [v for v in a.only.split(",") if v]
     for vid, name in enumerate(names):
@@ -63,6 +64,9 @@ def main():
             eng.score_device(d, out=out)
             torch.cuda.synchronize()
             ok = bool(np.array_equal(out[:1024].cpu().numpy().view(np.uint32), want.view(np.uint32)))
+            if ref_out is None:
+                ref_out = out.clone()   # every later variant's scores of ALL rows against the first variant's, bit for bit
+            same = bool(torch.equal(out.view(torch.int32), ref_out.view(torch.int32)))
             ts = []
             for _ in range(a.reps):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -75,7 +79,7 @@ def main():
             K = int(name.split("_k")[1].split("_")[0])
             r = {"order": order, "variant": info.variant_name.decode(), "visits_per_s": round(N * T * depth / ms * 1e3, 1),
                  "deep_gathers_per_s": round(N * T * max(0.0, depth - K) / ms * 1e3, 1), "lds_bytes": info.lds_bytes, "image_MB": info.image_bytes / 1e6,
-                 "ms": round(ms, 3), "Mtuples_s": round(N / ms / 1e3, 2), "bit_exact": ok}
+                 "ms": round(ms, 3), "Mtuples_s": round(N / ms / 1e3, 2), "bit_exact": ok, "all_rows_equal_first_variant": same}
             print(r, flush=True)
             res.append(r)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
