@@ -359,10 +359,12 @@ __device__ __forceinline__ uint32_t lds_poll_u32(uint32_t a) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile DDT_LDS(uint32_t)*>(a));
 }
 
-template <int K, int L, int THREADS, bool SLOW, bool VST>
+template <int K, int L, int NS, int THREADS, bool SLOW>
 __device__ __forceinline__ void sparse_walk_qw(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc, uint64_t (&dbg)[4]) {
-  constexpr int U = 8, TOPB = 8 << K, STEPB = U * TOPB, WAVES = THREADS / 64, PARTB = STEPB / WAVES;
-  static_assert(L >= 2 && L <= 4, "window of 2..4 PU groups");
+  // NS sets of 8 streams: PU group g walks on the streams of set g % NS, every set with its own window of L groups -- 8 NS gathers in flight per
+  // lane from ONE resident image (the top pass is decoupled from the walks)
+  constexpr int U = 8, S = U * NS, TOPB = 8 << K, STEPB = U * TOPB, WAVES = THREADS / 64, PARTB = STEPB / WAVES;
+  static_assert(L >= 2 && L <= 4 && (NS == 1 || NS == 2), "window of 2..4 PU groups, one or two sets of streams");
   static_assert(PARTB >= 2 * TOPB && PARTB % 1024 == 0, "a wave's quarter holds two trees' record 0 (A and its flag)");
   constexpr uint32_t kA = 4u;  // tree 0, record 0, word 1
   const GfSrc gs{};
@@ -381,8 +383,9 @@ __device__ __forceinline__ void sparse_walk_qw(const ScoreArgs& a, const SparseA
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(gp) : "memory");
     }
   };
-  // top pass of the resident image: K levels of 8-byte heap records, then the byte offset of the walker's level-K record
-  auto top_pass = [&](uint32_t (&ptr)[U]) {
+  uint32_t slot[L][S];  // entry pointer (byte offset of a deep record) of a walk not yet started / leaf bits of a finished one
+  // top pass of the resident image into slot j of set `set`: K levels of 8-byte heap records, then the byte offset of the walker's level-K record
+  auto top_pass = [&](const int j, const int set) {
     uint32_t m8[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) m8[u] = 8u;
@@ -398,61 +401,58 @@ __device__ __forceinline__ void sparse_walk_qw(const ScoreArgs& a, const SparseA
       for (int u = 0; u < U; ++u) m8[u] = (m8[u] << 1) + (sp_right<SLOW, false>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) ptr[u] = lds_u32((uint32_t)(u * TOPB)) + (m8[u] << 1);  // cbase + 16 * heap index at level K
+    for (int u = 0; u < U; ++u) slot[j][set * U + u] = lds_u32((uint32_t)(u * TOPB)) + (m8[u] << 1);  // cbase + 16 * heap index at level K
   };
 
-  uint32_t slot[L][U];  // entry pointer (byte offset of a deep record) of a walk not yet started / leaf bits of a finished one
 #pragma unroll
   for (int j = 0; j < L; ++j)
 #pragma unroll
-    for (int u = 0; u < U; ++u) slot[j][u] = 0u;
-  // ---- prologue: the first L images behind block barriers (nothing is in flight yet) ----
-  uint32_t nf = 0;  // filled slots of the window (wave-uniform)
+    for (int u = 0; u < S; ++u) slot[j][u] = idle_off;
+  // ---- prologue: the first L * NS images behind block barriers (nothing is in flight yet); group g = slot g / NS of set g % NS ----
+  uint32_t nf[NS];  // filled slots of a set's window (wave-uniform)
+#pragma unroll
+  for (int t = 0; t < NS; ++t) nf[t] = 0u;
   dma_part(0);
 #pragma unroll
-  for (int j = 0; j < L; ++j) {
-    if ((uint32_t)j < n_groups) {
+  for (int g = 0; g < L * NS; ++g) {
+    if ((uint32_t)g < n_groups) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      top_pass(slot[j]);
+      top_pass(g / NS, g % NS);
       __syncthreads();
-      if ((uint32_t)j + 1u < n_groups) dma_part((uint32_t)j + 1u);
-      nf = (uint32_t)j + 1u;
+      if ((uint32_t)g + 1u < n_groups) dma_part((uint32_t)g + 1u);
+      nf[g % NS] = (uint32_t)(g / NS) + 1u;
     }
   }
-  uint32_t gfill = nf;                    // next group to top-pass
-  uint32_t gdma = nf;                     // the image this wave loads next (or is loading: `pending`)
+  uint32_t gfill = n_groups < (uint32_t)(L * NS) ? n_groups : (uint32_t)(L * NS);  // next group to top-pass
+  uint32_t gdma = gfill;                  // the image this wave loads next (or is loading: `pending`)
   bool pending = gdma < n_groups;         // my quarter of image gdma is in flight
   uint32_t age = 0;                       // rounds issued since that DMA
 
-  // Lane state per stream u: the slot it is at (0 .. L; L = past the window) and `walking` = it has a live gather.  A lane at a FILLED slot
-  // is always walking it (it starts a walk in the step in which it finishes the one before, or in its first step after the slot is
-  // filled).  Two representations of "the slot it is at":
-  //   VST = false  one-hot lane masks ph[j] in SGPRs -- the selects cost one VALU each, but 8 x (L + 1) masks do not fit the SGPR file (L = 3:
-  //                the compiler spills to VGPR lanes);
-  //   VST = true   a VGPR counter st per stream, its masks recomputed by compares in every step -- no spills, ~3 VALU more per step.
-  uint64_t ph[U][VST ? 1 : L], walking[U];
-  uint32_t st[U];
-  u32x4 rr[U];
+  // Lane state per stream: st = the slot it is at (0 .. L; L = past the window), `walking` = it has a live gather.  A lane at a FILLED slot is
+  // always walking it (it starts a walk in the step in which it finishes the one before, or in its first step after the slot is filled).
+  uint64_t walking[S];
+  uint32_t st[S];
+  u32x4 rr[S];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
+  for (int u = 0; u < S; ++u) {
     st[u] = 0u;
-#pragma unroll
-    for (int j = 0; j < (VST ? 1 : L); ++j) ph[u][j] = j == 0 ? ~0ull : 0ull;
-    walking[u] = nf > 0u ? ~0ull : 0ull;
-    rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, nf > 0u ? slot[0][u] : idle_off, 0, 0);  // every lane starts on slot 0
-    __builtin_amdgcn_sched_barrier(0);  // in stream order, as in the loop: the wait the compiler puts in front of a visit is the loop's vmcnt(7)
+    walking[u] = nf[u / U] > 0u ? ~0ull : 0ull;
+    rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, slot[0][u], 0, 0);  // every lane starts on slot 0 (an unfilled slot holds idle_off)
+    __builtin_amdgcn_sched_barrier(0);  // in stream order, as in the loop: the wait the compiler puts in front of a visit is the loop's vmcnt(S - 1)
   }
   uint32_t folded = 0;
-  uint64_t any0 = ~0ull;  // lanes still at slot 0 on some stream (as of the last round)
+  uint64_t any0[NS];  // lanes still at slot 0 on some stream of the set (as of the last round)
+#pragma unroll
+  for (int t = 0; t < NS; ++t) any0[t] = ~0ull;
   const uint32_t guard_max = n_groups * 64u + 4096u;
-  const uint64_t t_loop0 = __builtin_amdgcn_s_memtime();
   for (uint32_t guard = 0; folded < n_groups && guard < guard_max; ++guard) {
     dbg[0] = guard + 1u;
-    const uint64_t t_it0 = __builtin_amdgcn_s_memtime();
     // ---- the image buffer's protocol (see above) ----
     if (pending && age >= 1u) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // only the last round's 8 gathers may still fly: the older DMA has landed
+      // only the last round's gathers may still fly: the older DMA has landed
+      if constexpr (S == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       if (lane == 0) *reinterpret_cast<volatile DDT_LDS(uint32_t)*>(my_flag) = gdma + 1u;
       ++gdma;
       pending = false;
@@ -462,56 +462,53 @@ __device__ __forceinline__ void sparse_walk_qw(const ScoreArgs& a, const SparseA
       pending = true;
       age = 0;
     }
-    // ---- window: fold the oldest group when every lane has left it; top-pass the next group when its image is complete ----
-    if (nf > 0u && (nf == (uint32_t)L || gfill >= n_groups) && any0 == 0ull) {
-      if (a.sum_mode == 1) {
+    // ---- windows: fold the oldest group when every lane has left it; top-pass the next group when its image is complete ----
 #pragma unroll
-        for (int u = 0; u < 8; ++u) dacc += (double)__uint_as_float(slot[0][u]);
-      } else {  // FPAddersReduceTree.sv:94-141, then the slot accumulate of this group's cluster
-        const float lf[1][8] = {{__uint_as_float(slot[0][0]), __uint_as_float(slot[0][1]), __uint_as_float(slot[0][2]), __uint_as_float(slot[0][3]),
-                                 __uint_as_float(slot[0][4]), __uint_as_float(slot[0][5]), __uint_as_float(slot[0][6]), __uint_as_float(slot[0][7])}};
-        double unused[1] = {0.0};
-        fold_leaves<8, 1, 0>(lf, 0, C, ra, unused, a.sum_mode == 2);
-      }
-      any0 = 0ull;
+    for (int t = 0; t < NS; ++t) {
+      if (folded % (uint32_t)NS == (uint32_t)t && nf[t] > 0u && (nf[t] == (uint32_t)L || gfill >= n_groups) && any0[t] == 0ull) {
+        if (a.sum_mode == 1) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+          for (int u = 0; u < 8; ++u) dacc += (double)__uint_as_float(slot[0][t * U + u]);
+        } else {  // FPAddersReduceTree.sv:94-141, then the slot accumulate of this group's cluster
+          const float lf[1][8] = {{__uint_as_float(slot[0][t * U + 0]), __uint_as_float(slot[0][t * U + 1]), __uint_as_float(slot[0][t * U + 2]),
+                                   __uint_as_float(slot[0][t * U + 3]), __uint_as_float(slot[0][t * U + 4]), __uint_as_float(slot[0][t * U + 5]),
+                                   __uint_as_float(slot[0][t * U + 6]), __uint_as_float(slot[0][t * U + 7])}};
+          double unused[1] = {0.0};
+          fold_leaves<8, 1, 0>(lf, 0, C, ra, unused, a.sum_mode == 2);
+        }
+        any0[t] = 0ull;
 #pragma unroll
-        for (int j = 0; j + 1 < L; ++j) slot[j][u] = slot[j + 1][u];
-        if constexpr (VST) {
+        for (int u = t * U; u < (t + 1) * U; ++u) {
+#pragma unroll
+          for (int j = 0; j + 1 < L; ++j) slot[j][u] = slot[j + 1][u];
           st[u] -= 1u;
-          any0 |= __ballot(st[u] == 0u);
-        } else {
-          uint64_t none = ~0ull;
+          any0[t] |= __ballot(st[u] == 0u);
+        }
+        --nf[t];
+        ++folded;
+      }
+    }
 #pragma unroll
-          for (int j = 0; j < L; ++j) none &= ~ph[u][j];
+    for (int t = 0; t < NS; ++t) {
+      if (gfill < n_groups && gfill % (uint32_t)NS == (uint32_t)t && nf[t] == (uint32_t)(L - 1)) {
+        bool ready = true;
 #pragma unroll
-          for (int j = 0; j + 1 < L; ++j) ph[u][j] = ph[u][j + 1];
-          ph[u][L - 1] = none;
-          any0 |= ph[u][0];
+        for (int w = 0; w < WAVES; ++w) ready = ready && lds_poll_u32((uint32_t)(w * PARTB + TOPB + 4)) == gfill + 1u;
+        if (ready) {
+          top_pass(L - 1, t);
+          if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<DDT_LDS(uint32_t)*>(kA), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          nf[t] = (uint32_t)L;
+          ++gfill;
         }
       }
-      --nf;
-      ++folded;
     }
-    if (nf == (uint32_t)(L - 1) && gfill < n_groups) {
-      bool ready = true;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) ready = ready && lds_poll_u32((uint32_t)(w * PARTB + TOPB + 4)) == gfill + 1u;
-      if (ready) {
-        top_pass(slot[L - 1]);
-        if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<DDT_LDS(uint32_t)*>(kA), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        nf = (uint32_t)L;
-        ++gfill;
-      }
-    }
-    const uint64_t t_r0 = __builtin_amdgcn_s_memtime();
-    dbg[2] += t_r0 - t_it0;
     // ---- one round: every stream visits the record that has arrived and issues its next gather ----
-    const bool full = nf == (uint32_t)L;
-    uint64_t at0 = 0ull;
+    uint64_t at0[NS];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int t = 0; t < NS; ++t) at0[t] = 0ull;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+      const uint32_t nfu = nf[u / U];
       // the record stays opaque until its own visit (see the lock-step kernel)
       asm volatile("" : "+v"(rr[u].x), "+v"(rr[u].y), "+v"(rr[u].z), "+v"(rr[u].w));
       const uint32_t f = sp_feature<false, false>(rr[u].y, lane_off, gs);
@@ -523,7 +520,7 @@ __device__ __forceinline__ void sparse_walk_qw(const ScoreArgs& a, const SparseA
       uint64_t at[L];                           // lanes at slot j (before this step's moves)
 #pragma unroll
       for (int j = 0; j < L; ++j) {
-        at[j] = VST ? __ballot(st[u] == (uint32_t)j) : ph[u][j];
+        at[j] = __ballot(st[u] == (uint32_t)j);
         slot[j][u] = mask_sel(fin & at[j], nxt, slot[j][u]);
       }
       // after the moves: lanes at slot j = (at[j] & ~fin) | (at[j-1] & fin)
@@ -531,14 +528,11 @@ __device__ __forceinline__ void sparse_walk_qw(const ScoreArgs& a, const SparseA
       now[0] = at[0] & ~fin;
 #pragma unroll
       for (int j = 1; j < L; ++j) now[j] = (at[j] & ~fin) | (at[j - 1] & fin);
-      if constexpr (VST) {
+      {
         uint64_t co;
         asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(st[u]), "=s"(co) : "v"(st[u]), "s"(fin));
-      } else {
-#pragma unroll
-        for (int j = 0; j < L; ++j) ph[u][j] = now[j];
       }
-      at0 |= now[0];
+      at0[u / U] |= now[0];
       walking[u] &= ~fin;
       // lanes without a live gather whose slot is filled start its walk (slot >= 1: slot 0 was started before the loop / is never re-entered)
       uint32_t np = slot[1][u];
@@ -546,7 +540,7 @@ __device__ __forceinline__ void sparse_walk_qw(const ScoreArgs& a, const SparseA
 #pragma unroll
       for (int j = 1; j < L; ++j) {
         if (j >= 2) np = mask_sel(now[j], slot[j][u], np);
-        below |= (full || (uint32_t)j < nf) ? now[j] : 0ull;
+        below |= (uint32_t)j < nfu ? now[j] : 0ull;
       }
       const uint64_t can = below & ~walking[u];
       const uint32_t addr = mask_sel(walking[u], nxt << 4, mask_sel(can, np, idle_off));
@@ -554,14 +548,13 @@ __device__ __forceinline__ void sparse_walk_qw(const ScoreArgs& a, const SparseA
       rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, addr, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    any0 = at0;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) any0[t] = at0[t];
     ++age;
-    dbg[1] += __builtin_amdgcn_s_memtime() - t_r0;
   }
-  dbg[3] = __builtin_amdgcn_s_memtime() - t_loop0;
 }
 
-template <int K, int L, int THREADS, bool VST>
+template <int K, int L, int NS, int THREADS>
 __global__ __launch_bounds__(THREADS, 2) void score_sparse_qw_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 8 << K, STEPB = 8 * TOPB, ROW = THREADS * 4;
   constexpr int FEAT_OFF = (STEPB + ROW - 1) / ROW * ROW;
@@ -575,18 +568,18 @@ __global__ __launch_bounds__(THREADS, 2) void score_sparse_qw_kernel(const Score
   double dacc = 0.0;
   const uint32_t C = a.clusters;
   uint64_t dbg[4] = {0, 0, 0, 0};
-  if (!slow) sparse_walk_qw<K, L, THREADS, false, VST>(a, x, tid, ra, dacc, dbg);
-  else sparse_walk_qw<K, L, THREADS, true, VST>(a, x, tid, ra, dacc, dbg);
+  if (!slow) sparse_walk_qw<K, L, NS, THREADS, false>(a, x, tid, ra, dacc, dbg);
+  else sparse_walk_qw<K, L, NS, THREADS, true>(a, x, tid, ra, dacc, dbg);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = x.debug ? (float)dbg[(x.debug - 1u) & 3u] : (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
 }
 
-template <int K, int L, int THREADS, bool VST>
+template <int K, int L, int NS, int THREADS>
 static hipError_t launch_sparse_qw(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_qw_kernel<K, L, THREADS, VST>;
+  auto kern = score_sparse_qw_kernel<K, L, NS, THREADS>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
@@ -604,9 +597,9 @@ static hipError_t launch_sparse_qw(const ScoreArgs& a, const Variant& v, hipStre
 #define DDT_SPM(M, K, U, T) /* dense level K+M behind M dense levels of 8-byte records (opt bit 3; Variant::top = M) */ \
   Variant { "sparse_dm" #M "_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2 | 8, &launch_sparse_v<K, U, T, false, true, false, M>, M }
 #define DDT_SPW(L, K, T) /* queued walkers over a window of L PU groups (opt bit 4; Variant::top = L), dense level K */ \
-  Variant { "sparse_qw" #L "_k" #K "_u8_t" #T, kKindSparse, K, T, 1, 8, 8, 1, 2 | 16, &launch_sparse_qw<K, L, T, true>, L }
-#define DDT_SPWM(L, K, T) /* ... the lane's slot as one-hot masks in SGPRs instead of a VGPR counter (A/B) */ \
-  Variant { "sparse_qwm" #L "_k" #K "_u8_t" #T, kKindSparse, K, T, 1, 8, 8, 1, 2 | 16, &launch_sparse_qw<K, L, T, false>, L }
+  Variant { "sparse_qw" #L "_k" #K "_u8_t" #T, kKindSparse, K, T, 1, 8, 8, 1, 2 | 16, &launch_sparse_qw<K, L, 1, T>, L }
+#define DDT_SPW2(L, K, T) /* ... two sets of 8 streams: 16 gathers in flight per lane */ \
+  Variant { "sparse_qx" #L "_k" #K "_u8_t" #T, kKindSparse, K, T, 1, 8, 8, 1, 2 | 16, &launch_sparse_qw<K, L, 2, T>, L }
 #define DDT_SPQD(K, U) /* rank-quantised + dense level K */ \
   Variant { "sparse_qd_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 3, &launch_sparse_v<K, U, 1024, true, true> }
 #define DDT_SPG(K, U, T) /* global features: no tile in LDS, any tuple width */ \
@@ -636,7 +629,7 @@ static const Variant g_sparse_variants[] = {
     // one mid level pays a little, three lose a fifth -- the padding under the early leaves of level 10 turns finished walkers into live gathers)
     DDT_SPM(1, 8, 8, 256), DDT_SPM(2, 8, 8, 256), DDT_SPM(1, 7, 8, 256), DDT_SPM(1, 8, 8, 128), DDT_SPM(1, 7, 8, 128),
     // queued walkers (round 5): lanes run ahead of their wave inside a window of L PU groups
-    DDT_SPW(2, 8, 256), DDT_SPW(3, 8, 256), DDT_SPW(4, 8, 256), DDT_SPW(3, 7, 256), DDT_SPW(3, 8, 128), DDT_SPWM(2, 8, 256), DDT_SPWM(3, 8, 256),
+    DDT_SPW(2, 8, 256), DDT_SPW(3, 8, 256), DDT_SPW2(2, 8, 256), DDT_SPW2(3, 8, 256),
     // tuples too wide for any feature tile (more than ~540 words): every feature is gathered from the tuple's row in global memory.
     // The correctness path of the sparse format, like the generic kernel of the perfect-tree format -- not a tuned kernel.
     DDT_SPG(6, 8, 256),

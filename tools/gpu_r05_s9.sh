@@ -8,4 +8,4 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$tag
 rm -rf "$OUT"; mkdir -p "$OUT"
 ( timeout 600 python -m pytest tests/test_sparse.py -m gpu -x -q -k "every_sparse_kernel_variant" ) > $OUT/pytest_variants.log 2>&1; tail -5 $OUT/pytest_variants.log
-( timeout 900 python tools/sparse_sweep.py --rows 4000000 --reps 3 --only sparse_dm1_k8_u8_t256,sparse_dk_k8_u8_t256,sparse_qw,sparse_qwm --out $OUT/sparse_sweep.json ) > $OUT/sparse_sweep.log 2>&1; tail -14 $OUT/sparse_sweep.log
+( timeout 900 python tools/sparse_sweep.py --rows 4000000 --reps 3 --only sparse_dm1_k8_u8_t256,sparse_dk_k8_u8_t256,sparse_qw,sparse_qx --out $OUT/sparse_sweep.json ) > $OUT/sparse_sweep.log 2>&1; tail -14 $OUT/sparse_sweep.log

@@ -938,6 +938,23 @@ int main(int argc, char** argv) {
     strip_comma(js);
     js += "  ],\n";
   }
+  if (on("lines")) {
+    // round 5: the cost of a gather wave-instruction against the number of cache LINES its 64 lanes touch -- region_bytes / 128 lines to pick
+    // from, in a window the L1 holds (16 KiB) and in one only the L2 holds (1 MiB).  (The rows above keep the region at 1-2 KiB = 8-16 lines.)
+    js += "  \"gather_lines\": [\n";
+    char* d_win;
+    CK(hipMalloc(&d_win, 1 << 20));
+    CK(hipMemset(d_win, 1, 1 << 20));
+    for (uint32_t win : {16384u, 1u << 20})
+      for (uint32_t region : {512u, 1024u, 2048u, 4096u, 8192u, 16384u, 65536u, 1u << 20})
+        if (region <= win) {
+          run_gather<16>(d_out, d_win, win, region, js);
+          run_gather<8>(d_out, d_win, win, region, js);
+        }
+    strip_comma(js);
+    js += "  ],\n";
+    CK(hipFree(d_win));
+  }
   if (on("gather")) {
     js += "  \"gather\": [\n";
     char* d_win;
