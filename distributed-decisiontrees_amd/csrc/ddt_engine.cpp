@@ -1869,11 +1869,6 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     }
     return DDT_OK;
   }
-  if (!strcmp(key, "sparse_qw")) {  // queued walkers (ddt_sparse_host.cpp sparse_rebuild): 0 never, 2..4 = window of that many PU groups; effective at the next sparse load
-    if (value != 0 && (value < 2 || value > 4)) return fail(e, DDT_EINVAL, "sparse_qw must be 0 or 2..4");
-    e->sparse_qw = (int)value;
-    return DDT_OK;
-  }
   if (!strcmp(key, "sparse_dm")) {  // dense mid levels (ddt_sparse_host.cpp sparse_rebuild): -1 automatic, 0 never, 1..3 exactly; effective at the next sparse load
     if (value < -1 || value > 3) return fail(e, DDT_EINVAL, "sparse_dm must be -1..3");  // (-1: one mid level where the forest fills it)
     e->sparse_dm = (int)value;

@@ -212,7 +212,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
 }
 
 // Stage the block's tuple tile feature-major in LDS (quad-coalesced loads + in-quad DPP transpose, see score_tile_kernel); returns the
-// lane's "saw a missing value" flag.  Shared by the lock-step and the queued-walker kernels.
+// lane's "saw a missing value" flag.
 template <int THREADS, int FEAT_OFF, int ROW>
 __device__ __forceinline__ uint32_t sparse_stage_tile(const ScoreArgs& a, const uint64_t tile0, const int tid) {
   const uint32_t W = a.tuple_words, lpt = W / 4u;
@@ -332,274 +332,12 @@ static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStrea
   return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// "sparse_qw<L>_*": QUEUED WALKERS (round 5).  Same images as the dense-level-K kernels (opt bit 1) plus two kinds of words in the unused
-// second word of a tree's heap record 0 (ddt_sparse_host.cpp): the kernel above walks the 8 trees of a PU group in lock-step, so a wave
-// issues a gather per tree and round until its DEEPEST lane is done -- on BASELINE config 4 nine gather instructions per tree for 4.07
-// live visits per lane, and the gather instruction is the unit the vector-memory pipe charges (~30 cycles whatever its live lanes,
-// DESIGN.md section 4).  Here a lane keeps, per stream u (= tree position in the PU group, 8 independent load chains as before), a WINDOW of
-// L consecutive groups: a slot holds the walk's entry pointer (from the top pass) until the lane starts it and its leaf afterwards.  A
-// lane that reaches a leaf starts its next slot's walk in the same stream at once; the wave folds slot 0 (reference adder order,
-// unchanged) when all its lanes have left it and shifts the window.  Gather instructions per tree and wave: the MEAN over a window instead
-// of the max over the wave per tree (simulated 6.4 / 5.7 / 5.3 rounds at L = 2 / 3 / 4 for config 4's depths against 8).
-// The top pass of the next group runs per WAVE whenever its window has room, between rounds and with the gathers in flight; the four
-// waves share one image buffer without a barrier:
-//   * image g's word A (LDS byte 4) carries 4 g (waves per block x g); a wave adds 1 after its top pass of g, so A = 4 (g + 1) <=> all four have read image g,
-//     and each wave then DMAs its quarter of image g + 1 (which rewrites A with the value it has);
-//   * a wave knows its quarter has landed when at most the 8 gathers of the following round are outstanding (loads return in order) and
-//     then writes g + 2 into its FLAG word (record 0 of the second tree of its quarter; the image carries 0 there); a wave top-passes image
-//     g + 1 when all four flags read g + 2.
-// No wave ever waits: whoever cannot advance keeps walking.  A watchdog ends a block whose protocol is stuck (wrong scores, no hang).
-__device__ __forceinline__ uint32_t mask_sel(uint64_t m, uint32_t t, uint32_t f) {  // per lane: m ? t : f (v_cndmask with the mask in SGPRs)
-  uint32_t d;
-  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(f), "v"(t), "s"(m));
-  return d;
-}
-__device__ __forceinline__ uint32_t lds_poll_u32(uint32_t a) {
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile DDT_LDS(uint32_t)*>(a));
-}
-
-template <int K, int L, int NS, int THREADS, bool SLOW>
-__device__ __forceinline__ void sparse_walk_qw(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc, uint64_t (&dbg)[4]) {
-  // NS sets of 8 streams: PU group g walks on the streams of set g % NS, every set with its own window of L groups -- 8 NS gathers in flight per
-  // lane from ONE resident image (the top pass is decoupled from the walks)
-  constexpr int U = 8, S = U * NS, TOPB = 8 << K, STEPB = U * TOPB, WAVES = THREADS / 64, PARTB = STEPB / WAVES;
-  static_assert(L >= 2 && L <= 4 && (NS == 1 || NS == 2), "window of 2..4 PU groups, one or two sets of streams");
-  static_assert(PARTB >= 2 * TOPB && PARTB % 1024 == 0, "a wave's quarter holds two trees' record 0 (A and its flag)");
-  constexpr uint32_t kA = 4u;  // tree 0, record 0, word 1
-  const GfSrc gs{};
-  const uint32_t lane_off = (uint32_t)tid * 4u, miss_key = a.miss_key, C = a.clusters, n_groups = x.n_groups;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const uint32_t my_flag = (uint32_t)(wave * PARTB + TOPB + 4);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(x.deep), 0, (int)x.deep_bytes, 0x00020000);
-  const uint32_t idle_off = x.idle_off;
-
-  auto dma_part = [&](uint32_t g) {  // this wave's quarter of image g
-    const uint4* src = a.img + (size_t)g * (STEPB / 16) + (size_t)wave * (PARTB / 16) + lane;
-#pragma unroll
-    for (int i = 0; i < PARTB / 1024; ++i) {
-      const uint32_t lds_addr = (uint32_t)(wave * PARTB + i * 1024);
-      const uint4* gp = src + i * 64;
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(gp) : "memory");
-    }
-  };
-  uint32_t slot[L][S];  // entry pointer (byte offset of a deep record) of a walk not yet started / leaf bits of a finished one
-  // top pass of the resident image into slot j of set `set`: K levels of 8-byte heap records, then the byte offset of the walker's level-K record
-  auto top_pass = [&](const int j, const int set) {
-    uint32_t m8[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) m8[u] = 8u;
-#pragma unroll
-    for (int lvl = 0; lvl < K; ++lvl) {
-      uint2 nd[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) nd[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
-      uint32_t f[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) f[u] = sp_feature<false, false>(nd[u].y, lane_off, gs);
-#pragma unroll
-      for (int u = 0; u < U; ++u) m8[u] = (m8[u] << 1) + (sp_right<SLOW, false>(f[u], nd[u].x, nd[u].y, miss_key) ? 8u : 0u);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) slot[j][set * U + u] = lds_u32((uint32_t)(u * TOPB)) + (m8[u] << 1);  // cbase + 16 * heap index at level K
-  };
-
-#pragma unroll
-  for (int j = 0; j < L; ++j)
-#pragma unroll
-    for (int u = 0; u < S; ++u) slot[j][u] = idle_off;
-  // ---- prologue: the first L * NS images behind block barriers (nothing is in flight yet); group g = slot g / NS of set g % NS ----
-  uint32_t nf[NS];  // filled slots of a set's window (wave-uniform)
-#pragma unroll
-  for (int t = 0; t < NS; ++t) nf[t] = 0u;
-  dma_part(0);
-#pragma unroll
-  for (int g = 0; g < L * NS; ++g) {
-    if ((uint32_t)g < n_groups) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      top_pass(g / NS, g % NS);
-      __syncthreads();
-      if ((uint32_t)g + 1u < n_groups) dma_part((uint32_t)g + 1u);
-      nf[g % NS] = (uint32_t)(g / NS) + 1u;
-    }
-  }
-  uint32_t gfill = n_groups < (uint32_t)(L * NS) ? n_groups : (uint32_t)(L * NS);  // next group to top-pass
-  uint32_t gdma = gfill;                  // the image this wave loads next (or is loading: `pending`)
-  bool pending = gdma < n_groups;         // my quarter of image gdma is in flight
-  uint32_t age = 0;                       // rounds issued since that DMA
-
-  // Lane state per stream: st = the slot it is at (0 .. L; L = past the window), `walking` = it has a live gather.  A lane at a FILLED slot is
-  // always walking it (it starts a walk in the step in which it finishes the one before, or in its first step after the slot is filled).
-  uint64_t walking[S];
-  uint32_t st[S];
-  u32x4 rr[S];
-#pragma unroll
-  for (int u = 0; u < S; ++u) {
-    st[u] = 0u;
-    walking[u] = nf[u / U] > 0u ? ~0ull : 0ull;
-    rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, slot[0][u], 0, 0);  // every lane starts on slot 0 (an unfilled slot holds idle_off)
-    __builtin_amdgcn_sched_barrier(0);  // in stream order, as in the loop: the wait the compiler puts in front of a visit is the loop's vmcnt(S - 1)
-  }
-  uint32_t folded = 0;
-  uint64_t any0[NS];  // lanes still at slot 0 on some stream of the set (as of the last round)
-#pragma unroll
-  for (int t = 0; t < NS; ++t) any0[t] = ~0ull;
-  const uint32_t guard_max = n_groups * 64u + 4096u;
-  for (uint32_t guard = 0; folded < n_groups && guard < guard_max; ++guard) {
-    dbg[0] = guard + 1u;
-    // ---- the image buffer's protocol (see above) ----
-    if (pending && age >= 1u) {
-      // only the last round's gathers may still fly: the older DMA has landed
-      if constexpr (S == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      if (lane == 0) *reinterpret_cast<volatile DDT_LDS(uint32_t)*>(my_flag) = gdma + 1u;
-      ++gdma;
-      pending = false;
-    }
-    if (!pending && gdma < n_groups && lds_poll_u32(kA) == (uint32_t)WAVES * gdma) {
-      dma_part(gdma);
-      pending = true;
-      age = 0;
-    }
-    // ---- windows: fold the oldest group when every lane has left it; top-pass the next group when its image is complete ----
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-      if (folded % (uint32_t)NS == (uint32_t)t && nf[t] > 0u && (nf[t] == (uint32_t)L || gfill >= n_groups) && any0[t] == 0ull) {
-        if (a.sum_mode == 1) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) dacc += (double)__uint_as_float(slot[0][t * U + u]);
-        } else {  // FPAddersReduceTree.sv:94-141, then the slot accumulate of this group's cluster
-          const float lf[1][8] = {{__uint_as_float(slot[0][t * U + 0]), __uint_as_float(slot[0][t * U + 1]), __uint_as_float(slot[0][t * U + 2]),
-                                   __uint_as_float(slot[0][t * U + 3]), __uint_as_float(slot[0][t * U + 4]), __uint_as_float(slot[0][t * U + 5]),
-                                   __uint_as_float(slot[0][t * U + 6]), __uint_as_float(slot[0][t * U + 7])}};
-          double unused[1] = {0.0};
-          fold_leaves<8, 1, 0>(lf, 0, C, ra, unused, a.sum_mode == 2);
-        }
-        any0[t] = 0ull;
-#pragma unroll
-        for (int u = t * U; u < (t + 1) * U; ++u) {
-#pragma unroll
-          for (int j = 0; j + 1 < L; ++j) slot[j][u] = slot[j + 1][u];
-          st[u] -= 1u;
-          any0[t] |= __ballot(st[u] == 0u);
-        }
-        --nf[t];
-        ++folded;
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-      if (gfill < n_groups && gfill % (uint32_t)NS == (uint32_t)t && nf[t] == (uint32_t)(L - 1)) {
-        bool ready = true;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) ready = ready && lds_poll_u32((uint32_t)(w * PARTB + TOPB + 4)) == gfill + 1u;
-        if (ready) {
-          top_pass(L - 1, t);
-          if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<DDT_LDS(uint32_t)*>(kA), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          nf[t] = (uint32_t)L;
-          ++gfill;
-        }
-      }
-    }
-    // ---- one round: every stream visits the record that has arrived and issues its next gather ----
-    uint64_t at0[NS];
-#pragma unroll
-    for (int t = 0; t < NS; ++t) at0[t] = 0ull;
-#pragma unroll
-    for (int u = 0; u < S; ++u) {
-      const uint32_t nfu = nf[u / U];
-      // the record stays opaque until its own visit (see the lock-step kernel)
-      asm volatile("" : "+v"(rr[u].x), "+v"(rr[u].y), "+v"(rr[u].z), "+v"(rr[u].w));
-      const uint32_t f = sp_feature<false, false>(rr[u].y, lane_off, gs);
-      const uint64_t rightm = __ballot(sp_right<SLOW, false>(f, rr[u].x, rr[u].y, miss_key));
-      const uint32_t lw = mask_sel(rightm, rr[u].y << 1, rr[u].y);  // kSpRightLeaf (bit 30) or kSpLeftLeaf (bit 31) into the sign bit
-      const uint64_t leafm = __ballot((int32_t)lw < 0);
-      const uint32_t nxt = mask_sel(rightm, rr[u].w, rr[u].z);
-      const uint64_t fin = walking[u] & leafm;  // walks that end with this visit: nxt is their leaf
-      uint64_t at[L];                           // lanes at slot j (before this step's moves)
-#pragma unroll
-      for (int j = 0; j < L; ++j) {
-        at[j] = __ballot(st[u] == (uint32_t)j);
-        slot[j][u] = mask_sel(fin & at[j], nxt, slot[j][u]);
-      }
-      // after the moves: lanes at slot j = (at[j] & ~fin) | (at[j-1] & fin)
-      uint64_t now[L];
-      now[0] = at[0] & ~fin;
-#pragma unroll
-      for (int j = 1; j < L; ++j) now[j] = (at[j] & ~fin) | (at[j - 1] & fin);
-      {
-        uint64_t co;
-        asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(st[u]), "=s"(co) : "v"(st[u]), "s"(fin));
-      }
-      at0[u / U] |= now[0];
-      walking[u] &= ~fin;
-      // lanes without a live gather whose slot is filled start its walk (slot >= 1: slot 0 was started before the loop / is never re-entered)
-      uint32_t np = slot[1][u];
-      uint64_t below = 0ull;
-#pragma unroll
-      for (int j = 1; j < L; ++j) {
-        if (j >= 2) np = mask_sel(now[j], slot[j][u], np);
-        below |= (uint32_t)j < nfu ? now[j] : 0ull;
-      }
-      const uint64_t can = below & ~walking[u];
-      const uint32_t addr = mask_sel(walking[u], nxt << 4, mask_sel(can, np, idle_off));
-      walking[u] |= can;
-      rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, addr, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int t = 0; t < NS; ++t) any0[t] = at0[t];
-    ++age;
-  }
-}
-
-template <int K, int L, int NS, int THREADS>
-__global__ __launch_bounds__(THREADS, 2) void score_sparse_qw_kernel(const ScoreArgs a, const SparseAux x) {
-  constexpr int TOPB = 8 << K, STEPB = 8 * TOPB, ROW = THREADS * 4;
-  constexpr int FEAT_OFF = (STEPB + ROW - 1) / ROW * ROW;
-  const int tid = threadIdx.x;
-  const uint64_t tile0 = (uint64_t)blockIdx.x * THREADS;
-  const uint32_t miss_any = sparse_stage_tile<THREADS, FEAT_OFF, ROW>(a, tile0, tid);
-  const bool slow = block_any<THREADS>(miss_any, 0u, tid);  // (its barrier publishes the tile; the flags use offset 0 before the first image)
-  __syncthreads();                                           // every wave has read the flags: the image may land on them
-  RefAcc<1> ra;
-  ra.init();
-  double dacc = 0.0;
-  const uint32_t C = a.clusters;
-  uint64_t dbg[4] = {0, 0, 0, 0};
-  if (!slow) sparse_walk_qw<K, L, NS, THREADS, false>(a, x, tid, ra, dacc, dbg);
-  else sparse_walk_qw<K, L, NS, THREADS, true>(a, x, tid, ra, dacc, dbg);
-  ra.align(C);
-  const uint64_t row = tile0 + (uint64_t)tid;
-  if (row < a.n) a.out[row] = x.debug ? (float)dbg[(x.debug - 1u) & 3u] : (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
-}
-
-template <int K, int L, int NS, int THREADS>
-static hipError_t launch_sparse_qw(const ScoreArgs& a, const Variant& v, hipStream_t s) {
-  const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
-  const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_qw_kernel<K, L, NS, THREADS>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
-  if (blocks == 0) return hipSuccess;
-  if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
-  hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(THREADS), lds, s, a, x);
-  return hipGetLastError();
-}
-
 #define DDT_SP(K, U, T) \
   Variant { "sparse_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 0, &launch_sparse_v<K, U, T, false> }
 #define DDT_SPD(K, U, T) /* dense level K: 8-byte records only in LDS (8 * 2^K bytes per tree) */ \
   Variant { "sparse_dk_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2, &launch_sparse_v<K, U, T, false, true> }
 #define DDT_SPM(M, K, U, T) /* dense level K+M behind M dense levels of 8-byte records (opt bit 3; Variant::top = M) */ \
   Variant { "sparse_dm" #M "_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2 | 8, &launch_sparse_v<K, U, T, false, true, false, M>, M }
-#define DDT_SPW(L, K, T) /* queued walkers over a window of L PU groups (opt bit 4; Variant::top = L), dense level K */ \
-  Variant { "sparse_qw" #L "_k" #K "_u8_t" #T, kKindSparse, K, T, 1, 8, 8, 1, 2 | 16, &launch_sparse_qw<K, L, 1, T>, L }
-#define DDT_SPW2(L, K, T) /* ... two sets of 8 streams: 16 gathers in flight per lane */ \
-  Variant { "sparse_qx" #L "_k" #K "_u8_t" #T, kKindSparse, K, T, 1, 8, 8, 1, 2 | 16, &launch_sparse_qw<K, L, 2, T>, L }
 #define DDT_SPQD(K, U) /* rank-quantised + dense level K */ \
   Variant { "sparse_qd_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 3, &launch_sparse_v<K, U, 1024, true, true> }
 #define DDT_SPG(K, U, T) /* global features: no tile in LDS, any tuple width */ \
@@ -628,8 +366,6 @@ static const Variant g_sparse_variants[] = {
     // (BASELINE config 4, one box, alternating: M = 0 / 1 / 2 / 3 -> 265-270 / 275 / 271-272 / 214-227 Mtuples/s, profiles/r05_pmc_cfg2_cfg4_cfg6.md:
     // one mid level pays a little, three lose a fifth -- the padding under the early leaves of level 10 turns finished walkers into live gathers)
     DDT_SPM(1, 8, 8, 256), DDT_SPM(2, 8, 8, 256), DDT_SPM(1, 7, 8, 256), DDT_SPM(1, 8, 8, 128), DDT_SPM(1, 7, 8, 128),
-    // queued walkers (round 5): lanes run ahead of their wave inside a window of L PU groups
-    DDT_SPW(2, 8, 256), DDT_SPW(3, 8, 256), DDT_SPW2(2, 8, 256), DDT_SPW2(3, 8, 256),
     // tuples too wide for any feature tile (more than ~540 words): every feature is gathered from the tuple's row in global memory.
     // The correctness path of the sparse format, like the generic kernel of the perfect-tree format -- not a tuned kernel.
     DDT_SPG(6, 8, 256),

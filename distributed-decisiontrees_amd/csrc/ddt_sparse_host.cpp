@@ -173,14 +173,6 @@ int sparse_rebuild(ddt_engine* e) {
       }
     }
   }
-  // Queued walkers (option "sparse_qw": 0 never, L = a window of L PU groups): the dense-level-K choice (with or without mid levels) has a
-  // "sparse_qw<L>_*" sibling of the same geometry -- same LDS, lanes run ahead of their wave (ddt_sparse.hip)
-  if (vid >= 0 && e->forced_variant < 0 && e->sparse_qw > 0 && (variant(vid).opt & 2) && !(variant(vid).opt & (1 | 4 | 16))) {
-    char name[48];
-    snprintf(name, sizeof(name), "sparse_qw%d_k%d_u8_t%d", e->sparse_qw, variant(vid).levels, variant(vid).threads);
-    const int vq = find_variant(name);
-    if (vq >= 0 && variant(vq).lds_bytes_sparse(tuple_words(e->p)) <= variant(vid).lds_bytes_sparse(tuple_words(e->p))) vid = vq;
-  }
   if (vid < 0)
     return fail(e, DDT_EUNSUPPORTED, "no sparse kernel fits: %u tuple words need more than %u bytes of LDS (or the forced variant %d / "
                 "sparse_top_levels %d is not a sparse kernel that fits)", tuple_words(e->p), kMaxLdsBytes, e->forced_variant, e->sparse_top_levels);
@@ -266,10 +258,6 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
   for (uint32_t i = 0; i < groups * 8u; ++i) {
     uint32_t* t = top.data() + (size_t)i * top_words;
     uint32_t* last = t + (4u << K) / 4u;  // 16-byte records of level K-1 (not dense level K)
-    // queued-walker kernels ("sparse_qw<L>_*", opt bit 4): the spare second word of heap record 0 of a group's FIRST tree carries (waves per block) * group --
-    // the value the block's "waves that have read the resident image" counter has when this image is loaded over it (ddt_sparse.hip); the
-    // other trees' spare words stay 0 (the waves' "my quarter has landed" flags)
-    if ((v.opt & 16) && i % 8u == 0u) t[1] = (uint32_t)(v.threads / 64) * (i / 8u);
     if (i >= T) {  // EMPTY slot: contributes exactly +0 (DTPU.sv:544,760)
       for (uint32_t m = 1; m < (1u << lvl8); ++m) put8(t, m, 0u, feat_word(0));
       if (dk) t[0] = cbase_of(0);  // the shared dummy block
@@ -445,7 +433,6 @@ int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, f
   x.deep = reinterpret_cast<const uint4*>(sp.d_deep);
   x.n_groups = sp.groups;
   x.deep_bytes = (uint32_t)std::min<uint64_t>(sp.deep_bytes, 0xFFFFFFFFull);
-  x.debug = getenv("DDT_QW_DEBUG") ? (uint32_t)atoi(getenv("DDT_QW_DEBUG")) : 0u;
   x.idle_off = e->sparse_idle_oob ? 0xFFFFFFF0u : 0u;  // (the packers keep the deep array below 2^28 records, i.e. deep_bytes <= 0xFFFFFFF0: that offset is always out of range)
   if (v.opt & 1) {  // rank-quantised: the batch's ranks + per-tile missing flags come from the q16 pre-pass (workspace slot e->q_slot)
     int rc = ensure_q16_workspace(e, n);

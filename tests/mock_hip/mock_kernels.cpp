@@ -337,9 +337,6 @@ const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
     Variant{"sparse_dm1_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 8, &launch_sparse, 1},
     Variant{"sparse_dm2_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 8, &launch_sparse, 2},
     Variant{"sparse_dk_k9_u8_t512", kKindSparse, 9, 512, 1, 8, 8, 1, 2, &launch_sparse},
-    // queued walkers (opt bit 4): the images of the dense-level-K kernels + the protocol words in the spare word of heap record 0, which no walk reads
-    Variant{"sparse_qw2_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 16, &launch_sparse, 2},
-    Variant{"sparse_qw3_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 16, &launch_sparse, 3},
     Variant{"sparse_qd_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3, &launch_sparse},
     Variant{"sparse_gf_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 4, &launch_sparse},
 };

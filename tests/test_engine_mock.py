@@ -866,32 +866,6 @@ def test_a_pu_group_beyond_the_u16_ranks_falls_back_and_says_so(mock):
     mock.ddt_destroy(e)
 
 
-@pytest.mark.parametrize("qw,dm,name", [(3, -1, "sparse_qw3_k8_u8_t256"), (2, 0, "sparse_qw2_k8_u8_t256"), (0, 0, "sparse_dk_k8_u8_t256"), (4, -1, "sparse_dm1_k8_u8_t256")])
-def test_sparse_forests_on_the_queued_walker_kernels(mock, qw, dm, name):
-    """Round 5: option sparse_qw = L moves the dense-level-K choice (with or without mid levels) to its queued-walker sibling when one of that
-    window exists (this model's table has L = 2, 3; L = 4 keeps the choice): the image is the dense-level-K image plus the protocol words,
-    which no walk reads -- scores against the oracle; the option's range."""
-    mock.mock_reset(2, 7, 8)
-    T, depth, F = 20, 14, 64
-    sp = O.gen_sparse_model(T, depth, F, 10, 700, 1)
-    n = 600
-    x = O.gen_tuples(0, n, F, 1)
-    x[::9, 3] = sp.params.missing_bits
-    want = O.score_sparse(sp, x)
-    p = ddt.make_sparse_params(T, depth, F)
-    mock.ddt_load_model_sparse.argtypes = [vp, C.POINTER(ddt.Params), vp, C.c_size_t, vp, C.c_uint32, C.c_uint32]
-    e, info = _engine(mock), ddt.Info()
-    assert mock.ddt_set_option(e, b"sparse_qw", 1) < 0 and mock.ddt_set_option(e, b"sparse_qw", 5) < 0
-    assert mock.ddt_set_option(e, b"sparse_qw", qw) == 0 and mock.ddt_set_option(e, b"sparse_dm", dm) == 0 and mock.ddt_set_option(e, b"sparse_q16", 0) == 0
-    lines, first = np.ascontiguousarray(sp.node_lines, np.uint32), np.ascontiguousarray(sp.first, np.uint64)
-    assert mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, 0, 1) == 0, mock.ddt_last_error(e)
-    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == name, info.variant_name
-    o = np.full(n, np.nan, np.float32)
-    assert mock.ddt_score_device(e, x.ctypes.data, n, o.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
-    assert np.array_equal(_bits(o), _bits(want))
-    mock.ddt_destroy(e)
-
-
 @pytest.mark.parametrize("T,depth,F,full,pm,dm,name", [(20, 14, 64, 10, 700, -1, "sparse_dm1_k8_u8_t256"), (20, 14, 64, 9, 400, -1, "sparse_dm1_k8_u8_t256"),
                                                        (20, 14, 64, 8, 300, -1, "sparse_dk_k8_u8_t256"), (20, 14, 64, 10, 700, 2, "sparse_dm2_k8_u8_t256"),
                                                        (20, 14, 64, 10, 700, 0, "sparse_dk_k8_u8_t256"), (12, 9, 64, 3, 500, 2, "sparse_dm2_k8_u8_t256")])

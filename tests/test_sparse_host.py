@@ -99,18 +99,16 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
     seen_k = set()
     tables = _rank_tables(s)
     for vid, name in _sparse_variants():
-        ranked, dense = name.startswith(("sparse_q_", "sparse_qd_")), name.startswith(("sparse_dk_", "sparse_qd_", "sparse_dm", "sparse_qw"))
+        ranked, dense = name.startswith(("sparse_q_", "sparse_qd_")), name.startswith(("sparse_dk_", "sparse_qd_", "sparse_dm"))
         mid = int(re.match(r"sparse_dm(\d)_", name).group(1)) if name.startswith("sparse_dm") else 0
         K = int(re.search(r"_k(\d+)_", name).group(1))
         gf = name.startswith("sparse_gf_")   # features gathered from global memory: the address field is the byte offset in the tuple's row
-        qw = name.startswith("sparse_qw")  # queued walkers: the dense-level-K image + the image-buffer protocol's words
-        if (ranked, dense, K, gf, mid, qw) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
+        if (ranked, dense, K, gf, mid) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
             continue
-        seen_k.add((ranked, dense, K, gf, mid, qw))
+        seen_k.add((ranked, dense, K, gf, mid))
         top, deep, info = _images(s, vid, order)
-        if dense and not ranked:  # the spare second word of heap record 0: 4 * group in a group's first tree for the queued walkers (ddt_sparse.hip), else 0
-            spare = top.reshape(info[2] * 8, -1)[:, 1]
-            assert np.array_equal(spare, np.where(np.arange(spare.size) % 8 == 0, np.arange(spare.size) // 8 * 4, 0) if qw else np.zeros_like(spare)), name
+        if dense and not ranked:  # the second word of heap record 0 is spare (0): no kernel reads it
+            assert not top.reshape(info[2] * 8, -1)[:, 1].any(), name
         assert info[3] == K and info[2] * 8 >= T and top.size == info[2] * 8 * ((8 if dense else 12) << K) // 4
         assert info[5] == (4 if gf else 2048 if ranked else 4 * int(name.rsplit("_t", 1)[1]))  # u16 rows of 1024 tuples / fp32 rows of the tile
         assert not gf or info[4] == 0
@@ -120,7 +118,7 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
                 want = O.traverse_sparse(s, x[r], i) if i < T else 0
                 assert got == want, (name, order, r, i, hex(got), hex(want))
     assert len([k for k in seen_k if not k[0] and not k[1]]) >= 4 and len([k for k in seen_k if k[0]]) >= 4 and len([k for k in seen_k if k[1]]) >= 4
-    assert any(k[3] for k in seen_k) and {k[4] for k in seen_k} >= {0, 1, 2} and any(k[5] for k in seen_k)
+    assert any(k[3] for k in seen_k) and {k[4] for k in seen_k} >= {0, 1, 2}
 
 
 def test_hook_rejects_what_the_loader_rejects():
