@@ -1912,6 +1912,10 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     }
     return DDT_OK;
   }
+  if (!strcmp(key, "sparse_peel_last")) {  // A/B: 0 = every round of the sparse kernels' deep loop issues its gathers, the one after the deepest level too (as before round 5); effective at the next call
+    e->sparse_peel_last = value != 0;
+    return DDT_OK;
+  }
   if (!strcmp(key, "sparse_idle_oob")) {  // A/B: 0 = finished walkers of the sparse kernels re-read record 0 (as before round 5); effective at the next call
     e->sparse_idle_oob = value != 0;
     return DDT_OK;

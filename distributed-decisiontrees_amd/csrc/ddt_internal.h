@@ -139,6 +139,8 @@ struct SparseAux {           // ScoreArgs::aux of the sparse kernels
   const uint4* deep;         // deep records (at least one, record 0 is a valid dummy)
   uint32_t n_groups;         // PU groups of 8 trees in the top image
   uint32_t deep_bytes;       // bytes of the deep array: the range of the buffer resource its records are gathered through
+  uint32_t max_rounds;       // visits of the deep loop after which every walker is at a leaf (>= 1; from the forest's deepest path and the kernel's K / M):
+                             // the last of them issues no gather (round 5)
   uint32_t idle_off;         // byte offset a FINISHED lane's (unconditional) gather uses: 0 = record 0 (rounds 2-4), 0xFFFFFFF0 = beyond the
                              // resource's range -- the lane gets 0 back and no cache access is made (round 5, option "sparse_idle_oob")
   // rank-quantised sparse kernels ("sparse_q_*", Variant::opt bit 0): thresholds are ranks, the features arrive as the u16 tiles

@@ -80,6 +80,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
   const uint32_t miss_key = a.miss_key, C = a.clusters;
   const uint4* __restrict__ deep = x.deep;
   const uint32_t n_steps = x.n_groups * 8u / (uint32_t)U;  // the host pads the image to whole passes
+  const uint32_t max_rounds = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.max_rounds);
   for (uint32_t g = 0; g < n_steps; ++g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the top images of this pass (and, first pass, the feature tile) are in LDS for everyone
@@ -175,25 +176,53 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
         }
       }
     }
-    for (;;) {
-      bool any = false;
+    // Rounds: every walker is at a leaf after x.max_rounds visits of this loop (the host knows the forest's deepest path), so the LAST possible
+    // round needs no gather behind its visits -- until round 5 it issued one per tree all the same (nine instead of eight per tree and wave on
+    // BASELINE config 4, each ~30 cycles of the vector-memory pipe: the unit this kernel is bound by).
+    bool alive = true;  // some lane of the wave is still walking
+    if (max_rounds > 1u) {
+      uint32_t r = 1u;
+      do {  // (one exit: with a counted exit beside the ballot's the structurizer copies the eight lane masks round every back edge)
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          // the record stays opaque until its own visit: otherwise pieces of later visits are hoisted in front of the earlier gathers
+          // and the first wait of a round covers half the queue
+          asm volatile("" : "+v"(rr[u].x), "+v"(rr[u].y), "+v"(rr[u].z), "+v"(rr[u].w));
+          const uint32_t f = sp_feature<Q, GF>(rr[u].y, lane_off, gs);
+          const bool right = sp_right<SLOW, Q>(f, rr[u].x, rr[u].y, miss_key);
+          const uint32_t lw = right ? (rr[u].y << 1) : rr[u].y;  // kSpRightLeaf (bit 30) or kSpLeftLeaf (bit 31) into the sign bit
+          const bool leaf = (int32_t)lw < 0;
+          const uint32_t nxt = right ? rr[u].w : rr[u].z;
+          if (act[u] && leaf) leafv[u] = __uint_as_float(nxt);
+          act[u] = act[u] && !leaf;
+          any = any || act[u];
+          rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, act[u] ? (nxt << 4) : idle_off, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);  // or the scheduler collects the loads at the end of the round again
+        }
+        alive = __ballot(any) != 0ull;
+      } while (alive && ++r < max_rounds);
+    }
+    if (!alive) {
+      // the wave left early with its last round's (idle) gathers in flight: consume them here, so that both exits reach the next pass with
+      // nothing outstanding in the compiler's books
+#pragma unroll
+      for (int u = 0; u < U; ++u) asm volatile("" : : "v"(rr[u].x), "v"(rr[u].y), "v"(rr[u].z), "v"(rr[u].w));
+    }
+    if (alive) {
+      // the last round: visits only.  A walker that is still alive stands on a record whose taken side is a leaf; a finished one has the zeros
+      // its out-of-range gather returned (no leaf flag) -- so the visit needs no `act` (a lane mask that is live out of the loop above costs
+      // three scalar instructions per tree and round on its back edge).  The host grants this round only with sparse_idle_oob on.
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        // the record stays opaque until its own visit: otherwise pieces of later visits are hoisted in front of the earlier gathers
-        // and the first wait of a round covers half the queue
         asm volatile("" : "+v"(rr[u].x), "+v"(rr[u].y), "+v"(rr[u].z), "+v"(rr[u].w));
         const uint32_t f = sp_feature<Q, GF>(rr[u].y, lane_off, gs);
         const bool right = sp_right<SLOW, Q>(f, rr[u].x, rr[u].y, miss_key);
-        const uint32_t lw = right ? (rr[u].y << 1) : rr[u].y;  // kSpRightLeaf (bit 30) or kSpLeftLeaf (bit 31) into the sign bit
-        const bool leaf = (int32_t)lw < 0;
+        const uint32_t lw = right ? (rr[u].y << 1) : rr[u].y;
         const uint32_t nxt = right ? rr[u].w : rr[u].z;
-        if (act[u] && leaf) leafv[u] = __uint_as_float(nxt);
-        act[u] = act[u] && !leaf;
-        any = any || act[u];
-        rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, act[u] ? (nxt << 4) : idle_off, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);  // or the scheduler collects the loads at the end of the round again
+        if ((int32_t)lw < 0) leafv[u] = __uint_as_float(nxt);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (__ballot(any) == 0ull) break;
     }
 
 #pragma unroll

@@ -433,6 +433,12 @@ int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, f
   x.deep = reinterpret_cast<const uint4*>(sp.d_deep);
   x.n_groups = sp.groups;
   x.deep_bytes = (uint32_t)std::min<uint64_t>(sp.deep_bytes, 0xFFFFFFFFull);
+  {  // visits of the kernel's deep loop on the forest's longest path: levels K-1 .. max_depth-1 (16-byte level K-1 records in LDS), K+M .. max_depth-1
+     // (dense level K behind M dense mid levels); a shallower forest still consumes the one (dummy) record every walker fetches
+    const uint32_t first_lvl = (v.opt & 2) ? (uint32_t)v.levels + ((v.opt & 8) ? (uint32_t)v.top : 0u) : (uint32_t)v.levels - 1u;
+    x.max_rounds = !(e->sparse_peel_last && e->sparse_idle_oob) ? 0xFFFFFFFFu :  // (the visit-only round tells a finished walker by the zeros of its out-of-range gather)
+                    sp.max_depth > first_lvl ? sp.max_depth - first_lvl : 1u;
+  }
   x.idle_off = e->sparse_idle_oob ? 0xFFFFFFF0u : 0u;  // (the packers keep the deep array below 2^28 records, i.e. deep_bytes <= 0xFFFFFFF0: that offset is always out of range)
   if (v.opt & 1) {  // rank-quantised: the batch's ranks + per-tile missing flags come from the q16 pre-pass (workspace slot e->q_slot)
     int rc = ensure_q16_workspace(e, n);
