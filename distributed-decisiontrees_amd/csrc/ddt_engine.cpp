@@ -1869,6 +1869,11 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     }
     return DDT_OK;
   }
+  if (!strcmp(key, "sparse_dp")) {  // dense pair records (ddt_sparse_host.cpp sparse_rebuild): -1 automatic, 0 never, 1 always; effective at the next sparse load
+    if (value < -1 || value > 1) return fail(e, DDT_EINVAL, "sparse_dp must be -1, 0 or 1");
+    e->sparse_dp = (int)value;
+    return DDT_OK;
+  }
   if (!strcmp(key, "sparse_dm")) {  // dense mid levels (ddt_sparse_host.cpp sparse_rebuild): -1 automatic, 0 never, 1..3 exactly; effective at the next sparse load
     if (value < -1 || value > 3) return fail(e, DDT_EINVAL, "sparse_dm must be -1..3");  // (-1: one mid level where the forest fills it)
     e->sparse_dm = (int)value;

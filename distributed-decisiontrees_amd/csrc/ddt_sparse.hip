@@ -70,9 +70,10 @@ __device__ __forceinline__ uint32_t sp_feature(uint32_t w, uint32_t lane_off, co
 // (profiles/r05_pmc_cfg2_cfg4_cfg6.md) put the kernel's bound at the L2's service of L1 misses -- 1.03 misses per tree and tuple, most of
 // them on the levels right below the top image, whose 16-byte records (96 KiB per PU group for levels 8-9) overflow a CU's 32 KiB L1.  Half
 // the bytes per hot record = twice the records per line and per L1.
-template <int K, int U, int THREADS, bool SLOW, bool Q, bool DK, bool GF = false, int M = 0>
+template <int K, int U, int THREADS, bool SLOW, bool Q, bool DK, bool GF = false, int M = 0, bool PR = false>
 __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc, const GfSrc& gs) {
   static_assert(M == 0 || DK, "dense mid levels extend the dense level K");
+  static_assert(!PR || (DK && M == 0 && !Q && !GF), "pair records: fp32 tile, dense levels K and K + 1");
   constexpr int TOPB = (DK ? 8 : 12) << K;
   constexpr int STEPB = U * TOPB;  // U trees per pass: one PU group (or two)
   // Q: the u16 tile of the q16 pre-pass -- tuples t and t + 512 of a tile share a dword (rank_kernel)
@@ -110,7 +111,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
     for (int u = 0; u < U; ++u) {
       if (DK) {
         r8[u] = lds_u2(m8[u] + (uint32_t)(u * TOPB));
-        if (M == 0) cb[u] = lds_u32((uint32_t)(u * TOPB)) + (m8[u] << 2);  // byte offset of the LEFT child's record
+        if (M == 0 && !PR) cb[u] = lds_u32((uint32_t)(u * TOPB)) + (m8[u] << 2);  // byte offset of the LEFT child's record
         else cb[u] = lds_u32((uint32_t)(u * TOPB));                        // dense mid levels: cbase itself (8-byte records at cbase + 8 h)
       } else {
         r[u] = lds_u4((m8[u] << 1) - (uint32_t)(4 << K) + (uint32_t)(u * TOPB));
@@ -141,7 +142,7 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
       leafv[u] = 0.f;
       if (!DK) rr[u] = u32x4{r[u].x, r[u].y, r[u].z, r[u].w};
     }
-    if constexpr (DK && M == 0) {  // first round: level K-1 out of the registers, every walker goes on to its level-K record
+    if constexpr (DK && M == 0 && !PR) {  // first round: level K-1 out of the registers, every walker goes on to its level-K record
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t f = sp_feature<Q, GF>(r8[u].y, lane_off, gs);
@@ -174,6 +175,39 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
           else rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m8[u] << 1) - (uint32_t)(8u << (K + M)), 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
+      }
+    }
+    if constexpr (PR) {
+      // "sparse_dp_*" (dense PAIR records, round 5): the levels K and K + 1 of a tree are one block of 2^K 16-byte records {key of the level-K
+      // node, keys of its two children, feature numbers of the three as bytes + their missing directions}: ONE gather decides two levels (the
+      // dense-mid form takes one per level), the next record is the walker's node in the dense block of level K + 2, by heap index.  The
+      // feature number, not its LDS address, is in the record (three of them share a word): address = tile base + number * ROW.
+      constexpr uint32_t ROWB = (uint32_t)THREADS * 4u;
+      const uint32_t fbase = (uint32_t)(((U * TOPB + ROWB - 1) / ROWB) * ROWB) + lane_off;  // FEAT_OFF + the lane's column
+      u32x4 pr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t f = sp_feature<Q, GF>(r8[u].y, lane_off, gs);
+        const bool right = sp_right<SLOW, Q>(f, r8[u].x, r8[u].y, miss_key);
+        m8[u] = (m8[u] << 1) + (right ? 8u : 0u);  // 8 * heap index at level K
+        pr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m8[u] << 1), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        asm volatile("" : "+v"(pr[u].x), "+v"(pr[u].y), "+v"(pr[u].z), "+v"(pr[u].w));
+        const uint32_t w = pr[u].w;
+        const uint32_t fa = lds_u32(((w & 0xFFu) * ROWB) + fbase);
+        bool r0 = (int32_t)fa >= (int32_t)pr[u].x;
+        if (SLOW) r0 = (fa == miss_key) ? ((w >> 24) & 1u) != 0u : r0;
+        const uint32_t kc = r0 ? pr[u].z : pr[u].y;
+        const uint32_t jc = (r0 ? (w >> 16) : (w >> 8)) & 0xFFu;
+        const uint32_t fc = lds_u32((jc * ROWB) + fbase);
+        bool r1 = (int32_t)fc >= (int32_t)kc;
+        if (SLOW) r1 = (fc == miss_key) ? ((w >> (r0 ? 26 : 25)) & 1u) != 0u : r1;
+        m8[u] = (m8[u] << 2) + (r0 ? 16u : 0u) + (r1 ? 8u : 0u);  // 8 * heap index at level K + 2
+        rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m8[u] << 1) - (uint32_t)(32u << K), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // Rounds: every walker is at a leaf after x.max_rounds visits of this loop (the host knows the forest's deepest path), so the LAST possible
@@ -279,7 +313,7 @@ __device__ __forceinline__ uint32_t sparse_stage_tile(const ScoreArgs& a, const 
   return miss_any;
 }
 
-template <int K, int U, int THREADS, bool Q, bool DK, bool GF = false, int M = 0>
+template <int K, int U, int THREADS, bool Q, bool DK, bool GF = false, int M = 0, bool PR = false>
 __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a, const SparseAux x) {
   static_assert(!GF || (!Q && !DK), "global-feature fallback: fp32 keys, 16-byte level K-1 records");
   constexpr int TOPB = (DK ? 8 : 12) << K;  // bytes of one tree's top image
@@ -335,18 +369,18 @@ __global__ __launch_bounds__(THREADS) void score_sparse_kernel(const ScoreArgs a
   double dacc = 0.0;
   const uint32_t C = a.clusters;
   if constexpr (GF) sparse_walk<K, U, THREADS, true, Q, DK, true>(a, x, tid, ra, dacc, gs);
-  else if (!slow) sparse_walk<K, U, THREADS, false, Q, DK, false, M>(a, x, tid, ra, dacc, gs);
-  else sparse_walk<K, U, THREADS, true, Q, DK, false, M>(a, x, tid, ra, dacc, gs);
+  else if (!slow) sparse_walk<K, U, THREADS, false, Q, DK, false, M, PR>(a, x, tid, ra, dacc, gs);
+  else sparse_walk<K, U, THREADS, true, Q, DK, false, M, PR>(a, x, tid, ra, dacc, gs);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
 }
 
-template <int K, int U, int THREADS, bool Q, bool DK = false, bool GF = false, int M = 0>
+template <int K, int U, int THREADS, bool Q, bool DK = false, bool GF = false, int M = 0, bool PR = false>
 static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_kernel<K, U, THREADS, Q, DK, GF, M>;
+  auto kern = score_sparse_kernel<K, U, THREADS, Q, DK, GF, M, PR>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
@@ -367,6 +401,8 @@ static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStrea
   Variant { "sparse_dk_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2, &launch_sparse_v<K, U, T, false, true> }
 #define DDT_SPM(M, K, U, T) /* dense level K+M behind M dense levels of 8-byte records (opt bit 3; Variant::top = M) */ \
   Variant { "sparse_dm" #M "_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2 | 8, &launch_sparse_v<K, U, T, false, true, false, M>, M }
+#define DDT_SPP(K, U, T) /* dense pair records for the levels K and K+1, dense level K+2 (opt bit 4; Variant::top = 2; at most 256 features) */ \
+  Variant { "sparse_dp_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2 | 16, &launch_sparse_v<K, U, T, false, true, false, 0, true>, 2 }
 #define DDT_SPQD(K, U) /* rank-quantised + dense level K */ \
   Variant { "sparse_qd_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 3, &launch_sparse_v<K, U, 1024, true, true> }
 #define DDT_SPG(K, U, T) /* global features: no tile in LDS, any tuple width */ \
@@ -395,6 +431,8 @@ static const Variant g_sparse_variants[] = {
     // (BASELINE config 4, one box, alternating: M = 0 / 1 / 2 / 3 -> 265-270 / 275 / 271-272 / 214-227 Mtuples/s, profiles/r05_pmc_cfg2_cfg4_cfg6.md:
     // one mid level pays a little, three lose a fifth -- the padding under the early leaves of level 10 turns finished walkers into live gathers)
     DDT_SPM(1, 8, 8, 256), DDT_SPM(2, 8, 8, 256), DDT_SPM(1, 7, 8, 256), DDT_SPM(1, 8, 8, 128), DDT_SPM(1, 7, 8, 128),
+    // dense pair records (round 5): two levels per gather below the top image, for forests that fill the levels K .. K+2
+    DDT_SPP(7, 8, 256), DDT_SPP(8, 8, 256), DDT_SPP(9, 8, 256), DDT_SPP(10, 8, 256),
     // tuples too wide for any feature tile (more than ~540 words): every feature is gathered from the tuple's row in global memory.
     // The correctness path of the sparse format, like the generic kernel of the perfect-tree format -- not a tuned kernel.
     DDT_SPG(6, 8, 256),

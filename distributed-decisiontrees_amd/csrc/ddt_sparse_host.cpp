@@ -31,6 +31,7 @@ int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {
   const uint32_t W = tuple_words(e->p);
   auto fits = [&](int vid, uint32_t budget) {
     if (vid < 0 || variant(vid).kind != kKindSparse || variant(vid).lds_bytes_sparse(W) > budget) return false;
+    if ((variant(vid).opt & 16) && e->p.num_features > 256u) return false;  // pair records carry feature numbers as bytes
     return !(variant(vid).opt & 1) || ranks_fit;  // rank-quantised kernels: every feature's table must fit 16-bit ranks
   };
   if (e->forced_variant >= 0) return fits(e->forced_variant, kMaxLdsBytes) ? e->forced_variant : -1;
@@ -139,7 +140,7 @@ int sparse_rebuild(ddt_engine* e) {
   // Dense mid levels (option "sparse_dm": -1 automatic, 0 never, M = exactly M): where the choice is a dense-level-K kernel that has
   // "sparse_dm<M>_*" siblings, the levels K .. K+M-1 become 8-byte heap records when the forest fills them at least half (the padding
   // under early leaves doubles per level).  Automatic = one mid level; more only when asked for (A/B)
-  if (vid >= 0 && e->forced_variant < 0 && e->sparse_dm != 0 && (variant(vid).opt & 2) && !(variant(vid).opt & (1 | 4 | 8))) {
+  if (vid >= 0 && e->forced_variant < 0 && (e->sparse_dm != 0 || e->sparse_dp != 0) && (variant(vid).opt & 2) && !(variant(vid).opt & (1 | 4 | 8 | 16))) {
     const Variant& dkv = variant(vid);
     const uint32_t K = (uint32_t)dkv.levels;
     std::vector<double> nodes(K + 4u, 0.0);  // internal nodes per level K .. K+3 over all forests
@@ -160,7 +161,22 @@ int sparse_rebuild(ddt_engine* e) {
         }
       }
     }
-    for (int M = 3; M >= 1; --M) {
+    // Dense pair records (option "sparse_dp": -1 automatic, 0 never, 1 always where such a kernel exists): one gather for the levels K and K+1 and
+    // a dense block at level K+2 -- when the forest fills all three at least half (the padding under early leaves turns finished walkers into
+    // live gathers) and its feature numbers fit a byte
+    bool took_pairs = false;
+    if (e->sparse_dp != 0 && e->sparse_dm <= 0 && e->p.num_features <= 256u) {
+      bool full = trees > 0.0;
+      for (uint32_t lvl = K; lvl < K + 3u; ++lvl) full = full && nodes[lvl] >= 0.5 * trees * (double)(1u << lvl);
+      char name[48];
+      snprintf(name, sizeof(name), "sparse_dp_k%u_u8_t%d", K, dkv.threads);
+      const int vp = find_variant(name);
+      if ((full || e->sparse_dp > 0) && vp >= 0 && variant(vp).lds_bytes_sparse(tuple_words(e->p)) <= dkv.lds_bytes_sparse(tuple_words(e->p))) {
+        vid = vp;
+        took_pairs = true;
+      }
+    }
+    for (int M = 3; M >= 1 && !took_pairs && e->sparse_dm != 0; --M) {
       if (e->sparse_dm > 0 ? M != e->sparse_dm : M > 1) continue;  // automatic: ONE mid level (measured: +2-4 %; two +1 %, three -17 %)
       bool full = trees > 0.0;
       for (uint32_t lvl = K; lvl < K + (uint32_t)M; ++lvl) full = full && nodes[lvl] >= 0.5 * trees * (double)(1u << lvl);
@@ -206,10 +222,14 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
   const bool dk = (v.opt & 2) != 0;  // dense level K: all K levels as 8-byte records in LDS, level K a dense block of deep records
   // dense MID levels ("sparse_dm<M>_*", opt bit 3): the levels K .. K+M-1 continue the heap as 8-byte records in the deep array (record of heap
   // node h at byte cbase + 8 h), the dense block of 16-byte records is level K+M (ddt_sparse.hip sparse_walk)
-  const uint32_t M = (dk && (v.opt & 8)) ? (uint32_t)v.top : 0u, KD = K + M;  // KD = the level of the dense 16-byte block
+  // dense PAIR records ("sparse_dp_*", opt bit 4): the levels K and K+1 as ONE block of 2^K 16-byte records {key of the level-K node, keys of its
+  // two children, their feature numbers as bytes + missing directions in the top byte} at byte cbase + 16 h (h = level-K heap index); the dense
+  // block of ordinary records is level K+2
+  const bool pairs = dk && (v.opt & 16) != 0;
+  const uint32_t M = pairs ? 2u : (dk && (v.opt & 8)) ? (uint32_t)v.top : 0u, KD = K + M;  // KD = the level of the dense 16-byte block
   const uint32_t top_words = v.top_bytes_sparse() / 4u;  // per tree
   const uint32_t lvl8 = dk ? K : K - 1u;                 // levels stored as 8-byte heap records in the top image
-  const uint32_t mid_words = 2u * ((1u << KD) - (1u << K));  // words of a tree's mid levels (8 bytes per record)
+  const uint32_t mid_words = pairs ? (4u << K) : 2u * ((1u << KD) - (1u << K));  // words of a tree's mid levels (8 bytes per record; pair records: 16 per level-K node)
   const uint32_t feat_off = v.feat_off_sparse(), row = v.row_bytes_sparse();
   auto feat_word = [&](uint32_t j) { return feat_off + j * row; };
 
@@ -236,14 +256,14 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
   } catch (const std::bad_alloc&) {
     return fail(e, DDT_ENOMEM, "sparse image allocation failed");
   }
-  for (size_t q = 0; q < mid_words / 2u; ++q) {  // (dense mid levels: the EMPTY slots' dummy heap)
+  for (size_t q = 0; q < mid_words / 2u && !pairs; ++q) {  // (dense mid levels: the EMPTY slots' dummy heap; pair records: all zero = feature 0 against key 0)
     deep[2u * q] = 0u;
     deep[2u * q + 1u] = feat_word(0);
   }
   for (size_t q = 0; q < (deep.size() - mid_words) / 4u; ++q) put16(deep.data() + mid_words + 4u * q, 0u, feat_word(0) | kSpLeftLeaf | kSpRightLeaf, 0u, 0u);
   // word 0 of a tree's top image: the byte offset the kernel adds a heap index to -- 16 h for the dense level K, 8 h for dense mid levels
   const auto cbase_of = [&](size_t first_record) {
-    return M ? (uint32_t)(first_record << 4) - (8u << K) : (uint32_t)(first_record << 4) - (16u << K);
+    return (M && !pairs) ? (uint32_t)(first_record << 4) - (8u << K) : (uint32_t)(first_record << 4) - (16u << K);
   };  // see ddt_internal.h
 
   std::vector<Cursor> cur, nxt;
@@ -306,6 +326,21 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
         nxt.clear();
         for (uint32_t k = 0; k < cur.size(); ++k) {
           const size_t w2 = 2u * (((size_t)1u << lvl) + k - ((size_t)1u << K));
+          if (pairs) {  // record of the level-K node (k at level K, k >> 1 at level K+1): word 0 / 1 / 2 = the node's / left child's / right child's key
+            uint32_t* pr = d8 + 4u * (lvl == K ? k : k >> 1);
+            const uint32_t pos = lvl == K ? 0u : 1u + (k & 1u);
+            if (cur[k].leaf) {  // padding under an early leaf: key 0, feature 0 -- any direction ends on the same value
+              nxt.push_back(cur[k]);
+              nxt.push_back(cur[k]);
+            } else {
+              const uint32_t n = cur[k].v;
+              pr[pos] = node_key(n);
+              pr[3] |= ((L[4u * n + 1u] & 0x7FFu) << (8u * pos)) | (((L[4u * n + 1u] >> 13) & 1u) << (24u + pos));
+              nxt.push_back(child(n, 0));
+              nxt.push_back(child(n, 1));
+            }
+            continue;
+          }
           if (cur[k].leaf) {
             d8[w2] = 0u;
             d8[w2 + 1u] = feat_word(0);
@@ -435,7 +470,7 @@ int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, f
   x.deep_bytes = (uint32_t)std::min<uint64_t>(sp.deep_bytes, 0xFFFFFFFFull);
   {  // visits of the kernel's deep loop on the forest's longest path: levels K-1 .. max_depth-1 (16-byte level K-1 records in LDS), K+M .. max_depth-1
      // (dense level K behind M dense mid levels); a shallower forest still consumes the one (dummy) record every walker fetches
-    const uint32_t first_lvl = (v.opt & 2) ? (uint32_t)v.levels + ((v.opt & 8) ? (uint32_t)v.top : 0u) : (uint32_t)v.levels - 1u;
+    const uint32_t first_lvl = (v.opt & 2) ? (uint32_t)v.levels + ((v.opt & 16) ? 2u : (v.opt & 8) ? (uint32_t)v.top : 0u) : (uint32_t)v.levels - 1u;
     x.max_rounds = !(e->sparse_peel_last && e->sparse_idle_oob) ? 0xFFFFFFFFu :  // (the visit-only round tells a finished walker by the zeros of its out-of-range gather)
                     sp.max_depth > first_lvl ? sp.max_depth - first_lvl : 1u;
   }

@@ -276,7 +276,19 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
           const uint32_t* r8 = deep + (size_t)((8u * m + tr[0]) / 4u);
           m = 2u * m + right(r8[0], r8[1]);
         }
+        const bool pairs = dense && (v.opt & 16) != 0;  // "sparse_dp_*": one 16-byte record {key, left key, right key, three feature numbers + missing directions} for the levels K and K+1
+        if (pairs) {
+          const uint32_t* pr = deep + (size_t)((16u * m + tr[0]) / 16u) * 4u;
+          auto right_j = [&](uint32_t key, uint32_t j, uint32_t miss_right) -> uint32_t {
+            const uint32_t raw = t[j], xk = a.ieee ? ieee_key(raw) : raw;
+            return raw == a.miss_raw ? miss_right : (uint32_t)!((int32_t)xk < (int32_t)key);
+          };
+          const uint32_t w = pr[3], r0 = right_j(pr[0], w & 0xFFu, (w >> 24) & 1u);
+          const uint32_t r1 = right_j(pr[1u + r0], (w >> (8u + 8u * r0)) & 0xFFu, (w >> (25u + r0)) & 1u);
+          m = 4u * m + 2u * r0 + r1;
+        }
         const uint32_t* rec = !dense ? tr + (4u << K) / 4u + 4u * (m - (1u << (K - 1)))
+                              : pairs ? deep + (size_t)((16u * m + tr[0] - (32u << K)) / 16u) * 4u
                               : mid  ? deep + (size_t)((16u * m + tr[0] - (8u << (K + mid))) / 16u) * 4u
                                      : deep + (size_t)((16u * m + tr[0]) / 16u) * 4u;
         for (int guard = 0; guard < 100; ++guard) {
@@ -337,6 +349,7 @@ const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
     Variant{"sparse_dm1_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 8, &launch_sparse, 1},
     Variant{"sparse_dm2_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 8, &launch_sparse, 2},
     Variant{"sparse_dk_k9_u8_t512", kKindSparse, 9, 512, 1, 8, 8, 1, 2, &launch_sparse},
+    Variant{"sparse_dp_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 16, &launch_sparse, 2},
     Variant{"sparse_qd_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3, &launch_sparse},
     Variant{"sparse_gf_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 4, &launch_sparse},
 };

@@ -866,6 +866,37 @@ def test_a_pu_group_beyond_the_u16_ranks_falls_back_and_says_so(mock):
     mock.ddt_destroy(e)
 
 
+@pytest.mark.parametrize("T,depth,F,full,pm,dp,name", [(20, 14, 64, 11, 700, -1, "sparse_dp_k8_u8_t256"), (20, 14, 64, 9, 300, -1, "sparse_dm1_k8_u8_t256"),
+                                                       (20, 14, 64, 9, 300, 1, "sparse_dp_k8_u8_t256"), (12, 9, 64, 3, 500, 1, "sparse_dp_k8_u8_t256"),
+                                                       (20, 14, 64, 11, 700, 0, "sparse_dm1_k8_u8_t256")])
+def test_sparse_forests_with_dense_pair_records(mock, T, depth, F, full, pm, dp, name):
+    """Round 5: the two levels below the top image as ONE block of 16-byte pair records (a gather decides two levels), the dense block at level
+    K + 2 (option sparse_dp: automatic when the forest fills the three levels, or forced -- then also on a forest shallower than the blocks):
+    choice, packing and the walk against the oracle, with missing values; the feeder."""
+    mock.mock_reset(2, 7, 8)
+    sp = O.gen_sparse_model(T, depth, F, full, pm, 1)
+    n = 500
+    x = O.gen_tuples(0, n, F, 1)
+    x[::5, 1] = sp.params.missing_bits
+    x[::7, F - 1] = sp.params.missing_bits
+    want = O.score_sparse(sp, x)
+    p = ddt.make_sparse_params(T, depth, F)
+    mock.ddt_load_model_sparse.argtypes = [vp, C.POINTER(ddt.Params), vp, C.c_size_t, vp, C.c_uint32, C.c_uint32]
+    e, info = _engine(mock), ddt.Info()
+    assert mock.ddt_set_option(e, b"sparse_dp", 2) < 0
+    assert mock.ddt_set_option(e, b"sparse_dp", dp) == 0 and mock.ddt_set_option(e, b"sparse_q16", 0) == 0
+    lines, first = np.ascontiguousarray(sp.node_lines, np.uint32), np.ascontiguousarray(sp.first, np.uint64)
+    assert mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, 0, 1) == 0, mock.ddt_last_error(e)
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == name, info.variant_name
+    o = np.full(n, np.nan, np.float32)
+    assert mock.ddt_score_device(e, x.ctypes.data, n, o.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
+    assert np.array_equal(_bits(o), _bits(want))
+    h = np.full(n, np.nan, np.float32)
+    assert mock.ddt_set_option(e, b"feeder_rows", 256) == 0 and mock.ddt_score(e, x.ctypes.data, n, h.ctypes.data) == 0
+    assert np.array_equal(_bits(h), _bits(want))
+    mock.ddt_destroy(e)
+
+
 @pytest.mark.parametrize("T,depth,F,full,pm,dm,name", [(20, 14, 64, 10, 700, -1, "sparse_dm1_k8_u8_t256"), (20, 14, 64, 9, 400, -1, "sparse_dm1_k8_u8_t256"),
                                                        (20, 14, 64, 8, 300, -1, "sparse_dk_k8_u8_t256"), (20, 14, 64, 10, 700, 2, "sparse_dm2_k8_u8_t256"),
                                                        (20, 14, 64, 10, 700, 0, "sparse_dk_k8_u8_t256"), (12, 9, 64, 3, 500, 2, "sparse_dm2_k8_u8_t256")])
@@ -882,6 +913,7 @@ def test_sparse_forests_with_dense_mid_levels(mock, T, depth, F, full, pm, dm, n
     mock.ddt_load_model_sparse.argtypes = [vp, C.POINTER(ddt.Params), vp, C.c_size_t, vp, C.c_uint32, C.c_uint32]
     e, info = _engine(mock), ddt.Info()
     assert mock.ddt_set_option(e, b"sparse_dm", dm) == 0 and mock.ddt_set_option(e, b"sparse_q16", 0) == 0   # (a forest this small would fit u16 ranks)
+    assert mock.ddt_set_option(e, b"sparse_dp", 0) == 0                                                        # (... and the pair records would take the fuller ones)
     lines, first = np.ascontiguousarray(sp.node_lines, np.uint32), np.ascontiguousarray(sp.first, np.uint64)
     assert mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, 0, 1) == 0, mock.ddt_last_error(e)
     assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == name, info.variant_name

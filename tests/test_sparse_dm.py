@@ -29,6 +29,7 @@ def test_dense_mid_levels_equal_the_oracle(T, depth, F, full, pm, dist):
     lines, first = np.ascontiguousarray(sp.node_lines, np.uint32), np.ascontiguousarray(sp.first, np.uint64)
     e = ddt.Engine(0)
     e.set_option("sparse_q16", 0)                      # (forests this small would fit u16 ranks: the fp32 family is what has the mid levels)
+    e.set_option("sparse_dp", 0)                       # (the dense pair records, tests/test_sparse_dp.py, would take the fuller forests)
     seen = set()
     for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
         want = O.score_sparse_fast(sp, x, sum_mode=ref) if sum_mode == 0 else O.score_sparse(sp, x, sum_mode=ref)

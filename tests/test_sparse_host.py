@@ -38,7 +38,7 @@ def _rank_tables(s):
     return [np.unique(nl[(nl[:, 1] & 0x7FF) == j, 0].view(np.int32)) for j in range(int(s.params.num_features))]
 
 
-def _walk(top, deep, info, slot, x, miss_bits, tables=None, mid=0):
+def _walk(top, deep, info, slot, x, miss_bits, tables=None, mid=0, pairs=False):
     """score_sparse_kernel's walk of one tree slot for one tuple (cmp_mode 0: signed compare of the raw bits); `tables`
     (rank-quantised kernels): the node word is the threshold's rank, the feature value is replaced by ITS rank = number of keys <= x"""
     _, _, _, K, feat_off, row = info
@@ -58,7 +58,23 @@ def _walk(top, deep, info, slot, x, miss_bits, tables=None, mid=0):
     m = 1
     for _ in range(K if dense else K - 1):
         m = 2 * m + int(right(int(t[2 * m]), int(t[2 * m + 1])))
-    if dense and mid:  # dense mid levels ("sparse_dm<M>_*"): M levels of 8-byte records that continue the heap at byte cbase + 8 h, then the
+    if dense and pairs:  # dense pair records ("sparse_dp_*"): one 16-byte record {key, left key, right key, feature numbers as bytes + missing
+        # directions in bits 24..26} per level-K node at byte cbase + 16 h; the dense block of level K + 2 at byte cbase - 32 * 2^K + 16 h
+
+        def right_j(key, j, miss_right):
+            f = int(x[j])
+            return bool(miss_right) if f == miss_bits else bool(np.uint32(f).view(np.int32) >= np.uint32(key).view(np.int32))
+
+        off = (16 * m + int(t[0])) & 0xFFFFFFFF
+        assert off % 16 == 0 and off // 16 < deep.shape[0]
+        ka, kl, kr, w = (int(v) for v in deep[off // 16])
+        r0 = right_j(ka, w & 0xFF, (w >> 24) & 1)
+        r1 = right_j(kr if r0 else kl, (w >> (16 if r0 else 8)) & 0xFF, (w >> (26 if r0 else 25)) & 1)
+        m = 4 * m + 2 * int(r0) + int(r1)
+        off = (16 * m + int(t[0]) - (32 << K)) & 0xFFFFFFFF
+        assert off % 16 == 0 and off // 16 < deep.shape[0]
+        rec = deep[off // 16]
+    elif dense and mid:  # dense mid levels ("sparse_dm<M>_*"): M levels of 8-byte records that continue the heap at byte cbase + 8 h, then the
         # dense block of 16-byte records of level K + M at byte cbase - 8 * 2^(K+M) + 16 h
         words = deep.reshape(-1)
         for _ in range(mid):
@@ -99,13 +115,14 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
     seen_k = set()
     tables = _rank_tables(s)
     for vid, name in _sparse_variants():
-        ranked, dense = name.startswith(("sparse_q_", "sparse_qd_")), name.startswith(("sparse_dk_", "sparse_qd_", "sparse_dm"))
+        ranked, dense = name.startswith(("sparse_q_", "sparse_qd_")), name.startswith(("sparse_dk_", "sparse_qd_", "sparse_dm", "sparse_dp"))
         mid = int(re.match(r"sparse_dm(\d)_", name).group(1)) if name.startswith("sparse_dm") else 0
         K = int(re.search(r"_k(\d+)_", name).group(1))
         gf = name.startswith("sparse_gf_")   # features gathered from global memory: the address field is the byte offset in the tuple's row
-        if (ranked, dense, K, gf, mid) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
+        pairs = name.startswith("sparse_dp")
+        if (ranked, dense, K, gf, mid, pairs) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
             continue
-        seen_k.add((ranked, dense, K, gf, mid))
+        seen_k.add((ranked, dense, K, gf, mid, pairs))
         top, deep, info = _images(s, vid, order)
         if dense and not ranked:  # the second word of heap record 0 is spare (0): no kernel reads it
             assert not top.reshape(info[2] * 8, -1)[:, 1].any(), name
@@ -114,11 +131,11 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
         assert not gf or info[4] == 0
         for r in range(x.shape[0]):
             for i in range(info[2] * 8):
-                got = _walk(top, deep, info, i, x[r], int(s.params.missing_bits), tables if ranked else None, mid)
+                got = _walk(top, deep, info, i, x[r], int(s.params.missing_bits), tables if ranked else None, mid, pairs)
                 want = O.traverse_sparse(s, x[r], i) if i < T else 0
                 assert got == want, (name, order, r, i, hex(got), hex(want))
     assert len([k for k in seen_k if not k[0] and not k[1]]) >= 4 and len([k for k in seen_k if k[0]]) >= 4 and len([k for k in seen_k if k[1]]) >= 4
-    assert any(k[3] for k in seen_k) and {k[4] for k in seen_k} >= {0, 1, 2}
+    assert any(k[3] for k in seen_k) and {k[4] for k in seen_k} >= {0, 1, 2} and any(k[5] for k in seen_k)
 
 
 def test_hook_rejects_what_the_loader_rejects():
