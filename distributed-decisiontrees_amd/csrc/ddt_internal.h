@@ -131,6 +131,13 @@ constexpr uint32_t kQ16TileCounterWords = 2;  // behind the kQ16GroupedCounters 
 //               256 tuples x 64 features share a CU (2 x 80 KiB), or one block of 512 holds K = 9 (160 KiB); the per-wave flags
 //               of the missing-value test live at LDS offset 0 before the first image arrives.  EMPTY slots share the dummy
 //               block deep[0, 2^K).
+//   dense mid levels ("sparse_dm<M>_*", opt bit 3, Variant::top = M): the levels K .. K+M-1 continue the heap as 8-byte records {thr_key, w} in the
+//               deep array (heap node h at byte cbase + 8 h, cbase = 16 * base - 8 * 2^K), the dense block of 16-byte records is level K+M
+//               (byte cbase - 8 * 2^(K+M) + 16 h)
+//   dense pair records ("sparse_dp_*", opt bit 4): the levels K and K+1 as ONE block of 2^K 16-byte records per tree {key of the level-K node,
+//               key of its left child, key of its right child, feature NUMBER of the three in the bytes 0 / 1 / 2 + their missing directions
+//               in the bits 24 / 25 / 26} at byte cbase + 16 h (cbase = 16 * base - 16 * 2^K, h = level-K heap index): one gather decides two
+//               levels; the dense block of ordinary records is level K+2 (byte cbase - 32 * 2^K + 16 h).  Feature numbers < 256.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kSpLeftLeaf = 0x80000000u, kSpRightLeaf = 0x40000000u, kSpMissRight = 0x20000000u, kSpAddrMask = 0x1FFFFFFFu;
 constexpr int kSparseMinTop = 6, kSparseMaxTop = 10;
