@@ -170,7 +170,7 @@ struct ddt_engine {
   int sparse_dk = 1;            // option "sparse_dk": 1 = dense-level-K sparse kernels where they exist (default), 0 = 16-byte level K-1 records in LDS
   int sparse_dm = -1;           // option "sparse_dm": dense mid levels of 8-byte records below the top image (-1 = where the forest fills them, 0 = never, 1..3 = exactly that many)
   int sparse_peel_last = 1;     // option "sparse_peel_last": 1 = the last possible round of a sparse kernel's deep loop issues no gather (default), 0 = as before round 5 (A/B)
-  int sparse_dp = -1;           // option "sparse_dp": dense pair records for the two levels below the top image (-1 = where the forest fills the levels K and K+1 at least half, 0 = never, 1 = always)
+  int sparse_dp = -1;           // option "sparse_dp": dense pair records for the two levels below the top image (-1 = where the forest fills level K at least half and level K+1 a quarter, 0 = never, 1 = always)
   int sparse_idle_oob = 1;      // option "sparse_idle_oob": 1 = a finished walker's gather is sent out of the buffer's range (no cache access; default), 0 = it re-reads record 0 (A/B)
   int sparse_q16 = 1;           // option "sparse_q16": 1 = rank-quantised sparse kernels when they fit (default), 0 = fp32 feature tiles
   ddt::RankDevice sp_rank;      // rank tables of the loaded sparse forests (rank-quantised kernels only)

@@ -162,13 +162,13 @@ int sparse_rebuild(ddt_engine* e) {
       }
     }
     // Dense pair records (option "sparse_dp": -1 automatic, 0 never, 1 always where such a kernel exists): one gather for the levels K and K+1 and
-    // a dense block at level K+2 -- when the forest fills the levels K and K+1 at least half (a walker that ends above them would fetch two
-    // padding records where the other forms fetch one; measured on four fills of the config-4 generator, level K+2 36 .. 73 % full: +2 .. +5 %
-    // over the better of the other two, profiles/r05_raw/s15_*) and its feature numbers fit a byte
+    // a dense block at level K+2 -- when the forest fills level K at least half and level K+1 a quarter (a walker that ends above them would
+    // fetch two padding records where the other forms fetch one; measured on seven fills of the config-4 generator, level K+1 30 .. 100 % and
+    // level K+2 6 .. 73 % full: +2 .. +5 % over the better of the other two, profiles/r05_raw/s15_*, s16_*) and its feature numbers fit a byte
     bool took_pairs = false;
     if (e->sparse_dp != 0 && e->sparse_dm <= 0 && e->p.num_features <= 256u) {
       bool full = trees > 0.0;
-      for (uint32_t lvl = K; lvl < K + 2u; ++lvl) full = full && nodes[lvl] >= 0.5 * trees * (double)(1u << lvl);
+      full = full && nodes[K] >= 0.5 * trees * (double)(1u << K) && nodes[K + 1u] >= 0.25 * trees * (double)(2u << K);
       char name[48];
       snprintf(name, sizeof(name), "sparse_dp_k%u_u8_t%d", K, dkv.threads);
       const int vp = find_variant(name);
