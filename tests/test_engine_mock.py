@@ -866,7 +866,7 @@ def test_a_pu_group_beyond_the_u16_ranks_falls_back_and_says_so(mock):
     mock.ddt_destroy(e)
 
 
-@pytest.mark.parametrize("T,depth,F,full,pm,dp,name", [(20, 14, 64, 11, 700, -1, "sparse_dp_k8_u8_t256"), (20, 14, 64, 9, 300, -1, "sparse_dm1_k8_u8_t256"),
+@pytest.mark.parametrize("T,depth,F,full,pm,dp,name", [(20, 14, 64, 11, 700, -1, "sparse_dp_k8_u8_t256"), (20, 14, 64, 9, 150, -1, "sparse_dm1_k8_u8_t256"),
                                                        (20, 14, 64, 9, 300, 1, "sparse_dp_k8_u8_t256"), (12, 9, 64, 3, 500, 1, "sparse_dp_k8_u8_t256"),
                                                        (20, 14, 64, 11, 700, 0, "sparse_dm1_k8_u8_t256")])
 def test_sparse_forests_with_dense_pair_records(mock, T, depth, F, full, pm, dp, name):
