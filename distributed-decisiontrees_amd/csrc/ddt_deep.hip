@@ -295,6 +295,8 @@ static const Variant g_deep_variants[] = {
     DDT_QD("q16d_d13_k8_c8_u4_cm", 13, 8, 8),
     DDT_QD("q16d_d14_k9_c4_u4_cm", 14, 9, 4),
     DDT_QD("q16d_d15_k8_c8_u4_cm", 15, 8, 8),
+    // (eleven levels out of LDS and ONE gather per tree, `q16d_d12_k11_c4`: 2 x 32 KiB of records + the rank tile = one block per CU -- measured and
+    // NOT instantiated: 512 / 171 / 64 trees x d12, 10 M tuples: 14.97 / 5.52 / 2.29 ms against 14.31 / 5.22 / 2.24 of the two-gather, two-block form)
     // (depth 16 measured and NOT instantiated: 64 trees x 32 features, 4 M tuples -- 693 Mtuples/s against 725 on the generic kernel: 131 k
     // thresholds per feature = four parts, each with a transpose + rank pre-pass, and four gathers per tree at one block per CU)
     DDT_QDW("q16dw_d12_k9_c4_u4_cm", 12, 9, 4),
