@@ -56,3 +56,35 @@ def test_dense_pair_records_equal_the_oracle(T, depth, F, full, pm, dist):
                 assert np.array_equal(_bits(got.cpu().numpy()), _bits(want[:k])), (name, k)
     assert F > 72 or any(s.startswith("sparse_dp_k") for s in seen)
     e.close()
+
+
+def test_dense_pair_records_with_classes_and_tree_shards():
+    """one-vs-all classes and tree shards (an engine loads a subset of the stream's trees) over pair-record images: every class / shard packs
+    its own blocks; per-class sums bit-exact, labels exact; the chain add of two class shards"""
+    import torch
+
+    e = ddt.Engine(0)
+    e.set_option("sparse_q16", 0)
+    e.set_option("sparse_dp", 1)
+    for (T, D, F, K, inter) in [(60, 13, 64, 3, True), (48, 12, 64, 4, False)]:
+        s = O.gen_sparse_model(T, D, F, 10, 650, 1, clusters=1)
+        x = O.gen_tuples(5, 3001, F, 1)
+        x[::17, 2] = s.params.missing_bits
+        want_l, want_s = O.classify_sparse(s, x, K, inter)
+        p = ddt.make_sparse_params(T, D, F, clusters=1)
+        e.load_model_sparse(p, s.node_lines, s.first, 0, 1, K, inter)
+        assert e.info().variant_name.decode().startswith("sparse_dp_k")
+        d = torch.from_numpy(x.view(np.int32)).cuda()
+        gl, gs = e.classify_device(d)
+        torch.cuda.synchronize()
+        assert np.array_equal(gl.cpu().numpy(), want_l) and np.array_equal(_bits(gs.cpu().numpy()), _bits(want_s)), (T, K, inter)
+        parts = []
+        for g in range(2):
+            e.load_model_sparse(p, s.node_lines, s.first, g, 2, K, inter)
+            assert e.info().variant_name.decode().startswith("sparse_dp_k")
+            parts.append(e.classify_device(d, want_labels=False)[1])
+        comb = torch.stack([e.chain_sum_device(torch.stack([parts[0][k], parts[1][k]])) for k in range(K)])
+        lab = e.argmax_device(comb.contiguous())
+        wl2, ws2 = O.classify_sparse(s, x, K, inter, n_devices=2)
+        assert np.array_equal(lab.cpu().numpy(), wl2) and np.array_equal(_bits(comb.cpu().numpy()), _bits(ws2))
+    e.close()
