@@ -73,7 +73,7 @@ __device__ __forceinline__ uint32_t sp_feature(uint32_t w, uint32_t lane_off, co
 template <int K, int U, int THREADS, bool SLOW, bool Q, bool DK, bool GF = false, int M = 0, bool PR = false>
 __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc, const GfSrc& gs) {
   static_assert(M == 0 || DK, "dense mid levels extend the dense level K");
-  static_assert(!PR || (DK && M == 0 && !Q && !GF), "pair records: fp32 tile, dense levels K and K + 1");
+  static_assert(!PR || (DK && M == 0 && !GF), "pair records: a feature tile in LDS, dense levels K and K + 1");
   constexpr int TOPB = (DK ? 8 : 12) << K;
   constexpr int STEPB = U * TOPB;  // U trees per pass: one PU group (or two)
   // Q: the u16 tile of the q16 pre-pass -- tuples t and t + 512 of a tile share a dword (rank_kernel)
@@ -182,8 +182,15 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
       // node, keys of its two children, feature numbers of the three as bytes + their missing directions}: ONE gather decides two levels (the
       // dense-mid form takes one per level), the next record is the walker's node in the dense block of level K + 2, by heap index.  The
       // feature number, not its LDS address, is in the record (three of them share a word): address = tile base + number * ROW.
-      constexpr uint32_t ROWB = (uint32_t)THREADS * 4u;
+      constexpr uint32_t ROWB = (uint32_t)THREADS * (Q ? 2u : 4u);  // (rank-quantised: the u16 tile of the q16 pre-pass, keys = ranks)
       const uint32_t fbase = (uint32_t)(((U * TOPB + ROWB - 1) / ROWB) * ROWB) + lane_off;  // FEAT_OFF + the lane's column
+      const uint32_t miss_f = Q ? kQMissing : miss_key;
+      auto feat = [&](uint32_t j) -> uint32_t {
+        const uint32_t addr = (j * ROWB) + fbase;
+        if (Q) return *reinterpret_cast<const DDT_LDS(uint16_t)*>(addr);
+        return lds_u32(addr);
+      };
+      auto ge = [&](uint32_t f, uint32_t key) -> bool { return Q ? f >= key : (int32_t)f >= (int32_t)key; };
       u32x4 pr[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -197,14 +204,14 @@ __device__ __forceinline__ void sparse_walk(const ScoreArgs& a, const SparseAux&
       for (int u = 0; u < U; ++u) {
         asm volatile("" : "+v"(pr[u].x), "+v"(pr[u].y), "+v"(pr[u].z), "+v"(pr[u].w));
         const uint32_t w = pr[u].w;
-        const uint32_t fa = lds_u32(((w & 0xFFu) * ROWB) + fbase);
-        bool r0 = (int32_t)fa >= (int32_t)pr[u].x;
-        if (SLOW) r0 = (fa == miss_key) ? ((w >> 24) & 1u) != 0u : r0;
+        const uint32_t fa = feat(w & 0xFFu);
+        bool r0 = ge(fa, pr[u].x);
+        if (SLOW) r0 = (fa == miss_f) ? ((w >> 24) & 1u) != 0u : r0;
         const uint32_t kc = r0 ? pr[u].z : pr[u].y;
         const uint32_t jc = (r0 ? (w >> 16) : (w >> 8)) & 0xFFu;
-        const uint32_t fc = lds_u32((jc * ROWB) + fbase);
-        bool r1 = (int32_t)fc >= (int32_t)kc;
-        if (SLOW) r1 = (fc == miss_key) ? ((w >> (r0 ? 26 : 25)) & 1u) != 0u : r1;
+        const uint32_t fc = feat(jc);
+        bool r1 = ge(fc, kc);
+        if (SLOW) r1 = (fc == miss_f) ? ((w >> (r0 ? 26 : 25)) & 1u) != 0u : r1;
         m8[u] = (m8[u] << 2) + (r0 ? 16u : 0u) + (r1 ? 8u : 0u);  // 8 * heap index at level K + 2
         rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m8[u] << 1) - (uint32_t)(32u << K), 0, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -403,6 +410,8 @@ static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStrea
   Variant { "sparse_dm" #M "_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2 | 8, &launch_sparse_v<K, U, T, false, true, false, M>, M }
 #define DDT_SPP(K, U, T) /* dense pair records for the levels K and K+1, dense level K+2 (opt bit 4; Variant::top = 2; at most 256 features) */ \
   Variant { "sparse_dp_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 2 | 16, &launch_sparse_v<K, U, T, false, true, false, 0, true>, 2 }
+#define DDT_SPQP(K, U) /* rank-quantised + dense pair records */ \
+  Variant { "sparse_qp_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 1 | 2 | 16, &launch_sparse_v<K, U, 1024, true, true, false, 0, true>, 2 }
 #define DDT_SPQD(K, U) /* rank-quantised + dense level K */ \
   Variant { "sparse_qd_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 3, &launch_sparse_v<K, U, 1024, true, true> }
 #define DDT_SPG(K, U, T) /* global features: no tile in LDS, any tuple width */ \
@@ -432,7 +441,10 @@ static const Variant g_sparse_variants[] = {
     // one mid level pays a little, three lose a fifth -- the padding under the early leaves of level 10 turns finished walkers into live gathers)
     DDT_SPM(1, 8, 8, 256), DDT_SPM(2, 8, 8, 256), DDT_SPM(1, 7, 8, 256), DDT_SPM(1, 8, 8, 128), DDT_SPM(1, 7, 8, 128),
     // dense pair records (round 5): two levels per gather below the top image, for forests that fill the levels K .. K+2
-    DDT_SPP(7, 8, 256), DDT_SPP(8, 8, 256), DDT_SPP(9, 8, 256), DDT_SPP(10, 8, 256),
+    // (K = 10 measured and NOT instantiated: the dense block would sit at level 12, 64 KiB per tree -- a 255-bin version of config 4 on 32 features:
+    // `sparse_qp_k10` 272.8 vs `sparse_qd_k10` 287.1 Mtuples/s; K = 9 on 64 features: 267.4 vs 263.1)
+    DDT_SPP(7, 8, 256), DDT_SPP(8, 8, 256), DDT_SPP(9, 8, 256),
+    DDT_SPQP(7, 8), DDT_SPQP(8, 8), DDT_SPQP(9, 8),
     // tuples too wide for any feature tile (more than ~540 words): every feature is gathered from the tuple's row in global memory.
     // The correctness path of the sparse format, like the generic kernel of the perfect-tree format -- not a tuned kernel.
     DDT_SPG(6, 8, 256),

@@ -140,7 +140,7 @@ int sparse_rebuild(ddt_engine* e) {
   // Dense mid levels (option "sparse_dm": -1 automatic, 0 never, M = exactly M): where the choice is a dense-level-K kernel that has
   // "sparse_dm<M>_*" siblings, the levels K .. K+M-1 become 8-byte heap records when the forest fills them at least half (the padding
   // under early leaves doubles per level).  Automatic = one mid level; more only when asked for (A/B)
-  if (vid >= 0 && e->forced_variant < 0 && (e->sparse_dm != 0 || e->sparse_dp != 0) && (variant(vid).opt & 2) && !(variant(vid).opt & (1 | 4 | 8 | 16))) {
+  if (vid >= 0 && e->forced_variant < 0 && (e->sparse_dm != 0 || e->sparse_dp != 0) && (variant(vid).opt & 2) && !(variant(vid).opt & (4 | 8 | 16))) {  // (rank-quantised choices: the pair records only)
     const Variant& dkv = variant(vid);
     const uint32_t K = (uint32_t)dkv.levels;
     std::vector<double> nodes(K + 4u, 0.0);  // internal nodes per level K .. K+3 over all forests
@@ -170,14 +170,15 @@ int sparse_rebuild(ddt_engine* e) {
       bool full = trees > 0.0;
       full = full && nodes[K] >= 0.5 * trees * (double)(1u << K) && nodes[K + 1u] >= 0.25 * trees * (double)(2u << K);
       char name[48];
-      snprintf(name, sizeof(name), "sparse_dp_k%u_u8_t%d", K, dkv.threads);
+      if (dkv.opt & 1) snprintf(name, sizeof(name), "sparse_qp_k%u_u8_t1024", K);
+      else snprintf(name, sizeof(name), "sparse_dp_k%u_u8_t%d", K, dkv.threads);
       const int vp = find_variant(name);
       if ((full || e->sparse_dp > 0) && vp >= 0 && variant(vp).lds_bytes_sparse(tuple_words(e->p)) <= dkv.lds_bytes_sparse(tuple_words(e->p))) {
         vid = vp;
         took_pairs = true;
       }
     }
-    for (int M = 3; M >= 1 && !took_pairs && e->sparse_dm != 0; --M) {
+    for (int M = 3; M >= 1 && !took_pairs && e->sparse_dm != 0 && !(dkv.opt & 1); --M) {
       if (e->sparse_dm > 0 ? M != e->sparse_dm : M > 1) continue;  // automatic: ONE mid level (measured: +2-4 %; two +1 %, three -17 %)
       bool full = trees > 0.0;
       for (uint32_t lvl = K; lvl < K + (uint32_t)M; ++lvl) full = full && nodes[lvl] >= 0.5 * trees * (double)(1u << lvl);

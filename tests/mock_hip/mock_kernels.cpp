@@ -280,6 +280,7 @@ hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t 
         if (pairs) {
           const uint32_t* pr = deep + (size_t)((16u * m + tr[0]) / 16u) * 4u;
           auto right_j = [&](uint32_t key, uint32_t j, uint32_t miss_right) -> uint32_t {
+            if (ranked) return rk[j] == 0xFFFFu ? miss_right : (uint32_t)(rk[j] >= key);
             const uint32_t raw = t[j], xk = a.ieee ? ieee_key(raw) : raw;
             return raw == a.miss_raw ? miss_right : (uint32_t)!((int32_t)xk < (int32_t)key);
           };
@@ -351,6 +352,7 @@ const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
     Variant{"sparse_dk_k9_u8_t512", kKindSparse, 9, 512, 1, 8, 8, 1, 2, &launch_sparse},
     Variant{"sparse_dp_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 2 | 16, &launch_sparse, 2},
     Variant{"sparse_qd_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3, &launch_sparse},
+    Variant{"sparse_qp_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3 | 16, &launch_sparse, 2},
     Variant{"sparse_gf_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 4, &launch_sparse},
 };
 constexpr int kMockDense = (int)(sizeof(g_mock_variants) / sizeof(g_mock_variants[0]));

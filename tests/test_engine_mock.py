@@ -897,6 +897,29 @@ def test_sparse_forests_with_dense_pair_records(mock, T, depth, F, full, pm, dp,
     mock.ddt_destroy(e)
 
 
+@pytest.mark.parametrize("dp,name", [(-1, "sparse_qp_k8_u8_t1024"), (0, "sparse_qd_k8_u8_t1024")])
+def test_rank_quantised_sparse_forests_with_dense_pair_records(mock, dp, name):
+    """... and the rank-quantised family (thresholds -> ranks, the u16 tiles of the q16 pre-pass): the same pair records with ranks as keys"""
+    mock.mock_reset(2, 7, 8)
+    T, depth, F = 20, 14, 64
+    sp = O.gen_sparse_model(T, depth, F, 11, 700, 1)
+    n = 1300
+    x = O.gen_tuples(0, n, F, 1)
+    x[::5, 1] = sp.params.missing_bits
+    want = O.score_sparse(sp, x)
+    p = ddt.make_sparse_params(T, depth, F)
+    mock.ddt_load_model_sparse.argtypes = [vp, C.POINTER(ddt.Params), vp, C.c_size_t, vp, C.c_uint32, C.c_uint32]
+    e, info = _engine(mock), ddt.Info()
+    assert mock.ddt_set_option(e, b"sparse_dp", dp) == 0
+    lines, first = np.ascontiguousarray(sp.node_lines, np.uint32), np.ascontiguousarray(sp.first, np.uint64)
+    assert mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, 0, 1) == 0, mock.ddt_last_error(e)
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == name, info.variant_name
+    o = np.full(n, np.nan, np.float32)
+    assert mock.ddt_score_device(e, x.ctypes.data, n, o.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
+    assert np.array_equal(_bits(o), _bits(want))
+    mock.ddt_destroy(e)
+
+
 @pytest.mark.parametrize("T,depth,F,full,pm,dm,name", [(20, 14, 64, 10, 700, -1, "sparse_dm1_k8_u8_t256"), (20, 14, 64, 9, 400, -1, "sparse_dm1_k8_u8_t256"),
                                                        (20, 14, 64, 8, 300, -1, "sparse_dk_k8_u8_t256"), (20, 14, 64, 10, 700, 2, "sparse_dm2_k8_u8_t256"),
                                                        (20, 14, 64, 10, 700, 0, "sparse_dk_k8_u8_t256"), (12, 9, 64, 3, 500, 2, "sparse_dm2_k8_u8_t256")])

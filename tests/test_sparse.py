@@ -188,10 +188,11 @@ def test_gpu_sparse_bit_exact_all_top_levels_and_orders(eng, shape):
                         assert ex.code == -5 and top == 10 and F > 60
                         continue
                     name = eng.info().variant_name.decode()
-                    assert ranked or not name.startswith(("sparse_q_", "sparse_qd_")), (name, ranked, top)
-                    assert dense or not name.startswith(("sparse_dk_", "sparse_qd_")), (name, dense, top)
-                    assert not (ranked and top == -1 and F <= 64) or name.startswith(("sparse_q_", "sparse_qd_")), (name, ranked, top)
-                    assert not (not ranked and dense and top in (-1, 6, 7, 8, 9) and F <= 32) or name.startswith("sparse_dk_"), (name, top)
+                    # (dense level K includes its forms with dense mid levels / dense pair records, chosen by the forest's fill)
+                    assert ranked or not name.startswith(("sparse_q_", "sparse_qd_", "sparse_qp_")), (name, ranked, top)
+                    assert dense or not name.startswith(("sparse_dk_", "sparse_qd_", "sparse_dm", "sparse_dp_", "sparse_qp_")), (name, dense, top)
+                    assert not (ranked and top == -1 and F <= 64) or name.startswith(("sparse_q_", "sparse_qd_", "sparse_qp_")), (name, ranked, top)
+                    assert not (not ranked and dense and top in (-1, 6, 7, 8, 9) and F <= 32) or name.startswith(("sparse_dk_", "sparse_dm", "sparse_dp_")), (name, top)
                     assert np.array_equal(_bits(got), _bits(want)), (shape, cmp_mode, top, order, name)
         eng.set_option("sparse_dk", 1)
         eng.set_option("sparse_q16", 1)

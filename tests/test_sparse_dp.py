@@ -40,7 +40,7 @@ def test_dense_pair_records_equal_the_oracle(T, depth, F, full, pm, dist):
             e.load_model_sparse(ddt.make_sparse_params(T, depth, F, sum_mode=sum_mode), lines, first)
             name = e.info().variant_name.decode()
             seen.add(name)
-            assert dp < 0 or F > 72 or name.startswith("sparse_dp_k"), (dp, name)     # forced: the two-block geometries (K = 7 .. 10, up to 72 features) have the sibling
+            assert dp < 0 or F > 72 or F <= 16 or name.startswith("sparse_dp_k"), (dp, name)     # forced: the two-block geometries with K = 7 .. 9 (17 .. 72 features) have the sibling
             for oob, peel in ((1, 1), (1, 0), (0, 1)):
                 e.set_option("sparse_idle_oob", oob)
                 e.set_option("sparse_peel_last", peel)
@@ -87,4 +87,31 @@ def test_dense_pair_records_with_classes_and_tree_shards():
         lab = e.argmax_device(comb.contiguous())
         wl2, ws2 = O.classify_sparse(s, x, K, inter, n_devices=2)
         assert np.array_equal(lab.cpu().numpy(), wl2) and np.array_equal(_bits(comb.cpu().numpy()), _bits(ws2))
+    e.close()
+
+
+@pytest.mark.parametrize("T,depth,F,full,pm", [(64, 16, 64, 10, 700), (40, 13, 72, 9, 500), (30, 12, 64, 11, 300), (24, 12, 20, 11, 300)])
+def test_dense_pair_records_rank_quantised(T, depth, F, full, pm):
+    """the rank-quantised family (`sparse_qp_*`: thresholds -> ranks, features -> the u16 tiles of the q16 pre-pass): the same pair records with
+    ranks as keys; missing values (rank 0xFFFF); both adders; ragged sizes"""
+    import torch
+
+    sp = O.gen_sparse_model(T, depth, F, full, pm, 1)
+    n = 150_001
+    x = O.gen_tuples(7, n, F, dist=1)
+    x[::29, :] = np.where(np.arange(F)[None, :] % 4 == 1, np.uint32(0x7FC00000), x[::29, :])
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    lines, first = np.ascontiguousarray(sp.node_lines, np.uint32), np.ascontiguousarray(sp.first, np.uint64)
+    e = ddt.Engine(0)
+    e.set_option("sparse_dp", 1)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        want = O.score_sparse_fast(sp, x, sum_mode=ref) if sum_mode == 0 else O.score_sparse(sp, x, sum_mode=ref)
+        e.load_model_sparse(ddt.make_sparse_params(T, depth, F, sum_mode=sum_mode), lines, first)
+        name = e.info().variant_name.decode()
+        assert name.startswith("sparse_qp_k") or F <= 32, name      # (K = 10, which up to 32 features reach, has no pair-record form: measured slower)
+        for k in (n, 1, 1023, 1025, 5000):
+            got = e.score_device(d[:k])
+            torch.cuda.synchronize()
+            bad = np.flatnonzero(_bits(got.cpu().numpy()) != _bits(want[:k]))
+            assert bad.size == 0, (name, sum_mode, k, bad[:8], bad.size)
     e.close()

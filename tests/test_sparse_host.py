@@ -63,7 +63,11 @@ def _walk(top, deep, info, slot, x, miss_bits, tables=None, mid=0, pairs=False):
 
         def right_j(key, j, miss_right):
             f = int(x[j])
-            return bool(miss_right) if f == miss_bits else bool(np.uint32(f).view(np.int32) >= np.uint32(key).view(np.int32))
+            if f == miss_bits:
+                return bool(miss_right)
+            if tables is not None:  # rank-quantised: the key is the threshold's rank, the feature its own rank
+                return int(np.searchsorted(tables[j], np.uint32(f).view(np.int32), side="right")) >= key if j < len(tables) else 0 >= key
+            return bool(np.uint32(f).view(np.int32) >= np.uint32(key).view(np.int32))
 
         off = (16 * m + int(t[0])) & 0xFFFFFFFF
         assert off % 16 == 0 and off // 16 < deep.shape[0]
@@ -115,11 +119,11 @@ def test_packed_images_walk_to_the_oracles_leaves(shape, order):
     seen_k = set()
     tables = _rank_tables(s)
     for vid, name in _sparse_variants():
-        ranked, dense = name.startswith(("sparse_q_", "sparse_qd_")), name.startswith(("sparse_dk_", "sparse_qd_", "sparse_dm", "sparse_dp"))
+        ranked, dense = name.startswith(("sparse_q_", "sparse_qd_", "sparse_qp_")), name.startswith(("sparse_dk_", "sparse_qd_", "sparse_dm", "sparse_dp", "sparse_qp_"))
         mid = int(re.match(r"sparse_dm(\d)_", name).group(1)) if name.startswith("sparse_dm") else 0
         K = int(re.search(r"_k(\d+)_", name).group(1))
         gf = name.startswith("sparse_gf_")   # features gathered from global memory: the address field is the byte offset in the tuple's row
-        pairs = name.startswith("sparse_dp")
+        pairs = name.startswith(("sparse_dp", "sparse_qp_"))
         if (ranked, dense, K, gf, mid, pairs) in seen_k:  # one variant per family and K: the packing depends on K and on the tile geometry only through the feature-row addresses
             continue
         seen_k.add((ranked, dense, K, gf, mid, pairs))
