@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, session 13: same-box A/B of two BUILDS on config 4 (lib/libddt_old.so = the commit before, lib/libddt.so = the working tree)
+# Round 5, session 13 (needs lib/libddt_old.so = a build of the commit before, made by hand): same-box A/B of two BUILDS on config 4 (lib/libddt_old.so = the commit before, lib/libddt.so = the working tree)
 set -u
 tag=${1:-r05_s13}
 cd "$GRAFT_REPO_ROOT"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, session 9: the queued-walker sparse kernels (sparse_qw<L>_*): parity of every sparse variant on the small forests of the suite,
+# Round 5, session 9 (historical: the kernels it names were removed after it, profiles/EXPERIMENTS.md): the queued-walker sparse kernels (sparse_qw<L>_*): parity of every sparse variant on the small forests of the suite,
 # then BASELINE config 4 -- the lock-step kernels against windows of 2 / 3 / 4 PU groups, both lane-state representations.
 set -u
 tag=${1:-r05_s9}
