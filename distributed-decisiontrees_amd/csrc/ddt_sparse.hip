@@ -443,6 +443,7 @@ static const Variant g_sparse_variants[] = {
     // dense pair records (round 5): two levels per gather below the top image, for forests that fill the levels K .. K+2
     // (K = 10 measured and NOT instantiated: the dense block would sit at level 12, 64 KiB per tree -- a 255-bin version of config 4 on 32 features:
     // `sparse_qp_k10` 272.8 vs `sparse_qd_k10` 287.1 Mtuples/s; K = 9 on 64 features: 267.4 vs 263.1)
+    // (one block of 512 tuples per CU, measured and NOT instantiated: `sparse_dp_k9_u8_t512` 250.5, `sparse_dp_k8_u8_t512` 258.0 against 293.4 Mtuples/s)
     DDT_SPP(7, 8, 256), DDT_SPP(8, 8, 256), DDT_SPP(9, 8, 256),
     DDT_SPQP(7, 8), DDT_SPQP(8, 8), DDT_SPQP(9, 8),
     // tuples too wide for any feature tile (more than ~540 words): every feature is gathered from the tuple's row in global memory.
