@@ -1030,6 +1030,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const int k = e->q_slot;
   // the transposed fp32 intermediate is only needed by the two-kernel pre-pass
   bool need_xT = e->sparse ? e->sp_rank.prepass.groups == 0 : (e->ens.empty() || e->ens[0].prepass.groups == 0);
+  const bool r32 = e->sparse && variant(e->variant_id).r32();  // 32-bit rank words, a flag per tile of 128 tuples at least
   bool in_parts = false;  // the sum's state between the parts' launches; tables per part
   if (!e->sparse)
     for (const Ensemble& m : e->ens) in_parts = in_parts || !m.parts.empty();
@@ -1048,9 +1049,9 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   e->q_rows[k] = 0;
   const uint32_t W = tuple_words(e->p);
   if (need_xT) HIP_TRY(e, hipMalloc(&e->q_xT[k], cap * W * 4));
-  HIP_TRY(e, hipMalloc(&e->q_q[k], cap * W * 2));
+  HIP_TRY(e, hipMalloc(&e->q_q[k], cap * W * (r32 ? 4 : 2)));
   if (in_parts) HIP_TRY(e, hipMalloc(&e->q_state[k], cap * 2 * sizeof(float)));
-  HIP_TRY(e, hipMalloc(&e->q_flags[k], (cap / 1024 + 2 + 2 * kQ16GroupedCounters + kQ16TileCounterWords) * 4));  // + the 8-byte work counters of the fused / grouped pre-pass + the _p kernels' tile counter
+  HIP_TRY(e, hipMalloc(&e->q_flags[k], (cap / (r32 ? 128 : 1024) + 2 + 2 * kQ16GroupedCounters + kQ16TileCounterWords) * 4));  // + the 8-byte work counters of the fused / grouped pre-pass + the _p kernels' tile counter
   e->q_rows[k] = cap;
   return DDT_OK;
 }
@@ -1358,7 +1359,7 @@ int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_
   if (timing) {
     int rc = timing_begin(e, s);
     if (rc) return rc;
-    if (!(variant(e->variant_id).opt & 1)) HIP_TRY(e, hipEventRecord(e->tev_cur[1], s));  // fp32 tiles: no pre-pass (else: sparse_launch)
+    if (!(variant(e->variant_id).opt & (1 | 32))) HIP_TRY(e, hipEventRecord(e->tev_cur[1], s));  // fp32 tiles: no pre-pass (else: sparse_launch)
   }
   int rc = sparse_launch(e, 0, d_tuples, n, d_scores, s);
   if (rc) {
@@ -1382,7 +1383,7 @@ int engine_classify_device(ddt_engine* e, const void* d_tuples, size_t n, float*
       // the other stream starts behind whatever the caller's stream has queued up to here (the tuples may come from there) and -- the
       // rank-quantised kernels -- behind the rank pre-pass of the batch, which is part of class 0's launch; NOT behind class 0's
       // scoring kernel: the fork event is recorded between the two (sparse_launch), or in front of the launch when there is no pre-pass
-      const bool ranked = (variant(e->variant_id).opt & 1) != 0;
+      const bool ranked = (variant(e->variant_id).opt & (1 | 32)) != 0;
       if (two && k == 0) {
         if (ranked) e->ev_fork = e->class_ev[0];
         else HIP_TRY(e, hipEventRecord(e->class_ev[0], s));
@@ -1879,14 +1880,16 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     e->sparse_dm = (int)value;
     return DDT_OK;
   }
-  if (!strcmp(key, "sparse_top_levels") || !strcmp(key, "sparse_deep_order") || !strcmp(key, "sparse_q16") || !strcmp(key, "sparse_dk")) {
+  if (!strcmp(key, "sparse_top_levels") || !strcmp(key, "sparse_deep_order") || !strcmp(key, "sparse_q16") || !strcmp(key, "sparse_dk") || !strcmp(key, "sparse_r32")) {
     // sparse forests: K = levels staged in LDS (-1 = as many as fit), order of the deep records (0 level order,
     // 1 depth-first per sub-tree), rank-quantised kernels (1 = when they fit, 0 = never), dense level K (1 = where such a kernel
     // exists, 0 = never); a loaded sparse model is re-packed
-    const bool top = key[7] == 't', rq = key[7] == 'q', dk = !strcmp(key, "sparse_dk");
+    // "sparse_r32": 32-bit ranks + pair records on every deep level (-1 = automatic: deep forests of >= 64 trees, 0 = never, 1 = wherever such a kernel fits)
+    const bool top = key[7] == 't', rq = key[7] == 'q', dk = !strcmp(key, "sparse_dk"), r32 = !strcmp(key, "sparse_r32");
     if (top && value >= 0 && (value < kSparseMinTop || value > kSparseMaxTop)) return fail(e, DDT_EINVAL, "sparse_top_levels must be -1 or %d..%d", kSparseMinTop, kSparseMaxTop);
-    if (!top && (value < 0 || value > 1)) return fail(e, DDT_EINVAL, "%s must be 0 or 1", key);
-    int& opt = top ? e->sparse_top_levels : rq ? e->sparse_q16 : dk ? e->sparse_dk : e->sparse_deep_order;
+    if (r32 && (value < -1 || value > 1)) return fail(e, DDT_EINVAL, "sparse_r32 must be -1, 0 or 1");
+    if (!top && !r32 && (value < 0 || value > 1)) return fail(e, DDT_EINVAL, "%s must be 0 or 1", key);
+    int& opt = top ? e->sparse_top_levels : rq ? e->sparse_q16 : dk ? e->sparse_dk : r32 ? e->sparse_r32 : e->sparse_deep_order;
     const int previous = opt;
     opt = (int)value;
     if (e->loaded && e->sparse) {
@@ -1935,7 +1938,7 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     if (value < 0) return fail(e, DDT_EINVAL, "reserve_rows must be >= 0");
     if (!e->loaded) return fail(e, DDT_ESTATE, "reserve_rows: load a model first (the workspace depends on its tuple width)");
     const Variant& cur = variant(e->variant_id);
-    const bool ranked = e->sparse ? (cur.opt & 1) != 0 : cur.kind == kKindQ16;
+    const bool ranked = e->sparse ? (cur.opt & (1 | 32)) != 0 : cur.kind == kKindQ16;
     if (!ranked || value == 0) return DDT_OK;  // nothing to reserve on the other paths
     DeviceGuard dg(e->device);
     if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);

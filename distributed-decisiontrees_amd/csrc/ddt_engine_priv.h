@@ -88,6 +88,7 @@ struct SparseForest {
   void* d_deep = nullptr;         // deep records
   size_t top_bytes = 0, deep_bytes = 0;
   uint32_t groups = 0;
+  uint32_t r_rounds = 1;          // "sparse_r_*" images: record hops on the longest path below the top image (SparseAux::max_rounds)
   uint32_t trees() const { return (uint32_t)ids.size(); }
 };
 
@@ -173,7 +174,11 @@ struct ddt_engine {
   int sparse_dp = -1;           // option "sparse_dp": dense pair records for the two levels below the top image (-1 = where the forest fills level K at least half and level K+1 a quarter, 0 = never, 1 = always)
   int sparse_idle_oob = 1;      // option "sparse_idle_oob": 1 = a finished walker's gather is sent out of the buffer's range (no cache access; default), 0 = it re-reads record 0 (A/B)
   int sparse_q16 = 1;           // option "sparse_q16": 1 = rank-quantised sparse kernels when they fit (default), 0 = fp32 feature tiles
-  ddt::RankDevice sp_rank;      // rank tables of the loaded sparse forests (rank-quantised kernels only)
+  ddt::RankDevice sp_rank;      // rank tables of the loaded sparse forests (rank-quantised kernels only; "sparse_r_*": the directories)
+  int sparse_r32 = -1;          // option "sparse_r32": 32-bit ranks + pair records on every deep level (-1 = where it measured faster: ddt_sparse_host.cpp sparse_rebuild, 0 = never, 1 = wherever they fit)
+  void* sp_r32_tab = nullptr;   // "sparse_r_*": the key blocks of the rank32 pre-pass (R32Aux::tab)
+  size_t sp_r32_tab_bytes = 0;
+  uint32_t sp_r32_blk_log2 = 2;
   int leaf_domain_check = 1;    // option "leaf_domain_check": reject leaves outside the exact domain of the reference adder
   ddt_stats st{};
   char err[256] = {0};

@@ -139,8 +139,38 @@ constexpr uint32_t kQ16TileCounterWords = 2;  // behind the kQ16GroupedCounters 
 //               in the bits 24 / 25 / 26} at byte cbase + 16 h (cbase = 16 * base - 16 * 2^K, h = level-K heap index): one gather decides two
 //               levels; the dense block of ordinary records is level K+2 (byte cbase - 32 * 2^K + 16 h).  Feature numbers < 256.
 // ---------------------------------------------------------------------------------------------------
+//   32-bit ranks, pair records on EVERY deep level ("sparse_r_*", Variant::opt bit 5, round 6; ddt_sparse_r.hip).  A node is ONE word
+//               rec = R << 12 | kSrLeftLeaf | kSrRightLeaf | kSrMissRight | feature number (< 256),  R = 1 + index of the threshold among the sorted
+//               distinct keys of its feature (< 2^20 - 1); the feature tile holds x' = rank(x) << 12 | 0xFFF (a missing value: 0xFFFFFFFF), written by
+//               the rank32 pre-pass, so that  !(x < t)  <=>  x' >= rec  as ONE unsigned compare, no mask.
+//               top image   per tree 4 * 2^K bytes: word 0 = cbase, words 1 .. 2^K - 1 the node words of levels 0..K-1 (1-based heap, early leaves
+//                           padded with 0 = "feature 0 against rank 0": any direction ends on the same value)
+//               deep array  16-byte PAIR records {node, left child, right child, ptr}: a child word is the child's node word, or the leaf's fp32 bits
+//                           when the node carries the matching leaf flag; the record of the grandchild on side r1 of the internal child on side r0
+//                           is at byte ptr + 32 r0 + 16 r1 (the host subtracts 32 from ptr when only the right child is internal: blocks of 2 or 4
+//                           slots).  A grandchild that is a LEAF has a LEAF record {kSrLeafRec, value, value, 0} in its slot -- one more gather for that
+//                           lane, no special case in the walk.  Level K is a dense block of 2^K pair records per tree: the record of heap node h (2^K <= h < 2^(K+1))
+//                           is at byte cbase + 16 h, cbase = the block's byte offset - 16 * 2^K (mod 2^32; the kernel carries 4 h).  EMPTY slots share a block of LEAF(+0).
+//               One gather decides two levels everywhere below the top image: 512 x depth 16 with K = 9: 4 gather instructions per tree and wave (7 before).
 constexpr uint32_t kSpLeftLeaf = 0x80000000u, kSpRightLeaf = 0x40000000u, kSpMissRight = 0x20000000u, kSpAddrMask = 0x1FFFFFFFu;
 constexpr int kSparseMinTop = 6, kSparseMaxTop = 10;
+constexpr uint32_t kSrLeftLeaf = 0x800u, kSrRightLeaf = 0x400u, kSrMissRight = 0x200u, kSrFeatMask = 0xFFu;
+constexpr uint32_t kSrLeafRec = kSrLeftLeaf | kSrRightLeaf;  // node word of a LEAF record: rank 0, feature 0, both sides leaves
+constexpr uint32_t kSrMissing = 0xFFFFFFFFu;                 // a missing value in the 32-bit rank tile
+constexpr uint32_t kSrMaxTable = (1u << 20) - 2u;            // distinct thresholds per feature
+constexpr uint32_t kSrMaxDir = 32767;                        // directory entries per feature (rank32_kernel keeps one feature's directory in LDS)
+
+// 32-bit rank pre-pass (ddt_sparse_r.hip rank32_kernel).  Per feature the sorted distinct keys in BLOCKS of 2^blk_log2 keys (>= 4; padded with
+// INT_MAX, one all-pad block behind them) in `tab`, and a DIRECTORY = the last key of every block, searched out of LDS exactly like rank_kernel's
+// table (Q16Aux::tables / tabP / tabS / Kpad hold the directory); the block the directory names is then read from `tab` with one 16-byte gather
+// per four keys.  tabP[j] = {directory entries, lo, hi, shift, P, key offset of the feature's blocks in tab, K (real keys), largest key}.
+struct R32Aux {
+  uint32_t* r = nullptr;           // workspace [n_pad / T][W][T] u32, T = the scoring kernel's tile
+  const uint32_t* tab = nullptr;
+  uint32_t tab_bytes = 0;
+  uint32_t blk_log2 = 2;
+  uint32_t tile = 256;
+};
 
 struct SparseAux {           // ScoreArgs::aux of the sparse kernels
   const uint4* deep;         // deep records (at least one, record 0 is a valid dummy)
@@ -153,6 +183,7 @@ struct SparseAux {           // ScoreArgs::aux of the sparse kernels
   // rank-quantised sparse kernels ("sparse_q_*", Variant::opt bit 0): thresholds are ranks, the features arrive as the u16 tiles
   // of the q16 pre-pass (the same tables / workspace / kernels as the perfect-tree q16 path); slow images = the same images
   Q16Aux q16;
+  R32Aux r32;                // "sparse_r_*": the 32-bit rank pre-pass (q16.xT / tile_flags / tables / tabP / tabS / Kpad / n_pad / skip_prepass are shared)
 };
 
 enum { kKindGeneric = 0, kKindTile = 1, kKindStream = 2, kKindQ16 = 3, kKindSparse = 4 };
@@ -231,7 +262,9 @@ struct Variant {
   // opt bit 0 ("sparse_q_*"): rank-quantised -- u16 feature tile (half the LDS per tuple: 1024 tuples = 16 waves share a CU
   // where the fp32 tile holds 512), node thresholds are ranks
   // opt bit 1 ("sparse_dk_*"): dense level K -- 8-byte records only in LDS, no flag bytes behind the tile (above: "Sparse forests")
-  uint32_t top_bytes_sparse() const { return ((opt & 2) ? 8u : 12u) << levels; }
+  // opt bit 5 ("sparse_r_*"): 32-bit ranks -- one-word nodes in the top image, a u32 feature tile written by the rank32 pre-pass, pair records below
+  bool r32() const { return kind == kKindSparse && (opt & 32) != 0; }
+  uint32_t top_bytes_sparse() const { return ((opt & 32) ? 4u : (opt & 2) ? 8u : 12u) << levels; }
   // opt bit 2 ("sparse_gf_*", any tuple width): no feature tile -- a feature is gathered from the tuple's row in global memory, the
   // record's address field is the byte offset of the feature inside the row (row 0 at 0, 4 bytes per feature)
   uint32_t row_bytes_sparse() const { return (opt & 4) ? 4u : (opt & 1) ? tile() * 2u : tile() * 4u; }
@@ -242,7 +275,7 @@ struct Variant {
   }
   uint32_t lds_bytes_sparse(uint32_t tuple_words) const {
     if (opt & 4) return (uint32_t)chunk_trees * top_bytes_sparse() + 64u;
-    return feat_off_sparse() + tuple_words * row_bytes_sparse() + ((opt & 2) ? 0u : 64u);
+    return feat_off_sparse() + tuple_words * row_bytes_sparse() + ((opt & (2 | 32)) ? 0u : 64u);
   }
 };
 
@@ -262,6 +295,9 @@ int num_deep_variants();                   // ddt_deep.hip: deep perfect trees, 
 const Variant& deep_variant(int i);
 int num_sparse_variants();                 // ddt_sparse.hip: appended after those
 const Variant& sparse_variant(int i);
+int num_sparse_r_variants();               // ddt_sparse_r.hip: and these last
+const Variant& sparse_r_variant(int i);
+hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint64_t n_pad, uint32_t* xT, hipStream_t s);  // ddt_kernels.hip
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact /* sum_mode 2 */, hipStream_t s);
 hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s);

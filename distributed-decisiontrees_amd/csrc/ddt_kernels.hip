@@ -640,6 +640,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restri
   for (uint32_t c = 0; c < W; ++c) xT[(uint64_t)c * n_pad + row0 + tid] = lds_u32((tid * S + c) * 4u);
 }
 
+hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint64_t n_pad, uint32_t* xT, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(transpose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((W + 1) * 256 * 4));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, tuples, W, n, n_pad, xT);
+  return hipGetLastError();
+}
+
 constexpr uint32_t kRankThreads = 1024;  // two blocks per CU share the LDS with their tables: 32 waves x 4 searches each
 // Search = one bucket lookup + a short binary search.  The key range [lo, hi] of the feature's table is cut into
 // kRankBuckets equal slices of 2^shift codes; starts[b] = number of keys in slices < b, and no slice holds P or more
@@ -2061,11 +2068,13 @@ static const Variant g_variants[] = {
 
 // ids: the perfect-tree kernels above, then the deep perfect-tree kernels of ddt_deep.hip, then the sparse-forest kernels of ddt_sparse.hip
 static constexpr int kDenseVariants = (int)(sizeof(g_variants) / sizeof(g_variants[0]));
-int num_variants() { return kDenseVariants + num_deep_variants() + num_sparse_variants(); }
+int num_variants() { return kDenseVariants + num_deep_variants() + num_sparse_variants() + num_sparse_r_variants(); }
 const Variant& variant(int i) {
   if (i < kDenseVariants) return g_variants[i];
   i -= kDenseVariants;
-  return i < num_deep_variants() ? deep_variant(i) : sparse_variant(i - num_deep_variants());
+  if (i < num_deep_variants()) return deep_variant(i);
+  i -= num_deep_variants();
+  return i < num_sparse_variants() ? sparse_variant(i) : sparse_r_variant(i - num_sparse_variants());
 }
 
 }  // namespace ddt

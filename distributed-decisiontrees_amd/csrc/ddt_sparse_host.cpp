@@ -108,6 +108,9 @@ static RankTables sparse_rank_tables(const ddt_params& p, const std::vector<cons
 
 void sparse_free(ddt_engine* e) {
   free_rank_device(e->sp_rank);
+  if (e->sp_r32_tab) (void)hipFree(e->sp_r32_tab);
+  e->sp_r32_tab = nullptr;
+  e->sp_r32_tab_bytes = 0;
   for (SparseForest& sp : e->sps) {
     for (void** p : {&sp.d_top, &sp.d_deep}) {
       if (*p) (void)hipFree(*p);
@@ -119,6 +122,27 @@ void sparse_free(ddt_engine* e) {
 }
 
 static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp, const RankTables* rt);
+static int sparse_pack_host_r(ddt_engine* e, const Variant& v, SparseForest& sp, const RankTables& rt, std::vector<uint32_t>& top, std::vector<uint32_t>& deep,
+                              uint32_t* groups_out);
+static int pack_rank32_tables(ddt_engine* e, const RankTables& rt, uint32_t W, RankHostTables& h, std::vector<uint32_t>& tab, uint32_t* blk_log2);
+
+// "sparse_r_*" (32-bit ranks, pair records on every deep level; ddt_sparse_r.hip): the largest K whose blocks still come two to a CU, then
+// one block per CU, 256-tuple tiles before 128
+static int pick_r32_variant(ddt_engine* e, uint32_t max_depth) {
+  const uint32_t W = tuple_words(e->p);
+  if (e->p.num_features > 256u) return -1;  // a node word carries the feature number in 8 bits
+  char name[40];
+  const int kcap = (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, 8u), 10u);
+  for (uint32_t budget : {kMaxLdsBytes / 2u, kMaxLdsBytes})
+    for (int T : {256, 128})
+      for (int K = e->sparse_top_levels >= 0 ? e->sparse_top_levels : kcap; K >= (e->sparse_top_levels >= 0 ? e->sparse_top_levels : 8); --K) {
+        snprintf(name, sizeof(name), "sparse_r_k%d_u8_t%d", K, T);
+        const int vid = find_variant(name);
+        if (vid >= 0 && variant(vid).lds_bytes_sparse(W) <= budget) return vid;
+      }
+  return -1;
+}
+
 static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest& sp, const RankTables* rt, std::vector<uint32_t>& top,
                             std::vector<uint32_t>& deep, uint32_t* groups_out);
 
@@ -137,6 +161,26 @@ int sparse_rebuild(ddt_engine* e) {
     return fail(e, DDT_ENOMEM, "rank table allocation failed");
   }
   int vid = pick_variant(e, max_depth, rt.max_len <= kQ16MaxTable);
+  // 32-bit ranks + pair records on every deep level (option "sparse_r32": -1 automatic, 0 never, 1 wherever such a kernel fits): for forests that
+  // go well below the top image -- every two levels there cost ONE gather instead of two -- and hold enough trees to carry the rank pre-pass
+  // (transpose + rank32_kernel per batch, which the fp32-tile kernels do not have)
+  if (e->forced_variant >= 0 && variant(e->forced_variant).r32()) {
+    const Variant& fv = variant(e->forced_variant);
+    if (e->p.num_features > 256u || rt.max_len > kSrMaxTable || fv.lds_bytes_sparse(tuple_words(e->p)) > kMaxLdsBytes) vid = -1;
+    else vid = e->forced_variant;
+  } else if (e->forced_variant < 0 && e->sparse_r32 != 0 && rt.max_len <= kSrMaxTable) {
+    // Automatic: where it measured faster on one MI355X (profiles/r06_sparse_r32.md; 4 M tuples, trees x depth x features: 512 x 16 x 64 +7 %, the
+    // same forest on 255 bins +30 %, 1000 x 13 x 28 +7 %, 128 x 14 x 20 +10 %, 512 x 16 x 32 +1 %) and not where it lost (64 x 16 x 64 -8 %,
+    // 256 x 12 x 64 -10 %, 512 x 10 x 64 -13 %, 128 features -3 %, and 780 k thresholds per feature -- key blocks of 32, eight gathers per value in the
+    // pre-pass -- -50 %): depth >= 13, at least two trees per tuple word (the pre-pass costs per word, the pair records pay per tree), tuples of at
+    // most 64 words (two 256-tuple blocks per CU), key blocks of four (at most 4 x 32767 distinct thresholds on a feature).
+    uint32_t trees = 0;
+    for (const SparseForest& sp : e->sps) trees += sp.trees();
+    const uint32_t W = tuple_words(e->p);
+    const bool pays = max_depth >= 13u && trees >= 2u * W && W <= 64u && rt.max_len <= 4u * kSrMaxDir && !getenv("DDT_R32_BLK_LOG2");
+    const int vr = (e->sparse_r32 > 0 || pays) ? pick_r32_variant(e, max_depth) : -1;
+    if (vr >= 0) vid = vr;
+  }
   // Dense mid levels (option "sparse_dm": -1 automatic, 0 never, M = exactly M): where the choice is a dense-level-K kernel that has
   // "sparse_dm<M>_*" siblings, the levels K .. K+M-1 become 8-byte heap records when the forest fills them at least half (the padding
   // under early leaves doubles per level).  Automatic = one mid level; more only when asked for (A/B)
@@ -195,6 +239,35 @@ int sparse_rebuild(ddt_engine* e) {
     return fail(e, DDT_EUNSUPPORTED, "no sparse kernel fits: %u tuple words need more than %u bytes of LDS (or the forced variant %d / "
                 "sparse_top_levels %d is not a sparse kernel that fits)", tuple_words(e->p), kMaxLdsBytes, e->forced_variant, e->sparse_top_levels);
   sparse_free(e);
+  free_q16_workspace(e);  // (its geometry follows the kernel family: u16 ranks in tiles of 1024, 32-bit rank words in tiles of the block size; callers have synchronised)
+  if (variant(vid).r32()) {  // directory + key blocks of the 32-bit rank pre-pass (shared by all classes)
+    RankHostTables h;
+    std::vector<uint32_t> tab;
+    uint32_t blk_log2 = 2;
+    int rc = pack_rank32_tables(e, rt, tuple_words(e->p), h, tab, &blk_log2);
+    if (rc) return rc;
+    rc = upload_rank_tables(e, h, e->sp_rank);
+    if (rc) return rc;
+    HIP_TRY(e, hipMalloc(&e->sp_r32_tab, tab.size() * 4u));
+    HIP_TRY(e, hipMemcpy(e->sp_r32_tab, tab.data(), tab.size() * 4u, hipMemcpyHostToDevice));
+    e->sp_r32_tab_bytes = tab.size() * 4u;
+    e->sp_r32_blk_log2 = blk_log2;
+    for (SparseForest& sp : e->sps) {
+      std::vector<uint32_t> top, deep;
+      uint32_t groups = 0;
+      rc = sparse_pack_host_r(e, variant(vid), sp, rt, top, deep, &groups);
+      if (rc) return rc;
+      HIP_TRY(e, hipMalloc(&sp.d_top, top.size() * 4u));
+      HIP_TRY(e, hipMalloc(&sp.d_deep, deep.size() * 4u));
+      HIP_TRY(e, hipMemcpy(sp.d_top, top.data(), top.size() * 4u, hipMemcpyHostToDevice));
+      HIP_TRY(e, hipMemcpy(sp.d_deep, deep.data(), deep.size() * 4u, hipMemcpyHostToDevice));
+      sp.top_bytes = top.size() * 4u;
+      sp.deep_bytes = deep.size() * 4u;
+      sp.groups = groups;
+    }
+    e->variant_id = vid;
+    return DDT_OK;
+  }
   const bool q = (variant(vid).opt & 1) != 0;
   if (q) {  // the tables of the rank pre-pass (shared by all classes)
     RankHostTables h;
@@ -433,6 +506,158 @@ static int sparse_pack_host(ddt_engine* e, const Variant& v, const SparseForest&
   return DDT_OK;
 }
 
+// Tables of the 32-bit rank pre-pass (ddt_internal.h R32Aux; ddt_sparse_r.hip rank32_kernel): per feature the keys in blocks of 2^blk_log2
+// (padded with INT_MAX, one all-pad block behind them) and the DIRECTORY of the blocks' last keys, which goes through pack_rank_tables like a
+// u16 table (flat [W][Kpad] + bucket starts + search parameters).  The block size is the smallest that keeps every directory within kSrMaxDir.
+static int pack_rank32_tables(ddt_engine* e, const RankTables& rt, uint32_t W, RankHostTables& h, std::vector<uint32_t>& tab, uint32_t* blk_log2_out) {
+  uint32_t bl = 2;
+  if (const char* v = getenv("DDT_R32_BLK_LOG2")) bl = std::min(std::max(atoi(v), 2), 8);  // A/B: larger blocks = smaller directories (more resident blocks per CU), more gathers per value
+  while (((uint64_t)rt.max_len + (1u << bl) - 1u) >> bl > kSrMaxDir) ++bl;
+  const uint32_t B = 1u << bl;
+  try {
+    RankTables dirt;
+    dirt.keys.resize(W);
+    std::vector<uint32_t> koff(W, 0u);
+    tab.clear();
+    for (uint32_t j = 0; j < W; ++j) {
+      const std::vector<uint32_t>& k = rt.keys[j];
+      const uint32_t nb = ((uint32_t)k.size() + B - 1u) / B;
+      koff[j] = (uint32_t)tab.size();
+      tab.insert(tab.end(), k.begin(), k.end());
+      tab.resize((size_t)koff[j] + (size_t)(nb + 1u) * B, 0x7FFFFFFFu);  // the last block's padding + one all-pad block
+      // (the last block's entry is the last REAL key, not its INT_MAX padding: the directory's key range -- what its bucket index slices -- stays
+      // the feature's own; values >= the largest key take the rank K without a search)
+      for (uint32_t b = 0; b < nb; ++b) dirt.keys[j].push_back(b + 1u < nb ? tab[(size_t)koff[j] + (size_t)b * B + B - 1u] : k.back());
+      if (dirt.keys[j].size() > dirt.max_len) dirt.max_len = (uint32_t)dirt.keys[j].size();
+    }
+    if ((uint64_t)tab.size() * 4u >= (1ull << 32)) return fail(e, DDT_EUNSUPPORTED, "rank tables of %zu keys exceed a 4 GiB buffer", tab.size());
+    const int rc = pack_rank_tables(e, dirt, W, false, h);
+    if (rc) return rc;
+    for (uint32_t j = 0; j < W; ++j) {
+      uint32_t* P = h.tabK.data() + (size_t)j * 8u;
+      P[5] = koff[j];
+      P[6] = (uint32_t)rt.keys[j].size();
+      P[7] = rt.keys[j].empty() ? 0x7FFFFFFFu : rt.keys[j].back();
+    }
+  } catch (const std::bad_alloc&) {
+    return fail(e, DDT_ENOMEM, "rank table allocation failed");
+  }
+  *blk_log2_out = bl;
+  return DDT_OK;
+}
+
+// Images of the "sparse_r_*" kernels (ddt_internal.h "32-bit ranks"): per tree a top image of one-word nodes and, in the deep array, its dense
+// block of level-K pair records followed by the exit blocks of the pair records below, level by level (breadth-first: measured faster than
+// depth-first for the one-record-per-level images, profiles/archive).  Also counts the record hops of the forest's longest path (sp.r_rounds).
+static int sparse_pack_host_r(ddt_engine* e, const Variant& v, SparseForest& sp, const RankTables& rt, std::vector<uint32_t>& top, std::vector<uint32_t>& deep,
+                              uint32_t* groups_out) {
+  const uint32_t K = (uint32_t)v.levels, T = sp.trees();
+  const uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
+  const uint32_t top_words = v.top_bytes_sparse() / 4u;  // 2^K per tree
+  uint32_t rounds = 1;
+  struct Todo {  // a pair record still to be written: rooted at tree node `node`, at record index `slot` of the deep array, `hop` records into the walk
+    uint32_t node, hop;
+    size_t slot;
+  };
+  try {
+    top.assign((size_t)groups * 8u * top_words, 0u);
+    // records 0 .. 2^K - 1: LEAF(+0) -- the dense block every EMPTY slot shares (DTPU.sv:544,760: an EMPTY slot adds exactly +0)
+    deep.assign((size_t)4u << K, 0u);
+    for (uint32_t q = 0; q < (1u << K); ++q) deep[4u * q] = kSrLeafRec;
+    std::vector<Cursor> cur, nxt;
+    std::vector<Todo> todo;
+    for (uint32_t i = 0; i < groups * 8u; ++i) {
+      uint32_t* t = top.data() + (size_t)i * top_words;
+      if (i >= T) {
+        t[0] = 0u - (16u << K);  // cbase of the shared block at byte 0
+        continue;                // (node words 0: feature 0 against rank 0 -- any direction ends in the block of LEAF(+0))
+      }
+      const uint32_t* L = sp.lines.data() + sp.first[i] * 4u;
+      auto child = [&](uint32_t n, uint32_t side) { return Cursor{((L[4u * n + 1u] >> (14u + side)) & 1u) != 0u, L[4u * n + 2u + side]}; };
+      auto node_word = [&](uint32_t n) -> uint32_t {  // R << 12 | flags | feature
+        const uint32_t j = L[4u * n + 1u] & 0x7FFu, key = thr_key(e->p, L[4u * n]);
+        const auto& k = rt.keys[j];
+        const uint32_t R = 1u + (uint32_t)(std::lower_bound(k.begin(), k.end(), key, [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; }) - k.begin());
+        return (R << 12) | (((L[4u * n + 1u] >> 13) & 1u) ? kSrMissRight : 0u) | (((L[4u * n + 1u] >> 14) & 1u) ? kSrLeftLeaf : 0u) |
+               (((L[4u * n + 1u] >> 15) & 1u) ? kSrRightLeaf : 0u) | j;
+      };
+      // ---- top heap, level by level (padding under an early leaf: node word 0, both children the leaf) ----
+      cur.assign(1, Cursor{false, 0u});
+      for (uint32_t lvl = 0; lvl < K; ++lvl) {
+        nxt.clear();
+        for (uint32_t k = 0; k < cur.size(); ++k) {
+          const uint32_t m = (1u << lvl) + k;
+          if (cur[k].leaf) {
+            if (m) t[m] = 0u;
+            nxt.push_back(cur[k]);
+            nxt.push_back(cur[k]);
+          } else {
+            t[m] = node_word(cur[k].v);
+            nxt.push_back(child(cur[k].v, 0));
+            nxt.push_back(child(cur[k].v, 1));
+          }
+        }
+        cur.swap(nxt);
+      }
+      // ---- the dense block of level K: a pair record per internal node, a LEAF record per (early) leaf ----
+      const size_t dense0 = deep.size() / 4u;
+      if ((dense0 + ((size_t)1u << K)) * 16u >= 0xFFFFFFF0ull) return fail(e, DDT_EUNSUPPORTED, "more than 4 GiB of deep records");
+      deep.resize(deep.size() + ((size_t)4u << K), 0u);
+      t[0] = (uint32_t)(dense0 * 16u) - (16u << K);
+      todo.clear();
+      for (uint32_t k = 0; k < cur.size(); ++k) {
+        if (cur[k].leaf) {
+          uint32_t* rec = deep.data() + (dense0 + k) * 4u;
+          rec[0] = kSrLeafRec;
+          rec[1] = rec[2] = cur[k].v;
+        } else {
+          todo.push_back(Todo{cur[k].v, 1u, dense0 + k});
+        }
+      }
+      // ---- pair records, breadth-first: writing one appends its exit block (2 or 4 slots) to the deep array ----
+      for (size_t q = 0; q < todo.size(); ++q) {
+        const Todo td = todo[q];
+        rounds = td.hop > rounds ? td.hop : rounds;
+        const uint32_t n = td.node;
+        const Cursor c0 = child(n, 0), c1 = child(n, 1);
+        uint32_t ptr = 0u;
+        const uint32_t inner = (c0.leaf ? 0u : 1u) + (c1.leaf ? 0u : 1u);
+        if (inner) {
+          const size_t block = deep.size() / 4u;
+          if ((block + 2u * inner) * 16u >= 0xFFFFFFF0ull) return fail(e, DDT_EUNSUPPORTED, "more than 4 GiB of deep records");
+          deep.resize(deep.size() + 8u * inner, 0u);
+          ptr = (uint32_t)(block * 16u) - (c0.leaf ? 32u : 0u);  // slot of the grandchild on side r1 of the child on side r0: ptr + 32 r0 + 16 r1
+          size_t slot = block;
+          for (const Cursor& c : {c0, c1}) {
+            if (c.leaf) continue;
+            for (uint32_t side = 0; side < 2; ++side, ++slot) {
+              const Cursor gc = child(c.v, side);
+              if (gc.leaf) {  // a leaf two levels down: a LEAF record in the grandchild's slot
+                uint32_t* rec = deep.data() + slot * 4u;
+                rec[0] = kSrLeafRec;
+                rec[1] = rec[2] = gc.v;
+                rounds = td.hop + 1u > rounds ? td.hop + 1u : rounds;
+              } else {
+                todo.push_back(Todo{gc.v, td.hop + 1u, slot});
+              }
+            }
+          }
+        }
+        uint32_t* rec = deep.data() + td.slot * 4u;
+        rec[0] = node_word(n);
+        rec[1] = c0.leaf ? c0.v : node_word(c0.v);
+        rec[2] = c1.leaf ? c1.v : node_word(c1.v);
+        rec[3] = ptr;
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    return fail(e, DDT_ENOMEM, "sparse image allocation failed");
+  }
+  sp.r_rounds = rounds;
+  *groups_out = groups;
+  return DDT_OK;
+}
+
 static int sparse_pack(ddt_engine* e, const Variant& v, SparseForest& sp, const RankTables* rt) {
   std::vector<uint32_t> top, deep;
   uint32_t groups = 0;
@@ -476,8 +701,28 @@ int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, f
     x.max_rounds = !(e->sparse_peel_last && e->sparse_idle_oob) ? 0xFFFFFFFFu :  // (the visit-only round tells a finished walker by the zeros of its out-of-range gather)
                     sp.max_depth > first_lvl ? sp.max_depth - first_lvl : 1u;
   }
-  x.idle_off = e->sparse_idle_oob ? 0xFFFFFFF0u : 0u;  // (the packers keep the deep array below 2^28 records, i.e. deep_bytes <= 0xFFFFFFF0: that offset is always out of range)
-  if (v.opt & 1) {  // rank-quantised: the batch's ranks + per-tile missing flags come from the q16 pre-pass (workspace slot e->q_slot)
+  if (v.r32()) x.max_rounds = sp.r_rounds;  // record hops on the forest's longest path, counted by the packer
+  x.idle_off = (e->sparse_idle_oob || v.r32()) ? 0xFFFFFFF0u : 0u;  // (the packers keep the deep array below 2^28 records, i.e. deep_bytes <= 0xFFFFFFF0: that offset is always out of range)
+  if (v.r32()) {  // 32-bit ranks: the batch's rank words + per-tile missing flags come from the rank32 pre-pass (workspace slot e->q_slot)
+    int rc = ensure_q16_workspace(e, n);
+    if (rc) return rc;
+    Q16Aux& qa = x.q16;
+    qa.xT = reinterpret_cast<uint32_t*>(e->q_xT[e->q_slot]);
+    qa.tile_flags = reinterpret_cast<uint32_t*>(e->q_flags[e->q_slot]);
+    qa.tables = reinterpret_cast<const uint32_t*>(e->sp_rank.d_tables);  // the directories
+    qa.tabP = reinterpret_cast<const uint32_t*>(e->sp_rank.d_tabK);
+    qa.tabS = reinterpret_cast<const uint16_t*>(e->sp_rank.d_tabS);
+    qa.Kpad = e->sp_rank.Kpad;
+    qa.skip_prepass = reuse_prepass ? 1u : 0u;
+    qa.n_pad = (n + 1023) / 1024 * 1024;
+    x.r32.r = reinterpret_cast<uint32_t*>(e->q_q[e->q_slot]);
+    x.r32.tab = reinterpret_cast<const uint32_t*>(e->sp_r32_tab);
+    x.r32.tab_bytes = (uint32_t)e->sp_r32_tab_bytes;
+    x.r32.blk_log2 = e->sp_r32_blk_log2;
+    x.r32.tile = (uint32_t)v.threads;
+    if (e->tev_cur) a.ev_mid = e->tev_cur[1];
+    else if (e->ev_fork && !reuse_prepass) a.ev_mid = e->ev_fork;
+  } else if (v.opt & 1) {  // rank-quantised: the batch's ranks + per-tile missing flags come from the q16 pre-pass (workspace slot e->q_slot)
     int rc = ensure_q16_workspace(e, n);
     if (rc) return rc;
     Q16Aux& qa = x.q16;
@@ -653,20 +898,21 @@ extern "C" int ddt_debug_sparse_image(const ddt_params* p, const void* node_line
   uint32_t groups = 0;
   RankTables rt;
   const bool q = (v.opt & 1) != 0;
-  if (q) {
+  if (q || v.r32()) {
     try {
       rt = sparse_rank_tables(*p, {&sp});
     } catch (const std::bad_alloc&) {
       return DDT_ENOMEM;
     }
-    if (rt.max_len > kQ16MaxTable) return DDT_EUNSUPPORTED;
+    if (rt.max_len > (v.r32() ? kSrMaxTable : kQ16MaxTable)) return DDT_EUNSUPPORTED;
+    if (v.r32() && p->num_features > 256u) return DDT_EUNSUPPORTED;
   }
-  rc = sparse_pack_host(e.get(), v, sp, q ? &rt : nullptr, top, deep, &groups);
+  rc = v.r32() ? sparse_pack_host_r(e.get(), v, sp, rt, top, deep, &groups) : sparse_pack_host(e.get(), v, sp, q ? &rt : nullptr, top, deep, &groups);
   if (rc) return rc;
   info_out[0] = top.size();
   info_out[1] = deep.size();
   info_out[2] = groups;
-  info_out[3] = (uint64_t)v.levels;
+  info_out[3] = (uint64_t)v.levels | (v.r32() ? (uint64_t)sp.r_rounds << 32 : 0ull);
   info_out[4] = v.feat_off_sparse();
   info_out[5] = v.row_bytes_sparse();
   if (top_out) {
@@ -676,6 +922,49 @@ extern "C" int ddt_debug_sparse_image(const ddt_params* p, const void* node_line
   if (deep_out) {
     if (deep_cap_words < deep.size()) return DDT_EINVAL;
     memcpy(deep_out, deep.data(), deep.size() * 4u);
+  }
+  return DDT_OK;
+}
+
+// Host-only test hook (include/ddt.h): the tables of the 32-bit rank pre-pass from sorted distinct keys per tuple word.
+extern "C" int ddt_debug_rank32_tables(const uint32_t* keys, const uint32_t* counts, uint32_t n_words, uint32_t* dir_out, size_t dir_cap_words,
+                                       uint32_t* par_out, uint16_t* starts_out, uint32_t* tab_out, size_t tab_cap_words, uint64_t info_out[4]) {
+  if (!keys || !counts || !info_out || n_words == 0 || n_words > 2048u || (n_words & 3u)) return DDT_EINVAL;
+  RankTables rt;
+  try {
+    rt.keys.resize(n_words);
+    size_t off = 0;
+    for (uint32_t w = 0; w < n_words; ++w) {
+      if (counts[w] > kSrMaxTable) return DDT_EUNSUPPORTED;
+      rt.keys[w].assign(keys + off, keys + off + counts[w]);
+      for (uint32_t i = 1; i < counts[w]; ++i)
+        if (!((int32_t)rt.keys[w][i - 1] < (int32_t)rt.keys[w][i])) return DDT_EINVAL;  // sorted, distinct
+      off += counts[w];
+      rt.max_len = counts[w] > rt.max_len ? counts[w] : rt.max_len;
+    }
+  } catch (const std::bad_alloc&) {
+    return DDT_ENOMEM;
+  }
+  std::unique_ptr<ddt_engine> e(new (std::nothrow) ddt_engine());
+  if (!e) return DDT_ENOMEM;
+  RankHostTables h;
+  std::vector<uint32_t> tab;
+  uint32_t bl = 2;
+  const int rc = pack_rank32_tables(e.get(), rt, n_words, h, tab, &bl);
+  if (rc) return rc;
+  info_out[0] = h.Kpad;
+  info_out[1] = bl;
+  info_out[2] = tab.size();
+  info_out[3] = 0;
+  if (dir_out) {
+    if (dir_cap_words < h.tab.size()) return DDT_EINVAL;
+    memcpy(dir_out, h.tab.data(), h.tab.size() * 4u);
+  }
+  if (par_out) memcpy(par_out, h.tabK.data(), h.tabK.size() * 4u);
+  if (starts_out) memcpy(starts_out, h.tabS.data(), h.tabS.size() * 2u);
+  if (tab_out) {
+    if (tab_cap_words < tab.size()) return DDT_EINVAL;
+    memcpy(tab_out, tab.data(), tab.size() * 4u);
   }
   return DDT_OK;
 }

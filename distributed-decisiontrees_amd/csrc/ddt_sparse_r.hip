@@ -1,0 +1,375 @@
+// ddt_sparse_r.hip -- SPARSE forests on 32-bit ranks: pair records on EVERY level below the top image (round 6; BASELINE config 4).
+//
+// Why: the sparse kernel of ddt_sparse.hip is bound by the NUMBER of gather wave-instructions it issues (7.0 per tree and wave on
+// 512 trees x depth <= 16 x 64 features, ~33 cycles of the CU's vector-memory pipe each = 89 % of its cycles, profiles/r05_pmc_cfg2_cfg4_cfg6.md
+// section 7): one 16-byte record {fp32 key, w, left, right} decides ONE level.  Three nodes fit 16 bytes only as one-word nodes, i.e. with
+// RANKS for thresholds -- and u16 ranks (the q16 pre-pass) stop at 65 k distinct thresholds per feature where this forest has ~100 k.  So the
+// ranks here are 20 bits wide and the feature tile stays 32 bits per value (the fp32 tile's size: two blocks of 256 tuples x 64 features per CU,
+// like `sparse_dp_k8_u8_t256`); a node is ONE word {rank : 20 | flags : 4 | feature : 8}, the tile holds rank(x) << 12 | 0xFFF, and the compare
+// !(x < t) (DTPU.sv:653-657) is ONE unsigned compare of the two words (ddt_internal.h "32-bit ranks").  Per tree:
+//   top     K levels out of LDS, 4 bytes per node (K = 9 in the 16 KiB that held K = 8 as 8-byte records)
+//   deep    16-byte PAIR records {node, left child, right child, ptr}: one gather decides TWO levels on every level below; early leaves
+//           are the child words themselves (flag in the node), a leaf two levels down is a LEAF record in the grandchild's slot.
+// Depth 16 with K = 9: 4 gather instructions per tree and wave.  The per-node work is the reference's (read node -> gather feature ->
+// compare / missing rule -> next node, DTPU.sv:579-720), the sums run in its adder order (FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131,
+// Core.sv:486-541).  What the ranks cost: a pre-pass per batch (transpose + rank32_kernel below) that the fp32-tile kernels do not have.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "ddt_device.h"
+#include "ddt_internal.h"
+
+namespace ddt {
+
+// ---------------------------------------------------------------------------------------------------
+// rank32_kernel: r(x) = #{keys <= x} against tables too long for LDS (100 k keys = 400 KiB per feature).  LDS holds the feature's DIRECTORY --
+// the last key of every block of 2^blk_log2 keys, searched like rank_kernel's table (bucket lookup + log2 P probes, ddt_kernels.hip) --
+// which names the one block that holds the answer; that block comes from global memory (L2-resident: the blocks of all features are a few
+// tens of MB) with ONE 16-byte gather per four keys.  Output: x' = r << 12 | 0xFFF in tiles [n_pad / T][W][T] (a missing value: 0xFFFFFFFF and
+// its tile's flag), what score_sparse_r_kernel DMAs into LDS.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kR32Threads = 1024;
+
+template <int POLICY>
+__global__ __launch_bounds__(kR32Threads) void rank32_kernel(const uint32_t* __restrict__ xT, uint64_t n, uint64_t n_pad, const uint32_t* __restrict__ dir,
+                                                             uint32_t Dpad, const uint32_t* __restrict__ tabP, const uint16_t* __restrict__ tabS,
+                                                             const uint32_t* __restrict__ tab, uint32_t tab_bytes, uint32_t blk_log2, uint32_t miss_raw,
+                                                             uint32_t ieee, uint32_t W, uint32_t tile_log2, uint32_t* __restrict__ r32,
+                                                             uint32_t* __restrict__ tile_flags) {
+  // Feature -> XCD affinity: workgroups go to the 8 XCDs round-robin by their linear id, and every value's key-block gather wants its feature's
+  // blocks in THAT XCD's L2 (100 k keys = 400 KiB per feature, 25 MB for 64 features against 4 MB of L2 per XCD).  So the grid is linear and
+  // feature j is only ever worked on by the blocks with id % 8 == j % 8: an XCD sees W / 8 features' tables.
+  const uint32_t tid = threadIdx.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, fper = (W + 7u) / 8u;
+  const uint32_t j = xcd + 8u * (slot % fper), chunk = slot / fper, chunks = gridDim.x / (8u * fper);
+  if (j >= W) return;
+  // (entry i at i + i / 32: the probes of a power-of-two search would otherwise all land in one bank, see rank_kernel)
+  for (uint32_t i = tid; i < Dpad; i += kR32Threads) lds_st_u32((i + (i >> 5)) * 4u, dir[(size_t)j * Dpad + i]);
+  const uint32_t starts_off = (Dpad + (Dpad >> 5) + 1u) * 4u;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(tabS + (size_t)j * kQ16RankBuckets);
+    for (uint32_t i = tid; i < kQ16RankBuckets / 2u; i += kR32Threads) lds_st_u32(starts_off + i * 4u, src[i]);
+  }
+  __syncthreads();
+  const uint32_t Kd = tabP[j * 8u + 0u], lo = tabP[j * 8u + 1u], shift = tabP[j * 8u + 3u], P = tabP[j * 8u + 4u];
+  const uint32_t koff = tabP[j * 8u + 5u], K = tabP[j * 8u + 6u], hi_real = tabP[j * 8u + 7u];
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(tab), 0, (int)tab_bytes, 0x00020000);
+  const uint32_t quads = 1u << (blk_log2 - 2u);  // 16-byte gathers per block
+  constexpr int ILP = 4;  // independent searches per lane: the dependent LDS reads of one search are latency bound
+  const uint64_t pass_rows = (uint64_t)kR32Threads * ILP, pass_stride = (uint64_t)chunks * pass_rows;
+  auto load_pass = [&](uint32_t (&dst)[ILP], uint64_t row0) {
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) {
+      const uint64_t row = row0 + (uint64_t)i * kR32Threads + tid;
+      dst[i] = row < n_pad ? __builtin_nontemporal_load(xT + (uint64_t)j * n_pad + row) : 0u;  // (streamed once: keep the L2 for the key blocks)
+    }
+  };
+  uint32_t raw_next[ILP];
+  load_pass(raw_next, (uint64_t)chunk * pass_rows);
+  for (uint64_t row0 = (uint64_t)chunk * pass_rows; row0 < n_pad; row0 += pass_stride) {
+    uint32_t raw[ILP], pos[ILP];
+    int32_t x[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) raw[i] = raw_next[i];
+    load_pass(raw_next, row0 + pass_stride);  // the next pass's column values fly while this pass searches
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) {
+      x[i] = (int32_t)(ieee ? ieee_key(raw[i]) : raw[i]);
+      uint32_t b = ((uint32_t)x[i] - lo) >> shift;  // wraps to a huge value below lo: selected away next
+      b = b < kQ16RankBuckets - 1u ? b : kQ16RankBuckets - 1u;
+      b = x[i] < (int32_t)lo ? 0u : b;
+      pos[i] = *reinterpret_cast<const DDT_LDS(uint16_t)*>(starts_off + b * 2u);
+    }
+    for (uint32_t step = P >> 1; step >= 1u; step >>= 1) {
+#pragma unroll
+      for (int i = 0; i < ILP; ++i) {
+        uint32_t probe = pos[i] + step - 1u;
+        probe = probe < Dpad - 1u ? probe : Dpad - 1u;  // entry Dpad-1 is always an INT_MAX pad
+        if ((int32_t)lds_u32((probe + (probe >> 5)) * 4u) <= x[i]) pos[i] += step;
+      }
+    }
+    // pos = number of blocks whose LAST key is <= x: all their keys count, and block `pos` holds the rest of the answer
+    uint32_t cnt[ILP], byte[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) {
+      pos[i] = pos[i] < Kd ? pos[i] : Kd;  // (block Kd is the all-pad block behind the feature's keys)
+      byte[i] = (koff + (pos[i] << blk_log2)) * 4u;
+      cnt[i] = 0u;
+    }
+    for (uint32_t qd = 0; qd < quads; ++qd) {
+      u32x4 v[ILP];
+#pragma unroll
+      for (int i = 0; i < ILP; ++i) {
+        if (POLICY == 0) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, byte[i] + 16u * qd, 0, 0);
+        else if (POLICY == 1) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, byte[i] + 16u * qd, 0, 16);  // sc1: served by the L2, no L1 line
+        else v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, byte[i] + 16u * qd, 0, 2);                      // nt
+      }
+#pragma unroll
+      for (int i = 0; i < ILP; ++i)
+        cnt[i] += ((int32_t)v[i].x <= x[i] ? 1u : 0u) + ((int32_t)v[i].y <= x[i] ? 1u : 0u) + ((int32_t)v[i].z <= x[i] ? 1u : 0u) +
+                  ((int32_t)v[i].w <= x[i] ? 1u : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < ILP; ++i) {
+      const uint64_t row = row0 + (uint64_t)i * kR32Threads + tid;
+      uint32_t r = (pos[i] << blk_log2) + cnt[i];
+      r = r < K ? r : K;
+      r = x[i] >= (int32_t)hi_real ? K : r;  // (also what keeps the INT_MAX pads of the last block out of the count)
+      uint32_t out = (r << 12) | 0xFFFu;
+      if (raw[i] == miss_raw && row < n) {  // bit equality with the missing pattern (DTPU.sv:653), before any transform
+        out = kSrMissing;
+        atomicOr(&tile_flags[row >> tile_log2], 1u);
+      }
+      if (row < n_pad) __builtin_nontemporal_store(out, r32 + ((((row >> tile_log2) * W + j) << tile_log2) + (row & ((1u << tile_log2) - 1u))));
+    }
+  }
+}
+
+hipError_t launch_r32_prepass(const ScoreArgs& a, const SparseAux& x, hipStream_t s) {
+  const Q16Aux& q = x.q16;
+  const R32Aux& r = x.r32;
+  const uint32_t W = a.tuple_words;
+  uint32_t tile_log2 = 0;
+  while ((1u << tile_log2) < r.tile) ++tile_log2;
+  const uint64_t tiles = q.n_pad >> tile_log2;
+  if (tiles == 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(q.tile_flags, 0, tiles * 4u, s);
+  if (e != hipSuccess) return e;
+  e = launch_transpose(a.tuples, W, a.n, q.n_pad, q.xT, s);
+  if (e != hipSuccess) return e;
+  const uint32_t lds = (q.Kpad + (q.Kpad >> 5) + 1u) * 4u + kQ16RankBuckets * 2u;
+  static const int policy = [] {  // A/B: cache policy of the key-block gathers (DDT_R32_POLICY = 0 default / 1 sc1 / 2 nt)
+    const char* v = getenv("DDT_R32_POLICY");
+    return v && v[0] ? atoi(v) : 0;
+  }();
+  auto kern = policy == 1 ? rank32_kernel<1> : policy == 2 ? rank32_kernel<2> : rank32_kernel<0>;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  // long-lived blocks: the directory (up to 128 KiB) is loaded once per block -- resident blocks per CU x CUs, split over the features
+  const uint32_t per_cu = lds <= 80u * 1024u ? 2u : 1u;
+  uint32_t bx = (uint32_t)((q.n_pad + kR32Threads * 4u - 1u) / (kR32Threads * 4u));  // row chunks per feature
+  const uint32_t fper = (W + 7u) / 8u;                                                // features per XCD
+  const uint32_t want = (per_cu * a.num_cus + 8u * fper - 1u) / (8u * fper);
+  if (bx > want) bx = want < 1u ? 1u : want;
+  hipLaunchKernelGGL(kern, dim3(8u * fper * bx), dim3(kR32Threads), lds, s, q.xT, a.n, q.n_pad, q.tables, q.Kpad, q.tabP, q.tabS, r.tab, r.tab_bytes,
+                     r.blk_log2, a.miss_raw, a.ieee, W, tile_log2, r.r, q.tile_flags);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The walk.  lane = tuple, U = 8 trees (one PU group) in lock-step, THREADS tuples per block with their rank words feature-major in LDS.
+// ---------------------------------------------------------------------------------------------------
+// x' >= rec, or the node's missing direction for a missing value (DTPU.sv:653-667).  Logical operators on purpose: hipcc keeps such lane
+// predicates as SGPR masks (ddt_sparse.hip sp_right)
+template <bool SLOW>
+__device__ __forceinline__ bool sr_right(uint32_t f, uint32_t rec) {
+  const bool ge = f >= rec;
+  if (!SLOW) return ge;
+  const bool miss = f == kSrMissing, mr = (rec & kSrMissRight) != 0u;
+  return (miss && mr) || (!miss && ge);
+}
+
+template <int K, int U, int THREADS, bool SLOW>
+__device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
+  constexpr int TOPB = 4 << K;       // bytes of one tree's top image
+  constexpr int STEPB = U * TOPB;    // top images resident per pass
+  constexpr uint32_t ROWB = (uint32_t)THREADS * 4u;
+  constexpr uint32_t FEAT_OFF = (uint32_t)((STEPB + ROWB - 1) / ROWB * ROWB);
+  static_assert((ROWB & (ROWB - 1u)) == 0u, "a feature row is a power of two");
+  constexpr uint32_t ROW_LOG2 = THREADS == 512 ? 11u : THREADS == 256 ? 10u : 9u;
+  static_assert((1u << ROW_LOG2) == ROWB, "tiles of 128 / 256 / 512 tuples");
+  const uint32_t lane_off = FEAT_OFF + (uint32_t)tid * 4u;
+  auto feat = [&](uint32_t rec) -> uint32_t { return lds_u32(((rec & kSrFeatMask) << ROW_LOG2) + lane_off); };
+  const uint32_t C = a.clusters;
+  const uint32_t n_steps = x.n_groups * 8u / (uint32_t)U;
+  const uint32_t max_rounds = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.max_rounds);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(x.deep), 0, (int)x.deep_bytes, 0x00020000);
+  const uint32_t idle_off = x.idle_off;  // beyond the resource's range: a finished walker's gather returns zeros and touches no cache
+  for (uint32_t g = 0; g < n_steps; ++g) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the top images of this pass (and, first pass, the rank tile) are in LDS for everyone
+
+    // ---- top phase: K levels over one-word nodes, 1-based heap in bytes: m4 <- 2 m4 + 4 right ----
+    uint32_t m4[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) m4[u] = 4u;
+#pragma unroll
+    for (int lvl = 0; lvl < K; ++lvl) {
+      uint32_t nd[U], f[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) nd[u] = lds_u32(m4[u] + (uint32_t)(u * TOPB));
+#pragma unroll
+      for (int u = 0; u < U; ++u) f[u] = feat(nd[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) m4[u] = (m4[u] << 1) + (sr_right<SLOW>(f[u], nd[u]) ? 4u : 0u);
+    }
+    uint32_t cb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));  // word 0 of the tree: cbase of its dense block of level-K pair records
+    __syncthreads();  // every wave is through with the top images: the buffer is free
+    if (g + 1 < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
+
+    // ---- deep phase: one 16-byte gather per TWO levels; a rotating pipeline of U chains (the gather of tree u's next record is issued right
+    //      after ITS visit and flies while the other seven are visited), gathers unconditional and in a fixed order (ddt_sparse.hip) ----
+    bool act[U];
+    float leafv[U];
+    u32x4 rr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      act[u] = true;
+      leafv[u] = 0.f;
+      rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m4[u] << 2), 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // A round = two HALF rounds of four trees.  The visits of a half advance together, stage by stage -- four feature reads of the nodes in
+    // flight, then four of the children, then the four gathers back to back -- so that a half round exposes the LDS latency twice, not eight
+    // times (with one visit after the other the chain node read -> compare -> child read -> compare of every tree stood alone: at two waves per
+    // SIMD that left the vector-memory pipe idle for a third of the kernel, 29.3 ms against a floor of 17 on BASELINE config 4); the other
+    // half's gathers fly meanwhile.
+    bool alive = true;
+    if (max_rounds > 1u) {
+      uint32_t r = 1u;
+      do {
+        bool any = false;
+#pragma unroll
+        for (int h = 0; h < U; h += 4) {
+          uint32_t fn[4], fc[4], cw[4], cn[4];
+          bool r0[4], leaf[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {  // the records stay opaque until their half's visits: nothing of them is hoisted in front of the other half's gathers
+            asm volatile("" : "+v"(rr[h + i].x), "+v"(rr[h + i].y), "+v"(rr[h + i].z), "+v"(rr[h + i].w));
+            fn[i] = feat(rr[h + i].x);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            r0[i] = sr_right<SLOW>(fn[i], rr[h + i].x);
+            cw[i] = r0[i] ? rr[h + i].z : rr[h + i].y;
+            leaf[i] = (rr[h + i].x & (r0[i] ? kSrRightLeaf : kSrLeftLeaf)) != 0u;
+            cn[i] = leaf[i] ? 0u : cw[i];
+            fc[i] = feat(cn[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool r1 = sr_right<SLOW>(fc[i], cn[i]);
+            const uint32_t nxt = rr[h + i].w + (r0[i] ? 32u : 0u) + (r1 ? 16u : 0u);
+            if (act[h + i] && leaf[i]) leafv[h + i] = __uint_as_float(cw[i]);
+            act[h + i] = act[h + i] && !leaf[i];
+            any = any || act[h + i];
+            rr[h + i] = __builtin_amdgcn_raw_buffer_load_b128(rs, act[h + i] ? nxt : idle_off, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        alive = __ballot(any) != 0ull;
+      } while (alive && ++r < max_rounds);
+    }
+    if (!alive) {
+      // the wave left early with its last round's (idle) gathers in flight: consume them, so that both exits reach the next pass with nothing
+      // outstanding in the compiler's books
+#pragma unroll
+      for (int u = 0; u < U; ++u) asm volatile("" : : "v"(rr[u].x), "v"(rr[u].y), "v"(rr[u].z), "v"(rr[u].w));
+    }
+    if (alive) {
+      // the last round: visits only.  A walker that is still alive stands on a record whose taken side is a leaf (the host counted the rounds:
+      // SparseAux::max_rounds); a finished one has the zeros its out-of-range gather returned -- no leaf flag
+#pragma unroll
+      for (int h = 0; h < U; h += 4) {
+        uint32_t fn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          asm volatile("" : "+v"(rr[h + i].x), "+v"(rr[h + i].y), "+v"(rr[h + i].z), "+v"(rr[h + i].w));
+          fn[i] = feat(rr[h + i].x);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool r0 = sr_right<SLOW>(fn[i], rr[h + i].x);
+          if ((rr[h + i].x & (r0 ? kSrRightLeaf : kSrLeftLeaf)) != 0u) leafv[h + i] = __uint_as_float(r0 ? rr[h + i].z : rr[h + i].y);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+#pragma unroll
+    for (int h = 0; h < U / 8; ++h) {
+      if (a.sum_mode == 1) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dacc += (double)leafv[8 * h + u];
+      } else {  // FPAddersReduceTree.sv:94-141, then the slot accumulate of this group's cluster
+        const float lf[1][8] = {{leafv[8 * h + 0], leafv[8 * h + 1], leafv[8 * h + 2], leafv[8 * h + 3], leafv[8 * h + 4], leafv[8 * h + 5],
+                                 leafv[8 * h + 6], leafv[8 * h + 7]}};
+        double unused[1] = {0.0};
+        fold_leaves<8, 1, 0>(lf, 0, C, ra, unused, a.sum_mode == 2);
+      }
+    }
+  }
+}
+
+template <int K, int U, int THREADS>
+__global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs a, const SparseAux x) {
+  constexpr int TOPB = 4 << K;
+  constexpr int STEPB = U * TOPB;
+  constexpr int ROW = THREADS * 4;
+  constexpr int FEAT_OFF = (STEPB + ROW - 1) / ROW * ROW;
+  static_assert(U == 8, "one PU group per pass");
+  static_assert((STEPB / 16) % 64 == 0, "whole waves per DMA");
+  const int tid = threadIdx.x;
+  const uint64_t tile0 = (uint64_t)blockIdx.x * THREADS;
+  const uint32_t W = a.tuple_words;
+
+  dma_chunk<THREADS, STEPB>(a.img, 0, 0, tid);  // top images of the first pass
+  {
+    // the rank tile is one contiguous block of W * ROW bytes of the pre-pass's output: DMA it in; the first barrier of the walk publishes it
+    const uint4* src = reinterpret_cast<const uint4*>(x.r32.r + (uint64_t)blockIdx.x * W * (uint32_t)THREADS);
+    const uint32_t units = W * (ROW / 16);
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    for (uint32_t u0 = 0; u0 < units; u0 += THREADS) {
+      const uint32_t lds_addr = (uint32_t)FEAT_OFF + (u0 + (uint32_t)wave_base) * 16u;
+      const uint4* g = src + (u0 + (uint32_t)tid);
+      if (u0 + (uint32_t)wave_base < units)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
+    }
+  }
+  const bool slow = __builtin_amdgcn_readfirstlane((int)x.q16.tile_flags[blockIdx.x]) != 0;  // the tile holds a missing value
+
+  RefAcc<1> ra;
+  ra.init();
+  double dacc = 0.0;
+  const uint32_t C = a.clusters;
+  if (!slow) sparse_r_walk<K, U, THREADS, false>(a, x, tid, ra, dacc);
+  else sparse_r_walk<K, U, THREADS, true>(a, x, tid, ra, dacc);
+  ra.align(C);
+  const uint64_t row = tile0 + (uint64_t)tid;
+  if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
+}
+
+template <int K, int U, int THREADS>
+static hipError_t launch_sparse_r_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
+  const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
+  const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
+  auto kern = score_sparse_r_kernel<K, U, THREADS>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  if (!x.q16.skip_prepass) {  // ranks + per-tile missing flags of this batch (reused by the other classes' launches)
+    e = launch_r32_prepass(a, x, s);
+    if (e != hipSuccess) return e;
+  }
+  if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
+  hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(THREADS), lds, s, a, x);
+  return hipGetLastError();
+}
+
+#define DDT_SPR(K, U, T) /* levels = K, threads = tile = T, opt bit 5 */ \
+  Variant { "sparse_r_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 32, &launch_sparse_r_v<K, U, T> }
+
+static const Variant g_sparse_r_variants[] = {
+    // two blocks of 256 tuples per CU at 64 features with K = 9 (2 x (16 + 64) KiB); K = 10 up to 48 features; K = 8 beyond 64 features (a block per CU)
+    DDT_SPR(8, 8, 256), DDT_SPR(9, 8, 256), DDT_SPR(10, 8, 256),
+    DDT_SPR(8, 8, 128), DDT_SPR(9, 8, 128),
+};
+
+int num_sparse_r_variants() { return (int)(sizeof(g_sparse_r_variants) / sizeof(g_sparse_r_variants[0])); }
+const Variant& sparse_r_variant(int i) { return g_sparse_r_variants[i]; }
+
+}  // namespace ddt

@@ -241,6 +241,102 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
   return hipSuccess;
 }
 
+// "sparse_r_*" (csrc/ddt_sparse_r.hip): the 32-bit rank pre-pass -- the kernel's own search (bucket lookup + probes over the DIRECTORY, then the
+// count inside the one block it names) on the tables the engine packed and uploaded; mock layout of the workspace: r[row][feature]
+uint32_t rank32_of(const Q16Aux& q, const R32Aux& r, uint32_t j, uint32_t raw, uint32_t ieee) {
+  const int32_t key = (int32_t)(ieee ? ieee_key(raw) : raw);
+  const uint32_t* P = q.tabP + (size_t)j * 8u;
+  const uint32_t Kd = P[0], lo = P[1], shift = P[3], Pp = P[4], koff = P[5], K = P[6], hi_real = P[7], B = 1u << r.blk_log2;
+  uint32_t b = ((uint32_t)key - lo) >> shift;
+  b = b < kQ16RankBuckets - 1u ? b : kQ16RankBuckets - 1u;
+  if (key < (int32_t)lo) b = 0u;
+  uint32_t pos = q.tabS[(size_t)j * kQ16RankBuckets + b];
+  for (uint32_t step = Pp >> 1; step >= 1u; step >>= 1) {
+    uint32_t probe = pos + step - 1u;
+    probe = probe < q.Kpad - 1u ? probe : q.Kpad - 1u;
+    if ((int32_t)q.tables[(size_t)j * q.Kpad + probe] <= key) pos += step;
+  }
+  pos = pos < Kd ? pos : Kd;
+  uint32_t cnt = 0;
+  for (uint32_t i = 0; i < B; ++i) cnt += (int32_t)r.tab[(size_t)koff + (size_t)pos * B + i] <= key ? 1u : 0u;
+  uint32_t rk = pos * B + cnt;
+  rk = rk < K ? rk : K;
+  if (key >= (int32_t)hi_real) rk = K;
+  return rk;
+}
+
+void enqueue_prepass_r32(const ScoreArgs& a, const SparseAux& x, hipStream_t s) {
+  const uint32_t W = a.tuple_words;
+  Op* pre = new Op();
+  pre->cost = (double)a.n * g_cost_row * 0.05;
+  pre->run = [=] {
+    const uint32_t T = x.r32.tile;
+    for (uint64_t t = 0; t < (a.n + T - 1) / T; ++t) x.q16.tile_flags[t] = 0u;
+    for (uint64_t i = 0; i < a.n; ++i)
+      for (uint32_t j = 0; j < W; ++j) {
+        const uint32_t raw = a.tuples[i * W + j];
+        uint32_t out;
+        if (raw == a.miss_raw) {
+          out = kSrMissing;
+          x.q16.tile_flags[i / T] = 1u;
+        } else {
+          out = (rank32_of(x.q16, x.r32, j, raw, a.ieee) << 12) | 0xFFFu;
+        }
+        x.r32.r[i * W + j] = out;
+      }
+  };
+  enqueue(s, pre);
+}
+
+// ... and the walk over one-word nodes and pair records (csrc/ddt_internal.h "32-bit ranks")
+hipError_t launch_sparse_r(const ScoreArgs& args, const Variant& var, hipStream_t s) {
+  const ScoreArgs a = args;
+  const Variant v = var;
+  const SparseAux x = *reinterpret_cast<const SparseAux*>(args.aux);
+  if (!x.q16.skip_prepass) enqueue_prepass_r32(a, x, s);
+  if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
+  Op* op = new Op();
+  op->cost = (double)a.n * g_cost_row;
+  op->run = [=] {
+    const uint32_t K = a.levels, W = a.tuple_words, tw = v.top_bytes_sparse() / 4u;
+    const uint32_t* top = reinterpret_cast<const uint32_t*>(a.img);
+    const uint32_t* deep = reinterpret_cast<const uint32_t*>(x.deep);
+    std::vector<float> leaf(a.n_trees);
+    for (uint64_t i = 0; i < a.n; ++i) {
+      const uint32_t* rk = x.r32.r + i * W;
+      const bool slow = x.q16.tile_flags[i / x.r32.tile] != 0u;
+      auto right = [&](uint32_t rec) -> uint32_t {
+        const uint32_t f = rk[rec & kSrFeatMask];
+        if (slow && f == kSrMissing) return (rec & kSrMissRight) ? 1u : 0u;
+        return f >= rec ? 1u : 0u;
+      };
+      for (uint32_t slot = 0; slot < a.n_trees; ++slot) {
+        const uint32_t* tr = top + (size_t)slot * tw;
+        uint32_t m = 1;
+        for (uint32_t lvl = 0; lvl < K; ++lvl) m = 2u * m + right(tr[m]);
+        uint32_t byte = tr[0] + 16u * m;
+        float lf = 0.0f;
+        uint32_t hops = 0;
+        for (;;) {
+          ++hops;
+          const uint32_t* rec = deep + byte / 4u;
+          const uint32_t r0 = right(rec[0]), cw = rec[1u + r0];
+          if (rec[0] & (r0 ? kSrRightLeaf : kSrLeftLeaf)) {
+            lf = f_of(cw);
+            break;
+          }
+          byte = rec[3] + 32u * r0 + 16u * right(cw);
+        }
+        if (hops > x.max_rounds) lf = __builtin_nanf("");  // the kernel would have stopped gathering: a wrong round count must show
+        leaf[slot] = lf;
+      }
+      a.out[i] = reduce(leaf.data(), a.n_trees, a.clusters, a.sum_mode);
+    }
+  };
+  enqueue(s, op);
+  return hipSuccess;
+}
+
 // sparse (explicit-children) forests: per PU group of 8 trees the top image (first K levels as a perfect heap, level K-1 as
 // 16-byte records), then the deep records -- csrc/ddt_internal.h "Sparse forests", csrc/ddt_sparse.hip
 hipError_t launch_sparse(const ScoreArgs& args, const Variant& var, hipStream_t s) {
@@ -354,6 +450,9 @@ const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
     Variant{"sparse_qd_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3, &launch_sparse},
     Variant{"sparse_qp_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3 | 16, &launch_sparse, 2},
     Variant{"sparse_gf_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 4, &launch_sparse},
+    Variant{"sparse_r_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 32, &launch_sparse_r},
+    Variant{"sparse_r_k9_u8_t256", kKindSparse, 9, 256, 1, 8, 8, 1, 32, &launch_sparse_r},
+    Variant{"sparse_r_k8_u8_t128", kKindSparse, 8, 128, 1, 8, 8, 1, 32, &launch_sparse_r},
 };
 constexpr int kMockDense = (int)(sizeof(g_mock_variants) / sizeof(g_mock_variants[0]));
 }  // namespace

@@ -318,6 +318,61 @@ def test_sparse_forests(mock, T, depth, F, full, pm, G, policy, seed):
     assert np.array_equal(_bits(acc), _bits(want))
 
 
+@pytest.mark.parametrize("policy,seed", SCHEDULES[:2])
+@pytest.mark.parametrize("T,depth,F,full,pm,G,cmp_mode,sum_mode", [(24, 13, 20, 4, 650, 1, 0, 0), (130, 16, 64, 3, 700, 1, 0, 2), (19, 9, 12, 2, 500, 3, 1, 0),
+                                                                   (9, 3, 5, 1, 400, 2, 0, 0), (12, 10, 7, 2, 500, 1, 0, 1), (40, 14, 200, 2, 600, 1, 1, 0)])
+def test_sparse_forests_on_32_bit_ranks(mock, T, depth, F, full, pm, G, cmp_mode, sum_mode, policy, seed):
+    """The "sparse_r_*" family (csrc/ddt_sparse_r.hip) through the real host side: rank tables -> key blocks + directory
+    (pack_rank32_tables), one-word nodes + pair / LEAF records (sparse_pack_host_r), workspace geometry, pre-pass -> scoring order on the
+    stream; the stand-in kernels replay the search and the walk on exactly those bytes.  Forced with option sparse_r32 = 1 (the automatic
+    rule wants depth >= 13 and two trees per tuple word: the (130, 16, 64) case also checks that it fires by itself)."""
+    mock.mock_reset(policy, seed, 8)
+    sp = O.gen_sparse_model(T, depth, F, full, pm, 1, cmp_mode=cmp_mode)
+    n = 700
+    x = O.gen_tuples(0, n, F, 1)
+    ref = {0: O.SUM_REF_NATIVE, 1: O.SUM_F64_SEQ, 2: O.SUM_REF_FLOPOCO}[sum_mode]
+    p = ddt.make_sparse_params(T, depth, F, cmp_mode=cmp_mode, sum_mode=sum_mode)
+    mock.ddt_load_model_sparse.argtypes = [vp, C.POINTER(ddt.Params), vp, C.c_size_t, vp, C.c_uint32, C.c_uint32]
+    s = _stream(mock)
+    lines = np.ascontiguousarray(sp.node_lines, np.uint32)
+    first = np.ascontiguousarray(sp.first, np.uint64)
+    info = ddt.Info()
+    parts = []
+    for g in range(G):
+        e = _engine(mock)
+        if T >= 128 and depth >= 13 and G == 1:  # the automatic choice
+            assert mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, g, G) == 0, mock.ddt_last_error(e)
+            assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_r_"), info.variant_name
+            assert mock.ddt_set_option(e, b"sparse_r32", 0) == 0
+            assert mock.ddt_get_info(e, C.byref(info)) == 0 and not info.variant_name.decode().startswith("sparse_r_")
+        assert mock.ddt_set_option(e, b"sparse_r32", 2) == -1
+        assert mock.ddt_set_option(e, b"sparse_r32", 1) == 0
+        assert mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, g, G) == 0, mock.ddt_last_error(e)
+        assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_r_"), info.variant_name
+        o = np.full(n, np.nan, np.float32)
+        assert mock.ddt_score_device(e, x.ctypes.data, n, o.ctypes.data, s) == 0
+        assert mock.hipStreamSynchronize(s) == 0
+        h = np.full(n, np.nan, np.float32)
+        assert mock.ddt_set_option(e, b"feeder_rows", 256) == 0 and mock.ddt_score(e, x.ctypes.data, n, h.ctypes.data) == 0   # and through the feeder
+        assert np.array_equal(_bits(h), _bits(o))
+        # switching the family off and on again re-packs the loaded forest and keeps scoring (the workspace geometry changes with it)
+        assert mock.ddt_set_option(e, b"sparse_r32", 0) == 0 and mock.ddt_score(e, x.ctypes.data, n, h.ctypes.data) == 0
+        assert np.array_equal(_bits(h), _bits(o))
+        assert mock.ddt_set_option(e, b"sparse_r32", 1) == 0 and mock.ddt_score(e, x.ctypes.data, n, h.ctypes.data) == 0
+        assert np.array_equal(_bits(h), _bits(o))
+        parts.append(o)
+        mock.ddt_destroy(e)
+    if G == 1:
+        want = O.score_sparse(sp, x, sum_mode=ref)
+        assert np.array_equal(_bits(parts[0]), _bits(want))
+    else:
+        want = O.score_sparse(sp, x, n_devices=G)
+        acc = parts[0]
+        for q in parts[1:]:
+            acc = O.fpadd_bits_batch(_bits(acc), _bits(q)).view(np.float32)
+        assert np.array_equal(_bits(acc), _bits(want))
+
+
 def test_the_cli_host_program_on_the_model(mock, tmp_path):
     """csrc/ddt_cli.cpp linked against the model build: gen -> score (one engine through the feeder; --shard i --of n; the
     single-process multi-GPU job --devices 4) -> whole result lines equal to the oracle / its multi-device model."""
