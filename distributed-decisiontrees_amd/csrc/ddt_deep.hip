@@ -222,11 +222,13 @@ __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) voi
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     uint32_t s_index = 0;
+    // the first chunk and the rank tile have nothing behind them: a full wait, OUTSIDE the loop -- tools/check_dma_waits.py follows every path of
+    // the built binary to the counted waits below, and the path "kernel entry -> counted wait" exists in the control-flow graph whatever k is
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t k = 0; k < n_chunks; k += 2) {
       // the DMA of this chunk is older than the SGS * G * U gathers issued behind it since the last barrier (every step issues all of its
-      // gathers, valid or not): count them out.  The first chunk and the rank tile have nothing behind them.
-      if (k == 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else wait_for_dma();
+      // gathers, valid or not): count them out
+      if (k != 0u) wait_for_dma();
       __syncthreads();
       const bool more1 = k + 1 < n_chunks;  // (chunks of 4 trees come in pairs: whole PU groups; chunks of 8 may end here)
       if (more1) dma_chunk<THREADS, CHUNK_BYTES>(img + (size_t)(k + 1) * GSKIP, k + 1, CHUNK_BYTES, tid);

@@ -6,7 +6,6 @@
 // rtl/DTEngine/PCIeReceiver.sv:136-139,230-312; line packing rtl/DTEngine/core/PipelinedMUX.sv:65;
 // model store rtl/DTEngine/core/DTPU.sv:282-354; result packing rtl/DTEngine/ResultsCombiner.sv:136-160.
 #include <hip/hip_runtime.h>
-#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -99,6 +98,10 @@ struct ddt_copy_pool {
 
 
 using namespace ddt;
+
+extern "C" {
+extern const int ddt_build_s2_checked, ddt_build_dma_checked;  // ddt_checks.cpp
+}
 
 namespace ddt {
 
@@ -456,25 +459,25 @@ bool classes_equal(const ddt_engine* e) {
 }
 
 // DDT_DISABLE_S2=1 in the environment: the AUTOMATIC choice skips the kernels that keep node records in SGPRs filled by inline-asm
-// scalar loads ("_s2", opt bit 1 of the rank-quantised kernels) -- for a build whose tools/check_s2_isa.py could not run (no
-// disassembler on the build machine: __graft_entry__.build() says so).  A forced "variant" still takes them.
-// The build itself can switch them off too: when __graft_entry__.build() could not run the check it leaves the marker file S2_UNCHECKED next to
-// libddt.so (and removes it once a check has passed); DDT_DISABLE_S2=0 overrides the marker (an explicit opt-in to the unchecked kernels).
+// scalar loads ("_s2", opt bit 1 of the rank-quantised kernels).  A forced "variant" still takes them.  Without the variable the BUILD decides:
+// ddt_build_s2_checked (ddt_checks.cpp) is 1 only when tools/check_s2_isa.py ran on this very binary and found nothing; a build whose check
+// could not run (no disassembler on the build machine) switches them off by itself.  DDT_DISABLE_S2=0 is the explicit opt-in to unchecked kernels.
 bool s2_disabled() {
   static const bool off = [] {
     const char* v = getenv("DDT_DISABLE_S2");
     if (v && v[0]) return v[0] != '0';
-    Dl_info di;
-    if (dladdr(reinterpret_cast<const void*>(&ddt_num_variants), &di) && di.dli_fname) {
-      std::string path(di.dli_fname);
-      const size_t slash = path.rfind('/');
-      path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/S2_UNCHECKED";
-      if (FILE* f = fopen(path.c_str(), "r")) {
-        fclose(f);
-        return true;
-      }
-    }
-    return false;
+    return ddt_build_s2_checked == 0;
+  }();
+  return off;
+}
+// ... and the deep kernels ("q16d_*"), whose chunk barriers wait with a hand-counted `s_waitcnt vmcnt(N)` (ddt_deep.hip wait_for_dma): correct
+// only for the instruction stream hipcc emitted, which tools/check_dma_waits.py verifies on the built binary (ddt_build_dma_checked).
+// DDT_DISABLE_DEEP=1 / 0 overrides, like DDT_DISABLE_S2.
+bool deep_disabled() {
+  static const bool off = [] {
+    const char* v = getenv("DDT_DISABLE_DEEP");
+    if (v && v[0]) return v[0] != '0';
+    return ddt_build_dma_checked == 0;
   }();
   return off;
 }
@@ -549,7 +552,7 @@ int auto_variant(const ddt_engine* e) {
   // (D - K + 1) / 2 gathers of 16-byte records per tree.  Whatever the number of trees: the alternative is the generic kernel.
   if (e->p.num_levels > 8u && e->p.sum_mode != 1u && tuple_words(e->p) <= 64u) {
     for (int i = 0; i < num_variants(); ++i)  // (table order: the two-blocks-per-CU forms first, then the wide ones for 33..64 words)
-      if (variant(i).kind == kKindQ16 && variant(i).deep() && variant_fits(variant(i), e)) return i;
+      if (variant(i).kind == kKindQ16 && variant(i).deep() && !deep_disabled() && variant_fits(variant(i), e)) return i;
   }
   // Tuples of 33..64 words, depth 8: the wide rank-quantised kernels (one block of 16 waves per CU, transpose + rank pre-pass) from the
   // same tree count on as the narrow ones -- 1000 x d8 x 64 / 48 / 33 features: 619 / 635 / 656 Mtuples/s against 432 / 533 / 535 on the fp32
@@ -590,8 +593,7 @@ int auto_variant(const ddt_engine* e) {
       const int i = find_variant("q16_d8_c8_u4_gl_s2_cm");
       if (i >= 0 && variant_fits(variant(i), e)) return i;
     }
-    static const char* qpref[] = {"q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4", "q16_d6_c16_u4_s2", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4_s2", "q16_d7_c8_u4", "q16_d5_c32_u4_s2", "q16_d5_c32_u4", "q16_d3_c128_u8",
-                                  "q16_d9_c4_u4", "q16_d10_c4_u4"};
+    static const char* qpref[] = {"q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4", "q16_d6_c16_u4_s2", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4_s2", "q16_d7_c8_u4", "q16_d5_c32_u4_s2", "q16_d5_c32_u4", "q16_d3_c128_u8"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
       if (i >= 0 && variant_fits(variant(i), e) && !((variant(i).opt & 2) && s2_disabled())) return i;
@@ -1769,6 +1771,7 @@ int ddt_get_info(const ddt_engine* e, ddt_info* out) {
   const Variant& v = variant(e->variant_id);
   if (!e->sparse && v.kind == kKindQ16 && !e->ens.empty()) out->prepass_groups = e->ens[0].prepass.groups;
   out->fallback_kernel = (v.kind == kKindGeneric || (v.kind == kKindSparse && (v.opt & 4))) ? 1u : 0u;
+  out->build_checks = (ddt_build_s2_checked ? 1u : 0u) | (ddt_build_dma_checked ? 2u : 0u);
   if (e->sparse) {
     uint32_t trees = 0, depth = 0;
     uint64_t lines = 0, img = 0;

@@ -158,6 +158,7 @@ constexpr uint32_t kSrLeftLeaf = 0x800u, kSrRightLeaf = 0x400u, kSrMissRight = 0
 constexpr uint32_t kSrLeafRec = kSrLeftLeaf | kSrRightLeaf;  // node word of a LEAF record: rank 0, feature 0, both sides leaves
 constexpr uint32_t kSrMissing = 0xFFFFFFFFu;                 // a missing value in the 32-bit rank tile
 constexpr uint32_t kSrMaxTable = (1u << 20) - 2u;            // distinct thresholds per feature
+constexpr uint32_t kSrMaxWords = 128;                        // tuple words (the pre-pass's transpose stages 256 rows x (W + 1) words in LDS)
 constexpr uint32_t kSrMaxDir = 32767;                        // directory entries per feature (rank32_kernel keeps one feature's directory in LDS)
 
 // 32-bit rank pre-pass (ddt_sparse_r.hip rank32_kernel).  Per feature the sorted distinct keys in BLOCKS of 2^blk_log2 keys (>= 4; padded with

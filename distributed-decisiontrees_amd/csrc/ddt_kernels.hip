@@ -11,8 +11,6 @@
 // per-lane feature gather is conflict-free for any feature index); the kernels, in file order:
 //   score_tile_kernel          fp32 features; the model streams through LDS in double-buffered chunks (global->LDS
 //                              DMA), U trees walked concurrently per lane, level loop fully unrolled.
-//   score_tile_persist_kernel  the same walk with one persistent block per CU, a continuous chunk ring across
-//                              tiles and the next tile's tuples prefetched into registers (opt-in _p variants).
 //   score_stream_kernel        small ensembles (whole model resident in LDS): persistent blocks, coalesced tuple
 //                              loads prefetched one tile ahead -- the HBM-bound regime.
 //   transpose_kernel, rank_kernel, fused_rank_kernel, score_q16_kernel
@@ -184,154 +182,6 @@ static hipError_t launch_tile(const ScoreArgs& a, const Variant& v, hipStream_t 
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
   hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(THREADS), lds, s, a);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// persistent form of the tile kernel (Variant::opt bit 1, suffix _p): one block per CU walks the tiles with a
-// grid stride; the model chunks stream through the two LDS buffers as ONE continuous ring across tiles (the
-// chunk count is even, so chunk 0 of the next tile always lands in buffer 0), and the next tile's tuples are
-// loaded into registers while the current tile is being scored.  What the plain form pays per tile is pure
-// latency (profiles/archive/r01_tile_overhead.md): with one block per CU all 16 waves sit in the tuple-load phase
-// together, then wait for the first model chunk.  VMEM issue order per tile and the waits that go with it:
-//   stage `pre` (already transposed) -> LDS | DMA(1) | PF x8 (next tile) | compute(0)
-//   B(k=0): vmcnt(8)  -> DMA(1) landed, the prefetch may still fly       | DMA(2) | compute(1)
-//   k >= 2: vmcnt(0) at both barriers; the last B issues DMA(0) of the NEXT tile
-//   tile end: transpose `pre` (hipcc waits for the prefetch there) | store the scores
-// The prefetch loads are ordinary loads, always exactly 8 per wave (clamped addresses, no predication), so
-// the counted wait is exact; the DMA is invisible to hipcc, so hipcc's own waits can only over-wait.
-// ---------------------------------------------------------------------------------------------------
-constexpr int kPrefetchLines = 8;  // W <= 32 words
-
-// lane t of a quad takes line 4h+t of rows quad_row+0..3 (see the staging comment in score_tile_kernel);
-// rows past the end and lines past the tuple re-read the last valid one (never staged / never stored)
-__device__ __forceinline__ void prefetch_tile(u32x4 (&pre)[2][4], const uint32_t* tuples, uint64_t quad_row, uint64_t n,
-                                              uint32_t W, uint32_t lpt, uint32_t t4) {
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t line = 4u * h + t4 < lpt ? 4u * h + t4 : lpt - 1u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint64_t rj = quad_row + (uint64_t)j < n ? quad_row + (uint64_t)j : n - 1u;
-      pre[h][j] = *reinterpret_cast<const u32x4*>(tuples + rj * W + 4u * line);
-    }
-  }
-}
-
-template <int D, int THREADS, int CT, int U, int OPT>
-__global__ __launch_bounds__(THREADS) void score_tile_persist_kernel(const ScoreArgs a) {
-  constexpr int R = 1;
-  constexpr int TILE = THREADS;
-  constexpr int TREE_BYTES = 12 << D;
-  constexpr int CHUNK_BYTES = TREE_BYTES * CT;
-  constexpr int ROW = TILE * 4;
-  constexpr bool FUSED = (OPT & 1) != 0;
-  constexpr int MB = FUSED ? (4 << D) : 0;
-  constexpr int FEAT_OFF = (MB + 2 * CHUNK_BYTES + ROW - 1) / ROW * ROW;
-  static_assert((ROW & (ROW - 1)) == 0, "tile must be a power of two");
-  static_assert(CT == 4 || CT % 8 == 0, "chunk = half a PU group or whole groups");
-  static_assert(CT != 4 || U == 4, "CT=4 needs U=4");
-
-  const int tid = threadIdx.x;
-  const uint32_t n_chunks = a.n_chunks, W = a.tuple_words, lpt = W / 4u;  // n_chunks is even (launch_tile_persist)
-  const uint64_t n_tiles = (a.n + TILE - 1) / TILE;
-  const uint32_t lane_off[R] = {(uint32_t)tid * 4u};
-  const uint32_t C = a.clusters, miss_key = a.miss_key;
-  const int SUM1 = (int)a.sum_mode;  // 0 reference order / IEEE adds, 1 fp64, 2 reference order / reference adder
-  const bool exact = SUM1 == 2;
-  const uint32_t t4 = (uint32_t)tid & 3u;
-  const uint32_t quad_col = (uint32_t)tid & ~3u;
-
-  u32x4 pre[2][4];
-  uint64_t tile = blockIdx.x;
-  prefetch_tile(pre, a.tuples, tile * TILE + quad_col, a.n, W, lpt, t4);
-  dma_chunk<THREADS, CHUNK_BYTES>(a.img, 0, MB, tid);
-  quad_transpose(pre[0], t4);
-  quad_transpose(pre[1], t4);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile only: this wave's share of chunk 0
-
-  for (;;) {
-    const uint64_t row = tile * TILE + (uint64_t)tid;
-    const bool valid = row < a.n;
-    const uint64_t next = tile + gridDim.x;
-    const bool has_next = next < n_tiles;
-
-    __syncthreads();  // every wave is done with the previous tile (feature tile, buffer 1) and chunk 0 is in buffer 0
-    uint32_t miss_any = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t line = 4u * h + (uint32_t)i;
-        if (line < lpt) {
-          const uint32_t fa = (uint32_t)FEAT_OFF + (4u * line) * (uint32_t)ROW + (uint32_t)tid * 4u;
-          lds_st_u32(fa + 0 * ROW, stage_word(pre[h][i].x, a, miss_any, valid));
-          lds_st_u32(fa + 1 * ROW, stage_word(pre[h][i].y, a, miss_any, valid));
-          lds_st_u32(fa + 2 * ROW, stage_word(pre[h][i].z, a, miss_any, valid));
-          lds_st_u32(fa + 3 * ROW, stage_word(pre[h][i].w, a, miss_any, valid));
-        }
-      }
-    }
-    const bool slow = block_any<THREADS>(miss_any, (uint32_t)FEAT_OFF + W * (uint32_t)ROW, tid);  // barrier inside
-
-    dma_chunk<THREADS, CHUNK_BYTES>(a.img, 1, MB + CHUNK_BYTES, tid);
-    // next tile's tuples -> registers (the last tile re-reads itself: keeps the VMEM count uniform)
-    prefetch_tile(pre, a.tuples, (has_next ? next : tile) * TILE + quad_col, a.n, W, lpt, t4);
-
-    RefAcc<R> ra;
-    ra.init();
-    double dacc[R] = {0.0};
-
-#define DDT_COMPUTE(BUF, PH)                                                                                          \
-  do {                                                                                                                \
-    if (SUM1 != 1) {                                                                                                  \
-      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 0, FUSED>(lane_off, miss_key, C, ra, dacc, exact); \
-      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 0, FUSED>(lane_off, miss_key, C, ra, dacc, exact);        \
-    } else {                                                                                                          \
-      if (!slow) compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, false, 1, FUSED>(lane_off, miss_key, C, ra, dacc, false); \
-      else compute_chunk<D, U, R, CT, MB + (BUF) * CHUNK_BYTES, PH, true, 1, FUSED>(lane_off, miss_key, C, ra, dacc, false);        \
-    }                                                                                                                 \
-  } while (0)
-
-    constexpr int PH1 = (CT == 4) ? 1 : 0;
-    for (uint32_t k = 0; k < n_chunks; k += 2) {
-      if (k != 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // chunk k is in buffer 0 for everyone; everyone is done with buffer 1
-        dma_chunk<THREADS, CHUNK_BYTES>(a.img, k + 1, MB + CHUNK_BYTES, tid);
-      }
-      DDT_COMPUTE(0, 0);
-      if (k == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // chunk k+1 is in buffer 1; everyone is done with buffer 0
-      dma_chunk<THREADS, CHUNK_BYTES>(a.img, k + 2 < n_chunks ? k + 2 : 0u, MB, tid);  // wraps to the next tile's chunk 0
-      DDT_COMPUTE(1, PH1);
-    }
-#undef DDT_COMPUTE
-
-    ra.align(C);
-    quad_transpose(pre[0], t4);  // hipcc's wait for the prefetch sits here, before the store goes out
-    quad_transpose(pre[1], t4);
-    if (valid) a.out[row] = (SUM1 != 1) ? ra.total(0, C, exact) : (float)dacc[0];
-    if (!has_next) break;
-    tile = next;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wrapped DMA of the last tile must not outlive the wave
-}
-
-template <int D, int THREADS, int R, int CT, int U, int STAGE, int OPT>
-static hipError_t launch_tile_persist(const ScoreArgs& a, const Variant& v, hipStream_t s) {
-  static_assert(R == 1 && STAGE == 1, "persistent form: one tuple per lane, DMA staging");
-  if (a.tuple_words > 4u * kPrefetchLines || (a.n_chunks & 1u) || a.n == 0) return a.n == 0 ? hipSuccess : hipErrorInvalidValue;
-  auto kern = score_tile_persist_kernel<D, THREADS, CT, U, OPT>;
-  const uint32_t lds = v.lds_bytes(a.tuple_words);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  const uint64_t tiles = (a.n + THREADS - 1) / THREADS;
-  if (tiles == 0) return hipSuccess;
-  uint64_t grid = (uint64_t)a.num_cus * (lds <= 80u * 1024u ? 2u : 1u);  // resident blocks: CUs x blocks per CU
-  if (grid > tiles) grid = tiles;
-  hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(THREADS), lds, s, a);
   return hipGetLastError();
 }
 
@@ -1977,8 +1827,6 @@ hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t 
 // ---------------------------------------------------------------------------------------------------
 #define DDT_V(NAME, D, TH, R, CT, U, ST, OPT) \
   Variant { NAME, kKindTile, D, TH, R, CT, U, ST, OPT, &launch_tile<D, TH, R, CT, U, ST, OPT> }
-#define DDT_VP(NAME, D, TH, R, CT, U, ST, OPT) \
-  Variant { NAME, kKindTile, D, TH, R, CT, U, ST, OPT, &launch_tile_persist<D, TH, R, CT, U, ST, OPT> }
 #define DDT_S(NAME, D, U, MAXLPT) \
   Variant { NAME, kKindStream, D, kStreamThreads, 1, 8, U, 0, MAXLPT, &launch_stream<D, U, MAXLPT> }
 
@@ -2018,9 +1866,8 @@ static const Variant g_variants[] = {
     DDT_Q("q16_d7_c8_u4", 7, 8, 4),
     DDT_Q("q16_d5_c32_u4", 5, 32, 4),
     DDT_Q("q16_d3_c128_u8", 3, 128, 8),
-    // deeper trees: 16 / 32 KiB chunks, one 1024-thread block per CU (the tile + two chunks no longer fit twice)
-    DDT_Q("q16_d9_c4_u4", 9, 4, 4),
-    DDT_Q("q16_d10_c4_u4", 10, 4, 4),
+    // (the one-block depth 9 / 10 forms "q16_d9_c4_u4" / "q16_d10_c4_u4" went in round 6: the deep kernels of ddt_deep.hip replaced them in round 5,
+    // 2418 / 2125 against 1823 / 1628 Mtuples/s; so did the persistent fp32 tile kernel "d8_t1024_r1_c4_u4_dma_fp", which no choice ever took)
     // tuples of 33..64 words ("q16w" / "q16dw": the record carries half the row offset, one block of 16 waves per CU: 16 KiB of chunks + up to
     // 128 KiB of ranks): the shapes that used to fall to the fp32 tile kernels at 8 waves per CU (depth <= 8) or to the generic kernel (deeper)
     Variant{"q16w_d8_c8_u4_gl_s2_cm_x", kKindQ16, 8, kQTile, 1, 8, 4, 1, 7 | 64, &launch_q16<8, 8, 4, 23 | 64>},
@@ -2030,7 +1877,6 @@ static const Variant g_variants[] = {
     // depth 8 (BASELINE configs 3 and 5): tree = 3 KiB.  suffix _f = last level fused with its leaves.  Experiment variants
     // that no choice uses any more were removed in round 2 (register-staged chunks, R = 2, the unfused forms, 8-chain
     // stream kernels; their measurements stay in profiles/archive/r01_sweep_*.json)
-    DDT_VP("d8_t1024_r1_c4_u4_dma_fp", 8, 1024, 1, 4, 4, 1, 3),  // _p = persistent blocks + register prefetch
     DDT_V("d8_t1024_r1_c4_u4_dma_f", 8, 1024, 1, 4, 4, 1, 1),
     DDT_V("d8_t512_r1_c8_u8_dma_f", 8, 512, 1, 8, 8, 1, 1),
     DDT_V("d8_t512_r1_c4_u4_dma_f", 8, 512, 1, 4, 4, 1, 1),  // 33..64 words per tuple: 128 KiB tile + 2 x 12 KiB chunks

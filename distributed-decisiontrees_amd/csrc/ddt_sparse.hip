@@ -428,18 +428,18 @@ static const Variant g_sparse_variants[] = {
     // measured and NOT instantiated (profiles/archive/r02_sparse_sweep_*.log): 16 trees in lock-step (u16: no gain over u8), half a
     // PU group per pass (u4: K + 1 at the same occupancy, but 4 loads in flight per lane: 159 vs 196 Mtuples/s)
     DDT_SP(6, 8, 256), DDT_SP(7, 8, 256), DDT_SP(8, 8, 256), DDT_SP(9, 8, 256), DDT_SP(10, 8, 256),
-    // 512-tuple tiles: one block of 8 waves per CU shares ONE set of top images (two 256-tuple blocks hold two)
-    DDT_SP(6, 8, 512), DDT_SP(7, 8, 512), DDT_SP(8, 8, 512), DDT_SP(9, 8, 512),
+    // (512-tuple tiles -- one block of 8 waves per CU with ONE set of top images -- went in round 6: the automatic choice never took them: K = 8 in
+    // two 256-tuple blocks 256.6 Mtuples/s, K = 9 in one block of 512 243.4, profiles/archive/r03_sparse_dense_level_k.json)
     // narrower tiles for wide tuples (the feature tile is 4 * W bytes per tuple)
     DDT_SP(6, 8, 128), DDT_SP(7, 8, 128), DDT_SP(8, 8, 128), DDT_SP(9, 8, 128), DDT_SP(10, 8, 128),
     DDT_SP(8, 8, 64), DDT_SP(9, 8, 64), DDT_SP(10, 8, 64),
     // dense level K: K = 8 at two 256-tuple blocks per CU / K = 9 in one block of 512 where the 16-byte level K-1 records allow 7 / 8
     DDT_SPD(6, 8, 256), DDT_SPD(7, 8, 256), DDT_SPD(8, 8, 256), DDT_SPD(9, 8, 256), DDT_SPD(10, 8, 256),
-    DDT_SPD(7, 8, 512), DDT_SPD(8, 8, 512), DDT_SPD(9, 8, 512), DDT_SPD(10, 8, 512),
     // dense mid levels (round 5): forests whose levels right below the top image are (nearly) complete
     // (BASELINE config 4, one box, alternating: M = 0 / 1 / 2 / 3 -> 265-270 / 275 / 271-272 / 214-227 Mtuples/s, profiles/r05_pmc_cfg2_cfg4_cfg6.md:
     // one mid level pays a little, three lose a fifth -- the padding under the early leaves of level 10 turns finished walkers into live gathers)
-    DDT_SPM(1, 8, 8, 256), DDT_SPM(2, 8, 8, 256), DDT_SPM(1, 7, 8, 256), DDT_SPM(1, 8, 8, 128), DDT_SPM(1, 7, 8, 128),
+    // (the 128-tuple forms went in round 6: no dense-level-K kernel of that tile exists for them to be the sibling of)
+    DDT_SPM(1, 8, 8, 256), DDT_SPM(2, 8, 8, 256), DDT_SPM(1, 7, 8, 256),
     // dense pair records (round 5): two levels per gather below the top image, for forests that fill the levels K .. K+2
     // (K = 10 measured and NOT instantiated: the dense block would sit at level 12, 64 KiB per tree -- a 255-bin version of config 4 on 32 features:
     // `sparse_qp_k10` 272.8 vs `sparse_qd_k10` 287.1 Mtuples/s; K = 9 on 64 features: 267.4 vs 263.1)

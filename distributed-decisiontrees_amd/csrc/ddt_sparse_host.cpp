@@ -63,7 +63,7 @@ int pick_variant(ddt_engine* e, uint32_t max_depth, bool ranks_fit) {
   const int kcap = (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, kSparseMinTop), kSparseMaxTop);
   // Geometries that keep >= 8 waves on a CU (then fewer, for very wide tuples), each with the largest K whose top
   // images fit next to the feature tile.
-  static const struct { int T; uint32_t blocks; } geo[] = {{256, 2}, {512, 1}, {128, 4}, {256, 1}, {128, 2}, {128, 1}, {64, 2}, {64, 1}};
+  static const struct { int T; uint32_t blocks; } geo[] = {{256, 2}, {128, 4}, {256, 1}, {128, 2}, {128, 1}, {64, 2}, {64, 1}};  // (512-tuple tiles never won a choice: removed in round 6)
   // The largest K wins, where a geometry with two or more blocks per CU counts one level more (one block's top phase overlaps the
   // others' deep phase: BASELINE config 4, profiles/archive/r03_sparse_dense_level_k.json -- K = 8 in two blocks 256.6 Mtuples/s, K = 9 in one
   // 243.4, K = 8 in one 232.5); ties go to the earlier geometry.
@@ -131,6 +131,7 @@ static int pack_rank32_tables(ddt_engine* e, const RankTables& rt, uint32_t W, R
 static int pick_r32_variant(ddt_engine* e, uint32_t max_depth) {
   const uint32_t W = tuple_words(e->p);
   if (e->p.num_features > 256u) return -1;  // a node word carries the feature number in 8 bits
+  if (W > kSrMaxWords) return -1;            // the pre-pass's transpose stages 256 rows x W words in LDS
   char name[40];
   const int kcap = (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, 8u), 10u);
   for (uint32_t budget : {kMaxLdsBytes / 2u, kMaxLdsBytes})
@@ -166,7 +167,7 @@ int sparse_rebuild(ddt_engine* e) {
   // (transpose + rank32_kernel per batch, which the fp32-tile kernels do not have)
   if (e->forced_variant >= 0 && variant(e->forced_variant).r32()) {
     const Variant& fv = variant(e->forced_variant);
-    if (e->p.num_features > 256u || rt.max_len > kSrMaxTable || fv.lds_bytes_sparse(tuple_words(e->p)) > kMaxLdsBytes) vid = -1;
+    if (e->p.num_features > 256u || tuple_words(e->p) > kSrMaxWords || rt.max_len > kSrMaxTable || fv.lds_bytes_sparse(tuple_words(e->p)) > kMaxLdsBytes) vid = -1;
     else vid = e->forced_variant;
   } else if (e->forced_variant < 0 && e->sparse_r32 != 0 && rt.max_len <= kSrMaxTable) {
     // Automatic: where it measured faster on one MI355X (profiles/r06_sparse_r32.md; 4 M tuples, trees x depth x features: 512 x 16 x 64 +7 %, the
@@ -905,7 +906,7 @@ extern "C" int ddt_debug_sparse_image(const ddt_params* p, const void* node_line
       return DDT_ENOMEM;
     }
     if (rt.max_len > (v.r32() ? kSrMaxTable : kQ16MaxTable)) return DDT_EUNSUPPORTED;
-    if (v.r32() && p->num_features > 256u) return DDT_EUNSUPPORTED;
+    if (v.r32() && (p->num_features > 256u || tuple_words(*p) > kSrMaxWords)) return DDT_EUNSUPPORTED;
   }
   rc = v.r32() ? sparse_pack_host_r(e.get(), v, sp, rt, top, deep, &groups) : sparse_pack_host(e.get(), v, sp, q ? &rt : nullptr, top, deep, &groups);
   if (rc) return rc;

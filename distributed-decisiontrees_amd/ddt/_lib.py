@@ -20,7 +20,7 @@ SYMBOLS = [
     "ddt_comm_get_unique_id", "ddt_comm_create", "ddt_comm_destroy", "ddt_comm_last_error", "ddt_comm_set_option",
     "ddt_score_sharded_device", "ddt_score_rowsharded_device", "ddt_classify_sharded_device",
     "ddt_group_create", "ddt_group_destroy", "ddt_group_last_error", "ddt_group_engine", "ddt_group_load_model",
-    "ddt_group_load_model_sparse", "ddt_group_score", "ddt_group_load_model_multiclass", "ddt_group_classify", "ddt_debug_prepass_image", "ddt_debug_sparse_image",
+    "ddt_group_load_model_sparse", "ddt_group_score", "ddt_group_load_model_multiclass", "ddt_group_classify", "ddt_debug_prepass_image", "ddt_debug_sparse_image", "ddt_debug_rank32_tables",
     "ddt_shard_range", "ddt_debug_model_image", "ddt_comm_chunk_schedule", "ddt_comm_score", "ddt_group_load_model_replicated", "ddt_group_score_rows",
     "ddt_host_register", "ddt_host_unregister",
     "ddt_comm_create_hybrid", "ddt_comm_layout", "ddt_hybrid_rows", "ddt_score_hybrid_device", "ddt_classify_hybrid_device", "ddt_comm_abort",
@@ -54,7 +54,7 @@ class Info(C.Structure):
         ("model_bytes_unpadded", C.c_uint64), ("image_bytes", C.c_uint64),
         ("variant_name", C.c_char * 64), ("device_name", C.c_char * 64),
         ("num_cus", C.c_uint32), ("clock_khz", C.c_uint32), ("lds_bytes_per_cu", C.c_uint32), ("prepass_groups", C.c_uint32),
-        ("fallback_kernel", C.c_uint32), ("reserved_info", C.c_uint32),
+        ("fallback_kernel", C.c_uint32), ("build_checks", C.c_uint32),
     ]
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DDT_ABI_VERSION 5 /* 5: ddt_info grew (fallback_kernel); 4: hybrid jobs (ddt_comm_create_hybrid, ddt_score_hybrid_device, ...), ddt_comm_abort; 3: ddt_stats grew */
+#define DDT_ABI_VERSION 6 /* 6: ddt_info::build_checks (was reserved), "sparse_r_*" kernels + option sparse_r32, ddt_debug_rank32_tables; 5: ddt_info grew (fallback_kernel); 4: hybrid jobs (ddt_comm_create_hybrid, ddt_score_hybrid_device, ...), ddt_comm_abort; 3: ddt_stats grew */
 
 /* Threading: an engine is not thread-safe -- calls on ONE engine must not overlap; different engines (also on the
  * same device) are independent.  ddt_*_device calls are asynchronous on the given stream; ddt_destroy and
@@ -94,7 +94,11 @@ typedef struct ddt_info {
   uint32_t fallback_kernel;          /* 1 = the model landed on a CORRECTNESS kernel ("generic" for perfect trees, "sparse_gf_*" for
                                         sparse forests): right results, no tuned path for this shape (depth / tuple width).  Callers
                                         that care about throughput should say so loudly (ddt_cli and bench.py do).              */
-  uint32_t reserved_info;            /* 0 */
+  uint32_t build_checks;             /* what the BUILD verified on this very binary's device code (csrc/ddt_checks.cpp): bit 0 = tools/check_s2_isa.py
+                                        passed (no instruction touches the "_s2" kernels' SGPR record sets with their scalar loads in flight), bit 1 =
+                                        tools/check_dma_waits.py passed (every counted s_waitcnt vmcnt(N) a barrier relies on covers the chunk DMA).
+                                        A clear bit = that check could not run on the build machine: the automatic kernel choice then avoids the
+                                        kernels concerned ("_s2" / "q16d_*"; environment DDT_DISABLE_S2=0 / DDT_DISABLE_DEEP=0 opts back in)      */
 } ddt_info;
 
 /* Observability counters, the analogue of CSR 220-226 / appStatus (EngineCSR.sv:113-126,

@@ -12,6 +12,13 @@
 // linked into libddt.so; the GPU parity tests are what holds the real kernels to the oracle.
 #include "mock_runtime.cpp"
 
+// what csrc/ddt_checks.cpp bakes into the real library after the instruction-level checks of its device code: the model has no device code,
+// so nothing is "unchecked" (a 0 would make the engine's automatic choice avoid the "_s2" / deep kernels' stand-ins)
+extern "C" {
+extern const int ddt_build_s2_checked = 1;
+extern const int ddt_build_dma_checked = 1;
+}
+
 #include <algorithm>
 
 namespace ddt {

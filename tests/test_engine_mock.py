@@ -320,7 +320,7 @@ def test_sparse_forests(mock, T, depth, F, full, pm, G, policy, seed):
 
 @pytest.mark.parametrize("policy,seed", SCHEDULES[:2])
 @pytest.mark.parametrize("T,depth,F,full,pm,G,cmp_mode,sum_mode", [(24, 13, 20, 4, 650, 1, 0, 0), (130, 16, 64, 3, 700, 1, 0, 2), (19, 9, 12, 2, 500, 3, 1, 0),
-                                                                   (9, 3, 5, 1, 400, 2, 0, 0), (12, 10, 7, 2, 500, 1, 0, 1), (40, 14, 200, 2, 600, 1, 1, 0)])
+                                                                   (9, 3, 5, 1, 400, 2, 0, 0), (12, 10, 7, 2, 500, 1, 0, 1), (40, 14, 100, 2, 600, 1, 1, 0)])
 def test_sparse_forests_on_32_bit_ranks(mock, T, depth, F, full, pm, G, cmp_mode, sum_mode, policy, seed):
     """The "sparse_r_*" family (csrc/ddt_sparse_r.hip) through the real host side: rank tables -> key blocks + directory
     (pack_rank32_tables), one-word nodes + pair / LEAF records (sparse_pack_host_r), workspace geometry, pre-pass -> scoring order on the

@@ -20,7 +20,7 @@ def _bits(a):
 
 @pytest.mark.parametrize("T,depth,F,full,pm,dist,auto", [(136, 16, 64, 10, 700, 0, True), (70, 14, 20, 6, 700, 1, True), (40, 14, 64, 11, 500, 1, False),
                                                           (24, 12, 40, 4, 800, 1, False), (9, 9, 64, 3, 600, 1, False), (17, 10, 100, 10, 0, 1, False),
-                                                          (12, 20, 200, 2, 850, 1, False), (3, 2, 5, 1, 500, 1, False)])
+                                                          (12, 20, 100, 2, 850, 1, False), (3, 2, 5, 1, 500, 1, False)])
 def test_pair_records_on_32_bit_ranks_equal_the_oracle(T, depth, F, full, pm, dist, auto):
     import torch
 
@@ -30,7 +30,7 @@ def test_pair_records_on_32_bit_ranks_equal_the_oracle(T, depth, F, full, pm, di
     if dist == 0:
         x[::9973, 3] = 0x7FC00000                      # a few tiles with a missing value
     else:
-        x[::331, :] = np.where(np.arange(F)[None, :] % 3 == 0, np.uint32(0x7FC00000), x[::331, :])   # missing values on a third of the features: every level sees them
+        x[::331, :] = np.where(np.arange(x.shape[1])[None, :] % 3 == 0, np.uint32(0x7FC00000), x[::331, :])   # missing values on a third of the features: every level sees them
     # values ON thresholds and right beside them (the rank must count keys <= x: an off-by-one flips exactly these rows)
     thr = sp.node_lines[:, 0][: 4000]
     fj = sp.node_lines[:, 1][: 4000] & 0x7FF
