@@ -630,6 +630,7 @@ void free_q16_workspace(ddt_engine* e) {
       *p = nullptr;
     }
     e->q_rows[k] = 0;
+    e->q_xT_valid[k] = false;
   }
 }
 
@@ -1049,6 +1050,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   }
   const uint64_t cap = rows > e->q_rows[k] ? rows : e->q_rows[k];
   e->q_rows[k] = 0;
+  e->q_xT_valid[k] = false;
   const uint32_t W = tuple_words(e->p);
   if (need_xT) HIP_TRY(e, hipMalloc(&e->q_xT[k], cap * W * 4));
   HIP_TRY(e, hipMalloc(&e->q_q[k], cap * W * (r32 ? 4 : 2)));
@@ -1208,6 +1210,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
   if (v.kind == kKindQ16) {
     int rc = ensure_q16_workspace(e, n);
     if (rc) return rc;
+    if (!reuse_prepass) e->q_xT_valid[e->q_slot] = false;  // a new batch
     qa.xT = reinterpret_cast<uint32_t*>(e->q_xT[e->q_slot]);
     qa.q = reinterpret_cast<uint16_t*>(e->q_q[e->q_slot]);
     qa.tile_flags = reinterpret_cast<uint32_t*>(e->q_flags[e->q_slot]);
@@ -1266,7 +1269,9 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     float* state = reinterpret_cast<float*>(e->q_state[e->q_slot]);
     uint32_t groups_before = 0;
     const uint32_t walk_all = qa.walk_subgroups;
-    bool xT_valid = false;  // the transposed tuples of this batch (transpose + rank pre-pass) serve every part that needs them
+    // the transposed tuples of this batch (transpose + rank pre-pass) serve every part that needs them -- and every CLASS of a one-vs-all model
+    // in parts (the flag used to start at false in every call, so K classes transposed the same batch K times)
+    bool xT_valid = reuse_prepass && e->q_xT_valid[e->q_slot];
     for (size_t k = 0; k < m.parts.size() && r == hipSuccess; ++k) {
       const Q16Part& part = m.parts[k];
       a.img = reinterpret_cast<const uint4*>(static_cast<const char*>(m.d_img) + part.chunk_begin * chunk_bytes);
@@ -1293,6 +1298,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
       groups_before += a.n_trees / 8u;
       e->st.kernel_launches++;
     }
+    e->q_xT_valid[e->q_slot] = xT_valid && r == hipSuccess;
     if (r == hipSuccess) e->st.kernel_launches--;  // (counted once more below)
   } else {
     r = v.launch(a, v, s);

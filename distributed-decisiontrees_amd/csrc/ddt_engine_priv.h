@@ -132,6 +132,7 @@ struct ddt_engine {
   void* q_flags[ddt::kQSlots] = {};
   void* q_state[ddt::kQSlots] = {};    // ensembles scored in parts: [2][rows] fp32 accumulator + running total between the parts' launches
   uint64_t q_rows[ddt::kQSlots] = {};  // capacity in rows (multiple of 1024)
+  bool q_xT_valid[ddt::kQSlots] = {};  // q_xT holds the transposed tuples of the batch being scored (set by a part's transpose, cleared by the next batch)
   int q_slot = 0;
   int q16_grouped_prepass = 1;  // option "q16_grouped_prepass": 0 = never split the pre-pass over feature groups
   int q16_prepass_groups = 0;   // option "q16_prepass_groups": force the number of feature groups (A/B), 0 = automatic

@@ -190,6 +190,47 @@ def test_other_configs_plumbing_on_the_cpu_model(monkeypatch):
     assert L.mock_errors() == 0
 
 
+def test_per_rank_proxies_plumbing_on_the_cpu_model(monkeypatch):
+    """`other_modes.per_rank_proxies` of the driver's line: one rank's workload of the three 8-GPU jobs through the real host
+    side on the CPU model -- shard 3 of 8, shard 1 of 2 on a quarter of the rows, the whole ensemble on an eighth -- each checked against the
+    oracle's model of the shard, plus the analytic model's 8-GPU prediction with its assumption spelled out; a failing leg costs only its entry."""
+    import numpy as np
+
+    import ddt
+    L = _build("libddt_host_mock.so")
+    L.mock_reset(2, 7, 8)
+    monkeypatch.setattr(_lib, "_lib", L)
+    world = fake_torch.World(1)
+    ft = fake_torch.make(world, L)
+    monkeypatch.setitem(sys.modules, "torch", ft)
+    monkeypatch.setitem(sys.modules, "torch.distributed", ft.distributed)
+    monkeypatch.setitem(sys.modules, "torch.cuda", ft.cuda)
+    world.local.rank = 0
+    bench = _bench_module()
+    T, D, F, N = 1000, 8, 32, 16 * 1024
+    w, f = ddt.synth_model(T, D, F, 0)
+    eng = ddt.Engine(0)
+    tuples = eng.synth_tuples_device(0, N, F, 0)
+    p = bench.collect_rank_proxies(0, tuples, 100.0, (T, D, F), (w, f), check_rows=1024)
+    eng.close()
+    for name, trees, rows in (("shard_of_8", 125, N), ("hybrid_rank_of_2x4", 500, N // 4), ("replica_of_8", 1000, N // 8)):
+        r = p[name]
+        assert "error" not in r, r
+        assert r["trees"] == trees and r["rows"] == rows and r["bit_exact"] is True and r["rows_checked"] == 1024 and r["compute_only_x"] > 0, (name, r)
+    m8 = p["model_8gpu"]
+    assert set(m8) >= {"tree_sharded_8", "hybrid_tree2_x_rows4_gathered", "replicas_8", "assumptions"} and "ASSUMPTION" in m8["assumptions"]
+    assert 4.0 < m8["tree_sharded_8"]["x_over_model_1gpu"] < 8.0 and m8["replicas_8"]["ms"] > 0   # (16 k rows: the fixed terms dominate the other two)
+    assert L.mock_errors() == 0
+
+    def runner(name, idx, cnt, rows):
+        if name == "hybrid_rank_of_2x4":
+            raise RuntimeError("boom")
+        return {"ms": 1.0}
+
+    p = bench.collect_rank_proxies(0, tuples, 100.0, (T, D, F), (w, f), runner=runner)
+    assert p["shard_of_8"] == {"ms": 1.0} and "boom" in p["hybrid_rank_of_2x4"]["error"] and p["replica_of_8"] == {"ms": 1.0} and "note" in p
+
+
 def test_other_configs_budget_and_failures_never_cost_the_line():
     bench = _bench_module()
     calls = []

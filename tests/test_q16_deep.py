@@ -90,6 +90,20 @@ def test_the_references_own_configuration():
     dl, dcs = e.classify_device(d[:150_000])
     torch.cuda.synchronize()
     assert np.array_equal(dl.cpu().numpy(), want_l) and np.array_equal(_bits(dcs.cpu().numpy()), _bits(want_cs))
+    # two classes of 300 trees: 38 k thresholds per feature and class -> EVERY class in parts of its own.  The batch's transposed tuples serve all
+    # parts of all classes (they used to be transposed once per class) -- and only that batch: two different batches back to back
+    T2 = 600
+    m2 = O.gen_model(T2, D, F, dist=0)
+    e.load_model_multiclass(ddt.make_params(T2, D, F, clusters=ddt.default_clusters(T2 // 2)), m2.wlines, m2.flines, 2, True)
+    assert e.info().variant_name.decode() == "q16d_d12_k9_c4_u4_cm"
+    mc2 = O.Model(O.make_params(T2, D, F, clusters=ddt.default_clusters(T2 // 2)), m2.wlines, m2.flines)
+    launches = e.stats().kernel_launches
+    ra, rb = e.classify_device(d[:50_000]), e.classify_device(d[200_000:250_000])
+    torch.cuda.synchronize()
+    assert e.stats().kernel_launches - launches >= 8                                     # 2 batches x 2 classes x >= 2 parts
+    for (gl, gs), xs in ((ra, x[:50_000]), (rb, x[200_000:250_000])):
+        wl, wcs = O.classify_fast(mc2, xs, 2, True)
+        assert np.array_equal(gl.cpu().numpy(), wl) and np.array_equal(_bits(gs.cpu().numpy()), _bits(wcs))
     e.close()
 
 

@@ -182,6 +182,13 @@ def test_default_command_carries_the_other_baseline_configs():
         assert 0 < c["roofline"]["frac"] < 1 and c["roofline"]["kernel_ms"] <= c["ms_per_step"] * 1.05 and c["fallback_kernel"] is False, (cfg, c)
     assert oc["1"]["roofline"]["frac"] > 0.5            # the HBM-bound shape
     assert j["other_modes"]["sum_mode2"]["bit_exact_vs_reference_adder"] is True and j["other_modes"]["sum_mode2"]["rows_checked"] >= 4_000_000
+    # one rank's workload of the 8-GPU jobs, on this GPU
+    pr = j["other_modes"]["per_rank_proxies"]
+    for name, trees in (("shard_of_8", 125), ("hybrid_rank_of_2x4", 500), ("replica_of_8", 1000)):
+        r = pr[name]
+        assert "error" not in r and r["trees"] == trees and r["bit_exact"] is True and r["ms"] > 0 and r["compute_only_x"] > 1.0, (name, r)
+    assert 5.0 < pr["shard_of_8"]["compute_only_x"] < 8.0 and pr["seconds"] < 5.0
+    assert "ASSUMPTION" in pr["model_8gpu"]["assumptions"] and pr["model_8gpu"]["tree_sharded_8"]["ms"] > 0
 
 
 def test_one_shard_of_a_tree_sharded_job_on_one_gpu():

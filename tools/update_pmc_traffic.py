@@ -21,6 +21,16 @@ def pmc(path, like):
     return out
 
 
+def launches(path, like):
+    """launches of the kernels whose name contains `like` in the PMC run under `path` (0 if none)"""
+    n = 0
+    for db in glob.glob(path + "/**/*.db", recursive=True):
+        cur = sqlite3.connect(db).cursor()
+        for (k,) in cur.execute("select count(*) from (select distinct dispatch_id from counters_collection where kernel_name like ?)", (f"%{like}%",)):
+            n += int(k)
+    return n
+
+
 def kib(d, key):
     return int(d[key] * 1024) if key in d else None
 
@@ -76,19 +86,24 @@ def main():
     f, w = pmc(ev + "/fetch_cfg6", "score_q16d"), pmc(ev + "/write_cfg6", "score_q16d")
     if f and w:
         fr6, wr6 = kib(f, "FETCH_SIZE"), kib(w, "WRITE_SIZE")
-        parts = 3
+        # parts and pre-pass launches per step come from the RUN (they were constants, silently wrong once the part plan changes): the
+        # command runs `steps_run` steps (3 timed + 1 warm-up; the transposed tuples are shared by a step's parts: one transpose per step)
+        n_tr = launches(ev + "/fetch_cfg6", "transpose_kernel")
+        steps_run = n_tr if n_tr else 4
+        parts = max(1, round(launches(ev + "/fetch_cfg6", "score_q16d") / steps_run))
         pre6 = {}
-        for name, like, calls in (("rank", "ddt::rank_kernel", 2), ("transpose", "transpose_kernel", 1), ("fused_rank", "fused_rank_kernel", 1)):
+        for name, like in (("rank", "ddt::rank_kernel"), ("transpose", "transpose_kernel"), ("fused_rank", "fused_rank_kernel"), ("grouped_rank", "grouped_rank_kernel")):
             f2, w2 = pmc(ev + "/fetch_cfg6", like), pmc(ev + "/write_cfg6", like)
             if f2 or w2:
-                pre6[name] = {"FETCH_SIZE": kib(f2, "FETCH_SIZE"), "WRITE_SIZE": kib(w2, "WRITE_SIZE"), "launches_per_step": calls}
+                pre6[name] = {"FETCH_SIZE": kib(f2, "FETCH_SIZE"), "WRITE_SIZE": kib(w2, "WRITE_SIZE"),
+                              "launches_per_step": max(1, round(launches(ev + "/fetch_cfg6", like) / steps_run))}
         scoring = parts * (2 * fr6 + wr6)
         step6 = scoring + sum(v["launches_per_step"] * (2 * (v["FETCH_SIZE"] or 0) + (v["WRITE_SIZE"] or 0)) for v in pre6.values())
-        j6 = {"rows": 10000000, "trees": 512, "kernel": "score_q16d_kernel<12,9,4> (q16d_d12_k9_c4_u4_cm), 3 parts per step",
+        j6 = {"rows": 10000000, "trees": 512, "kernel": f"score_q16d_kernel<12,9,4> (q16d_d12_k9_c4_u4_cm), {parts} parts per step", "parts_per_step": parts,
               "fetch_bytes_raw_per_launch": fr6, "fetch_bytes_x2_corrected_per_launch": 2 * fr6, "write_bytes_per_launch": wr6,
               "hbm_bytes_per_launch": scoring,
-              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the config-6 bench command.  The ensemble is scored in 3 parts: "
-                      "`hbm_bytes_per_launch` is the sum over the three scoring launches of one step (2 x FETCH + WRITE each; the u16 rank tiles, the "
+              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the config-6 bench command.  The ensemble is scored in parts (`parts_per_step`, counted in the run): "
+                      "`hbm_bytes_per_launch` is the sum over the scoring launches of one step (2 x FETCH + WRITE each; the u16 rank tiles, the "
                       "stage records' L2 misses, the sum's state between the parts), which is what the line's `kernel_ms` spans together with two "
                       "of the pre-passes; `prepass`: raw counter bytes per launch of the pre-pass kernels and their launches per step.",
               "prepass": pre6, "step_hbm_bytes_x2_corrected": step6, "algorithmic_bytes_per_step": 10000000 * 132 + 512 * (4 * 8191 + 2 * 4095),
