@@ -179,7 +179,13 @@ __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAu
   constexpr uint32_t ROW_LOG2 = THREADS == 512 ? 11u : THREADS == 256 ? 10u : 9u;
   static_assert((1u << ROW_LOG2) == ROWB, "tiles of 128 / 256 / 512 tuples");
   const uint32_t lane_off = FEAT_OFF + (uint32_t)tid * 4u;
-  auto feat = [&](uint32_t rec) -> uint32_t { return lds_u32(((rec & kSrFeatMask) << ROW_LOG2) + lane_off); };
+  // the feature's rank word: LDS address = feature number * ROWB + the lane's column.  Two VALU instructions -- the AND is kept opaque, or hipcc
+  // re-associates it into shift + and + add (three; 61 % of the kernel's issue slots were VALU: profiles/r06_sparse_r32.md)
+  auto feat = [&](uint32_t rec) -> uint32_t {
+    uint32_t j;
+    asm("v_and_b32 %0, 0xff, %1" : "=v"(j) : "v"(rec));
+    return lds_u32((j << ROW_LOG2) + lane_off);  // v_lshl_add_u32
+  };
   const uint32_t C = a.clusters;
   const uint32_t n_steps = x.n_groups * 8u / (uint32_t)U;
   const uint32_t max_rounds = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.max_rounds);
@@ -245,7 +251,9 @@ __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAu
             r0[i] = sr_right<SLOW>(fn[i], rr[h + i].x);
             cw[i] = r0[i] ? rr[h + i].z : rr[h + i].y;
             leaf[i] = (rr[h + i].x & (r0[i] ? kSrRightLeaf : kSrLeftLeaf)) != 0u;
-            cn[i] = leaf[i] ? 0u : cw[i];
+            // (a leaf's VALUE goes through the child's compare as if it were a node word: its low byte names some row of the tile -- rows beyond the
+            // tile lie beyond the block's LDS allocation, where a DS read returns 0 -- and whatever comes out is never used: the walker is done)
+            cn[i] = cw[i];
             fc[i] = feat(cn[i]);
           }
 #pragma unroll
