@@ -202,17 +202,25 @@ uint32_t max_trees(const ddt_engine* e) {
   return t;
 }
 
+// ---- feature compaction (round 6) --------------------------------------------------------------------------------
+// The rank-quantised kernels take tuples of at most 64 words (the u16 tile of 1024 tuples must fit LDS); the reference takes F <= 2048
+// (DTPU.sv:22-25,628).  A model of more than 64 tuple words that TESTS at most 64 distinct features (ddt_engine::fmap: compact index ->
+// feature number) still runs on them: the rank pre-pass gathers only those columns into its transposed intermediate, and tables, tiles,
+// node records and kernels see a tuple of q16_words() words.  Everything else (the wire format, the feeder, ddt_info) keeps the caller's width.
+uint32_t q16_words(const ddt_engine* e) { return e->fmap.empty() ? tuple_words(e->p) : (uint32_t)((e->fmap.size() + 3u) / 4u * 4u); }
+inline uint32_t q16_feat(const ddt_engine* e, uint32_t j) { return e->fmap.empty() ? j : e->finv[j]; }
+
 // q16: sorted distinct threshold keys (comparator domain) per feature, over the trees of EVERY ensemble of the
 // engine: the classes of a multi-class model share one set of tables, so one transpose + rank pre-pass per batch
 // serves all K scoring launches (launch_classify)
 RankTables rank_tables(const ddt_engine* e) {
   RankTables rt;
-  const uint32_t W = tuple_words(e->p), nint = e->nint;
+  const uint32_t W = q16_words(e), nint = e->nint;
   rt.keys.resize(W);
   for (const Ensemble& m : e->ens)
     for (uint32_t i = 0; i < m.trees(); ++i)
       for (uint32_t n = 0; n < nint; ++n)
-        rt.keys[m.fidx[(size_t)i * nint + n]].push_back(thr_key(e->p, m.thr[(size_t)i * nint + n]));
+        rt.keys[q16_feat(e, m.fidx[(size_t)i * nint + n])].push_back(thr_key(e->p, m.thr[(size_t)i * nint + n]));
   finish_rank_tables(rt);
   return rt;
 }
@@ -436,6 +444,7 @@ bool build_prepass_image(const RankTables& rt, uint32_t W, uint32_t groups_wante
 
 bool prepass_plan_exists(const ddt_engine* e) {
   PrepassPlan pl;
+  if (!e->fmap.empty()) return false;  // compacted features: the pre-pass is the gathering transpose + rank_kernel
   return build_prepass_image(rank_tables(e), tuple_words(e->p), (uint32_t)e->q16_prepass_groups, e->q16_fused_prepass != 0, e->q16_grouped_prepass != 0,
                              nullptr, &pl);
 }
@@ -488,8 +497,9 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
   if (v.kind == kKindSparse) return false;  // sparse forests pick their kernel in ddt_sparse_host.cpp
   if (v.kind == kKindGeneric) return true;
   if ((uint32_t)v.levels != e->p.num_levels) return false;
-  const uint32_t W = tuple_words(e->p);
+  uint32_t W = tuple_words(e->p);
   if (v.kind == kKindQ16) {
+    W = q16_words(e);  // (feature compaction: the width the rank-quantised kernels see)
     // depth <= 8: two blocks per CU or it is not worth it; deeper trees have no other specialised kernel: one block
     if (W > v.max_tuple_words_q16() || v.lds_bytes_q16(W) > (((v.levels <= 8 || v.deep()) && !v.wide()) ? kMaxLdsBytes / 2u : kMaxLdsBytes)) return false;
     // deep kernels: their stage gathers address the image with 32-bit byte offsets through one buffer resource
@@ -506,7 +516,7 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
         std::vector<std::vector<uint32_t>> cnt(groups, std::vector<uint32_t>(W, 0u));
         for (uint32_t i = 0; i < T; ++i) {
           std::vector<uint32_t>& c = cnt[cm_position(i, T, Cc) / 8u];
-          for (uint32_t n = 0; n < nint; ++n) ++c[m.fidx[(size_t)i * nint + n]];
+          for (uint32_t n = 0; n < nint; ++n) ++c[q16_feat(e, m.fidx[(size_t)i * nint + n])];
         }
         for (const auto& c : cnt)
           for (uint32_t k : c)
@@ -550,14 +560,14 @@ int auto_variant(const ddt_engine* e) {
   // Perfect trees deeper than 8 levels (the reference's own example is 512 x depth 12, profiler/profiler.cpp:32-38; a depth-12 tree is exactly
   // one PU's memory, DTPU.sv:22-25): the deep rank-quantised kernels -- K = 8 / 9 levels out of LDS at two blocks per CU, the rest in
   // (D - K + 1) / 2 gathers of 16-byte records per tree.  Whatever the number of trees: the alternative is the generic kernel.
-  if (e->p.num_levels > 8u && e->p.sum_mode != 1u && tuple_words(e->p) <= 64u) {
+  if (e->p.num_levels > 8u && e->p.sum_mode != 1u && q16_words(e) <= 64u) {
     for (int i = 0; i < num_variants(); ++i)  // (table order: the two-blocks-per-CU forms first, then the wide ones for 33..64 words)
       if (variant(i).kind == kKindQ16 && variant(i).deep() && !deep_disabled() && variant_fits(variant(i), e)) return i;
   }
   // Tuples of 33..64 words, depth 8: the wide rank-quantised kernels (one block of 16 waves per CU, transpose + rank pre-pass) from the
   // same tree count on as the narrow ones -- 1000 x d8 x 64 / 48 / 33 features: 619 / 635 / 656 Mtuples/s against 432 / 533 / 535 on the fp32
   // tile kernels (profiles/r05_wide_and_deep_ab.md); below that tree count and beyond 64 words the fp32 tile kernels
-  if (tuple_words(e->p) > 32u && tuple_words(e->p) <= 64u && total_trees(e) >= 224u) {
+  if (q16_words(e) > 32u && q16_words(e) <= 64u && total_trees(e) >= 224u) {
     static const char* wpref[] = {"q16w_d8_c8_u4_gl_s2_cm_x", "q16w_d8_c8_u4_gl"};  // (depth 8 only: at depth 6 the fp32 tile kernel is as fast)
     for (const char* name : wpref) {
       const int i = find_variant(name);
@@ -565,7 +575,7 @@ int auto_variant(const ddt_engine* e) {
     }
   }
   uint32_t q16_min = 224u;
-  if (tuple_words(e->p) <= 32u && total_trees(e) * e->p.num_levels >= kQ16MinTreeLevels && total_trees(e) < 224u && prepass_plan_exists(e))
+  if (q16_words(e) <= 32u && total_trees(e) * e->p.num_levels >= kQ16MinTreeLevels && total_trees(e) < 224u && prepass_plan_exists(e))
     q16_min = total_trees(e);
   if (total_trees(e) >= q16_min) {  // the pre-pass is shared by the classes of a multi-class model
     // (the cluster-major form only where there is a ring to save -- more than one cluster -- and the sum follows the reference's
@@ -607,7 +617,7 @@ int auto_variant(const ddt_engine* e) {
 }
 
 void free_images(ddt_engine* e) {
-  for (void** p : {&e->d_mc_img, &e->d_mc_img_slow}) {
+  for (void** p : {&e->d_mc_img, &e->d_mc_img_slow, &e->d_fmap}) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
@@ -815,7 +825,7 @@ uint32_t cm_position(uint32_t i, uint32_t T, uint32_t Cc) {
 // Cut a cluster-major image into parts whose distinct thresholds per feature fit the u16 ranks: chunks are taken in image order while
 // every feature's key set stays within kQ16MaxTable (greedy; a chunk of 8 trees alone never exceeds it).
 int plan_q16_parts(ddt_engine* e, const Variant& v, const Ensemble& m, Q16HostImage& h) {
-  const uint32_t T = m.trees(), nint = e->nint, W = tuple_words(e->p), CT = (uint32_t)v.chunk_trees;
+  const uint32_t T = m.trees(), nint = e->nint, W = q16_words(e), CT = (uint32_t)v.chunk_trees;
   const uint32_t Cc = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, Tpad = padded_trees(v, T), n_chunks = Tpad / CT;
   // (a part ends on a whole PU group -- the sum's state between two launches is {cluster accumulator, running total}, not a half group: the
   // deep kernels' chunks of 4 trees are taken in pairs)
@@ -838,7 +848,7 @@ int plan_q16_parts(ddt_engine* e, const Variant& v, const Ensemble& m, Q16HostIm
     for (uint32_t c = 0; c < n_chunks; c += pc) {
       std::vector<std::vector<uint32_t>> add(W);
       for (uint32_t i : trees_of_chunk[c])
-        for (uint32_t n = 0; n < nint; ++n) add[m.fidx[(size_t)i * nint + n]].push_back(thr_key(e->p, m.thr[(size_t)i * nint + n]));
+        for (uint32_t n = 0; n < nint; ++n) add[q16_feat(e, m.fidx[(size_t)i * nint + n])].push_back(thr_key(e->p, m.thr[(size_t)i * nint + n]));
       RankTables next;
       if (merged_fits(add, &next)) {
         cur = std::move(next);
@@ -861,7 +871,7 @@ int plan_q16_parts(ddt_engine* e, const Variant& v, const Ensemble& m, Q16HostIm
 
 // host half of build_image_q16 (no HIP call; also behind the test hook ddt_debug_model_image)
 int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const RankTables& rt, bool upload_tables, Q16HostImage& h) {
-  const uint32_t D = e->p.num_levels, T = m.trees(), nint = e->nint, nleaf = e->nleaf, W = tuple_words(e->p);
+  const uint32_t D = e->p.num_levels, T = m.trees(), nint = e->nint, nleaf = e->nleaf, W = q16_words(e);
   const uint32_t tree_words = v.tree_bytes_q16() / 4u, Tpad = padded_trees(v, T);
   std::vector<uint32_t>&fast = h.fast, &slow = h.slow;
   try {
@@ -875,7 +885,7 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
     if (rc) return rc;
   } else {
     RankHostTables rk;
-    const int rc = pack_rank_tables(e, rt, W, upload_tables, rk);
+    const int rc = pack_rank_tables(e, rt, W, upload_tables && e->fmap.empty(), rk);
     if (rc) return rc;
     h.tab.swap(rk.tab);
     h.tabK.swap(rk.tabK);
@@ -914,7 +924,7 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
       const uint32_t pos = cm_pos(i);
       const RankTables& trt = tables_of(pos);
       auto record = [&](uint32_t n, bool with_flag) -> uint32_t {  // node n of tree i (0-based heap)
-        const uint32_t j = m.fidx[(size_t)i * nint + n], key = thr_key(e->p, m.thr[(size_t)i * nint + n]);
+        const uint32_t j = q16_feat(e, m.fidx[(size_t)i * nint + n]), key = thr_key(e->p, m.thr[(size_t)i * nint + n]);
         const auto& k = trt.keys[j];
         const uint32_t idx = (uint32_t)(std::lower_bound(k.begin(), k.end(), key, [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; }) - k.begin());
         return (idx + 1u) | ((j * row) << 16) | ((with_flag && m.mright[(size_t)i * nint + n]) ? 1u << 16 : 0u);
@@ -949,7 +959,7 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
     uint32_t* t = fast.data() + rec_off(cm_pos(i));
     const RankTables& trt = tables_of(cm_pos(i));
     for (uint32_t n = 0; n < nint; ++n) {
-      const uint32_t j = m.fidx[(size_t)i * nint + n], key = thr_key(e->p, m.thr[(size_t)i * nint + n]);
+      const uint32_t j = q16_feat(e, m.fidx[(size_t)i * nint + n]), key = thr_key(e->p, m.thr[(size_t)i * nint + n]);
       const auto& k = trt.keys[j];
       const uint32_t idx = (uint32_t)(std::lower_bound(k.begin(), k.end(), key, [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; }) - k.begin());
       t[n + 1] = (idx + 1u) | ((j * row) << 16);
@@ -988,7 +998,7 @@ int build_image_q16(ddt_engine* e, const Variant& v, Ensemble& m, const RankTabl
     m.parts.resize(h.part_tables.size());
     for (size_t k = 0; k < m.parts.size(); ++k) {
       RankHostTables rk;
-      int rc2 = pack_rank_tables(e, h.part_tables[k], tuple_words(e->p), true, rk);
+      int rc2 = pack_rank_tables(e, h.part_tables[k], q16_words(e), e->fmap.empty(), rk);
       if (!rc2) rc2 = upload_rank_tables(e, rk, m.parts[k].rank);
       if (rc2) return rc2;
       m.parts[k].chunk_begin = h.part_chunk_begin[k];
@@ -1051,7 +1061,7 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   const uint64_t cap = rows > e->q_rows[k] ? rows : e->q_rows[k];
   e->q_rows[k] = 0;
   e->q_xT_valid[k] = false;
-  const uint32_t W = tuple_words(e->p);
+  const uint32_t W = e->sparse ? tuple_words(e->p) : q16_words(e);
   if (need_xT) HIP_TRY(e, hipMalloc(&e->q_xT[k], cap * W * 4));
   HIP_TRY(e, hipMalloc(&e->q_q[k], cap * W * (r32 ? 4 : 2)));
   if (in_parts) HIP_TRY(e, hipMalloc(&e->q_state[k], cap * 2 * sizeof(float)));
@@ -1060,7 +1070,28 @@ int ensure_q16_workspace(ddt_engine* e, size_t n) {
   return DDT_OK;
 }
 
+// the features the loaded trees test, when compaction applies: more than 64 tuple words, at most 64 of them used (option "feature_compaction")
+void plan_feature_compaction(ddt_engine* e) {
+  e->fmap.clear();
+  e->finv.clear();
+  if (e->d_fmap) (void)hipFree(e->d_fmap);
+  e->d_fmap = nullptr;
+  const uint32_t W = tuple_words(e->p);
+  if (!e->feature_compaction || W <= 64u) return;
+  std::vector<uint8_t> used(W, 0);
+  for (const Ensemble& m : e->ens)
+    for (uint16_t j : m.fidx) used[j] = 1;
+  std::vector<uint16_t> fmap;
+  for (uint32_t j = 0; j < W; ++j)
+    if (used[j]) fmap.push_back((uint16_t)j);
+  if (fmap.empty() || fmap.size() > 64u) return;
+  e->finv.assign(W, 0);
+  for (size_t c = 0; c < fmap.size(); ++c) e->finv[fmap[c]] = (uint16_t)c;
+  e->fmap.swap(fmap);
+}
+
 int select_and_build(ddt_engine* e) {
+  plan_feature_compaction(e);
   int vid = e->forced_variant;
   if (vid >= 0) {
     if (vid >= num_variants()) return fail(e, DDT_EINVAL, "variant %d out of range", vid);
@@ -1069,6 +1100,15 @@ int select_and_build(ddt_engine* e) {
                   e->p.num_levels, e->p.num_features);
   } else {
     vid = auto_variant(e);
+  }
+  if (variant(vid).kind != kKindQ16) {  // only the rank-quantised kernels read compacted tuples
+    e->fmap.clear();
+    e->finv.clear();
+  } else if (!e->fmap.empty()) {  // the column map of the gathering transpose: one word per compacted tuple word, ~0 = padding
+    std::vector<uint32_t> cols(q16_words(e), 0xFFFFFFFFu);
+    for (size_t c = 0; c < e->fmap.size(); ++c) cols[c] = e->fmap[c];
+    HIP_TRY(e, hipMalloc(&e->d_fmap, cols.size() * 4u));
+    HIP_TRY(e, hipMemcpy(e->d_fmap, cols.data(), cols.size() * 4u, hipMemcpyHostToDevice));
   }
   RankTables rt;
   if (variant(vid).kind == kKindQ16) rt = rank_tables(e);
@@ -1107,7 +1147,7 @@ void fill_args(const ddt_engine* e, const Ensemble& m, const void* d_tuples, siz
   a->tuples = reinterpret_cast<const uint32_t*>(d_tuples);
   a->out = d_scores;
   a->n = n;
-  a->tuple_words = tuple_words(e->p);
+  a->tuple_words = variant(e->variant_id).kind == kKindQ16 ? q16_words(e) : tuple_words(e->p);  // (feature compaction: what the kernels see)
   a->n_trees = m.img_trees;
   a->n_chunks = m.img_chunks;
   a->levels = e->p.num_levels;
@@ -1230,6 +1270,8 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     const uint32_t U = (uint32_t)v.ilp_trees;
     qa.walk_subgroups = e->q16_walk_padding ? 0u : (v.opt & 4) ? qa.real_groups * 8u / U : (m.trees() + U - 1u) / U;
     qa.prepass_nt = (uint32_t)e->q16_prepass_nt;
+    qa.fmap = reinterpret_cast<const uint32_t*>(e->d_fmap);  // (feature compaction)
+    qa.in_words = tuple_words(e->p);
     if (all_classes) {
       a.img = reinterpret_cast<const uint4*>(e->d_mc_img);
       qa.img_slow = reinterpret_cast<const uint4*>(e->d_mc_img_slow);
@@ -1445,6 +1487,62 @@ std::vector<uint32_t> shard_of(const std::vector<uint32_t>& ids, uint32_t g, uin
   return std::vector<uint32_t>(ids.begin() + b, ids.begin() + en);
 }
 
+// A perfect-tree model for which the automatic choice found no tuned kernel -- depth >= 9 with more than 64 tuple words TESTED (feature
+// compaction above takes the others), depth 16 -- landed on `generic`, which gathers every feature of every visit from global memory
+// (512 x depth 12 x 200 features: 17 Mtuples/s).  A perfect tree IS a sparse tree whose leaves all sit at depth D: such a model is handed to the
+// sparse-forest path (top levels out of LDS, a feature tile of 64..256 tuples, 16-byte records below; ddt_sparse_host.cpp) -- same node
+// semantics (DTPU.sv:579-720), same adder order, same EMPTY slots.  Option "generic_via_sparse" = 0 keeps `generic` (A/B, tests).
+int maybe_score_as_sparse(ddt_engine* e) {
+  e->perfect_as_sparse = false;
+  if (!e->generic_via_sparse || e->forced_variant >= 0 || variant(e->variant_id).kind != kKindGeneric) return DDT_OK;
+  const uint32_t D = e->p.num_levels, nint = e->nint, first_last = (1u << (D - 1u)) - 1u;
+  // Measured on one MI355X, 4 M tuples, Mtuples/s on the sparse path against `generic` (profiles/r06_generic_cliffs.md): 512 x d12 x 200 features
+  // 118.6 vs 16.0, x 100 features 285 vs 41, 256 x d9 x 400 144 vs 30, 64 x d15 x 200 482 vs 90; with the fp64 sum 512 x d12 x 32 528 vs 225, x 64
+  // 446 vs 248, 256 x d10 x 32 1150 vs 579; 64 x d15 x 4 (PU groups beyond u16 ranks) 2074 vs 1138; 512 x d16 x 64 59 vs 55 -- and 512 x d16 x 32
+  // 69 vs 97: at depth 16 with at most 32 tuple words `generic` (features in LDS, every walker alive to the last level either way) stays
+  if (D >= 16u && tuple_words(e->p) <= 32u) return DDT_OK;
+  if ((uint64_t)total_trees(e) * nint * 16ull > (3ull << 29)) return DDT_OK;  // (1.5 GiB of node lines: stay where we are)
+  std::vector<SparseForest> sps(e->ens.size());
+  try {
+    for (size_t k = 0; k < e->ens.size(); ++k) {
+      const Ensemble& m = e->ens[k];
+      SparseForest& sp = sps[k];
+      sp.ids = m.ids;
+      sp.max_depth = D;
+      sp.first.assign(1, 0u);
+      sp.lines.resize((size_t)m.trees() * nint * 4u);
+      for (uint32_t i = 0; i < m.trees(); ++i) {
+        uint32_t* L = sp.lines.data() + (size_t)i * nint * 4u;
+        for (uint32_t n = 0; n < nint; ++n) {  // 0-based heap: children 2n + 1, 2n + 2; the last level's children are the leaves
+          const bool last = n >= first_last;
+          L[4u * n + 0u] = m.thr[(size_t)i * nint + n];
+          L[4u * n + 1u] = (uint32_t)m.fidx[(size_t)i * nint + n] | (m.mright[(size_t)i * nint + n] ? 1u << 13 : 0u) | (last ? 3u << 14 : 0u);
+          L[4u * n + 2u] = last ? m.leaf[(size_t)i * e->nleaf + 2u * (n - first_last)] : 2u * n + 1u;
+          L[4u * n + 3u] = last ? m.leaf[(size_t)i * e->nleaf + 2u * (n - first_last) + 1u] : 2u * n + 2u;
+        }
+        sp.first.push_back(sp.first.back() + nint);
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    return DDT_OK;  // no memory for the second form: `generic` it is
+  }
+  const int generic_id = e->variant_id;
+  e->sps = std::move(sps);
+  e->sparse = true;
+  const int rc = sparse_rebuild(e);
+  if (rc != DDT_OK || (variant(e->variant_id).opt & 4)) {  // nothing fits, or only the sparse format's own correctness kernel: no gain
+    sparse_free(e);
+    e->sps.clear();
+    e->sparse = false;
+    e->variant_id = generic_id;
+    e->err[0] = 0;
+    return DDT_OK;
+  }
+  free_images(e);  // the generic image; the parsed trees (e->ens) stay for a later re-pack
+  e->perfect_as_sparse = true;
+  return DDT_OK;
+}
+
 int load_common(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wlines, const void* fl, size_t n_flines,
                 uint32_t num_classes, int interleaved, uint32_t shard_index, uint32_t shard_count) {
   if (!e) return DDT_EINVAL;
@@ -1481,6 +1579,7 @@ int load_common(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wli
   sparse_free(e);
   e->sps.clear();
   e->sparse = false;
+  e->perfect_as_sparse = false;
   e->loaded = false;
   e->p = *p;
   e->nint = (1u << p->num_levels) - 1u;
@@ -1488,6 +1587,8 @@ int load_common(ddt_engine* e, const ddt_params* p, const void* wl, size_t n_wli
   e->num_classes = num_classes;
   e->ens = std::move(ens);
   rc = select_and_build(e);
+  if (rc) return rc;
+  rc = maybe_score_as_sparse(e);
   if (rc) return rc;
   e->loaded = true;
   e->st.model_lines_in += lines;
@@ -1866,12 +1967,23 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
       if (!dg.ok) return fail(e, DDT_EHIP, "hipSetDevice(%d) failed", e->device);
       HIP_TRY(e, hipDeviceSynchronize());
       e->loaded = false;
-      int rc = e->sparse ? sparse_rebuild(e) : select_and_build(e);
+      if (e->perfect_as_sparse) {  // a perfect-tree model that was handed to the sparse path: the choice starts over from its perfect form
+        sparse_free(e);
+        e->sps.clear();
+        e->sparse = false;
+        e->perfect_as_sparse = false;
+      }
+      auto rebuild = [&]() -> int {
+        if (e->sparse) return sparse_rebuild(e);
+        const int r1 = select_and_build(e);
+        return r1 ? r1 : maybe_score_as_sparse(e);
+      };
+      int rc = rebuild();
       if (rc) {  // e.g. the variant does not fit this model: the setting is not taken and the model stays loaded as it was
         char why[sizeof(e->err)];
         snprintf(why, sizeof(why), "%s", e->err);
         e->forced_variant = before;
-        if ((e->sparse ? sparse_rebuild(e) : select_and_build(e)) == DDT_OK) e->loaded = true;
+        if (rebuild() == DDT_OK) e->loaded = true;
         snprintf(e->err, sizeof(e->err), "%s", why);
         return rc;
       }
@@ -1935,6 +2047,14 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   }
   if (!strcmp(key, "sparse_idle_oob")) {  // A/B: 0 = finished walkers of the sparse kernels re-read record 0 (as before round 5); effective at the next call
     e->sparse_idle_oob = value != 0;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "generic_via_sparse")) {  // 1 (default): a perfect-tree model without a tuned kernel is scored by the sparse-forest kernels (maybe_score_as_sparse);
+    e->generic_via_sparse = value != 0;       // 0: it stays on `generic` (A/B, tests).  Effective at the next model load
+    return DDT_OK;
+  }
+  if (!strcmp(key, "feature_compaction")) {  // 1 (default): a model of more than 64 tuple words that tests at most 64 features runs on the rank-quantised kernels over
+    e->feature_compaction = value != 0;       // the compacted columns; 0: never (A/B, tests).  Effective at the next model load
     return DDT_OK;
   }
   if (!strcmp(key, "leaf_domain_check")) {  // 1 (default): refuse -0 / sub-normal / Inf / NaN leaves in the reference-order sum

@@ -180,6 +180,12 @@ struct ddt_engine {
   void* sp_r32_tab = nullptr;   // "sparse_r_*": the key blocks of the rank32 pre-pass (R32Aux::tab)
   size_t sp_r32_tab_bytes = 0;
   uint32_t sp_r32_blk_log2 = 2;
+  // feature compaction (ddt_engine.cpp plan_feature_compaction): compact tuple word -> feature number, its inverse, the device copy of the map
+  std::vector<uint16_t> fmap, finv;
+  void* d_fmap = nullptr;
+  int generic_via_sparse = 1;   // option "generic_via_sparse": a perfect-tree model that would land on `generic` goes to the sparse-forest kernels
+  bool perfect_as_sparse = false;  // ... and did: e->sps was built from e->ens (ddt_engine.cpp maybe_score_as_sparse)
+  int feature_compaction = 1;   // option "feature_compaction": 0 = never (models of more than 64 tuple words then stay off the rank-quantised kernels)
   int leaf_domain_check = 1;    // option "leaf_domain_check": reject leaves outside the exact domain of the reference adder
   ddt_stats st{};
   char err[256] = {0};

@@ -107,6 +107,10 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   // feature) are scored in PARTS ("_cm" kernels only): consecutive chunks of the cluster-major image with rank tables of their own, one
   // pre-pass + scoring launch per part.  The reference-order sum runs THROUGH the parts: a launch starts from the accumulator and the
   // running total its predecessor left per tuple (state_in) after group0 PU groups, and leaves them (state_out) instead of the score.
+  // feature compaction (ddt_engine.cpp): the kernels see tuples of ScoreArgs::tuple_words words, the caller's rows have in_words of them; the
+  // pre-pass's transpose gathers column fmap[c] of a row into compact column c (~0: padding, reads as 0).  fmap == nullptr: no compaction
+  const uint32_t* fmap = nullptr;
+  uint32_t in_words = 0;
   const float* state_in = nullptr;   // [2][n_pad]: accumulator of the cluster in progress, running total over the finished clusters
   float* state_out = nullptr;
   uint32_t group0 = 0;               // PU groups (cluster-major order) in front of this launch's image

@@ -490,6 +490,43 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restri
   for (uint32_t c = 0; c < W; ++c) xT[(uint64_t)c * n_pad + row0 + tid] = lds_u32((tid * S + c) * 4u);
 }
 
+// Feature compaction (ddt_engine.cpp plan_feature_compaction): the same transposed intermediate from rows of `Win` words of which only the columns
+// cols[0 .. Wc) are wanted (~0 = a padding column: zeros).  R rows per block go through LDS [R][Win + 1] (coalesced 16-byte loads of whole rows --
+// the rows are read once, like every tuple row of every path -- odd stride: conflict-free column reads), then thread (row r, column group) writes
+// its columns.  R = the largest power of two <= 64 whose stage fits 96 KiB (Win = 2048: 8 rows).
+__global__ __launch_bounds__(256) void gather_transpose_kernel(const uint32_t* __restrict__ tuples, uint32_t Win, const uint32_t* __restrict__ cols,
+                                                               uint32_t Wc, uint64_t n, uint64_t n_pad, uint32_t R, uint32_t* __restrict__ xT) {
+  const uint32_t tid = threadIdx.x, S = Win + 1u, LPT = Win / 4u;
+  const uint64_t row0 = (uint64_t)blockIdx.x * R;
+  const uint32_t rows = row0 >= n ? 0u : (uint32_t)((n - row0) < R ? (n - row0) : R);
+  const uint4* src = reinterpret_cast<const uint4*>(tuples + row0 * Win);
+  for (uint32_t e = tid; e < rows * LPT; e += 256u) {
+    const uint4 v = src[e];
+    const uint32_t r = e / LPT, c = (e - r * LPT) * 4u;
+    lds_st_u32((r * S + c + 0u) * 4u, v.x);
+    lds_st_u32((r * S + c + 1u) * 4u, v.y);
+    lds_st_u32((r * S + c + 2u) * 4u, v.z);
+    lds_st_u32((r * S + c + 3u) * 4u, v.w);
+  }
+  __syncthreads();
+  const uint32_t r = tid % R, g = tid / R, G = 256u / R;
+  for (uint32_t c = g; c < Wc; c += G) {
+    const uint32_t f = cols[c];
+    xT[(uint64_t)c * n_pad + row0 + r] = (r < rows && f != 0xFFFFFFFFu) ? lds_u32((r * S + f) * 4u) : 0u;
+  }
+}
+
+hipError_t launch_gather_transpose(const uint32_t* tuples, uint32_t Win, const uint32_t* cols, uint32_t Wc, uint64_t n, uint64_t n_pad, uint32_t* xT,
+                                   hipStream_t s) {
+  uint32_t R = 64;
+  while (R > 8u && (size_t)R * (Win + 1u) * 4u > 96u * 1024u) R >>= 1;
+  const uint32_t lds = R * (Win + 1u) * 4u;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_transpose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(gather_transpose_kernel, dim3((uint32_t)(n_pad / R)), dim3(256), lds, s, tuples, Win, cols, Wc, n, n_pad, R, xT);
+  return hipGetLastError();
+}
+
 hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint64_t n_pad, uint32_t* xT, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(transpose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((W + 1) * 256 * 4));
   if (e != hipSuccess) return e;
@@ -1230,8 +1267,14 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
   } else {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(transpose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((W + 1) * 256 * 4));
     if (e != hipSuccess) return e;
-    if (!x.skip_transpose)
-      hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
+    if (!x.skip_transpose) {
+      if (x.fmap) {  // feature compaction: only the columns the model tests, out of rows of in_words words
+        e = launch_gather_transpose(a.tuples, x.in_words, x.fmap, W, a.n, x.n_pad, x.xT, s);
+        if (e != hipSuccess) return e;
+      } else {
+        hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
+      }
+    }
     // grid-stride over tiles; blockIdx.y = feature; the table (up to 128 KiB) is loaded once per block, so the blocks are as few and as
     // long-lived as fill the chip: resident blocks per CU (one with a big table, two when two fit) x CUs, split over the features.  (Until
     // round 5: up to 512 blocks per feature -- 16384 blocks of ~19 tiles each at 32 features, a third of whose time was the table load:

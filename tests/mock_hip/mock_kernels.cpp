@@ -101,7 +101,8 @@ void enqueue_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s) {
     for (uint64_t t = 0; t < tiles; ++t) x.tile_flags[t] = 0u;
     for (uint64_t i = 0; i < a.n; ++i)
       for (uint32_t j = 0; j < W; ++j) {
-        const uint32_t raw = a.tuples[i * W + j];
+        // (feature compaction, csrc/ddt_engine.cpp: compact column j = column fmap[j] of a row of in_words words; ~0 = padding, reads as 0)
+        const uint32_t raw = !x.fmap ? a.tuples[i * W + j] : x.fmap[j] == 0xFFFFFFFFu ? 0u : a.tuples[i * x.in_words + x.fmap[j]];
         uint16_t r;
         if (raw == a.miss_raw) {
           r = 0xFFFFu;

@@ -840,10 +840,26 @@ def test_deep_perfect_trees_on_the_deep_kernels(mock, T, D, F, clusters, name, p
         out = np.full(n, np.nan, np.float32)
         assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
         assert np.array_equal(_bits(out), _bits(O.score_shard(m, x, (T + 1) // 2, T, sum_mode=O.SUM_REF_NATIVE)))
-    # the fp64 sum runs in stream order: not on a cluster-major image -> the generic kernel, and the engine says so
+    # the fp64 sum runs in stream order: not on a cluster-major image.  Round 6: a perfect tree is a sparse tree whose leaves all sit at depth D --
+    # the model goes to the sparse-forest kernels (maybe_score_as_sparse) instead of `generic`; with the switch off: `generic`, and the engine says so
+    for via_sparse in (1, 0):
+        assert mock.ddt_set_option(e, b"generic_via_sparse", via_sparse) == 0
+        _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=1), None)
+        assert mock.ddt_get_info(e, C.byref(info)) == 0
+        if via_sparse:
+            assert info.variant_name.decode().startswith("sparse_") and info.fallback_kernel == 0 and info.num_levels == D and info.local_trees == T, info.variant_name
+        else:
+            assert info.variant_name.decode() == "generic" and info.fallback_kernel == 1
+        out = np.full(n, np.nan, np.float32)
+        assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
+        assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=O.SUM_F64_SEQ)))
+    # a forced perfect-tree kernel takes the model back from the sparse path, the automatic choice hands it over again
+    assert mock.ddt_set_option(e, b"generic_via_sparse", 1) == 0
     _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=1), None)
-    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == "generic" and info.fallback_kernel == 1
-    out = np.full(n, np.nan, np.float32)
+    assert mock.ddt_set_option(e, b"variant", _variant(mock, "generic")) == 0 and mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == "generic"
+    assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
+    assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=O.SUM_F64_SEQ)))
+    assert mock.ddt_set_option(e, b"variant", -1) == 0 and mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_")
     assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
     assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=O.SUM_F64_SEQ)))
     mock.ddt_destroy(e)
@@ -881,6 +897,54 @@ def test_tuples_of_33_to_64_words_take_the_wide_rank_quantised_kernels(mock, T, 
     mock.ddt_destroy(e)
 
 
+def _widen(m, F_small, F_wide, seed, **kw):
+    """the same trees over F_wide features of which only F_small are tested: feature j of the model becomes feature cols[j] (cols[0] = 0, so
+    that the lines' padding entries stay what they are)"""
+    rng = np.random.default_rng(seed)
+    cols = np.concatenate([[0], np.sort(rng.choice(np.arange(1, F_wide), F_small - 1, replace=False))]).astype(np.uint16)
+    fl = m.flines.copy()
+    fl = (fl & np.uint16(0xF800)) | cols[fl & np.uint16(0x7FF)]
+    q = m.params
+    return O.Model(O.make_params(q.num_trees, q.num_levels, F_wide, q.missing_bits, q.cmp_mode, q.clusters_per_tuple), m.wlines, fl), cols
+
+
+@pytest.mark.parametrize("T,D,Fs,Fw,clusters,sum_mode,name", [(9, 12, 60, 200, 1, 0, "q16dw_d12_k9_c4_u4_cm"), (12, 10, 30, 2048, 2, 2, "q16d_d10_k9_c4_u4_cm"),
+                                                               (230, 8, 40, 100, 2, 0, "q16w_d8_c8_u4_gl_s2_cm_x"), (260, 8, 20, 68, 4, 0, "q16_d8_c8_u4_gl_s2_cm_x"),
+                                                               (9, 12, 65, 200, 1, 0, "sparse_")])
+def test_wide_models_that_test_few_features_are_compacted(mock, T, D, Fs, Fw, clusters, sum_mode, name):
+    """a perfect-tree model of more than 64 tuple words (the reference takes F <= 2048, DTPU.sv:22-25,628) fell to `generic`
+    or to the fp32 tile kernels whatever it tested.  With at most 64 DISTINCT features in its nodes it now runs on the rank-quantised kernels:
+    the pre-pass's transpose gathers those columns (Q16Aux::fmap), tables / tiles / records see the compact width.  65 used features: not compacted -- the sparse-forest kernels (maybe_score_as_sparse)."""
+    mock.mock_reset(2, 4, 8)
+    n = 1100
+    m, cols = _widen(O.gen_model(T, D, Fs, 1, clusters=clusters), Fs, Fw, 5)
+    x = O.gen_tuples(0, n, Fw, 1)
+    x[::9, cols[1]] = m.params.missing_bits      # missing values on a tested column ...
+    x[::7, (int(cols[1]) + 1) % Fw] = m.params.missing_bits if (int(cols[1]) + 1) % Fw not in cols else x[::7, (int(cols[1]) + 1) % Fw]   # ... and on one no node reads
+    ref = {0: O.SUM_REF_NATIVE, 2: O.SUM_REF_FLOPOCO}[sum_mode]
+    want = O.score_fast(m, x, sum_mode=ref)
+    e, info = _engine(mock), ddt.Info()
+    _load(mock, e, m, ddt.make_params(T, D, Fw, clusters=clusters, sum_mode=sum_mode), None)
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith(name), info.variant_name   # (65 tested features: the sparse path)
+    assert info.tuple_words == (Fw + 3) // 4 * 4 and info.fallback_kernel == 0
+    s = _stream(mock)
+    outs = [np.full(n, np.nan, np.float32) for _ in range(2)]
+    for out in outs:
+        assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0, mock.ddt_last_error(e)
+    assert mock.hipStreamSynchronize(s) == 0
+    for out in outs:
+        assert np.array_equal(_bits(out), _bits(want))
+    host = np.full(n, np.nan, np.float32)
+    assert mock.ddt_set_option(e, b"feeder_rows", 500) == 0
+    assert mock.ddt_score(e, x.ctypes.data, n, host.ctypes.data) == 0 and np.array_equal(_bits(host), _bits(want))
+    # the A/B switch: off, the model is where it was before round 6 -- and still right
+    assert mock.ddt_set_option(e, b"feature_compaction", 0) == 0
+    _load(mock, e, m, ddt.make_params(T, D, Fw, clusters=clusters, sum_mode=sum_mode), None)
+    assert mock.ddt_get_info(e, C.byref(info)) == 0 and not info.variant_name.decode().startswith("q16"), info.variant_name
+    assert mock.ddt_score(e, x.ctypes.data, n, host.ctypes.data) == 0 and np.array_equal(_bits(host), _bits(want))
+    mock.ddt_destroy(e)
+
+
 @pytest.mark.parametrize("T,K,F,clusters", [(60, 3, 3, 1), (120, 2, 3, 2), (66, 3, 4, 4)])
 def test_multiclass_deep_models_scored_in_parts(mock, T, K, F, clusters):
     """The classes of a one-vs-all model share one set of rank tables; when those exceed the u16 ranks (here 512-tree-like threshold counts on 3-4
@@ -913,11 +977,17 @@ def test_a_pu_group_beyond_the_u16_ranks_falls_back_and_says_so(mock):
     T, D, F, n = 9, 15, 4, 300
     m, x = O.gen_model(T, D, F, 0), O.gen_tuples(0, n, F, 0)
     e, info = _engine(mock), ddt.Info()
-    _load(mock, e, m, ddt.make_params(T, D, F), None)
-    assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == "generic" and info.fallback_kernel == 1
-    out = np.full(n, np.nan, np.float32)
-    assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
-    assert np.array_equal(_bits(out), _bits(O.score_fast(m, x)))
+    for via_sparse in (0, 1):   # (round 6: by default such a model goes on to the sparse-forest kernels, which take any number of thresholds)
+        assert mock.ddt_set_option(e, b"generic_via_sparse", via_sparse) == 0
+        _load(mock, e, m, ddt.make_params(T, D, F), None)
+        assert mock.ddt_get_info(e, C.byref(info)) == 0
+        if via_sparse:
+            assert info.variant_name.decode().startswith("sparse_") and info.fallback_kernel == 0, info.variant_name
+        else:
+            assert info.variant_name.decode() == "generic" and info.fallback_kernel == 1
+        out = np.full(n, np.nan, np.float32)
+        assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
+        assert np.array_equal(_bits(out), _bits(O.score_fast(m, x)))
     mock.ddt_destroy(e)
 
 

@@ -326,17 +326,26 @@ def test_config4_shape_full_forest(eng):
     T, D, F, N = 512, 16, 64, 1_000_000
     w, f = ddt.synth_model(T, D, F)
     eng.set_option("variant", -1)
-    eng.load_model(ddt.make_params(T, D, F), w, f)
-    assert eng.info().variant_name.decode() == "generic"
+    m = O.Model(O.make_params(T, D, F), w, f)
     d = eng.synth_tuples_device(0, N, F)
-    a = eng.score_device(d)
-    b = eng.score_device(d)
-    torch.cuda.synchronize()
-    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     idx = torch.arange(0, N, 997, device="cuda")
     xs = d[idx].cpu().numpy().view(np.uint32)
-    m = O.Model(O.make_params(T, D, F), w, f)
-    assert np.array_equal(_bits(a[idx].cpu().numpy()), _bits(O.score(m, xs)))
+    want = O.score(m, xs)
+    try:
+        # round 6: no tuned perfect-tree kernel at depth 16 -> the engine hands the model to the sparse-forest kernels (a perfect tree is a sparse
+        # tree whose leaves all sit at depth D; here: 32-bit ranks + pair records); with the switch off it is `generic` as before
+        for via_sparse in (1, 0):
+            eng.set_option("generic_via_sparse", via_sparse)
+            eng.load_model(ddt.make_params(T, D, F), w, f)
+            name = eng.info().variant_name.decode()
+            assert (name.startswith("sparse_") and not eng.info().fallback_kernel) if via_sparse else name == "generic", name
+            a = eng.score_device(d)
+            b = eng.score_device(d)
+            torch.cuda.synchronize()
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+            assert np.array_equal(_bits(a[idx].cpu().numpy()), _bits(want)), name
+    finally:
+        eng.set_option("generic_via_sparse", 1)
     w2, f2 = ddt.synth_model(40, 6, 28)  # leave a small model behind for the tests that follow
     eng.load_model(ddt.make_params(40, 6, 28), w2, f2)
 

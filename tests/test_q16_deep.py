@@ -137,3 +137,47 @@ def test_tuples_of_33_to_64_words_on_the_wide_kernels(T, D, F, clusters, sum_mod
         assert np.array_equal(_bits(got.cpu().numpy()), _bits(want[:3000]))
         assert np.array_equal(_bits(e.score(x[:30_000])), _bits(want[:30_000]))
     e.close()
+
+
+def _widen(m, F_small, F_wide, seed):
+    """the same trees over F_wide features of which only F_small are tested (feature j -> cols[j]; cols[0] = 0 keeps the lines' padding entries)"""
+    rng = np.random.default_rng(seed)
+    cols = np.concatenate([[0], np.sort(rng.choice(np.arange(1, F_wide), F_small - 1, replace=False))]).astype(np.uint16)
+    fl = (m.flines & np.uint16(0xF800)) | cols[m.flines & np.uint16(0x7FF)]
+    q = m.params
+    return O.Model(O.make_params(q.num_trees, q.num_levels, F_wide, q.missing_bits, q.cmp_mode, q.clusters_per_tuple), m.wlines, fl), cols
+
+
+@pytest.mark.parametrize("T,D,Fs,Fw,clusters,name,n", [(40, 12, 60, 200, 2, "q16dw_d12_k9_c4_u4_cm", 150_001), (24, 10, 32, 2048, 1, "q16d_d10_k9_c4_u4_cm", 20_003),
+                                                        (300, 8, 48, 132, 4, "q16w_d8_c8_u4_gl_s2_cm_x", 90_000), (12, 15, 20, 400, 1, "q16d_d15_k8_c8_u4_cm", 60_000)])
+def test_wide_models_that_test_few_features_are_compacted(T, D, Fs, Fw, clusters, name, n):
+    """perfect-tree models of 65..2048 tuple words (DTPU.sv:22-25,628) whose nodes test at most 64 distinct features run on
+    the rank-quantised kernels over the compacted columns (the pre-pass's gathering transpose); both adders, missing values on tested and on
+    untested columns, ragged sizes, the host feeder; the switch off: the old kernel, the same bits."""
+    import torch
+
+    m, cols = _widen(O.gen_model(T, D, Fs, dist=1, clusters=clusters), Fs, Fw, 3)
+    x = O.gen_tuples(7, n, Fw, dist=1)
+    x[::11, cols[2]] = m.params.missing_bits
+    unused = next(j for j in range(Fw) if j not in set(cols.tolist()))
+    x[::5, unused] = m.params.missing_bits       # a missing value no node reads must not even pick the slow image's path wrongly
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    e = ddt.Engine(0)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        want = O.score_fast(m, x, sum_mode=ref)
+        e.load_model(ddt.make_params(T, D, Fw, clusters=clusters, sum_mode=sum_mode), m.wlines, m.flines)
+        info = e.info()
+        assert info.variant_name.decode() == name and info.fallback_kernel == 0 and info.tuple_words == (Fw + 3) // 4 * 4, info.variant_name
+        for k in (n, 1, 1023, 1025):
+            got = e.score_device(d[:k])
+            torch.cuda.synchronize()
+            bad = np.flatnonzero(_bits(got.cpu().numpy()) != _bits(want[:k]))
+            assert bad.size == 0, (name, sum_mode, k, bad[:8], bad.size)
+    assert np.array_equal(_bits(e.score(x[:50_001])), _bits(want[:50_001]))
+    e.set_option("feature_compaction", 0)
+    e.load_model(ddt.make_params(T, D, Fw, clusters=clusters, sum_mode=2), m.wlines, m.flines)
+    assert not e.info().variant_name.decode().startswith("q16")
+    got = e.score_device(d[:30_000])
+    torch.cuda.synchronize()
+    assert np.array_equal(_bits(got.cpu().numpy()), _bits(want[:30_000]))
+    e.close()

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--full-levels", type=int, default=10)
     ap.add_argument("--permille", type=int, default=700)
     ap.add_argument("--bins", type=int, default=0, help="sparse: snap every threshold to one of N values per feature (histogram-trained models)")
+    ap.add_argument("--wide-features", type=int, default=0, help="perfect trees: the model tests --features features out of this many (feature compaction A/B)")
+    ap.add_argument("--sum-mode", type=int, default=0)
     ap.add_argument("--variant", default="", help="kernel variant name")
     ap.add_argument("--opt", default="", help="engine options, comma separated key=value")
     a = ap.parse_args()
@@ -45,13 +47,19 @@ def main():
         eng.load_model_sparse(ddt.make_sparse_params(T, D, F), lines, first)
     else:
         w, f = ddt.synth_model(T, D, F, 0)
-        eng.load_model(ddt.make_params(T, D, F), w, f)
+        if a.wide_features > F:  # feature j of the model becomes column cols[j] of a tuple of --wide-features features
+            import numpy as np
+            cols = np.concatenate([[0], np.sort(np.random.default_rng(1).choice(np.arange(1, a.wide_features), F - 1, replace=False))]).astype(np.uint16)
+            f = np.ascontiguousarray(f).view(np.uint16).reshape(-1)
+            f = (f & np.uint16(0xF800)) | cols[f & np.uint16(0x7FF)]
+            F = a.wide_features
+        eng.load_model(ddt.make_params(T, D, F, sum_mode=a.sum_mode), w, f)
     info = eng.info()
     d = eng.synth_tuples_device(0, N, F)
     out = torch.empty(N, dtype=torch.float32, device="cuda")
     eng.score_device(d, out=out)
     torch.cuda.synchronize()
-    if not a.sparse and N >= 4096:  # parity on a prefix, so that an experiment cannot be fast and wrong
+    if not a.sparse and N >= 4096 and a.sum_mode == 0:  # parity on a prefix, so that an experiment cannot be fast and wrong
         import numpy as np
         from oracle import oracle as O
         m = O.Model(O.make_params(T, D, F), w, f)
