@@ -3,7 +3,7 @@
 //   tools/check_s2_isa.py      no instruction touches the "_s2" kernels' node-record SGPRs while their scalar loads are in flight
 //   tools/check_dma_waits.py   every counted `s_waitcnt vmcnt(N)` a barrier relies on covers the chunk DMA on every path (the deep kernels)
 // writes their outcome into lib/checks.flags and relinks with this file recompiled (the device code does not change).  A build that could
-// not run a check (no disassembler) keeps the 0: the automatic kernel choice then avoids the kernels concerned (csrc/ddt_engine.cpp
+// not run a check (no disassembler) keeps the 0: the automatic kernel choice then avoids the kernels concerned (csrc/ddt_choice.cpp
 // s2_disabled / deep_disabled) and ddt_info::build_checks says so.
 #ifndef DDT_S2_CHECKED
 #define DDT_S2_CHECKED 0

@@ -4,7 +4,7 @@
 // What it replaces: the same DTPU traversal loop + leaf reduce as ddt_kernels.hip (DTPU.sv:579-760; FPAddersReduceTree.sv:94-141,
 // FPAggregator.v:79-131, Core.sv:486-541) for trees whose node memory no longer fits a CU's LDS next to the tuples at two blocks per CU.
 // Rank-quantised like the depth-8 kernels (same records, same u16 rank tile, same pre-pass: ddt_kernels.hip launch_q16_prepass); image
-// layout: ddt_internal.h "deep rank-quantised kernels"; host packing: ddt_engine.cpp pack_image_q16.  No MFMA: compare + gather.
+// layout: ddt_internal.h "deep rank-quantised kernels"; host packing: ddt_image.cpp pack_image_q16.  No MFMA: compare + gather.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -287,7 +287,7 @@ static hipError_t launch_q16d(const ScoreArgs& a, const Variant& v, hipStream_t 
 #define DDT_QDW(NAME, D, K, CT) /* wide tuples (33..64 words): one block per CU */ \
   Variant { NAME, kKindQ16, D, kQTile, 1, CT, 4, 1, 36 | 64, &launch_q16d<D, K, CT, true>, K }
 
-// opt = cluster-major | deep (| wide), last field = K.  Table order = the engine's order of preference (ddt_engine.cpp auto_variant): the
+// opt = cluster-major | deep (| wide), last field = K.  Table order = the engine's order of preference (ddt_choice.cpp auto_variant): the
 // two-blocks-per-CU forms first, then the wide ones for tuples of 33..64 words
 static const Variant g_deep_variants[] = {
     DDT_QD("q16d_d12_k9_c4_u4_cm", 12, 9, 4),

@@ -1,5 +1,6 @@
 // ddt_engine_priv.h -- the engine object and the host-side helpers shared by the translation units of libddt.so
-// (ddt_engine.cpp: perfect-tree models, feeder, C-ABI; ddt_sparse_host.cpp: sparse forests; ddt_comm.cpp: RCCL).
+// (ddt_engine.cpp: launches, feeder, C-ABI; ddt_model.cpp / ddt_image.cpp / ddt_choice.cpp: perfect-tree models -- parsing, device images,
+// kernel choice; ddt_sparse_host.cpp: sparse forests; ddt_comm.cpp: RCCL).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -224,8 +225,34 @@ struct DeviceGuard {
   }
 };
 
-// helpers defined in ddt_engine.cpp
-uint32_t tuple_words(const ddt_params& p);
+// ---- ddt_model.cpp: the perfect-tree wire format ----
+uint32_t wlines_min(uint32_t D);
+uint32_t flines_min(uint32_t D);
+int validate(ddt_engine* e, const ddt_params* p, size_t n_wlines, size_t n_flines);
+int parse_trees(ddt_engine* eng, const ddt_params* p, const uint32_t* w, const uint16_t* f, std::vector<uint32_t> ids, ddt_engine::Ensemble* out);
+uint32_t padded_trees(const Variant& v, uint32_t T);
+uint32_t max_trees(const ddt_engine* e);
+// ---- ddt_image.cpp: device images, rank tables, pre-pass images ----
+uint32_t q16_words(const ddt_engine* e);                  // tuple words the rank-quantised kernels see (feature compaction)
+inline uint32_t q16_feat(const ddt_engine* e, uint32_t j) { return e->fmap.empty() ? j : e->finv[j]; }
+RankTables rank_tables(const ddt_engine* e);
+bool build_prepass_image(const RankTables& rt, uint32_t W, uint32_t groups_wanted, bool allow_one, bool allow_many, std::vector<uint32_t>* pimg,
+                         PrepassPlan* plan);
+bool prepass_plan_exists(const ddt_engine* e);
+uint32_t total_trees(const ddt_engine* e);
+uint32_t cm_position(uint32_t i, uint32_t T, uint32_t Cc);
+int build_image(ddt_engine* e, const Variant& v, ddt_engine::Ensemble& m);
+int build_image_q16(ddt_engine* e, const Variant& v, ddt_engine::Ensemble& m, const RankTables& rt, bool upload_tables);
+// ---- ddt_choice.cpp: which kernel ----
+bool classes_equal(const ddt_engine* e);
+bool s2_disabled();
+bool deep_disabled();
+bool variant_fits(const Variant& v, const ddt_engine* e);
+int auto_variant(const ddt_engine* e);
+int select_and_build(ddt_engine* e);
+int maybe_score_as_sparse(ddt_engine* e);
+uint32_t tuple_words(const ddt_params& p);               // (ddt_model.cpp)
+// ---- ddt_engine.cpp ----
 uint32_t thr_key(const ddt_params& p, uint32_t bits);
 std::vector<uint32_t> shard_of(const std::vector<uint32_t>& ids, uint32_t g, uint32_t G);
 void free_images(ddt_engine* e);

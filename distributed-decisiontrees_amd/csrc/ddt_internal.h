@@ -1,4 +1,4 @@
-// ddt_internal.h -- shared between the host engine (ddt_engine.cpp) and the HIP kernels (ddt_kernels.hip).
+// ddt_internal.h -- shared between the host side (ddt_engine.cpp, ddt_image.cpp, ddt_choice.cpp, ...) and the HIP kernels (ddt_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,7 +56,7 @@ constexpr uint32_t kQMissing = 0xFFFFu;  // rank of a missing feature value in t
 constexpr uint32_t kQ16RankBuckets = 4096;
 // LDS-resident rank pre-pass (no transposed fp32 intermediate): the features are cut into `groups` groups of `lines`
 // tuple lines (4 features each); a block keeps the tables of ONE group resident in LDS (image = bytes[g] at byte offset
-// img_off[g] of Q16Aux::prepass_img; layout: ddt_engine.cpp build_prepass_group).  groups == 1: fused_rank_kernel (all
+// img_off[g] of Q16Aux::prepass_img; layout: ddt_image.cpp build_prepass_group).  groups == 1: fused_rank_kernel (all
 // tables fit together, e.g. a 125-tree shard).  groups > 1: grouped_rank_kernel, ONE launch whose blocks are split over
 // the groups and over `parts` row partitions (= XCDs: the blocks of all groups that work on the same rows share one L2,
 // so a tuple row leaves HBM once although every group reads it).
@@ -98,7 +98,7 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   // n_segs > 1, trees per ensemble mod 8 in 1..4: the second half of every ensemble's partly filled PU group (= its chunk's second
   // sub-group) is EMPTY padding; that sub-group's walk is skipped, its +0 leaves are added as always.  The value is what the kernel's
   // count-down of an ensemble's chunks (seg_chunks .. 1) reads AT that chunk: seg_chunks - (the chunk's index in the ensemble's image).  In a
-  // cluster-major image the partial group is the last of ITS cluster's run, not necessarily of the image (ddt_engine.cpp cm_position).
+  // cluster-major image the partial group is the last of ITS cluster's run, not necessarily of the image (ddt_image.cpp cm_position).
   // 0 = nothing to skip (the count-down never reads 0).
   uint32_t seg_tail_left = 0;
   uint32_t* tile_counter = nullptr;  // work counter of the persistent blocks (zeroed per launch; engine workspace behind the pre-pass counters)
@@ -107,7 +107,7 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   // feature) are scored in PARTS ("_cm" kernels only): consecutive chunks of the cluster-major image with rank tables of their own, one
   // pre-pass + scoring launch per part.  The reference-order sum runs THROUGH the parts: a launch starts from the accumulator and the
   // running total its predecessor left per tuple (state_in) after group0 PU groups, and leaves them (state_out) instead of the score.
-  // feature compaction (ddt_engine.cpp): the kernels see tuples of ScoreArgs::tuple_words words, the caller's rows have in_words of them; the
+  // feature compaction (ddt_choice.cpp): the kernels see tuples of ScoreArgs::tuple_words words, the caller's rows have in_words of them; the
   // pre-pass's transpose gathers column fmap[c] of a row into compact column c (~0: padding, reads as 0).  fmap == nullptr: no compaction
   const uint32_t* fmap = nullptr;
   uint32_t in_words = 0;

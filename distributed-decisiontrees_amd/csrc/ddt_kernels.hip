@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restri
   for (uint32_t c = 0; c < W; ++c) xT[(uint64_t)c * n_pad + row0 + tid] = lds_u32((tid * S + c) * 4u);
 }
 
-// Feature compaction (ddt_engine.cpp plan_feature_compaction): the same transposed intermediate from rows of `Win` words of which only the columns
+// Feature compaction (ddt_choice.cpp plan_feature_compaction): the same transposed intermediate from rows of `Win` words of which only the columns
 // cols[0 .. Wc) are wanted (~0 = a padding column: zeros).  R rows per block go through LDS [R][Win + 1] (coalesced 16-byte loads of whole rows --
 // the rows are read once, like every tuple row of every path -- odd stride: conflict-free column reads), then thread (row r, column group) writes
 // its columns.  R = the largest power of two <= 64 whose stage fits 96 KiB (Win = 2048: 8 rows).
@@ -537,7 +537,7 @@ hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint
 constexpr uint32_t kRankThreads = 1024;  // two blocks per CU share the LDS with their tables: 32 waves x 4 searches each
 // Search = one bucket lookup + a short binary search.  The key range [lo, hi] of the feature's table is cut into
 // kRankBuckets equal slices of 2^shift codes; starts[b] = number of keys in slices < b, and no slice holds P or more
-// keys (P = power of two, per feature, from the host: ddt_engine.cpp build_image_q16), so log2(P) probes from
+// keys (P = power of two, per feature, from the host: ddt_image.cpp build_image_q16), so log2(P) probes from
 // starts[b] finish the count -- keys past the slice are > x by construction, no end test.  1000 trees x 255
 // nodes over 32 features (~8 k keys per table): 1 + 5 LDS reads instead of 13.  Degenerate key distributions
 // only make P larger, up to the plain binary search over the whole table.
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __re
 // Fused pre-pass for SMALL tables (all W tables + their bucket starts fit one CU's LDS, e.g. a 125-tree shard:
 // ~1000 keys per feature): one kernel reads the tuples row-wise and writes the rank tiles, no transposed fp32
 // intermediate -- HBM traffic 4F + 2F bytes per tuple instead of 4F + 4F + 4F + 2F.  The host packs the exact
-// LDS image (ddt_engine.cpp build_image_q16): per feature a skewed key table with >= P INT_MAX pads, 256 bucket
+// LDS image (ddt_image.cpp build_image_q16): per feature a skewed key table with >= P INT_MAX pads, 256 bucket
 // starts (u16) and 8 parameter words {K, lo, shift, table byte offset, starts byte offset, 0, 0, 0}.
 // A lane owns tuples t and t+512 of a tile (the two halves of one dword of the rank tile): quad-coalesced
 // loads + DPP transpose as in score_tile_kernel, then per feature two searches and one 4-byte store.
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __re
 // One tuple line (4 features) of two rows against the tables resident in LDS: 8 searches advance together (the
 // dependent LDS reads of one search are latency bound).  `par` = LDS byte address of the line's first parameter
 // block {K, lo, span, table byte offset | starts byte offset, segment table byte offset, segment shift, 0} (layout and
-// the segmented bucket index: ddt_engine.cpp build_prepass_group).  Search = segment lookup (a 32-entry table: few distinct
+// the segmented bucket index: ddt_image.cpp build_prepass_group).  Search = segment lookup (a 32-entry table: few distinct
 // addresses per wave) + bucket start + log2(P) probes; keys past the bucket are > x by construction, no end test.
 // Returns r(row0) | r(row1) << 16 per feature; in0 / in1 = the row exists (a missing value only counts there).
 __device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P, const uint32_t ieee, const uint32_t miss_raw, const bool in0,

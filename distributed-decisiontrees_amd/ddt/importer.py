@@ -82,7 +82,7 @@ class ImportedModel:
         return engine.load_model(self.params(**kw), self.wlines, self.flines, shard_index, shard_count)
 
 
-LEAF_MIN, LEAF_LIMIT = 2.0 ** -102, 2.0 ** 96   # the loader's exact leaf domain (csrc/ddt_engine.cpp leaf_outside_exact_domain)
+LEAF_MIN, LEAF_LIMIT = 2.0 ** -102, 2.0 ** 96   # the loader's exact leaf domain (csrc/ddt_model.cpp leaf_outside_exact_domain)
 
 
 def leaf_f32(v) -> np.float32:

@@ -102,7 +102,7 @@ def predict(g: Mi355x, n_trees: int, depth: int, n_features: int, n_gpus: int = 
             "t_score": t_score, "t_comm": t_comm}
 
 
-# ---- part 3: the engine's own cost model (what ddt_engine.cpp's auto_variant encodes), per GPU ----------------
+# ---- part 3: the engine's own cost model (what ddt_choice.cpp's auto_variant encodes), per GPU ----------------
 @dataclass
 class PathCosts:
     """Measured on one MI355X in round 4, milliseconds per 100 M tuples of 32 fp32 features, depth-8 trees (gpurun_out/r04_s3, r04_s4, r04_s5 =
@@ -120,7 +120,7 @@ class PathCosts:
 
 
 def prepass_ms(keys: int, c: "PathCosts") -> float:
-    """The engine's choice (ddt_engine.cpp build_prepass_image): cheapest feasible number of feature groups.  Bucket
+    """The engine's choice (ddt_image.cpp build_prepass_image): cheapest feasible number of feature groups.  Bucket
     budget -> probes: the LDS left after the tables holds ~2 bytes per bucket; P = power of two above the fullest bucket,
     about 4x the mean occupancy for thresholds uniform in value."""
     best = c.prepass_two_kernel
@@ -146,7 +146,7 @@ def engine_ms(trees: int, depth: int = 8, rows: float = 1e8, c: PathCosts = Path
     score = (c.q16_fixed + c.q16_ms_per_chunk * chunks) * scale
     q16 = pre * rows / 1e8 + score
     fp32 = (c.fp32_fixed + c.fp32_ms_per_tree * trees) * scale
-    q16_ok = trees >= 224 or (keys <= 8 * c.keys_per_group and trees * depth >= 640)  # ddt_engine.cpp kQ16MinTreeLevels
+    q16_ok = trees >= 224 or (keys <= 8 * c.keys_per_group and trees * depth >= 640)  # ddt_choice.cpp kQ16MinTreeLevels
     path = "q16" if q16_ok else "fp32"
     return {"path": path, "ms": q16 if path == "q16" else fp32, "q16_ms": q16, "fp32_ms": fp32, "prepass_ms": pre * rows / 1e8, "score_ms": score}
 

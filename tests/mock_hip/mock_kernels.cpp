@@ -1,5 +1,5 @@
 // mock_kernels.cpp -- TEST INFRASTRUCTURE (tests/test_engine_mock.py): CPU stand-ins for the scoring kernels, so that the REAL
-// host side of libddt (csrc/ddt_engine.cpp, ddt_comm.cpp, ddt_codec.cpp, ddt_sparse_host.cpp) can be built against the
+// host side of libddt (csrc/ddt_engine.cpp, ddt_model.cpp, ddt_image.cpp, ddt_choice.cpp, ddt_comm.cpp, ddt_codec.cpp, ddt_sparse_host.cpp) can be built against the
 // deferred-execution HIP / RCCL model of mock_runtime.cpp and run without a GPU: model load, image packing, variant choice,
 // the feeder's double buffering, the class launches on two streams, the rank-quantised path's workspace slots, the sharded
 // jobs -- all under adversarial stream schedules.
@@ -101,7 +101,7 @@ void enqueue_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s) {
     for (uint64_t t = 0; t < tiles; ++t) x.tile_flags[t] = 0u;
     for (uint64_t i = 0; i < a.n; ++i)
       for (uint32_t j = 0; j < W; ++j) {
-        // (feature compaction, csrc/ddt_engine.cpp: compact column j = column fmap[j] of a row of in_words words; ~0 = padding, reads as 0)
+        // (feature compaction, csrc/ddt_choice.cpp: compact column j = column fmap[j] of a row of in_words words; ~0 = padding, reads as 0)
         const uint32_t raw = !x.fmap ? a.tuples[i * W + j] : x.fmap[j] == 0xFFFFFFFFu ? 0u : a.tuples[i * x.in_words + x.fmap[j]];
         uint16_t r;
         if (raw == a.miss_raw) {
@@ -136,7 +136,7 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
     // "_p" kernels: the image may hold n_segs ensembles (classes) back to back, each with its own cluster-major order
     const uint32_t S = x.n_segs ? x.n_segs : 1u, seg_trees = a.n_trees / S;
     std::vector<float> leaf(seg_trees), img_order(a.n_trees);
-    // "_cm" images: PU groups in cluster-major order (csrc/ddt_engine.cpp pack_image_q16); original group g sits at position pos[g]
+    // "_cm" images: PU groups in cluster-major order (csrc/ddt_image.cpp pack_image_q16); original group g sits at position pos[g]
     std::vector<uint32_t> pos(seg_trees / 8u);
     for (uint32_t g = 0; g < (uint32_t)pos.size(); ++g) {
       pos[g] = g;

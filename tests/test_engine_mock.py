@@ -1,4 +1,4 @@
-"""The REAL host side of libddt -- csrc/ddt_engine.cpp, ddt_comm.cpp, ddt_codec.cpp, ddt_sparse_host.cpp, compiled unchanged --
+"""The REAL host side of libddt -- csrc/ddt_engine.cpp, ddt_model.cpp, ddt_image.cpp, ddt_choice.cpp, ddt_comm.cpp, ddt_codec.cpp, ddt_sparse_host.cpp, compiled unchanged --
 run without a GPU against the deferred-execution HIP / RCCL model of tests/mock_hip/ (see test_comm_mock.py) and CPU
 stand-ins for the kernels (mock_kernels.cpp) that read what the real kernels read: the packed images the engine uploads, the
 tuple lines, the threshold tables and the rank workspace of the rank-quantised path.  Results are held to the oracle bit for
@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 MOCK = os.path.join(HERE, "mock_hip")
 CSRC = os.path.join(os.path.dirname(HERE), "distributed-decisiontrees_amd", "csrc")
 vp = C.c_void_p
-SOURCES = ["ddt_engine.cpp", "ddt_comm.cpp", "ddt_codec.cpp", "ddt_sparse_host.cpp"]
+SOURCES = ["ddt_engine.cpp", "ddt_model.cpp", "ddt_image.cpp", "ddt_choice.cpp", "ddt_comm.cpp", "ddt_codec.cpp", "ddt_sparse_host.cpp"]
 SCHEDULES = [(0, 0), (1, 0), (2, 21), (2, 22), (2, 23)]
 
 

@@ -141,7 +141,7 @@ def test_xgboost_json_dump():
 
 
 def test_leaf_values_land_in_the_loaders_exact_domain():
-    """The importer's leaf rule == the loader's check (csrc/ddt_engine.cpp leaf_outside_exact_domain: +0 or a normal with
+    """The importer's leaf rule == the loader's check (csrc/ddt_model.cpp leaf_outside_exact_domain: +0 or a normal with
     2^-102 <= |v| < 2^96): what it emits loads with the default options; what it cannot represent raises instead of failing later."""
     for v, want in ((1e-35, 0.0), (-1e-35, 0.0), (-0.0, 0.0), (1e-45, 0.0), (2.0 ** -102, 2.0 ** -102), (-(2.0 ** -102), -(2.0 ** -102)),
                     (0.1, np.float32(0.1)), (2.0 ** 95, 2.0 ** 95)):
