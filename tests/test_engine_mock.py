@@ -937,6 +937,20 @@ def test_wide_models_that_test_few_features_are_compacted(mock, T, D, Fs, Fw, cl
     host = np.full(n, np.nan, np.float32)
     assert mock.ddt_set_option(e, b"feeder_rows", 500) == 0
     assert mock.ddt_score(e, x.ctypes.data, n, host.ctypes.data) == 0 and np.array_equal(_bits(host), _bits(want))
+    # a shard of a tree-sharded job compacts the features ITS trees test; one-vs-all classes share one column map
+    if T >= 12:
+        _load(mock, e, m, ddt.make_params(T, D, Fw, clusters=clusters), None, shard=(1, 2))
+        out = np.full(n, np.nan, np.float32)
+        assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
+        assert np.array_equal(_bits(out), _bits(O.score_shard(m, x, (T + 1) // 2, T, sum_mode=O.SUM_REF_NATIVE)))
+        K = 3
+        pk = ddt.make_params(T, D, Fw, clusters=1)
+        mk = O.Model(O.make_params(T, D, Fw, clusters=1), m.wlines, m.flines)
+        assert mock.ddt_load_model_multiclass(e, C.byref(pk), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8, K, 1, 0, 1) == 0, mock.ddt_last_error(e)
+        wl, wcs = O.classify_fast(mk, x, K, True)
+        gl, gs = np.full(n, -1, np.int32), np.full((K, n), np.nan, np.float32)
+        assert mock.ddt_classify_device(e, x.ctypes.data, n, gs.ctypes.data, gl.ctypes.data, None) == 0 and mock.hipDeviceSynchronize() == 0
+        assert np.array_equal(gl, wl) and np.array_equal(_bits(gs), _bits(wcs))
     # the A/B switch: off, the model is where it was before round 6 -- and still right
     assert mock.ddt_set_option(e, b"feature_compaction", 0) == 0
     _load(mock, e, m, ddt.make_params(T, D, Fw, clusters=clusters, sum_mode=sum_mode), None)

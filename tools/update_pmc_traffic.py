@@ -72,16 +72,31 @@ def main():
               "round": 4, "source": f"{ev} (tools/gpu_evidence_slim.sh): `python bench.py --config 1 --steps 10 --warmup 3 --no-cpu-baseline --no-streamed`"}
         json.dump(j1, open(os.path.join(ROOT, "profiles", "pmc_traffic_cfg1.json"), "w"), indent=1)
         print("config 1:", j1["hbm_bytes_per_launch"], "B/launch against", j1["algorithmic_bytes_per_launch"], "algorithmic")
-    # ---- config 4: sparse forest -----------------------------------------------------------------------------------
+    # ---- config 4: sparse forest (round 6: `sparse_r_k9_u8_t256` -- a rank pre-pass + the scoring kernel over the 32-bit rank tile) -------------
     p4 = os.path.join(ROOT, "profiles", "pmc_traffic_cfg4.json")
-    c4 = json.load(open(p4))
     f, w = pmc(ev + "/fetch_cfg4", "score_sparse"), pmc(ev + "/write_cfg4", "score_sparse")
     if f and w:
         fr4, wr4 = kib(f, "FETCH_SIZE"), kib(w, "WRITE_SIZE")
-        c4.update({"fetch_bytes_raw_per_launch": fr4, "write_bytes_per_launch": wr4,
-                   "hbm_bytes_per_launch": fr4 + c4["tuple_stream_bytes"] // 2 + wr4, "source": f"{ev}: `{cmd.format(4)}`"})
+        tile = 10000000 * 64 * 4  # the rank tile the scoring kernel DMAs in (wide coalesced stream: counted at half on gfx950)
+        pre4 = {}
+        for name, like in (("rank32", "rank32_kernel"), ("transpose", "transpose_kernel")):
+            f2, w2 = pmc(ev + "/fetch_cfg4", like), pmc(ev + "/write_cfg4", like)
+            if f2 or w2:
+                pre4[name] = {"FETCH_SIZE": kib(f2, "FETCH_SIZE"), "WRITE_SIZE": kib(w2, "WRITE_SIZE")}
+        scoring = fr4 + tile // 2 + wr4
+        c4 = {"rows": 10000000, "trees": 512, "kernel": "score_sparse_r_kernel<9,8,256> (sparse_r_k9_u8_t256)", "round": 6,
+              "fetch_bytes_raw_per_launch": fr4, "write_bytes_per_launch": wr4, "tuple_stream_bytes": tile, "hbm_bytes_per_launch": scoring,
+              "prepass": pre4, "step_hbm_bytes_x2_corrected": scoring + sum(2 * (v["FETCH_SIZE"] or 0) + (v["WRITE_SIZE"] or 0) for v in pre4.values()),
+              "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on the config-4 bench command, averaged over the launches. "
+                      "FETCH_SIZE counts the L2's fabric-side read requests (Infinity-Cache hits included, MI355X_MICROARCH.md).  Scoring kernel: the 2.56 GB "
+                      "rank tile arrives by wide global->LDS DMA (counted at half on gfx950: + tile / 2 added here); the rest are the L2 misses of the "
+                      "pair-record gathers into the model image (16-byte records pulled as whole lines; the image fits the 256 MiB Infinity Cache, so most "
+                      "of those requests do not reach HBM) -- the x2 correction is calibrated for wide streams only and is NOT applied to them.  `prepass`: raw "
+                      "counter bytes per launch of the transpose and the rank32 kernel; the step figure doubles their FETCH (streams) -- an upper bound for "
+                      "rank32, whose key-block gathers are not wide streams.",
+              "source": f"{ev}: `{cmd.format(4)}`"}
         json.dump(c4, open(p4, "w"), indent=1)
-        print("config 4:", c4["hbm_bytes_per_launch"], "B/launch")
+        print("config 4:", c4["hbm_bytes_per_launch"], "B/launch (scoring); step", c4["step_hbm_bytes_x2_corrected"])
     # ---- config 6: the reference's own 512 x d12 x 32 on the deep kernel, in parts (round 5) -------------------------------------------
     f, w = pmc(ev + "/fetch_cfg6", "score_q16d"), pmc(ev + "/write_cfg6", "score_q16d")
     if f and w:
