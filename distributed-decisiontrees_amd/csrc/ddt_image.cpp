@@ -42,7 +42,7 @@ RankTables rank_tables(const ddt_engine* e) {
 
 // LDS-resident rank pre-pass (fused_rank_kernel / grouped_rank_kernel, ddt_internal.h PrepassPlan).  The features are
 // cut into G = 1, 2, 4 or 8 groups of 8 / 4 / 2 / 1 tuple lines whose tables fit one CU's LDS.  Exact LDS image of a group:
-//   per feature  a skewed table of K + P keys (INT_MAX pads; entry i at word i + i/32)
+//   per feature  a table of K + P keys (INT_MAX pads; linear since round 6: entry i at word i)
 //   then         the bucket starts of all its features (u16: number of keys in the buckets below)
 //   then         per feature a segment table, kQ16Segments words {first bucket | log2(bucket width) << 16}
 //   then         per feature 8 parameter words {K, lo, span, table byte offset, starts byte offset, segment table byte
@@ -100,7 +100,7 @@ bool build_prepass_group(const RankTables& rt, uint32_t f0, uint32_t f1, std::ve
     size_t words = 0;
     for (uint32_t j = 0; j < nf; ++j) {
       const uint32_t len = F[j].K + P;
-      words += len + (len >> 5) + 1u;
+      words += len;  // (round 6: linear tables -- the probes start at a bucket's own first key, so no power-of-two stride lines them up on one bank)
     }
     words = (words + 3u) & ~(size_t)3u;
     const size_t fixed = words * 4u + (size_t)nf * (kQ16Segments + 8u) * 4u + 32u;
@@ -144,7 +144,7 @@ bool build_prepass_group(const RankTables& rt, uint32_t f0, uint32_t f1, std::ve
     for (uint32_t j = 0; j < nf; ++j) {
       const uint32_t len = F[j].K + P;
       tab_off[j] = (uint32_t)words * 4u;
-      words += len + (len >> 5) + 1u;
+      words += len;  // (round 6: linear tables -- the probes start at a bucket's own first key, so no power-of-two stride lines them up on one bank)
     }
     words = (words + 3u) & ~(size_t)3u;
     size_t half = words * 2u;  // in u16 units
@@ -167,7 +167,7 @@ bool build_prepass_group(const RankTables& rt, uint32_t f0, uint32_t f1, std::ve
     for (uint32_t j = 0; j < nf; ++j) {
       const std::vector<uint32_t>& k = rt.keys[f0 + j];
       const SegFeature& f = F[j];
-      for (uint32_t i = 0; i < k.size(); ++i) (*img)[tab_off[j] / 4u + i + (i >> 5)] = k[i];
+      for (uint32_t i = 0; i < k.size(); ++i) (*img)[tab_off[j] / 4u + i] = k[i];
       uint16_t* S = reinterpret_cast<uint16_t*>(img->data()) + starts_off[j] / 2u;
       uint32_t* seg = img->data() + seg_off[j] / 4u;
       uint32_t first = 0, run = 0;

@@ -640,7 +640,13 @@ __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __re
 // the segmented bucket index: ddt_image.cpp build_prepass_group).  Search = segment lookup (a 32-entry table: few distinct
 // addresses per wave) + bucket start + log2(P) probes; keys past the bucket are > x by construction, no end test.
 // Returns r(row0) | r(row1) << 16 per feature; in0 / in1 = the row exists (a missing value only counts there).
-__device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P, const uint32_t ieee, const uint32_t miss_raw, const bool in0,
+// Round 6 (counters: profiles/r06_prepass_valu.md -- these kernels were VALU-bound, 90-97 % of the issue slots, at ~57 instructions per value): the
+// search position is carried as the BYTE ADDRESS of its table entry, so a probe's address is that register plus a DS immediate ((step - 1) * 4 for
+// the unrolled steps 32 .. 1) and a step costs compare + select + add; the tables are linear (no i + i/32 skew to compute: the probes start at a
+// bucket's own first key, nothing lines them up on one bank); IEEE is a template parameter (the key transform of cmp_mode 1 is not selected away
+// per value in cmp_mode 0).
+template <bool IEEE>
+__device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P, const uint32_t miss_raw, const bool in0,
                                            const bool in1, const u32x4& v0, const u32x4& v1, bool& any_missing) {
   uint32_t K[4], tab[4], pos[4][2], missing = 0u;
   int32_t x[4][2];
@@ -655,22 +661,31 @@ __device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P,
     for (int h = 0; h < 2; ++h) {
       const uint32_t raw = h ? v1[c] : v0[c];
       if (raw == miss_raw && (h ? in1 : in0)) missing |= 1u << (2 * c + h);  // DTPU.sv:653, bit equality before any transform
-      x[c][h] = (int32_t)(ieee ? ieee_key(raw) : raw);
+      x[c][h] = (int32_t)(IEEE ? ieee_key(raw) : raw);
       uint32_t d = (uint32_t)x[c][h] - pa.y;
       d = x[c][h] < (int32_t)pa.y ? 0u : d;  // below the table: bucket 0, nothing there is <= x
       d = d < pa.z ? d : pa.z;               // above it: the last bucket, everything from there on is <= x
       const uint32_t sg = lds_u32(pb.y + (d >> pb.z) * 4u);  // first bucket | log2(bucket width) << 16
       const uint32_t bk = (sg & 0xFFFFu) + ((d & seg_mask) >> (sg >> 16));
-      pos[c][h] = *reinterpret_cast<const DDT_LDS(uint16_t)*>(pb.x + bk * 2u);
+      pos[c][h] = tab[c] + 4u * (uint32_t)*reinterpret_cast<const DDT_LDS(uint16_t)*>(pb.x + bk * 2u);  // byte address of the bucket's first key
     }
   }
-  for (uint32_t step = P >> 1; step >= 1u; step >>= 1) {
+  for (uint32_t step = P >> 1; step >= 64u; step >>= 1) {  // (buckets of 128 keys and more: degenerate key distributions only)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const uint32_t probe = pos[c][h] + step - 1u;  // < K + P: inside the padded table
-        if ((int32_t)lds_u32(tab[c] + (probe + (probe >> 5)) * 4u) <= x[c][h]) pos[c][h] += step;
+      for (int h = 0; h < 2; ++h)
+        if ((int32_t)lds_u32(pos[c][h] + (step - 1u) * 4u) <= x[c][h]) pos[c][h] += step * 4u;  // probe < K + P: inside the padded table
+    }
+  }
+#pragma unroll
+  for (uint32_t step = 32u; step >= 1u; step >>= 1) {
+    if (step < P) {  // wave-uniform
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if ((int32_t)lds_u32(pos[c][h] + (step - 1u) * 4u) <= x[c][h]) pos[c][h] += step * 4u;
       }
     }
   }
@@ -681,7 +696,8 @@ __device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P,
     uint32_t r[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      r[h] = pos[c][h] < K[c] ? pos[c][h] : K[c];
+      r[h] = (pos[c][h] - tab[c]) >> 2;
+      r[h] = r[h] < K[c] ? r[h] : K[c];
       r[h] = (missing >> (2 * c + h)) & 1u ? kQMissing : r[h];
     }
     out[c] = r[0] | (r[1] << 16);
@@ -691,6 +707,7 @@ __device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P,
 
 constexpr int kFusedThreads = 1024;  // two tiles per block and pass; 16 waves x 8 independent searches hide the LDS latency
 
+template <bool IEEE>
 __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
                                                                    const uint4* __restrict__ img_base, const PrepassPlan pl, uint32_t parts,
                                                                    uint32_t miss_raw, uint32_t ieee, uint32_t* __restrict__ q32,
@@ -735,7 +752,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
     for (int i = 0; i < 4; ++i) {
       const uint32_t line = 4u * g + (uint32_t)i;
       if (line >= lpt || line < line_lo || line >= line_hi) continue;  // this launch's feature group only
-      const u32x4 r = rank_line(par_off + 4u * (line - line_lo) * 32u, P, ieee, miss_raw, tile * kQTile + own < n,
+      const u32x4 r = rank_line<IEEE>(par_off + 4u * (line - line_lo) * 32u, P, miss_raw, tile * kQTile + own < n,
                                 tile * kQTile + own + 512u < n, v[0][i], v[1][i], any_missing);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -788,7 +805,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
 // lane in flight -- measured SLOWER, 7.3 vs 5.7 ms at 1000 trees: every 16-byte load pulls a whole line into the L2 the
 // groups share, and the footprint in flight then exceeds it.)
 // ---------------------------------------------------------------------------------------------------
-template <int L>
+template <int L, bool IEEE>
 __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
                                                                      const uint4* __restrict__ img_base, const PrepassPlan pl, uint32_t parts,
                                                                      uint32_t miss_raw, uint32_t ieee, uint32_t* __restrict__ q32,
@@ -858,7 +875,7 @@ __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint3
       for (int l = 0; l < L; ++l) {
         const uint32_t line = line_lo + (uint32_t)l;
         if (line >= lpt) continue;  // narrow tuples: the last group may be short (wave-uniform)
-        const u32x4 r = rank_line(par_off + 4u * (uint32_t)l * 32u, P, ieee, miss_raw, tile * kQTile + own < n, tile * kQTile + own + 512u < n,
+        const u32x4 r = rank_line<IEEE>(par_off + 4u * (uint32_t)l * 32u, P, miss_raw, tile * kQTile + own < n, tile * kQTile + own + 512u < n,
                                   cur[l][0], cur[l][1], miss);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1245,9 +1262,10 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
     if (per_pair < 1u) per_pair = 1u;
     const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
     if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto fk = a.ieee ? fused_rank_kernel<true> : fused_rank_kernel<false>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fused_rank_kernel, dim3(parts * pp.groups * per_pair), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp,
+    hipLaunchKernelGGL(fk, dim3(parts * pp.groups * per_pair), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp,
                        parts, a.miss_raw, a.ieee, reinterpret_cast<uint32_t*>(x.q), x.tile_flags, counter, x.prepass_nt);
   } else if (pp.groups) {  // one launch, blocks split over feature groups x row partitions (XCDs)
     uint32_t lds = 0;
@@ -1259,7 +1277,7 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
     const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
     if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
     const uint32_t grid = parts * pp.groups * per_pair;
-    auto gk = pp.lines == 1u ? grouped_rank_kernel<1> : grouped_rank_kernel<2>;
+    auto gk = pp.lines == 1u ? (a.ieee ? grouped_rank_kernel<1, true> : grouped_rank_kernel<1, false>) : (a.ieee ? grouped_rank_kernel<2, true> : grouped_rank_kernel<2, false>);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gk, dim3(grid), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp, parts, a.miss_raw, a.ieee,

@@ -1,4 +1,4 @@
-"""Host logic of the LDS-resident rank pre-pass, no GPU needed: the images `ddt_engine.cpp build_prepass_group` packs (skewed
+"""Host logic of the LDS-resident rank pre-pass, no GPU needed: the images `ddt_image.cpp build_prepass_group` packs (linear since round 6; until then skewed
 key tables + pads, segmented bucket index, parameter blocks) are built through the test hook
 `ddt_debug_prepass_image` and the kernel's search (`ddt_kernels.hip rank_line`: clamp, segment lookup, bucket start, log2 P
 probes without an end test) is replayed on them in numpy against a plain count of the keys <= x."""
@@ -46,7 +46,7 @@ def _replay(img, par_off, P, j, x):
     while step >= 1:
         probe = pos + step - 1
         assert probe.max() < K + P  # inside the padded table
-        pos = np.where(tab[probe + (probe >> 5)] <= xs, pos + step, pos)
+        pos = np.where(tab[probe] <= xs, pos + step, pos)   # (round 6: linear tables)
         step >>= 1
     return np.minimum(pos, K)
 
