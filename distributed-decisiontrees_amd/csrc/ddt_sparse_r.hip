@@ -182,9 +182,9 @@ __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAu
   // the feature's rank word: LDS address = feature number * ROWB + the lane's column.  Two VALU instructions -- the AND is kept opaque, or hipcc
   // re-associates it into shift + and + add (three; 61 % of the kernel's issue slots were VALU: profiles/r06_sparse_r32.md)
   auto feat = [&](uint32_t rec) -> uint32_t {
-    uint32_t j;
-    asm("v_and_b32 %0, 0xff, %1" : "=v"(j) : "v"(rec));
-    return lds_u32((j << ROW_LOG2) + lane_off);  // v_lshl_add_u32
+    uint32_t addr;  // (one asm statement: behind a lone v_and hipcc put an s_nop in front of the next VALU instruction -- it cannot see what the asm wrote)
+    asm("v_and_b32 %0, 0xff, %1\n\tv_lshl_add_u32 %0, %0, %2, %3" : "=&v"(addr) : "v"(rec), "n"(ROW_LOG2), "v"(lane_off));
+    return lds_u32(addr);
   };
   const uint32_t C = a.clusters;
   const uint32_t n_steps = x.n_groups * 8u / (uint32_t)U;
