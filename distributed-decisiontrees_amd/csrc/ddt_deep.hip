@@ -3,7 +3,7 @@
 //
 // What it replaces: the same DTPU traversal loop + leaf reduce as ddt_kernels.hip (DTPU.sv:579-760; FPAddersReduceTree.sv:94-141,
 // FPAggregator.v:79-131, Core.sv:486-541) for trees whose node memory no longer fits a CU's LDS next to the tuples at two blocks per CU.
-// Rank-quantised like the depth-8 kernels (same records, same u16 rank tile, same pre-pass: ddt_kernels.hip launch_q16_prepass); image
+// Rank-quantised like the depth-8 kernels (same records, same u16 rank tile, same pre-pass: ddt_prepass.hip launch_q16_prepass); image
 // layout: ddt_internal.h "deep rank-quantised kernels"; host packing: ddt_image.cpp pack_image_q16.  No MFMA: compare + gather.
 #include <hip/hip_runtime.h>
 

@@ -293,7 +293,7 @@ hipError_t launch_generic(const ScoreArgs& a, const Variant& v, hipStream_t s);
 uint32_t generic_lds_bytes(uint32_t levels, uint32_t tuple_words, bool* feat_in_lds, bool* tree_in_lds, uint32_t* top_levels);
 uint32_t stream_blocks_per_cu(uint32_t lds_bytes);
 
-hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s);  // ddt_kernels.hip: rank pre-pass of one batch
+hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s);  // ddt_prepass.hip: rank pre-pass of one batch
 
 constexpr int kQTile = 1024;               // tuples per u16 rank tile == threads of a rank-quantised scoring block
 int num_deep_variants();                   // ddt_deep.hip: deep perfect trees, appended to the variant table after the kernels of ddt_kernels.hip
@@ -302,7 +302,7 @@ int num_sparse_variants();                 // ddt_sparse.hip: appended after tho
 const Variant& sparse_variant(int i);
 int num_sparse_r_variants();               // ddt_sparse_r.hip: and these last
 const Variant& sparse_r_variant(int i);
-hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint64_t n_pad, uint32_t* xT, hipStream_t s);  // ddt_kernels.hip
+hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint64_t n_pad, uint32_t* xT, hipStream_t s);  // ddt_prepass.hip
 
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact /* sum_mode 2 */, hipStream_t s);
 hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s);

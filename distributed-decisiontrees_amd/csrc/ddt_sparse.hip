@@ -32,7 +32,7 @@ namespace ddt {
 // logical operators on purpose: hipcc keeps such lane predicates as SGPR masks (s_and / s_or), whereas a ternary
 // between two predicates is lowered to 0/1 VGPRs and four extra VALU instructions per visit.
 // Q (rank-quantised kernels): f is the u16 rank of the feature value, thr the node's rank R; x >= t  <=>  rank(x) >= R
-// (ddt_kernels.hip "The rank-quantised path"), a missing value has the rank kQMissing.
+// (ddt_prepass.hip "The rank-quantised path"), a missing value has the rank kQMissing.
 template <bool SLOW, bool Q>
 __device__ __forceinline__ bool sp_right(uint32_t f, uint32_t thr, uint32_t w, uint32_t miss_key) {
   const bool ge = Q ? f >= thr : (int32_t)f >= (int32_t)thr;

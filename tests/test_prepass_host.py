@@ -1,6 +1,6 @@
 """Host logic of the LDS-resident rank pre-pass, no GPU needed: the images `ddt_image.cpp build_prepass_group` packs (linear since round 6; until then skewed
 key tables + pads, segmented bucket index, parameter blocks) are built through the test hook
-`ddt_debug_prepass_image` and the kernel's search (`ddt_kernels.hip rank_line`: clamp, segment lookup, bucket start, log2 P
+`ddt_debug_prepass_image` and the kernel's search (`ddt_prepass.hip rank_line`: clamp, segment lookup, bucket start, log2 P
 probes without an end test) is replayed on them in numpy against a plain count of the keys <= x."""
 import ctypes as C
 

@@ -1,5 +1,5 @@
 """The rank-quantised path rests on two claims that need no GPU to check (numpy restatements of what
-csrc/ddt_image.cpp builds and csrc/ddt_kernels.hip searches):
+csrc/ddt_image.cpp builds and csrc/ddt_prepass.hip searches):
 
 1. exactness: with the sorted distinct thresholds t_0 < t_1 < ... of one feature (signed-int32 order of the key),
    r(x) = #{k : t_k <= x} satisfies  (x < t_k)  <=>  (r(x) < k + 1)  for every x -- a node only needs the rank.
