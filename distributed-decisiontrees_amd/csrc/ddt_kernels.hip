@@ -445,7 +445,6 @@ static hipError_t launch_stream(const ScoreArgs& a, const Variant& v, hipStream_
 
 // (the rank pre-pass of the rank-quantised path -- transpose_kernel, rank_kernel, fused_rank_kernel, grouped_rank_kernel, launch_q16_prepass --
 // lives in ddt_prepass.hip since round 6; the scoring kernels below DMA the u16 tiles it writes)
-constexpr uint32_t kRankBuckets = kQ16RankBuckets;
 
 
 // "_gl": the leaves stay in the global image and are gathered through a buffer resource over it: leaf m4 / 4 - 2^D of tree u of

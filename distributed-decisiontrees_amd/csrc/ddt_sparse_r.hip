@@ -311,7 +311,171 @@ __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAu
   }
 }
 
-template <int K, int U, int THREADS>
+// The same walk, software-pipelined ACROSS PU groups ("_pl"): the deep rounds of group g are latency-bound at two waves per SIMD (a round = LDS
+// read -> compare -> LDS read -> compare -> gather, then ~1 us until the records are back), and the top walk of group g + 1 -- 9 levels of LDS
+// reads and VALU work -- needs nothing of group g.  Its images are in LDS as soon as group g's top walk is over (the DMA is issued behind the
+// barrier that ends it), so a wave now walks a few top levels of g + 1 behind every deep round of g: the gathers fly under work instead of under a
+// wait.  Same two barriers per group.  The barrier that publishes the next images waits with a COUNTED `vmcnt(U)`: the DMA is older than exactly
+// the U first gathers of the group that were issued behind it (operations return in order) -- tools/check_dma_waits.py proves it on the binary.
+// The order of the sums is untouched: group g is folded before group g + 1's deep phase begins.
+template <int K, int U, int THREADS, bool SLOW>
+__device__ __forceinline__ void sparse_r_walk_pl(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
+  static_assert(U == 8, "the counted wait below is vmcnt(8)");
+  constexpr int TOPB = 4 << K;
+  constexpr int STEPB = U * TOPB;
+  constexpr uint32_t ROWB = (uint32_t)THREADS * 4u;
+  constexpr uint32_t FEAT_OFF = (uint32_t)((STEPB + ROWB - 1) / ROWB * ROWB);
+  constexpr uint32_t ROW_LOG2 = THREADS == 512 ? 11u : THREADS == 256 ? 10u : 9u;
+  static_assert((1u << ROW_LOG2) == ROWB, "tiles of 128 / 256 / 512 tuples");
+  const uint32_t lane_off = FEAT_OFF + (uint32_t)tid * 4u;
+  auto feat = [&](uint32_t rec) -> uint32_t {
+    uint32_t addr;
+    asm("v_and_b32 %0, 0xff, %1\n\tv_lshl_add_u32 %0, %0, %2, %3" : "=&v"(addr) : "v"(rec), "n"(ROW_LOG2), "v"(lane_off));
+    return lds_u32(addr);
+  };
+  const uint32_t C = a.clusters;
+  const uint32_t n_steps = x.n_groups * 8u / (uint32_t)U;
+  const uint32_t max_rounds = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.max_rounds);
+  // top levels of the next group walked behind every deep round (the rest behind the last one)
+  const uint32_t per_round = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)K + (max_rounds > 1u ? max_rounds - 1u : 1u) - 1u) / (max_rounds > 1u ? max_rounds - 1u : 1u)));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(x.deep), 0, (int)x.deep_bytes, 0x00020000);
+  const uint32_t idle_off = x.idle_off;
+  uint32_t m4[U];
+  auto top_reset = [&]() {
+#pragma unroll
+    for (int u = 0; u < U; ++u) m4[u] = 4u;
+  };
+  auto top_levels = [&](uint32_t count) {  // `count` more levels of the top walk over the images in LDS (level-independent code: a runtime loop)
+    for (uint32_t l = 0; l < count; ++l) {
+      uint32_t nd[U], f[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) nd[u] = lds_u32(m4[u] + (uint32_t)(u * TOPB));
+#pragma unroll
+      for (int u = 0; u < U; ++u) f[u] = feat(nd[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) m4[u] = (m4[u] << 1) + (sr_right<SLOW>(f[u], nd[u]) ? 4u : 0u);
+    }
+  };
+  u32x4 rr[U];
+  // ---- prologue: group 0's top walk, the plain way ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // images of group 0 and the rank tile are in LDS for everyone
+  top_reset();
+  top_levels((uint32_t)K);
+  {
+    uint32_t cb[U];  // (read before the barrier: behind it the DMA of the next images may land)
+#pragma unroll
+    for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));
+    __syncthreads();
+    if (1u < n_steps) dma_chunk<THREADS, STEPB>(a.img, 1, 0, tid);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m4[u] << 2), 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  for (uint32_t g = 0; g < n_steps; ++g) {
+    const bool next = g + 1u < n_steps;
+    if (next) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the DMA of the next images is older than the U gathers issued behind it
+      __syncthreads();                                   // ... and has landed for every wave
+      top_reset();
+    }
+    uint32_t lv = 0;  // levels of group g + 1 walked so far
+    bool act[U];
+    float leafv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      act[u] = true;
+      leafv[u] = 0.f;
+    }
+    bool alive = true;
+    if (max_rounds > 1u) {
+      uint32_t r = 1u;
+      do {
+        bool any = false;
+#pragma unroll
+        for (int h = 0; h < U; h += 4) {
+          uint32_t fn[4], fc[4], cw[4];
+          bool r0[4], leaf[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            asm volatile("" : "+v"(rr[h + i].x), "+v"(rr[h + i].y), "+v"(rr[h + i].z), "+v"(rr[h + i].w));
+            fn[i] = feat(rr[h + i].x);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            r0[i] = sr_right<SLOW>(fn[i], rr[h + i].x);
+            cw[i] = r0[i] ? rr[h + i].z : rr[h + i].y;
+            leaf[i] = (rr[h + i].x & (r0[i] ? kSrRightLeaf : kSrLeftLeaf)) != 0u;
+            fc[i] = feat(cw[i]);  // (a leaf's value read as a node word: see sparse_r_walk)
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bool r1 = sr_right<SLOW>(fc[i], cw[i]);
+            const uint32_t nxt = rr[h + i].w + (r0[i] ? 32u : 0u) + (r1 ? 16u : 0u);
+            if (act[h + i] && leaf[i]) leafv[h + i] = __uint_as_float(cw[i]);
+            act[h + i] = act[h + i] && !leaf[i];
+            any = any || act[h + i];
+            rr[h + i] = __builtin_amdgcn_raw_buffer_load_b128(rs, act[h + i] ? nxt : idle_off, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        alive = __ballot(any) != 0ull;
+        if (next) {  // the next group's top walk, a few levels behind every round: the gathers above fly meanwhile
+          const uint32_t c = (uint32_t)K - lv < per_round ? (uint32_t)K - lv : per_round;
+          top_levels(c);
+          lv += c;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } while (alive && ++r < max_rounds);
+    }
+    if (!alive) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) asm volatile("" : : "v"(rr[u].x), "v"(rr[u].y), "v"(rr[u].z), "v"(rr[u].w));
+    }
+    if (alive) {  // the last round: visits only (sparse_r_walk)
+#pragma unroll
+      for (int h = 0; h < U; h += 4) {
+        uint32_t fn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          asm volatile("" : "+v"(rr[h + i].x), "+v"(rr[h + i].y), "+v"(rr[h + i].z), "+v"(rr[h + i].w));
+          fn[i] = feat(rr[h + i].x);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool r0 = sr_right<SLOW>(fn[i], rr[h + i].x);
+          if ((rr[h + i].x & (r0 ? kSrRightLeaf : kSrLeftLeaf)) != 0u) leafv[h + i] = __uint_as_float(r0 ? rr[h + i].z : rr[h + i].y);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (next && lv < (uint32_t)K) top_levels((uint32_t)K - lv);
+    if (a.sum_mode == 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dacc += (double)leafv[u];
+    } else {  // FPAddersReduceTree.sv:94-141, then the slot accumulate of this group's cluster
+      const float lf[1][8] = {{leafv[0], leafv[1], leafv[2], leafv[3], leafv[4], leafv[5], leafv[6], leafv[7]}};
+      double unused[1] = {0.0};
+      fold_leaves<8, 1, 0>(lf, 0, C, ra, unused, a.sum_mode == 2);
+    }
+    if (next) {
+      uint32_t cb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));
+      __syncthreads();  // every wave is through with the images of group g + 1
+      if (g + 2u < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 2u, 0, tid);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {  // ... exactly U gathers behind that DMA: what the counted wait at the loop's top counts
+        rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m4[u] << 2), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
+template <int K, int U, int THREADS, bool PL>
 __global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 4 << K;
   constexpr int STEPB = U * TOPB;
@@ -342,8 +506,13 @@ __global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs
   ra.init();
   double dacc = 0.0;
   const uint32_t C = a.clusters;
-  if (!slow) sparse_r_walk<K, U, THREADS, false>(a, x, tid, ra, dacc);
-  else sparse_r_walk<K, U, THREADS, true>(a, x, tid, ra, dacc);
+  if constexpr (PL) {
+    if (!slow) sparse_r_walk_pl<K, U, THREADS, false>(a, x, tid, ra, dacc);
+    else sparse_r_walk_pl<K, U, THREADS, true>(a, x, tid, ra, dacc);
+  } else {
+    if (!slow) sparse_r_walk<K, U, THREADS, false>(a, x, tid, ra, dacc);
+    else sparse_r_walk<K, U, THREADS, true>(a, x, tid, ra, dacc);
+  }
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
@@ -353,7 +522,11 @@ template <int K, int U, int THREADS>
 static hipError_t launch_sparse_r_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  auto kern = score_sparse_r_kernel<K, U, THREADS>;
+  static const bool pipelined = [] {  // A/B: DDT_SPARSE_R_PL=0 -> the walk without the pipeline across PU groups
+    const char* v = getenv("DDT_SPARSE_R_PL");
+    return !(v && v[0] == '0');
+  }();
+  auto kern = pipelined ? score_sparse_r_kernel<K, U, THREADS, true> : score_sparse_r_kernel<K, U, THREADS, false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
