@@ -553,7 +553,9 @@ static int pack_rank32_tables(ddt_engine* e, const RankTables& rt, uint32_t W, R
 static int sparse_pack_host_r(ddt_engine* e, const Variant& v, SparseForest& sp, const RankTables& rt, std::vector<uint32_t>& top, std::vector<uint32_t>& deep,
                               uint32_t* groups_out) {
   const uint32_t K = (uint32_t)v.levels, T = sp.trees();
-  const uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
+  const uint32_t per_pass = std::max(1u, (uint32_t)v.chunk_trees / 8u);  // PU groups walked in lock-step
+  uint32_t groups = T ? (T + 7u) / 8u : 1u;  // an empty shard is one group of EMPTY slots
+  groups = (groups + per_pass - 1u) / per_pass * per_pass;  // whole passes: the padding groups are EMPTY slots too (+0)
   const uint32_t top_words = v.top_bytes_sparse() / 4u;  // 2^K per tree
   uint32_t rounds = 1;
   struct Todo {  // a pair record still to be written: rooted at tree node `node`, at record index `slot` of the deep array, `hop` records into the walk

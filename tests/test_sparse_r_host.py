@@ -159,12 +159,13 @@ def test_packed_r32_images_walk_to_the_oracles_leaves(shape):
         if not name.startswith("sparse_r_"):
             continue
         K = int(name.split("_k")[1].split("_")[0])
-        if K in seen:  # the packing depends on K only
+        U = int(name.split("_u")[1].split("_")[0])
+        if (K, U) in seen:  # the packing depends on K and on the PU groups per pass (padding to whole passes)
             continue
-        seen.add(K)
+        seen.add((K, U))
         top, deep, info = _images(s, vid)
         groups, rounds = info[2], info[3] >> 32
-        assert info[3] & 0xFFFFFFFF == K and groups * 8 >= T and top.size == groups * 8 << K
+        assert info[3] & 0xFFFFFFFF == K and groups * 8 >= T and groups % (U // 8) == 0 and top.size == groups * 8 << K
         deepest = 0
         for r in range(x.shape[0]):
             for i in range(groups * 8):
