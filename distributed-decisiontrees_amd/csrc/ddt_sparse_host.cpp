@@ -170,15 +170,15 @@ int sparse_rebuild(ddt_engine* e) {
     if (e->p.num_features > 256u || tuple_words(e->p) > kSrMaxWords || rt.max_len > kSrMaxTable || fv.lds_bytes_sparse(tuple_words(e->p)) > kMaxLdsBytes) vid = -1;
     else vid = e->forced_variant;
   } else if (e->forced_variant < 0 && e->sparse_r32 != 0 && rt.max_len <= kSrMaxTable) {
-    // Automatic: where it measured faster on one MI355X (profiles/r06_sparse_r32.md; 4 M tuples, trees x depth x features: 512 x 16 x 64 +7 %, the
-    // same forest on 255 bins +30 %, 1000 x 13 x 28 +7 %, 128 x 14 x 20 +10 %, 512 x 16 x 32 +1 %) and not where it lost (64 x 16 x 64 -8 %,
-    // 256 x 12 x 64 -10 %, 512 x 10 x 64 -13 %, 128 features -3 %, and 780 k thresholds per feature -- key blocks of 32, eight gathers per value in the
-    // pre-pass -- -50 %): depth >= 13, at least two trees per tuple word (the pre-pass costs per word, the pair records pay per tree), tuples of at
-    // most 64 words (two 256-tuple blocks per CU), key blocks of four (at most 4 x 32767 distinct thresholds on a feature).
+    // Automatic: where it measured faster on one MI355X (profiles/r06_sparse_r32.md section 4; 4 M tuples, trees x depth x features: 512 x 16 x 64 +12 %, the
+    // same forest on 255 bins +37 %, 1000 x 13 x 28 +10 %, 128 x 14 x 20 +13 %, 512 x 16 x 32 +5 %, 512 x 16 x 128 +4 %) and not where it lost (64 x 16 x 64
+    // -2.5 %, 256 x 12 x 64 -6 %, 512 x 10 x 64 -13 %, and 780 k thresholds per feature -- key blocks of 32, eight gathers per value in the pre-pass --
+    // -49 %): depth >= 13, at least two trees per tuple word (the pre-pass costs per word, the pair records pay per tree), tuples of at most 128 words,
+    // key blocks of four (at most 4 x 32767 distinct thresholds on a feature).
     uint32_t trees = 0;
     for (const SparseForest& sp : e->sps) trees += sp.trees();
     const uint32_t W = tuple_words(e->p);
-    const bool pays = max_depth >= 13u && trees >= 2u * W && W <= 64u && rt.max_len <= 4u * kSrMaxDir && !getenv("DDT_R32_BLK_LOG2");
+    const bool pays = max_depth >= 13u && trees >= 2u * W && W <= kSrMaxWords && rt.max_len <= 4u * kSrMaxDir && !getenv("DDT_R32_BLK_LOG2");
     const int vr = (e->sparse_r32 > 0 || pays) ? pick_r32_variant(e, max_depth) : -1;
     if (vr >= 0) vid = vr;
   }
