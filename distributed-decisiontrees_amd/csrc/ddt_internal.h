@@ -144,9 +144,11 @@ constexpr uint32_t kQ16TileCounterWords = 2;  // behind the kQ16GroupedCounters 
 //               levels; the dense block of ordinary records is level K+2 (byte cbase - 32 * 2^K + 16 h).  Feature numbers < 256.
 // ---------------------------------------------------------------------------------------------------
 //   32-bit ranks, pair records on EVERY deep level ("sparse_r_*", Variant::opt bit 5, round 6; ddt_sparse_r.hip).  A node is ONE word
-//               rec = R << 12 | kSrLeftLeaf | kSrRightLeaf | kSrMissRight | feature number (< 256),  R = 1 + index of the threshold among the sorted
-//               distinct keys of its feature (< 2^20 - 1); the feature tile holds x' = rank(x) << 12 | 0xFFF (a missing value: 0xFFFFFFFF), written by
-//               the rank32 pre-pass, so that  !(x < t)  <=>  x' >= rec  as ONE unsigned compare, no mask.
+//               rec = R << 15 | feature number << 8 | kSrLeftLeaf | kSrRightLeaf | kSrMissRight  (feature number < 128),  R = 1 + index of the
+//               threshold among the sorted distinct keys of its feature (< 2^17 - 1); the feature tile holds x' = rank(x) << 15 | 0x7FFF (a missing
+//               value: 0xFFFFFFFF), written by the rank32 pre-pass, so that  !(x < t)  <=>  x' >= rec  as ONE unsigned compare, no mask.  The feature
+//               number sits where the LDS address of its tile row has it (a row = 64 tuples x 4 bytes with "wave-private rows", Variant::wave_rows):
+//               address = (rec & mask) | the lane's column, ONE VALU instruction (v_and_or_b32).
 //               top image   per tree 4 * 2^K bytes: word 0 = cbase, words 1 .. 2^K - 1 the node words of levels 0..K-1 (1-based heap, early leaves
 //                           padded with 0 = "feature 0 against rank 0": any direction ends on the same value)
 //               deep array  16-byte PAIR records {node, left child, right child, ptr}: a child word is the child's node word, or the leaf's fp32 bits
@@ -158,10 +160,10 @@ constexpr uint32_t kQ16TileCounterWords = 2;  // behind the kQ16GroupedCounters 
 //               One gather decides two levels everywhere below the top image: 512 x depth 16 with K = 9: 4 gather instructions per tree and wave (7 before).
 constexpr uint32_t kSpLeftLeaf = 0x80000000u, kSpRightLeaf = 0x40000000u, kSpMissRight = 0x20000000u, kSpAddrMask = 0x1FFFFFFFu;
 constexpr int kSparseMinTop = 6, kSparseMaxTop = 10;
-constexpr uint32_t kSrLeftLeaf = 0x800u, kSrRightLeaf = 0x400u, kSrMissRight = 0x200u, kSrFeatMask = 0xFFu;
+constexpr uint32_t kSrLeftLeaf = 0x80u, kSrRightLeaf = 0x40u, kSrMissRight = 0x20u, kSrFeatShift = 8u, kSrFeatMask = 0x7F00u, kSrRankShift = 15u;
 constexpr uint32_t kSrLeafRec = kSrLeftLeaf | kSrRightLeaf;  // node word of a LEAF record: rank 0, feature 0, both sides leaves
 constexpr uint32_t kSrMissing = 0xFFFFFFFFu;                 // a missing value in the 32-bit rank tile
-constexpr uint32_t kSrMaxTable = (1u << 20) - 2u;            // distinct thresholds per feature
+constexpr uint32_t kSrMaxTable = (1u << 17) - 2u;            // distinct thresholds per feature (17-bit ranks)
 constexpr uint32_t kSrMaxWords = 128;                        // tuple words (the pre-pass's transpose stages 256 rows x (W + 1) words in LDS)
 constexpr uint32_t kSrMaxDir = 32767;                        // directory entries per feature (rank32_kernel keeps one feature's directory in LDS)
 
@@ -278,7 +280,29 @@ struct Variant {
     const uint32_t row = row_bytes_sparse(), need = (uint32_t)chunk_trees * top_bytes_sparse();
     return (need + row - 1u) / row * row;
   }
+  // "sparse_r_*": WAVE-PRIVATE ROWS -- the tile in LDS as [wave][feature][64 tuples], a wave's region padded to a power of two and aligned to it,
+  // so that a row's address is (node word & mask) | lane column, one VALU instruction (ddt_sparse_r.hip SrTile).  Taken for tuples of up to 64 words
+  // when the padding costs no block per CU (20 words pad to 32: three blocks of K = 10 become two -- measured 1361 vs 1600 Mtuples/s on 128 x d14 x 20)
+  static uint32_t wave_region_bytes(uint32_t tuple_words) {
+    uint32_t ws = 1024u;  // (tuple_words is a multiple of 4: whole 1 KiB DMA units)
+    while (ws < tuple_words * 256u) ws <<= 1;
+    return ws;
+  }
+  uint32_t lds_bytes_sparse_rows(uint32_t tuple_words, bool wave_rows) const {
+    const uint32_t need = (uint32_t)chunk_trees * top_bytes_sparse();
+    if (wave_rows) {
+      const uint32_t ws = wave_region_bytes(tuple_words);
+      return (need > ws ? need : ws) + (tile() / 64u) * ws;
+    }
+    return feat_off_sparse() + tuple_words * row_bytes_sparse();
+  }
+  bool wave_rows(uint32_t tuple_words) const {
+    if (!r32() || tuple_words > 64u) return false;
+    constexpr uint32_t lds_per_cu = 160u * 1024u;  // MI355X
+    return lds_per_cu / lds_bytes_sparse_rows(tuple_words, true) >= lds_per_cu / lds_bytes_sparse_rows(tuple_words, false);
+  }
   uint32_t lds_bytes_sparse(uint32_t tuple_words) const {
+    if (r32()) return lds_bytes_sparse_rows(tuple_words, wave_rows(tuple_words));
     if (opt & 4) return (uint32_t)chunk_trees * top_bytes_sparse() + 64u;
     return feat_off_sparse() + tuple_words * row_bytes_sparse() + ((opt & (2 | 32)) ? 0u : 64u);
   }

@@ -130,7 +130,7 @@ static int pack_rank32_tables(ddt_engine* e, const RankTables& rt, uint32_t W, R
 // one block per CU, 256-tuple tiles before 128
 static int pick_r32_variant(ddt_engine* e, uint32_t max_depth) {
   const uint32_t W = tuple_words(e->p);
-  if (e->p.num_features > 256u) return -1;  // a node word carries the feature number in 8 bits
+  if (e->p.num_features > 128u) return -1;  // a node word carries the feature number in 7 bits
   if (W > kSrMaxWords) return -1;            // the pre-pass's transpose stages 256 rows x W words in LDS
   char name[40];
   const int kcap = (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, 8u), 10u);
@@ -167,7 +167,7 @@ int sparse_rebuild(ddt_engine* e) {
   // (transpose + rank32_kernel per batch, which the fp32-tile kernels do not have)
   if (e->forced_variant >= 0 && variant(e->forced_variant).r32()) {
     const Variant& fv = variant(e->forced_variant);
-    if (e->p.num_features > 256u || tuple_words(e->p) > kSrMaxWords || rt.max_len > kSrMaxTable || fv.lds_bytes_sparse(tuple_words(e->p)) > kMaxLdsBytes) vid = -1;
+    if (e->p.num_features > 128u || tuple_words(e->p) > kSrMaxWords || rt.max_len > kSrMaxTable || fv.lds_bytes_sparse(tuple_words(e->p)) > kMaxLdsBytes) vid = -1;
     else vid = e->forced_variant;
   } else if (e->forced_variant < 0 && e->sparse_r32 != 0 && rt.max_len <= kSrMaxTable) {
     // Automatic: where it measured faster on one MI355X (profiles/r06_sparse_r32.md section 4; 4 M tuples, trees x depth x features: 512 x 16 x 64 +12 %, the
@@ -577,12 +577,12 @@ static int sparse_pack_host_r(ddt_engine* e, const Variant& v, SparseForest& sp,
       }
       const uint32_t* L = sp.lines.data() + sp.first[i] * 4u;
       auto child = [&](uint32_t n, uint32_t side) { return Cursor{((L[4u * n + 1u] >> (14u + side)) & 1u) != 0u, L[4u * n + 2u + side]}; };
-      auto node_word = [&](uint32_t n) -> uint32_t {  // R << 12 | flags | feature
+      auto node_word = [&](uint32_t n) -> uint32_t {  // R << 15 | feature << 8 | flags
         const uint32_t j = L[4u * n + 1u] & 0x7FFu, key = thr_key(e->p, L[4u * n]);
         const auto& k = rt.keys[j];
         const uint32_t R = 1u + (uint32_t)(std::lower_bound(k.begin(), k.end(), key, [](uint32_t a, uint32_t b) { return (int32_t)a < (int32_t)b; }) - k.begin());
-        return (R << 12) | (((L[4u * n + 1u] >> 13) & 1u) ? kSrMissRight : 0u) | (((L[4u * n + 1u] >> 14) & 1u) ? kSrLeftLeaf : 0u) |
-               (((L[4u * n + 1u] >> 15) & 1u) ? kSrRightLeaf : 0u) | j;
+        return (R << kSrRankShift) | (((L[4u * n + 1u] >> 13) & 1u) ? kSrMissRight : 0u) | (((L[4u * n + 1u] >> 14) & 1u) ? kSrLeftLeaf : 0u) |
+               (((L[4u * n + 1u] >> 15) & 1u) ? kSrRightLeaf : 0u) | (j << kSrFeatShift);
       };
       // ---- top heap, level by level (padding under an early leaf: node word 0, both children the leaf) ----
       cur.assign(1, Cursor{false, 0u});

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kR32Threads) void rank32_kernel(const uint32_t* __r
       uint32_t r = (pos[i] << blk_log2) + cnt[i];
       r = r < K ? r : K;
       r = x[i] >= (int32_t)hi_real ? K : r;  // (also what keeps the INT_MAX pads of the last block out of the count)
-      uint32_t out = (r << 12) | 0xFFFu;
+      uint32_t out = (r << kSrRankShift) | ((1u << kSrRankShift) - 1u);
       if (raw[i] == miss_raw && row < n) {  // bit equality with the missing pattern (DTPU.sv:653), before any transform
         out = kSrMissing;
         atomicOr(&tile_flags[row >> tile_log2], 1u);
@@ -159,6 +159,31 @@ hipError_t launch_r32_prepass(const ScoreArgs& a, const SparseAux& x, hipStream_
 // ---------------------------------------------------------------------------------------------------
 // The walk.  lane = tuple, U = 8 trees (one PU group) in lock-step, THREADS tuples per block with their rank words feature-major in LDS.
 // ---------------------------------------------------------------------------------------------------
+// Where the rank tile of a block lives in LDS (behind the top images of one pass) and how a lane finds a feature's row.
+//   rows of THREADS tuples (WP = false): [feature][THREADS x 4 bytes] at FEAT_OFF = the top images rounded up to a row -- the pre-pass's own layout.
+//   wave-private rows (WP = true, tuples of up to 64 words): [wave][feature][64 x 4 bytes]; a wave's region is `ws` = 256 bytes x the tuple words
+//   rounded up to a power of two, the regions start at a multiple of ws, so `(node word & mask) | lane_off` IS the address (the feature number sits
+//   at bit 8 of a node word: ddt_internal.h).  Same bank behaviour as before: the 64 lanes of a wave read 64 consecutive words.
+template <int THREADS, int STEPB, bool WP>
+struct SrTile {
+  uint32_t feat_off, lane_off, mask, ws_log2;
+  __device__ __forceinline__ SrTile(uint32_t W, int tid) {
+    if constexpr (WP) {
+      ws_log2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(40u - (uint32_t)__builtin_clz(W - 1u)));  // 256 * 2^ceil(log2 W); W >= 4
+      const uint32_t ws = 1u << ws_log2;
+      feat_off = ws > (uint32_t)STEPB ? ws : (uint32_t)STEPB;  // both powers of two: the larger is a multiple of the other
+      lane_off = feat_off + (((uint32_t)tid >> 6) << ws_log2) + ((uint32_t)tid & 63u) * 4u;
+      mask = (ws - 1u) & ~0xFFu;
+    } else {
+      constexpr uint32_t ROWB = (uint32_t)THREADS * 4u;
+      ws_log2 = 0u;
+      feat_off = (uint32_t)((STEPB + ROWB - 1) / ROWB * ROWB);
+      lane_off = feat_off + (uint32_t)tid * 4u;
+      mask = kSrFeatMask;
+    }
+  }
+};
+
 // x' >= rec, or the node's missing direction for a missing value (DTPU.sv:653-667).  Logical operators on purpose: hipcc keeps such lane
 // predicates as SGPR masks (ddt_sparse.hip sp_right)
 template <bool SLOW>
@@ -169,168 +194,38 @@ __device__ __forceinline__ bool sr_right(uint32_t f, uint32_t rec) {
   return (miss && mr) || (!miss && ge);
 }
 
-template <int K, int U, int THREADS, bool SLOW>
+// One PU group (U = 8 trees, lock-step): K levels over the one-word nodes of the top images in LDS (1-based heap in bytes: m4 <- 2 m4 + 4 right), then
+// ROUNDS of pair records, one 16-byte gather per TWO levels: a rotating pipeline of U chains, gathers unconditional and in a fixed order
+// (ddt_sparse.hip); a finished walker gathers from beyond the resource's range (zeros, no cache touched).
+//   * A round = two HALF rounds of four trees whose visits advance together, stage by stage -- four feature reads of the nodes in flight, then four of
+//     the children, then the four gathers back to back -- so that a half round exposes the LDS latency twice, not eight times (one visit after the
+//     other: 29.3 ms against a floor of 17 on BASELINE config 4); the other half's gathers fly meanwhile.
+//   * A leaf's VALUE goes through the child's compare as if it were a node word: its feature bits name some row of the tile (or, with rows of THREADS
+//     tuples, of the LDS beyond the block's allocation, where a DS read returns 0), and whatever comes out is never used: the walker is done.
+//   * Software-pipelined ACROSS PU groups: the deep rounds of group g are latency-bound at two waves per SIMD (a round = LDS read -> compare -> LDS
+//     read -> compare -> gather, then ~1 us until the records are back), and the top walk of group g + 1 -- K levels of LDS reads and VALU work --
+//     needs nothing of group g.  Its images are in LDS as soon as group g's top walk is over (the DMA is issued behind the barrier that ends it), so
+//     a wave walks a few top levels of g + 1 behind every deep round of g: the gathers fly under work instead of under a wait (config 4: 336 vs 327
+//     Mtuples/s, profiles/r06_sparse_r32.md).  Two barriers per group.  The barrier that publishes the next images waits with a COUNTED `vmcnt(U)`:
+//     the DMA is older than exactly the U first gathers of the group that were issued behind it (operations return in order) --
+//     tools/check_dma_waits.py proves it on the binary.  The order of the sums is untouched: group g is folded before group g + 1's deep phase begins.
+//   * The last round is visits only: a walker that is still alive stands on a record whose taken side is a leaf (the host counted the rounds:
+//     SparseAux::max_rounds); a finished one has the zeros its out-of-range gather returned -- no leaf flag.  A wave that leaves the rounds early
+//     consumes its last (idle) gathers, so that both exits reach the next group with nothing outstanding in the compiler's books.
+template <int K, int U, int THREADS, bool SLOW, bool WP>
 __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
-  constexpr int TOPB = 4 << K;       // bytes of one tree's top image
-  constexpr int STEPB = U * TOPB;    // top images resident per pass
-  constexpr uint32_t ROWB = (uint32_t)THREADS * 4u;
-  constexpr uint32_t FEAT_OFF = (uint32_t)((STEPB + ROWB - 1) / ROWB * ROWB);
-  static_assert((ROWB & (ROWB - 1u)) == 0u, "a feature row is a power of two");
-  constexpr uint32_t ROW_LOG2 = THREADS == 512 ? 11u : THREADS == 256 ? 10u : 9u;
-  static_assert((1u << ROW_LOG2) == ROWB, "tiles of 128 / 256 / 512 tuples");
-  const uint32_t lane_off = FEAT_OFF + (uint32_t)tid * 4u;
-  // the feature's rank word: LDS address = feature number * ROWB + the lane's column.  Two VALU instructions -- the AND is kept opaque, or hipcc
-  // re-associates it into shift + and + add (three; 61 % of the kernel's issue slots were VALU: profiles/r06_sparse_r32.md)
-  auto feat = [&](uint32_t rec) -> uint32_t {
-    uint32_t addr;  // (one asm statement: behind a lone v_and hipcc put an s_nop in front of the next VALU instruction -- it cannot see what the asm wrote)
-    asm("v_and_b32 %0, 0xff, %1\n\tv_lshl_add_u32 %0, %0, %2, %3" : "=&v"(addr) : "v"(rec), "n"(ROW_LOG2), "v"(lane_off));
-    return lds_u32(addr);
-  };
-  const uint32_t C = a.clusters;
-  const uint32_t n_steps = x.n_groups * 8u / (uint32_t)U;
-  const uint32_t max_rounds = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.max_rounds);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(x.deep), 0, (int)x.deep_bytes, 0x00020000);
-  const uint32_t idle_off = x.idle_off;  // beyond the resource's range: a finished walker's gather returns zeros and touches no cache
-  for (uint32_t g = 0; g < n_steps; ++g) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // the top images of this pass (and, first pass, the rank tile) are in LDS for everyone
-
-    // ---- top phase: K levels over one-word nodes, 1-based heap in bytes: m4 <- 2 m4 + 4 right ----
-    uint32_t m4[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) m4[u] = 4u;
-#pragma unroll
-    for (int lvl = 0; lvl < K; ++lvl) {
-      uint32_t nd[U], f[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) nd[u] = lds_u32(m4[u] + (uint32_t)(u * TOPB));
-#pragma unroll
-      for (int u = 0; u < U; ++u) f[u] = feat(nd[u]);
-#pragma unroll
-      for (int u = 0; u < U; ++u) m4[u] = (m4[u] << 1) + (sr_right<SLOW>(f[u], nd[u]) ? 4u : 0u);
-    }
-    uint32_t cb[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));  // word 0 of the tree: cbase of its dense block of level-K pair records
-    __syncthreads();  // every wave is through with the top images: the buffer is free
-    if (g + 1 < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 1, 0, tid);  // overlaps the deep phase below
-
-    // ---- deep phase: one 16-byte gather per TWO levels; a rotating pipeline of U chains (the gather of tree u's next record is issued right
-    //      after ITS visit and flies while the other seven are visited), gathers unconditional and in a fixed order (ddt_sparse.hip) ----
-    bool act[U];
-    float leafv[U];
-    u32x4 rr[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      act[u] = true;
-      leafv[u] = 0.f;
-      rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m4[u] << 2), 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // A round = two HALF rounds of four trees.  The visits of a half advance together, stage by stage -- four feature reads of the nodes in
-    // flight, then four of the children, then the four gathers back to back -- so that a half round exposes the LDS latency twice, not eight
-    // times (with one visit after the other the chain node read -> compare -> child read -> compare of every tree stood alone: at two waves per
-    // SIMD that left the vector-memory pipe idle for a third of the kernel, 29.3 ms against a floor of 17 on BASELINE config 4); the other
-    // half's gathers fly meanwhile.
-    bool alive = true;
-    if (max_rounds > 1u) {
-      uint32_t r = 1u;
-      do {
-        bool any = false;
-#pragma unroll
-        for (int h = 0; h < U; h += 4) {
-          uint32_t fn[4], fc[4], cw[4], cn[4];
-          bool r0[4], leaf[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {  // the records stay opaque until their half's visits: nothing of them is hoisted in front of the other half's gathers
-            asm volatile("" : "+v"(rr[h + i].x), "+v"(rr[h + i].y), "+v"(rr[h + i].z), "+v"(rr[h + i].w));
-            fn[i] = feat(rr[h + i].x);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            r0[i] = sr_right<SLOW>(fn[i], rr[h + i].x);
-            cw[i] = r0[i] ? rr[h + i].z : rr[h + i].y;
-            leaf[i] = (rr[h + i].x & (r0[i] ? kSrRightLeaf : kSrLeftLeaf)) != 0u;
-            // (a leaf's VALUE goes through the child's compare as if it were a node word: its low byte names some row of the tile -- rows beyond the
-            // tile lie beyond the block's LDS allocation, where a DS read returns 0 -- and whatever comes out is never used: the walker is done)
-            cn[i] = cw[i];
-            fc[i] = feat(cn[i]);
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const bool r1 = sr_right<SLOW>(fc[i], cn[i]);
-            const uint32_t nxt = rr[h + i].w + (r0[i] ? 32u : 0u) + (r1 ? 16u : 0u);
-            if (act[h + i] && leaf[i]) leafv[h + i] = __uint_as_float(cw[i]);
-            act[h + i] = act[h + i] && !leaf[i];
-            any = any || act[h + i];
-            rr[h + i] = __builtin_amdgcn_raw_buffer_load_b128(rs, act[h + i] ? nxt : idle_off, 0, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        alive = __ballot(any) != 0ull;
-      } while (alive && ++r < max_rounds);
-    }
-    if (!alive) {
-      // the wave left early with its last round's (idle) gathers in flight: consume them, so that both exits reach the next pass with nothing
-      // outstanding in the compiler's books
-#pragma unroll
-      for (int u = 0; u < U; ++u) asm volatile("" : : "v"(rr[u].x), "v"(rr[u].y), "v"(rr[u].z), "v"(rr[u].w));
-    }
-    if (alive) {
-      // the last round: visits only.  A walker that is still alive stands on a record whose taken side is a leaf (the host counted the rounds:
-      // SparseAux::max_rounds); a finished one has the zeros its out-of-range gather returned -- no leaf flag
-#pragma unroll
-      for (int h = 0; h < U; h += 4) {
-        uint32_t fn[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          asm volatile("" : "+v"(rr[h + i].x), "+v"(rr[h + i].y), "+v"(rr[h + i].z), "+v"(rr[h + i].w));
-          fn[i] = feat(rr[h + i].x);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool r0 = sr_right<SLOW>(fn[i], rr[h + i].x);
-          if ((rr[h + i].x & (r0 ? kSrRightLeaf : kSrLeftLeaf)) != 0u) leafv[h + i] = __uint_as_float(r0 ? rr[h + i].z : rr[h + i].y);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-
-#pragma unroll
-    for (int h = 0; h < U / 8; ++h) {
-      if (a.sum_mode == 1) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) dacc += (double)leafv[8 * h + u];
-      } else {  // FPAddersReduceTree.sv:94-141, then the slot accumulate of this group's cluster
-        const float lf[1][8] = {{leafv[8 * h + 0], leafv[8 * h + 1], leafv[8 * h + 2], leafv[8 * h + 3], leafv[8 * h + 4], leafv[8 * h + 5],
-                                 leafv[8 * h + 6], leafv[8 * h + 7]}};
-        double unused[1] = {0.0};
-        fold_leaves<8, 1, 0>(lf, 0, C, ra, unused, a.sum_mode == 2);
-      }
-    }
-  }
-}
-
-// The same walk, software-pipelined ACROSS PU groups ("_pl"): the deep rounds of group g are latency-bound at two waves per SIMD (a round = LDS
-// read -> compare -> LDS read -> compare -> gather, then ~1 us until the records are back), and the top walk of group g + 1 -- 9 levels of LDS
-// reads and VALU work -- needs nothing of group g.  Its images are in LDS as soon as group g's top walk is over (the DMA is issued behind the
-// barrier that ends it), so a wave now walks a few top levels of g + 1 behind every deep round of g: the gathers fly under work instead of under a
-// wait.  Same two barriers per group.  The barrier that publishes the next images waits with a COUNTED `vmcnt(U)`: the DMA is older than exactly
-// the U first gathers of the group that were issued behind it (operations return in order) -- tools/check_dma_waits.py proves it on the binary.
-// The order of the sums is untouched: group g is folded before group g + 1's deep phase begins.
-template <int K, int U, int THREADS, bool SLOW>
-__device__ __forceinline__ void sparse_r_walk_pl(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
   static_assert(U == 8 || U == 16, "the counted wait below is vmcnt(U)");
   constexpr int TOPB = 4 << K;
   constexpr int STEPB = U * TOPB;
   constexpr uint32_t ROWB = (uint32_t)THREADS * 4u;
-  constexpr uint32_t FEAT_OFF = (uint32_t)((STEPB + ROWB - 1) / ROWB * ROWB);
   constexpr uint32_t ROW_LOG2 = THREADS == 512 ? 11u : THREADS == 256 ? 10u : 9u;
   static_assert((1u << ROW_LOG2) == ROWB, "tiles of 128 / 256 / 512 tuples");
-  const uint32_t lane_off = FEAT_OFF + (uint32_t)tid * 4u;
+  const SrTile<THREADS, STEPB, WP> tl(a.tuple_words, tid);
+  const uint32_t lane_off = tl.lane_off, fmask = tl.mask;
   auto feat = [&](uint32_t rec) -> uint32_t {
     uint32_t addr;
-    asm("v_and_b32 %0, 0xff, %1\n\tv_lshl_add_u32 %0, %0, %2, %3" : "=&v"(addr) : "v"(rec), "n"(ROW_LOG2), "v"(lane_off));
+    if constexpr (WP) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(addr) : "v"(rec), "s"(fmask), "v"(lane_off));
+    else asm("v_and_b32 %0, 0x7f00, %1\n\tv_lshl_add_u32 %0, %0, %2, %3" : "=&v"(addr) : "v"(rec), "n"(ROW_LOG2 - kSrFeatShift), "v"(lane_off));
     return lds_u32(addr);
   };
   const uint32_t C = a.clusters;
@@ -409,7 +304,7 @@ __device__ __forceinline__ void sparse_r_walk_pl(const ScoreArgs& a, const Spars
             r0[i] = sr_right<SLOW>(fn[i], rr[h + i].x);
             cw[i] = r0[i] ? rr[h + i].z : rr[h + i].y;
             leaf[i] = (rr[h + i].x & (r0[i] ? kSrRightLeaf : kSrLeftLeaf)) != 0u;
-            fc[i] = feat(cw[i]);  // (a leaf's value read as a node word: see sparse_r_walk)
+            fc[i] = feat(cw[i]);  // (a leaf's value read as a node word: above)
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -435,7 +330,7 @@ __device__ __forceinline__ void sparse_r_walk_pl(const ScoreArgs& a, const Spars
 #pragma unroll
       for (int u = 0; u < U; ++u) asm volatile("" : : "v"(rr[u].x), "v"(rr[u].y), "v"(rr[u].z), "v"(rr[u].w));
     }
-    if (alive) {  // the last round: visits only (sparse_r_walk)
+    if (alive) {  // the last round: visits only
 #pragma unroll
       for (int h = 0; h < U; h += 4) {
         uint32_t fn[4];
@@ -480,12 +375,11 @@ __device__ __forceinline__ void sparse_r_walk_pl(const ScoreArgs& a, const Spars
   }
 }
 
-template <int K, int U, int THREADS, bool PL>
+template <int K, int U, int THREADS, bool WP>
 __global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 4 << K;
   constexpr int STEPB = U * TOPB;
   constexpr int ROW = THREADS * 4;
-  constexpr int FEAT_OFF = (STEPB + ROW - 1) / ROW * ROW;
   static_assert(U == 8 || U == 16, "one or two PU groups per pass");
   static_assert((STEPB / 16) % 64 == 0, "whole waves per DMA");
   const int tid = threadIdx.x;
@@ -494,14 +388,23 @@ __global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs
 
   dma_chunk<THREADS, STEPB>(a.img, 0, 0, tid);  // top images of the first pass
   {
-    // the rank tile is one contiguous block of W * ROW bytes of the pre-pass's output: DMA it in; the first barrier of the walk publishes it
+    // the rank tile is one contiguous block of W * ROW bytes of the pre-pass's output, [feature][THREADS tuples]: DMA it in; the first barrier of the
+    // walk publishes it.  A wave instruction fills 1 KiB of LDS with 64 pieces of 16 bytes from anywhere: for wave-private rows (SrTile) those are
+    // four rows of one wave's region = the 256-byte pieces [64 w, 64 w + 64) of four features' rows
+    const SrTile<THREADS, STEPB, WP> tl(W, tid);
     const uint4* src = reinterpret_cast<const uint4*>(x.r32.r + (uint64_t)blockIdx.x * W * (uint32_t)THREADS);
-    const uint32_t units = W * (ROW / 16);
+    const uint32_t units = WP ? (uint32_t)(THREADS / 64) << (tl.ws_log2 - 4u) : W * (ROW / 16);
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
     for (uint32_t u0 = 0; u0 < units; u0 += THREADS) {
-      const uint32_t lds_addr = (uint32_t)FEAT_OFF + (u0 + (uint32_t)wave_base) * 16u;
+      const uint32_t lds_addr = tl.feat_off + (u0 + (uint32_t)wave_base) * 16u;
       const uint4* g = src + (u0 + (uint32_t)tid);
-      if (u0 + (uint32_t)wave_base < units)
+      bool valid = u0 + (uint32_t)wave_base < units;
+      if constexpr (WP) {
+        const uint32_t byte = (u0 + (uint32_t)tid) * 16u, w = byte >> tl.ws_log2, rem = byte & ((1u << tl.ws_log2) - 1u), f = rem >> 8;
+        g = src + (f * (uint32_t)(ROW / 16) + w * 16u + ((rem & 255u) >> 4));
+        valid = valid && (uint32_t)__builtin_amdgcn_readfirstlane((int)f) < W;  // (rows come in fours and W is a multiple of 4: a wave's unit is whole)
+      }
+      if (valid)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
     }
   }
@@ -511,13 +414,8 @@ __global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs
   ra.init();
   double dacc = 0.0;
   const uint32_t C = a.clusters;
-  if constexpr (PL) {
-    if (!slow) sparse_r_walk_pl<K, U, THREADS, false>(a, x, tid, ra, dacc);
-    else sparse_r_walk_pl<K, U, THREADS, true>(a, x, tid, ra, dacc);
-  } else {
-    if (!slow) sparse_r_walk<K, U, THREADS, false>(a, x, tid, ra, dacc);
-    else sparse_r_walk<K, U, THREADS, true>(a, x, tid, ra, dacc);
-  }
+  if (!slow) sparse_r_walk<K, U, THREADS, false, WP>(a, x, tid, ra, dacc);
+  else sparse_r_walk<K, U, THREADS, true, WP>(a, x, tid, ra, dacc);
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
@@ -527,11 +425,8 @@ template <int K, int U, int THREADS>
 static hipError_t launch_sparse_r_v(const ScoreArgs& a, const Variant& v, hipStream_t s) {
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
-  static const bool pipelined = [] {  // A/B: DDT_SPARSE_R_PL=0 -> the walk without the pipeline across PU groups
-    const char* v = getenv("DDT_SPARSE_R_PL");
-    return !(v && v[0] == '0');
-  }();
-  auto kern = pipelined ? score_sparse_r_kernel<K, U, THREADS, true> : score_sparse_r_kernel<K, U, THREADS, false>;
+  // wave-private rows where their padding costs no block per CU (Variant::wave_rows: the same rule sized `lds`)
+  auto kern = v.wave_rows(a.tuple_words) ? score_sparse_r_kernel<K, U, THREADS, true> : score_sparse_r_kernel<K, U, THREADS, false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;

@@ -288,7 +288,7 @@ void enqueue_prepass_r32(const ScoreArgs& a, const SparseAux& x, hipStream_t s) 
           out = kSrMissing;
           x.q16.tile_flags[i / T] = 1u;
         } else {
-          out = (rank32_of(x.q16, x.r32, j, raw, a.ieee) << 12) | 0xFFFu;
+          out = (rank32_of(x.q16, x.r32, j, raw, a.ieee) << kSrRankShift) | ((1u << kSrRankShift) - 1u);
         }
         x.r32.r[i * W + j] = out;
       }
@@ -314,7 +314,7 @@ hipError_t launch_sparse_r(const ScoreArgs& args, const Variant& var, hipStream_
       const uint32_t* rk = x.r32.r + i * W;
       const bool slow = x.q16.tile_flags[i / x.r32.tile] != 0u;
       auto right = [&](uint32_t rec) -> uint32_t {
-        const uint32_t f = rk[rec & kSrFeatMask];
+        const uint32_t f = rk[(rec & kSrFeatMask) >> kSrFeatShift];
         if (slow && f == kSrMissing) return (rec & kSrMissRight) ? 1u : 0u;
         return f >= rec ? 1u : 0u;
       };

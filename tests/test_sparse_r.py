@@ -1,5 +1,5 @@
 """Sparse forests on 32-BIT RANKS with pair records on every deep level (`sparse_r_*`, csrc/ddt_sparse_r.hip, round 6) on the GPU, through the
-C-ABI against the sparse oracle, bit for bit: a node is one word {rank : 20 | flags | feature : 8}, the feature tile holds rank(x) << 12 | 0xFFF
+C-ABI against the sparse oracle, bit for bit: a node is one word {rank : 17 | feature : 7 | flags : 8}, the feature tile holds rank(x) << 15 | 0x7FFF
 written by the rank32 pre-pass (directory out of LDS + one 16-byte gather of the key block), a 16-byte record {node, left child, right child,
 pointer} decides two levels per gather.  The engine's own choice (asserted by name) and the forced one; tiles with and without missing values;
 ragged sizes; both comparators; all three sums; tables below and above one key block per directory entry; classes and tree shards; the host
@@ -65,14 +65,19 @@ def test_pair_records_on_32_bit_ranks_equal_the_oracle(T, depth, F, full, pm, di
     e.close()
 
 
-def test_ieee_comparator_and_key_blocks_of_eight():
-    """cmp_mode 1 (IEEE `<` through the order-preserving key: negative values, -0, NaN features) and a forest with more distinct thresholds on a
-    feature than 4 x 32767 -- the pre-pass then reads blocks of EIGHT keys (two gathers per value)"""
+def test_ieee_comparator_and_key_blocks_of_eight(monkeypatch):
+    """cmp_mode 1 (IEEE `<` through the order-preserving key: negative values, -0, NaN features), a feature with ~100 k distinct thresholds (a
+    directory of 25 k entries in the pre-pass), and blocks of EIGHT keys (two gathers per value: what tables beyond 4 x 32767 keys get; a 17-bit rank
+    ends at 131,070, so the block size is forced here -- `DDT_R32_BLK_LOG2`, read when the model is loaded)"""
     import torch
 
     e = ddt.Engine(0)
     e.set_option("sparse_r32", 1)
-    for (T, depth, F, full, pm, cmp_mode) in [(40, 15, 12, 5, 750, 1), (4, 16, 1, 14, 980, 0), (8, 16, 2, 14, 980, 1)]:
+    for (T, depth, F, full, pm, cmp_mode, blk) in [(40, 15, 12, 5, 750, 1, 0), (2, 16, 1, 14, 980, 0, 0), (4, 16, 2, 14, 980, 1, 3)]:
+        if blk:
+            monkeypatch.setenv("DDT_R32_BLK_LOG2", str(blk))
+        else:
+            monkeypatch.delenv("DDT_R32_BLK_LOG2", raising=False)
         sp = O.gen_sparse_model(T, depth, F, full, pm, 1, cmp_mode=cmp_mode)
         n = 50_001
         x = O.gen_tuples(9, n, F, dist=1)
@@ -89,6 +94,7 @@ def test_ieee_comparator_and_key_blocks_of_eight():
         torch.cuda.synchronize()
         bad = np.flatnonzero(_bits(got.cpu().numpy()) != _bits(want))
         assert bad.size == 0, (T, depth, F, cmp_mode, bad[:8], bad.size)
+    monkeypatch.delenv("DDT_R32_BLK_LOG2", raising=False)
     e.close()
 
 

@@ -2,7 +2,7 @@
 
 * the tables of the 32-bit rank pre-pass (`ddt_sparse_host.cpp pack_rank32_tables`: key blocks + the directory of their last keys + bucket
   starts) come back through `ddt_debug_rank32_tables` and rank32_kernel's search is replayed on them in numpy against a plain sorted-table
-  count -- tables from 0 to 140,000 keys (block sizes 4 and 8), keys at both ends of the int32 range, values on, between and beyond the keys;
+  count -- tables from 0 to 131,070 keys = the most a 17-bit rank holds (block sizes 4 and 8), keys at both ends of the int32 range, values on, between and beyond the keys;
 * the images (`sparse_pack_host_r`: one-word nodes in the top heap, pair / LEAF records below) come back through `ddt_debug_sparse_image`
   and are walked the way score_sparse_r_kernel walks them; every (tuple, tree) must end on the leaf the oracle's walk of the wire format
   ends on (DTPU.sv:579-720 semantics), EMPTY slots on +0, within the number of record hops the packer reports.
@@ -16,7 +16,7 @@ from oracle import oracle as O
 import ddt
 from ddt import _lib
 
-LEFT_LEAF, RIGHT_LEAF, MISS_RIGHT, FEAT = 0x800, 0x400, 0x200, 0xFF
+LEFT_LEAF, RIGHT_LEAF, MISS_RIGHT, FEAT_SHIFT, FEAT, RANK_SHIFT = 0x80, 0x40, 0x20, 8, 0x7F, 15  # csrc/ddt_internal.h kSr*
 MISSING = 0xFFFFFFFF
 BUCKETS = 4096
 
@@ -69,7 +69,7 @@ def _rank32(d, par, st, tab, Kpad, bl, j, x):
 def test_rank32_tables_replay_the_kernels_search():
     rng = np.random.default_rng(11)
     imin, imax = np.iinfo(np.int32).min, np.iinfo(np.int32).max
-    float_keys = np.unique(rng.random(140_000, dtype=np.float32)).view(np.int32)                 # one binade-spanning table: > 4 * 32767 keys -> blocks of 8
+    float_keys = np.unique(rng.random(200_000, dtype=np.float32))[:131_070].view(np.int32)        # the largest table: > 4 * 32767 keys -> blocks of 8
     words = [
         np.zeros(0, np.int32),                                                                  # unused feature: every value ranks 0
         np.asarray([5], np.int32),
@@ -118,11 +118,11 @@ def _images(s, variant):
 
 
 def _walk(top, deep, K, slot, xr, slow):
-    """score_sparse_r_kernel's walk of one tree slot: xr = the tuple's rank words (rank << 12 | 0xFFF, or MISSING)"""
+    """score_sparse_r_kernel's walk of one tree slot: xr = the tuple's rank words (rank << 15 | 0x7FFF, or MISSING)"""
     t = top[slot << K: (slot + 1) << K]
 
     def right(rec):
-        f = int(xr[rec & FEAT])
+        f = int(xr[(rec >> FEAT_SHIFT) & FEAT])
         if slow and f == MISSING:
             return int((rec & MISS_RIGHT) != 0)
         return int(f >= rec)
@@ -152,7 +152,7 @@ def test_packed_r32_images_walk_to_the_oracles_leaves(shape):
     tables = [np.unique(nl[(nl[:, 1] & 0x7FF) == j, 0].view(np.int32)) for j in range(x.shape[1])]
     miss = x == np.uint32(s.params.missing_bits)
     xr = np.stack([np.searchsorted(tables[j], x[:, j].view(np.int32), side="right").astype(np.uint64) for j in range(x.shape[1])], axis=1)
-    xr = ((xr << 12) | 0xFFF).astype(np.uint32)
+    xr = ((xr << RANK_SHIFT) | ((1 << RANK_SHIFT) - 1)).astype(np.uint32)
     xr[miss] = MISSING
     seen = set()
     for vid, name in enumerate(ddt.variant_names()):
