@@ -133,10 +133,10 @@ static int pick_r32_variant(ddt_engine* e, uint32_t max_depth) {
   if (e->p.num_features > 128u) return -1;  // a node word carries the feature number in 7 bits
   if (W > kSrMaxWords) return -1;            // the pre-pass's transpose stages 256 rows x W words in LDS
   char name[40];
-  const int kcap = (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, 8u), 10u);
+  const int kcap = (int)std::min<uint32_t>(std::max<uint32_t>(max_depth, 9u), 10u);  // (a top image may be deeper than the forest: early leaves are padded)
   for (uint32_t budget : {kMaxLdsBytes / 2u, kMaxLdsBytes})
     for (int T : {256, 128})
-      for (int K = e->sparse_top_levels >= 0 ? e->sparse_top_levels : kcap; K >= (e->sparse_top_levels >= 0 ? e->sparse_top_levels : 8); --K) {
+      for (int K = e->sparse_top_levels >= 0 ? e->sparse_top_levels : kcap; K >= (e->sparse_top_levels >= 0 ? e->sparse_top_levels : 9); --K) {
         snprintf(name, sizeof(name), "sparse_r_k%d_u8_t%d", K, T);
         const int vid = find_variant(name);
         if (vid >= 0 && variant(vid).lds_bytes_sparse(W) <= budget) return vid;
@@ -564,15 +564,16 @@ static int sparse_pack_host_r(ddt_engine* e, const Variant& v, SparseForest& sp,
   };
   try {
     top.assign((size_t)groups * 8u * top_words, 0u);
-    // records 0 .. 2^K - 1: LEAF(+0) -- the dense block every EMPTY slot shares (DTPU.sv:544,760: an EMPTY slot adds exactly +0)
-    deep.assign((size_t)4u << K, 0u);
-    for (uint32_t q = 0; q < (1u << K); ++q) deep[4u * q] = kSrLeafRec;
+    // records 0 .. 3: ZERO -- where a finished walker goes and stays (ddt_sparse_r.hip: {0, 0, 0, 0} has no leaf flag and its next block is byte 0);
+    // records 4 .. 4 + 2^K - 1: LEAF(+0) -- the dense block every EMPTY slot shares (DTPU.sv:544,760: an EMPTY slot adds exactly +0)
+    deep.assign(16u + ((size_t)4u << K), 0u);
+    for (uint32_t q = 0; q < (1u << K); ++q) deep[16u + 4u * q] = kSrLeafRec;
     std::vector<Cursor> cur, nxt;
     std::vector<Todo> todo;
     for (uint32_t i = 0; i < groups * 8u; ++i) {
       uint32_t* t = top.data() + (size_t)i * top_words;
       if (i >= T) {
-        t[0] = 0u - (16u << K);  // cbase of the shared block at byte 0
+        t[0] = 64u - (16u << K);  // cbase of the shared block at byte 64
         continue;                // (node words 0: feature 0 against rank 0 -- any direction ends in the block of LEAF(+0))
       }
       const uint32_t* L = sp.lines.data() + sp.first[i] * 4u;

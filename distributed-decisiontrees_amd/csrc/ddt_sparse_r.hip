@@ -15,6 +15,8 @@
 // Core.sv:486-541).  What the ranks cost: a pre-pass per batch (transpose + rank32_kernel below) that the fp32-tile kernels do not have.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdlib>
 
 #include "ddt_device.h"
@@ -375,7 +377,185 @@ __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAu
   }
 }
 
-template <int K, int U, int THREADS, bool WP>
+// The same walk with the deep rounds of CONSECUTIVE groups overlapped ("lag"): rounds 1 .. A of group g (A = half the rounds, rounded up) run
+// interleaved with rounds A + 1 .. R of group g - 1 -- the late rounds, where a third of the walkers and less are still alive, no longer stand
+// alone in front of their gathers' latency.  Two record sets per lane that swap roles from group to group (no register moves: a set's last gathers
+// are in flight when the group changes); group g - 1 is folded inside group g's step, before group g: the order of the sums is untouched.
+// Every iteration issues the same gathers in the same order (older set first, 2 x U, whatever is alive): the compiler's wait counts are exact on
+// every path.  That needs walkers without an "active" mask: bytes 0..63 of the deep array are ZERO records (ddt_sparse_host.cpp) -- a finished walker
+// is sent to byte 48, finds {0, 0, 0, 0} = "feature 0 against rank 0, no leaf flag, next block at 0" and stays inside those 64 bytes by itself.
+template <int K, int U, int THREADS, bool SLOW, bool WP, int NB, int ODD>
+__device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
+  static_assert(U == 8, "the counted wait below is vmcnt(8)");
+  constexpr int TOPB = 4 << K;
+  constexpr int STEPB = U * TOPB;
+  constexpr uint32_t ROWB = (uint32_t)THREADS * 4u;
+  constexpr uint32_t ROW_LOG2 = THREADS == 512 ? 11u : THREADS == 256 ? 10u : 9u;
+  static_assert((1u << ROW_LOG2) == ROWB, "tiles of 128 / 256 / 512 tuples");
+  const SrTile<THREADS, STEPB, WP> tl(a.tuple_words, tid);
+  const uint32_t lane_off = tl.lane_off, fmask = tl.mask;
+  auto feat = [&](uint32_t rec) -> uint32_t {
+    uint32_t addr;
+    if constexpr (WP) asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(addr) : "v"(rec), "s"(fmask), "v"(lane_off));
+    else asm("v_and_b32 %0, 0x7f00, %1\n\tv_lshl_add_u32 %0, %0, %2, %3" : "=&v"(addr) : "v"(rec), "n"(ROW_LOG2 - kSrFeatShift), "v"(lane_off));
+    return lds_u32(addr);
+  };
+  const uint32_t C = a.clusters;
+  const uint32_t n_steps = x.n_groups;
+  // R = SparseAux::max_rounds = 2 NB + ODD rounds, compile-time: the iterations below are straight-line code (with a runtime trip count the
+  // compiler's wait counts at the loop header were those of the loop's entry -- 7 where the back edge has 15 gathers behind the record)
+  constexpr uint32_t B = (uint32_t)NB, A = (uint32_t)(NB + ODD);  // rounds of a group walked in the next group's step / in its own
+  constexpr uint32_t per_round = ((uint32_t)K + A - 1u) / A;     // top levels of the next group behind every iteration
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(x.deep), 0, (int)x.deep_bytes, 0x00020000);
+  uint32_t m4[U];
+  auto top_reset = [&]() {
+#pragma unroll
+    for (int u = 0; u < U; ++u) m4[u] = 4u;
+  };
+  auto top_levels = [&](uint32_t count) {
+#pragma unroll
+    for (uint32_t l = 0; l < count; ++l) {
+      uint32_t nd[U], f[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) nd[u] = lds_u32(m4[u] + (uint32_t)(u * TOPB));
+#pragma unroll
+      for (int u = 0; u < U; ++u) f[u] = feat(nd[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) m4[u] = (m4[u] << 1) + (sr_right<SLOW>(f[u], nd[u]) ? 4u : 0u);
+    }
+  };
+  struct Set {
+    u32x4 rr[U];
+    float leafv[U];
+  };
+  // one round of a set: the visits of its U records (two levels each) and the next gathers
+  auto round = [&](Set& S) {
+#pragma unroll
+    for (int h = 0; h < U; h += 4) {
+      uint32_t fn[4], fc[4], cw[4];
+      bool r0[4], leaf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        asm volatile("" : "+v"(S.rr[h + i].x), "+v"(S.rr[h + i].y), "+v"(S.rr[h + i].z), "+v"(S.rr[h + i].w));
+        fn[i] = feat(S.rr[h + i].x);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        r0[i] = sr_right<SLOW>(fn[i], S.rr[h + i].x);
+        cw[i] = r0[i] ? S.rr[h + i].z : S.rr[h + i].y;
+        leaf[i] = (S.rr[h + i].x & (r0[i] ? kSrRightLeaf : kSrLeftLeaf)) != 0u;
+        fc[i] = feat(cw[i]);  // (a leaf's value read as a node word: above)
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool r1 = sr_right<SLOW>(fc[i], cw[i]);
+        uint32_t nxt = S.rr[h + i].w + (r0[i] ? 32u : 0u) + (r1 ? 16u : 0u);
+        asm volatile("" : "+v"(nxt));  // (computed for every lane: hipcc otherwise sinks the child's compare into a divergent branch on `leaf`)
+        S.leafv[h + i] = leaf[i] ? __uint_as_float(cw[i]) : S.leafv[h + i];
+        S.rr[h + i] = __builtin_amdgcn_raw_buffer_load_b128(rs, leaf[i] ? 48u : nxt, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto fold = [&](Set& S) {  // FPAddersReduceTree.sv:94-141, then the slot accumulate of this group's cluster
+    if (a.sum_mode == 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dacc += (double)S.leafv[u];
+    } else {
+      const float lf[1][8] = {{S.leafv[0], S.leafv[1], S.leafv[2], S.leafv[3], S.leafv[4], S.leafv[5], S.leafv[6], S.leafv[7]}};
+      double unused[1] = {0.0};
+      fold_leaves<8, 1, 0>(lf, 0, C, ra, unused, a.sum_mode == 2);
+    }
+  };
+  auto first_gathers = [&](Set& S, const uint32_t (&cb)[U]) {  // ... exactly U gathers behind the DMA of the images after next: what the counted wait counts
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      S.rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m4[u] << 2), 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      S.leafv[u] = 0.f;
+    }
+  };
+  auto next_top = [&](uint32_t& lv) {  // the next group's top walk, a few levels behind every iteration: the gathers fly meanwhile
+    const uint32_t c = (uint32_t)K - lv < per_round ? (uint32_t)K - lv : per_round;
+#pragma unroll
+    for (uint32_t l = 0; l < per_round; ++l)
+      if (l < c) top_levels(1u);
+    lv += c;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // group g's step: cur = its walkers (first gathers in flight, the youngest), prev = group g - 1's, A rounds in (at g = 0: idle walkers)
+  // (`next` = there is a group g + 1, compile-time: with a runtime flag the paths with and without its first gathers meet at the loop's back edge, and
+  // the compiler's wait counts for the other set's records become those of the path without -- 7 instead of 15)
+  auto step = [&](Set& cur, Set& prev, const uint32_t g, auto next_tag) {
+    constexpr bool next = decltype(next_tag)::value;
+    if constexpr (next) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the DMA of the next images is older than the U gathers issued behind it
+      __syncthreads();                                   // ... and has landed for every wave
+      top_reset();
+    }
+    uint32_t lv = 0;  // levels of group g + 1 walked so far
+#pragma unroll
+    for (uint32_t i = 0; i < B; ++i) {
+      round(prev);  // its records are the older ones
+      round(cur);
+      if constexpr (next) next_top(lv);
+    }
+    if (g > 0u) fold(prev);  // group g - 1 is through its R rounds: folded in stream order
+    if constexpr (A > B) {
+      round(cur);
+      if constexpr (next) next_top(lv);
+    }
+    if constexpr (next) {
+#pragma unroll
+      for (uint32_t l = 0; l < (uint32_t)K; ++l)
+        if (l >= lv) top_levels(1u);
+      uint32_t cb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));
+      __syncthreads();  // every wave is through with the images of group g + 1
+      if (g + 2u < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 2u, 0, tid);
+      first_gathers(prev, cb);  // the set of group g - 1 is free: it becomes group g + 1's
+    }
+  };
+  Set S0, S1;
+  // ---- prologue: group 0's top walk, the plain way ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // images of group 0 and the rank tile are in LDS for everyone
+  top_reset();
+  top_levels((uint32_t)K);
+  {
+    uint32_t cb[U];  // (read before the barrier: behind it the DMA of the next images may land)
+#pragma unroll
+    for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));
+    __syncthreads();
+    if (1u < n_steps) dma_chunk<THREADS, STEPB>(a.img, 1, 0, tid);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // the other set starts as eight finished walkers
+      S1.rr[u] = u32x4{0u, 0u, 0u, 0u};
+      S1.leafv[u] = 0.f;
+    }
+    first_gathers(S0, cb);
+  }
+  uint32_t g = 0;
+  for (; g + 2u < n_steps; g += 2u) {
+    step(S0, S1, g, std::true_type{});
+    step(S1, S0, g + 1u, std::true_type{});
+  }
+  if (g + 1u < n_steps) {  // two groups left
+    step(S0, S1, g, std::true_type{});
+    step(S1, S0, g + 1u, std::false_type{});
+#pragma unroll
+    for (uint32_t i = 0; i < B; ++i) round(S1);
+    fold(S1);
+  } else {  // one
+    step(S0, S1, g, std::false_type{});
+#pragma unroll
+    for (uint32_t i = 0; i < B; ++i) round(S0);
+    fold(S0);
+  }
+}
+
+template <int K, int U, int THREADS, bool WP, int NB, int ODD>  // NB + ODD > 0: the walk with 2 NB + ODD rounds, consecutive groups overlapped
 __global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 4 << K;
   constexpr int STEPB = U * TOPB;
@@ -414,8 +594,13 @@ __global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs
   ra.init();
   double dacc = 0.0;
   const uint32_t C = a.clusters;
-  if (!slow) sparse_r_walk<K, U, THREADS, false, WP>(a, x, tid, ra, dacc);
-  else sparse_r_walk<K, U, THREADS, true, WP>(a, x, tid, ra, dacc);
+  if constexpr (NB + ODD > 0) {
+    if (!slow) sparse_r_walk_lag<K, U, THREADS, false, WP, NB, ODD>(a, x, tid, ra, dacc);
+    else sparse_r_walk_lag<K, U, THREADS, true, WP, NB, ODD>(a, x, tid, ra, dacc);
+  } else {
+    if (!slow) sparse_r_walk<K, U, THREADS, false, WP>(a, x, tid, ra, dacc);
+    else sparse_r_walk<K, U, THREADS, true, WP>(a, x, tid, ra, dacc);
+  }
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
@@ -426,7 +611,18 @@ static hipError_t launch_sparse_r_v(const ScoreArgs& a, const Variant& v, hipStr
   const SparseAux& x = *reinterpret_cast<const SparseAux*>(a.aux);
   const uint32_t lds = v.lds_bytes_sparse(a.tuple_words);
   // wave-private rows where their padding costs no block per CU (Variant::wave_rows: the same rule sized `lds`)
-  auto kern = v.wave_rows(a.tuple_words) ? score_sparse_r_kernel<K, U, THREADS, true> : score_sparse_r_kernel<K, U, THREADS, false>;
+  // Consecutive groups overlapped (sparse_r_walk_lag) where the forest's longest path takes 2 .. 6 rounds and the LDS allows two blocks per CU at most:
+  // that walk holds two record sets per lane (~180 VGPRs = two waves per SIMD; 128 x d14 x 20 features, three blocks per CU: 1335 vs 1578 Mtuples/s)
+  static const bool lag_on = [] {  // A/B: DDT_SPARSE_R_LAG=0 -> a group's rounds alone, one group after the other
+    const char* v = getenv("DDT_SPARSE_R_LAG");
+    return !(v && v[0] == '0');
+  }();
+  const bool wp = v.wave_rows(a.tuple_words);
+  const uint32_t rounds = (lag_on && 3u * lds > 160u * 1024u) ? x.max_rounds : 0u;
+#define DDT_SR_KERN(NB, ODD) (wp ? score_sparse_r_kernel<K, U, THREADS, true, NB, ODD> : score_sparse_r_kernel<K, U, THREADS, false, NB, ODD>)
+  auto kern = rounds == 2u ? DDT_SR_KERN(1, 0) : rounds == 3u ? DDT_SR_KERN(1, 1) : rounds == 4u ? DDT_SR_KERN(2, 0) : rounds == 5u ? DDT_SR_KERN(2, 1)
+            : rounds == 6u ? DDT_SR_KERN(3, 0) : DDT_SR_KERN(0, 0);
+#undef DDT_SR_KERN
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const uint64_t blocks = (a.n + THREADS - 1) / THREADS;
@@ -445,9 +641,9 @@ static hipError_t launch_sparse_r_v(const ScoreArgs& a, const Variant& v, hipStr
   Variant { "sparse_r_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 32, &launch_sparse_r_v<K, U, T> }
 
 static const Variant g_sparse_r_variants[] = {
-    // two blocks of 256 tuples per CU at 64 features with K = 9 (2 x (16 + 64) KiB); K = 10 up to 48 features; K = 8 beyond 64 features (a block per CU)
-    DDT_SPR(8, 8, 256), DDT_SPR(9, 8, 256), DDT_SPR(10, 8, 256),
-    DDT_SPR(8, 8, 128), DDT_SPR(9, 8, 128),
+    // two blocks of 256 tuples per CU up to 64 tuple words with K = 9 (2 x (16 + 64) KiB), K = 10 up to 48; 128 tuples per block beyond 64 words (K = 9: 16 +
+    // 64 KiB at 128 words).  (K = 8 forms existed for 65..72 words and never won elsewhere: removed with the six-fold instantiation per round count)
+    DDT_SPR(9, 8, 256), DDT_SPR(10, 8, 256), DDT_SPR(9, 8, 128),
     // (two PU groups per pass -- 16 chains per lane, K = 8 in the same 16 KiB -- measured and NOT instantiated: config 4 301 vs 335 Mtuples/s on
     // k9_u8: five rounds instead of four, profiles/EXPERIMENTS.md round 6; the walks above take U = 16 should it be wanted again)
 };

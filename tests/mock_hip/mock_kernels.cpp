@@ -458,9 +458,9 @@ const Variant g_mock_sparse[] = {  // csrc/ddt_sparse.hip DDT_SP(K, U, T)
     Variant{"sparse_qd_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3, &launch_sparse},
     Variant{"sparse_qp_k8_u8_t1024", kKindSparse, 8, 1024, 1, 8, 8, 1, 3 | 16, &launch_sparse, 2},
     Variant{"sparse_gf_k6_u8_t256", kKindSparse, 6, 256, 1, 8, 8, 1, 4, &launch_sparse},
-    Variant{"sparse_r_k8_u8_t256", kKindSparse, 8, 256, 1, 8, 8, 1, 32, &launch_sparse_r},
     Variant{"sparse_r_k9_u8_t256", kKindSparse, 9, 256, 1, 8, 8, 1, 32, &launch_sparse_r},
-    Variant{"sparse_r_k8_u8_t128", kKindSparse, 8, 128, 1, 8, 8, 1, 32, &launch_sparse_r},
+    Variant{"sparse_r_k10_u8_t256", kKindSparse, 10, 256, 1, 8, 8, 1, 32, &launch_sparse_r},
+    Variant{"sparse_r_k9_u8_t128", kKindSparse, 9, 128, 1, 8, 8, 1, 32, &launch_sparse_r},
 };
 constexpr int kMockDense = (int)(sizeof(g_mock_variants) / sizeof(g_mock_variants[0]));
 }  // namespace
