@@ -4,8 +4,8 @@
 // 512 trees x depth <= 16 x 64 features, ~33 cycles of the CU's vector-memory pipe each = 89 % of its cycles, profiles/r05_pmc_cfg2_cfg4_cfg6.md
 // section 7): one 16-byte record {fp32 key, w, left, right} decides ONE level.  Three nodes fit 16 bytes only as one-word nodes, i.e. with
 // RANKS for thresholds -- and u16 ranks (the q16 pre-pass) stop at 65 k distinct thresholds per feature where this forest has ~100 k.  So the
-// ranks here are 20 bits wide and the feature tile stays 32 bits per value (the fp32 tile's size: two blocks of 256 tuples x 64 features per CU,
-// like `sparse_dp_k8_u8_t256`); a node is ONE word {rank : 20 | flags : 4 | feature : 8}, the tile holds rank(x) << 12 | 0xFFF, and the compare
+// ranks here are 17 bits wide and the feature tile stays 32 bits per value (the fp32 tile's size: two blocks of 256 tuples x 64 features per CU,
+// like `sparse_dp_k8_u8_t256`); a node is ONE word {rank : 17 | feature : 7 | flags : 8}, the tile holds rank(x) << 15 | 0x7FFF, and the compare
 // !(x < t) (DTPU.sv:653-657) is ONE unsigned compare of the two words (ddt_internal.h "32-bit ranks").  Per tree:
 //   top     K levels out of LDS, 4 bytes per node (K = 9 in the 16 KiB that held K = 8 as 8-byte records)
 //   deep    16-byte PAIR records {node, left child, right child, ptr}: one gather decides TWO levels on every level below; early leaves
@@ -13,6 +13,9 @@
 // Depth 16 with K = 9: 4 gather instructions per tree and wave.  The per-node work is the reference's (read node -> gather feature ->
 // compare / missing rule -> next node, DTPU.sv:579-720), the sums run in its adder order (FPAddersReduceTree.sv:94-141, FPAggregator.v:79-131,
 // Core.sv:486-541).  What the ranks cost: a pre-pass per batch (transpose + rank32_kernel below) that the fp32-tile kernels do not have.
+// The kernel is latency-bound at two waves per SIMD (LDS: 80 KiB per block of four waves); what the walk does about it: four trees' visits advance
+// together (half rounds), the next group's top levels are walked behind the deep rounds, and the late rounds of a group run under the early rounds
+// of the next (sparse_r_walk_lag).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -28,7 +31,7 @@ namespace ddt {
 // rank32_kernel: r(x) = #{keys <= x} against tables too long for LDS (100 k keys = 400 KiB per feature).  LDS holds the feature's DIRECTORY --
 // the last key of every block of 2^blk_log2 keys, searched like rank_kernel's table (bucket lookup + log2 P probes, ddt_kernels.hip) --
 // which names the one block that holds the answer; that block comes from global memory (L2-resident: the blocks of all features are a few
-// tens of MB) with ONE 16-byte gather per four keys.  Output: x' = r << 12 | 0xFFF in tiles [n_pad / T][W][T] (a missing value: 0xFFFFFFFF and
+// tens of MB) with ONE 16-byte gather per four keys.  Output: x' = r << 15 | 0x7FFF in tiles [n_pad / T][W][T] (a missing value: 0xFFFFFFFF and
 // its tile's flag), what score_sparse_r_kernel DMAs into LDS.
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kR32Threads = 1024;

@@ -375,8 +375,9 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * exist -- all top levels as 8-byte records in LDS, the first deep level addressed by the heap index; 0 = never), "sparse_r32"
  * (-1 = default: sparse forests of depth >= 13 with at least two trees per tuple word, tuples of at most 128 words and at most 131,068
  * distinct thresholds per feature run on the "sparse_r_*" kernels -- thresholds as
- * 20-bit ranks, a 32-bit rank tile written by a pre-pass per batch, 16-byte PAIR records {node, left child, right child, pointer}
- * on every level below the top image: one gather decides two levels; 0 = never; 1 = wherever such a kernel fits).  A refused
+ * 17-bit ranks, a 32-bit rank tile written by a pre-pass per batch, 16-byte PAIR records {node, left child, right child, pointer}
+ * on every level below the top image: one gather decides two levels; 0 = never; 1 = wherever such a kernel fits: at most 128 features and 131,070
+ * distinct thresholds per feature).  A refused
  * sparse_* value keeps the previous one and the loaded model. */
 int ddt_set_option(ddt_engine* e, const char* key, int64_t value);
 int ddt_num_variants(void);
@@ -452,7 +453,7 @@ int ddt_debug_sparse_image(const ddt_params* p, const void* node_lines, size_t n
 /*    ... for a "sparse_r_*" variant (32-bit ranks, pair records): top = one-word nodes, deep = pair / LEAF records (csrc/ddt_internal.h "32-bit
  *    ranks"); info_out[3] = K | (record hops on the longest path below the top image) << 32.
  *    The tables of the 32-bit rank pre-pass (csrc/ddt_sparse_r.hip rank32_kernel): keys / counts as for ddt_debug_prepass_image (n_words <= 2048,
- *    counts <= 2^20 - 2).  dir_out [n_words][Kpad] = the directory (last key of every block of 2^blk_log2 keys), par_out [n_words][8] = {directory
+ *    counts <= 2^17 - 2).  dir_out [n_words][Kpad] = the directory (last key of every block of 2^blk_log2 keys), par_out [n_words][8] = {directory
  *    entries, lo, hi, shift, P, key offset of the feature's blocks in tab_out, real keys, largest key}, starts_out [n_words][4096] bucket starts,
  *    tab_out = the key blocks.  info_out = {Kpad, blk_log2, tab words, 0}.  Outputs may be NULL to size them.  tests/test_sparse_r_host.py replays
  *    the kernel's search on them against a plain sorted-table count. */
