@@ -595,8 +595,8 @@ def main(argv=None, inproc_env=None):
         if sparse:
             # leaf depth of the model = node visits per tuple and tree: measured on a sample with the oracle below
             roofline["binding_resource"] = (
-                "sparse_r_*: two levels per 16-byte gather below the top image; at 4 gathers per tree and wave the kernel waits on its own VALU work at two "
-                "waves per SIMD (VALU issue ~55-61 %, vector-memory pipe ~57 % busy: profiles/r06_sparse_r32.md), not on HBM"
+                "sparse_r_*: two levels per 16-byte gather below the top image; at 4 gathers per tree and wave the kernel is latency-bound at two waves per "
+                "SIMD (LDS: 80 KiB per block of four waves; VALU issue and vector-memory pipe each ~55-60 % busy: profiles/r06_sparse_r32.md), not on HBM"
                 if info.variant_name.decode().startswith("sparse_r_") else
                 "vector-memory gathers of the deep phase: one 16-byte load per lane and visit (the VMEM address pipe takes about one lane per cycle and CU), not HBM")
             roofline["vmem_ceiling_gathers_per_s"] = info.num_cus * clock_hz

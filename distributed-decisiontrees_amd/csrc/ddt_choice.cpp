@@ -163,11 +163,7 @@ int auto_variant(const ddt_engine* e) {
       const int ix = find_variant("q16_d8_c8_u4_gl_s2_cm_x");
       if (ix >= 0 && variant_fits(variant(ix), e)) return ix;
     }
-    if (e->p.clusters_per_tuple > 1u && e->p.sum_mode != 1u && !s2_disabled()) {
-      const int i = find_variant("q16_d8_c8_u4_gl_s2_cm");
-      if (i >= 0 && variant_fits(variant(i), e)) return i;
-    }
-    static const char* qpref[] = {"q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4", "q16_d6_c16_u4_s2", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4_s2", "q16_d7_c8_u4", "q16_d5_c32_u4_s2", "q16_d5_c32_u4", "q16_d3_c128_u8"};
+    static const char* qpref[] = {"q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d6_c16_u4_s2", "q16_d6_c16_u4", "q16_d4_c64_u8", "q16_d7_c8_u4_s2", "q16_d7_c8_u4", "q16_d5_c32_u4_s2", "q16_d5_c32_u4", "q16_d3_c128_u8"};
     for (const char* name : qpref) {
       const int i = find_variant(name);
       if (i >= 0 && variant_fits(variant(i), e) && !((variant(i).opt & 2) && s2_disabled())) return i;

@@ -170,7 +170,7 @@ struct ddt_engine {
   std::vector<ddt::SparseForest> sps;  // one per class (single-output models: exactly one)
   int sparse_top_levels = -1;   // option "sparse_top_levels": K, -1 = the most the LDS takes
   int sparse_deep_order = 0;    // option "sparse_deep_order": 0 = level order (default: measured faster), 1 = depth-first per sub-tree
-  int sparse_dk = 1;            // option "sparse_dk": 1 = dense-level-K sparse kernels where they exist (default), 0 = 16-byte level K-1 records in LDS
+  int sparse_dk = 1;            // option "sparse_dk": 1 = dense-level-K sparse kernels where they exist (default), 0 = 16-byte level K-1 records in LDS (128- / 64-tuple tiles only)
   int sparse_dm = -1;           // option "sparse_dm": dense mid levels of 8-byte records below the top image (-1 = where the forest fills them, 0 = never, 1..3 = exactly that many)
   int sparse_peel_last = 1;     // option "sparse_peel_last": 1 = the last possible round of a sparse kernel's deep loop issues no gather (default), 0 = as before round 5 (A/B)
   int sparse_dp = -1;           // option "sparse_dp": dense pair records for the two levels below the top image (-1 = where the forest fills level K at least half and level K+1 a quarter, 0 = never, 1 = always)

@@ -1378,14 +1378,14 @@ hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t 
 static const Variant g_variants[] = {
     Variant{"generic", kKindGeneric, 0, kGenericThreads, 1, 1, 1, 0, 0, &launch_generic},
     // rank-quantised u16 path: 2 blocks x 1024 threads per CU
-    DDT_Q("q16_d8_c4_u4", 8, 4, 4),
+    // (`q16_d8_c4_u4`, nodes AND leaves of four trees per chunk in LDS, went at the end of round 6: unreachable -- `_gl` fits wherever it fitted)
     // _gl: the leaves stay in global memory (one 4-byte gather per tree on the otherwise idle vector-memory path), only the node
     // records are staged: the most conflict-laden LDS read of a tree (256 leaves behind 32 banks) is gone and a chunk holds 8
     // trees, so half the barriers.  1000 trees x 50 M tuples: 56.4 vs 59.4 ms; 8 trees in flight per lane (u8): 58.6
     DDT_QG("q16_d8_c8_u4_gl", 8, 8, 4),
     DDT_QGS("q16_d8_c8_u4_gl_s2", 8, 8, 4),
-    // _cm: cluster-major image order, one accumulator + a running total instead of the ring of C accumulators (sum modes 0 and 2)
-    DDT_QO("q16_d8_c8_u4_gl_s2_cm", 8, 8, 4, 7),
+    // _cm: cluster-major image order, one accumulator + a running total instead of the ring of C accumulators (sum modes 0 and 2) -- the forms that
+    // have it are `_p` and `_x` (`q16_d8_c8_u4_gl_s2_cm` itself, the unpinned walk, went at the end of round 6: `_x` replaced it everywhere)
     // _p: persistent blocks, the next rank tile prefetched into registers, several ensembles (classes) per pass (opt bit 3)
     Variant{"q16_d8_c8_u4_gl_s2_cm_p", kKindQ16, 8, kQTile, 1, 8, 4, 1, 15, &launch_q16p<8, 8, 4, true>},
     // _x: the plain launch with the pinned read order (four chains in flight per lane)

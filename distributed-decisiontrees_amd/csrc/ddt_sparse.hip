@@ -416,18 +416,16 @@ static hipError_t launch_sparse_v(const ScoreArgs& a, const Variant& v, hipStrea
   Variant { "sparse_qd_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 3, &launch_sparse_v<K, U, 1024, true, true> }
 #define DDT_SPG(K, U, T) /* global features: no tile in LDS, any tuple width */ \
   Variant { "sparse_gf_k" #K "_u" #U "_t" #T, kKindSparse, K, T, 1, U, U, 1, 4, &launch_sparse_v<K, U, T, false, false, true> }
-#define DDT_SPQ(K, U) /* rank-quantised: u16 feature tile of 1024 tuples = 16 waves per CU */ \
-  Variant { "sparse_q_k" #K "_u" #U "_t1024", kKindSparse, K, 1024, 1, U, U, 1, 1, &launch_sparse_v<K, U, 1024, true> }
 
 // `levels` = K (top levels staged in LDS), `chunk_trees` = trees walked in lock-step, `threads` = tuples per tile
 static const Variant g_sparse_variants[] = {
     // rank-quantised (thresholds -> ranks, features -> the u16 tiles of the q16 pre-pass): half the LDS per tuple, so a CU holds
     // 1024 walkers = 16 waves instead of 512 = 8 -- the deep phase is latency-bound, walkers in flight are what it needs
-    DDT_SPQ(6, 8), DDT_SPQ(7, 8), DDT_SPQ(8, 8), DDT_SPQ(9, 8),
+    // (the rank-quantised kernels without the dense level K, `sparse_q_k*`, went at the end of round 6: wherever one fitted, `sparse_qd_k*` of the same K fits)
     DDT_SPQD(6, 8), DDT_SPQD(7, 8), DDT_SPQD(8, 8), DDT_SPQD(9, 8), DDT_SPQD(10, 8),
     // measured and NOT instantiated (profiles/archive/r02_sparse_sweep_*.log): 16 trees in lock-step (u16: no gain over u8), half a
     // PU group per pass (u4: K + 1 at the same occupancy, but 4 loads in flight per lane: 159 vs 196 Mtuples/s)
-    DDT_SP(6, 8, 256), DDT_SP(7, 8, 256), DDT_SP(8, 8, 256), DDT_SP(9, 8, 256), DDT_SP(10, 8, 256),
+    // (`sparse_k*_t256` likewise: the dense-level-K kernels below take a third less LDS per tree at the same tile)
     // (512-tuple tiles -- one block of 8 waves per CU with ONE set of top images -- went in round 6: the automatic choice never took them: K = 8 in
     // two 256-tuple blocks 256.6 Mtuples/s, K = 9 in one block of 512 243.4, profiles/archive/r03_sparse_dense_level_k.json)
     // narrower tiles for wide tuples (the feature tile is 4 * W bytes per tuple)
@@ -439,7 +437,7 @@ static const Variant g_sparse_variants[] = {
     // (BASELINE config 4, one box, alternating: M = 0 / 1 / 2 / 3 -> 265-270 / 275 / 271-272 / 214-227 Mtuples/s, profiles/r05_pmc_cfg2_cfg4_cfg6.md:
     // one mid level pays a little, three lose a fifth -- the padding under the early leaves of level 10 turns finished walkers into live gathers)
     // (the 128-tuple forms went in round 6: no dense-level-K kernel of that tile exists for them to be the sibling of)
-    DDT_SPM(1, 8, 8, 256), DDT_SPM(2, 8, 8, 256), DDT_SPM(1, 7, 8, 256),
+    DDT_SPM(1, 8, 8, 256), DDT_SPM(1, 7, 8, 256),  // (two mid levels, `sparse_dm2_k8`: +1 % where one gives +2-4 %, never the automatic choice: removed)
     // dense pair records (round 5): two levels per gather below the top image, for forests that fill the levels K .. K+2
     // (K = 10 measured and NOT instantiated: the dense block would sit at level 12, 64 KiB per tree -- a 255-bin version of config 4 on 32 features:
     // `sparse_qp_k10` 272.8 vs `sparse_qd_k10` 287.1 Mtuples/s; K = 9 on 64 features: 267.4 vs 263.1)

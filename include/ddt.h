@@ -372,7 +372,8 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * default: sparse forests whose distinct thresholds per feature fit 16-bit ranks -- at most 32767, e.g. histogram-trained
  * models -- and whose tuples have at most 64..76 words run on the rank-quantised sparse kernels: u16 feature tile, 1024
  * tuples per block; 0 = always the fp32-tile kernels), "sparse_dk" (1 = default: the "dense level K" sparse kernels where they
- * exist -- all top levels as 8-byte records in LDS, the first deep level addressed by the heap index; 0 = never), "sparse_r32"
+ * exist -- all top levels as 8-byte records in LDS, the first deep level addressed by the heap index; 0 = never: only the kernels with 16-byte
+ * level K-1 records, which since round 6 exist for the 128- and 64-tuple tiles of wide tuples only -- an A/B and test switch), "sparse_r32"
  * (-1 = default: sparse forests of depth >= 13 with at least two trees per tuple word, tuples of at most 128 words and at most 131,068
  * distinct thresholds per feature run on the "sparse_r_*" kernels -- thresholds as
  * 17-bit ranks, a 32-bit rank tile written by a pre-pass per batch, 16-byte PAIR records {node, left child, right child, pointer}

@@ -133,7 +133,7 @@ def _mock_score(L, m, x, sum_mode, variant=None, shard=(0, 1)):
 
 
 @pytest.mark.parametrize("where", WHERE[:-1])
-@pytest.mark.parametrize("variant", [None, "q16_d8_c8_u4_gl_s2_cm", "q16_d8_c8_u4_gl_s2", "d8_t1024_r1_c4_u4_dma_f"])
+@pytest.mark.parametrize("variant", [None, "q16_d8_c8_u4_gl_s2_cm_x", "q16_d8_c8_u4_gl_s2", "d8_t1024_r1_c4_u4_dma_f"])
 def test_host_model_crafted(mock, where, variant):
     m, _ = _crafted(where)
     x = O.gen_tuples(0, 70, 32)

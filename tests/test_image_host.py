@@ -165,7 +165,7 @@ def test_eight_way_shard_of_the_headline_model():
     assert nfo["Tpad"] == 128                                          # whole chunks of 8: three EMPTY trees
 
 
-@pytest.mark.parametrize("name,T,D,F", [("q16_d8_c8_u4_gl_s2_cm", 37, 8, 32), ("q16_d8_c8_u4_gl_s2_cm", 300, 8, 32), ("q16_d8_c8_u4_gl_s2_cm", 1000, 8, 20), ("q16_d8_c8_u4_gl_s2", 37, 8, 32), ("q16_d8_c8_u4_gl", 37, 8, 32), ("q16_d8_c4_u4", 37, 8, 32), ("q16_d6_c16_u4", 100, 6, 28),
+@pytest.mark.parametrize("name,T,D,F", [("q16_d8_c8_u4_gl_s2_cm_x", 37, 8, 32), ("q16_d8_c8_u4_gl_s2_cm_x", 300, 8, 32), ("q16_d8_c8_u4_gl_s2_cm_x", 1000, 8, 20), ("q16_d8_c8_u4_gl_s2", 37, 8, 32), ("q16_d8_c8_u4_gl", 37, 8, 32), ("q16_d7_c8_u4", 37, 7, 32), ("q16_d6_c16_u4", 100, 6, 28),
                                         ("q16_d4_c64_u8", 9, 4, 16), ("q16_d3_c128_u8", 130, 3, 7)])
 def test_rank_quantised_images_with_missing_values(name, T, D, F):
     _check(T, D, F, name, 1)

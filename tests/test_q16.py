@@ -29,7 +29,7 @@ def _params(m, sum_mode=0):
 
 
 # cluster-major image + one accumulator / levels 0-1 from SGPRs / leaves gathered from global memory / leaves staged in LDS
-@pytest.mark.parametrize("kernel", ["q16_d8_c8_u4_gl_s2_cm", "q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl", "q16_d8_c4_u4"])
+@pytest.mark.parametrize("kernel", ["q16_d8_c8_u4_gl_s2_cm_x", "q16_d8_c8_u4_gl_s2", "q16_d8_c8_u4_gl"])
 @pytest.mark.parametrize("cmp_mode", [0, 1])
 def test_values_on_and_next_to_thresholds(cmp_mode, kernel):
     T, D, F, n = 200, 8, 32, 4096
@@ -68,10 +68,10 @@ def test_cluster_major_image_equals_the_ring(T, clusters):
     m = O.gen_model(T, D, F, dist=1, clusters=clusters)
     x = O.gen_tuples(1, n, F, dist=1)
     e = ddt.Engine(0)
-    e.set_option("variant", _variant("q16_d8_c8_u4_gl_s2_cm"))
+    e.set_option("variant", _variant("q16_d8_c8_u4_gl_s2_cm_x"))
     for sum_mode, ref_mode in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
         e.load_model(_params(m, sum_mode), m.wlines, m.flines)
-        assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm"
+        assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_x"
         assert np.array_equal(e.score(x).view(np.uint32), O.score(m, x, sum_mode=ref_mode).view(np.uint32)), (T, clusters, sum_mode)
     e.close()
 

@@ -33,7 +33,7 @@ def test_dense_mid_levels_equal_the_oracle(T, depth, F, full, pm, dist):
     seen = set()
     for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
         want = O.score_sparse_fast(sp, x, sum_mode=ref) if sum_mode == 0 else O.score_sparse(sp, x, sum_mode=ref)
-        for dm in (-1, 0, 1, 2):
+        for dm in (-1, 0, 1):
             e.set_option("sparse_dm", dm)
             e.load_model_sparse(ddt.make_sparse_params(T, depth, F, sum_mode=sum_mode), lines, first)
             name = e.info().variant_name.decode()
