@@ -47,7 +47,7 @@ def test_values_on_and_next_to_thresholds(cmp_mode, kernel):
     e.set_option("variant", _variant(kernel))
     want = O.score(m, x)
     for sum_mode in (0, 1, 2):
-        if kernel.endswith("_cm") and sum_mode == 1:  # the fp64 sum runs in stream order: a cluster-major image is refused for it
+        if "_cm" in kernel and sum_mode == 1:  # the fp64 sum runs in stream order: a cluster-major image is refused for it
             with pytest.raises(ddt.DDTError):
                 e.load_model(_params(m, sum_mode), m.wlines, m.flines)
             continue

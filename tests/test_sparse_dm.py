@@ -50,5 +50,5 @@ def test_dense_mid_levels_equal_the_oracle(T, depth, F, full, pm, dist):
                 got = e.score_device(d[:k])
                 torch.cuda.synchronize()
                 assert np.array_equal(_bits(got.cpu().numpy()), _bits(want[:k])), (name, k)
-    assert len(seen) >= (3 if F == 64 else 1)
+    assert len(seen) >= (2 if F == 64 else 1)
     e.close()
