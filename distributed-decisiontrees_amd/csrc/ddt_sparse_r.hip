@@ -431,8 +431,9 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
     u32x4 rr[U];
     float leafv[U];
   };
-  // one round of a set: the visits of its U records (two levels each) and the next gathers
-  auto round = [&](Set& S) {
+  // one round of a set: the visits of its U records (two levels each) and the next gathers (none in a set's last round: `last_tag`)
+  auto round = [&](Set& S, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
 #pragma unroll
     for (int h = 0; h < U; h += 4) {
       uint32_t fn[4], fc[4], cw[4];
@@ -447,15 +448,17 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
         r0[i] = sr_right<SLOW>(fn[i], S.rr[h + i].x);
         cw[i] = r0[i] ? S.rr[h + i].z : S.rr[h + i].y;
         leaf[i] = (S.rr[h + i].x & (r0[i] ? kSrRightLeaf : kSrLeftLeaf)) != 0u;
-        fc[i] = feat(cw[i]);  // (a leaf's value read as a node word: above)
+        if constexpr (!LAST) fc[i] = feat(cw[i]);  // (a leaf's value read as a node word: above)
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const bool r1 = sr_right<SLOW>(fc[i], cw[i]);
-        uint32_t nxt = S.rr[h + i].w + (r0[i] ? 32u : 0u) + (r1 ? 16u : 0u);
-        asm volatile("" : "+v"(nxt));  // (computed for every lane: hipcc otherwise sinks the child's compare into a divergent branch on `leaf`)
         S.leafv[h + i] = leaf[i] ? __uint_as_float(cw[i]) : S.leafv[h + i];
-        S.rr[h + i] = __builtin_amdgcn_raw_buffer_load_b128(rs, leaf[i] ? 48u : nxt, 0, 0);
+        if constexpr (!LAST) {
+          const bool r1 = sr_right<SLOW>(fc[i], cw[i]);
+          uint32_t nxt = S.rr[h + i].w + (r0[i] ? 32u : 0u) + (r1 ? 16u : 0u);
+          asm volatile("" : "+v"(nxt));  // (computed for every lane: hipcc otherwise sinks the child's compare into a divergent branch on `leaf`)
+          S.rr[h + i] = __builtin_amdgcn_raw_buffer_load_b128(rs, leaf[i] ? 48u : nxt, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -470,7 +473,7 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
       fold_leaves<8, 1, 0>(lf, 0, C, ra, unused, a.sum_mode == 2);
     }
   };
-  auto first_gathers = [&](Set& S, const uint32_t (&cb)[U]) {  // ... exactly U gathers behind the DMA of the images after next: what the counted wait counts
+  auto first_gathers = [&](Set& S, const uint32_t (&cb)[U]) {  // the dense level-K records of a group (issued in front of the DMA of the images after next)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       S.rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m4[u] << 2), 0, 0);
@@ -486,27 +489,46 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
     lv += c;
     __builtin_amdgcn_sched_barrier(0);
   };
-  // group g's step: cur = its walkers (first gathers in flight, the youngest), prev = group g - 1's, A rounds in (at g = 0: idle walkers)
+  // The barrier that publishes the images of group g + 1 stands in front of that group's first top levels, not at the step's top: the rounds before it
+  // read the rank tile only, so the DMA's flight (issued at the end of the step before) is covered by them.  Its wait is counted: the DMA is older than
+  // the gathers of the rounds in between -- NWAIT, a constant of (NB, ODD); tools/check_dma_waits.py proves it.  (The first gathers of a group go out
+  // IN FRONT of that DMA: operations return in order, and behind it they would come back only once its 16 KiB have landed.)
+  constexpr uint32_t NWAIT = B >= 1u ? (uint32_t)U + (A + 1u < (uint32_t)(2 * NB + ODD) ? (uint32_t)U : 0u) : 0u;
+  static_assert(NWAIT == 0u || NWAIT == 8u || NWAIT == 16u, "vmcnt immediate");
+  auto publish_next = [&]() {
+    if constexpr (NWAIT == 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (NWAIT == 8u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();
+    top_reset();
+  };
+  constexpr uint32_t RR = (uint32_t)(2 * NB + ODD);
+  // group g's step: cur = its walkers (first gathers in flight, the youngest), prev = group g - 1's, A rounds in (at g = 0: idle walkers).
   // (`next` = there is a group g + 1, compile-time: with a runtime flag the paths with and without its first gathers meet at the loop's back edge, and
   // the compiler's wait counts for the other set's records become those of the path without -- 7 instead of 15)
   auto step = [&](Set& cur, Set& prev, const uint32_t g, auto next_tag) {
     constexpr bool next = decltype(next_tag)::value;
-    if constexpr (next) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the DMA of the next images is older than the U gathers issued behind it
-      __syncthreads();                                   // ... and has landed for every wave
-      top_reset();
-    }
     uint32_t lv = 0;  // levels of group g + 1 walked so far
-#pragma unroll
-    for (uint32_t i = 0; i < B; ++i) {
-      round(prev);  // its records are the older ones
-      round(cur);
-      if constexpr (next) next_top(lv);
-    }
+    auto iter = [&](auto i_tag) {  // iteration i: round A + 1 + i of the older set, round 1 + i of this group's
+      constexpr uint32_t i = decltype(i_tag)::value;
+      round(prev, std::bool_constant<A + 1u + i == RR>{});
+      round(cur, std::bool_constant<1u + i == RR>{});
+      if constexpr (next) {
+        if constexpr (i == 0u) publish_next();
+        next_top(lv);
+      }
+    };
+    if constexpr (B >= 1u) iter(std::integral_constant<uint32_t, 0>{});
+    if constexpr (B >= 2u) iter(std::integral_constant<uint32_t, 1>{});
+    if constexpr (B >= 3u) iter(std::integral_constant<uint32_t, 2>{});
+    static_assert(B <= 3u, "up to six rounds");
     if (g > 0u) fold(prev);  // group g - 1 is through its R rounds: folded in stream order
     if constexpr (A > B) {
-      round(cur);
-      if constexpr (next) next_top(lv);
+      round(cur, std::bool_constant<A == RR>{});
+      if constexpr (next) {
+        if constexpr (B == 0u) publish_next();
+        next_top(lv);
+      }
     }
     if constexpr (next) {
 #pragma unroll
@@ -515,10 +537,16 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
       uint32_t cb[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));
-      __syncthreads();  // every wave is through with the images of group g + 1
-      if (g + 2u < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 2u, 0, tid);
       first_gathers(prev, cb);  // the set of group g - 1 is free: it becomes group g + 1's
+      __syncthreads();          // every wave is through with the images of group g + 1
+      if (g + 2u < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 2u, 0, tid);
     }
+  };
+  auto drain = [&](Set& S) {  // the last group's rounds A + 1 .. R
+    if constexpr (B >= 1u) round(S, std::bool_constant<A + 1u == RR>{});
+    if constexpr (B >= 2u) round(S, std::bool_constant<A + 2u == RR>{});
+    if constexpr (B >= 3u) round(S, std::bool_constant<A + 3u == RR>{});
+    fold(S);
   };
   Set S0, S1;
   // ---- prologue: group 0's top walk, the plain way ----
@@ -530,14 +558,14 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
     uint32_t cb[U];  // (read before the barrier: behind it the DMA of the next images may land)
 #pragma unroll
     for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));
-    __syncthreads();
-    if (1u < n_steps) dma_chunk<THREADS, STEPB>(a.img, 1, 0, tid);
 #pragma unroll
     for (int u = 0; u < U; ++u) {  // the other set starts as eight finished walkers
       S1.rr[u] = u32x4{0u, 0u, 0u, 0u};
       S1.leafv[u] = 0.f;
     }
     first_gathers(S0, cb);
+    __syncthreads();
+    if (1u < n_steps) dma_chunk<THREADS, STEPB>(a.img, 1, 0, tid);
   }
   uint32_t g = 0;
   for (; g + 2u < n_steps; g += 2u) {
@@ -547,14 +575,10 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
   if (g + 1u < n_steps) {  // two groups left
     step(S0, S1, g, std::true_type{});
     step(S1, S0, g + 1u, std::false_type{});
-#pragma unroll
-    for (uint32_t i = 0; i < B; ++i) round(S1);
-    fold(S1);
+    drain(S1);
   } else {  // one
     step(S0, S1, g, std::false_type{});
-#pragma unroll
-    for (uint32_t i = 0; i < B; ++i) round(S0);
-    fold(S0);
+    drain(S0);
   }
 }
 

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$tag
 rm -rf "$OUT"; mkdir -p "$OUT"
 ( timeout 900 python -m pytest tests/test_sparse_r.py tests/test_zz_late_gpu.py -m gpu -x -q ) > $OUT/tests.log 2>&1; grep "passed\|failed" $OUT/tests.log
-for lag in 1 0; do ( DDT_SPARSE_R_LAG=$lag timeout 600 python bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --no-streamed ) 2>/dev/null | tail -1 | python -c "
+for lag in 1 0 1; do ( DDT_SPARSE_R_LAG=$lag timeout 600 python bench.py --config 4 --steps 5 --warmup 2 --no-cpu-baseline --no-streamed ) 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
 print('cfg4 lag=$lag', d['value'], d['ms_per_step'], r['kernel'], r['kernel_ms'], r['prepass_ms'])" | tee -a $OUT/cfg4.log; done
