@@ -564,9 +564,11 @@ static int sparse_pack_host_r(ddt_engine* e, const Variant& v, SparseForest& sp,
   };
   try {
     top.assign((size_t)groups * 8u * top_words, 0u);
-    // records 0 .. 3: ZERO -- where a finished walker goes and stays (ddt_sparse_r.hip: {0, 0, 0, 0} has no leaf flag and its next block is byte 0);
+    // records 0 .. 3: {0, 0, 0, 0xFFFFFFC0} -- where a finished walker lands when it comes back from beyond the buffer's range with a record of zeros
+    // (ddt_sparse_r.hip: no leaf flag, next block at byte 0), and which sends it out of range again (0xFFFFFFC0 + 32 r0 + 16 r1 <= 0xFFFFFFF0: no wrap);
     // records 4 .. 4 + 2^K - 1: LEAF(+0) -- the dense block every EMPTY slot shares (DTPU.sv:544,760: an EMPTY slot adds exactly +0)
     deep.assign(16u + ((size_t)4u << K), 0u);
+    for (uint32_t q = 0; q < 4u; ++q) deep[4u * q + 3u] = 0xFFFFFFC0u;
     for (uint32_t q = 0; q < (1u << K); ++q) deep[16u + 4u * q] = kSrLeafRec;
     std::vector<Cursor> cur, nxt;
     std::vector<Todo> todo;
@@ -605,7 +607,7 @@ static int sparse_pack_host_r(ddt_engine* e, const Variant& v, SparseForest& sp,
       }
       // ---- the dense block of level K: a pair record per internal node, a LEAF record per (early) leaf ----
       const size_t dense0 = deep.size() / 4u;
-      if ((dense0 + ((size_t)1u << K)) * 16u >= 0xFFFFFFF0ull) return fail(e, DDT_EUNSUPPORTED, "more than 4 GiB of deep records");
+      if ((dense0 + ((size_t)1u << K)) * 16u >= 0xFFFFFFC0ull) return fail(e, DDT_EUNSUPPORTED, "more than 4 GiB of deep records");
       deep.resize(deep.size() + ((size_t)4u << K), 0u);
       t[0] = (uint32_t)(dense0 * 16u) - (16u << K);
       todo.clear();
@@ -628,7 +630,7 @@ static int sparse_pack_host_r(ddt_engine* e, const Variant& v, SparseForest& sp,
         const uint32_t inner = (c0.leaf ? 0u : 1u) + (c1.leaf ? 0u : 1u);
         if (inner) {
           const size_t block = deep.size() / 4u;
-          if ((block + 2u * inner) * 16u >= 0xFFFFFFF0ull) return fail(e, DDT_EUNSUPPORTED, "more than 4 GiB of deep records");
+          if ((block + 2u * inner) * 16u >= 0xFFFFFFC0ull) return fail(e, DDT_EUNSUPPORTED, "more than 4 GiB of deep records");
           deep.resize(deep.size() + 8u * inner, 0u);
           ptr = (uint32_t)(block * 16u) - (c0.leaf ? 32u : 0u);  // slot of the grandchild on side r1 of the child on side r0: ptr + 32 r0 + 16 r1
           size_t slot = block;

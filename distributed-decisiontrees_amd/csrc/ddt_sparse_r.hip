@@ -385,8 +385,9 @@ __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAu
 // alone in front of their gathers' latency.  Two record sets per lane that swap roles from group to group (no register moves: a set's last gathers
 // are in flight when the group changes); group g - 1 is folded inside group g's step, before group g: the order of the sums is untouched.
 // Every iteration issues the same gathers in the same order (older set first, 2 x U, whatever is alive): the compiler's wait counts are exact on
-// every path.  That needs walkers without an "active" mask: bytes 0..63 of the deep array are ZERO records (ddt_sparse_host.cpp) -- a finished walker
-// is sent to byte 48, finds {0, 0, 0, 0} = "feature 0 against rank 0, no leaf flag, next block at 0" and stays inside those 64 bytes by itself.
+// every path.  That needs walkers without an "active" mask: a finished walker is sent out of the buffer's range, gets {0, 0, 0, 0} = "feature 0 against
+// rank 0, no leaf flag, next block at 0", lands in bytes 0..63 of the deep array -- records {0, 0, 0, 0xFFFFFFC0} (ddt_sparse_host.cpp) -- and from there
+// goes out of range again: every second gather of a finished walker touches no cache, none needs a mask.
 template <int K, int U, int THREADS, bool SLOW, bool WP, int NB, int ODD>
 __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
   static_assert(U == 8, "the counted wait below is vmcnt(8)");
@@ -457,7 +458,7 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
           const bool r1 = sr_right<SLOW>(fc[i], cw[i]);
           uint32_t nxt = S.rr[h + i].w + (r0[i] ? 32u : 0u) + (r1 ? 16u : 0u);
           asm volatile("" : "+v"(nxt));  // (computed for every lane: hipcc otherwise sinks the child's compare into a divergent branch on `leaf`)
-          S.rr[h + i] = __builtin_amdgcn_raw_buffer_load_b128(rs, leaf[i] ? 48u : nxt, 0, 0);
+          S.rr[h + i] = __builtin_amdgcn_raw_buffer_load_b128(rs, leaf[i] ? 0xFFFFFFF0u : nxt, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
