@@ -168,6 +168,41 @@ def collect_rank_proxies(device_index, tuples, headline_ms, shape, model, check_
     return out
 
 
+def collect_small_batches(eng, tuples, out, ref_bits, rows_list=(1024, 16_384, 131_072), reps=15):
+    """`other_modes.small_batches` of the default command's line: what ONE call of the headline model costs on a batch of a few tiles -- the
+    regime a serving caller sees; `value` is measured at 100 M tuples per call.  Per batch size: median microseconds of a call (launch + stream
+    sync, device-resident tuples) with the launch cut into slices of the image (csrc/ddt_engine.cpp cluster_split_of: one block per (tile, PU
+    group run / cluster), the adds in the reference's order behind it) and uncut (one block per tile walks all the trees), and the cut call's
+    scores bit for bit against the timed region's own (`ref_bits`: the headline's output for the same rows, itself checked against the oracle)."""
+    import numpy as np
+    import torch
+
+    res = {}
+    for rows in rows_list:
+        d, o = tuples[:rows], out[:rows]
+        leg = {}
+        for name, opt in (("cut", -1), ("uncut", 0)):
+            eng.set_option("q16_cluster_split", opt)
+            for _ in range(3):
+                eng.score_device(d, out=o)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                eng.score_device(d, out=o)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e6)
+            leg[f"us_{name}"] = round(sorted(ts)[len(ts) // 2], 1)
+            if name == "cut":
+                leg["bit_exact_vs_timed_result"] = bool(np.array_equal(o.cpu().numpy().view(np.uint32), ref_bits[:rows]))
+        leg["x"] = round(leg["us_uncut"] / leg["us_cut"], 2) if leg["us_cut"] > 0 else None
+        res[str(rows)] = leg
+    eng.set_option("q16_cluster_split", -1)
+    res["note"] = ("median wall microseconds of one ddt_score_device call + stream sync from Python (host overhead ~20-30 us included); the cut launch is the "
+                   "library's automatic choice for batches of up to 384 tiles; never `value`")
+    return res
+
+
 def run_side_config(cfg, device_index, check_rows=262_144, rows=None, deadline=None):
     """One SHORT run of another BASELINE config on the same GPU, behind the default command's timed region (`other_configs` on the line): the
     config's model and full row count, a few steps, HIP-event kernel times from the library, and a prefix of the result against the oracle.
@@ -794,7 +829,7 @@ def main(argv=None, inproc_env=None):
             sum2 = {"error": repr(ex)}
 
     # ---- one rank's workload of the 8-GPU jobs on this one GPU, behind the timed region of the DEFAULT command (collect_rank_proxies) ----------
-    proxies = None
+    proxies = small = None
 
     # ---- the other BASELINE configs, each as a short run behind the timed region of the DEFAULT command (N = 1, config 3, no overrides): the
     # driver's line then carries a value, the dominant kernel's roofline fraction and an oracle check for every config, not for the headline alone
@@ -806,6 +841,11 @@ def main(argv=None, inproc_env=None):
             proxies = collect_rank_proxies(local, tuples, ms_per_step, (T, D, F), (w, f))
         except Exception as ex:
             proxies = {"error": repr(ex)}
+        try:   # (before anything else writes `out`: its first rows are the timed region's result)
+            eng.set_option("kernel_timing", 0)
+            small = collect_small_batches(eng, tuples, torch.empty(131_072, dtype=torch.float32, device=tuples.device), out[:131_072].cpu().numpy().view(np.uint32))
+        except Exception as ex:
+            small = {"error": repr(ex)}
     if world == 1 and rank == 0 and not multi and comm is None and default_cmd and not args.no_other_configs and not args.no_cpu_baseline:
         # (config 1 alone allocates 13.6 GB next to the headline's 12.8 GB of tuples: the headline's buffers go first)
         # ... on a device that is short of memory.  On MI355X (288 GB) they stay: a side leg's buffers then come out of fresh memory either way, and
@@ -863,6 +903,8 @@ def main(argv=None, inproc_env=None):
             line["other_modes"] = {"sum_mode2": sum2}
         if proxies:
             line.setdefault("other_modes", {})["per_rank_proxies"] = proxies
+        if small:
+            line.setdefault("other_modes", {})["small_batches"] = small
         if other_configs:
             line["other_configs"] = other_configs
         line["config"]["fallback_kernel"] = bool(info.fallback_kernel)

@@ -129,6 +129,9 @@ void free_q16_workspace(ddt_engine* e) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
+    if (e->q_split[k]) (void)hipFree(e->q_split[k]);
+    e->q_split[k] = nullptr;
+    e->q_split_floats[k] = 0;
     e->q_rows[k] = 0;
     e->q_xT_valid[k] = false;
   }
@@ -263,6 +266,43 @@ int timing_end(ddt_engine* e, hipStream_t s) {
   return DDT_OK;
 }
 
+// Small batches on the plain cluster-major depth-8 kernel: into how many slices to cut the launch (split == 0: one block per tile as always).
+// One block walks the whole ensemble for its 1024 tuples -- 0.35 ms per call at 1000 trees, whatever the batch, while a batch of a few tiles
+// leaves most CUs idle.  The walks are independent; the ADDS have the reference's order (per cluster acc <- x_g + acc over its PU groups,
+// FPAggregator.v:79-131; then total <- acc_c + total over the clusters, Core.sv:486-541) and are left to launch_cm_combine:
+//   batches whose (tile, cluster) blocks fill the chip: a slice = a cluster, whose accumulator the block carries itself (one partial per cluster);
+//   smaller ones: a slice = `len` consecutive PU groups, one partial per group -- down to one block per (tile, group) for a single tile.
+struct SplitPlan {
+  uint32_t split = 0, len = 0;  // slices; chunks per slice (0: the slices are the clusters)
+  uint32_t partials = 0;        // partial sums per tuple
+};
+static SplitPlan cluster_split_of(const ddt_engine* e, const Variant& v, const Ensemble& m, size_t n, bool reuse_prepass, bool all_classes) {
+  SplitPlan sp;
+  if (!v.has_split() || e->q16_cluster_split == 0 || all_classes || reuse_prepass || e->num_classes > 1 || !m.parts.empty() || n == 0) return sp;
+  if (e->p.sum_mode == 1u) return sp;  // (the fp64 sum runs in stream order: never on a cluster-major kernel anyway)
+  const uint32_t C = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, real = (m.trees() + 7u) / 8u;
+  if (real < 2u || (C & (C - 1u)) != 0u) return sp;
+  const uint64_t tiles = (n + 1023) / 1024;
+  if (e->q16_cluster_split < 0 && tiles > e->q16_split_max_tiles) return sp;
+  const uint32_t by_cluster = C < real ? C : real;
+  const uint32_t slots = 2u * (e->prop.multiProcessorCount > 0 ? (uint32_t)e->prop.multiProcessorCount : 256u);  // resident blocks (two per CU)
+  if (e->q16_split_groups != 0 && tiles * by_cluster < slots) {  // the clusters alone leave CUs idle: runs of groups, about one round of blocks
+    uint32_t want = (uint32_t)(slots / tiles);
+    if (e->q16_split_groups > 0) want = (uint32_t)e->q16_split_groups;  // (forced slice count: tests, A/B)
+    if (want > real) want = real;
+    if (want > by_cluster || e->q16_split_groups > 0) {
+      sp.len = (real + want - 1u) / want;
+      sp.split = (real + sp.len - 1u) / sp.len;
+      sp.partials = real;
+      if (sp.split >= 2u) return sp;
+      sp = SplitPlan();
+    }
+  }
+  if (by_cluster < 2u) return sp;
+  sp.split = sp.partials = by_cluster;
+  return sp;
+}
+
 // all_classes (only with e->mc_seg_chunks != 0, a "_p" kernel): ONE launch walks every class -- d_scores = [K][n] per-class sums (may
 // be NULL), labels (may be NULL) = their argmax
 int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t n, float* d_scores, hipStream_t s,
@@ -366,6 +406,27 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     }
     e->q_xT_valid[e->q_slot] = xT_valid && r == hipSuccess;
     if (r == hipSuccess) e->st.kernel_launches--;  // (counted once more below)
+  } else if (const SplitPlan sp = cluster_split_of(e, v, m, n, reuse_prepass, all_classes); sp.split) {
+    // a small batch: one block per (tile, slice of the image) instead of one per tile, then the adds in the reference's order
+    const uint64_t need = (uint64_t)sp.partials * qa.n_pad;
+    const int k = e->q_slot;
+    if (e->q_split_floats[k] < need) {
+      HIP_TRY(e, hipStreamSynchronize(s));  // (an earlier call on this stream may still read the old buffer)
+      if (e->q_split[k]) (void)hipFree(e->q_split[k]);
+      e->q_split[k] = nullptr;
+      e->q_split_floats[k] = 0;
+      HIP_TRY(e, hipMalloc(&e->q_split[k], need * sizeof(float)));
+      e->q_split_floats[k] = need;
+    }
+    qa.split = sp.split;
+    qa.split_len = sp.len;
+    a.out = reinterpret_cast<float*>(e->q_split[k]);
+    r = v.launch(a, v, s);
+    if (r == hipSuccess) {
+      r = launch_cm_combine(a.out, (size_t)qa.n_pad, n, qa.real_groups, e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, sp.len != 0u, d_scores,
+                            e->p.sum_mode == 2, s);
+      e->st.kernel_launches++;
+    }
   } else {
     r = v.launch(a, v, s);
   }
@@ -1085,6 +1146,21 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   if (!strcmp(key, "q16_prepass_nt")) {  // A/B: bit 0 = nontemporal stores of the rank tiles, bit 1 = nontemporal tuple loads (effective at the next call)
     if (value < 0 || value > 3) return fail(e, DDT_EINVAL, "q16_prepass_nt must be 0..3");
     e->q16_prepass_nt = (int)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "q16_cluster_split")) {  // 1 / 0: always / never cut a launch of the plain depth-8 cluster-major kernel at the clusters; -1: automatic (small batches)
+    if (value < -1 || value > 1) return fail(e, DDT_EINVAL, "q16_cluster_split must be -1, 0 or 1");
+    e->q16_cluster_split = (int)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "q16_split_groups")) {  // -1: automatic (runs of PU groups where the clusters alone leave CUs idle); 0: clusters only; > 0: that many slices (A/B, tests)
+    if (value < -1 || value > 65535) return fail(e, DDT_EINVAL, "q16_split_groups out of range");
+    e->q16_split_groups = (int)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "q16_split_max_tiles")) {  // automatic cluster split: batches of up to this many tiles of 1024 tuples
+    if (value < 0 || value > 0x7FFFFFFF) return fail(e, DDT_EINVAL, "q16_split_max_tiles out of range");
+    e->q16_split_max_tiles = (uint32_t)value;
     return DDT_OK;
   }
   if (!strcmp(key, "q16_persistent")) {  // 1 / 0: prefer / never pick the persistent "_p" rank-quantised kernel; -1: automatic.  Effective at the next model load

@@ -132,6 +132,8 @@ struct ddt_engine {
   void* q_q[ddt::kQSlots] = {};
   void* q_flags[ddt::kQSlots] = {};
   void* q_state[ddt::kQSlots] = {};    // ensembles scored in parts: [2][rows] fp32 accumulator + running total between the parts' launches
+  void* q_split[ddt::kQSlots] = {};    // small batches cut at the clusters (Q16Aux::split): [clusters][rows] fp32 partial sums
+  uint64_t q_split_floats[ddt::kQSlots] = {};
   uint64_t q_rows[ddt::kQSlots] = {};  // capacity in rows (multiple of 1024)
   bool q_xT_valid[ddt::kQSlots] = {};  // q_xT holds the transposed tuples of the batch being scored (set by a part's transpose, cleared by the next batch)
   int q_slot = 0;
@@ -140,6 +142,9 @@ struct ddt_engine {
   int q16_fused_prepass = 1;  // option "q16_fused_prepass": 0 forces the transpose + rank kernels (A/B, tests)
   int q16_prepass_nt = 0;     // option "q16_prepass_nt": bit 0 = nontemporal stores of the rank tiles, bit 1 = nontemporal tuple loads (A/B)
   int q16_persistent = -1;    // option "q16_persistent": 1 / 0 = prefer / never pick the persistent "_p" kernel, -1 = automatic
+  int q16_cluster_split = -1; // option "q16_cluster_split": 1 / 0 = always / never cut a launch at the clusters, -1 = automatic (batches of up to q16_split_max_tiles tiles)
+  uint32_t q16_split_max_tiles = 384;  // option "q16_split_max_tiles" (measured at 1000 trees: 256 tiles 344 vs 407 us, 512 tiles 632 vs 624; profiles/r06_small_batches.md)
+  int q16_split_groups = -1;  // option "q16_split_groups": slices finer than the clusters (a partial sum per PU group); -1 automatic, 0 never, > 0 that many slices
   bool collective_job = false;  // set by ddt_comm_create* / ddt_group_create* with more than one rank: collectives share the CUs with the scoring
   // "_p" kernels, multi-class models whose classes hold equally many trees: the classes' images back to back (fast / slow), so that
   // ONE launch walks every class (Q16Aux::n_segs); mc_seg_chunks = chunks per class, 0 = not built (one launch per class)

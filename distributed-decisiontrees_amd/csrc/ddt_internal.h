@@ -114,6 +114,11 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   const float* state_in = nullptr;   // [2][n_pad]: accumulator of the cluster in progress, running total over the finished clusters
   float* state_out = nullptr;
   uint32_t group0 = 0;               // PU groups (cluster-major order) in front of this launch's image
+  // small batches on a "_cm_x" kernel (Variant::has_split): split > 1 = the launch is cut into `split` slices of the image -- grid (tiles, split),
+  // ScoreArgs::out = a workspace of partial sums [positions][n_pad], added in the reference's order by launch_cm_combine behind the launch:
+  //   split_len == 0: a slice = a cluster (split = min(clusters, PU groups that hold a real tree)), one partial per cluster (its accumulator)
+  //   split_len  > 0: a slice = split_len consecutive chunks (split = ceil(real_groups / split_len)), one partial per PU group (its reduce tree)
+  uint32_t split = 0, split_len = 0;
 };
 constexpr uint32_t kQ16TileCounterWords = 2;  // behind the kQ16GroupedCounters 8-byte counters
 
@@ -251,6 +256,9 @@ struct Variant {
   // opt bit 6 ("q16w_*" / "q16dw_*"): tuples of up to 64 words -- a record's row-offset field holds HALF the byte offset (the kernel shifts it
   // back), the block takes up to 144 KiB of LDS (one block of 16 waves per CU)
   bool wide() const { return kind == kKindQ16 && (opt & 64) != 0; }
+  // the plain cluster-major depth-8 kernel ("q16_d8_c8_u4_gl_s2_cm_x") has a second instantiation whose grid is cut at the image's clusters
+  // (Q16Aux::split): what launch_score gives a batch of a few tiles
+  bool has_split() const { return kind == kKindQ16 && levels == 8 && chunk_trees == 8 && (opt & (4 | 8 | 32 | 64)) == 4; }
   uint32_t max_tuple_words_q16() const { return wide() ? 64u : 32u; }
   uint32_t deep_stages() const { return ((uint32_t)levels - (uint32_t)top + 1u) / 2u; }
   uint32_t deep_stage_level(uint32_t g) const { return g + 1u < deep_stages() ? (uint32_t)top + 2u * g : (uint32_t)levels - 1u; }
@@ -328,7 +336,10 @@ int num_sparse_r_variants();               // ddt_sparse_r.hip: and these last
 const Variant& sparse_r_variant(int i);
 hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint64_t n_pad, uint32_t* xT, hipStream_t s);  // ddt_prepass.hip
 
-hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact /* sum_mode 2 */, hipStream_t s);
+hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, float* out,
+                             bool exact /* sum_mode 2 */, hipStream_t s);
+hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact /* sum_mode 2 */, hipStream_t s,
+                            size_t pitch = 0 /* elements between the partial vectors; 0 = n */);
 hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s);
 hipError_t launch_argmax_strided(const float* scores, uint32_t K, size_t pitch, size_t n, int32_t* labels, hipStream_t s);
 hipError_t launch_synth_tuples(uint32_t* out, uint64_t row0, size_t n, uint32_t F, int dist, uint32_t missing_bits,

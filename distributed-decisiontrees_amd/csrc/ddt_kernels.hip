@@ -621,6 +621,16 @@ template <int D, int CT, int U, int OPT = 0>
 __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a, const Q16Aux x) {  // 8 waves per SIMD = two blocks per CU
   constexpr int THREADS = kQTile;
   constexpr bool GL = (OPT & 1) != 0, S2 = (OPT & 2) != 0, HOTDISP = S2, CM = (OPT & 4) != 0, PIN = (OPT & 16) != 0, WIDE = (OPT & 64) != 0;
+  // SPLIT (round 6, small batches): blockIdx.y = a SLICE of the cluster-major image.  A batch of a few tiles leaves most of the chip idle
+  // while one block walks the whole ensemble (0.35 ms per call at 1000 trees).  The walks are independent; only the adds have an order
+  // (FPAggregator.v:79-131: per cluster acc <- x_g + acc over its PU groups g; Core.sv:486-541: total <- acc_c + total over the clusters),
+  // so the adds are what is left to a second kernel (launch_cm_combine) that runs them in exactly that order:
+  //   Q16Aux::split_len == 0  a slice = a CLUSTER's run of PU groups (= chunks); the block carries the cluster's accumulator as the uncut
+  //                           launch would and leaves acc_c in out[c][row]: one partial sum per cluster
+  //   Q16Aux::split_len  > 0  a slice = split_len consecutive chunks; the block leaves every group's x_g (its 8-leaf reduce tree, + 0) in
+  //                           out[position of the group in the image][row]: up to one block per (tile, PU group) for batches of a tile or two
+  constexpr bool SPLIT = (OPT & 128) != 0;
+  static_assert(!SPLIT || (CM && CT == 8), "the cluster split cuts the cluster-major image at PU groups = chunks");
   static_assert(!S2 || U == 4, "_s2: 4 trees in flight");
   static_assert(!PIN || S2, "the pinned read order exists for the _s2 walk");
   constexpr int TREE_BYTES = GL ? (4 << D) : (8 << D);  // bytes of a tree in LDS (GL: node records only)
@@ -632,12 +642,29 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   static_assert(FEAT_OFF % ROW == 0, "row|lane OR trick");
   const int tid = threadIdx.x;
   const uint64_t tile = blockIdx.x, tile0 = tile * kQTile;
-  const uint32_t W = a.tuple_words, n_chunks = a.n_chunks;
+  const uint32_t W = a.tuple_words;
+  uint32_t n_chunks = a.n_chunks;
   constexpr int GSKIP = GCHUNK_UNITS - CHUNK_BYTES / 16;  // dma_chunk strides by the LDS chunk: skip the leaves of the chunks before
   // block-uniform: the tile holds a missing value.  readfirstlane: the flag arrives through a vector load, and without it hipcc
   // treats `img` (and every leaf-gather address derived from it) as lane-varying: 64-bit VALU address arithmetic per gather
   const bool slow = __builtin_amdgcn_readfirstlane((int)x.tile_flags[tile]) != 0;
   const uint4* img = slow ? x.img_slow : a.img;
+  uint32_t sp_pos = 0;  // SPLIT: which partial sum this block writes next
+  const uint64_t sp_row = tile0 + (uint64_t)tid;
+  if constexpr (SPLIT) {
+    uint32_t first = 0;
+    if (x.split_len) {  // split_len consecutive chunks, a partial sum per PU group
+      first = blockIdx.y * x.split_len;
+      n_chunks = x.real_groups - first < x.split_len ? x.real_groups - first : x.split_len;  // >= 1: the host launches ceil(real / split_len) slices
+      sp_pos = first;
+    } else {            // cluster blockIdx.y's run of PU groups (cluster j holds (real + C - 1 - j) / C of them: ddt_image.cpp cm_position)
+      const uint32_t lg = (uint32_t)__builtin_ctz(a.clusters | 0x100u);
+      for (uint32_t j = 0; j < blockIdx.y; ++j) first += (x.real_groups + a.clusters - 1u - j) >> lg;
+      n_chunks = (x.real_groups + a.clusters - 1u - blockIdx.y) >> lg;  // >= 1: the host launches min(C, real groups) clusters
+      sp_pos = blockIdx.y;
+    }
+    img += (size_t)first * GCHUNK_UNITS;
+  }
 
   dma_chunk<THREADS, CHUNK_BYTES>(img, 0, 0, tid);
   {  // the whole feature tile is one contiguous block of W*2048 bytes: DMA it in
@@ -658,8 +685,8 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   // which is all the reference's accumulate needs: FPAggregator.v:79-131 keeps one accumulator per cluster; Core.sv:486-541 adds
   // the clusters in order afterwards).  The kernel then carries ONE accumulator and a running total instead of a ring of C that is
   // rotated after every group (8 v_mov per PU group at C = 8): at a cluster's last group, total <- acc + total, acc <- 0.
-  const uint32_t Cc = a.clusters, C = CM ? 1u : Cc, lane2 = (((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1);  // see rank_kernel
-  const uint32_t cm_lg = (uint32_t)__builtin_ctz(Cc | 0x100u), cm_real = x.real_groups;
+  const uint32_t Cc = SPLIT ? 1u : a.clusters, C = CM ? 1u : Cc, lane2 = (((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1);  // see rank_kernel
+  const uint32_t cm_lg = (uint32_t)__builtin_ctz(Cc | 0x100u), cm_real = SPLIT ? (x.split_len ? 1u : n_chunks) : x.real_groups;  // SPLIT: the groups up to the first store
   uint32_t cm_groups = 0, cm_cluster = 0, cm_bound = (cm_real + Cc - 1u) >> cm_lg;  // wave-uniform: groups done, cluster, its end
   float cm_total = 0.f;
   if constexpr (CM) {  // a later part of an ensemble scored in parts (Q16Aux): take up the sum where the launch before left it
@@ -728,10 +755,17 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
       if constexpr (CM) {                                                                              \
         if (U == 8 || (((PH) + sg) & 1) == 1) { /* a PU group is complete */                           \
           if (++cm_groups == cm_bound) { /* ... and it was its cluster's last */                       \
-            cm_total = exact_l ? radd_exact(ra.a[0][0], cm_total) : ra.a[0][0] + cm_total;            \
-            ra.a[0][0] = 0.f;                                                                          \
-            ++cm_cluster;                                                                              \
-            cm_bound += cm_cluster < Cc ? (cm_real + Cc - 1u - cm_cluster) >> cm_lg : 0u;              \
+            if constexpr (SPLIT) { /* ... its slice's last / every group: the accumulator goes out as it is */ \
+              a.out[(uint64_t)sp_pos * x.n_pad + sp_row] = ra.a[0][0];                                 \
+              ra.a[0][0] = 0.f;                                                                        \
+              ++sp_pos;                                                                                \
+              cm_bound += x.split_len ? 1u : 0x40000000u;                                              \
+            } else {                                                                                   \
+              cm_total = exact_l ? radd_exact(ra.a[0][0], cm_total) : ra.a[0][0] + cm_total;          \
+              ra.a[0][0] = 0.f;                                                                        \
+              ++cm_cluster;                                                                            \
+              cm_bound += cm_cluster < Cc ? (cm_real + Cc - 1u - cm_cluster) >> cm_lg : 0u;            \
+            }                                                                                          \
           }                                                                                            \
         }                                                                                              \
       }                                                                                                \
@@ -786,6 +820,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
       return;
     }
   }
+  if constexpr (SPLIT) return;  // (every partial sum went out at its group: [slices or groups][n_pad], whole tiles)
   if (row < a.n) a.out[row] = (SUM1 == 1) ? (float)dacc[0] : CM ? cm_total : ra.total(0, C, exact);
 }
 
@@ -805,6 +840,15 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
     if (e != hipSuccess) return e;
   }
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
+  if constexpr ((OPT & 4) != 0 && CT == 8 && D == 8 && (OPT & 64) == 0) {  // the cluster split of a small batch (launch_score decides; Variant::has_split)
+    if (x.split > 1u) {  // (slices: clusters, or runs of split_len chunks)
+      auto ksplit = score_q16_kernel<D, CT, U, OPT | 128>;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(ksplit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(ksplit, dim3((uint32_t)tiles, x.split), dim3(kQTile), lds, s, a, x);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kQTile), lds, s, a, x);
   return hipGetLastError();
 }
@@ -1268,26 +1312,80 @@ hipError_t launch_generic(const ScoreArgs& a_in, const Variant&, hipStream_t s) 
 // ---------------------------------------------------------------------------------------------------
 // chain sum of partial score vectors: out = (((p0 + p1) + p2) + ...)  (ResultsCombiner.sv:292-311)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chain_sum_kernel(const float* __restrict__ parts, uint32_t n_parts, size_t n,
+__global__ __launch_bounds__(256) void chain_sum_kernel(const float* __restrict__ parts, uint32_t n_parts, size_t n, size_t pitch,
                                                         float* __restrict__ out, const bool exact) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float run = parts[i];
     if (!exact) {
-      for (uint32_t p = 1; p < n_parts; ++p) run = parts[(size_t)p * n + i] + run;  // local + upstream
+      for (uint32_t p = 1; p < n_parts; ++p) run = parts[(size_t)p * pitch + i] + run;  // local + upstream
     } else {
-      for (uint32_t p = 1; p < n_parts; ++p) run = radd_exact(parts[(size_t)p * n + i], run);  // sum_mode 2: the hop adders are the same FloPoCo adder
+      for (uint32_t p = 1; p < n_parts; ++p) run = radd_exact(parts[(size_t)p * pitch + i], run);  // sum_mode 2: the hop adders are the same FloPoCo adder
     }
     out[i] = run;
   }
 }
 
-hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact, hipStream_t s) {
+// The adds of a launch cut into slices (score_q16_kernel SPLIT), in the reference's order: per cluster acc <- p + acc over its partial sums
+// (FPAggregator.v:79-131; one per PU group in image order, or the cluster's finished accumulator), then total <- acc + total over the
+// clusters (Core.sv:486-541).  parts = [positions][pitch]; cluster c holds (real + C - 1 - c) / C groups (ddt_image.cpp cm_position).
+// A block = 64 tuples x 4 waves.  The clusters' chains are independent of each other: wave q runs the chains of clusters q, q + 4 -- sixteen
+// independent, coalesced loads in flight, then their adds in order -- and leaves the accumulators in LDS; wave 0 adds them in cluster order.
+// (One thread per tuple walking 125 dependent global loads took 31 us for a single tile; staged through LDS by a loop hipcc did not unroll 16.)
+__global__ __launch_bounds__(256) void cm_combine_kernel(const float* __restrict__ parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters,
+                                                         uint32_t per_group, float* __restrict__ out, const bool exact) {
+  extern __shared__ float cacc_dyn[];  // [8][64]: clusters_per_tuple is 1, 2, 4 or 8 (ddt_model.cpp); dynamic like every LDS byte of this library (tests/test_abi_host.py)
+  float (*cacc)[64] = reinterpret_cast<float (*)[64]>(cacc_dyn);
+  const uint32_t r = threadIdx.x & 63u, q = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * 64u + r;  // (< pitch: the partial vectors are whole tiles)
+  auto count_of = [&](uint32_t c) -> uint32_t {     // partial sums of cluster c
+    const uint32_t len = (real_groups + clusters - 1u - c) / clusters;
+    return per_group ? len : (len ? 1u : 0u);
+  };
+  uint32_t pos = 0;
+  for (uint32_t c = 0; c < clusters; ++c) {  // (wave-uniform)
+    const uint32_t cnt = count_of(c);
+    if ((c & 3u) == q) {
+      float acc = 0.f;
+      const float* src = parts + (size_t)pos * pitch + row;
+      for (uint32_t j0 = 0; j0 < cnt; j0 += 16u) {
+        float v[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; ++u) v[u] = j0 + u < cnt ? src[(size_t)(j0 + u) * pitch] : 0.f;
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; ++u)
+          if (j0 + u < cnt) acc = exact ? radd_exact(v[u], acc) : v[u] + acc;
+      }
+      cacc[c][r] = acc;
+    }
+    pos += cnt;
+  }
+  __syncthreads();
+  if (q == 0u && row < n) {
+    float total = 0.f;
+    for (uint32_t c = 0; c < clusters; ++c)
+      if (count_of(c)) total = exact ? radd_exact(cacc[c][r], total) : cacc[c][r] + total;
+    out[row] = total;
+  }
+}
+
+hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, float* out, bool exact,
+                             hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  (void)hipGetLastError();
+  const size_t blocks = (n + 63) / 64;
+  if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cm_combine_kernel, dim3((uint32_t)blocks), dim3(256), 8 * 64 * sizeof(float), s, parts, pitch, n, real_groups, clusters, per_group ? 1u : 0u, out, exact);
+  return hipGetLastError();
+}
+
+// pitch = elements between consecutive partial vectors (0: n, the vectors stand back to back)
+hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact, hipStream_t s, size_t pitch) {
   if (n == 0) return hipSuccess;
   (void)hipGetLastError();  // do not inherit a stale error
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048 * 8) blocks = 2048 * 8;
-  hipLaunchKernelGGL(chain_sum_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, parts, n_parts, n, out, exact);
+  hipLaunchKernelGGL(chain_sum_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, parts, n_parts, n, pitch ? pitch : n, out, exact);
   return hipGetLastError();
 }
 

@@ -197,6 +197,32 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
           if (x.seg_chunks - chunk == x.seg_tail_left && in_seg % CT >= 4u) img_order[t] = 0.0f;
         }
       }
+      if (cm && x.split > 1u) {
+        // a small batch cut into slices of the cluster-major image (csrc/ddt_kernels.hip score_q16_kernel SPLIT): every slice is a block that
+        // starts from a zero accumulator and lets it out -- at its end when the slices are the clusters (split_len == 0), at every PU group
+        // otherwise; the adds follow in launch_cm_combine
+        auto add = [&](float p, float q) -> float {
+          volatile float r = a.sum_mode == 2 ? ref_add_exact(p, q) : p + q;
+          return r;
+        };
+        const uint32_t Cc = a.clusters, real = x.real_groups;
+        uint32_t first = 0;
+        for (uint32_t sl = 0; sl < x.split; ++sl) {
+          const uint32_t len = x.split_len ? std::min(x.split_len, real - first) : (real + Cc - 1u - sl) / Cc;
+          float acc = 0.0f;
+          for (uint32_t g = first; g < first + len; ++g) {
+            const float* l = img_order.data() + g * 8u;
+            acc = add(add(add(add(l[0], l[1]), add(l[2], l[3])), add(add(l[4], l[5]), add(l[6], l[7]))), acc);
+            if (x.split_len) {
+              a.out[(size_t)g * x.n_pad + i] = acc;
+              acc = 0.0f;
+            }
+          }
+          if (!x.split_len) a.out[(size_t)sl * x.n_pad + i] = acc;
+          first += len;
+        }
+        continue;
+      }
       if (cm && (x.state_in || x.state_out || x.group0)) {
         // one PART of an ensemble scored in parts: the kernel's own accumulate over the groups of this image in cluster-major order,
         // starting from / leaving the sum's state (csrc/ddt_kernels.hip score_q16_kernel, "_cm")

@@ -212,6 +212,12 @@ def test_per_rank_proxies_plumbing_on_the_cpu_model(monkeypatch):
     eng = ddt.Engine(0)
     tuples = eng.synth_tuples_device(0, N, F, 0)
     p = bench.collect_rank_proxies(0, tuples, 100.0, (T, D, F), (w, f), check_rows=1024)
+    # `other_modes.small_batches`: one call on a batch of a few tiles, cut into slices of the image against uncut, through the real host side
+    eng.load_model(ddt.make_params(T, D, F), w, f)
+    full = eng.score_device(tuples)
+    ft.cuda.synchronize()
+    sb = bench.collect_small_batches(eng, tuples, ft.empty(N, dtype=ft.float32, device=tuples.device), full.cpu().numpy().view(np.uint32), rows_list=(1024, 5000), reps=2)
+    assert sb["1024"]["bit_exact_vs_timed_result"] is True and sb["5000"]["bit_exact_vs_timed_result"] is True and sb["5000"]["us_uncut"] > 0 and "note" in sb, sb
     eng.close()
     for name, trees, rows in (("shard_of_8", 125, N), ("hybrid_rank_of_2x4", 500, N // 4), ("replica_of_8", 1000, N // 8)):
         r = p[name]

@@ -658,6 +658,7 @@ def test_more_thresholds_than_u16_ranks_hold_is_scored_in_parts(mock, T, F, clus
     e, st = _engine(mock), ddt.Stats()
     for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
         _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), None)
+        assert mock.ddt_set_option(e, b"q16_cluster_split", 0) == 0     # (an ensemble in ONE part: a batch this small would be cut at its clusters)
         info = ddt.Info()
         assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_x"
         want = O.score(m, x, sum_mode=ref)
@@ -1085,4 +1086,58 @@ def test_sparse_forests_with_dense_mid_levels(mock, T, depth, F, full, pm, dm, n
     h = np.full(n, np.nan, np.float32)
     assert mock.ddt_set_option(e, b"feeder_rows", 256) == 0 and mock.ddt_score(e, x.ctypes.data, n, h.ctypes.data) == 0
     assert np.array_equal(_bits(h), _bits(want))
+    mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("T,clusters", [(300, 8), (300, 2), (125, 8), (230, 4), (224, 8), (1000, 8), (229, 1)])
+def test_small_batch_is_cut_at_the_clusters(mock, T, clusters):
+    """A batch of a few tiles on the plain depth-8 cluster-major kernel: one block per (tile, SLICE of the image) instead of one per tile -- a
+    slice is a cluster (its accumulator goes out) or a run of PU groups (every group's sum goes out) -- then the adds in the reference's order
+    (FPAggregator.v:79-131: per cluster acc <- x + acc; Core.sv:486-541: the clusters added in order afterwards) -- bit-exact with the oracle and with the uncut launch in both adders, with a missing value in one tile, for row counts that are
+    no whole tiles, back to back on one stream; the automatic rule follows the tile limit; one cluster = nothing to cut."""
+    mock.mock_reset(1, 11, 8)
+    D, F = 8, 12
+    m = O.gen_model(T, D, F, 1, clusters=clusters)
+    e, st, s = _engine(mock), ddt.Stats(), _stream(mock)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), "q16_d8_c8_u4_gl_s2_cm_x")
+        for n in (1, 700, 1024, 2500):
+            x = O.gen_tuples(3, n, F, 1)
+            if n > 1100:
+                x[1100, 2] = 0x7FC00000                                             # the second tile takes the slow image
+            want = O.score(m, x, sum_mode=ref)
+            got = {}
+            cut = 2 if (T + 7) // 8 > 1 else 1
+            for split, groups, launches in ((0, -1, 1), (1, 0, 2 if clusters > 1 else 1), (1, -1, cut), (-1, 5, cut), (-1, 1000, cut)):
+                assert mock.ddt_set_option(e, b"q16_cluster_split", split) == 0   # groups: 0 = the slices are the clusters, -1 = automatic (runs of PU
+                assert mock.ddt_set_option(e, b"q16_split_groups", groups) == 0   # groups for batches this small), k = k slices
+                assert mock.ddt_get_stats(e, C.byref(st)) == 0
+                before = st.kernel_launches
+                outs = [np.full(n, np.nan, np.float32) for _ in range(2)]
+                for out in outs:                                                     # back to back: the partial sums' workspace is reused in stream order
+                    assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0, mock.ddt_last_error(e)
+                assert mock.hipStreamSynchronize(s) == 0
+                for out in outs:
+                    assert np.array_equal(_bits(out), _bits(want)), (T, clusters, sum_mode, n, split)
+                assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.kernel_launches - before == 2 * launches, (split, n)
+                got[(split, groups)] = outs[0]
+            assert all(np.array_equal(_bits(got[(0, -1)]), _bits(g)) for g in got.values())
+        # the automatic rule: batches of up to q16_split_max_tiles tiles
+        assert mock.ddt_set_option(e, b"q16_cluster_split", -1) == 0 and mock.ddt_set_option(e, b"q16_split_max_tiles", 2) == 0
+        assert mock.ddt_set_option(e, b"q16_split_groups", 0) == 0
+        for n, cut in ((2048, True), (2049, False)):
+            x = O.gen_tuples(5, n, F, 1)
+            out = np.full(n, np.nan, np.float32)
+            assert mock.ddt_get_stats(e, C.byref(st)) == 0
+            before = st.kernel_launches
+            assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0 and mock.hipStreamSynchronize(s) == 0
+            assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=ref)))
+            assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.kernel_launches - before == (2 if cut and clusters > 1 else 1)
+        assert mock.ddt_set_option(e, b"q16_split_max_tiles", 384) == 0
+    # host buffers (the feeder's slots have workspaces of their own)
+    assert mock.ddt_set_option(e, b"q16_cluster_split", 1) == 0 and mock.ddt_set_option(e, b"q16_split_groups", -1) == 0
+    x = O.gen_tuples(9, 3000, F, 1)
+    out = np.full(3000, np.nan, np.float32)
+    assert mock.ddt_score(e, x.ctypes.data, 3000, out.ctypes.data) == 0, mock.ddt_last_error(e)
+    assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=O.SUM_REF_FLOPOCO)))
     mock.ddt_destroy(e)

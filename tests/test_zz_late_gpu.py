@@ -189,6 +189,12 @@ def test_default_command_carries_the_other_baseline_configs():
         assert "error" not in r and r["trees"] == trees and r["bit_exact"] is True and r["ms"] > 0 and r["compute_only_x"] > 1.0, (name, r)
     assert 5.0 < pr["shard_of_8"]["compute_only_x"] < 8.0 and pr["seconds"] < 5.0
     assert "ASSUMPTION" in pr["model_8gpu"]["assumptions"] and pr["model_8gpu"]["tree_sharded_8"]["ms"] > 0
+    # one call on a batch of a few tiles: cut into slices of the image (the automatic choice) against one block per tile
+    sb = j["other_modes"]["small_batches"]
+    assert "error" not in sb, sb
+    for rows in ("1024", "16384", "131072"):
+        assert sb[rows]["bit_exact_vs_timed_result"] is True and sb[rows]["us_cut"] > 0 and sb[rows]["us_uncut"] > 0, (rows, sb[rows])
+    assert sb["1024"]["x"] > 3.0 and sb["16384"]["x"] > 2.5 and sb["131072"]["x"] > 1.3, sb
 
 
 def test_one_shard_of_a_tree_sharded_job_on_one_gpu():

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Small-batch latency of one scoring call through the C-ABI (device-resident tuples, one `ddt_score_device` + a stream sync per call).
+
+bench.py measures throughput at BASELINE's row counts; this is the other end: what ONE call costs when the batch is a few rows to a few
+hundred thousand -- the regime a serving caller sees.  Per model and batch size: median and 90th percentile of `reps` calls in
+microseconds, the rows per second that is, the kernel, and a bit-for-bit check of the smallest and the largest batch against the oracle.
+
+Usage: latency_probe.py [--configs 3,2,6,4] [--rows 1,64,1024,...] [--reps 40] [--opt key=value ...] [--json out.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "distributed-decisiontrees_amd"))
+sys.path.insert(0, ROOT)
+
+SHAPES = {3: (1000, 8, 32), 2: (100, 6, 28), 6: (512, 12, 32), 4: (512, 16, 64), 1: (8, 4, 16)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="3,2,6,4")
+    ap.add_argument("--rows", default="1,64,1024,4096,16384,65536,262144,1048576")
+    ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+
+    import ddt
+
+    res = []
+    for cfg in [int(c) for c in args.configs.split(",")]:
+        T, D, F = SHAPES[cfg]
+        eng = ddt.Engine(0)
+        for kv in args.opt:
+            k, _, v = kv.partition("=")
+            eng.set_option(k, int(v))
+        if cfg == 4:
+            lines, first = ddt.synth_sparse_model(T, D, F, 8, 700, 0)
+            params = ddt.make_sparse_params(T, D, F)
+            eng.load_model_sparse(params, lines, first)
+        else:
+            w, f = ddt.synth_model(T, D, F, 0)
+            params = ddt.make_params(T, D, F)
+            eng.load_model(params, w, f)
+        rows = [int(r) for r in args.rows.split(",")]
+        nmax = max(rows)
+        tuples = eng.synth_tuples_device(0, nmax, F, 0)
+        W = ddt.tuple_words(F)
+        out = torch.empty(nmax, dtype=torch.float32, device=tuples.device)
+        ref = None
+        if not args.no_check:
+            from oracle import oracle as O  # the checker, behind the timed calls
+
+            ncheck = min(nmax, 16384)
+            x = tuples[:ncheck].cpu().numpy().view(np.uint32)
+            if cfg == 4:
+                ref = O.score_sparse_fast(O.SparseModel(O.make_sparse_params(T, D, F), lines, first), x)
+            else:
+                ref = O.score_fast(O.Model(O.make_params(T, D, F), w, f), x)
+        for n in rows:
+            t_in = tuples[:n]
+            o = out[:n]
+            for _ in range(5):
+                eng.score_device(t_in, out=o)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(args.reps):
+                t0 = time.perf_counter()
+                eng.score_device(t_in, out=o)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e6)
+            ts.sort()
+            med, p90 = ts[len(ts) // 2], ts[int(len(ts) * 0.9)]
+            ok = None
+            if ref is not None and n <= len(ref):
+                ok = bool(np.array_equal(o.cpu().numpy().view(np.uint32), np.asarray(ref[:n], dtype=np.float32).view(np.uint32)))
+            info = eng.info()
+            r = {"config": cfg, "trees": T, "depth": D, "features": F, "rows": n, "us_median": round(med, 1), "us_p90": round(p90, 1),
+                 "mtuples_per_s": round(n / med, 3), "kernel": info.variant_name.decode(), "bit_exact": ok}
+            res.append(r)
+            print(json.dumps(r), flush=True)
+        eng.close()
+        del tuples, out
+    if args.json:
+        json.dump(res, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
