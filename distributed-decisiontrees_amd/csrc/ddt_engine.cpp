@@ -266,7 +266,7 @@ int timing_end(ddt_engine* e, hipStream_t s) {
   return DDT_OK;
 }
 
-// Small batches on the plain cluster-major depth-8 kernel: into how many slices to cut the launch (split == 0: one block per tile as always).
+// Small batches on the plain rank-quantised kernels (Variant::has_split): into how many slices to cut the launch (split == 0: one block per tile as always).
 // One block walks the whole ensemble for its 1024 tuples -- 0.35 ms per call at 1000 trees, whatever the batch, while a batch of a few tiles
 // leaves most CUs idle.  The walks are independent; the ADDS have the reference's order (per cluster acc <- x_g + acc over its PU groups,
 // FPAggregator.v:79-131; then total <- acc_c + total over the clusters, Core.sv:486-541) and are left to launch_cm_combine:
@@ -279,21 +279,22 @@ struct SplitPlan {
 static SplitPlan cluster_split_of(const ddt_engine* e, const Variant& v, const Ensemble& m, size_t n, bool reuse_prepass, bool all_classes) {
   SplitPlan sp;
   if (!v.has_split() || e->q16_cluster_split == 0 || all_classes || reuse_prepass || e->num_classes > 1 || !m.parts.empty() || n == 0) return sp;
-  if (e->p.sum_mode == 1u) return sp;  // (the fp64 sum runs in stream order: never on a cluster-major kernel anyway)
+  if (e->p.sum_mode == 1u) return sp;  // (the fp64 sum runs in stream order over the trees: nothing to cut)
   const uint32_t C = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, real = (m.trees() + 7u) / 8u;
-  if (real < 2u || (C & (C - 1u)) != 0u) return sp;
+  const uint32_t gpc = (uint32_t)v.chunk_trees / 8u, chunks = (real + gpc - 1u) / gpc;  // PU groups per chunk; chunks that hold a real tree
+  if (chunks < 2u || (C & (C - 1u)) != 0u) return sp;
   const uint64_t tiles = (n + 1023) / 1024;
   if (e->q16_cluster_split < 0 && tiles > e->q16_split_max_tiles) return sp;
-  const uint32_t by_cluster = C < real ? C : real;
+  const uint32_t by_cluster = v.cm() ? (C < real ? C : real) : 1u;  // (an image in stream order has no runs of a cluster's groups)
   const uint32_t slots = 2u * (e->prop.multiProcessorCount > 0 ? (uint32_t)e->prop.multiProcessorCount : 256u);  // resident blocks (two per CU)
   if (e->q16_split_groups != 0 && tiles * by_cluster < slots) {  // the clusters alone leave CUs idle: runs of groups, about one round of blocks
     uint32_t want = (uint32_t)(slots / tiles);
     if (e->q16_split_groups > 0) want = (uint32_t)e->q16_split_groups;  // (forced slice count: tests, A/B)
-    if (want > real) want = real;
+    if (want > chunks) want = chunks;
     if (want > by_cluster || e->q16_split_groups > 0) {
-      sp.len = (real + want - 1u) / want;
-      sp.split = (real + sp.len - 1u) / sp.len;
-      sp.partials = real;
+      sp.len = (chunks + want - 1u) / want;
+      sp.split = (chunks + sp.len - 1u) / sp.len;
+      sp.partials = chunks * gpc;
       if (sp.split >= 2u) return sp;
       sp = SplitPlan();
     }
@@ -423,7 +424,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     a.out = reinterpret_cast<float*>(e->q_split[k]);
     r = v.launch(a, v, s);
     if (r == hipSuccess) {
-      r = launch_cm_combine(a.out, (size_t)qa.n_pad, n, qa.real_groups, e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, sp.len != 0u, d_scores,
+      r = launch_cm_combine(a.out, (size_t)qa.n_pad, n, qa.real_groups, e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, sp.len != 0u, v.cm(), d_scores,
                             e->p.sum_mode == 2, s);
       e->st.kernel_launches++;
     }

@@ -256,9 +256,13 @@ struct Variant {
   // opt bit 6 ("q16w_*" / "q16dw_*"): tuples of up to 64 words -- a record's row-offset field holds HALF the byte offset (the kernel shifts it
   // back), the block takes up to 144 KiB of LDS (one block of 16 waves per CU)
   bool wide() const { return kind == kKindQ16 && (opt & 64) != 0; }
-  // the plain cluster-major depth-8 kernel ("q16_d8_c8_u4_gl_s2_cm_x") has a second instantiation whose grid is cut at the image's clusters
-  // (Q16Aux::split): what launch_score gives a batch of a few tiles
-  bool has_split() const { return kind == kKindQ16 && levels == 8 && chunk_trees == 8 && (opt & (4 | 8 | 32 | 64)) == 4; }
+  // the plain rank-quantised kernels the automatic choice takes ("q16_d8_c8_u4_gl_s2_cm_x", its wide form, "q16_d{5,6,7}_*_s2", "q16_d{3,4}_*")
+  // have a second instantiation whose grid is cut into slices of the image (Q16Aux::split): what launch_score gives a batch of a few tiles
+  bool has_split() const {
+    if (kind != kKindQ16 || (opt & (8 | 32)) != 0 || chunk_trees % 8 != 0) return false;          // (not the persistent "_p" form, not the deep kernels)
+    return levels == 8 ? (opt & 4) != 0 : levels >= 5 ? (opt & 2) != 0 : levels >= 3;               // = the instantiations of launch_q16 (ddt_kernels.hip)
+  }
+  bool cm() const { return kind == kKindQ16 && (opt & 4) != 0; }                                    // cluster-major image
   uint32_t max_tuple_words_q16() const { return wide() ? 64u : 32u; }
   uint32_t deep_stages() const { return ((uint32_t)levels - (uint32_t)top + 1u) / 2u; }
   uint32_t deep_stage_level(uint32_t g) const { return g + 1u < deep_stages() ? (uint32_t)top + 2u * g : (uint32_t)levels - 1u; }
@@ -336,7 +340,7 @@ int num_sparse_r_variants();               // ddt_sparse_r.hip: and these last
 const Variant& sparse_r_variant(int i);
 hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint64_t n_pad, uint32_t* xT, hipStream_t s);  // ddt_prepass.hip
 
-hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, float* out,
+hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, bool cm_order, float* out,
                              bool exact /* sum_mode 2 */, hipStream_t s);
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact /* sum_mode 2 */, hipStream_t s,
                             size_t pitch = 0 /* elements between the partial vectors; 0 = n */);

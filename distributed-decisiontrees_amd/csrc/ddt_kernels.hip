@@ -630,7 +630,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   //   Q16Aux::split_len  > 0  a slice = split_len consecutive chunks; the block leaves every group's x_g (its 8-leaf reduce tree, + 0) in
   //                           out[position of the group in the image][row]: up to one block per (tile, PU group) for batches of a tile or two
   constexpr bool SPLIT = (OPT & 128) != 0;
-  static_assert(!SPLIT || (CM && CT == 8), "the cluster split cuts the cluster-major image at PU groups = chunks");
+  static_assert(!SPLIT || CT % 8 == 0, "a slice = whole chunks = whole PU groups");  // (image in stream order, !CM: a partial sum per group only)
   static_assert(!S2 || U == 4, "_s2: 4 trees in flight");
   static_assert(!PIN || S2, "the pinned read order exists for the _s2 walk");
   constexpr int TREE_BYTES = GL ? (4 << D) : (8 << D);  // bytes of a tree in LDS (GL: node records only)
@@ -649,21 +649,21 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   // treats `img` (and every leaf-gather address derived from it) as lane-varying: 64-bit VALU address arithmetic per gather
   const bool slow = __builtin_amdgcn_readfirstlane((int)x.tile_flags[tile]) != 0;
   const uint4* img = slow ? x.img_slow : a.img;
-  uint32_t sp_pos = 0;  // SPLIT: which partial sum this block writes next
+  uint32_t sp_pos = 0, sp_first = 0;  // SPLIT: which partial sum this block writes next; the slice's first chunk
   const uint64_t sp_row = tile0 + (uint64_t)tid;
   if constexpr (SPLIT) {
-    uint32_t first = 0;
-    if (x.split_len) {  // split_len consecutive chunks, a partial sum per PU group
-      first = blockIdx.y * x.split_len;
-      n_chunks = x.real_groups - first < x.split_len ? x.real_groups - first : x.split_len;  // >= 1: the host launches ceil(real / split_len) slices
-      sp_pos = first;
-    } else {            // cluster blockIdx.y's run of PU groups (cluster j holds (real + C - 1 - j) / C of them: ddt_image.cpp cm_position)
+    if (x.split_len) {  // split_len consecutive chunks, a partial sum per PU group (at its position in the image)
+      const uint32_t real_chunks = (x.real_groups * 8u + (uint32_t)CT - 1u) / (uint32_t)CT;
+      sp_first = blockIdx.y * x.split_len;
+      n_chunks = real_chunks - sp_first < x.split_len ? real_chunks - sp_first : x.split_len;  // >= 1: the host launches ceil(real chunks / split_len) slices
+      sp_pos = sp_first * (uint32_t)(CT / 8);
+    } else {            // (cluster-major images only) cluster blockIdx.y's run of PU groups = chunks: cluster j holds (real + C - 1 - j) / C of them (ddt_image.cpp cm_position)
       const uint32_t lg = (uint32_t)__builtin_ctz(a.clusters | 0x100u);
-      for (uint32_t j = 0; j < blockIdx.y; ++j) first += (x.real_groups + a.clusters - 1u - j) >> lg;
+      for (uint32_t j = 0; j < blockIdx.y; ++j) sp_first += (x.real_groups + a.clusters - 1u - j) >> lg;
       n_chunks = (x.real_groups + a.clusters - 1u - blockIdx.y) >> lg;  // >= 1: the host launches min(C, real groups) clusters
       sp_pos = blockIdx.y;
     }
-    img += (size_t)first * GCHUNK_UNITS;
+    img += (size_t)sp_first * GCHUNK_UNITS;
   }
 
   dma_chunk<THREADS, CHUNK_BYTES>(img, 0, 0, tid);
@@ -711,7 +711,10 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
   // loads are in flight (tools/check_s2_isa.py refused that build).  Shallow kernels are also the ones with many trees per chunk
   // (16..128), i.e. with the most padding to lose.
   constexpr bool TAILSKIP = D <= 6;
-  const uint32_t walk_sgs = x.walk_subgroups ? x.walk_subgroups : 0xFFFFFFFFu;
+  uint32_t walk_sgs = x.walk_subgroups ? x.walk_subgroups : 0xFFFFFFFFu;
+  if constexpr (SPLIT) {
+    if (x.walk_subgroups) walk_sgs -= sp_first * (uint32_t)(CT / U);  // (> 0: every chunk of a slice holds a real tree)
+  }
 
   // _s2: two SGPR sets take turns (even / odd sub-group of a chunk; a chunk has an even number of sub-groups, so every chunk
   // starts on top_a): one holds the level-0/1 records of the sub-group being walked, the other receives the next sub-group's
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(kQTile, 8) void score_q16_kernel(const ScoreArgs a,
       }                                                                                                \
       if (sum_l != 1) fold_leaves<U, 1, 0>(lf, ((PH) + sg) & 1, C, ra, dacc, exact_l);                 \
       else fold_leaves<U, 1, 1>(lf, ((PH) + sg) & 1, C, ra, dacc);                                     \
-      if constexpr (CM) {                                                                              \
+      if constexpr (CM || SPLIT) {                                                                     \
         if (U == 8 || (((PH) + sg) & 1) == 1) { /* a PU group is complete */                           \
           if (++cm_groups == cm_bound) { /* ... and it was its cluster's last */                       \
             if constexpr (SPLIT) { /* ... its slice's last / every group: the accumulator goes out as it is */ \
@@ -840,7 +843,8 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
     if (e != hipSuccess) return e;
   }
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
-  if constexpr ((OPT & 4) != 0 && CT == 8 && D == 8 && (OPT & 64) == 0) {  // the cluster split of a small batch (launch_score decides; Variant::has_split)
+  // the cut launch of a small batch (launch_score decides; the same predicate as Variant::has_split): the kernels the automatic choice takes
+  if constexpr (D == 8 ? (OPT & 4) != 0 : D >= 5 ? (OPT & 2) != 0 : true) {
     if (x.split > 1u) {  // (slices: clusters, or runs of split_len chunks)
       auto ksplit = score_q16_kernel<D, CT, U, OPT | 128>;
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(ksplit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1328,12 +1332,13 @@ __global__ __launch_bounds__(256) void chain_sum_kernel(const float* __restrict_
 
 // The adds of a launch cut into slices (score_q16_kernel SPLIT), in the reference's order: per cluster acc <- p + acc over its partial sums
 // (FPAggregator.v:79-131; one per PU group in image order, or the cluster's finished accumulator), then total <- acc + total over the
-// clusters (Core.sv:486-541).  parts = [positions][pitch]; cluster c holds (real + C - 1 - c) / C groups (ddt_image.cpp cm_position).
+// clusters (Core.sv:486-541).  parts = [positions][pitch]; cluster c holds (real + C - 1 - c) / C groups (ddt_image.cpp cm_position); position = the
+// group's place in the image the scoring kernel walked: cluster by cluster (cm_order) or in stream order.
 // A block = 64 tuples x 4 waves.  The clusters' chains are independent of each other: wave q runs the chains of clusters q, q + 4 -- sixteen
 // independent, coalesced loads in flight, then their adds in order -- and leaves the accumulators in LDS; wave 0 adds them in cluster order.
 // (One thread per tuple walking 125 dependent global loads took 31 us for a single tile; staged through LDS by a loop hipcc did not unroll 16.)
 __global__ __launch_bounds__(256) void cm_combine_kernel(const float* __restrict__ parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters,
-                                                         uint32_t per_group, float* __restrict__ out, const bool exact) {
+                                                         uint32_t per_group, uint32_t cm_order, float* __restrict__ out, const bool exact) {
   extern __shared__ float cacc_dyn[];  // [8][64]: clusters_per_tuple is 1, 2, 4 or 8 (ddt_model.cpp); dynamic like every LDS byte of this library (tests/test_abi_host.py)
   float (*cacc)[64] = reinterpret_cast<float (*)[64]>(cacc_dyn);
   const uint32_t r = threadIdx.x & 63u, q = threadIdx.x >> 6;
@@ -1347,11 +1352,13 @@ __global__ __launch_bounds__(256) void cm_combine_kernel(const float* __restrict
     const uint32_t cnt = count_of(c);
     if ((c & 3u) == q) {
       float acc = 0.f;
-      const float* src = parts + (size_t)pos * pitch + row;
+      // the cluster's j-th partial sum: at pos + j in a cluster-major image; in stream order group g belongs to cluster g mod C (Core.sv:291-316)
+      const float* src = parts + (size_t)(cm_order ? pos : c) * pitch + row;
+      const size_t step = (size_t)(cm_order ? 1u : clusters) * pitch;
       for (uint32_t j0 = 0; j0 < cnt; j0 += 16u) {
         float v[16];
 #pragma unroll
-        for (uint32_t u = 0; u < 16u; ++u) v[u] = j0 + u < cnt ? src[(size_t)(j0 + u) * pitch] : 0.f;
+        for (uint32_t u = 0; u < 16u; ++u) v[u] = j0 + u < cnt ? src[(size_t)(j0 + u) * step] : 0.f;
 #pragma unroll
         for (uint32_t u = 0; u < 16u; ++u)
           if (j0 + u < cnt) acc = exact ? radd_exact(v[u], acc) : v[u] + acc;
@@ -1369,13 +1376,13 @@ __global__ __launch_bounds__(256) void cm_combine_kernel(const float* __restrict
   }
 }
 
-hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, float* out, bool exact,
-                             hipStream_t s) {
+hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, bool cm_order, float* out,
+                             bool exact, hipStream_t s) {
   if (n == 0) return hipSuccess;
   (void)hipGetLastError();
   const size_t blocks = (n + 63) / 64;
   if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(cm_combine_kernel, dim3((uint32_t)blocks), dim3(256), 8 * 64 * sizeof(float), s, parts, pitch, n, real_groups, clusters, per_group ? 1u : 0u, out, exact);
+  hipLaunchKernelGGL(cm_combine_kernel, dim3((uint32_t)blocks), dim3(256), 8 * 64 * sizeof(float), s, parts, pitch, n, real_groups, clusters, per_group ? 1u : 0u, cm_order ? 1u : 0u, out, exact);
   return hipGetLastError();
 }
 

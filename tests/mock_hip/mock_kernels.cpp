@@ -197,29 +197,33 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
           if (x.seg_chunks - chunk == x.seg_tail_left && in_seg % CT >= 4u) img_order[t] = 0.0f;
         }
       }
-      if (cm && x.split > 1u) {
-        // a small batch cut into slices of the cluster-major image (csrc/ddt_kernels.hip score_q16_kernel SPLIT): every slice is a block that
-        // starts from a zero accumulator and lets it out -- at its end when the slices are the clusters (split_len == 0), at every PU group
-        // otherwise; the adds follow in launch_cm_combine
+      if (x.split > 1u) {
+        // a small batch cut into slices of the image (csrc/ddt_kernels.hip score_q16_kernel SPLIT): every slice is a block that starts from a zero
+        // accumulator and lets it out -- at its end when the slices are the clusters of a cluster-major image (split_len == 0), at every PU
+        // group otherwise (a slice = split_len chunks; the partial sum's position = the group's place in the image); the adds follow in
+        // launch_cm_combine
         auto add = [&](float p, float q) -> float {
           volatile float r = a.sum_mode == 2 ? ref_add_exact(p, q) : p + q;
           return r;
         };
-        const uint32_t Cc = a.clusters, real = x.real_groups;
-        uint32_t first = 0;
+        auto group_sum = [&](uint32_t g) -> float {
+          const float* l = img_order.data() + g * 8u;
+          return add(add(add(l[0], l[1]), add(l[2], l[3])), add(add(l[4], l[5]), add(l[6], l[7])));
+        };
+        const uint32_t Cc = a.clusters, real = x.real_groups, gpc = CT / 8u, real_chunks = (real + gpc - 1u) / gpc;
+        uint32_t first = 0;  // chunk
         for (uint32_t sl = 0; sl < x.split; ++sl) {
-          const uint32_t len = x.split_len ? std::min(x.split_len, real - first) : (real + Cc - 1u - sl) / Cc;
-          float acc = 0.0f;
-          for (uint32_t g = first; g < first + len; ++g) {
-            const float* l = img_order.data() + g * 8u;
-            acc = add(add(add(add(l[0], l[1]), add(l[2], l[3])), add(add(l[4], l[5]), add(l[6], l[7]))), acc);
-            if (x.split_len) {
-              a.out[(size_t)g * x.n_pad + i] = acc;
-              acc = 0.0f;
-            }
+          if (x.split_len) {
+            const uint32_t len = std::min(x.split_len, real_chunks - first);
+            for (uint32_t g = first * gpc; g < (first + len) * gpc; ++g) a.out[(size_t)g * x.n_pad + i] = add(group_sum(g), 0.0f);
+            first += len;
+          } else {  // (cm, one group per chunk)
+            const uint32_t len = (real + Cc - 1u - sl) / Cc;
+            float acc = 0.0f;
+            for (uint32_t g = first; g < first + len; ++g) acc = add(group_sum(g), acc);
+            a.out[(size_t)sl * x.n_pad + i] = acc;
+            first += len;
           }
-          if (!x.split_len) a.out[(size_t)sl * x.n_pad + i] = acc;
-          first += len;
         }
         continue;
       }
@@ -449,6 +453,11 @@ const Variant g_mock_variants[] = {
     Variant{"q16_d8_c8_u4_gl", kKindQ16, 8, 1024, 1, 8, 4, 1, 1, &launch_q16},
     Variant{"q16_d8_c4_u4", kKindQ16, 8, 1024, 1, 4, 4, 1, 0, &launch_q16},
     Variant{"q16_d6_c16_u4", kKindQ16, 6, 1024, 1, 16, 4, 1, 0, &launch_q16},
+    Variant{"q16_d6_c16_u4_s2", kKindQ16, 6, 1024, 1, 16, 4, 1, 2, &launch_q16},   // (images in stream order; the forms that have a cut launch)
+    Variant{"q16_d7_c8_u4_s2", kKindQ16, 7, 1024, 1, 8, 4, 1, 2, &launch_q16},
+    Variant{"q16_d5_c32_u4_s2", kKindQ16, 5, 1024, 1, 32, 4, 1, 2, &launch_q16},
+    Variant{"q16_d4_c64_u8", kKindQ16, 4, 1024, 1, 64, 8, 1, 0, &launch_q16},
+    Variant{"q16_d3_c128_u8", kKindQ16, 3, 1024, 1, 128, 8, 1, 0, &launch_q16},
     // deep rank-quantised kernels (opt 4 | 32: cluster-major, deep; last field = K)
     Variant{"q16d_d12_k9_c4_u4_cm", kKindQ16, 12, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},
     Variant{"q16d_d10_k9_c4_u4_cm", kKindQ16, 10, 1024, 1, 4, 4, 1, 36, &launch_q16, 9},

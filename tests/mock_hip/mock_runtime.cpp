@@ -680,8 +680,8 @@ hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, floa
   return hipSuccess;
 }
 
-hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, float* out, bool exact,
-                             hipStream_t s) {
+hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, bool cm_order, float* out,
+                             bool exact, hipStream_t s) {
   Op* op = new Op();
   op->cost = (double)n * (per_group ? real_groups : clusters) * g_cost_copy;
   op->run = [=] {
@@ -692,7 +692,10 @@ hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_
         const uint32_t len = (real_groups + clusters - 1u - c) / clusters, cnt = per_group ? len : (len ? 1u : 0u);
         if (!cnt) break;
         volatile float acc = 0.0f;
-        for (uint32_t j = 0; j < cnt; ++j) acc = exact ? ref_add_exact(parts[(size_t)(pos + j) * pitch + i], acc) : parts[(size_t)(pos + j) * pitch + i] + acc;
+        for (uint32_t j = 0; j < cnt; ++j) {  // the cluster's j-th partial sum: behind one another in a cluster-major image, every C-th group in stream order
+          const float p = parts[(size_t)(cm_order ? pos + j : c + j * clusters) * pitch + i];
+          acc = exact ? ref_add_exact(p, acc) : p + acc;
+        }
         total = exact ? ref_add_exact(acc, total) : acc + total;
         pos += cnt;
       }

@@ -1089,6 +1089,40 @@ def test_sparse_forests_with_dense_mid_levels(mock, T, depth, F, full, pm, dm, n
     mock.ddt_destroy(e)
 
 
+@pytest.mark.parametrize("T,D,clusters,name", [(300, 6, 4, "q16_d6_c16_u4_s2"), (1000, 6, 8, "q16_d6_c16_u4_s2"), (203, 7, 2, "q16_d7_c8_u4_s2"), (90, 5, 1, "q16_d5_c32_u4_s2"),
+                                                (500, 4, 4, "q16_d4_c64_u8"), (1030, 3, 8, "q16_d3_c128_u8"), (230, 8, 2, "q16w_d8_c8_u4_gl_s2_cm_x")])
+def test_small_batch_is_cut_into_runs_of_groups_on_every_depth(mock, T, D, clusters, name):
+    """The cut launch on the kernels whose images are in STREAM order (depths 3-7: group g belongs to cluster g mod C, Core.sv:291-316) and on the wide
+    depth-8 kernel: a slice is a run of chunks (2 ... 16 PU groups each), every group's sum goes out at the group's place in the image, and the
+    combine picks every C-th one for a cluster's chain -- the oracle's bits in both adders, EMPTY padding behind the last real tree included."""
+    mock.mock_reset(0, 5, 8)
+    F = 40 if name.startswith("q16w") else 10
+    m = O.gen_model(T, D, F, 1, clusters=clusters)
+    e, st, s = _engine(mock), ddt.Stats(), _stream(mock)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), name)
+        for n in (5, 1500):
+            x = O.gen_tuples(4, n, F, 1)
+            if n > 1100:
+                x[1100, 1] = 0x7FC00000
+            want = O.score(m, x, sum_mode=ref)
+            chunks = -(-((T + 7) // 8) // (mock_chunk_trees(name) // 8))
+            for groups in (-1, 2, 3, 1000):
+                assert mock.ddt_set_option(e, b"q16_cluster_split", 1) == 0 and mock.ddt_set_option(e, b"q16_split_groups", groups) == 0
+                assert mock.ddt_get_stats(e, C.byref(st)) == 0
+                before = st.kernel_launches
+                out = np.full(n, np.nan, np.float32)
+                assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0, mock.ddt_last_error(e)
+                assert mock.hipStreamSynchronize(s) == 0
+                assert np.array_equal(_bits(out), _bits(want)), (name, T, clusters, sum_mode, n, groups)
+                assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.kernel_launches - before == (2 if chunks > 1 else 1), (groups, chunks)
+    mock.ddt_destroy(e)
+
+
+def mock_chunk_trees(name):
+    return int(name.split("_c")[1].split("_")[0])
+
+
 @pytest.mark.parametrize("T,clusters", [(300, 8), (300, 2), (125, 8), (230, 4), (224, 8), (1000, 8), (229, 1)])
 def test_small_batch_is_cut_at_the_clusters(mock, T, clusters):
     """A batch of a few tiles on the plain depth-8 cluster-major kernel: one block per (tile, SLICE of the image) instead of one per tile -- a

@@ -61,6 +61,36 @@ def test_cut_launch_is_the_uncut_launch_bit_for_bit(T, clusters):
     e.close()
 
 
+@pytest.mark.parametrize("T,D,F,clusters,name", [(1000, 6, 28, 8, "q16_d6_c16_u4_s2"), (300, 6, 32, 4, "q16_d6_c16_u4_s2"), (403, 7, 32, 2, "q16_d7_c8_u4_s2"),
+                                                  (290, 5, 20, 1, "q16_d5_c32_u4_s2"), (700, 4, 16, 8, "q16_d4_c64_u8"), (1030, 3, 12, 8, "q16_d3_c128_u8"),
+                                                  (300, 8, 48, 4, "q16w_d8_c8_u4_gl_s2_cm_x")])
+def test_cut_launch_on_every_depth(T, D, F, clusters, name):
+    """Depths 3-7 keep their images in STREAM order (group g belongs to cluster g mod C, Core.sv:291-316): a slice is a run of chunks (2 ... 16 PU
+    groups each), every group's sum goes out at the group's place in the image, the combine picks every C-th for a cluster's chain.  And the
+    wide depth-8 kernel (cluster-major, 33-64 tuple words).  The engine's own kernel for these shapes, cut automatically."""
+    import torch
+
+    m = O.gen_model(T, D, F, dist=1, clusters=clusters)
+    e = ddt.Engine(0)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        e.load_model(ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), m.wlines, m.flines)
+        assert e.info().variant_name.decode() == name
+        for n, holes in ((1, 0), (1500, 2), (40_000, 5)):
+            x = _tuples(n, F, 11 + n % 100, holes)
+            d = torch.from_numpy(x.view(np.int32)).cuda()
+            want = O.score_fast(m, x, sum_mode=ref)
+            for split, groups in ((0, -1), (-1, -1), (1, 2), (1, 5), (1, 1000)):
+                e.set_option("q16_cluster_split", split)
+                e.set_option("q16_split_groups", groups)
+                before = e.stats().kernel_launches
+                got = e.score_device(d)
+                torch.cuda.synchronize()
+                assert e.stats().kernel_launches - before == (1 if split == 0 else 2), (split, groups, n)
+                bad = np.flatnonzero(_bits(got.cpu().numpy()) != _bits(want))
+                assert bad.size == 0, (name, T, clusters, sum_mode, n, split, groups, bad[:8], bad.size)
+    e.close()
+
+
 def test_automatic_rule_and_host_buffers():
     import torch
 

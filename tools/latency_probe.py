@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "distributed-decisiontrees_amd"))
 sys.path.insert(0, ROOT)
 
-SHAPES = {3: (1000, 8, 32), 2: (100, 6, 28), 6: (512, 12, 32), 4: (512, 16, 64), 1: (8, 4, 16)}
+SHAPES = {3: (1000, 8, 32), 2: (100, 6, 28), 6: (512, 12, 32), 4: (512, 16, 64), 1: (8, 4, 16),
+          # not BASELINE configs: 1000 trees at XGBoost's default depth, and shallow / odd depths
+          106: (1000, 6, 28), 107: (500, 7, 32), 104: (2000, 4, 16)}
 
 
 def main():
