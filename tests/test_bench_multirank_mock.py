@@ -182,7 +182,7 @@ def test_other_configs_plumbing_on_the_cpu_model(monkeypatch):
     monkeypatch.setitem(sys.modules, "torch.cuda", ft.cuda)
     world.local.rank = 0
     bench = _bench_module()
-    for cfg, kernel in ((2, "q16_d6_c16_u4"), (5, "q16_d8_c8_u4_gl_s2_cm_p"), (6, "q16d_d12_k9_c4_u4_cm")):
+    for cfg, kernel in ((2, "q16_d6_c16_u4_s2"), (5, "q16_d8_c8_u4_gl_s2_cm_p"), (6, "q16d_d12_k9_c4_u4_cm")):
         r = bench.run_side_config(cfg, 0, check_rows=1500, rows=2100)
         assert r["kernel"] == kernel and r["fallback_kernel"] is False, r
         assert r["parity"]["bit_exact"] is True and r["parity"]["rows_checked"] == 1500 and r["value"] > 0 and r["steps"] >= 3, r
