@@ -50,8 +50,12 @@ constexpr uint32_t q16d_stage_off(int D, int K, int g) {
 }
 
 // (three or four gathers per tree in flight -- depths 13..15 -- need more than the 64 VGPRs of two blocks per CU: one block of 16 waves then)
-template <int D, int K, int CT, bool WIDE = false>
-__global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) void score_q16d_kernel(const ScoreArgs a, const Q16Aux x) {
+// SPLIT (small batches, as score_q16_kernel's): grid (tiles, slices); block (tile, s) walks split_len PU groups of this launch's image from a zero
+// accumulator and leaves every group's sum (its 8-leaf reduce tree + 0) in out[group0 + the group's place in the image][row]; the adds follow in
+// launch_cm_combine, in the reference's order -- so the parts of an ensemble scored in parts need no state handed from launch to launch either.
+// (One block of 16 waves per CU: the stores keep the row index alive, and a batch of a few tiles has no second block to place.)
+template <int D, int K, int CT, bool WIDE = false, bool SPLIT = false>
+__global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE || SPLIT) ? 4 : 8) void score_q16d_kernel(const ScoreArgs a, const Q16Aux x) {
   constexpr int THREADS = kQTile, U = 4;
   constexpr int G = (D - K + 1) / 2;  // gathers per tree
   static_assert((D - K) % 2 == 1 && G >= 1 && G <= 4 && K >= 3, "D - K odd: pair stages and one terminal stage");
@@ -67,9 +71,19 @@ __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) voi
   static_assert(FEAT_OFF % ROW == 0, "row|lane OR trick");
   const int tid = threadIdx.x;
   const uint64_t tile = blockIdx.x, tile0 = tile * kQTile;
-  const uint32_t W = a.tuple_words, n_chunks = a.n_chunks;  // whole PU groups (an ensemble's part ends on a whole group too)
+  const uint32_t W = a.tuple_words;
+  uint32_t n_chunks = a.n_chunks;  // whole PU groups (an ensemble's part ends on a whole group too)
   const bool slow = __builtin_amdgcn_readfirstlane((int)x.tile_flags[tile]) != 0;
   const uint4* img = slow ? x.img_slow : a.img;
+  uint32_t sp_pos = 0;
+  const uint64_t sp_row = tile0 + (uint64_t)tid;
+  if constexpr (SPLIT) {
+    constexpr uint32_t CPG = 8u / (uint32_t)CT;  // chunks per PU group (CT = 4: two, CT = 8: one)
+    const uint32_t groups_here = a.n_chunks / CPG, first = blockIdx.y * x.split_len;
+    n_chunks = (groups_here - first < x.split_len ? groups_here - first : x.split_len) * CPG;  // >= 1 group: the host launches ceil(real groups / split_len) slices
+    img += (size_t)first * CPG * (size_t)(GCHUNK / 16u);
+    sp_pos = x.group0 + first;
+  }
 
   dma_chunk<THREADS, CHUNK_BYTES>(img, 0, 0, tid);
   {  // the rank tile: one contiguous block of W * 2048 bytes (score_q16_kernel)
@@ -90,19 +104,21 @@ __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) voi
   double dacc[1] = {0.0};
   const uint32_t Cc = a.clusters, lane2 = (((uint32_t)tid & 511u) << 2) | (((uint32_t)tid >> 9) << 1);
   const uint32_t cm_lg = (uint32_t)__builtin_ctz(Cc | 0x100u), cm_real = x.real_groups;
-  uint32_t cm_groups = 0, cm_cluster = 0, cm_bound = (cm_real + Cc - 1u) >> cm_lg;
+  uint32_t cm_groups = 0, cm_cluster = 0, cm_bound = SPLIT ? 1u : (cm_real + Cc - 1u) >> cm_lg;
   float cm_total = 0.f;
-  if (x.group0) {
-    cm_groups = x.group0;
-    while (cm_cluster < Cc && cm_groups >= cm_bound) {
-      ++cm_cluster;
-      cm_bound += cm_cluster < Cc ? (cm_real + Cc - 1u - cm_cluster) >> cm_lg : 0u;
+  if constexpr (!SPLIT) {
+    if (x.group0) {
+      cm_groups = x.group0;
+      while (cm_cluster < Cc && cm_groups >= cm_bound) {
+        ++cm_cluster;
+        cm_bound += cm_cluster < Cc ? (cm_real + Cc - 1u - cm_cluster) >> cm_lg : 0u;
+      }
     }
-  }
-  if (x.state_in) {
-    const uint64_t r0 = tile0 + (uint64_t)tid;
-    ra.a[0][0] = x.state_in[r0];
-    cm_total = x.state_in[x.n_pad + r0];
+    if (x.state_in) {
+      const uint64_t r0 = tile0 + (uint64_t)tid;
+      ra.a[0][0] = x.state_in[r0];
+      cm_total = x.state_in[x.n_pad + r0];
+    }
   }
   const bool exact = a.sum_mode == 2u;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(img), 0, (int)(n_chunks * GCHUNK), 0x00020000);
@@ -160,7 +176,11 @@ __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) voi
         constexpr int PH = ((TOPWALK ? SG + (SGS == 1 ? BUF : 0) : DRAIN) + G) & 1;  // parity of sub-group s - G (s is even at every chunk pair and in front of the drain)
         fold_leaves<U, 1, 0>(lf, PH, 1u, ra, dacc, exact);
         if (PH == 1) {  // a PU group is complete
-          if (++cm_groups == cm_bound) {  // ... and it was its cluster's last
+          if constexpr (SPLIT) {  // the group's sum goes out as it is
+            a.out[(uint64_t)sp_pos * x.n_pad + sp_row] = ra.a[0][0];
+            ra.a[0][0] = 0.f;
+            ++sp_pos;
+          } else if (++cm_groups == cm_bound) {  // ... and it was its cluster's last
             cm_total = exact ? radd_exact(ra.a[0][0], cm_total) : ra.a[0][0] + cm_total;
             ra.a[0][0] = 0.f;
             ++cm_cluster;
@@ -250,6 +270,7 @@ __global__ __launch_bounds__(kQTile, ((D - K + 1) / 2 >= 3 || WIDE) ? 4 : 8) voi
   if (!slow) run(std::false_type{});
   else run(std::true_type{});
 
+  if constexpr (SPLIT) return;  // (every group's sum went out at its fold)
   // (the row index is recomputed here from an opaque copy of the thread id: kept across the walk it costs the 64th and 65th VGPR, i.e. a spill)
   uint32_t tid_end = (uint32_t)threadIdx.x;
   asm volatile("" : "+v"(tid_end));
@@ -277,6 +298,13 @@ static hipError_t launch_q16d(const ScoreArgs& a, const Variant& v, hipStream_t 
     if (e != hipSuccess) return e;
   }
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
+  if (x.split > 0u) {  // a small batch cut into slices of PU groups (launch_score decides; every deep kernel has the form)
+    auto ksplit = score_q16d_kernel<D, K, CT, WIDE, true>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ksplit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ksplit, dim3((uint32_t)tiles, x.split), dim3(kQTile), lds, s, a, x);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(kern, dim3((uint32_t)tiles), dim3(kQTile), lds, s, a, x);
   return hipGetLastError();
 }

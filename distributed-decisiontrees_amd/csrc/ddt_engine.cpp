@@ -278,9 +278,24 @@ struct SplitPlan {
 };
 static SplitPlan cluster_split_of(const ddt_engine* e, const Variant& v, const Ensemble& m, size_t n, bool reuse_prepass, bool all_classes) {
   SplitPlan sp;
-  if (!v.has_split() || e->q16_cluster_split == 0 || all_classes || reuse_prepass || e->num_classes > 1 || !m.parts.empty() || n == 0) return sp;
+  if (!v.has_split() || e->q16_cluster_split == 0 || all_classes || reuse_prepass || e->num_classes > 1 || n == 0) return sp;
+  if (!m.parts.empty() && !v.deep()) return sp;  // (parts: the deep kernels' cut form only -- every group's sum goes out, no state between the parts)
   if (e->p.sum_mode == 1u) return sp;  // (the fp64 sum runs in stream order over the trees: nothing to cut)
   const uint32_t C = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, real = (m.trees() + 7u) / 8u;
+  if (v.deep()) {  // always runs of PU groups, a partial sum per group of the image (its EMPTY padding groups included: a slice ends where its part's image ends)
+    const uint64_t tiles = (n + 1023) / 1024;
+    // (automatic: up to 160 tiles -- the cut form runs one block of 16 waves per CU and writes a partial sum per group: 512 x d12 at 64 tiles 273 against 586 us,
+    // at 256 tiles 624 against 610, profiles/r06_small_batches.md)
+    if (real < 2u || (e->q16_cluster_split < 0 && tiles > std::min<uint64_t>(e->q16_split_max_tiles, 160u))) return sp;
+    const uint32_t slots = 2u * (e->prop.multiProcessorCount > 0 ? (uint32_t)e->prop.multiProcessorCount : 256u);
+    uint32_t want = e->q16_split_groups > 0 ? (uint32_t)e->q16_split_groups : (uint32_t)(slots / tiles);
+    want = want > real ? real : want < 1u ? 1u : want;
+    sp.len = (real + want - 1u) / want;
+    sp.split = (real + sp.len - 1u) / sp.len;
+    sp.partials = m.img_chunks * (uint32_t)v.chunk_trees / 8u;
+    if (sp.split < 2u && m.parts.empty()) sp = SplitPlan();
+    return sp;
+  }
   const uint32_t gpc = (uint32_t)v.chunk_trees / 8u, chunks = (real + gpc - 1u) / gpc;  // PU groups per chunk; chunks that hold a real tree
   if (chunks < 2u || (C & (C - 1u)) != 0u) return sp;
   const uint64_t tiles = (n + 1023) / 1024;
@@ -369,6 +384,23 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
   }
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   hipError_t r = hipSuccess;
+  // a small batch: one block per (tile, slice of the image) instead of one per tile, then the adds in the reference's order (launch_cm_combine)
+  const SplitPlan sp = v.kind == kKindQ16 ? cluster_split_of(e, v, m, n, reuse_prepass, all_classes) : SplitPlan();
+  float* partials = nullptr;
+  if (sp.split) {
+    const uint64_t need = (uint64_t)sp.partials * qa.n_pad;
+    const int k = e->q_slot;
+    if (e->q_split_floats[k] < need) {
+      HIP_TRY(e, hipStreamSynchronize(s));  // (an earlier call on this stream may still read the old buffer)
+      if (e->q_split[k]) (void)hipFree(e->q_split[k]);
+      e->q_split[k] = nullptr;
+      e->q_split_floats[k] = 0;
+      HIP_TRY(e, hipMalloc(&e->q_split[k], need * sizeof(float)));
+      e->q_split_floats[k] = need;
+    }
+    partials = reinterpret_cast<float*>(e->q_split[k]);
+  }
+  const uint32_t clusters = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u;
   if (v.kind == kKindQ16 && !m.parts.empty()) {
     // the ensemble in parts: per part its rank pre-pass (the same workspace, stream order) and a scoring launch over its chunks of the
     // image; the reference-order sum is handed from launch to launch through the state workspace (Q16Aux)
@@ -397,6 +429,17 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
       qa.group0 = groups_before;
       qa.state_in = k > 0 ? state : nullptr;
       qa.state_out = k + 1 < m.parts.size() ? state : nullptr;
+      if (sp.split) {  // cut (deep kernels): every group's sum to its place among the ensemble's, no state between the parts
+        const uint32_t here = part.chunks * (uint32_t)v.chunk_trees / 8u, real_here = qa.real_groups > groups_before ? std::min(here, qa.real_groups - groups_before) : 0u;
+        qa.state_in = qa.state_out = nullptr;
+        qa.split_len = sp.len;
+        qa.split = (real_here + sp.len - 1u) / sp.len;
+        a.out = partials;
+        if (!qa.split) {  // (a part of EMPTY padding only)
+          groups_before += here;
+          continue;
+        }
+      }
       const uint32_t sgs_before = part.chunk_begin * (uint32_t)v.chunk_trees / (uint32_t)v.ilp_trees;
       qa.walk_subgroups = (walk_all > sgs_before) ? walk_all - sgs_before : 0u;  // (0 = everything: only the last part has padding)
       if (k + 1 < m.parts.size()) qa.walk_subgroups = 0u;
@@ -406,26 +449,15 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
       e->st.kernel_launches++;
     }
     e->q_xT_valid[e->q_slot] = xT_valid && r == hipSuccess;
-    if (r == hipSuccess) e->st.kernel_launches--;  // (counted once more below)
-  } else if (const SplitPlan sp = cluster_split_of(e, v, m, n, reuse_prepass, all_classes); sp.split) {
-    // a small batch: one block per (tile, slice of the image) instead of one per tile, then the adds in the reference's order
-    const uint64_t need = (uint64_t)sp.partials * qa.n_pad;
-    const int k = e->q_slot;
-    if (e->q_split_floats[k] < need) {
-      HIP_TRY(e, hipStreamSynchronize(s));  // (an earlier call on this stream may still read the old buffer)
-      if (e->q_split[k]) (void)hipFree(e->q_split[k]);
-      e->q_split[k] = nullptr;
-      e->q_split_floats[k] = 0;
-      HIP_TRY(e, hipMalloc(&e->q_split[k], need * sizeof(float)));
-      e->q_split_floats[k] = need;
-    }
+    if (r == hipSuccess && sp.split) r = launch_cm_combine(partials, (size_t)qa.n_pad, n, qa.real_groups, clusters, true, true, d_scores, e->p.sum_mode == 2, s);
+    else if (r == hipSuccess) e->st.kernel_launches--;  // (counted once more below)
+  } else if (sp.split) {
     qa.split = sp.split;
     qa.split_len = sp.len;
-    a.out = reinterpret_cast<float*>(e->q_split[k]);
+    a.out = partials;
     r = v.launch(a, v, s);
     if (r == hipSuccess) {
-      r = launch_cm_combine(a.out, (size_t)qa.n_pad, n, qa.real_groups, e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, sp.len != 0u, v.cm(), d_scores,
-                            e->p.sum_mode == 2, s);
+      r = launch_cm_combine(partials, (size_t)qa.n_pad, n, qa.real_groups, clusters, sp.len != 0u, v.cm(), d_scores, e->p.sum_mode == 2, s);
       e->st.kernel_launches++;
     }
   } else {

@@ -117,7 +117,8 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   // small batches on a "_cm_x" kernel (Variant::has_split): split > 1 = the launch is cut into `split` slices of the image -- grid (tiles, split),
   // ScoreArgs::out = a workspace of partial sums [positions][n_pad], added in the reference's order by launch_cm_combine behind the launch:
   //   split_len == 0: a slice = a cluster (split = min(clusters, PU groups that hold a real tree)), one partial per cluster (its accumulator)
-  //   split_len  > 0: a slice = split_len consecutive chunks (split = ceil(real_groups / split_len)), one partial per PU group (its reduce tree)
+  //   split_len  > 0: a slice = split_len consecutive chunks -- deep kernels: PU groups, two chunks each at CT = 4 -- (split = ceil(real chunks /
+  //                   split_len)), one partial per PU group (its reduce tree); deep kernels: at position group0 + the group's place in this launch's image
   uint32_t split = 0, split_len = 0;
 };
 constexpr uint32_t kQ16TileCounterWords = 2;  // behind the kQ16GroupedCounters 8-byte counters
@@ -259,7 +260,9 @@ struct Variant {
   // the plain rank-quantised kernels the automatic choice takes ("q16_d8_c8_u4_gl_s2_cm_x", its wide form, "q16_d{5,6,7}_*_s2", "q16_d{3,4}_*")
   // have a second instantiation whose grid is cut into slices of the image (Q16Aux::split): what launch_score gives a batch of a few tiles
   bool has_split() const {
-    if (kind != kKindQ16 || (opt & (8 | 32)) != 0 || chunk_trees % 8 != 0) return false;          // (not the persistent "_p" form, not the deep kernels)
+    if (kind != kKindQ16 || (opt & 8) != 0) return false;                                          // (not the persistent "_p" form)
+    if (opt & 32) return true;                                                                      // the deep kernels: all of them (launch_q16d)
+    if (chunk_trees % 8 != 0) return false;
     return levels == 8 ? (opt & 4) != 0 : levels >= 5 ? (opt & 2) != 0 : levels >= 3;               // = the instantiations of launch_q16 (ddt_kernels.hip)
   }
   bool cm() const { return kind == kKindQ16 && (opt & 4) != 0; }                                    // cluster-major image

@@ -845,7 +845,7 @@ static hipError_t launch_q16(const ScoreArgs& a, const Variant& v, hipStream_t s
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
   // the cut launch of a small batch (launch_score decides; the same predicate as Variant::has_split): the kernels the automatic choice takes
   if constexpr (D == 8 ? (OPT & 4) != 0 : D >= 5 ? (OPT & 2) != 0 : true) {
-    if (x.split > 1u) {  // (slices: clusters, or runs of split_len chunks)
+    if (x.split > 0u) {  // (slices: clusters, or runs of split_len chunks)
       auto ksplit = score_q16_kernel<D, CT, U, OPT | 128>;
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(ksplit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;

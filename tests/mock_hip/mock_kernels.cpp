@@ -197,7 +197,7 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
           if (x.seg_chunks - chunk == x.seg_tail_left && in_seg % CT >= 4u) img_order[t] = 0.0f;
         }
       }
-      if (x.split > 1u) {
+      if (x.split > 0u) {
         // a small batch cut into slices of the image (csrc/ddt_kernels.hip score_q16_kernel SPLIT): every slice is a block that starts from a zero
         // accumulator and lets it out -- at its end when the slices are the clusters of a cluster-major image (split_len == 0), at every PU
         // group otherwise (a slice = split_len chunks; the partial sum's position = the group's place in the image); the adds follow in
@@ -210,10 +210,14 @@ hipError_t launch_q16(const ScoreArgs& args, const Variant& var, hipStream_t s) 
           const float* l = img_order.data() + g * 8u;
           return add(add(add(l[0], l[1]), add(l[2], l[3])), add(add(l[4], l[5]), add(l[6], l[7])));
         };
-        const uint32_t Cc = a.clusters, real = x.real_groups, gpc = CT / 8u, real_chunks = (real + gpc - 1u) / gpc;
-        uint32_t first = 0;  // chunk
+        const uint32_t Cc = a.clusters, real = x.real_groups, gpc = std::max(CT / 8u, 1u), real_chunks = (real + gpc - 1u) / gpc;
+        uint32_t first = 0;  // chunk (deep kernels: PU group)
         for (uint32_t sl = 0; sl < x.split; ++sl) {
-          if (x.split_len) {
+          if (x.split_len && v.deep()) {  // slices of PU groups of THIS launch's image (a part of the ensemble: its groups follow group0 others)
+            const uint32_t len = std::min(x.split_len, a.n_trees / 8u - first);
+            for (uint32_t g = first; g < first + len; ++g) a.out[(size_t)(x.group0 + g) * x.n_pad + i] = add(group_sum(g), 0.0f);
+            first += len;
+          } else if (x.split_len) {
             const uint32_t len = std::min(x.split_len, real_chunks - first);
             for (uint32_t g = first * gpc; g < (first + len) * gpc; ++g) a.out[(size_t)g * x.n_pad + i] = add(group_sum(g), 0.0f);
             first += len;

@@ -822,16 +822,21 @@ def test_deep_perfect_trees_on_the_deep_kernels(mock, T, D, F, clusters, name, p
         _load(mock, e, m, ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), None)
         assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode() == name and info.fallback_kernel == 0
         want = O.score_fast(m, x, sum_mode=ref)
-        assert mock.ddt_get_stats(e, C.byref(st)) == 0
-        before = st.kernel_launches
         s = _stream(mock)
-        outs = [np.full(n, np.nan, np.float32) for _ in range(2)]
-        for out in outs:
-            assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0, mock.ddt_last_error(e)
-        assert mock.hipStreamSynchronize(s) == 0
-        for out in outs:
-            assert np.array_equal(_bits(out), _bits(want)), (T, D, clusters, sum_mode)
-        assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.kernel_launches - before == 2 * parts
+        # uncut (one block per tile, the sum's state handed from part to part), and cut into runs of PU groups as a batch this small is by itself:
+        # every group's sum goes out, the parts need no state, one combine behind the last part (csrc/ddt_deep.hip SPLIT)
+        for split, groups, launches in ((0, -1, parts), (-1, -1, parts + 1 if T > 8 else parts), (1, 2, parts + 1 if T > 8 else parts), (1, 1000, parts + 1 if T > 8 else parts)):
+            assert mock.ddt_set_option(e, b"q16_cluster_split", split) == 0 and mock.ddt_set_option(e, b"q16_split_groups", groups) == 0
+            assert mock.ddt_get_stats(e, C.byref(st)) == 0
+            before = st.kernel_launches
+            outs = [np.full(n, np.nan, np.float32) for _ in range(2)]
+            for out in outs:
+                assert mock.ddt_score_device(e, x.ctypes.data, n, out.ctypes.data, s) == 0, mock.ddt_last_error(e)
+            assert mock.hipStreamSynchronize(s) == 0
+            for out in outs:
+                assert np.array_equal(_bits(out), _bits(want)), (T, D, clusters, sum_mode, split, groups)
+            assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.kernel_launches - before == 2 * launches, (split, groups)
+        assert mock.ddt_set_option(e, b"q16_cluster_split", -1) == 0 and mock.ddt_set_option(e, b"q16_split_groups", -1) == 0
         host = np.full(n, np.nan, np.float32)
         assert mock.ddt_set_option(e, b"feeder_rows", 512) == 0
         assert mock.ddt_score(e, x.ctypes.data, n, host.ctypes.data) == 0 and np.array_equal(_bits(host), _bits(want))

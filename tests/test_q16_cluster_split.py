@@ -142,3 +142,36 @@ def test_a_small_batch_is_faster_cut():
     assert np.array_equal(_bits(res[0]), _bits(res[-1]))
     assert med[-1] < 0.35 * med[0], med
     e.close()
+
+
+@pytest.mark.parametrize("T,D,F,clusters,name", [(512, 12, 32, 4, "q16d_d12_k9_c4_u4_cm"), (70, 12, 3, 8, "q16d_d12_k9_c4_u4_cm"), (100, 10, 28, 1, "q16d_d10_k9_c4_u4_cm"),
+                                                  (90, 11, 20, 8, "q16d_d11_k8_c8_u4_cm"), (130, 9, 32, 2, "q16d_d9_k8_c8_u4_cm"), (40, 14, 16, 2, "q16d_d14_k9_c4_u4_cm"),
+                                                  (64, 12, 48, 4, "q16dw_d12_k9_c4_u4_cm")])
+def test_cut_launch_on_the_deep_kernels(T, D, F, clusters, name):
+    """The deep kernels (depth 9-15, csrc/ddt_deep.hip SPLIT): slices of PU groups, every group's sum out at group0 + its place in the launch's
+    image, one combine behind the last launch -- also for an ensemble scored in PARTS (512 x d12 x 32 is three, 70 x d12 x 3 four: more than
+    32767 thresholds per feature), whose parts then hand no state from launch to launch.  Oracle's bits, both adders, the uncut launch beside it."""
+    import torch
+
+    m = O.gen_model(T, D, F, dist=0, clusters=clusters)
+    e = ddt.Engine(0)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        e.load_model(ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode), m.wlines, m.flines)
+        assert e.info().variant_name.decode() == name
+        for n, holes in ((1, 0), (1500, 2), (9000, 4)):
+            x = _tuples(n, F, 13 + n % 100, holes)
+            d = torch.from_numpy(x.view(np.int32)).cuda()
+            want = O.score_fast(m, x, sum_mode=ref)
+            launches = {}
+            for split, groups in ((0, -1), (-1, -1), (1, 2), (1, 3), (1, 1000)):
+                e.set_option("q16_cluster_split", split)
+                e.set_option("q16_split_groups", groups)
+                before = e.stats().kernel_launches
+                got = [e.score_device(d) for _ in range(2)]
+                torch.cuda.synchronize()
+                launches[(split, groups)] = (e.stats().kernel_launches - before) // 2
+                for g in got:
+                    bad = np.flatnonzero(_bits(g.cpu().numpy()) != _bits(want))
+                    assert bad.size == 0, (name, T, clusters, sum_mode, n, split, groups, bad[:8], bad.size)
+            assert all(v == launches[(0, -1)] + 1 for k, v in launches.items() if k != (0, -1)), launches   # the parts' launches + one combine
+    e.close()
