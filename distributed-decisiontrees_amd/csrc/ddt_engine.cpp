@@ -386,9 +386,26 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
   hipError_t r = hipSuccess;
   // a small batch: one block per (tile, slice of the image) instead of one per tile, then the adds in the reference's order (launch_cm_combine)
   const SplitPlan sp = v.kind == kKindQ16 ? cluster_split_of(e, v, m, n, reuse_prepass, all_classes) : SplitPlan();
+  // ... and the one-launch multi-class kernel ("_p": ONE block per tile walks every class): the plain kernel's cut form over the same image -- the
+  // classes stand back to back in it, each cluster-major -- with a partial sum per PU group, the combine per class, then the argmax
+  SplitPlan mcp;
+  const int ix = all_classes ? find_variant("q16_d8_c8_u4_gl_s2_cm_x") : -1;
+  if (ix >= 0 && e->q16_cluster_split != 0 && e->p.sum_mode != 1u && n > 0 && (v.opt & 64) == 0 && variant(ix).has_split()) {
+    const uint64_t tiles = (n + 1023) / 1024;
+    const uint32_t chunks = e->mc_seg_chunks * e->num_classes;
+    // (automatic: up to 160 tiles -- a partial sum per PU group of every class: 10 x 100 trees at 64 tiles 150 against 392 us, at 256 tiles 435 against 417)
+    if (e->q16_cluster_split > 0 || tiles <= std::min<uint64_t>(e->q16_split_max_tiles, 160u)) {
+      const uint32_t slots = 2u * (e->prop.multiProcessorCount > 0 ? (uint32_t)e->prop.multiProcessorCount : 256u);
+      uint32_t want = e->q16_split_groups > 0 ? (uint32_t)e->q16_split_groups : (uint32_t)(slots / tiles);
+      want = want > chunks ? chunks : want < 1u ? 1u : want;
+      mcp.len = (chunks + want - 1u) / want;
+      mcp.split = (chunks + mcp.len - 1u) / mcp.len;
+      mcp.partials = chunks + e->num_classes;  // (+ the class sums of a caller that asked for labels only)
+    }
+  }
   float* partials = nullptr;
-  if (sp.split) {
-    const uint64_t need = (uint64_t)sp.partials * qa.n_pad;
+  if (sp.split || mcp.split) {
+    const uint64_t need = (uint64_t)(sp.split ? sp.partials : mcp.partials) * qa.n_pad;
     const int k = e->q_slot;
     if (e->q_split_floats[k] < need) {
       HIP_TRY(e, hipStreamSynchronize(s));  // (an earlier call on this stream may still read the old buffer)
@@ -451,6 +468,29 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     e->q_xT_valid[e->q_slot] = xT_valid && r == hipSuccess;
     if (r == hipSuccess && sp.split) r = launch_cm_combine(partials, (size_t)qa.n_pad, n, qa.real_groups, clusters, true, true, d_scores, e->p.sum_mode == 2, s);
     else if (r == hipSuccess) e->st.kernel_launches--;  // (counted once more below)
+  } else if (mcp.split) {
+    const Variant& vx = variant(ix);
+    const uint32_t chunks = e->mc_seg_chunks * e->num_classes;
+    qa.real_groups = chunks;  // (the kernel's slices end with the image: every class's EMPTY padding groups are walked and never read)
+    qa.n_segs = 1;
+    qa.seg_chunks = 0;
+    qa.labels = nullptr;
+    qa.seg_tail_left = 0;
+    qa.walk_subgroups = 0;
+    qa.split = mcp.split;
+    qa.split_len = mcp.len;
+    a.out = partials;
+    r = vx.launch(a, vx, s);
+    float* cs = d_scores ? d_scores : partials + (size_t)chunks * qa.n_pad;
+    const size_t cs_pitch = d_scores ? n : (size_t)qa.n_pad;
+    if (r == hipSuccess) {
+      r = launch_cm_combine(partials, (size_t)qa.n_pad, n, (m.trees() + 7u) / 8u, clusters, true, true, cs, e->p.sum_mode == 2, s, e->num_classes, e->mc_seg_chunks, cs_pitch);
+      e->st.kernel_launches++;
+    }
+    if (r == hipSuccess && labels) {
+      r = launch_argmax_strided(cs, e->num_classes, cs_pitch, n, labels, s);
+      e->st.kernel_launches++;
+    }
   } else if (sp.split) {
     qa.split = sp.split;
     qa.split_len = sp.len;

@@ -343,8 +343,9 @@ int num_sparse_r_variants();               // ddt_sparse_r.hip: and these last
 const Variant& sparse_r_variant(int i);
 hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint64_t n_pad, uint32_t* xT, hipStream_t s);  // ddt_prepass.hip
 
+// n_classes > 1: the classes of a one-vs-all model, class_positions partial sums each, class k's sum to out[k * out_pitch + row]
 hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, bool cm_order, float* out,
-                             bool exact /* sum_mode 2 */, hipStream_t s);
+                             bool exact /* sum_mode 2 */, hipStream_t s, uint32_t n_classes = 1, uint32_t class_positions = 0, size_t out_pitch = 0);
 hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, float* out, bool exact /* sum_mode 2 */, hipStream_t s,
                             size_t pitch = 0 /* elements between the partial vectors; 0 = n */);
 hipError_t launch_argmax(const float* scores, uint32_t K, size_t n, int32_t* labels, hipStream_t s);

@@ -1338,7 +1338,11 @@ __global__ __launch_bounds__(256) void chain_sum_kernel(const float* __restrict_
 // independent, coalesced loads in flight, then their adds in order -- and leaves the accumulators in LDS; wave 0 adds them in cluster order.
 // (One thread per tuple walking 125 dependent global loads took 31 us for a single tile; staged through LDS by a loop hipcc did not unroll 16.)
 __global__ __launch_bounds__(256) void cm_combine_kernel(const float* __restrict__ parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters,
-                                                         uint32_t per_group, uint32_t cm_order, float* __restrict__ out, const bool exact) {
+                                                         uint32_t per_group, uint32_t cm_order, float* __restrict__ out, const bool exact,
+                                                         uint32_t class_positions, size_t out_pitch) {
+  // blockIdx.y = class of a one-vs-all model whose classes stand back to back in the image (class_positions partial sums each): its sum to out[class][row]
+  parts += (size_t)blockIdx.y * class_positions * pitch;
+  out += (size_t)blockIdx.y * out_pitch;
   extern __shared__ float cacc_dyn[];  // [8][64]: clusters_per_tuple is 1, 2, 4 or 8 (ddt_model.cpp); dynamic like every LDS byte of this library (tests/test_abi_host.py)
   float (*cacc)[64] = reinterpret_cast<float (*)[64]>(cacc_dyn);
   const uint32_t r = threadIdx.x & 63u, q = threadIdx.x >> 6;
@@ -1377,12 +1381,13 @@ __global__ __launch_bounds__(256) void cm_combine_kernel(const float* __restrict
 }
 
 hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, bool cm_order, float* out,
-                             bool exact, hipStream_t s) {
+                             bool exact, hipStream_t s, uint32_t n_classes, uint32_t class_positions, size_t out_pitch) {
   if (n == 0) return hipSuccess;
   (void)hipGetLastError();
   const size_t blocks = (n + 63) / 64;
-  if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(cm_combine_kernel, dim3((uint32_t)blocks), dim3(256), 8 * 64 * sizeof(float), s, parts, pitch, n, real_groups, clusters, per_group ? 1u : 0u, cm_order ? 1u : 0u, out, exact);
+  if (blocks > 0x7FFFFFFFull || n_classes == 0u || n_classes > 65535u) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cm_combine_kernel, dim3((uint32_t)blocks, n_classes), dim3(256), 8 * 64 * sizeof(float), s, parts, pitch, n, real_groups, clusters, per_group ? 1u : 0u,
+                     cm_order ? 1u : 0u, out, exact, class_positions, out_pitch);
   return hipGetLastError();
 }
 

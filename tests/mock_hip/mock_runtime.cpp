@@ -680,12 +680,15 @@ hipError_t launch_chain_sum(const float* parts, uint32_t n_parts, size_t n, floa
   return hipSuccess;
 }
 
-hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, bool cm_order, float* out,
-                             bool exact, hipStream_t s) {
+hipError_t launch_cm_combine(const float* parts0, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, bool cm_order, float* out0,
+                             bool exact, hipStream_t s, uint32_t n_classes, uint32_t class_positions, size_t out_pitch) {
   Op* op = new Op();
-  op->cost = (double)n * (per_group ? real_groups : clusters) * g_cost_copy;
+  op->cost = (double)n * (per_group ? real_groups : clusters) * g_cost_copy * n_classes;
   op->run = [=] {
+    for (uint32_t k = 0; k < n_classes; ++k)   // (the classes of a one-vs-all model: class_positions partial sums each, class k's sum to out[k][row])
     for (size_t i = 0; i < n; ++i) {
+      const float* parts = parts0 + (size_t)k * class_positions * pitch;
+      float* out = out0 + (size_t)k * out_pitch;
       volatile float total = 0.0f;
       uint32_t pos = 0;
       for (uint32_t c = 0; c < clusters; ++c) {  // per cluster acc <- p + acc (FPAggregator.v:79-131), then total <- acc + total (Core.sv:486-541)

@@ -1180,3 +1180,33 @@ def test_small_batch_is_cut_at_the_clusters(mock, T, clusters):
     assert mock.ddt_score(e, x.ctypes.data, 3000, out.ctypes.data) == 0, mock.ddt_last_error(e)
     assert np.array_equal(_bits(out), _bits(O.score(m, x, sum_mode=O.SUM_REF_FLOPOCO)))
     mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("T,K,clusters", [(1000, 10, 1), (300, 3, 2), (48, 3, 1), (210, 7, 4)])
+def test_small_multiclass_batch_is_cut_over_all_classes(mock, T, K, clusters):
+    """The one-launch multi-class kernel ("_p": ONE block per tile walks every class) on a batch of a few tiles: the plain kernel's cut form over the
+    same image -- the classes stand back to back in it -- with a partial sum per PU group, the combine per class in the reference's order, then the
+    argmax: sums and labels equal the uncut launch's and the oracle's bit for bit, in both adders, also for a caller that asks for labels only."""
+    mock.mock_reset(1, 3, 8)
+    D, F = 8, 12
+    m = O.gen_model(T, D, F, 1, clusters=clusters)
+    e, st, s = _engine(mock), ddt.Stats(), _stream(mock)
+    null = C.c_void_p(None)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        p = ddt.make_params(T, D, F, clusters=clusters, sum_mode=sum_mode)
+        assert mock.ddt_set_option(e, b"variant", _variant(mock, "q16_d8_c8_u4_gl_s2_cm_p")) == 0
+        assert mock.ddt_load_model_multiclass(e, C.byref(p), m.wlines.ctypes.data, m.wlines.size // 4, m.flines.ctypes.data, m.flines.size // 8, K, 1, 0, 1) == 0
+        for n in (3, 2500):
+            x = O.gen_tuples(2, n, F, 1)
+            labels, cs = O.classify(m, x, K, sum_mode=ref)
+            for split, groups, launches in ((0, -1, 1), (-1, -1, 3), (1, 4, 3), (1, 60000, 3)):
+                assert mock.ddt_set_option(e, b"q16_cluster_split", split) == 0 and mock.ddt_set_option(e, b"q16_split_groups", groups) == 0
+                assert mock.ddt_get_stats(e, C.byref(st)) == 0
+                before = st.kernel_launches
+                gs, gl, gl2 = np.full((K, n), np.nan, np.float32), np.full(n, -1, np.int32), np.full(n, -1, np.int32)
+                assert mock.ddt_classify_device(e, x.ctypes.data, n, gs.ctypes.data, gl.ctypes.data, s) == 0, mock.ddt_last_error(e)
+                assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.kernel_launches - before == launches, (split, groups)
+                assert mock.hipStreamSynchronize(s) == 0
+                assert mock.ddt_classify(e, x.ctypes.data, n, gl2.ctypes.data, null) == 0, mock.ddt_last_error(e)             # host buffers, labels only
+                assert np.array_equal(_bits(gs), _bits(cs)) and np.array_equal(gl, labels) and np.array_equal(gl2, labels), (T, K, clusters, sum_mode, n, split, groups)
+    mock.ddt_destroy(e)

@@ -175,3 +175,34 @@ def test_cut_launch_on_the_deep_kernels(T, D, F, clusters, name):
                     assert bad.size == 0, (name, T, clusters, sum_mode, n, split, groups, bad[:8], bad.size)
             assert all(v == launches[(0, -1)] + 1 for k, v in launches.items() if k != (0, -1)), launches   # the parts' launches + one combine
     e.close()
+
+
+@pytest.mark.parametrize("T,K,inter", [(1000, 10, True), (48, 3, False), (210, 7, True)])
+def test_cut_launch_over_the_classes_of_a_one_vs_all_model(T, K, inter):
+    """BASELINE config 5's kernel ("_p": one block per tile walks every class) on batches of a few tiles: the plain kernel's cut form over the same
+    image, the combine per class, the argmax -- sums and labels equal the uncut launch's and the oracle's, both adders."""
+    import torch
+
+    D, F = 8, 32
+    C = ddt.default_clusters(T // K)
+    m = O.gen_model(T, D, F, dist=1, clusters=C)
+    e = ddt.Engine(0)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        e.set_option("variant", -1)
+        e.load_model_multiclass(ddt.make_params(T, D, F, clusters=C, sum_mode=sum_mode), m.wlines, m.flines, K, inter)
+        e.set_option("variant", ddt.variant_names().index("q16_d8_c8_u4_gl_s2_cm_p"))
+        assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_p"
+        for n, holes in ((1, 0), (1500, 2), (50_000, 6)):
+            x = _tuples(n, F, 17 + n % 100, holes)
+            d = torch.from_numpy(x.view(np.int32)).cuda()
+            want_l, want_cs = O.classify_fast(m, x, K, inter, sum_mode=ref)
+            for split, groups, launches in ((0, -1, 1), (-1, -1, 3), (1, 3, 3), (1, 60000, 3)):
+                e.set_option("q16_cluster_split", split)
+                e.set_option("q16_split_groups", groups)
+                before = e.stats().kernel_launches
+                labels, cs = e.classify_device(d)
+                torch.cuda.synchronize()
+                assert e.stats().kernel_launches - before == launches, (split, groups, n)
+                assert np.array_equal(labels.cpu().numpy(), want_l), (T, K, sum_mode, n, split, groups)
+                assert np.array_equal(_bits(cs.cpu().numpy()), _bits(want_cs)), (T, K, sum_mode, n, split, groups)
+    e.close()

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "distributed-decisiontrees_amd"))
 sys.path.insert(0, ROOT)
 
-SHAPES = {3: (1000, 8, 32), 2: (100, 6, 28), 6: (512, 12, 32), 4: (512, 16, 64), 1: (8, 4, 16),
+SHAPES = {3: (1000, 8, 32), 2: (100, 6, 28), 6: (512, 12, 32), 4: (512, 16, 64), 1: (8, 4, 16), 5: (1000, 8, 32),   # 5: 10 classes x 100 trees, classified
           # not BASELINE configs: 1000 trees at XGBoost's default depth, and shallow / odd depths
           106: (1000, 6, 28), 107: (500, 7, 32), 104: (2000, 4, 16)}
 
@@ -47,6 +47,9 @@ def main():
             lines, first = ddt.synth_sparse_model(T, D, F, 8, 700, 0)
             params = ddt.make_sparse_params(T, D, F)
             eng.load_model_sparse(params, lines, first)
+        elif cfg == 5:
+            w, f = ddt.synth_model(T, D, F, 0)
+            eng.load_model_multiclass(ddt.make_params(T, D, F, clusters=ddt.default_clusters(T // 10)), w, f, 10, True)
         else:
             w, f = ddt.synth_model(T, D, F, 0)
             params = ddt.make_params(T, D, F)
@@ -62,20 +65,31 @@ def main():
 
             ncheck = min(nmax, 16384)
             x = tuples[:ncheck].cpu().numpy().view(np.uint32)
-            if cfg == 4:
+            if cfg == 5:
+                ref = None   # (labels and class sums: tests/test_q16_cluster_split.py)
+            elif cfg == 4:
                 ref = O.score_sparse_fast(O.SparseModel(O.make_sparse_params(T, D, F), lines, first), x)
             else:
                 ref = O.score_fast(O.Model(O.make_params(T, D, F), w, f), x)
+        cls = torch.empty((10, nmax), dtype=torch.float32, device=tuples.device) if cfg == 5 else None
+        lab = torch.empty(nmax, dtype=torch.int32, device=tuples.device) if cfg == 5 else None
+
+        def call(t_in, o, n):
+            if cfg == 5:
+                eng.classify_device(t_in, class_scores=cls.view(-1)[: 10 * n].view(10, n), labels=lab[:n])
+            else:
+                eng.score_device(t_in, out=o)
+
         for n in rows:
             t_in = tuples[:n]
             o = out[:n]
             for _ in range(5):
-                eng.score_device(t_in, out=o)
+                call(t_in, o, n)
             torch.cuda.synchronize()
             ts = []
             for _ in range(args.reps):
                 t0 = time.perf_counter()
-                eng.score_device(t_in, out=o)
+                call(t_in, o, n)
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t0) * 1e6)
             ts.sort()
