@@ -276,6 +276,9 @@ struct SplitPlan {
   uint32_t split = 0, len = 0;  // slices; chunks per slice (0: the slices are the clusters)
   uint32_t partials = 0;        // partial sums per tuple
 };
+// a partial sum per PU group costs 4 B x groups per tuple of workspace (and of traffic each way): no such plan beyond this many bytes per call
+constexpr uint64_t kSplitWorkspaceCap = 256ull << 20;
+static bool split_fits(uint32_t partials, size_t n) { return (uint64_t)partials * ((n + 1023) / 1024 * 1024) * 4ull <= kSplitWorkspaceCap; }
 static SplitPlan cluster_split_of(const ddt_engine* e, const Variant& v, const Ensemble& m, size_t n, bool reuse_prepass, bool all_classes) {
   SplitPlan sp;
   if (!v.has_split() || e->q16_cluster_split == 0 || all_classes || reuse_prepass || e->num_classes > 1 || n == 0) return sp;
@@ -293,7 +296,7 @@ static SplitPlan cluster_split_of(const ddt_engine* e, const Variant& v, const E
     sp.len = (real + want - 1u) / want;
     sp.split = (real + sp.len - 1u) / sp.len;
     sp.partials = m.img_chunks * (uint32_t)v.chunk_trees / 8u;
-    if (sp.split < 2u && m.parts.empty()) sp = SplitPlan();
+    if ((sp.split < 2u && m.parts.empty()) || !split_fits(sp.partials, n)) sp = SplitPlan();
     return sp;
   }
   const uint32_t gpc = (uint32_t)v.chunk_trees / 8u, chunks = (real + gpc - 1u) / gpc;  // PU groups per chunk; chunks that hold a real tree
@@ -310,7 +313,7 @@ static SplitPlan cluster_split_of(const ddt_engine* e, const Variant& v, const E
       sp.len = (chunks + want - 1u) / want;
       sp.split = (chunks + sp.len - 1u) / sp.len;
       sp.partials = chunks * gpc;
-      if (sp.split >= 2u) return sp;
+      if (sp.split >= 2u && split_fits(sp.partials, n)) return sp;
       sp = SplitPlan();
     }
   }
@@ -401,6 +404,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
       mcp.len = (chunks + want - 1u) / want;
       mcp.split = (chunks + mcp.len - 1u) / mcp.len;
       mcp.partials = chunks + e->num_classes;  // (+ the class sums of a caller that asked for labels only)
+      if (!split_fits(mcp.partials, n)) mcp = SplitPlan();
     }
   }
   float* partials = nullptr;
@@ -408,7 +412,7 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
     const uint64_t need = (uint64_t)(sp.split ? sp.partials : mcp.partials) * qa.n_pad;
     const int k = e->q_slot;
     if (e->q_split_floats[k] < need) {
-      HIP_TRY(e, hipStreamSynchronize(s));  // (an earlier call on this stream may still read the old buffer)
+      HIP_TRY(e, hipDeviceSynchronize());  // (earlier calls, on whatever stream, may still read the old buffer: as ensure_q16_workspace)
       if (e->q_split[k]) (void)hipFree(e->q_split[k]);
       e->q_split[k] = nullptr;
       e->q_split_floats[k] = 0;
