@@ -278,7 +278,10 @@ __device__ __forceinline__ u32x4 rank_line(const uint32_t par, const uint32_t P,
 
 constexpr int kFusedThreads = 1024;  // two tiles per block and pass; 16 waves x 8 independent searches hide the LDS latency
 
-template <bool IEEE>
+// GRAB = units (64 lanes x 2 rows) a wave takes per ticket: 4 for the batches the throughput figures are taken on (one ticket per unit made 781 k
+// same-address atomics per 100 M rows the bottleneck), 1 for a batch of a few tiles -- at 4 a single tile keeps TWO of a block's 16 waves busy, eight
+// load -> rank rounds each: 21 us of a 47 us call (profiles/r06_small_batches.md)
+template <bool IEEE, int GRAB = 4>
 __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
                                                                    const uint4* __restrict__ img_base, const PrepassPlan pl, uint32_t parts,
                                                                    uint32_t miss_raw, uint32_t ieee, uint32_t* __restrict__ q32,
@@ -342,13 +345,13 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
   const unsigned long long units = (unsigned long long)tiles * 8u;
   for (;;) {
     unsigned long long u0 = 0;
-    if ((tid & 63u) == 0u) u0 = atomicAdd(work_counter, 4ull);
+    if ((tid & 63u) == 0u) u0 = atomicAdd(work_counter, (unsigned long long)GRAB);
     u0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u0 >> 32)) << 32) |
          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u0);
     if (u0 >= units) break;
     const uint64_t tile = (u0 >> 3) * parts + part;
     bool miss = false;
-    for (uint32_t k = 0; k < 4u; ++k) {
+    for (uint32_t k = 0; k < (uint32_t)GRAB; ++k) {
       const uint32_t lt = ((((uint32_t)u0 & 7u) + k) << 6) | (tid & 63u);
 #pragma unroll
       for (uint32_t g = 0; g < 2u; ++g) {
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_rank_kernel(const uint32_
 // lane in flight -- measured SLOWER, 7.3 vs 5.7 ms at 1000 trees: every 16-byte load pulls a whole line into the L2 the
 // groups share, and the footprint in flight then exceeds it.)
 // ---------------------------------------------------------------------------------------------------
-template <int L, bool IEEE>
+template <int L, bool IEEE, int GRAB = 4>  // GRAB: fused_rank_kernel
 __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint32_t* __restrict__ tuples, uint64_t n, uint64_t n_pad, uint32_t W,
                                                                      const uint4* __restrict__ img_base, const PrepassPlan pl, uint32_t parts,
                                                                      uint32_t miss_raw, uint32_t ieee, uint32_t* __restrict__ q32,
@@ -427,19 +430,19 @@ __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint3
 
   for (;;) {
     unsigned long long u0 = 0;
-    if (lane == 0u) u0 = atomicAdd(counter, 4ull);
+    if (lane == 0u) u0 = atomicAdd(counter, (unsigned long long)GRAB);
     u0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u0 >> 32)) << 32) |
          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u0);
     if (u0 >= units) break;
     const uint64_t tile = (u0 >> 3) * parts + part;
-    const uint32_t lt0 = (((uint32_t)u0 & 7u) << 6) | lane;  // the 4 units of this grab: lt0, lt0 + 64, .. + 192 (< 512)
+    const uint32_t lt0 = (((uint32_t)u0 & 7u) << 6) | lane;  // the GRAB units of this grab: lt0, lt0 + 64, .. (< 512)
     bool miss = false;
     u32x4 cur[L][2], nxt[L][2];
     load_unit(cur, tile, lt0);
 #pragma unroll
-    for (uint32_t k = 0; k < 4u; ++k) {
+    for (uint32_t k = 0; k < (uint32_t)GRAB; ++k) {
       const uint32_t lt = lt0 + 64u * k;
-      if (k + 1u < 4u) load_unit(nxt, tile, lt + 64u);
+      if (k + 1u < (uint32_t)GRAB) load_unit(nxt, tile, lt + 64u);
       pair_swap(cur);
       const uint32_t own = L == 2 ? (lt & ~63u) + 32u * t2 + ((lt >> 1) & 31u) : lt;  // a permutation of the wave's 64 tuples
 #pragma unroll
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(kFusedThreads) void grouped_rank_kernel(const uint3
           else *dst = r[c];
         }
       }
-      if (k + 1u < 4u) {
+      if (k + 1u < (uint32_t)GRAB) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
           cur[l][0] = nxt[l][0];
@@ -481,6 +484,14 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
   e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters + kQ16TileCounterWords) * 4, s);  // + the _p kernels' tile counter
   if (e != hipSuccess) return e;
   const PrepassPlan& pp = x.prepass;
+  // a batch of a few tiles: a unit per ticket, blocks for every two tiles (option-free: the result is the same bits, only who ranks what changes)
+  static const bool small_on = [] {  // A/B: DDT_PREPASS_SMALL=0 -> four units per ticket whatever the batch
+    const char* v = getenv("DDT_PREPASS_SMALL");
+    return !(v && v[0] == '0');
+  }();
+  // (measured, profiles/r06_small_batches.md: the fused form wins up to 64 tiles -- 100 x d6: 54.5 against 68.1 us per call there --, the grouped form up
+  // to 16 -- 1000 x d8 at 64 tiles: 131.9 against 122.1)
+  const bool small = small_on && tiles <= ((pp.groups && pp.lines >= 4u) ? 64u : 16u);
   if (pp.groups && pp.lines >= 4u) {
     // 1 group (all tables fit one CU's LDS together) or 2 groups of 4 lines: quad-coalesced loads, every 64-byte sector a block
     // pulls is used whole (fused_rank_kernel); at most one block per CU
@@ -489,9 +500,10 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
     const uint32_t parts = (pp.groups > 1u && a.num_cus >= 8u * pp.groups && tiles >= 8u) ? 8u : 1u;
     uint32_t per_pair = a.num_cus / (parts * pp.groups);
     if (per_pair < 1u) per_pair = 1u;
-    const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
-    if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
-    auto fk = a.ieee ? fused_rank_kernel<true> : fused_rank_kernel<false>;
+    const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round (small batches: 2, a unit per wave)
+    const uint64_t per_block = small ? 2u : 8u;
+    if ((uint64_t)per_pair > (tiles_part + per_block - 1u) / per_block) per_pair = (uint32_t)((tiles_part + per_block - 1u) / per_block);
+    auto fk = small ? (a.ieee ? fused_rank_kernel<true, 1> : fused_rank_kernel<false, 1>) : (a.ieee ? fused_rank_kernel<true> : fused_rank_kernel<false>);
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fk, dim3(parts * pp.groups * per_pair), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp,
@@ -503,10 +515,14 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
     const uint32_t parts = (a.num_cus >= 8u * pp.groups && tiles >= 8u) ? 8u : 1u;
     uint32_t per_pair = a.num_cus / (parts * pp.groups);
     if (per_pair < 1u) per_pair = 1u;
-    const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round
-    if ((uint64_t)per_pair > (tiles_part + 7u) / 8u) per_pair = (uint32_t)((tiles_part + 7u) / 8u);
+    const uint64_t tiles_part = (tiles + parts - 1u) / parts;  // a block's 16 waves take 8 tiles per round (small batches: 2, a unit per wave)
+    const uint64_t per_block = small ? 2u : 8u;
+    if ((uint64_t)per_pair > (tiles_part + per_block - 1u) / per_block) per_pair = (uint32_t)((tiles_part + per_block - 1u) / per_block);
     const uint32_t grid = parts * pp.groups * per_pair;
-    auto gk = pp.lines == 1u ? (a.ieee ? grouped_rank_kernel<1, true> : grouped_rank_kernel<1, false>) : (a.ieee ? grouped_rank_kernel<2, true> : grouped_rank_kernel<2, false>);
+    auto gk = small ? (pp.lines == 1u ? (a.ieee ? grouped_rank_kernel<1, true, 1> : grouped_rank_kernel<1, false, 1>)
+                                      : (a.ieee ? grouped_rank_kernel<2, true, 1> : grouped_rank_kernel<2, false, 1>))
+                    : (pp.lines == 1u ? (a.ieee ? grouped_rank_kernel<1, true> : grouped_rank_kernel<1, false>)
+                                      : (a.ieee ? grouped_rank_kernel<2, true> : grouped_rank_kernel<2, false>));
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(gk, dim3(grid), dim3(kFusedThreads), lds, s, a.tuples, a.n, x.n_pad, W, x.prepass_img, pp, parts, a.miss_raw, a.ieee,
