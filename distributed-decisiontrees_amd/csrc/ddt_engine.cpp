@@ -278,7 +278,21 @@ struct SplitPlan {
 };
 // a partial sum per PU group costs 4 B x groups per tuple of workspace (and of traffic each way): no such plan beyond this many bytes per call
 constexpr uint64_t kSplitWorkspaceCap = 256ull << 20;
-static bool split_fits(uint32_t partials, size_t n) { return (uint64_t)partials * ((n + 1023) / 1024 * 1024) * 4ull <= kSplitWorkspaceCap; }
+bool split_fits(uint32_t partials, size_t n) { return (uint64_t)partials * ((n + 1023) / 1024 * 1024) * 4ull <= kSplitWorkspaceCap; }
+// the partial sums of a cut launch: `floats` of them in this feeder slot's workspace
+int ensure_split_workspace(ddt_engine* e, uint64_t floats, float** out) {
+  const int k = e->q_slot;
+  if (e->q_split_floats[k] < floats) {
+    HIP_TRY(e, hipDeviceSynchronize());  // (earlier calls, on whatever stream, may still read the old buffer: as ensure_q16_workspace)
+    if (e->q_split[k]) (void)hipFree(e->q_split[k]);
+    e->q_split[k] = nullptr;
+    e->q_split_floats[k] = 0;
+    HIP_TRY(e, hipMalloc(&e->q_split[k], floats * sizeof(float)));
+    e->q_split_floats[k] = floats;
+  }
+  *out = reinterpret_cast<float*>(e->q_split[k]);
+  return DDT_OK;
+}
 static SplitPlan cluster_split_of(const ddt_engine* e, const Variant& v, const Ensemble& m, size_t n, bool reuse_prepass, bool all_classes) {
   SplitPlan sp;
   if (!v.has_split() || e->q16_cluster_split == 0 || all_classes || reuse_prepass || e->num_classes > 1 || n == 0) return sp;
@@ -409,17 +423,8 @@ int launch_score(ddt_engine* e, const Ensemble& m, const void* d_tuples, size_t 
   }
   float* partials = nullptr;
   if (sp.split || mcp.split) {
-    const uint64_t need = (uint64_t)(sp.split ? sp.partials : mcp.partials) * qa.n_pad;
-    const int k = e->q_slot;
-    if (e->q_split_floats[k] < need) {
-      HIP_TRY(e, hipDeviceSynchronize());  // (earlier calls, on whatever stream, may still read the old buffer: as ensure_q16_workspace)
-      if (e->q_split[k]) (void)hipFree(e->q_split[k]);
-      e->q_split[k] = nullptr;
-      e->q_split_floats[k] = 0;
-      HIP_TRY(e, hipMalloc(&e->q_split[k], need * sizeof(float)));
-      e->q_split_floats[k] = need;
-    }
-    partials = reinterpret_cast<float*>(e->q_split[k]);
+    int rc = ensure_split_workspace(e, (uint64_t)(sp.split ? sp.partials : mcp.partials) * qa.n_pad, &partials);
+    if (rc) return rc;
   }
   const uint32_t clusters = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u;
   if (v.kind == kKindQ16 && !m.parts.empty()) {
@@ -1233,6 +1238,11 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
   if (!strcmp(key, "q16_split_groups")) {  // -1: automatic (runs of PU groups where the clusters alone leave CUs idle); 0: clusters only; > 0: that many slices (A/B, tests)
     if (value < -1 || value > 65535) return fail(e, DDT_EINVAL, "q16_split_groups out of range");
     e->q16_split_groups = (int)value;
+    return DDT_OK;
+  }
+  if (!strcmp(key, "sparse_split_max_tiles")) {  // automatic cut of the "sparse_r_*" launch: batches of up to this many tiles of the kernel's own size
+    if (value < 0 || value > 0x7FFFFFFF) return fail(e, DDT_EINVAL, "sparse_split_max_tiles out of range");
+    e->sparse_split_max_tiles = (uint32_t)value;
     return DDT_OK;
   }
   if (!strcmp(key, "q16_split_max_tiles")) {  // automatic cluster split: batches of up to this many tiles of 1024 tuples

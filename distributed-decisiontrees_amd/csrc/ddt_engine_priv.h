@@ -144,6 +144,7 @@ struct ddt_engine {
   int q16_persistent = -1;    // option "q16_persistent": 1 / 0 = prefer / never pick the persistent "_p" kernel, -1 = automatic
   int q16_cluster_split = -1; // option "q16_cluster_split": 1 / 0 = always / never cut a launch at the clusters, -1 = automatic (batches of up to q16_split_max_tiles tiles)
   uint32_t q16_split_max_tiles = 384;  // option "q16_split_max_tiles" (measured at 1000 trees: 256 tiles 344 vs 407 us, 512 tiles 632 vs 624; profiles/r06_small_batches.md)
+  uint32_t sparse_split_max_tiles = 256;  // option "sparse_split_max_tiles": the 32-bit-rank sparse kernels' launch is cut into slices of C PU groups on batches of up to this many of their tiles
   int q16_split_groups = -1;  // option "q16_split_groups": slices finer than the clusters (a partial sum per PU group); -1 automatic, 0 never, > 0 that many slices
   bool collective_job = false;  // set by ddt_comm_create* / ddt_group_create* with more than one rank: collectives share the CUs with the scoring
   // "_p" kernels, multi-class models whose classes hold equally many trees: the classes' images back to back (fast / slow), so that
@@ -263,6 +264,8 @@ std::vector<uint32_t> shard_of(const std::vector<uint32_t>& ids, uint32_t g, uin
 void free_images(ddt_engine* e);
 void free_q16_workspace(ddt_engine* e);
 int find_variant(const char* name);
+bool split_fits(uint32_t partials, size_t n);                                  // ddt_engine.cpp: a cut launch's partial sums within the workspace cap
+int ensure_split_workspace(ddt_engine* e, uint64_t floats, float** out);
 bool leaf_outside_exact_domain(uint32_t bits);
 // one scoring pass of the loaded model (perfect or sparse) over device-resident tuples, asynchronous on `s`
 int engine_score_device(ddt_engine* e, const void* d_tuples, size_t n, float* d_scores, hipStream_t s);

@@ -747,10 +747,32 @@ int sparse_launch(ddt_engine* e, uint32_t cls, const void* d_tuples, size_t n, f
     if (e->tev_cur) a.ev_mid = e->tev_cur[1];  // recorded between the pre-pass and the scoring kernel
     else if (e->ev_fork && !reuse_prepass) a.ev_mid = e->ev_fork;  // multi-class calls: where the other stream's classes may start
   }
+  // A batch of a few tiles on the 32-bit-rank kernels: one block walks all the forest's PU groups for its 256 tuples (0.23 ms at 512 trees).  Cut into
+  // slices of C consecutive groups (C = clusters: in stream order each cluster then takes ONE group's sum per slice, so the uncut walk's ring of
+  // accumulators IS the groups' sums), the adds in the reference's order behind it (launch_cm_combine): FPAggregator.v:79-131, Core.sv:486-541.
+  const uint32_t C = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u;
+  bool cut = false;
+  if (v.r32() && e->q16_cluster_split != 0 && e->p.sum_mode != 1u && !reuse_prepass && e->num_classes <= 1u && n > 0 && sp.groups > C) {
+    const uint64_t tiles = (n + (uint32_t)v.threads - 1u) / (uint32_t)v.threads;  // (blocks of the uncut launch: two per CU)
+    const uint32_t positions = (sp.groups + C - 1u) / C * C;
+    cut = (e->q16_cluster_split > 0 || tiles <= e->sparse_split_max_tiles) && split_fits(positions, n);
+    if (cut) {
+      float* partials = nullptr;
+      int rc = ensure_split_workspace(e, (uint64_t)positions * x.q16.n_pad, &partials);
+      if (rc) return rc;
+      x.q16.split = 1u;
+      a.out = partials;
+    }
+  }
   a.aux = &x;
   (void)hipGetLastError();  // a stale error of an unrelated earlier call must not be blamed on this launch
   hipError_t r = v.launch(a, v, s);
   if (r != hipSuccess) return fail(e, DDT_EHIP, "kernel launch (%s) -> %s", v.name, hipGetErrorString(r));
+  if (cut) {
+    r = launch_cm_combine(a.out, (size_t)x.q16.n_pad, n, sp.groups, C, true, false, d_scores, e->p.sum_mode == 2, s);
+    if (r != hipSuccess) return fail(e, DDT_EHIP, "cm_combine -> %s", hipGetErrorString(r));
+    e->st.kernel_launches++;
+  }
   return DDT_OK;
 }
 

@@ -218,7 +218,7 @@ __device__ __forceinline__ bool sr_right(uint32_t f, uint32_t rec) {
 //     SparseAux::max_rounds); a finished one has the zeros its out-of-range gather returned -- no leaf flag.  A wave that leaves the rounds early
 //     consumes its last (idle) gathers, so that both exits reach the next group with nothing outstanding in the compiler's books.
 template <int K, int U, int THREADS, bool SLOW, bool WP>
-__device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
+__device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc, const uint4* img, const uint32_t groups) {
   static_assert(U == 8 || U == 16, "the counted wait below is vmcnt(U)");
   constexpr int TOPB = 4 << K;
   constexpr int STEPB = U * TOPB;
@@ -234,7 +234,7 @@ __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAu
     return lds_u32(addr);
   };
   const uint32_t C = a.clusters;
-  const uint32_t n_steps = x.n_groups * 8u / (uint32_t)U;
+  const uint32_t n_steps = groups * 8u / (uint32_t)U;  // (`img`, `groups`: the launch's image, or a slice of it -- score_sparse_r_kernel)
   const uint32_t max_rounds = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.max_rounds);
   // top levels of the next group walked behind every deep round (the rest behind the last one)
   const uint32_t per_round = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)K + (max_rounds > 1u ? max_rounds - 1u : 1u) - 1u) / (max_rounds > 1u ? max_rounds - 1u : 1u)));
@@ -267,7 +267,7 @@ __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAu
 #pragma unroll
     for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));
     __syncthreads();
-    if (1u < n_steps) dma_chunk<THREADS, STEPB>(a.img, 1, 0, tid);
+    if (1u < n_steps) dma_chunk<THREADS, STEPB>(img, 1, 0, tid);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m4[u] << 2), 0, 0);
@@ -370,7 +370,7 @@ __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAu
 #pragma unroll
       for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));
       __syncthreads();  // every wave is through with the images of group g + 1
-      if (g + 2u < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 2u, 0, tid);
+      if (g + 2u < n_steps) dma_chunk<THREADS, STEPB>(img, g + 2u, 0, tid);
 #pragma unroll
       for (int u = 0; u < U; ++u) {  // ... exactly U gathers behind that DMA: what the counted wait at the loop's top counts
         rr[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, cb[u] + (m4[u] << 2), 0, 0);
@@ -389,7 +389,7 @@ __device__ __forceinline__ void sparse_r_walk(const ScoreArgs& a, const SparseAu
 // rank 0, no leaf flag, next block at 0", lands in bytes 0..63 of the deep array -- records {0, 0, 0, 0xFFFFFFC0} (ddt_sparse_host.cpp) -- and from there
 // goes out of range again: every second gather of a finished walker touches no cache, none needs a mask.
 template <int K, int U, int THREADS, bool SLOW, bool WP, int NB, int ODD>
-__device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc) {
+__device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const SparseAux& x, const int tid, RefAcc<1>& ra, double& dacc, const uint4* img, const uint32_t groups) {
   static_assert(U == 8, "the counted wait below is vmcnt(8)");
   constexpr int TOPB = 4 << K;
   constexpr int STEPB = U * TOPB;
@@ -405,7 +405,7 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
     return lds_u32(addr);
   };
   const uint32_t C = a.clusters;
-  const uint32_t n_steps = x.n_groups;
+  const uint32_t n_steps = groups;
   // R = SparseAux::max_rounds = 2 NB + ODD rounds, compile-time: the iterations below are straight-line code (with a runtime trip count the
   // compiler's wait counts at the loop header were those of the loop's entry -- 7 where the back edge has 15 gathers behind the record)
   constexpr uint32_t B = (uint32_t)NB, A = (uint32_t)(NB + ODD);  // rounds of a group walked in the next group's step / in its own
@@ -540,7 +540,7 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
       for (int u = 0; u < U; ++u) cb[u] = lds_u32((uint32_t)(u * TOPB));
       first_gathers(prev, cb);  // the set of group g - 1 is free: it becomes group g + 1's
       __syncthreads();          // every wave is through with the images of group g + 1
-      if (g + 2u < n_steps) dma_chunk<THREADS, STEPB>(a.img, g + 2u, 0, tid);
+      if (g + 2u < n_steps) dma_chunk<THREADS, STEPB>(img, g + 2u, 0, tid);
     }
   };
   auto drain = [&](Set& S) {  // the last group's rounds A + 1 .. R
@@ -566,7 +566,7 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
     }
     first_gathers(S0, cb);
     __syncthreads();
-    if (1u < n_steps) dma_chunk<THREADS, STEPB>(a.img, 1, 0, tid);
+    if (1u < n_steps) dma_chunk<THREADS, STEPB>(img, 1, 0, tid);
   }
   uint32_t g = 0;
   for (; g + 2u < n_steps; g += 2u) {
@@ -583,7 +583,9 @@ __device__ __forceinline__ void sparse_r_walk_lag(const ScoreArgs& a, const Spar
   }
 }
 
-template <int K, int U, int THREADS, bool WP, int NB, int ODD>  // NB + ODD > 0: the walk with 2 NB + ODD rounds, consecutive groups overlapped
+// SPLIT: a second instantiation (of the walk without the lag only: a batch of a few tiles is not where the lag pays) -- with the slices as run-time
+// selects in the one kernel, config 4's scoring took 23.2 instead of 23.03 ms (same box, alternating libraries: profiles/r06_raw/s45_*)
+template <int K, int U, int THREADS, bool WP, int NB, int ODD, bool SPLIT = false>  // NB + ODD > 0: the walk with 2 NB + ODD rounds, consecutive groups overlapped
 __global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs a, const SparseAux x) {
   constexpr int TOPB = 4 << K;
   constexpr int STEPB = U * TOPB;
@@ -594,7 +596,13 @@ __global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs
   const uint64_t tile0 = (uint64_t)blockIdx.x * THREADS;
   const uint32_t W = a.tuple_words;
 
-  dma_chunk<THREADS, STEPB>(a.img, 0, 0, tid);  // top images of the first pass
+  // A batch of a few tiles (Q16Aux::split, sparse_launch): blockIdx.y = a slice of C consecutive PU groups starting at a multiple of C -- in an image in
+  // stream order group g belongs to cluster g mod C (Core.sv:291-316), so within such a slice every cluster's accumulator takes exactly ONE group's
+  // sum (x + 0): the walk is the uncut launch's, only the epilogue lets the ring out instead of its total, and launch_cm_combine runs the adds.
+  const uint32_t g0 = SPLIT ? blockIdx.y * a.clusters : 0u;
+  const uint4* img = SPLIT ? a.img + (size_t)g0 * (STEPB / 16) : a.img;
+  const uint32_t groups = SPLIT ? (x.n_groups - g0 < a.clusters ? x.n_groups - g0 : a.clusters) : x.n_groups;
+  dma_chunk<THREADS, STEPB>(img, 0, 0, tid);  // top images of the first pass
   {
     // the rank tile is one contiguous block of W * ROW bytes of the pre-pass's output, [feature][THREADS tuples]: DMA it in; the first barrier of the
     // walk publishes it.  A wave instruction fills 1 KiB of LDS with 64 pieces of 16 bytes from anywhere: for wave-private rows (SrTile) those are
@@ -623,14 +631,20 @@ __global__ __launch_bounds__(THREADS) void score_sparse_r_kernel(const ScoreArgs
   double dacc = 0.0;
   const uint32_t C = a.clusters;
   if constexpr (NB + ODD > 0) {
-    if (!slow) sparse_r_walk_lag<K, U, THREADS, false, WP, NB, ODD>(a, x, tid, ra, dacc);
-    else sparse_r_walk_lag<K, U, THREADS, true, WP, NB, ODD>(a, x, tid, ra, dacc);
+    if (!slow) sparse_r_walk_lag<K, U, THREADS, false, WP, NB, ODD>(a, x, tid, ra, dacc, img, groups);
+    else sparse_r_walk_lag<K, U, THREADS, true, WP, NB, ODD>(a, x, tid, ra, dacc, img, groups);
   } else {
-    if (!slow) sparse_r_walk<K, U, THREADS, false, WP>(a, x, tid, ra, dacc);
-    else sparse_r_walk<K, U, THREADS, true, WP>(a, x, tid, ra, dacc);
+    if (!slow) sparse_r_walk<K, U, THREADS, false, WP>(a, x, tid, ra, dacc, img, groups);
+    else sparse_r_walk<K, U, THREADS, true, WP>(a, x, tid, ra, dacc, img, groups);
   }
   ra.align(C);
   const uint64_t row = tile0 + (uint64_t)tid;
+  if constexpr (SPLIT) {  // out = [groups rounded up to C][n_pad] partial sums: cluster k's accumulator = the sum of group g0 + k (+ 0; nothing beyond the forest's last group)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if ((uint32_t)k < C) a.out[(uint64_t)(g0 + (uint32_t)k) * x.q16.n_pad + row] = ra.a[0][k];
+    return;
+  }
   if (row < a.n) a.out[row] = (a.sum_mode == 1) ? (float)dacc : ra.total(0, C, a.sum_mode == 2);
 }
 
@@ -661,6 +675,14 @@ static hipError_t launch_sparse_r_v(const ScoreArgs& a, const Variant& v, hipStr
     if (e != hipSuccess) return e;
   }
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);
+  if (x.q16.split) {  // a batch of a few tiles: slices of C groups (sparse_launch)
+    const uint32_t C = a.clusters ? a.clusters : 1u;
+    auto ks = wp ? score_sparse_r_kernel<K, U, THREADS, true, 0, 0, true> : score_sparse_r_kernel<K, U, THREADS, false, 0, 0, true>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ks, dim3((uint32_t)blocks, (x.n_groups + C - 1u) / C), dim3(THREADS), lds, s, a, x);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(THREADS), lds, s, a, x);
   return hipGetLastError();
 }

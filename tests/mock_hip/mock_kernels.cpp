@@ -372,6 +372,20 @@ hipError_t launch_sparse_r(const ScoreArgs& args, const Variant& var, hipStream_
         if (hops > x.max_rounds) lf = __builtin_nanf("");  // the kernel would have stopped gathering: a wrong round count must show
         leaf[slot] = lf;
       }
+      if (x.q16.split) {
+        // a batch of a few tiles cut into slices of C consecutive PU groups (csrc/ddt_sparse_r.hip score_sparse_r_kernel): every cluster's accumulator
+        // takes ONE group's sum per slice and goes out as it is -- out[group][row] = the group's 8-leaf reduce tree + 0; the adds: launch_cm_combine
+        auto add = [&](float p, float q) -> float {
+          volatile float r = a.sum_mode == 2 ? ref_add_exact(p, q) : p + q;
+          return r;
+        };
+        const uint32_t C = a.clusters ? a.clusters : 1u, G = a.n_trees / 8u;
+        for (uint32_t g = 0; g < (G + C - 1u) / C * C; ++g) {
+          const float* l = leaf.data() + (size_t)g * 8u;
+          a.out[(size_t)g * x.q16.n_pad + i] = g < G ? add(add(add(add(l[0], l[1]), add(l[2], l[3])), add(add(l[4], l[5]), add(l[6], l[7]))), 0.0f) : 0.0f;
+        }
+        continue;
+      }
       a.out[i] = reduce(leaf.data(), a.n_trees, a.clusters, a.sum_mode);
     }
   };

@@ -1210,3 +1210,45 @@ def test_small_multiclass_batch_is_cut_over_all_classes(mock, T, K, clusters):
                 assert mock.ddt_classify(e, x.ctypes.data, n, gl2.ctypes.data, null) == 0, mock.ddt_last_error(e)             # host buffers, labels only
                 assert np.array_equal(_bits(gs), _bits(cs)) and np.array_equal(gl, labels) and np.array_equal(gl2, labels), (T, K, clusters, sum_mode, n, split, groups)
     mock.ddt_destroy(e)
+
+
+@pytest.mark.parametrize("T,depth,F,clusters", [(130, 14, 20, 1), (130, 14, 20, 4), (70, 13, 9, 8), (21, 10, 6, 2), (8, 9, 5, 4)])
+def test_small_batch_on_the_32_bit_rank_sparse_kernels_is_cut_into_slices_of_C_groups(mock, T, depth, F, clusters):
+    """`sparse_r_*` on a batch of a few tiles: grid (tiles, slices of C consecutive PU groups) -- in stream order group g belongs to cluster g mod C
+    (Core.sv:291-316), so within a slice every cluster's accumulator takes ONE group's sum: the uncut walk's ring IS the groups' sums, the
+    epilogue lets it out and launch_cm_combine runs the adds (FPAggregator.v:79-131, Core.sv:486-541).  Oracle's bits, both adders, cut and uncut."""
+    mock.mock_reset(1, 4, 8)
+    sp = O.gen_sparse_model(T, depth, F, 3, 650, 1, clusters=clusters)
+    mock.ddt_load_model_sparse.argtypes = [vp, C.POINTER(ddt.Params), vp, C.c_size_t, vp, C.c_uint32, C.c_uint32]
+    lines, first = np.ascontiguousarray(sp.node_lines, np.uint32), np.ascontiguousarray(sp.first, np.uint64)
+    e, s, st, info = _engine(mock), _stream(mock), ddt.Stats(), ddt.Info()
+    assert mock.ddt_set_option(e, b"sparse_r32", 1) == 0
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        p = ddt.make_sparse_params(T, depth, F, clusters=clusters, sum_mode=sum_mode)
+        assert mock.ddt_load_model_sparse(e, C.byref(p), lines.ctypes.data, lines.size // 4, first.ctypes.data, 0, 1) == 0, mock.ddt_last_error(e)
+        assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("sparse_r_")
+        cuts = (T + 7) // 8 > clusters
+        for n in (3, 900):
+            x = O.gen_tuples(6, n, F, 1)
+            x[n // 2, 1] = sp.params.missing_bits
+            want = O.score_sparse(sp, x, sum_mode=ref)
+            for split, launches in ((0, 1), (-1, 2 if cuts else 1), (1, 2 if cuts else 1)):
+                assert mock.ddt_set_option(e, b"q16_cluster_split", split) == 0
+                assert mock.ddt_get_stats(e, C.byref(st)) == 0
+                before = st.kernel_launches
+                outs = [np.full(n, np.nan, np.float32) for _ in range(2)]
+                for o in outs:
+                    assert mock.ddt_score_device(e, x.ctypes.data, n, o.ctypes.data, s) == 0, mock.ddt_last_error(e)
+                assert mock.hipStreamSynchronize(s) == 0
+                for o in outs:
+                    assert np.array_equal(_bits(o), _bits(want)), (T, clusters, sum_mode, n, split)
+                assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.kernel_launches - before == 2 * launches, (split, n)
+        assert mock.ddt_set_option(e, b"q16_cluster_split", -1) == 0 and mock.ddt_set_option(e, b"sparse_split_max_tiles", 2) == 0   # the kernel's own tiles (256 / 128 tuples)
+        x = O.gen_tuples(7, 1100, F, 1)
+        o = np.full(1100, np.nan, np.float32)
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0
+        before = st.kernel_launches
+        assert mock.ddt_score_device(e, x.ctypes.data, 1100, o.ctypes.data, s) == 0 and mock.hipStreamSynchronize(s) == 0
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0 and st.kernel_launches - before == 1 and np.array_equal(_bits(o), _bits(O.score_sparse(sp, x, sum_mode=ref)))
+        assert mock.ddt_set_option(e, b"sparse_split_max_tiles", 256) == 0
+    mock.ddt_destroy(e)

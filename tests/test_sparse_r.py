@@ -127,3 +127,33 @@ def test_classes_and_tree_shards():
         wl2, ws2 = O.classify_sparse(s, x, K, inter, n_devices=2)
         assert np.array_equal(lab.cpu().numpy(), wl2) and np.array_equal(_bits(comb.cpu().numpy()), _bits(ws2))
     e.close()
+
+
+@pytest.mark.parametrize("T,D,F,clusters", [(512, 16, 64, 4), (130, 14, 20, 1), (200, 13, 100, 8), (70, 15, 30, 2)])
+def test_small_batches_are_cut_into_slices_of_C_groups(T, D, F, clusters):
+    """A batch of a few tiles: grid (tiles, slices of C consecutive PU groups); within a slice every cluster's accumulator takes ONE group's sum (in
+    stream order group g belongs to cluster g mod C, Core.sv:291-316), the epilogue lets the ring out and `cm_combine_kernel` runs the adds in the
+    reference's order.  The uncut launch beside it, the oracle's bits, both adders, missing values, ragged row counts."""
+    import torch
+
+    sp = O.gen_sparse_model(T, D, F, 8, 700, 1, clusters=clusters)
+    e = ddt.Engine(0)
+    e.set_option("sparse_r32", 1)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        e.load_model_sparse(ddt.make_sparse_params(T, D, F, clusters=clusters, sum_mode=sum_mode), sp.node_lines, sp.first)
+        assert e.info().variant_name.decode().startswith("sparse_r_k")
+        for n in (1, 700, 20_001):
+            x = O.gen_tuples(3 + n % 7, n, F, dist=1)
+            x[::97, 1] = sp.params.missing_bits
+            d = torch.from_numpy(x.view(np.int32)).cuda()
+            want = O.score_sparse_fast(sp, x, sum_mode=ref) if hasattr(O, "score_sparse_fast") else O.score_sparse(sp, x, sum_mode=ref)
+            for split, launches in ((0, 1), (-1, 2), (1, 2)):
+                e.set_option("q16_cluster_split", split)
+                before = e.stats().kernel_launches
+                got = [e.score_device(d) for _ in range(2)]
+                torch.cuda.synchronize()
+                assert e.stats().kernel_launches - before == 2 * launches, (split, n)
+                for g in got:
+                    bad = np.flatnonzero(_bits(g.cpu().numpy()) != _bits(want))
+                    assert bad.size == 0, (T, D, clusters, sum_mode, n, split, bad[:8], bad.size)
+    e.close()
