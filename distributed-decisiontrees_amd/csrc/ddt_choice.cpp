@@ -69,7 +69,7 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
     // deep kernels: their stage gathers address the image with 32-bit byte offsets through one buffer resource
     if (v.deep() && (uint64_t)padded_trees(v, max_trees(e)) * v.tree_bytes_q16() >= (1ull << 31)) return false;
     if ((v.opt & 4) && e->p.sum_mode == 1u) return false;  // cluster-major image order: not the stream order the fp64 sum is defined on
-    if (rank_tables(e).max_len <= kQ16MaxTable) return true;
+    if (rank_tables(e).max_len <= e->q16_max_table) return true;
     // ... provided every PU group of 8 trees (the unit the parts are planned in: plan_q16_parts) stays within the u16 ranks by itself.  Up to
     // depth 12 it always does (8 x 4095 nodes); deeper trees on few features may not: counted per group and feature (nodes, an upper bound
     // of the distinct thresholds), in cluster-major order
@@ -84,7 +84,7 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
         }
         for (const auto& c : cnt)
           for (uint32_t k : c)
-            if (k > kQ16MaxTable) return false;
+            if (k > e->q16_max_table) return false;
       }
     }
     // more distinct thresholds on a feature than u16 ranks hold: the plain cluster-major kernels score the ensemble in PARTS with

@@ -1220,6 +1220,11 @@ int ddt_set_option(ddt_engine* e, const char* key, int64_t value) {
     e->q16_prepass_groups = (int)value;
     return DDT_OK;
   }
+  if (!strcmp(key, "q16_max_table")) {  // distinct thresholds per feature in ONE rank table: an ensemble beyond it is scored in parts (next model load; A/B, tests)
+    if (value < 255 || value > (int64_t)kQ16MaxTable) return fail(e, DDT_EINVAL, "q16_max_table must be in 255..%u", kQ16MaxTable);
+    e->q16_max_table = (uint32_t)value;
+    return DDT_OK;
+  }
   if (!strcmp(key, "q16_fused_prepass")) {  // 0: never the single-group form (all tables resident together); both 0: transpose + rank kernels.
                                             // These three take effect at the next model load (A/B and tests); defaults 1, 1, 0
     e->q16_fused_prepass = value != 0;

@@ -182,7 +182,7 @@ bool build_prepass_group(const RankTables& rt, uint32_t f0, uint32_t f1, std::ve
         std::vector<uint32_t> cnt(nb, 0u);
         for (uint32_t key : seg_keys[j][s]) ++cnt[((key - f.lo) & mask) >> f.sh[s]];
         for (uint32_t b = 0; b < nb; ++b) {
-          S[first + b] = (uint16_t)run;  // run <= K <= 32767
+          S[first + b] = (uint16_t)run;  // run <= K <= kQ16MaxTable
           run += cnt[b];
         }
         first += nb;
@@ -348,8 +348,7 @@ void finish_rank_tables(RankTables& rt) {
 // flat tables of rank_kernel ([W][Kpad] keys, per-feature search parameters, bucket starts) and -- want_prepass -- the LDS
 // images of the LDS-resident pre-pass, from the sorted distinct threshold keys per feature
 int pack_rank_tables(ddt_engine* e, const RankTables& rt, uint32_t W, bool want_prepass, RankHostTables& h) {
-  uint32_t Kpad = 2;
-  while (Kpad <= rt.max_len) Kpad <<= 1;  // power of two > max_len: the search reads indices < Kpad - 1
+  const uint32_t Kpad = q16_table_pad(rt.max_len);  // > max_len (a power of two up to 32767 keys): the search reads indices < Kpad - 1
   std::vector<uint32_t>&tab = h.tab, &tabK = h.tabK, &pimg = h.pimg;
   std::vector<uint16_t>& tabS = h.tabS;
   PrepassPlan& pplan = h.pplan;
@@ -379,7 +378,7 @@ int pack_rank_tables(ddt_engine* e, const RankTables& rt, uint32_t W, bool want_
       for (uint32_t key : k) ++cnt[(key - lo) >> shift];
       uint32_t run = 0, max_len = 0;
       for (uint32_t b = 0; b < kQ16RankBuckets; ++b) {
-        S[b] = (uint16_t)run;  // run <= K <= 32767
+        S[b] = (uint16_t)run;  // run <= K <= kQ16MaxTable
         run += cnt[b];
         max_len = cnt[b] > max_len ? cnt[b] : max_len;
       }
@@ -468,7 +467,7 @@ int plan_q16_parts(ddt_engine* e, const Variant& v, const Ensemble& m, Q16HostIm
       RankTables t = cur;
       for (uint32_t j = 0; j < W; ++j) t.keys[j].insert(t.keys[j].end(), add[j].begin(), add[j].end());
       finish_rank_tables(t);
-      if (t.max_len > kQ16MaxTable) return false;
+      if (t.max_len > e->q16_max_table) return false;
       *out = std::move(t);
       return true;
     };
@@ -485,7 +484,7 @@ int plan_q16_parts(ddt_engine* e, const Variant& v, const Ensemble& m, Q16HostIm
       h.part_chunk_begin.push_back(c);
       cur = RankTables{};
       cur.keys.assign(W, {});
-      if (!merged_fits(add, &next)) return fail(e, DDT_EUNSUPPORTED, "one PU group of trees has more than %u distinct thresholds on a feature", kQ16MaxTable);
+      if (!merged_fits(add, &next)) return fail(e, DDT_EUNSUPPORTED, "one PU group of trees has more than %u distinct thresholds on a feature", e->q16_max_table);
       cur = std::move(next);
     }
     h.part_tables.push_back(cur);
@@ -506,7 +505,7 @@ int pack_image_q16(ddt_engine* e, const Variant& v, const Ensemble& m, const Ran
   } catch (const std::bad_alloc&) {
     return fail(e, DDT_ENOMEM, "q16 image allocation failed");
   }
-  const bool in_parts = rt.max_len > kQ16MaxTable;  // (variant_fits has checked that this kernel can score in parts)
+  const bool in_parts = rt.max_len > e->q16_max_table;  // (variant_fits has checked that this kernel can score in parts)
   if (in_parts) {
     const int rc = plan_q16_parts(e, v, m, h);
     if (rc) return rc;

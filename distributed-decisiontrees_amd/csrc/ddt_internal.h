@@ -75,7 +75,7 @@ struct Q16Aux {               // device pointers of the rank-quantised path (Sco
   const uint32_t* tables;     // [W][Kpad] sorted distinct threshold keys per feature, padded with INT_MAX
   const uint32_t* tabP;       // [W][8] per feature: K (real table length), lo, hi (first / last key), shift, P, 0, 0, 0
   const uint16_t* tabS;       // [W][kQ16RankBuckets] bucket starts: number of keys in the slices below (rank_kernel)
-  uint32_t Kpad;              // power of two > max table length
+  uint32_t Kpad;              // entries per table, > max table length (ddt_engine_priv.h q16_table_pad: a power of two up to 32767 keys)
   const uint4* img_slow;      // image with the miss_right flags (used by tiles that contain a missing value)
   uint64_t n_pad;             // rows rounded up to whole tiles of 1024
   uint32_t skip_prepass;      // 1 = q / tile_flags already hold this batch (2nd..Kth class of a multi-class model)

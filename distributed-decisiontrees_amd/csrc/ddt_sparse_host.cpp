@@ -161,7 +161,7 @@ int sparse_rebuild(ddt_engine* e) {
   } catch (const std::bad_alloc&) {
     return fail(e, DDT_ENOMEM, "rank table allocation failed");
   }
-  int vid = pick_variant(e, max_depth, rt.max_len <= kQ16MaxTable);
+  int vid = pick_variant(e, max_depth, rt.max_len <= e->q16_max_table);
   // 32-bit ranks + pair records on every deep level (option "sparse_r32": -1 automatic, 0 never, 1 wherever such a kernel fits): for forests that
   // go well below the top image -- every two levels there cost ONE gather instead of two -- and hold enough trees to carry the rank pre-pass
   // (transpose + rank32_kernel per batch, which the fp32-tile kernels do not have)
@@ -932,7 +932,7 @@ extern "C" int ddt_debug_sparse_image(const ddt_params* p, const void* node_line
     } catch (const std::bad_alloc&) {
       return DDT_ENOMEM;
     }
-    if (rt.max_len > (v.r32() ? kSrMaxTable : kQ16MaxTable)) return DDT_EUNSUPPORTED;
+    if (rt.max_len > (v.r32() ? kSrMaxTable : e->q16_max_table)) return DDT_EUNSUPPORTED;
     if (v.r32() && (p->num_features > 256u || tuple_words(*p) > kSrMaxWords)) return DDT_EUNSUPPORTED;
   }
   rc = v.r32() ? sparse_pack_host_r(e.get(), v, sp, rt, top, deep, &groups) : sparse_pack_host(e.get(), v, sp, q ? &rt : nullptr, top, deep, &groups);

@@ -351,6 +351,8 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * "q16_fused_prepass" / "q16_grouped_prepass" (1 = default; 0 = never rank with all tables resident together / never
  * split the rank pre-pass over feature groups; both 0 = the transpose + rank kernels) and "q16_prepass_groups" (0 =
  * cheapest, default; 1, 2, 4, 8 = exactly that many feature groups): A/B switches, effective at the next model load;
+ * "q16_max_table" (255..37727, default 37727: the distinct thresholds per feature ONE rank table may hold -- what fits a block's LDS in the rank
+ * kernel; an ensemble beyond it is scored in parts; 32767 = the limit until round 6; effective at the next model load);
  * "q16_persistent" (-1 = default: the persistent depth-8 rank-quantised kernel -- resident blocks that take tiles from a ticket
  * counter -- where it wins: one-vs-all models whose classes hold equally many trees, scored in ONE launch, and engines inside a
  * multi-rank job; 1 = wherever it fits; 0 = never), "q16_prepass_nt" (A/B: bit 0 / 1 = nontemporal stores / loads in the rank
@@ -369,7 +371,7 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * "leaf_domain_check" (1 = default: refuse -0 / sub-normal / Inf / NaN leaves in the reference-order sum, where the
  * GPU's IEEE adds and the reference's adder differ), "sparse_top_levels" (-1 = auto, or 6..10 levels of a sparse
  * forest staged in LDS), "sparse_deep_order" (0 = level order, default; 1 = depth-first per sub-tree), "sparse_q16" (1 =
- * default: sparse forests whose distinct thresholds per feature fit 16-bit ranks -- at most 32767, e.g. histogram-trained
+ * default: sparse forests whose distinct thresholds per feature fit 16-bit ranks -- at most 37727 (what one block of the rank kernel holds in LDS), e.g. histogram-trained
  * models -- and whose tuples have at most 64..76 words run on the rank-quantised sparse kernels: u16 feature tile, 1024
  * tuples per block; 0 = always the fp32-tile kernels), "sparse_dk" (1 = default: the "dense level K" sparse kernels where they
  * exist -- all top levels as 8-byte records in LDS, the first deep level addressed by the heap index; 0 = never: only the kernels with 16-byte

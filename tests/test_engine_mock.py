@@ -645,9 +645,9 @@ def test_cluster_major_image_order(mock, T, clusters):
     mock.ddt_destroy(e)
 
 
-@pytest.mark.parametrize("T,F,clusters,parts", [(600, 4, 1, 2), (600, 4, 8, 2), (1100, 4, 4, 3), (300, 4, 2, 1)])
+@pytest.mark.parametrize("T,F,clusters,parts", [(600, 4, 1, 2), (600, 4, 8, 2), (1100, 4, 4, 2), (1250, 4, 4, 3), (300, 4, 2, 1)])
 def test_more_thresholds_than_u16_ranks_hold_is_scored_in_parts(mock, T, F, clusters, parts):
-    """u16 ranks stop at 32767 distinct thresholds per feature (the reference allows 8192 nodes x 64 PUs on one feature, DTPU.sv:22,74).
+    """u16 ranks stop at 37727 distinct thresholds per feature -- what one block's LDS holds in rank_kernel; 32767 until round 6 -- (the reference allows 8192 nodes x 64 PUs on one feature, DTPU.sv:22,74).
     Beyond that the cluster-major kernels score the ensemble in PARTS -- consecutive chunks of the image with rank tables of their own, a
     pre-pass + a scoring launch per part, the reference-order sum handed from launch to launch (accumulator + running total per tuple):
     bit-exact with the oracle for every cluster count and both adders, through resident and host calls, back to back."""
@@ -803,7 +803,7 @@ def _sparse_fuzz_round(mock, seed, seen):
 
 
 @pytest.mark.parametrize("T,D,F,clusters,name,parts", [(20, 12, 32, 1, "q16d_d12_k9_c4_u4_cm", 1), (13, 12, 8, 4, "q16d_d12_k9_c4_u4_cm", 1),
-                                                        (40, 12, 4, 2, "q16d_d12_k9_c4_u4_cm", 2), (70, 12, 3, 8, "q16d_d12_k9_c4_u4_cm", 4),
+                                                        (40, 12, 4, 2, "q16d_d12_k9_c4_u4_cm", 2), (70, 12, 3, 8, "q16d_d12_k9_c4_u4_cm", 3),
                                                         (11, 10, 16, 1, "q16d_d10_k9_c4_u4_cm", 1), (9, 11, 20, 8, "q16d_d11_k8_c8_u4_cm", 1),
                                                         (17, 9, 32, 2, "q16d_d9_k8_c8_u4_cm", 1), (5, 14, 12, 1, "q16d_d14_k9_c4_u4_cm", 1),
                                                         (9, 15, 12, 2, "q16d_d15_k8_c8_u4_cm", 1), (16, 15, 9, 2, "q16d_d15_k8_c8_u4_cm", 2)])
@@ -811,7 +811,7 @@ def test_deep_perfect_trees_on_the_deep_kernels(mock, T, D, F, clusters, name, p
     """Perfect trees deeper than 8 levels (the reference's own example: 512 x depth 12, profiler/profiler.cpp:32-38) take the deep
     rank-quantised kernels by themselves: K levels as a heap of 4-byte records, then pair / terminal records of 16 bytes per stage
     (csrc/ddt_internal.h).  The host side -- image packing in cluster-major order, the records' own next-block offsets, parts with rank
-    tables of their own when a feature carries more than 32767 distinct thresholds, the sum's state between the parts -- against the
+    tables of their own when a feature carries more than 37727 distinct thresholds, the sum's state between the parts -- against the
     oracle bit for bit, both adders, tiles with and without missing values, resident and host calls."""
     mock.mock_reset(2, 9, 8)
     n = 1300

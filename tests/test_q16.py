@@ -243,7 +243,7 @@ def test_grouped_and_two_kernel_prepass_agree(T, F):
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,F,clusters,n", [(600, 4, 1, 5000), (1100, 4, 8, 3000), (4000, 16, 8, 2500)])
 def test_ensembles_beyond_the_u16_rank_range_are_scored_in_parts(T, F, clusters, n):
-    """More than 32767 distinct thresholds on a feature (4000 trees x 255 nodes over 16 features: ~64 k each): the cluster-major kernel
+    """More than 37727 distinct thresholds on a feature (4000 trees x 255 nodes over 16 features: ~64 k each): the cluster-major kernel
     scores the ensemble in parts with rank tables of their own, the reference-order sum handed from launch to launch -- bit-exact, both adders."""
     import torch
 
@@ -263,4 +263,59 @@ def test_ensembles_beyond_the_u16_rank_range_are_scored_in_parts(T, F, clusters,
         want = O.score_fast(m, x, sum_mode=ref)
         assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), (T, clusters, sum_mode)
         assert np.array_equal(e.score(x).view(np.uint32), want.view(np.uint32))   # host feeder path
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,parts", [(32767, 1), (32768, 1), (35001, 1), (37727, 1), (37728, 2)])
+def test_rank_tables_of_up_to_37727_keys_fit_one_blocks_lds(K, parts):
+    """One rank table = what ONE block of rank_kernel holds in LDS (csrc/ddt_engine_priv.h kQ16MaxTable: 37727 keys; 32767 and a
+    power-of-two table until round 6).  A feature with EXACTLY K distinct thresholds: the table's padding (a multiple of 32 entries beyond
+    32767 keys), the probes' clamp at its last entry, ranks above 32767 in the u16 tile and in the node records; values on every key, one
+    code below and above, beyond both ends, missing.  One part up to 37727 keys, two from 37728; `q16_max_table` = 32767 (the old limit)
+    must give the same bits in more parts; the same model as a sparse forest (u16-rank sparse kernels, the same rank kernel)."""
+    import torch
+
+    T, D, F, n = 160, 8, 3, 6000
+    nint, rng = 255, np.random.default_rng(K)
+    keys = np.sort(rng.choice(np.arange(1, 1 << 24, dtype=np.int64), K, replace=False)) * 64 + 0x3D000000   # K distinct positive fp32 patterns
+    fidx = np.zeros((T, nint), np.int64)
+    thr = np.empty((T, nint), np.uint32)
+    flat = np.concatenate([keys, keys[rng.integers(0, K, T * nint - K - 300)]])                               # every key at least once, the rest repeats
+    rng.shuffle(flat)
+    thr.reshape(-1)[: flat.size] = flat.astype(np.uint32)
+    fidx.reshape(-1)[flat.size:] = rng.integers(1, F, 300)                                                    # 300 nodes on the other features
+    thr.reshape(-1)[flat.size:] = rng.random(300).astype(np.float32).view(np.uint32)
+    leaves = ((rng.integers(1, 1 << 20, (T, 1 << D)).astype(np.float32) - np.float32(1 << 19)) * np.float32(2.0 ** -24))
+    mr = rng.integers(0, 2, (T, nint))
+    m = O.pack_model(thr, fidx, mr, leaves, F, clusters=2)
+    x = O.gen_tuples(3, n, F, dist=0, missing_bits=m.params.missing_bits)
+    col = np.concatenate([keys[rng.integers(0, K, n - 8)] + rng.integers(-1, 2, n - 8), [keys[0] - 1, keys[0], keys[-1], keys[-1] + 1, 0, 0x7F000000, keys[K // 2], keys[32767 % K]]])
+    x[:, 0] = col.astype(np.uint32)
+    x[17, 0] = m.params.missing_bits
+    d = torch.from_numpy(x.view(np.int32)).cuda()
+    e = ddt.Engine(0)
+    for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
+        want = O.score_fast(m, x, sum_mode=ref)
+        for limit in (37727, 32767):
+            e.set_option("q16_max_table", limit)
+            e.set_option("q16_cluster_split", 0)                                # (count the parts, not the slices of a small batch)
+            e.load_model(_params(m, sum_mode), m.wlines, m.flines)
+            assert e.info().variant_name.decode() == "q16_d8_c8_u4_gl_s2_cm_x"
+            before = e.stats().kernel_launches
+            got = e.score_device(d)
+            torch.cuda.synchronize()
+            launches = e.stats().kernel_launches - before
+            assert launches == (parts if limit == 37727 else 1 if K <= 32767 else 2), (K, limit, launches)
+            assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), (K, sum_mode, limit)
+            assert np.array_equal(e.score(x).view(np.uint32), want.view(np.uint32))
+    with pytest.raises(ddt.DDTError):
+        e.set_option("q16_max_table", 37728)
+    e.set_option("q16_max_table", 37727)
+    s = O.sparse_from_perfect(m)
+    q = s.params
+    e.load_model_sparse(ddt.make_sparse_params(q.num_trees, q.num_levels, q.num_features, q.missing_bits, q.cmp_mode, q.clusters_per_tuple, 0), s.node_lines, s.first)
+    name = e.info().variant_name.decode()
+    assert name.startswith("sparse_q") == (K <= 37727), name                   # u16 ranks while ONE table holds the forest's thresholds (sparse forests have no parts)
+    assert np.array_equal(e.score(x).view(np.uint32), O.score_sparse_fast(s, x).view(np.uint32))
     e.close()

@@ -1,7 +1,7 @@
 """The deep rank-quantised kernels (`q16d_dD_kK_*`, csrc/ddt_deep.hip score_q16d_kernel) against the oracle on the GPU: perfect trees
 of depth 9..15 -- the reference's own example configuration is 512 trees x depth 12 x 32 features (profiler/profiler.cpp:32-38; a depth-12
 tree is one PU's memory, DTPU.sv:22-25).  K levels out of LDS, then (D - K + 1) / 2 gathers of 16-byte pair / terminal records per tree, as
-a pipeline that rotates across sub-groups and chunk barriers; cluster-major sums; ensembles with more than 32767 thresholds on a feature
+a pipeline that rotates across sub-groups and chunk barriers; cluster-major sums; ensembles with more than 37727 thresholds on a feature
 in parts.  Every row compared bit for bit, both adders, tiles with and without missing values, ragged sizes, many tiles per CU."""
 import numpy as np
 import pytest

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="also capture the call into a HIP graph (torch.cuda.CUDAGraph around ddt_score_device on the capture stream, after the warm-up calls "
+                         "that size the workspaces) and time its replays: us_graph_median / us_graph_host_median, and the replayed result against the oracle")
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
     import numpy as np
@@ -104,9 +107,39 @@ def main():
             ok = None
             if ref is not None and n <= len(ref):
                 ok = bool(np.array_equal(o.cpu().numpy().view(np.uint32), np.asarray(ref[:n], dtype=np.float32).view(np.uint32)))
+            gr = {}
+            if args.graph:
+                # the library's launches of one call (memset of the tile flags, rank pre-pass, scoring kernel(s), combine) as ONE graph launch: legal once
+                # the workspaces have their size (a call that grows one synchronises the device and reallocates, which a capture refuses)
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        call(t_in, o, n)
+                    o.zero_()
+                    g.replay()
+                    torch.cuda.synchronize()
+                    if ref is not None and n <= len(ref):
+                        gr["graph_bit_exact"] = bool(np.array_equal(o.cpu().numpy().view(np.uint32), np.asarray(ref[:n], dtype=np.float32).view(np.uint32)))
+                    gs, gh = [], []
+                    for _ in range(args.reps):
+                        t0 = time.perf_counter()
+                        g.replay()
+                        t1 = time.perf_counter()
+                        torch.cuda.synchronize()
+                        gs.append((time.perf_counter() - t0) * 1e6)
+                        gh.append((t1 - t0) * 1e6)
+                    gs.sort()
+                    gh.sort()
+                    gr["us_graph_median"] = round(gs[len(gs) // 2], 1)
+                    gr["us_graph_host_median"] = round(gh[len(gh) // 2], 1)
+                    del g
+                except Exception as ex:  # a capture the runtime refused: said, not hidden
+                    gr["graph_error"] = repr(ex)[:300]
+                    torch.cuda.synchronize()
             info = eng.info()
             r = {"config": cfg, "trees": T, "depth": D, "features": F, "rows": n, "us_median": round(med, 1), "us_p90": round(p90, 1), "us_host_call_median": round(hs[len(hs) // 2], 1),
                  "mtuples_per_s": round(n / med, 3), "kernel": info.variant_name.decode(), "bit_exact": ok}
+            r.update(gr)
             res.append(r)
             print(json.dumps(r), flush=True)
         eng.close()

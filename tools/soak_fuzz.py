@@ -55,7 +55,7 @@ def draw_case(rng):
         F = int(rng.integers(1, 33)) if rng.random() < 0.6 else int(rng.integers(33, 65)) if rng.random() < 0.7 else int(rng.integers(65, 260))
         c.update(T=T, D=D, F=F)
         if kind == "shard":
-            G = int(rng.choice([2, 3, 4, 8]))
+            G = min(int(rng.choice([2, 3, 4, 8])), T)  # (the library refuses more shards than trees: ddt_load_model_shard)
             c.update(G=G, g=int(rng.integers(0, G)))
         if kind == "classes":
             K = int(rng.integers(2, 13))
