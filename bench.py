@@ -609,7 +609,7 @@ def main(argv=None, inproc_env=None):
                     "prepass_ms": round(pre_ms, 4),  # rank pre-pass of the rank-quantised path (0 otherwise)
                     "prepass_groups": info.prepass_groups,  # feature groups of the LDS-resident pre-pass (0: transpose + rank kernels / n.a.)
                     "alg_bytes_per_launch": alg_bytes_per_launch,
-                    # an ensemble with more than 37727 distinct thresholds on a feature is scored in PARTS (one rank pre-pass + one scoring launch
+                    # an ensemble with more than 38848 distinct thresholds on a feature is scored in PARTS (one rank pre-pass + one scoring launch
                     # each, the reference-order sum handed on): kernel_ms is then everything behind the FIRST part's pre-pass
                     "scoring_launches_per_step": round(launches_per_step, 2),
                     "device": {"cus": info.num_cus, "clock_mhz": round(clock_hz / 1e6, 1), "lds_bytes_per_cu": info.lds_bytes_per_cu}}

@@ -139,7 +139,7 @@ struct ddt_engine {
   int q_slot = 0;
   int q16_grouped_prepass = 1;  // option "q16_grouped_prepass": 0 = never split the pre-pass over feature groups
   int q16_prepass_groups = 0;   // option "q16_prepass_groups": force the number of feature groups (A/B), 0 = automatic
-  uint32_t q16_max_table = 37727;  // option "q16_max_table" (= kQ16MaxTable below): distinct thresholds per feature one part's rank table may hold (A/B, tests: 32767 = the limit until round 6)
+  uint32_t q16_max_table = 38848;  // option "q16_max_table" (= kQ16MaxTable below): distinct thresholds per feature one part's rank table may hold (A/B, tests: 32767 = the limit until round 6)
   int q16_fused_prepass = 1;  // option "q16_fused_prepass": 0 forces the transpose + rank kernels (A/B, tests)
   int q16_prepass_nt = 0;     // option "q16_prepass_nt": bit 0 = nontemporal stores of the rank tiles, bit 1 = nontemporal tuple loads (A/B)
   int q16_persistent = -1;    // option "q16_persistent": 1 / 0 = prefer / never pick the persistent "_p" kernel, -1 = automatic
@@ -281,23 +281,24 @@ int timing_begin(ddt_engine* e, hipStream_t s);
 int timing_end(ddt_engine* e, hipStream_t s);
 void timing_resolve(ddt_engine* e, int keep_pending);
 // rank tables: host packing (no HIP call) and upload; tables longer than kQ16MaxTable keys do not fit the u16 ranks
-// Ranks must stay below 0xFFFF and a table must fit the LDS of ONE block of rank_kernel: entry i at word i + i / 32 (the skew), + 1 word, + the
-// bucket starts (kQ16RankBuckets u16), within MI355X's 160 KiB per workgroup.  Up to 32767 keys the table is padded to the next power of two
-// (128 KiB + 4 KiB of skew + 8 KiB); longer tables to a multiple of 32 entries (q16_table_pad) -- 37727 keys is what the last 20 KiB hold.
+// Ranks must stay below 0xFFFF and a table must fit the LDS of ONE block of rank_kernel: Kpad entries + the bucket starts (kQ16RankBuckets u16)
+// within MI355X's 160 KiB per workgroup.  Up to 32767 keys the table is padded to the next power of two (128 KiB + 8 KiB); a longer one to a multiple
+// of 32 entries with at least 64 pads behind its keys (q16_table_pad: a search probes up to P - 2 entries past its start, and P <= 64 unless the keys are
+// degenerate -- the kernel clamps then) -- 38848 keys is what 152 KiB hold.
 // (Until round 6 the limit was 32767: the reference's own example, 512 trees x depth 12 x 32 features = 65.4 k thresholds per feature, then
 // needed a THIRD part of 16 trees -- a rank pre-pass and a scoring launch over every tuple for 3 % of the trees.)
-constexpr uint32_t kQ16MaxTable = 37727;
+constexpr uint32_t kQ16MaxTable = 38848;
 constexpr uint32_t q16_table_pad(uint32_t max_len) {  // Q16Aux::Kpad: entries per table, > max_len (entry Kpad - 1 is always an INT_MAX pad)
-  if (max_len >= 32768u) return (max_len + 1u + 31u) / 32u * 32u;
+  if (max_len >= 32768u) return (max_len + 64u + 31u) / 32u * 32u;
   uint32_t k = 2;
   while (k <= max_len) k <<= 1;
   return k;
 }
-constexpr uint32_t q16_rank_lds_bytes(uint32_t Kpad) { return (Kpad + (Kpad >> 5) + 1u) * 4u + kQ16RankBuckets * 2u; }  // rank_kernel's LDS
+constexpr uint32_t q16_rank_lds_bytes(uint32_t Kpad) { return Kpad * 4u + kQ16RankBuckets * 2u; }  // rank_kernel's LDS
 static_assert(q16_rank_lds_bytes(q16_table_pad(kQ16MaxTable)) <= kMaxLdsBytes && q16_rank_lds_bytes(q16_table_pad(kQ16MaxTable + 32u)) > kMaxLdsBytes,
               "kQ16MaxTable = the longest table one block's LDS holds");
-static_assert(kQ16MaxTable == 37727u, "ddt_engine::q16_max_table's initialiser");
-static_assert(q16_table_pad(32767u) == 32768u && q16_table_pad(32768u) == 32800u && q16_table_pad(8160u) == 8192u, "table padding");
+static_assert(kQ16MaxTable == 38848u, "ddt_engine::q16_max_table's initialiser");
+static_assert(q16_table_pad(32767u) == 32768u && q16_table_pad(32768u) == 32832u && q16_table_pad(8160u) == 8192u, "table padding");
 void finish_rank_tables(RankTables& rt);  // sort + unique every feature's keys, set max_len
 int pack_rank_tables(ddt_engine* e, const RankTables& rt, uint32_t W, bool want_prepass, RankHostTables& h);
 int upload_rank_tables(ddt_engine* e, const RankHostTables& h, RankDevice& d);

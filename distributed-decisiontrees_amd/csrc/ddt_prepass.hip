@@ -112,17 +112,21 @@ constexpr uint32_t kRankThreads = 1024;  // two blocks per CU share the LDS with
 // starts[b] finish the count -- keys past the slice are > x by construction, no end test.  1000 trees x 255
 // nodes over 32 features (~8 k keys per table): 1 + 5 LDS reads instead of 13.  Degenerate key distributions
 // only make P larger, up to the plain binary search over the whole table.
+// Round 6 (late): the search as in rank_line below -- this kernel had kept round 2's form: a table skewed by i / 32 (against the bank pattern of a
+// binary search from entry 0, which the bucket starts ended), every probe's index clamped, skewed and scaled = 8 VALU instructions per probe, ~75
+// per value: 0.85 ms per 320 M values where the HBM needs 0.35.  Now the position is the BYTE ADDRESS of its entry in a LINEAR table, a probe is
+// ds_read_b32 with (step - 1) * 4 as the DS immediate and costs compare + select + add; the clamp (one v_min against a wave-uniform bound) only runs
+// for a feature whose pads behind the keys are fewer than P (K + P > Kpad, wave-uniform: the host pads long tables by 64 entries for that).  The LDS the
+// skew took (Kpad / 32 words) is table now: q16_rank_lds_bytes / kQ16MaxTable (ddt_engine_priv.h).
+template <bool IEEE>
 __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __restrict__ xT, uint64_t n, uint64_t n_pad,
                                                    const uint32_t* __restrict__ tables, uint32_t Kpad,
                                                    const uint32_t* __restrict__ tabP, const uint16_t* __restrict__ tabS,
-                                                   uint32_t miss_raw, uint32_t ieee,
+                                                   uint32_t miss_raw,
                                                    uint32_t W, uint16_t* __restrict__ q, uint32_t* __restrict__ tile_flags) {
   const uint32_t j = blockIdx.y, tid = threadIdx.x;
-  // The probes of a power-of-two binary search are all = step-1 (mod step): with a linear table every probe of
-  // the first steps lands in ONE bank (measured: 23.6 conflict cycles per DS op, LDS pipe 97 % busy).
-  // Entry i is therefore stored at i + i/32: one padding word per 32 entries rotates the bank per segment.
-  for (uint32_t i = tid; i < Kpad; i += kRankThreads) lds_st_u32((i + (i >> 5)) * 4u, tables[(size_t)j * Kpad + i]);
-  const uint32_t starts_off = (Kpad + (Kpad >> 5) + 1u) * 4u;
+  for (uint32_t i = tid; i < Kpad; i += kRankThreads) lds_st_u32(i * 4u, tables[(size_t)j * Kpad + i]);
+  const uint32_t starts_off = Kpad * 4u;
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(tabS + (size_t)j * kRankBuckets);
     for (uint32_t i = tid; i < kRankBuckets / 2u; i += kRankThreads) lds_st_u32(starts_off + i * 4u, src[i]);
@@ -130,6 +134,9 @@ __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __re
   __syncthreads();
   const uint32_t K = tabP[j * 8u + 0u], lo = tabP[j * 8u + 1u], hi = tabP[j * 8u + 2u], shift = tabP[j * 8u + 3u];
   const uint32_t P = tabP[j * 8u + 4u];
+  const uint32_t last = (Kpad - 1u) * 4u;  // byte address of the table's last entry: always an INT_MAX pad
+  // a search that starts at entry s <= K probes entries <= s + P - 2: inside the pads when K + P <= Kpad
+  const bool clamp = __builtin_amdgcn_readfirstlane((int)(K + P > Kpad)) != 0;
   // Lane (tid & 511) of half-block (tid >> 9) owns tuples t and t+512 of a tile -- the two halves of one dword of
   // the q tile (see the layout note below) -- in two tiles per pass: 4 independent searches per lane (the
   // dependent LDS reads of one search are latency bound) and full 4-byte, fully coalesced stores of the ranks.
@@ -147,6 +154,28 @@ __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __re
       dst[i] = tile < tiles ? xT[(uint64_t)j * n_pad + tile * kQTile + t + 512u * (uint32_t)(i & 1)] : 0u;
     }
   };
+  auto probes = [&](auto clamp_tag, const int32_t (&x)[ILP], uint32_t (&pos)[ILP]) {
+    constexpr bool CL = decltype(clamp_tag)::value;
+    for (uint32_t step = P >> 1; step >= 64u; step >>= 1) {  // (buckets of 128 keys and more: degenerate key distributions only)
+#pragma unroll
+      for (int i = 0; i < ILP; ++i) {
+        uint32_t a = pos[i] + (step - 1u) * 4u;
+        if (CL) a = a < last ? a : last;
+        if ((int32_t)lds_u32(a) <= x[i]) pos[i] += step * 4u;
+      }
+    }
+#pragma unroll
+    for (uint32_t step = 32u; step >= 1u; step >>= 1) {
+      if (step < P) {  // wave-uniform
+        const uint32_t bound = last - (step - 1u) * 4u;  // (step < P <= 2 K and K < Kpad: no wrap)
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) {
+          const uint32_t a = CL ? (pos[i] < bound ? pos[i] : bound) : pos[i];
+          if ((int32_t)lds_u32(a + (step - 1u) * 4u) <= x[i]) pos[i] += step * 4u;
+        }
+      }
+    }
+  };
   uint32_t raw_next[ILP];
   load_pass(raw_next, (uint64_t)blockIdx.x * 4u + sub);
   for (uint64_t tile0 = (uint64_t)blockIdx.x * 4u + sub; tile0 < tiles; tile0 += pass_stride) {
@@ -157,26 +186,21 @@ __global__ __launch_bounds__(kRankThreads) void rank_kernel(const uint32_t* __re
     load_pass(raw_next, tile0 + pass_stride);
 #pragma unroll
     for (int i = 0; i < ILP; ++i) {
-      x[i] = (int32_t)(ieee ? ieee_key(raw[i]) : raw[i]);
+      x[i] = (int32_t)(IEEE ? ieee_key(raw[i]) : raw[i]);
       uint32_t b = ((uint32_t)x[i] - lo) >> shift;  // wraps to a huge value below lo: selected away next
       b = b < kRankBuckets - 1u ? b : kRankBuckets - 1u;
       b = x[i] < (int32_t)lo ? 0u : b;
-      pos[i] = *reinterpret_cast<const DDT_LDS(uint16_t)*>(starts_off + b * 2u);
+      pos[i] = 4u * (uint32_t)*reinterpret_cast<const DDT_LDS(uint16_t)*>(starts_off + b * 2u);  // byte address of the bucket's first key
     }
-    for (uint32_t step = P >> 1; step >= 1u; step >>= 1) {
-#pragma unroll
-      for (int i = 0; i < ILP; ++i) {
-        uint32_t probe = pos[i] + step - 1u;
-        probe = probe < Kpad - 1u ? probe : Kpad - 1u;  // entry Kpad-1 is always the INT_MAX pad
-        if ((int32_t)lds_u32((probe + (probe >> 5)) * 4u) <= x[i]) pos[i] += step;
-      }
-    }
+    if (clamp) probes(std::true_type{}, x, pos);
+    else probes(std::false_type{}, x, pos);
     uint32_t r[ILP];
 #pragma unroll
     for (int i = 0; i < ILP; ++i) {
       const uint64_t tile = tile0 + 2u * (uint32_t)(i >> 1);
       const uint64_t row = tile * kQTile + t + 512u * (uint32_t)(i & 1);
-      r[i] = x[i] > (int32_t)hi ? K : (pos[i] < K ? pos[i] : K);
+      const uint32_t p = pos[i] >> 2;
+      r[i] = x[i] > (int32_t)hi ? K : (p < K ? p : K);
       if (raw[i] == miss_raw && tile < tiles && row < n) {  // bit equality with the missing pattern (DTPU.sv:653), before any transform
         r[i] = kQMissing;
         atomicOr(&tile_flags[tile], 1u);
@@ -476,8 +500,9 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
   const uint64_t tiles = (a.n + kQTile - 1) / kQTile;
   if (tiles == 0) return hipSuccess;
   const uint32_t W = a.tuple_words;
-  const uint32_t rank_lds = (x.Kpad + (x.Kpad >> 5) + 1u) * 4u + kRankBuckets * 2u;  // skewed table + bucket starts, see rank_kernel
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds);
+  const uint32_t rank_lds = x.Kpad * 4u + kRankBuckets * 2u;  // table + bucket starts, see rank_kernel
+  auto rk = a.ieee ? rank_kernel<true> : rank_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds);
   if (e != hipSuccess) return e;
   // tile flags + (8-byte aligned, right behind them) the work counters of the fused / grouped pre-pass
   unsigned long long* counter = reinterpret_cast<unsigned long long*>(x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u));
@@ -538,7 +563,7 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
         hipLaunchKernelGGL(transpose_kernel, dim3((uint32_t)(x.n_pad / 256)), dim3(256), (W + 1) * 256 * 4, s, a.tuples, W, a.n, x.n_pad, x.xT);
       }
     }
-    // grid-stride over tiles; blockIdx.y = feature; the table (up to 128 KiB) is loaded once per block, so the blocks are as few and as
+    // grid-stride over tiles; blockIdx.y = feature; the table (up to 152 KiB) is loaded once per block, so the blocks are as few and as
     // long-lived as fill the chip: resident blocks per CU (one with a big table, two when two fit) x CUs, split over the features.  (Until
     // round 5: up to 512 blocks per feature -- 16384 blocks of ~19 tiles each at 32 features, a third of whose time was the table load:
     // 1.19 ms per 10 M tuples x 32 features with 32 k keys each; DDT_RANK_GRID_OLD=1 brings that grid back for A/B.)
@@ -554,8 +579,8 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
       const uint32_t want = (per_cu * a.num_cus + W - 1u) / W;
       if (bx > want) bx = want < 1u ? 1u : want;
     }
-    hipLaunchKernelGGL(rank_kernel, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabP, x.tabS, a.miss_raw,
-                       a.ieee, W, x.q, x.tile_flags);
+    hipLaunchKernelGGL(rk, dim3(bx, W), dim3(kRankThreads), rank_lds, s, x.xT, a.n, x.n_pad, x.tables, x.Kpad, x.tabP, x.tabS, a.miss_raw, W, x.q,
+                       x.tile_flags);
   }
   return hipGetLastError();
 }

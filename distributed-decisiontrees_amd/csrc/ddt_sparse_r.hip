@@ -48,9 +48,9 @@ __global__ __launch_bounds__(kR32Threads) void rank32_kernel(const uint32_t* __r
   const uint32_t tid = threadIdx.x, xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, fper = (W + 7u) / 8u;
   const uint32_t j = xcd + 8u * (slot % fper), chunk = slot / fper, chunks = gridDim.x / (8u * fper);
   if (j >= W) return;
-  // (entry i at i + i / 32: the probes of a power-of-two search would otherwise all land in one bank, see rank_kernel)
-  for (uint32_t i = tid; i < Dpad; i += kR32Threads) lds_st_u32((i + (i >> 5)) * 4u, dir[(size_t)j * Dpad + i]);
-  const uint32_t starts_off = (Dpad + (Dpad >> 5) + 1u) * 4u;
+  // (a linear table, the search position carried as the byte address of its entry: rank_kernel, ddt_prepass.hip)
+  for (uint32_t i = tid; i < Dpad; i += kR32Threads) lds_st_u32(i * 4u, dir[(size_t)j * Dpad + i]);
+  const uint32_t starts_off = Dpad * 4u;
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(tabS + (size_t)j * kQ16RankBuckets);
     for (uint32_t i = tid; i < kQ16RankBuckets / 2u; i += kR32Threads) lds_st_u32(starts_off + i * 4u, src[i]);
@@ -60,6 +60,8 @@ __global__ __launch_bounds__(kR32Threads) void rank32_kernel(const uint32_t* __r
   const uint32_t koff = tabP[j * 8u + 5u], K = tabP[j * 8u + 6u], hi_real = tabP[j * 8u + 7u];
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(tab), 0, (int)tab_bytes, 0x00020000);
   const uint32_t quads = 1u << (blk_log2 - 2u);  // 16-byte gathers per block
+  const uint32_t last = (Dpad - 1u) * 4u;        // byte address of the directory's last entry: always an INT_MAX pad
+  const bool clamp = __builtin_amdgcn_readfirstlane((int)(Kd + P > Dpad)) != 0;  // a search probes entries <= start + P - 2: inside the pads otherwise
   constexpr int ILP = 4;  // independent searches per lane: the dependent LDS reads of one search are latency bound
   const uint64_t pass_rows = (uint64_t)kR32Threads * ILP, pass_stride = (uint64_t)chunks * pass_rows;
   auto load_pass = [&](uint32_t (&dst)[ILP], uint64_t row0) {
@@ -67,6 +69,28 @@ __global__ __launch_bounds__(kR32Threads) void rank32_kernel(const uint32_t* __r
     for (int i = 0; i < ILP; ++i) {
       const uint64_t row = row0 + (uint64_t)i * kR32Threads + tid;
       dst[i] = row < n_pad ? __builtin_nontemporal_load(xT + (uint64_t)j * n_pad + row) : 0u;  // (streamed once: keep the L2 for the key blocks)
+    }
+  };
+  auto probes = [&](auto clamp_tag, const int32_t (&x)[ILP], uint32_t (&pos)[ILP]) {  // as rank_kernel's (ddt_prepass.hip): compare + select + add per probe
+    constexpr bool CL = decltype(clamp_tag)::value;
+    for (uint32_t step = P >> 1; step >= 64u; step >>= 1) {
+#pragma unroll
+      for (int i = 0; i < ILP; ++i) {
+        uint32_t a = pos[i] + (step - 1u) * 4u;
+        if (CL) a = a < last ? a : last;
+        if ((int32_t)lds_u32(a) <= x[i]) pos[i] += step * 4u;
+      }
+    }
+#pragma unroll
+    for (uint32_t step = 32u; step >= 1u; step >>= 1) {
+      if (step < P) {  // wave-uniform
+        const uint32_t bound = last - (step - 1u) * 4u;
+#pragma unroll
+        for (int i = 0; i < ILP; ++i) {
+          const uint32_t a = CL ? (pos[i] < bound ? pos[i] : bound) : pos[i];
+          if ((int32_t)lds_u32(a + (step - 1u) * 4u) <= x[i]) pos[i] += step * 4u;
+        }
+      }
     }
   };
   uint32_t raw_next[ILP];
@@ -83,16 +107,12 @@ __global__ __launch_bounds__(kR32Threads) void rank32_kernel(const uint32_t* __r
       uint32_t b = ((uint32_t)x[i] - lo) >> shift;  // wraps to a huge value below lo: selected away next
       b = b < kQ16RankBuckets - 1u ? b : kQ16RankBuckets - 1u;
       b = x[i] < (int32_t)lo ? 0u : b;
-      pos[i] = *reinterpret_cast<const DDT_LDS(uint16_t)*>(starts_off + b * 2u);
+      pos[i] = 4u * (uint32_t)*reinterpret_cast<const DDT_LDS(uint16_t)*>(starts_off + b * 2u);  // byte address of the bucket's first entry
     }
-    for (uint32_t step = P >> 1; step >= 1u; step >>= 1) {
+    if (clamp) probes(std::true_type{}, x, pos);
+    else probes(std::false_type{}, x, pos);
 #pragma unroll
-      for (int i = 0; i < ILP; ++i) {
-        uint32_t probe = pos[i] + step - 1u;
-        probe = probe < Dpad - 1u ? probe : Dpad - 1u;  // entry Dpad-1 is always an INT_MAX pad
-        if ((int32_t)lds_u32((probe + (probe >> 5)) * 4u) <= x[i]) pos[i] += step;
-      }
-    }
+    for (int i = 0; i < ILP; ++i) pos[i] >>= 2;
     // pos = number of blocks whose LAST key is <= x: all their keys count, and block `pos` holds the rest of the answer
     uint32_t cnt[ILP], byte[ILP];
 #pragma unroll
@@ -142,7 +162,7 @@ hipError_t launch_r32_prepass(const ScoreArgs& a, const SparseAux& x, hipStream_
   if (e != hipSuccess) return e;
   e = launch_transpose(a.tuples, W, a.n, q.n_pad, q.xT, s);
   if (e != hipSuccess) return e;
-  const uint32_t lds = (q.Kpad + (q.Kpad >> 5) + 1u) * 4u + kQ16RankBuckets * 2u;
+  const uint32_t lds = q.Kpad * 4u + kQ16RankBuckets * 2u;
   static const int policy = [] {  // A/B: cache policy of the key-block gathers (DDT_R32_POLICY = 0 default / 1 sc1 / 2 nt)
     const char* v = getenv("DDT_R32_POLICY");
     return v && v[0] ? atoi(v) : 0;

@@ -153,7 +153,13 @@ int ddt_host_unregister(ddt_engine* e, void* ptr);
  * threads, the link transfer of k+1 on one ordered copy stream, kernels + scores back of k; ranges pinned with ddt_host_register
  * skip the staging copies.                                                                           */
 int ddt_score(ddt_engine* e, const void* tuple_lines, size_t n_tuples, float* scores_out);
-/* Device buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = the null stream).              */
+/* Device buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = the null stream).
+ * Stream capture: once a call of at least this size has sized the engine's workspaces ("reserve_rows", or one warm-up call), the call only
+ * enqueues work on `hip_stream` -- the tile flags' memset, the rank pre-pass, the scoring kernel(s), the combine of a cut launch -- with no
+ * allocation and no synchronisation, and everything that depends on the batch (missing-value flags, partial sums, ticket counters) is rebuilt on
+ * the stream: it may be captured into a HIP graph and replayed on new data in the same buffers (tests/test_graph_capture.py; not with
+ * "kernel_timing").  A replay costs what the call costs on the device (profiles/r06_small_batches.md: the host's share drops from ~15 to ~8 us,
+ * the call's latency does not move -- it is the device's).                                              */
 int ddt_score_device(ddt_engine* e, const void* d_tuple_lines, size_t n_tuples, float* d_scores,
                      void* hip_stream);
 
@@ -351,7 +357,7 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * "q16_fused_prepass" / "q16_grouped_prepass" (1 = default; 0 = never rank with all tables resident together / never
  * split the rank pre-pass over feature groups; both 0 = the transpose + rank kernels) and "q16_prepass_groups" (0 =
  * cheapest, default; 1, 2, 4, 8 = exactly that many feature groups): A/B switches, effective at the next model load;
- * "q16_max_table" (255..37727, default 37727: the distinct thresholds per feature ONE rank table may hold -- what fits a block's LDS in the rank
+ * "q16_max_table" (255..38848, default 38848: the distinct thresholds per feature ONE rank table may hold -- what fits a block's LDS in the rank
  * kernel; an ensemble beyond it is scored in parts; 32767 = the limit until round 6; effective at the next model load);
  * "q16_persistent" (-1 = default: the persistent depth-8 rank-quantised kernel -- resident blocks that take tiles from a ticket
  * counter -- where it wins: one-vs-all models whose classes hold equally many trees, scored in ONE launch, and engines inside a
@@ -371,7 +377,7 @@ const char* ddt_last_error(const ddt_engine* e); /* detail of the last failure o
  * "leaf_domain_check" (1 = default: refuse -0 / sub-normal / Inf / NaN leaves in the reference-order sum, where the
  * GPU's IEEE adds and the reference's adder differ), "sparse_top_levels" (-1 = auto, or 6..10 levels of a sparse
  * forest staged in LDS), "sparse_deep_order" (0 = level order, default; 1 = depth-first per sub-tree), "sparse_q16" (1 =
- * default: sparse forests whose distinct thresholds per feature fit 16-bit ranks -- at most 37727 (what one block of the rank kernel holds in LDS), e.g. histogram-trained
+ * default: sparse forests whose distinct thresholds per feature fit 16-bit ranks -- at most 38848 (what one block of the rank kernel holds in LDS), e.g. histogram-trained
  * models -- and whose tuples have at most 64..76 words run on the rank-quantised sparse kernels: u16 feature tile, 1024
  * tuples per block; 0 = always the fp32-tile kernels), "sparse_dk" (1 = default: the "dense level K" sparse kernels where they
  * exist -- all top levels as 8-byte records in LDS, the first deep level addressed by the heap index; 0 = never: only the kernels with 16-byte

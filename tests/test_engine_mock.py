@@ -645,9 +645,9 @@ def test_cluster_major_image_order(mock, T, clusters):
     mock.ddt_destroy(e)
 
 
-@pytest.mark.parametrize("T,F,clusters,parts", [(600, 4, 1, 2), (600, 4, 8, 2), (1100, 4, 4, 2), (1250, 4, 4, 3), (300, 4, 2, 1)])
+@pytest.mark.parametrize("T,F,clusters,parts", [(650, 4, 1, 2), (650, 4, 8, 2), (1100, 4, 4, 2), (1250, 4, 4, 3), (300, 4, 2, 1)])
 def test_more_thresholds_than_u16_ranks_hold_is_scored_in_parts(mock, T, F, clusters, parts):
-    """u16 ranks stop at 37727 distinct thresholds per feature -- what one block's LDS holds in rank_kernel; 32767 until round 6 -- (the reference allows 8192 nodes x 64 PUs on one feature, DTPU.sv:22,74).
+    """u16 ranks stop at 38848 distinct thresholds per feature -- what one block's LDS holds in rank_kernel; 32767 until round 6 -- (the reference allows 8192 nodes x 64 PUs on one feature, DTPU.sv:22,74).
     Beyond that the cluster-major kernels score the ensemble in PARTS -- consecutive chunks of the image with rank tables of their own, a
     pre-pass + a scoring launch per part, the reference-order sum handed from launch to launch (accumulator + running total per tuple):
     bit-exact with the oracle for every cluster count and both adders, through resident and host calls, back to back."""
@@ -811,7 +811,7 @@ def test_deep_perfect_trees_on_the_deep_kernels(mock, T, D, F, clusters, name, p
     """Perfect trees deeper than 8 levels (the reference's own example: 512 x depth 12, profiler/profiler.cpp:32-38) take the deep
     rank-quantised kernels by themselves: K levels as a heap of 4-byte records, then pair / terminal records of 16 bytes per stage
     (csrc/ddt_internal.h).  The host side -- image packing in cluster-major order, the records' own next-block offsets, parts with rank
-    tables of their own when a feature carries more than 37727 distinct thresholds, the sum's state between the parts -- against the
+    tables of their own when a feature carries more than 38848 distinct thresholds, the sum's state between the parts -- against the
     oracle bit for bit, both adders, tiles with and without missing values, resident and host calls."""
     mock.mock_reset(2, 9, 8)
     n = 1300

@@ -241,9 +241,9 @@ def test_grouped_and_two_kernel_prepass_agree(T, F):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T,F,clusters,n", [(600, 4, 1, 5000), (1100, 4, 8, 3000), (4000, 16, 8, 2500)])
+@pytest.mark.parametrize("T,F,clusters,n", [(650, 4, 1, 5000), (1100, 4, 8, 3000), (4000, 16, 8, 2500)])
 def test_ensembles_beyond_the_u16_rank_range_are_scored_in_parts(T, F, clusters, n):
-    """More than 37727 distinct thresholds on a feature (4000 trees x 255 nodes over 16 features: ~64 k each): the cluster-major kernel
+    """More than 38848 distinct thresholds on a feature (4000 trees x 255 nodes over 16 features: ~64 k each): the cluster-major kernel
     scores the ensemble in parts with rank tables of their own, the reference-order sum handed from launch to launch -- bit-exact, both adders."""
     import torch
 
@@ -267,12 +267,12 @@ def test_ensembles_beyond_the_u16_rank_range_are_scored_in_parts(T, F, clusters,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,parts", [(32767, 1), (32768, 1), (35001, 1), (37727, 1), (37728, 2)])
-def test_rank_tables_of_up_to_37727_keys_fit_one_blocks_lds(K, parts):
-    """One rank table = what ONE block of rank_kernel holds in LDS (csrc/ddt_engine_priv.h kQ16MaxTable: 37727 keys; 32767 and a
+@pytest.mark.parametrize("K,parts", [(32767, 1), (32768, 1), (35001, 1), (37727, 1), (38848, 1), (38849, 2)])
+def test_rank_tables_of_up_to_38848_keys_fit_one_blocks_lds(K, parts):
+    """One rank table = what ONE block of rank_kernel holds in LDS (csrc/ddt_engine_priv.h kQ16MaxTable: 38848 keys; 32767 and a
     power-of-two table until round 6).  A feature with EXACTLY K distinct thresholds: the table's padding (a multiple of 32 entries beyond
     32767 keys), the probes' clamp at its last entry, ranks above 32767 in the u16 tile and in the node records; values on every key, one
-    code below and above, beyond both ends, missing.  One part up to 37727 keys, two from 37728; `q16_max_table` = 32767 (the old limit)
+    code below and above, beyond both ends, missing.  One part up to 38848 keys, two from 38849; `q16_max_table` = 32767 (the old limit)
     must give the same bits in more parts; the same model as a sparse forest (u16-rank sparse kernels, the same rank kernel)."""
     import torch
 
@@ -297,7 +297,7 @@ def test_rank_tables_of_up_to_37727_keys_fit_one_blocks_lds(K, parts):
     e = ddt.Engine(0)
     for sum_mode, ref in ((0, O.SUM_REF_NATIVE), (2, O.SUM_REF_FLOPOCO)):
         want = O.score_fast(m, x, sum_mode=ref)
-        for limit in (37727, 32767):
+        for limit in (38848, 32767):
             e.set_option("q16_max_table", limit)
             e.set_option("q16_cluster_split", 0)                                # (count the parts, not the slices of a small batch)
             e.load_model(_params(m, sum_mode), m.wlines, m.flines)
@@ -306,16 +306,16 @@ def test_rank_tables_of_up_to_37727_keys_fit_one_blocks_lds(K, parts):
             got = e.score_device(d)
             torch.cuda.synchronize()
             launches = e.stats().kernel_launches - before
-            assert launches == (parts if limit == 37727 else 1 if K <= 32767 else 2), (K, limit, launches)
+            assert launches == (parts if limit == 38848 else 1 if K <= 32767 else 2), (K, limit, launches)
             assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), (K, sum_mode, limit)
             assert np.array_equal(e.score(x).view(np.uint32), want.view(np.uint32))
     with pytest.raises(ddt.DDTError):
-        e.set_option("q16_max_table", 37728)
-    e.set_option("q16_max_table", 37727)
+        e.set_option("q16_max_table", 38849)
+    e.set_option("q16_max_table", 38848)
     s = O.sparse_from_perfect(m)
     q = s.params
     e.load_model_sparse(ddt.make_sparse_params(q.num_trees, q.num_levels, q.num_features, q.missing_bits, q.cmp_mode, q.clusters_per_tuple, 0), s.node_lines, s.first)
     name = e.info().variant_name.decode()
-    assert name.startswith("sparse_q") == (K <= 37727), name                   # u16 ranks while ONE table holds the forest's thresholds (sparse forests have no parts)
+    assert name.startswith("sparse_q") == (K <= 38848), name                   # u16 ranks while ONE table holds the forest's thresholds (sparse forests have no parts)
     assert np.array_equal(e.score(x).view(np.uint32), O.score_sparse_fast(s, x).view(np.uint32))
     e.close()

@@ -150,7 +150,7 @@ def test_a_small_batch_is_faster_cut():
 def test_cut_launch_on_the_deep_kernels(T, D, F, clusters, name):
     """The deep kernels (depth 9-15, csrc/ddt_deep.hip SPLIT): slices of PU groups, every group's sum out at group0 + its place in the launch's
     image, one combine behind the last launch -- also for an ensemble scored in PARTS (512 x d12 x 32 is two, 70 x d12 x 3 three: more than
-    37727 thresholds per feature), whose parts then hand no state from launch to launch.  Oracle's bits, both adders, the uncut launch beside it."""
+    38848 thresholds per feature), whose parts then hand no state from launch to launch.  Oracle's bits, both adders, the uncut launch beside it."""
     import torch
 
     m = O.gen_model(T, D, F, dist=0, clusters=clusters)

@@ -1,7 +1,7 @@
 """The deep rank-quantised kernels (`q16d_dD_kK_*`, csrc/ddt_deep.hip score_q16d_kernel) against the oracle on the GPU: perfect trees
 of depth 9..15 -- the reference's own example configuration is 512 trees x depth 12 x 32 features (profiler/profiler.cpp:32-38; a depth-12
 tree is one PU's memory, DTPU.sv:22-25).  K levels out of LDS, then (D - K + 1) / 2 gathers of 16-byte pair / terminal records per tree, as
-a pipeline that rotates across sub-groups and chunk barriers; cluster-major sums; ensembles with more than 37727 thresholds on a feature
+a pipeline that rotates across sub-groups and chunk barriers; cluster-major sums; ensembles with more than 38848 thresholds on a feature
 in parts.  Every row compared bit for bit, both adders, tiles with and without missing values, ragged sizes, many tiles per CU."""
 import numpy as np
 import pytest
@@ -90,9 +90,9 @@ def test_the_references_own_configuration():
     dl, dcs = e.classify_device(d[:150_000])
     torch.cuda.synchronize()
     assert np.array_equal(dl.cpu().numpy(), want_l) and np.array_equal(_bits(dcs.cpu().numpy()), _bits(want_cs))
-    # two classes of 300 trees: 38 k thresholds per feature and class -> EVERY class in parts of its own.  The batch's transposed tuples serve all
+    # two classes of 320 trees: 41 k thresholds per feature and class -> EVERY class in parts of its own.  The batch's transposed tuples serve all
     # parts of all classes (they used to be transposed once per class) -- and only that batch: two different batches back to back
-    T2 = 600
+    T2 = 640
     m2 = O.gen_model(T2, D, F, dist=0)
     e.load_model_multiclass(ddt.make_params(T2, D, F, clusters=ddt.default_clusters(T2 // 2)), m2.wlines, m2.flines, 2, True)
     assert e.info().variant_name.decode() == "q16d_d12_k9_c4_u4_cm"
