@@ -342,6 +342,10 @@ const Variant& sparse_variant(int i);
 int num_sparse_r_variants();               // ddt_sparse_r.hip: and these last
 const Variant& sparse_r_variant(int i);
 hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint64_t n_pad, uint32_t* xT, hipStream_t s);  // ddt_prepass.hip
+// zeroes `words` 32-bit words with a KERNEL (tile flags, ticket counters): what every call clears in front of its pre-pass.  Not hipMemsetAsync: inside a
+// graph that PyTorch captured and replays, the memset node in front of the ticket-counter kernels did not reliably clear the counters (replays ranked
+// nothing and scored the previous batch's ranks; the same calls captured with plain hipStreamBeginCapture were fine) -- a kernel node has no such mode
+hipError_t launch_zero_words(uint32_t* p, uint64_t words, hipStream_t s);  // ddt_prepass.hip
 
 // n_classes > 1: the classes of a one-vs-all model, class_positions partial sums each, class k's sum to out[k * out_pitch + row]
 hipError_t launch_cm_combine(const float* parts, size_t pitch, size_t n, uint32_t real_groups, uint32_t clusters, bool per_group, bool cm_order, float* out,

@@ -1108,7 +1108,7 @@ static hipError_t launch_q16p(const ScoreArgs& a, const Variant& v, hipStream_t 
     e = launch_q16_prepass(a, x, s);  // its memset also zeroes the tile counter
     if (e != hipSuccess) return e;
   } else {
-    e = hipMemsetAsync(x.tile_counter, 0, kQ16TileCounterWords * 4, s);
+    e = launch_zero_words(x.tile_counter, kQ16TileCounterWords, s);
     if (e != hipSuccess) return e;
   }
   if (a.ev_mid) (void)hipEventRecord(a.ev_mid, s);

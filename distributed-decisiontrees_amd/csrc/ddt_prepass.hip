@@ -98,6 +98,16 @@ hipError_t launch_gather_transpose(const uint32_t* tuples, uint32_t Win, const u
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ p, uint64_t words) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < words; i += (uint64_t)gridDim.x * 256u) p[i] = 0u;
+}
+hipError_t launch_zero_words(uint32_t* p, uint64_t words, hipStream_t s) {
+  if (words == 0) return hipSuccess;
+  const uint64_t blocks = (words + 255u) / 256u;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((uint32_t)(blocks < 1024u ? blocks : 1024u)), dim3(256), 0, s, p, words);
+  return hipGetLastError();
+}
+
 hipError_t launch_transpose(const uint32_t* tuples, uint32_t W, uint64_t n, uint64_t n_pad, uint32_t* xT, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(transpose_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((W + 1) * 256 * 4));
   if (e != hipSuccess) return e;
@@ -506,7 +516,7 @@ hipError_t launch_q16_prepass(const ScoreArgs& a, const Q16Aux& x, hipStream_t s
   if (e != hipSuccess) return e;
   // tile flags + (8-byte aligned, right behind them) the work counters of the fused / grouped pre-pass
   unsigned long long* counter = reinterpret_cast<unsigned long long*>(x.tile_flags + ((tiles + 1u) & ~(uint64_t)1u));
-  e = hipMemsetAsync(x.tile_flags, 0, (((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters + kQ16TileCounterWords) * 4, s);  // + the _p kernels' tile counter
+  e = launch_zero_words(x.tile_flags, ((tiles + 1u) & ~(uint64_t)1u) + 2u * kQ16GroupedCounters + kQ16TileCounterWords, s);  // + the _p kernels' tile counter
   if (e != hipSuccess) return e;
   const PrepassPlan& pp = x.prepass;
   // a batch of a few tiles: a unit per ticket, blocks for every two tiles (option-free: the result is the same bits, only who ranks what changes)

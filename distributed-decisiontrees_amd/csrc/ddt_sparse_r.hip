@@ -158,7 +158,7 @@ hipError_t launch_r32_prepass(const ScoreArgs& a, const SparseAux& x, hipStream_
   while ((1u << tile_log2) < r.tile) ++tile_log2;
   const uint64_t tiles = q.n_pad >> tile_log2;
   if (tiles == 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(q.tile_flags, 0, tiles * 4u, s);
+  hipError_t e = launch_zero_words(q.tile_flags, tiles, s);
   if (e != hipSuccess) return e;
   e = launch_transpose(a.tuples, W, a.n, q.n_pad, q.xT, s);
   if (e != hipSuccess) return e;
