@@ -73,7 +73,7 @@ bool variant_fits(const Variant& v, const ddt_engine* e) {
     // ... provided every PU group of 8 trees (the unit the parts are planned in: plan_q16_parts) stays within the u16 ranks by itself.  Up to
     // depth 12 it always does (8 x 4095 nodes); deeper trees on few features may not: counted per group and feature (nodes, an upper bound
     // of the distinct thresholds), in cluster-major order
-    if (e->p.num_levels > 12u) {
+    if (e->p.num_levels > 12u || e->q16_max_table < 8u * 4095u) {  // (or a limit lowered through the option "q16_max_table")
       const uint32_t Cc = e->p.clusters_per_tuple ? e->p.clusters_per_tuple : 1u, nint = e->nint;
       for (const Ensemble& m : e->ens) {
         const uint32_t T = m.trees(), groups = (T + 7u) / 8u;

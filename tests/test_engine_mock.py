@@ -683,6 +683,31 @@ def test_more_thresholds_than_u16_ranks_hold_is_scored_in_parts(mock, T, F, clus
     mock.ddt_destroy(e)
 
 
+def test_a_lowered_table_limit_never_fails_a_load(mock):
+    """Option "q16_max_table" (A/B, tests): with a limit that ONE PU group of 8 trees exceeds on a feature (8 x 255 nodes on 2 features against 500 keys) the
+    rank-quantised kernels do not fit -- the engine takes another kernel and scores the oracle's bits; with a limit the groups fit, it scores in parts; out of
+    range: refused, the previous value kept."""
+    mock.mock_reset(2, 3, 8)
+    T, D, F, n = 240, 8, 2, 900
+    m, x = O.gen_model(T, D, F, 0), O.gen_tuples(0, n, F, 0)
+    want = O.score_fast(m, x, sum_mode=O.SUM_REF_NATIVE)
+    e, info, st = _engine(mock), ddt.Info(), ddt.Stats()
+    assert mock.ddt_set_option(e, b"q16_max_table", 38849) != 0 and mock.ddt_set_option(e, b"q16_max_table", 254) != 0
+    for limit, q16 in ((500, False), (3000, True), (38848, True)):
+        assert mock.ddt_set_option(e, b"q16_max_table", limit) == 0
+        _load(mock, e, m, ddt.make_params(T, D, F), None)
+        assert mock.ddt_get_info(e, C.byref(info)) == 0 and info.variant_name.decode().startswith("q16_") == q16, (limit, info.variant_name)
+        out = np.full(n, np.nan, np.float32)
+        assert mock.ddt_set_option(e, b"q16_cluster_split", 0) == 0 and mock.ddt_get_stats(e, C.byref(st)) == 0
+        before = st.kernel_launches
+        assert mock.ddt_score(e, x.ctypes.data, n, out.ctypes.data) == 0, mock.ddt_last_error(e)
+        assert np.array_equal(_bits(out), _bits(want)), limit
+        assert mock.ddt_get_stats(e, C.byref(st)) == 0
+        if limit == 3000:
+            assert st.kernel_launches - before >= 10                             # 30 PU groups of ~1020 keys per feature: two groups per part
+    mock.ddt_destroy(e)
+
+
 @pytest.mark.parametrize("policy,seed", SCHEDULES[:3])
 def test_registered_host_buffers_skip_the_staging(mock, policy, seed):
     """ddt_host_register: tuples and scores move straight between the caller's (pinned) buffers and the device; same results, many
