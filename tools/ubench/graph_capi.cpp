@@ -1,5 +1,8 @@
 // A captured ddt_score_device, replayed on new tuples in the same buffer, WITHOUT torch: plain hipStreamBeginCapture around the C-ABI call.
-// Prints per replay whether the scores equal those of a direct call on the same tuples (bitwise).  Build: see the command in the session script.
+// Prints per replay whether the scores equal those of a direct call on the same tuples (bitwise).  Modes (bits): 1 thread-local capture, 2 replay on the null
+// stream with the tuples copied from pageable host memory, 4 warm-up call on the null stream, 8 hipGraphInstantiateWithFlags(AutoFreeOnLaunch).
+// Build (from tools/ubench): hipcc --offload-arch=gfx950 -O2 -I../../include -o graph_capi graph_capi.cpp -L../../distributed-decisiontrees_amd/lib -lddt \
+//   -Wl,-rpath,'$ORIGIN/../../distributed-decisiontrees_amd/lib';  graph_memset.hip: hipcc --offload-arch=gfx950 -O2 -o graph_memset graph_memset.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
