@@ -17,9 +17,10 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 for cfg in 1 2 5; do
   ( timeout 600 python bench.py --config $cfg --no-cpu-baseline --no-streamed ) > $OUT/bench_cfg$cfg.log 2> $OUT/bench_cfg$cfg.err; tail -1 $OUT/bench_cfg$cfg.log | cut -c1-300
 done
-for cfg in 3 6 4 1; do
+for cfg in 3 6 4 1 2 5; do
   B="python $GRAFT_REPO_ROOT/bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-streamed --no-other-configs"
   [ $cfg = 1 ] && B="python $GRAFT_REPO_ROOT/bench.py --config 1 --steps 10 --warmup 3 --no-cpu-baseline --no-streamed"
+  [ $cfg = 2 ] && B="python $GRAFT_REPO_ROOT/bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline --no-streamed"
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats_cfg$cfg -o bench -- $B ) > $OUT/stats_cfg$cfg.log 2>&1; echo "cfg$cfg stats rc=$?"
   ( cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_cfg$cfg -o pmc -- $B ) > $OUT/fetch_cfg$cfg.log 2>&1; echo "cfg$cfg fetch rc=$?"
   ( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/write_cfg$cfg -o pmc -- $B ) > $OUT/write_cfg$cfg.log 2>&1; echo "cfg$cfg write rc=$?"

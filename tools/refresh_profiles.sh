@@ -21,6 +21,14 @@ if [ -d $E/stats_cfg1 ]; then
   python tools/prof_summary.py ${R}_final_bench_cfg1 --stats $E/stats_cfg1 --pmc $E/fetch_cfg1 $E/write_cfg1 --kernel score_stream --rows 200000000 --trees 8 \
     --levels 4 --features 16 --cmd "python bench.py --config 1 --steps 10 --warmup 3 --no-cpu-baseline --no-streamed" > /dev/null
 fi
+if [ -d $E/stats_cfg2 ]; then
+  python tools/prof_summary.py ${R}_final_bench_cfg2 --stats $E/stats_cfg2 --pmc $E/fetch_cfg2 $E/write_cfg2 --kernel score_q16 --rows 10000000 --trees 100 \
+    --levels 6 --features 28 --cmd "python bench.py --config 2 --steps 10 --warmup 3 --no-cpu-baseline --no-streamed" > /dev/null
+fi
+if [ -d $E/stats_cfg5 ]; then
+  python tools/prof_summary.py ${R}_final_bench_cfg5 --stats $E/stats_cfg5 --pmc $E/fetch_cfg5 $E/write_cfg5 --kernel score_q16p --rows 10000000 --trees 1000 \
+    --levels 8 --features 32 --cmd "python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline --no-streamed" > /dev/null
+fi
 grep "score_q16\|rank_kernel\|transpose_k\|score_sparse" profiles/${R}_final_bench_cfg3.md profiles/${R}_final_bench_cfg4.md | cut -c1-200 | head
 if [ -d $E/pmc_q16 ]; then
   python tools/prof_summary.py ${R}_pmc_q16_x --stats $E/pmc_q16/stats --pmc $E/pmc_q16/pmc1 $E/pmc_q16/pmc2 $E/pmc_q16/pmc3 --kernel score_q16 --rows 8000000 \
