@@ -3,7 +3,7 @@
 for each replay, which of the three batches the scores match (the diagnosis behind launch_zero_words, csrc/ddt_internal.h; the torch-free
 counterpart is tools/ubench/graph_capi.cpp)."""
 import os, sys, json
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "distributed-decisiontrees_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch, ddt
 from oracle import oracle as O
